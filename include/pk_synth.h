@@ -1,0 +1,132 @@
+/* pk_synth.h -- C ABI of libpk_synth.so, the MI355X (gfx950) synthesis engine
+ * behind Parakeet's inference API.
+ *
+ * The reference (PaddlePaddle/Parakeet) is pure Python over Paddle ops; it has
+ * no FFI of its own.  The seam this ABI replaces is the Python class API of
+ * the synthesis path; each entry point names the reference method whose device
+ * work it performs (paths relative to the reference repository root):
+ *
+ *   pk_pwg_*    parakeet/models/parallel_wavegan/parallel_wavegan.py
+ *               PWGGenerator.__init__ :369-443, set_state_dict,
+ *               remove_weight_norm :485-496, inference :498-520 (forward :445-472),
+ *               PWGInference.forward :772-775
+ *   pk_fs2_*    parakeet/models/fastspeech2/fastspeech2.py
+ *               FastSpeech2.__init__ :52-296, inference :468-558
+ *               (_forward(is_inference=True) :377-466),
+ *               FastSpeech2Inference.forward :668-671
+ *   pk_wf_*     parakeet/models/waveflow.py ConditionalWaveFlow.infer :785-805
+ *   pk_stft_mel parakeet/modules/audio.py STFT.magnitude :202-215 + MelScale :226-229,
+ *               parakeet/data/get_feats.py LogMelFBank.get_log_mel_fbank :80-88
+ *
+ * Conventions
+ *   - Every function returns PK_OK (0) or a negative pk_status; the message of
+ *     the last failure on the calling thread is pk_last_error().  Nothing
+ *     aborts.  The Python shim maps the codes back to the exception classes the
+ *     reference raises (ValueError / AssertionError / NotImplementedError).
+ *   - Plain pointers and sizes only.  Parameter arrays handed to *_set_param are
+ *     HOST pointers and are copied (the caller may free them at once, like
+ *     set_state_dict).  Data pointers of the compute calls are DEVICE pointers
+ *     unless the call's `flags` has PK_HOST_IO, in which case they are host
+ *     pointers and the engine stages them (synchronous on return).
+ *   - A pk_ctx owns one HIP device + one stream.  Handles created on a context
+ *     are not thread-safe; different contexts may be used concurrently.  Calls
+ *     are asynchronous on the context's stream unless stated; use pk_sync().
+ *   - Batches are "packed ragged": utterance b owns rows [cu[b], cu[b+1]) of a
+ *     row-major array; lengths are given per utterance on the host.
+ */
+#ifndef PK_SYNTH_H
+#define PK_SYNTH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PK_OK = 0,
+    PK_EINVAL = -1,        /* bad argument value              -> ValueError          */
+    PK_ESHAPE = -2,        /* shape / size mismatch           -> AssertionError      */
+    PK_EUNSUPPORTED = -3,  /* configuration not implemented   -> NotImplementedError */
+    PK_EHIP = -4,          /* HIP runtime failure             -> RuntimeError        */
+    PK_ENOMEM = -5,        /* allocation failure              -> MemoryError         */
+    PK_ESTATE = -6         /* call order (e.g. not finalized) -> RuntimeError        */
+} pk_status;
+
+enum { PK_HOST_IO = 1 };   /* flags bit: data pointers are host memory */
+
+typedef struct pk_ctx pk_ctx;
+typedef struct pk_pwg pk_pwg;
+typedef struct pk_fs2 pk_fs2;
+
+/* ---------------------------------------------------------------- context */
+const char* pk_last_error(void);
+const char* pk_version(void);
+/* Create a context on HIP device `device_id` with its own stream. */
+int pk_ctx_create(int device_id, pk_ctx** out);
+/* Run on an externally owned hipStream_t (e.g. torch's current stream), so
+ * that events recorded by the caller on that stream bracket the kernels. */
+int pk_ctx_set_stream(pk_ctx* ctx, void* hip_stream);
+int pk_sync(pk_ctx* ctx);
+void pk_ctx_destroy(pk_ctx* ctx);
+
+/* Per-kernel timing: when enabled every launch is bracketed by HIP events on
+ * the context's stream.  pk_prof_read() synchronises and returns, for the
+ * kernel class `name`, the number of launches and their summed duration (ms)
+ * since the last pk_prof_reset().  Used by bench.py for roofline.achieved. */
+int pk_prof_enable(pk_ctx* ctx, int on);
+int pk_prof_reset(pk_ctx* ctx);
+int pk_prof_read(pk_ctx* ctx, const char* name, int64_t* launches, double* total_ms);
+/* Writes a '\n'-separated "name launches total_ms" listing into buf. */
+int pk_prof_dump(pk_ctx* ctx, char* buf, int64_t buflen);
+
+/* ------------------------------------------------------ Parallel WaveGAN */
+/* Constructor arguments of PWGGenerator (parallel_wavegan.py:369-388) that
+ * change device work.  Unsupported combinations -> PK_EUNSUPPORTED. */
+typedef struct {
+    int32_t in_channels;        /* 1 */
+    int32_t out_channels;       /* 1 */
+    int32_t kernel_size;        /* 3 */
+    int32_t layers;             /* 30, must be a multiple of stacks (:398) */
+    int32_t stacks;             /* 3  */
+    int32_t residual_channels;  /* 64 */
+    int32_t gate_channels;      /* 128 */
+    int32_t skip_channels;      /* 64 */
+    int32_t aux_channels;       /* 80 */
+    int32_t aux_context_window; /* 2 */
+    int32_t n_upsample;         /* 4 */
+    int32_t upsample_scales[8]; /* 4,4,4,4 */
+    int32_t use_causal_conv;    /* 0 only */
+} pk_pwg_cfg;
+
+int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out);
+/* set_state_dict, one entry at a time.  `name` is the reference's state-dict
+ * key ("conv_layers.3.conv.weight", "...weight_g", "...weight_v", ...);
+ * float32 host data of the given shape. */
+int pk_pwg_set_param(pk_pwg* h, const char* name, const float* data,
+                     const int64_t* shape, int32_t ndim);
+/* PWGInference's normalizer (ZScore, parakeet/modules/normalizer.py:18-33):
+ * mel_in -> (mel_in - mu) / sigma.  NULL,NULL = identity. */
+int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_t n);
+/* remove_weight_norm + packing into the kernels' layouts + upload. */
+int pk_pwg_finalize(pk_pwg* h);
+/* PWGGenerator.inference for a packed batch.
+ *   mel    (sum(frames), aux_channels) float32, row-major, packed by utterance
+ *   frames (B) host int32, frames per utterance (>= 1)
+ *   noise  (sum(frames)*hop) float32 packed; the x = randn(...) of :515-516,
+ *          passed in so that results are reproducible
+ *   wav    (sum(frames)*hop) float32 packed output
+ * flags: PK_HOST_IO if mel/noise/wav are host pointers. */
+int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, int32_t B,
+                 const float* noise, float* wav, int32_t flags);
+/* Debug / test taps: copy internal activations of the LAST pk_pwg_infer call
+ * for utterance b to host.  what: 0 = upsampled conditioning c (aux, S_b),
+ * 1 = residual-stack output x (residual, S_b), 2 = scaled skip sum (skip, S_b),
+ * all channel-major. */
+int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
+void pk_pwg_destroy(pk_pwg* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PK_SYNTH_H */

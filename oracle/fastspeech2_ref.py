@@ -1,0 +1,210 @@
+"""Oracle: FastSpeech2 single-utterance inference (test infrastructure).
+
+Restates, op for op, the inference branch of
+parakeet/models/fastspeech2/fastspeech2.py:
+  FastSpeech2.inference          :468-558  (is_inference=True branch)
+  FastSpeech2._forward           :377-466
+  FastSpeech2Inference.forward   :668-671
+and the modules it calls:
+  Encoder.forward                fastspeech2_transformer/encoder.py:171-192
+  EncoderLayer.forward           fastspeech2_transformer/encoder_layer.py:64-115
+  MultiHeadedAttention           fastspeech2_transformer/attention.py:51-156
+  ScaledPositionalEncoding       fastspeech2_transformer/embedding.py:46-62,111-126
+  MultiLayeredConv1d.forward     fastspeech2_transformer/multi_layer_conv.py:62-77
+  DurationPredictor._forward     fastspeech2_predictor/duration_predictor.py:85-103
+  VariancePredictor.forward      fastspeech2_predictor/variance_predictor.py:77-104
+  LayerNorm(dim=1)               modules/layer_norm.py:34-63
+  LengthRegulator.forward/expand fastspeech2_predictor/length_regulator.py:46-89
+  Postnet.forward                modules/tacotron2/decoder.py:127-198
+  masked_fill                    modules/masked_fill.py:28-37
+  make_pad_mask/non_pad_mask     modules/nets_utils.py:54-125
+
+Configuration = examples/fastspeech2/ljspeech/conf/default.yaml:33-75
+(transformer encoder/decoder, conv1d position-wise layers, pre-norm, scaled
+positional encoding, no speaker / tone embedding, reduction_factor 1).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .nn_ref import (Weights, batch_norm_eval, conv1d, layer_norm, linear,
+                     make_non_pad_mask, make_pad_mask, masked_fill,
+                     round_half_away, sinusoid_table)
+
+DEFAULT_CFG = dict(
+    adim=384, aheads=2, elayers=4, eunits=1536, dlayers=4, dunits=1536,
+    positionwise_conv_kernel_size=3,
+    duration_predictor_layers=2, duration_predictor_chans=256, duration_predictor_kernel_size=3,
+    pitch_predictor_layers=5, pitch_predictor_chans=256, pitch_predictor_kernel_size=5,
+    energy_predictor_layers=2, energy_predictor_chans=256, energy_predictor_kernel_size=3,
+    pitch_embed_kernel_size=1, energy_embed_kernel_size=1,
+    postnet_layers=5, postnet_chans=256, postnet_filts=5)
+
+
+def scaled_posenc(W, x):
+    """ScaledPositionalEncoding.forward embedding.py:111-126: x + alpha * pe
+    (no sqrt(d) scaling, unlike PositionalEncoding.forward :78)."""
+    pe = sinusoid_table(x.shape[1], x.shape[2], x.dtype)
+    return x + W["alpha"] * pe.unsqueeze(0)
+
+
+def attention(W, x, mask, n_head):
+    """MultiHeadedAttention.forward attention.py:133-156 with query=key=value=x.
+    mask: (B,1,T) bool non-pad mask or None."""
+    B, T, D = x.shape
+    dk = D // n_head
+    q = linear(x, W["linear_q.weight"], W["linear_q.bias"]).reshape(B, T, n_head, dk).transpose(1, 2)
+    k = linear(x, W["linear_k.weight"], W["linear_k.bias"]).reshape(B, T, n_head, dk).transpose(1, 2)
+    v = linear(x, W["linear_v.weight"], W["linear_v.bias"]).reshape(B, T, n_head, dk).transpose(1, 2)
+    scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dk)
+    if mask is not None:
+        m = ~mask.unsqueeze(1)  # :110-111
+        min_value = float(np.finfo(np.float32).min)  # :112-114 (scores are float32 in the reference)
+        scores = masked_fill(scores, m, min_value)
+        attn = torch.softmax(scores, dim=-1)
+        attn = masked_fill(attn, m, 0.0)
+    else:
+        attn = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(attn, v).transpose(1, 2).reshape(B, T, D)
+    return linear(ctx, W["linear_out.weight"], W["linear_out.bias"])
+
+
+def conv_ffn(W, x):
+    """MultiLayeredConv1d.forward multi_layer_conv.py:62-77."""
+    k = W["w_1.weight"].shape[-1]
+    h = torch.relu(conv1d(x.transpose(1, 2), W["w_1.weight"], W["w_1.bias"], padding=(k - 1) // 2))
+    k2 = W["w_2.weight"].shape[-1]
+    return conv1d(h, W["w_2.weight"], W["w_2.bias"], padding=(k2 - 1) // 2).transpose(1, 2)
+
+
+def encoder_layer(W, x, mask, n_head):
+    """EncoderLayer.forward encoder_layer.py:64-115 (normalize_before=True,
+    concat_after=False, no cache, dropout off)."""
+    residual = x
+    h = layer_norm(x, W["norm1.weight"], W["norm1.bias"])
+    x = residual + attention(W.sub("self_attn."), h, mask, n_head)
+    residual = x
+    h = layer_norm(x, W["norm2.weight"], W["norm2.bias"])
+    return residual + conv_ffn(W.sub("feed_forward."), h)
+
+
+def encoder(W, xs, mask, n_layers, n_head, embed_ids):
+    """Encoder.forward encoder.py:171-192.  embed_ids=True: input_layer is
+    nn.Embedding(padding_idx=0) followed by ScaledPositionalEncoding (embed.0 /
+    embed.1); False: positional encoding only (embed.0) -- fastspeech2.py:250-266."""
+    if embed_ids:
+        table = W["embed.0.weight"].clone()
+        table[0] = 0.0  # padding_idx=0 -> zero row [paddle-semantics]
+        x = table[xs]
+        x = scaled_posenc(W.sub("embed.1."), x)
+    else:
+        x = scaled_posenc(W.sub("embed.0."), xs)
+    for i in range(n_layers):
+        x = encoder_layer(W.sub(f"encoders.{i}."), x, mask, n_head)
+    return layer_norm(x, W["after_norm.weight"], W["after_norm.bias"])
+
+
+def conv_relu_ln_stack(W, xs, n_layers):
+    """The conv stacks shared by DurationPredictor (:64-80) and
+    VariancePredictor (:61-75): [Conv1D -> ReLU -> LayerNorm(dim=1) -> Dropout]*n
+    on (B, C, T)."""
+    for j in range(n_layers):
+        w = W[f"conv.{j}.0.weight"]
+        xs = torch.relu(conv1d(xs, w, W[f"conv.{j}.0.bias"], padding=(w.shape[-1] - 1) // 2))
+        # LayerNorm(dim=1): transpose -> LN over channels -> transpose (layer_norm.py:50-63)
+        xs = layer_norm(xs.transpose(1, 2), W[f"conv.{j}.2.weight"], W[f"conv.{j}.2.bias"]).transpose(1, 2)
+    return xs
+
+
+def variance_predictor(W, hs, pad_mask, n_layers):
+    """VariancePredictor.forward variance_predictor.py:77-104 -> (B,T,1)."""
+    xs = conv_relu_ln_stack(W, hs.transpose(1, 2), n_layers)
+    xs = linear(xs.transpose(1, 2), W["linear.weight"], W["linear.bias"])
+    return masked_fill(xs, pad_mask.unsqueeze(-1), 0.0)
+
+
+def duration_inference(W, hs, pad_mask, n_layers, offset=1.0):
+    """DurationPredictor.inference duration_predictor.py:122-137 -> (B,T)
+    integer-valued float: clip(round(exp(x) - offset), min=0) :98."""
+    xs = conv_relu_ln_stack(W, hs.transpose(1, 2), n_layers)
+    xs = linear(xs.transpose(1, 2), W["linear.weight"], W["linear.bias"]).squeeze(-1)
+    xs = torch.clamp(round_half_away(torch.exp(xs) - offset), min=0)
+    return masked_fill(xs, pad_mask, 0.0)
+
+
+def length_regulate(hs, ds, alpha=1.0):
+    """LengthRegulator.forward/expand length_regulator.py:46-89.  hs (B,T,C),
+    ds (B,T) integer-valued.  The reference builds a dense 0/1 matrix in
+    float64 numpy and multiplies; the result is a pure row repeat, built here
+    the same way (matmul) so rows beyond an utterance's length are zero."""
+    if alpha != 1.0:
+        assert alpha > 0
+        ds = round_half_away(ds.to(torch.float32) * alpha)
+    ds = ds.to(torch.int64).numpy()
+    B, T = ds.shape
+    slens = ds.sum(-1)
+    t_dec = int(slens.max())
+    M = np.zeros([B, t_dec, T])
+    for i in range(B):
+        k = 0
+        for j in range(T):
+            d = int(ds[i, j])
+            if d >= 1:
+                M[i, k:k + d, j] = 1
+            k += d
+    return torch.matmul(torch.as_tensor(M).to(hs.dtype), hs)
+
+
+def postnet(W, xs, n_layers):
+    """Postnet.forward tacotron2/decoder.py:182-198 on (B, odim, T): Conv1D(no
+    bias) -> BatchNorm1D(eval) -> Tanh for all but the last layer, the last
+    one without Tanh (:127-169)."""
+    for j in range(n_layers):
+        w = W[f"postnet.{j}.0.weight"]
+        xs = conv1d(xs, w, None, padding=(w.shape[-1] - 1) // 2)
+        xs = batch_norm_eval(xs, W[f"postnet.{j}.1.weight"], W[f"postnet.{j}.1.bias"],
+                             W[f"postnet.{j}.1._mean"], W[f"postnet.{j}.1._variance"])
+        if j != n_layers - 1:
+            xs = torch.tanh(xs)
+    return xs
+
+
+def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts=False):
+    """FastSpeech2.inference fastspeech2.py:468-558 for one utterance.
+    ids: (T,) int64 -> normalised mel (L, odim)."""
+    cfg = dict(DEFAULT_CFG, **(cfg or {}))
+    W = Weights(state, dtype)
+    x = torch.as_tensor(np.asarray(ids)).to(torch.int64)
+    ilens = [int(x.shape[0])]                       # :519-521
+    xs = x.unsqueeze(0)                             # :522
+    x_masks = make_non_pad_mask(ilens).unsqueeze(-2)  # _source_mask :618-641
+    hs = encoder(W.sub("encoder."), xs, x_masks, cfg["elayers"], cfg["aheads"], True)  # :393
+    d_masks = make_pad_mask(ilens)                  # :410
+    p_outs = variance_predictor(W.sub("pitch_predictor."), hs, d_masks, cfg["pitch_predictor_layers"])
+    e_outs = variance_predictor(W.sub("energy_predictor."), hs, d_masks, cfg["energy_predictor_layers"])
+    d_outs = duration_inference(W.sub("duration_predictor."), hs, d_masks,
+                                cfg["duration_predictor_layers"])        # :423
+    kp = W["pitch_embed.0.weight"].shape[-1]
+    ke = W["energy_embed.0.weight"].shape[-1]
+    p_embs = conv1d(p_outs.transpose(1, 2), W["pitch_embed.0.weight"], W["pitch_embed.0.bias"],
+                    padding=(kp - 1) // 2).transpose(1, 2)               # :426-427
+    e_embs = conv1d(e_outs.transpose(1, 2), W["energy_embed.0.weight"], W["energy_embed.0.bias"],
+                    padding=(ke - 1) // 2).transpose(1, 2)               # :428-429
+    hs2 = hs + e_embs + p_embs                      # :430
+    hs_up = length_regulate(hs2, d_outs, alpha)     # :432
+    zs = encoder(W.sub("decoder."), hs_up, None, cfg["dlayers"], cfg["aheads"], False)  # :455 (h_masks=None)
+    before = linear(zs, W["feat_out.weight"], W["feat_out.bias"])        # :457
+    after = before + postnet(W.sub("postnet."), before.transpose(1, 2),
+                             cfg["postnet_layers"]).transpose(1, 2)      # :463-464
+    if return_parts:
+        return after[0], dict(hs=hs[0], p=p_outs[0, :, 0], e=e_outs[0, :, 0], d=d_outs[0],
+                              hs_up=hs_up[0], zs=zs[0], before=before[0])
+    return after[0]
+
+
+def fastspeech2_inference(state, mu, sigma, ids, cfg=None, alpha=1.0, dtype=torch.float32):
+    """FastSpeech2Inference.forward fastspeech2.py:668-671: inference then
+    ZScore.inverse (normalizer.py:30-33): x * sigma + mu."""
+    mel = inference(state, ids, cfg, alpha, dtype)
+    return mel * torch.as_tensor(sigma).to(dtype) + torch.as_tensor(mu).to(dtype)

@@ -1,0 +1,88 @@
+"""ctypes binding of include/pk_synth.h (libpk_synth.so).
+
+There is no fallback: if the shared library is missing or a call fails, an
+exception is raised.  Status codes map back to the exception classes the
+reference raises at the same places.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpk_synth.so")
+
+PK_OK = 0
+PK_HOST_IO = 1
+_EXC = {
+    -1: ValueError,
+    -2: AssertionError,
+    -3: NotImplementedError,
+    -4: RuntimeError,
+    -5: MemoryError,
+    -6: RuntimeError,
+}
+
+
+class PwgCfg(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("kernel_size", C.c_int32),
+        ("layers", C.c_int32), ("stacks", C.c_int32), ("residual_channels", C.c_int32),
+        ("gate_channels", C.c_int32), ("skip_channels", C.c_int32), ("aux_channels", C.c_int32),
+        ("aux_context_window", C.c_int32), ("n_upsample", C.c_int32),
+        ("upsample_scales", C.c_int32 * 8), ("use_causal_conv", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i32, i64, f32p, i32p, i64p, cstr = (C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_char_p)
+    sig = {
+        "pk_last_error": (cstr, []),
+        "pk_version": (cstr, []),
+        "pk_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "pk_ctx_set_stream": (C.c_int, [vp, vp]),
+        "pk_sync": (C.c_int, [vp]),
+        "pk_ctx_destroy": (None, [vp]),
+        "pk_prof_enable": (C.c_int, [vp, C.c_int]),
+        "pk_prof_reset": (C.c_int, [vp]),
+        "pk_prof_read": (C.c_int, [vp, cstr, C.POINTER(i64), C.POINTER(C.c_double)]),
+        "pk_prof_dump": (C.c_int, [vp, C.c_char_p, i64]),
+        "pk_pwg_create": (C.c_int, [vp, C.POINTER(PwgCfg), C.POINTER(vp)]),
+        "pk_pwg_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
+        "pk_pwg_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
+        "pk_pwg_finalize": (C.c_int, [vp]),
+        "pk_pwg_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
+        "pk_pwg_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
+        "pk_pwg_destroy": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+def lib():
+    """Load libpk_synth.so (built by parakeet_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP engine is not built "
+                "(run `python -m parakeet_amd.build`); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(status):
+    if status != PK_OK:
+        msg = lib().pk_last_error().decode("utf-8", "replace")
+        raise _EXC.get(status, RuntimeError)(f"pk_synth[{status}]: {msg}")
+
+
+def fptr(arr):
+    """Pointer of a C-contiguous float32 numpy array."""
+    return arr.ctypes.data_as(C.c_void_p)

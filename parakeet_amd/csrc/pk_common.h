@@ -1,0 +1,122 @@
+// pk_common.h -- internals shared by the translation units of libpk_synth.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pk_synth.h"
+
+void pk_set_error(const char* fmt, ...);
+
+#define PK_FAIL(code, ...)            \
+    do {                              \
+        pk_set_error(__VA_ARGS__);    \
+        return (code);                \
+    } while (0)
+
+#define PK_HIP(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            pk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                         __FILE__, __LINE__);                                     \
+            return PK_EHIP;                                                       \
+        }                                                                         \
+    } while (0)
+
+#define PK_TRY(expr)                  \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != PK_OK) return _s;   \
+    } while (0)
+
+struct pk_prof_rec {
+    int name_id;
+    hipEvent_t start, stop;
+};
+
+struct pk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    // profiler
+    bool prof_on = false;
+    std::vector<std::string> prof_names;
+    std::map<std::string, int> prof_ids;
+    std::vector<pk_prof_rec> prof_recs;
+    std::vector<hipEvent_t> event_pool;
+
+    int prof_begin(const char* name);   // returns record index or -1
+    void prof_end(int rec);
+};
+
+// Bracket a kernel launch with profiler events when enabled.
+#define PK_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                       \
+    do {                                                                            \
+        int _rec = (ctx)->prof_on ? (ctx)->prof_begin(name) : -1;                   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+        if (_rec >= 0) (ctx)->prof_end(_rec);                                       \
+        PK_HIP(hipGetLastError());                                                  \
+    } while (0)
+
+// Grow-only device buffer.
+struct pk_dbuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return PK_OK;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) PK_FAIL(PK_EHIP, "hipFree failed: %s", hipGetErrorString(e));
+        }
+        size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            PK_FAIL(PK_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return PK_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct pk_param {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+typedef std::map<std::string, pk_param> pk_param_map;
+
+int pk_store_param(pk_param_map& m, const char* name, const float* data, const int64_t* shape,
+                   int32_t ndim);
+// Returns the plain weight for `base` ("conv_layers.0.conv"): either
+// base.weight, or base.weight_g * base.weight_v / ||v|| (weight-norm fold,
+// nn.utils.remove_weight_norm; norm over all axes but 0).
+int pk_get_weight(const pk_param_map& m, const std::string& base, const std::vector<int64_t>& shape,
+                  std::vector<float>& out);
+int pk_get_vector(const pk_param_map& m, const std::string& name, int64_t n, std::vector<float>& out);
+
+int pk_upload(pk_ctx* ctx, pk_dbuf& buf, const void* host, size_t bytes);
+
+static inline int pk_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

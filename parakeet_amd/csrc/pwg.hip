@@ -1,0 +1,749 @@
+// pwg.hip -- Parallel WaveGAN generator on gfx950: kernels + pk_pwg_* entry points.
+//
+// Reference: parakeet/models/parallel_wavegan/parallel_wavegan.py
+//   ConvInUpsampleNet.forward :201-216, UpsampleNet.forward :119-138,
+//   ResidualBlock.forward :284-315, PWGGenerator.forward :445-472,
+//   PWGGenerator.inference :498-520, PWGInference.forward :772-775.
+//
+// Data layout in HBM ("timeline" layout).  All per-sample activations are
+// channel-major over ONE concatenated time axis of length Ttot that holds every
+// utterance of the batch, separated (and framed) by zero gaps of GAP samples:
+//
+//      |GAP| utt 0 (S_0) |GAP| utt 1 (S_1) |GAP| ... |GAP|
+//
+// x[ch][t], c[ch][t], skip[ch][t] with row stride Ttot.  GAP >= the largest
+// dilation, so a dilated tap that leaves an utterance reads zeros -- exactly the
+// zero padding nn.Conv1D applies at the utterance ends in the reference's
+// one-utterance-per-call inference.  S_b is a multiple of the hop (256), work
+// tiles are whole frames, so a tile is never partly valid and the gaps are never
+// written after the per-call zeroing.  Ragged batches cost nothing extra.
+//
+// The residual stack is 93 % of the end-to-end FLOPs and is a
+// chain of small dense contractions (K = 3*64 + 80 = 272 -> 128, then 64 -> 128)
+// per sample; it runs on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+#include <cmath>
+
+#include "pk_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int R = 64;     // residual channels
+constexpr int G = 128;    // gate channels
+constexpr int SK = 64;    // skip channels
+constexpr int AUX = 80;   // aux channels
+constexpr int KTAP = 3;   // kernel size of the dilated conv
+constexpr int KS_CONV = KTAP * R / 2;         // 96 k-steps (2 input channels per MFMA)
+constexpr int KS_AUX = AUX / 2;               // 40
+constexpr int KS1 = KS_CONV + KS_AUX;         // 136
+constexpr int KS2 = (G / 2) / 2;              // 32 k-steps over the 64 gated channels
+constexpr int TILE = 256;                     // samples per workgroup tile (one frame at hop 256)
+constexpr int WAVE_T = 32;                    // samples per wave (MFMA N)
+constexpr int MAX_UP_TAPS = 17;
+
+// Row of the 32x32 MFMA result held in accumulator register r of a lane whose
+// (lane >> 5) is hi.  (cdna guide: row = (r&3) + 8*(r>>2) + 4*hi, col = lane&31)
+__host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---------------------------------------------------------------- small kernels
+
+// Zero the GAP regions of a [rows][Ttot] buffer.  gap_start[g], g in [0, n_gaps).
+__global__ void k_zero_gaps(float* buf, const int* gap_start, int gap, int rows, long Ttot) {
+    int g = blockIdx.y;
+    int row = blockIdx.z;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < gap && row < rows) buf[(long)row * Ttot + gap_start[g] + i] = 0.f;
+}
+
+// conv_in: ZScore-normalise (PWGInference :773), replicate-pad by ctx (:518),
+// Conv1D(aux->aux, k=2ctx+1, no bias) (:188-192,214).
+// mel (sumL, AUX) packed row-major; wT [(ci*k + tap)][co]; out c0[co][cuL[b] + f], row stride sumL.
+__global__ void k_pwg_convin(const float* __restrict__ mel, const float* __restrict__ wT,
+                             const float* __restrict__ mu, const float* __restrict__ inv_sigma_or_sigma,
+                             int use_norm, const int* __restrict__ frame_utt,
+                             const int* __restrict__ cuL, int ctx, int sumL, float* __restrict__ out) {
+    extern __shared__ float s_in[];  // (2ctx+1) * AUX normalised inputs
+    const int f = blockIdx.x;        // global frame index
+    const int b = frame_utt[f];
+    const int lo = cuL[b], hi = cuL[b + 1];
+    const int k = 2 * ctx + 1;
+    for (int i = threadIdx.x; i < k * AUX; i += blockDim.x) {
+        int tap = i / AUX, ci = i % AUX;
+        int src = f + tap - ctx;
+        src = src < lo ? lo : (src >= hi ? hi - 1 : src);  // replicate padding inside the utterance
+        float v = mel[(long)src * AUX + ci];
+        if (use_norm) v = (v - mu[ci]) / inv_sigma_or_sigma[ci];
+        s_in[tap * AUX + ci] = v;
+    }
+    __syncthreads();
+    const int co = threadIdx.x;
+    if (co < AUX) {
+        float acc = 0.f;
+        for (int ci = 0; ci < AUX; ++ci)
+            for (int tap = 0; tap < k; ++tap)
+                acc = fmaf(wT[(ci * k + tap) * AUX + co], s_in[tap * AUX + ci], acc);
+        out[(long)co * sumL + f] = acc;
+    }
+}
+
+// One UpsampleNet stage: nearest stretch by s then Conv2D(1->1,(1,2s+1),pad (0,s), no bias)
+// (:102-113,132-138).  in[ch][in_off[b] + u], u in [0, Lin_b); out[ch][out_off[b] + t], t in [0, s*Lin_b).
+__global__ void k_pwg_upsample(const float* __restrict__ in, long in_stride, const int* __restrict__ in_off,
+                               const int* __restrict__ in_len, float* __restrict__ out, long out_stride,
+                               const int* __restrict__ out_off, int s, const float* __restrict__ w) {
+    const int b = blockIdx.z;
+    const int ch = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Lin = in_len[b];
+    const int Lout = Lin * s;
+    if (t >= Lout) return;
+    const float* src = in + (long)ch * in_stride + in_off[b];
+    float acc = 0.f;
+    const int taps = 2 * s + 1;
+    for (int j = 0; j < taps; ++j) {
+        int u = t + j - s;
+        if (u >= 0 && u < Lout) acc = fmaf(w[j], src[u / s], acc);
+    }
+    out[(long)ch * out_stride + out_off[b] + t] = acc;
+}
+
+// first_conv: Conv1D(1 -> R, k=1, bias) (:401-402,464) from packed noise into the timeline.
+__global__ void k_pwg_first(const float* __restrict__ noise, const float* __restrict__ w,
+                            const float* __restrict__ bias, const int* __restrict__ tile_t0, long Ttot,
+                            float* __restrict__ x) {
+    const int tile = blockIdx.x;
+    const long t = (long)tile_t0[tile] + threadIdx.x;
+    const float n = noise[(long)tile * TILE + threadIdx.x];
+#pragma unroll 8
+    for (int c = 0; c < R; ++c) x[(long)c * Ttot + t] = fmaf(w[c], n, bias[c]);
+}
+
+// ---------------------------------------------------------------- residual block
+struct PwgLayerArgs {
+    const float* xin;    // [R][Ttot]
+    float* xout;         // [R][Ttot]
+    const float* c;      // [AUX][Ttot]
+    float* skip;         // [SK][Ttot]
+    const float* w1;     // [KS1][64 lanes][4 co-tiles]  A fragments, stage 1
+    const float* w2;     // [KS2][64 lanes][4 out-tiles] A fragments, stage 2
+    const float* bias;   // [G + R + SK]: conv bias (gate), conv1x1_out bias, conv1x1_skip bias
+    const int* tile_t0;  // [ntiles] timeline offset of each 256-sample tile
+    long Ttot;
+    int ntiles;
+    int dilation;
+};
+
+// tanh(a) * sigmoid(b) (:309-310).  exp via v_exp_f32; |a| clamped where tanh is +-1 in fp32.
+__device__ __forceinline__ float gated(float a, float b) {
+    a = fminf(fmaxf(a, -10.f), 10.f);
+    const float ea = __expf(-2.f * a);
+    const float eb = __expf(-b);
+    return (1.f - ea) / ((1.f + ea) * (1.f + eb));
+}
+
+// One residual block for every tile of the batch.  Persistent workgroups of 8
+// waves; each wave owns 32 consecutive samples and ALL channels for them:
+//   stage 1  acc[4] (4 x 32 gate channels) += W1 (A, from LDS) x [x taps | c] (B, from global)
+//   gate     z = tanh(acc[0..1]) * sigmoid(acc[2..3])   -- stays in the accumulator registers
+//   stage 2  acc2[4] (out 0-31, out 32-63, skip 0-31, skip 32-63) += W2 (A) x z (B)
+// The K order of stage 2 is permuted on the host so that accumulator register r of
+// stage 1 IS the B operand of k-step r of stage 2 (no data movement between the GEMMs).
+template <bool FIRST>
+__global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[KS1 * 64 * 4 + G + R + SK];
+    float* lds_bias = lds + KS1 * 64 * 4;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.w1);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < KS1 * 64; i += 512) dst[i] = src[i];
+        if (threadIdx.x < G + R + SK) lds_bias[threadIdx.x] = a.bias[threadIdx.x];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const long Ttot = a.Ttot;
+    const int d = a.dilation;
+    const f32x4* lds_a = reinterpret_cast<const f32x4*>(lds) + lane;
+    const f32x4* w2 = reinterpret_cast<const f32x4*>(a.w2) + lane;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long t = (long)a.tile_t0[tile] + wave * WAVE_T + j;
+        const float* xb = a.xin + (long)hi * Ttot + t;   // + 2*cp*Ttot + (tap-1)*d
+        const float* cb = a.c + (long)hi * Ttot + t;     // + 2*ap*Ttot
+
+        // accumulators start from the conv bias
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_bias + 32 * q + 8 * r4 + 4 * hi);
+                acc[q][4 * r4 + 0] = bv[0];
+                acc[q][4 * r4 + 1] = bv[1];
+                acc[q][4 * r4 + 2] = bv[2];
+                acc[q][4 * r4 + 3] = bv[3];
+            }
+
+        // K loop of stage 1 in groups of 8 k-steps; the B values of group g+1 are
+        // in flight while group g runs on the matrix pipe (32 MFMAs = 2048 cycles).
+        constexpr int GRP = 8;
+        constexpr int NGRP = KS1 / GRP;           // 17 = 12 conv groups + 5 aux groups
+        constexpr int CONV_GRPS = KS_CONV / GRP;  // 12
+        auto group_ptr = [&](int g) -> const float* {
+            if (g < CONV_GRPS) {
+                const int tap = g >> 2, cg = g & 3;  // 4 groups of 8 channel pairs per tap
+                return xb + (long)(2 * GRP * cg) * Ttot + (long)(tap - 1) * d;
+            }
+            return cb + (long)(2 * GRP * (g - CONV_GRPS)) * Ttot;
+        };
+        float bcur[GRP], bnext[GRP];
+        {
+            const float* p = group_ptr(0);
+#pragma unroll
+            for (int s = 0; s < GRP; ++s) bcur[s] = p[(long)(2 * s) * Ttot];
+        }
+#pragma unroll 1
+        for (int g = 0; g < NGRP; ++g) {
+            {
+                const float* p = group_ptr(g + 1 < NGRP ? g + 1 : g);
+#pragma unroll
+                for (int s = 0; s < GRP; ++s) bnext[s] = p[(long)(2 * s) * Ttot];
+            }
+            const f32x4* la = lds_a + (long)g * GRP * 64;
+#pragma unroll
+            for (int s = 0; s < GRP; ++s) {
+                const f32x4 af = la[s * 64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bcur[s], acc[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < GRP; ++s) bcur[s] = bnext[s];
+        }
+
+        // gated activation; z overwrites acc[0], acc[1]
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = gated(acc[q][r], acc[q + 2][r]);
+
+        // stage 2: out / skip 1x1 convs, accumulators start from their biases
+        f32x16 acc2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_bias + G + 32 * q + 8 * r4 + 4 * hi);
+                acc2[q][4 * r4 + 0] = bv[0];
+                acc2[q][4 * r4 + 1] = bv[1];
+                acc2[q][4 * r4 + 2] = bv[2];
+                acc2[q][4 * r4 + 3] = bv[3];
+            }
+        // 32 k-steps in 8 groups of 4; the A fragments (global, L2-resident) of group
+        // g+1 are in flight while group g computes.  sched_barrier keeps hipcc from
+        // hoisting all 32 loads (128 VGPRs) to the top.
+        {
+            constexpr int G2 = 4;
+            f32x4 wcur[G2], wnext[G2];
+#pragma unroll
+            for (int s = 0; s < G2; ++s) wcur[s] = w2[s * 64];
+#pragma unroll
+            for (int g2 = 0; g2 < KS2 / G2; ++g2) {
+                if (g2 + 1 < KS2 / G2) {
+#pragma unroll
+                    for (int s = 0; s < G2; ++s) wnext[s] = w2[((g2 + 1) * G2 + s) * 64];
+                }
+#pragma unroll
+                for (int s = 0; s < G2; ++s) {
+                    const int ks = g2 * G2 + s;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][q], acc[ks >> 4][ks & 15],
+                                                                       acc2[q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < G2; ++s) wcur[s] = wnext[s];
+            }
+        }
+
+        // epilogue: res = (out + x_in) * sqrt(0.5) (:314); skips += skip (:468)
+        const float rs = 0.70710678118654752440f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long off = (long)(32 * q + mfma_row(r, hi)) * Ttot + t;
+                a.xout[off] = (acc2[q][r] + a.xin[off]) * rs;
+                if (FIRST)
+                    a.skip[off] = acc2[2 + q][r];
+                else
+                    a.skip[off] += acc2[2 + q][r];
+            }
+    }
+}
+
+// last_conv_layers: ReLU -> Conv1D(SK->SK,1) -> ReLU -> Conv1D(SK->1,1) (:429-440,471) on
+// skips * sqrt(1/layers) (:469).  One workgroup per tile, 8 waves x 32 samples.
+struct PwgLastArgs {
+    const float* skip;   // [SK][Ttot]
+    const float* w1;     // [SK/2 k-steps][64 lanes][2 co-tiles] A fragments
+    const float* b1;     // [SK]
+    const float* w2;     // [SK]
+    float b2;
+    float scale;
+    const int* tile_t0;
+    long Ttot;
+    float* wav;          // packed (ntiles*TILE)
+    float* skip_scaled;  // optional debug tap [SK][Ttot] (nullptr in production)
+};
+
+__global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const int tile = blockIdx.x;
+    const long t = (long)a.tile_t0[tile] + wave * WAVE_T + j;
+    const float* sb = a.skip + (long)hi * a.Ttot + t;
+    const f32x2* w1 = reinterpret_cast<const f32x2*>(a.w1) + lane;
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = a.b1[32 * q + mfma_row(r, hi)];
+#pragma unroll 8
+    for (int cp = 0; cp < SK / 2; ++cp) {
+        const float v = sb[(long)(2 * cp) * a.Ttot] * a.scale;
+        if (a.skip_scaled) a.skip_scaled[(long)(2 * cp + hi) * a.Ttot + t] = v;
+        const float bv = fmaxf(v, 0.f);
+        const f32x2 af = w1[cp * 64];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bv, acc[1], 0, 0, 0);
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            part = fmaf(a.w2[32 * q + mfma_row(r, hi)], fmaxf(acc[q][r], 0.f), part);
+    part += __shfl_xor(part, 32);
+    if (hi == 0) a.wav[(long)tile * TILE + wave * WAVE_T + j] = part + a.b2;
+}
+
+}  // namespace
+
+// ================================================================== host side
+struct pk_pwg {
+    pk_ctx* ctx = nullptr;
+    pk_pwg_cfg cfg;
+    pk_param_map params;
+    bool finalized = false;
+    int hop = 256;
+    int max_dilation = 512;
+    int gap = 512;
+    bool use_norm = false;
+    std::vector<float> h_mu, h_sigma;
+    // device weights
+    pk_dbuf d_first_w, d_first_b, d_convin_wT, d_up_w, d_mu, d_sigma;
+    pk_dbuf d_w1, d_w2, d_bias;     // all layers, concatenated
+    pk_dbuf d_l1, d_l1b, d_l2;
+    float l2_bias = 0.f;
+    // workspace
+    pk_dbuf ws_mel, ws_noise, ws_wav, ws_c0, ws_upA, ws_upB, ws_c, ws_x0, ws_x1, ws_skip, ws_dbg;
+    pk_dbuf ws_tab;   // int tables
+    // last call layout (for debug reads)
+    std::vector<int> last_frames, last_toff;
+    long last_Ttot = 0;
+    int last_x_final = 0;
+};
+
+extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
+    if (!ctx || !cfg || !out) PK_FAIL(PK_EINVAL, "pk_pwg_create: NULL argument");
+    *out = nullptr;
+    if (cfg->stacks <= 0 || cfg->layers <= 0 || cfg->layers % cfg->stacks != 0)
+        PK_FAIL(PK_ESHAPE, "PWGGenerator: layers (%d) must be a positive multiple of stacks (%d)",
+                cfg->layers, cfg->stacks);  // assert layers % stacks == 0 (:398)
+    if (cfg->use_causal_conv) PK_FAIL(PK_EUNSUPPORTED, "PWGGenerator: use_causal_conv=True is not implemented");
+    if (cfg->in_channels != 1 || cfg->out_channels != 1 || cfg->kernel_size != KTAP ||
+        cfg->residual_channels != R || cfg->gate_channels != G || cfg->skip_channels != SK ||
+        cfg->aux_channels != AUX)
+        PK_FAIL(PK_EUNSUPPORTED,
+                "PWGGenerator: kernels are built for in/out 1, kernel 3, residual 64, gate 128, "
+                "skip 64, aux 80 (got %d/%d, k%d, %d, %d, %d, %d)",
+                cfg->in_channels, cfg->out_channels, cfg->kernel_size, cfg->residual_channels,
+                cfg->gate_channels, cfg->skip_channels, cfg->aux_channels);
+    if (cfg->n_upsample < 1 || cfg->n_upsample > 8) PK_FAIL(PK_EINVAL, "PWGGenerator: 1..8 upsample scales");
+    int hop = 1;
+    for (int i = 0; i < cfg->n_upsample; ++i) {
+        int s = cfg->upsample_scales[i];
+        if (s < 1 || 2 * s + 1 > MAX_UP_TAPS) PK_FAIL(PK_EUNSUPPORTED, "upsample scale %d unsupported", s);
+        hop *= s;
+    }
+    if (hop != TILE) PK_FAIL(PK_EUNSUPPORTED, "prod(upsample_scales) must be %d (got %d)", TILE, hop);
+    if (cfg->aux_context_window < 0 || cfg->aux_context_window > 8)
+        PK_FAIL(PK_EINVAL, "aux_context_window out of range");
+    int lps = cfg->layers / cfg->stacks;
+    if (lps > 12) PK_FAIL(PK_EUNSUPPORTED, "dilation 2^%d too large", lps - 1);
+    pk_pwg* h = new pk_pwg();
+    h->ctx = ctx;
+    h->cfg = *cfg;
+    h->hop = hop;
+    h->max_dilation = 1 << (lps - 1);
+    h->gap = ((h->max_dilation + TILE - 1) / TILE) * TILE;
+    if (h->gap < TILE) h->gap = TILE;
+    *out = h;
+    return PK_OK;
+}
+
+extern "C" int pk_pwg_set_param(pk_pwg* h, const char* name, const float* data, const int64_t* shape,
+                                int32_t ndim) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_set_param: handle is NULL");
+    h->finalized = false;
+    return pk_store_param(h->params, name, data, shape, ndim);
+}
+
+extern "C" int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_t n) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_set_normalizer: handle is NULL");
+    if (!mu && !sigma) {
+        h->use_norm = false;
+        return PK_OK;
+    }
+    if (!mu || !sigma || n != AUX) PK_FAIL(PK_ESHAPE, "normalizer needs mu and sigma of %d elements", AUX);
+    h->h_mu.assign(mu, mu + n);
+    h->h_sigma.assign(sigma, sigma + n);
+    h->use_norm = true;
+    PK_HIP(hipSetDevice(h->ctx->device));
+    PK_TRY(pk_upload(h->ctx, h->d_mu, h->h_mu.data(), n * sizeof(float)));
+    PK_TRY(pk_upload(h->ctx, h->d_sigma, h->h_sigma.data(), n * sizeof(float)));
+    return PK_OK;
+}
+
+extern "C" int pk_pwg_finalize(pk_pwg* h) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_finalize: handle is NULL");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const pk_pwg_cfg& c = h->cfg;
+    std::vector<float> w, b;
+    // first_conv
+    PK_TRY(pk_get_weight(h->params, "first_conv", {R, 1, 1}, w));
+    PK_TRY(pk_get_vector(h->params, "first_conv.bias", R, b));
+    PK_TRY(pk_upload(ctx, h->d_first_w, w.data(), R * sizeof(float)));
+    PK_TRY(pk_upload(ctx, h->d_first_b, b.data(), R * sizeof(float)));
+    // conv_in -> [(ci*k + tap)][co]
+    const int kin = 2 * c.aux_context_window + 1;
+    PK_TRY(pk_get_weight(h->params, "upsample_net.conv_in", {AUX, AUX, kin}, w));
+    {
+        std::vector<float> wT((size_t)AUX * kin * AUX);
+        for (int co = 0; co < AUX; ++co)
+            for (int ci = 0; ci < AUX; ++ci)
+                for (int tap = 0; tap < kin; ++tap)
+                    wT[((size_t)ci * kin + tap) * AUX + co] = w[((size_t)co * AUX + ci) * kin + tap];
+        PK_TRY(pk_upload(ctx, h->d_convin_wT, wT.data(), wT.size() * sizeof(float)));
+    }
+    // upsample FIRs: up_layers.{2i+1}.weight (1,1,1,2s+1)
+    {
+        std::vector<float> up((size_t)c.n_upsample * MAX_UP_TAPS, 0.f);
+        for (int i = 0; i < c.n_upsample; ++i) {
+            int taps = 2 * c.upsample_scales[i] + 1;
+            PK_TRY(pk_get_weight(h->params, "upsample_net.upsample.up_layers." + std::to_string(2 * i + 1),
+                                 {1, 1, 1, taps}, w));
+            for (int j = 0; j < taps; ++j) up[(size_t)i * MAX_UP_TAPS + j] = w[j];
+        }
+        PK_TRY(pk_upload(ctx, h->d_up_w, up.data(), up.size() * sizeof(float)));
+    }
+    // residual blocks -> MFMA A-fragment layouts
+    {
+        const size_t n1 = (size_t)KS1 * 64 * 4, n2 = (size_t)KS2 * 64 * 4, nb = G + R + SK;
+        std::vector<float> W1(n1 * c.layers), W2(n2 * c.layers), B(nb * c.layers);
+        std::vector<float> wc, wa, wo, ws, bc, bo, bs;
+        for (int l = 0; l < c.layers; ++l) {
+            const std::string p = "conv_layers." + std::to_string(l);
+            PK_TRY(pk_get_weight(h->params, p + ".conv", {G, R, KTAP}, wc));
+            PK_TRY(pk_get_weight(h->params, p + ".conv1x1_aux", {G, AUX, 1}, wa));
+            PK_TRY(pk_get_weight(h->params, p + ".conv1x1_out", {R, G / 2, 1}, wo));
+            PK_TRY(pk_get_weight(h->params, p + ".conv1x1_skip", {SK, G / 2, 1}, ws));
+            PK_TRY(pk_get_vector(h->params, p + ".conv.bias", G, bc));
+            PK_TRY(pk_get_vector(h->params, p + ".conv1x1_out.bias", R, bo));
+            PK_TRY(pk_get_vector(h->params, p + ".conv1x1_skip.bias", SK, bs));
+            float* a1 = W1.data() + n1 * l;
+            for (int ks = 0; ks < KS1; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, hi = lane >> 5;
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = 32 * q + i;
+                        float v;
+                        if (ks < KS_CONV) {
+                            const int tap = ks / (R / 2), ci = 2 * (ks % (R / 2)) + hi;
+                            v = wc[((size_t)co * R + ci) * KTAP + tap];
+                        } else {
+                            const int ca = 2 * (ks - KS_CONV) + hi;
+                            v = wa[(size_t)co * AUX + ca];
+                        }
+                        a1[((size_t)ks * 64 + lane) * 4 + q] = v;
+                    }
+                }
+            float* a2 = W2.data() + n2 * l;
+            for (int zq = 0; zq < 2; ++zq)
+                for (int r = 0; r < 16; ++r)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, hi = lane >> 5;
+                        const int zc = 32 * zq + mfma_row(r, hi);  // gated channel fed by this k-slot
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = 32 * (q & 1) + i;
+                            const float v = (q < 2) ? wo[(size_t)row * (G / 2) + zc] : ws[(size_t)row * (G / 2) + zc];
+                            a2[((size_t)(zq * 16 + r) * 64 + lane) * 4 + q] = v;
+                        }
+                    }
+            float* bb = B.data() + nb * l;
+            for (int i = 0; i < G; ++i) bb[i] = bc[i];
+            for (int i = 0; i < R; ++i) bb[G + i] = bo[i];
+            for (int i = 0; i < SK; ++i) bb[G + R + i] = bs[i];
+        }
+        PK_TRY(pk_upload(ctx, h->d_w1, W1.data(), W1.size() * sizeof(float)));
+        PK_TRY(pk_upload(ctx, h->d_w2, W2.data(), W2.size() * sizeof(float)));
+        PK_TRY(pk_upload(ctx, h->d_bias, B.data(), B.size() * sizeof(float)));
+    }
+    // last layers
+    {
+        std::vector<float> w1, b1, w2, b2;
+        PK_TRY(pk_get_weight(h->params, "last_conv_layers.1", {SK, SK, 1}, w1));
+        PK_TRY(pk_get_vector(h->params, "last_conv_layers.1.bias", SK, b1));
+        PK_TRY(pk_get_weight(h->params, "last_conv_layers.3", {1, SK, 1}, w2));
+        PK_TRY(pk_get_vector(h->params, "last_conv_layers.3.bias", 1, b2));
+        std::vector<float> A((size_t)(SK / 2) * 64 * 2);
+        for (int cp = 0; cp < SK / 2; ++cp)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, hi = lane >> 5;
+                for (int q = 0; q < 2; ++q)
+                    A[((size_t)cp * 64 + lane) * 2 + q] = w1[(size_t)(32 * q + i) * SK + 2 * cp + hi];
+            }
+        PK_TRY(pk_upload(ctx, h->d_l1, A.data(), A.size() * sizeof(float)));
+        PK_TRY(pk_upload(ctx, h->d_l1b, b1.data(), SK * sizeof(float)));
+        PK_TRY(pk_upload(ctx, h->d_l2, w2.data(), SK * sizeof(float)));
+        h->l2_bias = b2[0];
+    }
+    h->finalized = true;
+    return PK_OK;
+}
+
+extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, int32_t B,
+                            const float* noise, float* wav, int32_t flags) {
+    if (!h || !mel || !frames || !noise || !wav) PK_FAIL(PK_EINVAL, "pk_pwg_infer: NULL argument");
+    if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_pwg_infer: call pk_pwg_finalize first");
+    if (B <= 0) PK_FAIL(PK_EINVAL, "pk_pwg_infer: batch size must be positive");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const pk_pwg_cfg& c = h->cfg;
+    const int hop = h->hop, gap = h->gap;
+    // ---- layout
+    std::vector<int> cuL(B + 1, 0), toff(B), gap_start(B + 1);
+    long t = 0;
+    for (int b = 0; b < B; ++b) {
+        if (frames[b] <= 0) PK_FAIL(PK_EINVAL, "pk_pwg_infer: utterance %d has %d frames", b, frames[b]);
+        cuL[b + 1] = cuL[b] + frames[b];
+        gap_start[b] = (int)t;
+        t += gap;
+        toff[b] = (int)t;
+        t += (long)frames[b] * hop;
+    }
+    gap_start[B] = (int)t;
+    t += gap;
+    const long Ttot = t;
+    const int sumL = cuL[B];
+    const long sumS = (long)sumL * hop;
+    if (Ttot >= (1L << 31)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
+    h->last_frames.assign(frames, frames + B);
+    h->last_toff = toff;
+    h->last_Ttot = Ttot;
+
+    // int tables: [cuL (B+1)] [toff (B)] [gap_start (B+1)] [frame_utt (sumL)] [tile_t0 (sumL)]
+    //             per upsample stage: in_off (B), in_len (B), out_off (B)
+    std::vector<int> tab;
+    auto push = [&](const std::vector<int>& v) {
+        size_t o = tab.size();
+        tab.insert(tab.end(), v.begin(), v.end());
+        return o;
+    };
+    const size_t o_cuL = push(cuL), o_gap = push(gap_start);
+    std::vector<int> frame_utt(sumL), tile_t0(sumL);
+    for (int b = 0; b < B; ++b)
+        for (int f = 0; f < frames[b]; ++f) {
+            frame_utt[cuL[b] + f] = b;
+            tile_t0[cuL[b] + f] = toff[b] + f * hop;
+        }
+    const size_t o_futt = push(frame_utt), o_tile = push(tile_t0);
+    std::vector<size_t> o_inoff(c.n_upsample), o_inlen(c.n_upsample), o_outoff(c.n_upsample);
+    {
+        int m = 1;
+        for (int i = 0; i < c.n_upsample; ++i) {
+            std::vector<int> in_off(B), in_len(B), out_off(B);
+            const int s = c.upsample_scales[i];
+            const bool last = (i == c.n_upsample - 1);
+            for (int b = 0; b < B; ++b) {
+                in_off[b] = cuL[b] * m;
+                in_len[b] = frames[b] * m;
+                out_off[b] = last ? toff[b] : cuL[b] * m * s;
+            }
+            o_inoff[i] = push(in_off);
+            o_inlen[i] = push(in_len);
+            o_outoff[i] = push(out_off);
+            m *= s;
+        }
+    }
+    PK_TRY(h->ws_tab.reserve(tab.size() * sizeof(int)));
+    PK_HIP(hipMemcpyAsync(h->ws_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));  // tab is a stack vector
+    const int* d_tab = h->ws_tab.as<int>();
+
+    // ---- workspaces
+    const float* d_mel = mel;
+    const float* d_noise = noise;
+    float* d_wav = wav;
+    if (flags & PK_HOST_IO) {
+        PK_TRY(h->ws_mel.reserve((size_t)sumL * AUX * 4));
+        PK_TRY(h->ws_noise.reserve((size_t)sumS * 4));
+        PK_TRY(h->ws_wav.reserve((size_t)sumS * 4));
+        PK_HIP(hipMemcpyAsync(h->ws_mel.p, mel, (size_t)sumL * AUX * 4, hipMemcpyHostToDevice, ctx->stream));
+        PK_HIP(hipMemcpyAsync(h->ws_noise.p, noise, (size_t)sumS * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_mel = h->ws_mel.as<float>();
+        d_noise = h->ws_noise.as<float>();
+        d_wav = h->ws_wav.as<float>();
+    }
+    PK_TRY(h->ws_c0.reserve((size_t)AUX * sumL * 4));
+    {
+        long inter = 1, m = 1;  // largest intermediate stage output per channel
+        for (int i = 0; i + 1 < c.n_upsample; ++i) {
+            m *= c.upsample_scales[i];
+            inter = m > inter ? m : inter;
+        }
+        PK_TRY(h->ws_upA.reserve((size_t)AUX * sumL * inter * 4));
+        PK_TRY(h->ws_upB.reserve((size_t)AUX * sumL * inter * 4));
+    }
+    PK_TRY(h->ws_c.reserve((size_t)AUX * Ttot * 4));
+    PK_TRY(h->ws_x0.reserve((size_t)R * Ttot * 4));
+    PK_TRY(h->ws_x1.reserve((size_t)R * Ttot * 4));
+    PK_TRY(h->ws_skip.reserve((size_t)SK * Ttot * 4));
+
+    // ---- zero the gaps of both ping-pong buffers
+    {
+        dim3 grid(pk_div_up(gap, 256), B + 1, R);
+        PK_LAUNCH(ctx, "pwg_zero_gaps", k_zero_gaps, grid, dim3(256), 0, h->ws_x0.as<float>(), d_tab + o_gap,
+                  gap, R, Ttot);
+        PK_LAUNCH(ctx, "pwg_zero_gaps", k_zero_gaps, grid, dim3(256), 0, h->ws_x1.as<float>(), d_tab + o_gap,
+                  gap, R, Ttot);
+    }
+    // ---- conditioning: conv_in + upsample stages
+    {
+        const int kin = 2 * c.aux_context_window + 1;
+        PK_LAUNCH(ctx, "pwg_convin", k_pwg_convin, dim3(sumL), dim3(128), kin * AUX * sizeof(float), d_mel,
+                  h->d_convin_wT.as<float>(), h->d_mu.as<float>(), h->d_sigma.as<float>(),
+                  h->use_norm ? 1 : 0, d_tab + o_futt, d_tab + o_cuL, c.aux_context_window, sumL,
+                  h->ws_c0.as<float>());
+        const float* in = h->ws_c0.as<float>();
+        long in_stride = sumL;
+        int m = 1, maxL = 0;
+        for (int b = 0; b < B; ++b) maxL = frames[b] > maxL ? frames[b] : maxL;
+        for (int i = 0; i < c.n_upsample; ++i) {
+            const int s = c.upsample_scales[i];
+            const bool last = (i == c.n_upsample - 1);
+            float* out = last ? h->ws_c.as<float>() : ((i & 1) ? h->ws_upB.as<float>() : h->ws_upA.as<float>());
+            const long out_stride = last ? Ttot : (long)sumL * m * s;
+            dim3 grid(pk_div_up((long)maxL * m * s, 256), AUX, B);
+            PK_LAUNCH(ctx, "pwg_upsample", k_pwg_upsample, grid, dim3(256), 0, in, in_stride,
+                      d_tab + o_inoff[i], d_tab + o_inlen[i], out, out_stride, d_tab + o_outoff[i], s,
+                      h->d_up_w.as<float>() + (size_t)i * MAX_UP_TAPS);
+            in = out;
+            in_stride = out_stride;
+            m *= s;
+        }
+    }
+    // ---- first conv
+    PK_LAUNCH(ctx, "pwg_first", k_pwg_first, dim3(sumL), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
+              h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>());
+    // ---- residual stack
+    {
+        const int lps = c.layers / c.stacks;
+        const int grid = sumL < ctx->n_cu ? sumL : ctx->n_cu;
+        for (int l = 0; l < c.layers; ++l) {
+            PwgLayerArgs a;
+            a.xin = (l & 1) ? h->ws_x1.as<float>() : h->ws_x0.as<float>();
+            a.xout = (l & 1) ? h->ws_x0.as<float>() : h->ws_x1.as<float>();
+            a.c = h->ws_c.as<float>();
+            a.skip = h->ws_skip.as<float>();
+            a.w1 = h->d_w1.as<float>() + (size_t)l * KS1 * 64 * 4;
+            a.w2 = h->d_w2.as<float>() + (size_t)l * KS2 * 64 * 4;
+            a.bias = h->d_bias.as<float>() + (size_t)l * (G + R + SK);
+            a.tile_t0 = d_tab + o_tile;
+            a.Ttot = Ttot;
+            a.ntiles = sumL;
+            a.dilation = 1 << (l % lps);
+            if (l == 0)
+                PK_LAUNCH(ctx, "pwg_layer", k_pwg_layer<true>, dim3(grid), dim3(512), 0, a);
+            else
+                PK_LAUNCH(ctx, "pwg_layer", k_pwg_layer<false>, dim3(grid), dim3(512), 0, a);
+        }
+        h->last_x_final = c.layers & 1;
+    }
+    // ---- last layers
+    {
+        PwgLastArgs a;
+        a.skip = h->ws_skip.as<float>();
+        a.w1 = h->d_l1.as<float>();
+        a.b1 = h->d_l1b.as<float>();
+        a.w2 = h->d_l2.as<float>();
+        a.b2 = h->l2_bias;
+        a.scale = (float)std::sqrt(1.0 / c.layers);
+        a.tile_t0 = d_tab + o_tile;
+        a.Ttot = Ttot;
+        a.wav = d_wav;
+        a.skip_scaled = nullptr;
+        PK_LAUNCH(ctx, "pwg_last", k_pwg_last, dim3(sumL), dim3(512), 0, a);
+    }
+    if (flags & PK_HOST_IO) {
+        PK_HIP(hipMemcpyAsync(wav, d_wav, (size_t)sumS * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host_out, int64_t n_floats) {
+    if (!h || !host_out) PK_FAIL(PK_EINVAL, "pk_pwg_debug_read: NULL argument");
+    if (h->last_Ttot == 0) PK_FAIL(PK_ESTATE, "pk_pwg_debug_read: no inference has run");
+    if (b < 0 || b >= (int)h->last_frames.size()) PK_FAIL(PK_EINVAL, "pk_pwg_debug_read: utterance out of range");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const long S = (long)h->last_frames[b] * h->hop;
+    const float* src;
+    int rows;
+    switch (what) {
+        case 0: src = h->ws_c.as<float>(); rows = AUX; break;
+        case 1: src = h->last_x_final ? h->ws_x1.as<float>() : h->ws_x0.as<float>(); rows = R; break;
+        case 2: src = h->ws_skip.as<float>(); rows = SK; break;
+        default: PK_FAIL(PK_EINVAL, "pk_pwg_debug_read: unknown tap %d", what);
+    }
+    if (n_floats != (int64_t)rows * S)
+        PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats, got %lld", rows * S, (long long)n_floats);
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    PK_HIP(hipMemcpy2D(host_out, S * sizeof(float), src + h->last_toff[b], h->last_Ttot * sizeof(float),
+                       S * sizeof(float), rows, hipMemcpyDeviceToHost));
+    return PK_OK;
+}
+
+extern "C" void pk_pwg_destroy(pk_pwg* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_up_w, &h->d_mu, &h->d_sigma,
+                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_l1, &h->d_l1b, &h->d_l2,
+                       &h->ws_mel, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_upA, &h->ws_upB, &h->ws_c,
+                       &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab};
+    for (auto* b : bufs) b->release();
+    delete h;
+}

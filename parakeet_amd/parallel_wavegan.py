@@ -1,0 +1,147 @@
+"""Parallel WaveGAN generator behind the reference's Python API.
+
+Mirrors parakeet/models/parallel_wavegan/parallel_wavegan.py:
+``PWGGenerator`` (constructor kwargs :369-388, ``set_state_dict``, ``eval``,
+``remove_weight_norm`` :485-496, ``inference`` :498-520) and ``PWGInference``
+(:766-775).  All arithmetic runs in libpk_synth.so (csrc/pwg.hip).
+
+Extensions over the reference (superset, not a break): ``inference`` takes an
+optional ``noise=`` (the reference draws ``paddle.randn`` inside the call, which
+cannot be reproduced), and ``inference_batch`` synthesises a ragged batch in
+one engine call.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .normalizer import ZScore
+from .runtime import Context, dptr, set_params, to_numpy_f32, wrap
+
+
+class PWGGenerator:
+    def __init__(self, in_channels=1, out_channels=1, kernel_size=3, layers=30, stacks=3,
+                 residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
+                 aux_context_window=2, dropout=0., bias=True, use_weight_norm=True,
+                 use_causal_conv=False, upsample_scales=(4, 4, 4, 4), nonlinear_activation=None,
+                 nonlinear_activation_params=None, interpolate_mode="nearest",
+                 freq_axis_kernel_size=1, device=None):
+        assert layers % stacks == 0  # parallel_wavegan.py:398
+        if not bias:
+            raise NotImplementedError("PWGGenerator(bias=False) is not implemented")
+        if nonlinear_activation is not None:
+            raise NotImplementedError("upsample nonlinear_activation is not implemented")
+        if interpolate_mode != "nearest" or freq_axis_kernel_size != 1:
+            raise NotImplementedError("only nearest stretch with freq_axis_kernel_size=1 is implemented")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.aux_channels = aux_channels
+        self.aux_context_window = aux_context_window
+        self.layers = layers
+        self.stacks = stacks
+        self.kernel_size = kernel_size
+        self.upsample_factor = int(np.prod(upsample_scales))
+        self.training = True
+        self._ctx = Context.get(device)
+        cfg = _capi.PwgCfg()
+        cfg.in_channels, cfg.out_channels, cfg.kernel_size = in_channels, out_channels, kernel_size
+        cfg.layers, cfg.stacks = layers, stacks
+        cfg.residual_channels, cfg.gate_channels = residual_channels, gate_channels
+        cfg.skip_channels, cfg.aux_channels = skip_channels, aux_channels
+        cfg.aux_context_window = aux_context_window
+        cfg.n_upsample = len(upsample_scales)
+        for i, s in enumerate(upsample_scales):
+            cfg.upsample_scales[i] = int(s)
+        cfg.use_causal_conv = 1 if use_causal_conv else 0
+        h = C.c_void_p()
+        _capi.check(self._ctx.lib.pk_pwg_create(self._ctx.handle, C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._finalized = False
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._ctx.lib.pk_pwg_destroy(h)
+            except Exception:
+                pass
+
+    # -- nn.Layer look-alikes ------------------------------------------------
+    def set_state_dict(self, state_dict):
+        set_params(self._ctx.lib.pk_pwg_set_param, self._h, state_dict)
+        self._finalized = False
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def remove_weight_norm(self):
+        """Numerically neutral here: weight_g / weight_v pairs are folded at finalize."""
+        return None
+
+    def set_normalizer(self, normalizer):
+        if normalizer is None:
+            _capi.check(self._ctx.lib.pk_pwg_set_normalizer(self._h, None, None, 0))
+        else:
+            mu, sigma = to_numpy_f32(normalizer.mu).reshape(-1), to_numpy_f32(normalizer.sigma).reshape(-1)
+            _capi.check(self._ctx.lib.pk_pwg_set_normalizer(self._h, _capi.fptr(mu), _capi.fptr(sigma), mu.size))
+
+    def _finalize(self):
+        if not self._finalized:
+            _capi.check(self._ctx.lib.pk_pwg_finalize(self._h))
+            self._finalized = True
+
+    # -- synthesis -------------------------------------------------------------
+    def inference_batch(self, mels, noises=None, generator=None):
+        """mels: list of (T'_b, aux) arrays.  Returns a list of (T'_b*hop, out) device tensors."""
+        ctx = Context.get(self._ctx.device)
+        self._finalize()
+        frames = np.array([int(m.shape[0]) for m in mels], dtype=np.int32)
+        self._last_frames = [int(f) for f in frames]
+        hop = self.upsample_factor
+        mel = torch.cat([ctx.to_device(m).reshape(-1, self.aux_channels) for m in mels], dim=0)
+        total = int(frames.sum()) * hop
+        if noises is None:
+            noise = torch.randn(total, device=ctx.device, dtype=torch.float32, generator=generator)
+        else:
+            noise = torch.cat([ctx.to_device(n).reshape(-1) for n in noises], dim=0)
+        assert noise.numel() == total, "noise length must be frames * hop"
+        wav = ctx.empty((total,))
+        _capi.check(ctx.lib.pk_pwg_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         len(mels), dptr(noise), dptr(wav), 0))
+        outs, o = [], 0
+        for f in frames:
+            n = int(f) * hop
+            outs.append(wrap(wav[o:o + n].reshape(n, self.out_channels)))
+            o += n
+        return outs
+
+    def inference(self, c=None, noise=None):
+        """(T', C_aux) -> (T, C_out); parallel_wavegan.py:498-520."""
+        return self.inference_batch([c], None if noise is None else [noise])[0]
+
+    def debug_tap(self, what, b):
+        rows = {0: self.aux_channels, 1: 64, 2: 64}[what]
+        # frames of utterance b are known to the engine; size is validated there
+        n = self._last_frames[b] * self.upsample_factor
+        out = np.empty((rows, n), dtype=np.float32)
+        _capi.check(self._ctx.lib.pk_pwg_debug_read(self._h, what, b, _capi.fptr(out), out.size))
+        return out
+
+
+class PWGInference:
+    """PWGInference (parallel_wavegan.py:766-775): normalizer(logmel) -> generator.inference."""
+
+    def __init__(self, normalizer, pwg_generator):
+        self.normalizer = normalizer
+        self.pwg_generator = pwg_generator
+        pwg_generator.set_normalizer(normalizer)
+
+    def forward(self, logmel, noise=None):
+        return self.pwg_generator.inference(logmel, noise=noise)
+
+    __call__ = forward
+
+    def eval(self):
+        return self

@@ -1,0 +1,193 @@
+"""Synthetic configurations, weights and inputs of LJSpeech shape.
+
+There are no checkpoints in this environment (and ``.pdz`` files need Paddle
+to unpickle), so benchmarks and parity tests run on random-initialised weights
+laid out exactly like the reference's ``state_dict()``: same key
+names, same array shapes.  The generators follow SURVEY.md 8(d):
+
+* FastSpeech2: Xavier-uniform for every >=2-D weight (init_type
+  ``xavier_uniform``, examples/fastspeech2/ljspeech/conf/default.yaml:53,
+  parakeet/modules/nets_utils.py:144-146), alpha = 1.  With ``perturb=True``
+  biases, LayerNorm / BatchNorm parameters and running stats are randomised so
+  that a parity test cannot pass with a dropped bias or a swapped gamma/beta.
+* duration head: ``fixed_duration=d`` sets ``duration_predictor.linear`` to
+  weight 0 / bias ln(d+1) so every token gets exactly d frames through the
+  normal inference path (the throughput configuration, L = 5*T); otherwise a
+  random head with bias ln 4 gives ragged integer durations.
+* Parallel WaveGAN: U(-1/sqrt(Cin*k), 1/sqrt(Cin*k)), weight-norm already
+  folded (``weight_norm=True`` emits weight_g / weight_v pairs instead).
+"""
+import math
+
+import numpy as np
+
+FS2_LJSPEECH = dict(
+    adim=384, aheads=2, elayers=4, eunits=1536, dlayers=4, dunits=1536,
+    positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3,
+    duration_predictor_layers=2, duration_predictor_chans=256, duration_predictor_kernel_size=3,
+    postnet_layers=5, postnet_filts=5, postnet_chans=256,
+    use_scaled_pos_enc=True, encoder_normalize_before=True, decoder_normalize_before=True,
+    reduction_factor=1, init_type="xavier_uniform", init_enc_alpha=1.0, init_dec_alpha=1.0,
+    pitch_predictor_layers=5, pitch_predictor_chans=256, pitch_predictor_kernel_size=5,
+    pitch_embed_kernel_size=1,
+    energy_predictor_layers=2, energy_predictor_chans=256, energy_predictor_kernel_size=3,
+    energy_embed_kernel_size=1)
+
+PWG_LJSPEECH = dict(
+    in_channels=1, out_channels=1, kernel_size=3, layers=30, stacks=3,
+    residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
+    aux_context_window=2, dropout=0.0, use_weight_norm=True, upsample_scales=[4, 4, 4, 4])
+
+SAMPLE_RATE = 22050
+HOP = 256
+
+
+def _xavier(rng, shape):
+    """Xavier-uniform with Paddle's fan computation: for a [in, out] Linear
+    weight fan_in = shape[0], fan_out = shape[1]; for conv [Cout, Cin, k]
+    fan_in = Cin*k, fan_out = Cout*k."""
+    if len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[2:]))
+        fan_in, fan_out = shape[1] * rf, shape[0] * rf
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=None, perturb=True):
+    cfg = dict(FS2_LJSPEECH, **(cfg or {}))
+    rng = np.random.default_rng(seed)
+    A = cfg["adim"]
+    st = {}
+
+    def small(n, scale=0.1):
+        return (rng.uniform(-scale, scale, size=(n,)) if perturb else np.zeros(n)).astype(np.float32)
+
+    def gamma(n):
+        return (rng.uniform(0.5, 1.5, size=(n,)) if perturb else np.ones(n)).astype(np.float32)
+
+    def ln(prefix, n):
+        st[prefix + ".weight"] = gamma(n)
+        st[prefix + ".bias"] = small(n)
+
+    def fft_stack(prefix, n_layers, units, embed_idx):
+        st[f"{prefix}.embed.{embed_idx}.alpha"] = np.array(
+            [cfg["init_enc_alpha" if prefix == "encoder" else "init_dec_alpha"]], dtype=np.float32)
+        k = cfg["positionwise_conv_kernel_size"]
+        for i in range(n_layers):
+            p = f"{prefix}.encoders.{i}"
+            for nm in ("q", "k", "v", "out"):
+                st[f"{p}.self_attn.linear_{nm}.weight"] = _xavier(rng, (A, A))
+                st[f"{p}.self_attn.linear_{nm}.bias"] = small(A)
+            st[f"{p}.feed_forward.w_1.weight"] = _xavier(rng, (units, A, k))
+            st[f"{p}.feed_forward.w_1.bias"] = small(units)
+            st[f"{p}.feed_forward.w_2.weight"] = _xavier(rng, (A, units, k))
+            st[f"{p}.feed_forward.w_2.bias"] = small(A)
+            ln(f"{p}.norm1", A)
+            ln(f"{p}.norm2", A)
+        ln(f"{prefix}.after_norm", A)
+
+    emb = _xavier(rng, (idim, A))
+    emb[0] = 0.0  # padding_idx row
+    st["encoder.embed.0.weight"] = emb
+    fft_stack("encoder", cfg["elayers"], cfg["eunits"], 1)
+    fft_stack("decoder", cfg["dlayers"], cfg["dunits"], 0)
+
+    def predictor(prefix, n_layers, chans, k):
+        for j in range(n_layers):
+            cin = A if j == 0 else chans
+            st[f"{prefix}.conv.{j}.0.weight"] = _xavier(rng, (chans, cin, k))
+            st[f"{prefix}.conv.{j}.0.bias"] = small(chans)
+            ln(f"{prefix}.conv.{j}.2", chans)
+        st[f"{prefix}.linear.weight"] = _xavier(rng, (chans, 1))
+        st[f"{prefix}.linear.bias"] = small(1)
+
+    predictor("duration_predictor", cfg["duration_predictor_layers"],
+              cfg["duration_predictor_chans"], cfg["duration_predictor_kernel_size"])
+    predictor("pitch_predictor", cfg["pitch_predictor_layers"],
+              cfg["pitch_predictor_chans"], cfg["pitch_predictor_kernel_size"])
+    predictor("energy_predictor", cfg["energy_predictor_layers"],
+              cfg["energy_predictor_chans"], cfg["energy_predictor_kernel_size"])
+    if fixed_duration is not None:
+        st["duration_predictor.linear.weight"][:] = 0.0
+        st["duration_predictor.linear.bias"][:] = math.log(fixed_duration + 1.0)
+    else:
+        c = cfg["duration_predictor_chans"]
+        st["duration_predictor.linear.weight"] = rng.uniform(-0.05, 0.05, size=(c, 1)).astype(np.float32)
+        st["duration_predictor.linear.bias"] = np.array([math.log(4.0)], dtype=np.float32)
+    for nm in ("pitch", "energy"):
+        k = cfg[f"{nm}_embed_kernel_size"]
+        st[f"{nm}_embed.0.weight"] = _xavier(rng, (A, 1, k))
+        st[f"{nm}_embed.0.bias"] = small(A)
+    st["feat_out.weight"] = _xavier(rng, (A, odim * cfg["reduction_factor"]))
+    st["feat_out.bias"] = small(odim * cfg["reduction_factor"])
+    n, ch, kf = cfg["postnet_layers"], cfg["postnet_chans"], cfg["postnet_filts"]
+    for j in range(n):
+        cin = odim if j == 0 else ch
+        cout = odim if j == n - 1 else ch
+        st[f"postnet.postnet.{j}.0.weight"] = _xavier(rng, (cout, cin, kf))
+        st[f"postnet.postnet.{j}.1.weight"] = rng.uniform(0.5, 1.5, size=(cout,)).astype(np.float32)
+        st[f"postnet.postnet.{j}.1.bias"] = small(cout)
+        st[f"postnet.postnet.{j}.1._mean"] = small(cout)
+        st[f"postnet.postnet.{j}.1._variance"] = (
+            rng.uniform(0.5, 1.5, size=(cout,)) if perturb else np.ones(cout)).astype(np.float32)
+    return st
+
+
+def pwg_state(cfg=None, seed=42, weight_norm=False):
+    cfg = dict(PWG_LJSPEECH, **(cfg or {}))
+    rng = np.random.default_rng(seed)
+    st = {}
+
+    def conv(name, cout, cin, k, bias=True):
+        lim = 1.0 / math.sqrt(cin * k)
+        w = rng.uniform(-lim, lim, size=(cout, cin, k)).astype(np.float32)
+        _put(name, w)
+        if bias:
+            st[name + ".bias"] = rng.uniform(-lim, lim, size=(cout,)).astype(np.float32)
+
+    def _put(name, w):
+        if weight_norm:
+            # weight_norm(dim=0): g is the per-output-channel norm (1-D, tests/unit/test_pwg.py:131-132)
+            g = rng.uniform(0.5, 1.5, size=(w.shape[0],)).astype(np.float32)
+            v = w
+            st[name + ".weight_g"] = g
+            st[name + ".weight_v"] = v
+        else:
+            st[name + ".weight"] = w
+
+    R, G, S, A = (cfg["residual_channels"], cfg["gate_channels"], cfg["skip_channels"],
+                  cfg["aux_channels"])
+    conv("first_conv", R, cfg["in_channels"], 1)
+    conv("upsample_net.conv_in", A, A, 2 * cfg["aux_context_window"] + 1, bias=False)
+    for i, s in enumerate(cfg["upsample_scales"]):
+        k = 2 * s + 1
+        w = (1.0 / k + rng.uniform(-0.05, 0.05, size=(1, 1, 1, k))).astype(np.float32)
+        _put(f"upsample_net.upsample.up_layers.{2 * i + 1}", w)
+    for i in range(cfg["layers"]):
+        p = f"conv_layers.{i}"
+        conv(p + ".conv", G, R, cfg["kernel_size"])
+        conv(p + ".conv1x1_aux", G, A, 1, bias=False)
+        conv(p + ".conv1x1_out", R, G // 2, 1)
+        conv(p + ".conv1x1_skip", S, G // 2, 1)
+    conv("last_conv_layers.1", S, S, 1)
+    conv("last_conv_layers.3", cfg["out_channels"], S, 1)
+    return st
+
+
+def phoneme_ids(n_tokens, idim=80, seed=10086):
+    """ids in [1, idim-2]: never the pad id 0, never <eos> = idim-1
+    (parakeet/models/fastspeech2/fastspeech2.py:126,143)."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(1, idim - 1, size=n_tokens).astype(np.int64)
+
+
+def mel_stats(odim=80, seed=7, identity=False):
+    """(mu, sigma) pairs like *_stats.npy = np.stack([mean_, scale_])
+    (utils/compute_statistics.py:101-107)."""
+    if identity:
+        return np.zeros(odim, np.float32), np.ones(odim, np.float32)
+    rng = np.random.default_rng(seed)
+    return (rng.normal(-1.0, 0.5, size=odim).astype(np.float32),
+            rng.uniform(0.5, 1.5, size=odim).astype(np.float32))
