@@ -121,10 +121,57 @@ int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, int32_t B,
                  const float* noise, float* wav, int32_t flags);
 /* Debug / test taps: copy internal activations of the LAST pk_pwg_infer call
  * for utterance b to host.  what: 0 = upsampled conditioning c (aux, S_b),
- * 1 = residual-stack output x (residual, S_b), 2 = scaled skip sum (skip, S_b),
- * all channel-major. */
+ * 1 = residual-stack output x (residual, S_b), 2 = skip sum before the sqrt(1/layers)
+ * scale (skip, S_b), all channel-major. */
 int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
 void pk_pwg_destroy(pk_pwg* h);
+
+/* ------------------------------------------------------------ FastSpeech2 */
+/* Constructor arguments of FastSpeech2 (fastspeech2.py:52-118) that change the
+ * inference computation.  Dropout rates, init_type and the loss switches are
+ * training-only and have no field.  Unsupported values -> PK_EUNSUPPORTED. */
+typedef struct {
+    int32_t idim, odim;
+    int32_t adim, aheads;
+    int32_t elayers, eunits, dlayers, dunits;
+    int32_t positionwise_conv_kernel_size;      /* positionwise_layer_type must be "conv1d" */
+    int32_t duration_predictor_layers, duration_predictor_chans, duration_predictor_kernel_size;
+    int32_t pitch_predictor_layers, pitch_predictor_chans, pitch_predictor_kernel_size;
+    int32_t energy_predictor_layers, energy_predictor_chans, energy_predictor_kernel_size;
+    int32_t pitch_embed_kernel_size, energy_embed_kernel_size;   /* 1 in every reference recipe */
+    int32_t postnet_layers, postnet_chans, postnet_filts;
+    int32_t use_batch_norm;
+    int32_t use_scaled_pos_enc;
+    int32_t encoder_normalize_before, decoder_normalize_before;  /* 1 only */
+    int32_t reduction_factor;                                    /* 1 only */
+    int32_t has_spk_embed, has_tone_embed;                       /* 0 only */
+} pk_fs2_cfg;
+
+int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out);
+/* set_state_dict entry; names are the reference's keys ("encoder.encoders.0.self_attn.linear_q.weight", ...).
+ * Linear weights are [in, out], Conv1D weights [Cout, Cin, k] (Paddle layouts). */
+int pk_fs2_set_param(pk_fs2* h, const char* name, const float* data,
+                     const int64_t* shape, int32_t ndim);
+/* FastSpeech2Inference's normalizer: output mel -> mel * sigma + mu (ZScore.inverse,
+ * fastspeech2.py:668-671).  NULL,NULL = return the normalised mel (FastSpeech2.inference). */
+int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* sigma, int32_t n);
+int pk_fs2_finalize(pk_fs2* h);
+/* Phase 1 of inference (_forward :390-432): encoder, pitch/energy/duration predictors, prefix
+ * sums.  ids: HOST int64, packed by utterance (sum(tok_lens)); tok_lens: HOST (B).
+ * alpha = LengthRegulator speed control.  out_frames (HOST, B) receives the number of mel
+ * frames of each utterance -- the output length is data dependent, so this call synchronises. */
+int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_lens, int32_t B, float alpha,
+                  int32_t* out_frames);
+/* Phase 2 (:432-466): length regulator, decoder, feat_out, postnet, (de)normalisation.
+ * mel_out: (sum(out_frames), odim) float32 packed by utterance; device pointer, or host with
+ * PK_HOST_IO. */
+int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags);
+/* Test taps of the last encode/decode for utterance b, copied to host:
+ * 0 hs (T,adim) | 1 pitch (T) | 2 energy (T) | 3 durations (T) | 4 length-regulated hs (L,adim; needs
+ * pk_fs2_set_debug(1)) | 5 decoder output (L,adim) | 6 before_outs (L,odim). */
+int pk_fs2_set_debug(pk_fs2* h, int32_t on);
+int pk_fs2_debug_read(pk_fs2* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
+void pk_fs2_destroy(pk_fs2* h);
 
 #ifdef __cplusplus
 }

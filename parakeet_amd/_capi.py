@@ -32,6 +32,19 @@ class PwgCfg(C.Structure):
     ]
 
 
+class Fs2Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "idim", "odim", "adim", "aheads", "elayers", "eunits", "dlayers", "dunits",
+        "positionwise_conv_kernel_size",
+        "duration_predictor_layers", "duration_predictor_chans", "duration_predictor_kernel_size",
+        "pitch_predictor_layers", "pitch_predictor_chans", "pitch_predictor_kernel_size",
+        "energy_predictor_layers", "energy_predictor_chans", "energy_predictor_kernel_size",
+        "pitch_embed_kernel_size", "energy_embed_kernel_size",
+        "postnet_layers", "postnet_chans", "postnet_filts",
+        "use_batch_norm", "use_scaled_pos_enc", "encoder_normalize_before", "decoder_normalize_before",
+        "reduction_factor", "has_spk_embed", "has_tone_embed")]
+
+
 _lib = None
 
 
@@ -56,6 +69,15 @@ def _declare(lib):
         "pk_pwg_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
         "pk_pwg_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
         "pk_pwg_destroy": (None, [vp]),
+        "pk_fs2_create": (C.c_int, [vp, C.POINTER(Fs2Cfg), C.POINTER(vp)]),
+        "pk_fs2_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
+        "pk_fs2_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
+        "pk_fs2_finalize": (C.c_int, [vp]),
+        "pk_fs2_encode": (C.c_int, [vp, i64p, i32p, i32, C.c_float, i32p]),
+        "pk_fs2_decode": (C.c_int, [vp, f32p, i32]),
+        "pk_fs2_set_debug": (C.c_int, [vp, i32]),
+        "pk_fs2_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
+        "pk_fs2_destroy": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

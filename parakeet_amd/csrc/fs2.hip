@@ -1,0 +1,981 @@
+// fs2.hip -- FastSpeech2 inference on gfx950: kernels + pk_fs2_* entry points.
+//
+// Reference: parakeet/models/fastspeech2/fastspeech2.py FastSpeech2.inference :468-558
+// (_forward(is_inference=True) :377-466) and the modules listed in SURVEY.md 8a
+// (encoder.py, encoder_layer.py, attention.py, embedding.py, multi_layer_conv.py,
+// duration_predictor.py, variance_predictor.py, length_regulator.py, layer_norm.py,
+// tacotron2/decoder.py Postnet, normalizer.py).
+//
+// Data layout ("row timeline").  Activations are channels-last [rows][C] fp32.  All
+// utterances of a batch share one row axis, separated and framed by GAPR zero rows:
+//
+//      |GAPR| utt 0 (T_0 rows) |GAPR| utt 1 (T_1 rows) |GAPR| ...
+//
+// GAPR >= the largest (k-1)/2 of any Conv1D on the path, and every tensor that
+// feeds a k>1 convolution has its gap rows forced to zero by the kernel that
+// produces it -- so a batched conv sees exactly the zero padding the reference's
+// one-utterance-per-call inference applies, and ragged batches are exact.
+// row_utt[r] = utterance id or -1 (gap), row_pos[r] = position inside the utterance.
+// There are two timelines per call: token rate (encoder, variance adaptor) and
+// frame rate (decoder, postnet); the length regulator maps one onto the other.
+#include <algorithm>
+#include <cmath>
+
+#include "pk_gemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// pe[pos][2i] = sin(pos * div[i]), pe[pos][2i+1] = cos(pos * div[i])   (embedding.py:46-62)
+__global__ void k_build_pe(float* pe, const float* div, int maxlen, int d) {
+    const int pos = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const float ang = (float)pos * div[c >> 1];
+        pe[(long)pos * d + c] = (c & 1) ? cosf(ang) : sinf(ang);
+    }
+}
+
+// x[r] = Emb[tok[r]] * xscale + alpha * PE[pos[r]]   (fastspeech2.py:165-168, embedding.py:111-126;
+// xscale = 1 for ScaledPositionalEncoding).  Gap rows are zeroed.  padding_idx row 0 of the table
+// is zero (set at finalize).
+__global__ void k_embed(const int* __restrict__ tok, const int* __restrict__ row_utt,
+                        const int* __restrict__ row_pos, const float* __restrict__ table,
+                        const float* __restrict__ pe, float alpha, float xscale, int d,
+                        float* __restrict__ x) {
+    const int r = blockIdx.x;
+    const bool valid = row_utt[r] >= 0;
+    const float* e = table + (long)(valid ? tok[r] : 0) * d;
+    const float* p = pe + (long)(valid ? row_pos[r] : 0) * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x)
+        x[(long)r * d + c] = valid ? (e[c] * xscale + alpha * p[c]) : 0.f;
+}
+
+// LayerNorm over the channel axis, one wave per row (nn.LayerNorm, eps 1e-5; also
+// LayerNorm(dim=1) of the predictors, which is the same thing in channels-last).
+// Gap rows -> 0.
+constexpr int LN_MAXPER = 8;
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ g,
+                                                   const float* __restrict__ b, const int* __restrict__ row_utt,
+                                                   int rows, int C, float eps, float* __restrict__ y) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int nper = C >> 6;
+    float* yo = y + (long)r * C;
+    if (row_utt[r] < 0) {
+#pragma unroll
+        for (int e = 0; e < LN_MAXPER; ++e)
+            if (e < nper) yo[lane + 64 * e] = 0.f;
+        return;
+    }
+    const float* xi = x + (long)r * C;
+    float v[LN_MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < LN_MAXPER; ++e)
+        if (e < nper) {
+            v[e] = xi[lane + 64 * e];
+            s += v[e];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < LN_MAXPER; ++e)
+        if (e < nper) {
+            const float dlt = v[e] - mean;
+            q += dlt * dlt;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float inv = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int e = 0; e < LN_MAXPER; ++e)
+        if (e < nper) {
+            const int c = lane + 64 * e;
+            yo[c] = (v[e] - mean) * inv * g[c] + b[c];
+        }
+}
+
+// Multi-head self-attention for one (utterance, head, 32-query tile) per wave
+// (attention.py:133-156 + forward_attention :88-131).  qkv rows are [q | k | v], each
+// heads*DK wide.  Flash-style: scores never leave registers.
+//   S^T[key][q]  = K . Q^T      (A = K rows, B = Q rows; the d axis is split so that a
+//                                lane reads contiguous floats: d = hi*DK/2 + ks)
+//   online softmax over keys (keys live in accumulator registers, queries in lanes)
+//   O[q][dv]    += P[q][key] . V[key][dv]   (A = P, taken straight from the S registers
+//                                thanks to a K-order permutation; B = V rows, coalesced)
+// Keys >= len get -inf (== masked_fill(min) -> softmax -> masked_fill(0) of the
+// reference); the decoder passes no mask (fastspeech2.py:452-455) and attends to its
+// whole utterance.
+struct AttnArgs {
+    const float* qkv;
+    int ld;
+    float* out;
+    int ldo;
+    const int* seg_start;
+    const int* seg_len;
+    int D;      // heads * DK
+    float scale;
+};
+
+template <int DK>
+__global__ __launch_bounds__(256, 1) void k_attention(AttnArgs a) {
+    constexpr int KH = DK / 2;   // k-steps of the QK^T product
+    constexpr int DT = DK / 32;  // 32-wide tiles of the value dimension
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = a.seg_len[b], start = a.seg_start[b];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= len) return;
+    const int j = lane & 31, hi = lane >> 5;
+    const long ld = a.ld;
+    const float* base = a.qkv + (long)start * ld + h * DK;
+
+    float qf[KH];
+    {
+        const int qr = min(q0 + j, len - 1);
+        const float* qp = base + (long)qr * ld + hi * KH;
+#pragma unroll
+        for (int c = 0; c < KH / 4; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qp + 4 * c);
+            qf[4 * c] = v[0];
+            qf[4 * c + 1] = v[1];
+            qf[4 * c + 2] = v[2];
+            qf[4 * c + 3] = v[3];
+        }
+    }
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < len; k0 += 32) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        {
+            const int kr = min(k0 + j, len - 1);
+            const float* kp = base + a.D + (long)kr * ld + hi * KH;
+#pragma unroll
+            for (int c = 0; c < KH / 4; ++c) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[e], qf[4 * c + e], S, 0, 0, 0);
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + mfma_row(r, hi);
+            S[r] = (key < len) ? S[r] * a.scale : -INFINITY;
+            mloc = fmaxf(mloc, S[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = expf(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[r] = expf(S[r] - m_new);
+            lsum += S[r];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ar = __shfl(alpha, mfma_row(r, hi));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt][r] *= ar;
+        }
+        const float* vp = base + 2 * a.D + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int vr = min(k0 + mfma_row(r, hi), len - 1);
+            const float* vrow = vp + (long)vr * ld;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[r], vrow[32 * dt], O[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + mfma_row(r, hi);
+        const float lr = __shfl(l_run, mfma_row(r, hi));
+        if (q < len) {
+            float* o = a.out + (long)(start + q) * a.ldo + h * DK + j;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] / lr;
+        }
+    }
+}
+
+// Predictor heads: Linear(C -> 1) per row (+ masked_fill) and, for the duration
+// predictor in inference, clip(round(exp(x) - offset), min=0) and the alpha speed
+// scaling round(d * alpha)  (duration_predictor.py:95-103, length_regulator.py:85-88;
+// paddle.round = half away from zero).
+__device__ __forceinline__ float round_half_away(float x) { return copysignf(floorf(fabsf(x) + 0.5f), x); }
+
+__global__ __launch_bounds__(256) void k_rowdot(const float* __restrict__ h, int C, const float* __restrict__ w,
+                                                float bias, const int* __restrict__ row_utt, int rows,
+                                                int duration_mode, float offset, float alpha,
+                                                float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    if (row_utt[r] < 0) {
+        if (lane == 0) out[r] = 0.f;
+        return;
+    }
+    const float* x = h + (long)r * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(x[c], w[c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s += bias;
+    if (duration_mode) {
+        s = fmaxf(round_half_away(expf(s) - offset), 0.f);
+        if (alpha != 1.0f) s = round_half_away(s * alpha);
+    }
+    if (lane == 0) out[r] = s;
+}
+
+// Inclusive prefix sum of the integer durations of each utterance; frames[b] = total.
+__global__ __launch_bounds__(256) void k_cumsum(const float* __restrict__ dur, const int* __restrict__ seg_start,
+                                                const int* __restrict__ seg_len, int* __restrict__ cum,
+                                                int* __restrict__ frames) {
+    __shared__ int sh[256];
+    const int b = blockIdx.x, start = seg_start[b], len = seg_len[b];
+    int carry = 0;
+    for (int base = 0; base < len; base += 256) {
+        const int t = base + threadIdx.x;
+        int v = (t < len) ? (int)dur[start + t] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int add = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (t < len) cum[start + t] = carry + sh[threadIdx.x];
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) frames[b] = carry;
+}
+
+// Length regulator + variance embeddings + decoder positional encoding, fused:
+//   hs2  = hs + (e * w_e + b_e) + (p * w_p + b_p)            fastspeech2.py:426-430 (k=1 convs)
+//   up[l] = hs2[token(l)]                                    length_regulator.py:46-66 (row repeat)
+//   x[l]  = up[l] * xscale + alpha_dec * PE[l]               decoder embed, fastspeech2.py:250-266
+// token(l) = first t with cum[t] > l (binary search in the utterance's prefix sums).
+__global__ __launch_bounds__(128) void k_regulate(
+    const float* __restrict__ hs, const float* __restrict__ p_out, const float* __restrict__ e_out,
+    const float* __restrict__ wp, const float* __restrict__ bp, const float* __restrict__ we,
+    const float* __restrict__ be, const int* __restrict__ cum, const int* __restrict__ tseg_start,
+    const int* __restrict__ tseg_len, const int* __restrict__ frow_utt, const int* __restrict__ frow_pos,
+    const float* __restrict__ pe, float alpha_dec, float xscale, int d, float* __restrict__ x,
+    float* __restrict__ hs_up_dbg) {
+    const int r = blockIdx.x;
+    const int b = frow_utt[r];
+    float* xo = x + (long)r * d;
+    if (b < 0) {
+        for (int c = threadIdx.x; c < d; c += blockDim.x) xo[c] = 0.f;
+        return;
+    }
+    const int l = frow_pos[r];
+    const int* cu = cum + tseg_start[b];
+    int lo = 0, hi = tseg_len[b] - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] > l) hi = mid; else lo = mid + 1;
+    }
+    const int tr = tseg_start[b] + lo;
+    const float pv = p_out[tr], ev = e_out[tr];
+    const float* src = hs + (long)tr * d;
+    const float* pp = pe + (long)l * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const float e_emb = fmaf(ev, we[c], be[c]);
+        const float p_emb = fmaf(pv, wp[c], bp[c]);
+        const float up = (src[c] + e_emb) + p_emb;
+        if (hs_up_dbg) hs_up_dbg[(long)r * d + c] = up;
+        xo[c] = up * xscale + alpha_dec * pp[c];
+    }
+}
+
+}  // namespace
+
+// ================================================================== host side
+struct Dense {
+    size_t w = 0, b = 0;   // offsets (floats) into the weight arena; b == SIZE_MAX: no bias
+    int Cin = 0, N = 0, taps = 1, pad = 0;
+};
+
+struct FftLayer {
+    size_t ln1_g, ln1_b, ln2_g, ln2_b;
+    Dense qkv, out, ffn1, ffn2;
+};
+
+struct Predictor {
+    std::vector<Dense> conv;
+    std::vector<size_t> ln_g, ln_b;
+    size_t lin_w;
+    float lin_b;
+    int chans;
+};
+
+struct Timeline {
+    int B = 0, rows = 0;
+    std::vector<int> seg_start, seg_len, row_utt, row_pos;
+    pk_dbuf d_tab;  // [seg_start B][seg_len B][row_utt rows_alloc][row_pos rows_alloc]
+    const int* d_seg_start() const { return d_tab.as<int>(); }
+    const int* d_seg_len() const { return d_tab.as<int>() + B; }
+    const int* d_row_utt() const { return d_tab.as<int>() + 2 * B; }
+    const int* d_row_pos() const { return d_tab.as<int>() + 2 * B + rows_alloc; }
+    int rows_alloc = 0;
+    void release() { d_tab.release(); }
+};
+
+struct pk_fs2 {
+    pk_ctx* ctx = nullptr;
+    pk_fs2_cfg cfg;
+    pk_param_map params;
+    bool finalized = false;
+    int gapr = 2;
+    int max_len = 0;
+    // weights
+    std::vector<float> arena_h;
+    pk_dbuf arena;
+    size_t emb_table = 0, enc_after_g = 0, enc_after_b = 0, dec_after_g = 0, dec_after_b = 0;
+    float alpha_enc = 1.f, alpha_dec = 1.f, xscale = 1.f;
+    std::vector<FftLayer> enc, dec;
+    Predictor dur, pitch, energy;
+    size_t pitch_w = 0, pitch_b = 0, energy_w = 0, energy_b = 0;
+    Dense feat_out;
+    std::vector<Dense> postnet;
+    size_t out_scale = 0, out_shift = 0;
+    bool has_out_affine = false;
+    std::vector<float> h_out_scale, h_out_shift;
+    pk_dbuf d_pe, d_div;
+    // per-call state
+    Timeline tl_tok, tl_frm;
+    pk_dbuf d_tok, d_x, d_h, d_qkv, d_ctx, d_f, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
+        d_before, d_q1, d_q2, d_rowmap, d_dbg_up, d_zs, d_mel_stage;
+    std::vector<int> frames;   // per utterance, result of encode
+    bool encoded = false;
+    bool debug = false;
+
+    const float* W(size_t off) const { return arena.as<float>() + off; }
+};
+
+static const int LEAD = 8;  // rows of margin in front of every activation buffer
+
+static int act_reserve(pk_dbuf& buf, int rows, int C) {
+    const size_t r = (size_t)((rows + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM + 2 * LEAD;
+    return buf.reserve(r * C * sizeof(float));
+}
+static float* act_ptr(const pk_dbuf& buf, int C) { return buf.as<float>() + (size_t)LEAD * C; }
+
+static int build_timeline(pk_ctx* ctx, Timeline& tl, const int* lens, int B, int gapr) {
+    tl.B = B;
+    tl.seg_start.resize(B);
+    tl.seg_len.assign(lens, lens + B);
+    int r = gapr;
+    for (int b = 0; b < B; ++b) {
+        tl.seg_start[b] = r;
+        r += lens[b] + gapr;
+    }
+    tl.rows = r;
+    tl.rows_alloc = ((r + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM;
+    tl.row_utt.assign(tl.rows_alloc, -1);
+    tl.row_pos.assign(tl.rows_alloc, 0);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < lens[b]; ++t) {
+            tl.row_utt[tl.seg_start[b] + t] = b;
+            tl.row_pos[tl.seg_start[b] + t] = t;
+        }
+    std::vector<int> tab;
+    tab.insert(tab.end(), tl.seg_start.begin(), tl.seg_start.end());
+    tab.insert(tab.end(), tl.seg_len.begin(), tl.seg_len.end());
+    tab.insert(tab.end(), tl.row_utt.begin(), tl.row_utt.end());
+    tab.insert(tab.end(), tl.row_pos.begin(), tl.row_pos.end());
+    return pk_upload(ctx, tl.d_tab, tab.data(), tab.size() * sizeof(int));
+}
+
+extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
+    if (!ctx || !cfg || !out) PK_FAIL(PK_EINVAL, "pk_fs2_create: NULL argument");
+    *out = nullptr;
+    const pk_fs2_cfg& c = *cfg;
+    if (c.idim <= 0 || c.odim <= 0 || c.adim <= 0 || c.aheads <= 0)
+        PK_FAIL(PK_EINVAL, "FastSpeech2: idim/odim/adim/aheads must be positive");
+    if (c.adim % c.aheads != 0) PK_FAIL(PK_ESHAPE, "FastSpeech2: adim %% aheads != 0 (attention.py:40)");
+    const int dk = c.adim / c.aheads;
+    if (dk != 64 && dk != 96 && dk != 128 && dk != 192)
+        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: head size %d not built (64/96/128/192)", dk);
+    if (c.adim % 64 != 0 || c.adim > 64 * LN_MAXPER)
+        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: adim must be a multiple of 64, <= %d", 64 * LN_MAXPER);
+    if (c.reduction_factor != 1) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: reduction_factor != 1 not implemented");
+    if (c.pitch_embed_kernel_size != 1 || c.energy_embed_kernel_size != 1)
+        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: pitch/energy_embed_kernel_size must be 1 (all reference recipes)");
+    if (!c.encoder_normalize_before || !c.decoder_normalize_before)
+        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: post-norm blocks not implemented");
+    if (c.has_spk_embed || c.has_tone_embed)
+        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: speaker / tone embedding not implemented");
+    if (c.postnet_layers > 0 && !c.use_batch_norm)
+        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: postnet without batch norm not implemented");
+    const int ks[] = {c.positionwise_conv_kernel_size, c.duration_predictor_kernel_size,
+                      c.pitch_predictor_kernel_size, c.energy_predictor_kernel_size,
+                      c.postnet_layers > 0 ? c.postnet_filts : 1};
+    int gapr = 1;
+    for (int k : ks) {
+        if (k < 1 || k % 2 == 0 || k > 15) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: conv kernel size %d unsupported", k);
+        gapr = std::max(gapr, (k - 1) / 2);
+    }
+    const int chans[] = {c.adim, c.eunits, c.dunits, c.duration_predictor_chans, c.pitch_predictor_chans,
+                         c.energy_predictor_chans, c.postnet_layers > 0 ? c.postnet_chans : 16, c.odim};
+    for (int ch : chans)
+        if (ch % PK_GEMM_BK != 0) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: channel count %d not a multiple of 16", ch);
+    const int pch[] = {c.duration_predictor_chans, c.pitch_predictor_chans, c.energy_predictor_chans};
+    for (int ch : pch)
+        if (ch % 64 != 0 || ch > 64 * LN_MAXPER)
+            PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: predictor channels must be a multiple of 64, <= %d", 64 * LN_MAXPER);
+    pk_fs2* h = new pk_fs2();
+    h->ctx = ctx;
+    h->cfg = c;
+    h->gapr = gapr;
+    if (gapr > LEAD) { delete h; PK_FAIL(PK_EUNSUPPORTED, "conv kernel too wide"); }
+    *out = h;
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_set_param(pk_fs2* h, const char* name, const float* data, const int64_t* shape,
+                                int32_t ndim) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_set_param: handle is NULL");
+    h->finalized = false;
+    return pk_store_param(h->params, name, data, shape, ndim);
+}
+
+extern "C" int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* sigma, int32_t n) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_set_normalizer: handle is NULL");
+    if (!mu && !sigma) {
+        h->has_out_affine = false;
+    } else {
+        if (!mu || !sigma || n != h->cfg.odim) PK_FAIL(PK_ESHAPE, "normalizer needs mu and sigma of odim elements");
+        h->h_out_scale.assign(sigma, sigma + n);
+        h->h_out_shift.assign(mu, mu + n);
+        h->has_out_affine = true;
+    }
+    h->finalized = false;
+    return PK_OK;
+}
+
+namespace {
+struct Arena {
+    std::vector<float>& v;
+    size_t put(const std::vector<float>& x) {
+        size_t o = (v.size() + 3) & ~(size_t)3;  // 16-byte alignment
+        v.resize(o);
+        v.insert(v.end(), x.begin(), x.end());
+        return o;
+    }
+};
+
+int add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<float>* bias, int Cin, int taps,
+                 int N, Dense& d) {
+    std::vector<float> packed;
+    pk_gemm_pack(kn.data(), Cin * taps, N, packed);
+    d.w = ar.put(packed);
+    d.b = bias ? ar.put(*bias) : (size_t)-1;
+    d.Cin = Cin;
+    d.N = N;
+    d.taps = taps;
+    d.pad = (taps - 1) / 2;
+    return PK_OK;
+}
+
+int add_conv(Arena& ar, const pk_param_map& P, const std::string& base, int Cout, int Cin, int k, bool bias,
+             Dense& d) {
+    std::vector<float> w, kn, b;
+    PK_TRY(pk_get_weight(P, base, {Cout, Cin, k}, w));
+    pk_conv_to_kn(w.data(), Cout, Cin, k, kn);
+    if (bias) PK_TRY(pk_get_vector(P, base + ".bias", Cout, b));
+    return add_dense_kn(ar, kn, bias ? &b : nullptr, Cin, k, Cout, d);
+}
+
+int add_vec(Arena& ar, const pk_param_map& P, const std::string& name, int n, size_t& off) {
+    std::vector<float> v;
+    PK_TRY(pk_get_vector(P, name, n, v));
+    off = ar.put(v);
+    return PK_OK;
+}
+
+int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int units,
+                  int k, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b) {
+    out.resize(n_layers);
+    for (int l = 0; l < n_layers; ++l) {
+        const std::string p = prefix + ".encoders." + std::to_string(l);
+        FftLayer& L = out[l];
+        PK_TRY(add_vec(ar, P, p + ".norm1.weight", A, L.ln1_g));
+        PK_TRY(add_vec(ar, P, p + ".norm1.bias", A, L.ln1_b));
+        PK_TRY(add_vec(ar, P, p + ".norm2.weight", A, L.ln2_g));
+        PK_TRY(add_vec(ar, P, p + ".norm2.bias", A, L.ln2_b));
+        // fused q|k|v projection: Linear weights are [in, out] (paddle)
+        std::vector<float> wq, wk, wv, bq, bk, bv, kn((size_t)A * 3 * A), bias(3 * A);
+        PK_TRY(pk_get_weight(P, p + ".self_attn.linear_q", {A, A}, wq));
+        PK_TRY(pk_get_weight(P, p + ".self_attn.linear_k", {A, A}, wk));
+        PK_TRY(pk_get_weight(P, p + ".self_attn.linear_v", {A, A}, wv));
+        PK_TRY(pk_get_vector(P, p + ".self_attn.linear_q.bias", A, bq));
+        PK_TRY(pk_get_vector(P, p + ".self_attn.linear_k.bias", A, bk));
+        PK_TRY(pk_get_vector(P, p + ".self_attn.linear_v.bias", A, bv));
+        for (int i = 0; i < A; ++i)
+            for (int o = 0; o < A; ++o) {
+                kn[(size_t)i * 3 * A + o] = wq[(size_t)i * A + o];
+                kn[(size_t)i * 3 * A + A + o] = wk[(size_t)i * A + o];
+                kn[(size_t)i * 3 * A + 2 * A + o] = wv[(size_t)i * A + o];
+            }
+        for (int o = 0; o < A; ++o) {
+            bias[o] = bq[o];
+            bias[A + o] = bk[o];
+            bias[2 * A + o] = bv[o];
+        }
+        PK_TRY(add_dense_kn(ar, kn, &bias, A, 1, 3 * A, L.qkv));
+        std::vector<float> wo, bo;
+        PK_TRY(pk_get_weight(P, p + ".self_attn.linear_out", {A, A}, wo));
+        PK_TRY(pk_get_vector(P, p + ".self_attn.linear_out.bias", A, bo));
+        PK_TRY(add_dense_kn(ar, wo, &bo, A, 1, A, L.out));
+        PK_TRY(add_conv(ar, P, p + ".feed_forward.w_1", units, A, k, true, L.ffn1));
+        PK_TRY(add_conv(ar, P, p + ".feed_forward.w_2", A, units, k, true, L.ffn2));
+    }
+    PK_TRY(add_vec(ar, P, prefix + ".after_norm.weight", A, after_g));
+    PK_TRY(add_vec(ar, P, prefix + ".after_norm.bias", A, after_b));
+    return PK_OK;
+}
+
+int add_predictor(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int chans,
+                  int k, Predictor& pr) {
+    pr.conv.resize(n_layers);
+    pr.ln_g.resize(n_layers);
+    pr.ln_b.resize(n_layers);
+    pr.chans = chans;
+    for (int j = 0; j < n_layers; ++j) {
+        const std::string p = prefix + ".conv." + std::to_string(j);
+        PK_TRY(add_conv(ar, P, p + ".0", chans, j == 0 ? A : chans, k, true, pr.conv[j]));
+        PK_TRY(add_vec(ar, P, p + ".2.weight", chans, pr.ln_g[j]));
+        PK_TRY(add_vec(ar, P, p + ".2.bias", chans, pr.ln_b[j]));
+    }
+    PK_TRY(add_vec(ar, P, prefix + ".linear.weight", chans, pr.lin_w));
+    std::vector<float> b;
+    PK_TRY(pk_get_vector(P, prefix + ".linear.bias", 1, b));
+    pr.lin_b = b[0];
+    return PK_OK;
+}
+}  // namespace
+
+static int ensure_pe(pk_fs2* h, int need) {
+    if (need <= h->max_len) return PK_OK;
+    pk_ctx* ctx = h->ctx;
+    const int d = h->cfg.adim;
+    int n = std::max(need, 1024);
+    n = std::max(n, h->max_len * 2);
+    if (!h->d_div.p) {
+        // div_term = exp(arange(0, d, 2) * -(log(10000)/d)) in float32 (embedding.py:56-58)
+        std::vector<float> div(d / 2);
+        const float cst = (float)(-(std::log(10000.0) / d));
+        for (int i = 0; i < d / 2; ++i) div[i] = expf((float)(2 * i) * cst);
+        PK_TRY(pk_upload(ctx, h->d_div, div.data(), div.size() * sizeof(float)));
+    }
+    PK_TRY(h->d_pe.reserve((size_t)n * d * sizeof(float)));
+    PK_LAUNCH(ctx, "fs2_build_pe", k_build_pe, dim3(n), dim3(128), 0, h->d_pe.as<float>(), h->d_div.as<float>(), n, d);
+    h->max_len = n;
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_finalize(pk_fs2* h) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_finalize: handle is NULL");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const pk_fs2_cfg& c = h->cfg;
+    const pk_param_map& P = h->params;
+    const int A = c.adim;
+    h->arena_h.clear();
+    Arena ar{h->arena_h};
+    {
+        std::vector<float> t;
+        PK_TRY(pk_get_weight(P, "encoder.embed.0", {c.idim, A}, t));
+        for (int i = 0; i < A; ++i) t[i] = 0.f;  // nn.Embedding(padding_idx=0): id 0 -> zero row
+        h->emb_table = ar.put(t);
+    }
+    std::vector<float> al;
+    if (c.use_scaled_pos_enc) {
+        PK_TRY(pk_get_vector(P, "encoder.embed.1.alpha", 1, al));
+        h->alpha_enc = al[0];
+        PK_TRY(pk_get_vector(P, "decoder.embed.0.alpha", 1, al));
+        h->alpha_dec = al[0];
+        h->xscale = 1.f;
+    } else {
+        h->alpha_enc = h->alpha_dec = 1.f;
+        h->xscale = std::sqrt((float)A);  // PositionalEncoding.forward embedding.py:78
+    }
+    PK_TRY(add_fft_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, h->enc,
+                         h->enc_after_g, h->enc_after_b));
+    PK_TRY(add_fft_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, h->dec,
+                         h->dec_after_g, h->dec_after_b));
+    PK_TRY(add_predictor(ar, P, "duration_predictor", c.duration_predictor_layers, A, c.duration_predictor_chans,
+                         c.duration_predictor_kernel_size, h->dur));
+    PK_TRY(add_predictor(ar, P, "pitch_predictor", c.pitch_predictor_layers, A, c.pitch_predictor_chans,
+                         c.pitch_predictor_kernel_size, h->pitch));
+    PK_TRY(add_predictor(ar, P, "energy_predictor", c.energy_predictor_layers, A, c.energy_predictor_chans,
+                         c.energy_predictor_kernel_size, h->energy));
+    PK_TRY(add_vec(ar, P, "pitch_embed.0.weight", A, h->pitch_w));
+    PK_TRY(add_vec(ar, P, "pitch_embed.0.bias", A, h->pitch_b));
+    PK_TRY(add_vec(ar, P, "energy_embed.0.weight", A, h->energy_w));
+    PK_TRY(add_vec(ar, P, "energy_embed.0.bias", A, h->energy_b));
+    {
+        std::vector<float> w, b;
+        PK_TRY(pk_get_weight(P, "feat_out", {A, c.odim}, w));
+        PK_TRY(pk_get_vector(P, "feat_out.bias", c.odim, b));
+        PK_TRY(add_dense_kn(ar, w, &b, A, 1, c.odim, h->feat_out));
+    }
+    h->postnet.resize(c.postnet_layers);
+    for (int j = 0; j < c.postnet_layers; ++j) {
+        const int cin = j == 0 ? c.odim : c.postnet_chans;
+        const int cout = j == c.postnet_layers - 1 ? c.odim : c.postnet_chans;
+        const std::string p = "postnet.postnet." + std::to_string(j);
+        std::vector<float> w, g, b, mean, var, kn, bias(cout);
+        PK_TRY(pk_get_weight(P, p + ".0", {cout, cin, c.postnet_filts}, w));
+        PK_TRY(pk_get_vector(P, p + ".1.weight", cout, g));
+        PK_TRY(pk_get_vector(P, p + ".1.bias", cout, b));
+        PK_TRY(pk_get_vector(P, p + ".1._mean", cout, mean));
+        PK_TRY(pk_get_vector(P, p + ".1._variance", cout, var));
+        // fold BatchNorm1D (eval, eps 1e-5) into the bias-free conv (tacotron2/decoder.py:133-147)
+        const size_t per = (size_t)cin * c.postnet_filts;
+        for (int o = 0; o < cout; ++o) {
+            const double s = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+            for (size_t i = 0; i < per; ++i) w[o * per + i] = (float)((double)w[o * per + i] * s);
+            bias[o] = (float)((double)b[o] - (double)mean[o] * s);
+        }
+        pk_conv_to_kn(w.data(), cout, cin, c.postnet_filts, kn);
+        PK_TRY(add_dense_kn(ar, kn, &bias, cin, c.postnet_filts, cout, h->postnet[j]));
+    }
+    if (h->has_out_affine) {
+        h->out_scale = ar.put(h->h_out_scale);
+        h->out_shift = ar.put(h->h_out_shift);
+    }
+    PK_TRY(pk_upload(ctx, h->arena, h->arena_h.data(), h->arena_h.size() * sizeof(float)));
+    h->arena_h.clear();
+    h->arena_h.shrink_to_fit();
+    PK_TRY(ensure_pe(h, 1024));
+    h->finalized = true;
+    h->encoded = false;
+    return PK_OK;
+}
+
+static int run_dense(pk_fs2* h, const char* name, const Dense& d, const float* A, int lda, float* C, int ldc,
+                     int rows, int act, const float* res, int ldr, const int* rowvalid) {
+    pk_gemm_args g;
+    g.A = A;
+    g.lda = lda;
+    g.Wp = h->W(d.w);
+    g.bias = d.b == (size_t)-1 ? nullptr : h->W(d.b);
+    g.res = res;
+    g.ldr = ldr;
+    g.C = C;
+    g.ldc = ldc;
+    g.rowvalid = rowvalid;
+    g.M = rows;
+    g.N = d.N;
+    g.Cin = d.Cin;
+    g.taps = d.taps;
+    g.pad = d.pad;
+    g.act = act;
+    return pk_gemm_launch(h->ctx, name, g);
+}
+
+static int run_layernorm(pk_fs2* h, const float* x, size_t g, size_t b, const Timeline& tl, int C, float* y) {
+    PK_LAUNCH(h->ctx, "fs2_layernorm", k_layernorm, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, x, h->W(g), h->W(b),
+              tl.d_row_utt(), tl.rows, C, 1e-5f, y);
+    return PK_OK;
+}
+
+static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float* out) {
+    const int A = h->cfg.adim, heads = h->cfg.aheads, dk = A / heads;
+    int maxlen = 0;
+    for (int l : tl.seg_len) maxlen = std::max(maxlen, l);
+    AttnArgs a;
+    a.qkv = qkv;
+    a.ld = 3 * A;
+    a.out = out;
+    a.ldo = A;
+    a.seg_start = tl.d_seg_start();
+    a.seg_len = tl.d_seg_len();
+    a.D = A;
+    a.scale = (float)(1.0 / std::sqrt((double)dk));
+    dim3 grid(pk_div_up(maxlen, 128), heads, tl.B);
+    switch (dk) {
+        case 64: PK_LAUNCH(h->ctx, "fs2_attention", k_attention<64>, grid, dim3(256), 0, a); break;
+        case 96: PK_LAUNCH(h->ctx, "fs2_attention", k_attention<96>, grid, dim3(256), 0, a); break;
+        case 128: PK_LAUNCH(h->ctx, "fs2_attention", k_attention<128>, grid, dim3(256), 0, a); break;
+        case 192: PK_LAUNCH(h->ctx, "fs2_attention", k_attention<192>, grid, dim3(256), 0, a); break;
+        default: PK_FAIL(PK_EUNSUPPORTED, "attention head size %d", dk);
+    }
+    return PK_OK;
+}
+
+// N FFT blocks + after_norm on the timeline tl; x is updated in place, result in hs.
+static int run_fft_stack(pk_fs2* h, const std::vector<FftLayer>& layers, size_t after_g, size_t after_b,
+                         const Timeline& tl, int units, float* hs_out) {
+    const int A = h->cfg.adim;
+    PK_TRY(act_reserve(h->d_h, tl.rows, A));
+    PK_TRY(act_reserve(h->d_qkv, tl.rows, 3 * A));
+    PK_TRY(act_reserve(h->d_ctx, tl.rows, A));
+    PK_TRY(act_reserve(h->d_f, tl.rows, units));
+    float* x = act_ptr(h->d_x, A);
+    float* hh = act_ptr(h->d_h, A);
+    float* qkv = act_ptr(h->d_qkv, 3 * A);
+    float* ctxb = act_ptr(h->d_ctx, A);
+    float* f = act_ptr(h->d_f, units);
+    const int* rv = tl.d_row_utt();
+    for (const FftLayer& L : layers) {
+        PK_TRY(run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh));
+        PK_TRY(run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));
+        PK_TRY(run_attention(h, tl, qkv, ctxb));
+        PK_TRY(run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
+        PK_TRY(run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh));
+        PK_TRY(run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv));
+        PK_TRY(run_dense(h, "fs2_conv_ffn2", L.ffn2, f, units, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
+    }
+    PK_TRY(run_layernorm(h, x, after_g, after_b, tl, A, hs_out));
+    return PK_OK;
+}
+
+static int run_predictor(pk_fs2* h, const Predictor& pr, const Timeline& tl, const float* hs, int duration_mode,
+                         float alpha, float* out) {
+    const int A = h->cfg.adim;
+    PK_TRY(act_reserve(h->d_p1, tl.rows, pr.chans));
+    PK_TRY(act_reserve(h->d_p2, tl.rows, pr.chans));
+    float* p1 = act_ptr(h->d_p1, pr.chans);
+    float* p2 = act_ptr(h->d_p2, pr.chans);
+    const float* in = hs;
+    int ldin = A;
+    for (size_t j = 0; j < pr.conv.size(); ++j) {
+        PK_TRY(run_dense(h, "fs2_conv_predictor", pr.conv[j], in, ldin, p1, pr.chans, tl.rows, PK_ACT_RELU, nullptr, 0,
+                         nullptr));
+        PK_TRY(run_layernorm(h, p1, pr.ln_g[j], pr.ln_b[j], tl, pr.chans, p2));
+        in = p2;
+        ldin = pr.chans;
+    }
+    PK_LAUNCH(h->ctx, "fs2_rowdot", k_rowdot, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, in, ldin, h->W(pr.lin_w),
+              pr.lin_b, tl.d_row_utt(), tl.rows, duration_mode, 1.0f, alpha, out);
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_lens, int32_t B, float alpha,
+                             int32_t* out_frames) {
+    if (!h || !ids || !tok_lens || !out_frames) PK_FAIL(PK_EINVAL, "pk_fs2_encode: NULL argument");
+    if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_fs2_encode: call pk_fs2_finalize first");
+    if (B <= 0) PK_FAIL(PK_EINVAL, "pk_fs2_encode: batch size must be positive");
+    if (!(alpha > 0.f)) PK_FAIL(PK_ESHAPE, "LengthRegulator: alpha must be > 0 (length_regulator.py:86)");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const pk_fs2_cfg& c = h->cfg;
+    const int A = c.adim;
+    int maxT = 0;
+    long sumT = 0;
+    for (int b = 0; b < B; ++b) {
+        if (tok_lens[b] <= 0) PK_FAIL(PK_EINVAL, "pk_fs2_encode: utterance %d has %d tokens", b, tok_lens[b]);
+        maxT = std::max(maxT, tok_lens[b]);
+        sumT += tok_lens[b];
+    }
+    h->encoded = false;
+    PK_TRY(build_timeline(ctx, h->tl_tok, tok_lens, B, h->gapr));
+    Timeline& tl = h->tl_tok;
+    PK_TRY(ensure_pe(h, maxT));
+    // token ids on the row timeline
+    {
+        std::vector<int> tok(tl.rows_alloc, 0);
+        long o = 0;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < tok_lens[b]; ++t, ++o) {
+                const int64_t id = ids[o];
+                if (id < 0 || id >= c.idim) PK_FAIL(PK_EINVAL, "pk_fs2_encode: token id %lld out of [0,%d)", (long long)id, c.idim);
+                tok[tl.seg_start[b] + t] = (int)id;
+            }
+        PK_TRY(pk_upload(ctx, h->d_tok, tok.data(), tok.size() * sizeof(int)));
+    }
+    PK_TRY(act_reserve(h->d_x, tl.rows, A));
+    PK_TRY(act_reserve(h->d_hs, tl.rows, A));
+    float* x = act_ptr(h->d_x, A);
+    float* hs = act_ptr(h->d_hs, A);
+    PK_LAUNCH(ctx, "fs2_embed", k_embed, dim3(tl.rows), dim3(128), 0, h->d_tok.as<int>(), tl.d_row_utt(),
+              tl.d_row_pos(), h->W(h->emb_table), h->d_pe.as<float>(), h->alpha_enc, h->xscale, A, x);
+    PK_TRY(run_fft_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    // variance adaptor
+    PK_TRY(h->d_pout.reserve((size_t)tl.rows_alloc * 4));
+    PK_TRY(h->d_eout.reserve((size_t)tl.rows_alloc * 4));
+    PK_TRY(h->d_dout.reserve((size_t)tl.rows_alloc * 4));
+    PK_TRY(h->d_cum.reserve((size_t)tl.rows_alloc * 4));
+    PK_TRY(h->d_frames.reserve((size_t)B * 4));
+    PK_TRY(run_predictor(h, h->pitch, tl, hs, 0, 1.f, h->d_pout.as<float>()));
+    PK_TRY(run_predictor(h, h->energy, tl, hs, 0, 1.f, h->d_eout.as<float>()));
+    PK_TRY(run_predictor(h, h->dur, tl, hs, 1, alpha, h->d_dout.as<float>()));
+    PK_LAUNCH(ctx, "fs2_cumsum", k_cumsum, dim3(B), dim3(256), 0, h->d_dout.as<float>(), tl.d_seg_start(),
+              tl.d_seg_len(), h->d_cum.as<int>(), h->d_frames.as<int>());
+    h->frames.resize(B);
+    PK_HIP(hipMemcpyAsync(h->frames.data(), h->d_frames.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b) out_frames[b] = h->frames[b];
+    h->encoded = true;
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
+    if (!h || !mel_out) PK_FAIL(PK_EINVAL, "pk_fs2_decode: NULL argument");
+    if (!h->encoded) PK_FAIL(PK_ESTATE, "pk_fs2_decode: call pk_fs2_encode first");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const pk_fs2_cfg& c = h->cfg;
+    const int A = c.adim, B = h->tl_tok.B;
+    // frame timeline; utterances with 0 frames get an empty segment
+    std::vector<int> lens(h->frames);
+    int maxL = 0;
+    long sumL = 0;
+    for (int b = 0; b < B; ++b) {
+        maxL = std::max(maxL, lens[b]);
+        sumL += lens[b];
+    }
+    if (sumL == 0) return PK_OK;
+    PK_TRY(build_timeline(ctx, h->tl_frm, lens.data(), B, h->gapr));
+    Timeline& tl = h->tl_frm;
+    PK_TRY(ensure_pe(h, maxL));
+    // packed output row of each timeline row
+    {
+        std::vector<int> rowmap(tl.rows_alloc, -1);
+        int o = 0;
+        for (int b = 0; b < B; ++b)
+            for (int l = 0; l < lens[b]; ++l) rowmap[tl.seg_start[b] + l] = o++;
+        PK_TRY(pk_upload(ctx, h->d_rowmap, rowmap.data(), rowmap.size() * sizeof(int)));
+    }
+    // d_hs keeps the encoder output (token rate) until k_regulate has consumed it; d_x was the
+    // encoder's residual stream and is free for the decoder.
+    PK_TRY(act_reserve(h->d_x, tl.rows, A));
+    float* x = act_ptr(h->d_x, A);
+    const float* hs_tok = act_ptr(h->d_hs, A);
+    float* up_dbg = nullptr;
+    if (h->debug) {
+        PK_TRY(act_reserve(h->d_dbg_up, tl.rows, A));
+        up_dbg = act_ptr(h->d_dbg_up, A);
+    }
+    PK_LAUNCH(ctx, "fs2_regulate", k_regulate, dim3(tl.rows), dim3(128), 0, hs_tok, h->d_pout.as<float>(),
+              h->d_eout.as<float>(), h->W(h->pitch_w), h->W(h->pitch_b), h->W(h->energy_w), h->W(h->energy_b),
+              h->d_cum.as<int>(), h->tl_tok.d_seg_start(), h->tl_tok.d_seg_len(), tl.d_row_utt(), tl.d_row_pos(),
+              h->d_pe.as<float>(), h->alpha_dec, h->xscale, A, x, up_dbg);
+    PK_TRY(act_reserve(h->d_zs, tl.rows, A));
+    float* zs = act_ptr(h->d_zs, A);
+    PK_TRY(run_fft_stack(h, h->dec, h->dec_after_g, h->dec_after_b, tl, c.dunits, zs));
+    // feat_out (+ row mask: the postnet convolves over it)
+    PK_TRY(act_reserve(h->d_before, tl.rows, c.odim));
+    float* before = act_ptr(h->d_before, c.odim);
+    float* d_out = mel_out;
+    if (flags & PK_HOST_IO) {
+        PK_TRY(h->d_mel_stage.reserve((size_t)sumL * c.odim * 4));
+        d_out = h->d_mel_stage.as<float>();
+    }
+    const float* cs = h->has_out_affine ? h->W(h->out_scale) : nullptr;
+    const float* ch = h->has_out_affine ? h->W(h->out_shift) : nullptr;
+    if (c.postnet_layers == 0) {
+        pk_gemm_args g;
+        g.A = zs; g.lda = A; g.Wp = h->W(h->feat_out.w); g.bias = h->W(h->feat_out.b);
+        g.C = d_out; g.ldc = c.odim; g.rowvalid = tl.d_row_utt(); g.cscale = cs; g.cshift = ch;
+        g.out_rowmap = h->d_rowmap.as<int>(); g.M = tl.rows; g.N = c.odim; g.Cin = A; g.taps = 1; g.pad = 0;
+        PK_TRY(pk_gemm_launch(ctx, "fs2_gemm_feat_out", g));
+    } else {
+        PK_TRY(run_dense(h, "fs2_gemm_feat_out", h->feat_out, zs, A, before, c.odim, tl.rows, PK_ACT_NONE, nullptr, 0,
+                         tl.d_row_utt()));
+        PK_TRY(act_reserve(h->d_q1, tl.rows, c.postnet_chans));
+        PK_TRY(act_reserve(h->d_q2, tl.rows, c.postnet_chans));
+        const float* in = before;
+        int ldin = c.odim;
+        for (int j = 0; j < c.postnet_layers; ++j) {
+            const Dense& d = h->postnet[j];
+            const bool last = j == c.postnet_layers - 1;
+            float* outb = act_ptr((j & 1) ? h->d_q2 : h->d_q1, c.postnet_chans);
+            pk_gemm_args g;
+            g.A = in; g.lda = ldin; g.Wp = h->W(d.w); g.bias = h->W(d.b);
+            g.M = tl.rows; g.N = d.N; g.Cin = d.Cin; g.taps = d.taps; g.pad = d.pad;
+            g.rowvalid = tl.d_row_utt();
+            if (!last) {
+                g.C = outb; g.ldc = c.postnet_chans; g.act = PK_ACT_TANH;
+            } else {
+                // after = before + postnet(before)  (:463-464), then ZScore.inverse (FastSpeech2Inference :670)
+                g.C = d_out; g.ldc = c.odim; g.act = PK_ACT_NONE; g.res = before; g.ldr = c.odim;
+                g.cscale = cs; g.cshift = ch; g.out_rowmap = h->d_rowmap.as<int>();
+            }
+            PK_TRY(pk_gemm_launch(ctx, "fs2_conv_postnet", g));
+            in = outb;
+            ldin = c.postnet_chans;
+        }
+    }
+    if (flags & PK_HOST_IO) {
+        PK_HIP(hipMemcpyAsync(mel_out, d_out, (size_t)sumL * c.odim * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_set_debug(pk_fs2* h, int32_t on) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_set_debug: handle is NULL");
+    h->debug = on != 0;
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_debug_read(pk_fs2* h, int32_t what, int32_t b, float* host_out, int64_t n_floats) {
+    if (!h || !host_out) PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: NULL argument");
+    if (!h->encoded) PK_FAIL(PK_ESTATE, "pk_fs2_debug_read: nothing has run");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const int A = h->cfg.adim;
+    const Timeline* tl = &h->tl_tok;
+    const float* src = nullptr;
+    int C = A;
+    switch (what) {
+        case 0: src = act_ptr(h->d_hs, A); break;                           // encoder output hs (T, adim)
+        case 1: src = h->d_pout.as<float>(); C = 1; break;                  // pitch (T,)
+        case 2: src = h->d_eout.as<float>(); C = 1; break;                  // energy (T,)
+        case 3: src = h->d_dout.as<float>(); C = 1; break;                  // durations (T,)
+        case 4: tl = &h->tl_frm; src = act_ptr(h->d_dbg_up, A); break;      // length-regulated hs (L, adim)
+        case 5: tl = &h->tl_frm; src = act_ptr(h->d_zs, A); break;      // decoder output zs (L, adim)
+        case 6: tl = &h->tl_frm; src = act_ptr(h->d_before, h->cfg.odim); C = h->cfg.odim; break;  // before_outs
+        default: PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: unknown tap %d", what);
+    }
+    if (b < 0 || b >= tl->B) PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: utterance out of range");
+    if (what == 4 && !h->debug) PK_FAIL(PK_ESTATE, "pk_fs2_debug_read: tap 4 needs pk_fs2_set_debug(1) before decode");
+    const long n = (long)tl->seg_len[b] * C;
+    if (n_floats != n) PK_FAIL(PK_ESHAPE, "pk_fs2_debug_read: expected %ld floats, got %lld", n, (long long)n_floats);
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    if (n > 0)
+        PK_HIP(hipMemcpy(host_out, src + (long)tl->seg_start[b] * C, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PK_OK;
+}
+
+extern "C" void pk_fs2_destroy(pk_fs2* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    pk_dbuf* bufs[] = {&h->arena, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
+                       &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
+                       &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
+    for (auto* b : bufs) b->release();
+    h->tl_tok.release();
+    h->tl_frm.release();
+    delete h;
+}

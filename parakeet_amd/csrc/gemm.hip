@@ -1,0 +1,156 @@
+// gemm.hip -- exact-fp32 MFMA implicit-conv GEMM (v_mfma_f32_32x32x2_f32).
+//
+// Block tile 128(M) x 128(N) x 16(K), 4 waves as 2(M) x 2(N), each wave a 64x64
+// sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator registers).  Activations are
+// channels-last [rows][C]; a k-tap Conv1D is the same GEMM with the A rows
+// shifted by (tap - pad) -- no im2col, no NCL<->NLC transposes (the reference
+// does four per FFN, fastspeech2_transformer/multi_layer_conv.py:75-77).
+//
+// LDS images (double buffered, 2 x 16 KB):
+//   As[kk][wm][i]{mt}  float2 per (k, wave-row, lane-row): one ds_read_b64 gives a
+//   lane its A operand for both of its M tiles; Bs[kk][wn][j]{nt} likewise.  The
+//   weight image is pre-packed on the host, so its staging is a straight copy.
+#include "pk_gemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr int BM = PK_GEMM_BM, BN = PK_GEMM_BN, BK = PK_GEMM_BK;
+
+__device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int nblk = blockIdx.y;
+    const int nslabs = a.taps * a.Cin / BK;
+    const int slabs_per_tap = a.Cin / BK;
+
+    // A loader: thread -> (row, 8 consecutive k)
+    const int lrow = tid >> 1, lhalf = tid & 1;
+    const float* arow = a.A + (long)(m0 + lrow - a.pad) * a.lda + lhalf * 8;
+    const int a_lds = (((lhalf * 8) * 2 + (lrow >> 6)) * 32 + (lrow & 31)) * 2 + ((lrow >> 5) & 1);
+    const float* wsrc = a.Wp + (long)nblk * nslabs * (BK * BN) + tid * 8;
+
+    f32x4 ra0, ra1, rb0, rb1;
+    auto load_slab = [&](int s) {
+        const int tap = s / slabs_per_tap, ci0 = (s - tap * slabs_per_tap) * BK;
+        const float* p = arow + (long)tap * a.lda + ci0;
+        ra0 = *reinterpret_cast<const f32x4*>(p);
+        ra1 = *reinterpret_cast<const f32x4*>(p + 4);
+        const float* q = wsrc + (long)s * (BK * BN);
+        rb0 = *reinterpret_cast<const f32x4*>(q);
+        rb1 = *reinterpret_cast<const f32x4*>(q + 4);
+    };
+    auto store_slab = [&](int buf) {
+        float* d = As[buf] + a_lds;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e * 128] = ra0[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[(4 + e) * 128] = ra1[e];
+        f32x4* b = reinterpret_cast<f32x4*>(Bs[buf] + tid * 8);
+        b[0] = rb0;
+        b[1] = rb1;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < nslabs; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslabs) load_slab(s + 1);
+        const f32x2* fa = reinterpret_cast<const f32x2*>(As[buf]) + (hi * 2 + wm) * 32 + i;
+        const f32x2* fb = reinterpret_cast<const f32x2*>(Bs[buf]) + (hi * 2 + wn) * 32 + i;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const f32x2 av = fa[ks * 128];
+            const f32x2 bv = fb[ks * 128];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < nslabs) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue
+    const int n_base = nblk * BN + wn * 64 + i;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n_base + nt * 32;
+        if (n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.f;
+        const float cs = a.cscale ? a.cscale[n] : 1.f;
+        const float ch = a.cshift ? a.cshift[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
+                if (m >= a.M) continue;
+                float v = acc[mt][nt][r] + bias;
+                if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (a.act == PK_ACT_TANH) v = tanhf(v);
+                if (a.res) v += a.res[(long)m * a.ldr + n];
+                if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                if (a.cscale) v = v * cs + ch;
+                int mo = m;
+                if (a.out_rowmap) {
+                    mo = a.out_rowmap[m];
+                    if (mo < 0) continue;
+                }
+                a.C[(long)mo * a.ldc + n] = v;
+            }
+    }
+}
+}  // namespace
+
+size_t pk_gemm_pack(const float* Wkn, int K, int N, std::vector<float>& out) {
+    const int nblks = (N + BN - 1) / BN, nslabs = K / BK;
+    out.assign((size_t)nblks * nslabs * BK * BN, 0.f);
+    for (int nb = 0; nb < nblks; ++nb)
+        for (int s = 0; s < nslabs; ++s) {
+            float* img = out.data() + ((size_t)nb * nslabs + s) * (BK * BN);
+            for (int kk = 0; kk < BK; ++kk)
+                for (int wn = 0; wn < 2; ++wn)
+                    for (int j = 0; j < 32; ++j)
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int n = nb * BN + wn * 64 + nt * 32 + j;
+                            const int k = s * BK + kk;
+                            img[((kk * 2 + wn) * 32 + j) * 2 + nt] = (n < N) ? Wkn[(size_t)k * N + n] : 0.f;
+                        }
+        }
+    return out.size();
+}
+
+void pk_conv_to_kn(const float* w, int Cout, int Cin, int k, std::vector<float>& out) {
+    out.resize((size_t)k * Cin * Cout);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int tap = 0; tap < k; ++tap)
+                out[((size_t)tap * Cin + ci) * Cout + co] = w[((size_t)co * Cin + ci) * k + tap];
+}
+
+int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& a) {
+    if (a.Cin % BK != 0) PK_FAIL(PK_EUNSUPPORTED, "GEMM: input channels (%d) must be a multiple of %d", a.Cin, BK);
+    if (a.M <= 0 || a.N <= 0) PK_FAIL(PK_EINVAL, "GEMM: empty problem");
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+    PK_LAUNCH(ctx, prof_name, k_gemm, grid, dim3(256), 0, a);
+    return PK_OK;
+}

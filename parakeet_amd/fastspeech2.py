@@ -1,0 +1,183 @@
+"""FastSpeech2 acoustic model behind the reference's Python API.
+
+Mirrors parakeet/models/fastspeech2/fastspeech2.py: ``FastSpeech2`` (constructor
+kwargs :52-118, ``set_state_dict``, ``eval``, ``inference`` :468-558) and
+``FastSpeech2Inference`` (:662-671).  All arithmetic runs in libpk_synth.so
+(csrc/fs2.hip, csrc/gemm.hip).  Training (``forward`` / loss) is out of scope.
+
+Extension over the reference: ``inference_batch`` runs a ragged batch in one
+engine call (the reference's ``inference`` is one utterance per call).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .runtime import Context, dptr, set_params, to_numpy_f32, wrap
+
+
+class FastSpeech2:
+    def __init__(self, idim, odim, adim=384, aheads=4, elayers=6, eunits=1536, dlayers=6, dunits=1536,
+                 postnet_layers=5, postnet_chans=512, postnet_filts=5, positionwise_layer_type="conv1d",
+                 positionwise_conv_kernel_size=1, use_scaled_pos_enc=True, use_batch_norm=True,
+                 encoder_normalize_before=True, decoder_normalize_before=True, encoder_concat_after=False,
+                 decoder_concat_after=False, reduction_factor=1, encoder_type="transformer",
+                 decoder_type="transformer", duration_predictor_layers=2, duration_predictor_chans=384,
+                 duration_predictor_kernel_size=3, energy_predictor_layers=2, energy_predictor_chans=384,
+                 energy_predictor_kernel_size=3, energy_predictor_dropout=0.5, energy_embed_kernel_size=9,
+                 energy_embed_dropout=0.5, stop_gradient_from_energy_predictor=False,
+                 pitch_predictor_layers=2, pitch_predictor_chans=384, pitch_predictor_kernel_size=3,
+                 pitch_predictor_dropout=0.5, pitch_embed_kernel_size=9, pitch_embed_dropout=0.5,
+                 stop_gradient_from_pitch_predictor=False, num_speakers=None, spk_embed_dim=None,
+                 spk_embed_integration_type="add", num_tones=None, tone_embed_dim=None,
+                 tone_embed_integration_type="add", transformer_enc_dropout_rate=0.1,
+                 transformer_enc_positional_dropout_rate=0.1, transformer_enc_attn_dropout_rate=0.1,
+                 transformer_dec_dropout_rate=0.1, transformer_dec_positional_dropout_rate=0.1,
+                 transformer_dec_attn_dropout_rate=0.1, duration_predictor_dropout_rate=0.1,
+                 postnet_dropout_rate=0.5, init_type="xavier_uniform", init_enc_alpha=1.0,
+                 init_dec_alpha=1.0, use_masking=False, use_weighted_masking=False, device=None):
+        if encoder_type != "transformer":
+            raise ValueError(f"{encoder_type} is not supported.")   # fastspeech2.py:187
+        if decoder_type != "transformer":
+            raise ValueError(f"{decoder_type} is not supported.")   # fastspeech2.py:268
+        if positionwise_layer_type != "conv1d":
+            raise NotImplementedError("only positionwise_layer_type='conv1d' is implemented")
+        if encoder_concat_after or decoder_concat_after:
+            raise NotImplementedError("concat_after=True is not implemented")
+        self.idim, self.odim = idim, odim
+        self._adim = adim
+        self.eos = idim - 1
+        self.reduction_factor = reduction_factor
+        self.padding_idx = 0
+        self.training = True
+        self._ctx = Context.get(device)
+        cfg = _capi.Fs2Cfg()
+        cfg.idim, cfg.odim, cfg.adim, cfg.aheads = idim, odim, adim, aheads
+        cfg.elayers, cfg.eunits, cfg.dlayers, cfg.dunits = elayers, eunits, dlayers, dunits
+        cfg.positionwise_conv_kernel_size = positionwise_conv_kernel_size
+        cfg.duration_predictor_layers = duration_predictor_layers
+        cfg.duration_predictor_chans = duration_predictor_chans
+        cfg.duration_predictor_kernel_size = duration_predictor_kernel_size
+        cfg.pitch_predictor_layers = pitch_predictor_layers
+        cfg.pitch_predictor_chans = pitch_predictor_chans
+        cfg.pitch_predictor_kernel_size = pitch_predictor_kernel_size
+        cfg.energy_predictor_layers = energy_predictor_layers
+        cfg.energy_predictor_chans = energy_predictor_chans
+        cfg.energy_predictor_kernel_size = energy_predictor_kernel_size
+        cfg.pitch_embed_kernel_size = pitch_embed_kernel_size
+        cfg.energy_embed_kernel_size = energy_embed_kernel_size
+        cfg.postnet_layers, cfg.postnet_chans, cfg.postnet_filts = postnet_layers, postnet_chans, postnet_filts
+        cfg.use_batch_norm = 1 if use_batch_norm else 0
+        cfg.use_scaled_pos_enc = 1 if use_scaled_pos_enc else 0
+        cfg.encoder_normalize_before = 1 if encoder_normalize_before else 0
+        cfg.decoder_normalize_before = 1 if decoder_normalize_before else 0
+        cfg.reduction_factor = reduction_factor
+        cfg.has_spk_embed = 0 if spk_embed_dim is None else 1
+        cfg.has_tone_embed = 0 if tone_embed_dim is None else 1
+        h = C.c_void_p()
+        _capi.check(self._ctx.lib.pk_fs2_create(self._ctx.handle, C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._finalized = False
+        self._last_tok, self._last_frames = [], []
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._ctx.lib.pk_fs2_destroy(h)
+            except Exception:
+                pass
+
+    def set_state_dict(self, state_dict):
+        set_params(self._ctx.lib.pk_fs2_set_param, self._h, state_dict)
+        self._finalized = False
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def set_normalizer(self, normalizer):
+        if normalizer is None:
+            _capi.check(self._ctx.lib.pk_fs2_set_normalizer(self._h, None, None, 0))
+        else:
+            mu, sigma = to_numpy_f32(normalizer.mu).reshape(-1), to_numpy_f32(normalizer.sigma).reshape(-1)
+            _capi.check(self._ctx.lib.pk_fs2_set_normalizer(self._h, _capi.fptr(mu), _capi.fptr(sigma), mu.size))
+        self._finalized = False
+
+    def _finalize(self):
+        if not self._finalized:
+            _capi.check(self._ctx.lib.pk_fs2_finalize(self._h))
+            self._finalized = True
+
+    def set_debug(self, on=True):
+        _capi.check(self._ctx.lib.pk_fs2_set_debug(self._h, 1 if on else 0))
+
+    # -- synthesis -----------------------------------------------------------
+    def encode_batch(self, texts, alpha=1.0):
+        """Phase 1: returns the per-utterance frame counts (host ints)."""
+        ctx = Context.get(self._ctx.device)
+        self._finalize()
+        ids = [np.asarray(t.cpu() if isinstance(t, torch.Tensor) else t).astype(np.int64).reshape(-1)
+               for t in texts]
+        lens = np.array([len(i) for i in ids], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate(ids))
+        frames = np.zeros(len(ids), dtype=np.int32)
+        _capi.check(ctx.lib.pk_fs2_encode(self._h, flat.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          lens.ctypes.data_as(C.POINTER(C.c_int32)), len(ids),
+                                          C.c_float(alpha), frames.ctypes.data_as(C.POINTER(C.c_int32))))
+        self._last_tok, self._last_frames = [int(v) for v in lens], [int(v) for v in frames]
+        return frames
+
+    def decode_packed(self):
+        """Phase 2: packed (sum(frames), odim) device tensor of the last encode."""
+        ctx = Context.get(self._ctx.device)
+        total = int(sum(self._last_frames))
+        mel = ctx.empty((total, self.odim))
+        if total:
+            _capi.check(ctx.lib.pk_fs2_decode(self._h, dptr(mel), 0))
+        return mel
+
+    def inference_batch(self, texts, alpha=1.0):
+        frames = self.encode_batch(texts, alpha)
+        mel = self.decode_packed()
+        outs, o = [], 0
+        for f in frames:
+            outs.append(wrap(mel[o:o + int(f)]))
+            o += int(f)
+        return outs
+
+    def inference(self, text, speech=None, durations=None, pitch=None, energy=None, alpha=1.0,
+                  use_teacher_forcing=False, spembs=None, spk_id=None, tone_id=None):
+        """(T,) int64 -> (L, odim); fastspeech2.py:468-558 (is_inference=True branch)."""
+        if use_teacher_forcing:
+            raise NotImplementedError("teacher forcing is a training-time path")
+        if spembs is not None or spk_id is not None or tone_id is not None:
+            raise NotImplementedError("speaker / tone embeddings are not implemented")
+        return self.inference_batch([text], alpha)[0]
+
+    def debug_tap(self, what, b):
+        n_rows = self._last_tok[b] if what <= 3 else self._last_frames[b]
+        width = {0: -1, 1: 1, 2: 1, 3: 1, 4: -1, 5: -1, 6: self.odim}[what]
+        if width == -1:
+            width = self._adim
+        out = np.empty((n_rows, width), dtype=np.float32)
+        _capi.check(self._ctx.lib.pk_fs2_debug_read(self._h, what, b, _capi.fptr(out), out.size))
+        return out[:, 0] if width == 1 else out
+
+
+class FastSpeech2Inference:
+    """FastSpeech2Inference (fastspeech2.py:662-671): inference then normalizer.inverse."""
+
+    def __init__(self, normalizer, model):
+        self.normalizer = normalizer
+        self.acoustic_model = model
+        model.set_normalizer(normalizer)
+
+    def forward(self, text, spk_id=None, alpha=1.0):
+        return self.acoustic_model.inference(text, spk_id=spk_id, alpha=alpha)
+
+    __call__ = forward
+
+    def eval(self):
+        return self

@@ -1,0 +1,130 @@
+"""GPU parity: FastSpeech2 inference (HIP, through the C ABI) vs the CPU oracle.
+
+Each utterance of a ragged batch is compared with an independent single-utterance
+oracle call -- the only form of inference the reference defines
+(fastspeech2.py:519-522).  Tolerance: north_star's mel L1 < 1e-4 and exactly equal
+integer durations; max-abs is asserted too.
+"""
+import numpy as np
+import pytest
+import torch
+
+from parakeet_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+MEL_L1_TOL = 1e-4      # BASELINE.json north_star
+MEL_MAX_TOL = 2e-3     # max-abs bound on the same comparison (fp32 summation-order noise)
+
+
+def _cfg(**over):
+    return dict(syn.FS2_LJSPEECH, **over)
+
+
+def _model_kwargs(cfg):
+    return {k: v for k, v in cfg.items()}
+
+
+def _oracle_cfg(cfg):
+    keys = ("adim aheads elayers eunits dlayers dunits positionwise_conv_kernel_size "
+            "duration_predictor_layers duration_predictor_chans duration_predictor_kernel_size "
+            "pitch_predictor_layers pitch_predictor_chans pitch_predictor_kernel_size "
+            "energy_predictor_layers energy_predictor_chans energy_predictor_kernel_size "
+            "pitch_embed_kernel_size energy_embed_kernel_size postnet_layers postnet_chans postnet_filts").split()
+    return {k: cfg[k] for k in keys}
+
+
+def _check(cfg, tok_lens, seed, alpha=1.0, fixed_duration=None, taps=True, idim=80, odim=80):
+    from oracle import fastspeech2_ref as ref
+    from parakeet_amd.fastspeech2 import FastSpeech2
+
+    state = syn.fastspeech2_state(idim, odim, cfg, seed=seed, fixed_duration=fixed_duration)
+    texts = [syn.phoneme_ids(T, idim, seed=seed + 10 + i) for i, T in enumerate(tok_lens)]
+    model = FastSpeech2(idim, odim, **_model_kwargs(cfg))
+    model.set_state_dict(state)
+    model.eval()
+    model.set_debug(True)
+    outs = model.inference_batch(texts, alpha=alpha)
+    for b, ids in enumerate(texts):
+        want, parts = ref.inference(state, ids, _oracle_cfg(cfg), alpha=alpha, dtype=torch.float64,
+                                    return_parts=True)
+        want = want.numpy()
+        d_ref = parts["d"].numpy()
+        if alpha != 1.0:
+            d_ref = np.sign(d_ref * alpha) * np.floor(np.abs(np.float32(d_ref) * np.float32(alpha)) + 0.5)
+        if taps:
+            hs = model.debug_tap(0, b)
+            assert np.abs(hs - parts["hs"].numpy()).max() < 1e-3, "encoder output"
+            assert np.abs(model.debug_tap(1, b) - parts["p"].numpy()).max() < 1e-3, "pitch"
+            assert np.abs(model.debug_tap(2, b) - parts["e"].numpy()).max() < 1e-3, "energy"
+        np.testing.assert_array_equal(model.debug_tap(3, b), d_ref)  # integer durations: exact
+        got = outs[b].numpy()
+        assert got.shape == want.shape, (got.shape, want.shape)
+        if taps and got.shape[0]:
+            assert np.abs(model.debug_tap(4, b) - parts["hs_up"].numpy()).max() < 1e-3, "length regulator"
+            assert np.abs(model.debug_tap(5, b) - parts["zs"].numpy()).max() < 2e-3, "decoder output"
+            assert np.abs(model.debug_tap(6, b) - parts["before"].numpy()).max() < 2e-3, "before_outs"
+        if got.size:
+            l1 = np.abs(got - want).mean()
+            mx = np.abs(got - want).max()
+            assert l1 < MEL_L1_TOL, f"utt {b}: mel L1 {l1}"
+            assert mx < MEL_MAX_TOL, f"utt {b}: mel max-abs {mx}"
+
+
+def test_fs2_ljspeech_ragged_batch():
+    _check(_cfg(), [37, 5, 64, 1, 23], seed=100)
+
+
+def test_fs2_ljspeech_fixed_duration_shape():
+    # throughput configuration: every token -> 5 frames through the normal inference path
+    _check(_cfg(), [16, 9], seed=101, fixed_duration=5)
+
+
+def test_fs2_alpha_speed_control():
+    _check(_cfg(), [21, 12], seed=102, alpha=1.3, taps=False)
+
+
+def test_fs2_four_heads_small():
+    # aheads=4 (d_k = 96), fewer layers, other kernel sizes
+    cfg = _cfg(aheads=4, elayers=2, dlayers=2, eunits=512, dunits=512, positionwise_conv_kernel_size=1,
+               pitch_predictor_layers=2, pitch_predictor_kernel_size=3, postnet_layers=3, postnet_chans=128)
+    _check(cfg, [19, 40, 7], seed=103)
+
+
+def test_fs2_long_utterance_multi_tile():
+    # > 128 tokens and several hundred frames: several GEMM row tiles and attention key tiles
+    _check(_cfg(), [150, 33], seed=104, taps=False)
+
+
+def test_fs2_inference_wrapper_denormalizes():
+    from oracle import fastspeech2_ref as ref
+    from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
+    from parakeet_amd.normalizer import ZScore
+    cfg = _cfg()
+    state = syn.fastspeech2_state(80, 80, cfg, seed=105)
+    mu, sigma = syn.mel_stats()
+    ids = syn.phoneme_ids(30, 80, seed=3)
+    model = FastSpeech2(80, 80, **cfg)
+    model.set_state_dict(state)
+    model.eval()
+    inf = FastSpeech2Inference(ZScore(mu, sigma), model)
+    got = inf(ids).numpy()
+    want = ref.fastspeech2_inference(state, mu, sigma, ids, _oracle_cfg(cfg), dtype=torch.float64).numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).mean() < MEL_L1_TOL
+
+
+def test_fs2_error_mapping():
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    with pytest.raises(ValueError):
+        FastSpeech2(80, 80, encoder_type="conformer")
+    with pytest.raises(NotImplementedError):
+        FastSpeech2(80, 80, **_cfg(reduction_factor=2))
+    m = FastSpeech2(80, 80, **_cfg())
+    with pytest.raises(RuntimeError):
+        m.inference(np.array([1, 2, 3]))            # parameters never set
+    m.set_state_dict(syn.fastspeech2_state(80, 80, _cfg()))
+    with pytest.raises(ValueError):
+        m.inference(np.array([1, 2, 999]))          # id out of range
+    with pytest.raises(AssertionError):
+        m.inference(np.array([1, 2, 3]), alpha=0.0)  # assert alpha > 0 (length_regulator.py:86)
