@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio samples/sec of FastSpeech2 + Parallel WaveGAN synthesis at 22.05 kHz.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the synthesis hot path (FastSpeech2.inference ->
+PWGGenerator.inference, mel stays in HBM) over one batch of synthetic
+utterances of LJSpeech shape.  Per GPU the batch is BASELINE.json config 4's
+per-GPU share: 256 utterances / 8 GPUs = 32 utterances of T = 128 phonemes,
+every phoneme 5 frames -> L = 640 frames -> 163 840 samples (7.43 s) each.
+Work per GPU is fixed as N grows (weak scaling); utterances are independent so
+there is no data-path collective (parakeet_amd/dist.py).  Inputs (token ids,
+vocoder noise) are generated before the timed region and the noise is resident
+in HBM; random-initialised weights of the reference architecture
+(parakeet_amd/synthetic.py).  All arithmetic is fp32 (exact-fp32 MFMA).
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+`roofline` (dominant kernel: the PWG residual block) and, at N = 1,
+`cpu_baseline` (the torch-CPU oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SAMPLE_RATE = 22050
+HOP = 256
+UTT_PER_GPU = 32
+TOKENS = 128
+FRAMES_PER_TOKEN = 5
+# algorithmic work of one ResidualBlock per output sample:
+# dilated conv 2*192*128 + aux 1x1 2*80*128 + skip 2*64*64 + out 2*64*64
+PWG_LAYER_FLOP_PER_SAMPLE = 86016
+# layer-granular byte model per sample per layer (read x 256 + read c 320 + write x 256 + RMW skip 512)
+PWG_LAYER_BYTES_PER_SAMPLE = 1344
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build_models(device):
+    from parakeet_amd import synthetic as syn
+    from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
+    from parakeet_amd.normalizer import ZScore
+    from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference
+    from parakeet_amd.synthesize import Synthesizer
+
+    fs2_state = syn.fastspeech2_state(80, 80, fixed_duration=FRAMES_PER_TOKEN)
+    pwg_state = syn.pwg_state()
+    am = FastSpeech2(80, 80, **syn.FS2_LJSPEECH, device=device)
+    am.set_state_dict(fs2_state)
+    am.eval()
+    voc = PWGGenerator(**syn.PWG_LJSPEECH, device=device)
+    voc.set_state_dict(pwg_state)
+    voc.remove_weight_norm()
+    voc.eval()
+    mu_f, sg_f = syn.mel_stats(seed=7)
+    mu_p, sg_p = syn.mel_stats(seed=8)
+    synth = Synthesizer(FastSpeech2Inference(ZScore(mu_f, sg_f), am), PWGInference(ZScore(mu_p, sg_p), voc))
+    return synth, fs2_state, pwg_state, (mu_f, sg_f, mu_p, sg_p)
+
+
+def cpu_baseline(fs2_state, pwg_state, stats):
+    """Time the torch-CPU oracle ("port") on a bounded sample of the same workload."""
+    from oracle import fastspeech2_ref, pwg_ref
+    from parakeet_amd import synthetic as syn
+    cores = min(os.cpu_count() or 1, 32)  # MKL/oneDNN stop scaling on these small convs well before 32
+    torch.set_num_threads(cores)
+    tokens = TOKENS  # one full utterance of the workload: 128 tokens -> 640 frames -> 163 840 samples
+    ids = syn.phoneme_ids(tokens, seed=10086)
+    mu_f, sg_f, mu_p, sg_p = stats
+    noise = torch.from_numpy(np.random.default_rng(42).normal(size=tokens * FRAMES_PER_TOKEN * HOP).astype(np.float32))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        logmel = fastspeech2_ref.fastspeech2_inference(fs2_state, mu_f, sg_f, ids)
+        wav = pwg_ref.pwg_inference(pwg_state, mu_p, sg_p, logmel, noise)
+    dt = time.perf_counter() - t0
+    n = int(wav.shape[0])
+    return {
+        "value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+        "sample": f"1 utterance, {tokens} tokens -> {n // HOP} frames -> {n} samples, FastSpeech2+PWG "
+                  f"torch-CPU fp32 oracle (Paddle-equivalent restatement), {dt:.1f} s wall",
+        "x_realtime": n / dt / SAMPLE_RATE,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from parakeet_amd import synthetic as syn
+    from parakeet_amd.runtime import Context
+
+    synth, fs2_state, pwg_state, stats = build_models(local_rank)
+    if distributed:
+        # weights come from rank 0 over RCCL (one flat broadcast per model), as a deployment would do it
+        from parakeet_amd import dist as pdist
+        fs2_b = pdist.broadcast_state_dict(fs2_state, src=0)
+        pwg_b = pdist.broadcast_state_dict(pwg_state, src=0)
+        synth.am.set_state_dict(fs2_b)
+        synth.voc.set_state_dict(pwg_b)
+
+    # this rank's shard of the global batch (weak scaling: UTT_PER_GPU each)
+    base = rank * UTT_PER_GPU
+    texts = [syn.phoneme_ids(TOKENS, seed=10086 + base + i) for i in range(UTT_PER_GPU)]
+    n_samples = UTT_PER_GPU * TOKENS * FRAMES_PER_TOKEN * HOP
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42 + rank)
+    noise = torch.randn(n_samples, device="cuda", generator=gen)
+
+    def step():
+        wav, frames = synth.synthesize_packed(texts, noise=noise)
+        return wav, frames
+
+    def barrier():
+        if distributed:
+            import torch.distributed as dist
+            dist.barrier()
+
+    wav, frames = step()  # build / first-touch pass (allocations, weight packing); never timed
+    for _ in range(args.warmup):
+        wav, frames = step()
+    torch.cuda.synchronize()
+    assert int(frames.sum()) * HOP == n_samples, "synthetic duration head must give 5 frames per token"
+    assert bool(torch.isfinite(wav).all()), "non-finite waveform"
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav, frames = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
+    ctx = Context.get(local_rank)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    prof_steps = 2
+    for _ in range(prof_steps):
+        step()
+    prof = ctx.prof_dump()
+    ctx.prof_enable(False)
+
+    if rank == 0:
+        total_samples = n_samples * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_samples * args.steps / elapsed
+        n_layer, ms_layer = prof.get("pwg_layer", (0, 0.0))
+        avg_ms = ms_layer / max(n_layer, 1)
+        flop_per_launch = PWG_LAYER_FLOP_PER_SAMPLE * n_samples
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pwg_layer_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        total_prof_ms = sum(ms for _, ms in prof.values()) / prof_steps
+        out = {
+            "metric": "audio samples/sec, FastSpeech2+PWGAN 22.05kHz",
+            "value": value,
+            "unit": "samples/s",
+            "x_realtime": value / SAMPLE_RATE,
+            "rtf_reference_convention": SAMPLE_RATE / value,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "FastSpeech2+PWG end-to-end (BASELINE config 4 per-GPU share): "
+                            f"{UTT_PER_GPU} utterances/GPU x {TOKENS} phonemes -> {TOKENS * FRAMES_PER_TOKEN} frames "
+                            f"-> {TOKENS * FRAMES_PER_TOKEN * HOP} samples each, LJSpeech architecture, random-init weights",
+                "utterances_per_gpu": UTT_PER_GPU,
+                "global_batch": UTT_PER_GPU * world,
+                "parallelism": f"dp{world} (utterance sharding, no data-path collective)",
+            },
+            "roofline": {
+                "kernel": "k_pwg_layer (PWG ResidualBlock, 30 launches/step)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic,
+                "avg_launch_ms": avg_ms,
+                "algorithmic_flop_per_launch": flop_per_launch,
+                "layer_granular_bytes_per_launch": PWG_LAYER_BYTES_PER_SAMPLE * n_samples,
+                "hbm_frac_layer_granular": (PWG_LAYER_BYTES_PER_SAMPLE * n_samples / (avg_ms * 1e-3) / 8.0e12)
+                if avg_ms > 0 else 0.0,
+            },
+            "kernel_ms_per_step": {k: ms / prof_steps for k, (_, ms) in sorted(prof.items())},
+            "kernel_ms_sum": total_prof_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fs2_state, pwg_state, stats)
+        print(json.dumps(out))
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

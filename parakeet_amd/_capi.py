@@ -7,6 +7,10 @@ reference raises at the same places.
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process cannot both own
+# the device.  Importing torch first makes libpk_synth.so bind to the runtime torch loaded.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpk_synth.so")
 

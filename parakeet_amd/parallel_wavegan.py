@@ -117,6 +117,26 @@ class PWGGenerator:
             o += n
         return outs
 
+    def infer_packed(self, mel, frames, noise=None, generator=None):
+        """mel: packed (sum(frames), aux) DEVICE tensor (e.g. FastSpeech2.decode_packed());
+        returns the packed (sum(frames)*hop,) device waveform -- no host round trip."""
+        ctx = Context.get(self._ctx.device)
+        self._finalize()
+        frames = np.ascontiguousarray(np.asarray(frames, dtype=np.int32))
+        self._last_frames = [int(f) for f in frames]
+        total = int(frames.sum()) * self.upsample_factor
+        mel = ctx.to_device(mel).reshape(-1, self.aux_channels)
+        assert mel.shape[0] == int(frames.sum()), "mel rows must equal sum(frames)"
+        if noise is None:
+            noise = torch.randn(total, device=ctx.device, dtype=torch.float32, generator=generator)
+        else:
+            noise = ctx.to_device(noise).reshape(-1)
+        assert noise.numel() == total, "noise length must be sum(frames) * hop"
+        wav = ctx.empty((total,))
+        _capi.check(ctx.lib.pk_pwg_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         len(frames), dptr(noise), dptr(wav), 0))
+        return wav
+
     def inference(self, c=None, noise=None):
         """(T', C_aux) -> (T, C_out); parallel_wavegan.py:498-520."""
         return self.inference_batch([c], None if noise is None else [noise])[0]

@@ -1,0 +1,45 @@
+"""End-to-end batched synthesis: FastSpeech2 -> Parallel WaveGAN on one GPU.
+
+The device-side equivalent of the loop body of
+examples/fastspeech2/ljspeech/synthesize_e2e.py:88-102
+(``mel = fastspeech2_inference(phone_ids); wav = pwg_inference(mel)``), for a
+ragged batch and with the mel never leaving HBM.  The only host<->device
+traffic inside a call is the token ids in and B frame counts out (the output
+length is data dependent).
+"""
+import numpy as np
+import torch
+
+from .runtime import wrap
+
+
+class Synthesizer:
+    def __init__(self, fastspeech2_inference, pwg_inference):
+        self.am = fastspeech2_inference.acoustic_model
+        self.voc = pwg_inference.pwg_generator
+        self.hop = self.voc.upsample_factor
+
+    def synthesize_packed(self, texts, alpha=1.0, noise=None, generator=None):
+        """Returns (packed wav device tensor, frames per utterance)."""
+        frames = self.am.encode_batch(texts, alpha)
+        if int(frames.sum()) == 0:
+            return torch.empty(0, device=self.am._ctx.device), frames
+        mel = self.am.decode_packed()
+        keep = frames > 0  # the vocoder needs >= 1 frame per utterance
+        wav = self.voc.infer_packed(mel, frames[keep], noise=noise, generator=generator)
+        return wav, frames
+
+    def synthesize_batch(self, texts, alpha=1.0, noises=None, generator=None):
+        noise = None
+        if noises is not None:
+            noise = torch.cat([torch.as_tensor(np.asarray(n)).reshape(-1) for n in noises])
+        wav, frames = self.synthesize_packed(texts, alpha, noise, generator)
+        outs, o = [], 0
+        for f in frames:
+            n = int(f) * self.hop
+            outs.append(wrap(wav[o:o + n].reshape(n, 1)))
+            o += n
+        return outs
+
+    def __call__(self, text, alpha=1.0, noise=None):
+        return self.synthesize_batch([text], alpha, None if noise is None else [noise])[0]

@@ -1,0 +1,53 @@
+"""CPU-side checks of the boundary: the library loads, exports every symbol that
+include/pk_synth.h declares, and fails loudly without a GPU (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pk_synth.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_build_and_exports():
+    import __graft_entry__ as ge
+    ge.build()
+    from parakeet_amd import _capi
+    lib = _capi.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"libpk_synth.so does not export {s}"
+    assert b"gfx950" in lib.pk_version()
+
+
+def test_binding_covers_header():
+    from parakeet_amd import _capi
+    bound = set(_capi._declare(_capi.lib()).keys())
+    assert set(_declared_symbols()) == bound
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from parakeet_amd import _capi
+    lib = _capi.lib()
+    h = C.c_void_p()
+    rc = lib.pk_ctx_create(0, C.byref(h))
+    assert rc == -4 and b"no HIP device" in lib.pk_last_error()
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    with pytest.raises(RuntimeError):
+        PWGGenerator()
+
+
+def test_struct_sizes_match_header():
+    from parakeet_amd import _capi
+    assert C.sizeof(_capi.PwgCfg) == 4 * (11 + 8 + 1)
+    assert C.sizeof(_capi.Fs2Cfg) == 4 * 30
