@@ -120,7 +120,7 @@ int pk_pwg_finalize(pk_pwg* h);
 int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, int32_t B,
                  const float* noise, float* wav, int32_t flags);
 /* Debug / test taps: copy internal activations of the LAST pk_pwg_infer call
- * for utterance b to host.  what: 0 = upsampled conditioning c (aux, S_b),
+ * for utterance b to host.  what: 0 = layer 0's conv1x1_aux(upsampled c) (gate, S_b),
  * 1 = residual-stack output x (residual, S_b), 2 = skip sum before the sqrt(1/layers)
  * scale (skip, S_b), all channel-major. */
 int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);

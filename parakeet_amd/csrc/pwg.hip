@@ -19,11 +19,22 @@
 // written after the per-call zeroing.  Ragged batches cost nothing extra.
 //
 // The residual stack is 93 % of the end-to-end FLOPs and is a
-// chain of small dense contractions (K = 3*64 + 80 = 272 -> 128, then 64 -> 128)
-// per sample; it runs on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+// chain of small dense contractions per sample; it runs on the exact-fp32 matrix
+// pipe (v_mfma_f32_32x32x2_f32).
+//
+// Conditioning path.  UpsampleNet is linear and identical for every mel channel
+// (one shared (1, 2s+1) FIR per stage, no bias, no activation in the LJSpeech
+// recipe), so it commutes with the per-layer channel mix conv1x1_aux:
+//     conv1x1_aux_l(Upsample(c0)) == Upsample(W_aux_l . c0)
+// The engine therefore projects at FRAME rate (one GEMM: [frames x 80] x
+// [80 x layers*128]) and applies the 4-stage upsampler as ONE composite,
+// phase-dependent 5-tap filter over frames (table built at finalize from the
+// stage FIRs, with exact zero-padding behaviour at utterance edges).  The
+// [80][samples] conditioning tensor is never materialised and the per-sample K of
+// the first contraction drops from 272 to 192.
 #include <cmath>
 
-#include "pk_common.h"
+#include "pk_gemm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -37,12 +48,15 @@ constexpr int SK = 64;    // skip channels
 constexpr int AUX = 80;   // aux channels
 constexpr int KTAP = 3;   // kernel size of the dilated conv
 constexpr int KS_CONV = KTAP * R / 2;         // 96 k-steps (2 input channels per MFMA)
-constexpr int KS_AUX = AUX / 2;               // 40
-constexpr int KS1 = KS_CONV + KS_AUX;         // 136
+constexpr int KS1 = KS_CONV;                  // 96 (the aux 1x1 conv is applied at frame rate)
 constexpr int KS2 = (G / 2) / 2;              // 32 k-steps over the 64 gated channels
 constexpr int TILE = 256;                     // samples per workgroup tile (one frame at hop 256)
 constexpr int WAVE_T = 32;                    // samples per wave (MFMA N)
 constexpr int MAX_UP_TAPS = 17;
+constexpr int UPW = 5;                        // frames touched by the composite upsampler (reach < 2 frames)
+constexpr int UPW_PAD = 8;                    // table row stride (floats)
+constexpr int N_EDGE_CLASS = 9;               // (min(frames before, 2), min(frames after, 2))
+constexpr int P_LEAD = 8;                     // margin rows around the frame-rate projection
 
 // Row of the 32x32 MFMA result held in accumulator register r of a lane whose
 // (lane >> 5) is hi.  (cdna guide: row = (r&3) + 8*(r>>2) + 4*hi, col = lane&31)
@@ -60,11 +74,11 @@ __global__ void k_zero_gaps(float* buf, const int* gap_start, int gap, int rows,
 
 // conv_in: ZScore-normalise (PWGInference :773), replicate-pad by ctx (:518),
 // Conv1D(aux->aux, k=2ctx+1, no bias) (:188-192,214).
-// mel (sumL, AUX) packed row-major; wT [(ci*k + tap)][co]; out c0[co][cuL[b] + f], row stride sumL.
+// mel (sumL, AUX) packed row-major; wT [(ci*k + tap)][co]; out c0[f][co] row-major (frame rate).
 __global__ void k_pwg_convin(const float* __restrict__ mel, const float* __restrict__ wT,
-                             const float* __restrict__ mu, const float* __restrict__ inv_sigma_or_sigma,
+                             const float* __restrict__ mu, const float* __restrict__ sigma,
                              int use_norm, const int* __restrict__ frame_utt,
-                             const int* __restrict__ cuL, int ctx, int sumL, float* __restrict__ out) {
+                             const int* __restrict__ cuL, int ctx, float* __restrict__ out) {
     extern __shared__ float s_in[];  // (2ctx+1) * AUX normalised inputs
     const int f = blockIdx.x;        // global frame index
     const int b = frame_utt[f];
@@ -75,7 +89,7 @@ __global__ void k_pwg_convin(const float* __restrict__ mel, const float* __restr
         int src = f + tap - ctx;
         src = src < lo ? lo : (src >= hi ? hi - 1 : src);  // replicate padding inside the utterance
         float v = mel[(long)src * AUX + ci];
-        if (use_norm) v = (v - mu[ci]) / inv_sigma_or_sigma[ci];
+        if (use_norm) v = (v - mu[ci]) / sigma[ci];
         s_in[tap * AUX + ci] = v;
     }
     __syncthreads();
@@ -85,29 +99,8 @@ __global__ void k_pwg_convin(const float* __restrict__ mel, const float* __restr
         for (int ci = 0; ci < AUX; ++ci)
             for (int tap = 0; tap < k; ++tap)
                 acc = fmaf(wT[(ci * k + tap) * AUX + co], s_in[tap * AUX + ci], acc);
-        out[(long)co * sumL + f] = acc;
+        out[(long)f * AUX + co] = acc;
     }
-}
-
-// One UpsampleNet stage: nearest stretch by s then Conv2D(1->1,(1,2s+1),pad (0,s), no bias)
-// (:102-113,132-138).  in[ch][in_off[b] + u], u in [0, Lin_b); out[ch][out_off[b] + t], t in [0, s*Lin_b).
-__global__ void k_pwg_upsample(const float* __restrict__ in, long in_stride, const int* __restrict__ in_off,
-                               const int* __restrict__ in_len, float* __restrict__ out, long out_stride,
-                               const int* __restrict__ out_off, int s, const float* __restrict__ w) {
-    const int b = blockIdx.z;
-    const int ch = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int Lin = in_len[b];
-    const int Lout = Lin * s;
-    if (t >= Lout) return;
-    const float* src = in + (long)ch * in_stride + in_off[b];
-    float acc = 0.f;
-    const int taps = 2 * s + 1;
-    for (int j = 0; j < taps; ++j) {
-        int u = t + j - s;
-        if (u >= 0 && u < Lout) acc = fmaf(w[j], src[u / s], acc);
-    }
-    out[(long)ch * out_stride + out_off[b] + t] = acc;
 }
 
 // first_conv: Conv1D(1 -> R, k=1, bias) (:401-402,464) from packed noise into the timeline.
@@ -121,17 +114,34 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
     for (int c = 0; c < R; ++c) x[(long)c * Ttot + t] = fmaf(w[c], n, bias[c]);
 }
 
+// Test tap: the sample-rate aux contribution of one layer, aux[co][s] =
+// sum_j T[class][phase][j] * P[frame + j - 2][layer*G + co], written channel-major for one utterance.
+__global__ void k_pwg_aux_debug(const float* __restrict__ P, int ldp, int col0, const float* __restrict__ uptab,
+                                const int* __restrict__ tile_cls, int tile0, int n_tiles, float* __restrict__ out) {
+    const int tl = blockIdx.x;  // tile within the utterance
+    const int co = blockIdx.y;
+    const int phase = threadIdx.x;
+    const int tile = tile0 + tl;
+    const float* w = uptab + ((long)tile_cls[tile] * TILE + phase) * UPW_PAD;
+    float acc = 0.f;
+    for (int jj = 0; jj < UPW; ++jj) acc = fmaf(w[jj], P[(long)(tile + jj - 2) * ldp + col0 + co], acc);
+    out[(long)co * n_tiles * TILE + (long)tl * TILE + phase] = acc;
+}
+
 // ---------------------------------------------------------------- residual block
 struct PwgLayerArgs {
-    const float* xin;    // [R][Ttot]
-    float* xout;         // [R][Ttot]
-    const float* c;      // [AUX][Ttot]
-    float* skip;         // [SK][Ttot]
-    const float* w1;     // [KS1][64 lanes][4 co-tiles]  A fragments, stage 1
-    const float* w2;     // [KS2][64 lanes][4 out-tiles] A fragments, stage 2
-    const float* bias;   // [G + R + SK]: conv bias (gate), conv1x1_out bias, conv1x1_skip bias
-    const int* tile_t0;  // [ntiles] timeline offset of each 256-sample tile
+    const float* xin;     // [R][Ttot]
+    float* xout;          // [R][Ttot]
+    float* skip;          // [SK][Ttot]
+    const float* w1;      // [KS1][64 lanes][4 co-tiles]  A fragments, dilated conv
+    const float* w2;      // [KS2][64 lanes][4 out-tiles] A fragments, out / skip 1x1 convs
+    const float* bias;    // [G + R + SK]: conv bias (gate), conv1x1_out bias, conv1x1_skip bias
+    const float* P;       // frame-rate aux projection, row f = frame f, this layer's G columns at P + col
+    const float* uptab;   // [N_EDGE_CLASS][TILE phases][UPW_PAD] composite upsampler weights
+    const int* tile_t0;   // [ntiles] timeline offset of each 256-sample tile (= frame)
+    const int* tile_cls;  // [ntiles] edge class of the frame
     long Ttot;
+    int ldp;
     int ntiles;
     int dilation;
 };
@@ -144,22 +154,34 @@ __device__ __forceinline__ float gated(float a, float b) {
     return (1.f - ea) / ((1.f + ea) * (1.f + eb));
 }
 
+constexpr int LDS_W1 = KS1 * 64 * 4;          // 24576 floats
+constexpr int LDS_W2 = KS2 * 64 * 4;          //  8192
+constexpr int LDS_BIAS = G + R + SK;          //   256
+constexpr int LDS_PW = UPW * G;               //   640 per wave
+constexpr int LDS_TOTAL = LDS_W1 + LDS_W2 + LDS_BIAS + 8 * LDS_PW;   // 38144 floats = 152 576 B
+
 // One residual block for every tile of the batch.  Persistent workgroups of 8
-// waves; each wave owns 32 consecutive samples and ALL channels for them:
-//   stage 1  acc[4] (4 x 32 gate channels) += W1 (A, from LDS) x [x taps | c] (B, from global)
+// waves (2 per SIMD, no barrier after the weight load: the two waves of a SIMD
+// drift apart so one's gate/epilogue VALU+memory phase hides under the other's
+// MFMA phase).  Each wave owns 32 consecutive samples and ALL channels for them:
+//   init     acc[4] = conv bias + composite-upsampled aux projection (5 frame taps)
+//   stage 1  acc[4] (4 x 32 gate channels) += W1 (A, LDS) x dilated x taps (B, global/L2)
 //   gate     z = tanh(acc[0..1]) * sigmoid(acc[2..3])   -- stays in the accumulator registers
-//   stage 2  acc2[4] (out 0-31, out 32-63, skip 0-31, skip 32-63) += W2 (A) x z (B)
+//   stage 2  acc2[4] (out 0-31, out 32-63, skip 0-31, skip 32-63) += W2 (A, LDS) x z (B)
 // The K order of stage 2 is permuted on the host so that accumulator register r of
 // stage 1 IS the B operand of k-step r of stage 2 (no data movement between the GEMMs).
 template <bool FIRST>
 __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[KS1 * 64 * 4 + G + R + SK];
-    float* lds_bias = lds + KS1 * 64 * 4;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL];
+    float* lds_bias = lds + LDS_W1 + LDS_W2;
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.w1);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         for (int i = threadIdx.x; i < KS1 * 64; i += 512) dst[i] = src[i];
-        if (threadIdx.x < G + R + SK) lds_bias[threadIdx.x] = a.bias[threadIdx.x];
+        const f32x4* src2 = reinterpret_cast<const f32x4*>(a.w2);
+        f32x4* dst2 = reinterpret_cast<f32x4*>(lds + LDS_W1);
+        for (int i = threadIdx.x; i < KS2 * 64; i += 512) dst2[i] = src2[i];
+        if (threadIdx.x < LDS_BIAS) lds_bias[threadIdx.x] = a.bias[threadIdx.x];
     }
     __syncthreads();
 
@@ -170,37 +192,64 @@ __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
     const long Ttot = a.Ttot;
     const int d = a.dilation;
     const f32x4* lds_a = reinterpret_cast<const f32x4*>(lds) + lane;
-    const f32x4* w2 = reinterpret_cast<const f32x4*>(a.w2) + lane;
+    const f32x4* lds_a2 = reinterpret_cast<const f32x4*>(lds + LDS_W1) + lane;
+    float* lds_p = lds + LDS_W1 + LDS_W2 + LDS_BIAS + wave * LDS_PW;  // wave-private staging
+    const int phase = wave * WAVE_T + j;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long t = (long)a.tile_t0[tile] + wave * WAVE_T + j;
+        const long t = (long)a.tile_t0[tile] + phase;
         const float* xb = a.xin + (long)hi * Ttot + t;   // + 2*cp*Ttot + (tap-1)*d
-        const float* cb = a.c + (long)hi * Ttot + t;     // + 2*ap*Ttot
 
-        // accumulators start from the conv bias
+        // frame-rate aux projection rows f-2..f+2 (UPW x G floats = 160 float4) -> wave-private LDS
+        {
+            const float* prow = a.P + (long)(tile - 2) * a.ldp;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int idx = lane + 64 * it;
+                if (idx < UPW * (G / 4)) {
+                    const int jj = idx >> 5, c4 = idx & 31;
+                    reinterpret_cast<f32x4*>(lds_p)[idx] =
+                        *reinterpret_cast<const f32x4*>(prow + (long)jj * a.ldp + 4 * c4);
+                }
+            }
+        }
+        float uw[UPW];
+        {
+            const float* wrow = a.uptab + ((long)a.tile_cls[tile] * TILE + phase) * UPW_PAD;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
+            uw[0] = w0[0]; uw[1] = w0[1]; uw[2] = w0[2]; uw[3] = w0[3];
+            uw[4] = wrow[4];
+        }
+
+        // accumulators start from conv bias + upsampled aux projection
         f32x16 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_bias + 32 * q + 8 * r4 + 4 * hi);
-                acc[q][4 * r4 + 0] = bv[0];
-                acc[q][4 * r4 + 1] = bv[1];
-                acc[q][4 * r4 + 2] = bv[2];
-                acc[q][4 * r4 + 3] = bv[3];
+                const int co0 = 32 * q + 8 * r4 + 4 * hi;
+                f32x4 v = *reinterpret_cast<const f32x4*>(lds_bias + co0);
+#pragma unroll
+                for (int jj = 0; jj < UPW; ++jj) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(lds_p + jj * G + co0);
+                    v[0] = fmaf(uw[jj], pv[0], v[0]);
+                    v[1] = fmaf(uw[jj], pv[1], v[1]);
+                    v[2] = fmaf(uw[jj], pv[2], v[2]);
+                    v[3] = fmaf(uw[jj], pv[3], v[3]);
+                }
+                acc[q][4 * r4 + 0] = v[0];
+                acc[q][4 * r4 + 1] = v[1];
+                acc[q][4 * r4 + 2] = v[2];
+                acc[q][4 * r4 + 3] = v[3];
             }
 
         // K loop of stage 1 in groups of 8 k-steps; the B values of group g+1 are
         // in flight while group g runs on the matrix pipe (32 MFMAs = 2048 cycles).
         constexpr int GRP = 8;
-        constexpr int NGRP = KS1 / GRP;           // 17 = 12 conv groups + 5 aux groups
-        constexpr int CONV_GRPS = KS_CONV / GRP;  // 12
+        constexpr int NGRP = KS1 / GRP;  // 12: 4 groups of 8 channel pairs per tap
         auto group_ptr = [&](int g) -> const float* {
-            if (g < CONV_GRPS) {
-                const int tap = g >> 2, cg = g & 3;  // 4 groups of 8 channel pairs per tap
-                return xb + (long)(2 * GRP * cg) * Ttot + (long)(tap - 1) * d;
-            }
-            return cb + (long)(2 * GRP * (g - CONV_GRPS)) * Ttot;
+            const int tap = g >> 2, cg = g & 3;
+            return xb + (long)(2 * GRP * cg) * Ttot + (long)(tap - 1) * d;
         };
         float bcur[GRP], bnext[GRP];
         {
@@ -245,32 +294,12 @@ __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
                 acc2[q][4 * r4 + 2] = bv[2];
                 acc2[q][4 * r4 + 3] = bv[3];
             }
-        // 32 k-steps in 8 groups of 4; the A fragments (global, L2-resident) of group
-        // g+1 are in flight while group g computes.  sched_barrier keeps hipcc from
-        // hoisting all 32 loads (128 VGPRs) to the top.
-        {
-            constexpr int G2 = 4;
-            f32x4 wcur[G2], wnext[G2];
 #pragma unroll
-            for (int s = 0; s < G2; ++s) wcur[s] = w2[s * 64];
+        for (int ks = 0; ks < KS2; ++ks) {
+            const f32x4 af = lds_a2[ks * 64];
 #pragma unroll
-            for (int g2 = 0; g2 < KS2 / G2; ++g2) {
-                if (g2 + 1 < KS2 / G2) {
-#pragma unroll
-                    for (int s = 0; s < G2; ++s) wnext[s] = w2[((g2 + 1) * G2 + s) * 64];
-                }
-#pragma unroll
-                for (int s = 0; s < G2; ++s) {
-                    const int ks = g2 * G2 + s;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[s][q], acc[ks >> 4][ks & 15],
-                                                                       acc2[q], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < G2; ++s) wcur[s] = wnext[s];
-            }
+            for (int q = 0; q < 4; ++q)
+                acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], acc[ks >> 4][ks & 15], acc2[q], 0, 0, 0);
         }
 
         // epilogue: res = (out + x_in) * sqrt(0.5) (:314); skips += skip (:468)
@@ -301,7 +330,6 @@ struct PwgLastArgs {
     const int* tile_t0;
     long Ttot;
     float* wav;          // packed (ntiles*TILE)
-    float* skip_scaled;  // optional debug tap [SK][Ttot] (nullptr in production)
 };
 
 __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
@@ -320,9 +348,7 @@ __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
         for (int r = 0; r < 16; ++r) acc[q][r] = a.b1[32 * q + mfma_row(r, hi)];
 #pragma unroll 8
     for (int cp = 0; cp < SK / 2; ++cp) {
-        const float v = sb[(long)(2 * cp) * a.Ttot] * a.scale;
-        if (a.skip_scaled) a.skip_scaled[(long)(2 * cp + hi) * a.Ttot + t] = v;
-        const float bv = fmaxf(v, 0.f);
+        const float bv = fmaxf(sb[(long)(2 * cp) * a.Ttot] * a.scale, 0.f);
         const f32x2 af = w1[cp * 64];
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bv, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bv, acc[1], 0, 0, 0);
@@ -351,17 +377,20 @@ struct pk_pwg {
     bool use_norm = false;
     std::vector<float> h_mu, h_sigma;
     // device weights
-    pk_dbuf d_first_w, d_first_b, d_convin_wT, d_up_w, d_mu, d_sigma;
+    pk_dbuf d_first_w, d_first_b, d_convin_wT, d_uptab, d_mu, d_sigma;
     pk_dbuf d_w1, d_w2, d_bias;     // all layers, concatenated
+    pk_dbuf d_waux;                 // packed GEMM weight [AUX] x [layers*G]
     pk_dbuf d_l1, d_l1b, d_l2;
     float l2_bias = 0.f;
     // workspace
-    pk_dbuf ws_mel, ws_noise, ws_wav, ws_c0, ws_upA, ws_upB, ws_c, ws_x0, ws_x1, ws_skip, ws_dbg;
+    pk_dbuf ws_mel, ws_noise, ws_wav, ws_c0, ws_P, ws_x0, ws_x1, ws_skip, ws_dbg;
     pk_dbuf ws_tab;   // int tables
     // last call layout (for debug reads)
-    std::vector<int> last_frames, last_toff;
+    std::vector<int> last_frames, last_toff, last_cuL;
     long last_Ttot = 0;
     int last_x_final = 0;
+    int last_ldp = 0;
+    size_t last_o_cls = 0;
 };
 
 extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
@@ -381,12 +410,15 @@ extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
                 cfg->gate_channels, cfg->skip_channels, cfg->aux_channels);
     if (cfg->n_upsample < 1 || cfg->n_upsample > 8) PK_FAIL(PK_EINVAL, "PWGGenerator: 1..8 upsample scales");
     int hop = 1;
+    double reach = 0.0;  // of the composite upsampler, in frames
     for (int i = 0; i < cfg->n_upsample; ++i) {
         int s = cfg->upsample_scales[i];
         if (s < 1 || 2 * s + 1 > MAX_UP_TAPS) PK_FAIL(PK_EUNSUPPORTED, "upsample scale %d unsupported", s);
         hop *= s;
+        reach += (double)s / hop;
     }
     if (hop != TILE) PK_FAIL(PK_EUNSUPPORTED, "prod(upsample_scales) must be %d (got %d)", TILE, hop);
+    if (reach >= 2.0) PK_FAIL(PK_EUNSUPPORTED, "upsample scales reach %.2f frames (>= 2)", reach);
     if (cfg->aux_context_window < 0 || cfg->aux_context_window > 8)
         PK_FAIL(PK_EINVAL, "aux_context_window out of range");
     int lps = cfg->layers / cfg->stacks;
@@ -425,6 +457,26 @@ extern "C" int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* si
     return PK_OK;
 }
 
+// UpsampleNet on a host vector (one channel): [stretch by s, FIR(2s+1) with zero padding s] per stage.
+static std::vector<double> upsample_sim(std::vector<double> x, const pk_pwg_cfg& c,
+                                        const std::vector<std::vector<double>>& firs) {
+    for (int i = 0; i < c.n_upsample; ++i) {
+        const int s = c.upsample_scales[i];
+        const long n = (long)x.size() * s;
+        std::vector<double> y(n, 0.0);
+        for (long t = 0; t < n; ++t) {
+            double acc = 0.0;
+            for (int j = 0; j <= 2 * s; ++j) {
+                const long u = t + j - s;
+                if (u >= 0 && u < n) acc += firs[i][j] * x[u / s];
+            }
+            y[t] = acc;
+        }
+        x.swap(y);
+    }
+    return x;
+}
+
 extern "C" int pk_pwg_finalize(pk_pwg* h) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_finalize: handle is NULL");
     pk_ctx* ctx = h->ctx;
@@ -447,21 +499,38 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                     wT[((size_t)ci * kin + tap) * AUX + co] = w[((size_t)co * AUX + ci) * kin + tap];
         PK_TRY(pk_upload(ctx, h->d_convin_wT, wT.data(), wT.size() * sizeof(float)));
     }
-    // upsample FIRs: up_layers.{2i+1}.weight (1,1,1,2s+1)
+    // composite upsampler table from the stage FIRs up_layers.{2i+1}.weight (1,1,1,2s+1):
+    // class (a, b) = (min(frames before, 2), min(frames after, 2)); a canonical utterance with exactly
+    // a frames before and b after reproduces the zero-padding behaviour at that distance from the edges
+    // (the composite reach is < 2 frames), impulse responses give the weights.
     {
-        std::vector<float> up((size_t)c.n_upsample * MAX_UP_TAPS, 0.f);
+        std::vector<std::vector<double>> firs(c.n_upsample);
         for (int i = 0; i < c.n_upsample; ++i) {
             int taps = 2 * c.upsample_scales[i] + 1;
             PK_TRY(pk_get_weight(h->params, "upsample_net.upsample.up_layers." + std::to_string(2 * i + 1),
                                  {1, 1, 1, taps}, w));
-            for (int j = 0; j < taps; ++j) up[(size_t)i * MAX_UP_TAPS + j] = w[j];
+            firs[i].assign(w.begin(), w.begin() + taps);
         }
-        PK_TRY(pk_upload(ctx, h->d_up_w, up.data(), up.size() * sizeof(float)));
+        std::vector<float> tab((size_t)N_EDGE_CLASS * TILE * UPW_PAD, 0.f);
+        for (int a = 0; a <= 2; ++a)
+            for (int bb = 0; bb <= 2; ++bb) {
+                const int Lc = a + bb + 1, fc = a, cls = a * 3 + bb;
+                for (int fi = 0; fi < Lc; ++fi) {
+                    std::vector<double> imp(Lc, 0.0);
+                    imp[fi] = 1.0;
+                    std::vector<double> y = upsample_sim(imp, c, firs);
+                    const int jj = fi - fc + 2;  // tap index of frame fi in the window fc-2..fc+2
+                    for (int p = 0; p < TILE; ++p)
+                        tab[((size_t)cls * TILE + p) * UPW_PAD + jj] = (float)y[(size_t)fc * TILE + p];
+                }
+            }
+        PK_TRY(pk_upload(ctx, h->d_uptab, tab.data(), tab.size() * sizeof(float)));
     }
-    // residual blocks -> MFMA A-fragment layouts
+    // residual blocks -> MFMA A-fragment layouts; aux 1x1 convs -> one frame-rate GEMM weight
     {
         const size_t n1 = (size_t)KS1 * 64 * 4, n2 = (size_t)KS2 * 64 * 4, nb = G + R + SK;
         std::vector<float> W1(n1 * c.layers), W2(n2 * c.layers), B(nb * c.layers);
+        std::vector<float> Wa((size_t)AUX * c.layers * G);   // [K = aux ch][N = layer*G + co]
         std::vector<float> wc, wa, wo, ws, bc, bo, bs;
         for (int l = 0; l < c.layers; ++l) {
             const std::string p = "conv_layers." + std::to_string(l);
@@ -476,19 +545,13 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
             for (int ks = 0; ks < KS1; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 31, hi = lane >> 5;
-                    for (int q = 0; q < 4; ++q) {
-                        const int co = 32 * q + i;
-                        float v;
-                        if (ks < KS_CONV) {
-                            const int tap = ks / (R / 2), ci = 2 * (ks % (R / 2)) + hi;
-                            v = wc[((size_t)co * R + ci) * KTAP + tap];
-                        } else {
-                            const int ca = 2 * (ks - KS_CONV) + hi;
-                            v = wa[(size_t)co * AUX + ca];
-                        }
-                        a1[((size_t)ks * 64 + lane) * 4 + q] = v;
-                    }
+                    const int tap = ks / (R / 2), ci = 2 * (ks % (R / 2)) + hi;
+                    for (int q = 0; q < 4; ++q)
+                        a1[((size_t)ks * 64 + lane) * 4 + q] = wc[((size_t)(32 * q + i) * R + ci) * KTAP + tap];
                 }
+            for (int ca = 0; ca < AUX; ++ca)
+                for (int co = 0; co < G; ++co)
+                    Wa[(size_t)ca * c.layers * G + (size_t)l * G + co] = wa[(size_t)co * AUX + ca];
             float* a2 = W2.data() + n2 * l;
             for (int zq = 0; zq < 2; ++zq)
                 for (int r = 0; r < 16; ++r)
@@ -509,6 +572,9 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         PK_TRY(pk_upload(ctx, h->d_w1, W1.data(), W1.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_w2, W2.data(), W2.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_bias, B.data(), B.size() * sizeof(float)));
+        std::vector<float> packed;
+        pk_gemm_pack(Wa.data(), AUX, c.layers * G, packed);
+        PK_TRY(pk_upload(ctx, h->d_waux, packed.data(), packed.size() * sizeof(float)));
     }
     // last layers
     {
@@ -561,10 +627,10 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     if (Ttot >= (1L << 31)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
     h->last_frames.assign(frames, frames + B);
     h->last_toff = toff;
+    h->last_cuL = cuL;
     h->last_Ttot = Ttot;
 
-    // int tables: [cuL (B+1)] [toff (B)] [gap_start (B+1)] [frame_utt (sumL)] [tile_t0 (sumL)]
-    //             per upsample stage: in_off (B), in_len (B), out_off (B)
+    // int tables: [cuL (B+1)] [gap_start (B+1)] [frame_utt (sumL)] [tile_t0 (sumL)] [tile_cls (sumL)]
     std::vector<int> tab;
     auto push = [&](const std::vector<int>& v) {
         size_t o = tab.size();
@@ -572,31 +638,16 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         return o;
     };
     const size_t o_cuL = push(cuL), o_gap = push(gap_start);
-    std::vector<int> frame_utt(sumL), tile_t0(sumL);
+    std::vector<int> frame_utt(sumL), tile_t0(sumL), tile_cls(sumL);
     for (int b = 0; b < B; ++b)
         for (int f = 0; f < frames[b]; ++f) {
             frame_utt[cuL[b] + f] = b;
             tile_t0[cuL[b] + f] = toff[b] + f * hop;
+            const int before = f < 2 ? f : 2, after = (frames[b] - 1 - f) < 2 ? (frames[b] - 1 - f) : 2;
+            tile_cls[cuL[b] + f] = before * 3 + after;
         }
-    const size_t o_futt = push(frame_utt), o_tile = push(tile_t0);
-    std::vector<size_t> o_inoff(c.n_upsample), o_inlen(c.n_upsample), o_outoff(c.n_upsample);
-    {
-        int m = 1;
-        for (int i = 0; i < c.n_upsample; ++i) {
-            std::vector<int> in_off(B), in_len(B), out_off(B);
-            const int s = c.upsample_scales[i];
-            const bool last = (i == c.n_upsample - 1);
-            for (int b = 0; b < B; ++b) {
-                in_off[b] = cuL[b] * m;
-                in_len[b] = frames[b] * m;
-                out_off[b] = last ? toff[b] : cuL[b] * m * s;
-            }
-            o_inoff[i] = push(in_off);
-            o_inlen[i] = push(in_len);
-            o_outoff[i] = push(out_off);
-            m *= s;
-        }
-    }
+    const size_t o_futt = push(frame_utt), o_tile = push(tile_t0), o_cls = push(tile_cls);
+    h->last_o_cls = o_cls;
     PK_TRY(h->ws_tab.reserve(tab.size() * sizeof(int)));
     PK_HIP(hipMemcpyAsync(h->ws_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     PK_HIP(hipStreamSynchronize(ctx->stream));  // tab is a stack vector
@@ -616,53 +667,45 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         d_noise = h->ws_noise.as<float>();
         d_wav = h->ws_wav.as<float>();
     }
-    PK_TRY(h->ws_c0.reserve((size_t)AUX * sumL * 4));
-    {
-        long inter = 1, m = 1;  // largest intermediate stage output per channel
-        for (int i = 0; i + 1 < c.n_upsample; ++i) {
-            m *= c.upsample_scales[i];
-            inter = m > inter ? m : inter;
-        }
-        PK_TRY(h->ws_upA.reserve((size_t)AUX * sumL * inter * 4));
-        PK_TRY(h->ws_upB.reserve((size_t)AUX * sumL * inter * 4));
-    }
-    PK_TRY(h->ws_c.reserve((size_t)AUX * Ttot * 4));
+    const int rows_alloc = ((sumL + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM;
+    const int ldp = c.layers * G;
+    h->last_ldp = ldp;
+    PK_TRY(h->ws_c0.reserve((size_t)(rows_alloc + 2 * P_LEAD) * AUX * 4));
+    PK_TRY(h->ws_P.reserve((size_t)(rows_alloc + 2 * P_LEAD) * ldp * 4));
     PK_TRY(h->ws_x0.reserve((size_t)R * Ttot * 4));
     PK_TRY(h->ws_x1.reserve((size_t)R * Ttot * 4));
     PK_TRY(h->ws_skip.reserve((size_t)SK * Ttot * 4));
+    float* c0 = h->ws_c0.as<float>() + (size_t)P_LEAD * AUX;
+    float* P = h->ws_P.as<float>() + (size_t)P_LEAD * ldp;
 
-    // ---- zero the gaps of both ping-pong buffers
+    // ---- zero the gaps of both ping-pong buffers and the margins of P (read with zero weights)
     {
         dim3 grid(pk_div_up(gap, 256), B + 1, R);
         PK_LAUNCH(ctx, "pwg_zero_gaps", k_zero_gaps, grid, dim3(256), 0, h->ws_x0.as<float>(), d_tab + o_gap,
                   gap, R, Ttot);
         PK_LAUNCH(ctx, "pwg_zero_gaps", k_zero_gaps, grid, dim3(256), 0, h->ws_x1.as<float>(), d_tab + o_gap,
                   gap, R, Ttot);
+        PK_HIP(hipMemsetAsync(h->ws_P.p, 0, (size_t)P_LEAD * ldp * 4, ctx->stream));
+        PK_HIP(hipMemsetAsync(P + (size_t)sumL * ldp, 0, (size_t)(rows_alloc - sumL + P_LEAD) * ldp * 4, ctx->stream));
     }
-    // ---- conditioning: conv_in + upsample stages
+    // ---- conditioning at frame rate: conv_in, then all layers' aux 1x1 convs as one GEMM
     {
         const int kin = 2 * c.aux_context_window + 1;
         PK_LAUNCH(ctx, "pwg_convin", k_pwg_convin, dim3(sumL), dim3(128), kin * AUX * sizeof(float), d_mel,
                   h->d_convin_wT.as<float>(), h->d_mu.as<float>(), h->d_sigma.as<float>(),
-                  h->use_norm ? 1 : 0, d_tab + o_futt, d_tab + o_cuL, c.aux_context_window, sumL,
-                  h->ws_c0.as<float>());
-        const float* in = h->ws_c0.as<float>();
-        long in_stride = sumL;
-        int m = 1, maxL = 0;
-        for (int b = 0; b < B; ++b) maxL = frames[b] > maxL ? frames[b] : maxL;
-        for (int i = 0; i < c.n_upsample; ++i) {
-            const int s = c.upsample_scales[i];
-            const bool last = (i == c.n_upsample - 1);
-            float* out = last ? h->ws_c.as<float>() : ((i & 1) ? h->ws_upB.as<float>() : h->ws_upA.as<float>());
-            const long out_stride = last ? Ttot : (long)sumL * m * s;
-            dim3 grid(pk_div_up((long)maxL * m * s, 256), AUX, B);
-            PK_LAUNCH(ctx, "pwg_upsample", k_pwg_upsample, grid, dim3(256), 0, in, in_stride,
-                      d_tab + o_inoff[i], d_tab + o_inlen[i], out, out_stride, d_tab + o_outoff[i], s,
-                      h->d_up_w.as<float>() + (size_t)i * MAX_UP_TAPS);
-            in = out;
-            in_stride = out_stride;
-            m *= s;
-        }
+                  h->use_norm ? 1 : 0, d_tab + o_futt, d_tab + o_cuL, c.aux_context_window, c0);
+        pk_gemm_args g;
+        g.A = c0;
+        g.lda = AUX;
+        g.Wp = h->d_waux.as<float>();
+        g.C = P;
+        g.ldc = ldp;
+        g.M = sumL;
+        g.N = ldp;
+        g.Cin = AUX;
+        g.taps = 1;
+        g.pad = 0;
+        PK_TRY(pk_gemm_launch(ctx, "pwg_aux_gemm", g));
     }
     // ---- first conv
     PK_LAUNCH(ctx, "pwg_first", k_pwg_first, dim3(sumL), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
@@ -675,13 +718,16 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             PwgLayerArgs a;
             a.xin = (l & 1) ? h->ws_x1.as<float>() : h->ws_x0.as<float>();
             a.xout = (l & 1) ? h->ws_x0.as<float>() : h->ws_x1.as<float>();
-            a.c = h->ws_c.as<float>();
             a.skip = h->ws_skip.as<float>();
             a.w1 = h->d_w1.as<float>() + (size_t)l * KS1 * 64 * 4;
             a.w2 = h->d_w2.as<float>() + (size_t)l * KS2 * 64 * 4;
             a.bias = h->d_bias.as<float>() + (size_t)l * (G + R + SK);
+            a.P = P + (size_t)l * G;
+            a.uptab = h->d_uptab.as<float>();
             a.tile_t0 = d_tab + o_tile;
+            a.tile_cls = d_tab + o_cls;
             a.Ttot = Ttot;
+            a.ldp = ldp;
             a.ntiles = sumL;
             a.dilation = 1 << (l % lps);
             if (l == 0)
@@ -703,7 +749,6 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         a.tile_t0 = d_tab + o_tile;
         a.Ttot = Ttot;
         a.wav = d_wav;
-        a.skip_scaled = nullptr;
         PK_LAUNCH(ctx, "pwg_last", k_pwg_last, dim3(sumL), dim3(512), 0, a);
     }
     if (flags & PK_HOST_IO) {
@@ -720,10 +765,22 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
     pk_ctx* ctx = h->ctx;
     PK_HIP(hipSetDevice(ctx->device));
     const long S = (long)h->last_frames[b] * h->hop;
+    if (what == 0) {
+        // sample-rate aux contribution of layer 0: conv1x1_aux(upsample_net(c)) (G, S_b), recomputed
+        if (n_floats != (int64_t)G * S) PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats", (long)G * S);
+        PK_TRY(h->ws_dbg.reserve((size_t)G * S * 4));
+        const float* P = h->ws_P.as<float>() + (size_t)P_LEAD * h->last_ldp;
+        dim3 grid(h->last_frames[b], G);
+        PK_LAUNCH(ctx, "pwg_aux_debug", k_pwg_aux_debug, grid, dim3(TILE), 0, P, h->last_ldp, 0,
+                  h->d_uptab.as<float>(), h->ws_tab.as<int>() + h->last_o_cls, h->last_cuL[b], h->last_frames[b],
+                  h->ws_dbg.as<float>());
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+        PK_HIP(hipMemcpy(host_out, h->ws_dbg.p, (size_t)G * S * 4, hipMemcpyDeviceToHost));
+        return PK_OK;
+    }
     const float* src;
     int rows;
     switch (what) {
-        case 0: src = h->ws_c.as<float>(); rows = AUX; break;
         case 1: src = h->last_x_final ? h->ws_x1.as<float>() : h->ws_x0.as<float>(); rows = R; break;
         case 2: src = h->ws_skip.as<float>(); rows = SK; break;
         default: PK_FAIL(PK_EINVAL, "pk_pwg_debug_read: unknown tap %d", what);
@@ -740,9 +797,9 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
     if (!h) return;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_up_w, &h->d_mu, &h->d_sigma,
-                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_l1, &h->d_l1b, &h->d_l2,
-                       &h->ws_mel, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_upA, &h->ws_upB, &h->ws_c,
+    pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_uptab, &h->d_mu, &h->d_sigma,
+                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_waux, &h->d_l1, &h->d_l1b, &h->d_l2,
+                       &h->ws_mel, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
                        &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab};
     for (auto* b : bufs) b->release();
     delete h;

@@ -142,7 +142,7 @@ class PWGGenerator:
         return self.inference_batch([c], None if noise is None else [noise])[0]
 
     def debug_tap(self, what, b):
-        rows = {0: self.aux_channels, 1: 64, 2: 64}[what]
+        rows = {0: 128, 1: 64, 2: 64}[what]
         # frames of utterance b are known to the engine; size is validated there
         n = self._last_frames[b] * self.upsample_factor
         out = np.empty((rows, n), dtype=np.float32)
