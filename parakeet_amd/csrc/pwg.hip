@@ -197,8 +197,11 @@ __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
     const int phase = wave * WAVE_T + j;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long t = (long)a.tile_t0[tile] + phase;
-        const float* xb = a.xin + (long)hi * Ttot + t;   // + 2*cp*Ttot + (tap-1)*d
+        // addresses = wave-uniform row pointer (SGPR pair) + one 32-bit per-lane element offset,
+        // so a load costs no address VGPRs: lane offset = (hi-dependent row) * Ttot + t
+        const unsigned t = (unsigned)a.tile_t0[tile] + (unsigned)phase;
+        const unsigned vo1 = (unsigned)hi * (unsigned)Ttot + t;       // B operand rows 2*cp + hi
+        const unsigned vo4 = 4u * (unsigned)hi * (unsigned)Ttot + t;  // result rows mfma_row(r, hi)
 
         // frame-rate aux projection rows f-2..f+2 (UPW x G floats = 160 float4) -> wave-private LDS
         {
@@ -243,37 +246,59 @@ __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
                 acc[q][4 * r4 + 3] = v[3];
             }
 
-        // K loop of stage 1 in groups of 8 k-steps; the B values of group g+1 are
-        // in flight while group g runs on the matrix pipe (32 MFMAs = 2048 cycles).
+        // K loop of stage 1: 12 groups of 8 k-steps (4 groups of 8 channel pairs per tap), two
+        // register sets in ping-pong: the B values of group g+1 are issued BEFORE group g's 32
+        // MFMAs (2048 matrix-pipe cycles) and first touched after them.  The sched_barriers pin
+        // that order -- left alone, hipcc sinks the loads to just before their use and every
+        // group eats a full memory round trip (measured: SQ_WAIT_ANY 54 % of wave cycles).
         constexpr int GRP = 8;
-        constexpr int NGRP = KS1 / GRP;  // 12: 4 groups of 8 channel pairs per tap
-        auto group_ptr = [&](int g) -> const float* {
+        constexpr int NGRP = KS1 / GRP;  // 12
+        auto group_ptr = [&](int g) -> const float* {   // wave-uniform
             const int tap = g >> 2, cg = g & 3;
-            return xb + (long)(2 * GRP * cg) * Ttot + (long)(tap - 1) * d;
+            return a.xin + (long)(2 * GRP * cg) * Ttot + (long)(tap - 1) * d;
         };
-        float bcur[GRP], bnext[GRP];
+        float bA[GRP], bB[GRP];
         {
             const float* p = group_ptr(0);
 #pragma unroll
-            for (int s = 0; s < GRP; ++s) bcur[s] = p[(long)(2 * s) * Ttot];
+            for (int s = 0; s < GRP; ++s) bA[s] = (p + (long)(2 * s) * Ttot)[vo1];
         }
 #pragma unroll 1
-        for (int g = 0; g < NGRP; ++g) {
+        for (int gg = 0; gg < NGRP / 2; ++gg) {
             {
-                const float* p = group_ptr(g + 1 < NGRP ? g + 1 : g);
+                const float* p = group_ptr(2 * gg + 1);
 #pragma unroll
-                for (int s = 0; s < GRP; ++s) bnext[s] = p[(long)(2 * s) * Ttot];
+                for (int s = 0; s < GRP; ++s) bB[s] = (p + (long)(2 * s) * Ttot)[vo1];
             }
-            const f32x4* la = lds_a + (long)g * GRP * 64;
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const f32x4* la = lds_a + (long)(2 * gg) * GRP * 64;
 #pragma unroll
-            for (int s = 0; s < GRP; ++s) {
-                const f32x4 af = la[s * 64];
+                for (int s = 0; s < GRP; ++s) {
+                    const f32x4 af = la[s * 64];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bcur[s], acc[q], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bA[s], acc[q], 0, 0, 0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float* p = group_ptr(2 * gg + 2 < NGRP ? 2 * gg + 2 : 0);
 #pragma unroll
-            for (int s = 0; s < GRP; ++s) bcur[s] = bnext[s];
+                for (int s = 0; s < GRP; ++s) bA[s] = (p + (long)(2 * s) * Ttot)[vo1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const f32x4* la = lds_a + (long)(2 * gg + 1) * GRP * 64;
+#pragma unroll
+                for (int s = 0; s < GRP; ++s) {
+                    const f32x4 af = la[s * 64];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bB[s], acc[q], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // gated activation; z overwrites acc[0], acc[1]
@@ -281,6 +306,20 @@ __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = gated(acc[q][r], acc[q + 2][r]);
+
+        // residual input and running skip sum of this wave's 64 x 32 outputs: issued now, consumed
+        // after stage 2 (the pointers may alias as far as hipcc knows, so a load placed next to its
+        // store would be serialised: 64 dependent round trips per tile).
+        float x_old[32], s_old[32];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long rowoff = (long)(32 * q + mfma_row(r, 0)) * Ttot;   // wave-uniform
+                x_old[16 * q + r] = (a.xin + rowoff)[vo4];
+                if (!FIRST) s_old[16 * q + r] = (a.skip + rowoff)[vo4];
+            }
+        __builtin_amdgcn_sched_barrier(0);
 
         // stage 2: out / skip 1x1 convs, accumulators start from their biases
         f32x16 acc2[4];
@@ -301,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
             for (int q = 0; q < 4; ++q)
                 acc2[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], acc[ks >> 4][ks & 15], acc2[q], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
 
         // epilogue: res = (out + x_in) * sqrt(0.5) (:314); skips += skip (:468)
         const float rs = 0.70710678118654752440f;
@@ -308,12 +348,9 @@ __global__ __launch_bounds__(512, 2) void k_pwg_layer(PwgLayerArgs a) {
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long off = (long)(32 * q + mfma_row(r, hi)) * Ttot + t;
-                a.xout[off] = (acc2[q][r] + a.xin[off]) * rs;
-                if (FIRST)
-                    a.skip[off] = acc2[2 + q][r];
-                else
-                    a.skip[off] += acc2[2 + q][r];
+                const long rowoff = (long)(32 * q + mfma_row(r, 0)) * Ttot;   // wave-uniform
+                (a.xout + rowoff)[vo4] = (acc2[q][r] + x_old[16 * q + r]) * rs;
+                (a.skip + rowoff)[vo4] = FIRST ? acc2[2 + q][r] : (s_old[16 * q + r] + acc2[2 + q][r]);
             }
     }
 }
@@ -624,7 +661,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     const long Ttot = t;
     const int sumL = cuL[B];
     const long sumS = (long)sumL * hop;
-    if (Ttot >= (1L << 31)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
+    // kernels address with 32-bit per-lane byte offsets of up to 5 rows of the timeline
+    if (Ttot * 5 * 4 >= (1L << 32)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
     h->last_frames.assign(frames, frames + B);
     h->last_toff = toff;
     h->last_cuL = cuL;

@@ -1,0 +1,24 @@
+"""One PWG (or e2e) pass for rocprofv3 --pmc collection.  usage: pmc_run.py [pwg|e2e] [B]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from parakeet_amd import synthetic as syn
+mode = sys.argv[1] if len(sys.argv) > 1 else "pwg"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+L = 640
+if mode == "pwg":
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    gen = PWGGenerator(**syn.PWG_LJSPEECH); gen.set_state_dict(syn.pwg_state()); gen.eval()
+    rng = np.random.default_rng(42)
+    mels = [torch.tensor(rng.normal(size=(L, 80)).astype(np.float32)).cuda() for _ in range(B)]
+    noises = [torch.randn(L * 256, device="cuda") for _ in range(B)]
+    gen.inference_batch(mels, noises)
+    torch.cuda.synchronize()
+else:
+    sys.argv = [sys.argv[0]]
+    import bench
+    synth, *_ = bench.build_models(0)
+    texts = [syn.phoneme_ids(128, seed=i) for i in range(B)]
+    noise = torch.randn(B * L * 256, device="cuda")
+    synth.synthesize_packed(texts, noise=noise)
+    torch.cuda.synchronize()

@@ -1,3 +1,4 @@
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, numpy as np, torch
 from parakeet_amd import synthetic as syn
 from parakeet_amd.fastspeech2 import FastSpeech2
