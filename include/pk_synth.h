@@ -53,7 +53,12 @@ typedef enum {
     PK_ESTATE = -6         /* call order (e.g. not finalized) -> RuntimeError        */
 } pk_status;
 
-enum { PK_HOST_IO = 1 };   /* flags bit: data pointers are host memory */
+enum {
+    PK_HOST_IO = 1,            /* flags bit: data pointers are host memory */
+    PK_PWG_C_HAS_CONTEXT = 2   /* pk_pwg_infer: mel rows already carry aux_context_window frames on both
+                                  sides of every utterance (PWGGenerator.forward); default: the engine
+                                  replicate-pads (PWGGenerator.inference) */
+};
 
 typedef struct pk_ctx pk_ctx;
 typedef struct pk_pwg pk_pwg;
@@ -112,6 +117,7 @@ int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_
 int pk_pwg_finalize(pk_pwg* h);
 /* PWGGenerator.inference for a packed batch.
  *   mel    (sum(frames), aux_channels) float32, row-major, packed by utterance
+ *          (with PK_PWG_C_HAS_CONTEXT: frames[b] + 2*ctx rows per utterance)
  *   frames (B) host int32, frames per utterance (>= 1)
  *   noise  (sum(frames)*hop) float32 packed; the x = randn(...) of :515-516,
  *          passed in so that results are reproducible

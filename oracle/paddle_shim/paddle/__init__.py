@@ -1,0 +1,271 @@
+"""Stand-in for ``paddle`` on torch-CPU (see oracle/paddle_shim/__init__.py)."""
+import contextlib
+
+import numpy as np
+import torch
+
+float32 = torch.float32
+float64 = torch.float64
+float16 = torch.float16
+int64 = torch.int64
+int32 = torch.int32
+bool = torch.bool  # noqa: A001  (paddle.bool)
+
+_DTYPES = {"float32": torch.float32, "float64": torch.float64, "float16": torch.float16,
+           "int64": torch.int64, "int32": torch.int32, "bool": torch.bool}
+_default_dtype = "float32"
+
+
+def _dt(d):
+    if d is None:
+        return None
+    if isinstance(d, str):
+        return _DTYPES[d]
+    if isinstance(d, np.dtype) or (isinstance(d, type) and issubclass(d, np.generic)):
+        return _DTYPES[np.dtype(d).name]
+    return d
+
+
+class Tensor(torch.Tensor):
+    """torch.Tensor with paddle's method conventions where they differ."""
+
+    @property
+    def shape(self):
+        return list(torch.Tensor.size(self))
+
+    @property
+    def place(self):
+        return "cpu"
+
+    def numpy(self):
+        return torch.Tensor.numpy(self.detach().as_subclass(torch.Tensor))
+
+    def transpose(self, *perm, **kw):
+        if "perm" in kw:
+            perm = (kw["perm"],)
+        if len(perm) == 1 and isinstance(perm[0], (list, tuple)):
+            return self.permute(*perm[0])
+        return torch.Tensor.transpose(self, *perm)
+
+    def cast(self, dtype):
+        return self.to(_dt(dtype))
+
+    astype = cast
+
+    def expand(self, *shape, **kw):
+        if "shape" in kw:
+            shape = tuple(kw["shape"])
+        elif len(shape) == 1 and isinstance(shape[0], (list, tuple)):
+            shape = tuple(shape[0])
+        return torch.Tensor.expand(self, *shape)
+
+
+def _wrap(t):
+    return t.as_subclass(Tensor) if isinstance(t, torch.Tensor) else t
+
+
+def to_tensor(data, dtype=None, place=None, stop_gradient=True):
+    if isinstance(data, torch.Tensor):
+        t = data.clone()
+    else:
+        arr = np.asarray(data)
+        if arr.dtype == np.float64 and dtype is None and not isinstance(data, np.ndarray):
+            arr = arr.astype(np.float32)  # python floats -> default dtype
+        t = torch.from_numpy(np.ascontiguousarray(arr)) if arr.ndim else torch.tensor(arr.item())
+        if arr.ndim == 0 and isinstance(data, float) and dtype is None:
+            t = t.to(torch.float32)
+    if dtype is not None:
+        t = t.to(_dt(dtype))
+    return _wrap(t)
+
+
+def cast(x, dtype):
+    return _wrap(x.to(_dt(dtype)))
+
+
+def get_default_dtype():
+    return _default_dtype
+
+
+def shape(x):
+    return list(torch.Tensor.size(x))
+
+
+def _shape_arg(s):
+    return [int(v) for v in s]
+
+
+def zeros(shape, dtype=None):
+    return _wrap(torch.zeros(_shape_arg(shape), dtype=_dt(dtype) or torch.float32))
+
+
+def ones(shape, dtype=None):
+    return _wrap(torch.ones(_shape_arg(shape), dtype=_dt(dtype) or torch.float32))
+
+
+def full(shape, fill_value, dtype=None):
+    return _wrap(torch.full(_shape_arg(shape), fill_value, dtype=_dt(dtype) or torch.float32))
+
+
+def zeros_like(x, dtype=None):
+    return _wrap(torch.zeros_like(x, dtype=_dt(dtype)))
+
+
+def ones_like(x, dtype=None):
+    return _wrap(torch.ones_like(x, dtype=_dt(dtype)))
+
+
+def randn(shape, dtype=None):
+    return _wrap(torch.randn(_shape_arg(shape), dtype=_dt(dtype) or torch.float32))
+
+
+def arange(start=0, end=None, step=1, dtype=None):
+    if end is None:
+        start, end = 0, start
+    d = _dt(dtype)
+    if d is None:
+        d = torch.float32 if any(isinstance(v, float) for v in (start, end, step)) else torch.int64
+    return _wrap(torch.arange(start, end, step, dtype=d))
+
+
+def expand(x, shape):
+    return _wrap(torch.Tensor.expand(x, *shape))
+
+
+def transpose(x, perm):
+    return _wrap(x.permute(*perm))
+
+
+def reshape(x, shape):
+    return _wrap(torch.reshape(x, tuple(shape)))
+
+
+def unsqueeze(x, axis):
+    return _wrap(torch.unsqueeze(x, axis))
+
+
+def squeeze(x, axis=None):
+    return _wrap(torch.squeeze(x) if axis is None else torch.squeeze(x, axis))
+
+
+def concat(xs, axis=0):
+    return _wrap(torch.cat(list(xs), dim=axis))
+
+
+def stack(xs, axis=0):
+    return _wrap(torch.stack(list(xs), dim=axis))
+
+
+def chunk(x, chunks, axis=0):
+    return [_wrap(t) for t in torch.chunk(x, chunks, dim=axis)]
+
+
+def matmul(x, y, transpose_x=False, transpose_y=False):
+    if transpose_x:
+        x = x.transpose(-1, -2) if not isinstance(x, Tensor) else torch.Tensor.transpose(x, -1, -2)
+    if transpose_y:
+        y = torch.Tensor.transpose(y, -1, -2)
+    return _wrap(torch.matmul(x, y))
+
+
+def sum(x, axis=None, keepdim=False):  # noqa: A001
+    return _wrap(torch.sum(x) if axis is None else torch.sum(x, dim=axis, keepdim=keepdim))
+
+
+def where(cond, x, y):
+    return _wrap(torch.where(cond, x, y))
+
+
+def gather(x, index, axis=0):
+    return _wrap(torch.index_select(x, axis, index.to(torch.int64)))
+
+
+def clip(x, min=None, max=None):  # noqa: A002
+    return _wrap(torch.clamp(x, min=min, max=max))
+
+
+def round(x):  # noqa: A001
+    """paddle.round: half away from zero [paddle-semantics]."""
+    return _wrap(torch.sign(x) * torch.floor(torch.abs(x) + 0.5))
+
+
+def exp(x):
+    return _wrap(torch.exp(x))
+
+
+def log(x):
+    return _wrap(torch.log(x))
+
+
+def sqrt(x):
+    return _wrap(torch.sqrt(x))
+
+
+def sin(x):
+    return _wrap(torch.sin(x))
+
+
+def cos(x):
+    return _wrap(torch.cos(x))
+
+
+def tanh(x):
+    return _wrap(torch.tanh(x))
+
+
+def logical_not(x):
+    return _wrap(torch.logical_not(x))
+
+
+def add(x, y):
+    return _wrap(torch.add(x, y))
+
+
+def subtract(x, y):
+    return _wrap(torch.sub(x, y))
+
+
+def multiply(x, y):
+    return _wrap(torch.mul(x, y))
+
+
+def divide(x, y):
+    return _wrap(torch.div(x, y))
+
+
+def broadcast_shape(a, b):
+    return list(torch.broadcast_shapes(tuple(a), tuple(b)))
+
+
+def create_parameter(shape, dtype, default_initializer=None, is_bias=False, attr=None):
+    p = torch.nn.Parameter(torch.zeros(_shape_arg(shape), dtype=_dt(dtype)), requires_grad=False)
+    if default_initializer is not None:
+        default_initializer(p)
+    return p
+
+
+@contextlib.contextmanager
+def no_grad():
+    with torch.no_grad():
+        yield
+
+
+def set_device(*a, **k):
+    return None
+
+
+def seed(s):
+    torch.manual_seed(s)
+
+
+from . import nn  # noqa: E402,F401
+
+
+class _Amp:
+    @staticmethod
+    @contextlib.contextmanager
+    def auto_cast(*a, **k):
+        yield
+
+
+amp = _Amp()

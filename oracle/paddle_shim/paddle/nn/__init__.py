@@ -1,0 +1,265 @@
+"""paddle.nn stand-ins on torch.nn.Module.  Parameter names and array layouts follow Paddle:
+Linear.weight [in, out]; ConvND.weight [Cout, Cin/groups, *k]; BatchNorm buffers ``_mean`` /
+``_variance``; LayerNorm / BatchNorm epsilon 1e-5  [paddle-semantics, from Paddle's API docs]."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from .. import Tensor, _dt, _wrap
+from . import functional  # noqa: F401
+from . import initializer  # noqa: F401
+
+
+def _param(*shape):
+    p = torch.nn.Parameter(torch.empty(*shape), requires_grad=False)
+    with torch.no_grad():
+        if p.dim() >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            p.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        else:
+            p.zero_()
+    return p
+
+
+class Layer(torch.nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def sublayers(self, include_self=False):
+        mods = list(self.modules())
+        return mods if include_self else mods[1:]
+
+    def add_sublayer(self, name, layer):
+        self.add_module(str(name), layer)
+        return layer
+
+    def set_state_dict(self, state):
+        own = dict(self.named_parameters())
+        own.update(dict(self.named_buffers()))
+        missing = [k for k in own if k not in state]
+        extra = [k for k in state if k not in own]
+        assert not missing and not extra, f"state dict mismatch: missing {missing[:5]}, unexpected {extra[:5]}"
+        with torch.no_grad():
+            for k, v in state.items():
+                t = torch.as_tensor(np.asarray(v))
+                assert tuple(t.shape) == tuple(own[k].shape) or t.numel() == own[k].numel(), (k, t.shape, own[k].shape)
+                own[k].copy_(t.reshape(own[k].shape).to(own[k].dtype))
+
+    def __call__(self, *a, **k):
+        return super().__call__(*a, **k)
+
+
+class Linear(Layer):
+    def __init__(self, in_features, out_features, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        self.weight = _param(in_features, out_features)
+        self.bias = None if bias_attr is False else _param(out_features)
+
+    def forward(self, x):
+        y = torch.matmul(x, self.weight)
+        return _wrap(y if self.bias is None else y + self.bias)
+
+
+class _ConvNd(Layer):
+    def _setup(self, cin, cout, k, stride, padding, dilation, groups, bias_attr, transposed=False):
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+        shape = (cin, cout // groups, *k) if transposed else (cout, cin // groups, *k)
+        self.weight = _param(*shape)
+        self.bias = None if bias_attr is False else _param(cout)
+
+
+class Conv1D(_ConvNd):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 padding_mode="zeros", weight_attr=None, bias_attr=None, data_format="NCL"):
+        super().__init__()
+        self._setup(in_channels, out_channels, (kernel_size,), stride, padding, dilation, groups, bias_attr)
+
+    def forward(self, x):
+        return functional.conv1d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v, v)
+
+
+class Conv2D(_ConvNd):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 padding_mode="zeros", weight_attr=None, bias_attr=None, data_format="NCHW"):
+        super().__init__()
+        self._setup(in_channels, out_channels, _pair(kernel_size), _pair(stride), padding, _pair(dilation),
+                    groups, bias_attr)
+
+    def forward(self, x):
+        return functional.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class Conv2DTranspose(_ConvNd):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0,
+                 groups=1, dilation=1, weight_attr=None, bias_attr=None, data_format="NCHW"):
+        super().__init__()
+        self._setup(in_channels, out_channels, _pair(kernel_size), _pair(stride), padding, _pair(dilation),
+                    groups, bias_attr, transposed=True)
+        self.output_padding = output_padding
+
+    def forward(self, x):
+        return functional.conv2d_transpose(x, self.weight, self.bias, self.stride, self.padding,
+                                           self.output_padding, self.dilation, self.groups)
+
+
+class LayerNorm(Layer):
+    def __init__(self, normalized_shape, epsilon=1e-05, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        if isinstance(normalized_shape, int):
+            normalized_shape = (normalized_shape,)
+        self._shape = tuple(normalized_shape)
+        self._eps = epsilon
+        self.weight = torch.nn.Parameter(torch.ones(self._shape), requires_grad=False)
+        self.bias = torch.nn.Parameter(torch.zeros(self._shape), requires_grad=False)
+
+    def forward(self, x):
+        return _wrap(TF.layer_norm(x, self._shape, self.weight, self.bias, self._eps))
+
+
+class BatchNorm1D(Layer):
+    def __init__(self, num_features, momentum=0.9, epsilon=1e-05, weight_attr=None, bias_attr=None,
+                 data_format="NCL", use_global_stats=None, name=None):
+        super().__init__()
+        self._eps = epsilon
+        self.weight = torch.nn.Parameter(torch.ones(num_features), requires_grad=False)
+        self.bias = torch.nn.Parameter(torch.zeros(num_features), requires_grad=False)
+        self.register_buffer("_mean", torch.zeros(num_features))
+        self.register_buffer("_variance", torch.ones(num_features))
+
+    def forward(self, x):
+        assert not self.training, "only eval-mode batch norm is restated"
+        return _wrap(TF.batch_norm(x, self._mean, self._variance, self.weight, self.bias, False, 0.0, self._eps))
+
+
+class Embedding(Layer):
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None, sparse=False, weight_attr=None, name=None):
+        super().__init__()
+        self.weight = _param(num_embeddings, embedding_dim)
+        self._padding_idx = padding_idx if (padding_idx is None or padding_idx >= 0) else num_embeddings + padding_idx
+
+    def forward(self, ids):
+        out = TF.embedding(ids.to(torch.int64), self.weight)
+        if self._padding_idx is not None:  # output rows at padding_idx are zeros [paddle-semantics]
+            out = torch.where((ids == self._padding_idx).unsqueeze(-1), torch.zeros_like(out), out)
+        return _wrap(out)
+
+
+class Dropout(Layer):
+    def __init__(self, p=0.5, axis=None, mode="upscale_in_train", name=None):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return _wrap(TF.dropout(x, self.p, self.training))
+
+
+class ReLU(Layer):
+    def forward(self, x):
+        return _wrap(torch.relu(x))
+
+
+class Tanh(Layer):
+    def forward(self, x):
+        return _wrap(torch.tanh(x))
+
+
+class Sigmoid(Layer):
+    def forward(self, x):
+        return _wrap(torch.sigmoid(x))
+
+
+class LeakyReLU(Layer):
+    def __init__(self, negative_slope=0.01):
+        super().__init__()
+        self.s = negative_slope
+
+    def forward(self, x):
+        return _wrap(TF.leaky_relu(x, self.s))
+
+
+class Softmax(Layer):
+    def __init__(self, axis=-1):
+        super().__init__()
+        self.axis = axis
+
+    def forward(self, x):
+        return _wrap(torch.softmax(x, dim=self.axis))
+
+
+class Pad1D(Layer):
+    def __init__(self, padding, mode="constant", value=0.0, data_format="NCL"):
+        super().__init__()
+        self.padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        self.mode, self.value = mode, value
+
+    def forward(self, x):
+        if self.mode == "constant":
+            return _wrap(TF.pad(x, self.padding, value=self.value))
+        return _wrap(TF.pad(x, self.padding, mode=self.mode))
+
+
+class MSELoss(Layer):
+    pass
+
+
+class L1Loss(Layer):
+    pass
+
+
+class Sequential(torch.nn.Sequential, Layer):
+    def __init__(self, *layers):
+        torch.nn.Sequential.__init__(self, *layers)
+
+
+class LayerList(torch.nn.ModuleList, Layer):
+    def __init__(self, sublayers=None):
+        torch.nn.ModuleList.__init__(self, sublayers)
+
+
+class _Utils:
+    """nn.utils.weight_norm(layer, name='weight', dim=0): weight = g * v / ||v|| with the norm over
+    all axes but `dim`; parameters weight_g (1-D, tests/unit/test_pwg.py:131-132) and weight_v."""
+
+    @staticmethod
+    def weight_norm(layer, name="weight", dim=0):
+        w = getattr(layer, name)
+        del layer._parameters[name]
+        v = torch.nn.Parameter(w.detach().clone(), requires_grad=False)
+        g = torch.nn.Parameter(w.detach().reshape(w.shape[0], -1).norm(dim=1), requires_grad=False)
+        layer.register_parameter(name + "_g", g)
+        layer.register_parameter(name + "_v", v)
+
+        def hook(mod, inputs):
+            vv = getattr(mod, name + "_v")
+            gg = getattr(mod, name + "_g")
+            nrm = vv.reshape(vv.shape[0], -1).norm(dim=1)
+            object.__setattr__(mod, name, vv * (gg / nrm).reshape((-1,) + (1,) * (vv.dim() - 1)))
+
+        layer._wn_hook = layer.register_forward_pre_hook(hook)
+        layer._wn_name = name
+        hook(layer, None)
+        return layer
+
+    @staticmethod
+    def remove_weight_norm(layer, name="weight"):
+        if not hasattr(layer, "_wn_hook"):
+            raise ValueError("weight_norm of '{}' not found in {}".format(name, layer))
+        vv, gg = getattr(layer, name + "_v"), getattr(layer, name + "_g")
+        nrm = vv.reshape(vv.shape[0], -1).norm(dim=1)
+        w = vv * (gg / nrm).reshape((-1,) + (1,) * (vv.dim() - 1))
+        layer._wn_hook.remove()
+        del layer._wn_hook
+        del layer._parameters[name + "_g"], layer._parameters[name + "_v"]
+        if name in layer.__dict__:
+            del layer.__dict__[name]
+        layer.register_parameter(name, torch.nn.Parameter(w.detach(), requires_grad=False))
+        return layer
+
+
+utils = _Utils()

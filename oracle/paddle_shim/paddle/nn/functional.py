@@ -1,0 +1,98 @@
+"""paddle.nn.functional stand-ins (paddle argument conventions -> torch)."""
+import torch
+import torch.nn.functional as TF
+
+from .. import _wrap
+
+
+def _pad2(padding):
+    """paddle conv2d padding: int | [h, w] | [top, bottom, left, right] | 'same'/'valid' (str)."""
+    if isinstance(padding, int):
+        return (padding, padding), None
+    padding = list(padding)
+    if len(padding) == 2:
+        return (padding[0], padding[1]), None
+    if len(padding) == 4:
+        top, bottom, left, right = padding
+        if top == bottom and left == right:
+            return (top, left), None
+        return (0, 0), (left, right, top, bottom)   # explicit pre-pad (torch F.pad order: last dim first)
+    raise ValueError(padding)
+
+
+def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, data_format="NCL"):
+    if isinstance(padding, (list, tuple)):
+        if len(padding) == 1:
+            padding = padding[0]
+        elif len(padding) == 2 and padding[0] != padding[1]:
+            x = TF.pad(x, (padding[0], padding[1]))
+            padding = 0
+        else:
+            padding = padding[0]
+    return _wrap(TF.conv1d(x, weight, bias, stride=stride, padding=padding, dilation=dilation, groups=groups))
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, data_format="NCHW"):
+    pad, pre = _pad2(padding)
+    if pre is not None:
+        x = TF.pad(x, pre)
+    return _wrap(TF.conv2d(x, weight, bias, stride=stride, padding=pad, dilation=dilation, groups=groups))
+
+
+def conv2d_transpose(x, weight, bias=None, stride=1, padding=0, output_padding=0, dilation=1, groups=1):
+    pad, pre = _pad2(padding)
+    assert pre is None
+    return _wrap(TF.conv_transpose2d(x, weight, bias, stride=stride, padding=pad, output_padding=output_padding,
+                                     groups=groups, dilation=dilation))
+
+
+def interpolate(x, size=None, scale_factor=None, mode="nearest", align_corners=False, data_format="NCHW"):
+    assert mode == "nearest"
+    # nearest with an integer scale factor: out[i] = in[i // s]  [paddle-semantics]
+    sf = scale_factor if isinstance(scale_factor, (list, tuple)) else (scale_factor,) * (x.dim() - 2)
+    out = x
+    for d, s in enumerate(sf):
+        s = int(s)
+        if s != 1:
+            out = torch.repeat_interleave(out, s, dim=2 + d)
+    return _wrap(out)
+
+
+def pad(x, pad, mode="constant", value=0.0, data_format="NCHW"):
+    """paddle.nn.functional.pad: for 3-D/4-D/5-D input and len(pad) == 2*(ndim-2), pad is
+    (left, right[, top, bottom[, front, back]]) -- the same order torch uses [paddle-semantics]."""
+    pad = [int(p) for p in pad]
+    if len(pad) == 2 * x.dim():
+        # "pad every dimension, starting from the first" form
+        pairs = [(pad[2 * i], pad[2 * i + 1]) for i in range(x.dim())]
+        flat = []
+        for a, b in reversed(pairs):
+            flat += [a, b]
+        return _wrap(TF.pad(x, flat, mode=mode, value=value))
+    if mode == "constant":
+        return _wrap(TF.pad(x, pad, mode="constant", value=value))
+    return _wrap(TF.pad(x, pad, mode=mode))
+
+
+def dropout(x, p=0.5, training=True, **k):
+    return _wrap(TF.dropout(x, p, training))
+
+
+def sigmoid(x):
+    return _wrap(torch.sigmoid(x))
+
+
+def relu(x):
+    return _wrap(torch.relu(x))
+
+
+def leaky_relu(x, negative_slope=0.01):
+    return _wrap(TF.leaky_relu(x, negative_slope))
+
+
+def softmax(x, axis=-1):
+    return _wrap(torch.softmax(x, dim=axis))
+
+
+def normalize(x, p=2, axis=1, epsilon=1e-12):
+    return _wrap(TF.normalize(x, p=p, dim=axis, eps=epsilon))

@@ -78,7 +78,7 @@ __global__ void k_zero_gaps(float* buf, const int* gap_start, int gap, int rows,
 __global__ void k_pwg_convin(const float* __restrict__ mel, const float* __restrict__ wT,
                              const float* __restrict__ mu, const float* __restrict__ sigma,
                              int use_norm, const int* __restrict__ frame_utt,
-                             const int* __restrict__ cuL, int ctx, float* __restrict__ out) {
+                             const int* __restrict__ cuL, int ctx, int has_ctx, float* __restrict__ out) {
     extern __shared__ float s_in[];  // (2ctx+1) * AUX normalised inputs
     const int f = blockIdx.x;        // global frame index
     const int b = frame_utt[f];
@@ -86,8 +86,14 @@ __global__ void k_pwg_convin(const float* __restrict__ mel, const float* __restr
     const int k = 2 * ctx + 1;
     for (int i = threadIdx.x; i < k * AUX; i += blockDim.x) {
         int tap = i / AUX, ci = i % AUX;
-        int src = f + tap - ctx;
-        src = src < lo ? lo : (src >= hi ? hi - 1 : src);  // replicate padding inside the utterance
+        int src;
+        if (has_ctx) {
+            // forward(x, c): c already carries ctx frames on both sides (:201-216, "valid" conv)
+            src = f + 2 * ctx * b + tap;
+        } else {
+            src = f + tap - ctx;
+            src = src < lo ? lo : (src >= hi ? hi - 1 : src);  // Pad1D(ctx, 'replicate') of inference (:518)
+        }
         float v = mel[(long)src * AUX + ci];
         if (use_norm) v = (v - mu[ci]) / sigma[ci];
         s_in[tap * AUX + ci] = v;
@@ -696,10 +702,11 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     const float* d_noise = noise;
     float* d_wav = wav;
     if (flags & PK_HOST_IO) {
-        PK_TRY(h->ws_mel.reserve((size_t)sumL * AUX * 4));
+        const size_t mel_rows = (size_t)sumL + ((flags & PK_PWG_C_HAS_CONTEXT) ? (size_t)2 * c.aux_context_window * B : 0);
+        PK_TRY(h->ws_mel.reserve(mel_rows * AUX * 4));
         PK_TRY(h->ws_noise.reserve((size_t)sumS * 4));
         PK_TRY(h->ws_wav.reserve((size_t)sumS * 4));
-        PK_HIP(hipMemcpyAsync(h->ws_mel.p, mel, (size_t)sumL * AUX * 4, hipMemcpyHostToDevice, ctx->stream));
+        PK_HIP(hipMemcpyAsync(h->ws_mel.p, mel, mel_rows * AUX * 4, hipMemcpyHostToDevice, ctx->stream));
         PK_HIP(hipMemcpyAsync(h->ws_noise.p, noise, (size_t)sumS * 4, hipMemcpyHostToDevice, ctx->stream));
         d_mel = h->ws_mel.as<float>();
         d_noise = h->ws_noise.as<float>();
@@ -731,7 +738,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         const int kin = 2 * c.aux_context_window + 1;
         PK_LAUNCH(ctx, "pwg_convin", k_pwg_convin, dim3(sumL), dim3(128), kin * AUX * sizeof(float), d_mel,
                   h->d_convin_wT.as<float>(), h->d_mu.as<float>(), h->d_sigma.as<float>(),
-                  h->use_norm ? 1 : 0, d_tab + o_futt, d_tab + o_cuL, c.aux_context_window, c0);
+                  h->use_norm ? 1 : 0, d_tab + o_futt, d_tab + o_cuL, c.aux_context_window,
+                  (flags & PK_PWG_C_HAS_CONTEXT) ? 1 : 0, c0);
         pk_gemm_args g;
         g.A = c0;
         g.lda = AUX;

@@ -137,6 +137,27 @@ class PWGGenerator:
                                          len(frames), dptr(noise), dptr(wav), 0))
         return wav
 
+    def forward(self, x, c):
+        """(N, C_in, T) noise, (N, C_aux, T' + 2*ctx) conditioning -> (N, C_out, T);
+        parallel_wavegan.py:445-472 (the batch form tests/unit/test_pwg.py exercises)."""
+        ctx = Context.get(self._ctx.device)
+        self._finalize()
+        c = ctx.to_device(c)
+        x = ctx.to_device(x)
+        N, _, Tc = c.shape
+        frames_each = Tc - 2 * self.aux_context_window
+        assert x.shape[-1] == frames_each * self.upsample_factor  # assert c.shape[-1] == x.shape[-1] (:462)
+        frames = np.full(N, frames_each, dtype=np.int32)
+        self._last_frames = [int(f) for f in frames]
+        mel = c.transpose(1, 2).contiguous().reshape(-1, self.aux_channels)
+        noise = x.reshape(-1).contiguous()
+        wav = ctx.empty((noise.numel(),))
+        _capi.check(ctx.lib.pk_pwg_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)), N,
+                                         dptr(noise), dptr(wav), _capi.PK_PWG_C_HAS_CONTEXT))
+        return wrap(wav.reshape(N, self.out_channels, -1))
+
+    __call__ = forward
+
     def inference(self, c=None, noise=None):
         """(T', C_aux) -> (T, C_out); parallel_wavegan.py:498-520."""
         return self.inference_batch([c], None if noise is None else [noise])[0]

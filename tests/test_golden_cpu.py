@@ -1,0 +1,37 @@
+"""The oracle against the golden vectors produced by the reference's own Python source run over
+the paddle stand-in (tools/make_golden.py, oracle/paddle_shim).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import fastspeech2_ref as fs2
+from oracle import pwg_ref
+from parakeet_amd import synthetic as syn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_fastspeech2_oracle_matches_reference_source():
+    g = np.load(os.path.join(GOLD, "fastspeech2_ljspeech.npz"))
+    state = syn.fastspeech2_state(80, 80, syn.FS2_LJSPEECH, seed=int(g["seed"]))
+    for i in range(3):
+        mel = fs2.inference(state, g[f"ids{i}"], alpha=float(g[f"alpha{i}"])).numpy()
+        assert mel.shape == g[f"mel{i}"].shape          # same integer durations
+        assert np.abs(mel - g[f"mel{i}"]).max() < 2e-5
+    logmel = fs2.fastspeech2_inference(state, g["mu"], g["sigma"], g["ids0"]).numpy()
+    assert np.abs(logmel - g["logmel0"]).max() < 2e-5
+
+
+def test_pwg_oracle_matches_reference_source():
+    g = np.load(os.path.join(GOLD, "pwg_ljspeech.npz"))
+    state = syn.pwg_state(syn.PWG_LJSPEECH, seed=int(g["seed"]), weight_norm=True)
+    y = pwg_ref.generator_forward(state, torch.from_numpy(g["fwd_x"]), torch.from_numpy(g["fwd_c"])).numpy()
+    assert np.abs(y - g["fwd_y"]).max() < 1e-5 * max(1.0, np.abs(g["fwd_y"]).max())
+    w = pwg_ref.generator_inference(state, torch.from_numpy(g["inf_mel"]), torch.from_numpy(g["inf_noise"])).numpy()
+    assert w.shape == g["inf_wav"].shape
+    assert np.abs(w - g["inf_wav"]).max() < 1e-5
+    logmel = g["inf_mel"] * g["sigma"] + g["mu"]
+    w2 = pwg_ref.pwg_inference(state, g["mu"], g["sigma"], torch.from_numpy(logmel),
+                               torch.from_numpy(g["inf_noise"])).numpy()
+    assert np.abs(w2 - g["pinf_wav"]).max() < 1e-5

@@ -1,0 +1,51 @@
+"""The HIP engine against the golden vectors produced by the reference's own Python source
+(tools/make_golden.py).  /root/reference is not needed at run time."""
+import os
+
+import numpy as np
+import pytest
+
+from parakeet_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_fastspeech2_engine_matches_reference_source():
+    from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
+    from parakeet_amd.normalizer import ZScore
+    g = np.load(os.path.join(GOLD, "fastspeech2_ljspeech.npz"))
+    model = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    model.set_state_dict(syn.fastspeech2_state(80, 80, syn.FS2_LJSPEECH, seed=int(g["seed"])))
+    model.eval()
+    for i in range(3):
+        mel = model.inference(g[f"ids{i}"], alpha=float(g[f"alpha{i}"])).numpy()
+        assert mel.shape == g[f"mel{i}"].shape
+        assert np.abs(mel - g[f"mel{i}"]).mean() < 1e-4     # north_star: mel L1 < 1e-4
+        assert np.abs(mel - g[f"mel{i}"]).max() < 2e-3
+    # ragged batch of all three == the three single-utterance references (alpha 1.0 ones)
+    outs = model.inference_batch([g["ids0"], g["ids1"]])
+    for i, o in enumerate(outs):
+        assert np.abs(o.numpy() - g[f"mel{i}"]).mean() < 1e-4
+    inf = FastSpeech2Inference(ZScore(g["mu"], g["sigma"]), model)
+    assert np.abs(inf(g["ids0"]).numpy() - g["logmel0"]).mean() < 1e-4
+
+
+def test_pwg_engine_matches_reference_source():
+    from parakeet_amd.normalizer import ZScore
+    from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference
+    g = np.load(os.path.join(GOLD, "pwg_ljspeech.npz"))
+    gen = PWGGenerator(**syn.PWG_LJSPEECH)
+    gen.set_state_dict(syn.pwg_state(syn.PWG_LJSPEECH, seed=int(g["seed"]), weight_norm=True))
+    gen.remove_weight_norm()
+    gen.eval()
+    scale = np.abs(g["fwd_y"]).max()
+    y = gen(g["fwd_x"], g["fwd_c"]).numpy()                    # forward(x, c), batch of 2
+    assert y.shape == g["fwd_y"].shape
+    assert np.abs(y - g["fwd_y"]).max() < 1e-4 * scale
+    w = gen.inference(g["inf_mel"], noise=g["inf_noise"]).numpy()
+    assert w.shape == g["inf_wav"].shape
+    assert np.abs(w - g["inf_wav"]).max() < 1e-4 * np.abs(g["inf_wav"]).max()
+    inf = PWGInference(ZScore(g["mu"], g["sigma"]), gen)
+    w2 = inf(g["inf_mel"] * g["sigma"] + g["mu"], noise=g["inf_noise"]).numpy()
+    assert np.abs(w2 - g["pinf_wav"]).max() < 1e-4 * np.abs(g["pinf_wav"]).max()

@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by executing the REFERENCE's own Python source
+(/root/reference/parakeet/models/...) over the torch-backed paddle stand-in
+(oracle/paddle_shim).  Runs only in the build container (needs /root/reference).
+
+Weights are not stored: they are regenerated from seeds by parakeet_amd.synthetic, whose
+state-dict keys the reference classes accept without remapping (set_state_dict asserts
+an exact key match).  Stored: inputs (ids / mel / noise) and the reference outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+ref_import.setup()
+import paddle  # noqa: E402  (the shim)
+
+from parakeet_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(ref_import.ROOT, "tests", "golden")
+
+
+def golden_fastspeech2():
+    fsm = ref_import.load("parakeet.models.fastspeech2.fastspeech2")
+    norm = ref_import.load("parakeet.modules.normalizer")
+    cfg = dict(syn.FS2_LJSPEECH)
+    state = syn.fastspeech2_state(80, 80, cfg, seed=2024)
+    model = fsm.FastSpeech2(idim=80, odim=80, **cfg)
+    model.set_state_dict(state)
+    model.eval()
+    mu, sigma = syn.mel_stats(seed=7)
+    inf = fsm.FastSpeech2Inference(norm.ZScore(paddle.to_tensor(mu), paddle.to_tensor(sigma)), model)
+    inf.eval()
+    out = {"seed": np.array(2024), "mu": mu, "sigma": sigma}
+    for i, (T, alpha) in enumerate([(9, 1.0), (14, 1.0), (11, 1.25)]):
+        ids = syn.phoneme_ids(T, seed=500 + i)
+        with paddle.no_grad():
+            mel = model.inference(paddle.to_tensor(ids), alpha=alpha).numpy()
+        out[f"ids{i}"] = ids
+        out[f"alpha{i}"] = np.array(alpha, np.float32)
+        out[f"mel{i}"] = mel.astype(np.float32)
+    with paddle.no_grad():
+        out["logmel0"] = inf(paddle.to_tensor(out["ids0"])).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fastspeech2_ljspeech.npz"), **out)
+    print("fastspeech2:", {k: v.shape for k, v in out.items() if k.startswith("mel")})
+
+
+def golden_pwg():
+    pw = ref_import.load("parakeet.models.parallel_wavegan.parallel_wavegan")
+    norm = ref_import.load("parakeet.modules.normalizer")
+    cfg = dict(syn.PWG_LJSPEECH)
+    state = syn.pwg_state(cfg, seed=77, weight_norm=True)
+    gen = pw.PWGGenerator(**{k: v for k, v in cfg.items()})
+    gen.set_state_dict(state)
+    gen.remove_weight_norm()
+    gen.eval()
+    rng = np.random.default_rng(5)
+    out = {"seed": np.array(77)}
+    # forward(x, c) on a batch, like tests/unit/test_pwg.py:135-136 (smaller)
+    x = rng.normal(size=(2, 1, 4 * 256)).astype(np.float32)
+    c = rng.normal(size=(2, 80, 4 + 4)).astype(np.float32)
+    with paddle.no_grad():
+        out["fwd_y"] = gen(paddle.to_tensor(x), paddle.to_tensor(c)).numpy().astype(np.float32)
+    out["fwd_x"], out["fwd_c"] = x, c
+    # inference(c) with the in-call randn replaced by a recorded draw
+    mel = rng.normal(size=(3, 80)).astype(np.float32)
+    noise = rng.normal(size=(1, 1, 3 * 256)).astype(np.float32)
+    orig = paddle.randn
+    paddle.randn = lambda shape, dtype=None: paddle.to_tensor(noise.reshape([int(s) for s in shape]))
+    mu, sigma = syn.mel_stats(seed=8)
+    try:
+        with paddle.no_grad():
+            out["inf_wav"] = gen.inference(paddle.to_tensor(mel)).numpy().astype(np.float32)
+            pinf = pw.PWGInference(norm.ZScore(paddle.to_tensor(mu), paddle.to_tensor(sigma)), gen)
+            out["pinf_wav"] = pinf(paddle.to_tensor(mel * sigma + mu)).numpy().astype(np.float32)
+    finally:
+        paddle.randn = orig
+    out["inf_mel"], out["inf_noise"], out["mu"], out["sigma"] = mel, noise.reshape(-1), mu, sigma
+    np.savez_compressed(os.path.join(OUT, "pwg_ljspeech.npz"), **out)
+    print("pwg:", out["fwd_y"].shape, out["inf_wav"].shape)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    golden_fastspeech2()
+    golden_pwg()
+    if "--with-waveflow" in sys.argv or True:
+        try:
+            from make_golden_waveflow import golden_waveflow
+            golden_waveflow(OUT)
+        except ImportError:
+            pass
