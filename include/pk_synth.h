@@ -63,6 +63,7 @@ enum {
 typedef struct pk_ctx pk_ctx;
 typedef struct pk_pwg pk_pwg;
 typedef struct pk_fs2 pk_fs2;
+typedef struct pk_wf pk_wf;
 
 /* ---------------------------------------------------------------- context */
 const char* pk_last_error(void);
@@ -178,6 +179,38 @@ int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags);
 int pk_fs2_set_debug(pk_fs2* h, int32_t on);
 int pk_fs2_debug_read(pk_fs2* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
 void pk_fs2_destroy(pk_fs2* h);
+
+/* --------------------------------------------------------------- WaveFlow */
+/* Constructor arguments of ConditionalWaveFlow (waveflow.py:741-757). */
+typedef struct {
+    int32_t n_upsample;
+    int32_t upsample_factors[4];   /* 16, 16 */
+    int32_t n_flows;               /* 8, even (:586-589) */
+    int32_t n_layers;              /* 8 = len(dilations_dict[n_group]) (:328-331) */
+    int32_t n_group;               /* 16, even */
+    int32_t channels;              /* 64 (paper small model) / 128 (repo default) */
+    int32_t n_mels;                /* 80 */
+    int32_t kernel_h, kernel_w;    /* 3, 3 */
+} pk_wf_cfg;
+
+int pk_wf_create(pk_ctx* ctx, const pk_wf_cfg* cfg, pk_wf** out);
+/* state-dict keys of ConditionalWaveFlow: encoder.{i}.*, decoder.{f}.input_proj.*,
+ * decoder.{f}.resnet.{l}.{conv,condition_proj,out_proj}.*, decoder.{f}.output_proj.*;
+ * weight_g / weight_v pairs are folded (recursively_remove_weight_norm). */
+int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+int pk_wf_finalize(pk_wf* h);
+/* For t_mel frames: length of the trimmed upsampled condition (= length of the z the reference
+ * draws, waveflow.py:799-801) and of the returned waveform (pruned to a multiple of n_group, :695). */
+int pk_wf_cond_length(pk_wf* h, int32_t t_mel, int32_t* cond_len, int32_t* wav_len);
+/* ConditionalWaveFlow.infer (:785-805) for a packed batch.
+ *   mel    (sum(frames), n_mels) float32 packed by utterance, time-major (the reference's
+ *          (B, C_mel, T_mel) transposed)
+ *   frames (B) host int32, >= 2
+ *   z      packed latent, cond_len(frames[b]) floats per utterance (the randn of :801)
+ *   wav    packed output, wav_len(frames[b]) floats per utterance */
+int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, int32_t B, const float* z,
+                float* wav, int32_t flags);
+void pk_wf_destroy(pk_wf* h);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ bool = torch.bool  # noqa: A001  (paddle.bool)
 _DTYPES = {"float32": torch.float32, "float64": torch.float64, "float16": torch.float16,
            "int64": torch.int64, "int32": torch.int32, "bool": torch.bool}
 _default_dtype = "float32"
+_name_counter = 0
 
 
 def _dt(d):
@@ -36,6 +37,14 @@ class Tensor(torch.Tensor):
     @property
     def place(self):
         return "cpu"
+
+    @property
+    def name(self):
+        global _name_counter
+        if not hasattr(self, "_pk_name"):
+            _name_counter += 1
+            self._pk_name = "generated_tensor_%d" % _name_counter
+        return self._pk_name
 
     def numpy(self):
         return torch.Tensor.numpy(self.detach().as_subclass(torch.Tensor))

@@ -31,13 +31,17 @@ class Layer(torch.nn.Module):
         mods = list(self.modules())
         return mods if include_self else mods[1:]
 
+    def register_buffer(self, name, tensor, persistable=True):
+        # buffers registered under an auto-generated tensor name (WaveFlow's perms) stay out of state_dict
+        persistent = persistable and not str(name).startswith("generated_tensor")
+        torch.nn.Module.register_buffer(self, name, tensor, persistent=persistent)
+
     def add_sublayer(self, name, layer):
         self.add_module(str(name), layer)
         return layer
 
     def set_state_dict(self, state):
-        own = dict(self.named_parameters())
-        own.update(dict(self.named_buffers()))
+        own = torch.nn.Module.state_dict(self)   # persistent entries only; tensors share storage
         missing = [k for k in own if k not in state]
         extra = [k for k in state if k not in own]
         assert not missing and not extra, f"state dict mismatch: missing {missing[:5]}, unexpected {extra[:5]}"
@@ -102,6 +106,8 @@ class Conv2DTranspose(_ConvNd):
         self._setup(in_channels, out_channels, _pair(kernel_size), _pair(stride), padding, _pair(dilation),
                     groups, bias_attr, transposed=True)
         self.output_padding = output_padding
+        self._kernel_size = list(_pair(kernel_size))
+        self._stride = list(_pair(stride))
 
     def forward(self, x):
         return functional.conv2d_transpose(x, self.weight, self.bias, self.stride, self.padding,

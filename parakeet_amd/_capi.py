@@ -50,6 +50,12 @@ class Fs2Cfg(C.Structure):
         "reduction_factor", "has_spk_embed", "has_tone_embed")]
 
 
+class WfCfg(C.Structure):
+    _fields_ = [("n_upsample", C.c_int32), ("upsample_factors", C.c_int32 * 4), ("n_flows", C.c_int32),
+                ("n_layers", C.c_int32), ("n_group", C.c_int32), ("channels", C.c_int32), ("n_mels", C.c_int32),
+                ("kernel_h", C.c_int32), ("kernel_w", C.c_int32)]
+
+
 _lib = None
 
 
@@ -83,6 +89,12 @@ def _declare(lib):
         "pk_fs2_set_debug": (C.c_int, [vp, i32]),
         "pk_fs2_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
         "pk_fs2_destroy": (None, [vp]),
+        "pk_wf_create": (C.c_int, [vp, C.POINTER(WfCfg), C.POINTER(vp)]),
+        "pk_wf_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
+        "pk_wf_finalize": (C.c_int, [vp]),
+        "pk_wf_cond_length": (C.c_int, [vp, i32, i32p, i32p]),
+        "pk_wf_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
+        "pk_wf_destroy": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -30,22 +30,32 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
     const int i = lane & 31, hi = lane >> 5;
     const int m0 = blockIdx.x * BM;
     const int nblk = blockIdx.y;
-    const int nslabs = a.taps * a.Cin / BK;
     const int slabs_per_tap = a.Cin / BK;
+    const int nmain = a.ntaps * slabs_per_tap;
+    const int nslabs = nmain + a.Cin2 / BK;
 
     // A loader: thread -> (row, 8 consecutive k)
     const int lrow = tid >> 1, lhalf = tid & 1;
-    const float* arow = a.A + (long)(m0 + lrow - a.pad) * a.lda + lhalf * 8;
+    const float* arow = a.A + (long)(m0 + lrow) * a.lda + lhalf * 8;
+    const float* arow2 = a.A2 + (long)(m0 + lrow) * a.lda2 + lhalf * 8;
     const int a_lds = (((lhalf * 8) * 2 + (lrow >> 6)) * 32 + (lrow & 31)) * 2 + ((lrow >> 5) & 1);
-    const float* wsrc = a.Wp + (long)nblk * nslabs * (BK * BN) + tid * 8;
+    const float* wsrc = a.Wp + (long)nblk * a.wslabs_total * (BK * BN) + tid * 8;
 
     f32x4 ra0, ra1, rb0, rb1;
     auto load_slab = [&](int s) {
-        const int tap = s / slabs_per_tap, ci0 = (s - tap * slabs_per_tap) * BK;
-        const float* p = arow + (long)tap * a.lda + ci0;
+        const float* p;
+        int wslab;
+        if (s < nmain) {
+            const int tap = s / slabs_per_tap, sl = s - tap * slabs_per_tap;
+            p = arow + a.tap_off[tap] + sl * BK;
+            wslab = a.tap_w[tap] * slabs_per_tap + sl;
+        } else {
+            p = arow2 + (s - nmain) * BK;
+            wslab = a.w2_slab0 + (s - nmain);
+        }
         ra0 = *reinterpret_cast<const f32x4*>(p);
         ra1 = *reinterpret_cast<const f32x4*>(p + 4);
-        const float* q = wsrc + (long)s * (BK * BN);
+        const float* q = wsrc + (long)wslab * (BK * BN);
         rb0 = *reinterpret_cast<const f32x4*>(q);
         rb1 = *reinterpret_cast<const f32x4*>(q + 4);
     };
@@ -90,6 +100,28 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
     }
 
     // epilogue
+    if (a.epi == PK_EPI_GATE) {
+        // acc[mt][0] = content, acc[mt][1] = gate of output channel nblk*64 + wn*32 + i
+        const int col0 = nblk * BN + wn * 64 + i;
+        const int n_out = nblk * 64 + wn * 32 + i;
+        if (n_out >= a.N / 2) return;
+        const float b0 = a.bias ? a.bias[col0] : 0.f, b1 = a.bias ? a.bias[col0 + 32] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
+                if (m >= a.M) continue;
+                float ca = acc[mt][0][r] + b0;
+                const float cb = acc[mt][1][r] + b1;
+                ca = fminf(fmaxf(ca, -10.f), 10.f);
+                const float ea = __expf(-2.f * ca), eb = __expf(-cb);
+                float v = (1.f - ea) / ((1.f + ea) * (1.f + eb));
+                if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                a.C[(long)m * a.ldc + n_out] = v;
+            }
+        return;
+    }
     const int n_base = nblk * BN + wn * 64 + i;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -98,6 +130,7 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
         const float bias = a.bias ? a.bias[n] : 0.f;
         const float cs = a.cscale ? a.cscale[n] : 1.f;
         const float ch = a.cshift ? a.cshift[n] : 0.f;
+        const bool to2 = a.nsplit > 0 && n >= a.nsplit;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -107,6 +140,13 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
                 float v = acc[mt][nt][r] + bias;
                 if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (a.act == PK_ACT_TANH) v = tanhf(v);
+                if (to2) {
+                    float* dst = a.C2 + (long)m * a.ldc2 + (n - a.nsplit);
+                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                    else if (a.acc2) v += *dst;
+                    *dst = v;
+                    continue;
+                }
                 if (a.res) v += a.res[(long)m * a.ldr + n];
                 if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
                 if (a.cscale) v = v * cs + ch;
@@ -147,9 +187,39 @@ void pk_conv_to_kn(const float* w, int Cout, int Cin, int k, std::vector<float>&
                 out[((size_t)tap * Cin + ci) * Cout + co] = w[((size_t)co * Cin + ci) * k + tap];
 }
 
-int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& a) {
-    if (a.Cin % BK != 0) PK_FAIL(PK_EUNSUPPORTED, "GEMM: input channels (%d) must be a multiple of %d", a.Cin, BK);
+void pk_gemm_gate_permute(const float* Wkn, int K, int Cz, std::vector<float>& out) {
+    const int N = 2 * Cz;
+    out.resize((size_t)K * N);
+    for (int k = 0; k < K; ++k)
+        for (int nb = 0; nb < Cz / 64; ++nb)
+            for (int wn = 0; wn < 2; ++wn)
+                for (int half = 0; half < 2; ++half)
+                    for (int j = 0; j < 32; ++j)
+                        out[(size_t)k * N + nb * 128 + wn * 64 + half * 32 + j] =
+                            Wkn[(size_t)k * N + half * Cz + nb * 64 + wn * 32 + j];
+}
+
+void pk_gemm_gate_permute_bias(const float* b, int Cz, std::vector<float>& out) {
+    pk_gemm_gate_permute(b, 1, Cz, out);
+}
+
+int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
+    pk_gemm_args a = in;
+    if (a.Cin % BK != 0 || a.Cin2 % BK != 0)
+        PK_FAIL(PK_EUNSUPPORTED, "GEMM: input channels (%d, %d) must be multiples of %d", a.Cin, a.Cin2, BK);
     if (a.M <= 0 || a.N <= 0) PK_FAIL(PK_EINVAL, "GEMM: empty problem");
+    if (a.ntaps == 0) {
+        if (a.taps > PK_GEMM_MAX_TAPS) PK_FAIL(PK_EUNSUPPORTED, "GEMM: more than %d taps", PK_GEMM_MAX_TAPS);
+        a.ntaps = a.taps;
+        for (int t = 0; t < a.taps; ++t) {
+            a.tap_off[t] = (long)(t - a.pad) * a.lda;
+            a.tap_w[t] = t;
+        }
+        a.wslabs_total = a.taps * a.Cin / BK + a.Cin2 / BK;
+    }
+    if (a.wslabs_total <= 0) PK_FAIL(PK_EINVAL, "GEMM: wslabs_total not set");
+    if (!a.A2) { a.A2 = a.A; a.lda2 = 0; }
+    if (a.epi == PK_EPI_GATE && (a.N % 128 != 0)) PK_FAIL(PK_EUNSUPPORTED, "gated GEMM needs N %% 128 == 0");
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
     PK_LAUNCH(ctx, prof_name, k_gemm, grid, dim3(256), 0, a);
     return PK_OK;

@@ -10,7 +10,10 @@ constexpr int PK_GEMM_BM = 128;
 constexpr int PK_GEMM_BN = 128;
 constexpr int PK_GEMM_BK = 16;
 
+constexpr int PK_GEMM_MAX_TAPS = 12;
+
 enum { PK_ACT_NONE = 0, PK_ACT_RELU = 1, PK_ACT_TANH = 2 };
+enum { PK_EPI_STD = 0, PK_EPI_GATE = 1 };
 
 // C[r, n] = epilogue( sum_{tap, ci} A[r + tap - pad, ci] * W[tap*Cin + ci, n] )
 //   epilogue: v += bias[n]; v = act(v); v += res[r, n]; v = rowvalid[r] ? v : 0;
@@ -34,6 +37,26 @@ struct pk_gemm_args {
     const int* out_rowmap = nullptr;  // < 0: row not stored
     int M = 0, N = 0, Cin = 0, taps = 1, pad = 0;
     int act = PK_ACT_NONE;
+    // ---- generalised K axis (WaveFlow's 2-D causal conv): K = ntaps*Cin (+ Cin2).
+    // ntaps == 0 means "taps/pad" above (tap t reads row r + t - pad).  Otherwise tap t reads
+    // A + tap_off[t] (floats) + r*lda and multiplies the weight slabs of packed tap tap_w[t]
+    // (so a caller can skip taps whose input is known to be zero without repacking weights).
+    int ntaps = 0;
+    long tap_off[PK_GEMM_MAX_TAPS] = {0};
+    int tap_w[PK_GEMM_MAX_TAPS] = {0};
+    const float* A2 = nullptr;   // second operand block appended to K (e.g. the conditioning row)
+    int lda2 = 0, Cin2 = 0;
+    int w2_slab0 = 0;            // first weight slab of the A2 block
+    int wslabs_total = 0;        // K slabs per N-block in the packed weight (set by the launcher when ntaps == 0)
+    // ---- epilogue variants
+    int epi = PK_EPI_STD;
+    // PK_EPI_GATE: columns are packed so that the two N-subtiles of a wave hold (content, gate) of the
+    //   same channel; stores tanh(content + b) * sigmoid(gate + b) to C[r, N/2 columns].
+    // nsplit > 0: columns >= nsplit go to C2[r, n - nsplit] (+= if acc2) instead of C, without `res`.
+    int nsplit = 0;
+    float* C2 = nullptr;
+    int ldc2 = 0;
+    int acc2 = 0;
 };
 
 // Pack a [K][N] row-major matrix (K = taps*Cin, multiple of 16) into per-(N tile,
@@ -41,5 +64,10 @@ struct pk_gemm_args {
 size_t pk_gemm_pack(const float* Wkn, int K, int N, std::vector<float>& out);
 // Conv1D weight [Cout][Cin][k] (paddle layout) -> [K = tap*Cin + ci][N = Cout] row-major.
 void pk_conv_to_kn(const float* w, int Cout, int Cin, int k, std::vector<float>& out);
+
+// Column permutation for PK_EPI_GATE: in[k][n] with n = half*Cz + c (half 0 = content, 1 = gate) ->
+// out[k][nblk*128 + wn*64 + half*32 + j] with c = nblk*64 + wn*32 + j.  Cz must be a multiple of 64.
+void pk_gemm_gate_permute(const float* Wkn, int K, int Cz, std::vector<float>& out);
+void pk_gemm_gate_permute_bias(const float* b, int Cz, std::vector<float>& out);
 
 int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& a);

@@ -1,0 +1,520 @@
+// waveflow.hip -- ConditionalWaveFlow.infer on gfx950: kernels + pk_wf_* entry points.
+//
+// Reference: parakeet/models/waveflow.py  UpsampleNet.forward(trim) :103-132, fold :32-51,
+// ResidualBlock.add_input :248-294, ResidualNet.add_input :368-392, Flow.inverse :515-556
+// (_predict_row_parameters :496-501, _inverse_transform_row :503-505), WaveFlow.inverse :674-711
+// (_create_perm :602-615, _trim :617-625), ConditionalWaveFlow.infer :785-805;
+// parakeet/modules/geometry.py shuffle_dim :18-50.
+//
+// Layout.  The folded signal is (H = n_group rows) x (W = T / n_group positions).  All utterances of
+// a batch share one position axis ("width timeline") framed by GAPW >= 2^(n_layers-1) zero positions,
+// so the width-dilated "same" convolutions see the reference's zero padding and ragged batches are
+// exact.  Per-position feature rows are channels-last [pos][C] fp32, i.e. GEMM A operands:
+//   hist[l][slot][pos][C]   inputs of residual layer l for the last 3 rows (the reference's
+//                           _conv_buffer, kept as a ring instead of concat-shifting every step)
+//   cond[h][pos][n_mels]    upsampled mel, folded; row permutations of the flows are index maps
+//   cur/nxt[h][pos]         the folded latent / signal
+// One autoregressive step (flow f, row i) = for each of the 8 layers: GEMM1 (3x3 dilated causal conv
+// as <=9 shifted taps + condition_proj as a second K block, gated-tanh epilogue) -> GEMM2 (out_proj,
+// residual into the next layer's ring slot, skip accumulated), then k_wf_step (output_proj, affine
+// inverse, input_proj of the new row).  Rows that do not exist yet (steps < 1) are skipped as taps
+// instead of being stored as zeros.
+#include <algorithm>
+#include <cmath>
+
+#include "pk_gemm.h"
+
+namespace {
+
+constexpr int WF_LEAD = 256;  // margin positions around every per-position buffer (>= largest tap shift)
+
+// One Conv2DTranspose(1,1,(3,2f),stride (1,f),padding (1,f//2)) + trim + leaky_relu(0.4) layer.
+// in[rows][M] (time-major, M mel bins), out likewise -- or, for the last layer, the folded
+// cond[h][pos][M] layout (pos = woff[b] + t / G, h = t % G, only t < pruned[b]).
+__global__ void k_wf_upsample(const float* __restrict__ in, const int* __restrict__ in_off,
+                              const int* __restrict__ in_len, float* __restrict__ out,
+                              const int* __restrict__ out_off, const float* __restrict__ w, float bias, int f,
+                              int M, int fold_G, const int* __restrict__ woff, const int* __restrict__ pruned,
+                              long cond_row_stride) {
+    const int b = blockIdx.z;
+    const int Tin = in_len[b];
+    const int Tout = f * Tin - f;  // (Tin-1)*f - 2*(f/2) + 2f, minus the trimmed (2f - f) columns
+    const int t = blockIdx.x * (blockDim.x / M) + threadIdx.x / M;
+    const int c = threadIdx.x % M;
+    if (t >= Tout || threadIdx.x >= (blockDim.x / M) * M) return;
+    const float* src = in + (long)in_off[b] * M;
+    float acc = bias;
+    // out[c][t] += in[c + 1 - ky][ix] * w[ky][kx],  kx = t + f/2 - f*ix in [0, 2f)
+    const int tt = t + f / 2;
+    const int ix_hi = tt / f;                 // kx = tt - f*ix >= 0
+    const int ix_lo = (tt - 2 * f) / f + 1;   // kx < 2f  (floor division handled below)
+    for (int ix = ix_hi; ix >= 0 && ix >= ix_hi - 1; --ix) {
+        const int kx = tt - f * ix;
+        if (kx < 0 || kx >= 2 * f || ix >= Tin) continue;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ci = c + 1 - ky;
+            if (ci >= 0 && ci < M) acc = fmaf(src[(long)ix * M + ci], w[ky * 2 * f + kx], acc);
+        }
+    }
+    (void)ix_lo;
+    acc = acc > 0.f ? acc : 0.4f * acc;
+    if (fold_G == 0) {
+        out[((long)out_off[b] + t) * M + c] = acc;
+    } else if (t < pruned[b]) {
+        out[(long)(t % fold_G) * cond_row_stride + ((long)woff[b] + t / fold_G) * M + c] = acc;
+    }
+}
+
+// cur[h][pos] = z[zoff[b] + G*w + h]  (fold :32-51 + transpose :697-698); gap positions -> 0
+__global__ void k_wf_fold(const float* __restrict__ z, const int* __restrict__ pos_utt,
+                          const int* __restrict__ pos_w, const int* __restrict__ zoff, int G, int npos,
+                          long row_stride, float* __restrict__ cur) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const int b = pos_utt[p];
+    for (int h = 0; h < G; ++h)
+        cur[(long)h * row_stride + p] = b >= 0 ? z[(long)zoff[b] + (long)G * pos_w[p] + h] : 0.f;
+}
+
+__global__ void k_wf_unfold(const float* __restrict__ cur, const int* __restrict__ pos_utt,
+                            const int* __restrict__ pos_w, const int* __restrict__ ooff, int G, int npos,
+                            long row_stride, float* __restrict__ wav) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const int b = pos_utt[p];
+    if (b < 0) return;
+    for (int h = 0; h < G; ++h) wav[(long)ooff[b] + (long)G * pos_w[p] + h] = cur[(long)h * row_stride + p];
+}
+
+// Start of a flow: x[0] = z'[0] (z' = rows of cur permuted, :704,540-542) and the input projection
+// of that first row into ring slot 1 of layer 0.  One wave per position.
+// Every step: params = output_proj(sum of skips) (:499-500), x[i] = (z'[i] - b) * exp(-logs) (:503-505),
+// then h0 = input_proj(x[i]) for the next step (:497).
+__global__ __launch_bounds__(256) void k_wf_step(const float* __restrict__ skipsum, int C,
+                                                 const float* __restrict__ w_out, float b_logs, float b_b,
+                                                 const float* __restrict__ z_row, float* __restrict__ x_row,
+                                                 const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                 float* __restrict__ h0_next, const int* __restrict__ pos_utt,
+                                                 int npos, int first) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npos) return;
+    const int lane = threadIdx.x & 63;
+    const bool valid = pos_utt[p] >= 0;
+    float xn = 0.f;
+    if (valid) {
+        if (first) {
+            xn = z_row[p];
+        } else {
+            const float* s = skipsum + (long)p * C;
+            float l = 0.f, bb = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float v = s[c];
+                l = fmaf(w_out[c], v, l);
+                bb = fmaf(w_out[C + c], v, bb);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                l += __shfl_xor(l, o);
+                bb += __shfl_xor(bb, o);
+            }
+            xn = (z_row[p] - (bb + b_b)) * expf(-(l + b_logs));
+        }
+    }
+    if (lane == 0) x_row[p] = xn;
+    if (h0_next)
+        for (int c = lane; c < C; c += 64) h0_next[(long)p * C + c] = valid ? fmaf(w_in[c], xn, b_in[c]) : 0.f;
+}
+
+}  // namespace
+
+// ================================================================== host side
+struct WfLayerW {
+    size_t w1, b1, w2, b2;   // packed GEMM weights (floats offsets into the arena)
+};
+
+struct WfFlowW {
+    size_t w_in, b_in, w_out;
+    float b_logs, b_b;
+    std::vector<WfLayerW> layers;
+};
+
+struct pk_wf {
+    pk_ctx* ctx = nullptr;
+    pk_wf_cfg cfg;
+    pk_param_map params;
+    bool finalized = false;
+    int gapw = 128;
+    std::vector<float> arena_h;
+    pk_dbuf arena;
+    std::vector<WfFlowW> flows;
+    std::vector<size_t> up_w;
+    std::vector<float> up_b;
+    // workspace
+    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip;
+    const float* W(size_t off) const { return arena.as<float>() + off; }
+};
+
+extern "C" int pk_wf_create(pk_ctx* ctx, const pk_wf_cfg* cfg, pk_wf** out) {
+    if (!ctx || !cfg || !out) PK_FAIL(PK_EINVAL, "pk_wf_create: NULL argument");
+    *out = nullptr;
+    const pk_wf_cfg& c = *cfg;
+    if (c.n_group % 2 || c.n_flows % 2 || c.n_group <= 0 || c.n_flows <= 0)
+        PK_FAIL(PK_EINVAL, "number of flows and number of group must be even since a permutation along "
+                           "group among flows is used.");  // waveflow.py:586-589 (ValueError)
+    if (c.n_group != 8 && c.n_group != 16)
+        PK_FAIL(PK_EUNSUPPORTED, "WaveFlow: n_group %d needs height dilations > 1 (not implemented)", c.n_group);
+    if (c.n_layers != 8) PK_FAIL(PK_EINVAL, "number of dilations_h should equals num of layers");  // :328-331
+    if (c.kernel_h != 3 || c.kernel_w != 3) PK_FAIL(PK_EUNSUPPORTED, "WaveFlow: kernel_size must be (3, 3)");
+    if (c.channels % 64 != 0 || c.channels > 256) PK_FAIL(PK_EUNSUPPORTED, "WaveFlow: channels must be 64/128/192/256");
+    if (c.n_mels % PK_GEMM_BK != 0) PK_FAIL(PK_EUNSUPPORTED, "WaveFlow: n_mels must be a multiple of 16");
+    if (c.n_upsample < 1 || c.n_upsample > 4) PK_FAIL(PK_EINVAL, "WaveFlow: 1..4 upsample layers");
+    for (int i = 0; i < c.n_upsample; ++i)
+        if (c.upsample_factors[i] < 2 || c.upsample_factors[i] % 2 || c.upsample_factors[i] > 64)
+            PK_FAIL(PK_EUNSUPPORTED, "WaveFlow: upsample factor %d unsupported", c.upsample_factors[i]);
+    pk_wf* h = new pk_wf();
+    h->ctx = ctx;
+    h->cfg = c;
+    h->gapw = 1 << (c.n_layers - 1);
+    *out = h;
+    return PK_OK;
+}
+
+extern "C" int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_wf_set_param: handle is NULL");
+    h->finalized = false;
+    return pk_store_param(h->params, name, data, shape, ndim);
+}
+
+namespace {
+struct Arena {
+    std::vector<float>& v;
+    size_t put(const std::vector<float>& x) {
+        size_t o = (v.size() + 3) & ~(size_t)3;
+        v.resize(o);
+        v.insert(v.end(), x.begin(), x.end());
+        return o;
+    }
+};
+}  // namespace
+
+extern "C" int pk_wf_finalize(pk_wf* h) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_wf_finalize: handle is NULL");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const pk_wf_cfg& c = h->cfg;
+    const pk_param_map& P = h->params;
+    const int C = c.channels, M = c.n_mels;
+    h->arena_h.clear();
+    Arena ar{h->arena_h};
+    h->up_w.resize(c.n_upsample);
+    h->up_b.resize(c.n_upsample);
+    for (int i = 0; i < c.n_upsample; ++i) {
+        const int f = c.upsample_factors[i];
+        std::vector<float> w, b;
+        PK_TRY(pk_get_weight(P, "encoder." + std::to_string(i), {1, 1, 3, 2 * f}, w));
+        PK_TRY(pk_get_vector(P, "encoder." + std::to_string(i) + ".bias", 1, b));
+        h->up_w[i] = ar.put(w);
+        h->up_b[i] = b[0];
+    }
+    h->flows.resize(c.n_flows);
+    for (int fl = 0; fl < c.n_flows; ++fl) {
+        const std::string p = "decoder." + std::to_string(fl);
+        WfFlowW& F = h->flows[fl];
+        std::vector<float> w, b;
+        PK_TRY(pk_get_weight(P, p + ".input_proj", {C, 1, 1, 1}, w));
+        PK_TRY(pk_get_vector(P, p + ".input_proj.bias", C, b));
+        F.w_in = ar.put(w);
+        F.b_in = ar.put(b);
+        PK_TRY(pk_get_weight(P, p + ".output_proj", {2, C, 1, 1}, w));
+        PK_TRY(pk_get_vector(P, p + ".output_proj.bias", 2, b));
+        F.w_out = ar.put(w);   // [logs row (C)] [b row (C)]  (chunk(params, 2, axis=1) :500)
+        F.b_logs = b[0];
+        F.b_b = b[1];
+        F.layers.resize(c.n_layers);
+        for (int l = 0; l < c.n_layers; ++l) {
+            const std::string q = p + ".resnet." + std::to_string(l);
+            std::vector<float> wc, bc, wp, bp, wo, bo;
+            PK_TRY(pk_get_weight(P, q + ".conv", {2 * C, C, 3, 3}, wc));
+            PK_TRY(pk_get_vector(P, q + ".conv.bias", 2 * C, bc));
+            PK_TRY(pk_get_weight(P, q + ".condition_proj", {2 * C, M, 1, 1}, wp));
+            PK_TRY(pk_get_vector(P, q + ".condition_proj.bias", 2 * C, bp));
+            PK_TRY(pk_get_weight(P, q + ".out_proj", {2 * C, C, 1, 1}, wo));
+            PK_TRY(pk_get_vector(P, q + ".out_proj.bias", 2 * C, bo));
+            // GEMM1 weight [K = (kr*3 + kc)*C + ci | 9C + m][N = 2C], gate-permuted columns
+            const int K1 = 9 * C + M;
+            std::vector<float> kn((size_t)K1 * 2 * C), perm, bias(2 * C), pbias, packed;
+            for (int co = 0; co < 2 * C; ++co) {
+                for (int ci = 0; ci < C; ++ci)
+                    for (int kr = 0; kr < 3; ++kr)
+                        for (int kc = 0; kc < 3; ++kc)
+                            kn[((size_t)(kr * 3 + kc) * C + ci) * 2 * C + co] = wc[(((size_t)co * C + ci) * 3 + kr) * 3 + kc];
+                for (int m = 0; m < M; ++m) kn[((size_t)9 * C + m) * 2 * C + co] = wp[(size_t)co * M + m];
+                bias[co] = bc[co] + bp[co];   // conv bias + condition_proj bias (:277-278)
+            }
+            pk_gemm_gate_permute(kn.data(), K1, C, perm);
+            pk_gemm_gate_permute_bias(bias.data(), C, pbias);
+            pk_gemm_pack(perm.data(), K1, 2 * C, packed);
+            F.layers[l].w1 = ar.put(packed);
+            F.layers[l].b1 = ar.put(pbias);
+            // GEMM2: out_proj [K = C][N = 2C] (res | skip, chunk :282)
+            std::vector<float> kn2((size_t)C * 2 * C), packed2;
+            for (int co = 0; co < 2 * C; ++co)
+                for (int ci = 0; ci < C; ++ci) kn2[(size_t)ci * 2 * C + co] = wo[(size_t)co * C + ci];
+            pk_gemm_pack(kn2.data(), C, 2 * C, packed2);
+            F.layers[l].w2 = ar.put(packed2);
+            F.layers[l].b2 = ar.put(bo);
+        }
+    }
+    PK_TRY(pk_upload(ctx, h->arena, h->arena_h.data(), h->arena_h.size() * sizeof(float)));
+    h->arena_h.clear();
+    h->arena_h.shrink_to_fit();
+    h->finalized = true;
+    return PK_OK;
+}
+
+static int wf_len_after(const pk_wf_cfg& c, int t_mel) {
+    long t = t_mel;
+    for (int i = 0; i < c.n_upsample; ++i) t = t * c.upsample_factors[i] - c.upsample_factors[i];
+    return (int)std::max<long>(t, 0);
+}
+
+extern "C" int pk_wf_cond_length(pk_wf* h, int32_t t_mel, int32_t* cond_len, int32_t* wav_len) {
+    if (!h || !cond_len || !wav_len) PK_FAIL(PK_EINVAL, "pk_wf_cond_length: NULL argument");
+    const int t = wf_len_after(h->cfg, t_mel);
+    *cond_len = t;
+    *wav_len = t / h->cfg.n_group * h->cfg.n_group;
+    return PK_OK;
+}
+
+extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, int32_t B, const float* z,
+                           float* wav, int32_t flags) {
+    if (!h || !mel || !frames || !z || !wav) PK_FAIL(PK_EINVAL, "pk_wf_infer: NULL argument");
+    if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_wf_infer: call pk_wf_finalize first");
+    if (B <= 0) PK_FAIL(PK_EINVAL, "pk_wf_infer: batch size must be positive");
+    pk_ctx* ctx = h->ctx;
+    PK_HIP(hipSetDevice(ctx->device));
+    const pk_wf_cfg& c = h->cfg;
+    const int C = c.channels, M = c.n_mels, G = c.n_group, NL = c.n_layers;
+    // ---- per-utterance sizes
+    std::vector<int> cuT(B + 1, 0), clen(B), pruned(B), Wb(B), woff(B), zoff(B), ooff(B);
+    long sumZ = 0, sumO = 0;
+    int pos = h->gapw;
+    for (int b = 0; b < B; ++b) {
+        if (frames[b] < 2) PK_FAIL(PK_EINVAL, "pk_wf_infer: utterance %d needs >= 2 mel frames", b);
+        cuT[b + 1] = cuT[b] + frames[b];
+        clen[b] = wf_len_after(c, frames[b]);
+        pruned[b] = clen[b] / G * G;
+        Wb[b] = pruned[b] / G;
+        if (Wb[b] <= 0) PK_FAIL(PK_EINVAL, "pk_wf_infer: utterance %d too short", b);
+        woff[b] = pos;
+        pos += Wb[b] + h->gapw;
+        zoff[b] = (int)sumZ;
+        ooff[b] = (int)sumO;
+        sumZ += clen[b];
+        sumO += pruned[b];
+    }
+    const int npos = pos;
+    const int npos_alloc = ((npos + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM;
+    const long pstride = (long)npos_alloc + 2 * WF_LEAD;   // positions per buffer row incl. margins
+    // ---- tables
+    std::vector<int> pos_utt(npos_alloc, -1), pos_w(npos_alloc, 0);
+    for (int b = 0; b < B; ++b)
+        for (int w = 0; w < Wb[b]; ++w) {
+            pos_utt[woff[b] + w] = b;
+            pos_w[woff[b] + w] = w;
+        }
+    std::vector<int> tab;
+    auto push = [&](const std::vector<int>& v) {
+        size_t o = tab.size();
+        tab.insert(tab.end(), v.begin(), v.end());
+        return o;
+    };
+    const size_t o_putt = push(pos_utt), o_pw = push(pos_w), o_woff = push(woff), o_zoff = push(zoff),
+                 o_ooff = push(ooff), o_pruned = push(pruned);
+    // per upsample layer: in_off, in_len, out_off
+    std::vector<size_t> o_inoff(c.n_upsample), o_inlen(c.n_upsample), o_outoff(c.n_upsample);
+    std::vector<long> layer_rows(c.n_upsample + 1);
+    {
+        std::vector<int> len(frames, frames + B), off(cuT.begin(), cuT.begin() + B);
+        layer_rows[0] = cuT[B];
+        for (int i = 0; i < c.n_upsample; ++i) {
+            const int f = c.upsample_factors[i];
+            std::vector<int> olen(B), ooff2(B);
+            long acc = 0;
+            for (int b = 0; b < B; ++b) {
+                olen[b] = f * len[b] - f;
+                ooff2[b] = (int)acc;
+                acc += olen[b];
+            }
+            o_inoff[i] = push(off);
+            o_inlen[i] = push(len);
+            o_outoff[i] = push(ooff2);
+            layer_rows[i + 1] = acc;
+            len = olen;
+            off = ooff2;
+        }
+    }
+    PK_TRY(h->ws_tab.reserve(tab.size() * sizeof(int)));
+    PK_HIP(hipMemcpyAsync(h->ws_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    const int* d_tab = h->ws_tab.as<int>();
+
+    // ---- io staging
+    const float* d_mel = mel;
+    const float* d_z = z;
+    float* d_wav = wav;
+    if (flags & PK_HOST_IO) {
+        PK_TRY(h->ws_mel.reserve((size_t)cuT[B] * M * 4));
+        PK_TRY(h->ws_z.reserve((size_t)sumZ * 4));
+        PK_TRY(h->ws_wav.reserve((size_t)sumO * 4));
+        PK_HIP(hipMemcpyAsync(h->ws_mel.p, mel, (size_t)cuT[B] * M * 4, hipMemcpyHostToDevice, ctx->stream));
+        PK_HIP(hipMemcpyAsync(h->ws_z.p, z, (size_t)sumZ * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_mel = h->ws_mel.as<float>();
+        d_z = h->ws_z.as<float>();
+        d_wav = h->ws_wav.as<float>();
+    }
+    // ---- workspaces
+    const long cond_row = pstride * M;          // floats per folded cond row
+    const long feat_row = pstride * C;          // floats per [pos][C] buffer
+    PK_TRY(h->ws_cond.reserve((size_t)G * cond_row * 4));
+    PK_TRY(h->ws_cur.reserve((size_t)G * pstride * 4));
+    PK_TRY(h->ws_nxt.reserve((size_t)G * pstride * 4));
+    PK_TRY(h->ws_hist.reserve((size_t)(NL + 1) * 3 * feat_row * 4));
+    PK_TRY(h->ws_zbuf.reserve((size_t)feat_row * 4));
+    PK_TRY(h->ws_skip.reserve((size_t)feat_row * 4));
+    for (int i = 0; i + 1 < c.n_upsample; ++i) PK_TRY(h->ws_u[i & 1].reserve((size_t)layer_rows[i + 1] * M * 4));
+    // cond gaps / margins are read by masked rows only, but must be finite
+    PK_HIP(hipMemsetAsync(h->ws_cond.p, 0, (size_t)G * cond_row * 4, ctx->stream));
+    PK_HIP(hipMemsetAsync(h->ws_hist.p, 0, (size_t)(NL + 1) * 3 * feat_row * 4, ctx->stream));
+    PK_HIP(hipMemsetAsync(h->ws_zbuf.p, 0, (size_t)feat_row * 4, ctx->stream));
+    float* cond = h->ws_cond.as<float>() + (size_t)WF_LEAD * M;
+    float* cur = h->ws_cur.as<float>() + WF_LEAD;
+    float* nxt = h->ws_nxt.as<float>() + WF_LEAD;
+    float* hist = h->ws_hist.as<float>() + (size_t)WF_LEAD * C;
+    float* zbuf = h->ws_zbuf.as<float>() + (size_t)WF_LEAD * C;
+    float* skip = h->ws_skip.as<float>() + (size_t)WF_LEAD * C;
+    auto hist_ptr = [&](int layer, int slot) { return hist + ((size_t)layer * 3 + slot) * feat_row; };
+
+    // ---- upsample (encoder)
+    {
+        const float* in = d_mel;
+        for (int i = 0; i < c.n_upsample; ++i) {
+            const int f = c.upsample_factors[i];
+            const bool last = i == c.n_upsample - 1;
+            float* out = last ? cond : h->ws_u[i & 1].as<float>();
+            int maxT = 0;
+            {
+                // largest output length of this layer
+                std::vector<int> len(frames, frames + B);
+                for (int k = 0; k <= i; ++k)
+                    for (int b = 0; b < B; ++b) len[b] = c.upsample_factors[k] * len[b] - c.upsample_factors[k];
+                for (int b = 0; b < B; ++b) maxT = std::max(maxT, len[b]);
+            }
+            const int tpb = 256 / M;  // time steps per block
+            dim3 grid(pk_div_up(maxT, tpb), 1, B);
+            PK_LAUNCH(ctx, "wf_upsample", k_wf_upsample, grid, dim3(256), 0, in, d_tab + o_inoff[i], d_tab + o_inlen[i],
+                      out, d_tab + o_outoff[i], h->W(h->up_w[i]), h->up_b[i], f, M, last ? G : 0, d_tab + o_woff,
+                      d_tab + o_pruned, cond_row);
+            in = out;
+        }
+    }
+    // ---- fold z
+    PK_LAUNCH(ctx, "wf_fold", k_wf_fold, dim3(pk_div_up(npos, 256)), dim3(256), 0, d_z, d_tab + o_putt, d_tab + o_pw,
+              d_tab + o_zoff, G, npos, pstride, cur);
+
+    // ---- flows, reversed (:703-706)
+    std::vector<int> cidx(G);
+    for (int i = 0; i < G; ++i) cidx[i] = i;
+    const int* rowvalid = d_tab + o_putt;
+    for (int fl = c.n_flows - 1; fl >= 0; --fl) {
+        std::vector<int> perm(G);   // _create_perm :602-615
+        for (int i = 0; i < G; ++i)
+            perm[i] = (fl < c.n_flows / 2) ? (G - 1 - i) : (i < G / 2 ? G / 2 - 1 - i : G + G / 2 - 1 - i);
+        std::vector<int> cnew(G);
+        for (int i = 0; i < G; ++i) cnew[i] = cidx[perm[i]];   // cumulative shuffle of the condition
+        cidx = cnew;
+        const WfFlowW& F = h->flows[fl];
+        // row 0: copy + input_proj into slot 1 of layer 0
+        PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out), F.b_logs,
+                  F.b_b, cur + (long)perm[0] * pstride, nxt, h->W(F.w_in), h->W(F.b_in), hist_ptr(0, 1), rowvalid,
+                  npos, 1);
+        for (int i = 1; i < G; ++i) {
+            const int slot = i % 3;
+            for (int l = 0; l < NL; ++l) {
+                const WfLayerW& L = F.layers[l];
+                pk_gemm_args g;
+                g.A = hist_ptr(l, 0);   // taps carry the slot offsets
+                g.lda = C;
+                g.Cin = C;
+                g.ntaps = 0;
+                const long dil = 1L << l;
+                for (int kr = 0; kr < 3; ++kr) {
+                    const int step = i - 2 + kr;   // kernel row kr reads the layer input of this step
+                    if (step < 1) continue;        // rows before the sequence start are zeros (:287-290)
+                    for (int kc = 0; kc < 3; ++kc) {
+                        g.tap_off[g.ntaps] = (long)(step % 3) * feat_row + (long)(kc - 1) * dil * C;
+                        g.tap_w[g.ntaps] = kr * 3 + kc;
+                        ++g.ntaps;
+                    }
+                }
+                g.A2 = cond + (long)cidx[i] * cond_row;
+                g.lda2 = M;
+                g.Cin2 = M;
+                g.w2_slab0 = 9 * C / PK_GEMM_BK;
+                g.wslabs_total = (9 * C + M) / PK_GEMM_BK;
+                g.Wp = h->W(L.w1);
+                g.bias = h->W(L.b1);
+                g.epi = PK_EPI_GATE;
+                g.C = zbuf;
+                g.ldc = C;
+                g.rowvalid = rowvalid;
+                g.M = npos;
+                g.N = 2 * C;
+                PK_TRY(pk_gemm_launch(ctx, "wf_gemm_conv_gate", g));
+                pk_gemm_args o;
+                o.A = zbuf;
+                o.lda = C;
+                o.Cin = C;
+                o.taps = 1;
+                o.pad = 0;
+                o.Wp = h->W(L.w2);
+                o.bias = h->W(L.b2);
+                o.res = hist_ptr(l, slot);
+                o.ldr = C;
+                o.C = hist_ptr(l + 1, slot);
+                o.ldc = C;
+                o.nsplit = C;
+                o.C2 = skip;
+                o.ldc2 = C;
+                o.acc2 = l > 0;
+                o.rowvalid = rowvalid;
+                o.M = npos;
+                o.N = 2 * C;
+                PK_TRY(pk_gemm_launch(ctx, "wf_gemm_out_proj", o));
+            }
+            float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
+            PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out),
+                      F.b_logs, F.b_b, cur + (long)perm[i] * pstride, nxt + (long)i * pstride, h->W(F.w_in),
+                      h->W(F.b_in), h0n, rowvalid, npos, 0);
+        }
+        std::swap(cur, nxt);
+    }
+    PK_LAUNCH(ctx, "wf_unfold", k_wf_unfold, dim3(pk_div_up(npos, 256)), dim3(256), 0, cur, d_tab + o_putt,
+              d_tab + o_pw, d_tab + o_ooff, G, npos, pstride, d_wav);
+    if (flags & PK_HOST_IO) {
+        PK_HIP(hipMemcpyAsync(wav, d_wav, (size_t)sumO * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PK_OK;
+}
+
+extern "C" void pk_wf_destroy(pk_wf* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    pk_dbuf* bufs[] = {&h->arena, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
+                       &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip};
+    for (auto* b : bufs) b->release();
+    delete h;
+}

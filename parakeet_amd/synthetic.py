@@ -38,6 +38,9 @@ PWG_LJSPEECH = dict(
     residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80,
     aux_context_window=2, dropout=0.0, use_weight_norm=True, upsample_scales=[4, 4, 4, 4])
 
+WAVEFLOW_LJSPEECH = dict(upsample_factors=[16, 16], n_flows=8, n_layers=8, n_group=16, channels=128,
+                         n_mels=80, kernel_size=[3, 3])   # examples/waveflow/config.py:32-41 (C=64: paper's small model)
+
 SAMPLE_RATE = 22050
 HOP = 256
 
@@ -191,3 +194,51 @@ def mel_stats(odim=80, seed=7, identity=False):
     rng = np.random.default_rng(seed)
     return (rng.normal(-1.0, 0.5, size=odim).astype(np.float32),
             rng.uniform(0.5, 1.5, size=odim).astype(np.float32))
+
+
+def waveflow_state(cfg=None, seed=2021, weight_norm=False, zero_output_proj=False):
+    """ConditionalWaveFlow state dict (parakeet/models/waveflow.py): encoder = 2 Conv2DTranspose,
+    decoder = n_flows Flows.  The reference initialises output_proj to zero (:441-446), which makes
+    every flow the identity; parity tests need a non-trivial transform, so it is small-random here
+    unless ``zero_output_proj``."""
+    cfg = dict(WAVEFLOW_LJSPEECH, **(cfg or {}))
+    rng = np.random.default_rng(seed)
+    C, M = cfg["channels"], cfg["n_mels"]
+    kh, kw = cfg["kernel_size"]
+    st = {}
+
+    def put(name, w, b):
+        if weight_norm:
+            st[name + ".weight_g"] = np.sqrt((w.reshape(w.shape[0], -1) ** 2).sum(1)).astype(np.float32) * \
+                rng.uniform(0.8, 1.2, size=w.shape[0]).astype(np.float32)
+            st[name + ".weight_v"] = w
+        else:
+            st[name + ".weight"] = w
+        st[name + ".bias"] = b
+
+    def u(lim, shape):
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    for i, f in enumerate(cfg["upsample_factors"]):
+        std = math.sqrt(1 / (3 * 2 * f))
+        # positive-mean taps so the two leaky-relu stages keep a usable dynamic range
+        put(f"encoder.{i}", (u(std, (1, 1, 3, 2 * f)) + std).astype(np.float32), u(std, (1,)))
+    for fl in range(cfg["n_flows"]):
+        p = f"decoder.{fl}"
+        put(p + ".input_proj", u(1.0, (C, 1, 1, 1)), u(1.0, (C,)))
+        for l in range(cfg["n_layers"]):
+            q = f"{p}.resnet.{l}"
+            std = math.sqrt(1.0 / (C * kh * kw))
+            put(q + ".conv", u(std, (2 * C, C, kh, kw)), u(std, (2 * C,)))
+            std = math.sqrt(1.0 / M)
+            put(q + ".condition_proj", u(std, (2 * C, M, 1, 1)), u(std, (2 * C,)))
+            std = math.sqrt(1.0 / C)
+            put(q + ".out_proj", u(std, (2 * C, C, 1, 1)), u(std, (2 * C,)))
+        if zero_output_proj:
+            st[p + ".output_proj.weight"] = np.zeros((2, C, 1, 1), np.float32)
+            st[p + ".output_proj.bias"] = np.zeros((2,), np.float32)
+        else:
+            std = 0.3 * math.sqrt(1.0 / C)
+            st[p + ".output_proj.weight"] = u(std, (2, C, 1, 1))
+            st[p + ".output_proj.bias"] = u(0.05, (2,))
+    return st
