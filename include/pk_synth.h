@@ -64,6 +64,7 @@ typedef struct pk_ctx pk_ctx;
 typedef struct pk_pwg pk_pwg;
 typedef struct pk_fs2 pk_fs2;
 typedef struct pk_wf pk_wf;
+typedef struct pk_mel pk_mel;
 
 /* ---------------------------------------------------------------- context */
 const char* pk_last_error(void);
@@ -211,6 +212,32 @@ int pk_wf_cond_length(pk_wf* h, int32_t t_mel, int32_t* cond_len, int32_t* wav_l
 int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, int32_t B, const float* z,
                 float* wav, int32_t flags);
 void pk_wf_destroy(pk_wf* h);
+
+/* ------------------------------------------------- STFT / mel / log features */
+/* parakeet/modules/audio.py STFT (:74-215) + MelScale (:218-229); host twin
+ * parakeet/data/get_feats.py LogMelFBank (:20-88). */
+typedef struct {
+    int32_t n_fft;        /* 1024 */
+    int32_t hop_length;   /* 256 */
+    int32_t center;       /* 1: reflect-pad n_fft/2 on both sides (:175-179) */
+    int32_t power;        /* 0: magnitude sqrt(re^2+im^2) (:202-215); 1: power (:198-200) */
+    int32_t n_mels;       /* 80; 0 = no mel stage */
+    int32_t log_base;     /* 0 none, 10 (TTS features, get_feats.py:84-85), 2 = natural log (:86-87) */
+    float log_floor;      /* 1e-10 (np.clip a_min, :83) */
+} pk_mel_cfg;
+
+/* window: n_fft floats (scipy.signal.get_window(..., fftbins=True), centre-padded to n_fft, :133-141);
+ * mel_basis: (n_mels, 1 + n_fft/2) row-major (librosa.filters.mel), may be NULL if n_mels == 0. */
+int pk_mel_create(pk_ctx* ctx, const pk_mel_cfg* cfg, const float* window, const float* mel_basis,
+                  pk_mel** out);
+/* frames = 1 + (n_samples + 2*pad - n_fft) / hop  (:103-105). */
+int pk_mel_num_frames(pk_mel* h, int32_t n_samples, int32_t* frames);
+/* wav: packed samples, lens (B) host.  out is packed by utterance, time-major:
+ * what 0: (frames, 2*n_bin) real | imag (STFT.forward); 1: (frames, n_bin) magnitude / power;
+ * 2: (frames, n_mels) mel (then log if configured). */
+int pk_mel_run(pk_mel* h, const float* wav, const int32_t* lens, int32_t B, float* out,
+               int32_t what, int32_t flags);
+void pk_mel_destroy(pk_mel* h);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,11 @@ class WfCfg(C.Structure):
                 ("kernel_h", C.c_int32), ("kernel_w", C.c_int32)]
 
 
+class MelCfg(C.Structure):
+    _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("center", C.c_int32), ("power", C.c_int32),
+                ("n_mels", C.c_int32), ("log_base", C.c_int32), ("log_floor", C.c_float)]
+
+
 _lib = None
 
 
@@ -95,6 +100,10 @@ def _declare(lib):
         "pk_wf_cond_length": (C.c_int, [vp, i32, i32p, i32p]),
         "pk_wf_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
         "pk_wf_destroy": (None, [vp]),
+        "pk_mel_create": (C.c_int, [vp, C.POINTER(MelCfg), f32p, f32p, C.POINTER(vp)]),
+        "pk_mel_num_frames": (C.c_int, [vp, i32, i32p]),
+        "pk_mel_run": (C.c_int, [vp, f32p, i32p, i32, f32p, i32, i32]),
+        "pk_mel_destroy": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

@@ -1,0 +1,167 @@
+"""STFT / mel features behind the reference's Python API.
+
+Mirrors parakeet/modules/audio.py ``STFT`` (:74-215: forward / power / magnitude) and ``MelScale``
+(:218-229), and the host feature extractor ``LogMelFBank`` of parakeet/data/get_feats.py (:20-88);
+the arithmetic (reflect padding, DFT-as-GEMM, magnitude, mel GEMM, log) runs in libpk_synth.so
+(csrc/mel.hip).  The window and the mel filterbank are host-side constants handed to the engine;
+``mel_filterbank`` follows the algorithm of librosa.filters.mel (Slaney scale and normalisation),
+which the reference calls at audio.py:221 / get_feats.py:49-55.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import scipy.signal
+import torch
+
+from . import _capi
+from .runtime import Context, dptr, wrap
+
+
+def _slaney_hz(m):
+    f_sp, brk_mel, step = 200.0 / 3.0, 15.0, math.log(6.4) / 27.0
+    m = np.asarray(m, dtype=np.float64)
+    lin = m * f_sp
+    return np.where(m >= brk_mel, 1000.0 * np.exp(step * (m - brk_mel)), lin)
+
+
+def _slaney_mel(f):
+    f_sp, brk_mel, step = 200.0 / 3.0, 15.0, math.log(6.4) / 27.0
+    return f / f_sp if f < 1000.0 else brk_mel + math.log(f / 1000.0) / step
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    """Triangular Slaney-normalised mel filters, (n_mels, 1 + n_fft//2) float32."""
+    fmax = sr / 2.0 if fmax is None else float(fmax)
+    freqs = np.arange(1 + n_fft // 2, dtype=np.float64) * (sr / 2.0) / (n_fft // 2)
+    edges = _slaney_hz(np.linspace(_slaney_mel(float(fmin)), _slaney_mel(fmax), n_mels + 2))
+    lo, mid, hi = edges[:-2, None], edges[1:-1, None], edges[2:, None]
+    up = (freqs[None, :] - lo) / (mid - lo)
+    down = (hi - freqs[None, :]) / (hi - mid)
+    tri = np.clip(np.minimum(up, down), 0.0, None)
+    return (tri * (2.0 / (hi - lo))).astype(np.float32)
+
+
+def _window(window, win_length, n_fft):
+    name = "hann" if window == "hanning" else window
+    w = scipy.signal.get_window(name, win_length, fftbins=True)
+    if n_fft != win_length:
+        left = (n_fft - win_length) // 2
+        w = np.pad(w, (left, n_fft - win_length - left))
+    return np.ascontiguousarray(w, dtype=np.float32)
+
+
+class _Engine:
+    def __init__(self, n_fft, hop_length, win_length, window, center, power, mel_basis, log_base, device=None):
+        self.ctx = Context.get(device)
+        cfg = _capi.MelCfg(n_fft, hop_length, 1 if center else 0, 1 if power else 0,
+                           0 if mel_basis is None else mel_basis.shape[0], log_base, 1e-10)
+        self.n_bin = 1 + n_fft // 2
+        self.n_mels = cfg.n_mels
+        win = _window(window, win_length or n_fft, n_fft)
+        basis = None if mel_basis is None else np.ascontiguousarray(mel_basis, np.float32)
+        h = C.c_void_p()
+        _capi.check(self.ctx.lib.pk_mel_create(self.ctx.handle, C.byref(cfg), _capi.fptr(win),
+                                               None if basis is None else _capi.fptr(basis), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.ctx.lib.pk_mel_destroy(h)
+            except Exception:
+                pass
+
+    def frames(self, n):
+        f = C.c_int32()
+        _capi.check(self.ctx.lib.pk_mel_num_frames(self.h, int(n), C.byref(f)))
+        return f.value
+
+    def run(self, wavs, what):
+        """wavs: list of 1-D arrays -> list of (frames, cols) device tensors."""
+        ctx = Context.get(self.ctx.device)
+        lens = np.array([int(np.prod(w.shape)) for w in wavs], dtype=np.int32)
+        x = torch.cat([ctx.to_device(w).reshape(-1) for w in wavs])
+        cols = {0: 2 * self.n_bin, 1: self.n_bin, 2: self.n_mels}[what]
+        nf = [self.frames(n) for n in lens]
+        out = ctx.empty((sum(nf), cols))
+        _capi.check(ctx.lib.pk_mel_run(self.h, dptr(x), lens.ctypes.data_as(C.POINTER(C.c_int32)), len(wavs),
+                                       dptr(out), what, 0))
+        res, o = [], 0
+        for f in nf:
+            res.append(out[o:o + f])
+            o += f
+        return res
+
+
+class STFT:
+    """(B, T) -> real, imag (B, n_bin, frames); audio.py:74-215."""
+
+    def __init__(self, n_fft, hop_length=None, win_length=None, window="hanning", center=True, pad_mode="reflect"):
+        if pad_mode != "reflect":
+            raise NotImplementedError("only pad_mode='reflect' is implemented")
+        win_length = win_length or n_fft
+        hop_length = hop_length or int(win_length // 4)
+        self.n_fft, self.hop_length, self.n_bin, self.center = n_fft, hop_length, 1 + n_fft // 2, center
+        self._mag = _Engine(n_fft, hop_length, win_length, window, center, False, None, 0)
+        self._pow = None
+        self._args = (n_fft, hop_length, win_length, window, center)
+
+    def _batch(self, x, eng, what):
+        x = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+        outs = eng.run([x[b] for b in range(x.shape[0])], what)
+        return torch.stack([o.transpose(0, 1) for o in outs], 0)
+
+    def forward(self, x):
+        y = self._batch(x, self._mag, 0)
+        return wrap(y[:, :self.n_bin]), wrap(y[:, self.n_bin:])
+
+    __call__ = forward
+
+    def power(self, x):
+        if self._pow is None:
+            n_fft, hop, win, window, center = self._args
+            self._pow = _Engine(n_fft, hop, win, window, center, True, None, 0)
+        return wrap(self._batch(x, self._pow, 1))
+
+    def magnitude(self, x):
+        return wrap(self._batch(x, self._mag, 1))
+
+
+class MelScale:
+    """(B, n_freq, frames) -> (B, n_mels, frames); audio.py:218-229 (a plain matmul with the basis)."""
+
+    def __init__(self, sr, n_fft, n_mels, fmin, fmax):
+        self.weight = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
+
+    def forward(self, spec):
+        return torch.matmul(self.weight.to(spec.device), spec)
+
+    __call__ = forward
+
+
+class LogMelFBank:
+    """get_feats.py:20-88 on the device: wav -> (num_frames, n_mels) log-mel."""
+
+    def __init__(self, sr=24000, n_fft=2048, hop_length=300, win_length=None, window="hann", n_mels=80,
+                 fmin=80, fmax=7600, eps=1e-10):
+        self.sr, self.n_fft, self.hop_length = sr, n_fft, hop_length
+        self.fmin = 0 if fmin is None else fmin
+        self.fmax = sr / 2 if fmax is None else fmax
+        self.mel_filter = mel_filterbank(sr, n_fft, n_mels, self.fmin, self.fmax)
+        self._args = (n_fft, hop_length, win_length or n_fft, window)
+        self._eng = {}
+
+    def _engine(self, base):
+        if base not in self._eng:
+            n_fft, hop, win, window = self._args
+            self._eng[base] = _Engine(n_fft, hop, win, window, True, False, self.mel_filter,
+                                      10 if base == "10" else 2)
+        return self._eng[base]
+
+    def get_log_mel_fbank(self, wav, base="10"):
+        return wrap(self._engine(base).run([wav], 2)[0])
+
+    def get_log_mel_fbank_batch(self, wavs, base="10"):
+        return [wrap(o) for o in self._engine(base).run(list(wavs), 2)]

@@ -1,0 +1,47 @@
+"""CPU checks of the STFT / mel oracle: against numpy's FFT, against mel-scale identities, and the
+product-side filterbank builder against the oracle's (two independent writings of librosa's algorithm)."""
+import numpy as np
+import torch
+
+from oracle import audio_ref
+
+
+def test_oracle_stft_matches_numpy_rfft():
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(2, 4096)).astype(np.float32)
+    re, im = audio_ref.stft(torch.from_numpy(x), n_fft=1024, hop_length=256, dtype=torch.float64)
+    assert re.shape == (2, 513, 1 + 4096 // 256)          # frames = 1 + T // hop (audio.py:103-105)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (512, 512)), mode="reflect")
+    win = audio_ref.window_padded("hann", 1024, 1024)
+    for f in (0, 3, 16):
+        spec = np.fft.rfft(xp[:, f * 256:f * 256 + 1024] * win, axis=-1)
+        np.testing.assert_allclose(re[:, :, f].numpy(), spec.real, atol=1e-9)
+        np.testing.assert_allclose(im[:, :, f].numpy(), spec.imag, atol=1e-9)
+
+
+def test_mel_scale_identities():
+    # Slaney scale: linear below 1 kHz (200/3 Hz per mel), log above; 1 kHz <-> 15 mel
+    assert abs(audio_ref.hz_to_mel(1000.0) - 15.0) < 1e-12
+    assert abs(audio_ref.mel_to_hz(15.0) - 1000.0) < 1e-9
+    assert abs(audio_ref.hz_to_mel(500.0) - 7.5) < 1e-12
+    f = np.array([80.0, 440.0, 1000.0, 4000.0, 7600.0])
+    np.testing.assert_allclose(audio_ref.mel_to_hz(audio_ref.hz_to_mel(f)), f, rtol=1e-12)
+    fb = audio_ref.mel_filterbank(22050, 1024, 80, 80, 7600)
+    assert fb.shape == (80, 513) and fb.dtype == np.float32
+    assert (fb >= 0).all() and (fb.sum(1) > 0).all()
+    # slaney norm: each triangle integrates to ~1 over frequency (bin width sr/n_fft)
+    area = fb.sum(1) * (22050 / 1024)
+    assert np.all(np.abs(area[10:] - 1.0) < 0.1)
+    # filters outside [fmin, fmax] are zero
+    freqs = np.linspace(0, 22050 / 2, 513)
+    assert fb[:, freqs < 80 - 1e-9].sum() == 0 and fb[:, freqs > 7600 + 1e-9].sum() == 0
+
+
+def test_product_filterbank_equals_oracle():
+    from parakeet_amd.audio import mel_filterbank
+    for args in [(22050, 1024, 80, 80, 7600), (24000, 2048, 80, 80, 7600), (22050, 1024, 80, 0, 8000),
+                 (16000, 512, 40, 0, None)]:
+        a = mel_filterbank(*args)
+        b = audio_ref.mel_filterbank(*args)
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
