@@ -239,6 +239,25 @@ int pk_mel_run(pk_mel* h, const float* wav, const int32_t* lens, int32_t B, floa
                int32_t what, int32_t flags);
 void pk_mel_destroy(pk_mel* h);
 
+/* ------------------------------------------ generic primitives (parakeet/modules) */
+/* sinusoid_position_encoding (positional_encoding.py:20-39) -> out (num_positions, feature_size), device. */
+int pk_op_sinusoid_position_encoding(pk_ctx* ctx, int32_t num_positions, int32_t feature_size,
+                                     float omega, int32_t start_pos, float* out);
+/* scaled_dot_product_attention (attention.py:22-58), eval mode (no dropout).  q (B,Tq,d), k (B,Tk,d),
+ * v (B,Tk,dv) device; mask float (zeros = padding, adds (1-mask)*-1e9) or NULL, mask_mode 0: (B,1,Tk),
+ * 1: (B,Tq,Tk), 2: (1,Tq,Tk).  out (B,Tq,dv); weights (B,Tq,Tk) or NULL. */
+int pk_op_scaled_dot_product_attention(pk_ctx* ctx, const float* q, const float* k, const float* v,
+                                       const float* mask, int32_t mask_mode, int32_t B, int32_t Tq,
+                                       int32_t Tk, int32_t d, int32_t dv, float* out, float* weights);
+/* Conv1dBatchNorm.forward (conv.py:186-260) in eval mode, data_format "NLC", stride 1, symmetric
+ * padding: x (B,T,Cin) device -> y (B, T+2*pad-k+1, Cout) device.  weight [Cout][Cin][k], bias [Cout] or
+ * NULL, BatchNorm1D weight/bias/_mean/_variance [Cout] (all four or none) are HOST pointers.
+ * Synchronous (weights are packed per call). */
+int pk_op_conv1d_batchnorm_nlc(pk_ctx* ctx, const float* x, int32_t B, int32_t T, int32_t Cin,
+                               int32_t Cout, int32_t k, int32_t pad, const float* weight,
+                               const float* bias, const float* bn_weight, const float* bn_bias,
+                               const float* bn_mean, const float* bn_var, float eps, float* y);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,182 @@
+// ops.hip -- generic primitives of parakeet/modules exposed on the engine's kernels:
+//   sinusoid_position_encoding   parakeet/modules/positional_encoding.py:20-39
+//   scaled_dot_product_attention parakeet/modules/attention.py:22-58 (float mask, returns the weights)
+//   Conv1dBatchNorm.forward      parakeet/modules/conv.py:186-260 (eval mode, NLC layout)
+// Not on the FastSpeech2/PWG/WaveFlow path; they serve the other models' inference code.
+#include <cmath>
+
+#include "pk_gemm.h"
+
+namespace {
+
+// enc[pos][2i] = sin(p), enc[pos][2i+1] = cos(p), p = (start + pos) * omega / 10000^(2i / size)
+__global__ void k_sinusoid(float* __restrict__ out, int num_positions, int size, float omega, int start_pos) {
+    const int pos = blockIdx.x;
+    for (int c = threadIdx.x; c < size; c += blockDim.x) {
+        const float channel = (float)(c & ~1);
+        const float p = ((float)(start_pos + pos) * omega) / powf(10000.0f, channel / (float)size);
+        out[(long)pos * size + c] = (c & 1) ? cosf(p) : sinf(p);
+    }
+}
+
+// One wave per (batch, query): weights = softmax(q.k^T / sqrt(d) + (1 - mask) * -1e9), out = weights . v
+// mask: float, strides given so that (B,1,Tk), (B,Tq,Tk) or (1,Tq,Tk) broadcast.
+__global__ __launch_bounds__(256) void k_sdpa(const float* __restrict__ q, const float* __restrict__ k,
+                                              const float* __restrict__ v, const float* __restrict__ mask,
+                                              long mask_sb, long mask_sq, int B, int Tq, int Tk, int d, int dv,
+                                              float* __restrict__ out, float* __restrict__ weights) {
+    extern __shared__ float sh[];   // per wave: d floats of q + Tk floats of scores
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= (long)B * Tq) return;
+    const int b = (int)(row / Tq), tq = (int)(row % Tq);
+    float* qs = sh + (size_t)wave * (d + Tk);
+    float* sc = qs + d;
+    const float* qp = q + row * d;
+    for (int c = lane; c < d; c += 64) qs[c] = qp[c];
+    const float scale = 1.0f / sqrtf((float)d);
+    float mx = -INFINITY;
+    for (int j = lane; j < Tk; j += 64) {
+        const float* kp = k + ((long)b * Tk + j) * d;
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) s = fmaf(qs[c], kp[c], s);
+        s *= scale;
+        if (mask) s += (1.0f - mask[b * mask_sb + tq * mask_sq + j]) * -1e9f;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < Tk; j += 64) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Tk; j += 64) {
+        sc[j] *= inv;
+        if (weights) weights[row * Tk + j] = sc[j];
+    }
+    for (int c = lane; c < dv; c += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < Tk; ++j) acc = fmaf(sc[j], v[((long)b * Tk + j) * dv + c], acc);
+        out[row * dv + c] = acc;
+    }
+}
+
+// rows of a (B, T, C) NLC tensor -> row timeline with `gap` zero rows around every sequence
+__global__ void k_nlc_to_timeline(const float* __restrict__ x, int T, int C, int gap, float* __restrict__ tl) {
+    const int r = blockIdx.x;                       // timeline row
+    const int per = T + gap;
+    const int b = (r - gap) / per, t = (r - gap) - b * per;
+    const bool valid = r >= gap && t < T;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        tl[(long)r * C + c] = valid ? x[((long)b * T + t) * C + c] : 0.f;
+}
+
+}  // namespace
+
+extern "C" int pk_op_sinusoid_position_encoding(pk_ctx* ctx, int32_t num_positions, int32_t feature_size,
+                                                float omega, int32_t start_pos, float* out) {
+    if (!ctx || !out) PK_FAIL(PK_EINVAL, "pk_op_sinusoid_position_encoding: NULL argument");
+    if (num_positions <= 0 || feature_size <= 0) PK_FAIL(PK_EINVAL, "sinusoid_position_encoding: empty table");
+    PK_HIP(hipSetDevice(ctx->device));
+    PK_LAUNCH(ctx, "op_sinusoid", k_sinusoid, dim3(num_positions), dim3(128), 0, out, num_positions, feature_size,
+              omega, start_pos);
+    return PK_OK;
+}
+
+extern "C" int pk_op_scaled_dot_product_attention(pk_ctx* ctx, const float* q, const float* k, const float* v,
+                                                  const float* mask, int32_t mask_mode, int32_t B, int32_t Tq,
+                                                  int32_t Tk, int32_t d, int32_t dv, float* out, float* weights) {
+    if (!ctx || !q || !k || !v || !out) PK_FAIL(PK_EINVAL, "pk_op_scaled_dot_product_attention: NULL argument");
+    if (B <= 0 || Tq <= 0 || Tk <= 0 || d <= 0 || dv <= 0) PK_FAIL(PK_EINVAL, "attention: empty problem");
+    PK_HIP(hipSetDevice(ctx->device));
+    long sb = 0, sq = 0;
+    switch (mask ? mask_mode : -1) {
+        case -1: break;
+        case 0: sb = Tk; sq = 0; break;                  // (B, 1, Tk)
+        case 1: sb = (long)Tq * Tk; sq = Tk; break;      // (B, Tq, Tk)
+        case 2: sb = 0; sq = Tk; break;                  // (1, Tq, Tk)
+        default: PK_FAIL(PK_EINVAL, "attention: unknown mask mode %d", mask_mode);
+    }
+    const size_t shmem = (size_t)4 * (d + Tk) * sizeof(float);
+    if (shmem > 64 * 1024) PK_FAIL(PK_EUNSUPPORTED, "attention: d + Tk = %d too large for this primitive", d + Tk);
+    const long rows = (long)B * Tq;
+    PK_LAUNCH(ctx, "op_sdpa", k_sdpa, dim3(pk_div_up(rows, 4)), dim3(256), shmem, q, k, v, mask, sb, sq, B, Tq, Tk,
+              d, dv, out, weights);
+    return PK_OK;
+}
+
+// y = BatchNorm1D_eval(Conv1D(x)) for NLC x (B, T, Cin), stride 1, symmetric padding `pad`
+// (T_out = T + 2*pad - k + 1).  bn_* may be NULL (plain conv).  Weights are packed per call.
+extern "C" int pk_op_conv1d_batchnorm_nlc(pk_ctx* ctx, const float* x, int32_t B, int32_t T, int32_t Cin,
+                                          int32_t Cout, int32_t k, int32_t pad, const float* weight,
+                                          const float* bias, const float* bn_weight, const float* bn_bias,
+                                          const float* bn_mean, const float* bn_var, float eps, float* y) {
+    if (!ctx || !x || !weight || !y) PK_FAIL(PK_EINVAL, "pk_op_conv1d_batchnorm_nlc: NULL argument");
+    if (B <= 0 || T <= 0 || k <= 0 || pad < 0 || k > PK_GEMM_MAX_TAPS) PK_FAIL(PK_EINVAL, "conv1d: bad shape");
+    if (Cin % PK_GEMM_BK != 0) PK_FAIL(PK_EUNSUPPORTED, "conv1d: in_channels must be a multiple of %d", PK_GEMM_BK);
+    const int Tout = T + 2 * pad - k + 1;
+    if (Tout <= 0) PK_FAIL(PK_ESHAPE, "conv1d: kernel larger than padded input");
+    PK_HIP(hipSetDevice(ctx->device));
+    // fold BN: w' = w * g / sqrt(var + eps), b' = (b - mean) * g / sqrt(var + eps) + beta
+    std::vector<float> w((size_t)Cout * Cin * k), b(Cout, 0.f), kn, packed;
+    for (int o = 0; o < Cout; ++o) {
+        double s = 1.0, sh = bias ? bias[o] : 0.0;
+        if (bn_weight) {
+            s = (double)bn_weight[o] / std::sqrt((double)bn_var[o] + eps);
+            sh = (sh - bn_mean[o]) * s + bn_bias[o];
+        }
+        for (size_t i = 0; i < (size_t)Cin * k; ++i) w[o * (size_t)Cin * k + i] = (float)(weight[o * (size_t)Cin * k + i] * s);
+        b[o] = (float)sh;
+    }
+    pk_conv_to_kn(w.data(), Cout, Cin, k, kn);
+    pk_gemm_pack(kn.data(), Cin * k, Cout, packed);
+    const int gap = k;   // >= both paddings
+    const int rows = gap + B * (T + gap);
+    const int rows_alloc = ((rows + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM + 2 * gap;
+    pk_dbuf d_w, d_b, d_tl, d_map;
+    int st = PK_OK;
+    auto cleanup = [&]() { d_w.release(); d_b.release(); d_tl.release(); d_map.release(); };
+    std::vector<int> rowmap(rows_alloc, -1);
+    // output row (b, t) = timeline row gap + b*(T+gap) + t - pad + (k-1)/2 ... expressed through the tap offsets below
+    for (int bb = 0; bb < B; ++bb)
+        for (int t = 0; t < Tout; ++t) rowmap[gap + bb * (T + gap) + t] = bb * Tout + t;
+    if ((st = pk_upload(ctx, d_w, packed.data(), packed.size() * 4)) != PK_OK ||
+        (st = pk_upload(ctx, d_b, b.data(), b.size() * 4)) != PK_OK ||
+        (st = pk_upload(ctx, d_map, rowmap.data(), rowmap.size() * 4)) != PK_OK ||
+        (st = d_tl.reserve((size_t)(rows_alloc + gap) * Cin * 4)) != PK_OK) {
+        cleanup();
+        return st;
+    }
+    float* tl = d_tl.as<float>() + (size_t)gap * Cin;
+    hipLaunchKernelGGL(k_nlc_to_timeline, dim3(rows), dim3(128), 0, ctx->stream, x, T, Cin, gap, tl);
+    pk_gemm_args g;
+    g.A = tl;
+    g.lda = Cin;
+    g.Cin = Cin;
+    g.ntaps = k;
+    for (int t = 0; t < k; ++t) {       // output t reads inputs t - pad + tap
+        g.tap_off[t] = (long)(t - pad) * Cin;
+        g.tap_w[t] = t;
+    }
+    g.wslabs_total = Cin * k / PK_GEMM_BK;
+    g.Wp = d_w.as<float>();
+    g.bias = d_b.as<float>();
+    g.C = y;
+    g.ldc = Cout;
+    g.out_rowmap = d_map.as<int>();
+    g.M = rows;
+    g.N = Cout;
+    st = pk_gemm_launch(ctx, "op_conv1d_bn", g);
+    if (st == PK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        pk_set_error("conv1d: stream sync failed");
+        st = PK_EHIP;
+    }
+    cleanup();
+    return st;
+}

@@ -1,0 +1,95 @@
+"""Generic primitives of ``parakeet.modules`` on the engine's kernels.
+
+``scaled_dot_product_attention`` (parakeet/modules/attention.py:22-58),
+``sinusoid_position_encoding`` (parakeet/modules/positional_encoding.py:20-39) and
+``Conv1dBatchNorm`` (parakeet/modules/conv.py:186-260, eval mode) with the reference's signatures.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .runtime import Context, dptr, to_numpy_f32, wrap
+
+
+def sinusoid_position_encoding(num_positions, feature_size, omega=1.0, start_pos=0, dtype=None):
+    ctx = Context.get()
+    out = ctx.empty((num_positions, feature_size))
+    _capi.check(ctx.lib.pk_op_sinusoid_position_encoding(ctx.handle, int(num_positions), int(feature_size),
+                                                         C.c_float(omega), int(start_pos), dptr(out)))
+    return wrap(out)
+
+
+def scaled_dot_product_attention(q, k, v, mask=None, dropout=0.0, training=True):
+    if dropout and training:
+        raise NotImplementedError("attention dropout is a training-time path")
+    ctx = Context.get()
+    q, k, v = ctx.to_device(q), ctx.to_device(k), ctx.to_device(v)
+    lead = q.shape[:-2]
+    B = int(np.prod(lead)) if lead else 1
+    Tq, d = q.shape[-2], q.shape[-1]
+    Tk, dv = k.shape[-2], v.shape[-1]
+    q2, k2, v2 = q.reshape(B, Tq, d), k.reshape(B, Tk, d), v.reshape(B, Tk, dv)
+    mptr, mode = None, 0
+    if mask is not None:
+        m = ctx.to_device(mask)
+        while m.dim() < q.dim():
+            m = m.unsqueeze(0)
+        if m.shape[-2] == 1:
+            m2, mode = m.expand(*lead, 1, Tk).reshape(B, 1, Tk).contiguous(), 0
+        elif int(np.prod(m.shape[:-2])) == 1 and B > 1:
+            m2, mode = m.reshape(1, Tq, Tk).contiguous(), 2
+        else:
+            m2, mode = m.expand(*lead, Tq, Tk).reshape(B, Tq, Tk).contiguous(), 1
+        mptr = dptr(m2)
+    out = ctx.empty((B, Tq, dv))
+    w = ctx.empty((B, Tq, Tk))
+    _capi.check(ctx.lib.pk_op_scaled_dot_product_attention(ctx.handle, dptr(q2), dptr(k2), dptr(v2), mptr, mode,
+                                                           B, Tq, Tk, d, dv, dptr(out), dptr(w)))
+    return wrap(out.reshape(*lead, Tq, dv)), wrap(w.reshape(*lead, Tq, Tk))
+
+
+class Conv1dBatchNorm:
+    """Conv1D followed by BatchNorm1D (eval mode); state-dict keys conv.weight [Cout,Cin,k], conv.bias,
+    bn.weight, bn.bias, bn._mean, bn._variance."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, weight_attr=None,
+                 bias_attr=None, data_format="NCL", momentum=0.9, epsilon=1e-05):
+        if stride != 1:
+            raise NotImplementedError("Conv1dBatchNorm: stride 1 only")
+        if not isinstance(padding, int):
+            raise NotImplementedError("Conv1dBatchNorm: int padding only")
+        self.cin, self.cout, self.k, self.pad = in_channels, out_channels, kernel_size, padding
+        self.data_format, self.eps = data_format, epsilon
+        self._state = None
+        self.training = True
+
+    def set_state_dict(self, state):
+        self._state = {k: to_numpy_f32(v) for k, v in state.items()}
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def forward(self, x):
+        if self._state is None:
+            raise RuntimeError("Conv1dBatchNorm: parameters were never set")
+        ctx = Context.get()
+        x = ctx.to_device(x)
+        if self.data_format == "NCL":
+            x = x.transpose(1, 2).contiguous()
+        B, T, _ = x.shape
+        tout = T + 2 * self.pad - self.k + 1
+        y = ctx.empty((B, tout, self.cout))
+        s = self._state
+        f = _capi.fptr
+        _capi.check(ctx.lib.pk_op_conv1d_batchnorm_nlc(
+            ctx.handle, dptr(x), B, T, self.cin, self.cout, self.k, self.pad, f(s["conv.weight"]),
+            f(s["conv.bias"]) if "conv.bias" in s else None, f(s["bn.weight"]), f(s["bn.bias"]), f(s["bn._mean"]),
+            f(s["bn._variance"]), C.c_float(self.eps), dptr(y)))
+        if self.data_format == "NCL":
+            y = y.transpose(1, 2).contiguous()
+        return wrap(y)
+
+    __call__ = forward

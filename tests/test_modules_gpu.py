@@ -1,0 +1,70 @@
+"""GPU parity of the generic parakeet.modules primitives against direct restatements of
+attention.py:22-58, positional_encoding.py:20-39 and conv.py:186-260."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sinusoid_position_encoding():
+    from parakeet_amd.modules import sinusoid_position_encoding
+    got = sinusoid_position_encoding(50, 64, omega=1.5, start_pos=3).numpy()
+    channel = np.arange(0, 64, 2, dtype=np.float64)
+    index = np.arange(3, 53, dtype=np.float64)
+    p = (index[:, None] * 1.5) / (10000.0 ** (channel / 64.0))
+    want = np.zeros((50, 64))
+    want[:, 0::2], want[:, 1::2] = np.sin(p), np.cos(p)
+    assert np.abs(got - want).max() < 5e-5
+
+
+def test_scaled_dot_product_attention_masks_and_weights():
+    from parakeet_amd.modules import scaled_dot_product_attention
+    rng = np.random.default_rng(0)
+    q = rng.normal(size=(2, 3, 7, 32)).astype(np.float32)
+    k = rng.normal(size=(2, 3, 11, 32)).astype(np.float32)
+    v = rng.normal(size=(2, 3, 11, 20)).astype(np.float32)
+    mask = np.ones((2, 3, 1, 11), np.float32)
+    mask[0, :, :, 8:] = 0
+    mask[1, :, :, 5:] = 0
+
+    def ref(q, k, v, m):
+        logit = torch.matmul(torch.tensor(q).double(), torch.tensor(k).double().transpose(-1, -2)) / math.sqrt(q.shape[-1])
+        if m is not None:
+            logit = logit + (1.0 - torch.tensor(m).double()) * -1e9
+        w = torch.softmax(logit, -1)
+        return torch.matmul(w, torch.tensor(v).double()).numpy(), w.numpy()
+
+    for m in (None, mask, np.tril(np.ones((7, 11), np.float32))):
+        out, w = scaled_dot_product_attention(q, k, v, m)
+        ro, rw = ref(q, k, v, m)
+        assert np.abs(out.numpy() - ro).max() < 1e-4
+        assert np.abs(w.numpy() - rw).max() < 1e-5
+
+
+def test_conv1d_batchnorm_ncl_and_nlc():
+    from parakeet_amd.modules import Conv1dBatchNorm
+    rng = np.random.default_rng(1)
+    cin, cout, k, pad = 32, 48, 5, 2
+    state = {"conv.weight": rng.normal(size=(cout, cin, k)).astype(np.float32) * 0.1,
+             "conv.bias": rng.normal(size=cout).astype(np.float32),
+             "bn.weight": rng.uniform(0.5, 1.5, cout).astype(np.float32),
+             "bn.bias": rng.normal(size=cout).astype(np.float32),
+             "bn._mean": rng.normal(size=cout).astype(np.float32),
+             "bn._variance": rng.uniform(0.5, 1.5, cout).astype(np.float32)}
+    x = rng.normal(size=(3, cin, 37)).astype(np.float32)
+    y = torch.nn.functional.conv1d(torch.tensor(x).double(), torch.tensor(state["conv.weight"]).double(),
+                                   torch.tensor(state["conv.bias"]).double(), padding=pad)
+    y = (y - torch.tensor(state["bn._mean"]).double()[None, :, None]) / torch.sqrt(
+        torch.tensor(state["bn._variance"]).double()[None, :, None] + 1e-5) * torch.tensor(
+        state["bn.weight"]).double()[None, :, None] + torch.tensor(state["bn.bias"]).double()[None, :, None]
+    for fmt in ("NCL", "NLC"):
+        m = Conv1dBatchNorm(cin, cout, k, padding=pad, data_format=fmt)
+        m.set_state_dict(state)
+        m.eval()
+        got = m(x if fmt == "NCL" else np.ascontiguousarray(x.transpose(0, 2, 1))).numpy()
+        want = y.numpy() if fmt == "NCL" else y.numpy().transpose(0, 2, 1)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 1e-4
