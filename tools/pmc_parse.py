@@ -12,7 +12,7 @@ for d in args:
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
             if kern and kern not in name: continue
-            short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+            short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
             dur[short].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         for (k, c), v in sorted(agg.items()):
