@@ -40,8 +40,10 @@ FRAMES_PER_TOKEN = 5
 # algorithmic work of one ResidualBlock per output sample:
 # dilated conv 2*192*128 + aux 1x1 2*80*128 + skip 2*64*64 + out 2*64*64
 PWG_LAYER_FLOP_PER_SAMPLE = 86016
-# layer-granular byte model per sample per layer (read x 256 + read c 320 + write x 256 + RMW skip 512)
+# SURVEY.md 8(d) layer-granular byte model per sample per layer (read x 256 + read c 320 + write x 256 +
+# RMW skip 512); the engine never materialises c, its own minimum is 1024 B
 PWG_LAYER_BYTES_PER_SAMPLE = 1344
+PWG_LAYER_MIN_BYTES_PER_SAMPLE = 1024
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -222,6 +224,9 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "layer_granular_bytes_per_launch": PWG_LAYER_BYTES_PER_SAMPLE * n_samples,
+                "engine_min_bytes_per_launch": PWG_LAYER_MIN_BYTES_PER_SAMPLE * n_samples,
+                "traffic_source": "profiles/pwg_layer_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                  "calibrated; same batch)" if traffic is not None else None,
                 "hbm_frac_layer_granular": (PWG_LAYER_BYTES_PER_SAMPLE * n_samples / (avg_ms * 1e-3) / 8.0e12)
                 if avg_ms > 0 else 0.0,
             },
