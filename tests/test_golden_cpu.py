@@ -35,3 +35,13 @@ def test_pwg_oracle_matches_reference_source():
     w2 = pwg_ref.pwg_inference(state, g["mu"], g["sigma"], torch.from_numpy(logmel),
                                torch.from_numpy(g["inf_noise"])).numpy()
     assert np.abs(w2 - g["pinf_wav"]).max() < 1e-5
+
+
+def test_waveflow_oracle_matches_reference_source():
+    from oracle import waveflow_ref
+    g = np.load(os.path.join(GOLD, "waveflow_c64.npz"))
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64)
+    state = syn.waveflow_state(cfg, seed=int(g["seed"]), weight_norm=True)
+    wav = waveflow_ref.infer(state, torch.from_numpy(g["mel"]), torch.from_numpy(g["z"]), cfg).numpy()
+    assert wav.shape == g["wav"].shape
+    assert np.abs(wav - g["wav"]).max() < 1e-5 * max(1.0, np.abs(g["wav"]).max())

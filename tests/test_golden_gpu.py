@@ -49,3 +49,15 @@ def test_pwg_engine_matches_reference_source():
     inf = PWGInference(ZScore(g["mu"], g["sigma"]), gen)
     w2 = inf(g["inf_mel"] * g["sigma"] + g["mu"], noise=g["inf_noise"]).numpy()
     assert np.abs(w2 - g["pinf_wav"]).max() < 1e-4 * np.abs(g["pinf_wav"]).max()
+
+
+def test_waveflow_engine_matches_reference_source():
+    from parakeet_amd.waveflow import ConditionalWaveFlow
+    g = np.load(os.path.join(GOLD, "waveflow_c64.npz"))
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64)
+    model = ConditionalWaveFlow(**cfg)
+    model.set_state_dict(syn.waveflow_state(cfg, seed=int(g["seed"]), weight_norm=True))
+    model.eval()
+    wav = model.infer(g["mel"], z=g["z"]).numpy()
+    assert wav.shape == g["wav"].shape
+    assert np.abs(wav - g["wav"]).max() < 1e-3 * np.abs(g["wav"]).max()
