@@ -21,9 +21,12 @@ constexpr int BM = PK_GEMM_BM, BN = PK_GEMM_BN, BK = PK_GEMM_BK;
 
 __device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// SPI = K slabs (of 16) consumed per barrier: 2 halves the barrier / LDS-turnaround count on long K
+// (64 KB of LDS, two blocks per CU); 1 keeps small problems at 32 KB.
+template <int SPI>
 __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    __shared__ __attribute__((aligned(16))) float As[2][SPI][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SPI][BK * BN];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -41,8 +44,9 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
     const int a_lds = (((lhalf * 8) * 2 + (lrow >> 6)) * 32 + (lrow & 31)) * 2 + ((lrow >> 5) & 1);
     const float* wsrc = a.Wp + (long)nblk * a.wslabs_total * (BK * BN) + tid * 8;
 
-    f32x4 ra0, ra1, rb0, rb1;
-    auto load_slab = [&](int s) {
+    f32x4 ra0[SPI], ra1[SPI], rb0[SPI], rb1[SPI];
+    auto load_slab = [&](int s, int u) {
+        if (s >= nslabs) return;
         const float* p;
         int wslab;
         if (s < nmain) {
@@ -53,21 +57,21 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
             p = arow2 + (s - nmain) * BK;
             wslab = a.w2_slab0 + (s - nmain);
         }
-        ra0 = *reinterpret_cast<const f32x4*>(p);
-        ra1 = *reinterpret_cast<const f32x4*>(p + 4);
+        ra0[u] = *reinterpret_cast<const f32x4*>(p);
+        ra1[u] = *reinterpret_cast<const f32x4*>(p + 4);
         const float* q = wsrc + (long)wslab * (BK * BN);
-        rb0 = *reinterpret_cast<const f32x4*>(q);
-        rb1 = *reinterpret_cast<const f32x4*>(q + 4);
+        rb0[u] = *reinterpret_cast<const f32x4*>(q);
+        rb1[u] = *reinterpret_cast<const f32x4*>(q + 4);
     };
-    auto store_slab = [&](int buf) {
-        float* d = As[buf] + a_lds;
+    auto store_slab = [&](int buf, int u) {
+        float* d = As[buf][u] + a_lds;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e * 128] = ra0[e];
+        for (int e = 0; e < 4; ++e) d[e * 128] = ra0[u][e];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[(4 + e) * 128] = ra1[e];
-        f32x4* b = reinterpret_cast<f32x4*>(Bs[buf] + tid * 8);
-        b[0] = rb0;
-        b[1] = rb1;
+        for (int e = 0; e < 4; ++e) d[(4 + e) * 128] = ra1[u][e];
+        f32x4* b = reinterpret_cast<f32x4*>(Bs[buf][u] + tid * 8);
+        b[0] = rb0[u];
+        b[1] = rb1[u];
     };
 
     f32x16 acc[2][2];
@@ -78,24 +82,36 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
-    for (int s = 0; s < nslabs; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nslabs) load_slab(s + 1);
-        const f32x2* fa = reinterpret_cast<const f32x2*>(As[buf]) + (hi * 2 + wm) * 32 + i;
-        const f32x2* fb = reinterpret_cast<const f32x2*>(Bs[buf]) + (hi * 2 + wn) * 32 + i;
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const f32x2 av = fa[ks * 128];
-            const f32x2 bv = fb[ks * 128];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+    for (int u = 0; u < SPI; ++u) load_slab(u, u);
+#pragma unroll
+    for (int u = 0; u < SPI; ++u) store_slab(0, u);
+    __syncthreads();
+    for (int s = 0; s < nslabs; s += SPI) {
+        const int buf = (s / SPI) & 1;
+#pragma unroll
+        for (int u = 0; u < SPI; ++u) load_slab(s + SPI + u, u);
+#pragma unroll
+        for (int u = 0; u < SPI; ++u) {
+            if (s + u < nslabs) {
+                const f32x2* fa = reinterpret_cast<const f32x2*>(As[buf][u]) + (hi * 2 + wm) * 32 + i;
+                const f32x2* fb = reinterpret_cast<const f32x2*>(Bs[buf][u]) + (hi * 2 + wn) * 32 + i;
+#pragma unroll
+                for (int ks = 0; ks < BK / 2; ++ks) {
+                    const f32x2 av = fa[ks * 128];
+                    const f32x2 bv = fb[ks * 128];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+                }
+            }
         }
-        if (s + 1 < nslabs) store_slab(buf ^ 1);
+        if (s + SPI < nslabs) {
+#pragma unroll
+            for (int u = 0; u < SPI; ++u)
+                if (s + SPI + u < nslabs) store_slab(buf ^ 1, u);
+        }
         __syncthreads();
     }
 
@@ -221,6 +237,10 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     if (!a.A2) { a.A2 = a.A; a.lda2 = 0; }
     if (a.epi == PK_EPI_GATE && (a.N % 128 != 0)) PK_FAIL(PK_EUNSUPPORTED, "gated GEMM needs N %% 128 == 0");
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
-    PK_LAUNCH(ctx, prof_name, k_gemm, grid, dim3(256), 0, a);
+    const int nslabs = a.ntaps * (a.Cin / BK) + a.Cin2 / BK;
+    // k_gemm<2> (two slabs per barrier, 64 KB LDS) measured slower on every FS2 / WaveFlow shape
+    // (ffn1 0.49 vs 0.42 ms, WaveFlow conv 160 vs 140 us): occupancy beats fewer barriers here.
+    (void)nslabs;
+    PK_LAUNCH(ctx, prof_name, k_gemm<1>, grid, dim3(256), 0, a);
     return PK_OK;
 }

@@ -343,14 +343,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         prefetch_head(next_tile);            // next tile's aux rows + upsampler weights
         __builtin_amdgcn_sched_barrier(0);
 
-        // gated activation; z overwrites acc[0], acc[1]
-        if (!(a.dbg & 1)) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][r] = gated(acc[q][r], acc[q + 2][r]);
-        }
-
+        // The gated activation z = tanh(a) * sigmoid(b) (overwriting acc[0], acc[1]) is computed inside
+        // pass 0 of stage 2, one k-step ahead of the MFMAs that consume it, so its VALU / transcendental
+        // work runs under this wave's own matrix instructions.
+        const bool do_gate = !(a.dbg & 1);
         // Stage 2 in two passes (out, then skip) so that only 32 old values + 32 accumulators are
         // live next to z: leaves registers for the next tile's prefetched head.  The old values of a
         // pass are requested before its 64 MFMAs (4096 matrix-pipe cycles) and consumed after them --
@@ -384,10 +380,15 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     acc2[q][4 * r4 + 2] = bv[2];
                     acc2[q][4 * r4 + 3] = bv[3];
                 }
+            if (pass == 0 && do_gate) acc[0][0] = gated(acc[0][0], acc[2][0]);
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
                 const f32x2 af = lds_w2[ks * 128 + pass];
                 acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], acc[ks >> 4][ks & 15], acc2[0], 0, 0, 0);
+                if (pass == 0 && do_gate && ks + 1 < KS2) {
+                    const int kn = ks + 1;   // gate of the next k-step, under the two MFMAs of this one
+                    acc[kn >> 4][kn & 15] = gated(acc[kn >> 4][kn & 15], acc[(kn >> 4) + 2][kn & 15]);
+                }
                 acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], acc[ks >> 4][ks & 15], acc2[1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -1,0 +1,132 @@
+"""Full-size (BASELINE.json configs 2-4 per-GPU share) checks through size-independent properties --
+the oracle would need minutes here, so these assert what must hold at any size:
+determinism, batch-composition invariance (an utterance's output does not depend on what else is in
+the batch or where it sits), duration/length bookkeeping, finiteness; plus edge cases of the domain
+(zero-frame utterances, single tokens, positional table growth)."""
+import numpy as np
+import pytest
+import torch
+
+from parakeet_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(fixed_duration=None, seed=10086):
+    from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
+    from parakeet_amd.normalizer import ZScore
+    from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference
+    from parakeet_amd.synthesize import Synthesizer
+    am = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am.set_state_dict(syn.fastspeech2_state(80, 80, fixed_duration=fixed_duration, seed=seed))
+    am.eval()
+    voc = PWGGenerator(**syn.PWG_LJSPEECH)
+    voc.set_state_dict(syn.pwg_state())
+    voc.remove_weight_norm()
+    voc.eval()
+    mu_f, sg_f = syn.mel_stats(seed=7)
+    mu_p, sg_p = syn.mel_stats(seed=8)
+    return Synthesizer(FastSpeech2Inference(ZScore(mu_f, sg_f), am), PWGInference(ZScore(mu_p, sg_p), voc))
+
+
+def test_e2e_batch32_full_size_properties():
+    synth = _models(fixed_duration=5)
+    texts = [syn.phoneme_ids(128, seed=100 + i) for i in range(32)]
+    n = 32 * 128 * 5 * 256
+    noise = torch.randn(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    wav1, frames = synth.synthesize_packed(texts, noise=noise)
+    assert frames.tolist() == [640] * 32 and wav1.numel() == n
+    assert bool(torch.isfinite(wav1).all())
+    wav2, _ = synth.synthesize_packed(texts, noise=noise)
+    assert torch.equal(wav1, wav2)                                   # deterministic, no atomics / races
+    # utterance 7 alone, and as the first of a different batch, gives bit-identical samples
+    per = 640 * 256
+    solo, _ = synth.synthesize_packed([texts[7]], noise=noise[7 * per:8 * per])
+    assert torch.equal(solo, wav1[7 * per:8 * per])
+    perm = [7, 0, 31]
+    nz = torch.cat([noise[i * per:(i + 1) * per] for i in perm])
+    sub, _ = synth.synthesize_packed([texts[i] for i in perm], noise=nz)
+    for k, i in enumerate(perm):
+        assert torch.equal(sub[k * per:(k + 1) * per], wav1[i * per:(i + 1) * per])
+    # different noise -> different audio, same length
+    wav3, _ = synth.synthesize_packed(texts, noise=noise.flip(0))
+    assert not torch.equal(wav3, wav1)
+
+
+def test_fs2_batch16_ragged_bookkeeping():
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    am = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am.set_state_dict(syn.fastspeech2_state(80, 80, seed=5))
+    am.eval()
+    am.set_debug(True)
+    rng = np.random.default_rng(0)
+    lens = rng.integers(37, 129, size=16).tolist()                   # BASELINE config 2 parity shape: T in [37,128]
+    texts = [syn.phoneme_ids(T, seed=200 + i) for i, T in enumerate(lens)]
+    outs = am.inference_batch(texts)
+    for b, o in enumerate(outs):
+        d = am.debug_tap(3, b)
+        assert d.shape == (lens[b],) and np.all(d >= 0) and np.all(d == np.round(d))
+        assert o.shape == (int(d.sum()), 80)                         # frames = sum of integer durations
+        assert np.isfinite(o.numpy()).all()
+    # batch-composition invariance: reversed batch gives bit-identical mels
+    rev = am.inference_batch(texts[::-1])
+    for b in range(16):
+        assert torch.equal(outs[b].as_subclass(torch.Tensor), rev[15 - b].as_subclass(torch.Tensor))
+
+
+def test_fs2_edge_cases_zero_frames_single_token_long_sequence():
+    from oracle import fastspeech2_ref as ref
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    # a duration head that predicts 0 frames for every token: exp(x) - 1 rounds to 0
+    st = syn.fastspeech2_state(80, 80, seed=9)
+    st["duration_predictor.linear.weight"][:] = 0.0
+    st["duration_predictor.linear.bias"][:] = np.log(1.2)
+    am = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am.set_state_dict(st)
+    am.eval()
+    outs = am.inference_batch([syn.phoneme_ids(5), syn.phoneme_ids(3)])
+    assert [tuple(o.shape) for o in outs] == [(0, 80), (0, 80)]
+    # mixed: one zero-frame utterance next to a normal one, single-token utterance
+    st2 = syn.fastspeech2_state(80, 80, seed=10)
+    am2 = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am2.set_state_dict(st2)
+    am2.eval()
+    ids = [np.array([5]), syn.phoneme_ids(40, seed=1)]
+    outs = am2.inference_batch(ids)
+    for i, o in zip(ids, outs):
+        want = ref.inference(st2, i).numpy()
+        assert o.shape == want.shape
+        if want.size:
+            assert np.abs(o.numpy() - want).mean() < 1e-4
+    # > 1024 frames: the positional table is regrown on demand (PE max_len 5000, embedding.py:36)
+    st3 = syn.fastspeech2_state(80, 80, seed=11, fixed_duration=9)
+    am3 = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am3.set_state_dict(st3)
+    am3.eval()
+    long_ids = syn.phoneme_ids(150, seed=2)
+    o = am3.inference(long_ids)
+    assert o.shape == (1350, 80)
+    want = ref.inference(st3, long_ids).numpy()
+    assert np.abs(o.numpy() - want).mean() < 1e-4
+
+
+def test_pwg_batch32_full_size_determinism_and_invariance():
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    gen = PWGGenerator(**syn.PWG_LJSPEECH)
+    gen.set_state_dict(syn.pwg_state())
+    gen.eval()
+    g = torch.Generator(device="cuda").manual_seed(42)
+    mel = torch.randn(32 * 640, 80, device="cuda", generator=g)
+    noise = torch.randn(32 * 640 * 256, device="cuda", generator=g)
+    frames = [640] * 32
+    a = gen.infer_packed(mel, frames, noise=noise)
+    b = gen.infer_packed(mel, frames, noise=noise)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    per = 640 * 256
+    one = gen.infer_packed(mel[5 * 640:6 * 640], [640], noise=noise[5 * per:6 * per])
+    assert torch.equal(one, a[5 * per:6 * per])
+    # ragged neighbours do not leak into each other: utterance 5 between short utterances
+    m2 = torch.cat([mel[:3], mel[5 * 640:6 * 640], mel[10:12]])
+    n2 = torch.cat([noise[:3 * 256], noise[5 * per:6 * per], noise[10 * 256:12 * 256]])
+    c = gen.infer_packed(m2, [3, 640, 2], noise=n2)
+    assert torch.equal(c[3 * 256:3 * 256 + per], a[5 * per:6 * per])

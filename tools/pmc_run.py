@@ -14,6 +14,12 @@ if mode == "pwg":
     noises = [torch.randn(L * 256, device="cuda") for _ in range(B)]
     gen.inference_batch(mels, noises)
     torch.cuda.synchronize()
+elif mode == "fs2":
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    m = FastSpeech2(80, 80, **syn.FS2_LJSPEECH); m.set_state_dict(syn.fastspeech2_state(fixed_duration=5)); m.eval()
+    texts = [syn.phoneme_ids(128, seed=i) for i in range(B)]
+    m.inference_batch(texts)
+    torch.cuda.synchronize()
 else:
     sys.argv = [sys.argv[0]]
     import bench
