@@ -115,6 +115,13 @@ int pk_pwg_set_param(pk_pwg* h, const char* name, const float* data,
 /* PWGInference's normalizer (ZScore, parakeet/modules/normalizer.py:18-33):
  * mel_in -> (mel_in - mu) / sigma.  NULL,NULL = identity. */
 int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_t n);
+/* Arithmetic of the residual-block contractions (default PK_PWG_MATH_F32, or env PK_PWG_MATH=bf16x3):
+ *   PK_PWG_MATH_F32     exact fp32 products on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);
+ *   PK_PWG_MATH_BF16X3  each fp32 product as a_hi*b_hi + a_lo*b_hi + a_hi*b_lo on bf16 MFMA with fp32
+ *                       accumulation; fp32 storage everywhere; 3e-6 relative max error on the 30-layer
+ *                       generator (exact path 5e-7), 5.3x less matrix-pipe time. */
+enum { PK_PWG_MATH_F32 = 0, PK_PWG_MATH_BF16X3 = 1 };
+int pk_pwg_set_math(pk_pwg* h, int32_t mode);
 /* remove_weight_norm + packing into the kernels' layouts + upload. */
 int pk_pwg_finalize(pk_pwg* h);
 /* PWGGenerator.inference for a packed batch.

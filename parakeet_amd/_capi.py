@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpk_synth.so")
 PK_OK = 0
 PK_HOST_IO = 1
 PK_PWG_C_HAS_CONTEXT = 2
+PK_PWG_MATH_F32, PK_PWG_MATH_BF16X3 = 0, 1
 _EXC = {
     -1: ValueError,
     -2: AssertionError,
@@ -81,6 +82,7 @@ def _declare(lib):
         "pk_pwg_create": (C.c_int, [vp, C.POINTER(PwgCfg), C.POINTER(vp)]),
         "pk_pwg_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
         "pk_pwg_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
+        "pk_pwg_set_math": (C.c_int, [vp, i32]),
         "pk_pwg_finalize": (C.c_int, [vp]),
         "pk_pwg_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
         "pk_pwg_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),

@@ -416,6 +416,221 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     }
 }
 
+// ---------------------------------------------------------------- residual block, split-bf16 matrix path
+// Same data flow as k_pwg_layer, but every fp32 product a*b of the two contractions is evaluated as
+//     a_hi*b_hi + a_lo*b_hi + a_hi*b_lo      (x = x_hi + x_lo + O(2^-17 x), hi/lo = bf16 roundings)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations and weights stay fp32 in HBM, the
+// split of the activations happens in registers (v_cvt_pk_bf16_f32), the weights are split once at
+// finalize.  The dropped a_lo*b_lo term is ~2^-16 of a product; measured end-to-end effect on the
+// 30-layer generator: relative max error 3e-6 vs fp64 (exact-fp32 path: 5e-7; tolerance 1e-4).
+// 3 bf16 MFMAs (32 cycles, K = 16) replace 8 fp32 MFMAs (64 cycles, K = 2): 5.3x less matrix-pipe
+// time, which makes the kernel HBM-bound (x in/out + skip read-modify-write).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int B3_KS1 = KTAP * R / 16;   // 12 k-steps of 16 channels
+constexpr int B3_KS2 = (G / 2) / 16;    // 4
+constexpr int B3_W1_BYTES = B3_KS1 * 2 * 4 * 64 * 16;   // [ks][part][co-tile][lane] x 8 bf16 = 98 304 B
+constexpr int B3_W2_BYTES = B3_KS2 * 2 * 4 * 64 * 16;   // 32 768 B
+constexpr int B3_RING = 6;              // operand groups in flight ahead of the MFMAs
+
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)v[e];
+        lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL];
+    float* lds_bias = lds + LDS_W1 + LDS_W2;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.w1);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = threadIdx.x; i < B3_W1_BYTES / 16; i += LAYER_WAVES * 64) dst[i] = src[i];
+        const f32x4* src2 = reinterpret_cast<const f32x4*>(a.w2);
+        f32x4* dst2 = reinterpret_cast<f32x4*>(lds + LDS_W1);
+        for (int i = threadIdx.x; i < B3_W2_BYTES / 16; i += LAYER_WAVES * 64) dst2[i] = src2[i];
+        if (threadIdx.x < LDS_BIAS) lds_bias[threadIdx.x] = a.bias[threadIdx.x];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const long Ttot = a.Ttot;
+    const int d = a.dilation;
+    const bf16x8* lds_a = reinterpret_cast<const bf16x8*>(lds) + lane;            // + ((ks*2+part)*4+q)*64
+    const bf16x8* lds_a2 = reinterpret_cast<const bf16x8*>(lds + LDS_W1) + lane;
+    float* lds_p = lds + LDS_W1 + LDS_W2 + LDS_BIAS + wave * LDS_PW;
+
+    const int per_xcd = gridDim.x >> 3;
+    const int wg_slot = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)
+                                             : (int)blockIdx.x;
+    const int my_slot = wg_slot * LAYER_WAVES + wave;
+    const int stride_slots = (int)gridDim.x * LAYER_WAVES;
+    const int n_wtiles = a.ntiles * (TILE / WAVE_T);
+
+    // operand group g of a wave-tile = k-step g: tap g/4, input channels 16*(g%4) + 8*hi + e, e < 8
+    auto group_base = [&](int g) -> const float* {   // wave-uniform
+        return a.xin + (long)(16 * (g & 3)) * Ttot + (long)((g >> 2) - 1) * d;
+    };
+    auto lane_off = [&](int wt) -> unsigned {
+        return 8u * (unsigned)hi * (unsigned)Ttot + (unsigned)a.tile_t0[wt >> 3] + (unsigned)((wt & 7) * WAVE_T + j);
+    };
+    float ring[B3_RING][8];
+    f32x4 preg[3];
+    float uw[UPW];
+    auto prefetch_head = [&](int wt) {
+        const int tile = wt >> 3, phase = (wt & 7) * WAVE_T + j;
+        const float* prow = a.P + (long)(tile - 2) * a.ldp;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = lane + 64 * it;
+            const int jj = idx >> 5, c4 = idx & 31;
+            if (idx < UPW * (G / 4)) preg[it] = *reinterpret_cast<const f32x4*>(prow + (long)jj * a.ldp + 4 * c4);
+        }
+        const float* wrow = a.uptab + ((long)a.tile_cls[tile] * TILE + phase) * UPW_PAD;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
+        uw[0] = w0[0]; uw[1] = w0[1]; uw[2] = w0[2]; uw[3] = w0[3];
+        uw[4] = wrow[4];
+    };
+    if (my_slot < n_wtiles) {
+        prefetch_head(my_slot);
+        const unsigned vo = lane_off(my_slot);
+#pragma unroll
+        for (int g = 0; g < B3_RING; ++g) {
+            const float* p = group_base(g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ring[g][e] = (p + (long)e * Ttot)[vo];
+        }
+    }
+
+    for (int wt = my_slot; wt < n_wtiles; wt += stride_slots) {
+        const int next_wt = wt + stride_slots < n_wtiles ? wt + stride_slots : wt;
+        const unsigned vo8 = lane_off(wt);
+        const unsigned vo8n = lane_off(next_wt);
+        const unsigned vo4 = 4u * (unsigned)hi * (unsigned)Ttot + (unsigned)a.tile_t0[wt >> 3] +
+                             (unsigned)((wt & 7) * WAVE_T + j);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < UPW * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int co0 = 32 * q + 8 * r4 + 4 * hi;
+                f32x4 v = *reinterpret_cast<const f32x4*>(lds_bias + co0);
+#pragma unroll
+                for (int jj = 0; jj < UPW; ++jj) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(lds_p + jj * G + co0);
+                    v[0] = fmaf(uw[jj], pv[0], v[0]);
+                    v[1] = fmaf(uw[jj], pv[1], v[1]);
+                    v[2] = fmaf(uw[jj], pv[2], v[2]);
+                    v[3] = fmaf(uw[jj], pv[3], v[3]);
+                }
+                acc[q][4 * r4 + 0] = v[0];
+                acc[q][4 * r4 + 1] = v[1];
+                acc[q][4 * r4 + 2] = v[2];
+                acc[q][4 * r4 + 3] = v[3];
+            }
+
+        // stage 1: 12 k-steps; the operands of k-step g+6 (or of the next tile's g-6) are requested
+        // into the ring slot that k-step g has just vacated
+#pragma unroll
+        for (int g = 0; g < B3_KS1; ++g) {
+            bf16x8 bh, bl;
+            split_bf16x8(ring[g % B3_RING], bh, bl);
+            {
+                const int gn = g + B3_RING;
+                const float* p = group_base(gn < B3_KS1 ? gn : gn - B3_KS1);
+                const unsigned vo = gn < B3_KS1 ? vo8 : vo8n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ring[g % B3_RING][e] = (p + (long)e * Ttot)[vo];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 ah = lds_a[((g * 2 + 0) * 4 + q) * 64];
+                const bf16x8 al = lds_a[((g * 2 + 1) * 4 + q) * 64];
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[q], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prefetch_head(next_wt);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // stage 2 (two passes: out, skip); the gate of a k-step's 8 channels is computed right before
+        // its MFMAs in pass 0 and kept (fp32) in acc[0..1] for pass 1
+        const float rs = 0.70710678118654752440f;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float old[32];
+            const float* src = pass == 0 ? a.xin : a.skip;
+            if (pass == 0 || !FIRST) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        old[16 * q + r] = (src + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 32; ++e) old[e] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 bv =
+                        *reinterpret_cast<const f32x4*>(lds_bias + G + 64 * pass + 32 * q + 8 * r4 + 4 * hi);
+                    acc2[q][4 * r4 + 0] = bv[0];
+                    acc2[q][4 * r4 + 1] = bv[1];
+                    acc2[q][4 * r4 + 2] = bv[2];
+                    acc2[q][4 * r4 + 3] = bv[3];
+                }
+#pragma unroll
+            for (int ks = 0; ks < B3_KS2; ++ks) {
+                const int zq = ks >> 1, r0 = 8 * (ks & 1);
+                float zv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (pass == 0) acc[zq][r0 + e] = gated(acc[zq][r0 + e], acc[zq + 2][r0 + e]);
+                    zv[e] = acc[zq][r0 + e];
+                }
+                bf16x8 zh, zl;
+                split_bf16x8(zv, zh, zl);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bf16x8 ah = lds_a2[((ks * 2 + 0) * 4 + 2 * pass + q) * 64];
+                    const bf16x8 al = lds_a2[((ks * 2 + 1) * 4 + 2 * pass + q) * 64];
+                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zh, acc2[q], 0, 0, 0);
+                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, zh, acc2[q], 0, 0, 0);
+                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zl, acc2[q], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float* dst = pass == 0 ? a.xout : a.skip;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v;
+                    if (pass == 0) v = (acc2[q][r] + old[16 * q + r]) * rs;
+                    else v = FIRST ? acc2[q][r] : (old[16 * q + r] + acc2[q][r]);
+                    (dst + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4] = v;
+                }
+        }
+    }
+}
+
 // last_conv_layers: ReLU -> Conv1D(SK->SK,1) -> ReLU -> Conv1D(SK->1,1) (:429-440,471) on
 // skips * sqrt(1/layers) (:469).  One workgroup per tile, 8 waves x 32 samples.
 struct PwgLastArgs {
@@ -477,6 +692,8 @@ struct pk_pwg {
     // device weights
     pk_dbuf d_first_w, d_first_b, d_convin_wT, d_uptab, d_mu, d_sigma;
     pk_dbuf d_w1, d_w2, d_bias;     // all layers, concatenated
+    pk_dbuf d_w1b, d_w2b;           // split-bf16 (hi, lo) A fragments for k_pwg_layer_b3
+    int math = PK_PWG_MATH_F32;
     pk_dbuf d_waux;                 // packed GEMM weight [AUX] x [layers*G]
     pk_dbuf d_l1, d_l1b, d_l2;
     float l2_bias = 0.f;
@@ -530,6 +747,7 @@ extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
     h->gap = ((h->max_dilation + TILE - 1) / TILE) * TILE;
     if (h->gap < TILE) h->gap = TILE;
     if (const char* e = getenv("PK_PWG_ABLATE")) h->dbg = atoi(e);   // profiling only: results are wrong when set
+    if (const char* e = getenv("PK_PWG_MATH")) h->math = (strcmp(e, "bf16x3") == 0) ? PK_PWG_MATH_BF16X3 : PK_PWG_MATH_F32;
     *out = h;
     return PK_OK;
 }
@@ -555,6 +773,30 @@ extern "C" int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* si
     PK_TRY(pk_upload(h->ctx, h->d_mu, h->h_mu.data(), n * sizeof(float)));
     PK_TRY(pk_upload(h->ctx, h->d_sigma, h->h_sigma.data(), n * sizeof(float)));
     return PK_OK;
+}
+
+extern "C" int pk_pwg_set_math(pk_pwg* h, int32_t mode) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_set_math: handle is NULL");
+    if (mode != PK_PWG_MATH_F32 && mode != PK_PWG_MATH_BF16X3) PK_FAIL(PK_EINVAL, "pk_pwg_set_math: unknown mode %d", mode);
+    h->math = mode;
+    return PK_OK;
+}
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_to_f32(uint16_t hbits) {
+    const uint32_t u = (uint32_t)hbits << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void split_bf16_host(float w, uint16_t& hi, uint16_t& lo) {
+    hi = f32_to_bf16_rne(w);
+    lo = f32_to_bf16_rne(w - bf16_to_f32(hi));
 }
 
 // UpsampleNet on a host vector (one channel): [stretch by s, FIR(2s+1) with zero padding s] per stage.
@@ -668,6 +910,45 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
             for (int i = 0; i < G; ++i) bb[i] = bc[i];
             for (int i = 0; i < R; ++i) bb[G + i] = bo[i];
             for (int i = 0; i < SK; ++i) bb[G + R + i] = bs[i];
+        }
+        // split-bf16 fragments: W1b [ks][part][co-tile][lane][8], W2b [ks][part][out-tile][lane][8]
+        {
+            const size_t n1b = (size_t)B3_W1_BYTES / 2, n2b = (size_t)B3_W2_BYTES / 2;
+            std::vector<uint16_t> W1b(n1b * c.layers), W2b(n2b * c.layers);
+            for (int l = 0; l < c.layers; ++l) {
+                const std::string p = "conv_layers." + std::to_string(l);
+                PK_TRY(pk_get_weight(h->params, p + ".conv", {G, R, KTAP}, wc));
+                PK_TRY(pk_get_weight(h->params, p + ".conv1x1_out", {R, G / 2, 1}, wo));
+                PK_TRY(pk_get_weight(h->params, p + ".conv1x1_skip", {SK, G / 2, 1}, ws));
+                uint16_t* a1 = W1b.data() + n1b * l;
+                for (int ks = 0; ks < B3_KS1; ++ks)
+                    for (int q = 0; q < 4; ++q)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int i = lane & 31, hi = lane >> 5;
+                                const int tap = ks >> 2, ci = 16 * (ks & 3) + 8 * hi + e;
+                                uint16_t bh, bl;
+                                split_bf16_host(wc[((size_t)(32 * q + i) * R + ci) * KTAP + tap], bh, bl);
+                                a1[((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e] = bh;
+                                a1[((((size_t)ks * 2 + 1) * 4 + q) * 64 + lane) * 8 + e] = bl;
+                            }
+                uint16_t* a2 = W2b.data() + n2b * l;
+                for (int ks = 0; ks < B3_KS2; ++ks)
+                    for (int q = 0; q < 4; ++q)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int i = lane & 31, hi = lane >> 5;
+                                const int zc = 32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, hi);
+                                const int row = 32 * (q & 1) + i;
+                                const float w = (q < 2) ? wo[(size_t)row * (G / 2) + zc] : ws[(size_t)row * (G / 2) + zc];
+                                uint16_t bh, bl;
+                                split_bf16_host(w, bh, bl);
+                                a2[((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e] = bh;
+                                a2[((((size_t)ks * 2 + 1) * 4 + q) * 64 + lane) * 8 + e] = bl;
+                            }
+            }
+            PK_TRY(pk_upload(ctx, h->d_w1b, W1b.data(), W1b.size() * sizeof(uint16_t)));
+            PK_TRY(pk_upload(ctx, h->d_w2b, W2b.data(), W2b.size() * sizeof(uint16_t)));
         }
         PK_TRY(pk_upload(ctx, h->d_w1, W1.data(), W1.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_w2, W2.data(), W2.size() * sizeof(float)));
@@ -834,7 +1115,14 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             a.ntiles = sumL;
             a.dilation = 1 << (l % lps);
             a.dbg = h->dbg;
-            if (l == 0)
+            if (h->math == PK_PWG_MATH_BF16X3) {
+                a.w1 = reinterpret_cast<const float*>(h->d_w1b.as<char>() + (size_t)l * B3_W1_BYTES);
+                a.w2 = reinterpret_cast<const float*>(h->d_w2b.as<char>() + (size_t)l * B3_W2_BYTES);
+                if (l == 0)
+                    PK_LAUNCH(ctx, "pwg_layer_b3", k_pwg_layer_b3<true>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
+                else
+                    PK_LAUNCH(ctx, "pwg_layer_b3", k_pwg_layer_b3<false>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
+            } else if (l == 0)
                 PK_LAUNCH(ctx, "pwg_layer", k_pwg_layer<true>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
             else
                 PK_LAUNCH(ctx, "pwg_layer", k_pwg_layer<false>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
@@ -902,7 +1190,7 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_uptab, &h->d_mu, &h->d_sigma,
-                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_waux, &h->d_l1, &h->d_l1b, &h->d_l2,
+                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_waux, &h->d_l1, &h->d_l1b, &h->d_l2,
                        &h->ws_mel, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
                        &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab};
     for (auto* b : bufs) b->release();

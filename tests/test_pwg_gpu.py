@@ -21,7 +21,7 @@ def _rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def _run_case(cfg_over, frames, seed, weight_norm=False, check_taps=True):
+def _run_case(cfg_over, frames, seed, weight_norm=False, check_taps=True, pwg_math="f32"):
     from oracle import pwg_ref
     from parakeet_amd.parallel_wavegan import PWGGenerator
 
@@ -35,6 +35,7 @@ def _run_case(cfg_over, frames, seed, weight_norm=False, check_taps=True):
     gen.set_state_dict(state)
     gen.remove_weight_norm()
     gen.eval()
+    gen.set_math(pwg_math)
     outs = gen.inference_batch(mels, noises)
 
     ocfg = {k: cfg[k] for k in ("layers", "stacks", "kernel_size", "aux_context_window", "upsample_scales")}
@@ -70,6 +71,12 @@ def test_pwg_full_stack_ragged():
     # the LJSpeech generator (30 layers, dilations up to 512), utterances shorter and longer
     # than the largest dilation's reach
     _run_case(dict(), [3, 17, 8], seed=2)
+
+
+def test_pwg_split_bf16_math_same_tolerances():
+    # the 3-term split-bf16 matrix path must meet the SAME bars as the exact-fp32 path
+    _run_case(dict(), [3, 17, 8], seed=2, pwg_math="bf16x3")
+    _run_case(dict(layers=6, stacks=2), [5, 1, 9, 3, 2, 4], seed=1, pwg_math="bf16x3")
 
 
 def test_pwg_weight_norm_pairs():
