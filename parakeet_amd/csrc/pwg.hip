@@ -218,8 +218,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int n_wtiles = a.ntiles * (TILE / WAVE_T);
     constexpr int GRP = 8;
     constexpr int NGRP = KS1 / GRP;  // 12 groups of 8 k-steps: 4 groups of 8 channel pairs per tap
+    // K order = (channel group, tap): the three reads of an x line (as tap -1, 0, +1 of three different
+    // tiles) then happen at nearly the same progress point of those tiles, i.e. close in time -> the
+    // line is still in the XCD's L2 for the 2nd and 3rd read (the L2 only holds ~3 us of this stream).
     auto group_ptr = [&](int g) -> const float* {   // wave-uniform
-        const int tap = g >> 2, cg = g & 3;
+        const int cg = g / 3, tap = g - 3 * cg;
         return a.xin + (long)(2 * GRP * cg) * Ttot + (long)(tap - 1) * d;
     };
 
@@ -430,7 +433,7 @@ constexpr int B3_KS1 = KTAP * R / 16;   // 12 k-steps of 16 channels
 constexpr int B3_KS2 = (G / 2) / 16;    // 4
 constexpr int B3_W1_BYTES = B3_KS1 * 2 * 4 * 64 * 16;   // [ks][part][co-tile][lane] x 8 bf16 = 98 304 B
 constexpr int B3_W2_BYTES = B3_KS2 * 2 * 4 * 64 * 16;   // 32 768 B
-constexpr int B3_RING = 6;              // operand groups in flight ahead of the MFMAs
+constexpr int B3_RING = 4;              // operand groups in flight ahead of the MFMAs (6 spills at 256 VGPRs)
 
 __device__ __forceinline__ void split_bf16x8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -472,9 +475,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int stride_slots = (int)gridDim.x * LAYER_WAVES;
     const int n_wtiles = a.ntiles * (TILE / WAVE_T);
 
-    // operand group g of a wave-tile = k-step g: tap g/4, input channels 16*(g%4) + 8*hi + e, e < 8
-    auto group_base = [&](int g) -> const float* {   // wave-uniform
-        return a.xin + (long)(16 * (g & 3)) * Ttot + (long)((g >> 2) - 1) * d;
+    // operand group g of a wave-tile = k-step g: tap g%3, input channels 16*(g/3) + 8*hi + e, e < 8
+    auto group_base = [&](int g) -> const float* {   // wave-uniform; K order (channel group, tap), see k_pwg_layer
+        const int cg = g / 3, tap = g - 3 * cg;
+        return a.xin + (long)(16 * cg) * Ttot + (long)(tap - 1) * d;
     };
     auto lane_off = [&](int wt) -> unsigned {
         return 8u * (unsigned)hi * (unsigned)Ttot + (unsigned)a.tile_t0[wt >> 3] + (unsigned)((wt & 7) * WAVE_T + j);
@@ -887,7 +891,8 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
             for (int ks = 0; ks < KS1; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 31, hi = lane >> 5;
-                    const int tap = ks / (R / 2), ci = 2 * (ks % (R / 2)) + hi;
+                    const int g = ks / 8, cg = g / 3, tap = g % 3;      // kernel's group order: (channel group, tap)
+                    const int ci = 2 * (8 * cg + ks % 8) + hi;
                     for (int q = 0; q < 4; ++q)
                         a1[((size_t)ks * 64 + lane) * 4 + q] = wc[((size_t)(32 * q + i) * R + ci) * KTAP + tap];
                 }
@@ -926,7 +931,7 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                         for (int lane = 0; lane < 64; ++lane)
                             for (int e = 0; e < 8; ++e) {
                                 const int i = lane & 31, hi = lane >> 5;
-                                const int tap = ks >> 2, ci = 16 * (ks & 3) + 8 * hi + e;
+                                const int tap = ks % 3, ci = 16 * (ks / 3) + 8 * hi + e;
                                 uint16_t bh, bl;
                                 split_bf16_host(wc[((size_t)(32 * q + i) * R + ci) * KTAP + tap], bh, bl);
                                 a1[((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e] = bh;
