@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpk_synth.so")
 PK_OK = 0
 PK_HOST_IO = 1
 PK_PWG_C_HAS_CONTEXT = 2
-PK_PWG_MATH_F32, PK_PWG_MATH_BF16X3 = 0, 1
+PK_PWG_MATH_F32, PK_PWG_MATH_BF16X3, PK_PWG_MATH_F16X3 = 0, 1, 2
 _EXC = {
     -1: ValueError,
     -2: AssertionError,

@@ -429,22 +429,39 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 // 3 bf16 MFMAs (32 cycles, K = 16) replace 8 fp32 MFMAs (64 cycles, K = 2): 5.3x less matrix-pipe
 // time, which makes the kernel HBM-bound (x in/out + skip read-modify-write).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool HALF> struct Split16 { typedef bf16x8 vec; typedef __bf16 elem; };
+template <> struct Split16<true> { typedef f16x8 vec; typedef _Float16 elem; };
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 constexpr int B3_KS1 = KTAP * R / 16;   // 12 k-steps of 16 channels
 constexpr int B3_KS2 = (G / 2) / 16;    // 4
 constexpr int B3_W1_BYTES = B3_KS1 * 2 * 4 * 64 * 16;   // [ks][part][co-tile][lane] x 8 bf16 = 98 304 B
 constexpr int B3_W2_BYTES = B3_KS2 * 2 * 4 * 64 * 16;   // 32 768 B
 constexpr int B3_RING = 4;              // operand groups in flight ahead of the MFMAs (6 spills at 256 VGPRs)
 
-__device__ __forceinline__ void split_bf16x8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+template <class V, class E, bool CLAMP>
+__device__ __forceinline__ void split_x8(const float (&v)[8], V& hi, V& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        hi[e] = (__bf16)v[e];
-        lo[e] = (__bf16)(v[e] - (float)hi[e]);
+        // fp16 parts: the high part saturates at +-65000 instead of overflowing to inf, the low part
+        // then carries the rest (still finite up to |x| ~ 1.3e5; no effect below 65000)
+        const float x = CLAMP ? __builtin_fminf(__builtin_fmaxf(v[e], -65000.f), 65000.f) : v[e];
+        hi[e] = (E)x;
+        lo[e] = (E)(v[e] - (float)hi[e]);
     }
 }
 
-template <bool FIRST>
+// HALF = false: bf16 parts (8 significant bits each, fp32 range); HALF = true: fp16 parts (11 bits each,
+// 22 bits per operand ~ fp32's 24; needs |x| < 65504 and keeps an absolute floor of 2^-25 per operand).
+template <bool FIRST, bool HALF>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
+    typedef typename Split16<HALF>::vec bf16x8;     // shadows the bf16 typedef inside this kernel
+    typedef typename Split16<HALF>::elem elem16;
     __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL];
     float* lds_bias = lds + LDS_W1 + LDS_W2;
     {
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
         for (int g = 0; g < B3_KS1; ++g) {
             bf16x8 bh, bl;
-            split_bf16x8(ring[g % B3_RING], bh, bl);
+            split_x8<bf16x8, elem16, HALF>(ring[g % B3_RING], bh, bl);
             {
                 const int gn = g + B3_RING;
                 const float* p = group_base(gn < B3_KS1 ? gn : gn - B3_KS1);
@@ -561,9 +578,9 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             for (int q = 0; q < 4; ++q) {
                 const bf16x8 ah = lds_a[((g * 2 + 0) * 4 + q) * 64];
                 const bf16x8 al = lds_a[((g * 2 + 1) * 4 + q) * 64];
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[q], 0, 0, 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[q], 0, 0, 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[q], 0, 0, 0);
+                acc[q] = mfma16(ah, bh, acc[q]);
+                acc[q] = mfma16(al, bh, acc[q]);
+                acc[q] = mfma16(ah, bl, acc[q]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -610,14 +627,14 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     zv[e] = acc[zq][r0 + e];
                 }
                 bf16x8 zh, zl;
-                split_bf16x8(zv, zh, zl);
+                split_x8<bf16x8, elem16, false>(zv, zh, zl);   // |z| < 1
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const bf16x8 ah = lds_a2[((ks * 2 + 0) * 4 + 2 * pass + q) * 64];
                     const bf16x8 al = lds_a2[((ks * 2 + 1) * 4 + 2 * pass + q) * 64];
-                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zh, acc2[q], 0, 0, 0);
-                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, zh, acc2[q], 0, 0, 0);
-                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zl, acc2[q], 0, 0, 0);
+                    acc2[q] = mfma16(ah, zh, acc2[q]);
+                    acc2[q] = mfma16(al, zh, acc2[q]);
+                    acc2[q] = mfma16(ah, zl, acc2[q]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -696,8 +713,8 @@ struct pk_pwg {
     // device weights
     pk_dbuf d_first_w, d_first_b, d_convin_wT, d_uptab, d_mu, d_sigma;
     pk_dbuf d_w1, d_w2, d_bias;     // all layers, concatenated
-    pk_dbuf d_w1b, d_w2b;           // split-bf16 (hi, lo) A fragments for k_pwg_layer_b3
-    int math = PK_PWG_MATH_F32;
+    pk_dbuf d_w1b, d_w2b, d_w1h, d_w2h;   // split (hi, lo) A fragments for k_pwg_layer_b3: bf16 / fp16 parts
+    int math = PK_PWG_MATH_F16X3;   // default: fp32-equivalent error (5e-7), 1.9x faster than the fp32 matrix pipe
     pk_dbuf d_waux;                 // packed GEMM weight [AUX] x [layers*G]
     pk_dbuf d_l1, d_l1b, d_l2;
     float l2_bias = 0.f;
@@ -751,7 +768,8 @@ extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
     h->gap = ((h->max_dilation + TILE - 1) / TILE) * TILE;
     if (h->gap < TILE) h->gap = TILE;
     if (const char* e = getenv("PK_PWG_ABLATE")) h->dbg = atoi(e);   // profiling only: results are wrong when set
-    if (const char* e = getenv("PK_PWG_MATH")) h->math = (strcmp(e, "bf16x3") == 0) ? PK_PWG_MATH_BF16X3 : PK_PWG_MATH_F32;
+    if (const char* e = getenv("PK_PWG_MATH"))
+        h->math = strcmp(e, "bf16x3") == 0 ? PK_PWG_MATH_BF16X3 : (strcmp(e, "f16x3") == 0 ? PK_PWG_MATH_F16X3 : PK_PWG_MATH_F32);
     *out = h;
     return PK_OK;
 }
@@ -781,7 +799,8 @@ extern "C" int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* si
 
 extern "C" int pk_pwg_set_math(pk_pwg* h, int32_t mode) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_set_math: handle is NULL");
-    if (mode != PK_PWG_MATH_F32 && mode != PK_PWG_MATH_BF16X3) PK_FAIL(PK_EINVAL, "pk_pwg_set_math: unknown mode %d", mode);
+    if (mode != PK_PWG_MATH_F32 && mode != PK_PWG_MATH_BF16X3 && mode != PK_PWG_MATH_F16X3)
+        PK_FAIL(PK_EINVAL, "pk_pwg_set_math: unknown mode %d", mode);
     h->math = mode;
     return PK_OK;
 }
@@ -798,9 +817,52 @@ static inline float bf16_to_f32(uint16_t hbits) {
     memcpy(&f, &u, 4);
     return f;
 }
-static inline void split_bf16_host(float w, uint16_t& hi, uint16_t& lo) {
-    hi = f32_to_bf16_rne(w);
-    lo = f32_to_bf16_rne(w - bf16_to_f32(hi));
+static inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));   // overflow / nan
+    if (x < 0x38800000u) {                                   // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 113 - (int)(x >> 23);              // 1..24
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t half = 1u << (shift + 12), mask = (half << 1) - 1;
+        uint32_t r = m >> (shift + 13);
+        const uint32_t rem = m & mask;
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = x - 0x38000000u;                            // rebias exponent
+    const uint32_t rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+static inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            e = 113;
+            while (!(m & 0x400u)) { m <<= 1; --e; }
+            x = sign | (e << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+static inline void split16_host(float w, bool half, uint16_t& hi, uint16_t& lo) {
+    if (half) {
+        hi = f32_to_f16_rne(w);
+        lo = f32_to_f16_rne(w - f16_to_f32(hi));
+    } else {
+        hi = f32_to_bf16_rne(w);
+        lo = f32_to_bf16_rne(w - bf16_to_f32(hi));
+    }
 }
 
 // UpsampleNet on a host vector (one channel): [stretch by s, FIR(2s+1) with zero padding s] per stage.
@@ -916,8 +978,10 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
             for (int i = 0; i < R; ++i) bb[G + i] = bo[i];
             for (int i = 0; i < SK; ++i) bb[G + R + i] = bs[i];
         }
-        // split-bf16 fragments: W1b [ks][part][co-tile][lane][8], W2b [ks][part][out-tile][lane][8]
-        {
+        // split 16-bit fragments: W1b [ks][part][co-tile][lane][8], W2b [ks][part][out-tile][lane][8];
+        // variant 0 = bf16 parts, variant 1 = fp16 parts
+        for (int variant = 0; variant < 2; ++variant) {
+            const bool half = variant == 1;
             const size_t n1b = (size_t)B3_W1_BYTES / 2, n2b = (size_t)B3_W2_BYTES / 2;
             std::vector<uint16_t> W1b(n1b * c.layers), W2b(n2b * c.layers);
             for (int l = 0; l < c.layers; ++l) {
@@ -933,7 +997,7 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                                 const int i = lane & 31, hi = lane >> 5;
                                 const int tap = ks % 3, ci = 16 * (ks / 3) + 8 * hi + e;
                                 uint16_t bh, bl;
-                                split_bf16_host(wc[((size_t)(32 * q + i) * R + ci) * KTAP + tap], bh, bl);
+                                split16_host(wc[((size_t)(32 * q + i) * R + ci) * KTAP + tap], half, bh, bl);
                                 a1[((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e] = bh;
                                 a1[((((size_t)ks * 2 + 1) * 4 + q) * 64 + lane) * 8 + e] = bl;
                             }
@@ -947,13 +1011,13 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                                 const int row = 32 * (q & 1) + i;
                                 const float w = (q < 2) ? wo[(size_t)row * (G / 2) + zc] : ws[(size_t)row * (G / 2) + zc];
                                 uint16_t bh, bl;
-                                split_bf16_host(w, bh, bl);
+                                split16_host(w, half, bh, bl);
                                 a2[((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e] = bh;
                                 a2[((((size_t)ks * 2 + 1) * 4 + q) * 64 + lane) * 8 + e] = bl;
                             }
             }
-            PK_TRY(pk_upload(ctx, h->d_w1b, W1b.data(), W1b.size() * sizeof(uint16_t)));
-            PK_TRY(pk_upload(ctx, h->d_w2b, W2b.data(), W2b.size() * sizeof(uint16_t)));
+            PK_TRY(pk_upload(ctx, half ? h->d_w1h : h->d_w1b, W1b.data(), W1b.size() * sizeof(uint16_t)));
+            PK_TRY(pk_upload(ctx, half ? h->d_w2h : h->d_w2b, W2b.data(), W2b.size() * sizeof(uint16_t)));
         }
         PK_TRY(pk_upload(ctx, h->d_w1, W1.data(), W1.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_w2, W2.data(), W2.size() * sizeof(float)));
@@ -1120,13 +1184,18 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             a.ntiles = sumL;
             a.dilation = 1 << (l % lps);
             a.dbg = h->dbg;
-            if (h->math == PK_PWG_MATH_BF16X3) {
-                a.w1 = reinterpret_cast<const float*>(h->d_w1b.as<char>() + (size_t)l * B3_W1_BYTES);
-                a.w2 = reinterpret_cast<const float*>(h->d_w2b.as<char>() + (size_t)l * B3_W2_BYTES);
-                if (l == 0)
-                    PK_LAUNCH(ctx, "pwg_layer_b3", k_pwg_layer_b3<true>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
-                else
-                    PK_LAUNCH(ctx, "pwg_layer_b3", k_pwg_layer_b3<false>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
+            if (h->math == PK_PWG_MATH_BF16X3 || h->math == PK_PWG_MATH_F16X3) {
+                const bool half = h->math == PK_PWG_MATH_F16X3;
+                a.w1 = reinterpret_cast<const float*>((half ? h->d_w1h : h->d_w1b).as<char>() + (size_t)l * B3_W1_BYTES);
+                a.w2 = reinterpret_cast<const float*>((half ? h->d_w2h : h->d_w2b).as<char>() + (size_t)l * B3_W2_BYTES);
+                const dim3 blk(LAYER_WAVES * 64);
+                if (half) {
+                    if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true>), dim3(grid), blk, 0, a);
+                    else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true>), dim3(grid), blk, 0, a);
+                } else {
+                    if (l == 0) PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<true, false>), dim3(grid), blk, 0, a);
+                    else PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<false, false>), dim3(grid), blk, 0, a);
+                }
             } else if (l == 0)
                 PK_LAUNCH(ctx, "pwg_layer", k_pwg_layer<true>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
             else
@@ -1195,7 +1264,7 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_uptab, &h->d_mu, &h->d_sigma,
-                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_waux, &h->d_l1, &h->d_l1b, &h->d_l2,
+                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1b, &h->d_l2,
                        &h->ws_mel, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
                        &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab};
     for (auto* b : bufs) b->release();

@@ -82,7 +82,7 @@ class PWGGenerator:
 
     def set_math(self, mode):
         """'f32' (exact fp32 MFMA, default) or 'bf16x3' (3-term split-bf16 MFMA, fp32 accumulate)."""
-        m = {"f32": _capi.PK_PWG_MATH_F32, "bf16x3": _capi.PK_PWG_MATH_BF16X3}[mode]
+        m = {"f32": _capi.PK_PWG_MATH_F32, "bf16x3": _capi.PK_PWG_MATH_BF16X3, "f16x3": _capi.PK_PWG_MATH_F16X3}[mode]
         _capi.check(self._ctx.lib.pk_pwg_set_math(self._h, m))
 
     def set_normalizer(self, normalizer):

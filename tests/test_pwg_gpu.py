@@ -21,7 +21,7 @@ def _rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def _run_case(cfg_over, frames, seed, weight_norm=False, check_taps=True, pwg_math="f32"):
+def _run_case(cfg_over, frames, seed, weight_norm=False, check_taps=True, pwg_math="f16x3"):
     from oracle import pwg_ref
     from parakeet_amd.parallel_wavegan import PWGGenerator
 
@@ -73,10 +73,34 @@ def test_pwg_full_stack_ragged():
     _run_case(dict(), [3, 17, 8], seed=2)
 
 
-def test_pwg_split_bf16_math_same_tolerances():
-    # the 3-term split-bf16 matrix path must meet the SAME bars as the exact-fp32 path
-    _run_case(dict(), [3, 17, 8], seed=2, pwg_math="bf16x3")
-    _run_case(dict(layers=6, stacks=2), [5, 1, 9, 3, 2, 4], seed=1, pwg_math="bf16x3")
+@pytest.mark.parametrize("mode", ["f32", "f16x3", "bf16x3"])
+def test_pwg_every_math_mode_meets_the_same_bars(mode):
+    # exact-fp32 MFMA, 3-term split-fp16 (the default) and 3-term split-bf16 all have to meet the SAME
+    # tolerances against the fp64 oracle, internal taps included
+    _run_case(dict(), [3, 17, 8], seed=2, pwg_math=mode)
+    _run_case(dict(layers=6, stacks=2), [5, 1, 9, 3, 2, 4], seed=1, pwg_math=mode)
+
+
+def test_pwg_default_math_is_fp32_equivalent():
+    # the default (split-fp16) path must be as close to the fp64 oracle as the exact-fp32 path is
+    from oracle import pwg_ref
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    state = syn.pwg_state()
+    rng = np.random.default_rng(3)
+    mel = rng.normal(size=(24, 80)).astype(np.float32)
+    noise = rng.normal(size=(24 * 256,)).astype(np.float32)
+    ref = pwg_ref.generator_inference(state, torch.from_numpy(mel), torch.from_numpy(noise),
+                                      dtype=torch.float64)[:, 0].numpy()
+    gen = PWGGenerator(**syn.PWG_LJSPEECH)
+    gen.set_state_dict(state)
+    gen.eval()
+    errs = {}
+    for mode in ("f32", "f16x3"):
+        gen.set_math(mode)
+        errs[mode] = _rel_err(gen.inference(mel, noise=noise).numpy()[:, 0], ref)
+    gen.set_math("f16x3")
+    assert errs["f32"] < 2e-6 and errs["f16x3"] < 2e-6, errs
+    assert errs["f16x3"] < 2.0 * errs["f32"] + 2e-7, errs
 
 
 def test_pwg_weight_norm_pairs():

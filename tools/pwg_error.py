@@ -12,7 +12,7 @@ noises = [rng.normal(size=(L * 256,)).astype(np.float32) for L in frames]
 ref = [pwg_ref.generator_inference(state, torch.from_numpy(m), torch.from_numpy(n), dtype=torch.float64)[:, 0].numpy() for m, n in zip(mels, noises)]
 ref32 = [pwg_ref.generator_inference(state, torch.from_numpy(m), torch.from_numpy(n), dtype=torch.float32)[:, 0].numpy() for m, n in zip(mels, noises)]
 gen = PWGGenerator(**syn.PWG_LJSPEECH); gen.set_state_dict(state); gen.eval()
-for mode in ("f32", "bf16x3"):
+for mode in ("f32", "bf16x3", "f16x3"):
     gen.set_math(mode)
     outs = gen.inference_batch(mels, noises)
     e = max(np.abs(o.numpy()[:, 0] - r).max() / np.abs(r).max() for o, r in zip(outs, ref))
