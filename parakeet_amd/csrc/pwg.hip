@@ -492,13 +492,17 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int stride_slots = (int)gridDim.x * LAYER_WAVES;
     const int n_wtiles = a.ntiles * (TILE / WAVE_T);
 
-    // operand group g of a wave-tile = k-step g: tap g%3, input channels 16*(g/3) + 8*hi + e, e < 8
-    auto group_base = [&](int g) -> const float* {   // wave-uniform; K order (channel group, tap), see k_pwg_layer
-        const int cg = g / 3, tap = g - 3 * cg;
-        return a.xin + (long)(16 * cg) * Ttot + (long)(tap - 1) * d;
+    // operand group g of a wave-tile = k-step g = (channel group cg = g/3, tap = g%3).  Element e of lane
+    // (j, hi) is input channel 32*(cg>>1) + mfma_row(8*(cg&1) + e, hi) -- the SAME channel the lane owns as
+    // output row in the epilogue, so the centre-tap operands double as the residual input x_in (no reload:
+    // by the time of the epilogue those lines have left the L2 and would come from HBM again).
+    auto group_row = [&](int g, int e) -> long {   // wave-uniform part of the channel row
+        const int cg = g / 3;
+        return (long)(32 * (cg >> 1) + mfma_row(8 * (cg & 1) + e, 0));
     };
+    auto group_shift = [&](int g) -> long { return (long)(g % 3 - 1) * d; };
     auto lane_off = [&](int wt) -> unsigned {
-        return 8u * (unsigned)hi * (unsigned)Ttot + (unsigned)a.tile_t0[wt >> 3] + (unsigned)((wt & 7) * WAVE_T + j);
+        return 4u * (unsigned)hi * (unsigned)Ttot + (unsigned)a.tile_t0[wt >> 3] + (unsigned)((wt & 7) * WAVE_T + j);
     };
     float ring[B3_RING][8];
     f32x4 preg[3];
@@ -522,9 +526,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const unsigned vo = lane_off(my_slot);
 #pragma unroll
         for (int g = 0; g < B3_RING; ++g) {
-            const float* p = group_base(g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ring[g][e] = (p + (long)e * Ttot)[vo];
+            for (int e = 0; e < 8; ++e) ring[g][e] = (a.xin + group_row(g, e) * Ttot + group_shift(g))[vo];
         }
     }
 
@@ -532,8 +535,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const int next_wt = wt + stride_slots < n_wtiles ? wt + stride_slots : wt;
         const unsigned vo8 = lane_off(wt);
         const unsigned vo8n = lane_off(next_wt);
-        const unsigned vo4 = 4u * (unsigned)hi * (unsigned)Ttot + (unsigned)a.tile_t0[wt >> 3] +
-                             (unsigned)((wt & 7) * WAVE_T + j);
+        const unsigned vo4 = vo8;   // operand rows and result rows share the lane offset
+        float x_old[32];
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = lane + 64 * it;
@@ -566,12 +569,17 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         for (int g = 0; g < B3_KS1; ++g) {
             bf16x8 bh, bl;
             split_x8<bf16x8, elem16, HALF>(ring[g % B3_RING], bh, bl);
+            if (g % 3 == 1) {   // centre tap: these fp32 values are x_in at this lane's output rows
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x_old[16 * ((g / 3) >> 1) + 8 * ((g / 3) & 1) + e] = ring[g % B3_RING][e];
+            }
             {
                 const int gn = g + B3_RING;
-                const float* p = group_base(gn < B3_KS1 ? gn : gn - B3_KS1);
+                const int gt = gn < B3_KS1 ? gn : gn - B3_KS1;
                 const unsigned vo = gn < B3_KS1 ? vo8 : vo8n;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ring[g % B3_RING][e] = (p + (long)e * Ttot)[vo];
+                for (int e = 0; e < 8; ++e)
+                    ring[g % B3_RING][e] = (a.xin + group_row(gt, e) * Ttot + group_shift(gt))[vo];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -593,13 +601,15 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             float old[32];
-            const float* src = pass == 0 ? a.xin : a.skip;
-            if (pass == 0 || !FIRST) {
+            if (pass == 0) {
+#pragma unroll
+                for (int e = 0; e < 32; ++e) old[e] = x_old[e];
+            } else if (!FIRST) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        old[16 * q + r] = (src + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4];
+                        old[16 * q + r] = (a.skip + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4];
             } else {
 #pragma unroll
                 for (int e = 0; e < 32; ++e) old[e] = 0.f;
@@ -995,7 +1005,8 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                         for (int lane = 0; lane < 64; ++lane)
                             for (int e = 0; e < 8; ++e) {
                                 const int i = lane & 31, hi = lane >> 5;
-                                const int tap = ks % 3, ci = 16 * (ks / 3) + 8 * hi + e;
+                                const int tap = ks % 3, cg = ks / 3;
+                                const int ci = 32 * (cg >> 1) + mfma_row(8 * (cg & 1) + e, hi);   // kernel's operand order
                                 uint16_t bh, bl;
                                 split16_host(wc[((size_t)(32 * q + i) * R + ci) * KTAP + tap], half, bh, bl);
                                 a1[((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e] = bh;
