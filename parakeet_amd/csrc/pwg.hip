@@ -11,7 +11,10 @@
 //
 //      |GAP| utt 0 (S_0) |GAP| utt 1 (S_1) |GAP| ... |GAP|
 //
-// x[ch][t], c[ch][t], skip[ch][t] with row stride Ttot.  GAP >= the largest
+// Storage is BLOCKED: block k holds samples [32k, 32k+32) of all 64 channels contiguously,
+//     addr(ch, t) = (t >> 5) * 2048 + ch * 32 + (t & 31)            (floats)
+// so the 64 x 32 patch a wave reads and writes per layer is ONE contiguous 8 KB range (a plain
+// [ch][Ttot] layout makes it 64 separate 128-byte pieces 20 MB apart -- one DRAM page each).  GAP >= the largest
 // dilation, so a dilated tap that leaves an utterance reads zeros -- exactly the
 // zero padding nn.Conv1D applies at the utterance ends in the reference's
 // one-utterance-per-call inference.  S_b is a multiple of the hop (256), work
@@ -59,6 +62,11 @@ constexpr int UPW_PAD = 8;                    // table row stride (floats)
 constexpr int N_EDGE_CLASS = 9;               // (min(frames before, 2), min(frames after, 2))
 constexpr int P_LEAD = 8;                     // margin rows around the frame-rate projection
 
+// blocked sample-timeline addressing (see the header comment)
+constexpr int XBLK = 32;                       // samples per block
+constexpr int XBLK_FLOATS = R * XBLK;          // 2048 floats = 8 KB
+__host__ __device__ inline long xoff(long t) { return (t >> 5) * XBLK_FLOATS + (t & 31); }   // + ch * 32
+
 // Row of the 32x32 MFMA result held in accumulator register r of a lane whose
 // (lane >> 5) is hi.  (cdna guide: row = (r&3) + 8*(r>>2) + 4*hi, col = lane&31)
 __host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -70,7 +78,8 @@ __global__ void k_zero_gaps(float* buf, const int* gap_start, int gap, int rows,
     int g = blockIdx.y;
     int row = blockIdx.z;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < gap && row < rows) buf[(long)row * Ttot + gap_start[g] + i] = 0.f;
+    (void)Ttot;
+    if (i < gap && row < rows) buf[xoff((long)gap_start[g] + i) + row * XBLK] = 0.f;
 }
 
 // conv_in: ZScore-normalise (PWGInference :773), replicate-pad by ctx (:518),
@@ -117,8 +126,10 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
     const int tile = blockIdx.x;
     const long t = (long)tile_t0[tile] + threadIdx.x;
     const float n = noise[(long)tile * TILE + threadIdx.x];
+    (void)Ttot;
+    const long xo = xoff(t);
 #pragma unroll 8
-    for (int c = 0; c < R; ++c) x[(long)c * Ttot + t] = fmaf(w[c], n, bias[c]);
+    for (int c = 0; c < R; ++c) x[xo + c * XBLK] = fmaf(w[c], n, bias[c]);
 }
 
 // Test tap: the sample-rate aux contribution of one layer, aux[co][s] =
@@ -223,8 +234,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     // line is still in the XCD's L2 for the 2nd and 3rd read (the L2 only holds ~3 us of this stream).
     auto group_ptr = [&](int g) -> const float* {   // wave-uniform
         const int cg = g / 3, tap = g - 3 * cg;
-        return a.xin + (long)(2 * GRP * cg) * Ttot + (long)(tap - 1) * d;
+        (void)tap;   // the tap shift moves lanes across blocks: it lives in the lane offset
+        return a.xin + (long)(2 * GRP * cg) * XBLK;
     };
+    auto group_tap = [&](int g) -> int { return g % 3; };
 
     // Software pipeline across tiles: everything a tile needs before its first MFMA (aux projection
     // rows, upsampler weights, the first operand group) is requested while the previous tile is still
@@ -247,11 +260,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         uw[4] = wrow[4];
     };
     auto load_group0 = [&](int wt) {
-        const unsigned tt = (unsigned)a.tile_t0[wt >> 3] + (unsigned)((wt & 7) * WAVE_T + j);
-        const unsigned vo = (unsigned)hi * (unsigned)Ttot + tt;
+        const long tt = (long)a.tile_t0[wt >> 3] + (wt & 7) * WAVE_T + j;
+        const unsigned vo = (unsigned)(xoff(tt - d) + hi * XBLK);   // group 0 = (cg 0, tap -1)
         const float* p = group_ptr(0);
 #pragma unroll
-        for (int s = 0; s < GRP; ++s) bA[s] = (p + (long)(2 * s) * Ttot)[vo];
+        for (int s = 0; s < GRP; ++s) bA[s] = (p + (long)(2 * s) * XBLK)[vo];
     };
     if (my_slot < n_wtiles) {
         prefetch_head(my_slot);
@@ -263,10 +276,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const int tile = wt >> 3;
         const int phase = (wt & 7) * WAVE_T + j;
         // addresses = wave-uniform row pointer (SGPR pair) + one 32-bit per-lane element offset,
-        // so a load costs no address VGPRs: lane offset = (hi-dependent row) * Ttot + t
-        const unsigned t = (unsigned)a.tile_t0[tile] + (unsigned)phase;
-        const unsigned vo1 = (unsigned)hi * (unsigned)Ttot + t;       // B operand rows 2*cp + hi
-        const unsigned vo4 = 4u * (unsigned)hi * (unsigned)Ttot + t;  // result rows mfma_row(r, hi)
+        // so a load costs no address VGPRs: lane offset = block/sample offset of (t + tap shift) + its row part
+        const long t = (long)a.tile_t0[tile] + phase;
+        unsigned vo1t[3];                                             // B operand rows 2*cp + hi, per tap
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) vo1t[tp] = (unsigned)(xoff(t + (long)(tp - 1) * d) + hi * XBLK);
+        const unsigned vo4 = (unsigned)(xoff(t) + 4 * hi * XBLK);      // result rows mfma_row(r, hi)
 
         // aux projection rows f-2..f+2 (UPW x G floats) -> wave-private LDS (no barrier: same wave)
 #pragma unroll
@@ -304,8 +319,9 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         for (int gg = 0; gg < NGRP / 2; ++gg) {
             {
                 const float* p = group_ptr(2 * gg + 1);
+                const unsigned vo1 = vo1t[group_tap(2 * gg + 1)];
 #pragma unroll
-                for (int s = 0; s < GRP; ++s) bB[s] = (p + (long)(2 * s) * Ttot)[vo1];
+                for (int s = 0; s < GRP; ++s) bB[s] = (p + (long)(2 * s) * XBLK)[vo1];
             }
             __builtin_amdgcn_sched_barrier(0);
             {
@@ -323,8 +339,9 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             __builtin_amdgcn_sched_barrier(0);
             if (2 * gg + 2 < NGRP) {
                 const float* p = group_ptr(2 * gg + 2);
+                const unsigned vo1 = vo1t[group_tap(2 * gg + 2)];
 #pragma unroll
-                for (int s = 0; s < GRP; ++s) bA[s] = (p + (long)(2 * s) * Ttot)[vo1];
+                for (int s = 0; s < GRP; ++s) bA[s] = (p + (long)(2 * s) * XBLK)[vo1];
             } else {
                 load_group0(next_tile);      // the next tile's first operand group
             }
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        old[16 * q + r] = (src + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4];
+                        old[16 * q + r] = (src + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4];
             } else {
 #pragma unroll
                 for (int e = 0; e < 32; ++e) old[e] = 0.f;
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     float v;
                     if (pass == 0) v = (acc2[q][r] + old[16 * q + r]) * rs;       // res = (out + x_in) * sqrt(0.5) (:314)
                     else v = FIRST ? acc2[q][r] : (old[16 * q + r] + acc2[q][r]);  // skips += skip (:468)
-                    (dst + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4] = v;
+                    (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
         }
     }
@@ -500,9 +517,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const int cg = g / 3;
         return (long)(32 * (cg >> 1) + mfma_row(8 * (cg & 1) + e, 0));
     };
-    auto group_shift = [&](int g) -> long { return (long)(g % 3 - 1) * d; };
-    auto lane_off = [&](int wt) -> unsigned {
-        return 4u * (unsigned)hi * (unsigned)Ttot + (unsigned)a.tile_t0[wt >> 3] + (unsigned)((wt & 7) * WAVE_T + j);
+    // lane offsets of a wave-tile for the three taps (the shift moves lanes across 32-sample blocks)
+    auto lane_off = [&](int wt, int tap) -> unsigned {
+        const long tt = (long)a.tile_t0[wt >> 3] + (wt & 7) * WAVE_T + j + (long)(tap - 1) * d;
+        return (unsigned)(xoff(tt) + 4 * hi * XBLK);
     };
     float ring[B3_RING][8];
     f32x4 preg[3];
@@ -523,19 +541,23 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     };
     if (my_slot < n_wtiles) {
         prefetch_head(my_slot);
-        const unsigned vo = lane_off(my_slot);
 #pragma unroll
         for (int g = 0; g < B3_RING; ++g) {
+            const unsigned vo = lane_off(my_slot, g % 3);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ring[g][e] = (a.xin + group_row(g, e) * Ttot + group_shift(g))[vo];
+            for (int e = 0; e < 8; ++e) ring[g][e] = (a.xin + group_row(g, e) * XBLK)[vo];
         }
     }
 
     for (int wt = my_slot; wt < n_wtiles; wt += stride_slots) {
         const int next_wt = wt + stride_slots < n_wtiles ? wt + stride_slots : wt;
-        const unsigned vo8 = lane_off(wt);
-        const unsigned vo8n = lane_off(next_wt);
-        const unsigned vo4 = vo8;   // operand rows and result rows share the lane offset
+        unsigned vo8[3], vo8n[3];
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            vo8[tp] = lane_off(wt, tp);
+            vo8n[tp] = lane_off(next_wt, tp);
+        }
+        const unsigned vo4 = vo8[1];   // centre tap: operand rows and result rows share the lane offset
         float x_old[32];
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
@@ -576,10 +598,9 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             {
                 const int gn = g + B3_RING;
                 const int gt = gn < B3_KS1 ? gn : gn - B3_KS1;
-                const unsigned vo = gn < B3_KS1 ? vo8 : vo8n;
+                const unsigned vo = gn < B3_KS1 ? vo8[gt % 3] : vo8n[gt % 3];
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    ring[g % B3_RING][e] = (a.xin + group_row(gt, e) * Ttot + group_shift(gt))[vo];
+                for (int e = 0; e < 8; ++e) ring[g % B3_RING][e] = (a.xin + group_row(gt, e) * XBLK)[vo];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -609,7 +630,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        old[16 * q + r] = (a.skip + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4];
+                        old[16 * q + r] = (a.skip + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4];
             } else {
 #pragma unroll
                 for (int e = 0; e < 32; ++e) old[e] = 0.f;
@@ -656,7 +677,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     float v;
                     if (pass == 0) v = (acc2[q][r] + old[16 * q + r]) * rs;
                     else v = FIRST ? acc2[q][r] : (old[16 * q + r] + acc2[q][r]);
-                    (dst + (long)(32 * q + mfma_row(r, 0)) * Ttot)[vo4] = v;
+                    (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
         }
     }
@@ -683,7 +704,7 @@ __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
     const int hi = lane >> 5;
     const int tile = blockIdx.x;
     const long t = (long)a.tile_t0[tile] + wave * WAVE_T + j;
-    const float* sb = a.skip + (long)hi * a.Ttot + t;
+    const float* sb = a.skip + xoff(t) + hi * XBLK;
     const f32x2* w1 = reinterpret_cast<const f32x2*>(a.w1) + lane;
     f32x16 acc[2];
 #pragma unroll
@@ -692,7 +713,7 @@ __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
         for (int r = 0; r < 16; ++r) acc[q][r] = a.b1[32 * q + mfma_row(r, hi)];
 #pragma unroll 8
     for (int cp = 0; cp < SK / 2; ++cp) {
-        const float bv = fmaxf(sb[(long)(2 * cp) * a.Ttot] * a.scale, 0.f);
+        const float bv = fmaxf(sb[(long)(2 * cp) * XBLK] * a.scale, 0.f);
         const f32x2 af = w1[cp * 64];
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bv, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bv, acc[1], 0, 0, 0);
@@ -1086,7 +1107,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     const int sumL = cuL[B];
     const long sumS = (long)sumL * hop;
     // kernels address with 32-bit per-lane byte offsets of up to 5 rows of the timeline
-    if (Ttot * 5 * 4 >= (1L << 32)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
+    if (Ttot * R >= (1L << 32)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
     h->last_frames.assign(frames, frames + B);
     h->last_toff = toff;
     h->last_cuL = cuL;
@@ -1265,8 +1286,11 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
     if (n_floats != (int64_t)rows * S)
         PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats, got %lld", rows * S, (long long)n_floats);
     PK_HIP(hipStreamSynchronize(ctx->stream));
-    PK_HIP(hipMemcpy2D(host_out, S * sizeof(float), src + h->last_toff[b], h->last_Ttot * sizeof(float),
-                       S * sizeof(float), rows, hipMemcpyDeviceToHost));
+    // blocked layout: channel ch of this utterance = S/32 pieces of 32 floats, one per block
+    for (int ch = 0; ch < rows; ++ch)
+        PK_HIP(hipMemcpy2D(host_out + (size_t)ch * S, XBLK * sizeof(float),
+                           src + xoff(h->last_toff[b]) + (size_t)ch * XBLK, XBLK_FLOATS * sizeof(float),
+                           XBLK * sizeof(float), S / XBLK, hipMemcpyDeviceToHost));
     return PK_OK;
 }
 
