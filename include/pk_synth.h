@@ -175,6 +175,11 @@ int pk_fs2_set_param(pk_fs2* h, const char* name, const float* data,
 /* FastSpeech2Inference's normalizer: output mel -> mel * sigma + mu (ZScore.inverse,
  * fastspeech2.py:668-671).  NULL,NULL = return the normalised mel (FastSpeech2.inference). */
 int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* sigma, int32_t n);
+/* Arithmetic of the dense layers (Linear / Conv1D GEMMs): 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA with
+ * fp32 accumulation (default; same construction and error class as PK_PWG_MATH_F16X3; layers whose input
+ * channel count is not a multiple of 32 stay on the exact path).  Attention, LayerNorm, softmax, the
+ * duration arithmetic and every stored tensor are fp32 in both modes.  Env PK_FS2_MATH=f32 overrides. */
+int pk_fs2_set_math(pk_fs2* h, int32_t mode);
 int pk_fs2_finalize(pk_fs2* h);
 /* Phase 1 of inference (_forward :390-432): encoder, pitch/energy/duration predictors, prefix
  * sums.  ids: HOST int64, packed by utterance (sum(tok_lens)); tok_lens: HOST (B).

@@ -90,6 +90,7 @@ def _declare(lib):
         "pk_fs2_create": (C.c_int, [vp, C.POINTER(Fs2Cfg), C.POINTER(vp)]),
         "pk_fs2_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
         "pk_fs2_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
+        "pk_fs2_set_math": (C.c_int, [vp, i32]),
         "pk_fs2_finalize": (C.c_int, [vp]),
         "pk_fs2_encode": (C.c_int, [vp, i64p, i32p, i32, C.c_float, i32p]),
         "pk_fs2_decode": (C.c_int, [vp, f32p, i32]),

@@ -20,6 +20,8 @@
 // frame rate (decoder, postnet); the length regulator maps one onto the other.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 #include "pk_gemm.h"
 
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(128) void k_regulate(
 // ================================================================== host side
 struct Dense {
     size_t w = 0, b = 0;   // offsets (floats) into the weight arena; b == SIZE_MAX: no bias
+    size_t wh = (size_t)-1;   // offset (halves) of the split-fp16 fragments, SIZE_MAX if Cin % 32 != 0
     int Cin = 0, N = 0, taps = 1, pad = 0;
 };
 
@@ -356,6 +359,9 @@ struct pk_fs2 {
     // weights
     std::vector<float> arena_h;
     pk_dbuf arena;
+    std::vector<uint16_t> arena16_h;
+    pk_dbuf arena16;
+    int math = PK_GEMM_MATH_F16X3;   // dense layers: 3-term split-fp16 MFMA (fp32-equivalent error) or exact fp32
     size_t emb_table = 0, enc_after_g = 0, enc_after_b = 0, dec_after_g = 0, dec_after_b = 0;
     float alpha_enc = 1.f, alpha_dec = 1.f, xscale = 1.f;
     std::vector<FftLayer> enc, dec;
@@ -453,6 +459,7 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
     h->ctx = ctx;
     h->cfg = c;
     h->gapr = gapr;
+    if (const char* e = getenv("PK_FS2_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     if (gapr > LEAD) { delete h; PK_FAIL(PK_EUNSUPPORTED, "conv kernel too wide"); }
     *out = h;
     return PK_OK;
@@ -482,10 +489,17 @@ extern "C" int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* si
 namespace {
 struct Arena {
     std::vector<float>& v;
+    std::vector<uint16_t>* v16 = nullptr;
     size_t put(const std::vector<float>& x) {
         size_t o = (v.size() + 3) & ~(size_t)3;  // 16-byte alignment
         v.resize(o);
         v.insert(v.end(), x.begin(), x.end());
+        return o;
+    }
+    size_t put16(const std::vector<uint16_t>& x) {
+        size_t o = (v16->size() + 7) & ~(size_t)7;
+        v16->resize(o);
+        v16->insert(v16->end(), x.begin(), x.end());
         return o;
     }
 };
@@ -495,6 +509,11 @@ int add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<floa
     std::vector<float> packed;
     pk_gemm_pack(kn.data(), Cin * taps, N, packed);
     d.w = ar.put(packed);
+    if (ar.v16 && Cin % PK_GEMM_HBK == 0) {
+        std::vector<uint16_t> ph;
+        pk_gemm_pack_h3(kn.data(), Cin * taps, N, ph);
+        d.wh = ar.put16(ph);
+    }
     d.b = bias ? ar.put(*bias) : (size_t)-1;
     d.Cin = Cin;
     d.N = N;
@@ -608,7 +627,8 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
     const pk_param_map& P = h->params;
     const int A = c.adim;
     h->arena_h.clear();
-    Arena ar{h->arena_h};
+    h->arena16_h.clear();
+    Arena ar{h->arena_h, &h->arena16_h};
     {
         std::vector<float> t;
         PK_TRY(pk_get_weight(P, "encoder.embed.0", {c.idim, A}, t));
@@ -674,6 +694,10 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
     PK_TRY(pk_upload(ctx, h->arena, h->arena_h.data(), h->arena_h.size() * sizeof(float)));
     h->arena_h.clear();
     h->arena_h.shrink_to_fit();
+    if (!h->arena16_h.empty())
+        PK_TRY(pk_upload(ctx, h->arena16, h->arena16_h.data(), h->arena16_h.size() * sizeof(uint16_t)));
+    h->arena16_h.clear();
+    h->arena16_h.shrink_to_fit();
     PK_TRY(ensure_pe(h, 1024));
     h->finalized = true;
     h->encoded = false;
@@ -686,6 +710,8 @@ static int run_dense(pk_fs2* h, const char* name, const Dense& d, const float* A
     g.A = A;
     g.lda = lda;
     g.Wp = h->W(d.w);
+    g.Wh = d.wh == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + d.wh;
+    g.math = h->math;
     g.bias = d.b == (size_t)-1 ? nullptr : h->W(d.b);
     g.res = res;
     g.ldr = ldr;
@@ -895,6 +921,7 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
     if (c.postnet_layers == 0) {
         pk_gemm_args g;
         g.A = zs; g.lda = A; g.Wp = h->W(h->feat_out.w); g.bias = h->W(h->feat_out.b);
+        g.Wh = h->feat_out.wh == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + h->feat_out.wh; g.math = h->math;
         g.C = d_out; g.ldc = c.odim; g.rowvalid = tl.d_row_utt(); g.cscale = cs; g.cshift = ch;
         g.out_rowmap = h->d_rowmap.as<int>(); g.M = tl.rows; g.N = c.odim; g.Cin = A; g.taps = 1; g.pad = 0;
         PK_TRY(pk_gemm_launch(ctx, "fs2_gemm_feat_out", g));
@@ -911,6 +938,7 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
             float* outb = act_ptr((j & 1) ? h->d_q2 : h->d_q1, c.postnet_chans);
             pk_gemm_args g;
             g.A = in; g.lda = ldin; g.Wp = h->W(d.w); g.bias = h->W(d.b);
+            g.Wh = d.wh == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + d.wh; g.math = h->math;
             g.M = tl.rows; g.N = d.N; g.Cin = d.Cin; g.taps = d.taps; g.pad = d.pad;
             g.rowvalid = tl.d_row_utt();
             if (!last) {
@@ -929,6 +957,13 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
         PK_HIP(hipMemcpyAsync(mel_out, d_out, (size_t)sumL * c.odim * 4, hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipStreamSynchronize(ctx->stream));
     }
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_set_math(pk_fs2* h, int32_t mode) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_set_math: handle is NULL");
+    if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3) PK_FAIL(PK_EINVAL, "pk_fs2_set_math: unknown mode %d", mode);
+    h->math = mode;
     return PK_OK;
 }
 
@@ -971,7 +1006,7 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     if (!h) return;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    pk_dbuf* bufs[] = {&h->arena, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
+    pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
                        &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
                        &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
     for (auto* b : bufs) b->release();

@@ -10,6 +10,9 @@
 //   As[kk][wm][i]{mt}  float2 per (k, wave-row, lane-row): one ds_read_b64 gives a
 //   lane its A operand for both of its M tiles; Bs[kk][wn][j]{nt} likewise.  The
 //   weight image is pre-packed on the host, so its staging is a straight copy.
+#include <cstring>
+#include <string>
+
 #include "pk_gemm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -20,6 +23,71 @@ namespace {
 constexpr int BM = PK_GEMM_BM, BN = PK_GEMM_BN, BK = PK_GEMM_BK;
 
 __device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Shared epilogue: acc[mt][nt] is the wave's 64x64 sub-tile (rows m0 + wm*64 + mt*32 + mfma_row(r, hi),
+// columns nblk*128 + wn*64 + nt*32 + i).
+__device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&acc)[2][2], int m0, int nblk, int wm,
+                                              int wn, int i, int hi) {
+    // epilogue
+    if (a.epi == PK_EPI_GATE) {
+        // acc[mt][0] = content, acc[mt][1] = gate of output channel nblk*64 + wn*32 + i
+        const int col0 = nblk * BN + wn * 64 + i;
+        const int n_out = nblk * 64 + wn * 32 + i;
+        if (n_out >= a.N / 2) return;
+        const float b0 = a.bias ? a.bias[col0] : 0.f, b1 = a.bias ? a.bias[col0 + 32] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
+                if (m >= a.M) continue;
+                float ca = acc[mt][0][r] + b0;
+                const float cb = acc[mt][1][r] + b1;
+                ca = fminf(fmaxf(ca, -10.f), 10.f);
+                const float ea = __expf(-2.f * ca), eb = __expf(-cb);
+                float v = (1.f - ea) / ((1.f + ea) * (1.f + eb));
+                if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                a.C[(long)m * a.ldc + n_out] = v;
+            }
+        return;
+    }
+    const int n_base = nblk * BN + wn * 64 + i;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n_base + nt * 32;
+        if (n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.f;
+        const float cs = a.cscale ? a.cscale[n] : 1.f;
+        const float ch = a.cshift ? a.cshift[n] : 0.f;
+        const bool to2 = a.nsplit > 0 && n >= a.nsplit;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
+                if (m >= a.M) continue;
+                float v = acc[mt][nt][r] + bias;
+                if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (a.act == PK_ACT_TANH) v = tanhf(v);
+                if (to2) {
+                    float* dst = a.C2 + (long)m * a.ldc2 + (n - a.nsplit);
+                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                    else if (a.acc2) v += *dst;
+                    *dst = v;
+                    continue;
+                }
+                if (a.res) v += a.res[(long)m * a.ldr + n];
+                if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                if (a.cscale) v = v * cs + ch;
+                int mo = m;
+                if (a.out_rowmap) {
+                    mo = a.out_rowmap[m];
+                    if (mo < 0) continue;
+                }
+                a.C[(long)mo * a.ldc + n] = v;
+            }
+    }
+}
 
 // SPI = K slabs (of 16) consumed per barrier: 2 halves the barrier / LDS-turnaround count on long K
 // (64 KB of LDS, two blocks per CU); 1 keeps small problems at 32 KB.
@@ -115,65 +183,114 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
         __syncthreads();
     }
 
-    // epilogue
-    if (a.epi == PK_EPI_GATE) {
-        // acc[mt][0] = content, acc[mt][1] = gate of output channel nblk*64 + wn*32 + i
-        const int col0 = nblk * BN + wn * 64 + i;
-        const int n_out = nblk * 64 + wn * 32 + i;
-        if (n_out >= a.N / 2) return;
-        const float b0 = a.bias ? a.bias[col0] : 0.f, b1 = a.bias ? a.bias[col0 + 32] : 0.f;
+    gemm_epilogue(a, acc, m0, nblk, wm, wn, i, hi);
+}
+
+// ---------------------------------------------------------------- split-fp16 variant
+// Same tiling and epilogue; every fp32 product is a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with fp16 parts on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation (error of the result = exact-fp32 class, see pwg.hip).
+// K slab = 32.  LDS per buffer: activations fp32 row-major [128][36] (padded: conflict-free 16-B reads),
+// split in registers after the read; weights pre-split on the host into MFMA fragments
+// [k-step][part][n-tile][lane] x 8 halves.  A operand = activations (rows), B operand = weights (cols).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int HBK = PK_GEMM_HBK;           // 32
+constexpr int A_LD = HBK + 4;              // 36 floats per row
+constexpr int H_A_FLOATS = BM * A_LD;      // 4608
+constexpr int H_B_BYTES = 2 * 2 * 4 * 64 * 16;   // 16 KB: [ks 2][part 2][nt 4][lane 64] x 16 B
+
+__global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
+    __shared__ __attribute__((aligned(16))) float As[2][H_A_FLOATS];
+    __shared__ __attribute__((aligned(16))) f16x8 Bs[2][H_B_BYTES / 16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int nblk = blockIdx.y;
+    const int slabs_per_tap = a.Cin / HBK;
+    const int nmain = a.ntaps * slabs_per_tap;
+    const int nslabs = nmain + a.Cin2 / HBK;
+
+    const int lrow = tid >> 1, lhalf = tid & 1;      // thread -> (row, 16 consecutive k)
+    const float* arow = a.A + (long)(m0 + lrow) * a.lda + lhalf * 16;
+    const float* arow2 = a.A2 + (long)(m0 + lrow) * a.lda2 + lhalf * 16;
+    const f16x8* wsrc = reinterpret_cast<const f16x8*>(a.Wh) + (long)nblk * a.wslabs_total * (H_B_BYTES / 16) + tid;
+
+    f32x4 ra[4];
+    f16x8 rb[4];
+    auto load_slab = [&](int s) {
+        const float* p;
+        int wslab;
+        if (s < nmain) {
+            const int tap = s / slabs_per_tap, sl = s - tap * slabs_per_tap;
+            p = arow + a.tap_off[tap] + sl * HBK;
+            wslab = a.tap_w[tap] * slabs_per_tap + sl;
+        } else {
+            p = arow2 + (s - nmain) * HBK;
+            wslab = a.w2_slab0 + (s - nmain);
+        }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int c = 0; c < 4; ++c) ra[c] = *reinterpret_cast<const f32x4*>(p + 4 * c);
+        const f16x8* q = wsrc + (long)wslab * (H_B_BYTES / 16);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
-                if (m >= a.M) continue;
-                float ca = acc[mt][0][r] + b0;
-                const float cb = acc[mt][1][r] + b1;
-                ca = fminf(fmaxf(ca, -10.f), 10.f);
-                const float ea = __expf(-2.f * ca), eb = __expf(-cb);
-                float v = (1.f - ea) / ((1.f + ea) * (1.f + eb));
-                if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
-                a.C[(long)m * a.ldc + n_out] = v;
-            }
-        return;
-    }
-    const int n_base = nblk * BN + wn * 64 + i;
+        for (int c = 0; c < 4; ++c) rb[c] = q[c * 256];
+    };
+    auto store_slab = [&](int buf) {
+        float* d = As[buf] + lrow * A_LD + lhalf * 16;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n_base + nt * 32;
-        if (n >= a.N) continue;
-        const float bias = a.bias ? a.bias[n] : 0.f;
-        const float cs = a.cscale ? a.cscale[n] : 1.f;
-        const float ch = a.cshift ? a.cshift[n] : 0.f;
-        const bool to2 = a.nsplit > 0 && n >= a.nsplit;
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(d + 4 * c) = ra[c];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int c = 0; c < 4; ++c) Bs[buf][tid + c * 256] = rb[c];
+    };
+
+    f32x16 acc[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
-                if (m >= a.M) continue;
-                float v = acc[mt][nt][r] + bias;
-                if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (a.act == PK_ACT_TANH) v = tanhf(v);
-                if (to2) {
-                    float* dst = a.C2 + (long)m * a.ldc2 + (n - a.nsplit);
-                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
-                    else if (a.acc2) v += *dst;
-                    *dst = v;
-                    continue;
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < nslabs; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslabs) load_slab(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[2], al[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float* ap = As[buf] + (wm * 64 + mt * 32 + i) * A_LD + ks * 16 + hi * 8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = __builtin_fminf(__builtin_fmaxf(v0[e], -65000.f), 65000.f);
+                    const float x1 = __builtin_fminf(__builtin_fmaxf(v1[e], -65000.f), 65000.f);
+                    ah[mt][e] = (_Float16)x0;
+                    ah[mt][4 + e] = (_Float16)x1;
+                    al[mt][e] = (_Float16)(v0[e] - (float)ah[mt][e]);
+                    al[mt][4 + e] = (_Float16)(v1[e] - (float)ah[mt][4 + e]);
                 }
-                if (a.res) v += a.res[(long)m * a.ldr + n];
-                if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
-                if (a.cscale) v = v * cs + ch;
-                int mo = m;
-                if (a.out_rowmap) {
-                    mo = a.out_rowmap[m];
-                    if (mo < 0) continue;
-                }
-                a.C[(long)mo * a.ldc + n] = v;
             }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f16x8 bh = Bs[buf][((ks * 2 + 0) * 4 + wn * 2 + nt) * 64 + lane];
+                const f16x8 bl = Bs[buf][((ks * 2 + 1) * 4 + wn * 2 + nt) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < nslabs) store_slab(buf ^ 1);
+        __syncthreads();
     }
+    gemm_epilogue(a, acc, m0, nblk, wm, wn, i, hi);
 }
 }  // namespace
 
@@ -190,6 +307,69 @@ size_t pk_gemm_pack(const float* Wkn, int K, int N, std::vector<float>& out) {
                             const int n = nb * BN + wn * 64 + nt * 32 + j;
                             const int k = s * BK + kk;
                             img[((kk * 2 + wn) * 32 + j) * 2 + nt] = (n < N) ? Wkn[(size_t)k * N + n] : 0.f;
+                        }
+        }
+    return out.size();
+}
+
+static inline uint16_t gemm_f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 113 - (int)(x >> 23);
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t half = 1u << (shift + 12), mask = (half << 1) - 1;
+        uint32_t r = m >> (shift + 13);
+        const uint32_t rem = m & mask;
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = x - 0x38000000u;
+    const uint32_t rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+static inline float gemm_f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            e = 113;
+            while (!(m & 0x400u)) { m <<= 1; --e; }
+            x = sign | (e << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+size_t pk_gemm_pack_h3(const float* Wkn, int K, int N, std::vector<uint16_t>& out) {
+    const int nblks = (N + BN - 1) / BN, nslabs = K / PK_GEMM_HBK;
+    const size_t per = H_B_BYTES / 2;   // halves per (n-block, slab)
+    out.assign((size_t)nblks * nslabs * per, 0);
+    for (int nb = 0; nb < nblks; ++nb)
+        for (int s = 0; s < nslabs; ++s) {
+            uint16_t* img = out.data() + ((size_t)nb * nslabs + s) * per;
+            for (int ks = 0; ks < 2; ++ks)
+                for (int nt = 0; nt < 4; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int j = lane & 31, kb = lane >> 5;
+                            const int k = s * PK_GEMM_HBK + ks * 16 + kb * 8 + e;
+                            const int n = nb * BN + nt * 32 + j;
+                            const float w = n < N ? Wkn[(size_t)k * N + n] : 0.f;
+                            const uint16_t h = gemm_f32_to_f16(w);
+                            const uint16_t l = gemm_f32_to_f16(w - gemm_f16_to_f32(h));
+                            img[((((size_t)ks * 2 + 0) * 4 + nt) * 64 + lane) * 8 + e] = h;
+                            img[((((size_t)ks * 2 + 1) * 4 + nt) * 64 + lane) * 8 + e] = l;
                         }
         }
     return out.size();
@@ -224,6 +404,8 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     if (a.Cin % BK != 0 || a.Cin2 % BK != 0)
         PK_FAIL(PK_EUNSUPPORTED, "GEMM: input channels (%d, %d) must be multiples of %d", a.Cin, a.Cin2, BK);
     if (a.M <= 0 || a.N <= 0) PK_FAIL(PK_EINVAL, "GEMM: empty problem");
+    const bool h3 = a.math == PK_GEMM_MATH_F16X3 && a.Wh && a.Cin % PK_GEMM_HBK == 0 && a.Cin2 % PK_GEMM_HBK == 0;
+    const int bk = h3 ? PK_GEMM_HBK : BK;
     if (a.ntaps == 0) {
         if (a.taps > PK_GEMM_MAX_TAPS) PK_FAIL(PK_EUNSUPPORTED, "GEMM: more than %d taps", PK_GEMM_MAX_TAPS);
         a.ntaps = a.taps;
@@ -231,7 +413,11 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
             a.tap_off[t] = (long)(t - a.pad) * a.lda;
             a.tap_w[t] = t;
         }
-        a.wslabs_total = a.taps * a.Cin / BK + a.Cin2 / BK;
+        a.wslabs_total = a.taps * a.Cin / bk + a.Cin2 / bk;
+    } else if (h3) {
+        // callers give slab bookkeeping in units of 16; the split kernel uses slabs of 32
+        a.w2_slab0 /= 2;
+        a.wslabs_total /= 2;
     }
     if (a.wslabs_total <= 0) PK_FAIL(PK_EINVAL, "GEMM: wslabs_total not set");
     if (!a.A2) { a.A2 = a.A; a.lda2 = 0; }
@@ -241,6 +427,12 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     // k_gemm<2> (two slabs per barrier, 64 KB LDS) measured slower on every FS2 / WaveFlow shape
     // (ffn1 0.49 vs 0.42 ms, WaveFlow conv 160 vs 140 us): occupancy beats fewer barriers here.
     (void)nslabs;
+    if (h3) {
+        const std::string nm = std::string(prof_name) + "_h3";
+        PK_LAUNCH(ctx, nm.c_str(), k_gemm_h3, grid, dim3(256), 0, a);
+        return PK_OK;
+    }
+    if (!a.Wp) PK_FAIL(PK_EINVAL, "GEMM: fp32 weights missing");
     PK_LAUNCH(ctx, prof_name, k_gemm<1>, grid, dim3(256), 0, a);
     return PK_OK;
 }

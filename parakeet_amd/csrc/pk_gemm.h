@@ -10,7 +10,9 @@ constexpr int PK_GEMM_BM = 128;
 constexpr int PK_GEMM_BN = 128;
 constexpr int PK_GEMM_BK = 16;
 
+constexpr int PK_GEMM_HBK = 32;   // K slab of the split-fp16 variant
 constexpr int PK_GEMM_MAX_TAPS = 12;
+enum { PK_GEMM_MATH_F32 = 0, PK_GEMM_MATH_F16X3 = 1 };
 
 enum { PK_ACT_NONE = 0, PK_ACT_RELU = 1, PK_ACT_TANH = 2 };
 enum { PK_EPI_STD = 0, PK_EPI_GATE = 1 };
@@ -26,6 +28,8 @@ struct pk_gemm_args {
     const float* A = nullptr;
     int lda = 0;
     const float* Wp = nullptr;   // packed by pk_gemm_pack()
+    const void* Wh = nullptr;    // packed by pk_gemm_pack_h3() (split-fp16 fragments); used when math == F16X3
+    int math = PK_GEMM_MATH_F32; // F16X3 needs Wh and input channels that are multiples of 32, else falls back
     const float* bias = nullptr;
     const float* res = nullptr;
     int ldr = 0;
@@ -62,6 +66,8 @@ struct pk_gemm_args {
 // Pack a [K][N] row-major matrix (K = taps*Cin, multiple of 16) into per-(N tile,
 // K slab) LDS images.  Returns floats written: ceil(N/128) * (K/16) * 2048.
 size_t pk_gemm_pack(const float* Wkn, int K, int N, std::vector<float>& out);
+// Split-fp16 fragments for k_gemm_h3: K multiple of 32.  Returns halves written.
+size_t pk_gemm_pack_h3(const float* Wkn, int K, int N, std::vector<uint16_t>& out);
 // Conv1D weight [Cout][Cin][k] (paddle layout) -> [K = tap*Cin + ci][N = Cout] row-major.
 void pk_conv_to_kn(const float* w, int Cout, int Cin, int k, std::vector<float>& out);
 

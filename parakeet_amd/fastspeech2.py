@@ -110,6 +110,10 @@ class FastSpeech2:
             _capi.check(self._ctx.lib.pk_fs2_finalize(self._h))
             self._finalized = True
 
+    def set_math(self, mode):
+        """'f16x3' (default: 3-term split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
+        _capi.check(self._ctx.lib.pk_fs2_set_math(self._h, {"f32": 0, "f16x3": 1}[mode]))
+
     def set_debug(self, on=True):
         _capi.check(self._ctx.lib.pk_fs2_set_debug(self._h, 1 if on else 0))
 
