@@ -216,6 +216,8 @@ int pk_wf_create(pk_ctx* ctx, const pk_wf_cfg* cfg, pk_wf** out);
  * decoder.{f}.resnet.{l}.{conv,condition_proj,out_proj}.*, decoder.{f}.output_proj.*;
  * weight_g / weight_v pairs are folded (recursively_remove_weight_norm). */
 int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs with fp32 accumulation (default, as pk_fs2_set_math). */
+int pk_wf_set_math(pk_wf* h, int32_t mode);
 int pk_wf_finalize(pk_wf* h);
 /* For t_mel frames: length of the trimmed upsampled condition (= length of the z the reference
  * draws, waveflow.py:799-801) and of the returned waveform (pruned to a multiple of n_group, :695). */

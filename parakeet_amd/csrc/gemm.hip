@@ -404,7 +404,11 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     if (a.Cin % BK != 0 || a.Cin2 % BK != 0)
         PK_FAIL(PK_EUNSUPPORTED, "GEMM: input channels (%d, %d) must be multiples of %d", a.Cin, a.Cin2, BK);
     if (a.M <= 0 || a.N <= 0) PK_FAIL(PK_EINVAL, "GEMM: empty problem");
-    const bool h3 = a.math == PK_GEMM_MATH_F16X3 && a.Wh && a.Cin % PK_GEMM_HBK == 0 && a.Cin2 % PK_GEMM_HBK == 0;
+    // short-K problems are epilogue / memory bound: the fp32 kernel's higher occupancy wins there
+    // (WaveFlow out_proj, K = 64: 64 us vs 92 us)
+    const int k_total = (a.ntaps ? a.ntaps : a.taps) * a.Cin + a.Cin2;
+    const bool h3 = a.math == PK_GEMM_MATH_F16X3 && a.Wh && a.Cin % PK_GEMM_HBK == 0 && a.Cin2 % PK_GEMM_HBK == 0 &&
+                    k_total >= 256;
     const int bk = h3 ? PK_GEMM_HBK : BK;
     if (a.ntaps == 0) {
         if (a.taps > PK_GEMM_MAX_TAPS) PK_FAIL(PK_EUNSUPPORTED, "GEMM: more than %d taps", PK_GEMM_MAX_TAPS);

@@ -21,6 +21,8 @@
 // instead of being stored as zeros.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 #include "pk_gemm.h"
 
@@ -35,7 +37,7 @@ __global__ void k_wf_upsample(const float* __restrict__ in, const int* __restric
                               const int* __restrict__ in_len, float* __restrict__ out,
                               const int* __restrict__ out_off, const float* __restrict__ w, float bias, int f,
                               int M, int fold_G, const int* __restrict__ woff, const int* __restrict__ pruned,
-                              long cond_row_stride) {
+                              long cond_row_stride, int cond_ld) {
     const int b = blockIdx.z;
     const int Tin = in_len[b];
     const int Tout = f * Tin - f;  // (Tin-1)*f - 2*(f/2) + 2f, minus the trimmed (2f - f) columns
@@ -62,7 +64,7 @@ __global__ void k_wf_upsample(const float* __restrict__ in, const int* __restric
     if (fold_G == 0) {
         out[((long)out_off[b] + t) * M + c] = acc;
     } else if (t < pruned[b]) {
-        out[(long)(t % fold_G) * cond_row_stride + ((long)woff[b] + t / fold_G) * M + c] = acc;
+        out[(long)(t % fold_G) * cond_row_stride + ((long)woff[b] + t / fold_G) * cond_ld + c] = acc;
     }
 }
 
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void k_wf_step(const float* __restrict__ skips
 // ================================================================== host side
 struct WfLayerW {
     size_t w1, b1, w2, b2;   // packed GEMM weights (floats offsets into the arena)
+    size_t w1h, w2h;         // split-fp16 fragments (halves offsets into arena16)
 };
 
 struct WfFlowW {
@@ -147,6 +150,10 @@ struct pk_wf {
     int gapw = 128;
     std::vector<float> arena_h;
     pk_dbuf arena;
+    std::vector<uint16_t> arena16_h;
+    pk_dbuf arena16;
+    int math = PK_GEMM_MATH_F16X3;
+    int mp = 96;              // mel channels padded to a multiple of 32 (GEMM K block of the condition)
     std::vector<WfFlowW> flows;
     std::vector<size_t> up_w;
     std::vector<float> up_b;
@@ -176,6 +183,8 @@ extern "C" int pk_wf_create(pk_ctx* ctx, const pk_wf_cfg* cfg, pk_wf** out) {
     h->ctx = ctx;
     h->cfg = c;
     h->gapw = 1 << (c.n_layers - 1);
+    h->mp = ((c.n_mels + PK_GEMM_HBK - 1) / PK_GEMM_HBK) * PK_GEMM_HBK;
+    if (const char* e = getenv("PK_WF_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     *out = h;
     return PK_OK;
 }
@@ -196,7 +205,20 @@ struct Arena {
         return o;
     }
 };
+size_t put16(std::vector<uint16_t>& v, const std::vector<uint16_t>& x) {
+    size_t o = (v.size() + 7) & ~(size_t)7;
+    v.resize(o);
+    v.insert(v.end(), x.begin(), x.end());
+    return o;
+}
 }  // namespace
+
+extern "C" int pk_wf_set_math(pk_wf* h, int32_t mode) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_wf_set_math: handle is NULL");
+    if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3) PK_FAIL(PK_EINVAL, "pk_wf_set_math: unknown mode %d", mode);
+    h->math = mode;
+    return PK_OK;
+}
 
 extern "C" int pk_wf_finalize(pk_wf* h) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_wf_finalize: handle is NULL");
@@ -206,7 +228,9 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
     const pk_param_map& P = h->params;
     const int C = c.channels, M = c.n_mels;
     h->arena_h.clear();
+    h->arena16_h.clear();
     Arena ar{h->arena_h};
+    const int MP = h->mp;
     h->up_w.resize(c.n_upsample);
     h->up_b.resize(c.n_upsample);
     for (int i = 0; i < c.n_upsample; ++i) {
@@ -242,8 +266,9 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
             PK_TRY(pk_get_weight(P, q + ".out_proj", {2 * C, C, 1, 1}, wo));
             PK_TRY(pk_get_vector(P, q + ".out_proj.bias", 2 * C, bo));
             // GEMM1 weight [K = (kr*3 + kc)*C + ci | 9C + m][N = 2C], gate-permuted columns
-            const int K1 = 9 * C + M;
-            std::vector<float> kn((size_t)K1 * 2 * C), perm, bias(2 * C), pbias, packed;
+            const int K1 = 9 * C + MP;   // condition block zero-padded to MP channels
+            std::vector<float> kn((size_t)K1 * 2 * C, 0.f), perm, bias(2 * C), pbias, packed;
+            std::vector<uint16_t> ph;
             for (int co = 0; co < 2 * C; ++co) {
                 for (int ci = 0; ci < C; ++ci)
                     for (int kr = 0; kr < 3; ++kr)
@@ -256,6 +281,8 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
             pk_gemm_gate_permute_bias(bias.data(), C, pbias);
             pk_gemm_pack(perm.data(), K1, 2 * C, packed);
             F.layers[l].w1 = ar.put(packed);
+            pk_gemm_pack_h3(perm.data(), K1, 2 * C, ph);
+            F.layers[l].w1h = put16(h->arena16_h, ph);
             F.layers[l].b1 = ar.put(pbias);
             // GEMM2: out_proj [K = C][N = 2C] (res | skip, chunk :282)
             std::vector<float> kn2((size_t)C * 2 * C), packed2;
@@ -263,12 +290,17 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
                 for (int ci = 0; ci < C; ++ci) kn2[(size_t)ci * 2 * C + co] = wo[(size_t)co * C + ci];
             pk_gemm_pack(kn2.data(), C, 2 * C, packed2);
             F.layers[l].w2 = ar.put(packed2);
+            pk_gemm_pack_h3(kn2.data(), C, 2 * C, ph);
+            F.layers[l].w2h = put16(h->arena16_h, ph);
             F.layers[l].b2 = ar.put(bo);
         }
     }
     PK_TRY(pk_upload(ctx, h->arena, h->arena_h.data(), h->arena_h.size() * sizeof(float)));
     h->arena_h.clear();
     h->arena_h.shrink_to_fit();
+    PK_TRY(pk_upload(ctx, h->arena16, h->arena16_h.data(), h->arena16_h.size() * sizeof(uint16_t)));
+    h->arena16_h.clear();
+    h->arena16_h.shrink_to_fit();
     h->finalized = true;
     return PK_OK;
 }
@@ -295,7 +327,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     pk_ctx* ctx = h->ctx;
     PK_HIP(hipSetDevice(ctx->device));
     const pk_wf_cfg& c = h->cfg;
-    const int C = c.channels, M = c.n_mels, G = c.n_group, NL = c.n_layers;
+    const int C = c.channels, M = c.n_mels, G = c.n_group, NL = c.n_layers, MP = h->mp;
     // ---- per-utterance sizes
     std::vector<int> cuT(B + 1, 0), clen(B), pruned(B), Wb(B), woff(B), zoff(B), ooff(B);
     long sumZ = 0, sumO = 0;
@@ -375,7 +407,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         d_wav = h->ws_wav.as<float>();
     }
     // ---- workspaces
-    const long cond_row = pstride * M;          // floats per folded cond row
+    const long cond_row = pstride * MP;         // floats per folded cond row (channels padded to MP, pad = 0)
     const long feat_row = pstride * C;          // floats per [pos][C] buffer
     PK_TRY(h->ws_cond.reserve((size_t)G * cond_row * 4));
     PK_TRY(h->ws_cur.reserve((size_t)G * pstride * 4));
@@ -388,7 +420,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     PK_HIP(hipMemsetAsync(h->ws_cond.p, 0, (size_t)G * cond_row * 4, ctx->stream));
     PK_HIP(hipMemsetAsync(h->ws_hist.p, 0, (size_t)(NL + 1) * 3 * feat_row * 4, ctx->stream));
     PK_HIP(hipMemsetAsync(h->ws_zbuf.p, 0, (size_t)feat_row * 4, ctx->stream));
-    float* cond = h->ws_cond.as<float>() + (size_t)WF_LEAD * M;
+    float* cond = h->ws_cond.as<float>() + (size_t)WF_LEAD * MP;
     float* cur = h->ws_cur.as<float>() + WF_LEAD;
     float* nxt = h->ws_nxt.as<float>() + WF_LEAD;
     float* hist = h->ws_hist.as<float>() + (size_t)WF_LEAD * C;
@@ -415,7 +447,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
             dim3 grid(pk_div_up(maxT, tpb), 1, B);
             PK_LAUNCH(ctx, "wf_upsample", k_wf_upsample, grid, dim3(256), 0, in, d_tab + o_inoff[i], d_tab + o_inlen[i],
                       out, d_tab + o_outoff[i], h->W(h->up_w[i]), h->up_b[i], f, M, last ? G : 0, d_tab + o_woff,
-                      d_tab + o_pruned, cond_row);
+                      d_tab + o_pruned, cond_row, MP);
             in = out;
         }
     }
@@ -459,11 +491,13 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                     }
                 }
                 g.A2 = cond + (long)cidx[i] * cond_row;
-                g.lda2 = M;
-                g.Cin2 = M;
+                g.lda2 = MP;
+                g.Cin2 = MP;
                 g.w2_slab0 = 9 * C / PK_GEMM_BK;
-                g.wslabs_total = (9 * C + M) / PK_GEMM_BK;
+                g.wslabs_total = (9 * C + MP) / PK_GEMM_BK;
                 g.Wp = h->W(L.w1);
+                g.Wh = h->arena16.as<uint16_t>() + L.w1h;
+                g.math = h->math;
                 g.bias = h->W(L.b1);
                 g.epi = PK_EPI_GATE;
                 g.C = zbuf;
@@ -479,6 +513,8 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 o.taps = 1;
                 o.pad = 0;
                 o.Wp = h->W(L.w2);
+                o.Wh = h->arena16.as<uint16_t>() + L.w2h;
+                o.math = h->math;
                 o.bias = h->W(L.b2);
                 o.res = hist_ptr(l, slot);
                 o.ldr = C;
@@ -513,7 +549,7 @@ extern "C" void pk_wf_destroy(pk_wf* h) {
     if (!h) return;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    pk_dbuf* bufs[] = {&h->arena, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
+    pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
                        &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip};
     for (auto* b : bufs) b->release();
     delete h;

@@ -49,6 +49,10 @@ class ConditionalWaveFlow:
         self.training = False
         return self
 
+    def set_math(self, mode):
+        """'f16x3' (default: split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
+        _capi.check(self._ctx.lib.pk_wf_set_math(self._h, {"f32": 0, "f16x3": 1}[mode]))
+
     def lengths(self, t_mel):
         a, b = C.c_int32(), C.c_int32()
         _capi.check(self._ctx.lib.pk_wf_cond_length(self._h, int(t_mel), C.byref(a), C.byref(b)))
