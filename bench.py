@@ -229,13 +229,14 @@ def main():
             torch.cuda.synchronize()
             dtw = time.perf_counter() - t1
             nsw = sum(o.numel() for o in out)
-            extras["waveflow_c64_batch8_fp32"] = {
-                "what": "BASELINE config 5 shape (ConditionalWaveFlow, 64 channels, batch 8 x 640 frames) in exact fp32",
+            extras["waveflow_c64_batch8"] = {
+                "what": "BASELINE config 5 shape (ConditionalWaveFlow, 64 channels, batch 8 x 640 frames), fp32 storage, "
+                        "split-fp16 conv GEMMs (default math)",
                 "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,
                 "reference_published": "about 40x real time on V100 (docs/src/released_models.md:275-276)"}
             del wf
         except Exception as e:  # never let an extra break the headline line
-            extras["waveflow_c64_batch8_fp32"] = {"error": repr(e)}
+            extras["waveflow_c64_batch8"] = {"error": repr(e)}
 
     if rank == 0:
         total_samples = n_samples * world
