@@ -167,7 +167,7 @@ struct PwgLayerArgs {
 
 // tanh(a) * sigmoid(b) (:309-310).  exp via v_exp_f32; |a| clamped where tanh is +-1 in fp32.
 __device__ __forceinline__ float gated(float a, float b) {
-    a = fminf(fmaxf(a, -10.f), 10.f);
+    a = __builtin_amdgcn_fmed3f(a, -10.f, 10.f);
     const float ea = __expf(-2.f * a);
     const float eb = __expf(-b);
     // v_rcp_f32 (1 ulp) instead of an IEEE divide: the gate is VALU time that the other wave's MFMAs
@@ -465,11 +465,23 @@ template <class V, class E, bool CLAMP>
 __device__ __forceinline__ void split_x8(const float (&v)[8], V& hi, V& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        // fp16 parts: the high part saturates at +-65000 instead of overflowing to inf, the low part
-        // then carries the rest (still finite up to |x| ~ 1.3e5; no effect below 65000)
-        const float x = CLAMP ? __builtin_fminf(__builtin_fmaxf(v[e], -65000.f), 65000.f) : v[e];
-        hi[e] = (E)x;
+        hi[e] = (E)v[e];
         lo[e] = (E)(v[e] - (float)hi[e]);
+    }
+}
+// fp16 parts: the high part is rounded toward zero by v_cvt_pkrtz_f16_f32 (two elements per instruction;
+// it saturates at +-65504 instead of overflowing to inf, so no clamp is needed), the low part is the
+// round-to-nearest fp16 of the exact remainder: |x - hi - lo| <= 2^-21 |x|.  2.5 VALU ops per element.
+typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
+template <>
+__device__ __forceinline__ void split_x8<f16x8, _Float16, true>(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+        hi[2 * p] = (_Float16)h[0];
+        hi[2 * p + 1] = (_Float16)h[1];
+        lo[2 * p] = (_Float16)(v[2 * p] - (float)h[0]);
+        lo[2 * p + 1] = (_Float16)(v[2 * p + 1] - (float)h[1]);
     }
 }
 
@@ -658,7 +670,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     zv[e] = acc[zq][r0 + e];
                 }
                 bf16x8 zh, zl;
-                split_x8<bf16x8, elem16, false>(zv, zh, zl);   // |z| < 1
+                split_x8<bf16x8, elem16, HALF>(zv, zh, zl);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const bf16x8 ah = lds_a2[((ks * 2 + 0) * 4 + 2 * pass + q) * 64];
