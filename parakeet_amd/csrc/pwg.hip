@@ -535,6 +535,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         return (unsigned)(xoff(tt) + 4 * hi * XBLK);
     };
     float ring[B3_RING][8];
+    bf16x8 ph, pl;     // split operands of the k-step about to run (produced one step ahead, under the MFMAs)
     f32x4 preg[3];
     float uw[UPW];
     auto prefetch_head = [&](int wt) {
@@ -559,8 +560,13 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
             for (int e = 0; e < 8; ++e) ring[g][e] = (a.xin + group_row(g, e) * XBLK)[vo];
         }
+        split_x8<bf16x8, elem16, HALF>(ring[0], ph, pl);
     }
+    // W1 fragments of the next (k-step, co-tile) in issue order, read one co-tile ahead of their MFMAs
+    bf16x8 c_ah = lds_a[0], c_al = lds_a[4 * 64];
 
+    // Invariant at the top of k-step g: (ph, pl) = split operands of group g; ring slots (g+1..g+RING-1) % RING
+    // hold groups g+1..g+RING-1 (of this tile, continuing into the next one); slot g % RING is free.
     for (int wt = my_slot; wt < n_wtiles; wt += stride_slots) {
         const int next_wt = wt + stride_slots < n_wtiles ? wt + stride_slots : wt;
         unsigned vo8[3], vo8n[3];
@@ -597,16 +603,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 acc[q][4 * r4 + 3] = v[3];
             }
 
-        // stage 1: 12 k-steps; the operands of k-step g+6 (or of the next tile's g-6) are requested
-        // into the ring slot that k-step g has just vacated
+        // stage 1: 12 k-steps.  Step g: refill the free ring slot with group g+RING, then run the 12 MFMAs of
+        // group g while the VALU splits group g+1 (sched_group_barrier interleaves them: a 32x32x16 MFMA
+        // occupies the matrix pipe for 8 issue slots, the split fits in the gaps).
 #pragma unroll
         for (int g = 0; g < B3_KS1; ++g) {
-            bf16x8 bh, bl;
-            split_x8<bf16x8, elem16, HALF>(ring[g % B3_RING], bh, bl);
-            if (g % 3 == 1) {   // centre tap: these fp32 values are x_in at this lane's output rows
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x_old[16 * ((g / 3) >> 1) + 8 * ((g / 3) & 1) + e] = ring[g % B3_RING][e];
-            }
             {
                 const int gn = g + B3_RING;
                 const int gt = gn < B3_KS1 ? gn : gn - B3_KS1;
@@ -615,39 +616,69 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 for (int e = 0; e < 8; ++e) ring[g % B3_RING][e] = (a.xin + group_row(gt, e) * XBLK)[vo];
             }
             __builtin_amdgcn_sched_barrier(0);
+            bf16x8 nh, nl;
+            {
+                const int g1 = (g + 1) % B3_KS1;
+                split_x8<bf16x8, elem16, HALF>(ring[(g + 1) % B3_RING], nh, nl);
+                if (g1 % 3 == 1) {   // centre tap: these fp32 values are x_in at this lane's output rows
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x_old[16 * ((g1 / 3) >> 1) + 8 * ((g1 / 3) & 1) + e] = ring[(g + 1) % B3_RING][e];
+                }
+            }
+            bf16x8 ah = c_ah, al = c_al;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bf16x8 ah = lds_a[((g * 2 + 0) * 4 + q) * 64];
-                const bf16x8 al = lds_a[((g * 2 + 1) * 4 + q) * 64];
-                acc[q] = mfma16(ah, bh, acc[q]);
-                acc[q] = mfma16(al, bh, acc[q]);
-                acc[q] = mfma16(ah, bl, acc[q]);
+                acc[q] = mfma16(ah, ph, acc[q]);
+                const int gq = (g * 4 + q + 1) % (B3_KS1 * 4);
+                const bf16x8 nah = lds_a[(((gq >> 2) * 2 + 0) * 4 + (gq & 3)) * 64];
+                const bf16x8 nal = lds_a[(((gq >> 2) * 2 + 1) * 4 + (gq & 3)) * 64];
+                acc[q] = mfma16(al, ph, acc[q]);
+                acc[q] = mfma16(ah, pl, acc[q]);
+                ah = nah;
+                al = nal;
+            }
+            c_ah = ah;
+            c_al = al;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            ph = nh;
+            pl = nl;
         }
         prefetch_head(next_wt);
+        float sk_old[32];   // skip accumulator: requested half-way through pass 0, used at the end of pass 1
         __builtin_amdgcn_sched_barrier(0);
 
-        // stage 2 (two passes: out, skip); the gate of a k-step's 8 channels is computed right before
-        // its MFMAs in pass 0 and kept (fp32) in acc[0..1] for pass 1
+        // stage 2 (two passes: out, skip).  The gate of k-step ks+1 (VALU + transcendental) is cut in pieces
+        // placed after the MFMAs of k-step ks in pass 0; its split parts are kept for pass 1.
         const float rs = 0.70710678118654752440f;
+        bf16x8 zh[B3_KS2], zl[B3_KS2];
+        float zv[8];
+        auto gate_piece = [&](int ks, int slot) {
+            if (ks >= B3_KS2) return;
+            const int zq = ks >> 1, r0 = 8 * (ks & 1);
+            if (slot < 4) {
+                zv[2 * slot] = gated(acc[zq][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot]);
+                zv[2 * slot + 1] = gated(acc[zq][r0 + 2 * slot + 1], acc[zq + 2][r0 + 2 * slot + 1]);
+            } else if (slot == 4) {
+                split_x8<bf16x8, elem16, HALF>(zv, zh[ks], zl[ks]);
+            }
+        };
+#pragma unroll
+        for (int slot = 0; slot < 5; ++slot) gate_piece(0, slot);
+        bf16x8 f_ah = lds_a2[0], f_al = lds_a2[4 * 64];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            float old[32];
-            if (pass == 0) {
-#pragma unroll
-                for (int e = 0; e < 32; ++e) old[e] = x_old[e];
-            } else if (!FIRST) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        old[16 * q + r] = (a.skip + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 32; ++e) old[e] = 0.f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
             f32x16 acc2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -660,25 +691,47 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     acc2[q][4 * r4 + 2] = bv[2];
                     acc2[q][4 * r4 + 3] = bv[3];
                 }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < B3_KS2; ++ks) {
-                const int zq = ks >> 1, r0 = 8 * (ks & 1);
-                float zv[8];
+            for (int idx = 0; idx < 2 * B3_KS2; ++idx) {
+                const int ks = idx >> 1, q = idx & 1;
+                if (!FIRST && pass == 0 && idx == B3_KS2) {   // half of acc[] is dead by now: registers are free
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (pass == 0) acc[zq][r0 + e] = gated(acc[zq][r0 + e], acc[zq + 2][r0 + e]);
-                    zv[e] = acc[zq][r0 + e];
+                    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            sk_old[16 * qq + r] = (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                bf16x8 zh, zl;
-                split_x8<bf16x8, elem16, HALF>(zv, zh, zl);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const bf16x8 ah = lds_a2[((ks * 2 + 0) * 4 + 2 * pass + q) * 64];
-                    const bf16x8 al = lds_a2[((ks * 2 + 1) * 4 + 2 * pass + q) * 64];
-                    acc2[q] = mfma16(ah, zh, acc2[q]);
-                    acc2[q] = mfma16(al, zh, acc2[q]);
-                    acc2[q] = mfma16(ah, zl, acc2[q]);
+                // W2 fragments of the next (pass, ks, q) in issue order
+                const int nidx = (pass * 2 * B3_KS2 + idx + 1) % (4 * B3_KS2);
+                const int npass = nidx / (2 * B3_KS2), nks = (nidx >> 1) % B3_KS2, nq = nidx & 1;
+                acc2[q] = mfma16(f_ah, zh[ks], acc2[q]);
+                const bf16x8 n_ah = lds_a2[((nks * 2 + 0) * 4 + 2 * npass + nq) * 64];
+                const bf16x8 n_al = lds_a2[((nks * 2 + 1) * 4 + 2 * npass + nq) * 64];
+                if (pass == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    gate_piece(ks + 1, 3 * q + 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                acc2[q] = mfma16(f_al, zh[ks], acc2[q]);
+                if (pass == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    gate_piece(ks + 1, 3 * q + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc2[q] = mfma16(f_ah, zl[ks], acc2[q]);
+                if (pass == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    gate_piece(ks + 1, 3 * q + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                f_ah = n_ah;
+                f_al = n_al;
             }
             __builtin_amdgcn_sched_barrier(0);
             float* dst = pass == 0 ? a.xout : a.skip;
@@ -687,8 +740,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v;
-                    if (pass == 0) v = (acc2[q][r] + old[16 * q + r]) * rs;
-                    else v = FIRST ? acc2[q][r] : (old[16 * q + r] + acc2[q][r]);
+                    if (pass == 0) v = (acc2[q][r] + x_old[16 * q + r]) * rs;
+                    else v = FIRST ? acc2[q][r] : (sk_old[16 * q + r] + acc2[q][r]);
                     (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
         }
