@@ -13,6 +13,8 @@
 #include <cstring>
 #include <string>
 
+#include <type_traits>
+
 #include "pk_gemm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -193,10 +195,12 @@ __global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
 // split in registers after the read; weights pre-split on the host into MFMA fragments
 // [k-step][part][n-tile][lane] x 8 halves.  A operand = activations (rows), B operand = weights (cols).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 constexpr int HBK = PK_GEMM_HBK;           // 32
 constexpr int A_LD = HBK + 4;              // 36 floats per row
 constexpr int H_A_FLOATS = BM * A_LD;      // 4608
 constexpr int H_B_BYTES = 2 * 2 * 4 * 64 * 16;   // 16 KB: [ks 2][part 2][nt 4][lane 64] x 16 B
+constexpr int H_DEPTH = 3;                 // slabs in flight between global memory and LDS
 
 __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
     __shared__ __attribute__((aligned(16))) float As[2][H_A_FLOATS];
@@ -216,9 +220,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
     const float* arow2 = a.A2 + (long)(m0 + lrow) * a.lda2 + lhalf * 16;
     const f16x8* wsrc = reinterpret_cast<const f16x8*>(a.Wh) + (long)nblk * a.wslabs_total * (H_B_BYTES / 16) + tid;
 
-    f32x4 ra[4];
-    f16x8 rb[4];
-    auto load_slab = [&](int s) {
+    // Global -> register staging ring, H_DEPTH slabs ahead of the MFMAs (one slab of compute is ~0.4 us,
+    // far less than the load latency under load), then registers -> LDS double buffer.
+    f32x4 ra[H_DEPTH][4];
+    f16x8 rb[H_DEPTH][4];
+    auto load_slab = [&](int s, auto SET) {
+        constexpr int set = decltype(SET)::value;
         const float* p;
         int wslab;
         if (s < nmain) {
@@ -230,17 +237,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
             wslab = a.w2_slab0 + (s - nmain);
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ra[c] = *reinterpret_cast<const f32x4*>(p + 4 * c);
+        for (int c = 0; c < 4; ++c) ra[set][c] = *reinterpret_cast<const f32x4*>(p + 4 * c);
         const f16x8* q = wsrc + (long)wslab * (H_B_BYTES / 16);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) rb[c] = q[c * 256];
+        for (int c = 0; c < 4; ++c) rb[set][c] = q[c * 256];
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf, auto SET) {
+        constexpr int set = decltype(SET)::value;
         float* d = As[buf] + lrow * A_LD + lhalf * 16;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(d + 4 * c) = ra[c];
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(d + 4 * c) = ra[set][c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Bs[buf][tid + c * 256] = rb[c];
+        for (int c = 0; c < 4; ++c) Bs[buf][tid + c * 256] = rb[set][c];
     };
 
     f32x16 acc[2][2];
@@ -251,30 +259,49 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    load_slab(0);
-    store_slab(0);
+    // Operand split (2.5 VALU ops per element: v_cvt_pkrtz high part, which saturates at +-65504, exact fp32
+    // remainder, round-to-nearest low part) of k-step ks+1 runs under the 12 MFMAs of k-step ks.
+    auto read_split = [&](int buf, int ks, f16x8 (&ah)[2], f16x8 (&al)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float* ap = As[buf] + (wm * 64 + mt * 32 + i) * A_LD + ks * 16 + hi * 8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+                ah[mt][2 * p] = (_Float16)h[0];
+                ah[mt][2 * p + 1] = (_Float16)h[1];
+                al[mt][2 * p] = (_Float16)(v[2 * p] - (float)h[0]);
+                al[mt][2 * p + 1] = (_Float16)(v[2 * p + 1] - (float)h[1]);
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    static_assert(H_DEPTH == 3, "the slab loop below is unrolled for a staging ring of 3");
+    // Loads and LDS stores are unconditional (slab indices clamp to the last slab, the surplus store goes to
+    // the buffer nobody reads any more): with branches around them the compiler's s_waitcnt insertion has
+    // to assume the shortest path and degrades every wait to vmcnt(0), i.e. no prefetch at all.
+    const int last = nslabs - 1;
+    load_slab(0, S0{});
+    load_slab(1 < last ? 1 : last, S1{});
+    load_slab(2 < last ? 2 : last, S2{});
+    store_slab(0, S0{});
     __syncthreads();
-    for (int s = 0; s < nslabs; ++s) {
+    f16x8 ah[2], al[2];
+    read_split(0, 0, ah, al);
+    // one slab: request slab s+DEPTH into the set slab s came from, run slab s, move slab s+1 to LDS
+    auto step = [&](int s, auto SET, auto NEXT) {
         const int buf = s & 1;
-        if (s + 1 < nslabs) load_slab(s + 1);
+        load_slab(s + H_DEPTH < last ? s + H_DEPTH : last, SET);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah[2], al[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float* ap = As[buf] + (wm * 64 + mt * 32 + i) * A_LD + ks * 16 + hi * 8;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = __builtin_fminf(__builtin_fmaxf(v0[e], -65000.f), 65000.f);
-                    const float x1 = __builtin_fminf(__builtin_fmaxf(v1[e], -65000.f), 65000.f);
-                    ah[mt][e] = (_Float16)x0;
-                    ah[mt][4 + e] = (_Float16)x1;
-                    al[mt][e] = (_Float16)(v0[e] - (float)ah[mt][e]);
-                    al[mt][4 + e] = (_Float16)(v1[e] - (float)ah[mt][4 + e]);
-                }
-            }
+            f16x8 nh[2], nl[2];
+            if (ks == 0) read_split(buf, 1, nh, nl);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const f16x8 bh = Bs[buf][((ks * 2 + 0) * 4 + wn * 2 + nt) * 64 + lane];
@@ -286,9 +313,34 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
                 }
             }
+            if (ks == 0) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    ah[mt] = nh[mt];
+                    al[mt] = nl[mt];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < nslabs) store_slab(buf ^ 1);
+        store_slab(buf ^ 1, NEXT);
         __syncthreads();
+        read_split(buf ^ 1, 0, ah, al);
+    };
+    int s = 0;
+    for (; s + H_DEPTH <= nslabs; s += H_DEPTH) {
+        step(s, S0{}, S1{});
+        step(s + 1, S1{}, S2{});
+        step(s + 2, S2{}, S0{});
+    }
+    if (s < nslabs) {
+        step(s, S0{}, S1{});
+        if (s + 1 < nslabs) step(s + 1, S1{}, S2{});
     }
     gemm_epilogue(a, acc, m0, nblk, wm, wn, i, hi);
 }
