@@ -133,8 +133,8 @@ int pk_pwg_finalize(pk_pwg* h);
  *   mel    (sum(frames), aux_channels) float32, row-major, packed by utterance
  *          (with PK_PWG_C_HAS_CONTEXT: frames[b] + 2*ctx rows per utterance)
  *   frames (B) host int32, frames per utterance (>= 1)
- *   noise  (sum(frames)*hop) float32 packed; the x = randn(...) of :515-516,
- *          passed in so that results are reproducible
+ *   noise  (sum(frames)*hop) float32 packed; the x = randn(...) of :515-516, passed in so that
+ *          results are reproducible; NULL = drawn internally (pk_randn stream of pk_pwg_set_seed)
  *   wav    (sum(frames)*hop) float32 packed output
  * flags: PK_HOST_IO if mel/noise/wav are host pointers. */
 int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, int32_t B,
@@ -226,7 +226,8 @@ int pk_wf_cond_length(pk_wf* h, int32_t t_mel, int32_t* cond_len, int32_t* wav_l
  *   mel    (sum(frames), n_mels) float32 packed by utterance, time-major (the reference's
  *          (B, C_mel, T_mel) transposed)
  *   frames (B) host int32, >= 2
- *   z      packed latent, cond_len(frames[b]) floats per utterance (the randn of :801)
+ *   z      packed latent, cond_len(frames[b]) floats per utterance (the randn of :801);
+ *          NULL = drawn internally (pk_randn stream of pk_wf_set_seed)
  *   wav    packed output, wav_len(frames[b]) floats per utterance */
 int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, int32_t B, const float* z,
                 float* wav, int32_t flags);
@@ -257,6 +258,20 @@ int pk_mel_num_frames(pk_mel* h, int32_t n_samples, int32_t* frames);
 int pk_mel_run(pk_mel* h, const float* wav, const int32_t* lens, int32_t B, float* out,
                int32_t what, int32_t flags);
 void pk_mel_destroy(pk_mel* h);
+
+/* ------------------------------------------------------------ normal noise */
+/* Standard-normal floats on the device: out[i] for i in [0, n), a pure function of (seed, offset + i).
+ * Replaces the paddle.randn calls of PWGGenerator.inference (parallel_wavegan.py:515-516) and
+ * ConditionalWaveFlow.infer (waveflow.py:801) for callers that hold no device RNG of their own.
+ * Philox4x32-10 (Salmon et al., SC'11; key = seed, counter = (offset + i) / 4) -> 4 x uint32 ->
+ * Box-Muller on pairs: u1 = (a + 1) * 2^-32 in (0, 1], u2 = b * 2^-32,
+ * r = sqrt(-2 ln u1), (z0, z1) = r * (cos, sin)(2 pi u2).  offset must be a multiple of 4.
+ * flags: PK_HOST_IO if out is a host pointer (then synchronous). */
+int pk_randn(pk_ctx* ctx, float* out, int64_t n, uint64_t seed, uint64_t offset, int32_t flags);
+/* Seed of the internal generator used when pk_pwg_infer / pk_wf_infer get noise == NULL (default 0);
+ * every such call consumes a fresh, non-overlapping range of the stream. */
+int pk_pwg_set_seed(pk_pwg* h, uint64_t seed);
+int pk_wf_set_seed(pk_wf* h, uint64_t seed);
 
 /* ------------------------------------------ generic primitives (parakeet/modules) */
 /* sinusoid_position_encoding (positional_encoding.py:20-39) -> out (num_positions, feature_size), device. */

@@ -82,6 +82,9 @@ def _declare(lib):
         "pk_pwg_create": (C.c_int, [vp, C.POINTER(PwgCfg), C.POINTER(vp)]),
         "pk_pwg_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
         "pk_pwg_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
+        "pk_randn": (C.c_int, [vp, f32p, i64, C.c_uint64, C.c_uint64, i32]),
+        "pk_pwg_set_seed": (C.c_int, [vp, C.c_uint64]),
+        "pk_wf_set_seed": (C.c_int, [vp, C.c_uint64]),
         "pk_pwg_set_math": (C.c_int, [vp, i32]),
         "pk_pwg_finalize": (C.c_int, [vp]),
         "pk_pwg_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),

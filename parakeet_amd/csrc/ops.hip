@@ -9,6 +9,50 @@
 
 namespace {
 
+// Philox4x32-10 block: counter (c0..c3), key (k0, k1) -> 4 x uint32
+__device__ __forceinline__ void philox4x32_10(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0,
+                                              unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+        const unsigned lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// One thread per Philox block = 4 normals (see pk_synth.h for the exact recipe).
+__global__ void k_randn(float* __restrict__ out, long n, unsigned long long seed, unsigned long long block0) {
+    const long blk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk * 4 >= n) return;
+    const unsigned long long ctr = block0 + (unsigned long long)blk;
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+    philox4x32_10(c0, c1, c2, c3, (unsigned)seed, (unsigned)(seed >> 32));
+    const float two_m32 = 2.3283064365386963e-10f;
+    float z[4];
+    {
+        const float u1 = ((float)c0 + 1.0f) * two_m32, u2 = (float)c1 * two_m32;
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[0] = r * cs;
+        z[1] = r * sn;
+    }
+    {
+        const float u1 = ((float)c2 + 1.0f) * two_m32, u2 = (float)c3 * two_m32;
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2] = r * cs;
+        z[3] = r * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (blk * 4 + e < n) out[blk * 4 + e] = z[e];
+}
+
 // enc[pos][2i] = sin(p), enc[pos][2i+1] = cos(p), p = (start + pos) * omega / 10000^(2i / size)
 __global__ void k_sinusoid(float* __restrict__ out, int num_positions, int size, float omega, int start_pos) {
     const int pos = blockIdx.x;
@@ -78,6 +122,32 @@ __global__ void k_nlc_to_timeline(const float* __restrict__ x, int T, int C, int
 }
 
 }  // namespace
+
+int pk_randn_device(pk_ctx* ctx, float* d_out, long n, unsigned long long seed, unsigned long long offset) {
+    if (offset & 3) PK_FAIL(PK_EINVAL, "pk_randn: offset must be a multiple of 4");
+    if (n <= 0) return PK_OK;
+    const long blocks = (n + 3) / 4;
+    PK_LAUNCH(ctx, "randn", k_randn, dim3((unsigned)pk_div_up(blocks, 256)), dim3(256), 0, d_out, n, seed, offset / 4);
+    return PK_OK;
+}
+
+extern "C" int pk_randn(pk_ctx* ctx, float* out, int64_t n, uint64_t seed, uint64_t offset, int32_t flags) {
+    if (!ctx || (!out && n > 0)) PK_FAIL(PK_EINVAL, "pk_randn: NULL argument");
+    if (n < 0) PK_FAIL(PK_EINVAL, "pk_randn: n must be >= 0");
+    PK_HIP(hipSetDevice(ctx->device));
+    if (!(flags & PK_HOST_IO)) return pk_randn_device(ctx, out, n, seed, offset);
+    float* d = nullptr;
+    if (n == 0) return PK_OK;
+    PK_HIP(hipMalloc(&d, (size_t)n * 4));
+    int rc = pk_randn_device(ctx, d, n, seed, offset);
+    if (rc == PK_OK) {
+        hipError_t e = hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(d); PK_FAIL(PK_EHIP, "pk_randn: %s", hipGetErrorString(e)); }
+    }
+    (void)hipFree(d);
+    return rc;
+}
 
 extern "C" int pk_op_sinusoid_position_encoding(pk_ctx* ctx, int32_t num_positions, int32_t feature_size,
                                                 float omega, int32_t start_pos, float* out) {

@@ -119,4 +119,7 @@ int pk_get_vector(const pk_param_map& m, const std::string& name, int64_t n, std
 
 int pk_upload(pk_ctx* ctx, pk_dbuf& buf, const void* host, size_t bytes);
 
+// ops.hip: standard-normal stream (Philox4x32-10 + Box-Muller) into device memory, on ctx->stream
+int pk_randn_device(pk_ctx* ctx, float* d_out, long n, unsigned long long seed, unsigned long long offset);
+
 static inline int pk_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -824,6 +824,7 @@ struct pk_pwg {
     int last_ldp = 0;
     size_t last_o_cls = 0;
     int dbg = 0;
+    unsigned long long seed = 0, rng_offset = 0;   // internal noise stream (noise == NULL)
 };
 
 extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
@@ -898,6 +899,13 @@ extern "C" int pk_pwg_set_math(pk_pwg* h, int32_t mode) {
     if (mode != PK_PWG_MATH_F32 && mode != PK_PWG_MATH_BF16X3 && mode != PK_PWG_MATH_F16X3)
         PK_FAIL(PK_EINVAL, "pk_pwg_set_math: unknown mode %d", mode);
     h->math = mode;
+    return PK_OK;
+}
+
+extern "C" int pk_pwg_set_seed(pk_pwg* h, uint64_t seed) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_set_seed: handle is NULL");
+    h->seed = seed;
+    h->rng_offset = 0;
     return PK_OK;
 }
 
@@ -1148,7 +1156,7 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
 
 extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, int32_t B,
                             const float* noise, float* wav, int32_t flags) {
-    if (!h || !mel || !frames || !noise || !wav) PK_FAIL(PK_EINVAL, "pk_pwg_infer: NULL argument");
+    if (!h || !mel || !frames || !wav) PK_FAIL(PK_EINVAL, "pk_pwg_infer: NULL argument");
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_pwg_infer: call pk_pwg_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_pwg_infer: batch size must be positive");
     pk_ctx* ctx = h->ctx;
@@ -1208,13 +1216,21 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     if (flags & PK_HOST_IO) {
         const size_t mel_rows = (size_t)sumL + ((flags & PK_PWG_C_HAS_CONTEXT) ? (size_t)2 * c.aux_context_window * B : 0);
         PK_TRY(h->ws_mel.reserve(mel_rows * AUX * 4));
-        PK_TRY(h->ws_noise.reserve((size_t)sumS * 4));
         PK_TRY(h->ws_wav.reserve((size_t)sumS * 4));
         PK_HIP(hipMemcpyAsync(h->ws_mel.p, mel, mel_rows * AUX * 4, hipMemcpyHostToDevice, ctx->stream));
-        PK_HIP(hipMemcpyAsync(h->ws_noise.p, noise, (size_t)sumS * 4, hipMemcpyHostToDevice, ctx->stream));
         d_mel = h->ws_mel.as<float>();
-        d_noise = h->ws_noise.as<float>();
         d_wav = h->ws_wav.as<float>();
+        if (noise) {
+            PK_TRY(h->ws_noise.reserve((size_t)sumS * 4));
+            PK_HIP(hipMemcpyAsync(h->ws_noise.p, noise, (size_t)sumS * 4, hipMemcpyHostToDevice, ctx->stream));
+            d_noise = h->ws_noise.as<float>();
+        }
+    }
+    if (!noise) {   // x = randn(...) (:515-516) drawn by the engine: next range of the handle's stream
+        PK_TRY(h->ws_noise.reserve((size_t)sumS * 4));
+        PK_TRY(pk_randn_device(ctx, h->ws_noise.as<float>(), sumS, h->seed, h->rng_offset));
+        h->rng_offset += ((unsigned long long)sumS + 3) / 4 * 4;
+        d_noise = h->ws_noise.as<float>();
     }
     const int rows_alloc = ((sumL + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM;
     const int ldp = c.layers * G;

@@ -153,6 +153,7 @@ struct pk_wf {
     std::vector<uint16_t> arena16_h;
     pk_dbuf arena16;
     int math = PK_GEMM_MATH_F16X3;
+    unsigned long long seed = 0, rng_offset = 0;   // internal latent stream (z == NULL)
     int mp = 96;              // mel channels padded to a multiple of 32 (GEMM K block of the condition)
     std::vector<WfFlowW> flows;
     std::vector<size_t> up_w;
@@ -212,6 +213,13 @@ size_t put16(std::vector<uint16_t>& v, const std::vector<uint16_t>& x) {
     return o;
 }
 }  // namespace
+
+extern "C" int pk_wf_set_seed(pk_wf* h, uint64_t seed) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_wf_set_seed: handle is NULL");
+    h->seed = seed;
+    h->rng_offset = 0;
+    return PK_OK;
+}
 
 extern "C" int pk_wf_set_math(pk_wf* h, int32_t mode) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_wf_set_math: handle is NULL");
@@ -321,7 +329,7 @@ extern "C" int pk_wf_cond_length(pk_wf* h, int32_t t_mel, int32_t* cond_len, int
 
 extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, int32_t B, const float* z,
                            float* wav, int32_t flags) {
-    if (!h || !mel || !frames || !z || !wav) PK_FAIL(PK_EINVAL, "pk_wf_infer: NULL argument");
+    if (!h || !mel || !frames || !wav) PK_FAIL(PK_EINVAL, "pk_wf_infer: NULL argument");
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_wf_infer: call pk_wf_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_wf_infer: batch size must be positive");
     pk_ctx* ctx = h->ctx;
@@ -398,13 +406,21 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     float* d_wav = wav;
     if (flags & PK_HOST_IO) {
         PK_TRY(h->ws_mel.reserve((size_t)cuT[B] * M * 4));
-        PK_TRY(h->ws_z.reserve((size_t)sumZ * 4));
         PK_TRY(h->ws_wav.reserve((size_t)sumO * 4));
         PK_HIP(hipMemcpyAsync(h->ws_mel.p, mel, (size_t)cuT[B] * M * 4, hipMemcpyHostToDevice, ctx->stream));
-        PK_HIP(hipMemcpyAsync(h->ws_z.p, z, (size_t)sumZ * 4, hipMemcpyHostToDevice, ctx->stream));
         d_mel = h->ws_mel.as<float>();
-        d_z = h->ws_z.as<float>();
         d_wav = h->ws_wav.as<float>();
+        if (z) {
+            PK_TRY(h->ws_z.reserve((size_t)sumZ * 4));
+            PK_HIP(hipMemcpyAsync(h->ws_z.p, z, (size_t)sumZ * 4, hipMemcpyHostToDevice, ctx->stream));
+            d_z = h->ws_z.as<float>();
+        }
+    }
+    if (!z) {   // z = randn(...) (:801) drawn by the engine: next range of the handle's stream
+        PK_TRY(h->ws_z.reserve((size_t)sumZ * 4));
+        PK_TRY(pk_randn_device(ctx, h->ws_z.as<float>(), sumZ, h->seed, h->rng_offset));
+        h->rng_offset += ((unsigned long long)sumZ + 3) / 4 * 4;
+        d_z = h->ws_z.as<float>();
     }
     // ---- workspaces
     const long cond_row = pstride * MP;         // floats per folded cond row (channels padded to MP, pad = 0)

@@ -81,9 +81,15 @@ class PWGGenerator:
         return None
 
     def set_math(self, mode):
-        """'f32' (exact fp32 MFMA, default) or 'bf16x3' (3-term split-bf16 MFMA, fp32 accumulate)."""
+        """'f16x3' (default: 3-term split-fp16 MFMA, fp32-equivalent error), 'f32' (exact fp32 MFMA) or
+        'bf16x3' (split-bf16)."""
         m = {"f32": _capi.PK_PWG_MATH_F32, "bf16x3": _capi.PK_PWG_MATH_BF16X3, "f16x3": _capi.PK_PWG_MATH_F16X3}[mode]
         _capi.check(self._ctx.lib.pk_pwg_set_math(self._h, m))
+
+    def set_seed(self, seed):
+        """Seed of the engine's own noise stream (Philox4x32-10 + Box-Muller, ``pk_randn``), used when
+        neither ``noise`` nor a torch ``generator`` is given -- the ``paddle.randn`` of :515-516."""
+        _capi.check(self._ctx.lib.pk_pwg_set_seed(self._h, int(seed) & (2 ** 64 - 1)))
 
     def set_normalizer(self, normalizer):
         if normalizer is None:
@@ -108,13 +114,15 @@ class PWGGenerator:
         mel = torch.cat([ctx.to_device(m).reshape(-1, self.aux_channels) for m in mels], dim=0)
         total = int(frames.sum()) * hop
         if noises is None:
-            noise = torch.randn(total, device=ctx.device, dtype=torch.float32, generator=generator)
+            # no noise given: the engine draws it (NULL) unless a torch generator is supplied
+            noise = None if generator is None else torch.randn(total, device=ctx.device, dtype=torch.float32,
+                                                               generator=generator)
         else:
             noise = torch.cat([ctx.to_device(n).reshape(-1) for n in noises], dim=0)
-        assert noise.numel() == total, "noise length must be frames * hop"
+        assert noise is None or noise.numel() == total, "noise length must be frames * hop"
         wav = ctx.empty((total,))
         _capi.check(ctx.lib.pk_pwg_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)),
-                                         len(mels), dptr(noise), dptr(wav), 0))
+                                         len(mels), None if noise is None else dptr(noise), dptr(wav), 0))
         outs, o = [], 0
         for f in frames:
             n = int(f) * hop
@@ -133,13 +141,14 @@ class PWGGenerator:
         mel = ctx.to_device(mel).reshape(-1, self.aux_channels)
         assert mel.shape[0] == int(frames.sum()), "mel rows must equal sum(frames)"
         if noise is None:
-            noise = torch.randn(total, device=ctx.device, dtype=torch.float32, generator=generator)
+            noise = None if generator is None else torch.randn(total, device=ctx.device, dtype=torch.float32,
+                                                               generator=generator)
         else:
             noise = ctx.to_device(noise).reshape(-1)
-        assert noise.numel() == total, "noise length must be sum(frames) * hop"
+        assert noise is None or noise.numel() == total, "noise length must be sum(frames) * hop"
         wav = ctx.empty((total,))
         _capi.check(ctx.lib.pk_pwg_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)),
-                                         len(frames), dptr(noise), dptr(wav), 0))
+                                         len(frames), None if noise is None else dptr(noise), dptr(wav), 0))
         return wav
 
     def forward(self, x, c):

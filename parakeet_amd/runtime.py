@@ -109,3 +109,12 @@ def set_params(setter, handle, state):
 
 def dptr(t):
     return C.c_void_p(t.data_ptr())
+
+
+def randn(n, seed=0, offset=0, device=None):
+    """n standard normals from the engine's counter-based generator (``pk_randn``: Philox4x32-10 +
+    Box-Muller), a pure function of (seed, offset + i); returns a device tensor."""
+    ctx = Context.get(device)
+    out = ctx.empty((int(n),))
+    _capi.check(ctx.lib.pk_randn(ctx.handle, dptr(out), int(n), int(seed) & (2 ** 64 - 1), int(offset), 0))
+    return out

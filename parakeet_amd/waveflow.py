@@ -53,6 +53,11 @@ class ConditionalWaveFlow:
         """'f16x3' (default: split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
         _capi.check(self._ctx.lib.pk_wf_set_math(self._h, {"f32": 0, "f16x3": 1}[mode]))
 
+    def set_seed(self, seed):
+        """Seed of the engine's own latent stream (``pk_randn``), used when neither ``z`` nor a torch
+        ``generator`` is given -- the ``paddle.randn`` of waveflow.py:801."""
+        _capi.check(self._ctx.lib.pk_wf_set_seed(self._h, int(seed) & (2 ** 64 - 1)))
+
     def lengths(self, t_mel):
         a, b = C.c_int32(), C.c_int32()
         _capi.check(self._ctx.lib.pk_wf_cond_length(self._h, int(t_mel), C.byref(a), C.byref(b)))
@@ -69,13 +74,13 @@ class ConditionalWaveFlow:
         lens = [self.lengths(int(f)) for f in frames]
         total_z = sum(a for a, _ in lens)
         if zs is None:
-            z = torch.randn(total_z, device=ctx.device, generator=generator)
+            z = None if generator is None else torch.randn(total_z, device=ctx.device, generator=generator)
         else:
             z = torch.cat([ctx.to_device(v).reshape(-1) for v in zs])
-        assert z.numel() == total_z, "z must have cond_len samples per utterance"
+        assert z is None or z.numel() == total_z, "z must have cond_len samples per utterance"
         wav = ctx.empty((sum(b for _, b in lens),))
         _capi.check(ctx.lib.pk_wf_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)), len(mels),
-                                        dptr(z), dptr(wav), 0))
+                                        None if z is None else dptr(z), dptr(wav), 0))
         outs, o = [], 0
         for _, n in lens:
             outs.append(wrap(wav[o:o + n]))
