@@ -1,0 +1,189 @@
+"""Checkpoint ingestion without Paddle.
+
+The reference stores checkpoints with ``paddle.save``:
+
+* ``snapshot_iter_*.pdz`` -- ``UpdaterBase.save`` (parakeet/training/updater.py:77-80) pickles the nested
+  archive built by ``StandardUpdater.state_dict`` (training/updaters/standard_updater.py:183-190):
+  ``{"epoch", "iteration", "<name>_params": layer.state_dict(), "<name>_optimizer": ...}``;
+  the recipes read ``["main_params"]`` (FastSpeech2, synthesize_e2e.py:56-57) and
+  ``["generator_params"]`` (Parallel WaveGAN, :60-61);
+* ``step-N.pdparams`` -- ``utils/checkpoint.py:61-108`` saves a bare ``layer.state_dict()`` (WaveFlow,
+  ``ConditionalWaveFlow.from_pretrained`` waveflow.py:827-852);
+* ``*_stats.npy`` -- ``np.stack([mean_, scale_])`` float32 (2, n_mels) (utils/compute_statistics.py:101-107);
+* ``phone_id_map.txt`` -- one ``<phone> <id>`` pair per line (synthesize_e2e.py:45-50).
+
+``paddle.save`` is a pickle stream in which every tensor has been replaced by plain numpy data: either the
+``ndarray`` itself (Paddle 2.0 state dicts, which also carry a ``"StructuredToParameterName@@"`` name table)
+or the tuple ``(tensor_name, ndarray)`` produced by its reducer (Paddle >= 2.1).  [paddle-format,
+unverified against a real file: Paddle is not installable here -- the layouts are written down from the
+Paddle 2.0/2.1 sources and the tests build archives in both forms.]  Because a pickle can execute code,
+the reader below is a *restricted* unpickler: it reconstructs numpy arrays, numpy scalars/dtypes and
+built-in containers, and refuses every other global.
+"""
+import io
+import os
+import pickle
+from collections import OrderedDict
+
+import numpy as np
+
+_NAME_TABLE_KEYS = ("StructuredToParameterName@@", "UnpackBigParamInfor@@")
+
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"): OrderedDict,
+    ("builtins", "dict"): dict, ("builtins", "list"): list, ("builtins", "tuple"): tuple,
+    ("builtins", "set"): set, ("builtins", "frozenset"): frozenset, ("builtins", "int"): int,
+    ("builtins", "float"): float, ("builtins", "complex"): complex, ("builtins", "str"): str,
+    ("builtins", "bytes"): bytes, ("builtins", "bytearray"): bytearray, ("builtins", "bool"): bool,
+    ("__builtin__", "dict"): dict, ("__builtin__", "list"): list, ("__builtin__", "tuple"): tuple,
+    ("__builtin__", "int"): int, ("__builtin__", "long"): int, ("__builtin__", "float"): float,
+    ("__builtin__", "str"): str, ("__builtin__", "bool"): bool, ("__builtin__", "set"): set,
+    ("_codecs", "encode"): __import__("_codecs").encode,   # protocol-2 pickles of numpy byte strings
+    ("numpy", "ndarray"): np.ndarray, ("numpy", "dtype"): np.dtype,
+}
+
+
+def _numpy_global(module, name):
+    # numpy moved numpy.core -> numpy._core in 2.x; archives written by either spell the same objects
+    if module in ("numpy.core.multiarray", "numpy._core.multiarray") and name in ("_reconstruct", "scalar"):
+        import numpy._core.multiarray as ma   # numpy 2.x (this image)
+        return getattr(ma, name)
+    if module in ("numpy.core.numeric", "numpy._core.numeric") and name == "_frombuffer":
+        import numpy._core.numeric as nn
+        return getattr(nn, name)
+    return None
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        obj = _ALLOWED_GLOBALS.get((module, name))
+        if obj is None:
+            obj = _numpy_global(module, name)
+        if obj is None:
+            raise pickle.UnpicklingError(
+                f"checkpoint refers to {module}.{name}, which a tensor archive has no business containing; "
+                "refusing to load it")
+        return obj
+
+
+def _plain(obj):
+    """Tensor leaves -> ndarray: accepts ndarray, (name, ndarray) pairs; drops Paddle's name tables."""
+    if isinstance(obj, np.ndarray):
+        return obj
+    if isinstance(obj, (tuple, list)) and len(obj) == 2 and isinstance(obj[0], str) and isinstance(obj[1], np.ndarray):
+        return obj[1]
+    if isinstance(obj, dict):
+        return OrderedDict((k, _plain(v)) for k, v in obj.items() if k not in _NAME_TABLE_KEYS)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(v) for v in obj)
+    return obj
+
+
+def load_archive(path_or_file):
+    """``paddle.load`` for tensor archives: nested dicts with numpy arrays at the leaves."""
+    if hasattr(path_or_file, "read"):
+        return _plain(_RestrictedUnpickler(path_or_file).load())
+    with open(path_or_file, "rb") as f:
+        return _plain(_RestrictedUnpickler(io.BufferedReader(f)).load())
+
+
+def load_params(path, key=None):
+    """State dict ``{reference key: float32 ndarray}`` from a ``.pdz`` (give ``key``, e.g. "main_params",
+    "generator_params") or a ``.pdparams`` file (``key=None``).  weight_g / weight_v pairs are kept:
+    the engine folds them at finalize (``remove_weight_norm`` semantics)."""
+    arch = load_archive(path)
+    if key is not None:
+        if not isinstance(arch, dict) or key not in arch:
+            have = sorted(arch) if isinstance(arch, dict) else type(arch).__name__
+            raise KeyError(f"{path}: no entry {key!r} in the archive (has {have})")
+        arch = arch[key]
+    if not isinstance(arch, dict):
+        raise ValueError(f"{path}: expected a state dict, found {type(arch).__name__}")
+    state = OrderedDict()
+    for name, value in arch.items():
+        if not isinstance(value, np.ndarray):
+            raise ValueError(f"{path}: entry {name!r} is {type(value).__name__}, not a tensor")
+        if value.dtype.kind == "f":
+            value = np.ascontiguousarray(value, dtype=np.float32)
+        state[name] = value
+    return state
+
+
+def load_stats(path):
+    """``(mu, sigma)`` float32 vectors from a ``*_stats.npy`` file of shape (2, n_bins)."""
+    stat = np.load(path, allow_pickle=False)
+    if stat.ndim != 2 or stat.shape[0] != 2:
+        raise ValueError(f"{path}: expected an array of shape (2, n_bins), got {stat.shape}")
+    return np.ascontiguousarray(stat[0], np.float32), np.ascontiguousarray(stat[1], np.float32)
+
+
+def load_phone_id_map(path):
+    """``{phone: id}`` and the vocabulary size (= number of lines, synthesize_e2e.py:45-50)."""
+    table = OrderedDict()
+    with open(path, "rt", encoding="utf-8") as f:
+        for line in f:
+            parts = line.strip().split()
+            if not parts:
+                continue
+            if len(parts) != 2:
+                raise ValueError(f"{path}: malformed line {line!r}")
+            table[parts[0]] = int(parts[1])
+    return table, len(table)
+
+
+def _config(cfg):
+    """A recipe's ``default.yaml`` (path) or an already parsed mapping."""
+    if isinstance(cfg, (str, os.PathLike)):
+        import yaml
+        with open(cfg, "rt") as f:
+            return yaml.safe_load(f)
+    return cfg
+
+
+def load_fastspeech2(config, checkpoint, stats, phones_dict=None, idim=None):
+    """The FastSpeech2 half of examples/fastspeech2/ljspeech/synthesize_e2e.py:45-83: returns
+    ``(FastSpeech2Inference, phone_id_map)``.  ``config``: the recipe's yaml (path or dict with ``n_mels``
+    and ``model``); ``idim`` overrides the vocabulary size read from ``phones_dict``."""
+    from .fastspeech2 import FastSpeech2, FastSpeech2Inference
+    from .normalizer import ZScore
+    cfg = _config(config)
+    phone_id_map = None
+    if phones_dict is not None:
+        phone_id_map, vocab = load_phone_id_map(phones_dict)
+        idim = vocab if idim is None else idim
+    if idim is None:
+        raise ValueError("load_fastspeech2: give phones_dict or idim")
+    model = FastSpeech2(idim=idim, odim=cfg["n_mels"], **cfg["model"])
+    model.set_state_dict(load_params(checkpoint, "main_params"))
+    model.eval()
+    mu, sigma = load_stats(stats)
+    return FastSpeech2Inference(ZScore(mu, sigma), model), phone_id_map
+
+
+def load_pwg(config, checkpoint, stats):
+    """The vocoder half of synthesize_e2e.py:59-83: returns ``PWGInference``."""
+    from .normalizer import ZScore
+    from .parallel_wavegan import PWGGenerator, PWGInference
+    cfg = _config(config)
+    vocoder = PWGGenerator(**cfg["generator_params"])
+    vocoder.set_state_dict(load_params(checkpoint, "generator_params"))
+    vocoder.remove_weight_norm()
+    vocoder.eval()
+    mu, sigma = load_stats(stats)
+    return PWGInference(ZScore(mu, sigma), vocoder)
+
+
+def load_waveflow(config, checkpoint_path):
+    """``ConditionalWaveFlow.from_pretrained`` (waveflow.py:827-852): ``checkpoint_path`` without the
+    ``.pdparams`` suffix, ``config`` with a ``model`` section (examples/waveflow/config.py:32-41)."""
+    from .waveflow import ConditionalWaveFlow
+    cfg = _config(config)
+    m = cfg["model"]
+    model = ConditionalWaveFlow(upsample_factors=m["upsample_factors"], n_flows=m["n_flows"],
+                                n_layers=m["n_layers"], n_group=m["n_group"], channels=m["channels"],
+                                n_mels=cfg["data"]["n_mels"] if "data" in cfg else m.get("n_mels", 80),
+                                kernel_size=m["kernel_size"])
+    path = str(checkpoint_path)
+    model.set_state_dict(load_params(path if path.endswith(".pdparams") else path + ".pdparams"))
+    model.eval()
+    return model

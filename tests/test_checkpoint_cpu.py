@@ -1,0 +1,89 @@
+"""parakeet_amd.checkpoint: Paddle-free readers for .pdz / .pdparams / stats / phone maps."""
+import io
+import os
+import pickle
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+from parakeet_amd import checkpoint as ck
+
+
+def _state(rng):
+    return OrderedDict([("encoder.embed.0.weight", rng.normal(size=(7, 4)).astype(np.float32)),
+                        ("conv.weight_g", rng.normal(size=(3,)).astype(np.float32)),
+                        ("conv.weight_v", rng.normal(size=(3, 2, 5)).astype(np.float32)),
+                        ("bn._variance", rng.uniform(0.5, 1.5, size=(3,)).astype(np.float64))])
+
+
+@pytest.mark.parametrize("protocol", [2, 4])
+def test_pdz_with_reduced_tensors(tmp_path, protocol):
+    # Paddle >= 2.1: every tensor pickled as the tuple (tensor_name, ndarray); updater archive layout
+    rng = np.random.default_rng(0)
+    st = _state(rng)
+    archive = {"epoch": 3, "iteration": 1234,
+               "main_params": OrderedDict((k, ("generated_tensor_%d" % i, v)) for i, (k, v) in enumerate(st.items())),
+               "main_optimizer": {"LR_Scheduler": {"last_epoch": 3, "last_lr": 1e-3}, "moment1_0": ("m", st["conv.weight_g"])}}
+    p = tmp_path / "snapshot_iter_1234.pdz"
+    with open(p, "wb") as f:
+        pickle.dump(archive, f, protocol=protocol)
+    arch = ck.load_archive(p)
+    assert arch["iteration"] == 1234 and arch["main_optimizer"]["LR_Scheduler"]["last_epoch"] == 3
+    got = ck.load_params(p, "main_params")
+    assert list(got) == list(st)
+    for k in st:
+        assert got[k].dtype == np.float32 and got[k].flags["C_CONTIGUOUS"]
+        np.testing.assert_array_equal(got[k], st[k].astype(np.float32))
+    with pytest.raises(KeyError):
+        ck.load_params(p, "generator_params")
+
+
+def test_pdparams_with_name_table(tmp_path):
+    # Paddle 2.0 state dict: bare ndarrays + "StructuredToParameterName@@"
+    rng = np.random.default_rng(1)
+    st = _state(rng)
+    saved = dict(st)
+    saved["StructuredToParameterName@@"] = {k: "param_%d" % i for i, k in enumerate(st)}
+    p = tmp_path / "step-10.pdparams"
+    with open(p, "wb") as f:
+        pickle.dump(saved, f, protocol=2)
+    got = ck.load_params(p)
+    assert set(got) == set(st)
+    np.testing.assert_array_equal(got["conv.weight_v"], st["conv.weight_v"])
+
+
+def test_refuses_code_execution(tmp_path):
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+
+    p = tmp_path / "evil.pdz"
+    with open(p, "wb") as f:
+        pickle.dump({"main_params": {"w": Evil()}}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        ck.load_archive(p)
+    with pytest.raises(pickle.UnpicklingError):
+        ck.load_archive(io.BytesIO(pickle.dumps(np.random.default_rng)))
+
+
+def test_stats_and_phone_map(tmp_path):
+    mu, sd = np.arange(80, dtype=np.float32), np.linspace(0.5, 2, 80).astype(np.float32)
+    np.save(tmp_path / "speech_stats.npy", np.stack([mu, sd]))
+    m, s = ck.load_stats(tmp_path / "speech_stats.npy")
+    np.testing.assert_array_equal(m, mu)
+    np.testing.assert_array_equal(s, sd)
+    np.save(tmp_path / "bad.npy", np.zeros((3, 80), np.float32))
+    with pytest.raises(ValueError):
+        ck.load_stats(tmp_path / "bad.npy")
+    (tmp_path / "phone_id_map.txt").write_text("<pad> 0\n<unk> 1\nAA0 2\nsp 3\n<eos> 4\n")
+    table, vocab = ck.load_phone_id_map(tmp_path / "phone_id_map.txt")
+    assert vocab == 5 and table["sp"] == 3 and list(table)[0] == "<pad>"
+
+
+def test_recipe_configs_parse():
+    here = os.path.dirname(__file__)
+    cfg = ck._config(os.path.join(here, "fixtures", "fastspeech2_ljspeech.yaml"))
+    assert cfg["n_mels"] == 80 and cfg["model"]["adim"] == 384 and cfg["model"]["pitch_embed_kernel_size"] == 1
+    cfg = ck._config(os.path.join(here, "fixtures", "pwg_ljspeech.yaml"))
+    assert cfg["generator_params"]["upsample_scales"] == [4, 4, 4, 4]
