@@ -164,7 +164,12 @@ typedef struct {
     int32_t use_scaled_pos_enc;
     int32_t encoder_normalize_before, decoder_normalize_before;  /* 1 only */
     int32_t reduction_factor;                                    /* 1 only */
-    int32_t has_spk_embed, has_tone_embed;                       /* 0 only */
+    /* multi-speaker recipes (aishell3 / vctk: spk_embed_dim 256, "concat"): spk_embedding_table
+     * [num_speakers, spk_embed_dim] (padding_idx 0) + spk_projection (fastspeech2.py:147-151,190-194). */
+    int32_t num_speakers;                /* 0 with spk_embed_dim: only external embeddings (spembs) */
+    int32_t spk_embed_dim;               /* 0 = single speaker */
+    int32_t spk_embed_integration_type;  /* 0 = "add", 1 = "concat" */
+    int32_t tone_embed_dim;              /* 0 only (no FastSpeech2 recipe uses tones) */
 } pk_fs2_cfg;
 
 int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out);
@@ -181,6 +186,12 @@ int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* sigma, int32_
  * duration arithmetic and every stored tensor are fp32 in both modes.  Env PK_FS2_MATH=f32 overrides. */
 int pk_fs2_set_math(pk_fs2* h, int32_t mode);
 int pk_fs2_finalize(pk_fs2* h);
+/* Speaker conditioning of the NEXT pk_fs2_encode call (_forward :396-402, _integrate_with_spk_embed
+ * :560-586): spk_id HOST int64 (B) looked up in spk_embedding_table, or spembs HOST float32
+ * (B, spk_embed_dim) external embeddings (win over spk_id, as in the reference); both NULL (or never
+ * called) = no integration, as when the reference gets neither.  B must equal the batch of that call;
+ * the setting is consumed by it. */
+int pk_fs2_set_speakers(pk_fs2* h, const int64_t* spk_id, const float* spembs, int32_t B);
 /* Phase 1 of inference (_forward :390-432): encoder, pitch/energy/duration predictors, prefix
  * sums.  ids: HOST int64, packed by utterance (sum(tok_lens)); tok_lens: HOST (B).
  * alpha = LengthRegulator speed control.  out_frames (HOST, B) receives the number of mel

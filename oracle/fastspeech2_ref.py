@@ -39,7 +39,8 @@ DEFAULT_CFG = dict(
     pitch_predictor_layers=5, pitch_predictor_chans=256, pitch_predictor_kernel_size=5,
     energy_predictor_layers=2, energy_predictor_chans=256, energy_predictor_kernel_size=3,
     pitch_embed_kernel_size=1, energy_embed_kernel_size=1,
-    postnet_layers=5, postnet_chans=256, postnet_filts=5)
+    postnet_layers=5, postnet_chans=256, postnet_filts=5,
+    spk_embed_dim=None, spk_embed_integration_type="add")
 
 
 def scaled_posenc(W, x):
@@ -170,9 +171,23 @@ def postnet(W, xs, n_layers):
     return xs
 
 
-def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts=False):
+def integrate_spk_embed(W, hs, spembs, integration_type):
+    """FastSpeech2._integrate_with_spk_embed fastspeech2.py:560-586.  hs (B,T,adim), spembs (B,D).
+    F.normalize: x / max(||x||_2, 1e-12) along axis 1."""
+    n = spembs / spembs.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    if integration_type == "add":
+        return hs + linear(n, W["spk_projection.weight"], W["spk_projection.bias"]).unsqueeze(1)
+    if integration_type == "concat":
+        n = n.unsqueeze(1).expand(-1, hs.shape[1], -1)
+        return linear(torch.cat([hs, n], dim=-1), W["spk_projection.weight"], W["spk_projection.bias"])
+    raise NotImplementedError("support only add or concat.")   # :584
+
+
+def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts=False, spk_id=None,
+              spembs=None):
     """FastSpeech2.inference fastspeech2.py:468-558 for one utterance.
-    ids: (T,) int64 -> normalised mel (L, odim)."""
+    ids: (T,) int64 -> normalised mel (L, odim).  spk_id (int) / spembs (D,): speaker conditioning of
+    the multi-speaker recipes (:396-402; spembs wins when both are given)."""
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
     W = Weights(state, dtype)
     x = torch.as_tensor(np.asarray(ids)).to(torch.int64)
@@ -180,6 +195,16 @@ def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts
     xs = x.unsqueeze(0)                             # :522
     x_masks = make_non_pad_mask(ilens).unsqueeze(-2)  # _source_mask :618-641
     hs = encoder(W.sub("encoder."), xs, x_masks, cfg["elayers"], cfg["aheads"], True)  # :393
+    if cfg.get("spk_embed_dim") is not None:        # :396-402
+        emb = None
+        if spembs is not None:
+            emb = torch.as_tensor(np.asarray(spembs)).to(dtype).reshape(1, -1)
+        elif spk_id is not None:
+            emb = W["spk_embedding_table.weight"][int(spk_id)].reshape(1, -1)
+            if int(spk_id) == 0:                    # nn.Embedding(padding_idx=0) returns zeros [paddle-semantics]
+                emb = torch.zeros_like(emb)
+        if emb is not None:
+            hs = integrate_spk_embed(W, hs, emb, cfg.get("spk_embed_integration_type", "add"))
     d_masks = make_pad_mask(ilens)                  # :410
     p_outs = variance_predictor(W.sub("pitch_predictor."), hs, d_masks, cfg["pitch_predictor_layers"])
     e_outs = variance_predictor(W.sub("energy_predictor."), hs, d_masks, cfg["energy_predictor_layers"])

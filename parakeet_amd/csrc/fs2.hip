@@ -318,6 +318,46 @@ __global__ __launch_bounds__(128) void k_regulate(
 }  // namespace
 
 // ================================================================== host side
+// Speaker vector per utterance: v[b] = normalize(e_b) . W + bias, e_b = spembs[b] or table[spk_id[b]]
+// (zero for the padding id 0); normalize = x / max(||x||_2, 1e-12) (F.normalize, fastspeech2.py:575,580).
+// W is [D][A] row-major (the whole spk_projection for "add", its last D rows for "concat").
+__global__ __launch_bounds__(256) void k_spk_vec(const long long* __restrict__ spk_id, const float* __restrict__ spembs,
+                                                 const float* __restrict__ table, const float* __restrict__ W,
+                                                 const float* __restrict__ bias, int D, int A,
+                                                 float* __restrict__ v) {
+    extern __shared__ float e[];   // D floats + 1
+    const int b = blockIdx.x;
+    const float* src = spembs ? spembs + (long)b * D : table + (long)spk_id[b] * D;
+    const bool zero = !spembs && spk_id[b] == 0;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const float x = zero ? 0.f : src[i];
+        e[i] = x;
+        ss += x * x;
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float inv = 1.0f / fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    for (int c = threadIdx.x; c < A; c += blockDim.x) {
+        float acc = 0.f;
+        for (int i = 0; i < D; ++i) acc = fmaf(e[i] * inv, W[(long)i * A + c], acc);
+        v[(long)b * A + c] = acc + bias[c];
+    }
+}
+
+// y[r] = x[r] + v[row_utt[r]] on the rows of the timeline that belong to an utterance
+__global__ __launch_bounds__(256) void k_add_rowvec(const float* __restrict__ x, const float* __restrict__ v,
+                                                    const int* __restrict__ row_utt, int rows, int A,
+                                                    float* __restrict__ y) {
+    const int r = blockIdx.x;
+    const int b = row_utt[r];
+    if (b < 0) return;
+    for (int c = threadIdx.x; c < A; c += blockDim.x) y[(long)r * A + c] = x[(long)r * A + c] + v[(long)b * A + c];
+}
+
 struct Dense {
     size_t w = 0, b = 0;   // offsets (floats) into the weight arena; b == SIZE_MAX: no bias
     size_t wh = (size_t)-1;   // offset (halves) of the split-fp16 fragments, SIZE_MAX if Cin % 32 != 0
@@ -369,6 +409,12 @@ struct pk_fs2 {
     size_t pitch_w = 0, pitch_b = 0, energy_w = 0, energy_b = 0;
     Dense feat_out;
     std::vector<Dense> postnet;
+    size_t spk_table = 0, spk_w = 0, spk_b = 0;   // embedding table, [D][A] speaker part of spk_projection, bias
+    Dense spk_hs;                                  // "concat": the [A][A] hidden-state part of spk_projection
+    std::vector<long long> cond_spk;               // conditioning of the next encode (pk_fs2_set_speakers)
+    std::vector<float> cond_emb;
+    int cond_B = 0;
+    pk_dbuf d_spk_id, d_spk_emb, d_spk_vec;
     size_t out_scale = 0, out_shift = 0;
     bool has_out_affine = false;
     std::vector<float> h_out_scale, h_out_shift;
@@ -435,8 +481,11 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: pitch/energy_embed_kernel_size must be 1 (all reference recipes)");
     if (!c.encoder_normalize_before || !c.decoder_normalize_before)
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: post-norm blocks not implemented");
-    if (c.has_spk_embed || c.has_tone_embed)
-        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: speaker / tone embedding not implemented");
+    if (c.tone_embed_dim != 0) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: tone embedding not implemented");
+    if (c.spk_embed_dim < 0 || c.num_speakers < 0) PK_FAIL(PK_EINVAL, "FastSpeech2: negative speaker sizes");
+    if (c.spk_embed_dim > 0 && c.spk_embed_integration_type != 0 && c.spk_embed_integration_type != 1)
+        PK_FAIL(PK_EUNSUPPORTED, "support only add or concat. (fastspeech2.py:584)");
+    if (c.spk_embed_dim > 8192) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: spk_embed_dim > 8192");
     if (c.postnet_layers > 0 && !c.use_batch_norm)
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: postnet without batch norm not implemented");
     const int ks[] = {c.positionwise_conv_kernel_size, c.duration_predictor_kernel_size,
@@ -687,6 +736,26 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
         pk_conv_to_kn(w.data(), cout, cin, c.postnet_filts, kn);
         PK_TRY(add_dense_kn(ar, kn, &bias, cin, c.postnet_filts, cout, h->postnet[j]));
     }
+    if (c.spk_embed_dim > 0) {
+        const int D = c.spk_embed_dim;
+        std::vector<float> t, w, b;
+        if (c.num_speakers > 0) {
+            PK_TRY(pk_get_weight(P, "spk_embedding_table", {c.num_speakers, D}, t));
+            h->spk_table = ar.put(t);
+        }
+        PK_TRY(pk_get_vector(P, "spk_projection.bias", A, b));
+        h->spk_b = ar.put(b);
+        if (c.spk_embed_integration_type == 0) {
+            PK_TRY(pk_get_weight(P, "spk_projection", {D, A}, w));
+            h->spk_w = ar.put(w);
+        } else {
+            // Linear(adim + D -> adim) on concat([hs, e]) = hs . W[:adim] + e . W[adim:] (+ bias, added with e's part)
+            PK_TRY(pk_get_weight(P, "spk_projection", {A + D, A}, w));
+            std::vector<float> whs(w.begin(), w.begin() + (size_t)A * A), wsp(w.begin() + (size_t)A * A, w.end());
+            PK_TRY(add_dense_kn(ar, whs, nullptr, A, 1, A, h->spk_hs));
+            h->spk_w = ar.put(wsp);
+        }
+    }
     if (h->has_out_affine) {
         h->out_scale = ar.put(h->h_out_scale);
         h->out_shift = ar.put(h->h_out_shift);
@@ -845,6 +914,34 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
     PK_LAUNCH(ctx, "fs2_embed", k_embed, dim3(tl.rows), dim3(128), 0, h->d_tok.as<int>(), tl.d_row_utt(),
               tl.d_row_pos(), h->W(h->emb_table), h->d_pe.as<float>(), h->alpha_enc, h->xscale, A, x);
     PK_TRY(run_fft_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    // speaker embedding (:396-402)
+    if (c.spk_embed_dim > 0 && h->cond_B > 0) {
+        const int D = c.spk_embed_dim;
+        const bool ext = !h->cond_emb.empty();
+        const int condB = h->cond_B;
+        h->cond_B = 0;   // consumed
+        if (condB != B) PK_FAIL(PK_ESHAPE, "pk_fs2_encode: speakers were set for %d utterances, batch has %d", condB, B);
+        const long long* d_id = nullptr;
+        const float* d_emb = nullptr;
+        if (ext) {
+            PK_TRY(pk_upload(ctx, h->d_spk_emb, h->cond_emb.data(), h->cond_emb.size() * sizeof(float)));
+            d_emb = h->d_spk_emb.as<float>();
+        } else {
+            PK_TRY(pk_upload(ctx, h->d_spk_id, h->cond_spk.data(), h->cond_spk.size() * sizeof(long long)));
+            d_id = h->d_spk_id.as<long long>();
+        }
+        PK_TRY(h->d_spk_vec.reserve((size_t)B * A * sizeof(float)));
+        PK_LAUNCH(ctx, "fs2_spk_vec", k_spk_vec, dim3(B), dim3(256), (size_t)D * sizeof(float), d_id, d_emb,
+                  h->W(h->spk_table), h->W(h->spk_w), h->W(h->spk_b), D, A, h->d_spk_vec.as<float>());
+        const float* src = hs;
+        if (c.spk_embed_integration_type == 1) {
+            PK_TRY(run_dense(h, "fs2_gemm_spk_proj", h->spk_hs, hs, A, x, A, tl.rows, PK_ACT_NONE, nullptr, 0,
+                             tl.d_row_utt()));
+            src = x;
+        }
+        PK_LAUNCH(ctx, "fs2_add_rowvec", k_add_rowvec, dim3(tl.rows), dim3(256), 0, src, h->d_spk_vec.as<float>(),
+                  tl.d_row_utt(), tl.rows, A, hs);
+    }
     // variance adaptor
     PK_TRY(h->d_pout.reserve((size_t)tl.rows_alloc * 4));
     PK_TRY(h->d_eout.reserve((size_t)tl.rows_alloc * 4));
@@ -957,6 +1054,28 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
         PK_HIP(hipMemcpyAsync(mel_out, d_out, (size_t)sumL * c.odim * 4, hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipStreamSynchronize(ctx->stream));
     }
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_set_speakers(pk_fs2* h, const int64_t* spk_id, const float* spembs, int32_t B) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_set_speakers: handle is NULL");
+    h->cond_B = 0;
+    h->cond_spk.clear();
+    h->cond_emb.clear();
+    if (!spk_id && !spembs) return PK_OK;
+    const pk_fs2_cfg& c = h->cfg;
+    if (c.spk_embed_dim <= 0) return PK_OK;   // a single-speaker model ignores speakers, like the reference (:396)
+    if (B <= 0) PK_FAIL(PK_EINVAL, "pk_fs2_set_speakers: batch size must be positive");
+    if (spembs) {
+        h->cond_emb.assign(spembs, spembs + (size_t)B * c.spk_embed_dim);
+    } else {
+        if (c.num_speakers <= 0) PK_FAIL(PK_ESTATE, "pk_fs2_set_speakers: the model has no spk_embedding_table");
+        for (int b = 0; b < B; ++b)
+            if (spk_id[b] < 0 || spk_id[b] >= c.num_speakers)
+                PK_FAIL(PK_EINVAL, "pk_fs2_set_speakers: speaker id %lld out of [0,%d)", (long long)spk_id[b], c.num_speakers);
+        h->cond_spk.assign(spk_id, spk_id + B);
+    }
+    h->cond_B = B;
     return PK_OK;
 }
 

@@ -73,8 +73,13 @@ class FastSpeech2:
         cfg.encoder_normalize_before = 1 if encoder_normalize_before else 0
         cfg.decoder_normalize_before = 1 if decoder_normalize_before else 0
         cfg.reduction_factor = reduction_factor
-        cfg.has_spk_embed = 0 if spk_embed_dim is None else 1
-        cfg.has_tone_embed = 0 if tone_embed_dim is None else 1
+        if spk_embed_dim is not None and spk_embed_integration_type not in ("add", "concat"):
+            raise NotImplementedError("support only add or concat.")   # fastspeech2.py:584
+        cfg.num_speakers = 0 if (num_speakers is None or spk_embed_dim is None) else int(num_speakers)
+        cfg.spk_embed_dim = 0 if spk_embed_dim is None else int(spk_embed_dim)
+        cfg.spk_embed_integration_type = 1 if spk_embed_integration_type == "concat" else 0
+        cfg.tone_embed_dim = 0 if tone_embed_dim is None else int(tone_embed_dim)
+        self.spk_embed_dim = spk_embed_dim
         h = C.c_void_p()
         _capi.check(self._ctx.lib.pk_fs2_create(self._ctx.handle, C.byref(cfg), C.byref(h)))
         self._h = h
@@ -118,12 +123,23 @@ class FastSpeech2:
         _capi.check(self._ctx.lib.pk_fs2_set_debug(self._h, 1 if on else 0))
 
     # -- synthesis -----------------------------------------------------------
-    def encode_batch(self, texts, alpha=1.0):
-        """Phase 1: returns the per-utterance frame counts (host ints)."""
+    def encode_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None):
+        """Phase 1: returns the per-utterance frame counts (host ints).  ``spk_ids`` (B,) ints or
+        ``spembs`` (B, spk_embed_dim): speaker conditioning of a multi-speaker model (:396-402)."""
         ctx = Context.get(self._ctx.device)
         self._finalize()
         ids = [np.asarray(t.cpu() if isinstance(t, torch.Tensor) else t).astype(np.int64).reshape(-1)
                for t in texts]
+        if self.spk_embed_dim is not None and (spk_ids is not None or spembs is not None):
+            if spembs is not None:
+                e = np.ascontiguousarray(to_numpy_f32(spembs).reshape(len(ids), self.spk_embed_dim))
+                _capi.check(ctx.lib.pk_fs2_set_speakers(self._h, None, _capi.fptr(e), len(ids)))
+            else:
+                sp = np.ascontiguousarray(np.asarray(
+                    spk_ids.cpu() if isinstance(spk_ids, torch.Tensor) else spk_ids).astype(np.int64).reshape(-1))
+                assert sp.size == len(ids), "one speaker id per utterance"
+                _capi.check(ctx.lib.pk_fs2_set_speakers(self._h, sp.ctypes.data_as(C.POINTER(C.c_int64)), None,
+                                                        len(ids)))
         lens = np.array([len(i) for i in ids], dtype=np.int32)
         flat = np.ascontiguousarray(np.concatenate(ids))
         frames = np.zeros(len(ids), dtype=np.int32)
@@ -142,8 +158,8 @@ class FastSpeech2:
             _capi.check(ctx.lib.pk_fs2_decode(self._h, dptr(mel), 0))
         return mel
 
-    def inference_batch(self, texts, alpha=1.0):
-        frames = self.encode_batch(texts, alpha)
+    def inference_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None):
+        frames = self.encode_batch(texts, alpha, spk_ids, spembs)
         mel = self.decode_packed()
         outs, o = [], 0
         for f in frames:
@@ -156,8 +172,13 @@ class FastSpeech2:
         """(T,) int64 -> (L, odim); fastspeech2.py:468-558 (is_inference=True branch)."""
         if use_teacher_forcing:
             raise NotImplementedError("teacher forcing is a training-time path")
-        if spembs is not None or spk_id is not None or tone_id is not None:
-            raise NotImplementedError("speaker / tone embeddings are not implemented")
+        if tone_id is not None:
+            raise NotImplementedError("tone embeddings are not implemented (no FastSpeech2 recipe uses them)")
+        if spembs is not None:      # (spk_embed_dim,), unsqueezed by the reference (:541-542)
+            return self.inference_batch([text], alpha, spembs=to_numpy_f32(spembs).reshape(1, -1))[0]
+        if spk_id is not None:
+            sid = np.asarray(spk_id.cpu() if isinstance(spk_id, torch.Tensor) else spk_id).reshape(-1)[:1]
+            return self.inference_batch([text], alpha, spk_ids=sid)[0]
         return self.inference_batch([text], alpha)[0]
 
     def debug_tap(self, what, b):

@@ -58,7 +58,10 @@ def _xavier(rng, shape):
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)
 
 
-def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=None, perturb=True):
+def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=None, perturb=True,
+                      num_speakers=None):
+    """``cfg`` may carry spk_embed_dim / spk_embed_integration_type (aishell3 / vctk recipes: 256, "concat");
+    ``num_speakers`` then sizes ``spk_embedding_table`` (fastspeech2.py:147-151, 190-194)."""
     cfg = dict(FS2_LJSPEECH, **(cfg or {}))
     rng = np.random.default_rng(seed)
     A = cfg["adim"]
@@ -135,6 +138,14 @@ def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=Non
         st[f"postnet.postnet.{j}.1._mean"] = small(cout)
         st[f"postnet.postnet.{j}.1._variance"] = (
             rng.uniform(0.5, 1.5, size=(cout,)) if perturb else np.ones(cout)).astype(np.float32)
+    if cfg.get("spk_embed_dim") is not None:
+        D = cfg["spk_embed_dim"]
+        tab = rng.normal(size=(num_speakers, D)).astype(np.float32)
+        tab[0] = 0.0  # padding_idx row (nn.Embedding(padding_idx=0), :147-151)
+        st["spk_embedding_table.weight"] = tab
+        kin = D if cfg.get("spk_embed_integration_type", "add") == "add" else A + D
+        st["spk_projection.weight"] = _xavier(rng, (kin, A))
+        st["spk_projection.bias"] = small(A)
     return st
 
 

@@ -23,6 +23,24 @@ def test_fastspeech2_oracle_matches_reference_source():
     assert np.abs(logmel - g["logmel0"]).max() < 2e-5
 
 
+def test_fastspeech2_multispeaker_oracle_matches_reference_source():
+    # aishell3 / vctk shape: spk_embed_dim 256, both integration types, table lookups (incl. the padding
+    # id 0) and an external speaker embedding
+    g = np.load(os.path.join(GOLD, "fastspeech2_multispeaker.npz"))
+    for kind in ("add", "concat"):
+        cfg = dict(syn.FS2_LJSPEECH, spk_embed_dim=256, spk_embed_integration_type=kind)
+        state = syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), num_speakers=6)
+        for i in range(3):
+            kw = dict(spembs=g[f"{kind}_spemb2"]) if i == 2 else dict(spk_id=int(g[f"{kind}_spk{i}"]))
+            mel = fs2.inference(state, g[f"{kind}_ids{i}"], cfg, **kw).numpy()
+            assert mel.shape == g[f"{kind}_mel{i}"].shape
+            assert np.abs(mel - g[f"{kind}_mel{i}"]).max() < 2e-5
+    # the speaker changes the result (the conditioning is live)
+    a = fs2.inference(state, g["concat_ids0"], cfg, spk_id=1).numpy()
+    b = fs2.inference(state, g["concat_ids0"], cfg, spk_id=2).numpy()
+    assert a.shape != b.shape or np.abs(a - b).max() > 1e-3
+
+
 def test_pwg_oracle_matches_reference_source():
     g = np.load(os.path.join(GOLD, "pwg_ljspeech.npz"))
     state = syn.pwg_state(syn.PWG_LJSPEECH, seed=int(g["seed"]), weight_norm=True)

@@ -31,6 +31,35 @@ def test_fastspeech2_engine_matches_reference_source():
     assert np.abs(inf(g["ids0"]).numpy() - g["logmel0"]).mean() < 1e-4
 
 
+@pytest.mark.parametrize("kind", ["add", "concat"])
+def test_fastspeech2_multispeaker_engine_matches_reference_source(kind):
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    g = np.load(os.path.join(GOLD, "fastspeech2_multispeaker.npz"))
+    cfg = dict(syn.FS2_LJSPEECH, spk_embed_dim=256, spk_embed_integration_type=kind)
+    model = FastSpeech2(80, 80, num_speakers=6, **cfg)
+    model.set_state_dict(syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), num_speakers=6))
+    model.eval()
+    for i in range(2):
+        mel = model.inference(g[f"{kind}_ids{i}"], spk_id=np.array([int(g[f"{kind}_spk{i}"])])).numpy()
+        assert mel.shape == g[f"{kind}_mel{i}"].shape           # same integer durations
+        assert np.abs(mel - g[f"{kind}_mel{i}"]).mean() < 1e-4
+    mel = model.inference(g[f"{kind}_ids2"], spembs=g[f"{kind}_spemb2"]).numpy()
+    assert mel.shape == g[f"{kind}_mel2"].shape
+    assert np.abs(mel - g[f"{kind}_mel2"]).mean() < 1e-4
+    # one ragged batch with a different speaker per utterance == the single-utterance references
+    outs = model.inference_batch([g[f"{kind}_ids0"], g[f"{kind}_ids1"]],
+                                 spk_ids=[int(g[f"{kind}_spk0"]), int(g[f"{kind}_spk1"])])
+    for i, o in enumerate(outs):
+        assert o.shape == g[f"{kind}_mel{i}"].shape
+        assert np.abs(o.numpy() - g[f"{kind}_mel{i}"]).mean() < 1e-4
+    # no speaker given: integration skipped, as in the reference (:396-402); conditioning does not leak
+    a = model.inference(g[f"{kind}_ids0"]).numpy()
+    b = model.inference(g[f"{kind}_ids0"]).numpy()
+    assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        model.inference(g[f"{kind}_ids0"], spk_id=np.array([6]))
+
+
 def test_pwg_engine_matches_reference_source():
     from parakeet_amd.normalizer import ZScore
     from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference

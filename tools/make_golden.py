@@ -49,6 +49,32 @@ def golden_fastspeech2():
     print("fastspeech2:", {k: v.shape for k, v in out.items() if k.startswith("mel")})
 
 
+def golden_fastspeech2_multispeaker():
+    """aishell3 / vctk shape: spk_embed_dim 256; both integration types; spk_id (incl. the padding id 0)
+    and an external speaker embedding."""
+    fsm = ref_import.load("parakeet.models.fastspeech2.fastspeech2")
+    out = {"seed": np.array(2025)}
+    rng = np.random.default_rng(31)
+    for kind in ("add", "concat"):
+        cfg = dict(syn.FS2_LJSPEECH, spk_embed_dim=256, spk_embed_integration_type=kind)
+        state = syn.fastspeech2_state(80, 80, cfg, seed=2025, num_speakers=6)
+        model = fsm.FastSpeech2(idim=80, odim=80, num_speakers=6, **cfg)
+        model.set_state_dict(state)
+        model.eval()
+        for i, spk in enumerate([3, 0]):
+            ids = syn.phoneme_ids(8 + i, seed=600 + i)
+            with paddle.no_grad():
+                mel = model.inference(paddle.to_tensor(ids), spk_id=paddle.to_tensor(np.array([spk]))).numpy()
+            out[f"{kind}_ids{i}"], out[f"{kind}_spk{i}"], out[f"{kind}_mel{i}"] = ids, np.array(spk), mel.astype(np.float32)
+        ids = syn.phoneme_ids(7, seed=610)
+        emb = rng.normal(size=(1, 256)).astype(np.float32)
+        with paddle.no_grad():
+            mel = model.inference(paddle.to_tensor(ids), spembs=paddle.to_tensor(emb[0])).numpy()
+        out[f"{kind}_ids2"], out[f"{kind}_spemb2"], out[f"{kind}_mel2"] = ids, emb[0], mel.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fastspeech2_multispeaker.npz"), **out)
+    print("fastspeech2 multi-speaker:", {k: v.shape for k, v in out.items() if "mel" in k})
+
+
 def golden_pwg():
     pw = ref_import.load("parakeet.models.parallel_wavegan.parallel_wavegan")
     norm = ref_import.load("parakeet.modules.normalizer")
@@ -87,6 +113,7 @@ def golden_pwg():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_fastspeech2()
+    golden_fastspeech2_multispeaker()
     golden_pwg()
     if "--with-waveflow" in sys.argv or True:
         try:
