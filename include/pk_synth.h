@@ -244,6 +244,47 @@ int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, int32_t B, co
                 float* wav, int32_t flags);
 void pk_wf_destroy(pk_wf* h);
 
+/* ------------------------------------------------------------ SpeedySpeech */
+/* SpeedySpeech(vocab_size, encoder_hidden_size, encoder_kernel_size, encoder_dilations,
+ * duration_predictor_hidden_size, decoder_hidden_size, decoder_output_size, decoder_kernel_size,
+ * decoder_dilations, tone_size) -- parakeet/models/speedyspeech/speedyspeech.py:142-166. */
+typedef struct {
+    int32_t vocab_size;
+    int32_t tone_size;                    /* 0 = no tone embedding (tone_size=None) */
+    int32_t encoder_hidden_size, encoder_kernel_size, n_encoder_dilations;
+    int32_t encoder_dilations[32];
+    int32_t duration_predictor_hidden_size;
+    int32_t decoder_hidden_size, decoder_output_size, decoder_kernel_size, n_decoder_dilations;
+    int32_t decoder_dilations[32];
+    /* Every convolution of the model is nn.Conv1D(..., dilation=d, padding="same").  Paddle's conv kernels
+     * (UpdatePaddingAndDilation, paddle/fluid/operators/conv_op.h, release 2.1) compute the "SAME" pads from
+     * the undilated kernel -- before = (k-1)/2, after = (k-1) - before -- and RESET THE DILATION TO 1, so the
+     * reference as it runs on Paddle does not dilate [paddle-semantics, unverified: Paddle is not installable
+     * in the build image].  1 = that behaviour (what released checkpoints were trained with), 0 = the
+     * convolution as written: dilation d, pads d*(k-1) split the same way. */
+    int32_t same_padding_resets_dilation;
+} pk_ss_cfg;
+typedef struct pk_ss pk_ss;
+
+int pk_ss_create(pk_ctx* ctx, const pk_ss_cfg* cfg, pk_ss** out);
+/* set_state_dict entry ("encoder.res_blocks.3.blocks.1.0.weight", "...2._variance", ...). */
+int pk_ss_set_param(pk_ss* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* SpeedySpeechInference's normalizer (:221-231): mel -> mel * sigma + mu.  NULL,NULL = SpeedySpeech.inference. */
+int pk_ss_set_normalizer(pk_ss* h, const float* mu, const float* sigma, int32_t n);
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math); env PK_SS_MATH=f32. */
+int pk_ss_set_math(pk_ss* h, int32_t mode);
+int pk_ss_finalize(pk_ss* h);
+/* Phase 1 of SpeedySpeech.inference (:178-196) for a packed batch: encoder, duration predictor,
+ * durations = round(exp(.)).  text / tones: HOST int64, packed by utterance (tones may be NULL, :183);
+ * tok_lens: HOST (B).  out_frames (B) host: decoder lengths (the sync the reference has at :194-196). */
+int pk_ss_encode(pk_ss* h, const int64_t* text, const int64_t* tones, const int32_t* tok_lens, int32_t B,
+                 int32_t* out_frames);
+/* Phase 2 (:197-218): expand, + sinusoid_position_encoding, decoder -> packed (sum(frames), output_size). */
+int pk_ss_decode(pk_ss* h, float* mel_out, int32_t flags);
+/* Test taps of the last encode: 0 = encodings (T_b, H), 1 = log-durations (T_b), 2 = durations (T_b). */
+int pk_ss_debug_read(pk_ss* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
+void pk_ss_destroy(pk_ss* h);
+
 /* ------------------------------------------------- STFT / mel / log features */
 /* parakeet/modules/audio.py STFT (:74-215) + MelScale (:218-229); host twin
  * parakeet/data/get_feats.py LogMelFBank (:20-88). */

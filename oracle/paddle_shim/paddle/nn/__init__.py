@@ -79,9 +79,11 @@ class Conv1D(_ConvNd):
                  padding_mode="zeros", weight_attr=None, bias_attr=None, data_format="NCL"):
         super().__init__()
         self._setup(in_channels, out_channels, (kernel_size,), stride, padding, dilation, groups, bias_attr)
+        self._data_format = data_format
 
     def forward(self, x):
-        return functional.conv1d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return functional.conv1d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups,
+                                 data_format=self._data_format)
 
 
 def _pair(v):
@@ -137,9 +139,14 @@ class BatchNorm1D(Layer):
         self.bias = torch.nn.Parameter(torch.zeros(num_features), requires_grad=False)
         self.register_buffer("_mean", torch.zeros(num_features))
         self.register_buffer("_variance", torch.ones(num_features))
+        self._data_format = data_format
 
     def forward(self, x):
         assert not self.training, "only eval-mode batch norm is restated"
+        if self._data_format == "NLC" and x.dim() == 3:
+            y = TF.batch_norm(x.transpose(1, 2), self._mean, self._variance, self.weight, self.bias, False, 0.0,
+                              self._eps)
+            return _wrap(y.transpose(1, 2))
         return _wrap(TF.batch_norm(x, self._mean, self._variance, self.weight, self.bias, False, 0.0, self._eps))
 
 

@@ -20,7 +20,28 @@ def _pad2(padding):
     raise ValueError(padding)
 
 
+# Paddle's conv kernels call UpdatePaddingAndDilation (paddle/fluid/operators/conv_op.h, release 2.1): with
+# padding_algorithm "SAME" the pads become pad_sum = max((out - 1) * stride + k - in, 0), before = pad_sum / 2,
+# after = pad_sum - before -- computed from the UNDILATED kernel size -- and the dilation is RESET TO 1.
+# [paddle-semantics, unverified here: Paddle cannot be installed in this image.]  True reproduces that; False
+# gives the mathematically dilated convolution with symmetric "same" padding d * (k - 1).
+SAME_PADDING_RESETS_DILATION = True
+
+
 def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, data_format="NCL"):
+    if data_format == "NLC":
+        y = conv1d(x.transpose(1, 2), weight, bias, stride, padding, dilation, groups, "NCL")
+        return _wrap(y.transpose(1, 2))
+    if isinstance(padding, str):
+        assert padding.lower() == "same" and stride in (1, (1,), [1]), padding
+        k = weight.shape[-1]
+        d = dilation[0] if isinstance(dilation, (list, tuple)) else dilation
+        if SAME_PADDING_RESETS_DILATION:
+            d = 1
+        pad_sum = d * (k - 1)
+        before = pad_sum // 2
+        x = TF.pad(x, (before, pad_sum - before))
+        return _wrap(TF.conv1d(x, weight, bias, stride=1, padding=0, dilation=d, groups=groups))
     if isinstance(padding, (list, tuple)):
         if len(padding) == 1:
             padding = padding[0]

@@ -57,6 +57,15 @@ class WfCfg(C.Structure):
                 ("kernel_h", C.c_int32), ("kernel_w", C.c_int32)]
 
 
+class SsCfg(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("tone_size", C.c_int32), ("encoder_hidden_size", C.c_int32),
+                ("encoder_kernel_size", C.c_int32), ("n_encoder_dilations", C.c_int32),
+                ("encoder_dilations", C.c_int32 * 32), ("duration_predictor_hidden_size", C.c_int32),
+                ("decoder_hidden_size", C.c_int32), ("decoder_output_size", C.c_int32),
+                ("decoder_kernel_size", C.c_int32), ("n_decoder_dilations", C.c_int32),
+                ("decoder_dilations", C.c_int32 * 32), ("same_padding_resets_dilation", C.c_int32)]
+
+
 class MelCfg(C.Structure):
     _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("center", C.c_int32), ("power", C.c_int32),
                 ("n_mels", C.c_int32), ("log_base", C.c_int32), ("log_floor", C.c_float)]
@@ -108,6 +117,15 @@ def _declare(lib):
         "pk_wf_cond_length": (C.c_int, [vp, i32, i32p, i32p]),
         "pk_wf_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
         "pk_wf_destroy": (None, [vp]),
+        "pk_ss_create": (C.c_int, [vp, C.POINTER(SsCfg), C.POINTER(vp)]),
+        "pk_ss_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
+        "pk_ss_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
+        "pk_ss_set_math": (C.c_int, [vp, i32]),
+        "pk_ss_finalize": (C.c_int, [vp]),
+        "pk_ss_encode": (C.c_int, [vp, i64p, i64p, i32p, i32, i32p]),
+        "pk_ss_decode": (C.c_int, [vp, f32p, i32]),
+        "pk_ss_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
+        "pk_ss_destroy": (None, [vp]),
         "pk_mel_create": (C.c_int, [vp, C.POINTER(MelCfg), f32p, f32p, C.POINTER(vp)]),
         "pk_mel_num_frames": (C.c_int, [vp, i32, i32p]),
         "pk_mel_run": (C.c_int, [vp, f32p, i32p, i32, f32p, i32, i32]),

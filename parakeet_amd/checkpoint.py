@@ -173,6 +173,22 @@ def load_pwg(config, checkpoint, stats):
     return PWGInference(ZScore(mu, sigma), vocoder)
 
 
+def load_speedyspeech(config, checkpoint, stats, phones_dict, tones_dict, same_padding_resets_dilation=True):
+    """The acoustic-model half of examples/speedyspeech/baker/synthesize_e2e.py:46-83: returns
+    ``(SpeedySpeechInference, phone_id_map, tone_id_map)``."""
+    from .normalizer import ZScore
+    from .speedyspeech import SpeedySpeech, SpeedySpeechInference
+    cfg = _config(config)
+    phone_map, vocab = load_phone_id_map(phones_dict)
+    tone_map, tone_size = load_phone_id_map(tones_dict)
+    model = SpeedySpeech(vocab_size=vocab, tone_size=tone_size,
+                         same_padding_resets_dilation=same_padding_resets_dilation, **cfg["model"])
+    model.set_state_dict(load_params(checkpoint, "main_params"))
+    model.eval()
+    mu, sigma = load_stats(stats)
+    return SpeedySpeechInference(ZScore(mu, sigma), model), phone_map, tone_map
+
+
 def load_waveflow(config, checkpoint_path):
     """``ConditionalWaveFlow.from_pretrained`` (waveflow.py:827-852): ``checkpoint_path`` without the
     ``.pdparams`` suffix, ``config`` with a ``model`` section (examples/waveflow/config.py:32-41)."""

@@ -69,6 +69,7 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
                 const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
                 if (m >= a.M) continue;
                 float v = acc[mt][nt][r] + bias;
+                if (a.res_pos == PK_RES_BEFORE_ACT && a.res && !to2) v += a.res[(long)m * a.ldr + n];
                 if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (a.act == PK_ACT_TANH) v = tanhf(v);
                 if (to2) {
@@ -78,9 +79,15 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
                     *dst = v;
                     continue;
                 }
-                if (a.res) v += a.res[(long)m * a.ldr + n];
-                if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
-                if (a.cscale) v = v * cs + ch;
+                if (a.res_pos == PK_RES_AFTER_ACT) {
+                    if (a.res) v += a.res[(long)m * a.ldr + n];
+                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                    if (a.cscale) v = v * cs + ch;
+                } else {
+                    if (a.cscale) v = v * cs + ch;
+                    if (a.res && a.res_pos == PK_RES_AFTER_AFFINE) v += a.res[(long)m * a.ldr + n];
+                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                }
                 int mo = m;
                 if (a.out_rowmap) {
                     mo = a.out_rowmap[m];

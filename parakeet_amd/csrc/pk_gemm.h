@@ -16,10 +16,14 @@ enum { PK_GEMM_MATH_F32 = 0, PK_GEMM_MATH_F16X3 = 1 };
 
 enum { PK_ACT_NONE = 0, PK_ACT_RELU = 1, PK_ACT_TANH = 2 };
 enum { PK_EPI_STD = 0, PK_EPI_GATE = 1 };
+enum { PK_RES_AFTER_ACT = 0, PK_RES_AFTER_AFFINE = 1, PK_RES_BEFORE_ACT = 2 };
 
 // C[r, n] = epilogue( sum_{tap, ci} A[r + tap - pad, ci] * W[tap*Cin + ci, n] )
 //   epilogue: v += bias[n]; v = act(v); v += res[r, n]; v = rowvalid[r] ? v : 0;
 //             v = v * cscale[n] + cshift[n]; store to C[out_rowmap ? out_rowmap[r] : r, n]
+//   res_pos moves the residual: PK_RES_AFTER_AFFINE  v = rowvalid ? act(v + bias) * cscale + cshift + res : 0
+//                               (x + BatchNorm(ReLU(conv(x))), SpeedySpeech's ResidualBlock)
+//                               PK_RES_BEFORE_ACT    v = rowvalid ? act(v + bias + res) * cscale + cshift : 0
 // A is row-major with leading dimension lda; rows r + tap - pad must be readable
 // for every r in [0, ceil(M/128)*128) (buffers carry a margin).  Rows of the
 // "row timeline" that belong to no utterance (gaps) are forced to zero via
@@ -33,6 +37,7 @@ struct pk_gemm_args {
     const float* bias = nullptr;
     const float* res = nullptr;
     int ldr = 0;
+    int res_pos = PK_RES_AFTER_ACT;
     float* C = nullptr;
     int ldc = 0;
     const int* rowvalid = nullptr;   // >= 0 means valid (utterance id), < 0 gap

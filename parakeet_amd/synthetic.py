@@ -41,6 +41,11 @@ PWG_LJSPEECH = dict(
 WAVEFLOW_LJSPEECH = dict(upsample_factors=[16, 16], n_flows=8, n_layers=8, n_group=16, channels=128,
                          n_mels=80, kernel_size=[3, 3])   # examples/waveflow/config.py:32-41 (C=64: paper's small model)
 
+SPEEDYSPEECH_BAKER = dict(   # examples/speedyspeech/baker/conf/default.yaml:23-31
+    encoder_hidden_size=128, encoder_kernel_size=3, encoder_dilations=[1, 3, 9, 27, 1, 3, 9, 27, 1, 1],
+    duration_predictor_hidden_size=128, decoder_hidden_size=128, decoder_output_size=80, decoder_kernel_size=3,
+    decoder_dilations=[1, 3, 9, 27, 1, 3, 9, 27, 1, 3, 9, 27, 1, 3, 9, 27, 1, 1])
+
 SAMPLE_RATE = 22050
 HOP = 256
 
@@ -252,4 +257,60 @@ def waveflow_state(cfg=None, seed=2021, weight_norm=False, zero_output_proj=Fals
             std = 0.3 * math.sqrt(1.0 / C)
             st[p + ".output_proj.weight"] = u(std, (2, C, 1, 1))
             st[p + ".output_proj.bias"] = u(0.05, (2,))
+    return st
+
+
+def speedyspeech_state(cfg=None, vocab_size=70, tone_size=7, seed=303, mean_duration=3.0):
+    """SpeedySpeech state dict (parakeet/models/speedyspeech/speedyspeech.py:21-170).  Keys follow the
+    attribute paths: Sequential(Conv1D, ReLU, BatchNorm1D) -> ``.0`` conv, ``.2`` batch norm.  The duration
+    head gets a bias of ln(mean_duration) and small weights so that round(exp(.)) spreads over 1..6."""
+    cfg = dict(SPEEDYSPEECH_BAKER, **(cfg or {}))
+    rng = np.random.default_rng(seed)
+    H = cfg["encoder_hidden_size"]
+    st = {}
+
+    def small(n, scale=0.1):
+        return rng.uniform(-scale, scale, size=(n,)).astype(np.float32)
+
+    def bn(prefix, n):
+        # small gains keep the 28-block residual streams O(1..10) with random weights
+        st[prefix + ".weight"] = rng.uniform(0.1, 0.4, size=(n,)).astype(np.float32)
+        st[prefix + ".bias"] = small(n)
+        st[prefix + "._mean"] = small(n)
+        st[prefix + "._variance"] = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+
+    def lin(prefix, cin, cout):
+        st[prefix + ".weight"] = _xavier(rng, (cin, cout))
+        st[prefix + ".bias"] = small(cout)
+
+    def res_block(prefix, ch, k, n):
+        for j in range(n):
+            st[f"{prefix}.blocks.{j}.0.weight"] = _xavier(rng, (ch, ch, k))
+            st[f"{prefix}.blocks.{j}.0.bias"] = small(ch)
+            bn(f"{prefix}.blocks.{j}.2", ch)
+
+    emb = rng.normal(scale=0.5, size=(vocab_size, H)).astype(np.float32)
+    emb[0] = 0.0
+    st["encoder.embedding.text_embedding.weight"] = emb
+    if tone_size:
+        t = rng.normal(scale=0.5, size=(tone_size, H)).astype(np.float32)
+        t[0] = 0.0
+        st["encoder.embedding.tone_embedding.weight"] = t
+    lin("encoder.prenet.0", H, H)
+    for i, _ in enumerate(cfg["encoder_dilations"]):
+        res_block(f"encoder.res_blocks.{i}", H, cfg["encoder_kernel_size"], 2)
+    lin("encoder.postnet1.0", H, H)
+    bn("encoder.postnet2.1", H)
+    lin("encoder.postnet2.2", H, H)
+    Hd = cfg["duration_predictor_hidden_size"]
+    for i, k in enumerate((4, 3, 1)):
+        res_block(f"duration_predictor.layers.{i}", Hd, k, 1)
+    st["duration_predictor.layers.3.weight"] = rng.uniform(-0.3, 0.3, size=(Hd, 1)).astype(np.float32)
+    st["duration_predictor.layers.3.bias"] = np.array([math.log(mean_duration)], dtype=np.float32)
+    D = cfg["decoder_hidden_size"]
+    for i, _ in enumerate(cfg["decoder_dilations"]):
+        res_block(f"decoder.res_blocks.{i}", D, cfg["decoder_kernel_size"], 2)
+    lin("decoder.postnet1.0", D, D)
+    res_block("decoder.postnet2.0", D, cfg["decoder_kernel_size"], 2)
+    lin("decoder.postnet2.1", D, cfg["decoder_output_size"])
     return st

@@ -41,6 +41,25 @@ def test_fastspeech2_multispeaker_oracle_matches_reference_source():
     assert a.shape != b.shape or np.abs(a - b).max() > 1e-3
 
 
+def test_speedyspeech_oracle_matches_reference_source():
+    # baker configuration, both readings of Paddle's padding="same" (oracle/speedyspeech_ref.py)
+    from oracle import speedyspeech_ref as ssr
+    g = np.load(os.path.join(GOLD, "speedyspeech_baker.npz"))
+    state = syn.speedyspeech_state(seed=int(g["seed"]))
+    for tag, quirk in (("rd", True), ("dil", False)):
+        for i in range(3):
+            mel = ssr.inference(state, g[f"{tag}_text{i}"], g[f"{tag}_tones{i}"],
+                                same_padding_resets_dilation=quirk).numpy()
+            assert mel.shape == g[f"{tag}_mel{i}"].shape          # same integer durations
+            assert np.abs(mel - g[f"{tag}_mel{i}"]).max() < 2e-5
+        logmel = ssr.speedyspeech_inference(state, g["mu"], g["sigma"], g[f"{tag}_text0"], g[f"{tag}_tones0"],
+                                            same_padding_resets_dilation=quirk).numpy()
+        assert np.abs(logmel - g[f"{tag}_logmel0"]).max() < 2e-5
+        nt = ssr.inference(state, g[f"{tag}_text1"], None, same_padding_resets_dilation=quirk).numpy()
+        assert nt.shape == g[f"{tag}_notone_mel"].shape and np.abs(nt - g[f"{tag}_notone_mel"]).max() < 2e-5
+    assert g["rd_mel2"].shape != g["dil_mel2"].shape or np.abs(g["rd_mel2"] - g["dil_mel2"]).max() > 1e-2
+
+
 def test_pwg_oracle_matches_reference_source():
     g = np.load(os.path.join(GOLD, "pwg_ljspeech.npz"))
     state = syn.pwg_state(syn.PWG_LJSPEECH, seed=int(g["seed"]), weight_norm=True)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""tests/golden/speedyspeech_baker.npz: the reference's SpeedySpeech source (parakeet/models/speedyspeech/
+speedyspeech.py) executed over oracle/paddle_shim, baker configuration, under both readings of Paddle's
+padding="same" (see oracle/speedyspeech_ref.py).  Build container only (needs /root/reference)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+ref_import.setup()
+import paddle  # noqa: E402
+import paddle.nn.functional as PF  # noqa: E402
+
+from parakeet_amd import synthetic as syn  # noqa: E402
+
+
+def golden_speedyspeech(out_dir):
+    ssm = ref_import.load("parakeet.models.speedyspeech.speedyspeech")
+    norm = ref_import.load("parakeet.modules.normalizer")
+    cfg = dict(syn.SPEEDYSPEECH_BAKER)
+    state = syn.speedyspeech_state(cfg, vocab_size=70, tone_size=7, seed=303)
+    model = ssm.SpeedySpeech(vocab_size=70, tone_size=7, **cfg)
+    model.set_state_dict(state)
+    model.eval()
+    mu, sigma = syn.mel_stats(seed=11)
+    inf = ssm.SpeedySpeechInference(norm.ZScore(paddle.to_tensor(mu), paddle.to_tensor(sigma)), model)
+    inf.eval()
+    out = {"seed": np.array(303), "mu": mu, "sigma": sigma}
+    rng = np.random.default_rng(17)
+    for tag, quirk in (("rd", True), ("dil", False)):
+        PF.SAME_PADDING_RESETS_DILATION = quirk
+        for i, T in enumerate((9, 14, 40)):
+            while True:   # keep exp(pred) at least 0.03 away from a rounding tie (fp32 summation-order noise is ~1e-5)
+                text = rng.integers(1, 70, size=T).astype(np.int64)
+                tones = rng.integers(1, 7, size=T).astype(np.int64)
+                with paddle.no_grad():
+                    ok = True
+                    for tn in ((tones, None) if i == 1 else (tones,)):
+                        enc = model.encoder(paddle.to_tensor(text[None]), None if tn is None else paddle.to_tensor(tn[None]))
+                        e = np.exp(model.duration_predictor(enc).numpy())
+                        ok = ok and np.abs(e - np.floor(e) - 0.5).min() > 0.03
+                if ok:
+                    break
+            with paddle.no_grad():
+                mel = model.inference(paddle.to_tensor(text), paddle.to_tensor(tones)).numpy()
+            out[f"{tag}_text{i}"], out[f"{tag}_tones{i}"], out[f"{tag}_mel{i}"] = text, tones, mel.astype(np.float32)
+        with paddle.no_grad():
+            out[f"{tag}_logmel0"] = inf(paddle.to_tensor(out[f"{tag}_text0"]),
+                                        paddle.to_tensor(out[f"{tag}_tones0"])).numpy().astype(np.float32)
+            out[f"{tag}_notone_mel"] = model.inference(paddle.to_tensor(out[f"{tag}_text1"])).numpy().astype(np.float32)
+    PF.SAME_PADDING_RESETS_DILATION = True
+    np.savez_compressed(os.path.join(out_dir, "speedyspeech_baker.npz"), **out)
+    print("speedyspeech:", {k: v.shape for k, v in out.items() if "mel" in k})
+
+
+if __name__ == "__main__":
+    golden_speedyspeech(os.path.join(ref_import.ROOT, "tests", "golden"))
