@@ -127,6 +127,11 @@ int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_
  *   PK_PWG_MATH_BF16X3  the same with bf16 parts (fp32 range, 8 + 8 bits): error 3.7e-6. */
 enum { PK_PWG_MATH_F32 = 0, PK_PWG_MATH_BF16X3 = 1, PK_PWG_MATH_F16X3 = 2 };
 int pk_pwg_set_math(pk_pwg* h, int32_t mode);
+/* Scheduling of the residual stack (no effect on results): the batch is processed in chunks of whole
+ * utterances of at most `samples` samples, all layers over one chunk before the next, so that the chunk's
+ * activations (768 B per sample) stay in the 256 MB Infinity Cache between layers (327 680 = two 7.4 s
+ * utterances = 252 MB).  Default: one chunk (measured faster, see pwg.hip); env PK_PWG_CHUNK_SAMPLES. */
+int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples);
 /* remove_weight_norm + packing into the kernels' layouts + upload. */
 int pk_pwg_finalize(pk_pwg* h);
 /* PWGGenerator.inference for a packed batch.

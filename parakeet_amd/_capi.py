@@ -95,6 +95,7 @@ def _declare(lib):
         "pk_pwg_set_seed": (C.c_int, [vp, C.c_uint64]),
         "pk_wf_set_seed": (C.c_int, [vp, C.c_uint64]),
         "pk_pwg_set_math": (C.c_int, [vp, i32]),
+        "pk_pwg_set_chunk_samples": (C.c_int, [vp, i64]),
         "pk_pwg_finalize": (C.c_int, [vp]),
         "pk_pwg_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
         "pk_pwg_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),

@@ -86,6 +86,10 @@ class PWGGenerator:
         m = {"f32": _capi.PK_PWG_MATH_F32, "bf16x3": _capi.PK_PWG_MATH_BF16X3, "f16x3": _capi.PK_PWG_MATH_F16X3}[mode]
         _capi.check(self._ctx.lib.pk_pwg_set_math(self._h, m))
 
+    def set_chunk_samples(self, samples):
+        """Scheduling only (results are unchanged): samples per cache-resident chunk of the residual stack."""
+        _capi.check(self._ctx.lib.pk_pwg_set_chunk_samples(self._h, int(samples)))
+
     def set_seed(self, seed):
         """Seed of the engine's own noise stream (Philox4x32-10 + Box-Muller, ``pk_randn``), used when
         neither ``noise`` nor a torch ``generator`` is given -- the ``paddle.randn`` of :515-516."""

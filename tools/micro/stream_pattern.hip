@@ -49,44 +49,29 @@ __global__ __launch_bounds__(512, 2) void k_stream(const float* __restrict__ xin
 }
 
 int main() {
-    const long S = 32L * 640 * 256, GAP = 1024, T = S + 2 * GAP;
+    // working-set sweep: does a chunk that fits the 256 MB Infinity Cache stream faster than the full batch?
+    const long GAP = 1024;
+    const long Smax = 32L * 640 * 256, Tmax = Smax + 2 * GAP;
     float *x0, *x1, *sk;
-    CK(hipMalloc(&x0, T * 64 * 4 + (64 << 20))); CK(hipMalloc(&x1, T * 64 * 4 + (64 << 20))); CK(hipMalloc(&sk, T * 64 * 4 + (64 << 20)));
-    CK(hipMemset(x0, 0, T * 64 * 4)); CK(hipMemset(x1, 0, T * 64 * 4)); CK(hipMemset(sk, 0, T * 64 * 4));
-    const int n_wt = (int)(S / 32);
+    CK(hipMalloc(&x0, Tmax * 64 * 4)); CK(hipMalloc(&x1, Tmax * 64 * 4)); CK(hipMalloc(&sk, Tmax * 64 * 4));
+    CK(hipMemset(x0, 0, Tmax * 64 * 4)); CK(hipMemset(x1, 0, Tmax * 64 * 4)); CK(hipMemset(sk, 0, Tmax * 64 * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto run = [&](const char* name, auto kern, int grid, int block, int d, double bytes_per_sample) -> int {
-        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, x0, x1, sk, GAP, n_wt, d);
-        CK(hipEventRecord(e0));
-        const int reps = 10;
-        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, x0, x1, sk, GAP, n_wt, d);
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("%-28s grid %4d x %3d  d=%3d : %.3f ms  -> %.2f TB/s of minimal traffic (%.0f B/sample)\n", name, grid, block, d, ms,
-               bytes_per_sample * S / ms / 1e9, bytes_per_sample);
-        return 0;
-    };
-    for (long shift : {0L, 8192L + 512, 65536L + 4096 + 256, (1L << 20) + 8192 + 1024}) {
-        printf("-- buffer shifts: x1 += %ld floats, skip += %ld floats\n", shift, 2 * shift);
-        float* x1s = x1 + shift; float* sks = sk + 2 * shift;
-        auto run2 = [&](const char* name, auto kern, int grid, int block, int d) {
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, x0, x1s, sks, GAP, n_wt, d);
-            hipEventRecord(e0);
-            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, x0, x1s, sks, GAP, n_wt, d);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-            printf("%-28s d=%3d : %.3f ms\n", name, d, ms);
-        };
-        run2("1 tap + skip rmw", k_stream<1, true>, 256, 512, 1);
-        run2("3 taps + skip rmw", k_stream<3, true>, 256, 512, 4);
-        run2("3 taps + skip rmw", k_stream<3, true>, 256, 512, 128);
+    for (int utts : {1, 2, 3, 4, 8, 32}) {
+        const long S = (long)utts * 640 * 256;
+        const int n_wt = (int)(S / 32);
+        for (int d : {1, 128}) {
+            // ping-pong like the layer stack: x0 -> x1, x1 -> x0, ... (30 passes)
+            for (int i = 0; i < 4; ++i)
+                hipLaunchKernelGGL((k_stream<3, true>), dim3(256), dim3(512), 0, 0, (i & 1) ? x1 : x0, (i & 1) ? x0 : x1, sk, GAP, n_wt, d);
+            CK(hipEventRecord(e0));
+            const int reps = 30;
+            for (int i = 0; i < reps; ++i)
+                hipLaunchKernelGGL((k_stream<3, true>), dim3(256), dim3(512), 0, 0, (i & 1) ? x1 : x0, (i & 1) ? x0 : x1, sk, GAP, n_wt, d);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            printf("utterances %2d (working set %6.1f MB) d=%3d : %.4f ms per pass -> %.2f TB/s of minimal traffic, %.3f ms per 32-utt equivalent\n",
+                   utts, 3.0 * S * 256 / 1e6, d, ms, 1024.0 * S / ms / 1e9, ms * 32 / utts);
+        }
     }
-    for (int grid : {256}) for (int block : {512}) {
-        run("x copy (1 tap, no skip)", k_stream<1, false>, grid, block, 1, 512);
-        run("1 tap + skip rmw", k_stream<1, true>, grid, block, 1, 1024);
-        for (int d : {1, 32, 512}) run("3 taps + skip rmw", k_stream<3, true>, grid, block, d, 1024);
-    }
-    run("3 taps + skip rmw", k_stream<3, true>, 1024, 256, 512, 1024);
-    run("3 taps + skip rmw", k_stream<3, true>, 2048, 256, 512, 1024);
     return 0;
 }
