@@ -487,7 +487,8 @@ __device__ __forceinline__ void split_x8<f16x8, _Float16, true>(const float (&v)
 
 // HALF = false: bf16 parts (8 significant bits each, fp32 range); HALF = true: fp16 parts (11 bits each,
 // 22 bits per operand ~ fp32's 24; needs |x| < 65504 and keeps an absolute floor of 2^-25 per operand).
-template <bool FIRST, bool HALF>
+// ABL (profiling only, PK_PWG_ABLATE=1): 1 = no global loads / stores of x and skip (compute-only time)
+template <bool FIRST, bool HALF, int ABL = 0>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
     typedef typename Split16<HALF>::vec bf16x8;     // shadows the bf16 typedef inside this kernel
     typedef typename Split16<HALF>::elem elem16;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         for (int g = 0; g < B3_RING; ++g) {
             const unsigned vo = lane_off(my_slot, g % 3);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ring[g][e] = (a.xin + group_row(g, e) * XBLK)[vo];
+            for (int e = 0; e < 8; ++e) ring[g][e] = ABL ? (float)(lane + e) * 1e-3f : (a.xin + group_row(g, e) * XBLK)[vo];
         }
         split_x8<bf16x8, elem16, HALF>(ring[0], ph, pl);
     }
@@ -613,7 +614,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 const int gt = gn < B3_KS1 ? gn : gn - B3_KS1;
                 const unsigned vo = gn < B3_KS1 ? vo8[gt % 3] : vo8n[gt % 3];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ring[g % B3_RING][e] = (a.xin + group_row(gt, e) * XBLK)[vo];
+                for (int e = 0; e < 8; ++e)
+                    ring[g % B3_RING][e] = ABL ? (float)(lane + e + g) * 1e-3f : (a.xin + group_row(gt, e) * XBLK)[vo];
             }
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 nh, nl;
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            sk_old[16 * qq + r] = (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4];
+                            sk_old[16 * qq + r] = ABL ? 0.5f : (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4];
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // W2 fragments of the next (pass, ks, q) in issue order
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     float v;
                     if (pass == 0) v = (acc2[q][r] + x_old[16 * q + r]) * rs;
                     else v = FIRST ? acc2[q][r] : (sk_old[16 * q + r] + acc2[q][r]);
-                    (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
+                    if (!ABL || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
         }
     }
@@ -1333,6 +1335,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 const dim3 blk(LAYER_WAVES * 64);
                 if (half) {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true>), dim3(grid), blk, 0, a);
+                    else if (h->dbg == 1) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 1>), dim3(grid), blk, 0, a);
                     else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true>), dim3(grid), blk, 0, a);
                 } else {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<true, false>), dim3(grid), blk, 0, a);

@@ -8,9 +8,9 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-python $R/bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
-pmc() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/pmc_$1 -o p -- python $R/tools/pmc_run.py pwg 32 > $OUT/pmc_$1.log 2>&1; }
+timeout 600 python $R/bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
+pmc() { timeout 240 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/pmc_$1 -o p -- python $R/tools/pmc_run.py pwg 32 > $OUT/pmc_$1.log 2>&1; }
 pmc A "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
 pmc B "FETCH_SIZE TCC_HIT"
 pmc C "WRITE_SIZE TCC_MISS TCC_REQ"
@@ -26,7 +26,8 @@ wcal = F["WRITE_SIZE"] * 1024 / (64 * 4 * n)      # known bytes: 64 channels x 4
 rcal = Z["FETCH_SIZE"] * 1024 / (64 * 4 * n)      # known bytes: 64 channels x 4 B per sample read (same dword-per-lane pattern)
 hbm = L["FETCH_SIZE"] * 1024 / rcal + L["WRITE_SIZE"] * 1024 / wcal
 clk = L["GRBM_GUI_ACTIVE"] / 8 / (L["_avg_ns_under_pmc"] * 1e-9)
-prof_key = "pwg_layer_h3" if "true>" in LK.split(",")[-1] and "b3" in LK else ("pwg_layer_b3" if "b3" in LK else "pwg_layer")
+targs = [t.strip() for t in LK[LK.index("<") + 1:LK.rindex(">")].split(",")]   # <FIRST, HALF[, ABL]>
+prof_key = ("pwg_layer_h3" if targs[1] == "true" else "pwg_layer_b3") if "b3" in LK else "pwg_layer"
 out = {"kernel": LK, "prof_key": prof_key, "hbm_bytes_per_launch": hbm,
        "fetch_size_kb": L["FETCH_SIZE"], "write_size_kb": L["WRITE_SIZE"],
        "fetch_calibration": rcal, "write_calibration": wcal,

@@ -7,11 +7,10 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-pmc() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/pmc_$1 -o p -- python $R/tools/pmc_run.py fs2 32 > $OUT/pmc_$1.log 2>&1; }
+pmc() { timeout 240 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/pmc_$1 -o p -- python $R/tools/pmc_run.py fs2 32 > $OUT/pmc_$1.log 2>&1; }
 pmc A "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
 pmc B "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM"
-pmc C "FETCH_SIZE TCC_HIT TCC_MISS TCC_REQ"
-python $R/tools/pmc_parse.py $OUT/pmc_A $OUT/pmc_B $OUT/pmc_C --kernel=k_ > $OUT/pmc_fs2.json
+python $R/tools/pmc_parse.py $OUT/pmc_A $OUT/pmc_B --kernel=k_ > $OUT/pmc_fs2.json
 python - <<PY
 import json
 d = json.load(open("$OUT/pmc_fs2.json"))
