@@ -6,7 +6,7 @@ from parakeet_amd.fastspeech2 import FastSpeech2
 from oracle import fastspeech2_ref as ref
 state = syn.fastspeech2_state(80, 80, seed=77)
 texts = [syn.phoneme_ids(T, seed=300 + i) for i, T in enumerate([60, 33, 90])]
-cfg = {k: syn.FS2_LJSPEECH[k] for k in ref.DEFAULT_CFG}
+cfg = {k: syn.FS2_LJSPEECH[k] for k in ref.DEFAULT_CFG if k in syn.FS2_LJSPEECH}
 want = [ref.inference(state, t, cfg, dtype=torch.float64).numpy() for t in texts]
 w32 = [ref.inference(state, t, cfg, dtype=torch.float32).numpy() for t in texts]
 m = FastSpeech2(80, 80, **syn.FS2_LJSPEECH); m.set_state_dict(state); m.eval()
