@@ -93,3 +93,73 @@ class Conv1dBatchNorm:
         return wrap(y)
 
     __call__ = forward
+
+
+class Linear:
+    """nn.Linear with Paddle's [in, out] weight, on the engine's GEMM (Conv1D k = 1 without batch norm)."""
+
+    def __init__(self, in_features, out_features):
+        self.cin, self.cout = in_features, out_features
+        self.weight = self.bias = None
+
+    def set(self, weight, bias):
+        w = to_numpy_f32(weight)
+        assert w.shape == (self.cin, self.cout), f"Linear weight must be [in, out] = {(self.cin, self.cout)}"
+        self.weight = np.ascontiguousarray(w.T.reshape(self.cout, self.cin, 1))
+        self.bias = None if bias is None else to_numpy_f32(bias).reshape(self.cout)
+
+    def __call__(self, x):
+        ctx = Context.get()
+        x = ctx.to_device(x)
+        lead = x.shape[:-1]
+        x2 = x.reshape(1, -1, self.cin).contiguous()
+        y = ctx.empty((1, x2.shape[1], self.cout))
+        f = _capi.fptr
+        _capi.check(ctx.lib.pk_op_conv1d_batchnorm_nlc(
+            ctx.handle, dptr(x2), 1, x2.shape[1], self.cin, self.cout, 1, 0, f(self.weight),
+            None if self.bias is None else f(self.bias), None, None, None, None, C.c_float(1e-5), dptr(y)))
+        return y.reshape(*lead, self.cout)
+
+
+class MultiheadAttention:
+    """parakeet/modules/attention.py:178-255 (eval mode): affine_q/k/v -> split heads ->
+    scaled_dot_product_attention (float mask, additive -1e9) -> concat heads -> affine_o.
+    State-dict keys affine_{q,k,v,o}.{weight [in, out], bias}.  Returns (out, attention_weights (B, h, Tq, Tk)).
+    The head split / concat are layout moves done with tensor views; the math runs on the engine."""
+
+    def __init__(self, model_dim, num_heads, dropout=0.0, k_dim=None, v_dim=None):
+        if model_dim % num_heads != 0:
+            raise ValueError("model_dim must be divisible by num_heads")   # attention.py:213-214
+        depth = model_dim // num_heads
+        k_dim, v_dim = k_dim or depth, v_dim or depth
+        self.affine_q = Linear(model_dim, num_heads * k_dim)
+        self.affine_k = Linear(model_dim, num_heads * k_dim)
+        self.affine_v = Linear(model_dim, num_heads * v_dim)
+        self.affine_o = Linear(num_heads * v_dim, model_dim)
+        self.num_heads, self.model_dim, self.dropout = num_heads, model_dim, dropout
+        self.training = True
+
+    def set_state_dict(self, state):
+        for nm in ("q", "k", "v", "o"):
+            getattr(self, "affine_" + nm).set(state[f"affine_{nm}.weight"], state.get(f"affine_{nm}.bias"))
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def _split(self, x):
+        B, T, _ = x.shape
+        return x.reshape(B, T, self.num_heads, -1).permute(0, 2, 1, 3).contiguous()   # (B, h, T, C)
+
+    def forward(self, q, k, v, mask):
+        if self.dropout and self.training:
+            raise NotImplementedError("attention dropout is a training-time path")
+        ctx = Context.get()
+        q, k, v = self._split(self.affine_q(q)), self._split(self.affine_k(k)), self._split(self.affine_v(v))
+        m = None if mask is None else ctx.to_device(mask).unsqueeze(1)                  # the h dim (:242)
+        ctxv, w = scaled_dot_product_attention(q, k, v, m, 0.0, False)
+        B, h, T, C_ = ctxv.shape
+        merged = ctxv.as_subclass(torch.Tensor).permute(0, 2, 1, 3).reshape(B, T, h * C_).contiguous()
+        return wrap(self.affine_o(merged)), w
+
+    __call__ = forward

@@ -68,3 +68,41 @@ def test_conv1d_batchnorm_ncl_and_nlc():
         want = y.numpy() if fmt == "NCL" else y.numpy().transpose(0, 2, 1)
         assert got.shape == want.shape
         assert np.abs(got - want).max() < 1e-4
+
+
+def test_multihead_attention_matches_torch_reference():
+    """MultiheadAttention (modules/attention.py:178-255) vs a plain fp32 torch restatement."""
+    from parakeet_amd.modules import MultiheadAttention
+    rng = np.random.default_rng(5)
+    B, Tq, Tk, D, H = 3, 9, 13, 64, 4
+    st = {}
+    for nm in "qkvo":
+        st[f"affine_{nm}.weight"] = rng.normal(scale=0.2, size=(D, D)).astype(np.float32)
+        st[f"affine_{nm}.bias"] = rng.normal(scale=0.1, size=(D,)).astype(np.float32)
+    q = rng.normal(size=(B, Tq, D)).astype(np.float32)
+    k = rng.normal(size=(B, Tk, D)).astype(np.float32)
+    v = rng.normal(size=(B, Tk, D)).astype(np.float32)
+    mask = np.ones((B, 1, Tk), np.float32)
+    mask[1, :, 9:] = 0
+    mask[2, :, 4:] = 0
+    mha = MultiheadAttention(D, H)
+    mha.set_state_dict(st)
+    mha.eval()
+    out, w = mha(q, k, v, mask)
+    t = {n: torch.from_numpy(a) for n, a in st.items()}
+
+    def lin(x, nm):
+        return torch.from_numpy(x) @ t[f"affine_{nm}.weight"] + t[f"affine_{nm}.bias"] if isinstance(x, np.ndarray) \
+            else x @ t[f"affine_{nm}.weight"] + t[f"affine_{nm}.bias"]
+
+    def split(x, T):
+        return x.reshape(B, T, H, D // H).permute(0, 2, 1, 3)
+    qq, kk, vv = split(lin(q, "q"), Tq), split(lin(k, "k"), Tk), split(lin(v, "v"), Tk)
+    s = qq @ kk.transpose(-1, -2) / np.sqrt(D // H) + (1.0 - torch.from_numpy(mask).unsqueeze(1)) * -1e9
+    p = torch.softmax(s, -1)
+    ref = lin((p @ vv).permute(0, 2, 1, 3).reshape(B, Tq, D), "o")
+    assert tuple(w.shape) == (B, H, Tq, Tk)
+    assert np.abs(w.cpu().numpy() - p.numpy()).max() < 1e-5
+    assert np.abs(out.cpu().numpy() - ref.numpy()).max() < 1e-4
+    with pytest.raises(ValueError):
+        MultiheadAttention(30, 4)
