@@ -159,7 +159,10 @@ typedef struct {
     int32_t idim, odim;
     int32_t adim, aheads;
     int32_t elayers, eunits, dlayers, dunits;
-    int32_t positionwise_conv_kernel_size;      /* positionwise_layer_type must be "conv1d" */
+    int32_t positionwise_conv_kernel_size;
+    int32_t positionwise_layer_type;            /* 0 "conv1d" (MultiLayeredConv1d), 1 "linear"
+                                                 * (PositionwiseFeedForward), 2 "conv1d-linear" (Conv1dLinear);
+                                                 * encoder.py:145-170 */
     int32_t duration_predictor_layers, duration_predictor_chans, duration_predictor_kernel_size;
     int32_t pitch_predictor_layers, pitch_predictor_chans, pitch_predictor_kernel_size;
     int32_t energy_predictor_layers, energy_predictor_chans, energy_predictor_kernel_size;

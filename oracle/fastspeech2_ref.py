@@ -72,11 +72,18 @@ def attention(W, x, mask, n_head):
 
 
 def conv_ffn(W, x):
-    """MultiLayeredConv1d.forward multi_layer_conv.py:62-77."""
-    k = W["w_1.weight"].shape[-1]
-    h = torch.relu(conv1d(x.transpose(1, 2), W["w_1.weight"], W["w_1.bias"], padding=(k - 1) // 2))
-    k2 = W["w_2.weight"].shape[-1]
-    return conv1d(h, W["w_2.weight"], W["w_2.bias"], padding=(k2 - 1) // 2).transpose(1, 2)
+    """The position-wise layer of an FFT block, by weight rank (Linear weights are [in, out], Conv1D weights
+    [Cout, Cin, k]): MultiLayeredConv1d multi_layer_conv.py:62-77 ("conv1d"), Conv1dLinear :112-127
+    ("conv1d-linear"), PositionwiseFeedForward positionwise_feed_forward.py:41-44 ("linear")."""
+    if W["w_1.weight"].dim() == 3:
+        k = W["w_1.weight"].shape[-1]
+        h = torch.relu(conv1d(x.transpose(1, 2), W["w_1.weight"], W["w_1.bias"], padding=(k - 1) // 2)).transpose(1, 2)
+    else:
+        h = torch.relu(linear(x, W["w_1.weight"], W["w_1.bias"]))
+    if W["w_2.weight"].dim() == 3:
+        k2 = W["w_2.weight"].shape[-1]
+        return conv1d(h.transpose(1, 2), W["w_2.weight"], W["w_2.bias"], padding=(k2 - 1) // 2).transpose(1, 2)
+    return linear(h, W["w_2.weight"], W["w_2.bias"])
 
 
 def encoder_layer(W, x, mask, n_head):

@@ -41,7 +41,7 @@ class PwgCfg(C.Structure):
 class Fs2Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "idim", "odim", "adim", "aheads", "elayers", "eunits", "dlayers", "dunits",
-        "positionwise_conv_kernel_size",
+        "positionwise_conv_kernel_size", "positionwise_layer_type",
         "duration_predictor_layers", "duration_predictor_chans", "duration_predictor_kernel_size",
         "pitch_predictor_layers", "pitch_predictor_chans", "pitch_predictor_kernel_size",
         "energy_predictor_layers", "energy_predictor_chans", "energy_predictor_kernel_size",

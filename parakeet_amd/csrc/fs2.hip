@@ -482,6 +482,8 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
     if (!c.encoder_normalize_before || !c.decoder_normalize_before)
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: post-norm blocks not implemented");
     if (c.tone_embed_dim != 0) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: tone embedding not implemented");
+    if (c.positionwise_layer_type < 0 || c.positionwise_layer_type > 2)
+        PK_FAIL(PK_EUNSUPPORTED, "Support only linear or conv1d. (encoder.py:169)");
     if (c.spk_embed_dim < 0 || c.num_speakers < 0) PK_FAIL(PK_EINVAL, "FastSpeech2: negative speaker sizes");
     if (c.spk_embed_dim > 0 && c.spk_embed_integration_type != 0 && c.spk_embed_integration_type != 1)
         PK_FAIL(PK_EUNSUPPORTED, "support only add or concat. (fastspeech2.py:584)");
@@ -588,7 +590,7 @@ int add_vec(Arena& ar, const pk_param_map& P, const std::string& name, int n, si
 }
 
 int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int units,
-                  int k, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b) {
+                  int k, int ff_type, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b) {
     out.resize(n_layers);
     for (int l = 0; l < n_layers; ++l) {
         const std::string p = prefix + ".encoders." + std::to_string(l);
@@ -621,8 +623,23 @@ int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, i
         PK_TRY(pk_get_weight(P, p + ".self_attn.linear_out", {A, A}, wo));
         PK_TRY(pk_get_vector(P, p + ".self_attn.linear_out.bias", A, bo));
         PK_TRY(add_dense_kn(ar, wo, &bo, A, 1, A, L.out));
-        PK_TRY(add_conv(ar, P, p + ".feed_forward.w_1", units, A, k, true, L.ffn1));
-        PK_TRY(add_conv(ar, P, p + ".feed_forward.w_2", A, units, k, true, L.ffn2));
+        // position-wise layer (encoder.py:145-170): conv1d = (k, k), conv1d-linear = (k, Linear), linear = 2 x Linear
+        if (ff_type == 1) {
+            std::vector<float> w, b;
+            PK_TRY(pk_get_weight(P, p + ".feed_forward.w_1", {A, units}, w));
+            PK_TRY(pk_get_vector(P, p + ".feed_forward.w_1.bias", units, b));
+            PK_TRY(add_dense_kn(ar, w, &b, A, 1, units, L.ffn1));
+        } else {
+            PK_TRY(add_conv(ar, P, p + ".feed_forward.w_1", units, A, k, true, L.ffn1));
+        }
+        if (ff_type == 0) {
+            PK_TRY(add_conv(ar, P, p + ".feed_forward.w_2", A, units, k, true, L.ffn2));
+        } else {
+            std::vector<float> w, b;
+            PK_TRY(pk_get_weight(P, p + ".feed_forward.w_2", {units, A}, w));
+            PK_TRY(pk_get_vector(P, p + ".feed_forward.w_2.bias", A, b));
+            PK_TRY(add_dense_kn(ar, w, &b, units, 1, A, L.ffn2));
+        }
     }
     PK_TRY(add_vec(ar, P, prefix + ".after_norm.weight", A, after_g));
     PK_TRY(add_vec(ar, P, prefix + ".after_norm.bias", A, after_b));
@@ -695,9 +712,9 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
         h->alpha_enc = h->alpha_dec = 1.f;
         h->xscale = std::sqrt((float)A);  // PositionalEncoding.forward embedding.py:78
     }
-    PK_TRY(add_fft_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, h->enc,
+    PK_TRY(add_fft_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, h->enc,
                          h->enc_after_g, h->enc_after_b));
-    PK_TRY(add_fft_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, h->dec,
+    PK_TRY(add_fft_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, h->dec,
                          h->dec_after_g, h->dec_after_b));
     PK_TRY(add_predictor(ar, P, "duration_predictor", c.duration_predictor_layers, A, c.duration_predictor_chans,
                          c.duration_predictor_kernel_size, h->dur));

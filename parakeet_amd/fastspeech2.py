@@ -41,8 +41,8 @@ class FastSpeech2:
             raise ValueError(f"{encoder_type} is not supported.")   # fastspeech2.py:187
         if decoder_type != "transformer":
             raise ValueError(f"{decoder_type} is not supported.")   # fastspeech2.py:268
-        if positionwise_layer_type != "conv1d":
-            raise NotImplementedError("only positionwise_layer_type='conv1d' is implemented")
+        if positionwise_layer_type not in ("conv1d", "linear", "conv1d-linear"):
+            raise NotImplementedError("Support only linear or conv1d.")   # encoder.py:169
         if encoder_concat_after or decoder_concat_after:
             raise NotImplementedError("concat_after=True is not implemented")
         self.idim, self.odim = idim, odim
@@ -56,6 +56,7 @@ class FastSpeech2:
         cfg.idim, cfg.odim, cfg.adim, cfg.aheads = idim, odim, adim, aheads
         cfg.elayers, cfg.eunits, cfg.dlayers, cfg.dunits = elayers, eunits, dlayers, dunits
         cfg.positionwise_conv_kernel_size = positionwise_conv_kernel_size
+        cfg.positionwise_layer_type = {"conv1d": 0, "linear": 1, "conv1d-linear": 2}[positionwise_layer_type]
         cfg.duration_predictor_layers = duration_predictor_layers
         cfg.duration_predictor_chans = duration_predictor_chans
         cfg.duration_predictor_kernel_size = duration_predictor_kernel_size

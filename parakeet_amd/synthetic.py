@@ -91,9 +91,10 @@ def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=Non
             for nm in ("q", "k", "v", "out"):
                 st[f"{p}.self_attn.linear_{nm}.weight"] = _xavier(rng, (A, A))
                 st[f"{p}.self_attn.linear_{nm}.bias"] = small(A)
-            st[f"{p}.feed_forward.w_1.weight"] = _xavier(rng, (units, A, k))
+            kind = cfg.get("positionwise_layer_type", "conv1d")   # encoder.py:145-170
+            st[f"{p}.feed_forward.w_1.weight"] = _xavier(rng, (A, units) if kind == "linear" else (units, A, k))
             st[f"{p}.feed_forward.w_1.bias"] = small(units)
-            st[f"{p}.feed_forward.w_2.weight"] = _xavier(rng, (A, units, k))
+            st[f"{p}.feed_forward.w_2.weight"] = _xavier(rng, (A, units, k) if kind == "conv1d" else (units, A))
             st[f"{p}.feed_forward.w_2.bias"] = small(A)
             ln(f"{p}.norm1", A)
             ln(f"{p}.norm2", A)

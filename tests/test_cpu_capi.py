@@ -50,5 +50,5 @@ def test_no_gpu_fails_loudly():
 def test_struct_sizes_match_header():
     from parakeet_amd import _capi
     assert C.sizeof(_capi.PwgCfg) == 4 * (11 + 8 + 1)
-    assert C.sizeof(_capi.Fs2Cfg) == 4 * 32
+    assert C.sizeof(_capi.Fs2Cfg) == 4 * 33
     assert C.sizeof(_capi.WfCfg) == 4 * (1 + 4 + 7)

@@ -41,6 +41,18 @@ def test_fastspeech2_multispeaker_oracle_matches_reference_source():
     assert a.shape != b.shape or np.abs(a - b).max() > 1e-3
 
 
+def test_fastspeech2_ffn_variants_oracle_matches_reference_source():
+    g = np.load(os.path.join(GOLD, "fastspeech2_ffn_variants.npz"))
+    for kind in ("linear", "conv1d-linear"):
+        cfg = dict(syn.FS2_LJSPEECH, positionwise_layer_type=kind)
+        state = syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), fixed_duration=2)
+        tag = kind.replace("-", "_")
+        for i in range(2):
+            mel = fs2.inference(state, g[f"{tag}_ids{i}"], cfg).numpy()
+            assert mel.shape == g[f"{tag}_mel{i}"].shape
+            assert np.abs(mel - g[f"{tag}_mel{i}"]).max() < 2e-5
+
+
 def test_speedyspeech_oracle_matches_reference_source():
     # baker configuration, both readings of Paddle's padding="same" (oracle/speedyspeech_ref.py)
     from oracle import speedyspeech_ref as ssr

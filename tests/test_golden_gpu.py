@@ -60,6 +60,23 @@ def test_fastspeech2_multispeaker_engine_matches_reference_source(kind):
         model.inference(g[f"{kind}_ids0"], spk_id=np.array([6]))
 
 
+@pytest.mark.parametrize("kind", ["linear", "conv1d-linear"])
+def test_fastspeech2_ffn_variants_engine_matches_reference_source(kind):
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    g = np.load(os.path.join(GOLD, "fastspeech2_ffn_variants.npz"))
+    cfg = dict(syn.FS2_LJSPEECH, positionwise_layer_type=kind)
+    model = FastSpeech2(80, 80, **cfg)
+    model.set_state_dict(syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), fixed_duration=2))
+    model.eval()
+    tag = kind.replace("-", "_")
+    outs = model.inference_batch([g[f"{tag}_ids0"], g[f"{tag}_ids1"]])
+    for i, o in enumerate(outs):
+        assert o.shape == g[f"{tag}_mel{i}"].shape
+        assert np.abs(o.numpy() - g[f"{tag}_mel{i}"]).mean() < 1e-4
+    with pytest.raises(NotImplementedError):
+        FastSpeech2(80, 80, **dict(cfg, positionwise_layer_type="conv2d"))
+
+
 def test_pwg_engine_matches_reference_source():
     from parakeet_amd.normalizer import ZScore
     from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference

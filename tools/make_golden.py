@@ -75,6 +75,26 @@ def golden_fastspeech2_multispeaker():
     print("fastspeech2 multi-speaker:", {k: v.shape for k, v in out.items() if "mel" in k})
 
 
+def golden_fastspeech2_ffn_variants():
+    """positionwise_layer_type "linear" and "conv1d-linear" (encoder.py:145-170); the LJSpeech recipe uses "conv1d"."""
+    fsm = ref_import.load("parakeet.models.fastspeech2.fastspeech2")
+    out = {"seed": np.array(2026)}
+    for kind in ("linear", "conv1d-linear"):
+        cfg = dict(syn.FS2_LJSPEECH, positionwise_layer_type=kind)
+        state = syn.fastspeech2_state(80, 80, cfg, seed=2026, fixed_duration=2)   # 2 frames per token
+        model = fsm.FastSpeech2(idim=80, odim=80, **cfg)
+        model.set_state_dict(state)
+        model.eval()
+        tag = kind.replace("-", "_")
+        for i in range(2):
+            ids = syn.phoneme_ids(7 + 3 * i, seed=700 + i)
+            with paddle.no_grad():
+                mel = model.inference(paddle.to_tensor(ids)).numpy()
+            out[f"{tag}_ids{i}"], out[f"{tag}_mel{i}"] = ids, mel.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fastspeech2_ffn_variants.npz"), **out)
+    print("fastspeech2 ffn variants:", {k: v.shape for k, v in out.items() if "mel" in k})
+
+
 def golden_pwg():
     pw = ref_import.load("parakeet.models.parallel_wavegan.parallel_wavegan")
     norm = ref_import.load("parakeet.modules.normalizer")
@@ -114,6 +134,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_fastspeech2()
     golden_fastspeech2_multispeaker()
+    golden_fastspeech2_ffn_variants()
     golden_pwg()
     if "--with-waveflow" in sys.argv or True:
         try:
