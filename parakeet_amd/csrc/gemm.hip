@@ -62,38 +62,60 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
         const float cs = a.cscale ? a.cscale[n] : 1.f;
         const float ch = a.cshift ? a.cshift[n] : 0.f;
         const bool to2 = a.nsplit > 0 && n >= a.nsplit;
+        // Phase 1: every load of the epilogue (row validity, residual / running sum, row map) is issued before
+        // the first store AND none of them depends on another loaded value (row indices are clamped instead of
+        // branching on validity).  Otherwise each lane pays one serialised memory round trip per element:
+        // load rowvalid -> wait -> branch -> load residual -> wait -> store, 32 times (measured on WaveFlow's
+        // res|skip projection: 64 us of a 64 us kernel).
+        float oldv[2][16];
+        int valid[2][16];    // 1 = store the value, 0 = store zero (gap row), -1 = no store
+        int mo[2][16];
+        const int m_last = a.M - 1;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = min(m0 + wm * 64 + mt * 32 + mfma_row(r, hi), m_last);
+                valid[mt][r] = a.rowvalid ? a.rowvalid[m] : 0;          // raw value for now
+                mo[mt][r] = a.out_rowmap && !to2 ? a.out_rowmap[m] : m;
+                if (to2) oldv[mt][r] = a.acc2 ? a.C2[(long)m * a.ldc2 + (n - a.nsplit)] : 0.f;
+                else oldv[mt][r] = a.res ? a.res[(long)m * a.ldr + n] : 0.f;
+            }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
-                if (m >= a.M) continue;
+                const bool gap = valid[mt][r] < 0;
+                valid[mt][r] = (m > m_last || mo[mt][r] < 0) ? -1 : (gap ? 0 : 1);
+                if (gap && to2) oldv[mt][r] = 0.f;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (valid[mt][r] < 0) continue;
+                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
                 float v = acc[mt][nt][r] + bias;
-                if (a.res_pos == PK_RES_BEFORE_ACT && a.res && !to2) v += a.res[(long)m * a.ldr + n];
+                if (a.res_pos == PK_RES_BEFORE_ACT && !to2) v += oldv[mt][r];
                 if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (a.act == PK_ACT_TANH) v = tanhf(v);
                 if (to2) {
-                    float* dst = a.C2 + (long)m * a.ldc2 + (n - a.nsplit);
-                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
-                    else if (a.acc2) v += *dst;
-                    *dst = v;
+                    v = valid[mt][r] ? v + oldv[mt][r] : 0.f;
+                    a.C2[(long)m * a.ldc2 + (n - a.nsplit)] = v;
                     continue;
                 }
                 if (a.res_pos == PK_RES_AFTER_ACT) {
-                    if (a.res) v += a.res[(long)m * a.ldr + n];
-                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                    v += oldv[mt][r];
+                    if (!valid[mt][r]) v = 0.f;
                     if (a.cscale) v = v * cs + ch;
                 } else {
                     if (a.cscale) v = v * cs + ch;
-                    if (a.res && a.res_pos == PK_RES_AFTER_AFFINE) v += a.res[(long)m * a.ldr + n];
-                    if (a.rowvalid && a.rowvalid[m] < 0) v = 0.f;
+                    if (a.res_pos == PK_RES_AFTER_AFFINE) v += oldv[mt][r];
+                    if (!valid[mt][r]) v = 0.f;
                 }
-                int mo = m;
-                if (a.out_rowmap) {
-                    mo = a.out_rowmap[m];
-                    if (mo < 0) continue;
-                }
-                a.C[(long)mo * a.ldc + n] = v;
+                a.C[(long)mo[mt][r] * a.ldc + n] = v;
             }
     }
 }
@@ -349,6 +371,61 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
         step(s, S0{}, S1{});
         if (s + 1 < nslabs) step(s + 1, S1{}, S2{});
     }
+    if (a.epi == PK_EPI_GATE_PROJ) {
+        // ---- stage 2: z = tanh(content + b) * sigmoid(gate + b) -> LDS, then out = z . W2 (K = 64, N = 128)
+        __syncthreads();   // every wave is done reading the last slab
+        {
+            const int col0 = wn * 64 + i;
+            const float b0 = a.bias ? a.bias[col0] : 0.f, b1 = a.bias ? a.bias[col0 + 32] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + mt * 32 + mfma_row(r, hi);
+                    float ca = acc[mt][0][r] + b0;
+                    const float cb = acc[mt][1][r] + b1;
+                    ca = fminf(fmaxf(ca, -10.f), 10.f);
+                    const float ea = __expf(-2.f * ca), eb = __expf(-cb);
+                    float v = (1.f - ea) / ((1.f + ea) * (1.f + eb));
+                    const int m = m0 + row;
+                    if (m >= a.M || (a.rowvalid && a.rowvalid[m] < 0)) v = 0.f;
+                    As[wn][row * A_LD + i] = v;   // z channel wn*32 + i = k-slab wn, k = i
+                }
+            const f16x8* w2 = reinterpret_cast<const f16x8*>(a.Wh2) + tid;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) Bs[c >> 2][tid + (c & 3) * 256] = w2[c * 256];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                read_split(sl, ks, ah, al);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f16x8 bh = Bs[sl][((ks * 2 + 0) * 4 + wn * 2 + nt) * 64 + lane];
+                    const f16x8 bl = Bs[sl][((ks * 2 + 1) * 4 + wn * 2 + nt) * 64 + lane];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        pk_gemm_args b = a;
+        b.epi = PK_EPI_STD;
+        b.bias = a.bias2;
+        b.act = PK_ACT_NONE;
+        gemm_epilogue(b, acc, m0, nblk, wm, wn, i, hi);
+        return;
+    }
     gemm_epilogue(a, acc, m0, nblk, wm, wn, i, hi);
 }
 }  // namespace
@@ -485,6 +562,8 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     if (a.wslabs_total <= 0) PK_FAIL(PK_EINVAL, "GEMM: wslabs_total not set");
     if (!a.A2) { a.A2 = a.A; a.lda2 = 0; }
     if (a.epi == PK_EPI_GATE && (a.N % 128 != 0)) PK_FAIL(PK_EUNSUPPORTED, "gated GEMM needs N %% 128 == 0");
+    if (a.epi == PK_EPI_GATE_PROJ && (!h3 || a.N != 128 || !a.Wh2))
+        PK_FAIL(PK_EUNSUPPORTED, "fused gate + projection needs the split-fp16 kernel, N == 128 and Wh2");
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
     const int nslabs = a.ntaps * (a.Cin / BK) + a.Cin2 / BK;
     // k_gemm<2> (two slabs per barrier, 64 KB LDS) measured slower on every FS2 / WaveFlow shape

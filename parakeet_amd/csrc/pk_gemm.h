@@ -15,7 +15,7 @@ constexpr int PK_GEMM_MAX_TAPS = 12;
 enum { PK_GEMM_MATH_F32 = 0, PK_GEMM_MATH_F16X3 = 1 };
 
 enum { PK_ACT_NONE = 0, PK_ACT_RELU = 1, PK_ACT_TANH = 2 };
-enum { PK_EPI_STD = 0, PK_EPI_GATE = 1 };
+enum { PK_EPI_STD = 0, PK_EPI_GATE = 1, PK_EPI_GATE_PROJ = 2 };
 enum { PK_RES_AFTER_ACT = 0, PK_RES_AFTER_AFFINE = 1, PK_RES_BEFORE_ACT = 2 };
 
 // C[r, n] = epilogue( sum_{tap, ci} A[r + tap - pad, ci] * W[tap*Cin + ci, n] )
@@ -61,6 +61,12 @@ struct pk_gemm_args {
     int epi = PK_EPI_STD;
     // PK_EPI_GATE: columns are packed so that the two N-subtiles of a wave hold (content, gate) of the
     //   same channel; stores tanh(content + b) * sigmoid(gate + b) to C[r, N/2 columns].
+    // PK_EPI_GATE_PROJ (split-fp16 kernel only, N == 128, i.e. 64 gated channels): the gated tile z[128][64]
+    //   never leaves the chip -- it is written to LDS and multiplied by the 64 x 128 matrix Wh2 (+ bias2) in
+    //   the same launch; the STD epilogue (res / nsplit / C2 / acc2 / rowvalid) then applies to that product.
+    //   WaveFlow: conv + gate (:228-262) followed by the res|skip 1x1 projection (:263-266) as one kernel.
+    const void* Wh2 = nullptr;   // pk_gemm_pack_h3 of the [64][128] projection
+    const float* bias2 = nullptr;
     // nsplit > 0: columns >= nsplit go to C2[r, n - nsplit] (+= if acc2) instead of C, without `res`.
     int nsplit = 0;
     float* C2 = nullptr;

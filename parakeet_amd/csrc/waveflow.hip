@@ -154,6 +154,7 @@ struct pk_wf {
     pk_dbuf arena16;
     int math = PK_GEMM_MATH_F16X3;
     unsigned long long seed = 0, rng_offset = 0;   // internal latent stream (z == NULL)
+    bool no_fuse = getenv("PK_WF_NO_FUSE") != nullptr;   // measurement switch: separate out_proj launches
     int mp = 96;              // mel channels padded to a multiple of 32 (GEMM K block of the condition)
     std::vector<WfFlowW> flows;
     std::vector<size_t> up_w;
@@ -487,6 +488,8 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out), F.b_logs,
                   F.b_b, cur + (long)perm[0] * pstride, nxt, h->W(F.w_in), h->W(F.b_in), hist_ptr(0, 1), rowvalid,
                   npos, 1);
+        // the fused kernel needs the 64-channel shape (one 128-column block) and the split-fp16 path
+        const bool fuse_proj = C == 64 && h->math == PK_GEMM_MATH_F16X3 && MP % PK_GEMM_HBK == 0 && !h->no_fuse;
         for (int i = 1; i < G; ++i) {
             const int slot = i % 3;
             for (int l = 0; l < NL; ++l) {
@@ -515,12 +518,28 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 g.Wh = h->arena16.as<uint16_t>() + L.w1h;
                 g.math = h->math;
                 g.bias = h->W(L.b1);
-                g.epi = PK_EPI_GATE;
-                g.C = zbuf;
-                g.ldc = C;
                 g.rowvalid = rowvalid;
                 g.M = npos;
                 g.N = 2 * C;
+                if (fuse_proj) {
+                    // conv + gate + res|skip projection in one launch: z never reaches HBM
+                    g.epi = PK_EPI_GATE_PROJ;
+                    g.Wh2 = h->arena16.as<uint16_t>() + L.w2h;
+                    g.bias2 = h->W(L.b2);
+                    g.res = hist_ptr(l, slot);
+                    g.ldr = C;
+                    g.C = hist_ptr(l + 1, slot);
+                    g.ldc = C;
+                    g.nsplit = C;
+                    g.C2 = skip;
+                    g.ldc2 = C;
+                    g.acc2 = l > 0;
+                    PK_TRY(pk_gemm_launch(ctx, "wf_gemm_conv_gate_proj", g));
+                    continue;
+                }
+                g.epi = PK_EPI_GATE;
+                g.C = zbuf;
+                g.ldc = C;
                 PK_TRY(pk_gemm_launch(ctx, "wf_gemm_conv_gate", g));
                 pk_gemm_args o;
                 o.A = zbuf;
