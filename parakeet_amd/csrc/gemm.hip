@@ -67,55 +67,57 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
         // branching on validity).  Otherwise each lane pays one serialised memory round trip per element:
         // load rowvalid -> wait -> branch -> load residual -> wait -> store, 32 times (measured on WaveFlow's
         // res|skip projection: 64 us of a 64 us kernel).
-        float oldv[2][16];
-        int valid[2][16];    // 1 = store the value, 0 = store zero (gap row), -1 = no store
-        int mo[2][16];
+        // (done in batches of EB rows: EB values per lane in flight; 8 keeps k_gemm<1> at 3 waves per SIMD)
+        constexpr int EB = 8;
         const int m_last = a.M - 1;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = min(m0 + wm * 64 + mt * 32 + mfma_row(r, hi), m_last);
-                valid[mt][r] = a.rowvalid ? a.rowvalid[m] : 0;          // raw value for now
-                mo[mt][r] = a.out_rowmap && !to2 ? a.out_rowmap[m] : m;
-                if (to2) oldv[mt][r] = a.acc2 ? a.C2[(long)m * a.ldc2 + (n - a.nsplit)] : 0.f;
-                else oldv[mt][r] = a.res ? a.res[(long)m * a.ldr + n] : 0.f;
-            }
+            for (int rb = 0; rb < 16; rb += EB) {
+                float oldv[EB];
+                int valid[EB];    // 1 = store the value, 0 = store zero (gap row), -1 = no store
+                int mo[EB];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
-                const bool gap = valid[mt][r] < 0;
-                valid[mt][r] = (m > m_last || mo[mt][r] < 0) ? -1 : (gap ? 0 : 1);
-                if (gap && to2) oldv[mt][r] = 0.f;
-            }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (valid[mt][r] < 0) continue;
-                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
-                float v = acc[mt][nt][r] + bias;
-                if (a.res_pos == PK_RES_BEFORE_ACT && !to2) v += oldv[mt][r];
-                if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (a.act == PK_ACT_TANH) v = tanhf(v);
-                if (to2) {
-                    v = valid[mt][r] ? v + oldv[mt][r] : 0.f;
-                    a.C2[(long)m * a.ldc2 + (n - a.nsplit)] = v;
-                    continue;
+                for (int q = 0; q < EB; ++q) {
+                    const int m = min(m0 + wm * 64 + mt * 32 + mfma_row(rb + q, hi), m_last);
+                    valid[q] = a.rowvalid ? a.rowvalid[m] : 0;          // raw value for now
+                    mo[q] = a.out_rowmap && !to2 ? a.out_rowmap[m] : m;
+                    if (to2) oldv[q] = a.acc2 ? a.C2[(long)m * a.ldc2 + (n - a.nsplit)] : 0.f;
+                    else oldv[q] = a.res ? a.res[(long)m * a.ldr + n] : 0.f;
                 }
-                if (a.res_pos == PK_RES_AFTER_ACT) {
-                    v += oldv[mt][r];
-                    if (!valid[mt][r]) v = 0.f;
-                    if (a.cscale) v = v * cs + ch;
-                } else {
-                    if (a.cscale) v = v * cs + ch;
-                    if (a.res_pos == PK_RES_AFTER_AFFINE) v += oldv[mt][r];
-                    if (!valid[mt][r]) v = 0.f;
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    const int m = m0 + wm * 64 + mt * 32 + mfma_row(rb + q, hi);
+                    const bool gap = valid[q] < 0;
+                    valid[q] = (m > m_last || mo[q] < 0) ? -1 : (gap ? 0 : 1);
+                    if (gap && to2) oldv[q] = 0.f;
                 }
-                a.C[(long)mo[mt][r] * a.ldc + n] = v;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    if (valid[q] < 0) continue;
+                    const int r = rb + q;
+                    const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
+                    float v = acc[mt][nt][r] + bias;
+                    if (a.res_pos == PK_RES_BEFORE_ACT && !to2) v += oldv[q];
+                    if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (a.act == PK_ACT_TANH) v = tanhf(v);
+                    if (to2) {
+                        v = valid[q] ? v + oldv[q] : 0.f;
+                        a.C2[(long)m * a.ldc2 + (n - a.nsplit)] = v;
+                        continue;
+                    }
+                    if (a.res_pos == PK_RES_AFTER_ACT) {
+                        v += oldv[q];
+                        if (!valid[q]) v = 0.f;
+                        if (a.cscale) v = v * cs + ch;
+                    } else {
+                        if (a.cscale) v = v * cs + ch;
+                        if (a.res_pos == PK_RES_AFTER_AFFINE) v += oldv[q];
+                        if (!valid[q]) v = 0.f;
+                    }
+                    a.C[(long)mo[q] * a.ldc + n] = v;
+                }
             }
     }
 }
@@ -123,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
 // SPI = K slabs (of 16) consumed per barrier: 2 halves the barrier / LDS-turnaround count on long K
 // (64 KB of LDS, two blocks per CU); 1 keeps small problems at 32 KB.
 template <int SPI>
-__global__ __launch_bounds__(256) void k_gemm(pk_gemm_args a) {
+__global__ __launch_bounds__(256, 3) void k_gemm(pk_gemm_args a) {
     __shared__ __attribute__((aligned(16))) float As[2][SPI][BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][SPI][BK * BN];
     const int tid = threadIdx.x;
