@@ -82,41 +82,23 @@ __global__ void k_zero_gaps(float* buf, const int* gap_start, int gap, int rows,
     if (i < gap && row < rows) buf[xoff((long)gap_start[g] + i) + row * XBLK] = 0.f;
 }
 
-// conv_in: ZScore-normalise (PWGInference :773), replicate-pad by ctx (:518),
-// Conv1D(aux->aux, k=2ctx+1, no bias) (:188-192,214).
-// mel (sumL, AUX) packed row-major; wT [(ci*k + tap)][co]; out c0[f][co] row-major (frame rate).
-__global__ void k_pwg_convin(const float* __restrict__ mel, const float* __restrict__ wT,
-                             const float* __restrict__ mu, const float* __restrict__ sigma,
-                             int use_norm, const int* __restrict__ frame_utt,
-                             const int* __restrict__ cuL, int ctx, int has_ctx, float* __restrict__ out) {
-    extern __shared__ float s_in[];  // (2ctx+1) * AUX normalised inputs
-    const int f = blockIdx.x;        // global frame index
-    const int b = frame_utt[f];
-    const int lo = cuL[b], hi = cuL[b + 1];
-    const int k = 2 * ctx + 1;
-    for (int i = threadIdx.x; i < k * AUX; i += blockDim.x) {
-        int tap = i / AUX, ci = i % AUX;
-        int src;
-        if (has_ctx) {
-            // forward(x, c): c already carries ctx frames on both sides (:201-216, "valid" conv)
-            src = f + 2 * ctx * b + tap;
-        } else {
-            src = f + tap - ctx;
-            src = src < lo ? lo : (src >= hi ? hi - 1 : src);  // Pad1D(ctx, 'replicate') of inference (:518)
-        }
-        float v = mel[(long)src * AUX + ci];
-        if (use_norm) v = (v - mu[ci]) / sigma[ci];
-        s_in[tap * AUX + ci] = v;
+// conv_in, step 1: ZScore-normalise (PWGInference :773) and lay the mel frames out as a padded row timeline
+// for the GEMM of step 2: utterance b owns rows [cuL[b] + 2*ctx*b, +frames_b + 2*ctx); the ctx rows on either
+// side are Pad1D(ctx, 'replicate') of inference (:518) or, for forward(x, c), the context frames the caller's c
+// already carries (:201-216).  Step 2 is Conv1D(aux -> aux, k = 2ctx+1, no bias) (:188-192,214) as one implicit
+// GEMM (K = (2ctx+1) * 80) whose row map drops the padded rows.  prow_src[row] = source mel row.
+__global__ void k_pwg_convin_prep(const float* __restrict__ mel, const float* __restrict__ mu,
+                                  const float* __restrict__ sigma, int use_norm, const int* __restrict__ prow_src,
+                                  int rows, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    const int c = threadIdx.x;
+    if (c >= AUX) return;
+    float v = 0.f;
+    if (r < rows) {
+        v = mel[(long)prow_src[r] * AUX + c];
+        if (use_norm) v = (v - mu[c]) / sigma[c];
     }
-    __syncthreads();
-    const int co = threadIdx.x;
-    if (co < AUX) {
-        float acc = 0.f;
-        for (int ci = 0; ci < AUX; ++ci)
-            for (int tap = 0; tap < k; ++tap)
-                acc = fmaf(wT[(ci * k + tap) * AUX + co], s_in[tap * AUX + ci], acc);
-        out[(long)f * AUX + co] = acc;
-    }
+    out[(long)r * AUX + c] = v;
 }
 
 // first_conv: Conv1D(1 -> R, k=1, bias) (:401-402,464) from packed noise into the timeline.
@@ -795,6 +777,61 @@ __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
     if (hi == 0) a.wav[(long)tile * TILE + wave * WAVE_T + j] = part + a.b2;
 }
 
+// Split-fp16 variant (default math): the 64 -> 64 conv as 3-term split-fp16 MFMA sums (24 x 32-cycle MFMAs
+// per wave instead of 64 x 64-cycle ones), all 32 skip values of a lane requested before the first MFMA,
+// W fragments ([ks 4][part 2][co-tile 2][lane][8 halves] = 16 KB) staged in LDS once per workgroup.  The
+// operand channel of element e of k-step ks is 32*(ks>>1) + mfma_row(8*(ks&1) + e, hi), as in the layer kernel.
+__global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
+    __shared__ __attribute__((aligned(16))) f16x8 wl[4 * 2 * 2 * 64];
+    {
+        const f16x8* src = reinterpret_cast<const f16x8*>(a.w1);
+        for (int i = threadIdx.x; i < 4 * 2 * 2 * 64; i += 512) wl[i] = src[i];
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31;
+    const int hi = lane >> 5;
+    const int tile = blockIdx.x;
+    const long t = (long)a.tile_t0[tile] + wave * WAVE_T + j;
+    const float* sb = a.skip + xoff(t) + 4 * hi * XBLK;
+    float sv[4][8];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            sv[ks][e] = sb[(long)(32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, 0)) * XBLK];
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = a.b1[32 * q + mfma_row(r, hi)];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(sv[ks][e] * a.scale, 0.f);   // ReLU(skips * sqrt(1/layers)) (:469-471)
+        f16x8 bh, bl;
+        split_x8<f16x8, _Float16, true>(v, bh, bl);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f16x8 ah = wl[((ks * 2 + 0) * 2 + q) * 64 + lane];
+            const f16x8 al = wl[((ks * 2 + 1) * 2 + q) * 64 + lane];
+            acc[q] = mfma16(ah, bh, acc[q]);
+            acc[q] = mfma16(al, bh, acc[q]);
+            acc[q] = mfma16(ah, bl, acc[q]);
+        }
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            part = fmaf(a.w2[32 * q + mfma_row(r, hi)], fmaxf(acc[q][r], 0.f), part);
+    part += __shfl_xor(part, 32);
+    if (hi == 0) a.wav[(long)tile * TILE + wave * WAVE_T + j] = part + a.b2;
+}
+
 }  // namespace
 
 // ================================================================== host side
@@ -814,10 +851,10 @@ struct pk_pwg {
     pk_dbuf d_w1b, d_w2b, d_w1h, d_w2h;   // split (hi, lo) A fragments for k_pwg_layer_b3: bf16 / fp16 parts
     int math = PK_PWG_MATH_F16X3;   // default: fp32-equivalent error (5e-7), 1.9x faster than the fp32 matrix pipe
     pk_dbuf d_waux;                 // packed GEMM weight [AUX] x [layers*G]
-    pk_dbuf d_l1, d_l1b, d_l2;
+    pk_dbuf d_l1, d_l1b, d_l2, d_l1h;   // d_l1h: split-fp16 fragments of last_conv_layers.1
     float l2_bias = 0.f;
     // workspace
-    pk_dbuf ws_mel, ws_noise, ws_wav, ws_c0, ws_P, ws_x0, ws_x1, ws_skip, ws_dbg;
+    pk_dbuf ws_mel, ws_noise, ws_wav, ws_c0, ws_cin, ws_P, ws_x0, ws_x1, ws_skip, ws_dbg;
     pk_dbuf ws_tab;   // int tables
     // last call layout (for debug reads)
     std::vector<int> last_frames, last_toff, last_cuL;
@@ -1011,16 +1048,15 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
     PK_TRY(pk_get_vector(h->params, "first_conv.bias", R, b));
     PK_TRY(pk_upload(ctx, h->d_first_w, w.data(), R * sizeof(float)));
     PK_TRY(pk_upload(ctx, h->d_first_b, b.data(), R * sizeof(float)));
-    // conv_in -> [(ci*k + tap)][co]
+    // conv_in -> implicit-GEMM weight [K = tap*AUX + ci][N = AUX]
     const int kin = 2 * c.aux_context_window + 1;
+    if (kin > PK_GEMM_MAX_TAPS) PK_FAIL(PK_EUNSUPPORTED, "PWG: aux_context_window %d too wide", c.aux_context_window);
     PK_TRY(pk_get_weight(h->params, "upsample_net.conv_in", {AUX, AUX, kin}, w));
     {
-        std::vector<float> wT((size_t)AUX * kin * AUX);
-        for (int co = 0; co < AUX; ++co)
-            for (int ci = 0; ci < AUX; ++ci)
-                for (int tap = 0; tap < kin; ++tap)
-                    wT[((size_t)ci * kin + tap) * AUX + co] = w[((size_t)co * AUX + ci) * kin + tap];
-        PK_TRY(pk_upload(ctx, h->d_convin_wT, wT.data(), wT.size() * sizeof(float)));
+        std::vector<float> kn, packed;
+        pk_conv_to_kn(w.data(), AUX, AUX, kin, kn);
+        pk_gemm_pack(kn.data(), AUX * kin, AUX, packed);
+        PK_TRY(pk_upload(ctx, h->d_convin_wT, packed.data(), packed.size() * sizeof(float)));
     }
     // composite upsampler table from the stage FIRs up_layers.{2i+1}.weight (1,1,1,2s+1):
     // class (a, b) = (min(frames before, 2), min(frames after, 2)); a canonical utterance with exactly
@@ -1157,6 +1193,21 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                     A[((size_t)cp * 64 + lane) * 2 + q] = w1[(size_t)(32 * q + i) * SK + 2 * cp + hi];
             }
         PK_TRY(pk_upload(ctx, h->d_l1, A.data(), A.size() * sizeof(float)));
+        {
+            std::vector<uint16_t> Ah((size_t)4 * 2 * 2 * 64 * 8);
+            for (int ks = 0; ks < 4; ++ks)
+                for (int q = 0; q < 2; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int i = lane & 31, hi = lane >> 5;
+                            const int ci = 32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, hi);
+                            uint16_t bh, bl;
+                            split16_host(w1[(size_t)(32 * q + i) * SK + ci], true, bh, bl);
+                            Ah[((((size_t)ks * 2 + 0) * 2 + q) * 64 + lane) * 8 + e] = bh;
+                            Ah[((((size_t)ks * 2 + 1) * 2 + q) * 64 + lane) * 8 + e] = bl;
+                        }
+            PK_TRY(pk_upload(ctx, h->d_l1h, Ah.data(), Ah.size() * sizeof(uint16_t)));
+        }
         PK_TRY(pk_upload(ctx, h->d_l1b, b1.data(), SK * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_l2, w2.data(), SK * sizeof(float)));
         h->l2_bias = b2[0];
@@ -1214,7 +1265,27 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             tile_cls[cuL[b] + f] = before * 3 + after;
         }
     const size_t o_futt = push(frame_utt), o_tile = push(tile_t0), o_cls = push(tile_cls);
+    (void)o_futt;
     h->last_o_cls = o_cls;
+    // conv_in's padded row timeline (k_pwg_convin_prep): source mel row and destination c0 row (-1: padding)
+    const int cw = c.aux_context_window;
+    const int rows_p = sumL + 2 * cw * B;
+    const int rows_p_alloc = ((rows_p + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM;
+    std::vector<int> prow_src(rows_p_alloc, 0), prow_out(rows_p_alloc, -1);
+    for (int b = 0; b < B; ++b) {
+        const int r0 = cuL[b] + 2 * cw * b;
+        for (int jr = 0; jr < frames[b] + 2 * cw; ++jr) {
+            int f = jr - cw;
+            if (flags & PK_PWG_C_HAS_CONTEXT) {
+                prow_src[r0 + jr] = r0 + jr;   // c already carries the context frames
+            } else {
+                const int fc = f < 0 ? 0 : (f >= frames[b] ? frames[b] - 1 : f);
+                prow_src[r0 + jr] = cuL[b] + fc;
+            }
+            if (f >= 0 && f < frames[b]) prow_out[r0 + jr] = cuL[b] + f;
+        }
+    }
+    const size_t o_psrc = push(prow_src), o_pout = push(prow_out);
     PK_TRY(h->ws_tab.reserve(tab.size() * sizeof(int)));
     PK_HIP(hipMemcpyAsync(h->ws_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     PK_HIP(hipStreamSynchronize(ctx->stream));  // tab is a stack vector
@@ -1266,11 +1337,26 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     }
     // ---- conditioning at frame rate: conv_in, then all layers' aux 1x1 convs as one GEMM
     {
-        const int kin = 2 * c.aux_context_window + 1;
-        PK_LAUNCH(ctx, "pwg_convin", k_pwg_convin, dim3(sumL), dim3(128), kin * AUX * sizeof(float), d_mel,
-                  h->d_convin_wT.as<float>(), h->d_mu.as<float>(), h->d_sigma.as<float>(),
-                  h->use_norm ? 1 : 0, d_tab + o_futt, d_tab + o_cuL, c.aux_context_window,
-                  (flags & PK_PWG_C_HAS_CONTEXT) ? 1 : 0, c0);
+        const int kin = 2 * cw + 1;
+        PK_TRY(h->ws_cin.reserve((size_t)(rows_p_alloc + 2 * P_LEAD) * AUX * 4));
+        float* cin = h->ws_cin.as<float>() + (size_t)P_LEAD * AUX;
+        PK_LAUNCH(ctx, "pwg_convin_prep", k_pwg_convin_prep, dim3(rows_p_alloc), dim3(128), 0, d_mel,
+                  h->d_mu.as<float>(), h->d_sigma.as<float>(), h->use_norm ? 1 : 0, d_tab + o_psrc, rows_p, cin);
+        {
+            pk_gemm_args g;
+            g.A = cin;
+            g.lda = AUX;
+            g.Wp = h->d_convin_wT.as<float>();
+            g.C = c0;
+            g.ldc = AUX;
+            g.M = rows_p;
+            g.N = AUX;
+            g.Cin = AUX;
+            g.taps = kin;
+            g.pad = cw;
+            g.out_rowmap = d_tab + o_pout;
+            PK_TRY(pk_gemm_launch(ctx, "pwg_convin_gemm", g));
+        }
         pk_gemm_args g;
         g.A = c0;
         g.lda = AUX;
@@ -1361,7 +1447,12 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         a.tile_t0 = d_tab + o_tile;
         a.Ttot = Ttot;
         a.wav = d_wav;
-        PK_LAUNCH(ctx, "pwg_last", k_pwg_last, dim3(sumL), dim3(512), 0, a);
+        if (h->math == PK_PWG_MATH_F32) {
+            PK_LAUNCH(ctx, "pwg_last", k_pwg_last, dim3(sumL), dim3(512), 0, a);
+        } else {
+            a.w1 = reinterpret_cast<const float*>(h->d_l1h.as<char>());
+            PK_LAUNCH(ctx, "pwg_last_h3", k_pwg_last_h3, dim3(sumL), dim3(512), 0, a);
+        }
     }
     if (flags & PK_HOST_IO) {
         PK_HIP(hipMemcpyAsync(wav, d_wav, (size_t)sumS * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1413,8 +1504,8 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_uptab, &h->d_mu, &h->d_sigma,
-                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1b, &h->d_l2,
-                       &h->ws_mel, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
+                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1h, &h->d_l1b, &h->d_l2,
+                       &h->ws_mel, &h->ws_cin, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
                        &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab};
     for (auto* b : bufs) b->release();
     delete h;
