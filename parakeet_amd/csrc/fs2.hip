@@ -221,6 +221,139 @@ __global__ __launch_bounds__(256, 1) void k_attention(AttnArgs a) {
     }
 }
 
+// Split-fp16 variant (default math): the two contractions of k_attention as 3-term split-fp16 MFMA sums
+// (v_mfma_f32_32x32x16_f16, fp32 accumulate; softmax and all sums in fp32): 72 x 32-cycle MFMAs per 32-key
+// tile instead of 192 x 64-cycle ones.  Q is split once per wave; K, P and V tiles are split in registers.
+//   S^T = K . Q^T : A = K rows (lane: key j, k = d0 + 8*hi + e -> 32 contiguous bytes), B = Q rows, same k
+//   O   = P . V   : A = P, element e of k-step s is accumulator register 8*s + e of S (K-permutation chaining),
+//                   B = V[key(8*s + e, hi)][32*dt + j]
+typedef _Float16 at_f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 at_pkh2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void at_split8(const float (&v)[8], at_f16x8& hi, at_f16x8& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const at_pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+        hi[2 * p] = (_Float16)h[0];
+        hi[2 * p + 1] = (_Float16)h[1];
+        lo[2 * p] = (_Float16)(v[2 * p] - (float)h[0]);
+        lo[2 * p + 1] = (_Float16)(v[2 * p + 1] - (float)h[1]);
+    }
+}
+__device__ __forceinline__ f32x16 at_mfma3(at_f16x8 ah, at_f16x8 al, at_f16x8 bh, at_f16x8 bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+}
+
+template <int DK>
+__global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
+    constexpr int KS = DK / 16;  // k-steps of the QK^T product
+    constexpr int DT = DK / 32;  // 32-wide tiles of the value dimension
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = a.seg_len[b], start = a.seg_start[b];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= len) return;
+    const int j = lane & 31, hi = lane >> 5;
+    const long ld = a.ld;
+    const float* base = a.qkv + (long)start * ld + h * DK;
+
+    at_f16x8 qh[KS], ql[KS];
+    {
+        const int qr = min(q0 + j, len - 1);
+        const float* qp = base + (long)qr * ld + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            at_split8(v, qh[ks], ql[ks]);
+        }
+    }
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < len; k0 += 32) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        {
+            const int kr = min(k0 + j, len - 1);
+            const float* kp = base + a.D + (long)kr * ld + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(kp + 16 * ks);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(kp + 16 * ks + 4);
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                at_f16x8 kh, kl;
+                at_split8(v, kh, kl);
+                S = at_mfma3(kh, kl, qh[ks], ql[ks], S);
+            }
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + mfma_row(r, hi);
+            S[r] = (key < len) ? S[r] * a.scale : -INFINITY;
+            mloc = fmaxf(mloc, S[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = expf(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[r] = expf(S[r] - m_new);
+            lsum += S[r];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ar = __shfl(alpha, mfma_row(r, hi));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt][r] *= ar;
+        }
+        const float* vp = base + 2 * a.D + j;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pv[8];
+            long voff[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pv[e] = S[8 * s2 + e];
+                voff[e] = (long)min(k0 + mfma_row(8 * s2 + e, hi), len - 1) * ld;
+            }
+            at_f16x8 ph, pl;
+            at_split8(pv, ph, pl);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                float vv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = vp[voff[e] + 32 * dt];
+                at_f16x8 vh, vl;
+                at_split8(vv, vh, vl);
+                O[dt] = at_mfma3(ph, pl, vh, vl, O[dt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + mfma_row(r, hi);
+        const float lr = __shfl(l_run, mfma_row(r, hi));
+        if (q < len) {
+            float* o = a.out + (long)(start + q) * a.ldo + h * DK + j;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] / lr;
+        }
+    }
+}
+
 // Predictor heads: Linear(C -> 1) per row (+ masked_fill) and, for the duration
 // predictor in inference, clip(round(exp(x) - offset), min=0) and the alpha speed
 // scaling round(d * alpha)  (duration_predictor.py:95-103, length_regulator.py:85-88;
@@ -833,6 +966,16 @@ static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float*
     a.D = A;
     a.scale = (float)(1.0 / std::sqrt((double)dk));
     dim3 grid(pk_div_up(maxlen, 128), heads, tl.B);
+    if (h->math == PK_GEMM_MATH_F16X3) {
+        switch (dk) {
+            case 64: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3<64>, grid, dim3(256), 0, a); break;
+            case 96: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3<96>, grid, dim3(256), 0, a); break;
+            case 128: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3<128>, grid, dim3(256), 0, a); break;
+            case 192: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3<192>, grid, dim3(256), 0, a); break;
+            default: PK_FAIL(PK_EUNSUPPORTED, "attention head size %d", dk);
+        }
+        return PK_OK;
+    }
     switch (dk) {
         case 64: PK_LAUNCH(h->ctx, "fs2_attention", k_attention<64>, grid, dim3(256), 0, a); break;
         case 96: PK_LAUNCH(h->ctx, "fs2_attention", k_attention<96>, grid, dim3(256), 0, a); break;
