@@ -52,3 +52,11 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_capi.PwgCfg) == 4 * (11 + 8 + 1)
     assert C.sizeof(_capi.Fs2Cfg) == 4 * 33
     assert C.sizeof(_capi.WfCfg) == 4 * (1 + 4 + 7)
+
+
+def test_smoke_config_subset_is_valid():
+    """__graft_entry__.smoke() builds the oracle's config from its own; optional oracle keys must not break it."""
+    import __graft_entry__ as g
+    import inspect
+    src = inspect.getsource(g.smoke)
+    assert "if k in fcfg" in src
