@@ -165,3 +165,32 @@ class LogMelFBank:
 
     def get_log_mel_fbank_batch(self, wavs, base="10"):
         return [wrap(o) for o in self._engine(base).run(list(wavs), 2)]
+
+
+def write_wav(path, wav, samplerate, subtype="PCM_16"):
+    """Minimal stand-in for the ``soundfile.write(path, wav.numpy(), samplerate=fs)`` at the end of the
+    synthesis recipes (examples/fastspeech2/ljspeech/synthesize_e2e.py:104-107): RIFF/WAVE, mono or
+    (T, C) float input in [-1, 1].  "PCM_16" (libsndfile's default for .wav: clip, scale by 32767, round to
+    nearest) or "FLOAT" (32-bit IEEE samples, lossless)."""
+    import struct
+    x = np.asarray(wav.cpu() if isinstance(wav, torch.Tensor) else wav, dtype=np.float32)
+    if x.ndim == 1:
+        x = x[:, None]
+    if x.ndim != 2:
+        raise ValueError("write_wav: expected (T,) or (T, channels)")
+    n, ch = x.shape
+    if subtype == "PCM_16":
+        data = np.rint(np.clip(x, -1.0, 1.0) * 32767.0).astype("<i2").tobytes()
+        fmt, bits = 1, 16
+    elif subtype == "FLOAT":
+        data = x.astype("<f4").tobytes()
+        fmt, bits = 3, 32
+    else:
+        raise ValueError(f"write_wav: unsupported subtype {subtype!r}")
+    block = ch * bits // 8
+    header = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, fmt, ch, int(samplerate), int(samplerate) * block, block, bits) + b"data" + struct.pack(
+        "<I", len(data))
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(data)

@@ -45,3 +45,20 @@ def test_product_filterbank_equals_oracle():
         b = audio_ref.mel_filterbank(*args)
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
+
+
+def test_write_wav_roundtrip(tmp_path):
+    import wave
+    from parakeet_amd.audio import write_wav
+    rng = np.random.default_rng(0)
+    x = np.clip(rng.normal(scale=0.4, size=2205), -1.5, 1.5).astype(np.float32)
+    p = tmp_path / "a.wav"
+    write_wav(p, x.reshape(-1, 1), 22050)
+    with wave.open(str(p), "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 22050, 2205)
+        pcm = np.frombuffer(w.readframes(2205), dtype="<i2")
+    assert np.array_equal(pcm, np.rint(np.clip(x, -1, 1) * 32767).astype(np.int16))
+    write_wav(tmp_path / "f.wav", x, 22050, subtype="FLOAT")
+    raw = (tmp_path / "f.wav").read_bytes()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE" and len(raw) == 44 + 4 * 2205
+    assert np.array_equal(np.frombuffer(raw[44:], dtype="<f4"), x)

@@ -52,3 +52,33 @@ def test_end_to_end_from_checkpoint_files(tmp_path):
     wav2 = PWGInference(ZScore(pmu, psd), ref_voc)(mel2, noise=noise).numpy()
     assert np.array_equal(mel.numpy(), mel2.numpy())
     assert np.array_equal(wav, wav2) and wav.shape == (33 * 256, 1)
+
+
+def test_example_recipe_script_writes_wavs(tmp_path):
+    """examples/synthesize_e2e.py (the reference recipe's arguments) on a synthetic checkpoint directory."""
+    import subprocess
+    import sys
+    import wave
+    fs2_state, pwg_state = syn.fastspeech2_state(fixed_duration=2), syn.pwg_state(weight_norm=True)
+    with open(tmp_path / "fs2.pdz", "wb") as f:
+        pickle.dump({"main_params": {k: ("t", v) for k, v in fs2_state.items()}}, f, protocol=2)
+    with open(tmp_path / "pwg.pdz", "wb") as f:
+        pickle.dump({"generator_params": dict(pwg_state)}, f, protocol=4)
+    np.save(tmp_path / "speech_stats.npy", np.stack(syn.mel_stats(seed=5)))
+    np.save(tmp_path / "pwg_stats.npy", np.stack(syn.mel_stats(seed=6)))
+    phones = ["<pad>", "<unk>", "sp"] + ["P%d" % i for i in range(76)] + ["<eos>"]
+    (tmp_path / "phone_id_map.txt").write_text("".join(f"{p} {i}\n" for i, p in enumerate(phones)))
+    (tmp_path / "sentences.txt").write_text("001 P1 P2 , P3 P40\n002 P7 XX P9 P10 P11 P12 .\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "synthesize_e2e.py"),
+                        "--fastspeech2-config", os.path.join(FIX, "fastspeech2_ljspeech.yaml"),
+                        "--fastspeech2-checkpoint", str(tmp_path / "fs2.pdz"),
+                        "--fastspeech2-stat", str(tmp_path / "speech_stats.npy"),
+                        "--pwg-config", os.path.join(FIX, "pwg_ljspeech.yaml"),
+                        "--pwg-checkpoint", str(tmp_path / "pwg.pdz"), "--pwg-stat", str(tmp_path / "pwg_stats.npy"),
+                        "--phones-dict", str(tmp_path / "phone_id_map.txt"), "--text", str(tmp_path / "sentences.txt"),
+                        "--output-dir", str(tmp_path / "out")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for utt, n_tok in (("001", 5), ("002", 7)):
+        with wave.open(str(tmp_path / "out" / f"{utt}.wav"), "rb") as w:
+            assert w.getframerate() == 22050 and w.getnframes() == n_tok * 2 * 256
