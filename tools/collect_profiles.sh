@@ -20,7 +20,7 @@ python - <<PY
 import json
 d = json.load(open("$OUT/pmc_pwg.json"))
 LK = [k for k in d if k.startswith("k_pwg_layer") and "false" in k][0]
-L = d[LK]; F = d["k_pwg_first"]; Z = d["k_pwg_last"]
+L = d[LK]; F = d["k_pwg_first"]; Z = d.get("k_pwg_last_h3") or d["k_pwg_last"]
 n = 32 * 163840
 wcal = F["WRITE_SIZE"] * 1024 / (64 * 4 * n)      # known bytes: 64 channels x 4 B per sample written
 rcal = Z["FETCH_SIZE"] * 1024 / (64 * 4 * n)      # known bytes: 64 channels x 4 B per sample read (same dword-per-lane pattern)
@@ -31,7 +31,7 @@ prof_key = ("pwg_layer_h3" if targs[1] == "true" else "pwg_layer_b3") if "b3" in
 out = {"kernel": LK, "prof_key": prof_key, "hbm_bytes_per_launch": hbm,
        "fetch_size_kb": L["FETCH_SIZE"], "write_size_kb": L["WRITE_SIZE"],
        "fetch_calibration": rcal, "write_calibration": wcal,
-       "calibration_note": "FETCH_SIZE calibrated on k_pwg_last (reads exactly 64x4 B/sample with the same dword-per-lane, 128-B-segment pattern), WRITE_SIZE on k_pwg_first (writes exactly 64x4 B/sample); MI355X_MICROARCH.md HBM section: FETCH_SIZE under-counts wide streams by 2x on gfx950",
+       "calibration_note": "FETCH_SIZE calibrated on k_pwg_last[_h3] (reads exactly 64x4 B/sample with the same dword-per-lane, 128-B-segment pattern), WRITE_SIZE on k_pwg_first (writes exactly 64x4 B/sample); MI355X_MICROARCH.md HBM section: FETCH_SIZE under-counts wide streams by 2x on gfx950",
        "mfma_busy_frac": L["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * L["GRBM_GUI_ACTIVE"] / 8),
        "effective_clock_ghz": clk / 1e9,
        "wait_any_frac": L["SQ_WAIT_ANY"] / L["SQ_WAVE_CYCLES"],
