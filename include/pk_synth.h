@@ -177,7 +177,12 @@ typedef struct {
     int32_t num_speakers;                /* 0 with spk_embed_dim: only external embeddings (spembs) */
     int32_t spk_embed_dim;               /* 0 = single speaker */
     int32_t spk_embed_integration_type;  /* 0 = "add", 1 = "concat" */
-    int32_t tone_embed_dim;              /* 0 only (no FastSpeech2 recipe uses tones) */
+    /* tone embedding (fastspeech2.py:153-157,197-202,404-408): tone_embedding_table [num_tones, tone_embed_dim]
+     * (padding_idx 0) + tone_projection; only integration type "add" (0) -- with the 1-D tone ids that
+     * FastSpeech2.inference forwards, the reference's "concat" branch (:606-610) cannot broadcast. */
+    int32_t num_tones;
+    int32_t tone_embed_dim;              /* 0 = no tone embedding */
+    int32_t tone_embed_integration_type; /* 0 = "add" only */
 } pk_fs2_cfg;
 
 int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out);
@@ -200,6 +205,10 @@ int pk_fs2_finalize(pk_fs2* h);
  * called) = no integration, as when the reference gets neither.  B must equal the batch of that call;
  * the setting is consumed by it. */
 int pk_fs2_set_speakers(pk_fs2* h, const int64_t* spk_id, const float* spembs, int32_t B);
+/* Tone conditioning of the NEXT pk_fs2_encode call (:404-408, _integrate_with_tone_embed :588-604 with the
+ * 1-D tone ids of FastSpeech2.inference: hs[t] += tone_projection(normalize(tone_embedding_table[tone[t]]))).
+ * tone_id: HOST int64 packed by utterance like the token ids (n = sum of token counts); NULL clears. */
+int pk_fs2_set_tones(pk_fs2* h, const int64_t* tone_id, int64_t n);
 /* Phase 1 of inference (_forward :390-432): encoder, pitch/energy/duration predictors, prefix
  * sums.  ids: HOST int64, packed by utterance (sum(tok_lens)); tok_lens: HOST (B).
  * alpha = LengthRegulator speed control.  out_frames (HOST, B) receives the number of mel

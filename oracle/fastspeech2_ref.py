@@ -40,7 +40,7 @@ DEFAULT_CFG = dict(
     energy_predictor_layers=2, energy_predictor_chans=256, energy_predictor_kernel_size=3,
     pitch_embed_kernel_size=1, energy_embed_kernel_size=1,
     postnet_layers=5, postnet_chans=256, postnet_filts=5,
-    spk_embed_dim=None, spk_embed_integration_type="add")
+    spk_embed_dim=None, spk_embed_integration_type="add", tone_embed_dim=None)
 
 
 def scaled_posenc(W, x):
@@ -191,7 +191,7 @@ def integrate_spk_embed(W, hs, spembs, integration_type):
 
 
 def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts=False, spk_id=None,
-              spembs=None):
+              spembs=None, tone_id=None):
     """FastSpeech2.inference fastspeech2.py:468-558 for one utterance.
     ids: (T,) int64 -> normalised mel (L, odim).  spk_id (int) / spembs (D,): speaker conditioning of
     the multi-speaker recipes (:396-402; spembs wins when both are given)."""
@@ -212,6 +212,14 @@ def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts
                 emb = torch.zeros_like(emb)
         if emb is not None:
             hs = integrate_spk_embed(W, hs, emb, cfg.get("spk_embed_integration_type", "add"))
+    if cfg.get("tone_embed_dim") is not None and tone_id is not None:   # :404-408
+        # inference forwards the (T,) ids un-batched (:546,556): tone_embs is (T, Dt), F.normalize's default
+        # axis 1 is then the feature axis, and hs (1,T,adim) + (T,adim) broadcasts ("add", :598-601)
+        tid = torch.as_tensor(np.asarray(tone_id)).to(torch.int64)
+        te = W["tone_embedding_table.weight"][tid]
+        te = torch.where((tid == 0).unsqueeze(-1), torch.zeros_like(te), te)   # padding_idx 0 [paddle-semantics]
+        te = te / te.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        hs = hs + linear(te, W["tone_projection.weight"], W["tone_projection.bias"])
     d_masks = make_pad_mask(ilens)                  # :410
     p_outs = variance_predictor(W.sub("pitch_predictor."), hs, d_masks, cfg["pitch_predictor_layers"])
     e_outs = variance_predictor(W.sub("energy_predictor."), hs, d_masks, cfg["energy_predictor_layers"])

@@ -48,7 +48,8 @@ class Fs2Cfg(C.Structure):
         "pitch_embed_kernel_size", "energy_embed_kernel_size",
         "postnet_layers", "postnet_chans", "postnet_filts",
         "use_batch_norm", "use_scaled_pos_enc", "encoder_normalize_before", "decoder_normalize_before",
-        "reduction_factor", "num_speakers", "spk_embed_dim", "spk_embed_integration_type", "tone_embed_dim")]
+        "reduction_factor", "num_speakers", "spk_embed_dim", "spk_embed_integration_type", "num_tones", "tone_embed_dim",
+        "tone_embed_integration_type")]
 
 
 class WfCfg(C.Structure):
@@ -105,6 +106,7 @@ def _declare(lib):
         "pk_fs2_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
         "pk_fs2_set_math": (C.c_int, [vp, i32]),
         "pk_fs2_set_speakers": (C.c_int, [vp, i64p, f32p, i32]),
+        "pk_fs2_set_tones": (C.c_int, [vp, i64p, i64]),
         "pk_fs2_finalize": (C.c_int, [vp]),
         "pk_fs2_encode": (C.c_int, [vp, i64p, i32p, i32, C.c_float, i32p]),
         "pk_fs2_decode": (C.c_int, [vp, f32p, i32]),

@@ -491,6 +491,16 @@ __global__ __launch_bounds__(256) void k_add_rowvec(const float* __restrict__ x,
     for (int c = threadIdx.x; c < A; c += blockDim.x) y[(long)r * A + c] = x[(long)r * A + c] + v[(long)b * A + c];
 }
 
+// hs[r] += ptone[tone[r]] on the rows of the timeline that belong to an utterance
+__global__ __launch_bounds__(256) void k_add_tone(float* __restrict__ hs, const float* __restrict__ ptone,
+                                                  const int* __restrict__ tone, const int* __restrict__ row_utt,
+                                                  int A) {
+    const int r = blockIdx.x;
+    if (row_utt[r] < 0) return;
+    const float* src = ptone + (long)tone[r] * A;
+    for (int c = threadIdx.x; c < A; c += blockDim.x) hs[(long)r * A + c] += src[c];
+}
+
 struct Dense {
     size_t w = 0, b = 0;   // offsets (floats) into the weight arena; b == SIZE_MAX: no bias
     size_t wh = (size_t)-1;   // offset (halves) of the split-fp16 fragments, SIZE_MAX if Cin % 32 != 0
@@ -542,6 +552,9 @@ struct pk_fs2 {
     size_t pitch_w = 0, pitch_b = 0, energy_w = 0, energy_b = 0;
     Dense feat_out;
     std::vector<Dense> postnet;
+    size_t tone_table = 0;                         // [num_tones][A]: tone_projection(normalize(embedding row))
+    std::vector<long long> cond_tone;              // conditioning of the next encode (pk_fs2_set_tones)
+    pk_dbuf d_tone;
     size_t spk_table = 0, spk_w = 0, spk_b = 0;   // embedding table, [D][A] speaker part of spk_projection, bias
     Dense spk_hs;                                  // "concat": the [A][A] hidden-state part of spk_projection
     std::vector<long long> cond_spk;               // conditioning of the next encode (pk_fs2_set_speakers)
@@ -614,7 +627,11 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: pitch/energy_embed_kernel_size must be 1 (all reference recipes)");
     if (!c.encoder_normalize_before || !c.decoder_normalize_before)
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: post-norm blocks not implemented");
-    if (c.tone_embed_dim != 0) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: tone embedding not implemented");
+    if (c.tone_embed_dim < 0 || c.num_tones < 0) PK_FAIL(PK_EINVAL, "FastSpeech2: negative tone sizes");
+    if (c.tone_embed_dim > 0 && c.num_tones <= 0) PK_FAIL(PK_EINVAL, "FastSpeech2: tone_embed_dim needs num_tones");
+    if (c.tone_embed_dim > 0 && c.tone_embed_integration_type != 0)
+        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: tone_embed_integration_type 'concat' is not implemented "
+                                 "(the reference's branch cannot broadcast 1-D tone ids, fastspeech2.py:606-610)");
     if (c.positionwise_layer_type < 0 || c.positionwise_layer_type > 2)
         PK_FAIL(PK_EUNSUPPORTED, "Support only linear or conv1d. (encoder.py:169)");
     if (c.spk_embed_dim < 0 || c.num_speakers < 0) PK_FAIL(PK_EINVAL, "FastSpeech2: negative speaker sizes");
@@ -886,6 +903,27 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
         pk_conv_to_kn(w.data(), cout, cin, c.postnet_filts, kn);
         PK_TRY(add_dense_kn(ar, kn, &bias, cin, c.postnet_filts, cout, h->postnet[j]));
     }
+    if (c.tone_embed_dim > 0) {
+        // "add": hs[t] += Linear(F.normalize(E[tone[t]])) is a function of the tone id alone -> one table
+        const int Dt = c.tone_embed_dim;
+        std::vector<float> e, w, b, tab((size_t)c.num_tones * A);
+        PK_TRY(pk_get_weight(P, "tone_embedding_table", {c.num_tones, Dt}, e));
+        PK_TRY(pk_get_weight(P, "tone_projection", {Dt, A}, w));
+        PK_TRY(pk_get_vector(P, "tone_projection.bias", A, b));
+        for (int k = 0; k < c.num_tones; ++k) {
+            double ss = 0.0;
+            if (k != 0)   // nn.Embedding(padding_idx=0) returns zeros for id 0
+                for (int i = 0; i < Dt; ++i) ss += (double)e[(size_t)k * Dt + i] * e[(size_t)k * Dt + i];
+            const double inv = 1.0 / std::max(std::sqrt(ss), 1e-12);
+            for (int o = 0; o < A; ++o) {
+                double acc = 0.0;
+                if (k != 0)
+                    for (int i = 0; i < Dt; ++i) acc += (double)e[(size_t)k * Dt + i] * inv * w[(size_t)i * A + o];
+                tab[(size_t)k * A + o] = (float)(acc + b[o]);
+            }
+        }
+        h->tone_table = ar.put(tab);
+    }
     if (c.spk_embed_dim > 0) {
         const int D = c.spk_embed_dim;
         std::vector<float> t, w, b;
@@ -1102,6 +1140,19 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
         PK_LAUNCH(ctx, "fs2_add_rowvec", k_add_rowvec, dim3(tl.rows), dim3(256), 0, src, h->d_spk_vec.as<float>(),
                   tl.d_row_utt(), tl.rows, A, hs);
     }
+    // tone embedding (:404-408)
+    if (c.tone_embed_dim > 0 && !h->cond_tone.empty()) {
+        std::vector<long long> ct;
+        ct.swap(h->cond_tone);   // consumed
+        if ((long)ct.size() != sumT) PK_FAIL(PK_ESHAPE, "pk_fs2_encode: %zu tone ids for %ld tokens", ct.size(), sumT);
+        std::vector<int> tn(tl.rows_alloc, 0);
+        long o = 0;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < tok_lens[b]; ++t, ++o) tn[tl.seg_start[b] + t] = (int)ct[o];
+        PK_TRY(pk_upload(ctx, h->d_tone, tn.data(), tn.size() * sizeof(int)));
+        PK_LAUNCH(ctx, "fs2_add_tone", k_add_tone, dim3(tl.rows), dim3(256), 0, hs, h->W(h->tone_table),
+                  h->d_tone.as<int>(), tl.d_row_utt(), A);
+    }
     // variance adaptor
     PK_TRY(h->d_pout.reserve((size_t)tl.rows_alloc * 4));
     PK_TRY(h->d_eout.reserve((size_t)tl.rows_alloc * 4));
@@ -1239,6 +1290,18 @@ extern "C" int pk_fs2_set_speakers(pk_fs2* h, const int64_t* spk_id, const float
     return PK_OK;
 }
 
+extern "C" int pk_fs2_set_tones(pk_fs2* h, const int64_t* tone_id, int64_t n) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_set_tones: handle is NULL");
+    h->cond_tone.clear();
+    if (!tone_id || h->cfg.tone_embed_dim <= 0) return PK_OK;   // a model without tones ignores them (:404)
+    if (n <= 0) PK_FAIL(PK_EINVAL, "pk_fs2_set_tones: n must be positive");
+    for (int64_t i = 0; i < n; ++i)
+        if (tone_id[i] < 0 || tone_id[i] >= h->cfg.num_tones)
+            PK_FAIL(PK_EINVAL, "pk_fs2_set_tones: tone id %lld out of [0,%d)", (long long)tone_id[i], h->cfg.num_tones);
+    h->cond_tone.assign(tone_id, tone_id + n);
+    return PK_OK;
+}
+
 extern "C" int pk_fs2_set_math(pk_fs2* h, int32_t mode) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_set_math: handle is NULL");
     if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3) PK_FAIL(PK_EINVAL, "pk_fs2_set_math: unknown mode %d", mode);
@@ -1287,7 +1350,7 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
                        &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
-                       &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
+                       &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
     for (auto* b : bufs) b->release();
     h->tl_tok.release();
     h->tl_frm.release();

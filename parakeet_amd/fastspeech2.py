@@ -79,7 +79,13 @@ class FastSpeech2:
         cfg.num_speakers = 0 if (num_speakers is None or spk_embed_dim is None) else int(num_speakers)
         cfg.spk_embed_dim = 0 if spk_embed_dim is None else int(spk_embed_dim)
         cfg.spk_embed_integration_type = 1 if spk_embed_integration_type == "concat" else 0
+        if tone_embed_dim is not None and tone_embed_integration_type != "add":
+            raise NotImplementedError("tone_embed_integration_type='concat': the reference's branch cannot "
+                                      "broadcast the 1-D tone ids of inference (fastspeech2.py:606-610)")
+        cfg.num_tones = 0 if (num_tones is None or tone_embed_dim is None) else int(num_tones)
         cfg.tone_embed_dim = 0 if tone_embed_dim is None else int(tone_embed_dim)
+        cfg.tone_embed_integration_type = 0
+        self.tone_embed_dim = tone_embed_dim
         self.spk_embed_dim = spk_embed_dim
         h = C.c_void_p()
         _capi.check(self._ctx.lib.pk_fs2_create(self._ctx.handle, C.byref(cfg), C.byref(h)))
@@ -124,13 +130,19 @@ class FastSpeech2:
         _capi.check(self._ctx.lib.pk_fs2_set_debug(self._h, 1 if on else 0))
 
     # -- synthesis -----------------------------------------------------------
-    def encode_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None):
+    def encode_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None, tone_ids=None):
         """Phase 1: returns the per-utterance frame counts (host ints).  ``spk_ids`` (B,) ints or
         ``spembs`` (B, spk_embed_dim): speaker conditioning of a multi-speaker model (:396-402)."""
         ctx = Context.get(self._ctx.device)
         self._finalize()
         ids = [np.asarray(t.cpu() if isinstance(t, torch.Tensor) else t).astype(np.int64).reshape(-1)
                for t in texts]
+        if self.tone_embed_dim is not None and tone_ids is not None:
+            tn = [np.asarray(t.cpu() if isinstance(t, torch.Tensor) else t).astype(np.int64).reshape(-1)
+                  for t in tone_ids]
+            assert [len(t) for t in tn] == [len(i) for i in ids], "one tone id per token"
+            tflat = np.ascontiguousarray(np.concatenate(tn))
+            _capi.check(ctx.lib.pk_fs2_set_tones(self._h, tflat.ctypes.data_as(C.POINTER(C.c_int64)), tflat.size))
         if self.spk_embed_dim is not None and (spk_ids is not None or spembs is not None):
             if spembs is not None:
                 e = np.ascontiguousarray(to_numpy_f32(spembs).reshape(len(ids), self.spk_embed_dim))
@@ -159,8 +171,8 @@ class FastSpeech2:
             _capi.check(ctx.lib.pk_fs2_decode(self._h, dptr(mel), 0))
         return mel
 
-    def inference_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None):
-        frames = self.encode_batch(texts, alpha, spk_ids, spembs)
+    def inference_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None, tone_ids=None):
+        frames = self.encode_batch(texts, alpha, spk_ids, spembs, tone_ids)
         mel = self.decode_packed()
         outs, o = [], 0
         for f in frames:
@@ -173,14 +185,13 @@ class FastSpeech2:
         """(T,) int64 -> (L, odim); fastspeech2.py:468-558 (is_inference=True branch)."""
         if use_teacher_forcing:
             raise NotImplementedError("teacher forcing is a training-time path")
-        if tone_id is not None:
-            raise NotImplementedError("tone embeddings are not implemented (no FastSpeech2 recipe uses them)")
+        tones = None if tone_id is None else [tone_id]   # (T,) ids, forwarded un-batched by the reference (:546,556)
         if spembs is not None:      # (spk_embed_dim,), unsqueezed by the reference (:541-542)
-            return self.inference_batch([text], alpha, spembs=to_numpy_f32(spembs).reshape(1, -1))[0]
+            return self.inference_batch([text], alpha, spembs=to_numpy_f32(spembs).reshape(1, -1), tone_ids=tones)[0]
         if spk_id is not None:
             sid = np.asarray(spk_id.cpu() if isinstance(spk_id, torch.Tensor) else spk_id).reshape(-1)[:1]
-            return self.inference_batch([text], alpha, spk_ids=sid)[0]
-        return self.inference_batch([text], alpha)[0]
+            return self.inference_batch([text], alpha, spk_ids=sid, tone_ids=tones)[0]
+        return self.inference_batch([text], alpha, tone_ids=tones)[0]
 
     def debug_tap(self, what, b):
         n_rows = self._last_tok[b] if what <= 3 else self._last_frames[b]

@@ -64,7 +64,7 @@ def _xavier(rng, shape):
 
 
 def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=None, perturb=True,
-                      num_speakers=None):
+                      num_speakers=None, num_tones=None):
     """``cfg`` may carry spk_embed_dim / spk_embed_integration_type (aishell3 / vctk recipes: 256, "concat");
     ``num_speakers`` then sizes ``spk_embedding_table`` (fastspeech2.py:147-151, 190-194)."""
     cfg = dict(FS2_LJSPEECH, **(cfg or {}))
@@ -144,6 +144,13 @@ def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=Non
         st[f"postnet.postnet.{j}.1._mean"] = small(cout)
         st[f"postnet.postnet.{j}.1._variance"] = (
             rng.uniform(0.5, 1.5, size=(cout,)) if perturb else np.ones(cout)).astype(np.float32)
+    if cfg.get("tone_embed_dim") is not None:
+        Dt = cfg["tone_embed_dim"]
+        tt = rng.normal(size=(num_tones, Dt)).astype(np.float32)
+        tt[0] = 0.0
+        st["tone_embedding_table.weight"] = tt
+        st["tone_projection.weight"] = _xavier(rng, (Dt, A))   # "add" integration (:197-199)
+        st["tone_projection.bias"] = small(A)
     if cfg.get("spk_embed_dim") is not None:
         D = cfg["spk_embed_dim"]
         tab = rng.normal(size=(num_speakers, D)).astype(np.float32)

@@ -50,7 +50,7 @@ def test_no_gpu_fails_loudly():
 def test_struct_sizes_match_header():
     from parakeet_amd import _capi
     assert C.sizeof(_capi.PwgCfg) == 4 * (11 + 8 + 1)
-    assert C.sizeof(_capi.Fs2Cfg) == 4 * 33
+    assert C.sizeof(_capi.Fs2Cfg) == 4 * 35
     assert C.sizeof(_capi.WfCfg) == 4 * (1 + 4 + 7)
 
 

@@ -53,6 +53,17 @@ def test_fastspeech2_ffn_variants_oracle_matches_reference_source():
             assert np.abs(mel - g[f"{tag}_mel{i}"]).max() < 2e-5
 
 
+def test_fastspeech2_tone_embedding_oracle_matches_reference_source():
+    g = np.load(os.path.join(GOLD, "fastspeech2_tones.npz"))
+    cfg = dict(syn.FS2_LJSPEECH, tone_embed_dim=64, tone_embed_integration_type="add")
+    state = syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), num_tones=6, fixed_duration=2)
+    for i in range(2):
+        mel = fs2.inference(state, g[f"ids{i}"], cfg, tone_id=g[f"tones{i}"]).numpy()
+        assert mel.shape == g[f"mel{i}"].shape and np.abs(mel - g[f"mel{i}"]).max() < 2e-5
+    other = fs2.inference(state, g["ids0"], cfg, tone_id=(g["tones0"] + 1) % 6).numpy()
+    assert np.abs(other - g["mel0"]).max() > 1e-3      # the conditioning is live
+
+
 def test_speedyspeech_oracle_matches_reference_source():
     # baker configuration, both readings of Paddle's padding="same" (oracle/speedyspeech_ref.py)
     from oracle import speedyspeech_ref as ssr

@@ -77,6 +77,26 @@ def test_fastspeech2_ffn_variants_engine_matches_reference_source(kind):
         FastSpeech2(80, 80, **dict(cfg, positionwise_layer_type="conv2d"))
 
 
+def test_fastspeech2_tone_embedding_engine_matches_reference_source():
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    g = np.load(os.path.join(GOLD, "fastspeech2_tones.npz"))
+    cfg = dict(syn.FS2_LJSPEECH, tone_embed_dim=64, tone_embed_integration_type="add")
+    model = FastSpeech2(80, 80, num_tones=6, **cfg)
+    model.set_state_dict(syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), num_tones=6, fixed_duration=2))
+    model.eval()
+    mel = model.inference(g["ids0"], tone_id=g["tones0"]).numpy()
+    assert mel.shape == g["mel0"].shape and np.abs(mel - g["mel0"]).mean() < 1e-4
+    outs = model.inference_batch([g["ids0"], g["ids1"]], tone_ids=[g["tones0"], g["tones1"]])
+    for i, o in enumerate(outs):
+        assert o.shape == g[f"mel{i}"].shape and np.abs(o.numpy() - g[f"mel{i}"]).mean() < 1e-4
+    a = model.inference(g["ids0"]).numpy()                 # no tones given: integration skipped (:404-405)
+    assert np.abs(a - g["mel0"]).max() > 1e-3
+    with pytest.raises(ValueError):
+        model.inference(g["ids0"], tone_id=np.full_like(g["tones0"], 6))
+    with pytest.raises(NotImplementedError):
+        FastSpeech2(80, 80, num_tones=6, **dict(cfg, tone_embed_integration_type="concat"))
+
+
 def test_pwg_engine_matches_reference_source():
     from parakeet_amd.normalizer import ZScore
     from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference

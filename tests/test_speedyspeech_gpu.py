@@ -76,3 +76,32 @@ def test_error_mapping_and_shapes():
         m.inference(np.array([1, 2, 70]))    # id out of range
     with pytest.raises(ValueError):
         m.inference(np.array([1, 2]), np.array([1, 9]))
+
+
+def test_predictor_style_pipeline_speedyspeech_pwg():
+    """The loop body of examples/speedyspeech/baker/inference.py:100-126 over the engine."""
+    from parakeet_amd.normalizer import ZScore
+    from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference
+    from parakeet_amd.predictor import create_predictor
+    from parakeet_amd.speedyspeech import SpeedySpeechInference
+    m = _model(True, 5)
+    am = create_predictor(SpeedySpeechInference(ZScore(*syn.mel_stats(seed=1)), m), ["phones", "tones"])
+    gen = PWGGenerator(**syn.PWG_LJSPEECH)
+    gen.set_state_dict(syn.pwg_state())
+    gen.eval()
+    gen.set_seed(3)
+    voc = create_predictor(PWGInference(ZScore(*syn.mel_stats(seed=2)), gen), ["logmel"])
+    phones, tones = np.arange(1, 8), np.array([1, 2, 3, 4, 5, 6, 1])
+    for name, v in zip(am.get_input_names(), (phones, tones)):
+        h = am.get_input_handle(name)
+        h.reshape(v.shape)
+        h.copy_from_cpu(v)
+    am.run()
+    mel = am.get_output_handle(am.get_output_names()[0]).copy_to_cpu()
+    assert mel.ndim == 2 and mel.shape[1] == 80 and mel.shape[0] > 0
+    mh = voc.get_input_handle(voc.get_input_names()[0])
+    mh.reshape(mel.shape)
+    mh.copy_from_cpu(mel)
+    voc.run()
+    wav = voc.get_output_handle(voc.get_output_names()[0]).copy_to_cpu()
+    assert wav.shape == (mel.shape[0] * 256, 1) and np.isfinite(wav).all()

@@ -95,6 +95,26 @@ def golden_fastspeech2_ffn_variants():
     print("fastspeech2 ffn variants:", {k: v.shape for k, v in out.items() if "mel" in k})
 
 
+def golden_fastspeech2_tones():
+    """tone_embed_dim 64, "add"; tone ids forwarded as FastSpeech2.inference does (1-D)."""
+    fsm = ref_import.load("parakeet.models.fastspeech2.fastspeech2")
+    cfg = dict(syn.FS2_LJSPEECH, tone_embed_dim=64, tone_embed_integration_type="add")
+    state = syn.fastspeech2_state(80, 80, cfg, seed=2027, num_tones=6, fixed_duration=2)
+    model = fsm.FastSpeech2(idim=80, odim=80, num_tones=6, **cfg)
+    model.set_state_dict(state)
+    model.eval()
+    out = {"seed": np.array(2027)}
+    rng = np.random.default_rng(41)
+    for i in range(2):
+        ids = syn.phoneme_ids(9 + 4 * i, seed=800 + i)
+        tones = rng.integers(0, 6, size=ids.shape[0]).astype(np.int64)   # includes the padding id 0
+        with paddle.no_grad():
+            mel = model.inference(paddle.to_tensor(ids), tone_id=paddle.to_tensor(tones)).numpy()
+        out[f"ids{i}"], out[f"tones{i}"], out[f"mel{i}"] = ids, tones, mel.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fastspeech2_tones.npz"), **out)
+    print("fastspeech2 tones:", {k: v.shape for k, v in out.items() if "mel" in k})
+
+
 def golden_pwg():
     pw = ref_import.load("parakeet.models.parallel_wavegan.parallel_wavegan")
     norm = ref_import.load("parakeet.modules.normalizer")
@@ -135,6 +155,7 @@ if __name__ == "__main__":
     golden_fastspeech2()
     golden_fastspeech2_multispeaker()
     golden_fastspeech2_ffn_variants()
+    golden_fastspeech2_tones()
     golden_pwg()
     if "--with-waveflow" in sys.argv or True:
         try:
