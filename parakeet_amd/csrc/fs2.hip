@@ -354,6 +354,160 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
     }
 }
 
+// LDS-staged version of k_attention_h3: one workgroup = 4 waves = 4 query tiles (128 queries) of one
+// (utterance, head).  Every 32-key tile of K and V is loaded from HBM/L2 ONCE per workgroup, split into fp16
+// (hi, lo) parts by the loading threads and parked in LDS in MFMA fragment order, so the inner loop of a wave is
+// ds_read_b128 + MFMA only (the per-wave version loads and splits each tile four times over).  48 KB of LDS:
+//   Kf[ks][part][lane]   A fragments of S^T = K . Q^T : 8 halves = K[key = lane&31][16*ks + 8*(lane>>5) + e]
+//   Vf[s2][dt][part][lane] B fragments of O = P . V   : 8 halves = V[key(8*s2 + e, lane>>5)][32*dt + (lane&31)]
+// The next tile's global loads are issued before the current tile's MFMAs (registers), stored after them.
+constexpr int ATT_THREADS = 256;
+template <int DK>
+__global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a) {
+    constexpr int KS = DK / 16;
+    constexpr int DT = DK / 32;
+    constexpr int NT = ATT_THREADS;
+    constexpr int KG = (32 * (DK / 8) + NT - 1) / NT;      // 8-float groups of the K tile per thread (3 for DK = 192)
+    constexpr int VG = (2 * DT * 64 + NT - 1) / NT;        // V fragment lanes per thread (3 for DK = 192)
+    __shared__ __attribute__((aligned(16))) at_f16x8 Kf[KS * 2 * 64];
+    __shared__ __attribute__((aligned(16))) at_f16x8 Vf[2 * DT * 2 * 64];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = a.seg_len[b], start = a.seg_start[b];
+    if ((int)blockIdx.x * (NT / 2) >= len) return;    // uniform over the workgroup
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q0 = (blockIdx.x * (NT / 64) + wave) * 32;
+    const int j = lane & 31, hi = lane >> 5;
+    const long ld = a.ld;
+    const float* base = a.qkv + (long)start * ld + h * DK;
+
+    at_f16x8 qh[KS], ql[KS];
+    {
+        const int qr = min(q0 + j, len - 1);
+        const float* qp = base + (long)qr * ld + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            at_split8(v, qh[ks], ql[ks]);
+        }
+    }
+    f32x16 O[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    float kreg[KG][8], vreg[VG][8];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const int idx = min(tid + NT * g, 32 * (DK / 8) - 1);   // (key, 8-float group) of the K tile
+            const int key = idx / (DK / 8), grp = idx % (DK / 8);
+            const float* kp = base + a.D + (long)min(k0 + key, len - 1) * ld + 8 * grp;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(kp);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(kp + 4);
+            kreg[g][0] = v0[0]; kreg[g][1] = v0[1]; kreg[g][2] = v0[2]; kreg[g][3] = v0[3];
+            kreg[g][4] = v1[0]; kreg[g][5] = v1[1]; kreg[g][6] = v1[2]; kreg[g][7] = v1[3];
+        }
+#pragma unroll
+        for (int g = 0; g < VG; ++g) {
+            const int idx = min(tid + NT * g, 2 * DT * 64 - 1);     // (s2, dt, fragment lane) of the V tile
+            const int fl = idx & 63, dt = (idx >> 6) % DT, s2 = idx / (64 * DT);
+            const float* vp = base + 2 * a.D + 32 * dt + (fl & 31);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                vreg[g][e] = vp[(long)min(k0 + mfma_row(8 * s2 + e, fl >> 5), len - 1) * ld];
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const int idx = tid + NT * g;
+            if (idx >= 32 * (DK / 8)) break;
+            const int key = idx / (DK / 8), grp = idx % (DK / 8);
+            at_f16x8 fh, fl_;
+            at_split8(kreg[g], fh, fl_);
+            const int ks = grp >> 1, fl = key + 32 * (grp & 1);
+            Kf[(ks * 2 + 0) * 64 + fl] = fh;
+            Kf[(ks * 2 + 1) * 64 + fl] = fl_;
+        }
+#pragma unroll
+        for (int g = 0; g < VG; ++g) {
+            const int idx = tid + NT * g;
+            if (idx >= 2 * DT * 64) break;
+            const int fl = idx & 63, dt = (idx >> 6) % DT, s2 = idx / (64 * DT);
+            at_f16x8 fh, fl_;
+            at_split8(vreg[g], fh, fl_);
+            Vf[((s2 * DT + dt) * 2 + 0) * 64 + fl] = fh;
+            Vf[((s2 * DT + dt) * 2 + 1) * 64 + fl] = fl_;
+        }
+    };
+
+    load_tile(0);
+    for (int k0 = 0; k0 < len; k0 += 32) {
+        __syncthreads();          // every wave is done with the previous tile's fragments
+        store_tile();
+        __syncthreads();
+        if (k0 + 32 < len) load_tile(k0 + 32);
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            S = at_mfma3(Kf[(ks * 2 + 0) * 64 + lane], Kf[(ks * 2 + 1) * 64 + lane], qh[ks], ql[ks], S);
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + mfma_row(r, hi);
+            S[r] = (key < len) ? S[r] * a.scale : -INFINITY;
+            mloc = fmaxf(mloc, S[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = expf(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[r] = expf(S[r] - m_new);
+            lsum += S[r];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ar = __shfl(alpha, mfma_row(r, hi));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt][r] *= ar;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = S[8 * s2 + e];
+            at_f16x8 ph, pl;
+            at_split8(pv, ph, pl);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                O[dt] = at_mfma3(ph, pl, Vf[((s2 * DT + dt) * 2 + 0) * 64 + lane],
+                                 Vf[((s2 * DT + dt) * 2 + 1) * 64 + lane], O[dt]);
+        }
+    }
+    if (q0 >= len) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + mfma_row(r, hi);
+        const float lr = __shfl(l_run, mfma_row(r, hi));
+        if (q < len) {
+            float* o = a.out + (long)(start + q) * a.ldo + h * DK + j;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] / lr;
+        }
+    }
+}
+
 // Predictor heads: Linear(C -> 1) per row (+ masked_fill) and, for the duration
 // predictor in inference, clip(round(exp(x) - offset), min=0) and the alpha speed
 // scaling round(d * alpha)  (duration_predictor.py:95-103, length_regulator.py:85-88;
@@ -545,6 +699,7 @@ struct pk_fs2 {
     std::vector<uint16_t> arena16_h;
     pk_dbuf arena16;
     int math = PK_GEMM_MATH_F16X3;   // dense layers: 3-term split-fp16 MFMA (fp32-equivalent error) or exact fp32
+    bool attn_lds = getenv("PK_FS2_ATTN_NO_LDS") == nullptr;   // measurement switch: per-wave K/V loads instead
     size_t emb_table = 0, enc_after_g = 0, enc_after_b = 0, dec_after_g = 0, dec_after_b = 0;
     float alpha_enc = 1.f, alpha_dec = 1.f, xscale = 1.f;
     std::vector<FftLayer> enc, dec;
@@ -1004,6 +1159,17 @@ static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float*
     a.D = A;
     a.scale = (float)(1.0 / std::sqrt((double)dk));
     dim3 grid(pk_div_up(maxlen, 128), heads, tl.B);
+    if (h->math == PK_GEMM_MATH_F16X3 && h->attn_lds) {
+        dim3 g2(pk_div_up(maxlen, ATT_THREADS / 2), heads, tl.B);
+        switch (dk) {
+            case 64: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3_lds<64>, g2, dim3(ATT_THREADS), 0, a); break;
+            case 96: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3_lds<96>, g2, dim3(ATT_THREADS), 0, a); break;
+            case 128: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3_lds<128>, g2, dim3(ATT_THREADS), 0, a); break;
+            case 192: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3_lds<192>, g2, dim3(ATT_THREADS), 0, a); break;
+            default: PK_FAIL(PK_EUNSUPPORTED, "attention head size %d", dk);
+        }
+        return PK_OK;
+    }
     if (h->math == PK_GEMM_MATH_F16X3) {
         switch (dk) {
             case 64: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3<64>, grid, dim3(256), 0, a); break;
