@@ -222,9 +222,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm(pk_gemm_args a) {
 // ---------------------------------------------------------------- split-fp16 variant
 // Same tiling and epilogue; every fp32 product is a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with fp16 parts on
 // v_mfma_f32_32x32x16_f16, fp32 accumulation (error of the result = exact-fp32 class, see pwg.hip).
-// K slab = 32.  LDS per buffer: activations fp32 row-major [128][36] (padded: conflict-free 16-B reads),
-// split in registers after the read; weights pre-split on the host into MFMA fragments
-// [k-step][part][n-tile][lane] x 8 halves.  A operand = activations (rows), B operand = weights (cols).
+// K slab = 32.  A operand = activations (rows), B operand = weights (cols).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 constexpr int HBK = PK_GEMM_HBK;           // 32
@@ -233,8 +231,27 @@ constexpr int H_A_FLOATS = BM * A_LD;      // 4608
 constexpr int H_B_BYTES = 2 * 2 * 4 * 64 * 16;   // 16 KB: [ks 2][part 2][nt 4][lane 64] x 16 B
 constexpr int H_DEPTH = 3;                 // slabs in flight between global memory and LDS
 
+// Both operands live in LDS as ready MFMA fragments of fp16 (hi, lo) parts:
+//   Af[buf][ks 2][part 2][mt 4][lane 64] x 16 B  (activations: split ONCE per element by the thread that loaded
+//                                                it, when it moves its registers to LDS -- MFMA and VALU do not
+//                                                overlap on this part, so every VALU instruction kept out of
+//                                                the four waves' inner loops is matrix time won)
+//   Bs[buf][ks 2][part 2][nt 4][lane 64] x 16 B  (weights: pre-split at finalize)
+// so the inner loop is ds_read_b128 + MFMA only.
+__device__ __forceinline__ void gemm_split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        // v_cvt_pkrtz: round toward zero, saturating at +-65504; lo = fp16_rne(x - hi): |x - hi - lo| <= 2^-21 |x|
+        const pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+        hi[2 * p] = (_Float16)h[0];
+        hi[2 * p + 1] = (_Float16)h[1];
+        lo[2 * p] = (_Float16)(v[2 * p] - (float)h[0]);
+        lo[2 * p + 1] = (_Float16)(v[2 * p + 1] - (float)h[1]);
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
-    __shared__ __attribute__((aligned(16))) float As[2][H_A_FLOATS];
+    __shared__ __attribute__((aligned(16))) f16x8 Af[2][H_B_BYTES / 16];
     __shared__ __attribute__((aligned(16))) f16x8 Bs[2][H_B_BYTES / 16];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -246,10 +263,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
     const int nmain = a.ntaps * slabs_per_tap;
     const int nslabs = nmain + a.Cin2 / HBK;
 
-    const int lrow = tid >> 1, lhalf = tid & 1;      // thread -> (row, 16 consecutive k)
+    const int lrow = tid >> 1, lhalf = tid & 1;      // thread -> (row, 16 consecutive k = k-step lhalf of the slab)
     const float* arow = a.A + (long)(m0 + lrow) * a.lda + lhalf * 16;
     const float* arow2 = a.A2 + (long)(m0 + lrow) * a.lda2 + lhalf * 16;
     const f16x8* wsrc = reinterpret_cast<const f16x8*>(a.Wh) + (long)nblk * a.wslabs_total * (H_B_BYTES / 16) + tid;
+    // fragment slots of this thread's 16 values: (ks = lhalf, mt = lrow / 32, lane = lrow % 32 + 32 * khalf)
+    const int a_slot = ((lhalf * 2 + 0) * 4 + (lrow >> 5)) * 64 + (lrow & 31);   // part 0, khalf 0; part: +256, khalf: +32
 
     // Global -> register staging ring, H_DEPTH slabs ahead of the MFMAs (one slab of compute is ~0.4 us,
     // far less than the load latency under load), then registers -> LDS double buffer.
@@ -275,9 +294,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
     };
     auto store_slab = [&](int buf, auto SET) {
         constexpr int set = decltype(SET)::value;
-        float* d = As[buf] + lrow * A_LD + lhalf * 16;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(d + 4 * c) = ra[set][c];
+        for (int kh = 0; kh < 2; ++kh) {
+            const f32x4 v0 = ra[set][2 * kh], v1 = ra[set][2 * kh + 1];
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            f16x8 fh, fl;
+            gemm_split8(v, fh, fl);
+            Af[buf][a_slot + 32 * kh] = fh;
+            Af[buf][a_slot + 32 * kh + 256] = fl;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) Bs[buf][tid + c * 256] = rb[set][c];
     };
@@ -290,25 +315,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // Operand split (2.5 VALU ops per element: v_cvt_pkrtz high part, which saturates at +-65504, exact fp32
-    // remainder, round-to-nearest low part) of k-step ks+1 runs under the 12 MFMAs of k-step ks.
-    auto read_split = [&](int buf, int ks, f16x8 (&ah)[2], f16x8 (&al)[2]) {
+    // one K slab of MFMAs from LDS buffer `buf`
+    auto mma_slab = [&](int buf) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const float* ap = As[buf] + (wm * 64 + mt * 32 + i) * A_LD + ks * 16 + hi * 8;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);
-            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[2], al[2];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
-                ah[mt][2 * p] = (_Float16)h[0];
-                ah[mt][2 * p + 1] = (_Float16)h[1];
-                al[mt][2 * p] = (_Float16)(v[2 * p] - (float)h[0]);
-                al[mt][2 * p + 1] = (_Float16)(v[2 * p + 1] - (float)h[1]);
+            for (int mt = 0; mt < 2; ++mt) {
+                ah[mt] = Af[buf][((ks * 2 + 0) * 4 + wm * 2 + mt) * 64 + lane];
+                al[mt] = Af[buf][((ks * 2 + 1) * 4 + wm * 2 + mt) * 64 + lane];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f16x8 bh = Bs[buf][((ks * 2 + 0) * 4 + wn * 2 + nt) * 64 + lane];
+                const f16x8 bl = Bs[buf][((ks * 2 + 1) * 4 + wn * 2 + nt) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                }
             }
         }
     };
+
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
     typedef std::integral_constant<int, 2> S2;
@@ -322,46 +352,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
     load_slab(2 < last ? 2 : last, S2{});
     store_slab(0, S0{});
     __syncthreads();
-    f16x8 ah[2], al[2];
-    read_split(0, 0, ah, al);
     // one slab: request slab s+DEPTH into the set slab s came from, run slab s, move slab s+1 to LDS
     auto step = [&](int s, auto SET, auto NEXT) {
         const int buf = s & 1;
         load_slab(s + H_DEPTH < last ? s + H_DEPTH : last, SET);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 nh[2], nl[2];
-            if (ks == 0) read_split(buf, 1, nh, nl);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const f16x8 bh = Bs[buf][((ks * 2 + 0) * 4 + wn * 2 + nt) * 64 + lane];
-                const f16x8 bl = Bs[buf][((ks * 2 + 1) * 4 + wn * 2 + nt) * 64 + lane];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-                }
-            }
-            if (ks == 0) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-                for (int m = 0; m < 12; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    ah[mt] = nh[mt];
-                    al[mt] = nl[mt];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        mma_slab(buf);
+        __builtin_amdgcn_sched_barrier(0);
         store_slab(buf ^ 1, NEXT);
         __syncthreads();
-        read_split(buf ^ 1, 0, ah, al);
     };
     int s = 0;
     for (; s + H_DEPTH <= nslabs; s += H_DEPTH) {
@@ -374,11 +373,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
         if (s + 1 < nslabs) step(s + 1, S1{}, S2{});
     }
     if (a.epi == PK_EPI_GATE_PROJ) {
-        // ---- stage 2: z = tanh(content + b) * sigmoid(gate + b) -> LDS, then out = z . W2 (K = 64, N = 128)
-        __syncthreads();   // every wave is done reading the last slab
+        // ---- stage 2: z = tanh(content + b) * sigmoid(gate + b) -> LDS fragments, then out = z . W2 (K = 64, N = 128)
         {
             const int col0 = wn * 64 + i;
             const float b0 = a.bias ? a.bias[col0] : 0.f, b1 = a.bias ? a.bias[col0 + 32] : 0.f;
+            // z channel wn*32 + i = k-slab wn, k = i: k-step i/16, k half (i/8)&1, element i%8
+            _Float16* zf = reinterpret_cast<_Float16*>(Af[wn]);
+            const int e_off = (((i >> 4) * 2 + 0) * 4 * 64 + 32 * ((i >> 3) & 1)) * 8 + (i & 7);   // part 0, mt 0, row 0
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -391,7 +392,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
                     float v = (1.f - ea) / ((1.f + ea) * (1.f + eb));
                     const int m = m0 + row;
                     if (m >= a.M || (a.rowvalid && a.rowvalid[m] < 0)) v = 0.f;
-                    As[wn][row * A_LD + i] = v;   // z channel wn*32 + i = k-slab wn, k = i
+                    const _Float16 vh = (_Float16)v;                 // |z| < 1: no saturation issue
+                    const _Float16 vl = (_Float16)(v - (float)vh);
+                    const int o = e_off + ((row >> 5) * 64 + (row & 31)) * 8;
+                    zf[o] = vh;
+                    zf[o + 4 * 64 * 8] = vl;                         // part 1
                 }
             const f16x8* w2 = reinterpret_cast<const f16x8*>(a.Wh2) + tid;
 #pragma unroll
@@ -404,23 +409,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                read_split(sl, ks, ah, al);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const f16x8 bh = Bs[sl][((ks * 2 + 0) * 4 + wn * 2 + nt) * 64 + lane];
-                    const f16x8 bl = Bs[sl][((ks * 2 + 1) * 4 + wn * 2 + nt) * 64 + lane];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-                    }
-                }
-            }
+        mma_slab(0);
+        mma_slab(1);
         pk_gemm_args b = a;
         b.epi = PK_EPI_STD;
         b.bias = a.bias2;
