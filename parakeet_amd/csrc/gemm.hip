@@ -26,9 +26,10 @@ constexpr int BM = PK_GEMM_BM, BN = PK_GEMM_BN, BK = PK_GEMM_BK;
 
 __device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// Shared epilogue: acc[mt][nt] is the wave's 64x64 sub-tile (rows m0 + wm*64 + mt*32 + mfma_row(r, hi),
+// Shared epilogue: acc[mt][nt] is the wave's (32*MT)x64 sub-tile (rows m0 + wm*32*MT + mt*32 + mfma_row(r, hi),
 // columns nblk*128 + wn*64 + nt*32 + i).
-__device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&acc)[2][2], int m0, int nblk, int wm,
+template <int MT>
+__device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&acc)[MT][2], int m0, int nblk, int wm,
                                               int wn, int i, int hi) {
     // epilogue
     if (a.epi == PK_EPI_GATE) {
@@ -38,10 +39,10 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
         if (n_out >= a.N / 2) return;
         const float b0 = a.bias ? a.bias[col0] : 0.f, b1 = a.bias ? a.bias[col0 + 32] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
+                const int m = m0 + wm * (32 * MT) + mt * 32 + mfma_row(r, hi);
                 if (m >= a.M) continue;
                 float ca = acc[mt][0][r] + b0;
                 const float cb = acc[mt][1][r] + b1;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
         constexpr int EB = 8;
         const int m_last = a.M - 1;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int rb = 0; rb < 16; rb += EB) {
                 float oldv[EB];
@@ -79,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
                 int mo[EB];
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
-                    const int m = min(m0 + wm * 64 + mt * 32 + mfma_row(rb + q, hi), m_last);
+                    const int m = min(m0 + wm * (32 * MT) + mt * 32 + mfma_row(rb + q, hi), m_last);
                     valid[q] = a.rowvalid ? a.rowvalid[m] : 0;          // raw value for now
                     mo[q] = a.out_rowmap && !to2 ? a.out_rowmap[m] : m;
                     if (to2) oldv[q] = a.acc2 ? a.C2[(long)m * a.ldc2 + (n - a.nsplit)] : 0.f;
@@ -87,7 +88,7 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
                 }
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
-                    const int m = m0 + wm * 64 + mt * 32 + mfma_row(rb + q, hi);
+                    const int m = m0 + wm * (32 * MT) + mt * 32 + mfma_row(rb + q, hi);
                     const bool gap = valid[q] < 0;
                     valid[q] = (m > m_last || mo[q] < 0) ? -1 : (gap ? 0 : 1);
                     if (gap && to2) oldv[q] = 0.f;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void gemm_epilogue(const pk_gemm_args& a, f32x16 (&ac
                 for (int q = 0; q < EB; ++q) {
                     if (valid[q] < 0) continue;
                     const int r = rb + q;
-                    const int m = m0 + wm * 64 + mt * 32 + mfma_row(r, hi);
+                    const int m = m0 + wm * (32 * MT) + mt * 32 + mfma_row(r, hi);
                     float v = acc[mt][nt][r] + bias;
                     if (a.res_pos == PK_RES_BEFORE_ACT && !to2) v += oldv[q];
                     if (a.act == PK_ACT_RELU) v = fmaxf(v, 0.f);
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm(pk_gemm_args a) {
         __syncthreads();
     }
 
-    gemm_epilogue(a, acc, m0, nblk, wm, wn, i, hi);
+    gemm_epilogue<2>(a, acc, m0, nblk, wm, wn, i, hi);
 }
 
 // ---------------------------------------------------------------- split-fp16 variant
@@ -250,29 +251,37 @@ __device__ __forceinline__ void gemm_split8(const float (&v)[8], f16x8& hi, f16x
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
-    __shared__ __attribute__((aligned(16))) f16x8 Af[2][H_B_BYTES / 16];
+// MT = 32-row MFMA tiles per wave along M: 2 -> 128-row workgroup tiles (2 workgroups per CU), 1 -> 64-row tiles
+// (48 KB of LDS, <= 170 VGPRs: 3 workgroups per CU) for grids that would otherwise end in a nearly empty round.
+template <int MT>
+__global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_h3(pk_gemm_args a) {
+    constexpr int TM = 64 * MT;                 // rows per workgroup
+    constexpr int AG = MT;                      // 8-float groups of the A slab per thread
+    __shared__ __attribute__((aligned(16))) f16x8 Af[2][2 * 2 * 2 * MT * 64];
     __shared__ __attribute__((aligned(16))) f16x8 Bs[2][H_B_BYTES / 16];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, hi = lane >> 5;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = blockIdx.x * TM;
     const int nblk = blockIdx.y;
     const int slabs_per_tap = a.Cin / HBK;
     const int nmain = a.ntaps * slabs_per_tap;
     const int nslabs = nmain + a.Cin2 / HBK;
 
-    const int lrow = tid >> 1, lhalf = tid & 1;      // thread -> (row, 16 consecutive k = k-step lhalf of the slab)
-    const float* arow = a.A + (long)(m0 + lrow) * a.lda + lhalf * 16;
-    const float* arow2 = a.A2 + (long)(m0 + lrow) * a.lda2 + lhalf * 16;
+    // thread -> (row, AG consecutive 8-float groups): MT = 2: 16 floats = one k-step; MT = 1: 8 floats = half a k-step
+    const int lrow = (tid * AG) >> 2, lgrp = (tid * AG) & 3;
+    const float* arow = a.A + (long)(m0 + lrow) * a.lda + lgrp * 8;
+    const float* arow2 = a.A2 + (long)(m0 + lrow) * a.lda2 + lgrp * 8;
     const f16x8* wsrc = reinterpret_cast<const f16x8*>(a.Wh) + (long)nblk * a.wslabs_total * (H_B_BYTES / 16) + tid;
-    // fragment slots of this thread's 16 values: (ks = lhalf, mt = lrow / 32, lane = lrow % 32 + 32 * khalf)
-    const int a_slot = ((lhalf * 2 + 0) * 4 + (lrow >> 5)) * 64 + (lrow & 31);   // part 0, khalf 0; part: +256, khalf: +32
+    // fragment slot of group g: (ks = g / 2, part, mt = lrow / 32, lane = lrow % 32 + 32 * (g % 2))
+    auto a_slot = [&](int g, int part) {
+        return (((g >> 1) * 2 + part) * (2 * MT) + (lrow >> 5)) * 64 + (lrow & 31) + 32 * (g & 1);
+    };
 
     // Global -> register staging ring, H_DEPTH slabs ahead of the MFMAs (one slab of compute is ~0.4 us,
     // far less than the load latency under load), then registers -> LDS double buffer.
-    f32x4 ra[H_DEPTH][4];
+    f32x4 ra[H_DEPTH][2 * AG];
     f16x8 rb[H_DEPTH][4];
     auto load_slab = [&](int s, auto SET) {
         constexpr int set = decltype(SET)::value;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
             wslab = a.w2_slab0 + (s - nmain);
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ra[set][c] = *reinterpret_cast<const f32x4*>(p + 4 * c);
+        for (int c = 0; c < 2 * AG; ++c) ra[set][c] = *reinterpret_cast<const f32x4*>(p + 4 * c);
         const f16x8* q = wsrc + (long)wslab * (H_B_BYTES / 16);
 #pragma unroll
         for (int c = 0; c < 4; ++c) rb[set][c] = q[c * 256];
@@ -295,21 +304,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
     auto store_slab = [&](int buf, auto SET) {
         constexpr int set = decltype(SET)::value;
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const f32x4 v0 = ra[set][2 * kh], v1 = ra[set][2 * kh + 1];
+        for (int g = 0; g < AG; ++g) {
+            const f32x4 v0 = ra[set][2 * g], v1 = ra[set][2 * g + 1];
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             f16x8 fh, fl;
             gemm_split8(v, fh, fl);
-            Af[buf][a_slot + 32 * kh] = fh;
-            Af[buf][a_slot + 32 * kh + 256] = fl;
+            Af[buf][a_slot(lgrp + g, 0)] = fh;
+            Af[buf][a_slot(lgrp + g, 1)] = fl;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) Bs[buf][tid + c * 256] = rb[set][c];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -319,18 +328,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
     auto mma_slab = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah[2], al[2];
+            f16x8 ah[MT], al[MT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                ah[mt] = Af[buf][((ks * 2 + 0) * 4 + wm * 2 + mt) * 64 + lane];
-                al[mt] = Af[buf][((ks * 2 + 1) * 4 + wm * 2 + mt) * 64 + lane];
+            for (int mt = 0; mt < MT; ++mt) {
+                ah[mt] = Af[buf][((ks * 2 + 0) * (2 * MT) + wm * MT + mt) * 64 + lane];
+                al[mt] = Af[buf][((ks * 2 + 1) * (2 * MT) + wm * MT + mt) * 64 + lane];
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const f16x8 bh = Bs[buf][((ks * 2 + 0) * 4 + wn * 2 + nt) * 64 + lane];
                 const f16x8 bl = Bs[buf][((ks * 2 + 1) * 4 + wn * 2 + nt) * 64 + lane];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
@@ -379,12 +388,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
             const float b0 = a.bias ? a.bias[col0] : 0.f, b1 = a.bias ? a.bias[col0 + 32] : 0.f;
             // z channel wn*32 + i = k-slab wn, k = i: k-step i/16, k half (i/8)&1, element i%8
             _Float16* zf = reinterpret_cast<_Float16*>(Af[wn]);
-            const int e_off = (((i >> 4) * 2 + 0) * 4 * 64 + 32 * ((i >> 3) & 1)) * 8 + (i & 7);   // part 0, mt 0, row 0
+            const int e_off = (((i >> 4) * 2 + 0) * (2 * MT) * 64 + 32 * ((i >> 3) & 1)) * 8 + (i & 7);   // part 0, mt 0, row 0
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 64 + mt * 32 + mfma_row(r, hi);
+                    const int row = wm * (32 * MT) + mt * 32 + mfma_row(r, hi);
                     float ca = acc[mt][0][r] + b0;
                     const float cb = acc[mt][1][r] + b1;
                     ca = fminf(fmaxf(ca, -10.f), 10.f);
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
                     const _Float16 vl = (_Float16)(v - (float)vh);
                     const int o = e_off + ((row >> 5) * 64 + (row & 31)) * 8;
                     zf[o] = vh;
-                    zf[o + 4 * 64 * 8] = vl;                         // part 1
+                    zf[o + (2 * MT) * 64 * 8] = vl;                  // part 1
                 }
             const f16x8* w2 = reinterpret_cast<const f16x8*>(a.Wh2) + tid;
 #pragma unroll
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -415,10 +424,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_h3(pk_gemm_args a) {
         b.epi = PK_EPI_STD;
         b.bias = a.bias2;
         b.act = PK_ACT_NONE;
-        gemm_epilogue(b, acc, m0, nblk, wm, wn, i, hi);
+        gemm_epilogue<MT>(b, acc, m0, nblk, wm, wn, i, hi);
         return;
     }
-    gemm_epilogue(a, acc, m0, nblk, wm, wn, i, hi);
+    gemm_epilogue<MT>(a, acc, m0, nblk, wm, wn, i, hi);
 }
 }  // namespace
 
@@ -563,7 +572,20 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     (void)nslabs;
     if (h3) {
         const std::string nm = std::string(prof_name) + "_h3";
-        PK_LAUNCH(ctx, nm.c_str(), k_gemm_h3, grid, dim3(256), 0, a);
+        // 128-row tiles at 2 workgroups per CU, or 64-row tiles at 3 per CU: take the 64-row grid when the
+        // 128-row one would leave the machine idle in its last round (fewer rounds-equivalents of work)
+        const long slots2 = 2L * ctx->n_cu, slots3 = 3L * ctx->n_cu;
+        const long wg2 = (long)grid.x * grid.y, wg1 = (long)((a.M + 63) / 64) * grid.y;
+        const double t2 = (double)((wg2 + slots2 - 1) / slots2);            // rounds of full-size work
+        static const double small_factor = getenv("PK_GEMM_SMALL_FACTOR") ? atof(getenv("PK_GEMM_SMALL_FACTOR")) : 0.7;
+        const double t1 = small_factor * (double)((wg1 + slots3 - 1) / slots3);   // half-size tiles, 3 per CU share the pipes
+        static const int force = getenv("PK_GEMM_TILE") ? atoi(getenv("PK_GEMM_TILE")) : 0;   // 64 / 128: measurement override
+        if (force == 64 || (force != 128 && t1 < t2)) {
+            dim3 g1((a.M + 63) / 64, grid.y);
+            PK_LAUNCH(ctx, nm.c_str(), k_gemm_h3<1>, g1, dim3(256), 0, a);
+        } else {
+            PK_LAUNCH(ctx, nm.c_str(), k_gemm_h3<2>, grid, dim3(256), 0, a);
+        }
         return PK_OK;
     }
     if (!a.Wp) PK_FAIL(PK_EINVAL, "GEMM: fp32 weights missing");
