@@ -108,14 +108,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # PK_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, weight broadcast, barriers, max-reduce) at N = 1
+    distributed = world > 1 or bool(os.environ.get("PK_BENCH_FORCE_DIST"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # stdout is for the one JSON line: RCCL prints its NCCL_DEBUG=VERSION banner (set on the GPU boxes) with
+        # printf when the communicator is created, so fd 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from parakeet_amd import synthetic as syn
     from parakeet_amd.runtime import Context
