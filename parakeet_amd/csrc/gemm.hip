@@ -542,10 +542,12 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
         PK_FAIL(PK_EUNSUPPORTED, "GEMM: input channels (%d, %d) must be multiples of %d", a.Cin, a.Cin2, BK);
     if (a.M <= 0 || a.N <= 0) PK_FAIL(PK_EINVAL, "GEMM: empty problem");
     // short-K problems are epilogue / memory bound: the fp32 kernel's higher occupancy wins there
-    // (WaveFlow out_proj, K = 64: 64 us vs 92 us)
+    // (WaveFlow out_proj, K = 64: 64 us vs 92 us); from K = 128 the split kernel with its 64-row tiles is ahead
+    // (WaveFlow C = 128 out_proj 140 -> 104 us, SpeedySpeech Linear layers)
     const int k_total = (a.ntaps ? a.ntaps : a.taps) * a.Cin + a.Cin2;
+    static const int h3_min_k = getenv("PK_GEMM_H3_MINK") ? atoi(getenv("PK_GEMM_H3_MINK")) : 128;
     const bool h3 = a.math == PK_GEMM_MATH_F16X3 && a.Wh && a.Cin % PK_GEMM_HBK == 0 && a.Cin2 % PK_GEMM_HBK == 0 &&
-                    k_total >= 256;
+                    k_total >= h3_min_k;
     const int bk = h3 ? PK_GEMM_HBK : BK;
     if (a.ntaps == 0) {
         if (a.taps > PK_GEMM_MAX_TAPS) PK_FAIL(PK_EUNSUPPORTED, "GEMM: more than %d taps", PK_GEMM_MAX_TAPS);
