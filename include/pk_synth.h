@@ -121,9 +121,9 @@ int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_
  *   PK_PWG_MATH_F16X3   each fp32 product as a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with fp16 parts
  *                       (11 + 11 significant bits per operand, dropped term 2^-22) on
  *                       v_mfma_f32_32x32x16_f16, fp32 accumulation.  Measured on the 30-layer generator:
- *                       relative max error 5.3e-7 vs the fp64 oracle -- the same as the exact path
- *                       (5.8e-7) and as a CPU fp32 run (6.0e-7).  5.3x less matrix-pipe time.  Needs
- *                       |activation| < 65000 (saturating split; a PWG residual stream is O(1..10));
+ *                       relative max error 7e-7 (rms 2.3e-7) vs the fp64 oracle -- the class of the exact
+ *                       path (5e-7, rms 1.9e-7) and of a CPU fp32 run (6e-7).  5.3x less matrix-pipe time.
+ *                       Needs |activation| < 65504 (saturating split; a PWG residual stream is O(1..10));
  *   PK_PWG_MATH_BF16X3  the same with bf16 parts (fp32 range, 8 + 8 bits): error 3.7e-6. */
 enum { PK_PWG_MATH_F32 = 0, PK_PWG_MATH_BF16X3 = 1, PK_PWG_MATH_F16X3 = 2 };
 int pk_pwg_set_math(pk_pwg* h, int32_t mode);
