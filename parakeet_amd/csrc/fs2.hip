@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_cumsum(const float* __restrict__ dur, c
         sh[threadIdx.x] = v;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
-            int add = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            int add = ((int)threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
             __syncthreads();
             sh[threadIdx.x] += add;
             __syncthreads();

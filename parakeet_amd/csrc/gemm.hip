@@ -227,8 +227,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm(pk_gemm_args a) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 constexpr int HBK = PK_GEMM_HBK;           // 32
-constexpr int A_LD = HBK + 4;              // 36 floats per row
-constexpr int H_A_FLOATS = BM * A_LD;      // 4608
 constexpr int H_B_BYTES = 2 * 2 * 4 * 64 * 16;   // 16 KB: [ks 2][part 2][nt 4][lane 64] x 16 B
 constexpr int H_DEPTH = 3;                 // slabs in flight between global memory and LDS
 

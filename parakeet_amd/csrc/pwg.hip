@@ -193,10 +193,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int wave = threadIdx.x >> 6;
     const int j = lane & 31;
     const int hi = lane >> 5;
-    const long Ttot = a.Ttot;
     const int d = a.dilation;
     const f32x4* lds_a = reinterpret_cast<const f32x4*>(lds) + lane;
-    const f32x4* lds_a2 = reinterpret_cast<const f32x4*>(lds + LDS_W1) + lane;
     float* lds_p = lds + LDS_W1 + LDS_W2 + LDS_BIAS + wave * LDS_PW;  // wave-private staging
 
     // Work unit = one wave-tile of 32 samples (8 per frame); waves are independent, so a workgroup
@@ -491,7 +489,6 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int wave = threadIdx.x >> 6;
     const int j = lane & 31;
     const int hi = lane >> 5;
-    const long Ttot = a.Ttot;
     const int d = a.dilation;
     const bf16x8* lds_a = reinterpret_cast<const bf16x8*>(lds) + lane;            // + ((ks*2+part)*4+q)*64
     const bf16x8* lds_a2 = reinterpret_cast<const bf16x8*>(lds + LDS_W1) + lane;
@@ -1255,7 +1252,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         tab.insert(tab.end(), v.begin(), v.end());
         return o;
     };
-    const size_t o_cuL = push(cuL), o_gap = push(gap_start);
+    push(cuL);
+    const size_t o_gap = push(gap_start);
     std::vector<int> frame_utt(sumL), tile_t0(sumL), tile_cls(sumL);
     for (int b = 0; b < B; ++b)
         for (int f = 0; f < frames[b]; ++f) {
