@@ -450,18 +450,24 @@ __device__ __forceinline__ void split_x8(const float (&v)[8], V& hi, V& lo) {
     }
 }
 // fp16 parts: the high part is rounded toward zero by v_cvt_pkrtz_f16_f32 (two elements per instruction;
-// it saturates at +-65504 instead of overflowing to inf, so no clamp is needed), the low part is the
-// round-to-nearest fp16 of the exact remainder: |x - hi - lo| <= 2^-21 |x|.  2.5 VALU ops per element.
+// it saturates at +-65504 instead of overflowing to inf, so no clamp is needed), the remainder x - hi is formed
+// exactly by v_fma_mix_f32 reading the packed fp16 high part in place (one instruction per element instead of
+// v_cvt_f32_f16 + subtract: -1 % on the layer kernel, A/B on one box), the low part is its round-to-nearest
+// fp16: |x - hi - lo| <= 2^-21 |x|.  2 VALU ops per element.
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 template <>
 __device__ __forceinline__ void split_x8<f16x8, _Float16, true>(const float (&v)[8], f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        float l0, l1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hu), "v"(v[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hu), "v"(v[2 * p + 1]));
         hi[2 * p] = (_Float16)h[0];
         hi[2 * p + 1] = (_Float16)h[1];
-        lo[2 * p] = (_Float16)(v[2 * p] - (float)h[0]);
-        lo[2 * p + 1] = (_Float16)(v[2 * p + 1] - (float)h[1]);
+        lo[2 * p] = (_Float16)l0;
+        lo[2 * p + 1] = (_Float16)l1;
     }
 }
 
