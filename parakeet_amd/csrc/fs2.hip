@@ -232,11 +232,17 @@ typedef __fp16 at_pkh2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void at_split8(const float (&v)[8], at_f16x8& hi, at_f16x8& lo) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
+        // hi = v_cvt_pkrtz (round toward zero, saturating at +-65504); x - hi exactly by v_fma_mix_f32 on the packed
+        // high part; lo = fp16_rne(x - hi): |x - hi - lo| <= 2^-21 |x|
         const at_pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        float l0, l1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hu), "v"(v[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hu), "v"(v[2 * p + 1]));
         hi[2 * p] = (_Float16)h[0];
         hi[2 * p + 1] = (_Float16)h[1];
-        lo[2 * p] = (_Float16)(v[2 * p] - (float)h[0]);
-        lo[2 * p + 1] = (_Float16)(v[2 * p + 1] - (float)h[1]);
+        lo[2 * p] = (_Float16)l0;
+        lo[2 * p + 1] = (_Float16)l1;
     }
 }
 __device__ __forceinline__ f32x16 at_mfma3(at_f16x8 ah, at_f16x8 al, at_f16x8 bh, at_f16x8 bl, f32x16 c) {
