@@ -194,3 +194,13 @@ def write_wav(path, wav, samplerate, subtype="PCM_16"):
     with open(path, "wb") as f:
         f.write(header)
         f.write(data)
+
+
+def stft(x, fft_size, hop_length=None, win_length=None, window="hann", center=True, pad_mode="reflect"):
+    """``parakeet.modules.stft_loss.stft`` (:20-67): (B, T) -> magnitude spectrogram (B, frames, fft_size//2+1),
+    ``sqrt(clip(re^2 + im^2, min=1e-7))``.  The transform runs on the engine (STFT-as-GEMM + magnitude kernel);
+    the floor is one elementwise maximum with sqrt(1e-7) on the result."""
+    win_length = win_length or fft_size
+    t = STFT(fft_size, hop_length, win_length, window, center, pad_mode)
+    mag = t.magnitude(x).as_subclass(torch.Tensor)                    # (B, bins, frames)
+    return wrap(torch.clamp_min(mag, float(np.sqrt(np.float32(1e-7)))).transpose(1, 2).contiguous())

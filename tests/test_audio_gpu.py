@@ -52,3 +52,22 @@ def test_mel_l1_metric_on_synthesised_audio():
     b = fb.get_log_mel_fbank(w * 2.0).numpy()
     assert np.abs(a - fb.get_log_mel_fbank(w).numpy()).mean() == 0.0
     assert abs(np.abs(b - a).mean() - np.log10(2.0)) < 1e-3
+
+
+def test_stft_function_of_stft_loss():
+    """parakeet.modules.stft_loss.stft (:20-67): clipped magnitude, (B, frames, bins)."""
+    from parakeet_amd.audio import stft
+    rng = np.random.default_rng(4)
+    x = rng.normal(scale=0.3, size=(2, 4096)).astype(np.float32)
+    x[1, 1000:3000] = 0.0                                            # silence: exercises the 1e-7 floor
+    got = stft(x, 512, 128, 512, "hann").cpu().numpy()
+    w = np.asarray(__import__("scipy.signal", fromlist=["get_window"]).get_window("hann", 512, fftbins=True))
+    xp = np.pad(x.astype(np.float64), ((0, 0), (256, 256)), mode="reflect")
+    frames = 1 + (xp.shape[1] - 512) // 128
+    ref = np.empty((2, frames, 257))
+    for f in range(frames):
+        spec = np.fft.rfft(xp[:, f * 128:f * 128 + 512] * w, axis=1)
+        ref[:, f] = np.sqrt(np.clip(spec.real ** 2 + spec.imag ** 2, 1e-7, None))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    assert got.min() >= np.sqrt(np.float32(1e-7)) * 0.999
