@@ -204,3 +204,60 @@ def stft(x, fft_size, hop_length=None, win_length=None, window="hann", center=Tr
     t = STFT(fft_size, hop_length, win_length, window, center, pad_mode)
     mag = t.magnitude(x).as_subclass(torch.Tensor)                    # (B, bins, frames)
     return wrap(torch.clamp_min(mag, float(np.sqrt(np.float32(1e-7)))).transpose(1, 2).contiguous())
+
+
+class LogMagnitude:
+    """parakeet/audio/spec_normalizer.py:37-53 (the WaveFlow / Tacotron2 feature domain): log(max(x, min))."""
+
+    def __init__(self, min=1e-5):   # noqa: A002  (the reference's argument name)
+        self.min = min
+
+    def transform(self, x):
+        return np.log(np.maximum(np.asarray(x), self.min))
+
+    def inverse(self, x):
+        return np.exp(np.asarray(x))
+
+
+class AudioProcessor:
+    """parakeet/audio/audio.py:20-102 with the transforms on the engine: ``spectrogram`` = |STFT|,
+    ``mel_spectrogram`` = mel_filter . |STFT| (the Slaney filterbank of ``librosa.filters.mel``), both returned
+    as (bins, frames) numpy arrays like the reference.  ``read_wav`` reads PCM / float RIFF files at the
+    processor's sample rate (the reference resamples with librosa, which this image does not have)."""
+
+    def __init__(self, sample_rate, n_fft, win_length, hop_length, n_mels=80, fmin=0, fmax=None, window="hann",
+                 center=True, pad_mode="reflect", normalize=True):
+        if pad_mode != "reflect":
+            raise NotImplementedError("only pad_mode='reflect' is implemented")
+        self.sample_rate, self.normalize = sample_rate, normalize
+        self.n_fft, self.win_length, self.hop_length = n_fft, win_length, hop_length
+        self.window, self.center, self.pad_mode = window, center, pad_mode
+        self.n_mels, self.fmin, self.fmax = n_mels, fmin, fmax
+        self.mel_filter = mel_filterbank(sample_rate, n_fft, n_mels, fmin or 0, fmax or sample_rate / 2)
+        self.inv_mel_filter = np.linalg.pinv(self.mel_filter)
+        self._spec = _Engine(n_fft, hop_length, win_length, window, center, False, None, 0)
+        self._mel = _Engine(n_fft, hop_length, win_length, window, center, False, self.mel_filter, 0)
+
+    def read_wav(self, filename):
+        import wave
+        with wave.open(str(filename), "rb") as w:
+            if w.getframerate() != self.sample_rate:
+                raise NotImplementedError(f"{filename}: {w.getframerate()} Hz, resampling to {self.sample_rate} Hz "
+                                          "needs librosa")
+            raw = w.readframes(w.getnframes())
+            ch, width = w.getnchannels(), w.getsampwidth()
+        if width != 2:
+            raise NotImplementedError("read_wav: 16-bit PCM only")
+        wav = np.frombuffer(raw, dtype="<i2").astype(np.float32).reshape(-1, ch).mean(axis=1) / 32768.0
+        if self.normalize:
+            wav = wav / np.max(np.abs(wav)) * 0.999
+        return wav
+
+    def write_wav(self, path, wav):
+        write_wav(path, wav, self.sample_rate)
+
+    def spectrogram(self, wav):
+        return self._spec.run([np.asarray(wav, dtype=np.float32)], 1)[0].cpu().numpy().T
+
+    def mel_spectrogram(self, wav):
+        return self._mel.run([np.asarray(wav, dtype=np.float32)], 2)[0].cpu().numpy().T

@@ -71,3 +71,28 @@ def test_stft_function_of_stft_loss():
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
     assert got.min() >= np.sqrt(np.float32(1e-7)) * 0.999
+
+
+def test_audio_processor_and_log_magnitude(tmp_path):
+    """AudioProcessor.spectrogram / mel_spectrogram (audio/audio.py:95-102) + LogMagnitude (the WaveFlow feature
+    domain, examples/waveflow/preprocess.py:57-87) against the oracle's librosa-algorithm restatement."""
+    from oracle import audio_ref
+    from parakeet_amd.audio import AudioProcessor, LogMagnitude
+    rng = np.random.default_rng(8)
+    wav = (0.3 * rng.normal(size=6000)).astype(np.float32)
+    p = AudioProcessor(sample_rate=22050, n_fft=1024, win_length=1024, hop_length=256, n_mels=80, fmin=0, fmax=8000)
+    S = p.spectrogram(wav)
+    M = p.mel_spectrogram(wav)
+    re_im = audio_ref.stft(torch.from_numpy(wav)[None], 1024, 256, 1024, "hann")
+    ref_S = torch.sqrt(re_im[0] ** 2 + re_im[1] ** 2)[0].numpy()
+    assert S.shape == ref_S.shape == (513, 1 + 6000 // 256)
+    assert np.abs(S - ref_S).max() < 2e-4 * ref_S.max()
+    basis = audio_ref.mel_filterbank(22050, 1024, 80, 0, 8000)
+    ref_M = basis @ ref_S
+    assert np.abs(M - ref_M).max() < 2e-4 * ref_M.max()
+    norm = LogMagnitude(1e-5)
+    logm = norm.transform(M)
+    assert np.allclose(norm.inverse(logm), np.maximum(M, 1e-5), rtol=1e-6)
+    p.write_wav(tmp_path / "x.wav", wav)
+    back = AudioProcessor(22050, 1024, 1024, 256, normalize=False).read_wav(tmp_path / "x.wav")
+    assert np.abs(back - np.clip(wav, -1, 1)).max() < 2.0 / 32768      # written x 32767, read / 32768, + rounding
