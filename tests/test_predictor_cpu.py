@@ -27,3 +27,16 @@ def test_predictor_protocol():
     out = p.get_output_handle(p.get_output_names()[0]).copy_to_cpu()
     assert out.shape == (6, 3) and np.array_equal(out[:, 0], (a + b).astype(np.float32))
     assert len(calls) == 1
+
+
+def test_nets_utils_worked_examples():
+    """The docstring examples of parakeet/modules/nets_utils.py:36-42,71-75,119-123 and fastspeech2.py:634-637."""
+    from parakeet_amd import nets_utils as nu
+    x = [np.ones(4), np.ones(2), np.ones(1)]
+    assert np.array_equal(nu.pad_list(x, 0), [[1, 1, 1, 1], [1, 1, 0, 0], [1, 0, 0, 0]])
+    assert np.array_equal(nu.make_pad_mask([5, 3, 2]).astype(int), [[0, 0, 0, 0, 0], [0, 0, 0, 1, 1], [0, 0, 1, 1, 1]])
+    assert np.array_equal(nu.make_non_pad_mask(np.array([5, 3, 2])).astype(int),
+                          [[1, 1, 1, 1, 1], [1, 1, 1, 0, 0], [1, 1, 0, 0, 0]])
+    assert nu.source_mask([5, 3]).shape == (2, 1, 5)
+    with pytest.raises(ValueError):
+        nu.make_pad_mask([3], length_dim=0)
