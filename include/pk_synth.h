@@ -361,6 +361,13 @@ int pk_op_conv1d_batchnorm_nlc(pk_ctx* ctx, const float* x, int32_t B, int32_t T
                                const float* bias, const float* bn_weight, const float* bn_bias,
                                const float* bn_mean, const float* bn_var, float eps, float* y);
 
+/* expand (modules/expansion.py:19-37; LengthRegulator.expand length_regulator.py:46-66 without the alpha
+ * scaling): token t of utterance b is repeated durations[b][t] times; sequences shorter than the longest are
+ * zero-padded.  encodings (B, T, C) device; durations HOST int64 (B, T), >= 0; out (B, t_dec, C) device with
+ * t_dec = max_b sum_t durations[b][t], which the caller computes to size `out` (0 is allowed: nothing is written). */
+int pk_op_expand(pk_ctx* ctx, const float* encodings, const int64_t* durations, int32_t B, int32_t T, int32_t C,
+                 int32_t t_dec, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,7 @@ def _declare(lib):
         "pk_mel_num_frames": (C.c_int, [vp, i32, i32p]),
         "pk_mel_run": (C.c_int, [vp, f32p, i32p, i32, f32p, i32, i32]),
         "pk_mel_destroy": (None, [vp]),
+        "pk_op_expand": (C.c_int, [vp, f32p, i64p, i32, i32, i32, i32, f32p]),
         "pk_op_sinusoid_position_encoding": (C.c_int, [vp, i32, i32, C.c_float, i32, f32p]),
         "pk_op_scaled_dot_product_attention": (C.c_int, [vp, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32,
                                                          f32p, f32p]),

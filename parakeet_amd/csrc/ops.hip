@@ -4,6 +4,7 @@
 //   Conv1dBatchNorm.forward      parakeet/modules/conv.py:186-260 (eval mode, NLC layout)
 // Not on the FastSpeech2/PWG/WaveFlow path; they serve the other models' inference code.
 #include <cmath>
+#include <vector>
 
 #include "pk_gemm.h"
 
@@ -51,6 +52,14 @@ __global__ void k_randn(float* __restrict__ out, long n, unsigned long long seed
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (blk * 4 + e < n) out[blk * 4 + e] = z[e];
+}
+
+// out[r] = src[r] >= 0 ? enc[src[r]] : 0   (row gather of the expansion / length regulator)
+__global__ __launch_bounds__(128) void k_gather_rows(const float* __restrict__ enc, const int* __restrict__ src, int C,
+                                                     float* __restrict__ out) {
+    const long r = blockIdx.x;
+    const int s = src[r];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[r * C + c] = s >= 0 ? enc[(long)s * C + c] : 0.f;
 }
 
 // enc[pos][2i] = sin(p), enc[pos][2i+1] = cos(p), p = (start + pos) * omega / 10000^(2i / size)
@@ -146,6 +155,36 @@ extern "C" int pk_randn(pk_ctx* ctx, float* out, int64_t n, uint64_t seed, uint6
         if (e != hipSuccess) { (void)hipFree(d); PK_FAIL(PK_EHIP, "pk_randn: %s", hipGetErrorString(e)); }
     }
     (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int pk_op_expand(pk_ctx* ctx, const float* encodings, const int64_t* durations, int32_t B, int32_t T,
+                            int32_t C, int32_t t_dec, float* out) {
+    if (!ctx || !encodings || !durations || (!out && t_dec > 0)) PK_FAIL(PK_EINVAL, "pk_op_expand: NULL argument");
+    if (B <= 0 || T <= 0 || C <= 0 || t_dec < 0) PK_FAIL(PK_EINVAL, "expand: bad shape");
+    PK_HIP(hipSetDevice(ctx->device));
+    std::vector<int> src((size_t)B * t_dec, -1);
+    for (int b = 0; b < B; ++b) {
+        long k = 0;
+        for (int t = 0; t < T; ++t) {
+            const int64_t d = durations[(size_t)b * T + t];
+            if (d < 0) PK_FAIL(PK_EINVAL, "expand: negative duration at (%d, %d)", b, t);
+            if (k + d > t_dec) PK_FAIL(PK_ESHAPE, "expand: utterance %d needs more than t_dec = %d frames", b, t_dec);
+            for (int64_t i = 0; i < d; ++i) src[(size_t)b * t_dec + k + i] = b * T + t;
+            k += d;
+        }
+    }
+    if (t_dec == 0) return PK_OK;
+    pk_dbuf d_src;
+    int rc = pk_upload(ctx, d_src, src.data(), src.size() * sizeof(int));
+    if (rc == PK_OK) {
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((size_t)B * t_dec)), dim3(128), 0, ctx->stream, encodings,
+                           d_src.as<int>(), C, out);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // d_src is released below
+        if (e != hipSuccess) { d_src.release(); PK_FAIL(PK_EHIP, "pk_op_expand: %s", hipGetErrorString(e)); }
+    }
+    d_src.release();
     return rc;
 }
 

@@ -21,6 +21,22 @@ def sinusoid_position_encoding(num_positions, feature_size, omega=1.0, start_pos
     return wrap(out)
 
 
+def expand(encodings, durations):
+    """parakeet/modules/expansion.py:19-37: (B, T, C), (B, T) integer durations -> (B, t_dec, C), token t repeated
+    durations[b][t] times, shorter sequences zero-padded (the reference builds a dense 0/1 matrix and matmuls)."""
+    ctx = Context.get()
+    enc = ctx.to_device(encodings).contiguous()
+    d = np.ascontiguousarray(np.asarray(durations.cpu() if isinstance(durations, torch.Tensor) else durations)
+                             .astype(np.int64))
+    B, T, Cc = enc.shape
+    assert d.shape == (B, T), "durations must be (B, T)"
+    t_dec = max(int(np.maximum(d, 0).sum(-1).max()), 0) if d.size else 0
+    out = ctx.empty((B, t_dec, Cc))
+    _capi.check(ctx.lib.pk_op_expand(ctx.handle, dptr(enc), d.ctypes.data_as(C.POINTER(C.c_int64)), B, T, Cc, t_dec,
+                                     dptr(out) if t_dec else None))
+    return wrap(out)
+
+
 def scaled_dot_product_attention(q, k, v, mask=None, dropout=0.0, training=True):
     if dropout and training:
         raise NotImplementedError("attention dropout is a training-time path")

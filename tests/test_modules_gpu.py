@@ -106,3 +106,23 @@ def test_multihead_attention_matches_torch_reference():
     assert np.abs(out.cpu().numpy() - ref.numpy()).max() < 1e-4
     with pytest.raises(ValueError):
         MultiheadAttention(30, 4)
+
+
+def test_expand_matches_reference_construction():
+    """modules/expansion.py:19-37 (the case of tests/unit/test_expansion.py:20-24 plus a zero-duration token)."""
+    from parakeet_amd.modules import expand
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(2, 4, 3)).astype(np.float32)
+    d = np.array([[1, 2, 2, 1], [3, 1, 4, 0]])
+    y = expand(x, d).cpu().numpy()
+    assert y.shape == (2, 8, 3)
+    M = np.zeros((2, 8, 4))
+    for i in range(2):
+        k = 0
+        for j in range(4):
+            M[i, k:k + d[i, j], j] = 1
+            k += d[i, j]
+    assert np.array_equal(y, (M @ x).astype(np.float32))
+    assert np.array_equal(y[0, 6:], np.zeros((2, 3), np.float32))          # padding of the shorter sequence
+    with pytest.raises(ValueError):
+        expand(x, -d)
