@@ -250,6 +250,37 @@ def main():
             del wf
         except Exception as e:  # never let an extra break the headline line
             extras["waveflow_c64_batch8"] = {"error": repr(e)}
+        try:   # the two acoustic models alone (BASELINE config 2 shape at 32 utterances; SpeedySpeech)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                synth.am.inference_batch(texts)
+            torch.cuda.synchronize()
+            dta = (time.perf_counter() - t1) / args.steps
+            extras["fastspeech2_batch32"] = {
+                "what": "FastSpeech2 inference alone, 32 x 128 tokens -> 640 frames, default math",
+                "ms_per_batch": dta * 1e3, "utterances_per_s": UTT_PER_GPU / dta,
+                "algorithmic_tflops": 30.26e9 * UTT_PER_GPU / dta / 1e12}
+            from parakeet_amd.speedyspeech import SpeedySpeech
+            ssm = SpeedySpeech(vocab_size=70, tone_size=7, **syn.SPEEDYSPEECH_BAKER)
+            ssm.set_state_dict(syn.speedyspeech_state())
+            ssm.eval()
+            rng = np.random.default_rng(0)
+            ph = [rng.integers(1, 70, size=TOKENS) for _ in range(UTT_PER_GPU)]
+            tn = [rng.integers(1, 7, size=TOKENS) for _ in range(UTT_PER_GPU)]
+            outs = ssm.inference_batch(ph, tn)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                outs = ssm.inference_batch(ph, tn)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / args.steps
+            extras["speedyspeech_baker_batch32"] = {
+                "what": "SpeedySpeech (baker configuration) inference alone, 32 x 128 phones with tones",
+                "ms_per_batch": dts * 1e3, "utterances_per_s": UTT_PER_GPU / dts,
+                "frames": int(sum(o.shape[0] for o in outs))}
+            del ssm
+        except Exception as e:
+            extras["acoustic_models"] = {"error": repr(e)}
 
     if rank == 0:
         total_samples = n_samples * world
