@@ -1,16 +1,21 @@
 #!/usr/bin/env python
 """Headline benchmark: audio samples/sec of FastSpeech2 + Parallel WaveGAN synthesis at 22.05 kHz.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+    (N > 1: either launched by the driver as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`, or plain `python bench.py --gpus N`, which
+     re-executes itself under torch.distributed.run with N ranks on 127.0.0.1)
 
 One "step" = one pass of the synthesis hot path (FastSpeech2.inference ->
 PWGGenerator.inference, mel stays in HBM) over one batch of synthetic
 utterances of LJSpeech shape.  Per GPU the batch is BASELINE.json config 4's
 per-GPU share: 256 utterances / 8 GPUs = 32 utterances of T = 128 phonemes,
 every phoneme 5 frames -> L = 640 frames -> 163 840 samples (7.43 s) each.
-Work per GPU is fixed as N grows (weak scaling); utterances are independent so
-there is no data-path collective (parakeet_amd/dist.py).  Inputs (token ids,
+Work per GPU is fixed as N grows (weak scaling, the default); `--scaling strong` instead splits the SAME 256
+utterances (BASELINE config 4) over the N ranks with parakeet_amd.dist.shard_indices, each rank running its
+share in mini-batches of 32.  Utterances are independent so there is no data-path collective
+(parakeet_amd/dist.py); collecting the packed waveforms on every rank (`gather_ragged`, one RCCL all_gather)
+is timed separately and reported as `gather_ms`, it is not part of `value`.  Inputs (token ids,
 vocoder noise) are generated before the timed region and the noise is resident
 in HBM; random-initialised weights of the reference architecture
 (parakeet_amd/synthetic.py).  Everything is stored and accumulated in fp32.  The dense contractions use
@@ -72,28 +77,84 @@ def build_models(device):
     return synth, fs2_state, pwg_state, (mu_f, sg_f, mu_p, sg_p)
 
 
-def cpu_baseline(fs2_state, pwg_state, stats):
-    """Time the torch-CPU oracle ("port") on a bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5):
+    """Time the torch-CPU oracle ("port") on a bounded sample of the same workload: utterance 0 of the
+    benchmark batch (same ids, same noise), BASELINE.md section 2's protocol -- `warmup` untimed runs
+    (on a quarter-length utterance: they only warm the thread pool / allocator / oneDNN primitives),
+    `timed` full runs, median.  Returns (record, logmel, wav) of the last run for the parity check."""
     from oracle import fastspeech2_ref, pwg_ref
-    from parakeet_amd import synthetic as syn
-    cores = min(os.cpu_count() or 1, 32)  # MKL/oneDNN stop scaling on these small convs well before 32
-    torch.set_num_threads(cores)
-    tokens = TOKENS  # one full utterance of the workload: 128 tokens -> 640 frames -> 163 840 samples
-    ids = syn.phoneme_ids(tokens, seed=10086)
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()          # the threads torch actually uses, not a cap
     mu_f, sg_f, mu_p, sg_p = stats
-    noise = torch.from_numpy(np.random.default_rng(42).normal(size=tokens * FRAMES_PER_TOKEN * HOP).astype(np.float32))
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        logmel = fastspeech2_ref.fastspeech2_inference(fs2_state, mu_f, sg_f, ids)
-        wav = pwg_ref.pwg_inference(pwg_state, mu_p, sg_p, logmel, noise)
-    dt = time.perf_counter() - t0
+    noise = torch.as_tensor(noise).float().cpu()
+
+    def run(tok_ids, nz):
+        with torch.no_grad():
+            logmel = fastspeech2_ref.fastspeech2_inference(fs2_state, mu_f, sg_f, tok_ids)
+            wav = pwg_ref.pwg_inference(pwg_state, mu_p, sg_p, logmel, nz)
+        return logmel, wav
+
+    short = max(len(ids) // 4, 1)
+    for _ in range(warmup):
+        run(ids[:short], noise[:short * FRAMES_PER_TOKEN * HOP])
+    times = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        logmel, wav = run(ids, noise)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     n = int(wav.shape[0])
-    return {
-        "value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-        "sample": f"1 utterance, {tokens} tokens -> {n // HOP} frames -> {n} samples, FastSpeech2+PWG "
-                  f"torch-CPU fp32 oracle (Paddle-equivalent restatement), {dt:.1f} s wall",
+    rec = {
+        "value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+        "sample": f"utterance 0 of the benchmark batch ({len(ids)} tokens -> {n // HOP} frames -> {n} samples), "
+                  f"FastSpeech2+PWG torch-CPU fp32 oracle (Paddle-equivalent restatement); {warmup} warm-up + "
+                  f"{timed} timed runs, median {dt:.2f} s (min {min(times):.2f}, max {max(times):.2f})",
         "x_realtime": n / dt / SAMPLE_RATE,
     }
+    return rec, logmel.numpy(), wav[:, 0].numpy()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, PK_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class _DryStep:
+    """--dry-run only (tests/test_bench_cpu.py): stands in for the engine so that the orchestration around it
+    -- rank/shard bookkeeping, weight broadcast, barriers, max-over-ranks timing, ragged gather, the JSON
+    line -- runs on CPU over gloo.  Produces zeros of the right length; never reports a throughput."""
+
+    def __init__(self, n_tokens):
+        self.n_tokens = n_tokens
+
+    def __call__(self, texts, noise):
+        frames = np.full(len(texts), self.n_tokens * FRAMES_PER_TOKEN, dtype=np.int32)
+        return torch.zeros(int(frames.sum()) * HOP), frames
 
 
 def main():
@@ -101,19 +162,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 32 utterances per GPU; strong: the same --global-batch utterances split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=256, help="utterances of a strong-scaling step")
+    ap.add_argument("--minibatch", type=int, default=UTT_PER_GPU, help="utterances per engine call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-value extra measurements")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU/gloo rehearsal of the multi-process orchestration with a stub in place of the engine "
+                         "(test infrastructure; prints value null)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.dry_run and (not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
+        raise SystemExit(self_spawn(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     # PK_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, weight broadcast, barriers, max-reduce) at N = 1
     distributed = world > 1 or bool(os.environ.get("PK_BENCH_FORCE_DIST"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    if distributed:
+    dry = args.dry_run
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} needs HIP device {local_rank}, {torch.cuda.device_count()} visible")
+        torch.cuda.set_device(local_rank)
+    dev = "cpu" if dry else "cuda"
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    if distributed and dry:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    elif distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # stdout is for the one JSON line: RCCL prints its NCCL_DEBUG=VERSION banner (set on the GPU boxes) with
@@ -125,34 +214,54 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
+            assert dist.get_world_size() == args.gpus, "RCCL communicator does not span --gpus ranks"
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    from parakeet_amd import dist as pdist
     from parakeet_amd import synthetic as syn
-    from parakeet_amd.runtime import Context
 
-    synth, fs2_state, pwg_state, stats = build_models(local_rank)
-    if distributed:
-        # weights come from rank 0 over RCCL (one flat broadcast per model), as a deployment would do it
-        from parakeet_amd import dist as pdist
-        fs2_b = pdist.broadcast_state_dict(fs2_state, src=0)
-        pwg_b = pdist.broadcast_state_dict(pwg_state, src=0)
-        synth.am.set_state_dict(fs2_b)
-        synth.voc.set_state_dict(pwg_b)
+    if dry:
+        synth, fs2_state, pwg_state, stats = _DryStep(TOKENS), {"w": np.arange(8, dtype=np.float32)}, {}, None
+        if distributed:
+            got = pdist.broadcast_state_dict(fs2_state if rank == 0 else {"w": np.zeros(8, np.float32)}, src=0)
+            assert np.array_equal(got["w"], fs2_state["w"])
+    else:
+        from parakeet_amd.runtime import Context
+        synth, fs2_state, pwg_state, stats = build_models(local_rank)
+        if distributed:
+            # weights come from rank 0 over RCCL (one flat broadcast per model), as a deployment would do it
+            fs2_b = pdist.broadcast_state_dict(fs2_state, src=0)
+            pwg_b = pdist.broadcast_state_dict(pwg_state, src=0)
+            synth.am.set_state_dict(fs2_b)
+            synth.voc.set_state_dict(pwg_b)
 
-    # this rank's shard of the global batch (weak scaling: UTT_PER_GPU each)
-    base = rank * UTT_PER_GPU
-    texts = [syn.phoneme_ids(TOKENS, seed=10086 + base + i) for i in range(UTT_PER_GPU)]
-    n_samples = UTT_PER_GPU * TOKENS * FRAMES_PER_TOKEN * HOP
-    gen = torch.Generator(device="cuda")
+    # this rank's utterances.  weak: UTT_PER_GPU per rank (global batch grows with N); strong: the same
+    # --global-batch utterances for every N, dealt out by cost (all equal here) with shard_indices
+    if args.scaling == "weak":
+        own = list(range(rank * UTT_PER_GPU, (rank + 1) * UTT_PER_GPU))
+        global_batch = UTT_PER_GPU * world
+    else:
+        global_batch = args.global_batch
+        own = pdist.shard_indices([TOKENS] * global_batch, world, rank)
+    texts_all = [syn.phoneme_ids(TOKENS, seed=10086 + i) for i in own]
+    per_utt = TOKENS * FRAMES_PER_TOKEN * HOP
+    n_samples = len(own) * per_utt                      # this rank's samples per step
+    mb = max(1, args.minibatch)
+    chunks = [(a, min(a + mb, len(own))) for a in range(0, len(own), mb)]
+    gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
-    noise = torch.randn(n_samples, device="cuda", generator=gen)
+    noise = torch.randn(n_samples, device=dev, generator=gen)   # resident in HBM before the timed region
 
     def step():
-        wav, frames = synth.synthesize_packed(texts, noise=noise)
-        return wav, frames
+        """One pass of the hot path over this rank's share; returns the last mini-batch's (wav, frames)."""
+        out = None
+        for a, b in chunks:
+            nz = noise[a * per_utt:b * per_utt]
+            out = synth(texts_all[a:b], nz) if dry else synth.synthesize_packed(texts_all[a:b], noise=nz)
+        return out
 
     def barrier():
         if distributed:
@@ -162,23 +271,52 @@ def main():
     wav, frames = step()  # build / first-touch pass (allocations, weight packing); never timed
     for _ in range(args.warmup):
         wav, frames = step()
-    torch.cuda.synchronize()
-    assert int(frames.sum()) * HOP == n_samples, "synthetic duration head must give 5 frames per token"
+    sync()
+    a_last, b_last = chunks[-1]
+    assert int(frames.sum()) * HOP == (b_last - a_last) * per_utt, "synthetic duration head must give 5 frames per token"
     assert bool(torch.isfinite(wav).all()), "non-finite waveform"
 
     barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wav, frames = step()
-    torch.cuda.synchronize()
+    sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    gather_ms = None
     if distributed:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # result collection: every rank's packed waveform of its last mini-batch on every rank --
+        # one all_gather of the lengths + one padded all_gather; timed on its own, never part of `value`
+        lens = [int(f) * HOP for f in frames]
+        pdist.gather_ragged(wav, lens)      # communicator / buffer warm-up
+        barrier()
+        sync()
+        tg = time.perf_counter()
+        bufs, meta = pdist.gather_ragged(wav, lens)
+        sync()
+        tgm = torch.tensor([time.perf_counter() - tg], device=dev, dtype=torch.float64)
+        dist.all_reduce(tgm, op=dist.ReduceOp.MAX)
+        gather_ms = float(tgm.item()) * 1e3
+        assert [int(b.numel()) for b in bufs] == [sum(m) for m in meta] and len(bufs) == world
+
+    if dry:
+        if rank == 0:
+            print(json.dumps({
+                "metric": "audio samples/sec, FastSpeech2+PWGAN 22.05kHz", "value": None, "unit": "samples/s",
+                "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "scaling": args.scaling, "gather_ms": gather_ms,
+                "config": {"global_batch": global_batch, "utterances_this_rank": len(own),
+                           "minibatches_per_step": len(chunks)}}))
+        if distributed:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
     ctx = Context.get(local_rank)
@@ -189,10 +327,22 @@ def main():
         step()
     prof = ctx.prof_dump()
     ctx.prof_enable(False)
+    layer_samples = (chunks[0][1] - chunks[0][0]) * per_utt   # samples one PWG layer launch processes
+
+    # ---- the engine's output for utterance 0 of this rank's first mini-batch (default math), kept for the
+    # parity check against the CPU oracle below (same ids, same noise; outside the timed region)
+    parity_src = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        a0, b0 = chunks[0]
+        w0, _ = synth.synthesize_packed(texts_all[a0:b0], noise=noise[a0 * per_utt:b0 * per_utt])
+        m0 = synth.am.decode_packed(denormalize=True)
+        torch.cuda.synchronize()
+        parity_src = (m0[:TOKENS * FRAMES_PER_TOKEN].cpu().numpy(), w0[:per_utt].cpu().numpy())
 
     # ---- extra measurements (do not feed `value`): the split-bf16 PWG matrix path, WaveFlow
     extras = {}
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and args.scaling == "weak":
+        texts = texts_all[:UTT_PER_GPU]
         for mode, key in (("f32", "all_exact_f32_mfma"), ("bf16x3", "pwg_bf16x3_split")):
             synth.voc.set_math(mode)
             synth.am.set_math("f32" if mode == "f32" else "f16x3")
@@ -283,21 +433,21 @@ def main():
             extras["acoustic_models"] = {"error": repr(e)}
 
     if rank == 0:
-        total_samples = n_samples * world
+        total_samples = global_batch * per_utt             # whole job, all ranks, per step
         ms_per_step = elapsed / args.steps * 1e3
         value = total_samples * args.steps / elapsed
         layer_key = next((k for k in ("pwg_layer_h3", "pwg_layer_b3", "pwg_layer") if k in prof), "pwg_layer")
         n_layer, ms_layer = prof.get(layer_key, (0, 0.0))
         avg_ms = ms_layer / max(n_layer, 1)
-        flop_per_launch = PWG_LAYER_FLOP_PER_SAMPLE * n_samples
-        bytes_per_launch = PWG_LAYER_BYTES_PER_SAMPLE * n_samples
+        flop_per_launch = PWG_LAYER_FLOP_PER_SAMPLE * layer_samples
+        bytes_per_launch = PWG_LAYER_BYTES_PER_SAMPLE * layer_samples
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pwg_layer_traffic.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("prof_key", "pwg_layer") == layer_key:
+                if tj.get("prof_key", "pwg_layer") == layer_key and tj.get("samples_per_launch", 32 * per_utt) == layer_samples:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -322,7 +472,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "dtype_note": "fp32 storage and accumulation everywhere; the dense contractions (PWG residual blocks and "
@@ -337,8 +487,9 @@ def main():
                 "workload": "FastSpeech2+PWG end-to-end (BASELINE config 4 per-GPU share): "
                             f"{UTT_PER_GPU} utterances/GPU x {TOKENS} phonemes -> {TOKENS * FRAMES_PER_TOKEN} frames "
                             f"-> {TOKENS * FRAMES_PER_TOKEN * HOP} samples each, LJSpeech architecture, random-init weights",
-                "utterances_per_gpu": UTT_PER_GPU,
-                "global_batch": UTT_PER_GPU * world,
+                "utterances_per_gpu": len(own),
+                "global_batch": global_batch,
+                "minibatch": mb,
                 "parallelism": f"dp{world} (utterance sharding, no data-path collective)",
             },
             "roofline": dict(roof, **{
@@ -350,7 +501,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_tflops": flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-                "engine_min_bytes_per_launch": PWG_LAYER_MIN_BYTES_PER_SAMPLE * n_samples,
+                "engine_min_bytes_per_launch": PWG_LAYER_MIN_BYTES_PER_SAMPLE * layer_samples,
                 "note": "algorithmic bytes = SURVEY.md 8(d) layer-granular model, 1344 B/sample/layer x samples per "
                         "launch; the engine itself never materialises the upsampled conditioning (1024 B/sample)",
                 "traffic_source": "profiles/pwg_layer_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
@@ -361,8 +512,24 @@ def main():
         }
         if extras:
             out["extras"] = extras
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+            out["gather_note"] = ("parakeet_amd.dist.gather_ragged of every rank's packed waveform (last mini-batch) "
+                                  "onto every rank: one all_gather of lengths + one padded RCCL all_gather; not in `value`")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fs2_state, pwg_state, stats)
+            rec, ref_mel, ref_wav = cpu_baseline(fs2_state, pwg_state, stats, texts_all[0], noise[:per_utt].cpu())
+            out["cpu_baseline"] = rec
+            if parity_src is not None:
+                got_mel, got_wav = parity_src
+                out["parity_check"] = {
+                    "what": "engine (default math, inside the 32-utterance batch) vs the fp32 CPU oracle run timed above: "
+                            "same token ids, same vocoder noise, utterance 0",
+                    "frames_equal": bool(got_mel.shape == ref_mel.shape),
+                    "mel_l1": float(np.abs(got_mel - ref_mel).mean()) if got_mel.shape == ref_mel.shape else None,
+                    "wav_relmax": float(np.abs(got_wav - ref_wav).max() / (np.abs(ref_wav).max() + 1e-30))
+                    if got_wav.shape == ref_wav.shape else None,
+                    "bars": {"mel_l1": 1e-4, "wav_relmax": 1e-4},
+                }
         print(json.dumps(out))
     if distributed:
         import torch.distributed as dist

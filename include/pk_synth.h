@@ -55,9 +55,16 @@ typedef enum {
 
 enum {
     PK_HOST_IO = 1,            /* flags bit: data pointers are host memory */
-    PK_PWG_C_HAS_CONTEXT = 2   /* pk_pwg_infer: mel rows already carry aux_context_window frames on both
+    PK_PWG_C_HAS_CONTEXT = 2,  /* pk_pwg_infer: mel rows already carry aux_context_window frames on both
                                   sides of every utterance (PWGGenerator.forward); default: the engine
                                   replicate-pads (PWGGenerator.inference) */
+    PK_APPLY_NORMALIZER = 4    /* pk_fs2_decode / pk_ss_decode / pk_pwg_infer: apply the ZScore registered with
+                                  pk_*_set_normalizer in THIS call (the *Inference wrappers of the reference:
+                                  FastSpeech2Inference.forward fastspeech2.py:668-671, PWGInference.forward
+                                  parallel_wavegan.py:772-775, SpeedySpeechInference.forward :221-231).
+                                  Without it the call stays in the model's own (normalised) domain, as
+                                  model.inference() does in the reference -- the registered statistics are
+                                  per-handle state, their use is per call */
 };
 
 typedef struct pk_ctx pk_ctx;
@@ -360,6 +367,12 @@ int pk_op_conv1d_batchnorm_nlc(pk_ctx* ctx, const float* x, int32_t B, int32_t T
                                int32_t Cout, int32_t k, int32_t pad, const float* weight,
                                const float* bias, const float* bn_weight, const float* bn_bias,
                                const float* bn_mean, const float* bn_var, float eps, float* y);
+
+/* Plain row-major product y[M][N] = x[M][K] . w[K][N] (+ bias[N]) on the exact-fp32 MFMA GEMM: the
+ * `paddle.matmul(self.weight, spectrogram)` of MelScale.forward (modules/audio.py:226-229) with rows =
+ * (batch, frame).  x, y device; w, bias (or NULL) HOST.  Synchronous (the weight is packed per call). */
+int pk_op_matmul(pk_ctx* ctx, const float* x, int32_t M, int32_t K, int32_t N, const float* w,
+                 const float* bias, float* y);
 
 /* expand (modules/expansion.py:19-37; LengthRegulator.expand length_regulator.py:46-66 without the alpha
  * scaling): token t of utterance b is repeated durations[b][t] times; sequences shorter than the longest are

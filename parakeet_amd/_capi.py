@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpk_synth.so")
 PK_OK = 0
 PK_HOST_IO = 1
 PK_PWG_C_HAS_CONTEXT = 2
+PK_APPLY_NORMALIZER = 4
 PK_PWG_MATH_F32, PK_PWG_MATH_BF16X3, PK_PWG_MATH_F16X3 = 0, 1, 2
 _EXC = {
     -1: ValueError,
@@ -137,6 +138,7 @@ def _declare(lib):
         "pk_op_sinusoid_position_encoding": (C.c_int, [vp, i32, i32, C.c_float, i32, f32p]),
         "pk_op_scaled_dot_product_attention": (C.c_int, [vp, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32,
                                                          f32p, f32p]),
+        "pk_op_matmul": (C.c_int, [vp, f32p, i32, i32, i32, f32p, f32p, f32p]),
         "pk_op_conv1d_batchnorm_nlc": (C.c_int, [vp, f32p, i32, i32, i32, i32, i32, i32, f32p, f32p, f32p, f32p,
                                                  f32p, f32p, C.c_float, f32p]),
     }
@@ -155,6 +157,12 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP engine is not built "
                 "(run `python -m parakeet_amd.build`); there is no CPU fallback")
+        from . import build as _build
+        want, have = _build.source_hash(), _build.library_hash(LIB_PATH)
+        if have != want and not os.environ.get("PK_ALLOW_STALE_LIB"):
+            raise RuntimeError(
+                f"{LIB_PATH} was built from other sources (library {str(have)[:12]}, tree {want[:12]}): "
+                "run `python -m parakeet_amd.build` (or __graft_entry__.build()); a stale engine is never used")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

@@ -134,9 +134,24 @@ class MelScale:
 
     def __init__(self, sr, n_fft, n_mels, fmin, fmax):
         self.weight = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
+        self._wkn = np.ascontiguousarray(self.weight.numpy().T)          # [n_freq][n_mels]
 
     def forward(self, spec):
-        return torch.matmul(self.weight.to(spec.device), spec)
+        """``paddle.matmul(self.weight, spectrogram)`` as one engine GEMM over rows = (batch, frame)
+        (``pk_op_matmul``); torch only moves data (the NCL <-> rows transposes)."""
+        ctx = Context.get()
+        spec = ctx.to_device(spec)
+        squeeze = spec.dim() == 2
+        if squeeze:
+            spec = spec[None]
+        B, F, T = spec.shape
+        assert F == self._wkn.shape[0], "MelScale: spectrogram has the wrong number of frequency bins"
+        n_mels = self._wkn.shape[1]
+        x = spec.transpose(1, 2).contiguous().reshape(B * T, F)
+        y = ctx.empty((B * T, n_mels))
+        _capi.check(ctx.lib.pk_op_matmul(ctx.handle, dptr(x), B * T, F, n_mels, _capi.fptr(self._wkn), None, dptr(y)))
+        out = y.reshape(B, T, n_mels).transpose(1, 2).contiguous()
+        return wrap(out[0] if squeeze else out)
 
     __call__ = forward
 

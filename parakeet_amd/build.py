@@ -1,5 +1,14 @@
-"""Build libpk_synth.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libpk_synth.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library carries a hash of the sources it was built from (``pk_version()``: ``PK_SOURCE_HASH=<sha256>;``).
+``build()`` rebuilds whenever that hash differs from the sources on disk; modification times are not
+consulted (the .so is git-ignored but travels to the GPU box, where a stale binary may well be newer than
+an edited source).  Without hipcc (never the case in the build image) a mismatching library is an error,
+not something to run.
+"""
+import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -17,12 +26,29 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_hash():
+    """sha256 over every source the library is built from (names and contents, sorted)."""
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
+    for path in [os.path.join(CSRC, f) for f in files] + [os.path.join(INCLUDE, "pk_synth.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def library_hash(path=LIB):
+    """The PK_SOURCE_HASH string embedded in a built library (read from the file, nothing is loaded)."""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        m = re.search(rb"PK_SOURCE_HASH=([0-9a-f]{64});", f.read())
+    return m.group(1).decode() if m else None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "pk_synth.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_hash() != source_hash()
 
 
 def build(force=False, verbose=False, extra_flags=()):
@@ -30,6 +56,7 @@ def build(force=False, verbose=False, extra_flags=()):
         return LIB
     objs = []
     procs = []
+    extra_flags = list(extra_flags) + [f'-DPK_SOURCE_HASH="{source_hash()}"']
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
@@ -48,6 +75,8 @@ def build(force=False, verbose=False, extra_flags=()):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    if library_hash() != source_hash():
+        raise RuntimeError("libpk_synth.so does not carry the hash of the sources it was just built from")
     return LIB
 
 

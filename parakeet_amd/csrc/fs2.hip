@@ -999,7 +999,7 @@ static int ensure_pe(pk_fs2* h, int need) {
 extern "C" int pk_fs2_finalize(pk_fs2* h) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_fs2_finalize: handle is NULL");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_fs2_cfg& c = h->cfg;
     const pk_param_map& P = h->params;
     const int A = c.adim;
@@ -1251,7 +1251,7 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_fs2_encode: batch size must be positive");
     if (!(alpha > 0.f)) PK_FAIL(PK_ESHAPE, "LengthRegulator: alpha must be > 0 (length_regulator.py:86)");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_fs2_cfg& c = h->cfg;
     const int A = c.adim;
     int maxT = 0;
@@ -1262,6 +1262,20 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
         sumT += tok_lens[b];
     }
     h->encoded = false;
+    // Per-call conditioning (pk_fs2_set_speakers / pk_fs2_set_tones) is taken off the handle FIRST, so that no
+    // exit path -- error or success -- leaves it behind for an unrelated later encode, and its counts are
+    // validated before anything is launched.
+    const int condB = h->cond_B;
+    std::vector<long long> cond_spk, cond_tone;
+    std::vector<float> cond_emb;
+    cond_spk.swap(h->cond_spk);
+    cond_emb.swap(h->cond_emb);
+    cond_tone.swap(h->cond_tone);
+    h->cond_B = 0;
+    if (c.spk_embed_dim > 0 && condB > 0 && condB != B)
+        PK_FAIL(PK_ESHAPE, "pk_fs2_encode: speakers were set for %d utterances, batch has %d", condB, B);
+    if (c.tone_embed_dim > 0 && !cond_tone.empty() && (long)cond_tone.size() != sumT)
+        PK_FAIL(PK_ESHAPE, "pk_fs2_encode: %zu tone ids for %ld tokens", cond_tone.size(), sumT);
     PK_TRY(build_timeline(ctx, h->tl_tok, tok_lens, B, h->gapr));
     Timeline& tl = h->tl_tok;
     PK_TRY(ensure_pe(h, maxT));
@@ -1285,19 +1299,16 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
               tl.d_row_pos(), h->W(h->emb_table), h->d_pe.as<float>(), h->alpha_enc, h->xscale, A, x);
     PK_TRY(run_fft_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
     // speaker embedding (:396-402)
-    if (c.spk_embed_dim > 0 && h->cond_B > 0) {
+    if (c.spk_embed_dim > 0 && condB > 0) {
         const int D = c.spk_embed_dim;
-        const bool ext = !h->cond_emb.empty();
-        const int condB = h->cond_B;
-        h->cond_B = 0;   // consumed
-        if (condB != B) PK_FAIL(PK_ESHAPE, "pk_fs2_encode: speakers were set for %d utterances, batch has %d", condB, B);
+        const bool ext = !cond_emb.empty();
         const long long* d_id = nullptr;
         const float* d_emb = nullptr;
         if (ext) {
-            PK_TRY(pk_upload(ctx, h->d_spk_emb, h->cond_emb.data(), h->cond_emb.size() * sizeof(float)));
+            PK_TRY(pk_upload(ctx, h->d_spk_emb, cond_emb.data(), cond_emb.size() * sizeof(float)));
             d_emb = h->d_spk_emb.as<float>();
         } else {
-            PK_TRY(pk_upload(ctx, h->d_spk_id, h->cond_spk.data(), h->cond_spk.size() * sizeof(long long)));
+            PK_TRY(pk_upload(ctx, h->d_spk_id, cond_spk.data(), cond_spk.size() * sizeof(long long)));
             d_id = h->d_spk_id.as<long long>();
         }
         PK_TRY(h->d_spk_vec.reserve((size_t)B * A * sizeof(float)));
@@ -1313,10 +1324,8 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
                   tl.d_row_utt(), tl.rows, A, hs);
     }
     // tone embedding (:404-408)
-    if (c.tone_embed_dim > 0 && !h->cond_tone.empty()) {
-        std::vector<long long> ct;
-        ct.swap(h->cond_tone);   // consumed
-        if ((long)ct.size() != sumT) PK_FAIL(PK_ESHAPE, "pk_fs2_encode: %zu tone ids for %ld tokens", ct.size(), sumT);
+    if (c.tone_embed_dim > 0 && !cond_tone.empty()) {
+        const std::vector<long long>& ct = cond_tone;
         std::vector<int> tn(tl.rows_alloc, 0);
         long o = 0;
         for (int b = 0; b < B; ++b)
@@ -1348,7 +1357,7 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
     if (!h || !mel_out) PK_FAIL(PK_EINVAL, "pk_fs2_decode: NULL argument");
     if (!h->encoded) PK_FAIL(PK_ESTATE, "pk_fs2_decode: call pk_fs2_encode first");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_fs2_cfg& c = h->cfg;
     const int A = c.adim, B = h->tl_tok.B;
     // frame timeline; utterances with 0 frames get an empty segment
@@ -1396,8 +1405,9 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
         PK_TRY(h->d_mel_stage.reserve((size_t)sumL * c.odim * 4));
         d_out = h->d_mel_stage.as<float>();
     }
-    const float* cs = h->has_out_affine ? h->W(h->out_scale) : nullptr;
-    const float* ch = h->has_out_affine ? h->W(h->out_shift) : nullptr;
+    const bool denorm = h->has_out_affine && (flags & PK_APPLY_NORMALIZER);   // FastSpeech2Inference (:668-671)
+    const float* cs = denorm ? h->W(h->out_scale) : nullptr;
+    const float* ch = denorm ? h->W(h->out_shift) : nullptr;
     if (c.postnet_layers == 0) {
         pk_gemm_args g;
         g.A = zs; g.lda = A; g.Wp = h->W(h->feat_out.w); g.bias = h->W(h->feat_out.b);
@@ -1491,7 +1501,7 @@ extern "C" int pk_fs2_debug_read(pk_fs2* h, int32_t what, int32_t b, float* host
     if (!h || !host_out) PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: NULL argument");
     if (!h->encoded) PK_FAIL(PK_ESTATE, "pk_fs2_debug_read: nothing has run");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const int A = h->cfg.adim;
     const Timeline* tl = &h->tl_tok;
     const float* src = nullptr;
@@ -1518,7 +1528,7 @@ extern "C" int pk_fs2_debug_read(pk_fs2* h, int32_t what, int32_t b, float* host
 
 extern "C" void pk_fs2_destroy(pk_fs2* h) {
     if (!h) return;
-    (void)hipSetDevice(h->ctx->device);
+    pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
                        &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,

@@ -72,7 +72,7 @@ extern "C" int pk_mel_create(pk_ctx* ctx, const pk_mel_cfg* cfg, const float* wi
     if (c.n_fft <= 0 || c.n_fft % PK_GEMM_BK != 0) PK_FAIL(PK_EUNSUPPORTED, "STFT: n_fft must be a multiple of 16");
     if (c.hop_length <= 0 || c.hop_length % 4 != 0) PK_FAIL(PK_EUNSUPPORTED, "STFT: hop_length must be a multiple of 4");
     if (c.n_mels < 0 || (c.n_mels > 0 && !mel_basis)) PK_FAIL(PK_EINVAL, "pk_mel_create: mel basis missing");
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     pk_mel* h = new pk_mel();
     h->ctx = ctx;
     h->cfg = c;
@@ -119,7 +119,7 @@ extern "C" int pk_mel_run(pk_mel* h, const float* wav, const int32_t* lens, int3
     if (what < 0 || what > 2) PK_FAIL(PK_EINVAL, "pk_mel_run: what must be 0 (re|im), 1 (spectrum) or 2 (mel)");
     if (what == 2 && h->cfg.n_mels <= 0) PK_FAIL(PK_ESTATE, "pk_mel_run: no mel basis was given");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_mel_cfg& c = h->cfg;
     const int N = c.n_fft, hop = c.hop_length, nb = h->n_bin, pad = c.center ? N / 2 : 0;
     std::vector<int> woff(B), nfr(B), row0(B);
@@ -238,7 +238,7 @@ extern "C" int pk_mel_run(pk_mel* h, const float* wav, const int32_t* lens, int3
 
 extern "C" void pk_mel_destroy(pk_mel* h) {
     if (!h) return;
-    (void)hipSetDevice(h->ctx->device);
+    pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->d_dft, &h->d_melw, &h->ws_tab, &h->ws_ltab, &h->ws_wav, &h->ws_xpad, &h->ws_reim,
                        &h->ws_spec, &h->ws_out};

@@ -130,6 +130,13 @@ __global__ void k_nlc_to_timeline(const float* __restrict__ x, int T, int C, int
         tl[(long)r * C + c] = valid ? x[((long)b * T + t) * C + c] : 0.f;
 }
 
+// copy an [M][K] row-major matrix into [rows_alloc][Kp] with zero padding (columns K..Kp, rows M..rows_alloc)
+__global__ void k_pad_rows(const float* __restrict__ x, int M, int K, int Kp, float* __restrict__ y) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < Kp; c += blockDim.x)
+        y[(long)r * Kp + c] = (r < M && c < K) ? x[(long)r * K + c] : 0.f;
+}
+
 }  // namespace
 
 int pk_randn_device(pk_ctx* ctx, float* d_out, long n, unsigned long long seed, unsigned long long offset) {
@@ -143,7 +150,7 @@ int pk_randn_device(pk_ctx* ctx, float* d_out, long n, unsigned long long seed, 
 extern "C" int pk_randn(pk_ctx* ctx, float* out, int64_t n, uint64_t seed, uint64_t offset, int32_t flags) {
     if (!ctx || (!out && n > 0)) PK_FAIL(PK_EINVAL, "pk_randn: NULL argument");
     if (n < 0) PK_FAIL(PK_EINVAL, "pk_randn: n must be >= 0");
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     if (!(flags & PK_HOST_IO)) return pk_randn_device(ctx, out, n, seed, offset);
     float* d = nullptr;
     if (n == 0) return PK_OK;
@@ -162,7 +169,7 @@ extern "C" int pk_op_expand(pk_ctx* ctx, const float* encodings, const int64_t* 
                             int32_t C, int32_t t_dec, float* out) {
     if (!ctx || !encodings || !durations || (!out && t_dec > 0)) PK_FAIL(PK_EINVAL, "pk_op_expand: NULL argument");
     if (B <= 0 || T <= 0 || C <= 0 || t_dec < 0) PK_FAIL(PK_EINVAL, "expand: bad shape");
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     std::vector<int> src((size_t)B * t_dec, -1);
     for (int b = 0; b < B; ++b) {
         long k = 0;
@@ -192,7 +199,7 @@ extern "C" int pk_op_sinusoid_position_encoding(pk_ctx* ctx, int32_t num_positio
                                                 float omega, int32_t start_pos, float* out) {
     if (!ctx || !out) PK_FAIL(PK_EINVAL, "pk_op_sinusoid_position_encoding: NULL argument");
     if (num_positions <= 0 || feature_size <= 0) PK_FAIL(PK_EINVAL, "sinusoid_position_encoding: empty table");
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     PK_LAUNCH(ctx, "op_sinusoid", k_sinusoid, dim3(num_positions), dim3(128), 0, out, num_positions, feature_size,
               omega, start_pos);
     return PK_OK;
@@ -203,7 +210,7 @@ extern "C" int pk_op_scaled_dot_product_attention(pk_ctx* ctx, const float* q, c
                                                   int32_t Tk, int32_t d, int32_t dv, float* out, float* weights) {
     if (!ctx || !q || !k || !v || !out) PK_FAIL(PK_EINVAL, "pk_op_scaled_dot_product_attention: NULL argument");
     if (B <= 0 || Tq <= 0 || Tk <= 0 || d <= 0 || dv <= 0) PK_FAIL(PK_EINVAL, "attention: empty problem");
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     long sb = 0, sq = 0;
     switch (mask ? mask_mode : -1) {
         case -1: break;
@@ -231,7 +238,7 @@ extern "C" int pk_op_conv1d_batchnorm_nlc(pk_ctx* ctx, const float* x, int32_t B
     if (Cin % PK_GEMM_BK != 0) PK_FAIL(PK_EUNSUPPORTED, "conv1d: in_channels must be a multiple of %d", PK_GEMM_BK);
     const int Tout = T + 2 * pad - k + 1;
     if (Tout <= 0) PK_FAIL(PK_ESHAPE, "conv1d: kernel larger than padded input");
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     // fold BN: w' = w * g / sqrt(var + eps), b' = (b - mean) * g / sqrt(var + eps) + beta
     std::vector<float> w((size_t)Cout * Cin * k), b(Cout, 0.f), kn, packed;
     for (int o = 0; o < Cout; ++o) {
@@ -284,6 +291,48 @@ extern "C" int pk_op_conv1d_batchnorm_nlc(pk_ctx* ctx, const float* x, int32_t B
     st = pk_gemm_launch(ctx, "op_conv1d_bn", g);
     if (st == PK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
         pk_set_error("conv1d: stream sync failed");
+        st = PK_EHIP;
+    }
+    cleanup();
+    return st;
+}
+
+// y[M][N] = x[M][K] . w[K][N] (+ bias[N]) on the exact-fp32 MFMA GEMM; K is zero-padded to the kernel's slab.
+extern "C" int pk_op_matmul(pk_ctx* ctx, const float* x, int32_t M, int32_t K, int32_t N, const float* w,
+                            const float* bias, float* y) {
+    if (!ctx || !x || !w || !y) PK_FAIL(PK_EINVAL, "pk_op_matmul: NULL argument");
+    if (M <= 0 || K <= 0 || N <= 0) PK_FAIL(PK_EINVAL, "pk_op_matmul: bad shape");
+    PK_DEVICE(ctx->device);
+    const int Kp = ((K + PK_GEMM_BK - 1) / PK_GEMM_BK) * PK_GEMM_BK;
+    const int rows_alloc = ((M + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM;
+    std::vector<float> kn((size_t)Kp * N, 0.f), packed;
+    memcpy(kn.data(), w, (size_t)K * N * sizeof(float));
+    pk_gemm_pack(kn.data(), Kp, N, packed);
+    pk_dbuf d_w, d_b, d_x;
+    int st = PK_OK;
+    auto cleanup = [&]() { d_w.release(); d_b.release(); d_x.release(); };
+    if ((st = pk_upload(ctx, d_w, packed.data(), packed.size() * 4)) != PK_OK ||
+        (bias && (st = pk_upload(ctx, d_b, bias, (size_t)N * 4)) != PK_OK) ||
+        (st = d_x.reserve((size_t)rows_alloc * Kp * 4)) != PK_OK) {
+        cleanup();
+        return st;
+    }
+    hipLaunchKernelGGL(k_pad_rows, dim3(rows_alloc), dim3(128), 0, ctx->stream, x, M, K, Kp, d_x.as<float>());
+    pk_gemm_args g;
+    g.A = d_x.as<float>();
+    g.lda = Kp;
+    g.Wp = d_w.as<float>();
+    g.bias = bias ? d_b.as<float>() : nullptr;
+    g.C = y;
+    g.ldc = N;
+    g.M = M;
+    g.N = N;
+    g.Cin = Kp;
+    g.taps = 1;
+    g.pad = 0;
+    st = pk_gemm_launch(ctx, "op_matmul", g);
+    if (st == PK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        pk_set_error("pk_op_matmul: stream sync failed");
         st = PK_EHIP;
     }
     cleanup();

@@ -36,6 +36,27 @@ void pk_set_error(const char* fmt, ...);
         if (_s != PK_OK) return _s;   \
     } while (0)
 
+// Engine calls run on the context's device and leave the caller's current HIP device as they found it
+// (torch tracks its own current device; a stray hipSetDevice inside a ctypes call would silently redirect
+// the caller's next allocations in single-process multi-GPU use).
+struct pk_device_guard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit pk_device_guard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+        else prev = -1;   // nothing to restore
+    }
+    ~pk_device_guard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    pk_device_guard(const pk_device_guard&) = delete;
+    pk_device_guard& operator=(const pk_device_guard&) = delete;
+};
+#define PK_DEVICE(dev)                                                                          \
+    pk_device_guard _dg(dev);                                                                   \
+    if (_dg.err != hipSuccess) PK_FAIL(PK_EHIP, "hipSetDevice(%d) failed: %s", (int)(dev), hipGetErrorString(_dg.err))
+
 struct pk_prof_rec {
     int name_id;
     hipEvent_t start, stop;

@@ -13,7 +13,14 @@ void pk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pk_last_error(void) { return g_err; }
-extern "C" const char* pk_version(void) { return "parakeet_amd 0.1 (gfx950)"; }
+// PK_SOURCE_HASH = sha256 over csrc/* and include/pk_synth.h at build time (parakeet_amd/build.py passes it with
+// -D).  build() compares the hash inside an existing libpk_synth.so with the sources on disk and rebuilds on
+// any mismatch -- file times do not decide (the .so is git-ignored but shipped, so a stale binary can be
+// newer than an edited source).
+#ifndef PK_SOURCE_HASH
+#define PK_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* pk_version(void) { return "parakeet_amd 0.2 (gfx950) PK_SOURCE_HASH=" PK_SOURCE_HASH ";"; }
 
 extern "C" int pk_ctx_create(int device_id, pk_ctx** out) {
     if (!out) PK_FAIL(PK_EINVAL, "pk_ctx_create: out is NULL");
@@ -25,7 +32,7 @@ extern "C" int pk_ctx_create(int device_id, pk_ctx** out) {
                 e == hipSuccess ? "count 0" : hipGetErrorString(e));
     if (device_id < 0 || device_id >= n)
         PK_FAIL(PK_EINVAL, "pk_ctx_create: device %d out of range [0,%d)", device_id, n);
-    PK_HIP(hipSetDevice(device_id));
+    PK_DEVICE(device_id);
     pk_ctx* c = new pk_ctx();
     c->device = device_id;
     hipDeviceProp_t prop;
@@ -53,14 +60,14 @@ extern "C" int pk_ctx_set_stream(pk_ctx* ctx, void* hip_stream) {
 
 extern "C" int pk_sync(pk_ctx* ctx) {
     if (!ctx) PK_FAIL(PK_EINVAL, "pk_sync: ctx is NULL");
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     PK_HIP(hipStreamSynchronize(ctx->stream));
     return PK_OK;
 }
 
 extern "C" void pk_ctx_destroy(pk_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    pk_device_guard _dg(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& r : ctx->prof_recs) {
         (void)hipEventDestroy(r.start);

@@ -932,7 +932,7 @@ extern "C" int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* si
     h->h_mu.assign(mu, mu + n);
     h->h_sigma.assign(sigma, sigma + n);
     h->use_norm = true;
-    PK_HIP(hipSetDevice(h->ctx->device));
+    PK_DEVICE(h->ctx->device);
     PK_TRY(pk_upload(h->ctx, h->d_mu, h->h_mu.data(), n * sizeof(float)));
     PK_TRY(pk_upload(h->ctx, h->d_sigma, h->h_sigma.data(), n * sizeof(float)));
     return PK_OK;
@@ -1043,7 +1043,7 @@ static std::vector<double> upsample_sim(std::vector<double> x, const pk_pwg_cfg&
 extern "C" int pk_pwg_finalize(pk_pwg* h) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_finalize: handle is NULL");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_pwg_cfg& c = h->cfg;
     std::vector<float> w, b;
     // first_conv
@@ -1225,7 +1225,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_pwg_infer: call pk_pwg_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_pwg_infer: batch size must be positive");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_pwg_cfg& c = h->cfg;
     const int hop = h->hop, gap = h->gap;
     // ---- layout
@@ -1345,7 +1345,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         PK_TRY(h->ws_cin.reserve((size_t)(rows_p_alloc + 2 * P_LEAD) * AUX * 4));
         float* cin = h->ws_cin.as<float>() + (size_t)P_LEAD * AUX;
         PK_LAUNCH(ctx, "pwg_convin_prep", k_pwg_convin_prep, dim3(rows_p_alloc), dim3(128), 0, d_mel,
-                  h->d_mu.as<float>(), h->d_sigma.as<float>(), h->use_norm ? 1 : 0, d_tab + o_psrc, rows_p, cin);
+                  h->d_mu.as<float>(), h->d_sigma.as<float>(), (h->use_norm && (flags & PK_APPLY_NORMALIZER)) ? 1 : 0, d_tab + o_psrc, rows_p, cin);
         {
             pk_gemm_args g;
             g.A = cin;
@@ -1470,7 +1470,7 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
     if (h->last_Ttot == 0) PK_FAIL(PK_ESTATE, "pk_pwg_debug_read: no inference has run");
     if (b < 0 || b >= (int)h->last_frames.size()) PK_FAIL(PK_EINVAL, "pk_pwg_debug_read: utterance out of range");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const long S = (long)h->last_frames[b] * h->hop;
     if (what == 0) {
         // sample-rate aux contribution of layer 0: conv1x1_aux(upsample_net(c)) (G, S_b), recomputed
@@ -1505,7 +1505,7 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
 
 extern "C" void pk_pwg_destroy(pk_pwg* h) {
     if (!h) return;
-    (void)hipSetDevice(h->ctx->device);
+    pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_uptab, &h->d_mu, &h->d_sigma,
                        &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1h, &h->d_l1b, &h->d_l2,

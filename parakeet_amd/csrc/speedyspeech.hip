@@ -403,7 +403,7 @@ extern "C" int pk_ss_set_math(pk_ss* h, int32_t mode) {
 extern "C" int pk_ss_finalize(pk_ss* h) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_ss_finalize: handle is NULL");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_ss_cfg& c = h->cfg;
     const pk_param_map& P = h->params;
     const int H = h->H;
@@ -470,7 +470,7 @@ extern "C" int pk_ss_encode(pk_ss* h, const int64_t* text, const int64_t* tones,
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_ss_encode: call pk_ss_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_ss_encode: batch size must be positive");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_ss_cfg& c = h->cfg;
     const int H = h->H;
     if (tones && c.tone_size <= 0) PK_FAIL(PK_ESTATE, "pk_ss_encode: the model has no tone embedding");
@@ -550,7 +550,7 @@ extern "C" int pk_ss_decode(pk_ss* h, float* mel_out, int32_t flags) {
     if (!h || !mel_out) PK_FAIL(PK_EINVAL, "pk_ss_decode: NULL argument");
     if (!h->encoded) PK_FAIL(PK_ESTATE, "pk_ss_decode: call pk_ss_encode first");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_ss_cfg& c = h->cfg;
     const int H = h->H, B = h->tl_tok.B, O = c.decoder_output_size;
     long total = 0;
@@ -596,8 +596,8 @@ extern "C" int pk_ss_decode(pk_ss* h, float* mel_out, int32_t flags) {
         d_out = h->d_stage.as<float>();
     }
     PK_TRY(launch_dense(h, "ss_gemm_out", h->dec_out, z, d_out, O, rows, PK_ACT_NONE, nullptr, 0, rv,
-                        h->has_out_affine ? h->W(h->dec_out.cs) : nullptr,
-                        h->has_out_affine ? h->W(h->dec_out.ch) : nullptr, h->d_rowmap.as<int>()));
+                        (h->has_out_affine && (flags & PK_APPLY_NORMALIZER)) ? h->W(h->dec_out.cs) : nullptr,
+                        (h->has_out_affine && (flags & PK_APPLY_NORMALIZER)) ? h->W(h->dec_out.ch) : nullptr, h->d_rowmap.as<int>()));
     if (flags & PK_HOST_IO) {
         PK_HIP(hipMemcpyAsync(mel_out, d_out, (size_t)total * O * 4, hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipStreamSynchronize(ctx->stream));
@@ -611,7 +611,7 @@ extern "C" int pk_ss_debug_read(pk_ss* h, int32_t what, int32_t b, float* host_o
     if (!h->encoded) PK_FAIL(PK_ESTATE, "pk_ss_debug_read: no encode has run");
     if (b < 0 || b >= h->tl_tok.B) PK_FAIL(PK_EINVAL, "pk_ss_debug_read: utterance out of range");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const int T = h->tl_tok.seg_len[b], s0 = h->tl_tok.seg_start[b], H = h->H;
     const float* src;
     long n;
@@ -629,7 +629,7 @@ extern "C" int pk_ss_debug_read(pk_ss* h, int32_t what, int32_t b, float* host_o
 
 extern "C" void pk_ss_destroy(pk_ss* h) {
     if (!h) return;
-    (void)hipSetDevice(h->ctx->device);
+    pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_text, &h->d_tone, &h->d_e, &h->d_a, &h->d_b, &h->d_c, &h->d_enc,
                        &h->d_pred, &h->d_dur, &h->d_cum, &h->d_frames, &h->d_rowmap, &h->d_stage, &h->tl_tok.d_tab,

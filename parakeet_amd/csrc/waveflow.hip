@@ -232,7 +232,7 @@ extern "C" int pk_wf_set_math(pk_wf* h, int32_t mode) {
 extern "C" int pk_wf_finalize(pk_wf* h) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_wf_finalize: handle is NULL");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_wf_cfg& c = h->cfg;
     const pk_param_map& P = h->params;
     const int C = c.channels, M = c.n_mels;
@@ -334,7 +334,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_wf_infer: call pk_wf_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_wf_infer: batch size must be positive");
     pk_ctx* ctx = h->ctx;
-    PK_HIP(hipSetDevice(ctx->device));
+    PK_DEVICE(ctx->device);
     const pk_wf_cfg& c = h->cfg;
     const int C = c.channels, M = c.n_mels, G = c.n_group, NL = c.n_layers, MP = h->mp;
     // ---- per-utterance sizes
@@ -582,7 +582,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
 
 extern "C" void pk_wf_destroy(pk_wf* h) {
     if (!h) return;
-    (void)hipSetDevice(h->ctx->device);
+    pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
                        &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip};

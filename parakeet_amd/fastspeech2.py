@@ -110,6 +110,10 @@ class FastSpeech2:
         return self
 
     def set_normalizer(self, normalizer):
+        """Register ZScore statistics on the engine handle.  Registering changes nothing by itself: they are
+        applied only by calls that ask for it (``denormalize=True``, what ``FastSpeech2Inference`` passes), so
+        ``inference()`` itself stays in the normalised domain like the reference's (fastspeech2.py:468-558)."""
+        self._norm_owner = None
         if normalizer is None:
             _capi.check(self._ctx.lib.pk_fs2_set_normalizer(self._h, None, None, 0))
         else:
@@ -162,18 +166,19 @@ class FastSpeech2:
         self._last_tok, self._last_frames = [int(v) for v in lens], [int(v) for v in frames]
         return frames
 
-    def decode_packed(self):
-        """Phase 2: packed (sum(frames), odim) device tensor of the last encode."""
+    def decode_packed(self, denormalize=False):
+        """Phase 2: packed (sum(frames), odim) device tensor of the last encode.  ``denormalize``: apply the
+        registered ZScore.inverse in the output epilogue (FastSpeech2Inference.forward :668-671)."""
         ctx = Context.get(self._ctx.device)
         total = int(sum(self._last_frames))
         mel = ctx.empty((total, self.odim))
         if total:
-            _capi.check(ctx.lib.pk_fs2_decode(self._h, dptr(mel), 0))
+            _capi.check(ctx.lib.pk_fs2_decode(self._h, dptr(mel), _capi.PK_APPLY_NORMALIZER if denormalize else 0))
         return mel
 
-    def inference_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None, tone_ids=None):
+    def inference_batch(self, texts, alpha=1.0, spk_ids=None, spembs=None, tone_ids=None, denormalize=False):
         frames = self.encode_batch(texts, alpha, spk_ids, spembs, tone_ids)
-        mel = self.decode_packed()
+        mel = self.decode_packed(denormalize)
         outs, o = [], 0
         for f in frames:
             outs.append(wrap(mel[o:o + int(f)]))
@@ -181,17 +186,18 @@ class FastSpeech2:
         return outs
 
     def inference(self, text, speech=None, durations=None, pitch=None, energy=None, alpha=1.0,
-                  use_teacher_forcing=False, spembs=None, spk_id=None, tone_id=None):
+                  use_teacher_forcing=False, spembs=None, spk_id=None, tone_id=None, denormalize=False):
         """(T,) int64 -> (L, odim); fastspeech2.py:468-558 (is_inference=True branch)."""
         if use_teacher_forcing:
             raise NotImplementedError("teacher forcing is a training-time path")
         tones = None if tone_id is None else [tone_id]   # (T,) ids, forwarded un-batched by the reference (:546,556)
         if spembs is not None:      # (spk_embed_dim,), unsqueezed by the reference (:541-542)
-            return self.inference_batch([text], alpha, spembs=to_numpy_f32(spembs).reshape(1, -1), tone_ids=tones)[0]
+            return self.inference_batch([text], alpha, spembs=to_numpy_f32(spembs).reshape(1, -1), tone_ids=tones,
+                                        denormalize=denormalize)[0]
         if spk_id is not None:
             sid = np.asarray(spk_id.cpu() if isinstance(spk_id, torch.Tensor) else spk_id).reshape(-1)[:1]
-            return self.inference_batch([text], alpha, spk_ids=sid, tone_ids=tones)[0]
-        return self.inference_batch([text], alpha, tone_ids=tones)[0]
+            return self.inference_batch([text], alpha, spk_ids=sid, tone_ids=tones, denormalize=denormalize)[0]
+        return self.inference_batch([text], alpha, tone_ids=tones, denormalize=denormalize)[0]
 
     def debug_tap(self, what, b):
         n_rows = self._last_tok[b] if what <= 3 else self._last_frames[b]
@@ -209,10 +215,20 @@ class FastSpeech2Inference:
     def __init__(self, normalizer, model):
         self.normalizer = normalizer
         self.acoustic_model = model
-        model.set_normalizer(normalizer)
+        self.bind()
+
+    def bind(self):
+        """Make this wrapper's statistics the ones registered on the model's engine handle (a no-op unless
+        another wrapper around the same model registered different ones since).  The model's own
+        ``inference()`` is unaffected either way."""
+        m = self.acoustic_model
+        if getattr(m, "_norm_owner", None) is not self:
+            m.set_normalizer(self.normalizer)
+            m._norm_owner = self
+        return m
 
     def forward(self, text, spk_id=None, alpha=1.0):
-        return self.acoustic_model.inference(text, spk_id=spk_id, alpha=alpha)
+        return self.bind().inference(text, spk_id=spk_id, alpha=alpha, denormalize=True)
 
     __call__ = forward
 

@@ -96,6 +96,9 @@ class PWGGenerator:
         _capi.check(self._ctx.lib.pk_pwg_set_seed(self._h, int(seed) & (2 ** 64 - 1)))
 
     def set_normalizer(self, normalizer):
+        """Register ZScore statistics; applied only by calls passing ``normalize=True`` (what PWGInference
+        does) -- ``inference()`` / ``forward()`` themselves take already-normalised features like the reference's."""
+        self._norm_owner = None
         if normalizer is None:
             _capi.check(self._ctx.lib.pk_pwg_set_normalizer(self._h, None, None, 0))
         else:
@@ -108,7 +111,7 @@ class PWGGenerator:
             self._finalized = True
 
     # -- synthesis -------------------------------------------------------------
-    def inference_batch(self, mels, noises=None, generator=None):
+    def inference_batch(self, mels, noises=None, generator=None, normalize=False):
         """mels: list of (T'_b, aux) arrays.  Returns a list of (T'_b*hop, out) device tensors."""
         ctx = Context.get(self._ctx.device)
         self._finalize()
@@ -126,7 +129,8 @@ class PWGGenerator:
         assert noise is None or noise.numel() == total, "noise length must be frames * hop"
         wav = ctx.empty((total,))
         _capi.check(ctx.lib.pk_pwg_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)),
-                                         len(mels), None if noise is None else dptr(noise), dptr(wav), 0))
+                                         len(mels), None if noise is None else dptr(noise), dptr(wav),
+                                         _capi.PK_APPLY_NORMALIZER if normalize else 0))
         outs, o = [], 0
         for f in frames:
             n = int(f) * hop
@@ -134,7 +138,7 @@ class PWGGenerator:
             o += n
         return outs
 
-    def infer_packed(self, mel, frames, noise=None, generator=None):
+    def infer_packed(self, mel, frames, noise=None, generator=None, normalize=False):
         """mel: packed (sum(frames), aux) DEVICE tensor (e.g. FastSpeech2.decode_packed());
         returns the packed (sum(frames)*hop,) device waveform -- no host round trip."""
         ctx = Context.get(self._ctx.device)
@@ -152,7 +156,8 @@ class PWGGenerator:
         assert noise is None or noise.numel() == total, "noise length must be sum(frames) * hop"
         wav = ctx.empty((total,))
         _capi.check(ctx.lib.pk_pwg_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)),
-                                         len(frames), None if noise is None else dptr(noise), dptr(wav), 0))
+                                         len(frames), None if noise is None else dptr(noise), dptr(wav),
+                                         _capi.PK_APPLY_NORMALIZER if normalize else 0))
         return wav
 
     def forward(self, x, c):
@@ -176,9 +181,9 @@ class PWGGenerator:
 
     __call__ = forward
 
-    def inference(self, c=None, noise=None):
+    def inference(self, c=None, noise=None, normalize=False):
         """(T', C_aux) -> (T, C_out); parallel_wavegan.py:498-520."""
-        return self.inference_batch([c], None if noise is None else [noise])[0]
+        return self.inference_batch([c], None if noise is None else [noise], normalize=normalize)[0]
 
     def debug_tap(self, what, b):
         rows = {0: 128, 1: 64, 2: 64}[what]
@@ -195,10 +200,17 @@ class PWGInference:
     def __init__(self, normalizer, pwg_generator):
         self.normalizer = normalizer
         self.pwg_generator = pwg_generator
-        pwg_generator.set_normalizer(normalizer)
+        self.bind()
+
+    def bind(self):
+        g = self.pwg_generator
+        if getattr(g, "_norm_owner", None) is not self:
+            g.set_normalizer(self.normalizer)
+            g._norm_owner = self
+        return g
 
     def forward(self, logmel, noise=None):
-        return self.pwg_generator.inference(logmel, noise=noise)
+        return self.bind().inference(logmel, noise=noise, normalize=True)
 
     __call__ = forward
 

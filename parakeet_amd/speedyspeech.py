@@ -63,6 +63,8 @@ class SpeedySpeech:
         return self
 
     def set_normalizer(self, normalizer):
+        """Register ZScore statistics; applied only by calls passing ``denormalize=True`` (see FastSpeech2)."""
+        self._norm_owner = None
         if normalizer is None:
             _capi.check(self._ctx.lib.pk_ss_set_normalizer(self._h, None, None, 0))
         else:
@@ -99,27 +101,27 @@ class SpeedySpeech:
         self._last_tok, self._last_frames = [int(v) for v in lens], [int(v) for v in frames]
         return frames
 
-    def decode_packed(self):
+    def decode_packed(self, denormalize=False):
         ctx = Context.get(self._ctx.device)
         total = int(sum(self._last_frames))
         mel = ctx.empty((total, self.odim))
         if total:
-            _capi.check(ctx.lib.pk_ss_decode(self._h, dptr(mel), 0))
+            _capi.check(ctx.lib.pk_ss_decode(self._h, dptr(mel), _capi.PK_APPLY_NORMALIZER if denormalize else 0))
         return mel
 
-    def inference_batch(self, texts, tones=None):
+    def inference_batch(self, texts, tones=None, denormalize=False):
         """Lists of (T_b,) phone / tone ids -> list of (L_b, output_size) device tensors."""
         frames = self.encode_batch(texts, tones)
-        mel = self.decode_packed()
+        mel = self.decode_packed(denormalize)
         outs, o = [], 0
         for f in frames:
             outs.append(wrap(mel[o:o + int(f)]))
             o += int(f)
         return outs
 
-    def inference(self, text, tones=None):
+    def inference(self, text, tones=None, denormalize=False):
         """(T,) int -> (L, output_size); speedyspeech.py:178-218."""
-        return self.inference_batch([text], None if tones is None else [tones])[0]
+        return self.inference_batch([text], None if tones is None else [tones], denormalize)[0]
 
     def debug_tap(self, what, b):
         T = self._last_tok[b]
@@ -134,10 +136,17 @@ class SpeedySpeechInference:
     def __init__(self, normalizer, speedyspeech_model):
         self.normalizer = normalizer
         self.acoustic_model = speedyspeech_model
-        speedyspeech_model.set_normalizer(normalizer)
+        self.bind()
+
+    def bind(self):
+        m = self.acoustic_model
+        if getattr(m, "_norm_owner", None) is not self:
+            m.set_normalizer(self.normalizer)
+            m._norm_owner = self
+        return m
 
     def forward(self, phones, tones=None):
-        return self.acoustic_model.inference(phones, tones)
+        return self.bind().inference(phones, tones, denormalize=True)
 
     __call__ = forward
 

@@ -15,18 +15,21 @@ from .runtime import wrap
 
 class Synthesizer:
     def __init__(self, fastspeech2_inference, pwg_inference):
+        self.am_inference, self.voc_inference = fastspeech2_inference, pwg_inference
         self.am = fastspeech2_inference.acoustic_model
         self.voc = pwg_inference.pwg_generator
         self.hop = self.voc.upsample_factor
 
     def synthesize_packed(self, texts, alpha=1.0, noise=None, generator=None):
         """Returns (packed wav device tensor, frames per utterance)."""
+        self.am_inference.bind()
+        self.voc_inference.bind()
         frames = self.am.encode_batch(texts, alpha)
         if int(frames.sum()) == 0:
             return torch.empty(0, device=self.am._ctx.device), frames
-        mel = self.am.decode_packed()
+        mel = self.am.decode_packed(denormalize=True)       # FastSpeech2Inference: log-mel domain
         keep = frames > 0  # the vocoder needs >= 1 frame per utterance
-        wav = self.voc.infer_packed(mel, frames[keep], noise=noise, generator=generator)
+        wav = self.voc.infer_packed(mel, frames[keep], noise=noise, generator=generator, normalize=True)
         return wav, frames
 
     def synthesize_batch(self, texts, alpha=1.0, noises=None, generator=None):

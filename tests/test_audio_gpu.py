@@ -96,3 +96,19 @@ def test_audio_processor_and_log_magnitude(tmp_path):
     p.write_wav(tmp_path / "x.wav", wav)
     back = AudioProcessor(22050, 1024, 1024, 256, normalize=False).read_wav(tmp_path / "x.wav")
     assert np.abs(back - np.clip(wav, -1, 1)).max() < 2.0 / 32768      # written x 32767, read / 32768, + rounding
+
+
+def test_melscale_runs_on_the_engine_and_matches_fp64():
+    """MelScale.forward (modules/audio.py:226-229) = matmul(basis, spectrogram): through pk_op_matmul, not torch."""
+    from parakeet_amd.audio import STFT, MelScale
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-1, 1, size=(2, 9000)).astype(np.float32)
+    st = STFT(1024, 256)
+    mag = st.magnitude(x)                                     # (2, 513, frames)
+    ms = MelScale(22050, 1024, 80, 80, 7600)
+    got = ms(mag).numpy()
+    want = np.einsum("mf,bft->bmt", ms.weight.numpy().astype(np.float64), mag.numpy().astype(np.float64))
+    assert got.shape == want.shape == (2, 80, mag.shape[-1])
+    assert np.abs(got - want).max() < 2e-6 * np.abs(want).max()
+    one = ms(mag[0]).numpy()                                  # un-batched (n_freq, frames) input
+    np.testing.assert_array_equal(one, got[0])

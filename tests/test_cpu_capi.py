@@ -60,3 +60,28 @@ def test_smoke_config_subset_is_valid():
     import inspect
     src = inspect.getsource(g.smoke)
     assert "if k in fcfg" in src
+
+
+def test_build_rebuilds_on_source_hash_mismatch_not_on_mtime(tmp_path, monkeypatch):
+    """a stale-but-newer .so must not be used.  The library embeds the sha256 of its
+    sources; needs_build() compares hashes, file times are irrelevant."""
+    import shutil
+    from parakeet_amd import build as b
+    assert b.library_hash() == b.source_hash(), "in-tree library is stale: run python -m parakeet_amd.build"
+    assert not b.needs_build()
+    # a copy of the tree's sources with one edited file -> different hash -> rebuild required, although the
+    # library file is newer than every source
+    csrc = tmp_path / "csrc"
+    shutil.copytree(b.CSRC, csrc, ignore=shutil.ignore_patterns("*.o"))
+    with open(csrc / "ops.hip", "a") as f:
+        f.write("\n// edited\n")
+    os.utime(csrc / "ops.hip", (0, 0))
+    monkeypatch.setattr(b, "CSRC", str(csrc))
+    assert b.source_hash() != b.library_hash()
+    assert b.needs_build()
+    # and the loader refuses a library whose hash differs from the tree
+    from parakeet_amd import _capi
+    monkeypatch.setattr(_capi, "_lib", None)
+    import pytest
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _capi.lib()

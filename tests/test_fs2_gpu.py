@@ -112,6 +112,15 @@ def test_fs2_inference_wrapper_denormalizes():
     want = ref.fastspeech2_inference(state, mu, sigma, ids, _oracle_cfg(cfg), dtype=torch.float64).numpy()
     assert got.shape == want.shape
     assert np.abs(got - want).mean() < MEL_L1_TOL
+    # wrapping does not change the model's own inference(): it stays in the normalised domain like the
+    # reference's (fastspeech2.py:468-558); two wrappers with different statistics around one model coexist
+    plain = model.inference(ids).numpy()
+    want_plain = ref.inference(state, ids, _oracle_cfg(cfg), dtype=torch.float64).numpy()
+    assert np.abs(plain - want_plain).mean() < MEL_L1_TOL
+    inf2 = FastSpeech2Inference(ZScore(mu + 1.0, sigma * 2.0), model)
+    want2 = ref.fastspeech2_inference(state, mu + 1.0, sigma * 2.0, ids, _oracle_cfg(cfg), dtype=torch.float64).numpy()
+    assert np.abs(inf2(ids).numpy() - want2).mean() < MEL_L1_TOL
+    assert np.abs(inf(ids).numpy() - want).mean() < MEL_L1_TOL
 
 
 def test_fs2_error_mapping():

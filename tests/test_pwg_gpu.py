@@ -146,6 +146,11 @@ def test_pwg_inference_wrapper_normalizes():
     ref = pwg_ref.pwg_inference(state, mu, sigma, torch.from_numpy(logmel), torch.from_numpy(noise), ocfg,
                                 torch.float64).numpy()
     assert _rel_err(got, ref) < 1e-4
+    # the wrapper does not turn the generator's own inference() into a normalising one (:498-520 takes
+    # already-normalised features)
+    norm = ((logmel - mu) / sigma).astype(np.float32)
+    plain = gen.inference(norm, noise=noise).numpy()
+    assert _rel_err(plain, ref) < 1e-4
 
 
 def test_pwg_error_mapping():
