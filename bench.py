@@ -88,14 +88,23 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5):
+def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5, budget_s=30.0):
     """Time the torch-CPU oracle ("port") on a bounded sample of the same workload: utterance 0 of the
     benchmark batch (same ids, same noise), BASELINE.md section 2's protocol -- `warmup` untimed runs
     (on a quarter-length utterance: they only warm the thread pool / allocator / oneDNN primitives),
-    `timed` full runs, median.  Returns (record, logmel, wav) of the last run for the parity check."""
+    up to `timed` full runs, median -- bounded to about `budget_s` seconds of CPU work: no further run is
+    started once the budget is spent (a slow host gives fewer runs, never a bench that takes many minutes).
+    Returns (record, logmel, wav) of the last run for the parity check."""
     from oracle import fastspeech2_ref, pwg_ref
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()          # the threads torch actually uses, not a cap
+    # threads: the cores this process may run on, at most 32 -- the GPU boxes expose a few hundred logical CPUs to a
+    # container that owns a fraction of them, and an intra-op pool of that size does not finish (round 2: > 5 min
+    # for what 32 threads do in 7 s).  `cores` reports the threads torch actually used.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 32)))
+    cores = torch.get_num_threads()
     mu_f, sg_f, mu_p, sg_p = stats
     noise = torch.as_tensor(noise).float().cpu()
 
@@ -113,10 +122,14 @@ def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5):
         t0 = time.perf_counter()
         logmel, wav = run(ids, noise)
         times.append(time.perf_counter() - t0)
+        if sum(times) + times[-1] > budget_s:
+            break
+    timed = len(times)
     dt = float(np.median(times))
     n = int(wav.shape[0])
     rec = {
-        "value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+        "value": n / dt, "unit": "samples/s", "cores": cores, "cores_available": avail, "kind": "port",
+        "cpu_model": _cpu_model(),
         "sample": f"utterance 0 of the benchmark batch ({len(ids)} tokens -> {n // HOP} frames -> {n} samples), "
                   f"FastSpeech2+PWG torch-CPU fp32 oracle (Paddle-equivalent restatement); {warmup} warm-up + "
                   f"{timed} timed runs, median {dt:.2f} s (min {min(times):.2f}, max {max(times):.2f})",
@@ -155,6 +168,15 @@ class _DryStep:
     def __call__(self, texts, noise):
         frames = np.full(len(texts), self.n_tokens * FRAMES_PER_TOKEN, dtype=np.int32)
         return torch.zeros(int(frames.sum()) * HOP), frames
+
+
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    """Progress on stderr (stdout carries the one JSON line): shows where a slow run spends its time."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -268,7 +290,9 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    _log("models built; first-touch pass")
     wav, frames = step()  # build / first-touch pass (allocations, weight packing); never timed
+    _log("warm-up")
     for _ in range(args.warmup):
         wav, frames = step()
     sync()
@@ -278,12 +302,14 @@ def main():
 
     barrier()
     sync()
+    _log("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wav, frames = step()
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    _log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     gather_ms = None
     if distributed:
         import torch.distributed as dist
@@ -341,6 +367,7 @@ def main():
 
     # ---- extra measurements (do not feed `value`): the split-bf16 PWG matrix path, WaveFlow
     extras = {}
+    _log("per-kernel profile done; extras")
     if world == 1 and not args.no_extras and args.scaling == "weak":
         texts = texts_all[:UTT_PER_GPU]
         for mode, key in (("f32", "all_exact_f32_mfma"), ("bf16x3", "pwg_bf16x3_split")):
@@ -517,6 +544,7 @@ def main():
             out["gather_note"] = ("parakeet_amd.dist.gather_ragged of every rank's packed waveform (last mini-batch) "
                                   "onto every rank: one all_gather of lengths + one padded RCCL all_gather; not in `value`")
         if world == 1 and not args.no_cpu_baseline:
+            _log("cpu_baseline (torch-CPU oracle, bounded)")
             rec, ref_mel, ref_wav = cpu_baseline(fs2_state, pwg_state, stats, texts_all[0], noise[:per_utt].cpu())
             out["cpu_baseline"] = rec
             if parity_src is not None:
@@ -530,6 +558,7 @@ def main():
                     if got_wav.shape == ref_wav.shape else None,
                     "bars": {"mel_l1": 1e-4, "wav_relmax": 1e-4},
                 }
+        _log("done")
         print(json.dumps(out))
     if distributed:
         import torch.distributed as dist

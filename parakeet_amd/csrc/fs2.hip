@@ -24,9 +24,11 @@
 #include <cstring>
 
 #include "pk_gemm.h"
+#include "pk_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -62,7 +64,9 @@ __global__ void k_embed(const int* __restrict__ tok, const int* __restrict__ row
 constexpr int LN_MAXPER = 8;
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ g,
                                                    const float* __restrict__ b, const int* __restrict__ row_utt,
-                                                   int rows, int C, float eps, float* __restrict__ y) {
+                                                   int rows, int C, float eps, float* __restrict__ y,
+                                                   float* __restrict__ amax) {
+    // amax (optional): max|y[r, :]| per row for the block scaling of the split-fp16 GEMM that consumes y (pk_split.h)
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -72,6 +76,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < LN_MAXPER; ++e)
             if (e < nper) yo[lane + 64 * e] = 0.f;
+        if (amax && lane == 0) amax[r] = 0.f;
         return;
     }
     const float* xi = x + (long)r * C;
@@ -96,12 +101,20 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float inv = 1.0f / sqrtf(q / (float)C + eps);
+    float am = 0.f;
 #pragma unroll
     for (int e = 0; e < LN_MAXPER; ++e)
         if (e < nper) {
             const int c = lane + 64 * e;
-            yo[c] = (v[e] - mean) * inv * g[c] + b[c];
+            const float yv = (v[e] - mean) * inv * g[c] + b[c];
+            yo[c] = yv;
+            am = fmaxf(am, fabsf(yv));
         }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+        if (lane == 0) amax[r] = am;
+    }
 }
 
 // Multi-head self-attention for one (utterance, head, 32-query tile) per wave
@@ -124,7 +137,31 @@ struct AttnArgs {
     const int* seg_len;
     int D;      // heads * DK
     float scale;
+    const unsigned* amax;   // split-fp16 kernels: fp32 bits of max|q|, max|k|, max|v| per (utterance, head) [B][H][3]
 };
+
+// Block maxima for the split-fp16 attention kernels (pk_split.h): one (utterance, head) = one block of Q, of K
+// and of V.  grid (ceil(maxlen / 32), heads, B), 4 waves x 8 rows; atomicMax on fp32 bits of non-negative values
+// into zeroed memory.
+__global__ __launch_bounds__(256) void k_qkv_amax(const float* __restrict__ qkv, int ld, const int* __restrict__ seg_start,
+                                                  const int* __restrict__ seg_len, int D, int dk,
+                                                  unsigned* __restrict__ amax) {
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int len = seg_len[b], start = seg_start[b];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * 32 + wave * 8;
+    if (r0 >= len) return;
+    const int r1 = min(r0 + 8, len);
+    for (int part = 0; part < 3; ++part) {
+        const float* p = qkv + (long)start * ld + part * D + h * dk;
+        float m = 0.f;
+        for (int r = r0; r < r1; ++r)
+            for (int c = lane; c < dk; c += 64) m = fmaxf(m, fabsf(p[(long)r * ld + c]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) atomicMax(amax + ((long)b * gridDim.y + h) * 3 + part, __float_as_uint(m));
+    }
+}
 
 template <int DK>
 __global__ __launch_bounds__(256, 1) void k_attention(AttnArgs a) {
@@ -245,6 +282,35 @@ __device__ __forceinline__ void at_split8(const float (&v)[8], at_f16x8& hi, at_
         lo[2 * p + 1] = (_Float16)l1;
     }
 }
+// split of 2^k * x (block scaling, pk_split.h)
+__device__ __forceinline__ void at_split8s(const float (&v)[8], float s, at_f16x8& hi, at_f16x8& lo) {
+    float t[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x2 u = {v[2 * p], v[2 * p + 1]};
+        u *= s;
+        t[2 * p] = u[0];
+        t[2 * p + 1] = u[1];
+    }
+    at_split8(t, hi, lo);
+}
+// the three block scales of an (utterance, head) and the constants that undo them
+struct AtScales {
+    float sq, sk, sv;   // 2^kq, 2^kk, 2^kv
+    float cs;           // softmax scale / (2^kq 2^kk): S^T accumulators -> logits
+    float co;           // 1 / 2^kv: the 2^14 of P cancels against the row sum of the same P
+};
+__device__ __forceinline__ AtScales at_scales(const AttnArgs& a, int b, int h, int heads) {
+    const unsigned* m = a.amax + ((long)b * heads + h) * 3;
+    const int kq = blk_scale_exp(m[0]), kk = blk_scale_exp(m[1]), kv = blk_scale_exp(m[2]);
+    AtScales s;
+    s.sq = pow2f(kq);
+    s.sk = pow2f(kk);
+    s.sv = pow2f(kv);
+    s.cs = a.scale * pow2f(-kq) * pow2f(-kk);
+    s.co = pow2f(-kv);
+    return s;
+}
 __device__ __forceinline__ f32x16 at_mfma3(at_f16x8 ah, at_f16x8 al, at_f16x8 bh, at_f16x8 bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
@@ -263,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
     const int j = lane & 31, hi = lane >> 5;
     const long ld = a.ld;
     const float* base = a.qkv + (long)start * ld + h * DK;
+    const AtScales sc = at_scales(a, b, h, gridDim.y);
 
     at_f16x8 qh[KS], ql[KS];
     {
@@ -273,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            at_split8(v, qh[ks], ql[ks]);
+            at_split8s(v, sc.sq, qh[ks], ql[ks]);
         }
     }
     f32x16 O[DT];
@@ -296,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(kp + 16 * ks + 4);
                 const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 at_f16x8 kh, kl;
-                at_split8(v, kh, kl);
+                at_split8s(v, sc.sk, kh, kl);
                 S = at_mfma3(kh, kl, qh[ks], ql[ks], S);
             }
         }
@@ -304,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + mfma_row(r, hi);
-            S[r] = (key < len) ? S[r] * a.scale : -INFINITY;
+            S[r] = (key < len) ? S[r] * sc.cs : -INFINITY;
             mloc = fmaxf(mloc, S[r]);
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
@@ -332,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
             long voff[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                pv[e] = S[8 * s2 + e];
+                pv[e] = S[8 * s2 + e] * PK_UNIT_SCALE;   // p <= 1: fixed block scale 2^14
                 voff[e] = (long)min(k0 + mfma_row(8 * s2 + e, hi), len - 1) * ld;
             }
             at_f16x8 ph, pl;
@@ -343,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) vv[e] = vp[voff[e] + 32 * dt];
                 at_f16x8 vh, vl;
-                at_split8(vv, vh, vl);
+                at_split8s(vv, sc.sv, vh, vl);
                 O[dt] = at_mfma3(ph, pl, vh, vl, O[dt]);
             }
         }
@@ -354,8 +421,9 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
         const float lr = __shfl(l_run, mfma_row(r, hi));
         if (q < len) {
             float* o = a.out + (long)(start + q) * a.ldo + h * DK + j;
+            const float f = sc.co * (1.f / PK_UNIT_SCALE) / lr;   // O = 2^14 2^kv sum p v
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] / lr;
+            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] * f;
         }
     }
 }
@@ -385,6 +453,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
     const int j = lane & 31, hi = lane >> 5;
     const long ld = a.ld;
     const float* base = a.qkv + (long)start * ld + h * DK;
+    const AtScales sc = at_scales(a, b, h, gridDim.y);
 
     at_f16x8 qh[KS], ql[KS];
     {
@@ -395,7 +464,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            at_split8(v, qh[ks], ql[ks]);
+            at_split8s(v, sc.sq, qh[ks], ql[ks]);
         }
     }
     f32x16 O[DT];
@@ -434,7 +503,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
             if (idx >= 32 * (DK / 8)) break;
             const int key = idx / (DK / 8), grp = idx % (DK / 8);
             at_f16x8 fh, fl_;
-            at_split8(kreg[g], fh, fl_);
+            at_split8s(kreg[g], sc.sk, fh, fl_);
             const int ks = grp >> 1, fl = key + 32 * (grp & 1);
             Kf[(ks * 2 + 0) * 64 + fl] = fh;
             Kf[(ks * 2 + 1) * 64 + fl] = fl_;
@@ -445,7 +514,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
             if (idx >= 2 * DT * 64) break;
             const int fl = idx & 63, dt = (idx >> 6) % DT, s2 = idx / (64 * DT);
             at_f16x8 fh, fl_;
-            at_split8(vreg[g], fh, fl_);
+            at_split8s(vreg[g], sc.sv, fh, fl_);
             Vf[((s2 * DT + dt) * 2 + 0) * 64 + fl] = fh;
             Vf[((s2 * DT + dt) * 2 + 1) * 64 + fl] = fl_;
         }
@@ -467,7 +536,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + mfma_row(r, hi);
-            S[r] = (key < len) ? S[r] * a.scale : -INFINITY;
+            S[r] = (key < len) ? S[r] * sc.cs : -INFINITY;
             mloc = fmaxf(mloc, S[r]);
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
@@ -492,7 +561,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
         for (int s2 = 0; s2 < 2; ++s2) {
             float pv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pv[e] = S[8 * s2 + e];
+            for (int e = 0; e < 8; ++e) pv[e] = S[8 * s2 + e] * PK_UNIT_SCALE;   // p <= 1: fixed block scale 2^14
             at_f16x8 ph, pl;
             at_split8(pv, ph, pl);
 #pragma unroll
@@ -508,8 +577,9 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
         const float lr = __shfl(l_run, mfma_row(r, hi));
         if (q < len) {
             float* o = a.out + (long)(start + q) * a.ldo + h * DK + j;
+            const float f = sc.co * (1.f / PK_UNIT_SCALE) / lr;   // O = 2^14 2^kv sum p v
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] / lr;
+            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] * f;
         }
     }
 }
@@ -728,6 +798,7 @@ struct pk_fs2 {
     pk_dbuf d_pe, d_div;
     // per-call state
     Timeline tl_tok, tl_frm;
+    pk_dbuf d_lnamax;
     pk_dbuf d_tok, d_x, d_h, d_qkv, d_ctx, d_f, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
         d_before, d_q1, d_q2, d_rowmap, d_dbg_up, d_zs, d_mel_stage;
     std::vector<int> frames;   // per utterance, result of encode
@@ -1123,8 +1194,10 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
 }
 
 static int run_dense(pk_fs2* h, const char* name, const Dense& d, const float* A, int lda, float* C, int ldc,
-                     int rows, int act, const float* res, int ldr, const int* rowvalid) {
+                     int rows, int act, const float* res, int ldr, const int* rowvalid,
+                     const float* a_amax = nullptr) {
     pk_gemm_args g;
+    g.a_amax = a_amax;   // row maxima of A when its producer left them (k_layernorm), else computed by the launcher
     g.A = A;
     g.lda = lda;
     g.Wp = h->W(d.w);
@@ -1145,9 +1218,10 @@ static int run_dense(pk_fs2* h, const char* name, const Dense& d, const float* A
     return pk_gemm_launch(h->ctx, name, g);
 }
 
-static int run_layernorm(pk_fs2* h, const float* x, size_t g, size_t b, const Timeline& tl, int C, float* y) {
+static int run_layernorm(pk_fs2* h, const float* x, size_t g, size_t b, const Timeline& tl, int C, float* y,
+                         float* amax = nullptr) {
     PK_LAUNCH(h->ctx, "fs2_layernorm", k_layernorm, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, x, h->W(g), h->W(b),
-              tl.d_row_utt(), tl.rows, C, 1e-5f, y);
+              tl.d_row_utt(), tl.rows, C, 1e-5f, y, amax);
     return PK_OK;
 }
 
@@ -1164,6 +1238,16 @@ static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float*
     a.seg_len = tl.d_seg_len();
     a.D = A;
     a.scale = (float)(1.0 / std::sqrt((double)dk));
+    a.amax = nullptr;
+    if (h->math == PK_GEMM_MATH_F16X3) {   // block maxima of Q, K, V per (utterance, head) for the operand scales
+        pk_ctx_scratch* sc = pk_ctx_get_scratch(h->ctx);
+        const size_t nb = (size_t)tl.B * heads * 3 * sizeof(unsigned);
+        PK_TRY(sc->attn_amax.reserve(nb));
+        PK_HIP(hipMemsetAsync(sc->attn_amax.p, 0, nb, h->ctx->stream));
+        PK_LAUNCH(h->ctx, "fs2_qkv_amax", k_qkv_amax, dim3(pk_div_up(maxlen, 32), heads, tl.B), dim3(256), 0, qkv,
+                  3 * A, tl.d_seg_start(), tl.d_seg_len(), A, dk, sc->attn_amax.as<unsigned>());
+        a.amax = sc->attn_amax.as<unsigned>();
+    }
     dim3 grid(pk_div_up(maxlen, 128), heads, tl.B);
     if (h->math == PK_GEMM_MATH_F16X3 && h->attn_lds) {
         dim3 g2(pk_div_up(maxlen, ATT_THREADS / 2), heads, tl.B);
@@ -1210,13 +1294,21 @@ static int run_fft_stack(pk_fs2* h, const std::vector<FftLayer>& layers, size_t 
     float* ctxb = act_ptr(h->d_ctx, A);
     float* f = act_ptr(h->d_f, units);
     const int* rv = tl.d_row_utt();
+    // row maxima of the LayerNorm outputs, left by k_layernorm for the split-fp16 GEMMs that read them (rows outside
+    // the timeline: zero)
+    float* ham = nullptr;
+    if (h->math == PK_GEMM_MATH_F16X3) {
+        PK_TRY(act_reserve(h->d_lnamax, tl.rows, 1));
+        PK_HIP(hipMemsetAsync(h->d_lnamax.p, 0, h->d_lnamax.cap, h->ctx->stream));
+        ham = act_ptr(h->d_lnamax, 1);
+    }
     for (const FftLayer& L : layers) {
-        PK_TRY(run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh));
-        PK_TRY(run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));
+        PK_TRY(run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh, ham));
+        PK_TRY(run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, ham));
         PK_TRY(run_attention(h, tl, qkv, ctxb));
         PK_TRY(run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
-        PK_TRY(run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh));
-        PK_TRY(run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv));
+        PK_TRY(run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh, ham));
+        PK_TRY(run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv, ham));
         PK_TRY(run_dense(h, "fs2_conv_ffn2", L.ffn2, f, units, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
     }
     PK_TRY(run_layernorm(h, x, after_g, after_b, tl, A, hs_out));
@@ -1530,7 +1622,7 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     if (!h) return;
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
+    pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_lnamax, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
                        &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
                        &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
     for (auto* b : bufs) b->release();

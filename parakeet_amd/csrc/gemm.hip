@@ -10,12 +10,14 @@
 //   As[kk][wm][i]{mt}  float2 per (k, wave-row, lane-row): one ds_read_b64 gives a
 //   lane its A operand for both of its M tiles; Bs[kk][wn][j]{nt} likewise.  The
 //   weight image is pre-packed on the host, so its staging is a straight copy.
+#include <algorithm>
 #include <cstring>
 #include <string>
 
 #include <type_traits>
 
 #include "pk_gemm.h"
+#include "pk_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -224,6 +226,10 @@ __global__ __launch_bounds__(256, 3) void k_gemm(pk_gemm_args a) {
 // Same tiling and epilogue; every fp32 product is a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with fp16 parts on
 // v_mfma_f32_32x32x16_f16, fp32 accumulation (error of the result = exact-fp32 class, see pwg.hip).
 // K slab = 32.  A operand = activations (rows), B operand = weights (cols).
+// Block scaling (pk_split.h): the weight fragments of 128-column block nb hold W * 2^kw[nb] (kw[] = header of the
+// packed blob); an activation row is split as 2^kx * a with kx from a_amax[] = max|A[r, :]| over the rows its taps
+// read (and a2_amax[] for the appended operand), supplied by the producer of A or computed by k_row_amax; the
+// accumulators are multiplied by 2^-(kx + kw) before the epilogue.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 constexpr int HBK = PK_GEMM_HBK;           // 32
@@ -254,6 +260,41 @@ __device__ __forceinline__ void gemm_split8(const float (&v)[8], f16x8& hi, f16x
     }
 }
 
+// max|A[r, 0..C)| for rows r0 <= r < r1 of a row-major matrix: one wave per row (amax is indexed like A: row r ->
+// amax[r], rows before the base are valid memory on both)
+__global__ __launch_bounds__(256) void k_row_amax(const float* __restrict__ A, long lda, int C, long r0, long r1,
+                                                  float* __restrict__ amax) {
+    const long r = r0 + (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= r1) return;
+    const int lane = threadIdx.x & 63;
+    const float* row = A + r * lda;
+    float m = 0.f;
+    if ((C & 3) == 0 && (lda & 3) == 0) {
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, fabsf(row[c]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) amax[r] = m;
+}
+
+// split of 2^k * x (x scaled exactly, then as gemm_split8)
+__device__ __forceinline__ void gemm_split8s(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
+    float t[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x2 u = {v[2 * p], v[2 * p + 1]};
+        u *= s;
+        t[2 * p] = u[0];
+        t[2 * p + 1] = u[1];
+    }
+    gemm_split8(t, hi, lo);
+}
+
 // MT = 32-row MFMA tiles per wave along M: 2 -> 128-row workgroup tiles (2 workgroups per CU), 1 -> 64-row tiles
 // (48 KB of LDS, <= 170 VGPRs: 3 workgroups per CU) for grids that would otherwise end in a nearly empty round.
 template <int MT>
@@ -264,6 +305,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_h3(pk_gemm_args a
     // neighbouring loader threads write no longer collide (PMC: 20 % of the LDS cycles were bank conflicts)
     __shared__ __attribute__((aligned(16))) f16x8 Af[2][2 * 2 * 2 * MT * 65];
     __shared__ __attribute__((aligned(16))) f16x8 Bs[2][H_B_BYTES / 16];
+    __shared__ float rinv[TM];                  // per output row: 2^-(kx + kw), applied to the accumulators
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -278,7 +320,21 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_h3(pk_gemm_args a
     const int lrow = (tid * AG) >> 2, lgrp = (tid * AG) & 3;
     const float* arow = a.A + (long)(m0 + lrow) * a.lda + lgrp * 8;
     const float* arow2 = a.A2 + (long)(m0 + lrow) * a.lda2 + lgrp * 8;
-    const f16x8* wsrc = reinterpret_cast<const f16x8*>(a.Wh) + (long)nblk * a.wslabs_total * (H_B_BYTES / 16) + tid;
+    // packed weights: header of ceil(nblks / 4) x 16 B with the exponent of every 128-column block, then fragments
+    const int hdr16 = ((int)gridDim.y + 3) >> 2;
+    const int kw = reinterpret_cast<const int*>(a.Wh)[nblk];
+    const f16x8* wsrc = reinterpret_cast<const f16x8*>(a.Wh) + hdr16 + (long)nblk * a.wslabs_total * (H_B_BYTES / 16) + tid;
+    // this thread's A row: its scale 2^kx from the largest magnitude among the rows its taps read
+    float sx;
+    {
+        const long m = m0 + lrow;
+        float am = 0.f;
+        for (int t = 0; t < a.ntaps; ++t) am = fmaxf(am, a.a_amax[m + a.tap_row[t]]);
+        if (a.Cin2 > 0) am = fmaxf(am, a.a2_amax[m]);
+        const int kx = blk_scale_exp(__float_as_uint(am));
+        sx = pow2f(kx);
+        if (lgrp == 0) rinv[lrow] = pow2f(-(kx + kw));   // visible after the first barrier of the K loop
+    }
     // fragment slot of group g: (ks = g / 2, part, mt = lrow / 32, lane = lrow % 32 + 32 * (g % 2))
     auto a_slot = [&](int g, int part) {
         return (((g >> 1) * 2 + part) * (2 * MT) + (lrow >> 5)) * 65 + (lrow & 31) + 32 * (g & 1);
@@ -313,7 +369,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_h3(pk_gemm_args a
             const f32x4 v0 = ra[set][2 * g], v1 = ra[set][2 * g + 1];
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             f16x8 fh, fl;
-            gemm_split8(v, fh, fl);
+            gemm_split8s(v, sx, fh, fl);
             Af[buf][a_slot(lgrp + g, 0)] = fh;
             Af[buf][a_slot(lgrp + g, 1)] = fl;
         }
@@ -386,6 +442,15 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_h3(pk_gemm_args a
         step(s, S0{}, S1{});
         if (s + 1 < nslabs) step(s + 1, S1{}, S2{});
     }
+    // undo the block scales: row r of the tile was accumulated as 2^(kx_r + kw) * (A W)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ri = rinv[wm * (32 * MT) + mt * 32 + mfma_row(r, hi)];
+            acc[mt][0][r] *= ri;
+            acc[mt][1][r] *= ri;
+        }
     if (a.epi == PK_EPI_GATE_PROJ) {
         // ---- stage 2: z = tanh(content + b) * sigmoid(gate + b) -> LDS fragments, then out = z . W2 (K = 64, N = 128)
         {
@@ -406,13 +471,14 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_h3(pk_gemm_args a
                     float v = (1.f - ea) / ((1.f + ea) * (1.f + eb));
                     const int m = m0 + row;
                     if (m >= a.M || (a.rowvalid && a.rowvalid[m] < 0)) v = 0.f;
-                    const _Float16 vh = (_Float16)v;                 // |z| < 1: no saturation issue
+                    v *= PK_UNIT_SCALE;                              // |z| < 1: fixed block scale 2^14
+                    const _Float16 vh = (_Float16)v;
                     const _Float16 vl = (_Float16)(v - (float)vh);
                     const int o = e_off + ((row >> 5) * 65 + (row & 31)) * 8;
                     zf[o] = vh;
                     zf[o + (2 * MT) * 65 * 8] = vl;                  // part 1
                 }
-            const f16x8* w2 = reinterpret_cast<const f16x8*>(a.Wh2) + tid;
+            const f16x8* w2 = reinterpret_cast<const f16x8*>(a.Wh2) + 1 + tid;   // + header (one 128-column block)
 #pragma unroll
             for (int c = 0; c < 8; ++c) Bs[c >> 2][tid + (c & 3) * 256] = w2[c * 256];
         }
@@ -425,6 +491,15 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_h3(pk_gemm_args a
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         mma_slab(0);
         mma_slab(1);
+        {
+            const float s2 = pow2f(-(PK_UNIT_EXP + reinterpret_cast<const int*>(a.Wh2)[0]));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= s2;
+        }
         pk_gemm_args b = a;
         b.epi = PK_EPI_STD;
         b.bias = a.bias2;
@@ -496,10 +571,23 @@ static inline float gemm_f16_to_f32(uint16_t h) {
 size_t pk_gemm_pack_h3(const float* Wkn, int K, int N, std::vector<uint16_t>& out) {
     const int nblks = (N + BN - 1) / BN, nslabs = K / PK_GEMM_HBK;
     const size_t per = H_B_BYTES / 2;   // halves per (n-block, slab)
-    out.assign((size_t)nblks * nslabs * per, 0);
+    // header: one int per 128-column block = exponent kw of its block scale (pk_split.h), padded to 16 bytes
+    const size_t hdr = (size_t)((nblks + 3) / 4) * 8;   // halves
+    out.assign(hdr + (size_t)nblks * nslabs * per, 0);
+    std::vector<int> kws(nblks, 0);
+    for (int nb = 0; nb < nblks; ++nb) {
+        float m = 0.f;
+        for (int k = 0; k < K; ++k)
+            for (int n = nb * BN; n < N && n < (nb + 1) * BN; ++n) {
+                const float v = std::fabs(Wkn[(size_t)k * N + n]);
+                if (std::isfinite(v) && v > m) m = v;
+            }
+        kws[nb] = pk_weight_scale_exp(&m, 1);
+    }
+    memcpy(out.data(), kws.data(), nblks * sizeof(int));
     for (int nb = 0; nb < nblks; ++nb)
         for (int s = 0; s < nslabs; ++s) {
-            uint16_t* img = out.data() + ((size_t)nb * nslabs + s) * per;
+            uint16_t* img = out.data() + hdr + ((size_t)nb * nslabs + s) * per;
             for (int ks = 0; ks < 2; ++ks)
                 for (int nt = 0; nt < 4; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
@@ -507,7 +595,7 @@ size_t pk_gemm_pack_h3(const float* Wkn, int K, int N, std::vector<uint16_t>& ou
                             const int j = lane & 31, kb = lane >> 5;
                             const int k = s * PK_GEMM_HBK + ks * 16 + kb * 8 + e;
                             const int n = nb * BN + nt * 32 + j;
-                            const float w = n < N ? Wkn[(size_t)k * N + n] : 0.f;
+                            const float w = n < N ? std::ldexp(Wkn[(size_t)k * N + n], kws[nb]) : 0.f;
                             const uint16_t h = gemm_f32_to_f16(w);
                             const uint16_t l = gemm_f32_to_f16(w - gemm_f16_to_f32(h));
                             img[((((size_t)ks * 2 + 0) * 4 + nt) * 64 + lane) * 8 + e] = h;
@@ -539,6 +627,12 @@ void pk_gemm_gate_permute(const float* Wkn, int K, int Cz, std::vector<float>& o
 
 void pk_gemm_gate_permute_bias(const float* b, int Cz, std::vector<float>& out) {
     pk_gemm_gate_permute(b, 1, Cz, out);
+}
+
+int pk_row_amax_launch(pk_ctx* ctx, const float* A, long lda, int C, long r0, long r1, float* amax) {
+    if (r1 <= r0) return PK_OK;
+    PK_LAUNCH(ctx, "row_amax", k_row_amax, dim3(pk_div_up(r1 - r0, 4)), dim3(256), 0, A, lda, C, r0, r1, amax);
+    return PK_OK;
 }
 
 int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
@@ -578,6 +672,30 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     // (ffn1 0.49 vs 0.42 ms, WaveFlow conv 160 vs 140 us): occupancy beats fewer barriers here.
     (void)nslabs;
     if (h3) {
+        // block scaling: row maxima of the A operand(s) over every row a tile can read
+        const long rows_pad = (long)grid.x * BM;
+        long lo = 0, hi_row = 0;
+        for (int t = 0; t < a.ntaps; ++t) {
+            if (a.lda <= 0 || a.tap_off[t] % a.lda != 0)
+                PK_FAIL(PK_EUNSUPPORTED, "split-fp16 GEMM: tap offset %ld is not a whole number of rows (lda %d)",
+                        a.tap_off[t], a.lda);
+            a.tap_row[t] = (int)(a.tap_off[t] / a.lda);
+            lo = std::min<long>(lo, a.tap_row[t]);
+            hi_row = std::max<long>(hi_row, a.tap_row[t]);
+        }
+        if (!a.a_amax) {
+            pk_ctx_scratch* sc = pk_ctx_get_scratch(ctx);
+            PK_TRY(sc->row_amax.reserve((size_t)(rows_pad + hi_row - lo) * sizeof(float)));
+            float* am = sc->row_amax.as<float>() - lo;
+            PK_TRY(pk_row_amax_launch(ctx, a.A, a.lda, a.Cin, lo, rows_pad + hi_row, am));
+            a.a_amax = am;
+        }
+        if (a.Cin2 > 0 && !a.a2_amax) {
+            pk_ctx_scratch* sc = pk_ctx_get_scratch(ctx);
+            PK_TRY(sc->row_amax2.reserve((size_t)rows_pad * sizeof(float)));
+            PK_TRY(pk_row_amax_launch(ctx, a.A2, a.lda2, a.Cin2, 0, rows_pad, sc->row_amax2.as<float>()));
+            a.a2_amax = sc->row_amax2.as<float>();
+        }
         const std::string nm = std::string(prof_name) + "_h3";
         // 128-row tiles at 2 workgroups per CU, or 64-row tiles at 3 per CU: take the 64-row grid when the
         // 128-row one would leave the machine idle in its last round (fewer rounds-equivalents of work)

@@ -62,6 +62,7 @@ struct pk_prof_rec {
     hipEvent_t start, stop;
 };
 
+struct pk_ctx_scratch;
 struct pk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -73,6 +74,7 @@ struct pk_ctx {
     std::map<std::string, int> prof_ids;
     std::vector<pk_prof_rec> prof_recs;
     std::vector<hipEvent_t> event_pool;
+    pk_ctx_scratch* scratch = nullptr;   // small grow-only device buffers shared by the launchers (stream-ordered)
 
     int prof_begin(const char* name);   // returns record index or -1
     void prof_end(int rec);
@@ -116,6 +118,14 @@ struct pk_dbuf {
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// per-context scratch (allocated on first use, freed by pk_ctx_destroy)
+struct pk_ctx_scratch {
+    pk_dbuf row_amax;    // pk_gemm_launch: max|A[r, :]| per row when the caller does not supply it
+    pk_dbuf row_amax2;
+    pk_dbuf attn_amax;   // run_attention: max|q|, |k|, |v| per (utterance, head)
+};
+pk_ctx_scratch* pk_ctx_get_scratch(pk_ctx* ctx);
 
 struct pk_param {
     std::vector<int64_t> shape;

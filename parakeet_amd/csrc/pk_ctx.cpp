@@ -74,8 +74,19 @@ extern "C" void pk_ctx_destroy(pk_ctx* ctx) {
         (void)hipEventDestroy(r.stop);
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->scratch) {
+        ctx->scratch->row_amax.release();
+        ctx->scratch->row_amax2.release();
+        ctx->scratch->attn_amax.release();
+        delete ctx->scratch;
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+pk_ctx_scratch* pk_ctx_get_scratch(pk_ctx* ctx) {
+    if (!ctx->scratch) ctx->scratch = new pk_ctx_scratch();
+    return ctx->scratch;
 }
 
 // ------------------------------------------------------------------ profiler

@@ -72,7 +72,17 @@ struct pk_gemm_args {
     float* C2 = nullptr;
     int ldc2 = 0;
     int acc2 = 0;
+    // ---- block scaling of the split-fp16 kernel (pk_split.h).  a_amax[r] = max|A[r, 0..Cin)| indexed like the rows
+    // of A (negative / beyond-M indices as far as the taps reach), a2_amax[r] likewise for A2.  NULL: the launcher
+    // computes them with k_row_amax into the context's scratch (one extra read of A).  Producers that know their
+    // row maxima (k_layernorm) pass them and save that pass.  tap_row[] is set by the launcher (tap_off / lda).
+    const float* a_amax = nullptr;
+    const float* a2_amax = nullptr;
+    int tap_row[PK_GEMM_MAX_TAPS] = {0};
 };
+
+// max|A[r, 0..C)| for r0 <= r < r1 into amax[r] (amax indexed like the rows of A); on ctx->stream
+int pk_row_amax_launch(pk_ctx* ctx, const float* A, long lda, int C, long r0, long r1, float* amax);
 
 // Pack a [K][N] row-major matrix (K = taps*Cin, multiple of 16) into per-(N tile,
 // K slab) LDS images.  Returns floats written: ceil(N/128) * (K/16) * 2048.

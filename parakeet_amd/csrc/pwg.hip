@@ -39,6 +39,7 @@
 #include <cstdlib>
 
 #include "pk_gemm.h"
+#include "pk_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -104,14 +105,26 @@ __global__ void k_pwg_convin_prep(const float* __restrict__ mel, const float* __
 // first_conv: Conv1D(1 -> R, k=1, bias) (:401-402,464) from packed noise into the timeline.
 __global__ void k_pwg_first(const float* __restrict__ noise, const float* __restrict__ w,
                             const float* __restrict__ bias, const int* __restrict__ tile_t0, long Ttot,
-                            float* __restrict__ x) {
+                            float* __restrict__ x, unsigned* __restrict__ xe) {
     const int tile = blockIdx.x;
     const long t = (long)tile_t0[tile] + threadIdx.x;
     const float n = noise[(long)tile * TILE + threadIdx.x];
     (void)Ttot;
     const long xo = xoff(t);
+    float am = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < R; ++c) x[xo + c * XBLK] = fmaf(w[c], n, bias[c]);
+    for (int c = 0; c < R; ++c) {
+        const float v = fmaf(w[c], n, bias[c]);
+        am = fmaxf(am, fabsf(v));
+        x[xo + c * XBLK] = v;
+    }
+    // max|x| per 32-sample block for the first layer's operand scale (see "block scaling")
+    am = fmaxf(am, __shfl_xor(am, 16));
+    am = fmaxf(am, __shfl_xor(am, 8));
+    am = fmaxf(am, __shfl_xor(am, 4));
+    am = fmaxf(am, __shfl_xor(am, 2));
+    am = fmaxf(am, __shfl_xor(am, 1));
+    if ((threadIdx.x & 31) == 0) xe[t >> 5] = __float_as_uint(am);
 }
 
 // Test tap: the sample-rate aux contribution of one layer, aux[co][s] =
@@ -145,6 +158,11 @@ struct PwgLayerArgs {
     int ntiles;
     int dilation;
     int dbg;   // ablation switches for profiling only (PK_PWG_ABLATE env var); 0 in production
+    // scaled split-fp16 path (k_pwg_layer_b3<., true>) only -- see "block scaling" below
+    const unsigned* xe_in;   // [Ttot/32] bits of max|x| per 32-sample block of xin (0 in the gaps)
+    unsigned* xe_out;        // the same for xout, written by this launch
+    int k1;                  // W1 fragments hold conv.weight * 2^k1
+    float i0, i1;            // sqrt(0.5) / (2^14 * 2^k2out), 1 / (2^14 * 2^k2skip): undo the stage-2 scales
 };
 
 // tanh(a) * sigmoid(b) (:309-310).  exp via v_exp_f32; |a| clamped where tanh is +-1 in fp32.
@@ -155,6 +173,29 @@ __device__ __forceinline__ float gated(float a, float b) {
     // v_rcp_f32 (1 ulp) instead of an IEEE divide: the gate is VALU time that the other wave's MFMAs
     // only partly hide (ablation: -0.13 ms per layer launch with the gate removed)
     return (1.f - ea) * __builtin_amdgcn_rcpf((1.f + ea) * (1.f + eb));
+}
+
+// ---------------------------------------------------------------- block scaling of the split-fp16 operands
+// (pk_split.h).  Here: weights one exponent per tensor; x one exponent per wave tile, from the per-block max|x|
+// that the producer of x (k_pwg_first / the previous layer's epilogue) leaves in xe[]; z = tanh * sigmoid with the
+// fixed 2^14, folded into the gate's last multiply.  tests/test_pwg_gpu.py::test_pwg_split_math_is_scale_invariant
+constexpr float PK_Z_SCALE = PK_UNIT_SCALE;
+__device__ __forceinline__ float wave_max64(float v) {
+    v = fmaxf(v, __shfl_xor(v, 32));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 1));
+    return v;
+}
+// 2^14 * tanh(a / S) * sigmoid(b / S) from accumulators that hold S * (pre-activation): cb = -log2(e) / S, the
+// clamp of gated() moves behind the multiply (|2 a log2 e| <= 20 log2 e).  Same instruction count as gated().
+__device__ __forceinline__ float gated_s(float a, float b, float ca, float cb) {   // ca = 2 cb
+    const float ta = __builtin_amdgcn_fmed3f(a * ca, -28.853900817779268f, 28.853900817779268f);
+    const float ea = __builtin_amdgcn_exp2f(ta);
+    const float eb = __builtin_amdgcn_exp2f(b * cb);
+    return fmaf(ea, -PK_Z_SCALE, PK_Z_SCALE) * __builtin_amdgcn_rcpf((1.f + ea) * (1.f + eb));
 }
 
 constexpr int LDS_W1 = KS1 * 64 * 4;          // 24576 floats
@@ -471,8 +512,22 @@ __device__ __forceinline__ void split_x8<f16x8, _Float16, true>(const float (&v)
     }
 }
 
+// split of s * x, s = the block's power of two (see "block scaling"): one v_pk_mul_f32 per pair on top of split_x8
+__device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
+    float t[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x2 u = {v[2 * p], v[2 * p + 1]};
+        u *= s;
+        t[2 * p] = u[0];
+        t[2 * p + 1] = u[1];
+    }
+    split_x8<f16x8, _Float16, true>(t, hi, lo);
+}
+
 // HALF = false: bf16 parts (8 significant bits each, fp32 range); HALF = true: fp16 parts (11 bits each,
-// 22 bits per operand ~ fp32's 24; needs |x| < 65504 and keeps an absolute floor of 2^-25 per operand).
+// 22 bits per operand ~ fp32's 24) of block-scaled operands (see "block scaling" above: no subnormal parts, no
+// dependence on the magnitude of weights or activations; |x| beyond 2^113 aside).
 // ABL (profiling only, PK_PWG_ABLATE=1): 1 = no global loads / stores of x and skip (compute-only time)
 template <bool FIRST, bool HALF, int ABL = 0>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
@@ -506,6 +561,31 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int my_slot = wg_slot * LAYER_WAVES + wave;
     const int stride_slots = (int)gridDim.x * LAYER_WAVES;
     const int n_wtiles = a.ntiles * (TILE / WAVE_T);
+
+    // block scaling (HALF): lanes 0..4 fetch max|x| of the 32-sample blocks the three taps of a wave tile touch
+    // (d < 32: the blocks before / at / after the tile; d >= 32, a multiple of 32: exactly the blocks at -d, 0, +d)
+    int eoff = 0;
+    if (HALF) {
+        const int dc = (d + 31) >> 5, df = d >> 5;
+        eoff = lane == 0 ? -dc : (lane == 1 ? -df : (lane == 3 ? df : (lane == 4 ? dc : 0)));
+    }
+    auto load_amax = [&](int wt) -> unsigned {
+        const long tt0 = (long)a.tile_t0[wt >> 3] + (wt & 7) * WAVE_T;
+        return ABL ? 0x3f800000u : a.xe_in[(tt0 >> 5) + eoff];
+    };
+    auto tile_scale_exp = [&](unsigned ev) -> int {   // wave-uniform (SGPR) exponent k of the tile's x scale 2^k
+        unsigned m = (unsigned)__builtin_amdgcn_readlane((int)ev, 0);
+        const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)ev, 1);
+        const unsigned m2 = (unsigned)__builtin_amdgcn_readlane((int)ev, 2);
+        const unsigned m3 = (unsigned)__builtin_amdgcn_readlane((int)ev, 3);
+        const unsigned m4 = (unsigned)__builtin_amdgcn_readlane((int)ev, 4);
+        m = m > m1 ? m : m1;
+        m = m > m2 ? m : m2;
+        m = m > m3 ? m : m3;
+        m = m > m4 ? m : m4;
+        return blk_scale_exp(m);
+    };
+    int kx = 0, kx_next = 0;   // x-scale exponents of the current / the next wave tile
 
     // operand group g of a wave-tile = k-step g = (channel group cg = g/3, tap = g%3).  Element e of lane
     // (j, hi) is input channel 32*(cg>>1) + mfma_row(8*(cg&1) + e, hi) -- the SAME channel the lane owns as
@@ -546,7 +626,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
             for (int e = 0; e < 8; ++e) ring[g][e] = ABL ? (float)(lane + e) * 1e-3f : (a.xin + group_row(g, e) * XBLK)[vo];
         }
-        split_x8<bf16x8, elem16, HALF>(ring[0], ph, pl);
+        if constexpr (HALF) {
+            kx = tile_scale_exp(load_amax(my_slot));
+            split_x8s(ring[0], pow2f(kx), ph, pl);
+        } else {
+            split_x8<bf16x8, elem16, HALF>(ring[0], ph, pl);
+        }
     }
     // W1 fragments of the next (k-step, co-tile) in issue order, read one co-tile ahead of their MFMAs
     bf16x8 c_ah = lds_a[0], c_al = lds_a[4 * 64];
@@ -568,6 +653,21 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             const int idx = lane + 64 * it;
             if (idx < UPW * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
         }
+        // HALF: the stage-1 accumulators hold S1 * (pre-activation), S1 = 2^(kx + k1) = x scale * W1 scale
+        unsigned ev_next = 0;
+        float sx = 1.f, gca = 0.f, gcb = 0.f;
+        if constexpr (HALF) {
+            ev_next = load_amax(next_wt);
+            const int ks1 = kx + a.k1;
+            sx = pow2f(kx);
+            const float S1 = pow2f(ks1);
+#pragma unroll
+            for (int jj = 0; jj < UPW; ++jj) uw[jj] *= S1;
+            const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
+            gcb = __int_as_float(cbb);
+            gca = __int_as_float(cbb + (1 << 23));   // 2 * gcb
+        }
+        const float S1b = HALF ? pow2f(kx + a.k1) : 1.f;
         f32x16 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -575,6 +675,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int co0 = 32 * q + 8 * r4 + 4 * hi;
                 f32x4 v = *reinterpret_cast<const f32x4*>(lds_bias + co0);
+                if constexpr (HALF) v *= S1b;
 #pragma unroll
                 for (int jj = 0; jj < UPW; ++jj) {
                     const f32x4 pv = *reinterpret_cast<const f32x4*>(lds_p + jj * G + co0);
@@ -606,7 +707,13 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             bf16x8 nh, nl;
             {
                 const int g1 = (g + 1) % B3_KS1;
-                split_x8<bf16x8, elem16, HALF>(ring[(g + 1) % B3_RING], nh, nl);
+                if constexpr (HALF) {
+                    if (g == B3_KS1 - 2) kx_next = tile_scale_exp(ev_next);
+                    // group 0 of the NEXT tile is split under the last k-step of this one: its own scale
+                    split_x8s(ring[(g + 1) % B3_RING], g + 1 < B3_KS1 ? sx : pow2f(kx_next), nh, nl);
+                } else {
+                    split_x8<bf16x8, elem16, HALF>(ring[(g + 1) % B3_RING], nh, nl);
+                }
                 if (g1 % 3 == 1) {   // centre tap: these fp32 values are x_in at this lane's output rows
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -654,8 +761,13 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             if (ks >= B3_KS2) return;
             const int zq = ks >> 1, r0 = 8 * (ks & 1);
             if (slot < 4) {
-                zv[2 * slot] = gated(acc[zq][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot]);
-                zv[2 * slot + 1] = gated(acc[zq][r0 + 2 * slot + 1], acc[zq + 2][r0 + 2 * slot + 1]);
+                if constexpr (HALF) {   // z * 2^14 from the scaled accumulators
+                    zv[2 * slot] = gated_s(acc[zq][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot], gca, gcb);
+                    zv[2 * slot + 1] = gated_s(acc[zq][r0 + 2 * slot + 1], acc[zq + 2][r0 + 2 * slot + 1], gca, gcb);
+                } else {
+                    zv[2 * slot] = gated(acc[zq][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot]);
+                    zv[2 * slot + 1] = gated(acc[zq][r0 + 2 * slot + 1], acc[zq + 2][r0 + 2 * slot + 1]);
+                }
             } else if (slot == 4) {
                 split_x8<bf16x8, elem16, HALF>(zv, zh[ks], zl[ks]);
             }
@@ -722,16 +834,30 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             }
             __builtin_amdgcn_sched_barrier(0);
             float* dst = pass == 0 ? a.xout : a.skip;
+            float am = 0.f;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v;
-                    if (pass == 0) v = (acc2[q][r] + x_old[16 * q + r]) * rs;
-                    else v = FIRST ? acc2[q][r] : (sk_old[16 * q + r] + acc2[q][r]);
+                    if constexpr (HALF) {   // acc2 = 2^14 * 2^k2 * (W2 z + b); i0 carries the sqrt(0.5) of :314
+                        if (pass == 0) v = fmaf(acc2[q][r], a.i0, x_old[16 * q + r] * rs);
+                        else v = FIRST ? acc2[q][r] * a.i1 : fmaf(acc2[q][r], a.i1, sk_old[16 * q + r]);
+                        if (pass == 0) am = fmaxf(am, fabsf(v));
+                    } else {
+                        if (pass == 0) v = (acc2[q][r] + x_old[16 * q + r]) * rs;
+                        else v = FIRST ? acc2[q][r] : (sk_old[16 * q + r] + acc2[q][r]);
+                    }
                     if (!ABL || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
+            if constexpr (HALF) {
+                if (pass == 0) {   // max|x_out| of this 64 x 32 block for the next layer's operand scale
+                    am = wave_max64(am);
+                    if (lane == 0 && (!ABL || a.Ttot < 0)) a.xe_out[vo4 >> 11] = __float_as_uint(am);
+                }
+            }
         }
+        kx = kx_next;
     }
 }
 
@@ -747,6 +873,7 @@ struct PwgLastArgs {
     const int* tile_t0;
     long Ttot;
     float* wav;          // packed (ntiles*TILE)
+    int kw;              // k_pwg_last_h3: the W fragments hold last_conv_layers.1.weight * 2^kw
 };
 
 __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
@@ -809,13 +936,26 @@ __global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = a.b1[32 * q + mfma_row(r, hi)];
     __syncthreads();
+    // block scaling: the wave has its whole 64 x 32 operand in registers, so the block maximum is formed here
+    float am = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sv[ks][e] = fmaxf(sv[ks][e] * a.scale, 0.f);   // ReLU(skips * sqrt(1/layers)) (:469-471)
+            am = fmaxf(am, sv[ks][e]);
+        }
+    am = wave_max64(am);
+    const int kx = blk_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(am)));
+    const float sx = pow2f(kx), S = pow2f(kx + a.kw), Sinv = pow2f(-(kx + a.kw));
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] *= S;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(sv[ks][e] * a.scale, 0.f);   // ReLU(skips * sqrt(1/layers)) (:469-471)
         f16x8 bh, bl;
-        split_x8<f16x8, _Float16, true>(v, bh, bl);
+        split_x8s(sv[ks], sx, bh, bl);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const f16x8 ah = wl[((ks * 2 + 0) * 2 + q) * 64 + lane];
@@ -830,9 +970,9 @@ __global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            part = fmaf(a.w2[32 * q + mfma_row(r, hi)], fmaxf(acc[q][r], 0.f), part);
+            part = fmaf(a.w2[32 * q + mfma_row(r, hi)], fmaxf(acc[q][r], 0.f), part);   // ReLU commutes with S > 0
     part += __shfl_xor(part, 32);
-    if (hi == 0) a.wav[(long)tile * TILE + wave * WAVE_T + j] = part + a.b2;
+    if (hi == 0) a.wav[(long)tile * TILE + wave * WAVE_T + j] = fmaf(part, Sinv, a.b2);
 }
 
 }  // namespace
@@ -856,6 +996,11 @@ struct pk_pwg {
     pk_dbuf d_waux;                 // packed GEMM weight [AUX] x [layers*G]
     pk_dbuf d_l1, d_l1b, d_l2, d_l1h;   // d_l1h: split-fp16 fragments of last_conv_layers.1
     float l2_bias = 0.f;
+    // block-scaled split-fp16 path: per-layer weight exponents (fragments hold w * 2^k), the bias image whose
+    // stage-2 entries carry 2^14 * 2^k2, and max|x| per 32-sample block of the two x buffers
+    std::vector<int> k1, k2o, k2s;
+    int kw_last = 0;
+    pk_dbuf d_bias_h, ws_xe0, ws_xe1;
     // workspace
     pk_dbuf ws_mel, ws_noise, ws_wav, ws_c0, ws_cin, ws_P, ws_x0, ws_x1, ws_skip, ws_dbg;
     pk_dbuf ws_tab;   // int tables
@@ -1138,11 +1283,24 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
             const bool half = variant == 1;
             const size_t n1b = (size_t)B3_W1_BYTES / 2, n2b = (size_t)B3_W2_BYTES / 2;
             std::vector<uint16_t> W1b(n1b * c.layers), W2b(n2b * c.layers);
+            if (half) {
+                h->k1.assign(c.layers, 0);
+                h->k2o.assign(c.layers, 0);
+                h->k2s.assign(c.layers, 0);
+            }
             for (int l = 0; l < c.layers; ++l) {
                 const std::string p = "conv_layers." + std::to_string(l);
                 PK_TRY(pk_get_weight(h->params, p + ".conv", {G, R, KTAP}, wc));
                 PK_TRY(pk_get_weight(h->params, p + ".conv1x1_out", {R, G / 2, 1}, wo));
                 PK_TRY(pk_get_weight(h->params, p + ".conv1x1_skip", {SK, G / 2, 1}, ws));
+                if (half) {   // fp16 parts are taken of w * 2^k (exact), k per tensor: no subnormal parts
+                    h->k1[l] = pk_weight_scale_exp(wc.data(), wc.size());
+                    h->k2o[l] = pk_weight_scale_exp(wo.data(), wo.size());
+                    h->k2s[l] = pk_weight_scale_exp(ws.data(), ws.size());
+                    for (auto& v : wc) v = std::ldexp(v, h->k1[l]);
+                    for (auto& v : wo) v = std::ldexp(v, h->k2o[l]);
+                    for (auto& v : ws) v = std::ldexp(v, h->k2s[l]);
+                }
                 uint16_t* a1 = W1b.data() + n1b * l;
                 for (int ks = 0; ks < B3_KS1; ++ks)
                     for (int q = 0; q < 4; ++q)
@@ -1177,6 +1335,15 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         PK_TRY(pk_upload(ctx, h->d_w1, W1.data(), W1.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_w2, W2.data(), W2.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_bias, B.data(), B.size() * sizeof(float)));
+        {   // bias image of the scaled path: stage-2 accumulators start from 2^14 * 2^k2 * bias
+            std::vector<float> Bh(B);
+            for (int l = 0; l < c.layers; ++l) {
+                float* bb = Bh.data() + nb * l;
+                for (int i = 0; i < R; ++i) bb[G + i] = std::ldexp(bb[G + i], 14 + h->k2o[l]);
+                for (int i = 0; i < SK; ++i) bb[G + R + i] = std::ldexp(bb[G + R + i], 14 + h->k2s[l]);
+            }
+            PK_TRY(pk_upload(ctx, h->d_bias_h, Bh.data(), Bh.size() * sizeof(float)));
+        }
         std::vector<float> packed;
         pk_gemm_pack(Wa.data(), AUX, c.layers * G, packed);
         PK_TRY(pk_upload(ctx, h->d_waux, packed.data(), packed.size() * sizeof(float)));
@@ -1198,6 +1365,8 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         PK_TRY(pk_upload(ctx, h->d_l1, A.data(), A.size() * sizeof(float)));
         {
             std::vector<uint16_t> Ah((size_t)4 * 2 * 2 * 64 * 8);
+            h->kw_last = pk_weight_scale_exp(w1.data(), w1.size());
+            for (auto& v : w1) v = std::ldexp(v, h->kw_last);   // (w1 is not used below this block)
             for (int ks = 0; ks < 4; ++ks)
                 for (int q = 0; q < 2; ++q)
                     for (int lane = 0; lane < 64; ++lane)
@@ -1326,6 +1495,9 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     PK_TRY(h->ws_x0.reserve((size_t)R * Ttot * 4));
     PK_TRY(h->ws_x1.reserve((size_t)R * Ttot * 4));
     PK_TRY(h->ws_skip.reserve((size_t)SK * Ttot * 4));
+    const size_t n_blk = (size_t)(Ttot / XBLK) + 1;
+    PK_TRY(h->ws_xe0.reserve(n_blk * 4));
+    PK_TRY(h->ws_xe1.reserve(n_blk * 4));
     float* c0 = h->ws_c0.as<float>() + (size_t)P_LEAD * AUX;
     float* P = h->ws_P.as<float>() + (size_t)P_LEAD * ldp;
 
@@ -1336,6 +1508,9 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                   gap, R, Ttot);
         PK_LAUNCH(ctx, "pwg_zero_gaps", k_zero_gaps, grid, dim3(256), 0, h->ws_x1.as<float>(), d_tab + o_gap,
                   gap, R, Ttot);
+        // max|x| per block: 0 in the gaps, the producers of x fill the rest
+        PK_HIP(hipMemsetAsync(h->ws_xe0.p, 0, n_blk * 4, ctx->stream));
+        PK_HIP(hipMemsetAsync(h->ws_xe1.p, 0, n_blk * 4, ctx->stream));
         PK_HIP(hipMemsetAsync(h->ws_P.p, 0, (size_t)P_LEAD * ldp * 4, ctx->stream));
         PK_HIP(hipMemsetAsync(P + (size_t)sumL * ldp, 0, (size_t)(rows_alloc - sumL + P_LEAD) * ldp * 4, ctx->stream));
     }
@@ -1376,7 +1551,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     }
     // ---- first conv
     PK_LAUNCH(ctx, "pwg_first", k_pwg_first, dim3(sumL), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
-              h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>());
+              h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>());
     // ---- residual stack.  Optionally the batch is cut into chunks of whole utterances whose x ping-pong +
     // skip buffers (3 x 256 B per sample) fit the 256 MB Infinity Cache, all layers running over one chunk
     // before the next.  A pure load/store kernel with this access pattern gains from that (tools/micro/
@@ -1418,8 +1593,18 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             a.ntiles = ntile;
             a.dilation = 1 << (l % lps);
             a.dbg = h->dbg;
+            a.xe_in = (l & 1) ? h->ws_xe1.as<unsigned>() : h->ws_xe0.as<unsigned>();
+            a.xe_out = (l & 1) ? h->ws_xe0.as<unsigned>() : h->ws_xe1.as<unsigned>();
+            a.k1 = 0;
+            a.i0 = a.i1 = 1.f;
             if (h->math == PK_PWG_MATH_BF16X3 || h->math == PK_PWG_MATH_F16X3) {
                 const bool half = h->math == PK_PWG_MATH_F16X3;
+                if (half) {
+                    a.bias = h->d_bias_h.as<float>() + (size_t)l * (G + R + SK);
+                    a.k1 = h->k1[l];
+                    a.i0 = (float)std::ldexp(0.70710678118654752440, -(14 + h->k2o[l]));
+                    a.i1 = (float)std::ldexp(1.0, -(14 + h->k2s[l]));
+                }
                 a.w1 = reinterpret_cast<const float*>((half ? h->d_w1h : h->d_w1b).as<char>() + (size_t)l * B3_W1_BYTES);
                 a.w2 = reinterpret_cast<const float*>((half ? h->d_w2h : h->d_w2b).as<char>() + (size_t)l * B3_W2_BYTES);
                 const dim3 blk(LAYER_WAVES * 64);
@@ -1451,6 +1636,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         a.tile_t0 = d_tab + o_tile;
         a.Ttot = Ttot;
         a.wav = d_wav;
+        a.kw = h->kw_last;
         if (h->math == PK_PWG_MATH_F32) {
             PK_LAUNCH(ctx, "pwg_last", k_pwg_last, dim3(sumL), dim3(512), 0, a);
         } else {
@@ -1509,6 +1695,7 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_uptab, &h->d_mu, &h->d_sigma,
                        &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1h, &h->d_l1b, &h->d_l2,
+                       &h->d_bias_h, &h->ws_xe0, &h->ws_xe1,
                        &h->ws_mel, &h->ws_cin, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
                        &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab};
     for (auto* b : bufs) b->release();

@@ -160,7 +160,7 @@ struct pk_wf {
     std::vector<size_t> up_w;
     std::vector<float> up_b;
     // workspace
-    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip;
+    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip, ws_hamax, ws_camax;
     const float* W(size_t off) const { return arena.as<float>() + off; }
 };
 
@@ -432,6 +432,12 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     PK_TRY(h->ws_hist.reserve((size_t)(NL + 1) * 3 * feat_row * 4));
     PK_TRY(h->ws_zbuf.reserve((size_t)feat_row * 4));
     PK_TRY(h->ws_skip.reserve((size_t)feat_row * 4));
+    // block scaling of the split-fp16 GEMMs (pk_split.h): max|row| of every hist / cond row, kept next to the data
+    // so that a launch only scans the one row set that is new (zero = margins, gaps and rows not yet written)
+    PK_TRY(h->ws_hamax.reserve((size_t)(NL + 1) * 3 * pstride * 4));
+    PK_TRY(h->ws_camax.reserve((size_t)G * pstride * 4));
+    PK_HIP(hipMemsetAsync(h->ws_hamax.p, 0, (size_t)(NL + 1) * 3 * pstride * 4, ctx->stream));
+    PK_HIP(hipMemsetAsync(h->ws_camax.p, 0, (size_t)G * pstride * 4, ctx->stream));
     for (int i = 0; i + 1 < c.n_upsample; ++i) PK_TRY(h->ws_u[i & 1].reserve((size_t)layer_rows[i + 1] * M * 4));
     // cond gaps / margins are read by masked rows only, but must be finite
     PK_HIP(hipMemsetAsync(h->ws_cond.p, 0, (size_t)G * cond_row * 4, ctx->stream));
@@ -444,6 +450,10 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     float* zbuf = h->ws_zbuf.as<float>() + (size_t)WF_LEAD * C;
     float* skip = h->ws_skip.as<float>() + (size_t)WF_LEAD * C;
     auto hist_ptr = [&](int layer, int slot) { return hist + ((size_t)layer * 3 + slot) * feat_row; };
+    float* hamax = h->ws_hamax.as<float>() + WF_LEAD;
+    float* camax = h->ws_camax.as<float>() + WF_LEAD;
+    auto hamax_ptr = [&](int layer, int slot) { return hamax + ((size_t)layer * 3 + slot) * pstride; };
+    const bool split_math = h->math == PK_GEMM_MATH_F16X3;
 
     // ---- upsample (encoder)
     {
@@ -468,6 +478,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
             in = out;
         }
     }
+    if (split_math) PK_TRY(pk_row_amax_launch(ctx, cond, MP, MP, 0, (long)G * pstride - WF_LEAD, camax));
     // ---- fold z
     PK_LAUNCH(ctx, "wf_fold", k_wf_fold, dim3(pk_div_up(npos, 256)), dim3(256), 0, d_z, d_tab + o_putt, d_tab + o_pw,
               d_tab + o_zoff, G, npos, pstride, cur);
@@ -488,6 +499,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out), F.b_logs,
                   F.b_b, cur + (long)perm[0] * pstride, nxt, h->W(F.w_in), h->W(F.b_in), hist_ptr(0, 1), rowvalid,
                   npos, 1);
+        if (split_math) PK_TRY(pk_row_amax_launch(ctx, hist_ptr(0, 1), C, C, 0, npos, hamax_ptr(0, 1)));
         // the fused kernel needs the 64-channel shape (one 128-column block) and the split-fp16 path
         const bool fuse_proj = C == 64 && h->math == PK_GEMM_MATH_F16X3 && MP % PK_GEMM_HBK == 0 && !h->no_fuse;
         for (int i = 1; i < G; ++i) {
@@ -509,6 +521,8 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                         ++g.ntaps;
                     }
                 }
+                g.a_amax = hamax_ptr(l, 0);
+                g.a2_amax = camax + (long)cidx[i] * pstride;
                 g.A2 = cond + (long)cidx[i] * cond_row;
                 g.lda2 = MP;
                 g.Cin2 = MP;
@@ -535,6 +549,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                     g.ldc2 = C;
                     g.acc2 = l > 0;
                     PK_TRY(pk_gemm_launch(ctx, "wf_gemm_conv_gate_proj", g));
+                    if (l + 1 < NL) PK_TRY(pk_row_amax_launch(ctx, hist_ptr(l + 1, slot), C, C, 0, npos, hamax_ptr(l + 1, slot)));
                     continue;
                 }
                 g.epi = PK_EPI_GATE;
@@ -563,11 +578,14 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 o.M = npos;
                 o.N = 2 * C;
                 PK_TRY(pk_gemm_launch(ctx, "wf_gemm_out_proj", o));
+                if (split_math && l + 1 < NL)
+                    PK_TRY(pk_row_amax_launch(ctx, hist_ptr(l + 1, slot), C, C, 0, npos, hamax_ptr(l + 1, slot)));
             }
             float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
             PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out),
                       F.b_logs, F.b_b, cur + (long)perm[i] * pstride, nxt + (long)i * pstride, h->W(F.w_in),
                       h->W(F.b_in), h0n, rowvalid, npos, 0);
+            if (split_math && h0n) PK_TRY(pk_row_amax_launch(ctx, h0n, C, C, 0, npos, hamax_ptr(0, (i + 1) % 3)));
         }
         std::swap(cur, nxt);
     }
@@ -585,7 +603,8 @@ extern "C" void pk_wf_destroy(pk_wf* h) {
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
-                       &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip};
+                       &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip,
+                       &h->ws_hamax, &h->ws_camax};
     for (auto* b : bufs) b->release();
     delete h;
 }

@@ -103,6 +103,89 @@ def test_pwg_default_math_is_fp32_equivalent():
     assert errs["f16x3"] < 2.0 * errs["f32"] + 2e-7, errs
 
 
+def _rescaled_state(state, cfg, kx, ks):
+    """An equivalent generator whose residual stream is 2^kx times and whose skip sums are 2^ks times larger:
+    first_conv and every conv1x1_out scaled by 2^kx with every dilated conv's weight by 2^-kx, every conv1x1_skip
+    by 2^ks with last_conv_layers.1.weight by 2^-ks (ReLU commutes with a positive factor).  Powers of two: in
+    exact fp32 arithmetic the waveform is bit-identical to the original's."""
+    out = {k: np.array(v, dtype=np.float32, copy=True) for k, v in state.items()}
+    fx, fs = np.float32(2.0 ** kx), np.float32(2.0 ** ks)
+    out["first_conv.weight"] *= fx
+    out["first_conv.bias"] *= fx
+    for i in range(cfg["layers"]):
+        p = f"conv_layers.{i}."
+        out[p + "conv1x1_out.weight"] *= fx
+        out[p + "conv1x1_out.bias"] *= fx
+        out[p + "conv.weight"] /= fx
+        out[p + "conv1x1_skip.weight"] *= fs
+        out[p + "conv1x1_skip.bias"] *= fs
+    out["last_conv_layers.1.weight"] /= fs
+    return out
+
+
+@pytest.mark.parametrize("kx,ks", [(-10, 6), (6, -10), (-20, 12), (-30, -30), (12, 10)])
+def test_pwg_split_math_is_scale_invariant(kx, ks):
+    """the split-fp16 products must not depend on the magnitude of weights or activations.
+    A generator whose internal streams are rescaled by powers of two (compensated downstream) has to give the
+    waveform of the original, at the exact-fp32 path's error against the fp64 oracle."""
+    from oracle import pwg_ref
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    cfg = dict(syn.PWG_LJSPEECH)
+    state = {k: np.asarray(v) for k, v in syn.pwg_state(cfg, seed=21).items()}
+    rng = np.random.default_rng(4)
+    mel = rng.normal(size=(12, 80)).astype(np.float32)
+    noise = rng.normal(size=(12 * 256,)).astype(np.float32)
+    ref = pwg_ref.generator_inference(state, torch.from_numpy(mel), torch.from_numpy(noise),
+                                      dtype=torch.float64)[:, 0].numpy()
+    gen = PWGGenerator(**cfg)
+    gen.set_state_dict(_rescaled_state(state, cfg, kx, ks))
+    gen.eval()
+    errs = {}
+    for mode in ("f32", "f16x3"):
+        gen.set_math(mode)
+        errs[mode] = _rel_err(gen.inference(mel, noise=noise).numpy()[:, 0], ref)
+    assert errs["f32"] < 2e-6, errs
+    assert errs["f16x3"] < 2.0 * errs["f32"] + 2e-7, errs
+    # and against the unscaled generator on the same path: the block scaling makes the split exact under
+    # power-of-two rescaling (only parts below 2^-39 of their block maximum can differ)
+    base = PWGGenerator(**cfg)
+    base.set_state_dict(state)
+    base.eval()
+    base.set_math("f16x3")
+    w0 = base.inference(mel, noise=noise).numpy()[:, 0]
+    gen.set_math("f16x3")
+    w1 = gen.inference(mel, noise=noise).numpy()[:, 0]
+    assert _rel_err(w1, w0) < 1e-6
+
+
+def test_pwg_split_math_lognormal_weights():
+    """Trained weights are not U(-1/sqrt(K), 1/sqrt(K)): element magnitudes spread over several decades."""
+    from oracle import pwg_ref
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    cfg = dict(syn.PWG_LJSPEECH)
+    state = {k: np.array(v, dtype=np.float32, copy=True) for k, v in syn.pwg_state(cfg, seed=22).items()}
+    rng = np.random.default_rng(5)
+    for k in state:
+        if k.endswith(".weight") and state[k].ndim == 3 and "upsample" not in k:
+            f = np.exp(rng.normal(scale=1.0, size=state[k].shape))          # sigma = 1: ~ 2.5 decades
+            w = state[k] * f
+            state[k] = (w * (np.abs(state[k]).sum() / np.abs(w).sum())).astype(np.float32)   # same L1 mass
+    mel = rng.normal(size=(10, 80)).astype(np.float32)
+    noise = rng.normal(size=(10 * 256,)).astype(np.float32)
+    ref = pwg_ref.generator_inference(state, torch.from_numpy(mel), torch.from_numpy(noise),
+                                      dtype=torch.float64)[:, 0].numpy()
+    gen = PWGGenerator(**cfg)
+    gen.set_state_dict(state)
+    gen.eval()
+    errs = {}
+    for mode in ("f32", "f16x3"):
+        gen.set_math(mode)
+        errs[mode] = _rel_err(gen.inference(mel, noise=noise).numpy()[:, 0], ref)
+    # such a generator amplifies rounding noise (saturating gates), so the bar is the exact-fp32 path's own error
+    assert errs["f32"] < 1e-4, errs
+    assert errs["f16x3"] < 2.0 * errs["f32"] + 2e-7, errs
+
+
 def test_pwg_weight_norm_pairs():
     # weight_g / weight_v state dicts (use_weight_norm=True checkpoints) are folded by the engine
     _run_case(dict(layers=4, stacks=2), [6, 4], seed=3, weight_norm=True, check_taps=False)
