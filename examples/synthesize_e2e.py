@@ -2,9 +2,12 @@
 """FastSpeech2 + Parallel WaveGAN synthesis from released checkpoints on the MI355X engine -- the counterpart
 of the reference's examples/fastspeech2/ljspeech/synthesize_e2e.py with the same arguments, minus Paddle.
 
-The reference turns sentences into phones with ``parakeet.frontend.English`` (g2p_en + nltk), which this
-image does not have; ``--text`` therefore holds *phone* sequences, one ``utt_id PH1 PH2 ...`` per line
-(what ``frontend.phoneticize`` returns, :90-99; unknown phones and punctuation map to "sp" exactly as there).
+``--text`` holds one ``utt_id sentence`` per line as in the reference (:45-50).  Sentences go through
+``parakeet_amd.frontend.English`` -- the reference's ``parakeet.frontend.English`` with its g2p_en backend replaced
+by a lexicon-driven one (``--lexicon``: a CMUdict-format file; words it lacks fall back to letter-to-sound rules
+and are listed on stderr) -- and the recipe's id mapping (start / end symbols dropped, unknown phones and
+punctuation -> "sp", :88-97).  With ``--phones-input`` the lines hold phone sequences instead
+(``utt_id PH1 PH2 ...``, what ``frontend.phoneticize`` returns).
 All utterances are synthesised as ONE ragged batch (the reference loops one by one, :88-107).
 """
 import argparse
@@ -16,9 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from parakeet_amd import checkpoint  # noqa: E402
 from parakeet_amd.audio import write_wav  # noqa: E402
+from parakeet_amd.frontend import English, phones_to_ids  # noqa: E402
+from parakeet_amd.frontend.phone_map import RECIPE_PUNC as PUNC  # noqa: E402  (synthesize_e2e.py:67)
 from parakeet_amd.synthesize import Synthesizer  # noqa: E402
-
-PUNC = "：，；。？！“”‘’':,;.?!"   # synthesize_e2e.py:66
 
 
 def main():
@@ -30,7 +33,10 @@ def main():
     ap.add_argument("--pwg-checkpoint", required=True)
     ap.add_argument("--pwg-stat", required=True)
     ap.add_argument("--phones-dict", default="phone_id_map.txt")
-    ap.add_argument("--text", required=True, help="'utt_id PH1 PH2 ...' per line")
+    ap.add_argument("--text", required=True, help="'utt_id sentence' per line")
+    ap.add_argument("--lexicon", default=None, help="CMUdict-format pronunciation lexicon for the English frontend "
+                                                    "(default: the small demonstration lexicon of the package)")
+    ap.add_argument("--phones-input", action="store_true", help="--text holds 'utt_id PH1 PH2 ...' lines")
     ap.add_argument("--output-dir", required=True)
     ap.add_argument("--seed", type=int, default=0, help="seed of the engine's noise stream")
     args = ap.parse_args()
@@ -41,15 +47,21 @@ def main():
     voc.pwg_generator.set_seed(args.seed)
     fs = checkpoint._config(args.fastspeech2_config)["fs"]
 
+    frontend = None if args.phones_input else English(lexicon=args.lexicon)
     utt_ids, batch = [], []
     with open(args.text, "rt") as f:
         for line in f:
             parts = line.strip().split()
             if not parts:
                 continue
-            phones = [p if (p in phone_id_map and p not in PUNC) else "sp" for p in parts[1:]]   # :94-98
+            if frontend is None:
+                ids = phones_to_ids(parts[1:], phone_id_map, PUNC, strip_start_end=False)
+            else:
+                ids = phones_to_ids(frontend.phoneticize(" ".join(parts[1:])), phone_id_map, PUNC)   # :89-97
+                if frontend.backend.oov:
+                    print(f"{parts[0]}: not in the lexicon, pronounced by rule: {frontend.backend.oov}", file=sys.stderr)
             utt_ids.append(parts[0])
-            batch.append([phone_id_map[p] for p in phones])
+            batch.append([int(i) for i in ids])
     os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.perf_counter()
     wavs = Synthesizer(am, voc).synthesize_batch(batch)

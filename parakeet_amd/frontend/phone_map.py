@@ -1,0 +1,42 @@
+"""From frontend phones to the ids a trained FastSpeech2 expects
+(examples/fastspeech2/ljspeech/synthesize_e2e.py:53-56,66-67,88-97).
+
+The acoustic model's vocabulary is the ``phone_id_map.txt`` written at preprocessing time (one ``phone id`` pair per
+line, parakeet/datasets/preprocess_utils.py:92-103); the recipe drops the start / end symbols, drops whitespace
+tokens, and maps everything the map does not know -- and every punctuation mark -- to the pause phone ``sp``.
+"""
+import numpy as np
+
+__all__ = ["RECIPE_PUNC", "read_phone_id_map", "phones_to_ids", "text_to_ids"]
+
+RECIPE_PUNC = "：，；。？！“”‘’':,;.?!"     # synthesize_e2e.py:67
+
+
+def read_phone_id_map(path):
+    """``phone id`` per line -> dict, ids as int (synthesize_e2e.py:53-56)."""
+    table = {}
+    with open(path, encoding="utf-8") as f:
+        for line in f:
+            fields = line.split()
+            if not fields:
+                continue
+            if len(fields) != 2:
+                raise ValueError(f"{path}: expected 'phone id', got {line!r}")
+            table[fields[0]] = int(fields[1])
+    return table
+
+
+def phones_to_ids(phones, phone_id_map, punc=RECIPE_PUNC, strip_start_end=True):
+    """The loop body of synthesize_e2e.py:88-97 on an already phoneticized sentence."""
+    if strip_start_end:
+        phones = phones[1:-1]                   # remove start_symbol and end_symbol (:90-91)
+    phones = [p for p in phones if not p.isspace()]
+    if "sp" not in phone_id_map and any((p not in phone_id_map or p in punc) for p in phones):
+        raise KeyError("phone_id_map has no 'sp' entry to map unknown phones and punctuation to")
+    phones = [p if (p in phone_id_map and p not in punc) else "sp" for p in phones]
+    return np.asarray([phone_id_map[p] for p in phones], dtype=np.int64)
+
+
+def text_to_ids(frontend, sentence, phone_id_map, punc=RECIPE_PUNC):
+    """``frontend.phoneticize`` + the recipe's mapping: raw text -> int64 ids for ``FastSpeech2.inference``."""
+    return phones_to_ids(frontend.phoneticize(sentence), phone_id_map, punc)
