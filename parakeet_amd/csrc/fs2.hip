@@ -29,6 +29,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int FS2_MAX_HEADS = 16;   // (q|k|v, head) magnitude-bound constants are passed to a kernel by value
 
 namespace {
 
@@ -311,6 +312,46 @@ __device__ __forceinline__ AtScales at_scales(const AttnArgs& a, int b, int h, i
     s.co = pow2f(-kv);
     return s;
 }
+// Magnitude bounds instead of passes over the activations (see Dense): from the row maxima ham[] that k_layernorm
+// leaves for its output h,
+//   per (utterance, head): |q|, |k|, |v| <= max_r ham[r] * c1 + c0   -> the attention kernels' block maxima
+//   per row: |ctx[r, :]| <= max_head bound_v (a convex combination of the utterance's value rows)
+struct QkvBoundC {
+    float c1[3 * FS2_MAX_HEADS], c0[3 * FS2_MAX_HEADS];
+};
+__global__ __launch_bounds__(256) void k_fs2_seg_bounds(const float* __restrict__ ham, const int* __restrict__ seg_start,
+                                                        const int* __restrict__ seg_len, int heads, QkvBoundC c,
+                                                        unsigned* __restrict__ segb, float* __restrict__ ctx_bound) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int start = seg_start[b], len = seg_len[b];
+    float m = 0.f;
+    for (int r = threadIdx.x; r < len; r += 256) m = fmaxf(m, ham[start + r]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float vb = 0.f;
+    for (int hd = 0; hd < heads; ++hd) vb = fmaxf(vb, fmaf(m, c.c1[2 * FS2_MAX_HEADS + hd], c.c0[2 * FS2_MAX_HEADS + hd]));
+    if (threadIdx.x < 3 * heads) {
+        const int part = threadIdx.x / heads, hd = threadIdx.x % heads;
+        segb[((long)b * heads + hd) * 3 + part] =
+            __float_as_uint(fmaf(m, c.c1[part * FS2_MAX_HEADS + hd], c.c0[part * FS2_MAX_HEADS + hd]));
+    }
+    for (int r = threadIdx.x; r < len; r += 256) ctx_bound[start + r] = vb;
+}
+// per row: |relu(conv(h) + b)[r, :]| <= max_tap ham[r + tap] * c1 + c0 (gap rows: 0)
+__global__ __launch_bounds__(256) void k_fs2_row_bounds(const float* __restrict__ ham, const int* __restrict__ row_utt,
+                                                        int rows, int pad, float c1, float c0,
+                                                        float* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float m = 0.f;
+    for (int t = -pad; t <= pad; ++t) m = fmaxf(m, ham[r + t]);
+    out[r] = row_utt[r] >= 0 ? fmaf(m, c1, c0) : 0.f;
+}
+
 __device__ __forceinline__ f32x16 at_mfma3(at_f16x8 ah, at_f16x8 al, at_f16x8 bh, at_f16x8 bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
@@ -443,7 +484,10 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
     constexpr int NT = ATT_THREADS;
     constexpr int KG = (32 * (DK / 8) + NT - 1) / NT;      // 8-float groups of the K tile per thread (3 for DK = 192)
     constexpr int VG = (2 * DT * 64 + NT - 1) / NT;        // V fragment lanes per thread (3 for DK = 192)
-    __shared__ __attribute__((aligned(16))) at_f16x8 Kf[KS * 2 * 64];
+    // 65 slots per 64-lane fragment block: neighbouring loader threads write different k-steps of the same key, i.e.
+    // blocks 2 KB apart -- the same banks without the pad (PMC r01: 48 % of this kernel's LDS cycles were conflicts)
+    constexpr int KP = 65;
+    __shared__ __attribute__((aligned(16))) at_f16x8 Kf[KS * 2 * KP];
     __shared__ __attribute__((aligned(16))) at_f16x8 Vf[2 * DT * 2 * 64];
     const int b = blockIdx.z, h = blockIdx.y;
     const int len = a.seg_len[b], start = a.seg_start[b];
@@ -505,8 +549,8 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
             at_f16x8 fh, fl_;
             at_split8s(kreg[g], sc.sk, fh, fl_);
             const int ks = grp >> 1, fl = key + 32 * (grp & 1);
-            Kf[(ks * 2 + 0) * 64 + fl] = fh;
-            Kf[(ks * 2 + 1) * 64 + fl] = fl_;
+            Kf[(ks * 2 + 0) * KP + fl] = fh;
+            Kf[(ks * 2 + 1) * KP + fl] = fl_;
         }
 #pragma unroll
         for (int g = 0; g < VG; ++g) {
@@ -531,7 +575,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            S = at_mfma3(Kf[(ks * 2 + 0) * 64 + lane], Kf[(ks * 2 + 1) * 64 + lane], qh[ks], ql[ks], S);
+            S = at_mfma3(Kf[(ks * 2 + 0) * KP + lane], Kf[(ks * 2 + 1) * KP + lane], qh[ks], ql[ks], S);
         float mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -735,11 +779,17 @@ struct Dense {
     size_t w = 0, b = 0;   // offsets (floats) into the weight arena; b == SIZE_MAX: no bias
     size_t wh = (size_t)-1;   // offset (halves) of the split-fp16 fragments, SIZE_MAX if Cin % 32 != 0
     int Cin = 0, N = 0, taps = 1, pad = 0;
+    // |y[r, n]| <= c1 * max|x[r + tap, :]| + c0 with c1 = max_n sum_k |W[k, n]|, c0 = max_n |bias[n]|: an upper
+    // bound on the magnitude of this layer's output rows, used as the block maximum of the NEXT split-fp16 GEMM's
+    // operand scale (pk_split.h) so that no pass over the activations is needed.  A bound that is loose by 2^k
+    // only moves the scheme's error floor from 2^-39 to 2^(k-39) of the block maximum (fp32 itself: 2^-24).
+    float c1 = 0.f, c0 = 0.f;
 };
 
 struct FftLayer {
     size_t ln1_g, ln1_b, ln2_g, ln2_b;
     Dense qkv, out, ffn1, ffn2;
+    float qkv_c1[3 * FS2_MAX_HEADS] = {0}, qkv_c0[3 * FS2_MAX_HEADS] = {0};   // the same bound per (q|k|v, head)
 };
 
 struct Predictor {
@@ -798,7 +848,8 @@ struct pk_fs2 {
     pk_dbuf d_pe, d_div;
     // per-call state
     Timeline tl_tok, tl_frm;
-    pk_dbuf d_lnamax;
+    pk_dbuf d_lnamax, d_cbnd, d_fbnd, d_segb;
+    bool no_bounds = getenv("PK_FS2_NO_BOUNDS") != nullptr;   // measurement switch: block maxima by passes over the data
     pk_dbuf d_tok, d_x, d_h, d_qkv, d_ctx, d_f, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
         d_before, d_q1, d_q2, d_rowmap, d_dbg_up, d_zs, d_mel_stage;
     std::vector<int> frames;   // per utterance, result of encode
@@ -937,6 +988,20 @@ struct Arena {
     }
 };
 
+// c1 = max over columns [n0, n1) of sum_k |W[k, n]|, c0 = max |bias[n]| (see Dense)
+static void dense_bound(const std::vector<float>& kn, const std::vector<float>* bias, int K, int N, int n0, int n1,
+                        float& c1, float& c0) {
+    double m1 = 0.0, m0 = 0.0;
+    for (int n = n0; n < n1; ++n) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += std::fabs((double)kn[(size_t)k * N + n]);
+        m1 = std::max(m1, s);
+        if (bias) m0 = std::max(m0, std::fabs((double)(*bias)[n]));
+    }
+    c1 = (float)(m1 * (1.0 + 1e-6));
+    c0 = (float)(m0 * (1.0 + 1e-6));
+}
+
 int add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<float>* bias, int Cin, int taps,
                  int N, Dense& d) {
     std::vector<float> packed;
@@ -952,6 +1017,7 @@ int add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<floa
     d.N = N;
     d.taps = taps;
     d.pad = (taps - 1) / 2;
+    dense_bound(kn, bias, Cin * taps, N, 0, N, d.c1, d.c0);
     return PK_OK;
 }
 
@@ -972,7 +1038,7 @@ int add_vec(Arena& ar, const pk_param_map& P, const std::string& name, int n, si
 }
 
 int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int units,
-                  int k, int ff_type, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b) {
+                  int k, int ff_type, int heads, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b) {
     out.resize(n_layers);
     for (int l = 0; l < n_layers; ++l) {
         const std::string p = prefix + ".encoders." + std::to_string(l);
@@ -1001,6 +1067,10 @@ int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, i
             bias[2 * A + o] = bv[o];
         }
         PK_TRY(add_dense_kn(ar, kn, &bias, A, 1, 3 * A, L.qkv));
+        for (int part = 0; part < 3; ++part)
+            for (int hd = 0; hd < heads && hd < FS2_MAX_HEADS; ++hd)
+                dense_bound(kn, &bias, A, 3 * A, part * A + hd * (A / heads), part * A + (hd + 1) * (A / heads),
+                            L.qkv_c1[part * FS2_MAX_HEADS + hd], L.qkv_c0[part * FS2_MAX_HEADS + hd]);
         std::vector<float> wo, bo;
         PK_TRY(pk_get_weight(P, p + ".self_attn.linear_out", {A, A}, wo));
         PK_TRY(pk_get_vector(P, p + ".self_attn.linear_out.bias", A, bo));
@@ -1094,9 +1164,9 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
         h->alpha_enc = h->alpha_dec = 1.f;
         h->xscale = std::sqrt((float)A);  // PositionalEncoding.forward embedding.py:78
     }
-    PK_TRY(add_fft_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, h->enc,
+    PK_TRY(add_fft_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->enc,
                          h->enc_after_g, h->enc_after_b));
-    PK_TRY(add_fft_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, h->dec,
+    PK_TRY(add_fft_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->dec,
                          h->dec_after_g, h->dec_after_b));
     PK_TRY(add_predictor(ar, P, "duration_predictor", c.duration_predictor_layers, A, c.duration_predictor_chans,
                          c.duration_predictor_kernel_size, h->dur));
@@ -1225,7 +1295,8 @@ static int run_layernorm(pk_fs2* h, const float* x, size_t g, size_t b, const Ti
     return PK_OK;
 }
 
-static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float* out) {
+static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float* out,
+                         const unsigned* seg_bounds = nullptr) {
     const int A = h->cfg.adim, heads = h->cfg.aheads, dk = A / heads;
     int maxlen = 0;
     for (int l : tl.seg_len) maxlen = std::max(maxlen, l);
@@ -1238,8 +1309,8 @@ static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float*
     a.seg_len = tl.d_seg_len();
     a.D = A;
     a.scale = (float)(1.0 / std::sqrt((double)dk));
-    a.amax = nullptr;
-    if (h->math == PK_GEMM_MATH_F16X3) {   // block maxima of Q, K, V per (utterance, head) for the operand scales
+    a.amax = seg_bounds;   // bounds on |q|, |k|, |v| per (utterance, head) from k_fs2_seg_bounds, when the caller has them
+    if (h->math == PK_GEMM_MATH_F16X3 && !seg_bounds) {   // else: the block maxima themselves, one pass over qkv
         pk_ctx_scratch* sc = pk_ctx_get_scratch(h->ctx);
         const size_t nb = (size_t)tl.B * heads * 3 * sizeof(unsigned);
         PK_TRY(sc->attn_amax.reserve(nb));
@@ -1296,20 +1367,45 @@ static int run_fft_stack(pk_fs2* h, const std::vector<FftLayer>& layers, size_t 
     const int* rv = tl.d_row_utt();
     // row maxima of the LayerNorm outputs, left by k_layernorm for the split-fp16 GEMMs that read them (rows outside
     // the timeline: zero)
-    float* ham = nullptr;
+    // ... and magnitude bounds derived from them for the tensors in between (see Dense): no pass over qkv, the
+    // attention output or the FFN hidden activations is needed for the operand scales
+    float *ham = nullptr, *cbnd = nullptr, *fbnd = nullptr;
+    unsigned* segb = nullptr;
+    const int heads = h->cfg.aheads;
+    const bool bounds = h->math == PK_GEMM_MATH_F16X3 && heads <= FS2_MAX_HEADS && !h->no_bounds;
     if (h->math == PK_GEMM_MATH_F16X3) {
         PK_TRY(act_reserve(h->d_lnamax, tl.rows, 1));
         PK_HIP(hipMemsetAsync(h->d_lnamax.p, 0, h->d_lnamax.cap, h->ctx->stream));
         ham = act_ptr(h->d_lnamax, 1);
     }
+    if (bounds) {
+        PK_TRY(act_reserve(h->d_cbnd, tl.rows, 1));
+        PK_TRY(act_reserve(h->d_fbnd, tl.rows, 1));
+        PK_TRY(h->d_segb.reserve((size_t)tl.B * heads * 3 * sizeof(unsigned)));
+        PK_HIP(hipMemsetAsync(h->d_cbnd.p, 0, h->d_cbnd.cap, h->ctx->stream));
+        PK_HIP(hipMemsetAsync(h->d_fbnd.p, 0, h->d_fbnd.cap, h->ctx->stream));
+        cbnd = act_ptr(h->d_cbnd, 1);
+        fbnd = act_ptr(h->d_fbnd, 1);
+        segb = h->d_segb.as<unsigned>();
+    }
     for (const FftLayer& L : layers) {
         PK_TRY(run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh, ham));
         PK_TRY(run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, ham));
-        PK_TRY(run_attention(h, tl, qkv, ctxb));
-        PK_TRY(run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
+        if (bounds) {
+            QkvBoundC qc;
+            memcpy(qc.c1, L.qkv_c1, sizeof(qc.c1));
+            memcpy(qc.c0, L.qkv_c0, sizeof(qc.c0));
+            PK_LAUNCH(h->ctx, "fs2_bounds", k_fs2_seg_bounds, dim3(tl.B), dim3(256), 0, ham, tl.d_seg_start(),
+                      tl.d_seg_len(), heads, qc, segb, cbnd);
+        }
+        PK_TRY(run_attention(h, tl, qkv, ctxb, segb));
+        PK_TRY(run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, cbnd));
         PK_TRY(run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh, ham));
         PK_TRY(run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv, ham));
-        PK_TRY(run_dense(h, "fs2_conv_ffn2", L.ffn2, f, units, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
+        if (bounds)
+            PK_LAUNCH(h->ctx, "fs2_bounds", k_fs2_row_bounds, dim3(pk_div_up(tl.rows, 256)), dim3(256), 0, ham, rv,
+                      tl.rows, L.ffn1.pad, L.ffn1.c1, L.ffn1.c0, fbnd);
+        PK_TRY(run_dense(h, "fs2_conv_ffn2", L.ffn2, f, units, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, fbnd));
     }
     PK_TRY(run_layernorm(h, x, after_g, after_b, tl, A, hs_out));
     return PK_OK;
@@ -1622,7 +1718,7 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     if (!h) return;
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_lnamax, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
+    pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_lnamax, &h->d_cbnd, &h->d_fbnd, &h->d_segb, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
                        &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
                        &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
     for (auto* b : bufs) b->release();

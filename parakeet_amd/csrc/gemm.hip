@@ -260,26 +260,29 @@ __device__ __forceinline__ void gemm_split8(const float (&v)[8], f16x8& hi, f16x
     }
 }
 
-// max|A[r, 0..C)| for rows r0 <= r < r1 of a row-major matrix: one wave per row (amax is indexed like A: row r ->
-// amax[r], rows before the base are valid memory on both)
+// max|A[r, 0..C)| for rows r0 <= r < r1 of a row-major matrix (amax is indexed like A: row r -> amax[r], rows
+// before the base are valid memory on both).  LPR lanes share a row (16 for C <= 64, 32 for C <= 128, else 64), so
+// narrow matrices keep all lanes busy: a wave covers 64 / LPR rows with 16-byte loads.
 __global__ __launch_bounds__(256) void k_row_amax(const float* __restrict__ A, long lda, int C, long r0, long r1,
-                                                  float* __restrict__ amax) {
-    const long r = r0 + (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= r1) return;
+                                                  float* __restrict__ amax, int lpr) {
     const int lane = threadIdx.x & 63;
-    const float* row = A + r * lda;
+    const int rpw = 64 / lpr;                       // rows per wave
+    const int sub = lane & (lpr - 1);
+    const long r = r0 + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr;
     float m = 0.f;
-    if ((C & 3) == 0 && (lda & 3) == 0) {
-        for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (r < r1) {
+        const float* row = A + r * lda;
+        if ((C & 3) == 0 && (lda & 3) == 0) {
+            for (int c = sub * 4; c < C; c += lpr * 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
+        } else {
+            for (int c = sub; c < C; c += lpr) m = fmaxf(m, fabsf(row[c]));
         }
-    } else {
-        for (int c = lane; c < C; c += 64) m = fmaxf(m, fabsf(row[c]));
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) amax[r] = m;
+    for (int o = lpr >> 1; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (sub == 0 && r < r1) amax[r] = m;
 }
 
 // split of 2^k * x (x scaled exactly, then as gemm_split8)
@@ -631,7 +634,9 @@ void pk_gemm_gate_permute_bias(const float* b, int Cz, std::vector<float>& out) 
 
 int pk_row_amax_launch(pk_ctx* ctx, const float* A, long lda, int C, long r0, long r1, float* amax) {
     if (r1 <= r0) return PK_OK;
-    PK_LAUNCH(ctx, "row_amax", k_row_amax, dim3(pk_div_up(r1 - r0, 4)), dim3(256), 0, A, lda, C, r0, r1, amax);
+    const int lpr = C <= 64 ? 16 : (C <= 128 ? 32 : 64);
+    PK_LAUNCH(ctx, "row_amax", k_row_amax, dim3(pk_div_up(r1 - r0, 4 * (64 / lpr))), dim3(256), 0, A, lda, C, r0, r1,
+              amax, lpr);
     return PK_OK;
 }
 

@@ -180,14 +180,22 @@ __device__ __forceinline__ float gated(float a, float b) {
 // that the producer of x (k_pwg_first / the previous layer's epilogue) leaves in xe[]; z = tanh * sigmoid with the
 // fixed 2^14, folded into the gate's last multiply.  tests/test_pwg_gpu.py::test_pwg_split_math_is_scale_invariant
 constexpr float PK_Z_SCALE = PK_UNIT_SCALE;
+// max over the 64 lanes of a wave, returned wave-uniform.  DPP only (no LDS-pipe round trips as with ds_bpermute):
+// quad swaps, two rotations inside the 16-lane row (max is idempotent, so after them every lane holds its row's
+// maximum), then row_bcast15 / row_bcast31 carry the running maximum into rows 1, 3 and 2, 3: row 3 holds the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float v) {
+    const int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(v, __int_as_float(t));
+}
 __device__ __forceinline__ float wave_max64(float v) {
-    v = fmaxf(v, __shfl_xor(v, 32));
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 8));
-    v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 2));
-    v = fmaxf(v, __shfl_xor(v, 1));
-    return v;
+    v = dpp_max_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_max_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_max_step<0x124, 0xf>(v);   // row_ror:4
+    v = dpp_max_step<0x128, 0xf>(v);   // row_ror:8
+    v = dpp_max_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // 2^14 * tanh(a / S) * sigmoid(b / S) from accumulators that hold S * (pre-activation): cb = -log2(e) / S, the
 // clamp of gated() moves behind the multiply (|2 a log2 e| <= 20 log2 e).  Same instruction count as gated().
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             if constexpr (HALF) {
                 if (pass == 0) {   // max|x_out| of this 64 x 32 block for the next layer's operand scale
                     am = wave_max64(am);
-                    if (lane == 0 && (!ABL || a.Ttot < 0)) a.xe_out[vo4 >> 11] = __float_as_uint(am);
+                    if (lane == 0 && (!ABL || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
                 }
             }
         }
@@ -1669,6 +1677,15 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
                   h->ws_dbg.as<float>());
         PK_HIP(hipStreamSynchronize(ctx->stream));
         PK_HIP(hipMemcpy(host_out, h->ws_dbg.p, (size_t)G * S * 4, hipMemcpyDeviceToHost));
+        return PK_OK;
+    }
+    if (what == 3) {
+        // max|x| per 32-sample block of the final residual stream, as the last layer's epilogue left it for a next
+        // layer's operand scale (block-scaled split-fp16 path only)
+        if (n_floats != S / XBLK) PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats", S / XBLK);
+        const pk_dbuf& xe = h->last_x_final ? h->ws_xe1 : h->ws_xe0;
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+        PK_HIP(hipMemcpy(host_out, xe.as<float>() + h->last_toff[b] / XBLK, (size_t)(S / XBLK) * 4, hipMemcpyDeviceToHost));
         return PK_OK;
     }
     const float* src;

@@ -186,10 +186,13 @@ class PWGGenerator:
         return self.inference_batch([c], None if noise is None else [noise], normalize=normalize)[0]
 
     def debug_tap(self, what, b):
-        rows = {0: 128, 1: 64, 2: 64}[what]
         # frames of utterance b are known to the engine; size is validated there
         n = self._last_frames[b] * self.upsample_factor
-        out = np.empty((rows, n), dtype=np.float32)
+        if what == 3:       # max|x| per 32-sample block of the final residual stream (block-scaled split path)
+            out = np.empty((n // 32,), dtype=np.float32)
+        else:
+            rows = {0: 128, 1: 64, 2: 64}[what]
+            out = np.empty((rows, n), dtype=np.float32)
         _capi.check(self._ctx.lib.pk_pwg_debug_read(self._h, what, b, _capi.fptr(out), out.size))
         return out
 

@@ -158,6 +158,26 @@ def test_pwg_split_math_is_scale_invariant(kx, ks):
     assert _rel_err(w1, w0) < 1e-6
 
 
+def test_pwg_block_maxima_are_exact():
+    """The operand scale of a layer comes from max|x| per 32-sample block, written by the previous layer's epilogue
+    (a DPP wave reduction): it has to be the maximum of exactly the values that were stored."""
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    cfg = dict(syn.PWG_LJSPEECH, layers=6, stacks=3)
+    gen = PWGGenerator(**cfg)
+    gen.set_state_dict(syn.pwg_state(cfg, seed=31))
+    gen.eval()
+    gen.set_math("f16x3")
+    rng = np.random.default_rng(6)
+    frames = [5, 2, 9]
+    mels = [rng.normal(size=(L, 80)).astype(np.float32) for L in frames]
+    noises = [(rng.normal(size=(L * 256,)) * 10.0 ** rng.uniform(-3, 2)).astype(np.float32) for L in frames]
+    gen.inference_batch(mels, noises)
+    for b, L in enumerate(frames):
+        x = gen.debug_tap(1, b)                                   # (64, S) final residual stream
+        want = np.abs(x).reshape(64, -1, 32).max(axis=(0, 2))
+        np.testing.assert_array_equal(gen.debug_tap(3, b), want)
+
+
 def test_pwg_split_math_lognormal_weights():
     """Trained weights are not U(-1/sqrt(K), 1/sqrt(K)): element magnitudes spread over several decades."""
     from oracle import pwg_ref
