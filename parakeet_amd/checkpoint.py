@@ -12,13 +12,26 @@ The reference stores checkpoints with ``paddle.save``:
 * ``*_stats.npy`` -- ``np.stack([mean_, scale_])`` float32 (2, n_mels) (utils/compute_statistics.py:101-107);
 * ``phone_id_map.txt`` -- one ``<phone> <id>`` pair per line (synthesize_e2e.py:45-50).
 
-``paddle.save`` is a pickle stream in which every tensor has been replaced by plain numpy data: either the
-``ndarray`` itself (Paddle 2.0 state dicts, which also carry a ``"StructuredToParameterName@@"`` name table)
-or the tuple ``(tensor_name, ndarray)`` produced by its reducer (Paddle >= 2.1).  [paddle-format,
-unverified against a real file: Paddle is not installable here -- the layouts are written down from the
-Paddle 2.0/2.1 sources and the tests build archives in both forms.]  Because a pickle can execute code,
-the reader below is a *restricted* unpickler: it reconstructs numpy arrays, numpy scalars/dtypes and
-built-in containers, and refuses every other global.
+``paddle.save`` (python/paddle/framework/io.py of Paddle 2.1.x, the version the reference pins: README.md:50)
+writes a pickle stream, default protocol 2, through one of two paths:
+
+* ``save`` -> ``_is_state_dict(obj)`` true (a bare ``layer.state_dict()``: every value a tensor) ->
+  ``_legacy_save``: ``_build_saved_state_dict`` turns every tensor into its ``ndarray`` and adds the table
+  ``"StructuredToParameterName@@": {structured key: parameter name}``; ``_unpack_saved_dict`` (protocols 2 and 3)
+  cuts arrays of more than (2^30 - 1) / itemsize elements into flat slices ``"<key>@@.<i>"`` described by
+  ``"UnpackBigParamInfor@@": {key: {"OriginShape": shape, "slices": [names]}}``; then ``pickle.dump``.
+* anything else (the updaters' nested archive: ``epoch`` / ``iteration`` are ints) -> ``_pickle_save``: a
+  ``pickle.Pickler`` whose ``dispatch_table`` reduces ``VarBase`` / ``ParamBase`` to
+  ``(tuple, ((tensor.name, tensor.numpy()),))`` and ``LoDTensor`` to ``(eval, ('data', {'data': ndarray}))``.
+
+So a tensor arrives as the ``ndarray`` itself, as the pair ``(tensor_name, ndarray)``, or -- for the rare
+``LoDTensor`` leaves of an optimizer state -- through ``eval('data', {'data': ndarray})``.  ``load_archive`` undoes
+all of it (``_pack_loaded_dict`` re-merges the big-parameter slices).  [paddle-format: Paddle is not installable
+here, so no file written by Paddle itself has been read; ``tools/make_paddle_fixture.py`` re-implements the two
+save paths above around a stand-in tensor class, with the real ``pickle`` / ``numpy`` machinery, and the committed
+fixtures under ``tests/golden/paddle21_*`` are its output.]  Because a pickle can execute code, the reader is a
+*restricted* unpickler: it reconstructs numpy arrays, numpy scalars / dtypes and built-in containers, maps ``eval``
+to a stub that accepts exactly the call above, and refuses every other global.
 """
 import io
 import os
@@ -43,14 +56,31 @@ _ALLOWED_GLOBALS = {
 }
 
 
+def _lodtensor_eval(expr, env=None, *rest):
+    """Stand-in for the ``eval`` that Paddle's LoDTensor reducer pickles: only ``eval('data', {'data': x})``."""
+    if expr != "data" or rest or not isinstance(env, dict) or set(env) != {"data"} or not isinstance(env["data"], np.ndarray):
+        raise pickle.UnpicklingError("checkpoint calls eval() with something other than Paddle's LoDTensor reducer")
+    return env["data"]
+
+
+_ALLOWED_GLOBALS[("builtins", "eval")] = _lodtensor_eval
+_ALLOWED_GLOBALS[("__builtin__", "eval")] = _lodtensor_eval
+
+
 def _numpy_global(module, name):
     # numpy moved numpy.core -> numpy._core in 2.x; archives written by either spell the same objects
+    import importlib
     if module in ("numpy.core.multiarray", "numpy._core.multiarray") and name in ("_reconstruct", "scalar"):
-        import numpy._core.multiarray as ma   # numpy 2.x (this image)
-        return getattr(ma, name)
-    if module in ("numpy.core.numeric", "numpy._core.numeric") and name == "_frombuffer":
-        import numpy._core.numeric as nn
-        return getattr(nn, name)
+        sub = "multiarray"
+    elif module in ("numpy.core.numeric", "numpy._core.numeric") and name == "_frombuffer":
+        sub = "numeric"
+    else:
+        return None
+    for pkg in ("numpy._core.", "numpy.core."):     # numpy 2.x (this image), then numpy 1.x
+        try:
+            return getattr(importlib.import_module(pkg + sub), name)
+        except (ImportError, AttributeError):
+            continue
     return None
 
 
@@ -66,13 +96,32 @@ class _RestrictedUnpickler(pickle.Unpickler):
         return obj
 
 
+def _pack_loaded_dict(obj):
+    """Undo ``_unpack_saved_dict``: ``"<key>@@.<i>"`` slices + ``"UnpackBigParamInfor@@"`` -> the original array."""
+    info = obj.get("UnpackBigParamInfor@@")
+    if not isinstance(info, dict):
+        return obj
+    out = OrderedDict(obj)
+    for key, desc in info.items():
+        try:
+            parts = [np.asarray(_plain(out[name])).reshape(-1) for name in desc["slices"]]
+            out[key] = np.concatenate(parts).reshape(tuple(desc["OriginShape"]))
+        except (KeyError, TypeError, ValueError) as e:
+            raise ValueError(f"archive: cannot re-assemble the sliced parameter {key!r}: {e}") from None
+        for name in desc["slices"]:
+            out.pop(name, None)
+    return out
+
+
 def _plain(obj):
-    """Tensor leaves -> ndarray: accepts ndarray, (name, ndarray) pairs; drops Paddle's name tables."""
+    """Tensor leaves -> ndarray: accepts ndarray, (name, ndarray) pairs; re-merges sliced big parameters and drops
+    Paddle's bookkeeping tables."""
     if isinstance(obj, np.ndarray):
         return obj
     if isinstance(obj, (tuple, list)) and len(obj) == 2 and isinstance(obj[0], str) and isinstance(obj[1], np.ndarray):
         return obj[1]
     if isinstance(obj, dict):
+        obj = _pack_loaded_dict(obj)
         return OrderedDict((k, _plain(v)) for k, v in obj.items() if k not in _NAME_TABLE_KEYS)
     if isinstance(obj, (list, tuple)):
         return type(obj)(_plain(v) for v in obj)

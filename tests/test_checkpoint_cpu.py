@@ -87,3 +87,64 @@ def test_recipe_configs_parse():
     assert cfg["n_mels"] == 80 and cfg["model"]["adim"] == 384 and cfg["model"]["pitch_embed_kernel_size"] == 1
     cfg = ck._config(os.path.join(here, "fixtures", "pwg_ljspeech.yaml"))
     assert cfg["generator_params"]["upsample_scales"] == [4, 4, 4, 4]
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _expected():
+    with np.load(os.path.join(GOLD, "paddle21_expected.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_fixture_updater_archive_in_paddle21_layout():
+    """tests/golden/paddle21_updater.pdz (tools/make_paddle_fixture.py): protocol 2, tensors through the
+    dispatch-table reducer ((tuple, ((name, ndarray),))), one LoDTensor leaf through eval -- the layout
+    paddle.save 2.1 gives StandardUpdater.state_dict (parakeet/training/updaters/standard_updater.py:183-190)."""
+    path = os.path.join(GOLD, "paddle21_updater.pdz")
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"\x80\x02" and b"__builtin__\ntuple" in raw and b"__builtin__\neval" in raw
+    want = _expected()
+    got = ck.load_params(path, "main_params")
+    assert list(got) == list(want)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k])
+    arch = ck.load_archive(path)
+    assert arch["epoch"] == 1 and arch["iteration"] == 7
+    opt = arch["main_optimizer"]
+    assert opt["LR_Scheduler"] == {"last_epoch": 7, "last_lr": 0.001}
+    np.testing.assert_allclose(opt["param_0_beta1_pow_acc_0"], [0.9 ** 7], rtol=1e-6)     # the eval-reduced leaf
+    np.testing.assert_array_equal(opt["param_0_moment1_0"], want["encoder.embed.0.weight"] * np.float32(0.1))
+
+
+@pytest.mark.parametrize("name", ["paddle21_state.pdparams", "paddle21_state_sliced.pdparams"])
+def test_fixture_state_dict_in_paddle21_layout(name):
+    """_legacy_save layout: bare ndarrays + StructuredToParameterName@@; the sliced variant also carries
+    UnpackBigParamInfor@@ and '<key>@@.<i>' pieces that have to be re-merged."""
+    path = os.path.join(GOLD, name)
+    with open(path, "rb") as f:
+        raw = pickle.load(f)                         # the fixture holds nothing but numpy data and containers
+    assert "StructuredToParameterName@@" in raw
+    assert ("UnpackBigParamInfor@@" in raw) == ("sliced" in name)
+    want = _expected()
+    got = ck.load_params(path)
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k].shape == want[k].shape
+        np.testing.assert_array_equal(got[k], want[k])
+
+
+def test_eval_stub_only_accepts_the_lodtensor_reducer():
+    class Sneaky:
+        def __reduce__(self):
+            return (eval, ("__import__('os').getcwd()",))
+
+    with pytest.raises(pickle.UnpicklingError):
+        ck.load_archive(io.BytesIO(pickle.dumps({"x": Sneaky()}, protocol=2)))
+
+
+def test_broken_slice_table_is_reported():
+    bad = {"w@@.0": np.zeros(3, np.float32),
+           "UnpackBigParamInfor@@": {"w": {"OriginShape": (2, 3), "slices": ["w@@.0", "w@@.1"]}}}
+    with pytest.raises(ValueError):
+        ck.load_archive(io.BytesIO(pickle.dumps(bad, protocol=2)))
