@@ -75,12 +75,12 @@ __host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r
 // ---------------------------------------------------------------- small kernels
 
 // Zero the GAP regions of a [rows][Ttot] buffer.  gap_start[g], g in [0, n_gaps).
-__global__ void k_zero_gaps(float* buf, const int* gap_start, int gap, int rows, long Ttot) {
+__global__ void k_zero_gaps(float* buf, const int* gap_start, const int* gap_len, int rows, long Ttot) {
     int g = blockIdx.y;
     int row = blockIdx.z;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     (void)Ttot;
-    if (i < gap && row < rows) buf[xoff((long)gap_start[g] + i) + row * XBLK] = 0.f;
+    if (i < gap_len[g] && row < rows) buf[xoff((long)gap_start[g] + i) + row * XBLK] = 0.f;
 }
 
 // conv_in, step 1: ZScore-normalise (PWGInference :773) and lay the mel frames out as a padded row timeline
@@ -102,19 +102,77 @@ __global__ void k_pwg_convin_prep(const float* __restrict__ mel, const float* __
     out[(long)r * AUX + c] = v;
 }
 
+// ---------------------------------------------------------------- hop sizes other than 256 (GEN kernels)
+// The kernels schedule 256-sample tiles of 8 wave tiles.  With hop = prod(upsample_scales) = 256 (LJSpeech) a tile
+// IS a frame: utterances are whole numbers of tiles and the frame / phase of a sample are tile index / offset.
+// For any other hop (baker, vctk: 300) a tile is a 256-sample chunk of its utterance: the last chunk is partly
+// valid (samples at or beyond S_b = frames * hop are stored as zeros, so they stay the zero padding the reference's
+// convolutions see), a 32-sample wave tile can straddle two frames (hop >= 32), and frame, phase and edge class are
+// computed per lane from the tables below.
+struct PwgGen {
+    const int* tile_s0;    // [tiles] sample offset of the tile inside its utterance
+    const int* tile_utt;   // [tiles] utterance of the tile
+    const int* utt_S;      // [B] samples
+    const int* utt_F;      // [B] frames
+    const int* utt_row0;   // [B] row of the utterance's frame 0 in the frame-rate projection P
+    const int* utt_off;    // [B] offset of the utterance in the packed noise / wav buffers
+    const float* P0;       // P + this layer's column block, row 0 = frame 0 of utterance 0
+    int hop;
+    float inv_hop;
+};
+struct PwgGenCoord {
+    int fa;       // frame of the wave tile's first (clamped) sample: P rows fa-2 .. fa+3 are staged
+    int df;       // this lane's frame - fa (0 or 1)
+    int cls;      // edge class of this lane's frame
+    int phase;    // sample - frame * hop
+    int row0;
+    bool valid;   // sample < S_b
+};
+__device__ __forceinline__ int gen_div_hop(int s, int hop, float inv_hop) {   // floor(s / hop), 0 <= s < 2^24
+    int q = (int)((float)s * inv_hop);
+    const int r = s - q * hop;
+    q += r < 0 ? -1 : (r >= hop ? 1 : 0);
+    return q;
+}
+__device__ __forceinline__ PwgGenCoord gen_coord(const PwgGen& g, int tile, int sub, int j) {
+    const int b = g.tile_utt[tile];
+    const int S = g.utt_S[b], F = g.utt_F[b];
+    const int s0 = g.tile_s0[tile] + sub * WAVE_T;
+    PwgGenCoord c;
+    c.valid = s0 + j < S;
+    const int sc = min(s0 + j, S - 1), s0c = min(s0, S - 1);
+    const int f = gen_div_hop(sc, g.hop, g.inv_hop);
+    c.fa = gen_div_hop(s0c, g.hop, g.inv_hop);
+    c.df = f - c.fa;
+    c.phase = sc - f * g.hop;
+    c.cls = min(f, 2) * 3 + min(F - 1 - f, 2);
+    c.row0 = g.utt_row0[b];
+    return c;
+}
+
 // first_conv: Conv1D(1 -> R, k=1, bias) (:401-402,464) from packed noise into the timeline.
+template <bool GEN>
 __global__ void k_pwg_first(const float* __restrict__ noise, const float* __restrict__ w,
                             const float* __restrict__ bias, const int* __restrict__ tile_t0, long Ttot,
-                            float* __restrict__ x, unsigned* __restrict__ xe) {
+                            float* __restrict__ x, unsigned* __restrict__ xe, PwgGen g) {
     const int tile = blockIdx.x;
     const long t = (long)tile_t0[tile] + threadIdx.x;
-    const float n = noise[(long)tile * TILE + threadIdx.x];
+    float n;
+    bool valid = true;
+    if constexpr (GEN) {
+        const int b = g.tile_utt[tile];
+        const int sidx = g.tile_s0[tile] + (int)threadIdx.x;
+        valid = sidx < g.utt_S[b];
+        n = valid ? noise[(long)g.utt_off[b] + sidx] : 0.f;
+    } else {
+        n = noise[(long)tile * TILE + threadIdx.x];
+    }
     (void)Ttot;
     const long xo = xoff(t);
     float am = 0.f;
 #pragma unroll 8
     for (int c = 0; c < R; ++c) {
-        const float v = fmaf(w[c], n, bias[c]);
+        const float v = valid ? fmaf(w[c], n, bias[c]) : 0.f;
         am = fmaxf(am, fabsf(v));
         x[xo + c * XBLK] = v;
     }
@@ -129,16 +187,17 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
 
 // Test tap: the sample-rate aux contribution of one layer, aux[co][s] =
 // sum_j T[class][phase][j] * P[frame + j - 2][layer*G + co], written channel-major for one utterance.
+// (frame-indexed: row0 = P row of the utterance's frame 0, n_frames frames, hop threads per block)
 __global__ void k_pwg_aux_debug(const float* __restrict__ P, int ldp, int col0, const float* __restrict__ uptab,
-                                const int* __restrict__ tile_cls, int tile0, int n_tiles, float* __restrict__ out) {
-    const int tl = blockIdx.x;  // tile within the utterance
+                                int row0, int n_frames, int hop, float* __restrict__ out) {
+    const int f = blockIdx.x;   // frame within the utterance
     const int co = blockIdx.y;
     const int phase = threadIdx.x;
-    const int tile = tile0 + tl;
-    const float* w = uptab + ((long)tile_cls[tile] * TILE + phase) * UPW_PAD;
+    const int cls = min(f, 2) * 3 + min(n_frames - 1 - f, 2);
+    const float* w = uptab + ((long)cls * hop + phase) * UPW_PAD;
     float acc = 0.f;
-    for (int jj = 0; jj < UPW; ++jj) acc = fmaf(w[jj], P[(long)(tile + jj - 2) * ldp + col0 + co], acc);
-    out[(long)co * n_tiles * TILE + (long)tl * TILE + phase] = acc;
+    for (int jj = 0; jj < UPW; ++jj) acc = fmaf(w[jj], P[(long)(row0 + f + jj - 2) * ldp + col0 + co], acc);
+    out[(long)co * n_frames * hop + (long)f * hop + phase] = acc;
 }
 
 // ---------------------------------------------------------------- residual block
@@ -163,6 +222,7 @@ struct PwgLayerArgs {
     unsigned* xe_out;        // the same for xout, written by this launch
     int k1;                  // W1 fragments hold conv.weight * 2^k1
     float i0, i1;            // sqrt(0.5) / (2^14 * 2^k2out), 1 / (2^14 * 2^k2skip): undo the stage-2 scales
+    PwgGen gen;              // GEN kernels only (hop != 256)
 };
 
 // tanh(a) * sigmoid(b) (:309-310).  exp via v_exp_f32; |a| clamped where tanh is +-1 in fp32.
@@ -210,8 +270,10 @@ constexpr int LDS_W1 = KS1 * 64 * 4;          // 24576 floats
 constexpr int LDS_W2 = KS2 * 64 * 4;          //  8192
 constexpr int LDS_BIAS = G + R + SK;          //   256
 constexpr int LDS_PW = UPW * G;               //   640 per wave
+constexpr int LDS_PW_GEN = (UPW + 1) * G;     //   768 per wave: one more row when a wave tile straddles two frames (GEN)
 constexpr int LAYER_WAVES = 8;                // waves per workgroup (2 per SIMD; 12 = 3 per SIMD spills at 168 VGPRs and measured slower)
-constexpr int LDS_TOTAL = LDS_W1 + LDS_W2 + LDS_BIAS + LAYER_WAVES * LDS_PW;   // 40704 floats = 162 816 B
+constexpr int LDS_TOTAL = LDS_W1 + LDS_W2 + LDS_BIAS + LAYER_WAVES * LDS_PW;   // 38144 floats = 152 576 B
+constexpr int LDS_TOTAL_GEN = LDS_W1 + LDS_W2 + LDS_BIAS + LAYER_WAVES * LDS_PW_GEN;   // 39168 floats = 156 672 B
 
 // One residual block for every tile of the batch.  Persistent workgroups of 8
 // waves (2 per SIMD, no barrier after the weight load: the two waves of a SIMD
@@ -223,9 +285,9 @@ constexpr int LDS_TOTAL = LDS_W1 + LDS_W2 + LDS_BIAS + LAYER_WAVES * LDS_PW;   /
 //   stage 2  acc2[4] (out 0-31, out 32-63, skip 0-31, skip 32-63) += W2 (A, LDS) x z (B)
 // The K order of stage 2 is permuted on the host so that accumulator register r of
 // stage 1 IS the B operand of k-step r of stage 2 (no data movement between the GEMMs).
-template <bool FIRST>
+template <bool FIRST, bool GEN = false>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer(PwgLayerArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL];
+    __shared__ __attribute__((aligned(16))) float lds[GEN ? LDS_TOTAL_GEN : LDS_TOTAL];
     float* lds_bias = lds + LDS_W1 + LDS_W2;
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.w1);
@@ -244,7 +306,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int hi = lane >> 5;
     const int d = a.dilation;
     const f32x4* lds_a = reinterpret_cast<const f32x4*>(lds) + lane;
-    float* lds_p = lds + LDS_W1 + LDS_W2 + LDS_BIAS + wave * LDS_PW;  // wave-private staging
+    float* lds_p = lds + LDS_W1 + LDS_W2 + LDS_BIAS + wave * (GEN ? LDS_PW_GEN : LDS_PW);  // wave-private staging
 
     // Work unit = one wave-tile of 32 samples (8 per frame); waves are independent, so a workgroup
     // is just LAYER_WAVES of them sharing the LDS-resident weights.  Order: workgroup b is dispatched
@@ -274,16 +336,29 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     f32x4 preg[3];
     float uw[UPW];
     float bA[GRP], bB[GRP];
+    int df_n = 0;          // GEN: this lane's frame minus the first staged frame (0 / 1) of the tile being prefetched
+    bool valid_n = true;   // GEN: the lane's sample lies inside its utterance
     auto prefetch_head = [&](int wt) {
         const int tile = wt >> 3, phase = (wt & 7) * WAVE_T + j;
-        const float* prow = a.P + (long)(tile - 2) * a.ldp;
+        const float* prow;
+        long wsel;   // row of the upsampler table: edge class * hop + phase
+        if constexpr (GEN) {
+            const PwgGenCoord gc = gen_coord(a.gen, tile, wt & 7, j);
+            prow = a.gen.P0 + (long)(gc.row0 + gc.fa - 2) * a.ldp;
+            wsel = (long)gc.cls * a.gen.hop + gc.phase;
+            df_n = gc.df;
+            valid_n = gc.valid;
+        } else {
+            prow = a.P + (long)(tile - 2) * a.ldp;
+        }
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = lane + 64 * it;
             const int jj = idx >> 5, c4 = idx & 31;
-            if (idx < UPW * (G / 4)) preg[it] = *reinterpret_cast<const f32x4*>(prow + (long)jj * a.ldp + 4 * c4);
+            if (idx < (UPW + (GEN ? 1 : 0)) * (G / 4)) preg[it] = *reinterpret_cast<const f32x4*>(prow + (long)jj * a.ldp + 4 * c4);
         }
-        const float* wrow = a.uptab + ((long)a.tile_cls[tile] * TILE + phase) * UPW_PAD;
+        if constexpr (!GEN) wsel = (long)a.tile_cls[tile] * TILE + phase;
+        const float* wrow = a.uptab + wsel * UPW_PAD;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
         uw[0] = w0[0]; uw[1] = w0[1]; uw[2] = w0[2]; uw[3] = w0[3];
         uw[4] = wrow[4];
@@ -316,8 +391,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = lane + 64 * it;
-            if (idx < UPW * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
+            if (idx < (UPW + (GEN ? 1 : 0)) * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
         }
+        const bool lane_valid = valid_n;                 // of THIS tile (prefetch_head(next) overwrites valid_n)
+        const float* lds_pl = lds_p + (GEN ? df_n * G : 0);   // GEN: lanes in the tile's second frame read one row on
         // accumulators start from conv bias + upsampled aux projection
         f32x16 acc[4];
 #pragma unroll
@@ -328,7 +405,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 f32x4 v = *reinterpret_cast<const f32x4*>(lds_bias + co0);
 #pragma unroll
                 for (int jj = 0; jj < UPW; ++jj) {
-                    const f32x4 pv = *reinterpret_cast<const f32x4*>(lds_p + jj * G + co0);
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(lds_pl + jj * G + co0);
                     v[0] = fmaf(uw[jj], pv[0], v[0]);
                     v[1] = fmaf(uw[jj], pv[1], v[1]);
                     v[2] = fmaf(uw[jj], pv[2], v[2]);
@@ -459,6 +536,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     float v;
                     if (pass == 0) v = (acc2[q][r] + old[16 * q + r]) * rs;       // res = (out + x_in) * sqrt(0.5) (:314)
                     else v = FIRST ? acc2[q][r] : (old[16 * q + r] + acc2[q][r]);  // skips += skip (:468)
+                    if (GEN && pass == 0 && !lane_valid) v = 0.f;   // beyond the utterance: stays zero padding
                     (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
         }
@@ -537,11 +615,11 @@ __device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& h
 // 22 bits per operand ~ fp32's 24) of block-scaled operands (see "block scaling" above: no subnormal parts, no
 // dependence on the magnitude of weights or activations; |x| beyond 2^113 aside).
 // ABL (profiling only, PK_PWG_ABLATE=1): 1 = no global loads / stores of x and skip (compute-only time)
-template <bool FIRST, bool HALF, int ABL = 0>
+template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
     typedef typename Split16<HALF>::vec bf16x8;     // shadows the bf16 typedef inside this kernel
     typedef typename Split16<HALF>::elem elem16;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_TOTAL];
+    __shared__ __attribute__((aligned(16))) float lds[GEN ? LDS_TOTAL_GEN : LDS_TOTAL];
     float* lds_bias = lds + LDS_W1 + LDS_W2;
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.w1);
@@ -561,7 +639,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int d = a.dilation;
     const bf16x8* lds_a = reinterpret_cast<const bf16x8*>(lds) + lane;            // + ((ks*2+part)*4+q)*64
     const bf16x8* lds_a2 = reinterpret_cast<const bf16x8*>(lds + LDS_W1) + lane;
-    float* lds_p = lds + LDS_W1 + LDS_W2 + LDS_BIAS + wave * LDS_PW;
+    float* lds_p = lds + LDS_W1 + LDS_W2 + LDS_BIAS + wave * (GEN ? LDS_PW_GEN : LDS_PW);
 
     const int per_xcd = gridDim.x >> 3;
     const int wg_slot = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)
@@ -612,16 +690,29 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     bf16x8 ph, pl;     // split operands of the k-step about to run (produced one step ahead, under the MFMAs)
     f32x4 preg[3];
     float uw[UPW];
+    int df_n = 0;          // GEN: this lane's frame minus the first staged frame (0 / 1) of the tile being prefetched
+    bool valid_n = true;   // GEN: the lane's sample lies inside its utterance
     auto prefetch_head = [&](int wt) {
         const int tile = wt >> 3, phase = (wt & 7) * WAVE_T + j;
-        const float* prow = a.P + (long)(tile - 2) * a.ldp;
+        const float* prow;
+        long wsel;   // row of the upsampler table: edge class * hop + phase
+        if constexpr (GEN) {
+            const PwgGenCoord gc = gen_coord(a.gen, tile, wt & 7, j);
+            prow = a.gen.P0 + (long)(gc.row0 + gc.fa - 2) * a.ldp;
+            wsel = (long)gc.cls * a.gen.hop + gc.phase;
+            df_n = gc.df;
+            valid_n = gc.valid;
+        } else {
+            prow = a.P + (long)(tile - 2) * a.ldp;
+        }
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = lane + 64 * it;
             const int jj = idx >> 5, c4 = idx & 31;
-            if (idx < UPW * (G / 4)) preg[it] = *reinterpret_cast<const f32x4*>(prow + (long)jj * a.ldp + 4 * c4);
+            if (idx < (UPW + (GEN ? 1 : 0)) * (G / 4)) preg[it] = *reinterpret_cast<const f32x4*>(prow + (long)jj * a.ldp + 4 * c4);
         }
-        const float* wrow = a.uptab + ((long)a.tile_cls[tile] * TILE + phase) * UPW_PAD;
+        if constexpr (!GEN) wsel = (long)a.tile_cls[tile] * TILE + phase;
+        const float* wrow = a.uptab + wsel * UPW_PAD;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
         uw[0] = w0[0]; uw[1] = w0[1]; uw[2] = w0[2]; uw[3] = w0[3];
         uw[4] = wrow[4];
@@ -659,8 +750,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = lane + 64 * it;
-            if (idx < UPW * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
+            if (idx < (UPW + (GEN ? 1 : 0)) * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
         }
+        const bool lane_valid = valid_n;                 // of THIS tile (prefetch_head(next) overwrites valid_n)
+        const float* lds_pl = lds_p + (GEN ? df_n * G : 0);   // GEN: lanes in the tile's second frame read one row on
         // HALF: the stage-1 accumulators hold S1 * (pre-activation), S1 = 2^(kx + k1) = x scale * W1 scale
         unsigned ev_next = 0;
         float sx = 1.f, gca = 0.f, gcb = 0.f;
@@ -686,7 +779,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 if constexpr (HALF) v *= S1b;
 #pragma unroll
                 for (int jj = 0; jj < UPW; ++jj) {
-                    const f32x4 pv = *reinterpret_cast<const f32x4*>(lds_p + jj * G + co0);
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(lds_pl + jj * G + co0);
                     v[0] = fmaf(uw[jj], pv[0], v[0]);
                     v[1] = fmaf(uw[jj], pv[1], v[1]);
                     v[2] = fmaf(uw[jj], pv[2], v[2]);
@@ -851,10 +944,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     if constexpr (HALF) {   // acc2 = 2^14 * 2^k2 * (W2 z + b); i0 carries the sqrt(0.5) of :314
                         if (pass == 0) v = fmaf(acc2[q][r], a.i0, x_old[16 * q + r] * rs);
                         else v = FIRST ? acc2[q][r] * a.i1 : fmaf(acc2[q][r], a.i1, sk_old[16 * q + r]);
+                        if (GEN && pass == 0 && !lane_valid) v = 0.f;   // beyond the utterance: stays zero padding
                         if (pass == 0) am = fmaxf(am, fabsf(v));
                     } else {
                         if (pass == 0) v = (acc2[q][r] + x_old[16 * q + r]) * rs;
                         else v = FIRST ? acc2[q][r] : (sk_old[16 * q + r] + acc2[q][r]);
+                        if (GEN && pass == 0 && !lane_valid) v = 0.f;
                     }
                     if (!ABL || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
@@ -882,8 +977,23 @@ struct PwgLastArgs {
     long Ttot;
     float* wav;          // packed (ntiles*TILE)
     int kw;              // k_pwg_last_h3: the W fragments hold last_conv_layers.1.weight * 2^kw
+    PwgGen gen;          // GEN kernels only (hop != 256): wav is packed per utterance, S_b samples each
 };
+// packed output index of sample (tile, offset) and whether it belongs to the utterance
+template <bool GEN>
+__device__ __forceinline__ long last_out_index(const PwgLastArgs& a, int tile, int off, bool& valid) {
+    if constexpr (GEN) {
+        const int b = a.gen.tile_utt[tile];
+        const int sidx = a.gen.tile_s0[tile] + off;
+        valid = sidx < a.gen.utt_S[b];
+        return (long)a.gen.utt_off[b] + sidx;
+    } else {
+        valid = true;
+        return (long)tile * TILE + off;
+    }
+}
 
+template <bool GEN>
 __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -912,13 +1022,16 @@ __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
         for (int r = 0; r < 16; ++r)
             part = fmaf(a.w2[32 * q + mfma_row(r, hi)], fmaxf(acc[q][r], 0.f), part);
     part += __shfl_xor(part, 32);
-    if (hi == 0) a.wav[(long)tile * TILE + wave * WAVE_T + j] = part + a.b2;
+    bool valid;
+    const long oi = last_out_index<GEN>(a, tile, wave * WAVE_T + j, valid);
+    if (hi == 0 && valid) a.wav[oi] = part + a.b2;
 }
 
 // Split-fp16 variant (default math): the 64 -> 64 conv as 3-term split-fp16 MFMA sums (24 x 32-cycle MFMAs
 // per wave instead of 64 x 64-cycle ones), all 32 skip values of a lane requested before the first MFMA,
 // W fragments ([ks 4][part 2][co-tile 2][lane][8 halves] = 16 KB) staged in LDS once per workgroup.  The
 // operand channel of element e of k-step ks is 32*(ks>>1) + mfma_row(8*(ks&1) + e, hi), as in the layer kernel.
+template <bool GEN>
 __global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
     __shared__ __attribute__((aligned(16))) f16x8 wl[4 * 2 * 2 * 64];
     {
@@ -945,12 +1058,14 @@ __global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
         for (int r = 0; r < 16; ++r) acc[q][r] = a.b1[32 * q + mfma_row(r, hi)];
     __syncthreads();
     // block scaling: the wave has its whole 64 x 32 operand in registers, so the block maximum is formed here
+    bool lane_valid;
+    const long out_idx = last_out_index<GEN>(a, tile, wave * WAVE_T + j, lane_valid);
     float am = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            sv[ks][e] = fmaxf(sv[ks][e] * a.scale, 0.f);   // ReLU(skips * sqrt(1/layers)) (:469-471)
+            sv[ks][e] = lane_valid ? fmaxf(sv[ks][e] * a.scale, 0.f) : 0.f;   // ReLU(skips * sqrt(1/layers)) (:469-471)
             am = fmaxf(am, sv[ks][e]);
         }
     am = wave_max64(am);
@@ -980,7 +1095,7 @@ __global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
         for (int r = 0; r < 16; ++r)
             part = fmaf(a.w2[32 * q + mfma_row(r, hi)], fmaxf(acc[q][r], 0.f), part);   // ReLU commutes with S > 0
     part += __shfl_xor(part, 32);
-    if (hi == 0) a.wav[(long)tile * TILE + wave * WAVE_T + j] = fmaf(part, Sinv, a.b2);
+    if (hi == 0 && lane_valid) a.wav[out_idx] = fmaf(part, Sinv, a.b2);
 }
 
 }  // namespace
@@ -1047,7 +1162,10 @@ extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
         hop *= s;
         reach += (double)s / hop;
     }
-    if (hop != TILE) PK_FAIL(PK_EUNSUPPORTED, "prod(upsample_scales) must be %d (got %d)", TILE, hop);
+    // hop == 256 (LJSpeech): a work tile is a frame; any other hop >= 32 (baker / vctk: [4,5,3,5] = 300) runs the
+    // GEN kernels, which compute frame and phase per sample
+    if (hop < WAVE_T || hop > 1024)
+        PK_FAIL(PK_EUNSUPPORTED, "prod(upsample_scales) = %d: hop sizes from %d to 1024 are supported", hop, WAVE_T);
     if (reach >= 2.0) PK_FAIL(PK_EUNSUPPORTED, "upsample scales reach %.2f frames (>= 2)", reach);
     if (cfg->aux_context_window < 0 || cfg->aux_context_window > 8)
         PK_FAIL(PK_EINVAL, "aux_context_window out of range");
@@ -1226,7 +1344,8 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                                  {1, 1, 1, taps}, w));
             firs[i].assign(w.begin(), w.begin() + taps);
         }
-        std::vector<float> tab((size_t)N_EDGE_CLASS * TILE * UPW_PAD, 0.f);
+        const int hop = h->hop;   // phases per frame
+        std::vector<float> tab((size_t)N_EDGE_CLASS * hop * UPW_PAD, 0.f);
         for (int a = 0; a <= 2; ++a)
             for (int bb = 0; bb <= 2; ++bb) {
                 const int Lc = a + bb + 1, fc = a, cls = a * 3 + bb;
@@ -1235,8 +1354,8 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                     imp[fi] = 1.0;
                     std::vector<double> y = upsample_sim(imp, c, firs);
                     const int jj = fi - fc + 2;  // tap index of frame fi in the window fc-2..fc+2
-                    for (int p = 0; p < TILE; ++p)
-                        tab[((size_t)cls * TILE + p) * UPW_PAD + jj] = (float)y[(size_t)fc * TILE + p];
+                    for (int p = 0; p < hop; ++p)
+                        tab[((size_t)cls * hop + p) * UPW_PAD + jj] = (float)y[(size_t)fc * hop + p];
                 }
             }
         PK_TRY(pk_upload(ctx, h->d_uptab, tab.data(), tab.size() * sizeof(float)));
@@ -1405,22 +1524,35 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     PK_DEVICE(ctx->device);
     const pk_pwg_cfg& c = h->cfg;
     const int hop = h->hop, gap = h->gap;
-    // ---- layout
-    std::vector<int> cuL(B + 1, 0), toff(B), gap_start(B + 1);
-    long t = 0;
+    // ---- layout.  Utterances start on 256-sample boundaries (work tiles are 256-sample chunks of an utterance;
+    // with hop == 256 a tile is a frame), the zeroed gap in front of each runs from the end of the previous
+    // utterance's last 32-sample block: at least `gap` samples, longer by the alignment when hop != 256.
+    const bool gen = hop != TILE;
+    std::vector<int> cuL(B + 1, 0), cuC(B + 1, 0), toff(B), gap_start(B + 1), gap_len(B + 1), utt_S(B), utt_off(B);
+    long t = 0, packed = 0;
     for (int b = 0; b < B; ++b) {
         if (frames[b] <= 0) PK_FAIL(PK_EINVAL, "pk_pwg_infer: utterance %d has %d frames", b, frames[b]);
+        const long S_b = (long)frames[b] * hop;
+        if (S_b >= (1L << 24)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: utterance %d is longer than 2^24 samples", b);
         cuL[b + 1] = cuL[b] + frames[b];
+        cuC[b + 1] = cuC[b] + (int)((S_b + TILE - 1) / TILE);
         gap_start[b] = (int)t;
-        t += gap;
+        t = (t + TILE - 1) / TILE * TILE + gap;
+        gap_len[b] = (int)(t - gap_start[b]);
         toff[b] = (int)t;
-        t += (long)frames[b] * hop;
+        utt_S[b] = (int)S_b;
+        utt_off[b] = (int)packed;
+        packed += S_b;
+        t = (t + S_b + XBLK - 1) / XBLK * XBLK;     // the last block is written whole (zeros beyond S_b)
     }
     gap_start[B] = (int)t;
-    t += gap;
+    t = (t + TILE - 1) / TILE * TILE + gap;
+    gap_len[B] = (int)(t - gap_start[B]);
     const long Ttot = t;
-    const int sumL = cuL[B];
+    const int sumL = cuL[B];          // frames
+    const int sumC = cuC[B];          // 256-sample work tiles (== sumL when hop == 256)
     const long sumS = (long)sumL * hop;
+    if (packed >= (1L << 31)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
     // kernels address with 32-bit per-lane byte offsets of up to 5 rows of the timeline
     if (Ttot * R >= (1L << 32)) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_infer: %ld samples do not fit one call", sumS);
     h->last_frames.assign(frames, frames + B);
@@ -1435,18 +1567,23 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         tab.insert(tab.end(), v.begin(), v.end());
         return o;
     };
-    push(cuL);
-    const size_t o_gap = push(gap_start);
-    std::vector<int> frame_utt(sumL), tile_t0(sumL), tile_cls(sumL);
+    const size_t o_cul = push(cuL);
+    const size_t o_gap = push(gap_start), o_gaplen = push(gap_len);
+    // per work tile: timeline offset, edge class of the frame (hop == 256), sample offset in / index of the utterance
+    std::vector<int> tile_t0(sumC), tile_cls(sumC, 0), tile_s0(sumC), tile_utt(sumC);
     for (int b = 0; b < B; ++b)
-        for (int f = 0; f < frames[b]; ++f) {
-            frame_utt[cuL[b] + f] = b;
-            tile_t0[cuL[b] + f] = toff[b] + f * hop;
-            const int before = f < 2 ? f : 2, after = (frames[b] - 1 - f) < 2 ? (frames[b] - 1 - f) : 2;
-            tile_cls[cuL[b] + f] = before * 3 + after;
+        for (int k = 0; k < cuC[b + 1] - cuC[b]; ++k) {
+            const int i = cuC[b] + k;
+            tile_t0[i] = toff[b] + k * TILE;
+            tile_s0[i] = k * TILE;
+            tile_utt[i] = b;
+            if (!gen) {
+                const int before = k < 2 ? k : 2, after = (frames[b] - 1 - k) < 2 ? (frames[b] - 1 - k) : 2;
+                tile_cls[i] = before * 3 + after;
+            }
         }
-    const size_t o_futt = push(frame_utt), o_tile = push(tile_t0), o_cls = push(tile_cls);
-    (void)o_futt;
+    const size_t o_tile = push(tile_t0), o_cls = push(tile_cls), o_ts0 = push(tile_s0), o_tutt = push(tile_utt);
+    const size_t o_uS = push(utt_S), o_uF = push(std::vector<int>(frames, frames + B)), o_uoff = push(utt_off);
     h->last_o_cls = o_cls;
     // conv_in's padded row timeline (k_pwg_convin_prep): source mel row and destination c0 row (-1: padding)
     const int cw = c.aux_context_window;
@@ -1510,12 +1647,22 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     float* P = h->ws_P.as<float>() + (size_t)P_LEAD * ldp;
 
     // ---- zero the gaps of both ping-pong buffers and the margins of P (read with zero weights)
+    PwgGen gtab;
+    gtab.tile_s0 = d_tab + o_ts0;
+    gtab.tile_utt = d_tab + o_tutt;
+    gtab.utt_S = d_tab + o_uS;
+    gtab.utt_F = d_tab + o_uF;
+    gtab.utt_row0 = d_tab + o_cul;
+    gtab.utt_off = d_tab + o_uoff;
+    gtab.P0 = nullptr;
+    gtab.hop = hop;
+    gtab.inv_hop = 1.0f / (float)hop;
     {
-        dim3 grid(pk_div_up(gap, 256), B + 1, R);
+        dim3 grid(pk_div_up(gap + TILE, 256), B + 1, R);
         PK_LAUNCH(ctx, "pwg_zero_gaps", k_zero_gaps, grid, dim3(256), 0, h->ws_x0.as<float>(), d_tab + o_gap,
-                  gap, R, Ttot);
+                  d_tab + o_gaplen, R, Ttot);
         PK_LAUNCH(ctx, "pwg_zero_gaps", k_zero_gaps, grid, dim3(256), 0, h->ws_x1.as<float>(), d_tab + o_gap,
-                  gap, R, Ttot);
+                  d_tab + o_gaplen, R, Ttot);
         // max|x| per block: 0 in the gaps, the producers of x fill the rest
         PK_HIP(hipMemsetAsync(h->ws_xe0.p, 0, n_blk * 4, ctx->stream));
         PK_HIP(hipMemsetAsync(h->ws_xe1.p, 0, n_blk * 4, ctx->stream));
@@ -1558,8 +1705,12 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         PK_TRY(pk_gemm_launch(ctx, "pwg_aux_gemm", g));
     }
     // ---- first conv
-    PK_LAUNCH(ctx, "pwg_first", k_pwg_first, dim3(sumL), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
-              h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>());
+    if (gen)
+        PK_LAUNCH(ctx, "pwg_first", k_pwg_first<true>, dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
+    else
+        PK_LAUNCH(ctx, "pwg_first", k_pwg_first<false>, dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
     // ---- residual stack.  Optionally the batch is cut into chunks of whole utterances whose x ping-pong +
     // skip buffers (3 x 256 B per sample) fit the 256 MB Infinity Cache, all layers running over one chunk
     // before the next.  A pure load/store kernel with this access pattern gains from that (tools/micro/
@@ -1583,7 +1734,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             chunk_first.push_back(B);
         }
         for (size_t ck = 0; ck + 1 < chunk_first.size(); ++ck) {
-        const int tile0 = cuL[chunk_first[ck]], ntile = cuL[chunk_first[ck + 1]] - tile0;
+        const int tile0 = cuC[chunk_first[ck]], ntile = cuC[chunk_first[ck + 1]] - tile0;
+        const int row0 = cuL[chunk_first[ck]];   // first P row of the chunk (== tile0 when hop == 256)
         for (int l = 0; l < c.layers; ++l) {
             PwgLayerArgs a;
             a.xin = (l & 1) ? h->ws_x1.as<float>() : h->ws_x0.as<float>();
@@ -1592,7 +1744,11 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             a.w1 = h->d_w1.as<float>() + (size_t)l * KS1 * 64 * 4;
             a.w2 = h->d_w2.as<float>() + (size_t)l * KS2 * 64 * 4;
             a.bias = h->d_bias.as<float>() + (size_t)l * (G + R + SK);
-            a.P = P + (size_t)l * G + (size_t)tile0 * ldp;
+            a.P = P + (size_t)l * G + (size_t)row0 * ldp;
+            a.gen = gtab;
+            a.gen.tile_s0 += tile0;
+            a.gen.tile_utt += tile0;
+            a.gen.P0 = P + (size_t)l * G;
             a.uptab = h->d_uptab.as<float>();
             a.tile_t0 = d_tab + o_tile + tile0;
             a.tile_cls = d_tab + o_cls + tile0;
@@ -1616,7 +1772,15 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 a.w1 = reinterpret_cast<const float*>((half ? h->d_w1h : h->d_w1b).as<char>() + (size_t)l * B3_W1_BYTES);
                 a.w2 = reinterpret_cast<const float*>((half ? h->d_w2h : h->d_w2b).as<char>() + (size_t)l * B3_W2_BYTES);
                 const dim3 blk(LAYER_WAVES * 64);
-                if (half) {
+                if (gen) {   // hop != 256: frame / phase per sample (GEN kernels)
+                    if (half) {
+                        if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true>), dim3(grid), blk, 0, a);
+                        else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true>), dim3(grid), blk, 0, a);
+                    } else {
+                        if (l == 0) PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<true, false, 0, true>), dim3(grid), blk, 0, a);
+                        else PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<false, false, 0, true>), dim3(grid), blk, 0, a);
+                    }
+                } else if (half) {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true>), dim3(grid), blk, 0, a);
                     else if (h->dbg == 1) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 1>), dim3(grid), blk, 0, a);
                     else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true>), dim3(grid), blk, 0, a);
@@ -1624,10 +1788,13 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<true, false>), dim3(grid), blk, 0, a);
                     else PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<false, false>), dim3(grid), blk, 0, a);
                 }
+            } else if (gen) {
+                if (l == 0) PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<true, true>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
+                else PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<false, true>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
             } else if (l == 0)
-                PK_LAUNCH(ctx, "pwg_layer", k_pwg_layer<true>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
+                PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<true, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
             else
-                PK_LAUNCH(ctx, "pwg_layer", k_pwg_layer<false>, dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
+                PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<false, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
         }
         }
         h->last_x_final = c.layers & 1;
@@ -1645,11 +1812,14 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         a.Ttot = Ttot;
         a.wav = d_wav;
         a.kw = h->kw_last;
+        a.gen = gtab;
         if (h->math == PK_PWG_MATH_F32) {
-            PK_LAUNCH(ctx, "pwg_last", k_pwg_last, dim3(sumL), dim3(512), 0, a);
+            if (gen) PK_LAUNCH(ctx, "pwg_last", k_pwg_last<true>, dim3(sumC), dim3(512), 0, a);
+            else PK_LAUNCH(ctx, "pwg_last", k_pwg_last<false>, dim3(sumC), dim3(512), 0, a);
         } else {
             a.w1 = reinterpret_cast<const float*>(h->d_l1h.as<char>());
-            PK_LAUNCH(ctx, "pwg_last_h3", k_pwg_last_h3, dim3(sumL), dim3(512), 0, a);
+            if (gen) PK_LAUNCH(ctx, "pwg_last_h3", k_pwg_last_h3<true>, dim3(sumC), dim3(512), 0, a);
+            else PK_LAUNCH(ctx, "pwg_last_h3", k_pwg_last_h3<false>, dim3(sumC), dim3(512), 0, a);
         }
     }
     if (flags & PK_HOST_IO) {
@@ -1672,9 +1842,8 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
         PK_TRY(h->ws_dbg.reserve((size_t)G * S * 4));
         const float* P = h->ws_P.as<float>() + (size_t)P_LEAD * h->last_ldp;
         dim3 grid(h->last_frames[b], G);
-        PK_LAUNCH(ctx, "pwg_aux_debug", k_pwg_aux_debug, grid, dim3(TILE), 0, P, h->last_ldp, 0,
-                  h->d_uptab.as<float>(), h->ws_tab.as<int>() + h->last_o_cls, h->last_cuL[b], h->last_frames[b],
-                  h->ws_dbg.as<float>());
+        PK_LAUNCH(ctx, "pwg_aux_debug", k_pwg_aux_debug, grid, dim3(h->hop), 0, P, h->last_ldp, 0,
+                  h->d_uptab.as<float>(), h->last_cuL[b], h->last_frames[b], h->hop, h->ws_dbg.as<float>());
         PK_HIP(hipStreamSynchronize(ctx->stream));
         PK_HIP(hipMemcpy(host_out, h->ws_dbg.p, (size_t)G * S * 4, hipMemcpyDeviceToHost));
         return PK_OK;
@@ -1682,10 +1851,11 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
     if (what == 3) {
         // max|x| per 32-sample block of the final residual stream, as the last layer's epilogue left it for a next
         // layer's operand scale (block-scaled split-fp16 path only)
-        if (n_floats != S / XBLK) PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats", S / XBLK);
+        const long nblk = (S + XBLK - 1) / XBLK;
+        if (n_floats != nblk) PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats", nblk);
         const pk_dbuf& xe = h->last_x_final ? h->ws_xe1 : h->ws_xe0;
         PK_HIP(hipStreamSynchronize(ctx->stream));
-        PK_HIP(hipMemcpy(host_out, xe.as<float>() + h->last_toff[b] / XBLK, (size_t)(S / XBLK) * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(host_out, xe.as<float>() + h->last_toff[b] / XBLK, (size_t)nblk * 4, hipMemcpyDeviceToHost));
         return PK_OK;
     }
     const float* src;
@@ -1698,11 +1868,18 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
     if (n_floats != (int64_t)rows * S)
         PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats, got %lld", rows * S, (long long)n_floats);
     PK_HIP(hipStreamSynchronize(ctx->stream));
-    // blocked layout: channel ch of this utterance = S/32 pieces of 32 floats, one per block
-    for (int ch = 0; ch < rows; ++ch)
-        PK_HIP(hipMemcpy2D(host_out + (size_t)ch * S, XBLK * sizeof(float),
-                           src + xoff(h->last_toff[b]) + (size_t)ch * XBLK, XBLK_FLOATS * sizeof(float),
-                           XBLK * sizeof(float), S / XBLK, hipMemcpyDeviceToHost));
+    // blocked layout: channel ch of this utterance = S/32 pieces of 32 floats, one per block (+ a shorter last
+    // piece when S is not a multiple of 32, hop != 256)
+    for (int ch = 0; ch < rows; ++ch) {
+        if (S / XBLK > 0)
+            PK_HIP(hipMemcpy2D(host_out + (size_t)ch * S, XBLK * sizeof(float),
+                               src + xoff(h->last_toff[b]) + (size_t)ch * XBLK, XBLK_FLOATS * sizeof(float),
+                               XBLK * sizeof(float), S / XBLK, hipMemcpyDeviceToHost));
+        if (S % XBLK)
+            PK_HIP(hipMemcpy(host_out + (size_t)ch * S + S / XBLK * XBLK,
+                             src + xoff(h->last_toff[b] + S / XBLK * XBLK) + (size_t)ch * XBLK,
+                             (size_t)(S % XBLK) * sizeof(float), hipMemcpyDeviceToHost));
+    }
     return PK_OK;
 }
 

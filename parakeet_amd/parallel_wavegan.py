@@ -189,7 +189,7 @@ class PWGGenerator:
         # frames of utterance b are known to the engine; size is validated there
         n = self._last_frames[b] * self.upsample_factor
         if what == 3:       # max|x| per 32-sample block of the final residual stream (block-scaled split path)
-            out = np.empty((n // 32,), dtype=np.float32)
+            out = np.empty(((n + 31) // 32,), dtype=np.float32)
         else:
             rows = {0: 128, 1: 64, 2: 64}[what]
             out = np.empty((rows, n), dtype=np.float32)

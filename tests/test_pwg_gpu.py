@@ -28,8 +28,9 @@ def _run_case(cfg_over, frames, seed, weight_norm=False, check_taps=True, pwg_ma
     cfg = dict(syn.PWG_LJSPEECH, **cfg_over)
     state = syn.pwg_state(cfg, seed=seed, weight_norm=weight_norm)
     rng = np.random.default_rng(seed + 1)
+    hop = int(np.prod(cfg["upsample_scales"]))
     mels = [rng.normal(size=(L, 80)).astype(np.float32) for L in frames]
-    noises = [rng.normal(size=(L * 256,)).astype(np.float32) for L in frames]
+    noises = [rng.normal(size=(L * hop,)).astype(np.float32) for L in frames]
 
     gen = PWGGenerator(**cfg)
     gen.set_state_dict(state)
@@ -79,6 +80,22 @@ def test_pwg_every_math_mode_meets_the_same_bars(mode):
     # tolerances against the fp64 oracle, internal taps included
     _run_case(dict(), [3, 17, 8], seed=2, pwg_math=mode)
     _run_case(dict(layers=6, stacks=2), [5, 1, 9, 3, 2, 4], seed=1, pwg_math=mode)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3", "bf16x3"])
+def test_pwg_hop_300_baker_and_vctk_scales(mode):
+    # upsample_scales [4, 5, 3, 5] (hop 300: the baker / vctk recipes, and the vocoder SpeedySpeech is paired with):
+    # frames are not whole numbers of 32-sample wave tiles, so a tile can straddle two frames and the last block of
+    # an utterance is partly valid -- same bars as the hop-256 cases, internal taps included
+    scales = dict(upsample_scales=[4, 5, 3, 5])
+    _run_case(dict(scales, layers=6, stacks=3), [5, 1, 9, 3, 2], seed=7, pwg_math=mode)
+    _run_case(scales, [3, 17, 8], seed=8, pwg_math=mode)
+
+
+def test_pwg_other_hops():
+    # any hop from 32 up: [2, 4, 4] = 32 (a wave tile per frame), [3, 5, 7] = 105, [8, 8, 8] = 512 (> one tile)
+    for i, sc in enumerate(([2, 4, 4], [3, 5, 7], [8, 8, 8])):
+        _run_case(dict(upsample_scales=sc, layers=4, stacks=2), [4, 1, 7], seed=40 + i)
 
 
 def test_pwg_default_math_is_fp32_equivalent():
