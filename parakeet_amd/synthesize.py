@@ -1,11 +1,13 @@
-"""End-to-end batched synthesis: FastSpeech2 -> Parallel WaveGAN on one GPU.
+"""End-to-end batched synthesis: FastSpeech2 (or SpeedySpeech) -> Parallel WaveGAN on one GPU.
 
 The device-side equivalent of the loop body of
 examples/fastspeech2/ljspeech/synthesize_e2e.py:88-102
 (``mel = fastspeech2_inference(phone_ids); wav = pwg_inference(mel)``), for a
 ragged batch and with the mel never leaving HBM.  The only host<->device
 traffic inside a call is the token ids in and B frame counts out (the output
-length is data dependent).
+length is data dependent).  With a ``SpeedySpeechInference`` as the acoustic model (``tones=`` per utterance) it is
+the loop body of examples/speedyspeech/baker/synthesize_e2e.py:113-131; that recipe's vocoder has hop 300
+(upsample_scales [4, 5, 3, 5]), which the Parallel WaveGAN kernels handle like any hop from 32 to 1024.
 """
 import numpy as np
 import torch
@@ -20,11 +22,16 @@ class Synthesizer:
         self.voc = pwg_inference.pwg_generator
         self.hop = self.voc.upsample_factor
 
-    def synthesize_packed(self, texts, alpha=1.0, noise=None, generator=None):
+    def synthesize_packed(self, texts, alpha=1.0, noise=None, generator=None, tones=None):
         """Returns (packed wav device tensor, frames per utterance)."""
         self.am_inference.bind()
         self.voc_inference.bind()
-        frames = self.am.encode_batch(texts, alpha)
+        if type(self.am).__name__ == "SpeedySpeech":
+            assert alpha == 1.0, "SpeedySpeech has no speed control (speedyspeech.py:178-218)"
+            frames = self.am.encode_batch(texts, tones)
+        else:
+            assert tones is None, "tone ids go to FastSpeech2 through encode_batch(tone_ids=...)"
+            frames = self.am.encode_batch(texts, alpha)
         if int(frames.sum()) == 0:
             return torch.empty(0, device=self.am._ctx.device), frames
         mel = self.am.decode_packed(denormalize=True)       # FastSpeech2Inference: log-mel domain
@@ -32,11 +39,11 @@ class Synthesizer:
         wav = self.voc.infer_packed(mel, frames[keep], noise=noise, generator=generator, normalize=True)
         return wav, frames
 
-    def synthesize_batch(self, texts, alpha=1.0, noises=None, generator=None):
+    def synthesize_batch(self, texts, alpha=1.0, noises=None, generator=None, tones=None):
         noise = None
         if noises is not None:
             noise = torch.cat([torch.as_tensor(np.asarray(n)).reshape(-1) for n in noises])
-        wav, frames = self.synthesize_packed(texts, alpha, noise, generator)
+        wav, frames = self.synthesize_packed(texts, alpha, noise, generator, tones)
         outs, o = [], 0
         for f in frames:
             n = int(f) * self.hop

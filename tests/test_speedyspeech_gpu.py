@@ -105,3 +105,40 @@ def test_predictor_style_pipeline_speedyspeech_pwg():
     voc.run()
     wav = voc.get_output_handle(voc.get_output_names()[0]).copy_to_cpu()
     assert wav.shape == (mel.shape[0] * 256, 1) and np.isfinite(wav).all()
+
+
+def test_speedyspeech_to_baker_pwg_end_to_end():
+    """examples/speedyspeech/baker/synthesize_e2e.py:113-131 as one ragged batch: SpeedySpeechInference (baker
+    configuration) into the baker vocoder, upsample_scales [4, 5, 3, 5] = hop 300, mel staying in HBM -- against
+    the two CPU oracles chained the same way."""
+    from oracle import pwg_ref
+    from parakeet_amd.normalizer import ZScore
+    from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference
+    from parakeet_amd.speedyspeech import SpeedySpeechInference
+    from parakeet_amd.synthesize import Synthesizer
+    m = _model(True, 5)
+    mu_a, sg_a = syn.mel_stats(seed=1)
+    mu_v, sg_v = syn.mel_stats(seed=2)
+    pcfg = dict(syn.PWG_LJSPEECH, upsample_scales=[4, 5, 3, 5])
+    pstate = syn.pwg_state(pcfg, seed=9)
+    gen = PWGGenerator(**pcfg)
+    gen.set_state_dict(pstate)
+    gen.remove_weight_norm()
+    gen.eval()
+    synth = Synthesizer(SpeedySpeechInference(ZScore(mu_a, sg_a), m), PWGInference(ZScore(mu_v, sg_v), gen))
+    rng = np.random.default_rng(2)
+    lens = [9, 4, 13]
+    phones = [rng.integers(1, 70, size=T) for T in lens]
+    tones = [rng.integers(1, 7, size=T) for T in lens]
+    mels = m.inference_batch(phones, tones, denormalize=True)          # (acoustic-model parity: the tests above)
+    frames = [int(x.shape[0]) for x in mels]
+    noises = [rng.normal(size=(L * 300,)).astype(np.float32) for L in frames]
+    wavs = synth.synthesize_batch(phones, noises=noises, tones=tones)
+    ocfg = {k: pcfg[k] for k in ("layers", "stacks", "kernel_size", "aux_context_window", "upsample_scales")}
+    for b, L in enumerate(frames):
+        assert wavs[b].shape == (L * 300, 1)
+        ref = pwg_ref.pwg_inference(pstate, mu_v, sg_v, torch.from_numpy(mels[b].numpy()), torch.from_numpy(noises[b]),
+                                    ocfg, torch.float64).numpy()
+        got = wavs[b].numpy()
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err < 1e-4, f"utt {b}: wav rel err {err}"
