@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "pk_gemm.h"
+#include "pk_wf_layer.h"
 
 namespace {
 
@@ -37,7 +38,7 @@ __global__ void k_wf_upsample(const float* __restrict__ in, const int* __restric
                               const int* __restrict__ in_len, float* __restrict__ out,
                               const int* __restrict__ out_off, const float* __restrict__ w, float bias, int f,
                               int M, int fold_G, const int* __restrict__ woff, const int* __restrict__ pruned,
-                              long cond_row_stride, int cond_ld) {
+                              long cond_row_stride, int cond_ld, int blocked) {
     const int b = blockIdx.z;
     const int Tin = in_len[b];
     const int Tout = f * Tin - f;  // (Tin-1)*f - 2*(f/2) + 2f, minus the trimmed (2f - f) columns
@@ -64,7 +65,10 @@ __global__ void k_wf_upsample(const float* __restrict__ in, const int* __restric
     if (fold_G == 0) {
         out[((long)out_off[b] + t) * M + c] = acc;
     } else if (t < pruned[b]) {
-        out[(long)(t % fold_G) * cond_row_stride + ((long)woff[b] + t / fold_G) * cond_ld + c] = acc;
+        const long pos = (long)woff[b] + t / fold_G;
+        // blocked: [pos / 32][cond_ld][32] (pk_wf_layer.h), else [pos][cond_ld]
+        const long off = blocked ? (pos >> 5) * ((long)cond_ld * 32) + (long)c * 32 + (pos & 31) : pos * cond_ld + c;
+        out[(long)(t % fold_G) * cond_row_stride + off] = acc;
     }
 }
 
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(256) void k_wf_step(const float* __restrict__ skips
 struct WfLayerW {
     size_t w1, b1, w2, b2;   // packed GEMM weights (floats offsets into the arena)
     size_t w1h, w2h;         // split-fp16 fragments (halves offsets into arena16)
+    WflPacked fl;            // the fused layer kernel's fragments (64-channel model), offsets into the same arenas
 };
 
 struct WfFlowW {
@@ -302,6 +307,9 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
             pk_gemm_pack_h3(kn2.data(), C, 2 * C, ph);
             F.layers[l].w2h = put16(h->arena16_h, ph);
             F.layers[l].b2 = ar.put(bo);
+            if (C == WFL_C && MP == WFL_MP)
+                F.layers[l].fl = wfl_pack(wc.data(), bc.data(), wp.data(), bp.data(), M, wo.data(), bo.data(),
+                                          h->arena16_h, h->arena_h);
         }
     }
     PK_TRY(pk_upload(ctx, h->arena, h->arena_h.data(), h->arena_h.size() * sizeof(float)));
@@ -434,6 +442,9 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     PK_TRY(h->ws_skip.reserve((size_t)feat_row * 4));
     // block scaling of the split-fp16 GEMMs (pk_split.h): max|row| of every hist / cond row, kept next to the data
     // so that a launch only scans the one row set that is new (zero = margins, gaps and rows not yet written)
+    // (the fused layer kernel keeps block maxima instead, one per 32 positions, in the same buffers)
+    const bool use_wfl = C == WFL_C && MP == WFL_MP && h->math == PK_GEMM_MATH_F16X3 && !h->no_fuse;
+    const long bstride = pstride / WFL_BLK;   // blocks per buffer row incl. margins
     PK_TRY(h->ws_hamax.reserve((size_t)(NL + 1) * 3 * pstride * 4));
     PK_TRY(h->ws_camax.reserve((size_t)G * pstride * 4));
     PK_HIP(hipMemsetAsync(h->ws_hamax.p, 0, (size_t)(NL + 1) * 3 * pstride * 4, ctx->stream));
@@ -474,11 +485,15 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
             dim3 grid(pk_div_up(maxT, tpb), 1, B);
             PK_LAUNCH(ctx, "wf_upsample", k_wf_upsample, grid, dim3(256), 0, in, d_tab + o_inoff[i], d_tab + o_inlen[i],
                       out, d_tab + o_outoff[i], h->W(h->up_w[i]), h->up_b[i], f, M, last ? G : 0, d_tab + o_woff,
-                      d_tab + o_pruned, cond_row, MP);
+                      d_tab + o_pruned, cond_row, MP, use_wfl ? 1 : 0);
             in = out;
         }
     }
-    if (split_math) PK_TRY(pk_row_amax_launch(ctx, cond, MP, MP, 0, (long)G * pstride - WF_LEAD, camax));
+    unsigned* hbmax = h->ws_hamax.as<unsigned>() + WF_LEAD / WFL_BLK;   // block maxima (fused layer kernel)
+    unsigned* cbmax = h->ws_camax.as<unsigned>() + WF_LEAD / WFL_BLK;
+    auto hbmax_ptr = [&](int layer, int slot) { return hbmax + ((size_t)layer * 3 + slot) * bstride; };
+    if (use_wfl) PK_TRY(wfl_cond_amax_launch(ctx, cond, cond_row, G, npos_alloc / WFL_BLK, bstride, cbmax));
+    else if (split_math) PK_TRY(pk_row_amax_launch(ctx, cond, MP, MP, 0, (long)G * pstride - WF_LEAD, camax));
     // ---- fold z
     PK_LAUNCH(ctx, "wf_fold", k_wf_fold, dim3(pk_div_up(npos, 256)), dim3(256), 0, d_z, d_tab + o_putt, d_tab + o_pw,
               d_tab + o_zoff, G, npos, pstride, cur);
@@ -496,15 +511,58 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         cidx = cnew;
         const WfFlowW& F = h->flows[fl];
         // row 0: copy + input_proj into slot 1 of layer 0
+        if (use_wfl) {
+            PK_TRY(wfl_step_launch(ctx, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[0] * pstride, nxt,
+                                   h->W(F.w_in), h->W(F.b_in), hist_ptr(0, 1), hbmax_ptr(0, 1), rowvalid, npos_alloc, 1));
+        } else {
         PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out), F.b_logs,
                   F.b_b, cur + (long)perm[0] * pstride, nxt, h->W(F.w_in), h->W(F.b_in), hist_ptr(0, 1), rowvalid,
                   npos, 1);
         if (split_math) PK_TRY(pk_row_amax_launch(ctx, hist_ptr(0, 1), C, C, 0, npos, hamax_ptr(0, 1)));
+        }
         // the fused kernel needs the 64-channel shape (one 128-column block) and the split-fp16 path
         const bool fuse_proj = C == 64 && h->math == PK_GEMM_MATH_F16X3 && MP % PK_GEMM_HBK == 0 && !h->no_fuse;
         for (int i = 1; i < G; ++i) {
             const int slot = i % 3;
-            for (int l = 0; l < NL; ++l) {
+            for (int l = 0; l < NL && use_wfl; ++l) {
+                // the fused layer kernel (wf_layer.hip): conv taps + condition + gate + res|skip projection
+                const WfLayerW& L = F.layers[l];
+                WflLaunch w;
+                w.w.w1 = h->arena16.as<uint16_t>() + L.fl.w1;
+                w.w.w2 = h->arena16.as<uint16_t>() + L.fl.w2;
+                w.w.b1 = h->W(L.fl.b1);
+                w.w.b2s = h->W(L.fl.b2s);
+                w.w.k1 = L.fl.k1;
+                w.w.k2res = L.fl.k2res;
+                w.w.k2skip = L.fl.k2skip;
+                w.in0 = hist_ptr(l, 0);
+                w.slot_stride = feat_row;
+                w.in_amax0 = hbmax_ptr(l, 0);
+                w.amax_stride = bstride;
+                w.cur_slot = slot;
+                w.out = l + 1 < NL ? hist_ptr(l + 1, slot) : nullptr;   // the last layer's residual output is unused (:390)
+                w.out_amax = l + 1 < NL ? hbmax_ptr(l + 1, slot) : nullptr;
+                w.skip = skip;
+                w.first = l == 0;
+                w.cond = cond + (long)cidx[i] * cond_row;
+                w.cond_amax = cbmax + (long)cidx[i] * bstride;
+                w.ntap = 0;
+                for (int kr = 0; kr < 3; ++kr) {
+                    const int step = i - 2 + kr;   // kernel row kr reads the layer input of this step
+                    if (step < 1) continue;        // rows before the sequence start are zeros (:287-290)
+                    for (int kc = 0; kc < 3; ++kc) {
+                        w.tap_slot[w.ntap] = step % 3;
+                        w.tap_shift[w.ntap] = (kc - 1) * (1 << l);
+                        w.tap_w[w.ntap] = kr * 3 + kc;
+                        ++w.ntap;
+                    }
+                }
+                for (int t = w.ntap; t < 9; ++t) w.tap_slot[t] = w.tap_shift[t] = w.tap_w[t] = 0;
+                w.pos_utt = rowvalid;
+                w.npos_alloc = npos_alloc;
+                PK_TRY(wfl_layer_launch(ctx, w));
+            }
+            for (int l = 0; l < NL && !use_wfl; ++l) {
                 const WfLayerW& L = F.layers[l];
                 pk_gemm_args g;
                 g.A = hist_ptr(l, 0);   // taps carry the slot offsets
@@ -582,6 +640,12 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                     PK_TRY(pk_row_amax_launch(ctx, hist_ptr(l + 1, slot), C, C, 0, npos, hamax_ptr(l + 1, slot)));
             }
             float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
+            if (use_wfl) {
+                PK_TRY(wfl_step_launch(ctx, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[i] * pstride,
+                                       nxt + (long)i * pstride, h->W(F.w_in), h->W(F.b_in), h0n,
+                                       h0n ? hbmax_ptr(0, (i + 1) % 3) : nullptr, rowvalid, npos_alloc, 0));
+                continue;
+            }
             PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out),
                       F.b_logs, F.b_b, cur + (long)perm[i] * pstride, nxt + (long)i * pstride, h->W(F.w_in),
                       h->W(F.b_in), h0n, rowvalid, npos, 0);
