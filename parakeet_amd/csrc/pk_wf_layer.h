@@ -58,6 +58,8 @@ struct WflLaunch {
     int tap_slot[9], tap_shift[9], tap_w[9];   // ring slot, position shift, weight tap index kr*3 + kc
     const int* pos_utt;      // [npos_alloc] utterance of a position, < 0: gap (outputs forced to 0)
     int npos_alloc;          // multiple of 32
+    int active, tiles_per_wg;   // set by wfl_layer_launch: most waves that take a tile per round, tiles per workgroup
+    int warm;                   // measurement switches: bit 0 touch the weight lines up front, bit 1 even rounds
 };
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);
 

@@ -13,8 +13,10 @@
 //     its B operand (the input features of those positions, per tap) comes straight from global memory / L2 into
 //     registers -- the blocked [pos/32][ch][32] layout makes every load a coalesced 128-byte segment -- and is
 //     split in registers;
-//   * weights are the A operand: streamed through LDS in slabs of two k-steps (16 KB), double buffered, each slab
-//     used by the 8 waves = 256 positions of the workgroup; the out-projection weights (32 KB) stay resident;
+//   * weights are the A operand: streamed through LDS in slabs of six k-steps (48 KB), double buffered, each slab
+//     used by the 8 waves = 256 positions of the workgroup -- a slab is 72 MFMAs per wave, long enough to cover the
+//     L2 latency of the next slab's loads (two-k-step slabs measured 1.9 us per slab against 0.64 us of matrix
+//     work); the out-projection weights (32 KB) stay resident;
 //   * the gated activations never leave the accumulator registers: register r of the first contraction IS the B
 //     operand element of k-step r / 8 of the second (K order of W2 permuted at pack time), as in pwg.hip;
 //   * results are stored in the same blocked layout (coalesced), with the block maxima the next layer's operand
@@ -22,7 +24,9 @@
 // Rows before the sequence start are skipped as taps (ntap = 3, 6, 9), never stored as zeros.
 #include "pk_wf_layer.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "pk_split.h"
@@ -38,6 +42,7 @@ constexpr int WAVES = 8;
 constexpr int THREADS = WAVES * 64;
 constexpr int WAVE_T = 32;
 constexpr int KCH = 512;   // 16-byte chunks per k-step of A fragments (= threads: one chunk per thread per k-step)
+constexpr int SLAB = 6;    // k-steps per weight slab: 18, 30 and 42 k-steps (3, 6, 9 taps + condition) are multiples
 constexpr int BLK_C = WFL_C * WFL_BLK;      // 2048 floats per feature block
 constexpr int BLK_M = WFL_MP * WFL_BLK;     // 3072 floats per condition block
 
@@ -95,9 +100,17 @@ __device__ __forceinline__ float gated_s(float a, float b, float ca, float cb) {
 }
 
 __global__ __launch_bounds__(THREADS, 2) void k_wf_layer(WflLaunch a) {
-    __shared__ __attribute__((aligned(16))) f16x8 wbuf[2][2 * KCH];   // two slabs of two k-steps: 32 KB
+    __shared__ __attribute__((aligned(16))) f16x8 wbuf[2][SLAB * KCH];   // two slabs of six k-steps: 96 KB
     __shared__ __attribute__((aligned(16))) f16x8 w2l[WFL_KS2 * KCH]; // out projection, resident: 32 KB
     __shared__ float lb[256];                                         // b1 [128] | b2s [128]
+    // per logical k-step (taps whose row exists, then the condition block): where its B operand lives and which
+    // packed weight k-step multiplies it.  Table driven so that the loads below are straight-line code: with
+    // branches around them hipcc's s_waitcnt insertion falls back to vmcnt(0) before every load (seen in the first
+    // version of this kernel: 60 % of the wave cycles in SQ_WAIT_ANY).
+    __shared__ long kt_off[WFL_KS1];     // element offset from in0 of (position 0, channel 0 of this k-step)
+    __shared__ int kt_shift[WFL_KS1];    // position shift of the tap
+    __shared__ int kt_blk[WFL_KS1];      // floats per 32-position block of the source (64 or 96 channels)
+    __shared__ int kt_w[WFL_KS1];        // packed k-step of W1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     {
@@ -107,22 +120,55 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer(WflLaunch a) {
         else if (tid < 256) lb[tid] = a.w.b2s[tid - 128];
     }
     __syncthreads();
+    // Measurement switch (PK_WF_WARM bit 0, default off): touch one dword of every 128-byte line of W1 up front.
+    // Every launch uses another layer's weights, so their lines are cold in this XCD's L2; measured: no gain (the
+    // slab loads are issued a slab ahead, which covers the miss).
+    float warm = 0.f;
+    if (a.warm & 1) {
+        const float* wl = reinterpret_cast<const float*>(a.w.w1);
+        constexpr int W1_LINES = (int)(WFL_W1_HALVES * 2 / 128);   // 2688
+        for (int i = tid; i < W1_LINES; i += THREADS) warm += wl[(long)i * 32];
+    }
     const int ntap = a.ntap;
     const int nks_conv = WFL_KS_TAP * ntap;
-    const int nslab = (nks_conv + WFL_KS_COND) / 2;     // 9, 15 or 21: a multiple of 3
+    const int nks = nks_conv + WFL_KS_COND;
+    const int nslab = nks / SLAB;  // 3, 5 or 7
+    if (tid < nks) {
+        const int ks = tid;
+        if (ks < nks_conv) {
+            const int t = ks >> 2;
+            kt_off[ks] = (long)a.tap_slot[t] * a.slot_stride + (long)(16 * (ks & 3)) * WFL_BLK;
+            kt_shift[ks] = a.tap_shift[t];
+            kt_blk[ks] = BLK_C;
+            kt_w[ks] = a.tap_w[t] * WFL_KS_TAP + (ks & 3);
+        } else {
+            kt_off[ks] = (a.cond - a.in0) + (long)(16 * (ks - nks_conv)) * WFL_BLK;
+            kt_shift[ks] = 0;
+            kt_blk[ks] = BLK_M;
+            kt_w[ks] = 9 * WFL_KS_TAP + (ks - nks_conv);
+        }
+    }
     const f16x8* w1 = reinterpret_cast<const f16x8*>(a.w.w1) + tid;
-    auto w_kstep = [&](int ks) -> const f16x8* {        // packed k-step of logical k-step ks
-        const int wk = ks < nks_conv ? a.tap_w[ks >> 2] * WFL_KS_TAP + (ks & 3) : 9 * WFL_KS_TAP + (ks - nks_conv);
-        return w1 + (long)wk * KCH;
-    };
+    auto w_kstep = [&](int ks) -> const f16x8* { return w1 + (long)kt_w[ks] * KCH; };   // packed k-step of logical ks
+    __syncthreads();   // tables visible
     const int ntiles = a.npos_alloc / WAVE_T;
-    const int tiles_per_round = (int)gridDim.x * WAVES;
     const float i_res = pow2f(-(PK_UNIT_EXP + a.w.k2res)), i_skip = pow2f(-(PK_UNIT_EXP + a.w.k2skip));
+    // A workgroup owns tiles_per_wg consecutive wave tiles and works through them in rounds of at most `active`
+    // tiles (one pass over the weights per round).  The waves of a round run in lockstep (they share the LDS weight
+    // slabs), so a round takes as long as its busiest SIMD: measured 25 us with one working wave per SIMD, 35 us
+    // with two.  Full rounds first (11 tiles = 8 + 3: 35 + 25 us) therefore beat even rounds (6 + 5: a SIMD with two
+    // waves in both, 35 + 35 us) and rounds of four (3 x 25 us).  The other waves only move weights and keep the
+    // barriers.
+    const int t_begin = (int)blockIdx.x * a.tiles_per_wg, t_end = min(t_begin + a.tiles_per_wg, ntiles);
+    const int nrounds = (t_end - t_begin + a.active - 1) / a.active;
 
-    for (int base = (int)blockIdx.x * WAVES; base < ntiles; base += tiles_per_round) {   // uniform over the workgroup
+    for (int base = t_begin, rnd = 0; base < t_end; ++rnd) {   // uniform over the workgroup
+        const int nact = (a.warm & 2) ? (t_end - base + (nrounds - rnd) - 1) / (nrounds - rnd)   // even rounds (A/B)
+                                      : min(a.active, t_end - base);                           // tiles of this round
         const int wt = base + wave;
-        const bool tile_ok = wt < ntiles;
-        const int p0 = tile_ok ? wt * WAVE_T : 0;   // idle waves shadow tile 0 (loads only) to keep the barriers
+        const bool tile_ok = wave < nact;
+        base += nact;
+        const int p0 = tile_ok ? wt * WAVE_T : 0;
         const int p = p0 + j;
         const bool lane_ok = tile_ok && a.pos_utt[p] >= 0;
 
@@ -151,73 +197,68 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer(WflLaunch a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = lb[32 * q + mfma_row(r, hi)] * S1;
 
-        // ---- B operand of slab s (two k-steps): 8 channels per lane and k-step, 128-byte segments across lanes
-        auto load_b = [&](int s, float (&dst)[2][8]) {
+        // ---- B operand of k-step ks: 8 channels per lane, 128-byte segments across the lanes of a half wave
+        auto load_b = [&](int ks, float (&dst)[8]) {
+            const int q = p + kt_shift[ks];
+            const float* src = a.in0 + kt_off[ks] + (long)(q >> 5) * kt_blk[ks] + (q & 31) + (8 * hi) * WFL_BLK;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int ks = 2 * s + kk;
-                const float* src;
-                if (ks < nks_conv) {
-                    const int t = ks >> 2;
-                    const int q = p + a.tap_shift[t];
-                    src = a.in0 + (long)a.tap_slot[t] * a.slot_stride + (long)(q >> 5) * BLK_C + (q & 31) +
-                          (16 * (ks & 3) + 8 * hi) * WFL_BLK;
-                } else {
-                    src = a.cond + (long)(p >> 5) * BLK_M + (p & 31) + (16 * (ks - nks_conv) + 8 * hi) * WFL_BLK;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dst[kk][e] = src[e * WFL_BLK];
-            }
+            for (int e = 0; e < 8; ++e) dst[e] = src[e * WFL_BLK];
         };
-        float ring[3][2][8];
-        f16x8 wreg[2];
-        auto mma_slab = [&](int s, const float (&bv)[2][8]) {
-            const f16x8* wl = wbuf[s & 1] + lane;
+        f16x8 wreg[SLAB];      // next slab's weights on their way from global memory to the other LDS buffer
+        // Working and idle waves run separate copies of the slab loop (same number of barriers): the working copy
+        // has no branch inside, loads and LDS stores are unconditional (the slab after the last one is the last one
+        // again, parked in the buffer nobody reads any more).
+        if (tile_ok) {
+            float ring[SLAB][8];   // B operands, one slab ahead: slot kk is refilled as soon as k-step kk has split it
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                f16x8 bh, bl;
-                split8s(bv[kk], sx, bh, bl);
+            for (int kk = 0; kk < SLAB; ++kk) {
+                wreg[kk] = *w_kstep(kk);
+                load_b(kk, ring[kk]);
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f16x8 ah = wl[kk * KCH + (0 * 4 + q) * 64];
-                    const f16x8 al = wl[kk * KCH + (1 * 4 + q) * 64];
-                    acc[q] = mfma16(ah, bh, acc[q]);
-                    acc[q] = mfma16(al, bh, acc[q]);
-                    acc[q] = mfma16(ah, bl, acc[q]);
-                }
-            }
-        };
-        // one slab: request the next slab's weights and the B operand two slabs ahead, run this slab, park the
-        // weights in the other LDS buffer, barrier (everyone is done reading this buffer / sees the other one)
-        auto slab_step = [&](int s, const float (&cur)[2][8], float (&ahead)[2][8]) {
-            if (s + 1 < nslab) {
-                wreg[0] = *w_kstep(2 * s + 2);
-                wreg[1] = *w_kstep(2 * s + 3);
-            }
-            if (s + 2 < nslab) load_b(s + 2, ahead);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_slab(s, cur);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < nslab) {
-                wbuf[(s + 1) & 1][tid] = wreg[0];
-                wbuf[(s + 1) & 1][KCH + tid] = wreg[1];
-            }
+            for (int kk = 0; kk < SLAB; ++kk) wbuf[0][kk * KCH + tid] = wreg[kk];
             __syncthreads();
-        };
-        // prologue: slab 0 weights into LDS, B operands of slabs 0 and 1 in flight
-        wreg[0] = *w_kstep(0);
-        wreg[1] = *w_kstep(1);
-        load_b(0, ring[0]);
-        load_b(1, ring[1]);
-        wbuf[0][tid] = wreg[0];
-        wbuf[0][KCH + tid] = wreg[1];
-        __syncthreads();
-        for (int s = 0; s < nslab; s += 3) {
-            slab_step(s, ring[0], ring[2]);
-            slab_step(s + 1, ring[1], ring[0]);
-            slab_step(s + 2, ring[2], ring[1]);
+            for (int s = 0; s < nslab; ++s) {
+                const int sn = min(s + 1, nslab - 1);
+#pragma unroll
+                for (int kk = 0; kk < SLAB; ++kk) wreg[kk] = *w_kstep(SLAB * sn + kk);
+                __builtin_amdgcn_sched_barrier(0);   // keep the weight loads up here: hipcc would sink them to their stores
+                const f16x8* wl = wbuf[s & 1] + lane;
+#pragma unroll
+                for (int kk = 0; kk < SLAB; ++kk) {
+                    f16x8 bh, bl;
+                    split8s(ring[kk], sx, bh, bl);
+                    load_b(SLAB * sn + kk, ring[kk]);
+                    __builtin_amdgcn_sched_barrier(0);   // ... and these ahead of the k-step's MFMAs
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f16x8 ah = wl[kk * KCH + (0 * 4 + q) * 64];
+                        const f16x8 al = wl[kk * KCH + (1 * 4 + q) * 64];
+                        acc[q] = mfma16(ah, bh, acc[q]);
+                        acc[q] = mfma16(al, bh, acc[q]);
+                        acc[q] = mfma16(ah, bl, acc[q]);
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < SLAB; ++kk) wbuf[(s + 1) & 1][kk * KCH + tid] = wreg[kk];
+                __syncthreads();   // everyone is done reading this slab's buffer and sees the other one
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < SLAB; ++kk) wreg[kk] = *w_kstep(kk);
+#pragma unroll
+            for (int kk = 0; kk < SLAB; ++kk) wbuf[0][kk * KCH + tid] = wreg[kk];
+            __syncthreads();
+            for (int s = 0; s < nslab; ++s) {
+                const int sn = min(s + 1, nslab - 1);
+#pragma unroll
+                for (int kk = 0; kk < SLAB; ++kk) wreg[kk] = *w_kstep(SLAB * sn + kk);
+#pragma unroll
+                for (int kk = 0; kk < SLAB; ++kk) wbuf[(s + 1) & 1][kk * KCH + tid] = wreg[kk];
+                __syncthreads();
+            }
         }
-
+        if (!tile_ok) continue;   // (no barrier below this point)
         // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection
         f16x8 zh[WFL_KS2], zl[WFL_KS2];
 #pragma unroll
@@ -271,12 +312,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer(WflLaunch a) {
                     float v = fmaf(acc2[q][r], inv, old[16 * q + r]);   // res = x_in + res (:281); skips summed (:390)
                     if (!lane_ok) v = 0.f;                              // gap positions stay zero
                     if (pass == 0) am = fmaxf(am, fabsf(v));
-                    if (tile_ok && dst) (dst + po)[(32 * q + mfma_row(r, hi)) * WFL_BLK] = v;
+                    if (dst) (dst + po)[(32 * q + mfma_row(r, hi)) * WFL_BLK] = v;
                 }
         }
         am = wave_max64(am);
-        if (lane == 0 && tile_ok && a.out_amax) a.out_amax[p0 >> 5] = __float_as_uint(am);
+        if (lane == 0 && a.out_amax) a.out_amax[p0 >> 5] = __float_as_uint(am);
     }
+    if (warm == 1.2345e-30f) a.skip[0] = warm;   // never true: keeps the warm-up loads
 }
 
 // max|cond| per block: one wave per (row, block) of 96 x 32 contiguous floats
@@ -442,8 +484,14 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     if (a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9)
         PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (npos %d, taps %d)", a.npos_alloc, a.ntap);
     const int ntiles = a.npos_alloc / WAVE_T;
-    const int grid = std::min(ctx->n_cu, (ntiles + WAVES - 1) / WAVES);
-    PK_LAUNCH(ctx, "wf_layer", k_wf_layer, dim3(grid), dim3(THREADS), 0, a);
+    WflLaunch b = a;
+    static const int active_env = getenv("PK_WF_ACTIVE") ? atoi(getenv("PK_WF_ACTIVE")) : WAVES;   // measurement switch
+    b.active = active_env >= 1 && active_env <= WAVES ? active_env : WAVES;
+    static const int warm_env = getenv("PK_WF_WARM") ? atoi(getenv("PK_WF_WARM")) : 0;   // measurement switches
+    b.warm = warm_env;
+    b.tiles_per_wg = std::max(1, (ntiles + ctx->n_cu - 1) / ctx->n_cu);
+    const int grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
+    PK_LAUNCH(ctx, "wf_layer", k_wf_layer, dim3(grid), dim3(THREADS), 0, b);
     return PK_OK;
 }
 

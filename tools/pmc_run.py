@@ -14,6 +14,16 @@ if mode == "pwg":
     noises = [torch.randn(L * 256, device="cuda") for _ in range(B)]
     gen.inference_batch(mels, noises)
     torch.cuda.synchronize()
+elif mode == "wf":
+    from parakeet_amd.waveflow import ConditionalWaveFlow
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64, n_flows=2)      # two flows = 240 layer launches are plenty for counters
+    m = ConditionalWaveFlow(**cfg); m.set_state_dict(syn.waveflow_state(cfg)); m.eval()
+    rng = np.random.default_rng(0)
+    Bw = min(B, 8)
+    mels = [torch.tensor(np.maximum(rng.normal(-4, 2, size=(80, L)), np.log(1e-5)).astype(np.float32)).cuda() for _ in range(Bw)]
+    zs = [torch.randn(m.lengths(L)[0], device="cuda") for _ in range(Bw)]
+    m.infer_batch(mels, zs)
+    torch.cuda.synchronize()
 elif mode == "fs2":
     from parakeet_amd.fastspeech2 import FastSpeech2
     m = FastSpeech2(80, 80, **syn.FS2_LJSPEECH); m.set_state_dict(syn.fastspeech2_state(fixed_duration=5)); m.eval()
