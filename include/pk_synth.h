@@ -109,7 +109,7 @@ typedef struct {
     int32_t aux_channels;       /* 80 */
     int32_t aux_context_window; /* 2 */
     int32_t n_upsample;         /* 4 */
-    int32_t upsample_scales[8]; /* 4,4,4,4 */
+    int32_t upsample_scales[8]; /* 4,4,4,4 (LJSpeech, hop 256) or 4,5,3,5 (baker / vctk, hop 300); any product 32..1024 */
     int32_t use_causal_conv;    /* 0 only */
 } pk_pwg_cfg;
 
@@ -130,7 +130,9 @@ int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_
  *                       v_mfma_f32_32x32x16_f16, fp32 accumulation.  Measured on the 30-layer generator:
  *                       relative max error 7e-7 (rms 2.3e-7) vs the fp64 oracle -- the class of the exact
  *                       path (5e-7, rms 1.9e-7) and of a CPU fp32 run (6e-7).  5.3x less matrix-pipe time.
- *                       Needs |activation| < 65504 (saturating split; a PWG residual stream is O(1..10));
+ *                       Operands are block scaled by powers of two before the split (csrc/pk_split.h): the
+ *                       error does not depend on the magnitude of weights or activations (floor 2^-39 of the
+ *                       block maximum, fp32 range);
  *   PK_PWG_MATH_BF16X3  the same with bf16 parts (fp32 range, 8 + 8 bits): error 3.7e-6. */
 enum { PK_PWG_MATH_F32 = 0, PK_PWG_MATH_BF16X3 = 1, PK_PWG_MATH_F16X3 = 2 };
 int pk_pwg_set_math(pk_pwg* h, int32_t mode);
@@ -200,10 +202,11 @@ int pk_fs2_set_param(pk_fs2* h, const char* name, const float* data,
 /* FastSpeech2Inference's normalizer: output mel -> mel * sigma + mu (ZScore.inverse,
  * fastspeech2.py:668-671).  NULL,NULL = return the normalised mel (FastSpeech2.inference). */
 int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* sigma, int32_t n);
-/* Arithmetic of the dense layers (Linear / Conv1D GEMMs): 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA with
- * fp32 accumulation (default; same construction and error class as PK_PWG_MATH_F16X3; layers whose input
- * channel count is not a multiple of 32 stay on the exact path).  Attention, LayerNorm, softmax, the
- * duration arithmetic and every stored tensor are fp32 in both modes.  Env PK_FS2_MATH=f32 overrides. */
+/* Arithmetic of the dense layers (Linear / Conv1D GEMMs) and of the two attention contractions: 0 = exact fp32
+ * MFMA, 1 = block-scaled 3-term split-fp16 MFMA with fp32 accumulation (default; same construction and error
+ * class as PK_PWG_MATH_F16X3; layers whose input channel count is not a multiple of 32 stay on the exact path).
+ * LayerNorm, softmax, the duration arithmetic and every stored tensor are fp32 in both modes.
+ * Env PK_FS2_MATH=f32 overrides. */
 int pk_fs2_set_math(pk_fs2* h, int32_t mode);
 int pk_fs2_finalize(pk_fs2* h);
 /* Speaker conditioning of the NEXT pk_fs2_encode call (_forward :396-402, _integrate_with_spk_embed
