@@ -503,12 +503,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "dtype_note": "fp32 storage and accumulation everywhere; the dense contractions (PWG residual blocks and "
-                          "last convs, FastSpeech2 Linear/Conv1D/attention) evaluate each fp32 product as a 3-term split-fp16 MFMA sum "
-                          "(a_hi*b_hi + a_lo*b_hi + a_hi*b_lo): measured error = the exact-fp32 MFMA path's (PWG wav "
-                          "7.1e-7 vs 5.3e-7 rel. max, FS2 mel L1 1.7e-6 vs 1.1e-6, vs the fp64 oracle, whose own fp32 "
-                          "run is at 6.0e-7 / 5.4e-7; same test tolerances); softmax/LayerNorm/durations are plain "
-                          "fp32; the all-exact-fp32 "
-                          "configuration is timed under extras",
+                          "last convs, FastSpeech2 Linear/Conv1D/attention) evaluate each fp32 product as a 3-term split-fp16 "
+                          "MFMA sum (a_hi*b_hi + a_lo*b_hi + a_hi*b_lo) of BLOCK-SCALED operands (every operand block is "
+                          "multiplied by the power of two that brings its maximum to [2^13, 2^14) before the split, exactly "
+                          "undone in the epilogue: DESIGN.md 4.7), so the error is the exact-fp32 MFMA path's independent of "
+                          "the magnitude of weights or activations (tests rescale a model's internal streams by 2^-30..2^12; "
+                          "PWG wav 7.1e-7 vs 5.3e-7 rel. max, FS2 mel L1 1.7e-6 vs 1.1e-6 against the fp64 oracle, whose own "
+                          "fp32 run is at 6.0e-7 / 5.4e-7; same test tolerances; parity_check below compares this very "
+                          "batch with the fp32 CPU oracle); softmax/LayerNorm/durations are plain fp32; the "
+                          "all-exact-fp32 configuration is timed under extras",
             "data": "synthetic",
             "config": {
                 "workload": "FastSpeech2+PWG end-to-end (BASELINE config 4 per-GPU share): "

@@ -156,7 +156,7 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
                             const float* __restrict__ bias, const int* __restrict__ tile_t0, long Ttot,
                             float* __restrict__ x, unsigned* __restrict__ xe, PwgGen g) {
     const int tile = blockIdx.x;
-    const long t = (long)tile_t0[tile] + threadIdx.x;
+    const long t = (long)(tile_t0[tile] & ~255) + threadIdx.x;   // low bits: the tile's edge class (layer kernels)
     float n;
     bool valid = true;
     if constexpr (GEN) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         uw[4] = wrow[4];
     };
     auto load_group0 = [&](int wt) {
-        const long tt = (long)a.tile_t0[wt >> 3] + (wt & 7) * WAVE_T + j;
+        const long tt = (long)(a.tile_t0[wt >> 3] & ~255) + (wt & 7) * WAVE_T + j;
         const unsigned vo = (unsigned)(xoff(tt - d) + hi * XBLK);   // group 0 = (cg 0, tap -1)
         const float* p = group_ptr(0);
 #pragma unroll
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const int phase = (wt & 7) * WAVE_T + j;
         // addresses = wave-uniform row pointer (SGPR pair) + one 32-bit per-lane element offset,
         // so a load costs no address VGPRs: lane offset = block/sample offset of (t + tap shift) + its row part
-        const long t = (long)a.tile_t0[tile] + phase;
+        const long t = (long)(a.tile_t0[tile] & ~255) + phase;
         unsigned vo1t[3];                                             // B operand rows 2*cp + hi, per tap
 #pragma unroll
         for (int tp = 0; tp < 3; ++tp) vo1t[tp] = (unsigned)(xoff(t + (long)(tp - 1) * d) + hi * XBLK);
@@ -655,8 +655,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const int dc = (d + 31) >> 5, df = d >> 5;
         eoff = lane == 0 ? -dc : (lane == 1 ? -df : (lane == 3 ? df : (lane == 4 ? dc : 0)));
     }
-    auto load_amax = [&](int wt) -> unsigned {
-        const long tt0 = (long)a.tile_t0[wt >> 3] + (wt & 7) * WAVE_T;
+    // (t0 = the tile's tile_t0 entry: timeline offset | edge class.  It is loaded ONE TILE AHEAD -- a load whose
+    // result feeds an address makes hipcc wait with vmcnt(0), i.e. for every prefetched operand in flight behind it;
+    // round 1 paid that twice per tile: tile_t0 at the top of the tile, tile_cls in prefetch_head)
+    auto load_amax = [&](int t0, int wt) -> unsigned {
+        const long tt0 = (long)(t0 & ~255) + (wt & 7) * WAVE_T;
         return ABL ? 0x3f800000u : a.xe_in[(tt0 >> 5) + eoff];
     };
     auto tile_scale_exp = [&](unsigned ev) -> int {   // wave-uniform (SGPR) exponent k of the tile's x scale 2^k
@@ -682,8 +685,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         return (long)(32 * (cg >> 1) + mfma_row(8 * (cg & 1) + e, 0));
     };
     // lane offsets of a wave-tile for the three taps (the shift moves lanes across 32-sample blocks)
-    auto lane_off = [&](int wt, int tap) -> unsigned {
-        const long tt = (long)a.tile_t0[wt >> 3] + (wt & 7) * WAVE_T + j + (long)(tap - 1) * d;
+    auto lane_off = [&](int t0, int wt, int tap) -> unsigned {
+        const long tt = (long)(t0 & ~255) + (wt & 7) * WAVE_T + j + (long)(tap - 1) * d;
         return (unsigned)(xoff(tt) + 4 * hi * XBLK);
     };
     float ring[B3_RING][8];
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     float uw[UPW];
     int df_n = 0;          // GEN: this lane's frame minus the first staged frame (0 / 1) of the tile being prefetched
     bool valid_n = true;   // GEN: the lane's sample lies inside its utterance
-    auto prefetch_head = [&](int wt) {
+    auto prefetch_head = [&](int wt, int cls) {   // cls: edge class of the tile (hop 256), known a tile ahead
         const int tile = wt >> 3, phase = (wt & 7) * WAVE_T + j;
         const float* prow;
         long wsel;   // row of the upsampler table: edge class * hop + phase
@@ -711,22 +714,26 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             const int jj = idx >> 5, c4 = idx & 31;
             if (idx < (UPW + (GEN ? 1 : 0)) * (G / 4)) preg[it] = *reinterpret_cast<const f32x4*>(prow + (long)jj * a.ldp + 4 * c4);
         }
-        if constexpr (!GEN) wsel = (long)a.tile_cls[tile] * TILE + phase;
+        if constexpr (!GEN) wsel = (long)cls * TILE + phase;
         const float* wrow = a.uptab + wsel * UPW_PAD;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow);
         uw[0] = w0[0]; uw[1] = w0[1]; uw[2] = w0[2]; uw[3] = w0[3];
         uw[4] = wrow[4];
     };
+    unsigned vo8n[3] = {0, 0, 0};   // lane offsets of the three taps of the NEXT tile (this tile's at the loop top)
     if (my_slot < n_wtiles) {
-        prefetch_head(my_slot);
+        const int t0c = a.tile_t0[my_slot >> 3];
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) vo8n[tp] = lane_off(t0c, my_slot, tp);
+        prefetch_head(my_slot, __builtin_amdgcn_readfirstlane(t0c & 255));
 #pragma unroll
         for (int g = 0; g < B3_RING; ++g) {
-            const unsigned vo = lane_off(my_slot, g % 3);
+            const unsigned vo = vo8n[g % 3];
 #pragma unroll
             for (int e = 0; e < 8; ++e) ring[g][e] = ABL ? (float)(lane + e) * 1e-3f : (a.xin + group_row(g, e) * XBLK)[vo];
         }
         if constexpr (HALF) {
-            kx = tile_scale_exp(load_amax(my_slot));
+            kx = tile_scale_exp(load_amax(t0c, my_slot));
             split_x8s(ring[0], pow2f(kx), ph, pl);
         } else {
             split_x8<bf16x8, elem16, HALF>(ring[0], ph, pl);
@@ -739,12 +746,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     // hold groups g+1..g+RING-1 (of this tile, continuing into the next one); slot g % RING is free.
     for (int wt = my_slot; wt < n_wtiles; wt += stride_slots) {
         const int next_wt = wt + stride_slots < n_wtiles ? wt + stride_slots : wt;
-        unsigned vo8[3], vo8n[3];
+        unsigned vo8[3];
 #pragma unroll
-        for (int tp = 0; tp < 3; ++tp) {
-            vo8[tp] = lane_off(wt, tp);
-            vo8n[tp] = lane_off(next_wt, tp);
-        }
+        for (int tp = 0; tp < 3; ++tp) vo8[tp] = vo8n[tp];
+        const int t0n = a.tile_t0[next_wt >> 3];   // requested here, first used at k-step T0_USE of stage 1
+        int cls_next = 0;
         const unsigned vo4 = vo8[1];   // centre tap: operand rows and result rows share the lane offset
         float x_old[32];
 #pragma unroll
@@ -758,7 +764,6 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         unsigned ev_next = 0;
         float sx = 1.f, gca = 0.f, gcb = 0.f;
         if constexpr (HALF) {
-            ev_next = load_amax(next_wt);
             const int ks1 = kx + a.k1;
             sx = pow2f(kx);
             const float S1 = pow2f(ks1);
@@ -794,8 +799,15 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         // stage 1: 12 k-steps.  Step g: refill the free ring slot with group g+RING, then run the 12 MFMAs of
         // group g while the VALU splits group g+1 (sched_group_barrier interleaves them: a 32x32x16 MFMA
         // occupies the matrix pipe for 8 issue slots, the split fits in the gaps).
+        constexpr int T0_USE = 3;   // the next tile's offsets are formed here: before the ring reaches into it (g = 8)
 #pragma unroll
         for (int g = 0; g < B3_KS1; ++g) {
+            if (g == T0_USE) {
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp) vo8n[tp] = lane_off(t0n, next_wt, tp);
+                cls_next = __builtin_amdgcn_readfirstlane(t0n & 255);
+                if constexpr (HALF) ev_next = load_amax(t0n, next_wt);
+            }
             {
                 const int gn = g + B3_RING;
                 const int gt = gn < B3_KS1 ? gn : gn - B3_KS1;
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             ph = nh;
             pl = nl;
         }
-        prefetch_head(next_wt);
+        prefetch_head(next_wt, cls_next);
         float sk_old[32];   // skip accumulator: requested half-way through pass 0, used at the end of pass 1
         __builtin_amdgcn_sched_barrier(0);
 
@@ -1000,7 +1012,7 @@ __global__ __launch_bounds__(512) void k_pwg_last(PwgLastArgs a) {
     const int j = lane & 31;
     const int hi = lane >> 5;
     const int tile = blockIdx.x;
-    const long t = (long)a.tile_t0[tile] + wave * WAVE_T + j;
+    const long t = (long)(a.tile_t0[tile] & ~255) + wave * WAVE_T + j;
     const float* sb = a.skip + xoff(t) + hi * XBLK;
     const f32x2* w1 = reinterpret_cast<const f32x2*>(a.w1) + lane;
     f32x16 acc[2];
@@ -1043,7 +1055,7 @@ __global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
     const int j = lane & 31;
     const int hi = lane >> 5;
     const int tile = blockIdx.x;
-    const long t = (long)a.tile_t0[tile] + wave * WAVE_T + j;
+    const long t = (long)(a.tile_t0[tile] & ~255) + wave * WAVE_T + j;
     const float* sb = a.skip + xoff(t) + 4 * hi * XBLK;
     float sv[4][8];
 #pragma unroll
@@ -1574,12 +1586,13 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < cuC[b + 1] - cuC[b]; ++k) {
             const int i = cuC[b] + k;
-            tile_t0[i] = toff[b] + k * TILE;
+            tile_t0[i] = toff[b] + k * TILE;     // a multiple of 256: the low bits carry the edge class (below)
             tile_s0[i] = k * TILE;
             tile_utt[i] = b;
             if (!gen) {
                 const int before = k < 2 ? k : 2, after = (frames[b] - 1 - k) < 2 ? (frames[b] - 1 - k) : 2;
                 tile_cls[i] = before * 3 + after;
+                tile_t0[i] |= tile_cls[i];       // one load gives the split layer kernel both, a tile ahead
             }
         }
     const size_t o_tile = push(tile_t0), o_cls = push(tile_cls), o_ts0 = push(tile_s0), o_tutt = push(tile_utt);
