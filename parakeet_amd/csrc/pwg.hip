@@ -266,6 +266,24 @@ __device__ __forceinline__ float gated_s(float a, float b, float ca, float cb) {
     return fmaf(ea, -PK_Z_SCALE, PK_Z_SCALE) * __builtin_amdgcn_rcpf((1.f + ea) * (1.f + eb));
 }
 
+// two gates at once on packed fp32 math (v_pk_mul / v_pk_add / v_pk_fma process a register pair per issue slot; the
+// clamp and the transcendentals stay per element): 15 instructions per pair instead of ~20
+__device__ __forceinline__ f32x2 gated_s2(f32x2 a, f32x2 b, float ca, float cb) {
+    f32x2 ta = a * ca, tb = b * cb;
+    ta[0] = __builtin_amdgcn_fmed3f(ta[0], -28.853900817779268f, 28.853900817779268f);
+    ta[1] = __builtin_amdgcn_fmed3f(ta[1], -28.853900817779268f, 28.853900817779268f);
+    f32x2 ea, eb, rc;
+    ea[0] = __builtin_amdgcn_exp2f(ta[0]);
+    ea[1] = __builtin_amdgcn_exp2f(ta[1]);
+    eb[0] = __builtin_amdgcn_exp2f(tb[0]);
+    eb[1] = __builtin_amdgcn_exp2f(tb[1]);
+    const f32x2 num = ea * (-PK_Z_SCALE) + PK_Z_SCALE;
+    const f32x2 den = (ea + 1.f) * (eb + 1.f);
+    rc[0] = __builtin_amdgcn_rcpf(den[0]);
+    rc[1] = __builtin_amdgcn_rcpf(den[1]);
+    return num * rc;
+}
+
 constexpr int LDS_W1 = KS1 * 64 * 4;          // 24576 floats
 constexpr int LDS_W2 = KS2 * 64 * 4;          //  8192
 constexpr int LDS_BIAS = G + R + SK;          //   256
@@ -875,8 +893,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             const int zq = ks >> 1, r0 = 8 * (ks & 1);
             if (slot < 4) {
                 if constexpr (HALF) {   // z * 2^14 from the scaled accumulators
-                    zv[2 * slot] = gated_s(acc[zq][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot], gca, gcb);
-                    zv[2 * slot + 1] = gated_s(acc[zq][r0 + 2 * slot + 1], acc[zq + 2][r0 + 2 * slot + 1], gca, gcb);
+                    const f32x2 av = {acc[zq][r0 + 2 * slot], acc[zq][r0 + 2 * slot + 1]};
+                    const f32x2 bv = {acc[zq + 2][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot + 1]};
+                    const f32x2 z2 = gated_s2(av, bv, gca, gcb);
+                    zv[2 * slot] = z2[0];
+                    zv[2 * slot + 1] = z2[1];
                 } else {
                     zv[2 * slot] = gated(acc[zq][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot]);
                     zv[2 * slot + 1] = gated(acc[zq][r0 + 2 * slot + 1], acc[zq + 2][r0 + 2 * slot + 1]);
