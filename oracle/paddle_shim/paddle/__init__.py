@@ -242,6 +242,14 @@ def divide(x, y):
     return _wrap(torch.div(x, y))
 
 
+def tril(x, diagonal=0):
+    return _wrap(torch.tril(x.to(torch.int8), diagonal).to(x.dtype) if x.dtype == torch.bool else torch.tril(x, diagonal))
+
+
+def argmax(x, axis=None, keepdim=False):
+    return _wrap(torch.argmax(x) if axis is None else torch.argmax(x, dim=axis, keepdim=keepdim))
+
+
 def broadcast_shape(a, b):
     return list(torch.broadcast_shapes(tuple(a), tuple(b)))
 

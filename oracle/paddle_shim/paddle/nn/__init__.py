@@ -36,6 +36,12 @@ class Layer(torch.nn.Module):
         persistent = persistable and not str(name).startswith("generated_tensor")
         torch.nn.Module.register_buffer(self, name, tensor, persistent=persistent)
 
+    def named_sublayers(self, prefix="", include_self=False):
+        for n, m in self.named_modules(prefix=prefix):
+            if m is self and not include_self:
+                continue
+            yield n, m
+
     def add_sublayer(self, name, layer):
         self.add_module(str(name), layer)
         return layer
@@ -169,7 +175,7 @@ class Dropout(Layer):
         self.p = p
 
     def forward(self, x):
-        return _wrap(TF.dropout(x, self.p, self.training))
+        return functional.dropout(x, self.p, self.training)
 
 
 class ReLU(Layer):

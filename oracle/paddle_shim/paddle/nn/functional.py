@@ -95,7 +95,16 @@ def pad(x, pad, mode="constant", value=0.0, data_format="NCHW"):
     return _wrap(TF.pad(x, pad, mode=mode))
 
 
+# Tacotron2-style prenets keep dropout ON at inference (modules/tacotron2/decoder.py:78-81, models/tacotron2.py:61-80),
+# so a reproducible run needs the mask injected: when DROPOUT_HOOK is set, every *active* dropout call
+# (training=True, p > 0) returns DROPOUT_HOOK(x, p) instead of drawing from torch's generator.  The hook owns the
+# upscale_in_train convention (x * keep / (1 - p)) [paddle-semantics: the default mode of paddle.nn.functional.dropout].
+DROPOUT_HOOK = None
+
+
 def dropout(x, p=0.5, training=True, **k):
+    if DROPOUT_HOOK is not None and training and p > 0:
+        return _wrap(DROPOUT_HOOK(x, p))
     return _wrap(TF.dropout(x, p, training))
 
 

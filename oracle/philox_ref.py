@@ -46,3 +46,24 @@ def randn(n, seed=0, offset=0, dtype=np.float64):
         out[:, 2 * h] = rad * np.cos(2.0 * np.pi * u2)
         out[:, 2 * h + 1] = rad * np.sin(2.0 * np.pi * u2)
     return out.reshape(-1)[:n].astype(dtype)
+
+
+DROPOUT_STREAM = 0x44524F50   # "DROP": counter word 3 of the dropout stream (the noise stream uses 0)
+
+
+def dropout_threshold(p):
+    """keep <=> random 32-bit word >= threshold; P(keep) = 1 - threshold / 2^32 (exactly 1 - p for dyadic p)."""
+    return int(min(max(np.floor(float(p) * 4294967296.0), 0.0), 4294967295.0))
+
+
+def dropout_keep(index, p, seed=0):
+    """The engine's dropout stream (include/pk_synth.h, "dropout stream"): element ``index`` (any integer array,
+    < 2^64) -> keep flag.  Word index & 3 of the Philox block with counter (lo(index >> 2), hi(index >> 2), 0, "DROP")
+    and key (lo(seed), hi(seed))."""
+    idx = np.asarray(index, dtype=np.uint64)
+    blk = idx >> np.uint64(2)
+    counter = np.stack([blk & MASK, blk >> np.uint64(32), np.zeros_like(blk),
+                        np.full_like(blk, DROPOUT_STREAM)], axis=-1)
+    r = philox4x32_10(counter, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    word = np.take_along_axis(r, (idx & np.uint64(3)).astype(np.int64)[..., None], axis=-1)[..., 0]
+    return word >= np.uint32(dropout_threshold(p))

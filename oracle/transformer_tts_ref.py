@@ -1,0 +1,193 @@
+"""Oracle: TransformerTTS single-utterance inference (test infrastructure).
+
+Restates, op for op, parakeet/models/transformer_tts/transformer_tts.py
+  TransformerTTS.inference                   :511-647  (no teacher forcing, no GST, no speaker embedding)
+and the modules it calls:
+  Encoder.forward                            fastspeech2_transformer/encoder.py:171-192
+  EncoderPrenet (tacotron2 Encoder, elayers=0) modules/tacotron2/encoder.py:150-176
+  Decoder.forward_one_step                   fastspeech2_transformer/decoder.py:190-227
+  DecoderLayer.forward (cache branch)        fastspeech2_transformer/decoder_layer.py:74-158
+  MultiHeadedAttention                       fastspeech2_transformer/attention.py:51-156
+  PositionwiseFeedForward                    fastspeech2_transformer/positionwise_feed_forward.py:41-44
+  DecoderPrenet (tacotron2 Prenet)           modules/tacotron2/decoder.py:62-81
+  Postnet                                    modules/tacotron2/decoder.py:127-198
+  subsequent_mask                            fastspeech2_transformer/mask.py:18-35
+
+Two properties of the reference loop that this restatement keeps, because they decide the numbers:
+
+* ``Decoder.forward_one_step`` applies ``self.embed`` to the WHOLE prefix ``ys`` at every step, and the decoder
+  prenet inside it calls ``F.dropout(x)`` with the defaults p = 0.5, training = True -- dropout stays on at
+  inference and ignores ``dprenet_dropout_rate`` (modules/tacotron2/decoder.py:78-81).  So at step s the
+  first decoder layer sees s freshly re-dropped rows; only the layer OUTPUTS are cached (decoder.py:213-218), and
+  layers >= 1 read the cached rows of the layer below.
+* with a cache, a layer computes the last query row only and its mask row is all ones (decoder_layer.py:110-120):
+  the self-attention of step s is unmasked over the s rows.
+
+A reproducible run needs the dropout mask injected.  ``drop`` is a callable (step, layer, rows, units) -> keep
+array of shape (rows, units); the default is the engine's counter-based dropout stream (oracle/philox_ref.py
+``dropout_keep``; include/pk_synth.h), element index ((step*(step-1)/2 + pos) * n_layers + layer) * units + unit
+with step counted from 1.  ``drop=None`` switches dropout off (x unchanged: the deterministic variant).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import philox_ref
+from .fastspeech2_ref import conv_ffn, encoder_layer, postnet, scaled_posenc
+from .nn_ref import Weights, batch_norm_eval, conv1d, layer_norm, linear, sinusoid_table
+
+DEFAULT_CFG = dict(
+    embed_dim=0, eprenet_conv_layers=0, eprenet_conv_filts=0, eprenet_conv_chans=0,
+    dprenet_layers=2, dprenet_units=256, adim=512, aheads=8, elayers=6, eunits=1024, dlayers=6, dunits=1024,
+    postnet_layers=5, postnet_filts=5, postnet_chans=256, reduction_factor=1, use_scaled_pos_enc=True)
+
+PRENET_DROPOUT_P = 0.5   # F.dropout's default; Prenet.forward passes no rate (modules/tacotron2/decoder.py:80)
+
+
+def stream_dropout(seed, n_layers, units, p=PRENET_DROPOUT_P):
+    def drop(step, layer, rows, n_units):
+        assert n_units == units
+        tri = step * (step - 1) // 2
+        pos = np.arange(rows, dtype=np.uint64)[:, None]
+        u = np.arange(units, dtype=np.uint64)[None, :]
+        idx = ((np.uint64(tri) + pos) * np.uint64(n_layers) + np.uint64(layer)) * np.uint64(units) + u
+        return philox_ref.dropout_keep(idx, p, seed)
+    return drop
+
+
+def mha(W, q_in, kv_in, n_head):
+    """MultiHeadedAttention.forward attention.py:133-156, mask None (or all ones).  q_in (B,Tq,D), kv_in (B,Tk,D).
+    Returns (output, attention weights (B, H, Tq, Tk))."""
+    B, Tq, D = q_in.shape
+    Tk = kv_in.shape[1]
+    dk = D // n_head
+    q = linear(q_in, W["linear_q.weight"], W["linear_q.bias"]).reshape(B, Tq, n_head, dk).transpose(1, 2)
+    k = linear(kv_in, W["linear_k.weight"], W["linear_k.bias"]).reshape(B, Tk, n_head, dk).transpose(1, 2)
+    v = linear(kv_in, W["linear_v.weight"], W["linear_v.bias"]).reshape(B, Tk, n_head, dk).transpose(1, 2)
+    attn = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dk), dim=-1)
+    ctx = torch.matmul(attn, v).transpose(1, 2).reshape(B, Tq, D)
+    return linear(ctx, W["linear_out.weight"], W["linear_out.bias"]), attn
+
+
+def encoder_input(W, ids, cfg):
+    """The encoder's ``embed`` Sequential (transformer_tts.py:258-277, encoder.py:112-121): Embedding(padding_idx=0)
+    [+ conv prenet + Linear] followed by ScaledPositionalEncoding."""
+    if cfg["eprenet_conv_layers"] > 0:
+        P = W.sub("embed.0.0.")
+        table = P["embed.weight"].clone()
+        table[0] = 0.0                                   # padding_idx=0 [paddle-semantics]
+        x = table[ids].transpose(1, 2)                   # tacotron2/encoder.py:150
+        for i in range(cfg["eprenet_conv_layers"]):      # Conv1D(no bias) -> BatchNorm1D -> ReLU -> Dropout(eval: off)
+            w = P[f"convs.{i}.0.weight"]
+            x = conv1d(x, w, None, padding=(w.shape[-1] - 1) // 2)
+            x = torch.relu(batch_norm_eval(x, P[f"convs.{i}.1.weight"], P[f"convs.{i}.1.bias"],
+                                           P[f"convs.{i}.1._mean"], P[f"convs.{i}.1._variance"]))
+        x = linear(x.transpose(1, 2), W["embed.0.1.weight"], W["embed.0.1.bias"])
+    else:
+        table = W["embed.0.weight"].clone()
+        table[0] = 0.0
+        x = table[ids]
+    return scaled_posenc(W.sub("embed.1."), x)
+
+
+def encode(W, ids, cfg):
+    """Encoder.forward encoder.py:171-192 with masks=None (transformer_tts.py:585)."""
+    x = encoder_input(W, ids, cfg)
+    for i in range(cfg["elayers"]):
+        x = encoder_layer(W.sub(f"encoders.{i}."), x, None, cfg["aheads"])
+    return layer_norm(x, W["after_norm.weight"], W["after_norm.bias"])
+
+
+def decoder_embed(W, ys, step, cfg, drop):
+    """decoder.embed = Sequential(Sequential(DecoderPrenet, Linear), ScaledPositionalEncoding) on the whole prefix
+    ys (1, step, odim)."""
+    x = ys
+    for j in range(cfg["dprenet_layers"]):
+        x = torch.relu(linear(x, W[f"embed.0.0.prenet.{j}.0.weight"], W[f"embed.0.0.prenet.{j}.0.bias"]))
+        if drop is not None:
+            keep = torch.as_tensor(drop(step, j, x.shape[1], x.shape[2]))
+            x = torch.where(keep.unsqueeze(0), x / (1.0 - PRENET_DROPOUT_P), torch.zeros_like(x))
+    x = linear(x, W["embed.0.1.weight"], W["embed.0.1.bias"])
+    return scaled_posenc(W.sub("embed.1."), x)
+
+
+def decoder_layer_step(W, tgt, memory, cache, n_head):
+    """DecoderLayer.forward decoder_layer.py:74-158, normalize_before=True, concat_after=False.
+    tgt (1, s, D); cache (1, s-1, D) or None.  Returns (x (1, s, D), src attention weights (H, T) of the last row)."""
+    residual = tgt
+    t = layer_norm(tgt, W["norm1.weight"], W["norm1.bias"])
+    if cache is None:
+        tq = t
+    else:
+        tq = t[:, -1:, :]
+        residual = residual[:, -1:, :]
+    x = residual + mha(W.sub("self_attn."), tq, t, n_head)[0]
+    residual = x
+    h = layer_norm(x, W["norm2.weight"], W["norm2.bias"])
+    a, attn = mha(W.sub("src_attn."), h, memory, n_head)
+    x = residual + a
+    residual = x
+    h = layer_norm(x, W["norm3.weight"], W["norm3.bias"])
+    x = residual + conv_ffn(W.sub("feed_forward."), h)
+    if cache is not None:
+        x = torch.cat([cache, x], dim=1)
+    return x, attn[0, :, -1]
+
+
+def inference(state, ids, cfg=None, threshold=0.5, minlenratio=0.0, maxlenratio=10.0, seed=0, drop="stream",
+              dtype=torch.float32, return_parts=False):
+    """TransformerTTS.inference transformer_tts.py:511-647.  ids (T,) int64 without <eos>.
+    Returns (outs (L, odim), probs (L,), att_ws (dlayers, aheads, L, T+1))."""
+    cfg = dict(DEFAULT_CFG, **(cfg or {}))
+    if cfg.get("reduction_factor", 1) != 1:
+        raise NotImplementedError("reduction_factor != 1")
+    W = Weights(state, dtype)
+    idim = (state["encoder.embed.0.weight"] if "encoder.embed.0.weight" in state
+            else state["encoder.embed.0.0.embed.weight"]).shape[0]
+    odim = state["feat_out.weight"].shape[1]
+    x = np.pad(np.asarray(ids), (0, 1), "constant", constant_values=idim - 1)      # :563-565 add <eos>
+    xs = torch.as_tensor(x).to(torch.int64).unsqueeze(0)
+    hs = encode(W.sub("encoder."), xs, cfg)                                        # :584-585
+    maxlen = int(hs.shape[1] * maxlenratio / 1)                                    # :597-598
+    minlen = int(hs.shape[1] * minlenratio / 1)
+    if drop == "stream":
+        drop = stream_dropout(seed, cfg["dprenet_layers"], cfg["dprenet_units"])
+    D = W.sub("decoder.")
+    idx = 0
+    ys = torch.zeros(1, 1, odim, dtype=dtype)                                      # :601-602
+    outs, probs, att_ws = [], [], []
+    cache = None
+    parts = {}
+    while True:
+        idx += 1
+        xdec = decoder_embed(D, ys, idx, cfg, drop)                                # decoder.py:210
+        if cache is None:
+            cache = [None] * cfg["dlayers"]
+        new_cache, att_step = [], []
+        for l in range(cfg["dlayers"]):                                            # decoder.py:214-218
+            xdec, a = decoder_layer_step(D.sub(f"decoders.{l}."), xdec, hs, cache[l], cfg["aheads"])
+            new_cache.append(xdec)
+            att_step.append(a)
+        cache = new_cache
+        z = layer_norm(xdec[:, -1], D["after_norm.weight"], D["after_norm.bias"])  # decoder.py:220-221
+        out = linear(z, W["feat_out.weight"], W["feat_out.bias"]).reshape(1, odim)  # :613-615
+        outs.append(out)
+        probs.append(torch.sigmoid(linear(z, W["prob_out.weight"], W["prob_out.bias"]))[0])   # :616
+        ys = torch.cat([ys, out.reshape(1, 1, odim)], dim=1)                       # :619-621
+        att_ws.append(torch.stack(att_step, dim=0))                                # (dlayers, H, T)
+        if int((probs[-1] >= threshold).sum()) > 0 or idx >= maxlen:               # :638-639
+            if idx < minlen:                                                       # :641-642
+                continue
+            before = torch.cat(outs, dim=0).unsqueeze(0).transpose(1, 2)           # :644-645
+            after = before
+            if cfg["postnet_layers"] > 0:
+                after = before + postnet(W.sub("postnet."), before, cfg["postnet_layers"])   # :646-648
+            mel = after.transpose(1, 2).squeeze(0)
+            probs_t = torch.cat(probs, dim=0)
+            break
+    att = torch.stack(att_ws, dim=2)                                               # (dlayers, H, L, T)
+    if return_parts:
+        parts.update(hs=hs[0], before=before[0].transpose(0, 1), zs=cache[-1][0])
+        return mel, probs_t, att, parts
+    return mel, probs_t, att

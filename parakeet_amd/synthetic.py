@@ -322,3 +322,101 @@ def speedyspeech_state(cfg=None, vocab_size=70, tone_size=7, seed=303, mean_dura
     res_block("decoder.postnet2.0", D, cfg["decoder_kernel_size"], 2)
     lin("decoder.postnet2.1", D, cfg["decoder_output_size"])
     return st
+
+
+# examples/transformer_tts/ljspeech/conf/default.yaml:19-45
+TRANSFORMER_TTS_LJSPEECH = dict(
+    embed_dim=0, eprenet_conv_layers=0, eprenet_conv_filts=0, eprenet_conv_chans=0,
+    dprenet_layers=2, dprenet_units=256, adim=512, aheads=8, elayers=6, eunits=1024, dlayers=6, dunits=1024,
+    positionwise_layer_type="conv1d", positionwise_conv_kernel_size=1,
+    postnet_layers=5, postnet_filts=5, postnet_chans=256, use_scaled_pos_enc=True,
+    encoder_normalize_before=True, decoder_normalize_before=True, reduction_factor=1,
+    init_type="xavier_uniform", init_enc_alpha=1.0, init_dec_alpha=1.0)
+
+
+def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, stop_gain=1.0):
+    """TransformerTTS state dict (parakeet/models/transformer_tts/transformer_tts.py:172-358): key names and shapes
+    are the reference's ``state_dict()``.  Encoder input layer: nn.Embedding(padding_idx=0) when
+    ``eprenet_conv_layers == 0`` (the LJSpeech recipe), else Sequential(EncoderPrenet, Linear) (:258-277); decoder
+    input layer: Sequential(DecoderPrenet, Linear) (:311-321).  ``stop_bias`` / ``stop_gain`` shift and scale the
+    stop-token head ``prob_out`` so that a test can choose where sigmoid(.) >= threshold fires."""
+    cfg = dict(TRANSFORMER_TTS_LJSPEECH, **(cfg or {}))
+    rng = np.random.default_rng(seed)
+    A, H = cfg["adim"], cfg["aheads"]
+    assert A % H == 0
+    st = {}
+
+    def small(n, scale=0.1):
+        return rng.uniform(-scale, scale, size=(n,)).astype(np.float32)
+
+    def ln(prefix, n):
+        st[prefix + ".weight"] = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+        st[prefix + ".bias"] = small(n)
+
+    def lin(prefix, cin, cout):
+        st[prefix + ".weight"] = _xavier(rng, (cin, cout))
+        st[prefix + ".bias"] = small(cout)
+
+    def bn(prefix, n):
+        st[prefix + ".weight"] = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+        st[prefix + ".bias"] = small(n)
+        st[prefix + "._mean"] = small(n)
+        st[prefix + "._variance"] = rng.uniform(0.5, 1.5, size=(n,)).astype(np.float32)
+
+    def mha(prefix):
+        for nm in ("q", "k", "v", "out"):
+            lin(f"{prefix}.linear_{nm}", A, A)
+
+    if cfg["eprenet_conv_layers"] > 0:
+        E, C, kf = cfg["embed_dim"], cfg["eprenet_conv_chans"], cfg["eprenet_conv_filts"]
+        emb = _xavier(rng, (idim, E))
+        emb[0] = 0.0
+        st["encoder.embed.0.0.embed.weight"] = emb
+        for i in range(cfg["eprenet_conv_layers"]):
+            st[f"encoder.embed.0.0.convs.{i}.0.weight"] = _xavier(rng, (C, E if i == 0 else C, kf))
+            bn(f"encoder.embed.0.0.convs.{i}.1", C)
+        lin("encoder.embed.0.1", C, A)
+    else:
+        emb = _xavier(rng, (idim, A))
+        emb[0] = 0.0
+        st["encoder.embed.0.weight"] = emb
+    st["encoder.embed.1.alpha"] = np.array(cfg["init_enc_alpha"], dtype=np.float32)
+    k = cfg["positionwise_conv_kernel_size"]
+    kind = cfg.get("positionwise_layer_type", "conv1d")
+    for i in range(cfg["elayers"]):
+        p = f"encoder.encoders.{i}"
+        mha(p + ".self_attn")
+        U = cfg["eunits"]
+        st[f"{p}.feed_forward.w_1.weight"] = _xavier(rng, (A, U) if kind == "linear" else (U, A, k))
+        st[f"{p}.feed_forward.w_1.bias"] = small(U)
+        st[f"{p}.feed_forward.w_2.weight"] = _xavier(rng, (A, U, k) if kind == "conv1d" else (U, A))
+        st[f"{p}.feed_forward.w_2.bias"] = small(A)
+        ln(p + ".norm1", A)
+        ln(p + ".norm2", A)
+    ln("encoder.after_norm", A)
+    P = cfg["dprenet_units"]
+    for j in range(cfg["dprenet_layers"]):
+        lin(f"decoder.embed.0.0.prenet.{j}.0", odim if j == 0 else P, P)
+    lin("decoder.embed.0.1", P, A)
+    st["decoder.embed.1.alpha"] = np.array(cfg["init_dec_alpha"], dtype=np.float32)
+    for i in range(cfg["dlayers"]):
+        p = f"decoder.decoders.{i}"
+        mha(p + ".self_attn")
+        mha(p + ".src_attn")
+        lin(p + ".feed_forward.w_1", A, cfg["dunits"])
+        lin(p + ".feed_forward.w_2", cfg["dunits"], A)
+        for n in (1, 2, 3):
+            ln(f"{p}.norm{n}", A)
+    ln("decoder.after_norm", A)
+    r = cfg["reduction_factor"]
+    lin("feat_out", A, odim * r)
+    lin("prob_out", A, r)
+    st["prob_out.weight"] = (st["prob_out.weight"] * stop_gain).astype(np.float32)
+    st["prob_out.bias"] = (st["prob_out.bias"] + stop_bias).astype(np.float32)
+    n, ch, kf = cfg["postnet_layers"], cfg["postnet_chans"], cfg["postnet_filts"]
+    for j in range(n):
+        cin = odim if j == 0 else ch
+        cout = odim if j == n - 1 else ch
+        st[f"postnet.postnet.{j}.0.weight"] = _xavier(rng, (cout, cin, kf))
+        bn(f"postnet.postnet.{j}.1", cout)
+    return st

@@ -1,0 +1,19 @@
+"""Case tables shared by tools/make_golden_ar.py (which runs the reference source) and the tests that replay them
+against the oracle and the HIP engine.  Each TransformerTTS case: name, config overrides on
+parakeet_amd.synthetic.TRANSFORMER_TTS_LJSPEECH, idim, tokens, seed (weights, ids = 700 + seed, dropout stream),
+keyword arguments of synthetic.transformer_tts_state, keyword arguments of inference()."""
+
+TTS_CASES = [
+    # the LJSpeech recipe's layout (embedding input layer, 8 heads x 64, k = 1 position-wise convs); stops at maxlen
+    ("lj", dict(elayers=2, dlayers=3, postnet_layers=5), 40, 9, 11, dict(stop_bias=-6.0), dict(maxlenratio=1.5)),
+    # the stop token fires through the normal path (sigmoid(prob_out) >= threshold), 0.09 away from the threshold
+    ("stop", dict(elayers=1, dlayers=2, postnet_layers=2), 40, 6, 12, dict(stop_bias=0.0, stop_gain=2.0),
+     dict(maxlenratio=6.0, threshold=0.5)),
+    # stop probabilities above the threshold from the first step: minlenratio keeps the loop going (:641-642)
+    ("minlen", dict(elayers=1, dlayers=1, postnet_layers=0), 40, 5, 13, dict(stop_bias=3.0),
+     dict(minlenratio=1.5, maxlenratio=3.0)),
+    # encoder conv prenet (Embedding -> [Conv1D k5 -> BatchNorm -> ReLU] x 2 -> Linear), 4 heads x 64, k = 3 FFN convs
+    ("eprenet", dict(elayers=1, dlayers=2, postnet_layers=2, embed_dim=128, eprenet_conv_layers=2, eprenet_conv_filts=5,
+                     eprenet_conv_chans=64, adim=256, aheads=4, eunits=512, dunits=512, dprenet_units=128,
+                     positionwise_conv_kernel_size=3), 30, 8, 14, dict(stop_bias=-6.0), dict(maxlenratio=1.0)),
+]

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Golden vectors of the autoregressive acoustic models from the REFERENCE's own Python source
+(/root/reference/parakeet/models/transformer_tts/transformer_tts.py, models/tacotron2.py) executed over the
+torch-backed paddle stand-in.  Build container only.
+
+Both models keep the decoder prenet's dropout ON at inference (modules/tacotron2/decoder.py:78-81,
+models/tacotron2.py:61-80).  The stand-in's ``F.dropout`` hands every active call to DROPOUT_HOOK, which applies the
+engine's counter-based dropout stream (oracle/philox_ref.py ``dropout_keep``), so the vectors are reproducible and the
+HIP engine can be compared with them bit for bit in its decisions (keep / drop) and to fp32 accuracy in its values.
+Weights are regenerated from seeds by parakeet_amd.synthetic."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+ref_import.setup()
+import paddle  # noqa: E402  (the shim)
+import paddle.nn.functional as PF  # noqa: E402
+
+from oracle import philox_ref  # noqa: E402
+from oracle import transformer_tts_ref as tt_ref  # noqa: E402
+from parakeet_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(ref_import.ROOT, "tests", "golden")
+
+
+class TransformerTTSDropout:
+    """F.dropout hook for TransformerTTS.inference: the prenet is applied to the whole prefix (1, step, units) once per
+    decoding step, layer after layer, so the step is the row count and the layer is the call count modulo n_layers."""
+
+    def __init__(self, seed, n_layers, units):
+        self.drop = tt_ref.stream_dropout(seed, n_layers, units)
+        self.n_layers, self.calls = n_layers, 0
+
+    def __call__(self, x, p):
+        assert p == 0.5 and x.dim() == 3 and x.shape[0] == 1
+        layer = self.calls % self.n_layers
+        self.calls += 1
+        keep = torch.as_tensor(self.drop(int(x.shape[1]), layer, int(x.shape[1]), int(x.shape[2])))
+        return torch.where(keep.unsqueeze(0), x / (1.0 - p), torch.zeros_like(x))
+
+
+sys.path.insert(0, os.path.join(ref_import.ROOT, "tests"))
+from ar_cases import TTS_CASES  # noqa: E402
+
+
+def golden_transformer_tts():
+    ttm = ref_import.load("parakeet.models.transformer_tts.transformer_tts")
+    out = {}
+    for name, over, idim, T, seed, skw, kw in TTS_CASES:
+        cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, **over)
+        state = syn.transformer_tts_state(idim, 80, cfg, seed=seed, **skw)
+        model = ttm.TransformerTTS(idim=idim, odim=80, **cfg)
+        model.set_state_dict(state)
+        model.eval()
+        ids = syn.phoneme_ids(T, idim=idim, seed=700 + seed)
+        PF.DROPOUT_HOOK = TransformerTTSDropout(seed=seed, n_layers=cfg["dprenet_layers"], units=cfg["dprenet_units"])
+        try:
+            with paddle.no_grad():
+                mel, probs, att = model.inference(paddle.to_tensor(ids), **kw)
+        finally:
+            PF.DROPOUT_HOOK = None
+        out[f"{name}_ids"] = ids
+        out[f"{name}_seed"] = np.array(seed)
+        out[f"{name}_mel"] = mel.numpy().astype(np.float32)
+        out[f"{name}_probs"] = probs.numpy().astype(np.float32)
+        out[f"{name}_att"] = att.numpy().astype(np.float32)
+        print("transformer_tts", name, out[f"{name}_mel"].shape, out[f"{name}_att"].shape,
+              "probs", np.round(out[f"{name}_probs"], 3)[:12])
+    np.savez_compressed(os.path.join(OUT, "transformer_tts.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["transformer_tts", "tacotron2"]
+    if "transformer_tts" in which:
+        golden_transformer_tts()
+    if "tacotron2" in which and "golden_tacotron2" in globals():
+        golden_tacotron2()

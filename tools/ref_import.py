@@ -25,7 +25,8 @@ def setup():
         sys.modules[name] = m
         return m
     ns("parakeet", os.path.join(REF, "parakeet"))
-    for sub in ("models", "modules", "utils", "models.fastspeech2", "models.parallel_wavegan", "models.speedyspeech"):
+    for sub in ("models", "modules", "utils", "models.fastspeech2", "models.parallel_wavegan", "models.speedyspeech",
+                "models.transformer_tts", "modules.fastspeech2_transformer", "modules.tacotron2"):
         ns("parakeet." + sub, os.path.join(REF, "parakeet", *sub.split(".")))
     # parakeet.utils.checkpoint is imported by waveflow.py at module level only for from_pretrained
     ck = types.ModuleType("parakeet.utils.checkpoint")
