@@ -15,6 +15,8 @@
  *               (_forward(is_inference=True) :377-466),
  *               FastSpeech2Inference.forward :668-671
  *   pk_wf_*     parakeet/models/waveflow.py ConditionalWaveFlow.infer :785-805
+ *   pk_tts_*    parakeet/models/transformer_tts/transformer_tts.py TransformerTTS.inference :511-647,
+ *               TransformerTTSInference.forward :757-767
  *   pk_stft_mel parakeet/modules/audio.py STFT.magnitude :202-215 + MelScale :226-229,
  *               parakeet/data/get_feats.py LogMelFBank.get_log_mel_fbank :80-88
  *
@@ -58,13 +60,15 @@ enum {
     PK_PWG_C_HAS_CONTEXT = 2,  /* pk_pwg_infer: mel rows already carry aux_context_window frames on both
                                   sides of every utterance (PWGGenerator.forward); default: the engine
                                   replicate-pads (PWGGenerator.inference) */
-    PK_APPLY_NORMALIZER = 4    /* pk_fs2_decode / pk_ss_decode / pk_pwg_infer: apply the ZScore registered with
+    PK_APPLY_NORMALIZER = 4,   /* pk_fs2_decode / pk_ss_decode / pk_pwg_infer: apply the ZScore registered with
                                   pk_*_set_normalizer in THIS call (the *Inference wrappers of the reference:
                                   FastSpeech2Inference.forward fastspeech2.py:668-671, PWGInference.forward
                                   parallel_wavegan.py:772-775, SpeedySpeechInference.forward :221-231).
                                   Without it the call stays in the model's own (normalised) domain, as
                                   model.inference() does in the reference -- the registered statistics are
                                   per-handle state, their use is per call */
+    PK_TTS_KEEP_ATT = 8        /* pk_tts_infer: keep the encoder-decoder attention weights (TransformerTTS.inference's
+                                  third return value) for pk_tts_read */
 };
 
 typedef struct pk_ctx pk_ctx;
@@ -311,6 +315,76 @@ int pk_ss_decode(pk_ss* h, float* mel_out, int32_t flags);
 /* Test taps of the last encode: 0 = encodings (T_b, H), 1 = log-durations (T_b), 2 = durations (T_b). */
 int pk_ss_debug_read(pk_ss* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
 void pk_ss_destroy(pk_ss* h);
+
+/* ----------------------------------------------------------- dropout stream */
+/* Tacotron2-style decoder prenets keep dropout ON at inference -- TransformerTTS through
+ * modules/tacotron2/decoder.py:78-81 (F.dropout(x): p = 0.5, training = True whatever model.eval() says),
+ * Tacotron2 through models/tacotron2.py:76-79 (training=True) -- so the reference's outputs depend on Paddle's
+ * generator.  The engine draws the masks from a counter-based stream instead, a pure function of (seed, element
+ * index): Philox4x32-10 with key = seed and counter = (lo(e >> 2), hi(e >> 2), 0, 0x44524F50); element e uses
+ * word e & 3 of that block; keep <=> word >= floor(p * 2^32); kept values are multiplied by 1 / (1 - p)
+ * (upscale_in_train, paddle.nn.functional.dropout's default mode).  oracle/philox_ref.py restates it; the golden
+ * vectors of tests/golden/ come from the reference source run with this stream injected.
+ * The element index of a model is stated with its entry point. */
+
+/* ----------------------------------------------------------- TransformerTTS */
+/* TransformerTTS(idim, odim, **model_cfg) -- parakeet/models/transformer_tts/transformer_tts.py:172-358.
+ * Built: the embedding or conv-prenet encoder input layer, pre-norm blocks, the decoder prenet, the stop token,
+ * the postnet.  Refused with PK_EUNSUPPORTED: post-norm / concat_after blocks, reduction_factor != 1,
+ * spk_embed_dim, use_gst, dprenet_layers == 0. */
+typedef struct {
+    int32_t idim, odim;
+    int32_t embed_dim, eprenet_conv_layers, eprenet_conv_chans, eprenet_conv_filts;   /* layers 0: nn.Embedding(idim, adim) (:272-277) */
+    int32_t dprenet_layers, dprenet_units;
+    int32_t adim, aheads;
+    int32_t elayers, eunits, dlayers, dunits;
+    int32_t postnet_layers, postnet_chans, postnet_filts;
+    int32_t positionwise_layer_type;       /* encoder only, 0 conv1d, 1 linear, 2 conv1d-linear (encoder.py:145-170) */
+    int32_t positionwise_conv_kernel_size;
+    int32_t use_scaled_pos_enc, use_batch_norm;
+    int32_t encoder_normalize_before, decoder_normalize_before;
+    int32_t encoder_concat_after, decoder_concat_after;
+    int32_t reduction_factor;
+    int32_t spk_embed_dim;                 /* 0 = None */
+    int32_t use_gst;
+} pk_tts_cfg;
+typedef struct pk_tts pk_tts;
+
+int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out);
+/* set_state_dict entry ("decoder.decoders.2.src_attn.linear_q.weight", "decoder.embed.0.0.prenet.1.0.bias", ...). */
+int pk_tts_set_param(pk_tts* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* TransformerTTSInference's normalizer (:757-767): mel -> mel * sigma + mu, applied by pk_tts_read under
+ * PK_APPLY_NORMALIZER.  NULL,NULL removes it. */
+int pk_tts_set_normalizer(pk_tts* h, const float* mu, const float* sigma, int32_t n);
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math); env PK_TTS_MATH=f32. */
+int pk_tts_set_math(pk_tts* h, int32_t mode);
+/* Decoder-prenet dropout: 1 (default) = the dropout stream above with p = 0.5, element index
+ * ((s*(s-1)/2 + pos) * dprenet_layers + layer) * dprenet_units + unit for decoding step s = 1, 2, ... and prefix
+ * position pos < s (the reference re-applies the prenet to the whole prefix at every step, decoder.py:210);
+ * 0 = no dropout (deterministic variant; not what the reference computes). */
+int pk_tts_set_dropout(pk_tts* h, int32_t on);
+int pk_tts_finalize(pk_tts* h);
+/* TransformerTTS.inference (:511-647) for a packed batch, up to (not including) the postnet: <eos> = idim - 1 is
+ * appended to every utterance (:563-565), the encoder runs once, then the decoder is stepped until every utterance
+ * has stopped: utterance b ends at the first step s >= int(T_b * minlenratio) with sigmoid(prob_out) >= threshold
+ * or s >= int(T_b * maxlenratio), T_b counting <eos> (:597-598, :638-642).
+ *   ids      HOST int64, packed by utterance, WITHOUT <eos>;  tok_lens HOST (B)
+ *   seeds    HOST (B) dropout-stream seed per utterance, or NULL = seed 0 for every utterance
+ *   out_frames (B) host: L_b (the per-step sync the reference has at :638)
+ * flags: PK_TTS_KEEP_ATT keeps the encoder-decoder attention weights for pk_tts_read. */
+int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int32_t B, double threshold,
+                 double minlenratio, double maxlenratio, const uint64_t* seeds, int32_t flags, int32_t* out_frames);
+/* Postnet + outputs of the last pk_tts_infer (:644-651).
+ *   mel_out   packed (sum(L_b), odim): outs + postnet(outs), de-normalised under PK_APPLY_NORMALIZER
+ *   probs_out packed (sum(L_b)) stop probabilities, or NULL
+ *   att_out   per utterance (dlayers, aheads, L_b, T_b) encoder-decoder attention weights, utterances one after
+ *             another, or NULL; needs PK_TTS_KEEP_ATT at infer
+ * flags: PK_HOST_IO if the three are host pointers. */
+int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* att_out, int32_t flags);
+/* Test taps of the last infer: 0 = encoder output hs (T_b, adim), 1 = outs before the postnet (L_b, odim),
+ * 2 = last decoder layer's output rows (L_b, adim). */
+int pk_tts_debug_read(pk_tts* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
+void pk_tts_destroy(pk_tts* h);
 
 /* ------------------------------------------------- STFT / mel / log features */
 /* parakeet/modules/audio.py STFT (:74-215) + MelScale (:218-229); host twin

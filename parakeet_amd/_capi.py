@@ -18,6 +18,7 @@ PK_OK = 0
 PK_HOST_IO = 1
 PK_PWG_C_HAS_CONTEXT = 2
 PK_APPLY_NORMALIZER = 4
+PK_TTS_KEEP_ATT = 8
 PK_PWG_MATH_F32, PK_PWG_MATH_BF16X3, PK_PWG_MATH_F16X3 = 0, 1, 2
 _EXC = {
     -1: ValueError,
@@ -66,6 +67,16 @@ class SsCfg(C.Structure):
                 ("decoder_hidden_size", C.c_int32), ("decoder_output_size", C.c_int32),
                 ("decoder_kernel_size", C.c_int32), ("n_decoder_dilations", C.c_int32),
                 ("decoder_dilations", C.c_int32 * 32), ("same_padding_resets_dilation", C.c_int32)]
+
+
+class TtsCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "idim", "odim", "embed_dim", "eprenet_conv_layers", "eprenet_conv_chans", "eprenet_conv_filts",
+        "dprenet_layers", "dprenet_units", "adim", "aheads", "elayers", "eunits", "dlayers", "dunits",
+        "postnet_layers", "postnet_chans", "postnet_filts", "positionwise_layer_type",
+        "positionwise_conv_kernel_size", "use_scaled_pos_enc", "use_batch_norm", "encoder_normalize_before",
+        "decoder_normalize_before", "encoder_concat_after", "decoder_concat_after", "reduction_factor",
+        "spk_embed_dim", "use_gst")]
 
 
 class MelCfg(C.Structure):
@@ -130,6 +141,17 @@ def _declare(lib):
         "pk_ss_decode": (C.c_int, [vp, f32p, i32]),
         "pk_ss_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
         "pk_ss_destroy": (None, [vp]),
+        "pk_tts_create": (C.c_int, [vp, C.POINTER(TtsCfg), C.POINTER(vp)]),
+        "pk_tts_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
+        "pk_tts_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
+        "pk_tts_set_math": (C.c_int, [vp, i32]),
+        "pk_tts_set_dropout": (C.c_int, [vp, i32]),
+        "pk_tts_finalize": (C.c_int, [vp]),
+        "pk_tts_infer": (C.c_int, [vp, i64p, i32p, i32, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_uint64), i32,
+                                   i32p]),
+        "pk_tts_read": (C.c_int, [vp, f32p, f32p, f32p, i32]),
+        "pk_tts_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
+        "pk_tts_destroy": (None, [vp]),
         "pk_mel_create": (C.c_int, [vp, C.POINTER(MelCfg), f32p, f32p, C.POINTER(vp)]),
         "pk_mel_num_frames": (C.c_int, [vp, i32, i32p]),
         "pk_mel_run": (C.c_int, [vp, f32p, i32p, i32, f32p, i32, i32]),

@@ -23,13 +23,14 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "pk_fft.h"
 #include "pk_gemm.h"
 #include "pk_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int FS2_MAX_HEADS = 16;   // (q|k|v, head) magnitude-bound constants are passed to a kernel by value
+constexpr int FS2_MAX_HEADS = PK_FFT_MAX_HEADS;   // (q|k|v, head) magnitude-bound constants are passed to a kernel by value
 
 namespace {
 
@@ -62,7 +63,7 @@ __global__ void k_embed(const int* __restrict__ tok, const int* __restrict__ row
 // LayerNorm over the channel axis, one wave per row (nn.LayerNorm, eps 1e-5; also
 // LayerNorm(dim=1) of the predictors, which is the same thing in channels-last).
 // Gap rows -> 0.
-constexpr int LN_MAXPER = 8;
+constexpr int LN_MAXPER = PK_FFT_LN_MAXPER;
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ g,
                                                    const float* __restrict__ b, const int* __restrict__ row_utt,
                                                    int rows, int C, float eps, float* __restrict__ y,
@@ -775,22 +776,9 @@ __global__ __launch_bounds__(256) void k_add_tone(float* __restrict__ hs, const 
     for (int c = threadIdx.x; c < A; c += blockDim.x) hs[(long)r * A + c] += src[c];
 }
 
-struct Dense {
-    size_t w = 0, b = 0;   // offsets (floats) into the weight arena; b == SIZE_MAX: no bias
-    size_t wh = (size_t)-1;   // offset (halves) of the split-fp16 fragments, SIZE_MAX if Cin % 32 != 0
-    int Cin = 0, N = 0, taps = 1, pad = 0;
-    // |y[r, n]| <= c1 * max|x[r + tap, :]| + c0 with c1 = max_n sum_k |W[k, n]|, c0 = max_n |bias[n]|: an upper
-    // bound on the magnitude of this layer's output rows, used as the block maximum of the NEXT split-fp16 GEMM's
-    // operand scale (pk_split.h) so that no pass over the activations is needed.  A bound that is loose by 2^k
-    // only moves the scheme's error floor from 2^-39 to 2^(k-39) of the block maximum (fp32 itself: 2^-24).
-    float c1 = 0.f, c0 = 0.f;
-};
-
-struct FftLayer {
-    size_t ln1_g, ln1_b, ln2_g, ln2_b;
-    Dense qkv, out, ffn1, ffn2;
-    float qkv_c1[3 * FS2_MAX_HEADS] = {0}, qkv_c0[3 * FS2_MAX_HEADS] = {0};   // the same bound per (q|k|v, head)
-};
+typedef pk_fft_dense Dense;
+typedef pk_fft_layer FftLayer;
+typedef pk_fft_timeline Timeline;
 
 struct Predictor {
     std::vector<Dense> conv;
@@ -800,32 +788,12 @@ struct Predictor {
     int chans;
 };
 
-struct Timeline {
-    int B = 0, rows = 0;
-    std::vector<int> seg_start, seg_len, row_utt, row_pos;
-    pk_dbuf d_tab;  // [seg_start B][seg_len B][row_utt rows_alloc][row_pos rows_alloc]
-    const int* d_seg_start() const { return d_tab.as<int>(); }
-    const int* d_seg_len() const { return d_tab.as<int>() + B; }
-    const int* d_row_utt() const { return d_tab.as<int>() + 2 * B; }
-    const int* d_row_pos() const { return d_tab.as<int>() + 2 * B + rows_alloc; }
-    int rows_alloc = 0;
-    void release() { d_tab.release(); }
-};
-
-struct pk_fs2 {
-    pk_ctx* ctx = nullptr;
+struct pk_fs2 : pk_fft_core {
     pk_fs2_cfg cfg;
     pk_param_map params;
     bool finalized = false;
     int gapr = 2;
-    int max_len = 0;
-    // weights
-    std::vector<float> arena_h;
-    pk_dbuf arena;
-    std::vector<uint16_t> arena16_h;
-    pk_dbuf arena16;
-    int math = PK_GEMM_MATH_F16X3;   // dense layers: 3-term split-fp16 MFMA (fp32-equivalent error) or exact fp32
-    bool attn_lds = getenv("PK_FS2_ATTN_NO_LDS") == nullptr;   // measurement switch: per-wave K/V loads instead
+    // weights (arena, math mode, positional table and the FFT-stack buffers: pk_fft_core)
     size_t emb_table = 0, enc_after_g = 0, enc_after_b = 0, dec_after_g = 0, dec_after_b = 0;
     float alpha_enc = 1.f, alpha_dec = 1.f, xscale = 1.f;
     std::vector<FftLayer> enc, dec;
@@ -845,29 +813,23 @@ struct pk_fs2 {
     size_t out_scale = 0, out_shift = 0;
     bool has_out_affine = false;
     std::vector<float> h_out_scale, h_out_shift;
-    pk_dbuf d_pe, d_div;
     // per-call state
     Timeline tl_tok, tl_frm;
-    pk_dbuf d_lnamax, d_cbnd, d_fbnd, d_segb;
-    bool no_bounds = getenv("PK_FS2_NO_BOUNDS") != nullptr;   // measurement switch: block maxima by passes over the data
-    pk_dbuf d_tok, d_x, d_h, d_qkv, d_ctx, d_f, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
+    pk_dbuf d_tok, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
         d_before, d_q1, d_q2, d_rowmap, d_dbg_up, d_zs, d_mel_stage;
     std::vector<int> frames;   // per utterance, result of encode
     bool encoded = false;
     bool debug = false;
-
-    const float* W(size_t off) const { return arena.as<float>() + off; }
 };
 
-static const int LEAD = 8;  // rows of margin in front of every activation buffer
+static const int LEAD = PK_FFT_LEAD;  // rows of margin in front of every activation buffer
 
-static int act_reserve(pk_dbuf& buf, int rows, int C) {
+int pk_fft_act_reserve(pk_dbuf& buf, int rows, int C) {
     const size_t r = (size_t)((rows + PK_GEMM_BM - 1) / PK_GEMM_BM) * PK_GEMM_BM + 2 * LEAD;
     return buf.reserve(r * C * sizeof(float));
 }
-static float* act_ptr(const pk_dbuf& buf, int C) { return buf.as<float>() + (size_t)LEAD * C; }
 
-static int build_timeline(pk_ctx* ctx, Timeline& tl, const int* lens, int B, int gapr) {
+int pk_fft_build_timeline(pk_ctx* ctx, Timeline& tl, const int* lens, int B, int gapr) {
     tl.B = B;
     tl.seg_start.resize(B);
     tl.seg_len.assign(lens, lens + B);
@@ -942,6 +904,10 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
     pk_fs2* h = new pk_fs2();
     h->ctx = ctx;
     h->cfg = c;
+    h->adim = c.adim;
+    h->aheads = c.aheads;
+    h->attn_lds = getenv("PK_FS2_ATTN_NO_LDS") == nullptr;
+    h->no_bounds = getenv("PK_FS2_NO_BOUNDS") != nullptr;
     h->gapr = gapr;
     if (const char* e = getenv("PK_FS2_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     if (gapr > LEAD) { delete h; PK_FAIL(PK_EUNSUPPORTED, "conv kernel too wide"); }
@@ -970,23 +936,7 @@ extern "C" int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* si
     return PK_OK;
 }
 
-namespace {
-struct Arena {
-    std::vector<float>& v;
-    std::vector<uint16_t>* v16 = nullptr;
-    size_t put(const std::vector<float>& x) {
-        size_t o = (v.size() + 3) & ~(size_t)3;  // 16-byte alignment
-        v.resize(o);
-        v.insert(v.end(), x.begin(), x.end());
-        return o;
-    }
-    size_t put16(const std::vector<uint16_t>& x) {
-        size_t o = (v16->size() + 7) & ~(size_t)7;
-        v16->resize(o);
-        v16->insert(v16->end(), x.begin(), x.end());
-        return o;
-    }
-};
+typedef pk_fft_arena Arena;
 
 // c1 = max over columns [n0, n1) of sum_k |W[k, n]|, c0 = max |bias[n]| (see Dense)
 static void dense_bound(const std::vector<float>& kn, const std::vector<float>* bias, int K, int N, int n0, int n1,
@@ -1002,7 +952,7 @@ static void dense_bound(const std::vector<float>& kn, const std::vector<float>* 
     c0 = (float)(m0 * (1.0 + 1e-6));
 }
 
-int add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<float>* bias, int Cin, int taps,
+int pk_fft_add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<float>* bias, int Cin, int taps,
                  int N, Dense& d) {
     std::vector<float> packed;
     pk_gemm_pack(kn.data(), Cin * taps, N, packed);
@@ -1021,32 +971,70 @@ int add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<floa
     return PK_OK;
 }
 
-int add_conv(Arena& ar, const pk_param_map& P, const std::string& base, int Cout, int Cin, int k, bool bias,
+int pk_fft_add_conv(Arena& ar, const pk_param_map& P, const std::string& base, int Cout, int Cin, int k, bool bias,
              Dense& d) {
     std::vector<float> w, kn, b;
     PK_TRY(pk_get_weight(P, base, {Cout, Cin, k}, w));
     pk_conv_to_kn(w.data(), Cout, Cin, k, kn);
     if (bias) PK_TRY(pk_get_vector(P, base + ".bias", Cout, b));
-    return add_dense_kn(ar, kn, bias ? &b : nullptr, Cin, k, Cout, d);
+    return pk_fft_add_dense_kn(ar, kn, bias ? &b : nullptr, Cin, k, Cout, d);
 }
 
-int add_vec(Arena& ar, const pk_param_map& P, const std::string& name, int n, size_t& off) {
+int pk_fft_add_vec(Arena& ar, const pk_param_map& P, const std::string& name, int n, size_t& off) {
     std::vector<float> v;
     PK_TRY(pk_get_vector(P, name, n, v));
     off = ar.put(v);
     return PK_OK;
 }
 
-int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int units,
+int pk_fft_add_linear(Arena& ar, const pk_param_map& P, const std::string& base, int Cin, int N, Dense& d) {
+    std::vector<float> w, b;
+    PK_TRY(pk_get_weight(P, base, {Cin, N}, w));   // Linear weight [in, out]
+    PK_TRY(pk_get_vector(P, base + ".bias", N, b));
+    return pk_fft_add_dense_kn(ar, w, &b, Cin, 1, N, d);
+}
+
+int pk_fft_add_conv_bn(Arena& ar, const pk_param_map& P, const std::string& conv_base, const std::string& bn_base,
+                       int Cout, int Cin, int k, Dense& d) {
+    std::vector<float> w, g, b, mean, var, kn, bias(Cout);
+    PK_TRY(pk_get_weight(P, conv_base, {Cout, Cin, k}, w));
+    PK_TRY(pk_get_vector(P, bn_base + ".weight", Cout, g));
+    PK_TRY(pk_get_vector(P, bn_base + ".bias", Cout, b));
+    PK_TRY(pk_get_vector(P, bn_base + "._mean", Cout, mean));
+    PK_TRY(pk_get_vector(P, bn_base + "._variance", Cout, var));
+    // fold BatchNorm1D (eval, eps 1e-5) into the bias-free conv (tacotron2/decoder.py:133-147)
+    const size_t per = (size_t)Cin * k;
+    for (int o = 0; o < Cout; ++o) {
+        const double s = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+        for (size_t i = 0; i < per; ++i) w[o * per + i] = (float)((double)w[o * per + i] * s);
+        bias[o] = (float)((double)b[o] - (double)mean[o] * s);
+    }
+    pk_conv_to_kn(w.data(), Cout, Cin, k, kn);
+    return pk_fft_add_dense_kn(ar, kn, &bias, Cin, k, Cout, d);
+}
+
+int pk_fft_add_postnet(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int odim, int chans,
+                       int filts, std::vector<Dense>& out) {
+    out.resize(n_layers);
+    for (int j = 0; j < n_layers; ++j) {
+        const int cin = j == 0 ? odim : chans;
+        const int cout = j == n_layers - 1 ? odim : chans;
+        const std::string p = prefix + ".postnet." + std::to_string(j);
+        PK_TRY(pk_fft_add_conv_bn(ar, P, p + ".0", p + ".1", cout, cin, filts, out[j]));
+    }
+    return PK_OK;
+}
+
+int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int units,
                   int k, int ff_type, int heads, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b) {
     out.resize(n_layers);
     for (int l = 0; l < n_layers; ++l) {
         const std::string p = prefix + ".encoders." + std::to_string(l);
         FftLayer& L = out[l];
-        PK_TRY(add_vec(ar, P, p + ".norm1.weight", A, L.ln1_g));
-        PK_TRY(add_vec(ar, P, p + ".norm1.bias", A, L.ln1_b));
-        PK_TRY(add_vec(ar, P, p + ".norm2.weight", A, L.ln2_g));
-        PK_TRY(add_vec(ar, P, p + ".norm2.bias", A, L.ln2_b));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm1.weight", A, L.ln1_g));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm1.bias", A, L.ln1_b));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm2.weight", A, L.ln2_g));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm2.bias", A, L.ln2_b));
         // fused q|k|v projection: Linear weights are [in, out] (paddle)
         std::vector<float> wq, wk, wv, bq, bk, bv, kn((size_t)A * 3 * A), bias(3 * A);
         PK_TRY(pk_get_weight(P, p + ".self_attn.linear_q", {A, A}, wq));
@@ -1066,7 +1054,7 @@ int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, i
             bias[A + o] = bk[o];
             bias[2 * A + o] = bv[o];
         }
-        PK_TRY(add_dense_kn(ar, kn, &bias, A, 1, 3 * A, L.qkv));
+        PK_TRY(pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 3 * A, L.qkv));
         for (int part = 0; part < 3; ++part)
             for (int hd = 0; hd < heads && hd < FS2_MAX_HEADS; ++hd)
                 dense_bound(kn, &bias, A, 3 * A, part * A + hd * (A / heads), part * A + (hd + 1) * (A / heads),
@@ -1074,30 +1062,31 @@ int add_fft_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, i
         std::vector<float> wo, bo;
         PK_TRY(pk_get_weight(P, p + ".self_attn.linear_out", {A, A}, wo));
         PK_TRY(pk_get_vector(P, p + ".self_attn.linear_out.bias", A, bo));
-        PK_TRY(add_dense_kn(ar, wo, &bo, A, 1, A, L.out));
+        PK_TRY(pk_fft_add_dense_kn(ar, wo, &bo, A, 1, A, L.out));
         // position-wise layer (encoder.py:145-170): conv1d = (k, k), conv1d-linear = (k, Linear), linear = 2 x Linear
         if (ff_type == 1) {
             std::vector<float> w, b;
             PK_TRY(pk_get_weight(P, p + ".feed_forward.w_1", {A, units}, w));
             PK_TRY(pk_get_vector(P, p + ".feed_forward.w_1.bias", units, b));
-            PK_TRY(add_dense_kn(ar, w, &b, A, 1, units, L.ffn1));
+            PK_TRY(pk_fft_add_dense_kn(ar, w, &b, A, 1, units, L.ffn1));
         } else {
-            PK_TRY(add_conv(ar, P, p + ".feed_forward.w_1", units, A, k, true, L.ffn1));
+            PK_TRY(pk_fft_add_conv(ar, P, p + ".feed_forward.w_1", units, A, k, true, L.ffn1));
         }
         if (ff_type == 0) {
-            PK_TRY(add_conv(ar, P, p + ".feed_forward.w_2", A, units, k, true, L.ffn2));
+            PK_TRY(pk_fft_add_conv(ar, P, p + ".feed_forward.w_2", A, units, k, true, L.ffn2));
         } else {
             std::vector<float> w, b;
             PK_TRY(pk_get_weight(P, p + ".feed_forward.w_2", {units, A}, w));
             PK_TRY(pk_get_vector(P, p + ".feed_forward.w_2.bias", A, b));
-            PK_TRY(add_dense_kn(ar, w, &b, units, 1, A, L.ffn2));
+            PK_TRY(pk_fft_add_dense_kn(ar, w, &b, units, 1, A, L.ffn2));
         }
     }
-    PK_TRY(add_vec(ar, P, prefix + ".after_norm.weight", A, after_g));
-    PK_TRY(add_vec(ar, P, prefix + ".after_norm.bias", A, after_b));
+    PK_TRY(pk_fft_add_vec(ar, P, prefix + ".after_norm.weight", A, after_g));
+    PK_TRY(pk_fft_add_vec(ar, P, prefix + ".after_norm.bias", A, after_b));
     return PK_OK;
 }
 
+namespace {
 int add_predictor(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int chans,
                   int k, Predictor& pr) {
     pr.conv.resize(n_layers);
@@ -1106,11 +1095,11 @@ int add_predictor(Arena& ar, const pk_param_map& P, const std::string& prefix, i
     pr.chans = chans;
     for (int j = 0; j < n_layers; ++j) {
         const std::string p = prefix + ".conv." + std::to_string(j);
-        PK_TRY(add_conv(ar, P, p + ".0", chans, j == 0 ? A : chans, k, true, pr.conv[j]));
-        PK_TRY(add_vec(ar, P, p + ".2.weight", chans, pr.ln_g[j]));
-        PK_TRY(add_vec(ar, P, p + ".2.bias", chans, pr.ln_b[j]));
+        PK_TRY(pk_fft_add_conv(ar, P, p + ".0", chans, j == 0 ? A : chans, k, true, pr.conv[j]));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".2.weight", chans, pr.ln_g[j]));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".2.bias", chans, pr.ln_b[j]));
     }
-    PK_TRY(add_vec(ar, P, prefix + ".linear.weight", chans, pr.lin_w));
+    PK_TRY(pk_fft_add_vec(ar, P, prefix + ".linear.weight", chans, pr.lin_w));
     std::vector<float> b;
     PK_TRY(pk_get_vector(P, prefix + ".linear.bias", 1, b));
     pr.lin_b = b[0];
@@ -1118,10 +1107,10 @@ int add_predictor(Arena& ar, const pk_param_map& P, const std::string& prefix, i
 }
 }  // namespace
 
-static int ensure_pe(pk_fs2* h, int need) {
+int pk_fft_ensure_pe(pk_fft_core* h, int need) {
     if (need <= h->max_len) return PK_OK;
     pk_ctx* ctx = h->ctx;
-    const int d = h->cfg.adim;
+    const int d = h->adim;
     int n = std::max(need, 1024);
     n = std::max(n, h->max_len * 2);
     if (!h->d_div.p) {
@@ -1164,9 +1153,9 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
         h->alpha_enc = h->alpha_dec = 1.f;
         h->xscale = std::sqrt((float)A);  // PositionalEncoding.forward embedding.py:78
     }
-    PK_TRY(add_fft_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->enc,
+    PK_TRY(pk_fft_add_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->enc,
                          h->enc_after_g, h->enc_after_b));
-    PK_TRY(add_fft_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->dec,
+    PK_TRY(pk_fft_add_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->dec,
                          h->dec_after_g, h->dec_after_b));
     PK_TRY(add_predictor(ar, P, "duration_predictor", c.duration_predictor_layers, A, c.duration_predictor_chans,
                          c.duration_predictor_kernel_size, h->dur));
@@ -1174,37 +1163,17 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
                          c.pitch_predictor_kernel_size, h->pitch));
     PK_TRY(add_predictor(ar, P, "energy_predictor", c.energy_predictor_layers, A, c.energy_predictor_chans,
                          c.energy_predictor_kernel_size, h->energy));
-    PK_TRY(add_vec(ar, P, "pitch_embed.0.weight", A, h->pitch_w));
-    PK_TRY(add_vec(ar, P, "pitch_embed.0.bias", A, h->pitch_b));
-    PK_TRY(add_vec(ar, P, "energy_embed.0.weight", A, h->energy_w));
-    PK_TRY(add_vec(ar, P, "energy_embed.0.bias", A, h->energy_b));
+    PK_TRY(pk_fft_add_vec(ar, P, "pitch_embed.0.weight", A, h->pitch_w));
+    PK_TRY(pk_fft_add_vec(ar, P, "pitch_embed.0.bias", A, h->pitch_b));
+    PK_TRY(pk_fft_add_vec(ar, P, "energy_embed.0.weight", A, h->energy_w));
+    PK_TRY(pk_fft_add_vec(ar, P, "energy_embed.0.bias", A, h->energy_b));
     {
         std::vector<float> w, b;
         PK_TRY(pk_get_weight(P, "feat_out", {A, c.odim}, w));
         PK_TRY(pk_get_vector(P, "feat_out.bias", c.odim, b));
-        PK_TRY(add_dense_kn(ar, w, &b, A, 1, c.odim, h->feat_out));
+        PK_TRY(pk_fft_add_dense_kn(ar, w, &b, A, 1, c.odim, h->feat_out));
     }
-    h->postnet.resize(c.postnet_layers);
-    for (int j = 0; j < c.postnet_layers; ++j) {
-        const int cin = j == 0 ? c.odim : c.postnet_chans;
-        const int cout = j == c.postnet_layers - 1 ? c.odim : c.postnet_chans;
-        const std::string p = "postnet.postnet." + std::to_string(j);
-        std::vector<float> w, g, b, mean, var, kn, bias(cout);
-        PK_TRY(pk_get_weight(P, p + ".0", {cout, cin, c.postnet_filts}, w));
-        PK_TRY(pk_get_vector(P, p + ".1.weight", cout, g));
-        PK_TRY(pk_get_vector(P, p + ".1.bias", cout, b));
-        PK_TRY(pk_get_vector(P, p + ".1._mean", cout, mean));
-        PK_TRY(pk_get_vector(P, p + ".1._variance", cout, var));
-        // fold BatchNorm1D (eval, eps 1e-5) into the bias-free conv (tacotron2/decoder.py:133-147)
-        const size_t per = (size_t)cin * c.postnet_filts;
-        for (int o = 0; o < cout; ++o) {
-            const double s = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
-            for (size_t i = 0; i < per; ++i) w[o * per + i] = (float)((double)w[o * per + i] * s);
-            bias[o] = (float)((double)b[o] - (double)mean[o] * s);
-        }
-        pk_conv_to_kn(w.data(), cout, cin, c.postnet_filts, kn);
-        PK_TRY(add_dense_kn(ar, kn, &bias, cin, c.postnet_filts, cout, h->postnet[j]));
-    }
+    PK_TRY(pk_fft_add_postnet(ar, P, "postnet", c.postnet_layers, c.odim, c.postnet_chans, c.postnet_filts, h->postnet));
     if (c.tone_embed_dim > 0) {
         // "add": hs[t] += Linear(F.normalize(E[tone[t]])) is a function of the tone id alone -> one table
         const int Dt = c.tone_embed_dim;
@@ -1242,7 +1211,7 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
             // Linear(adim + D -> adim) on concat([hs, e]) = hs . W[:adim] + e . W[adim:] (+ bias, added with e's part)
             PK_TRY(pk_get_weight(P, "spk_projection", {A + D, A}, w));
             std::vector<float> whs(w.begin(), w.begin() + (size_t)A * A), wsp(w.begin() + (size_t)A * A, w.end());
-            PK_TRY(add_dense_kn(ar, whs, nullptr, A, 1, A, h->spk_hs));
+            PK_TRY(pk_fft_add_dense_kn(ar, whs, nullptr, A, 1, A, h->spk_hs));
             h->spk_w = ar.put(wsp);
         }
     }
@@ -1257,15 +1226,14 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
         PK_TRY(pk_upload(ctx, h->arena16, h->arena16_h.data(), h->arena16_h.size() * sizeof(uint16_t)));
     h->arena16_h.clear();
     h->arena16_h.shrink_to_fit();
-    PK_TRY(ensure_pe(h, 1024));
+    PK_TRY(pk_fft_ensure_pe(h, 1024));
     h->finalized = true;
     h->encoded = false;
     return PK_OK;
 }
 
-static int run_dense(pk_fs2* h, const char* name, const Dense& d, const float* A, int lda, float* C, int ldc,
-                     int rows, int act, const float* res, int ldr, const int* rowvalid,
-                     const float* a_amax = nullptr) {
+int pk_fft_run_dense(pk_fft_core* h, const char* name, const Dense& d, const float* A, int lda, float* C, int ldc,
+                     int rows, int act, const float* res, int ldr, const int* rowvalid, const float* a_amax) {
     pk_gemm_args g;
     g.a_amax = a_amax;   // row maxima of A when its producer left them (k_layernorm), else computed by the launcher
     g.A = A;
@@ -1288,16 +1256,16 @@ static int run_dense(pk_fs2* h, const char* name, const Dense& d, const float* A
     return pk_gemm_launch(h->ctx, name, g);
 }
 
-static int run_layernorm(pk_fs2* h, const float* x, size_t g, size_t b, const Timeline& tl, int C, float* y,
-                         float* amax = nullptr) {
+int pk_fft_run_layernorm(pk_fft_core* h, const float* x, size_t g, size_t b, const Timeline& tl, int C, float* y,
+                         float* amax) {
     PK_LAUNCH(h->ctx, "fs2_layernorm", k_layernorm, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, x, h->W(g), h->W(b),
               tl.d_row_utt(), tl.rows, C, 1e-5f, y, amax);
     return PK_OK;
 }
 
-static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float* out,
-                         const unsigned* seg_bounds = nullptr) {
-    const int A = h->cfg.adim, heads = h->cfg.aheads, dk = A / heads;
+int pk_fft_run_attention(pk_fft_core* h, const Timeline& tl, const float* qkv, float* out,
+                         const unsigned* seg_bounds) {
+    const int A = h->adim, heads = h->aheads, dk = A / heads;
     int maxlen = 0;
     for (int l : tl.seg_len) maxlen = std::max(maxlen, l);
     AttnArgs a;
@@ -1352,18 +1320,18 @@ static int run_attention(pk_fs2* h, const Timeline& tl, const float* qkv, float*
 }
 
 // N FFT blocks + after_norm on the timeline tl; x is updated in place, result in hs.
-static int run_fft_stack(pk_fs2* h, const std::vector<FftLayer>& layers, size_t after_g, size_t after_b,
+int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t after_g, size_t after_b,
                          const Timeline& tl, int units, float* hs_out) {
-    const int A = h->cfg.adim;
-    PK_TRY(act_reserve(h->d_h, tl.rows, A));
-    PK_TRY(act_reserve(h->d_qkv, tl.rows, 3 * A));
-    PK_TRY(act_reserve(h->d_ctx, tl.rows, A));
-    PK_TRY(act_reserve(h->d_f, tl.rows, units));
-    float* x = act_ptr(h->d_x, A);
-    float* hh = act_ptr(h->d_h, A);
-    float* qkv = act_ptr(h->d_qkv, 3 * A);
-    float* ctxb = act_ptr(h->d_ctx, A);
-    float* f = act_ptr(h->d_f, units);
+    const int A = h->adim;
+    PK_TRY(pk_fft_act_reserve(h->d_h, tl.rows, A));
+    PK_TRY(pk_fft_act_reserve(h->d_qkv, tl.rows, 3 * A));
+    PK_TRY(pk_fft_act_reserve(h->d_ctx, tl.rows, A));
+    PK_TRY(pk_fft_act_reserve(h->d_f, tl.rows, units));
+    float* x = pk_fft_act_ptr(h->d_x, A);
+    float* hh = pk_fft_act_ptr(h->d_h, A);
+    float* qkv = pk_fft_act_ptr(h->d_qkv, 3 * A);
+    float* ctxb = pk_fft_act_ptr(h->d_ctx, A);
+    float* f = pk_fft_act_ptr(h->d_f, units);
     const int* rv = tl.d_row_utt();
     // row maxima of the LayerNorm outputs, left by k_layernorm for the split-fp16 GEMMs that read them (rows outside
     // the timeline: zero)
@@ -1371,26 +1339,26 @@ static int run_fft_stack(pk_fs2* h, const std::vector<FftLayer>& layers, size_t 
     // attention output or the FFN hidden activations is needed for the operand scales
     float *ham = nullptr, *cbnd = nullptr, *fbnd = nullptr;
     unsigned* segb = nullptr;
-    const int heads = h->cfg.aheads;
+    const int heads = h->aheads;
     const bool bounds = h->math == PK_GEMM_MATH_F16X3 && heads <= FS2_MAX_HEADS && !h->no_bounds;
     if (h->math == PK_GEMM_MATH_F16X3) {
-        PK_TRY(act_reserve(h->d_lnamax, tl.rows, 1));
+        PK_TRY(pk_fft_act_reserve(h->d_lnamax, tl.rows, 1));
         PK_HIP(hipMemsetAsync(h->d_lnamax.p, 0, h->d_lnamax.cap, h->ctx->stream));
-        ham = act_ptr(h->d_lnamax, 1);
+        ham = pk_fft_act_ptr(h->d_lnamax, 1);
     }
     if (bounds) {
-        PK_TRY(act_reserve(h->d_cbnd, tl.rows, 1));
-        PK_TRY(act_reserve(h->d_fbnd, tl.rows, 1));
+        PK_TRY(pk_fft_act_reserve(h->d_cbnd, tl.rows, 1));
+        PK_TRY(pk_fft_act_reserve(h->d_fbnd, tl.rows, 1));
         PK_TRY(h->d_segb.reserve((size_t)tl.B * heads * 3 * sizeof(unsigned)));
         PK_HIP(hipMemsetAsync(h->d_cbnd.p, 0, h->d_cbnd.cap, h->ctx->stream));
         PK_HIP(hipMemsetAsync(h->d_fbnd.p, 0, h->d_fbnd.cap, h->ctx->stream));
-        cbnd = act_ptr(h->d_cbnd, 1);
-        fbnd = act_ptr(h->d_fbnd, 1);
+        cbnd = pk_fft_act_ptr(h->d_cbnd, 1);
+        fbnd = pk_fft_act_ptr(h->d_fbnd, 1);
         segb = h->d_segb.as<unsigned>();
     }
     for (const FftLayer& L : layers) {
-        PK_TRY(run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh, ham));
-        PK_TRY(run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, ham));
+        PK_TRY(pk_fft_run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh, ham));
+        PK_TRY(pk_fft_run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, ham));
         if (bounds) {
             QkvBoundC qc;
             memcpy(qc.c1, L.qkv_c1, sizeof(qc.c1));
@@ -1398,32 +1366,77 @@ static int run_fft_stack(pk_fs2* h, const std::vector<FftLayer>& layers, size_t 
             PK_LAUNCH(h->ctx, "fs2_bounds", k_fs2_seg_bounds, dim3(tl.B), dim3(256), 0, ham, tl.d_seg_start(),
                       tl.d_seg_len(), heads, qc, segb, cbnd);
         }
-        PK_TRY(run_attention(h, tl, qkv, ctxb, segb));
-        PK_TRY(run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, cbnd));
-        PK_TRY(run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh, ham));
-        PK_TRY(run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv, ham));
+        PK_TRY(pk_fft_run_attention(h, tl, qkv, ctxb, segb));
+        PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, cbnd));
+        PK_TRY(pk_fft_run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh, ham));
+        PK_TRY(pk_fft_run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv, ham));
         if (bounds)
             PK_LAUNCH(h->ctx, "fs2_bounds", k_fs2_row_bounds, dim3(pk_div_up(tl.rows, 256)), dim3(256), 0, ham, rv,
                       tl.rows, L.ffn1.pad, L.ffn1.c1, L.ffn1.c0, fbnd);
-        PK_TRY(run_dense(h, "fs2_conv_ffn2", L.ffn2, f, units, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, fbnd));
+        PK_TRY(pk_fft_run_dense(h, "fs2_conv_ffn2", L.ffn2, f, units, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, fbnd));
     }
-    PK_TRY(run_layernorm(h, x, after_g, after_b, tl, A, hs_out));
+    PK_TRY(pk_fft_run_layernorm(h, x, after_g, after_b, tl, A, hs_out));
+    return PK_OK;
+}
+
+int pk_fft_run_postnet(pk_fft_core* h, const char* name, const std::vector<Dense>& postnet, const float* before, int odim,
+                       int chans, const Timeline& tl, pk_dbuf& q1, pk_dbuf& q2, float* d_out, const int* out_rowmap,
+                       const float* cscale, const float* cshift) {
+    const int n = (int)postnet.size();
+    PK_TRY(pk_fft_act_reserve(q1, tl.rows, chans));
+    PK_TRY(pk_fft_act_reserve(q2, tl.rows, chans));
+    const float* in = before;
+    int ldin = odim;
+    for (int j = 0; j < n; ++j) {
+        const Dense& d = postnet[j];
+        const bool last = j == n - 1;
+        float* outb = pk_fft_act_ptr((j & 1) ? q2 : q1, chans);
+        pk_gemm_args g;
+        g.A = in; g.lda = ldin; g.Wp = h->W(d.w); g.bias = h->W(d.b);
+        g.Wh = d.wh == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + d.wh; g.math = h->math;
+        g.M = tl.rows; g.N = d.N; g.Cin = d.Cin; g.taps = d.taps; g.pad = d.pad;
+        g.rowvalid = tl.d_row_utt();
+        if (!last) {
+            g.C = outb; g.ldc = chans; g.act = PK_ACT_TANH;
+        } else {
+            g.C = d_out; g.ldc = odim; g.act = PK_ACT_NONE; g.res = before; g.ldr = odim;
+            g.cscale = cscale; g.cshift = cshift; g.out_rowmap = out_rowmap;
+        }
+        PK_TRY(pk_gemm_launch(h->ctx, name, g));
+        in = outb;
+        ldin = chans;
+    }
+    return PK_OK;
+}
+
+int pk_fft_embed(pk_fft_core* h, const char* name, const int* d_tok, const Timeline& tl, size_t table, float alpha,
+                 float xscale, float* x) {
+    PK_LAUNCH(h->ctx, name, k_embed, dim3(tl.rows), dim3(128), 0, d_tok, tl.d_row_utt(), tl.d_row_pos(), h->W(table),
+              h->d_pe.as<float>(), alpha, xscale, h->adim, x);
+    return PK_OK;
+}
+
+int pk_fft_layernorm_rows(pk_fft_core* h, const float* x, size_t g, size_t b, const int* d_row_utt, int rows, int C,
+                          float* y, float* amax) {
+    if (C % 64 != 0 || C > 64 * LN_MAXPER) PK_FAIL(PK_EUNSUPPORTED, "LayerNorm: %d channels (multiple of 64, <= %d)", C, 64 * LN_MAXPER);
+    PK_LAUNCH(h->ctx, "fft_layernorm", k_layernorm, dim3(pk_div_up(rows, 4)), dim3(256), 0, x, h->W(g), h->W(b),
+              d_row_utt, rows, C, 1e-5f, y, amax);
     return PK_OK;
 }
 
 static int run_predictor(pk_fs2* h, const Predictor& pr, const Timeline& tl, const float* hs, int duration_mode,
                          float alpha, float* out) {
     const int A = h->cfg.adim;
-    PK_TRY(act_reserve(h->d_p1, tl.rows, pr.chans));
-    PK_TRY(act_reserve(h->d_p2, tl.rows, pr.chans));
-    float* p1 = act_ptr(h->d_p1, pr.chans);
-    float* p2 = act_ptr(h->d_p2, pr.chans);
+    PK_TRY(pk_fft_act_reserve(h->d_p1, tl.rows, pr.chans));
+    PK_TRY(pk_fft_act_reserve(h->d_p2, tl.rows, pr.chans));
+    float* p1 = pk_fft_act_ptr(h->d_p1, pr.chans);
+    float* p2 = pk_fft_act_ptr(h->d_p2, pr.chans);
     const float* in = hs;
     int ldin = A;
     for (size_t j = 0; j < pr.conv.size(); ++j) {
-        PK_TRY(run_dense(h, "fs2_conv_predictor", pr.conv[j], in, ldin, p1, pr.chans, tl.rows, PK_ACT_RELU, nullptr, 0,
+        PK_TRY(pk_fft_run_dense(h, "fs2_conv_predictor", pr.conv[j], in, ldin, p1, pr.chans, tl.rows, PK_ACT_RELU, nullptr, 0,
                          nullptr));
-        PK_TRY(run_layernorm(h, p1, pr.ln_g[j], pr.ln_b[j], tl, pr.chans, p2));
+        PK_TRY(pk_fft_run_layernorm(h, p1, pr.ln_g[j], pr.ln_b[j], tl, pr.chans, p2));
         in = p2;
         ldin = pr.chans;
     }
@@ -1464,9 +1477,9 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
         PK_FAIL(PK_ESHAPE, "pk_fs2_encode: speakers were set for %d utterances, batch has %d", condB, B);
     if (c.tone_embed_dim > 0 && !cond_tone.empty() && (long)cond_tone.size() != sumT)
         PK_FAIL(PK_ESHAPE, "pk_fs2_encode: %zu tone ids for %ld tokens", cond_tone.size(), sumT);
-    PK_TRY(build_timeline(ctx, h->tl_tok, tok_lens, B, h->gapr));
+    PK_TRY(pk_fft_build_timeline(ctx, h->tl_tok, tok_lens, B, h->gapr));
     Timeline& tl = h->tl_tok;
-    PK_TRY(ensure_pe(h, maxT));
+    PK_TRY(pk_fft_ensure_pe(h, maxT));
     // token ids on the row timeline
     {
         std::vector<int> tok(tl.rows_alloc, 0);
@@ -1479,13 +1492,12 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
             }
         PK_TRY(pk_upload(ctx, h->d_tok, tok.data(), tok.size() * sizeof(int)));
     }
-    PK_TRY(act_reserve(h->d_x, tl.rows, A));
-    PK_TRY(act_reserve(h->d_hs, tl.rows, A));
-    float* x = act_ptr(h->d_x, A);
-    float* hs = act_ptr(h->d_hs, A);
-    PK_LAUNCH(ctx, "fs2_embed", k_embed, dim3(tl.rows), dim3(128), 0, h->d_tok.as<int>(), tl.d_row_utt(),
-              tl.d_row_pos(), h->W(h->emb_table), h->d_pe.as<float>(), h->alpha_enc, h->xscale, A, x);
-    PK_TRY(run_fft_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    PK_TRY(pk_fft_act_reserve(h->d_x, tl.rows, A));
+    PK_TRY(pk_fft_act_reserve(h->d_hs, tl.rows, A));
+    float* x = pk_fft_act_ptr(h->d_x, A);
+    float* hs = pk_fft_act_ptr(h->d_hs, A);
+    PK_TRY(pk_fft_embed(h, "fs2_embed", h->d_tok.as<int>(), tl, h->emb_table, h->alpha_enc, h->xscale, x));
+    PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
     // speaker embedding (:396-402)
     if (c.spk_embed_dim > 0 && condB > 0) {
         const int D = c.spk_embed_dim;
@@ -1504,7 +1516,7 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
                   h->W(h->spk_table), h->W(h->spk_w), h->W(h->spk_b), D, A, h->d_spk_vec.as<float>());
         const float* src = hs;
         if (c.spk_embed_integration_type == 1) {
-            PK_TRY(run_dense(h, "fs2_gemm_spk_proj", h->spk_hs, hs, A, x, A, tl.rows, PK_ACT_NONE, nullptr, 0,
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_spk_proj", h->spk_hs, hs, A, x, A, tl.rows, PK_ACT_NONE, nullptr, 0,
                              tl.d_row_utt()));
             src = x;
         }
@@ -1557,9 +1569,9 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
         sumL += lens[b];
     }
     if (sumL == 0) return PK_OK;
-    PK_TRY(build_timeline(ctx, h->tl_frm, lens.data(), B, h->gapr));
+    PK_TRY(pk_fft_build_timeline(ctx, h->tl_frm, lens.data(), B, h->gapr));
     Timeline& tl = h->tl_frm;
-    PK_TRY(ensure_pe(h, maxL));
+    PK_TRY(pk_fft_ensure_pe(h, maxL));
     // packed output row of each timeline row
     {
         std::vector<int> rowmap(tl.rows_alloc, -1);
@@ -1570,24 +1582,24 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
     }
     // d_hs keeps the encoder output (token rate) until k_regulate has consumed it; d_x was the
     // encoder's residual stream and is free for the decoder.
-    PK_TRY(act_reserve(h->d_x, tl.rows, A));
-    float* x = act_ptr(h->d_x, A);
-    const float* hs_tok = act_ptr(h->d_hs, A);
+    PK_TRY(pk_fft_act_reserve(h->d_x, tl.rows, A));
+    float* x = pk_fft_act_ptr(h->d_x, A);
+    const float* hs_tok = pk_fft_act_ptr(h->d_hs, A);
     float* up_dbg = nullptr;
     if (h->debug) {
-        PK_TRY(act_reserve(h->d_dbg_up, tl.rows, A));
-        up_dbg = act_ptr(h->d_dbg_up, A);
+        PK_TRY(pk_fft_act_reserve(h->d_dbg_up, tl.rows, A));
+        up_dbg = pk_fft_act_ptr(h->d_dbg_up, A);
     }
     PK_LAUNCH(ctx, "fs2_regulate", k_regulate, dim3(tl.rows), dim3(128), 0, hs_tok, h->d_pout.as<float>(),
               h->d_eout.as<float>(), h->W(h->pitch_w), h->W(h->pitch_b), h->W(h->energy_w), h->W(h->energy_b),
               h->d_cum.as<int>(), h->tl_tok.d_seg_start(), h->tl_tok.d_seg_len(), tl.d_row_utt(), tl.d_row_pos(),
               h->d_pe.as<float>(), h->alpha_dec, h->xscale, A, x, up_dbg);
-    PK_TRY(act_reserve(h->d_zs, tl.rows, A));
-    float* zs = act_ptr(h->d_zs, A);
-    PK_TRY(run_fft_stack(h, h->dec, h->dec_after_g, h->dec_after_b, tl, c.dunits, zs));
+    PK_TRY(pk_fft_act_reserve(h->d_zs, tl.rows, A));
+    float* zs = pk_fft_act_ptr(h->d_zs, A);
+    PK_TRY(pk_fft_run_stack(h, h->dec, h->dec_after_g, h->dec_after_b, tl, c.dunits, zs));
     // feat_out (+ row mask: the postnet convolves over it)
-    PK_TRY(act_reserve(h->d_before, tl.rows, c.odim));
-    float* before = act_ptr(h->d_before, c.odim);
+    PK_TRY(pk_fft_act_reserve(h->d_before, tl.rows, c.odim));
+    float* before = pk_fft_act_ptr(h->d_before, c.odim);
     float* d_out = mel_out;
     if (flags & PK_HOST_IO) {
         PK_TRY(h->d_mel_stage.reserve((size_t)sumL * c.odim * 4));
@@ -1604,32 +1616,11 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
         g.out_rowmap = h->d_rowmap.as<int>(); g.M = tl.rows; g.N = c.odim; g.Cin = A; g.taps = 1; g.pad = 0;
         PK_TRY(pk_gemm_launch(ctx, "fs2_gemm_feat_out", g));
     } else {
-        PK_TRY(run_dense(h, "fs2_gemm_feat_out", h->feat_out, zs, A, before, c.odim, tl.rows, PK_ACT_NONE, nullptr, 0,
+        PK_TRY(pk_fft_run_dense(h, "fs2_gemm_feat_out", h->feat_out, zs, A, before, c.odim, tl.rows, PK_ACT_NONE, nullptr, 0,
                          tl.d_row_utt()));
-        PK_TRY(act_reserve(h->d_q1, tl.rows, c.postnet_chans));
-        PK_TRY(act_reserve(h->d_q2, tl.rows, c.postnet_chans));
-        const float* in = before;
-        int ldin = c.odim;
-        for (int j = 0; j < c.postnet_layers; ++j) {
-            const Dense& d = h->postnet[j];
-            const bool last = j == c.postnet_layers - 1;
-            float* outb = act_ptr((j & 1) ? h->d_q2 : h->d_q1, c.postnet_chans);
-            pk_gemm_args g;
-            g.A = in; g.lda = ldin; g.Wp = h->W(d.w); g.bias = h->W(d.b);
-            g.Wh = d.wh == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + d.wh; g.math = h->math;
-            g.M = tl.rows; g.N = d.N; g.Cin = d.Cin; g.taps = d.taps; g.pad = d.pad;
-            g.rowvalid = tl.d_row_utt();
-            if (!last) {
-                g.C = outb; g.ldc = c.postnet_chans; g.act = PK_ACT_TANH;
-            } else {
-                // after = before + postnet(before)  (:463-464), then ZScore.inverse (FastSpeech2Inference :670)
-                g.C = d_out; g.ldc = c.odim; g.act = PK_ACT_NONE; g.res = before; g.ldr = c.odim;
-                g.cscale = cs; g.cshift = ch; g.out_rowmap = h->d_rowmap.as<int>();
-            }
-            PK_TRY(pk_gemm_launch(ctx, "fs2_conv_postnet", g));
-            in = outb;
-            ldin = c.postnet_chans;
-        }
+        // after = before + postnet(before)  (:463-464), then ZScore.inverse (FastSpeech2Inference :670)
+        PK_TRY(pk_fft_run_postnet(h, "fs2_conv_postnet", h->postnet, before, c.odim, c.postnet_chans, tl, h->d_q1, h->d_q2,
+                                  d_out, h->d_rowmap.as<int>(), cs, ch));
     }
     if (flags & PK_HOST_IO) {
         PK_HIP(hipMemcpyAsync(mel_out, d_out, (size_t)sumL * c.odim * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1695,13 +1686,13 @@ extern "C" int pk_fs2_debug_read(pk_fs2* h, int32_t what, int32_t b, float* host
     const float* src = nullptr;
     int C = A;
     switch (what) {
-        case 0: src = act_ptr(h->d_hs, A); break;                           // encoder output hs (T, adim)
+        case 0: src = pk_fft_act_ptr(h->d_hs, A); break;                           // encoder output hs (T, adim)
         case 1: src = h->d_pout.as<float>(); C = 1; break;                  // pitch (T,)
         case 2: src = h->d_eout.as<float>(); C = 1; break;                  // energy (T,)
         case 3: src = h->d_dout.as<float>(); C = 1; break;                  // durations (T,)
-        case 4: tl = &h->tl_frm; src = act_ptr(h->d_dbg_up, A); break;      // length-regulated hs (L, adim)
-        case 5: tl = &h->tl_frm; src = act_ptr(h->d_zs, A); break;      // decoder output zs (L, adim)
-        case 6: tl = &h->tl_frm; src = act_ptr(h->d_before, h->cfg.odim); C = h->cfg.odim; break;  // before_outs
+        case 4: tl = &h->tl_frm; src = pk_fft_act_ptr(h->d_dbg_up, A); break;      // length-regulated hs (L, adim)
+        case 5: tl = &h->tl_frm; src = pk_fft_act_ptr(h->d_zs, A); break;      // decoder output zs (L, adim)
+        case 6: tl = &h->tl_frm; src = pk_fft_act_ptr(h->d_before, h->cfg.odim); C = h->cfg.odim; break;  // before_outs
         default: PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: unknown tap %d", what);
     }
     if (b < 0 || b >= tl->B) PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: utterance out of range");
@@ -1718,8 +1709,8 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     if (!h) return;
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->d_lnamax, &h->d_cbnd, &h->d_fbnd, &h->d_segb, &h->d_pe, &h->d_div, &h->d_tok, &h->d_x, &h->d_h, &h->d_qkv, &h->d_ctx, &h->d_f,
-                       &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
+    h->release_core();
+    pk_dbuf* bufs[] = {&h->d_tok, &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
                        &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
     for (auto* b : bufs) b->release();
     h->tl_tok.release();

@@ -7,22 +7,9 @@
 #include <vector>
 
 #include "pk_gemm.h"
+#include "pk_philox.h"
 
 namespace {
-
-// Philox4x32-10 block: counter (c0..c3), key (k0, k1) -> 4 x uint32
-__device__ __forceinline__ void philox4x32_10(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0,
-                                              unsigned k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
-        const unsigned lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
-        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
 
 // One thread per Philox block = 4 normals (see pk_synth.h for the exact recipe).
 __global__ void k_randn(float* __restrict__ out, long n, unsigned long long seed, unsigned long long block0) {

@@ -1,0 +1,900 @@
+// tts.hip -- TransformerTTS inference on gfx950: kernels + pk_tts_* entry points.
+//
+// Reference: parakeet/models/transformer_tts/transformer_tts.py TransformerTTS.inference :511-647,
+//   Decoder.forward_one_step   parakeet/modules/fastspeech2_transformer/decoder.py:190-227
+//   DecoderLayer.forward       parakeet/modules/fastspeech2_transformer/decoder_layer.py:74-158 (cache branch)
+//   MultiHeadedAttention       parakeet/modules/fastspeech2_transformer/attention.py:51-156
+//   DecoderPrenet (Prenet)     parakeet/modules/tacotron2/decoder.py:62-81   (dropout stays on at inference)
+//   EncoderPrenet              parakeet/modules/tacotron2/encoder.py:150-176
+//   Postnet                    parakeet/modules/tacotron2/decoder.py:127-198
+//
+// The text encoder is the same `Encoder` class FastSpeech2 uses: it runs on the shared row-timeline machinery of
+// pk_fft.h (fs2.hip).  The decoder is autoregressive; what the engine does with the reference's loop:
+//
+//  * B utterances are decoded in lockstep, one frame per step for every utterance.  All per-frame tensors are
+//    POSITION-MAJOR: row = pos * B + b, so the rows of steps 1..s are the contiguous prefix [0, s*B) and every GEMM
+//    of a step is one launch over a contiguous row range with no per-step index tables.
+//  * The reference re-applies decoder.embed (prenet with always-on dropout -> Linear -> positional encoding) to the
+//    WHOLE prefix at every step (decoder.py:210) and caches layer outputs only (:213-218).  Layer 0 therefore sees
+//    s freshly re-dropped rows at step s: the engine recomputes prenet, embedding, norm1 and the K/V projection of
+//    layer 0 for the s*B prefix rows each step (one GEMM each).  For layers >= 1 the inputs of old rows are cached
+//    layer outputs, so their K/V rows never change: they are projected once, when the row is new (a KV cache the
+//    reference does not have: it re-projects the whole prefix in every layer at every step).
+//  * with a cache the reference computes the last query row only and its mask row is all ones
+//    (decoder_layer.py:110-120): k_tts_attn_step is one query per (utterance, head) over s keys; the same kernel
+//    serves the encoder-decoder attention over the T_b memory rows, whose K/V projections are computed once per call.
+//  * an utterance that has stopped keeps being stepped (its rows are ignored) until all have; the stop state lives
+//    on the device and is polled every few steps.
+//
+// Dropout: include/pk_synth.h "dropout stream".
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pk_fft.h"
+#include "pk_philox.h"
+
+namespace {
+
+typedef pk_fft_dense Dense;
+typedef pk_fft_timeline Timeline;
+
+// ---------------------------------------------------------------------------------------------- kernels
+
+// Prenet dropout, in place, on prefix rows (row = pos * B + b): one thread per 4 units.
+//   element index ((tri + pos) * J + j) * U + u,  tri = s * (s - 1) / 2 for decoding step s  (pk_synth.h)
+__global__ __launch_bounds__(256) void k_tts_dropout(float* __restrict__ x, int rows, int U, int B,
+                                                     unsigned long long tri, int J, int j,
+                                                     const unsigned long long* __restrict__ seeds, unsigned thr,
+                                                     float scale) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = U >> 2;
+    if (q >= (long)rows * per_row) return;
+    const int r = (int)(q / per_row), u4 = (int)(q - (long)r * per_row) * 4;
+    const int pos = r / B, b = r - pos * B;
+    const unsigned long long e = ((tri + (unsigned long long)pos) * (unsigned long long)J + (unsigned long long)j) *
+                                     (unsigned long long)U + (unsigned long long)u4;
+    unsigned w[4];
+    pk_dropout_words(e, seeds ? seeds[b] : 0ull, w);
+    float4* p = reinterpret_cast<float4*>(x + (long)r * U + u4);
+    float4 v = *p;
+    v.x = w[0] >= thr ? v.x * scale : 0.f;
+    v.y = w[1] >= thr ? v.y * scale : 0.f;
+    v.z = w[2] >= thr ? v.z * scale : 0.f;
+    v.w = w[3] >= thr ? v.w * scale : 0.f;
+    *p = v;
+}
+
+// out[r][c] = alpha * pe[r / B][c]: the positional term of decoder.embed in position-major rows, added by the
+// epilogue of the embedding GEMM (ScaledPositionalEncoding.forward embedding.py:111-126)
+__global__ __launch_bounds__(128) void k_tts_pe_pos_major(const float* __restrict__ pe, float alpha, int B, int A,
+                                                          float* __restrict__ out) {
+    const long r = blockIdx.x;
+    const float* p = pe + (r / B) * A;
+    for (int c = threadIdx.x; c < A; c += blockDim.x) out[r * A + c] = alpha * p[c];
+}
+
+// the same term on a row timeline (encoder conv prenet path): gap rows zero
+__global__ __launch_bounds__(128) void k_tts_pe_timeline(const float* __restrict__ pe, float alpha,
+                                                         const int* __restrict__ row_utt,
+                                                         const int* __restrict__ row_pos, int A,
+                                                         float* __restrict__ out) {
+    const long r = blockIdx.x;
+    const bool valid = row_utt[r] >= 0;
+    const float* p = pe + (long)(valid ? row_pos[r] : 0) * A;
+    for (int c = threadIdx.x; c < A; c += blockDim.x) out[r * A + c] = valid ? alpha * p[c] : 0.f;
+}
+
+// x[r] = table[tok[r]] (row 0 of the table is zero: padding_idx), gap rows zero
+__global__ __launch_bounds__(128) void k_tts_lookup(const int* __restrict__ tok, const int* __restrict__ row_utt,
+                                                    const float* __restrict__ table, int E, float* __restrict__ x) {
+    const long r = blockIdx.x;
+    const bool valid = row_utt[r] >= 0;
+    const float* e = table + (long)(valid ? tok[r] : 0) * E;
+    for (int c = threadIdx.x; c < E; c += blockDim.x) x[r * E + c] = valid ? e[c] : 0.f;
+}
+
+// One decoding step of MultiHeadedAttention (attention.py:133-156) for ONE query row per utterance:
+//   grid (heads, B), 256 threads.  Key / value row j of utterance b is row kbase[b] + j * kstride (ld = ldkv).
+//   self-attention: K/V = the layer's projected prefix rows (position-major: kbase = b, kstride = B, n = step);
+//   encoder-decoder attention: K/V = the projected memory rows of the token timeline (kbase = seg_start, kstride 1,
+//   klen = T_b), whose softmax weights are the att_ws the reference returns (:623-636).
+struct AttnStep {
+    const float* q;     // query rows [B][ldq], head h at column h * dk
+    int ldq;
+    const float* K;
+    const float* V;
+    int ldkv;
+    const int* kbase;   // per utterance, NULL: b
+    const int* klen;    // per utterance, NULL: n
+    int kstride, n, dk;
+    float scale;
+    float* out;         // [B][ldo]
+    int ldo;
+    float* att;         // NULL or base of the attention-weight store
+    const long* att_off;  // per utterance offset (floats) of its (layers, heads, cap_b, T_b) block
+    const int* att_cap;   // per utterance cap_b
+    int layer, step;      // step counted from 0
+};
+
+__global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
+    extern __shared__ float sm[];
+    const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dk = a.dk;
+    const int n = a.klen ? a.klen[b] : a.n;
+    const long base = a.kbase ? a.kbase[b] : b;
+    float* qs = sm;           // dk (16-byte aligned: dk % 4 == 0)
+    float* red = sm + dk;     // 256 partial sums + 8 reduction slots
+    float* sc = red + 264;    // n scores -> probabilities
+    const float* qp = a.q + (long)b * a.ldq + head * dk;
+    for (int c = tid; c < dk; c += 256) qs[c] = qp[c] * a.scale;
+    __syncthreads();
+    // scores: 16 lanes x float4 per key row, 4 keys per wave, 16 keys per pass
+    const int sub = lane & 15, kq = lane >> 4, nv = dk >> 2;
+    for (int j0 = 0; j0 < n; j0 += 16) {
+        const int j = j0 + wave * 4 + kq;
+        float s = 0.f;
+        if (j < n) {
+            const float4* kp = reinterpret_cast<const float4*>(a.K + (base + (long)j * a.kstride) * a.ldkv + head * dk);
+            for (int c4 = sub; c4 < nv; c4 += 16) {
+                const float4 kv = kp[c4];
+                const float4 qv = *reinterpret_cast<const float4*>(qs + 4 * c4);
+                s = fmaf(kv.x, qv.x, s);
+                s = fmaf(kv.y, qv.y, s);
+                s = fmaf(kv.z, qv.z, s);
+                s = fmaf(kv.w, qv.w, s);
+            }
+        }
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 1);
+        if (j < n && sub == 0) sc[j] = s;
+    }
+    __syncthreads();
+    // softmax over the n keys
+    float m = -INFINITY;
+    for (int j = tid; j < n; j += 256) m = fmaxf(m, sc[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[256 + wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[256], red[257]), fmaxf(red[258], red[259]));
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float p = expf(sc[j] - m);
+        sc[j] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[260 + wave] = sum;
+    __syncthreads();   // also publishes the probabilities in sc[]
+    sum = (red[260] + red[261]) + (red[262] + red[263]);
+    const float inv = 1.f / sum;
+    // context: groups of dk threads walk the keys G apart, lanes across the head dimension (coalesced V rows)
+    const int G = 256 / dk;
+    const int g = tid / dk, c = tid - g * dk;
+    float acc = 0.f;
+    if (g < G) {
+        const float* vp = a.V + head * dk + c;
+#pragma unroll 4
+        for (int j = g; j < n; j += G) acc = fmaf(sc[j], vp[(base + (long)j * a.kstride) * a.ldkv], acc);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < dk) {
+        float o = 0.f;
+        for (int gg = 0; gg < G; ++gg) o += red[gg * dk + tid];
+        a.out[(long)b * a.ldo + head * dk + tid] = o * inv;
+    }
+    if (a.att) {
+        const int cap = a.att_cap[b];
+        if (a.step < cap) {
+            float* ap = a.att + a.att_off[b] + (((long)a.layer * gridDim.x + head) * cap + a.step) * n;
+            for (int j = tid; j < n; j += 256) ap[j] = sc[j] * inv;
+        }
+    }
+}
+
+// prob_out + sigmoid + the stop rule of :638-642, one wave per utterance.  len[b] == 0 while utterance b runs.
+__global__ __launch_bounds__(256) void k_tts_stop(const float* __restrict__ z, int A, const float* __restrict__ w,
+                                                  float bias, int B, int step, float thr,
+                                                  const int* __restrict__ minlen, const int* __restrict__ maxlen,
+                                                  float* __restrict__ probs, int* __restrict__ len,
+                                                  int* __restrict__ ndone) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int c = lane; c < A; c += 64) s = fmaf(z[(long)b * A + c], w[c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        const float p = 1.f / (1.f + expf(-(s + bias)));
+        probs[(long)(step - 1) * B + b] = p;
+        if (len[b] == 0 && (p >= thr || step >= maxlen[b]) && step >= minlen[b]) {
+            len[b] = step;
+            atomicAdd(ndone, 1);
+        }
+    }
+}
+
+// Position-major rows -> a row timeline (or packed rows through rowmap): timeline row r of utterance u at position p
+// takes src row (p + off) * B + u; gap rows are zeroed when rowmap == NULL.  Optional per-column affine.
+__global__ __launch_bounds__(128) void k_tts_gather(const float* __restrict__ src, int C, int B, int off,
+                                                    const int* __restrict__ row_utt, const int* __restrict__ row_pos,
+                                                    const int* __restrict__ rowmap, const float* __restrict__ cscale,
+                                                    const float* __restrict__ cshift, float* __restrict__ dst) {
+    const long r = blockIdx.x;
+    const int u = row_utt[r];
+    const long o = rowmap ? rowmap[r] : r;
+    if (o < 0) return;
+    if (u < 0) {
+        if (!rowmap)
+            for (int c = threadIdx.x; c < C; c += blockDim.x) dst[o * C + c] = 0.f;
+        return;
+    }
+    const float* s = src + ((long)(row_pos[r] + off) * B + u) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v = s[c];
+        if (cscale) v = v * cscale[c] + cshift[c];
+        dst[o * C + c] = v;
+    }
+}
+
+struct DecLayer {
+    size_t ln1_g, ln1_b, ln2_g, ln2_b, ln3_g, ln3_b;
+    Dense qkv, out, src_q, src_kv, src_out, ffn1, ffn2;
+};
+}  // namespace
+
+struct pk_tts : pk_fft_core {
+    pk_tts_cfg cfg;
+    pk_param_map params;
+    bool finalized = false, inferred = false;
+    int gapr = 1;
+    bool dropout = true;
+    // weights
+    size_t emb_table = 0;
+    float alpha_enc = 1.f, alpha_dec = 1.f;
+    std::vector<Dense> eprenet;
+    Dense eprenet_lin;
+    std::vector<pk_fft_layer> enc;
+    size_t enc_after_g = 0, enc_after_b = 0, dec_after_g = 0, dec_after_b = 0;
+    std::vector<Dense> dprenet;
+    Dense dlin, feat_out;
+    std::vector<DecLayer> dec;
+    size_t prob_w = 0;
+    float prob_b = 0.f;
+    std::vector<Dense> postnet;
+    size_t out_scale = 0, out_shift = 0;
+    bool has_out_affine = false;
+    std::vector<float> h_out_scale, h_out_shift;
+    // per call
+    Timeline tl_tok, tl_frm;
+    int B = 0, Lcap = 0, steps = 0;
+    bool keep_att = false;
+    std::vector<int> T, len, cap;
+    std::vector<long> att_off;
+    long att_total = 0;
+    pk_dbuf d_tok, d_e1, d_e2, d_tpe, d_hs, d_valid, d_y, d_p0, d_p1, d_x0, d_t, d_ham, d_peb, d_rt, d_rc, d_rx, d_rq,
+        d_rf, d_rz, d_probs, d_state, d_seeds, d_att, d_attoff, d_before, d_q1, d_q2, d_rowmap, d_stage, d_stage2;
+    std::vector<pk_dbuf> d_qkv_l, d_xc_l, d_mkv_l;
+};
+
+// ---------------------------------------------------------------------------------------------- create / params
+extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
+    if (!ctx || !cfg || !out) PK_FAIL(PK_EINVAL, "pk_tts_create: NULL argument");
+    *out = nullptr;
+    const pk_tts_cfg& c = *cfg;
+    if (c.idim <= 1 || c.odim <= 0 || c.adim <= 0 || c.aheads <= 0)
+        PK_FAIL(PK_EINVAL, "TransformerTTS: idim/odim/adim/aheads must be positive");
+    if (c.adim % c.aheads != 0) PK_FAIL(PK_ESHAPE, "TransformerTTS: adim %% aheads != 0 (attention.py:40)");
+    const int dk = c.adim / c.aheads;
+    if (dk != 64 && dk != 96 && dk != 128 && dk != 192)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: head size %d not built (64/96/128/192)", dk);
+    if (c.adim % 64 != 0 || c.adim > 64 * PK_FFT_LN_MAXPER)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: adim must be a multiple of 64, <= %d", 64 * PK_FFT_LN_MAXPER);
+    if (c.reduction_factor != 1) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: reduction_factor != 1 not implemented");
+    if (!c.encoder_normalize_before || !c.decoder_normalize_before)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: post-norm blocks not implemented");
+    if (c.encoder_concat_after || c.decoder_concat_after)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: concat_after not implemented");
+    if (!c.use_scaled_pos_enc) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: use_scaled_pos_enc=False not implemented");
+    if (c.spk_embed_dim > 0) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: speaker embeddings not implemented");
+    if (c.use_gst) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: global style tokens not implemented");
+    if (c.dprenet_layers <= 0)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: dprenet_layers == 0 (the 'linear' decoder input layer) not implemented");
+    if (c.dprenet_units % 16 != 0 || c.dprenet_units <= 0)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: dprenet_units must be a positive multiple of 16");
+    if (c.elayers < 0 || c.dlayers <= 0) PK_FAIL(PK_EINVAL, "TransformerTTS: elayers >= 0, dlayers > 0");
+    if (c.positionwise_layer_type < 0 || c.positionwise_layer_type > 2)
+        PK_FAIL(PK_EUNSUPPORTED, "Support only linear or conv1d. (encoder.py:169)");
+    if (c.postnet_layers > 0 && !c.use_batch_norm)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: postnet without batch norm not implemented");
+    if (c.eprenet_conv_layers > 0 && !c.use_batch_norm)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: encoder prenet without batch norm not implemented");
+    if (c.eprenet_conv_layers < 0 || c.postnet_layers < 0) PK_FAIL(PK_EINVAL, "TransformerTTS: negative layer count");
+    const int ks[] = {c.positionwise_conv_kernel_size, c.postnet_layers > 0 ? c.postnet_filts : 1,
+                      c.eprenet_conv_layers > 0 ? c.eprenet_conv_filts : 1};
+    int gapr = 1;
+    for (int k : ks) {
+        if (k < 1 || k % 2 == 0 || k > PK_GEMM_MAX_TAPS)
+            PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: conv kernel size %d unsupported", k);
+        gapr = std::max(gapr, (k - 1) / 2);
+    }
+    if (gapr > PK_FFT_LEAD) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: conv kernel too wide");
+    const int chans[] = {c.adim, c.eunits, c.dunits, c.odim, c.postnet_layers > 0 ? c.postnet_chans : 16,
+                         c.eprenet_conv_layers > 0 ? c.eprenet_conv_chans : 16,
+                         c.eprenet_conv_layers > 0 ? c.embed_dim : 16};
+    for (int ch : chans)
+        if (ch <= 0 || ch % PK_GEMM_BK != 0)
+            PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: channel count %d not a positive multiple of 16", ch);
+    pk_tts* h = new pk_tts();
+    h->ctx = ctx;
+    h->cfg = c;
+    h->adim = c.adim;
+    h->aheads = c.aheads;
+    h->gapr = gapr;
+    if (const char* e = getenv("PK_TTS_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
+    *out = h;
+    return PK_OK;
+}
+
+extern "C" int pk_tts_set_param(pk_tts* h, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_set_param: handle is NULL");
+    h->finalized = false;
+    return pk_store_param(h->params, name, data, shape, ndim);
+}
+
+extern "C" int pk_tts_set_normalizer(pk_tts* h, const float* mu, const float* sigma, int32_t n) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_set_normalizer: handle is NULL");
+    if (!mu && !sigma) {
+        h->has_out_affine = false;
+    } else {
+        if (!mu || !sigma || n != h->cfg.odim) PK_FAIL(PK_ESHAPE, "normalizer needs mu and sigma of odim elements");
+        h->h_out_scale.assign(sigma, sigma + n);   // ZScore.inverse: x * sigma + mu (normalizer.py:30-33)
+        h->h_out_shift.assign(mu, mu + n);
+        h->has_out_affine = true;
+    }
+    h->finalized = false;
+    return PK_OK;
+}
+
+extern "C" int pk_tts_set_math(pk_tts* h, int32_t mode) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_set_math: handle is NULL");
+    if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3) PK_FAIL(PK_EINVAL, "pk_tts_set_math: unknown mode %d", mode);
+    h->math = mode;
+    return PK_OK;
+}
+
+extern "C" int pk_tts_set_dropout(pk_tts* h, int32_t on) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_set_dropout: handle is NULL");
+    h->dropout = on != 0;
+    return PK_OK;
+}
+
+namespace {
+// k | v projections of one attention module fused into one [A][2A] dense layer
+int add_kv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A, Dense& d) {
+    std::vector<float> wk, wv, bk, bv, kn((size_t)A * 2 * A), bias(2 * A);
+    PK_TRY(pk_get_weight(P, p + ".linear_k", {A, A}, wk));
+    PK_TRY(pk_get_weight(P, p + ".linear_v", {A, A}, wv));
+    PK_TRY(pk_get_vector(P, p + ".linear_k.bias", A, bk));
+    PK_TRY(pk_get_vector(P, p + ".linear_v.bias", A, bv));
+    for (int i = 0; i < A; ++i)
+        for (int o = 0; o < A; ++o) {
+            kn[(size_t)i * 2 * A + o] = wk[(size_t)i * A + o];
+            kn[(size_t)i * 2 * A + A + o] = wv[(size_t)i * A + o];
+        }
+    for (int o = 0; o < A; ++o) {
+        bias[o] = bk[o];
+        bias[A + o] = bv[o];
+    }
+    return pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 2 * A, d);
+}
+
+int add_qkv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A, Dense& d) {
+    std::vector<float> wq, wk, wv, bq, bk, bv, kn((size_t)A * 3 * A), bias(3 * A);
+    PK_TRY(pk_get_weight(P, p + ".linear_q", {A, A}, wq));
+    PK_TRY(pk_get_weight(P, p + ".linear_k", {A, A}, wk));
+    PK_TRY(pk_get_weight(P, p + ".linear_v", {A, A}, wv));
+    PK_TRY(pk_get_vector(P, p + ".linear_q.bias", A, bq));
+    PK_TRY(pk_get_vector(P, p + ".linear_k.bias", A, bk));
+    PK_TRY(pk_get_vector(P, p + ".linear_v.bias", A, bv));
+    for (int i = 0; i < A; ++i)
+        for (int o = 0; o < A; ++o) {
+            kn[(size_t)i * 3 * A + o] = wq[(size_t)i * A + o];
+            kn[(size_t)i * 3 * A + A + o] = wk[(size_t)i * A + o];
+            kn[(size_t)i * 3 * A + 2 * A + o] = wv[(size_t)i * A + o];
+        }
+    for (int o = 0; o < A; ++o) {
+        bias[o] = bq[o];
+        bias[A + o] = bk[o];
+        bias[2 * A + o] = bv[o];
+    }
+    return pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 3 * A, d);
+}
+}  // namespace
+
+extern "C" int pk_tts_finalize(pk_tts* h) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_finalize: handle is NULL");
+    pk_ctx* ctx = h->ctx;
+    PK_DEVICE(ctx->device);
+    const pk_tts_cfg& c = h->cfg;
+    const pk_param_map& P = h->params;
+    const int A = c.adim;
+    h->arena_h.clear();
+    h->arena16_h.clear();
+    pk_fft_arena ar{h->arena_h, &h->arena16_h};
+    std::vector<float> al;
+    // encoder input layer (:258-277)
+    if (c.eprenet_conv_layers > 0) {
+        std::vector<float> t;
+        PK_TRY(pk_get_weight(P, "encoder.embed.0.0.embed", {c.idim, c.embed_dim}, t));
+        for (int i = 0; i < c.embed_dim; ++i) t[i] = 0.f;   // nn.Embedding(padding_idx=0): id 0 -> zero row
+        h->emb_table = ar.put(t);
+        h->eprenet.resize(c.eprenet_conv_layers);
+        for (int i = 0; i < c.eprenet_conv_layers; ++i) {
+            const std::string p = "encoder.embed.0.0.convs." + std::to_string(i);
+            PK_TRY(pk_fft_add_conv_bn(ar, P, p + ".0", p + ".1", c.eprenet_conv_chans,
+                                      i == 0 ? c.embed_dim : c.eprenet_conv_chans, c.eprenet_conv_filts, h->eprenet[i]));
+        }
+        PK_TRY(pk_fft_add_linear(ar, P, "encoder.embed.0.1", c.eprenet_conv_chans, A, h->eprenet_lin));
+    } else {
+        std::vector<float> t;
+        PK_TRY(pk_get_weight(P, "encoder.embed.0", {c.idim, A}, t));
+        for (int i = 0; i < A; ++i) t[i] = 0.f;
+        h->emb_table = ar.put(t);
+    }
+    PK_TRY(pk_get_vector(P, "encoder.embed.1.alpha", 1, al));
+    h->alpha_enc = al[0];
+    PK_TRY(pk_fft_add_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size,
+                            c.positionwise_layer_type, c.aheads, h->enc, h->enc_after_g, h->enc_after_b));
+    // decoder input layer: Sequential(Sequential(Prenet, Linear), ScaledPositionalEncoding) (:311-321, decoder.py:124-127)
+    h->dprenet.resize(c.dprenet_layers);
+    for (int j = 0; j < c.dprenet_layers; ++j)
+        PK_TRY(pk_fft_add_linear(ar, P, "decoder.embed.0.0.prenet." + std::to_string(j) + ".0",
+                                 j == 0 ? c.odim : c.dprenet_units, c.dprenet_units, h->dprenet[j]));
+    PK_TRY(pk_fft_add_linear(ar, P, "decoder.embed.0.1", c.dprenet_units, A, h->dlin));
+    PK_TRY(pk_get_vector(P, "decoder.embed.1.alpha", 1, al));
+    h->alpha_dec = al[0];
+    h->dec.resize(c.dlayers);
+    for (int l = 0; l < c.dlayers; ++l) {
+        const std::string p = "decoder.decoders." + std::to_string(l);
+        DecLayer& L = h->dec[l];
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm1.weight", A, L.ln1_g));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm1.bias", A, L.ln1_b));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm2.weight", A, L.ln2_g));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm2.bias", A, L.ln2_b));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm3.weight", A, L.ln3_g));
+        PK_TRY(pk_fft_add_vec(ar, P, p + ".norm3.bias", A, L.ln3_b));
+        PK_TRY(add_qkv(ar, P, p + ".self_attn", A, L.qkv));
+        PK_TRY(pk_fft_add_linear(ar, P, p + ".self_attn.linear_out", A, A, L.out));
+        PK_TRY(pk_fft_add_linear(ar, P, p + ".src_attn.linear_q", A, A, L.src_q));
+        PK_TRY(add_kv(ar, P, p + ".src_attn", A, L.src_kv));
+        PK_TRY(pk_fft_add_linear(ar, P, p + ".src_attn.linear_out", A, A, L.src_out));
+        PK_TRY(pk_fft_add_linear(ar, P, p + ".feed_forward.w_1", A, c.dunits, L.ffn1));   // PositionwiseFeedForward
+        PK_TRY(pk_fft_add_linear(ar, P, p + ".feed_forward.w_2", c.dunits, A, L.ffn2));
+    }
+    PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.weight", A, h->dec_after_g));
+    PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.bias", A, h->dec_after_b));
+    PK_TRY(pk_fft_add_linear(ar, P, "feat_out", A, c.odim, h->feat_out));
+    {
+        std::vector<float> w, b;
+        PK_TRY(pk_get_weight(P, "prob_out", {A, 1}, w));
+        PK_TRY(pk_get_vector(P, "prob_out.bias", 1, b));
+        h->prob_w = ar.put(w);
+        h->prob_b = b[0];
+    }
+    PK_TRY(pk_fft_add_postnet(ar, P, "postnet", c.postnet_layers, c.odim, c.postnet_chans, c.postnet_filts, h->postnet));
+    if (h->has_out_affine) {
+        h->out_scale = ar.put(h->h_out_scale);
+        h->out_shift = ar.put(h->h_out_shift);
+    }
+    PK_TRY(pk_upload(ctx, h->arena, h->arena_h.data(), h->arena_h.size() * sizeof(float)));
+    h->arena_h.clear();
+    h->arena_h.shrink_to_fit();
+    if (!h->arena16_h.empty())
+        PK_TRY(pk_upload(ctx, h->arena16, h->arena16_h.data(), h->arena16_h.size() * sizeof(uint16_t)));
+    h->arena16_h.clear();
+    h->arena16_h.shrink_to_fit();
+    PK_TRY(pk_fft_ensure_pe(h, 1024));
+    h->d_qkv_l.resize(c.dlayers);
+    h->d_xc_l.resize(c.dlayers);
+    h->d_mkv_l.resize(c.dlayers);
+    h->finalized = true;
+    h->inferred = false;
+    return PK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- inference
+namespace {
+constexpr int SLACK = 2 * PK_GEMM_BM;   // rows a GEMM tile may read beyond the rows it was asked for
+
+int rows_reserve(pk_dbuf& buf, long rows, int C) { return pk_fft_act_reserve(buf, (int)(rows + SLACK), C); }
+
+int attn_step(pk_tts* h, const char* name, const AttnStep& a, int heads, int B, int nmax) {
+    const size_t smem = (size_t)(a.dk + 264 + nmax + 4) * sizeof(float);
+    if (smem > 60 * 1024) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: %d attention keys exceed the step kernel's LDS budget", nmax);
+    PK_LAUNCH(h->ctx, name, k_tts_attn_step, dim3(heads, B), dim3(256), smem, a);
+    return PK_OK;
+}
+
+int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B) {
+    pk_ctx* ctx = h->ctx;
+    const pk_tts_cfg& c = h->cfg;
+    const int A = c.adim;
+    PK_TRY(pk_fft_build_timeline(ctx, h->tl_tok, h->T.data(), B, h->gapr));
+    Timeline& tl = h->tl_tok;
+    {
+        std::vector<int> tok(tl.rows_alloc, 0);
+        long o = 0;
+        for (int b = 0; b < B; ++b) {
+            for (int t = 0; t < tok_lens[b]; ++t, ++o) {
+                const int64_t id = ids[o];
+                if (id < 0 || id >= c.idim) PK_FAIL(PK_EINVAL, "pk_tts_infer: token id %lld out of [0,%d)", (long long)id, c.idim);
+                tok[tl.seg_start[b] + t] = (int)id;
+            }
+            tok[tl.seg_start[b] + tok_lens[b]] = c.idim - 1;   // <eos> (:563-565)
+        }
+        PK_TRY(pk_upload(ctx, h->d_tok, tok.data(), tok.size() * sizeof(int)));
+    }
+    PK_TRY(pk_fft_act_reserve(h->d_x, tl.rows, A));
+    PK_TRY(pk_fft_act_reserve(h->d_hs, tl.rows, A));
+    float* x = pk_fft_act_ptr(h->d_x, A);
+    float* hs = pk_fft_act_ptr(h->d_hs, A);
+    if (c.eprenet_conv_layers > 0) {
+        const int E = c.embed_dim, Cc = c.eprenet_conv_chans;
+        PK_TRY(pk_fft_act_reserve(h->d_e1, tl.rows, std::max(E, Cc)));
+        PK_TRY(pk_fft_act_reserve(h->d_e2, tl.rows, std::max(E, Cc)));
+        PK_TRY(pk_fft_act_reserve(h->d_tpe, tl.rows, A));
+        // the activation buffers are shared between widths: pointers are taken with the width actually stored
+        float* cur = pk_fft_act_ptr(h->d_e1, E);
+        PK_HIP(hipMemsetAsync(h->d_e1.p, 0, h->d_e1.cap, ctx->stream));   // margins read by the k > 1 taps
+        PK_HIP(hipMemsetAsync(h->d_e2.p, 0, h->d_e2.cap, ctx->stream));
+        PK_LAUNCH(ctx, "tts_lookup", k_tts_lookup, dim3(tl.rows), dim3(128), 0, h->d_tok.as<int>(), tl.d_row_utt(),
+                  h->W(h->emb_table), E, cur);
+        int ldin = E;
+        for (int i = 0; i < c.eprenet_conv_layers; ++i) {
+            // Conv1D(no bias) -> BatchNorm1D -> ReLU (-> Dropout: eval) (tacotron2/encoder.py:98-110); gap rows -> 0
+            float* nxt = pk_fft_act_ptr((i & 1) ? h->d_e1 : h->d_e2, Cc);
+            PK_TRY(pk_fft_run_dense(h, "tts_conv_eprenet", h->eprenet[i], cur, ldin, nxt, Cc, tl.rows, PK_ACT_RELU, nullptr,
+                                    0, tl.d_row_utt()));
+            cur = nxt;
+            ldin = Cc;
+        }
+        float* tpe = pk_fft_act_ptr(h->d_tpe, A);
+        PK_LAUNCH(ctx, "tts_pe", k_tts_pe_timeline, dim3(tl.rows), dim3(128), 0, h->d_pe.as<float>(), h->alpha_enc,
+                  tl.d_row_utt(), tl.d_row_pos(), A, tpe);
+        // Linear + x + alpha * pe
+        PK_TRY(pk_fft_run_dense(h, "tts_gemm_eprenet_lin", h->eprenet_lin, cur, ldin, x, A, tl.rows, PK_ACT_NONE, tpe, A,
+                                tl.d_row_utt()));
+    } else {
+        PK_TRY(pk_fft_embed(h, "tts_embed", h->d_tok.as<int>(), tl, h->emb_table, h->alpha_enc, 1.f, x));
+    }
+    PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    // encoder-decoder attention: K | V of the memory, once per decoder layer
+    for (int l = 0; l < c.dlayers; ++l) {
+        PK_TRY(pk_fft_act_reserve(h->d_mkv_l[l], tl.rows, 2 * A));
+        PK_TRY(pk_fft_run_dense(h, "tts_gemm_mem_kv", h->dec[l].src_kv, hs, A, pk_fft_act_ptr(h->d_mkv_l[l], 2 * A), 2 * A,
+                                tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));
+    }
+    return PK_OK;
+}
+}  // namespace
+
+extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int32_t B, double threshold,
+                            double minlenratio, double maxlenratio, const uint64_t* seeds, int32_t flags,
+                            int32_t* out_frames) {
+    if (!h || !ids || !tok_lens || !out_frames) PK_FAIL(PK_EINVAL, "pk_tts_infer: NULL argument");
+    if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_tts_infer: call pk_tts_finalize first");
+    if (B <= 0) PK_FAIL(PK_EINVAL, "pk_tts_infer: batch size must be positive");
+    if (!(minlenratio >= 0.0) || !(maxlenratio >= 0.0)) PK_FAIL(PK_EINVAL, "pk_tts_infer: length ratios must be >= 0");
+    pk_ctx* ctx = h->ctx;
+    PK_DEVICE(ctx->device);
+    const pk_tts_cfg& c = h->cfg;
+    const int A = c.adim, H = c.aheads, dk = A / H, O = c.odim, U = c.dprenet_units, J = c.dprenet_layers;
+    h->inferred = false;
+    h->B = B;
+    h->keep_att = (flags & PK_TTS_KEEP_ATT) != 0;
+    h->T.resize(B);
+    h->cap.resize(B);
+    std::vector<int> minlen(B), maxlen(B);
+    int maxT = 0, Lcap = 1;
+    for (int b = 0; b < B; ++b) {
+        if (tok_lens[b] < 0) PK_FAIL(PK_EINVAL, "pk_tts_infer: utterance %d has %d tokens", b, tok_lens[b]);
+        h->T[b] = tok_lens[b] + 1;                                   // with <eos>
+        maxlen[b] = (int)((double)h->T[b] * maxlenratio / 1.0);      // :597-598 (reduction_factor 1)
+        minlen[b] = (int)((double)h->T[b] * minlenratio / 1.0);
+        h->cap[b] = std::max(1, std::max(maxlen[b], minlen[b]));
+        maxT = std::max(maxT, h->T[b]);
+        Lcap = std::max(Lcap, h->cap[b]);
+    }
+    h->Lcap = Lcap;
+    const long rowsCap = (long)Lcap * B;
+    if (rowsCap + B + SLACK > 0x3fffffff) PK_FAIL(PK_EUNSUPPORTED, "pk_tts_infer: %ld decoder rows", rowsCap);
+    PK_TRY(pk_fft_ensure_pe(h, std::max(maxT, Lcap)));
+    PK_TRY(encode(h, ids, tok_lens, B));
+    const Timeline& tlk = h->tl_tok;
+    // ---- decoder state
+    PK_TRY(rows_reserve(h->d_y, rowsCap + B, O));
+    PK_TRY(rows_reserve(h->d_p0, rowsCap, U));
+    PK_TRY(rows_reserve(h->d_p1, rowsCap, U));
+    PK_TRY(rows_reserve(h->d_x0, rowsCap, A));
+    PK_TRY(rows_reserve(h->d_t, rowsCap, A));
+    PK_TRY(rows_reserve(h->d_ham, rowsCap, 1));
+    PK_TRY(rows_reserve(h->d_peb, rowsCap, A));
+    for (int l = 0; l < c.dlayers; ++l) {
+        PK_TRY(rows_reserve(h->d_qkv_l[l], rowsCap, 3 * A));
+        PK_TRY(rows_reserve(h->d_xc_l[l], rowsCap, A));
+    }
+    pk_dbuf* rowbufs[] = {&h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rz};
+    for (pk_dbuf* rb : rowbufs) PK_TRY(rows_reserve(*rb, B, A));
+    PK_TRY(rows_reserve(h->d_rf, B, c.dunits));
+    PK_TRY(h->d_probs.reserve((size_t)(rowsCap + B) * sizeof(float)));
+    // rows of a "timeline" whose every row is valid, for the LayerNorm launcher
+    {
+        const size_t nvalid = (size_t)(rowsCap + B + SLACK);
+        PK_TRY(h->d_valid.reserve(nvalid * sizeof(int)));
+        PK_HIP(hipMemsetAsync(h->d_valid.p, 0, nvalid * sizeof(int), ctx->stream));
+    }
+    // state block: [len B][minlen B][maxlen B][cap B][ndone 1]
+    {
+        std::vector<int> st(4 * (size_t)B + 1, 0);
+        for (int b = 0; b < B; ++b) {
+            st[B + b] = minlen[b];
+            st[2 * B + b] = maxlen[b];
+            st[3 * B + b] = h->cap[b];
+        }
+        PK_TRY(pk_upload(ctx, h->d_state, st.data(), st.size() * sizeof(int)));
+    }
+    int* d_len = h->d_state.as<int>();
+    const int* d_minlen = d_len + B;
+    const int* d_maxlen = d_len + 2 * B;
+    const int* d_cap = d_len + 3 * B;
+    int* d_ndone = d_len + 4 * B;
+    const unsigned long long* d_seeds = nullptr;
+    if (seeds) {
+        PK_TRY(pk_upload(ctx, h->d_seeds, seeds, (size_t)B * sizeof(uint64_t)));
+        d_seeds = h->d_seeds.as<unsigned long long>();
+    }
+    float* att = nullptr;
+    const long* d_attoff = nullptr;
+    h->att_off.assign(B, 0);
+    h->att_total = 0;
+    if (h->keep_att) {
+        for (int b = 0; b < B; ++b) {
+            h->att_off[b] = h->att_total;
+            h->att_total += (long)c.dlayers * H * h->cap[b] * h->T[b];
+        }
+        PK_TRY(h->d_att.reserve((size_t)h->att_total * sizeof(float)));
+        PK_TRY(pk_upload(ctx, h->d_attoff, h->att_off.data(), (size_t)B * sizeof(long)));
+        att = h->d_att.as<float>();
+        d_attoff = h->d_attoff.as<long>();
+    }
+    float* Y = pk_fft_act_ptr(h->d_y, O);
+    float* P[2] = {pk_fft_act_ptr(h->d_p0, U), pk_fft_act_ptr(h->d_p1, U)};
+    float* X0 = pk_fft_act_ptr(h->d_x0, A);
+    float* Tn = pk_fft_act_ptr(h->d_t, A);
+    float* ham = pk_fft_act_ptr(h->d_ham, 1);
+    float* PEB = pk_fft_act_ptr(h->d_peb, A);
+    float* rt = pk_fft_act_ptr(h->d_rt, A);
+    float* rc = pk_fft_act_ptr(h->d_rc, A);
+    float* rx = pk_fft_act_ptr(h->d_rx, A);
+    float* rq = pk_fft_act_ptr(h->d_rq, A);
+    float* rz = pk_fft_act_ptr(h->d_rz, A);
+    float* rf = pk_fft_act_ptr(h->d_rf, c.dunits);
+    const int* valid = h->d_valid.as<int>();
+    PK_HIP(hipMemsetAsync(Y, 0, (size_t)B * O * sizeof(float), ctx->stream));   // ys = zeros(1, 1, odim) (:601-602)
+    PK_LAUNCH(ctx, "tts_pe", k_tts_pe_pos_major, dim3((unsigned)rowsCap), dim3(128), 0, h->d_pe.as<float>(),
+              h->alpha_dec, B, A, PEB);
+    const unsigned thr = h->dropout ? pk_dropout_threshold(0.5) : 0u;   // F.dropout's default p (decoder.py:80)
+    const float dscale = 2.0f;
+    const float att_scale = (float)(1.0 / std::sqrt((double)dk));
+    static const int poll = getenv("PK_TTS_POLL") ? std::max(1, atoi(getenv("PK_TTS_POLL"))) : 4;
+    const bool use_ham = h->math == PK_GEMM_MATH_F16X3;
+    int s = 0;
+    for (s = 1; s <= Lcap; ++s) {
+        const int R = s * B;
+        const long nr = (long)(s - 1) * B;   // first new row
+        // decoder.embed on the whole prefix (decoder.py:210)
+        const float* in = Y;
+        int ldin = O;
+        for (int j = 0; j < J; ++j) {
+            float* o = P[j & 1];
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_prenet", h->dprenet[j], in, ldin, o, U, R, PK_ACT_RELU, nullptr, 0, nullptr));
+            if (h->dropout)
+                PK_LAUNCH(ctx, "tts_dropout", k_tts_dropout, dim3(pk_div_up((long)R * (U / 4), 256)), dim3(256), 0, o, R, U,
+                          B, (unsigned long long)s * (unsigned long long)(s - 1) / 2ull, J, j, d_seeds, thr, dscale);
+            in = o;
+            ldin = U;
+        }
+        PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, PEB, A, nullptr));
+        // layer 0: norm1 and q | k | v of every prefix row
+        PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
+        PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, Tn, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
+                                PK_ACT_NONE, nullptr, 0, nullptr, use_ham ? ham : nullptr));
+        for (int l = 0; l < c.dlayers; ++l) {
+            const DecLayer& L = h->dec[l];
+            const float* xin = (l == 0 ? X0 : pk_fft_act_ptr(h->d_xc_l[l - 1], A)) + nr * A;
+            float* qkv = pk_fft_act_ptr(h->d_qkv_l[l], 3 * A);
+            if (l > 0) {
+                PK_TRY(pk_fft_layernorm_rows(h, xin, L.ln1_g, L.ln1_b, valid, B, A, rt, use_ham ? ham : nullptr));
+                PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv", L.qkv, rt, A, qkv + nr * 3 * A, 3 * A, B, PK_ACT_NONE, nullptr, 0,
+                                        nullptr, use_ham ? ham : nullptr));
+            }
+            AttnStep a;
+            memset(&a, 0, sizeof(a));
+            a.q = qkv + nr * 3 * A; a.ldq = 3 * A;
+            a.K = qkv + A; a.V = qkv + 2 * A; a.ldkv = 3 * A;
+            a.kbase = nullptr; a.klen = nullptr; a.kstride = B; a.n = s; a.dk = dk; a.scale = att_scale;
+            a.out = rc; a.ldo = A;
+            PK_TRY(attn_step(h, "tts_attn_self", a, H, B, s));
+            // x = residual + self_attn(...)   (decoder_layer.py:127-128)
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_attn_out", L.out, rc, A, rx, A, B, PK_ACT_NONE, xin, A, nullptr));
+            // x = residual + src_attn(norm2(x), memory, memory)   (:132-141)
+            PK_TRY(pk_fft_layernorm_rows(h, rx, L.ln2_g, L.ln2_b, valid, B, A, rt, use_ham ? ham : nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_src_q", L.src_q, rt, A, rq, A, B, PK_ACT_NONE, nullptr, 0, nullptr,
+                                    use_ham ? ham : nullptr));
+            const float* mkv = pk_fft_act_ptr(h->d_mkv_l[l], 2 * A);
+            memset(&a, 0, sizeof(a));
+            a.q = rq; a.ldq = A;
+            a.K = mkv; a.V = mkv + A; a.ldkv = 2 * A;
+            a.kbase = tlk.d_seg_start(); a.klen = tlk.d_seg_len(); a.kstride = 1; a.n = 0; a.dk = dk; a.scale = att_scale;
+            a.out = rc; a.ldo = A;
+            a.att = att; a.att_off = d_attoff; a.att_cap = d_cap; a.layer = l; a.step = s - 1;
+            PK_TRY(attn_step(h, "tts_attn_src", a, H, B, maxT));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_src_out", L.src_out, rc, A, rx, A, B, PK_ACT_NONE, rx, A, nullptr));
+            // x = residual + feed_forward(norm3(x))   (:145-148); the result is the layer's cached output row
+            PK_TRY(pk_fft_layernorm_rows(h, rx, L.ln3_g, L.ln3_b, valid, B, A, rt, use_ham ? ham : nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_ffn1", L.ffn1, rt, A, rf, c.dunits, B, PK_ACT_RELU, nullptr, 0, nullptr,
+                                    use_ham ? ham : nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_ffn2", L.ffn2, rf, c.dunits, pk_fft_act_ptr(h->d_xc_l[l], A) + nr * A, A, B,
+                                    PK_ACT_NONE, rx, A, nullptr));
+        }
+        // after_norm of the last row, feat_out -> the next prefix row, prob_out -> stop state (:613-616, :638-642)
+        PK_TRY(pk_fft_layernorm_rows(h, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, h->dec_after_g, h->dec_after_b,
+                                     valid, B, A, rz, use_ham ? ham : nullptr));
+        PK_TRY(pk_fft_run_dense(h, "tts_gemm_feat_out", h->feat_out, rz, A, Y + (long)s * B * O, O, B, PK_ACT_NONE, nullptr, 0,
+                                nullptr, use_ham ? ham : nullptr));
+        PK_LAUNCH(ctx, "tts_stop", k_tts_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, rz, A, h->W(h->prob_w), h->prob_b, B, s,
+                  (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone);
+        if (s % poll == 0 || s == Lcap) {
+            int ndone = 0;
+            PK_HIP(hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PK_HIP(hipStreamSynchronize(ctx->stream));
+            if (ndone >= B) break;
+        }
+    }
+    h->steps = std::min(s, Lcap);
+    h->len.resize(B);
+    PK_HIP(hipMemcpyAsync(h->len.data(), d_len, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b) {
+        if (h->len[b] <= 0 || h->len[b] > h->steps)
+            PK_FAIL(PK_EHIP, "pk_tts_infer: utterance %d did not stop within %d steps (internal error)", b, h->steps);
+        out_frames[b] = h->len[b];
+    }
+    h->inferred = true;
+    return PK_OK;
+}
+
+extern "C" int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* att_out, int32_t flags) {
+    if (!h || !mel_out) PK_FAIL(PK_EINVAL, "pk_tts_read: NULL argument");
+    if (!h->inferred) PK_FAIL(PK_ESTATE, "pk_tts_read: call pk_tts_infer first");
+    if (att_out && !h->keep_att) PK_FAIL(PK_ESTATE, "pk_tts_read: attention weights need PK_TTS_KEEP_ATT at pk_tts_infer");
+    pk_ctx* ctx = h->ctx;
+    PK_DEVICE(ctx->device);
+    const pk_tts_cfg& c = h->cfg;
+    const int B = h->B, O = c.odim, H = c.aheads;
+    long total = 0;
+    for (int b = 0; b < B; ++b) total += h->len[b];
+    PK_TRY(pk_fft_build_timeline(ctx, h->tl_frm, h->len.data(), B, h->gapr));
+    Timeline& tl = h->tl_frm;
+    {
+        std::vector<int> rowmap(tl.rows_alloc, -1);
+        int o = 0;
+        for (int b = 0; b < B; ++b)
+            for (int l = 0; l < h->len[b]; ++l) rowmap[tl.seg_start[b] + l] = o++;
+        PK_TRY(pk_upload(ctx, h->d_rowmap, rowmap.data(), rowmap.size() * sizeof(int)));
+    }
+    const bool host = (flags & PK_HOST_IO) != 0;
+    float* d_mel = mel_out;
+    if (host) {
+        PK_TRY(h->d_stage.reserve((size_t)total * O * sizeof(float)));
+        d_mel = h->d_stage.as<float>();
+    }
+    const bool denorm = h->has_out_affine && (flags & PK_APPLY_NORMALIZER);   // TransformerTTSInference (:757-767)
+    const float* cs = denorm ? h->W(h->out_scale) : nullptr;
+    const float* ch = denorm ? h->W(h->out_shift) : nullptr;
+    const float* Y = pk_fft_act_ptr(h->d_y, O);
+    if (c.postnet_layers == 0) {
+        PK_LAUNCH(ctx, "tts_gather", k_tts_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
+                  h->d_rowmap.as<int>(), cs, ch, d_mel);
+    } else {
+        // outs on a frame timeline with zero gap rows, then outs + postnet(outs) (:644-648)
+        PK_TRY(pk_fft_act_reserve(h->d_before, tl.rows, O));
+        PK_HIP(hipMemsetAsync(h->d_before.p, 0, h->d_before.cap, ctx->stream));
+        float* before = pk_fft_act_ptr(h->d_before, O);
+        PK_LAUNCH(ctx, "tts_gather", k_tts_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
+                  (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, before);
+        PK_TRY(pk_fft_run_postnet(h, "tts_conv_postnet", h->postnet, before, O, c.postnet_chans, tl, h->d_q1, h->d_q2, d_mel,
+                                  h->d_rowmap.as<int>(), cs, ch));
+    }
+    if (host) PK_HIP(hipMemcpyAsync(mel_out, d_mel, (size_t)total * O * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (probs_out) {
+        float* d_p = probs_out;
+        if (host) {
+            PK_TRY(h->d_stage2.reserve((size_t)total * sizeof(float)));
+            d_p = h->d_stage2.as<float>();
+        }
+        PK_LAUNCH(ctx, "tts_gather", k_tts_gather, dim3(tl.rows), dim3(128), 0, h->d_probs.as<float>(), 1, B, 0,
+                  tl.d_row_utt(), tl.d_row_pos(), h->d_rowmap.as<int>(), (const float*)nullptr, (const float*)nullptr, d_p);
+        if (host) PK_HIP(hipMemcpyAsync(probs_out, d_p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (att_out) {
+        // per utterance (dlayers, heads, L_b, T_b) out of the (dlayers, heads, cap_b, T_b) store
+        long o = 0;
+        for (int b = 0; b < B; ++b) {
+            const size_t width = (size_t)h->len[b] * h->T[b] * sizeof(float);
+            const size_t spitch = (size_t)h->cap[b] * h->T[b] * sizeof(float);
+            PK_HIP(hipMemcpy2DAsync(att_out + o, width, h->d_att.as<float>() + h->att_off[b], spitch, width,
+                                    (size_t)c.dlayers * H, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+            o += (long)c.dlayers * H * h->len[b] * h->T[b];
+        }
+    }
+    if (host) PK_HIP(hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+/* what: 0 = encoder output hs (T_b, adim), 1 = outs before the postnet (L_b, odim), 2 = last decoder layer's output
+ * rows (L_b, adim). */
+extern "C" int pk_tts_debug_read(pk_tts* h, int32_t what, int32_t b, float* host_out, int64_t n_floats) {
+    if (!h || !host_out) PK_FAIL(PK_EINVAL, "pk_tts_debug_read: NULL argument");
+    if (!h->inferred) PK_FAIL(PK_ESTATE, "pk_tts_debug_read: nothing has run");
+    if (b < 0 || b >= h->B) PK_FAIL(PK_EINVAL, "pk_tts_debug_read: utterance out of range");
+    pk_ctx* ctx = h->ctx;
+    PK_DEVICE(ctx->device);
+    const int A = h->cfg.adim, O = h->cfg.odim, B = h->B;
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    if (what == 0) {
+        const long n = (long)h->T[b] * A;
+        if (n_floats != n) PK_FAIL(PK_ESHAPE, "pk_tts_debug_read: expected %ld floats, got %lld", n, (long long)n_floats);
+        PK_HIP(hipMemcpy(host_out, pk_fft_act_ptr(h->d_hs, A) + (long)h->tl_tok.seg_start[b] * A, n * sizeof(float),
+                         hipMemcpyDeviceToHost));
+        return PK_OK;
+    }
+    if (what != 1 && what != 2) PK_FAIL(PK_EINVAL, "pk_tts_debug_read: unknown tap %d", what);
+    const int C = what == 1 ? O : A;
+    const float* src = what == 1 ? pk_fft_act_ptr(h->d_y, O) + (long)B * O
+                                 : pk_fft_act_ptr(h->d_xc_l[h->cfg.dlayers - 1], A);
+    const long n = (long)h->len[b] * C;
+    if (n_floats != n) PK_FAIL(PK_ESHAPE, "pk_tts_debug_read: expected %ld floats, got %lld", n, (long long)n_floats);
+    // rows (p * B + b) of a position-major array: one strided copy
+    PK_HIP(hipMemcpy2D(host_out, (size_t)C * sizeof(float), src + (long)b * C, (size_t)B * C * sizeof(float),
+                       (size_t)C * sizeof(float), (size_t)h->len[b], hipMemcpyDeviceToHost));
+    return PK_OK;
+}
+
+extern "C" void pk_tts_destroy(pk_tts* h) {
+    if (!h) return;
+    pk_device_guard _dg(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    h->release_core();
+    pk_dbuf* bufs[] = {&h->d_tok, &h->d_e1, &h->d_e2, &h->d_tpe, &h->d_hs, &h->d_valid, &h->d_y, &h->d_p0, &h->d_p1,
+                       &h->d_x0, &h->d_t, &h->d_ham, &h->d_peb, &h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rf, &h->d_rz,
+                       &h->d_probs, &h->d_state, &h->d_seeds, &h->d_att, &h->d_attoff, &h->d_before, &h->d_q1, &h->d_q2,
+                       &h->d_rowmap, &h->d_stage, &h->d_stage2};
+    for (auto* b : bufs) b->release();
+    for (auto& b : h->d_qkv_l) b.release();
+    for (auto& b : h->d_xc_l) b.release();
+    for (auto& b : h->d_mkv_l) b.release();
+    h->tl_tok.release();
+    h->tl_frm.release();
+    delete h;
+}

@@ -1,0 +1,115 @@
+"""TransformerTTS on the HIP engine (csrc/tts.hip) vs the golden vectors of the reference source (dropout stream
+injected, tools/make_golden_ar.py) and vs the fp64 oracle, through the C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transformer_tts_ref as tt
+from parakeet_amd import synthetic as syn
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ar_cases import TTS_CASES  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _model(cfg, idim, state, math=None):
+    from parakeet_amd.transformer_tts import TransformerTTS
+    m = TransformerTTS(idim=idim, odim=80, **cfg)
+    m.set_state_dict(state)
+    m.eval()
+    if math:
+        m.set_math(math)
+    return m
+
+
+def _close(a, b, l1=1e-4, mx=2e-3):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return a.shape == b.shape and np.abs(a - b).mean() < l1 and np.abs(a - b).max() < mx
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", [c[0] for c in TTS_CASES])
+def test_engine_matches_reference_source(case, math):
+    name, over, idim, T, seed, skw, kw = [c for c in TTS_CASES if c[0] == case][0]
+    g = np.load(os.path.join(GOLD, "transformer_tts.npz"))
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, **over)
+    m = _model(cfg, idim, syn.transformer_tts_state(idim, 80, cfg, seed=seed, **skw), math)
+    mel, probs, att = m.inference(g[f"{name}_ids"], seed=seed, **kw)
+    assert mel.shape == g[f"{name}_mel"].shape                      # same stop decision
+    assert _close(mel.numpy(), g[f"{name}_mel"])                    # mel L1 bar of the north star
+    assert np.abs(probs.numpy() - g[f"{name}_probs"]).max() < 1e-4
+    assert att.shape == g[f"{name}_att"].shape
+    assert np.abs(att.numpy() - g[f"{name}_att"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+def test_engine_vs_fp64_oracle_with_taps(math):
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=2, dlayers=2, postnet_layers=3)
+    state = syn.transformer_tts_state(50, 80, cfg, seed=77, stop_bias=-6.0)
+    ids = syn.phoneme_ids(12, idim=50, seed=78)
+    m = _model(cfg, 50, state, math)
+    mel, probs, att = m.inference(ids, maxlenratio=2.0, seed=5)
+    ref, rprobs, ratt, parts = tt.inference(state, ids, cfg, maxlenratio=2.0, seed=5, dtype=torch.float64,
+                                            return_parts=True)
+    assert mel.shape == ref.shape == (26, 80)
+    assert np.abs(m.debug_tap(0, 0) - parts["hs"].numpy()).max() < 1e-4          # encoder output
+    assert np.abs(m.debug_tap(2, 0) - parts["zs"].numpy()).max() < 2e-4          # last decoder layer, every step
+    assert np.abs(m.debug_tap(1, 0) - parts["before"].numpy()).max() < 2e-4      # outs before the postnet
+    assert _close(mel.numpy(), ref.numpy())
+    assert np.abs(probs.numpy() - rprobs.numpy()).max() < 1e-4
+    assert np.abs(att.numpy() - ratt.numpy()).max() < 1e-4
+    assert np.abs(att.numpy().sum(-1) - 1.0).max() < 1e-5                        # softmax rows
+
+
+def test_ragged_batch_equals_single_utterances():
+    """Lockstep decoding of utterances that stop at different steps, each with its own dropout seed: every
+    utterance must reproduce its single-utterance run (rows of finished utterances are ignored)."""
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=2, postnet_layers=2)
+    state = syn.transformer_tts_state(40, 80, cfg, seed=12, stop_bias=-0.7, stop_gain=2.0)
+    m = _model(cfg, 40, state)
+    texts = [syn.phoneme_ids(T, idim=40, seed=300 + T) for T in (6, 2, 9, 4)]
+    seeds = [12, 13, 14, 15]
+    outs = m.inference_batch(texts, maxlenratio=3.0, seeds=seeds)
+    lens = [int(o[0].shape[0]) for o in outs]
+    assert lens == [18, 9, 30, 4]                                                # stop token, maxlen, maxlen, stop token
+    for t, sd, (mel, probs, att) in zip(texts, seeds, outs):
+        ref, rprobs, ratt = tt.inference(state, t, cfg, maxlenratio=3.0, seed=sd, dtype=torch.float64)
+        assert _close(mel.numpy(), ref.numpy())
+        assert np.abs(probs.numpy() - rprobs.numpy()).max() < 1e-4
+        assert np.abs(att.numpy() - ratt.numpy()).max() < 1e-4
+        one = m.inference(t, maxlenratio=3.0, seed=sd)
+        assert one[0].shape == mel.shape and np.abs(one[0].numpy() - mel.numpy()).max() < 1e-5
+
+
+def test_dropout_switch_normalizer_and_errors():
+    from parakeet_amd.normalizer import ZScore
+    from parakeet_amd.transformer_tts import TransformerTTS, TransformerTTSInference
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=1, postnet_layers=0)
+    state = syn.transformer_tts_state(40, 80, cfg, seed=3, stop_bias=-6.0)
+    ids = syn.phoneme_ids(5, idim=40, seed=4)
+    m = _model(cfg, 40, state)
+    a = m.inference(ids, maxlenratio=1.0, seed=1)[0].numpy()
+    b = m.inference(ids, maxlenratio=1.0, seed=2)[0].numpy()
+    assert np.abs(a - b).max() > 1e-3                                            # the mask is live
+    assert np.array_equal(a, m.inference(ids, maxlenratio=1.0, seed=1)[0].numpy())   # and reproducible
+    m.set_dropout(False)
+    c = m.inference(ids, maxlenratio=1.0)[0].numpy()
+    ref = tt.inference(state, ids, cfg, maxlenratio=1.0, drop=None, dtype=torch.float64)[0].numpy()
+    assert _close(c, ref)
+    m.set_dropout(True)
+    mu, sigma = syn.mel_stats(seed=9)
+    inf = TransformerTTSInference(ZScore(mu, sigma), m)
+    lm = inf(ids, seed=1).numpy()                                                # default maxlenratio 10
+    raw = m.inference(ids, seed=1)[0].numpy()
+    assert np.abs(lm - (raw * sigma + mu)).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        TransformerTTS(idim=40, odim=80, **dict(cfg, reduction_factor=2))
+    with pytest.raises(NotImplementedError):
+        TransformerTTS(idim=40, odim=80, **dict(cfg, spk_embed_dim=64))
+    with pytest.raises(ValueError):
+        m.inference(np.array([1, 2, 40]))                                        # id out of range
