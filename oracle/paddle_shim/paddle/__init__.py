@@ -150,10 +150,18 @@ def reshape(x, shape):
 
 
 def unsqueeze(x, axis):
+    if isinstance(axis, (list, tuple)):
+        for a in axis:
+            x = torch.unsqueeze(x, a)
+        return _wrap(x)
     return _wrap(torch.unsqueeze(x, axis))
 
 
 def squeeze(x, axis=None):
+    if isinstance(axis, (list, tuple)):
+        for a in sorted((a % x.dim() for a in axis), reverse=True):
+            x = torch.squeeze(x, a)
+        return _wrap(x)
     return _wrap(torch.squeeze(x) if axis is None else torch.squeeze(x, axis))
 
 

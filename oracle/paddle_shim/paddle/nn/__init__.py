@@ -169,6 +169,97 @@ class Embedding(Layer):
         return _wrap(out)
 
 
+class LSTMCell(Layer):
+    """paddle.nn.LSTMCell: weight_ih [4H, in], weight_hh [4H, H], bias_ih / bias_hh [4H]; gates in the order
+    i, f, g (cell candidate), o along the 4H axis; c' = f * c + i * tanh(g), h' = o * tanh(c')
+    [paddle-semantics, from Paddle's API documentation of LSTMCell].  forward -> (h', (h', c'))."""
+
+    def __init__(self, input_size, hidden_size, weight_ih_attr=None, weight_hh_attr=None, bias_ih_attr=None,
+                 bias_hh_attr=None, name=None):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        k = 1.0 / math.sqrt(hidden_size)
+        for nm, shape in (("weight_ih", (4 * hidden_size, input_size)), ("weight_hh", (4 * hidden_size, hidden_size)),
+                          ("bias_ih", (4 * hidden_size,)), ("bias_hh", (4 * hidden_size,))):
+            p = torch.nn.Parameter(torch.empty(*shape).uniform_(-k, k), requires_grad=False)
+            self.register_parameter(nm, p)
+
+    def forward(self, inputs, states=None):
+        if states is None:
+            z = torch.zeros(inputs.shape[0], self.hidden_size, dtype=inputs.dtype)
+            states = (z, z)
+        h, c = states
+        gates = torch.matmul(inputs, self.weight_ih.t()) + self.bias_ih + torch.matmul(h, self.weight_hh.t()) + self.bias_hh
+        i, f, g, o = torch.chunk(gates, 4, dim=-1)
+        c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h2 = torch.sigmoid(o) * torch.tanh(c2)
+        return _wrap(h2), (_wrap(h2), _wrap(c2))
+
+
+class _BiRNN(Layer):
+    def __init__(self, cell_fw, cell_bw):
+        super().__init__()
+        self.cell_fw, self.cell_bw = cell_fw, cell_bw
+
+
+class _RNN(Layer):
+    def __init__(self, cell):
+        super().__init__()
+        self.cell = cell
+
+
+class LSTM(torch.nn.ModuleList, Layer):
+    """paddle.nn.LSTM (RNNBase is a LayerList): sublayer "{layer}" is RNN(cell) or BiRNN(cell_fw, cell_bw), and every
+    cell parameter is ALSO registered on the LSTM itself under the cuDNN-style names weight_ih_l{k}[_reverse], ...
+    (RNNBase.__init__ setattr's them), so a state dict carries both "lstm.0.cell_fw.weight_ih" and
+    "lstm.weight_ih_l0" for the same array [paddle-semantics, from the 2.1 source of python/paddle/nn/layer/rnn.py as
+    recalled; unverified].  batch-first unless time_major; outputs = concat(forward, backward) on the last axis;
+    zero initial states; sequence_length=None processes every step."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, direction="forward", time_major=False, dropout=0.0,
+                 weight_ih_attr=None, weight_hh_attr=None, bias_ih_attr=None, bias_hh_attr=None, name=None):
+        torch.nn.ModuleList.__init__(self)
+        self.bidirectional = direction in ("bidirectional", "bidirect")
+        assert self.bidirectional or direction == "forward", direction
+        self.time_major, self.hidden_size, self.num_layers = time_major, hidden_size, num_layers
+        nd = 2 if self.bidirectional else 1
+        for layer in range(num_layers):
+            isz = input_size if layer == 0 else nd * hidden_size
+            if self.bidirectional:
+                self.append(_BiRNN(LSTMCell(isz, hidden_size), LSTMCell(isz, hidden_size)))
+            else:
+                self.append(_RNN(LSTMCell(isz, hidden_size)))
+            cells = [self[layer].cell_fw, self[layer].cell_bw] if self.bidirectional else [self[layer].cell]
+            for d, cell in enumerate(cells):
+                suffix = "_reverse" if d == 1 else ""
+                for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    self.register_parameter(f"{nm}_l{layer}{suffix}", getattr(cell, nm))
+
+    def flatten_parameters(self):
+        return None
+
+    def forward(self, inputs, initial_states=None, sequence_length=None):
+        assert initial_states is None and sequence_length is None, "only the inference call pattern is restated"
+        x = inputs.transpose(0, 1) if not self.time_major else inputs          # (T, B, C)
+        x = x.as_subclass(torch.Tensor) if isinstance(x, torch.Tensor) else x
+        hs, cs = [], []
+        for layer in range(self.num_layers):
+            cells = [self[layer].cell_fw, self[layer].cell_bw] if self.bidirectional else [self[layer].cell]
+            outs = []
+            for d, cell in enumerate(cells):
+                steps = range(x.shape[0] - 1, -1, -1) if d == 1 else range(x.shape[0])
+                state, seq = None, [None] * x.shape[0]
+                for t in steps:
+                    h, state = cell(x[t], state)
+                    seq[t] = h
+                outs.append(torch.stack(seq, dim=0))
+                hs.append(state[0])
+                cs.append(state[1])
+            x = torch.cat(outs, dim=-1)
+        y = x if self.time_major else x.transpose(0, 1)
+        return _wrap(y), (_wrap(torch.stack(hs, 0)), _wrap(torch.stack(cs, 0)))
+
+
 class Dropout(Layer):
     def __init__(self, p=0.5, axis=None, mode="upscale_in_train", name=None):
         super().__init__()

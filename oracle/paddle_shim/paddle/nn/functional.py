@@ -126,3 +126,7 @@ def softmax(x, axis=-1):
 
 def normalize(x, p=2, axis=1, epsilon=1e-12):
     return _wrap(TF.normalize(x, p=p, dim=axis, eps=epsilon))
+
+
+def tanh(x):
+    return _wrap(torch.tanh(x))

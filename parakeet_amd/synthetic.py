@@ -420,3 +420,76 @@ def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, 
         st[f"postnet.postnet.{j}.0.weight"] = _xavier(rng, (cout, cin, kf))
         bn(f"postnet.postnet.{j}.1", cout)
     return st
+
+
+# examples/tacotron2/config.py:31-54
+TACOTRON2_LJSPEECH = dict(
+    vocab_size=37, n_tones=None, d_mels=80, reduction_factor=1, d_encoder=512, encoder_conv_layers=3,
+    encoder_kernel_size=5, d_prenet=256, d_attention_rnn=1024, d_decoder_rnn=1024, d_attention=128,
+    attention_filters=32, attention_kernel_size=31, d_postnet=512, postnet_kernel_size=5, postnet_conv_layers=5,
+    p_encoder_dropout=0.5, p_prenet_dropout=0.5, p_attention_dropout=0.1, p_decoder_dropout=0.1,
+    p_postnet_dropout=0.5, d_global_condition=None, use_stop_token=True)
+
+
+def tacotron2_state(cfg=None, seed=2222, stop_bias=0.0, stop_gain=1.0, lstm_aliases=True):
+    """Tacotron2 state dict (parakeet/models/tacotron2.py:626-689).  ``lstm_aliases``: paddle.nn.LSTM registers every
+    cell parameter twice -- "encoder.lstm.0.cell_fw.weight_ih" and the cuDNN-style "encoder.lstm.weight_ih_l0"
+    (RNNBase.__init__) -- and a state dict carries both names for the same array; False keeps only the cell names."""
+    cfg = dict(TACOTRON2_LJSPEECH, **(cfg or {}))
+    rng = np.random.default_rng(seed)
+    E, M = cfg["d_encoder"], cfg["d_mels"] * cfg["reduction_factor"]
+    st = {}
+
+    def u(shape, lim):
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    def conv_bn(prefix, cout, cin, k):
+        st[prefix + ".conv.weight"] = _xavier(rng, (cout, cin, k))
+        st[prefix + ".conv.bias"] = u((cout,), 0.1)
+        st[prefix + ".bn.weight"] = rng.uniform(0.5, 1.5, size=(cout,)).astype(np.float32)
+        st[prefix + ".bn.bias"] = u((cout,), 0.1)
+        st[prefix + ".bn._mean"] = u((cout,), 0.1)
+        st[prefix + ".bn._variance"] = rng.uniform(0.5, 1.5, size=(cout,)).astype(np.float32)
+
+    def lstm_cell(prefix, isz, hsz):
+        k = 1.0 / math.sqrt(hsz)
+        st[prefix + ".weight_ih"] = u((4 * hsz, isz), k)
+        st[prefix + ".weight_hh"] = u((4 * hsz, hsz), k)
+        st[prefix + ".bias_ih"] = u((4 * hsz,), k)
+        st[prefix + ".bias_hh"] = u((4 * hsz,), k)
+
+    st["embedding.weight"] = u((cfg["vocab_size"], E), 0.5)
+    if cfg.get("n_tones"):
+        t = u((cfg["n_tones"], E), 0.3)
+        t[0] = 0.0   # padding_idx=0
+        st["embedding_tones.weight"] = t
+    for i in range(cfg["encoder_conv_layers"]):
+        conv_bn(f"encoder.conv_batchnorms.{i}", E, E, cfg["encoder_kernel_size"])
+    Hh = E // 2
+    for d, nm in enumerate(("cell_fw", "cell_bw")):
+        lstm_cell(f"encoder.lstm.0.{nm}", E, Hh)
+        if lstm_aliases:
+            suffix = "_reverse" if d else ""
+            for p in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                st[f"encoder.lstm.{p}_l0{suffix}"] = st[f"encoder.lstm.0.{nm}.{p}"]
+    De = E + (cfg.get("d_global_condition") or 0)
+    P, Ha, Hd, Da = cfg["d_prenet"], cfg["d_attention_rnn"], cfg["d_decoder_rnn"], cfg["d_attention"]
+    st["decoder.prenet.linear1.weight"] = _xavier(rng, (M, P))
+    st["decoder.prenet.linear2.weight"] = _xavier(rng, (P, P))
+    lstm_cell("decoder.attention_rnn", P + De, Ha)
+    st["decoder.attention_layer.query_layer.weight"] = _xavier(rng, (Ha, Da))
+    st["decoder.attention_layer.key_layer.weight"] = _xavier(rng, (De, Da))
+    st["decoder.attention_layer.value.weight"] = (_xavier(rng, (Da, 1)) * 4.0).astype(np.float32)   # peaky alignments
+    F, K = cfg["attention_filters"], cfg["attention_kernel_size"]
+    st["decoder.attention_layer.location_conv.weight"] = _xavier(rng, (F, 2, K))
+    st["decoder.attention_layer.location_layer.weight"] = _xavier(rng, (F, Da))
+    lstm_cell("decoder.decoder_rnn", Ha + De, Hd)
+    st["decoder.linear_projection.weight"] = _xavier(rng, (Hd + De, M))
+    st["decoder.linear_projection.bias"] = u((M,), 0.1)
+    if cfg["use_stop_token"]:
+        st["decoder.stop_layer.weight"] = (_xavier(rng, (Hd + De, 1)) * stop_gain).astype(np.float32)
+        st["decoder.stop_layer.bias"] = np.array([stop_bias], dtype=np.float32)
+    n, C, kf = cfg["postnet_conv_layers"], cfg["d_postnet"], cfg["postnet_kernel_size"]
+    for j in range(n):
+        conv_bn(f"postnet.conv_batchnorms.{j}", M if j == n - 1 else C, M if j == 0 else C, kf)
+    return st

@@ -17,3 +17,21 @@ TTS_CASES = [
                      eprenet_conv_chans=64, adim=256, aheads=4, eunits=512, dunits=512, dprenet_units=128,
                      positionwise_conv_kernel_size=3), 30, 8, 14, dict(stop_bias=-6.0), dict(maxlenratio=1.0)),
 ]
+
+# Tacotron2: name, config overrides on synthetic.TACOTRON2_LJSPEECH, tokens, seed (weights, ids = 800 + seed, dropout
+# stream), keyword arguments of synthetic.tacotron2_state, max_decoder_steps
+_T2_SMALL = dict(d_encoder=128, encoder_conv_layers=2, d_prenet=64, d_attention_rnn=128, d_decoder_rnn=128, d_attention=64,
+                 attention_filters=8, attention_kernel_size=7, d_postnet=64, postnet_conv_layers=3)
+T2_CASES = [
+    # the stop token fires through the normal path (sigmoid(stop_logit) > 0.5) at step 29 of at most 60; the head's
+    # gain / bias are chosen so that the logit is 0.15 away from zero at its two closest steps
+    ("stop", dict(_T2_SMALL), 11, 21, dict(stop_bias=-31.4, stop_gain=500.0), 60),
+    # no stop token: "content exhausted" rule on the alignment argmax (:520-525)
+    ("nostop", dict(_T2_SMALL, use_stop_token=False), 7, 22, dict(), 60),
+    # max_decoder_steps reached (:526-528)
+    ("maxsteps", dict(_T2_SMALL, p_prenet_dropout=0.25), 9, 23, dict(stop_bias=-8.0), 12),
+    # tone embedding (padding id 0 included)
+    ("tones", dict(_T2_SMALL, n_tones=5), 8, 24, dict(stop_bias=-8.0), 10),
+    # the LJSpeech recipe's sizes (examples/tacotron2/config.py:31-54)
+    ("lj", dict(), 12, 25, dict(stop_bias=-8.0), 14),
+]

@@ -6,11 +6,12 @@ import sys
 import numpy as np
 
 from oracle import philox_ref
+from oracle import tacotron2_ref as t2
 from oracle import transformer_tts_ref as tt
 from parakeet_amd import synthetic as syn
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from ar_cases import TTS_CASES  # noqa: E402
+from ar_cases import T2_CASES, TTS_CASES  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -164,3 +165,40 @@ def test_engine_decoding_schedule_is_the_reference_loop():
         assert np.abs(probs.numpy() - rprobs.numpy()).max() < 1e-12
         lens.append(ref.shape[0])
     assert len(set(lens)) > 1
+
+
+def test_tacotron2_oracle_matches_reference_source():
+    g = np.load(os.path.join(GOLD, "tacotron2.npz"))
+    for name, over, T, seed, skw, max_steps in T2_CASES:
+        cfg = dict(syn.TACOTRON2_LJSPEECH, **over)
+        state = syn.tacotron2_state(cfg, seed=seed, **skw)
+        o = t2.infer(state, g[f"{name}_ids"], cfg, tones=g[f"{name}_tones"] if cfg["n_tones"] else None,
+                     max_decoder_steps=max_steps, seed=seed)
+        for k, v in o.items():
+            assert v.shape == g[f"{name}_{k}"].shape, (name, k)          # same stop decision
+            tol = 2e-3 if (k == "stop_logits" and name == "stop") else 2e-5   # that head has a gain of 500
+            assert np.abs(v.numpy() - g[f"{name}_{k}"]).max() < tol, (name, k)
+    # the three ways a run ends
+    p = 1.0 / (1.0 + np.exp(-g["stop_stop_logits"]))
+    assert p[-1] > 0.5 and (p[:-1] <= 0.5).all() and len(p) == 29 and abs(p[-1] - 0.5) > 0.02
+    assert "nostop_stop_logits" not in g.files
+    a = g["nostop_alignments"].argmax(-1)
+    first = int(np.argmax(a == a.shape[0] * 0 + g["nostop_ids"].shape[0] - 1))
+    assert len(a) == first + 22                                          # i > first_hit_end + 20 (:523-525)
+    assert g["maxsteps_mel_output"].shape[0] == 12
+
+
+def test_tacotron2_lstm_aliases_and_dropout():
+    import torch
+    cfg = dict(syn.TACOTRON2_LJSPEECH, **T2_CASES[2][1])
+    a = syn.tacotron2_state(cfg, seed=5, stop_bias=-8.0, lstm_aliases=True)
+    b = syn.tacotron2_state(cfg, seed=5, stop_bias=-8.0, lstm_aliases=False)
+    assert set(a) - set(b) == {f"encoder.lstm.{p}_l0{s}" for p in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+                               for s in ("", "_reverse")}
+    assert np.array_equal(a["encoder.lstm.weight_hh_l0_reverse"], a["encoder.lstm.0.cell_bw.weight_hh"])
+    ids = np.arange(1, 8)
+    x = t2.infer(b, ids, cfg, max_decoder_steps=5, seed=1)["mel_output"].numpy()
+    y = t2.infer(b, ids, cfg, max_decoder_steps=5, seed=2)["mel_output"].numpy()
+    z = t2.infer(b, ids, cfg, max_decoder_steps=5, drop=None)["mel_output"].numpy()
+    assert x.shape == (5, 80) and np.abs(x - y).max() > 1e-3 and np.abs(x - z).max() > 1e-3
+    assert np.array_equal(x[0], y[0])   # step 0: the query is zero, relu(0) = 0, the mask is moot

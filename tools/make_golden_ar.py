@@ -23,6 +23,7 @@ import paddle  # noqa: E402  (the shim)
 import paddle.nn.functional as PF  # noqa: E402
 
 from oracle import philox_ref  # noqa: E402
+from oracle import tacotron2_ref as t2_ref  # noqa: E402
 from oracle import transformer_tts_ref as tt_ref  # noqa: E402
 from parakeet_amd import synthetic as syn  # noqa: E402
 
@@ -46,7 +47,7 @@ class TransformerTTSDropout:
 
 
 sys.path.insert(0, os.path.join(ref_import.ROOT, "tests"))
-from ar_cases import TTS_CASES  # noqa: E402
+from ar_cases import T2_CASES, TTS_CASES  # noqa: E402
 
 
 def golden_transformer_tts():
@@ -73,6 +74,52 @@ def golden_transformer_tts():
         print("transformer_tts", name, out[f"{name}_mel"].shape, out[f"{name}_att"].shape,
               "probs", np.round(out[f"{name}_probs"], 3)[:12])
     np.savez_compressed(os.path.join(OUT, "transformer_tts.npz"), **out)
+
+
+class Tacotron2Dropout:
+    """F.dropout hook for Tacotron2.infer: only DecoderPreNet calls it with training=True (models/tacotron2.py:76-79),
+    twice per decoding step on a (1, d_prenet) query."""
+
+    def __init__(self, seed, units, p):
+        self.drop = t2_ref.stream_dropout(seed, units, p)
+        self.p, self.calls = p, 0
+
+    def __call__(self, x, p):
+        assert p == self.p and x.dim() == 2 and x.shape[0] == 1
+        step, layer = divmod(self.calls, 2)
+        self.calls += 1
+        keep = torch.as_tensor(self.drop(step, layer, int(x.shape[1])))
+        return torch.where(keep.unsqueeze(0), x / (1.0 - p), torch.zeros_like(x))
+
+
+def golden_tacotron2():
+    t2m = ref_import.load("parakeet.models.tacotron2")
+    out = {}
+    for name, over, T, seed, skw, max_steps in T2_CASES:
+        cfg = dict(syn.TACOTRON2_LJSPEECH, **over)
+        state = syn.tacotron2_state(cfg, seed=seed, **skw)
+        model = t2m.Tacotron2(**cfg)
+        model.set_state_dict(state)
+        model.eval()
+        rng = np.random.default_rng(800 + seed)
+        ids = rng.integers(1, cfg["vocab_size"], size=(1, T)).astype(np.int64)
+        tones = rng.integers(0, cfg["n_tones"], size=(1, T)).astype(np.int64) if cfg["n_tones"] else None
+        PF.DROPOUT_HOOK = Tacotron2Dropout(seed, cfg["d_prenet"], cfg["p_prenet_dropout"])
+        try:
+            with paddle.no_grad():
+                o = model.infer(paddle.to_tensor(ids), max_decoder_steps=max_steps,
+                                tones=None if tones is None else paddle.to_tensor(tones))
+        finally:
+            PF.DROPOUT_HOOK = None
+        out[f"{name}_ids"] = ids[0]
+        if tones is not None:
+            out[f"{name}_tones"] = tones[0]
+        for k in ("mel_output", "mel_outputs_postnet", "alignments", "stop_logits"):
+            if k in o:
+                out[f"{name}_{k}"] = o[k].numpy()[0].astype(np.float32)
+        print("tacotron2", name, out[f"{name}_mel_output"].shape, out[f"{name}_alignments"].shape,
+              np.round(1 / (1 + np.exp(-out[f"{name}_stop_logits"])), 3)[-4:] if f"{name}_stop_logits" in out else "")
+    np.savez_compressed(os.path.join(OUT, "tacotron2.npz"), **out)
 
 
 if __name__ == "__main__":
