@@ -17,6 +17,7 @@
  *   pk_wf_*     parakeet/models/waveflow.py ConditionalWaveFlow.infer :785-805
  *   pk_tts_*    parakeet/models/transformer_tts/transformer_tts.py TransformerTTS.inference :511-647,
  *               TransformerTTSInference.forward :757-767
+ *   pk_taco_*   parakeet/models/tacotron2.py Tacotron2.infer :781-840 (Tacotron2Decoder.infer :474-541)
  *   pk_stft_mel parakeet/modules/audio.py STFT.magnitude :202-215 + MelScale :226-229,
  *               parakeet/data/get_feats.py LogMelFBank.get_log_mel_fbank :80-88
  *
@@ -385,6 +386,52 @@ int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* att_out, int
  * 2 = last decoder layer's output rows (L_b, adim). */
 int pk_tts_debug_read(pk_tts* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
 void pk_tts_destroy(pk_tts* h);
+
+/* ---------------------------------------------------------------- Tacotron2 */
+/* Tacotron2(vocab_size, n_tones, d_mels, d_encoder, ...) -- parakeet/models/tacotron2.py:626-689.
+ * Refused with PK_EUNSUPPORTED: reduction_factor != 1, d_global_condition. */
+typedef struct {
+    int32_t vocab_size;
+    int32_t n_tones;                 /* 0 = None */
+    int32_t d_mels, reduction_factor;
+    int32_t d_encoder, encoder_conv_layers, encoder_kernel_size;
+    int32_t d_prenet, d_attention_rnn, d_decoder_rnn;
+    int32_t d_attention, attention_filters, attention_kernel_size;
+    int32_t d_postnet, postnet_kernel_size, postnet_conv_layers;
+    int32_t d_global_condition;      /* 0 = None */
+    int32_t use_stop_token;
+    float p_prenet_dropout;          /* DecoderPreNet applies it with training=True (:76-79) */
+} pk_taco_cfg;
+typedef struct pk_taco pk_taco;
+
+int pk_taco_create(pk_ctx* ctx, const pk_taco_cfg* cfg, pk_taco** out);
+/* set_state_dict entry.  paddle.nn.LSTM registers each cell parameter twice ("encoder.lstm.0.cell_fw.weight_ih" and
+ * "encoder.lstm.weight_ih_l0"); either name is accepted, the cuDNN-style one wins when both are given. */
+int pk_taco_set_param(pk_taco* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math); env PK_TACO_MATH=f32. */
+int pk_taco_set_math(pk_taco* h, int32_t mode);
+/* Decoder-prenet dropout: 1 (default) = the dropout stream with p = p_prenet_dropout, element index
+ * (step * 2 + layer) * d_prenet + unit for decoding step 0, 1, ...; 0 = no dropout (not what the reference computes). */
+int pk_taco_set_dropout(pk_taco* h, int32_t on);
+int pk_taco_finalize(pk_taco* h);
+/* Tacotron2.infer (:781-840) for a packed batch, up to (not including) the postnet: embedding (+ tones), encoder
+ * (conv stack, bidirectional LSTM), then the attention decoder is stepped in lockstep until every utterance has
+ * ended: sigmoid(stop_logit) > 0.5 with a stop token (:515-518), else the "content exhausted" rule on the argmax of
+ * the alignment (:520-525), or max_decoder_steps (:526-528).
+ *   ids / tones  HOST int64, packed by utterance (tones NULL unless n_tones > 0);  tok_lens HOST (B)
+ *   seeds        HOST (B) dropout-stream seed per utterance, or NULL = 0
+ *   out_frames   (B) host: decoder steps L_b */
+int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tones, const int32_t* tok_lens, int32_t B,
+                  int32_t max_decoder_steps, const uint64_t* seeds, int32_t flags, int32_t* out_frames);
+/* Outputs of the last pk_taco_infer (:825-838), each packed by utterance, any of them may be NULL:
+ *   mel_output (sum(L_b), d_mels); mel_outputs_postnet = mel_output + postnet(mel_output), same shape;
+ *   alignments: per utterance (L_b, T_b); stop_logits (sum(L_b)), only with a stop token.
+ * flags: PK_HOST_IO if they are host pointers. */
+int pk_taco_read(pk_taco* h, float* mel_output, float* mel_outputs_postnet, float* alignments, float* stop_logits,
+                 int32_t flags);
+/* Test tap of the last infer: 0 = encoder outputs (T_b, d_encoder). */
+int pk_taco_debug_read(pk_taco* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
+void pk_taco_destroy(pk_taco* h);
 
 /* ------------------------------------------------- STFT / mel / log features */
 /* parakeet/modules/audio.py STFT (:74-215) + MelScale (:218-229); host twin

@@ -79,6 +79,14 @@ class TtsCfg(C.Structure):
         "spk_embed_dim", "use_gst")]
 
 
+class TacoCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "vocab_size", "n_tones", "d_mels", "reduction_factor", "d_encoder", "encoder_conv_layers",
+        "encoder_kernel_size", "d_prenet", "d_attention_rnn", "d_decoder_rnn", "d_attention", "attention_filters",
+        "attention_kernel_size", "d_postnet", "postnet_kernel_size", "postnet_conv_layers", "d_global_condition",
+        "use_stop_token")] + [("p_prenet_dropout", C.c_float)]
+
+
 class MelCfg(C.Structure):
     _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("center", C.c_int32), ("power", C.c_int32),
                 ("n_mels", C.c_int32), ("log_base", C.c_int32), ("log_floor", C.c_float)]
@@ -152,6 +160,15 @@ def _declare(lib):
         "pk_tts_read": (C.c_int, [vp, f32p, f32p, f32p, i32]),
         "pk_tts_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
         "pk_tts_destroy": (None, [vp]),
+        "pk_taco_create": (C.c_int, [vp, C.POINTER(TacoCfg), C.POINTER(vp)]),
+        "pk_taco_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
+        "pk_taco_set_math": (C.c_int, [vp, i32]),
+        "pk_taco_set_dropout": (C.c_int, [vp, i32]),
+        "pk_taco_finalize": (C.c_int, [vp]),
+        "pk_taco_infer": (C.c_int, [vp, i64p, i64p, i32p, i32, i32, C.POINTER(C.c_uint64), i32, i32p]),
+        "pk_taco_read": (C.c_int, [vp, f32p, f32p, f32p, f32p, i32]),
+        "pk_taco_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
+        "pk_taco_destroy": (None, [vp]),
         "pk_mel_create": (C.c_int, [vp, C.POINTER(MelCfg), f32p, f32p, C.POINTER(vp)]),
         "pk_mel_num_frames": (C.c_int, [vp, i32, i32p]),
         "pk_mel_run": (C.c_int, [vp, f32p, i32p, i32, f32p, i32, i32]),

@@ -995,9 +995,10 @@ int pk_fft_add_linear(Arena& ar, const pk_param_map& P, const std::string& base,
 }
 
 int pk_fft_add_conv_bn(Arena& ar, const pk_param_map& P, const std::string& conv_base, const std::string& bn_base,
-                       int Cout, int Cin, int k, Dense& d) {
-    std::vector<float> w, g, b, mean, var, kn, bias(Cout);
+                       int Cout, int Cin, int k, Dense& d, bool conv_bias) {
+    std::vector<float> w, g, b, mean, var, kn, bias(Cout), cb(Cout, 0.f);
     PK_TRY(pk_get_weight(P, conv_base, {Cout, Cin, k}, w));
+    if (conv_bias) PK_TRY(pk_get_vector(P, conv_base + ".bias", Cout, cb));
     PK_TRY(pk_get_vector(P, bn_base + ".weight", Cout, g));
     PK_TRY(pk_get_vector(P, bn_base + ".bias", Cout, b));
     PK_TRY(pk_get_vector(P, bn_base + "._mean", Cout, mean));
@@ -1007,7 +1008,7 @@ int pk_fft_add_conv_bn(Arena& ar, const pk_param_map& P, const std::string& conv
     for (int o = 0; o < Cout; ++o) {
         const double s = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
         for (size_t i = 0; i < per; ++i) w[o * per + i] = (float)((double)w[o * per + i] * s);
-        bias[o] = (float)((double)b[o] - (double)mean[o] * s);
+        bias[o] = (float)((double)b[o] + ((double)cb[o] - (double)mean[o]) * s);
     }
     pk_conv_to_kn(w.data(), Cout, Cin, k, kn);
     return pk_fft_add_dense_kn(ar, kn, &bias, Cin, k, Cout, d);

@@ -97,10 +97,11 @@ int pk_fft_add_linear(pk_fft_arena& ar, const pk_param_map& P, const std::string
                       pk_fft_dense& d);   // Linear weight [in, out] + bias
 int pk_fft_add_conv(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int Cout, int Cin, int k,
                     bool bias, pk_fft_dense& d);
-// Conv1D(no bias) -> BatchNorm1D(eval, eps 1e-5) folded into one dense layer (tacotron2/decoder.py:133-147,
-// tacotron2/encoder.py:98-110): conv at `conv_base`, batch norm at `bn_base`
+// Conv1D -> BatchNorm1D(eval, eps 1e-5) folded into one dense layer (tacotron2/decoder.py:133-147,
+// tacotron2/encoder.py:98-110; with conv_bias: Conv1dBatchNorm, modules/conv.py:186-260): conv at `conv_base`,
+// batch norm at `bn_base`
 int pk_fft_add_conv_bn(pk_fft_arena& ar, const pk_param_map& P, const std::string& conv_base,
-                       const std::string& bn_base, int Cout, int Cin, int k, pk_fft_dense& d);
+                       const std::string& bn_base, int Cout, int Cin, int k, pk_fft_dense& d, bool conv_bias = false);
 int pk_fft_add_vec(pk_fft_arena& ar, const pk_param_map& P, const std::string& name, int n, size_t& off);
 // `n_layers` EncoderLayers under prefix + ".encoders.{l}" and prefix + ".after_norm"; ff_type 0 conv1d, 1 linear,
 // 2 conv1d-linear (encoder.py:145-170)

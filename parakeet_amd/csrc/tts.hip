@@ -34,8 +34,8 @@
 #include <string>
 #include <vector>
 
+#include "pk_ar.h"
 #include "pk_fft.h"
-#include "pk_philox.h"
 
 namespace {
 
@@ -43,30 +43,6 @@ typedef pk_fft_dense Dense;
 typedef pk_fft_timeline Timeline;
 
 // ---------------------------------------------------------------------------------------------- kernels
-
-// Prenet dropout, in place, on prefix rows (row = pos * B + b): one thread per 4 units.
-//   element index ((tri + pos) * J + j) * U + u,  tri = s * (s - 1) / 2 for decoding step s  (pk_synth.h)
-__global__ __launch_bounds__(256) void k_tts_dropout(float* __restrict__ x, int rows, int U, int B,
-                                                     unsigned long long tri, int J, int j,
-                                                     const unsigned long long* __restrict__ seeds, unsigned thr,
-                                                     float scale) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    const int per_row = U >> 2;
-    if (q >= (long)rows * per_row) return;
-    const int r = (int)(q / per_row), u4 = (int)(q - (long)r * per_row) * 4;
-    const int pos = r / B, b = r - pos * B;
-    const unsigned long long e = ((tri + (unsigned long long)pos) * (unsigned long long)J + (unsigned long long)j) *
-                                     (unsigned long long)U + (unsigned long long)u4;
-    unsigned w[4];
-    pk_dropout_words(e, seeds ? seeds[b] : 0ull, w);
-    float4* p = reinterpret_cast<float4*>(x + (long)r * U + u4);
-    float4 v = *p;
-    v.x = w[0] >= thr ? v.x * scale : 0.f;
-    v.y = w[1] >= thr ? v.y * scale : 0.f;
-    v.z = w[2] >= thr ? v.z * scale : 0.f;
-    v.w = w[3] >= thr ? v.w * scale : 0.f;
-    *p = v;
-}
 
 // out[r][c] = alpha * pe[r / B][c]: the positional term of decoder.embed in position-major rows, added by the
 // epilogue of the embedding GEMM (ScaledPositionalEncoding.forward embedding.py:111-126)
@@ -219,29 +195,6 @@ __global__ __launch_bounds__(256) void k_tts_stop(const float* __restrict__ z, i
             len[b] = step;
             atomicAdd(ndone, 1);
         }
-    }
-}
-
-// Position-major rows -> a row timeline (or packed rows through rowmap): timeline row r of utterance u at position p
-// takes src row (p + off) * B + u; gap rows are zeroed when rowmap == NULL.  Optional per-column affine.
-__global__ __launch_bounds__(128) void k_tts_gather(const float* __restrict__ src, int C, int B, int off,
-                                                    const int* __restrict__ row_utt, const int* __restrict__ row_pos,
-                                                    const int* __restrict__ rowmap, const float* __restrict__ cscale,
-                                                    const float* __restrict__ cshift, float* __restrict__ dst) {
-    const long r = blockIdx.x;
-    const int u = row_utt[r];
-    const long o = rowmap ? rowmap[r] : r;
-    if (o < 0) return;
-    if (u < 0) {
-        if (!rowmap)
-            for (int c = threadIdx.x; c < C; c += blockDim.x) dst[o * C + c] = 0.f;
-        return;
-    }
-    const float* s = src + ((long)(row_pos[r] + off) * B + u) * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float v = s[c];
-        if (cscale) v = v * cscale[c] + cshift[c];
-        dst[o * C + c] = v;
     }
 }
 
@@ -708,7 +661,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             float* o = P[j & 1];
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_prenet", h->dprenet[j], in, ldin, o, U, R, PK_ACT_RELU, nullptr, 0, nullptr));
             if (h->dropout)
-                PK_LAUNCH(ctx, "tts_dropout", k_tts_dropout, dim3(pk_div_up((long)R * (U / 4), 256)), dim3(256), 0, o, R, U,
+                PK_LAUNCH(ctx, "tts_dropout", k_ar_dropout, dim3(pk_div_up((long)R * (U / 4), 256)), dim3(256), 0, o, U, R, U,
                           B, (unsigned long long)s * (unsigned long long)(s - 1) / 2ull, J, j, d_seeds, thr, dscale);
             in = o;
             ldin = U;
@@ -813,14 +766,14 @@ extern "C" int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* a
     const float* ch = denorm ? h->W(h->out_shift) : nullptr;
     const float* Y = pk_fft_act_ptr(h->d_y, O);
     if (c.postnet_layers == 0) {
-        PK_LAUNCH(ctx, "tts_gather", k_tts_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
+        PK_LAUNCH(ctx, "tts_gather", k_ar_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
                   h->d_rowmap.as<int>(), cs, ch, d_mel);
     } else {
         // outs on a frame timeline with zero gap rows, then outs + postnet(outs) (:644-648)
         PK_TRY(pk_fft_act_reserve(h->d_before, tl.rows, O));
         PK_HIP(hipMemsetAsync(h->d_before.p, 0, h->d_before.cap, ctx->stream));
         float* before = pk_fft_act_ptr(h->d_before, O);
-        PK_LAUNCH(ctx, "tts_gather", k_tts_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
+        PK_LAUNCH(ctx, "tts_gather", k_ar_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
                   (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, before);
         PK_TRY(pk_fft_run_postnet(h, "tts_conv_postnet", h->postnet, before, O, c.postnet_chans, tl, h->d_q1, h->d_q2, d_mel,
                                   h->d_rowmap.as<int>(), cs, ch));
@@ -832,7 +785,7 @@ extern "C" int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* a
             PK_TRY(h->d_stage2.reserve((size_t)total * sizeof(float)));
             d_p = h->d_stage2.as<float>();
         }
-        PK_LAUNCH(ctx, "tts_gather", k_tts_gather, dim3(tl.rows), dim3(128), 0, h->d_probs.as<float>(), 1, B, 0,
+        PK_LAUNCH(ctx, "tts_gather", k_ar_gather, dim3(tl.rows), dim3(128), 0, h->d_probs.as<float>(), 1, B, 0,
                   tl.d_row_utt(), tl.d_row_pos(), h->d_rowmap.as<int>(), (const float*)nullptr, (const float*)nullptr, d_p);
         if (host) PK_HIP(hipMemcpyAsync(probs_out, d_p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
