@@ -458,6 +458,51 @@ def main():
             del ssm
         except Exception as e:
             extras["acoustic_models"] = {"error": repr(e)}
+        try:   # the autoregressive acoustic models at the same shape: 32 x 128 tokens -> 640 frames each
+            from parakeet_amd.tacotron2 import Tacotron2
+            from parakeet_amd.transformer_tts import TransformerTTS
+            rng = np.random.default_rng(0)
+            frames_per_utt = TOKENS * 5
+            tcfg = dict(syn.TRANSFORMER_TTS_LJSPEECH)
+            ttm = TransformerTTS(idim=80, odim=80, **tcfg)
+            ttm.set_state_dict(syn.transformer_tts_state(80, 80, tcfg, stop_bias=-8.0))
+            ttm.eval()
+            tx = [rng.integers(1, 79, size=TOKENS) for _ in range(UTT_PER_GPU)]
+            ratio = (frames_per_utt + 0.5) / (TOKENS + 1)
+            ttm.inference_batch(tx, maxlenratio=ratio, return_att=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            outs = ttm.inference_batch(tx, maxlenratio=ratio, return_att=False)
+            torch.cuda.synchronize()
+            dtt = time.perf_counter() - t1
+            nf = int(sum(o[0].shape[0] for o in outs))
+            extras["transformer_tts_batch32"] = {
+                "what": "TransformerTTS (LJSpeech recipe sizes) inference alone, 32 x 128 tokens decoded in lockstep for 640 "
+                        "steps (the stop token is held off so that every utterance runs to int(129 * maxlenratio) = 640 "
+                        "frames), prenet dropout stream on, default math",
+                "ms_per_batch": dtt * 1e3, "us_per_step": dtt / frames_per_utt * 1e6, "frames": nf,
+                "utterances_per_s": UTT_PER_GPU / dtt, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtt}
+            del ttm
+            ccfg = dict(syn.TACOTRON2_LJSPEECH)
+            tcm = Tacotron2(**ccfg)
+            tcm.set_state_dict(syn.tacotron2_state(ccfg, stop_bias=-8.0))
+            tcm.eval()
+            cx = [rng.integers(1, 37, size=TOKENS) for _ in range(UTT_PER_GPU)]
+            tcm.infer_batch(cx, max_decoder_steps=frames_per_utt)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            outs = tcm.infer_batch(cx, max_decoder_steps=frames_per_utt)
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t1
+            nf = int(sum(o["mel_output"].shape[0] for o in outs))
+            extras["tacotron2_batch32"] = {
+                "what": "Tacotron2 (examples/tacotron2/config.py sizes) inference alone, 32 x 128 tokens decoded in lockstep "
+                        "for max_decoder_steps = 640 (stop token held off), prenet dropout stream on, default math",
+                "ms_per_batch": dtc * 1e3, "us_per_step": dtc / frames_per_utt * 1e6, "frames": nf,
+                "utterances_per_s": UTT_PER_GPU / dtc, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtc}
+            del tcm
+        except Exception as e:
+            extras["autoregressive_models"] = {"error": repr(e)}
 
     if rank == 0:
         total_samples = global_batch * per_utt             # whole job, all ranks, per step

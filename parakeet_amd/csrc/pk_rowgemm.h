@@ -1,0 +1,56 @@
+// pk_rowgemm.h -- "row GEMM": y[M][N] = epilogue(LN?(x)[M][K] . W[K][N]) for the FEW rows (one per utterance of the
+// batch) that an autoregressive decoder produces per step (tts.hip, taco2.hip).  The tile GEMM of gemm.hip needs
+// 20-60 us for such a problem (4..32 workgroups, a three-slab pipeline to fill, a barrier per slab); here the weight
+// matrix is the only real traffic and is streamed exactly once, sequentially:
+//   weights are pre-tiled at finalize as [N / CW][K][CW] (CW = 16 or 64 columns per workgroup), so a workgroup's slab
+//   is one contiguous K x CW x 4-byte range; a workgroup = CW output columns x up to 32 rows, 8 waves; a wave-wide load
+//   covers 64 / CW consecutive k of the slab (256 bytes), the 8 waves the next 2 KB, 16 loads in flight per wave; a lane
+//   owns one (column, K-part) pair and all 32 rows (accumulators in registers); the activations sit transposed in LDS
+//   ([k][32 rows], broadcast reads); the 8 * 64 / CW K-parts are summed through LDS in a fixed order (deterministic).
+//   CW = 16 everywhere: measured (MI355X, 32 rows) against CW = 64 for N >= 2048: K = 2560, N = 4096 took 68 us with 64
+//   workgroups of 64 columns (42 MB at 0.6 TB/s: too few loads in flight), the narrow tiling gives 256 workgroups.
+//   Arithmetic: plain fp32 FMA on the VALU (exact: no operand splitting, no block scaling) -- the matrix pipe would
+//   buy nothing at 32 rows, the kernel is bound by the weight stream (4 B per 2 x 32 FLOP).
+//   Optional prologue: LayerNorm over K (K <= 512) of every row, so that norm -> Linear is one launch.
+//   Optional epilogue: bias, ReLU, dropout (the dropout stream of pk_synth.h), residual.
+#pragma once
+#include <vector>
+
+#include "pk_common.h"
+
+constexpr int PK_RG_KC = 512;     // K chunk staged in LDS
+constexpr int PK_RG_ROWS = 32;
+
+// columns per workgroup for a layer with N outputs
+static inline int pk_rowgemm_cw(int N) {
+    (void)N;
+    return 16;
+}
+// [K][N] row-major -> tiles [ceil(N / cw)][K][cw], columns beyond N zero
+void pk_rowgemm_pack(const float* Wkn, int K, int N, std::vector<float>& out);
+
+struct pk_rowgemm_args {
+    const float* x = nullptr;   // [M][ldx], K columns used; ldx % 4 == 0, 16-byte aligned
+    int ldx = 0;
+    const float* Wt = nullptr;  // pk_rowgemm_pack of the [K][N] matrix (paddle Linear.weight is stored [in, out])
+    const float* bias = nullptr;   // [N] or NULL
+    const float* res = nullptr;    // [M][ldr] or NULL: added last
+    int ldr = 0;
+    float* y = nullptr;
+    int ldy = 0;
+    int M = 0, K = 0, N = 0;
+    int act = 0;                   // PK_ACT_NONE / PK_ACT_RELU (pk_gemm.h)
+    const float* ln_g = nullptr;   // LayerNorm(K) weight / bias applied to x first (needs K <= PK_RG_KC), or NULL
+    const float* ln_b = nullptr;
+    float ln_eps = 1e-5f;
+    // dropout after the activation (before the residual): element index ((drop_base * drop_J + drop_j) * N + n) of the
+    // utterance's stream (row m = utterance m), keep <=> word >= drop_thr, kept values * drop_scale
+    int dropout = 0;
+    unsigned long long drop_base = 0;
+    int drop_J = 1, drop_j = 0;
+    const unsigned long long* drop_seeds = nullptr;
+    unsigned drop_thr = 0;
+    float drop_scale = 1.f;
+};
+
+int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args& a);

@@ -1,0 +1,161 @@
+// rowgemm.hip -- see pk_rowgemm.h.
+#include "pk_rowgemm.h"
+
+#include "pk_gemm.h"
+#include "pk_philox.h"
+
+void pk_rowgemm_pack(const float* Wkn, int K, int N, std::vector<float>& out) {
+    const int cw = pk_rowgemm_cw(N), nb = (N + cw - 1) / cw;
+    out.assign((size_t)nb * K * cw, 0.f);
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < cw && b * cw + c < N; ++c)
+                out[((size_t)b * K + k) * cw + c] = Wkn[(size_t)k * N + b * cw + c];
+}
+
+namespace {
+constexpr int KC = PK_RG_KC, ROWS = PK_RG_ROWS;
+
+// CW columns per workgroup, KSUB = 64 / CW consecutive k per wave-wide load, 8 * KSUB K-parts per workgroup
+template <int CW>
+__global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
+    constexpr int KSUB = 64 / CW, PARTS = 8 * KSUB;
+    __shared__ __attribute__((aligned(16))) float xs[KC * ROWS];   // xs[k * 32 + m], 64 KB
+    __shared__ float red[PARTS * ROWS * CW];                       // red[(part * 32 + m) * CW + col], 64 KB
+    __shared__ float stat[2 * ROWS];                               // LayerNorm: mean | rstd per row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
+    const int col = lane % CW, ks = lane / CW;
+    const int part = wave * KSUB + ks;                            // this lane's K-part: k = part, part + PARTS, ...
+    const int m0 = blockIdx.y * ROWS;
+    const int rows = min(ROWS, a.M - m0);
+    if (a.ln_g) {
+        // two-pass LayerNorm statistics of rows 4 * wave .. 4 * wave + 3 (K <= 512: up to 8 values per lane)
+        for (int mm = 0; mm < 4; ++mm) {
+            const int m = wave * 4 + mm;
+            if (m >= rows) continue;   // wave-uniform
+            const float* xr = a.x + (long)(m0 + m) * a.ldx;
+            float v[KC / 64];
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < KC / 64; ++e) {
+                const int k = lane + 64 * e;
+                v[e] = k < a.K ? xr[k] : 0.f;
+                s += v[e];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s / (float)a.K;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < KC / 64; ++e) {
+                const int k = lane + 64 * e;
+                const float d = k < a.K ? v[e] - mean : 0.f;
+                q += d * d;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            if (lane == 0) {
+                stat[m] = mean;
+                stat[ROWS + m] = 1.0f / sqrtf(q / (float)a.K + a.ln_eps);
+            }
+        }
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    // The weight loads are issued WG at a time, unconditionally (indices clamped, a select zeroes what lies beyond the
+    // chunk: a branch around a load makes the compiler wait for vmcnt(0) at every use) -- the kernel is bound by the
+    // latency of the weight stream, not by its volume.
+    constexpr int WG = 16;
+    const float* slab = a.Wt + (long)blockIdx.x * a.K * CW;   // this workgroup's [K][CW] slab
+    for (int k0 = 0; k0 < a.K; k0 += KC) {
+        const int kc = min(KC, a.K - k0);
+        __syncthreads();   // the previous chunk is consumed (first pass: the LayerNorm statistics are published)
+        // stage x[m0 + m][k0 + 4 * k4 ..] -> xs[(4 * k4 + i) * 32 + m]; lanes = 32 rows x 2 groups of 4 columns
+        for (int e = tid; e < (kc >> 2) * ROWS; e += 512) {
+            const int m = e & (ROWS - 1), k4 = e >> 5;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < rows) {
+                v = *reinterpret_cast<const float4*>(a.x + (long)(m0 + m) * a.ldx + k0 + 4 * k4);
+                if (a.ln_g) {
+                    const float mean = stat[m], rstd = stat[ROWS + m];
+                    const float4 g = *reinterpret_cast<const float4*>(a.ln_g + k0 + 4 * k4);
+                    const float4 bb = *reinterpret_cast<const float4*>(a.ln_b + k0 + 4 * k4);
+                    v.x = (v.x - mean) * rstd * g.x + bb.x;
+                    v.y = (v.y - mean) * rstd * g.y + bb.y;
+                    v.z = (v.z - mean) * rstd * g.z + bb.z;
+                    v.w = (v.w - mean) * rstd * g.w + bb.w;
+                }
+            }
+            float* d = xs + (4 * k4) * ROWS + m;
+            d[0] = v.x;
+            d[ROWS] = v.y;
+            d[2 * ROWS] = v.z;
+            d[3 * ROWS] = v.w;
+        }
+        __syncthreads();
+        // k-steps of this lane in the chunk: k = part + PARTS * j < kc  (K % 8 == 0; with KSUB = 4 a chunk that is not
+        // a multiple of 32 leaves the last step to some of the parts only: clamp + select)
+        const int nk = (kc + PARTS - 1) / PARTS;
+        for (int j0 = 0; j0 < nk; j0 += WG) {
+            float w[WG];
+#pragma unroll
+            for (int g = 0; g < WG; ++g) {
+                const int k = min(part + PARTS * (j0 + g), kc - 1);
+                w[g] = slab[(long)(k0 + k) * CW + col];
+            }
+#pragma unroll
+            for (int g = 0; g < WG; ++g) {
+                const int kk = part + PARTS * (j0 + g);
+                const int k = min(kk, kc - 1);
+                const float wv = kk < kc ? w[g] : 0.f;
+                const float4* xr = reinterpret_cast<const float4*>(xs + k * ROWS);
+#pragma unroll
+                for (int q = 0; q < ROWS / 4; ++q) {
+                    const float4 xv = xr[q];
+                    acc[4 * q + 0] = fmaf(xv.x, wv, acc[4 * q + 0]);
+                    acc[4 * q + 1] = fmaf(xv.y, wv, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(xv.z, wv, acc[4 * q + 2]);
+                    acc[4 * q + 3] = fmaf(xv.w, wv, acc[4 * q + 3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) red[(part * ROWS + r) * CW + col] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < ROWS * CW; e += 512) {
+        const int m = e / CW, c = e - m * CW;
+        const int nn = blockIdx.x * CW + c;
+        if (m >= rows || nn >= a.N) continue;
+        float s = 0.f;
+#pragma unroll 8
+        for (int p = 0; p < PARTS; ++p) s += red[(p * ROWS + m) * CW + c];
+        if (a.bias) s += a.bias[nn];
+        if (a.act == PK_ACT_RELU) s = fmaxf(s, 0.f);
+        if (a.dropout) {
+            const unsigned long long eidx = (a.drop_base * (unsigned long long)a.drop_J + (unsigned long long)a.drop_j) *
+                                                (unsigned long long)a.N + (unsigned long long)nn;
+            unsigned w4[4];
+            pk_dropout_words(eidx & ~3ull, a.drop_seeds ? a.drop_seeds[m0 + m] : 0ull, w4);
+            s = w4[eidx & 3ull] >= a.drop_thr ? s * a.drop_scale : 0.f;
+        }
+        if (a.res) s += a.res[(long)(m0 + m) * a.ldr + nn];
+        a.y[(long)(m0 + m) * a.ldy + nn] = s;
+    }
+}
+}  // namespace
+
+int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args& a) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) PK_FAIL(PK_EINVAL, "row GEMM: empty problem");
+    if (a.K % 8 != 0 || a.ldx % 4 != 0)
+        PK_FAIL(PK_EUNSUPPORTED, "row GEMM: K (%d) must be a multiple of 8 and ldx (%d) of 4", a.K, a.ldx);
+    if (a.ln_g && (a.K > KC || !a.ln_b)) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: the LayerNorm prologue needs K <= %d", KC);
+    if (a.act != PK_ACT_NONE && a.act != PK_ACT_RELU) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: activation %d", a.act);
+    const int cw = pk_rowgemm_cw(a.N);
+    dim3 grid((a.N + cw - 1) / cw, (a.M + ROWS - 1) / ROWS);
+    if (cw == 64) PK_LAUNCH(ctx, prof_name, k_rowgemm<64>, grid, dim3(512), 0, a);
+    else PK_LAUNCH(ctx, prof_name, k_rowgemm<16>, grid, dim3(512), 0, a);
+    return PK_OK;
+}

@@ -15,8 +15,9 @@
 // Decoder: B utterances in lockstep, one frame per step.  The LSTMCells' operands are laid out so that each cell is ONE
 // GEMM per step: the cell input is a row [x | context | h] that the producing kernels write in place (prenet GEMM ->
 // first slice, attention kernel -> context slice, the cell's own pointwise kernel -> h slice), multiplied by
-// [W_ih^T ; W_hh^T] with bias b_ih + b_hh.  k_taco_lsa is the whole LocationSensitiveAttention step for one utterance
-// per workgroup (query projection, location conv + projection, energies, softmax, context, cumulative weights).
+// [W_ih^T ; W_hh^T] with bias b_ih + b_hh.  The per-step products have B rows (one per utterance): they run on the
+// row GEMM (pk_rowgemm.h: weights streamed once, fp32 FMA, ReLU + prenet dropout in the epilogue) unless
+// PK_AR_ROWGEMM=0 selects the tile GEMM.  LocationSensitiveAttention is three launches (see LsaArgs).
 // Stop rules run on the device (k_taco_stop); a finished utterance keeps being stepped and is ignored.
 //
 // LSTM semantics [paddle-semantics, from Paddle's API documentation]: gate order i, f, g, o along the 4H axis.
@@ -30,6 +31,7 @@
 
 #include "pk_ar.h"
 #include "pk_fft.h"
+#include "pk_rowgemm.h"
 
 namespace {
 typedef pk_fft_dense Dense;
@@ -116,19 +118,27 @@ __global__ __launch_bounds__(256) void k_taco_lstm_point(const float* __restrict
     h2[(long)b * ld2 + u] = h;
 }
 
-// One step of LocationSensitiveAttention.forward (attention.py:300-348) + the state updates of _decode (:387-397)
-// for one utterance per workgroup (256 threads = 4 waves).
+// One step of LocationSensitiveAttention.forward (attention.py:300-348) + the state updates of _decode (:387-397), as
+// three launches so that the whole chip works on it (one workgroup per utterance used 32 of 256 CUs and took 480 us):
+//   processed_query = query_layer(attention_hidden)          a row GEMM (pk_rowgemm.h)
+//   k_taco_lsa_energy   one WAVE per memory row of the token timeline:
+//        alignment[t] = value(tanh(location_layer(location_conv(cat))[t] + processed_key[t] + processed_query))
+//   k_taco_lsa_ctx      per utterance (x column blocks): softmax over its T memory rows, the new / cumulative weights,
+//        the alignment row, attention_context = weights^T . memory written to the three operand rows that consume it
 struct LsaArgs {
-    const float* query; int ldq;      // attention_hidden [B][ldq], Ha wide
-    int Ha, Da, E, F, K;              // K = location kernel size (odd), F <= 64, Da <= 256
-    const float* Wq;                  // query_layer [Ha][Da]
+    int Da, E, F, K;                  // K = location kernel size (odd), F <= 64, Da <= 256
+    const float* pq;                  // processed query [B][Da]
     const float* Wconv;               // location_conv [F][2][K]
     const float* Wloc;                // location_layer [F][Da]
     const float* v;                   // value [Da]
     const float* pkey;                // processed memory [rows][Da]
     const float* mem;                 // memory [rows][E]
+    const int* row_utt;               // token timeline
+    const int* row_pos;
     const int* seg_start;
     const int* seg_len;
+    int rows;
+    float* energy;                    // [rows]
     float* attw;                      // [rows]: attention_weights (previous -> new)
     float* cum;                       // [rows]: attention_weights_cum
     float* ctx1; int ld1;             // three copies of the context vector
@@ -139,72 +149,72 @@ struct LsaArgs {
     int step;
 };
 
-__global__ __launch_bounds__(256) void k_taco_lsa(LsaArgs a) {
+__global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
+    __shared__ float win[4][2][64];   // per wave: the attw / cum window t - pad .. t + pad
+    __shared__ float loc[4][64];      // per wave: location_conv output of its row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    const int b = r < a.rows ? a.row_utt[r] : -1;
+    const bool valid = b >= 0;   // wave-uniform
+    const int K = a.K, pad = (K - 1) / 2, F = a.F, Da = a.Da;
+    int t = 0, T = 0;
+    long s0 = 0;
+    if (valid) {
+        t = a.row_pos[r];
+        T = a.seg_len[b];
+        s0 = a.seg_start[b];
+        if (lane < K) {
+            const int tt = t + lane - pad;
+            const bool in = tt >= 0 && tt < T;   // zero padding of the conv at the utterance's ends
+            win[wave][0][lane] = in ? a.attw[s0 + tt] : 0.f;
+            win[wave][1][lane] = in ? a.cum[s0 + tt] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (valid && lane < F) {
+        const float* wc = a.Wconv + (long)lane * 2 * K;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            acc = fmaf(wc[k], win[wave][0][k], acc);
+            acc = fmaf(wc[K + k], win[wave][1][k], acc);
+        }
+        loc[wave][lane] = acc;
+    }
+    __syncthreads();
+    float e = 0.f;
+    if (valid) {
+        const float* pq = a.pq + (long)b * Da;
+        for (int d = lane; d < Da; d += 64) {
+            float pl = 0.f;
+            for (int f = 0; f < F; ++f) pl = fmaf(loc[wave][f], a.Wloc[(long)f * Da + d], pl);
+            e = fmaf(a.v[d], tanhf(pl + a.pkey[(long)r * Da + d] + pq[d]), e);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if (valid && lane == 0) a.energy[r] = e;
+}
+
+// grid (B, ceil(E / 256)), 256 threads: every block redoes the (cheap) softmax of its utterance, block column 0 also
+// stores the weights; thread c of block column y owns context column y * 256 + c.
+__global__ __launch_bounds__(256) void k_taco_lsa_ctx(LsaArgs a) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = a.seg_len[b];
     const long s0 = a.seg_start[b];
-    const int Da = a.Da, F = a.F, K = a.K, pad = (K - 1) / 2;
-    float* pq = sm;                  // Da
-    float* red = pq + Da;            // 256 + 8
-    float* loc = red + 264;          // 4 waves x 64
-    float* sc = loc + 256;           // T
-    // processed_query = query_layer(query)   (:330)
-    {
-        const int parts = 256 / Da;
-        const int part = tid / Da, d = tid - part * Da;
-        float acc = 0.f;
-        if (part < parts) {
-            const float* q = a.query + (long)b * a.ldq;
-            for (int k = part; k < a.Ha; k += parts) acc = fmaf(q[k], a.Wq[(long)k * Da + d], acc);
-        }
-        red[tid] = acc;
-        __syncthreads();
-        if (tid < Da) {
-            float s = 0.f;
-            for (int p = 0; p < parts; ++p) s += red[p * Da + tid];
-            pq[tid] = s;
-        }
-        __syncthreads();
-    }
-    // alignment[t] = value(tanh(location_layer(location_conv(cat))[t] + processed_key[t] + processed_query))  (:331-336)
-    const int iters = (T + 3) / 4;
-    for (int it = 0; it < iters; ++it) {
-        const int t = it * 4 + wave;
-        if (t < T && lane < F) {
-            float acc = 0.f;
-            const float* wc = a.Wconv + (long)lane * 2 * K;
-            for (int k = 0; k < K; ++k) {
-                const int tt = t + k - pad;
-                if (tt >= 0 && tt < T) {
-                    acc = fmaf(wc[k], a.attw[s0 + tt], acc);
-                    acc = fmaf(wc[K + k], a.cum[s0 + tt], acc);
-                }
-            }
-            loc[wave * 64 + lane] = acc;
-        }
-        __syncthreads();
-        float e = 0.f;
-        if (t < T) {
-            for (int d = lane; d < Da; d += 64) {
-                float pl = 0.f;
-                for (int f = 0; f < F; ++f) pl = fmaf(loc[wave * 64 + f], a.Wloc[(long)f * Da + d], pl);
-                e = fmaf(a.v[d], tanhf(pl + a.pkey[(s0 + t) * Da + d] + pq[d]), e);
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-        if (t < T && lane == 0) sc[t] = e;
-        __syncthreads();
-    }
-    // attention_weights = softmax(alignment) over the T memory positions  (:341)
+    float* red = sm;          // 8
+    float* sc = sm + 8;       // T
     float m = -INFINITY;
-    for (int t = tid; t < T; t += 256) m = fmaxf(m, sc[t]);
+    for (int t = tid; t < T; t += 256) {
+        const float e = a.energy[s0 + t];
+        sc[t] = e;
+        m = fmaxf(m, e);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) red[256 + wave] = m;
+    if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[256], red[257]), fmaxf(red[258], red[259]));
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
     for (int t = tid; t < T; t += 256) {
         const float p = expf(sc[t] - m);
@@ -213,23 +223,34 @@ __global__ __launch_bounds__(256) void k_taco_lsa(LsaArgs a) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) red[260 + wave] = sum;
-    __syncthreads();
-    sum = (red[260] + red[261]) + (red[262] + red[263]);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();   // also publishes sc[]
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
     const float inv = 1.f / sum;
-    // new weights, cumulative weights (:397), alignment row
-    float* al = a.align ? a.align + a.align_off[b] + (long)a.step * T : nullptr;
-    for (int t = tid; t < T; t += 256) {
-        const float w = sc[t] * inv;
-        a.attw[s0 + t] = w;
-        a.cum[s0 + t] += w;
-        if (al) al[t] = w;
+    if (blockIdx.y == 0) {
+        // new weights, cumulative weights (:397), alignment row
+        float* al = a.align ? a.align + a.align_off[b] + (long)a.step * T : nullptr;
+        for (int t = tid; t < T; t += 256) {
+            const float w = sc[t] * inv;
+            a.attw[s0 + t] = w;
+            a.cum[s0 + t] += w;
+            if (al) al[t] = w;
+        }
     }
     // attention_context = weights^T . memory  (:342-343)
-    for (int c = tid; c < a.E; c += 256) {
-        float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc = fmaf(sc[t], a.mem[(s0 + t) * a.E + c], acc);
-        acc *= inv;
+    const int c = blockIdx.y * 256 + tid;
+    if (c < a.E) {
+        const float* mp = a.mem + s0 * a.E + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int t = 0;
+        for (; t + 3 < T; t += 4) {
+            a0 = fmaf(sc[t], mp[(long)t * a.E], a0);
+            a1 = fmaf(sc[t + 1], mp[(long)(t + 1) * a.E], a1);
+            a2 = fmaf(sc[t + 2], mp[(long)(t + 2) * a.E], a2);
+            a3 = fmaf(sc[t + 3], mp[(long)(t + 3) * a.E], a3);
+        }
+        for (; t < T; ++t) a0 = fmaf(sc[t], mp[(long)t * a.E], a0);
+        const float acc = ((a0 + a1) + (a2 + a3)) * inv;
         a.ctx1[(long)b * a.ld1 + c] = acc;
         a.ctx2[(long)b * a.ld2 + c] = acc;
         a.ctx3[(long)b * a.ld3 + c] = acc;
@@ -298,17 +319,21 @@ struct pk_taco : pk_fft_core {
     int gapr = 1;
     bool dropout = true;
     // weights
-    size_t emb = 0, temb = 0, whhT = 0, Wq = 0, Wconv = 0, Wloc = 0, vvec = 0, stop_w = 0;
+    size_t emb = 0, temb = 0, whhT = 0, Wconv = 0, Wloc = 0, vvec = 0, stop_w = 0;
     float stop_b = 0.f;
     std::vector<Dense> econv, postnet;
     Dense lstm_in, key_layer, pre1, pre2, att_rnn, dec_rnn, proj;
+    struct RowW {
+        size_t w = 0, b = (size_t)-1;
+        int K = 0, N = 0;
+    } rw_pre1, rw_pre2, rw_att, rw_dec, rw_proj, rw_q;   // the same layers as pk_rowgemm_pack tiles for the row GEMM
     // per call
     Timeline tl_tok, tl_frm;
     int B = 0, cap = 0, steps = 0, maxT = 0;
     std::vector<int> T, len;
     std::vector<long> align_off;
     pk_dbuf d_tok, d_tone, d_e1, d_e2, d_xg, d_mem, d_pkey, d_attw, d_cum, d_in1, d_in2, d_in3, d_p1, d_gates, d_catt,
-        d_cdec, d_zero, d_y, d_logits, d_state, d_seeds, d_align, d_alignoff, d_before, d_q1, d_q2, d_rowmap, d_stage,
+        d_cdec, d_zero, d_y, d_pq, d_energy, d_logits, d_state, d_seeds, d_align, d_alignoff, d_before, d_q1, d_q2, d_rowmap, d_stage,
         d_stage2;
 };
 
@@ -328,7 +353,8 @@ int find_param(const pk_param_map& P, const std::vector<std::string>& names, int
 }
 
 // One LSTMCell as one dense layer on the operand row [x (in) | h (H)]: kn = [W_ih^T ; W_hh^T], bias = b_ih + b_hh
-int add_cell(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int in, int H, Dense& d) {
+int add_cell(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int in, int H, Dense& d,
+             pk_taco::RowW& rw) {
     std::vector<float> wih, whh, bih, bhh;
     PK_TRY(find_param(P, {p + ".weight_ih"}, 4 * H, in, wih));
     PK_TRY(find_param(P, {p + ".weight_hh"}, 4 * H, H, whh));
@@ -341,6 +367,12 @@ int add_cell(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int 
         for (int k = 0; k < H; ++k) kn[(size_t)(in + k) * N + g] = whh[(size_t)g * H + k];
         bias[g] = bih[g] + bhh[g];
     }
+    std::vector<float> wt;
+    pk_rowgemm_pack(kn.data(), K, N, wt);
+    rw.w = ar.put(wt);
+    rw.b = ar.put(bias);
+    rw.K = K;
+    rw.N = N;
     return pk_fft_add_dense_kn(ar, kn, &bias, K, 1, N, d);
 }
 }  // namespace
@@ -358,8 +390,8 @@ extern "C" int pk_taco_create(pk_ctx* ctx, const pk_taco_cfg* cfg, pk_taco** out
         if (s <= 0 || s % PK_GEMM_BK != 0) PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: size %d not a positive multiple of 16", s);
     if (c.d_attention > 256) PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: d_attention > 256");
     if (c.attention_filters <= 0 || c.attention_filters > 64) PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: attention_filters must be in [1, 64]");
-    if (c.attention_kernel_size < 1 || c.attention_kernel_size % 2 == 0)
-        PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: attention_kernel_size must be odd");
+    if (c.attention_kernel_size < 1 || c.attention_kernel_size % 2 == 0 || c.attention_kernel_size > 63)
+        PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: attention_kernel_size must be odd and <= 63");
     if (c.encoder_conv_layers < 0 || c.postnet_conv_layers < 1) PK_FAIL(PK_EINVAL, "Tacotron2: layer counts");
     const int ks[] = {c.encoder_conv_layers > 0 ? c.encoder_kernel_size : 1, c.postnet_kernel_size};
     int gapr = 1;
@@ -453,10 +485,16 @@ extern "C" int pk_taco_finalize(pk_taco* h) {
         PK_TRY(pk_fft_add_dense_kn(ar, w, nullptr, E, 1, Da, h->key_layer));
         PK_TRY(pk_get_weight(P, "decoder.prenet.linear1", {M, Pn}, w));
         PK_TRY(pk_fft_add_dense_kn(ar, w, nullptr, M, 1, Pn, h->pre1));
+        std::vector<float> wt;
+        pk_rowgemm_pack(w.data(), M, Pn, wt);
+        h->rw_pre1.w = ar.put(wt); h->rw_pre1.K = M; h->rw_pre1.N = Pn;
         PK_TRY(pk_get_weight(P, "decoder.prenet.linear2", {Pn, Pn}, w));
         PK_TRY(pk_fft_add_dense_kn(ar, w, nullptr, Pn, 1, Pn, h->pre2));
+        pk_rowgemm_pack(w.data(), Pn, Pn, wt);
+        h->rw_pre2.w = ar.put(wt); h->rw_pre2.K = Pn; h->rw_pre2.N = Pn;
         PK_TRY(pk_get_weight(P, "decoder.attention_layer.query_layer", {Ha, Da}, w));
-        h->Wq = ar.put(w);
+        pk_rowgemm_pack(w.data(), Ha, Da, wt);
+        h->rw_q.w = ar.put(wt); h->rw_q.K = Ha; h->rw_q.N = Da;
         PK_TRY(pk_get_weight(P, "decoder.attention_layer.value", {Da, 1}, w));
         h->vvec = ar.put(w);
         PK_TRY(pk_get_weight(P, "decoder.attention_layer.location_conv", {F, 2, K}, w));
@@ -464,9 +502,17 @@ extern "C" int pk_taco_finalize(pk_taco* h) {
         PK_TRY(pk_get_weight(P, "decoder.attention_layer.location_layer", {F, Da}, w));
         h->Wloc = ar.put(w);
     }
-    PK_TRY(add_cell(ar, P, "decoder.attention_rnn", Pn + E, Ha, h->att_rnn));   // input [prenet | context] (:380)
-    PK_TRY(add_cell(ar, P, "decoder.decoder_rnn", Ha + E, Hd, h->dec_rnn));     // input [attention_hidden | context] (:400-401)
+    PK_TRY(add_cell(ar, P, "decoder.attention_rnn", Pn + E, Ha, h->att_rnn, h->rw_att));   // input [prenet | context] (:380)
+    PK_TRY(add_cell(ar, P, "decoder.decoder_rnn", Ha + E, Hd, h->dec_rnn, h->rw_dec));     // input [attention_hidden | context] (:400-401)
     PK_TRY(pk_fft_add_linear(ar, P, "decoder.linear_projection", Hd + E, M, h->proj));   // [decoder_hidden | context] (:409-412)
+    {
+        std::vector<float> w, b;
+        PK_TRY(pk_get_weight(P, "decoder.linear_projection", {Hd + E, M}, w));
+        PK_TRY(pk_get_vector(P, "decoder.linear_projection.bias", M, b));
+        std::vector<float> wt;
+        pk_rowgemm_pack(w.data(), Hd + E, M, wt);
+        h->rw_proj.w = ar.put(wt); h->rw_proj.b = ar.put(b); h->rw_proj.K = Hd + E; h->rw_proj.N = M;
+    }
     if (c.use_stop_token) {
         std::vector<float> w, b;
         PK_TRY(pk_get_weight(P, "decoder.stop_layer", {Hd + E, 1}, w));
@@ -586,6 +632,8 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     PK_TRY(h->d_attw.reserve((size_t)tl.rows_alloc * sizeof(float)));
     PK_TRY(h->d_cum.reserve((size_t)tl.rows_alloc * sizeof(float)));
     PK_TRY(h->d_logits.reserve((size_t)cap * B * sizeof(float)));
+    PK_TRY(rows_reserve(h->d_pq, B, Da));
+    PK_TRY(h->d_energy.reserve((size_t)tl.rows_alloc * sizeof(float)));
     pk_dbuf* zbufs[] = {&h->d_in1, &h->d_in2, &h->d_in3, &h->d_zero, &h->d_catt, &h->d_cdec, &h->d_attw, &h->d_cum};
     for (pk_dbuf* z : zbufs) PK_HIP(hipMemsetAsync(z->p, 0, z->cap, ctx->stream));
     // state block: [len B][first_hit B][ndone 1]
@@ -621,45 +669,74 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     const bool drop = h->dropout && p > 0.f;
     const unsigned thr = pk_dropout_threshold((double)p);
     const float dscale = 1.0f / (1.0f - p);
-    const size_t lsa_smem = (size_t)(Da + 264 + 256 + maxT + 4) * sizeof(float);
+    const size_t lsa_smem = (size_t)(8 + maxT + 4) * sizeof(float);
     if (lsa_smem > 60 * 1024) PK_FAIL(PK_EUNSUPPORTED, "pk_taco_infer: %d tokens exceed the attention kernel's LDS budget", maxT);
     static const int poll = getenv("PK_TACO_POLL") ? std::max(1, atoi(getenv("PK_TACO_POLL"))) : 8;
+    static const bool use_rg = getenv("PK_AR_ROWGEMM") ? atoi(getenv("PK_AR_ROWGEMM")) != 0 : true;
+    float* pq = pk_fft_act_ptr(h->d_pq, Da);
+    // row GEMM of one of the per-step layers (B rows)
+    auto rowgemm = [&](const char* name, const pk_taco::RowW& w, const float* x, int ldx, float* y, int ldy, int act,
+                       int drop_layer, unsigned long long step) -> int {
+        pk_rowgemm_args g;
+        g.x = x; g.ldx = ldx; g.Wt = h->W(w.w); g.bias = w.b == (size_t)-1 ? nullptr : h->W(w.b);
+        g.y = y; g.ldy = ldy; g.M = B; g.K = w.K; g.N = w.N; g.act = act;
+        if (drop_layer >= 0 && drop) {
+            g.dropout = 1; g.drop_base = step; g.drop_J = 2; g.drop_j = drop_layer; g.drop_seeds = d_seeds;
+            g.drop_thr = thr; g.drop_scale = dscale;
+        }
+        return pk_rowgemm_launch(ctx, name, g);
+    };
     int i = 0;
     for (i = 0; i < cap; ++i) {
         // query = prenet(previous mel_output) (:499-500, :538); the first query is zeros (:493-497)
         const float* q = i == 0 ? zero : Y + (long)(i - 1) * B * M;
-        PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre1, q, M, p1, Pn, B, PK_ACT_RELU, nullptr, 0, nullptr));
-        if (drop)
-            PK_LAUNCH(ctx, "taco_dropout", k_ar_dropout, dim3(pk_div_up((long)B * (Pn / 4), 256)), dim3(256), 0, p1, Pn, B, Pn,
-                      B, (unsigned long long)i, 2, 0, d_seeds, thr, dscale);
-        PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre2, p1, Pn, in1, K1, B, PK_ACT_RELU, nullptr, 0, nullptr));
-        if (drop)
-            PK_LAUNCH(ctx, "taco_dropout", k_ar_dropout, dim3(pk_div_up((long)B * (Pn / 4), 256)), dim3(256), 0, in1, K1, B, Pn,
-                      B, (unsigned long long)i, 2, 1, d_seeds, thr, dscale);
-        // attention_rnn (:380-385) on [prenet | context | attention_hidden]
-        PK_TRY(pk_fft_run_dense(h, "taco_gemm_att_rnn", h->att_rnn, in1, K1, gates, 4 * Ha, B, PK_ACT_NONE, nullptr, 0, nullptr));
+        if (use_rg) {
+            PK_TRY(rowgemm("taco_row_prenet", h->rw_pre1, q, M, p1, Pn, PK_ACT_RELU, 0, (unsigned long long)i));
+            PK_TRY(rowgemm("taco_row_prenet", h->rw_pre2, p1, Pn, in1, K1, PK_ACT_RELU, 1, (unsigned long long)i));
+            // attention_rnn (:380-385) on [prenet | context | attention_hidden]
+            PK_TRY(rowgemm("taco_row_att_rnn", h->rw_att, in1, K1, gates, 4 * Ha, PK_ACT_NONE, -1, 0));
+        } else {
+            PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre1, q, M, p1, Pn, B, PK_ACT_RELU, nullptr, 0, nullptr));
+            if (drop)
+                PK_LAUNCH(ctx, "taco_dropout", k_ar_dropout, dim3(pk_div_up((long)B * (Pn / 4), 256)), dim3(256), 0, p1, Pn, B,
+                          Pn, B, (unsigned long long)i, 2, 0, d_seeds, thr, dscale);
+            PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre2, p1, Pn, in1, K1, B, PK_ACT_RELU, nullptr, 0, nullptr));
+            if (drop)
+                PK_LAUNCH(ctx, "taco_dropout", k_ar_dropout, dim3(pk_div_up((long)B * (Pn / 4), 256)), dim3(256), 0, in1, K1, B,
+                          Pn, B, (unsigned long long)i, 2, 1, d_seeds, thr, dscale);
+            PK_TRY(pk_fft_run_dense(h, "taco_gemm_att_rnn", h->att_rnn, in1, K1, gates, 4 * Ha, B, PK_ACT_NONE, nullptr, 0, nullptr));
+        }
         PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Ha, 256)), dim3(256), 0, gates,
                   h->d_catt.as<float>(), Ha, B, in1 + Pn + E, K1, in2, K2);
-        // location sensitive attention (:387-397)
+        // location sensitive attention (:387-397): processed query, energies of every memory row, softmax + context
+        PK_TRY(rowgemm("taco_row_query", h->rw_q, in2, K2, pq, Da, PK_ACT_NONE, -1, 0));
         LsaArgs a;
         memset(&a, 0, sizeof(a));
-        a.query = in2; a.ldq = K2;
-        a.Ha = Ha; a.Da = Da; a.E = E; a.F = c.attention_filters; a.K = c.attention_kernel_size;
-        a.Wq = h->W(h->Wq); a.Wconv = h->W(h->Wconv); a.Wloc = h->W(h->Wloc); a.v = h->W(h->vvec);
+        a.Da = Da; a.E = E; a.F = c.attention_filters; a.K = c.attention_kernel_size;
+        a.pq = pq; a.Wconv = h->W(h->Wconv); a.Wloc = h->W(h->Wloc); a.v = h->W(h->vvec);
         a.pkey = pkey; a.mem = mem;
-        a.seg_start = tl.d_seg_start(); a.seg_len = tl.d_seg_len();
+        a.row_utt = tl.d_row_utt(); a.row_pos = tl.d_row_pos();
+        a.seg_start = tl.d_seg_start(); a.seg_len = tl.d_seg_len(); a.rows = tl.rows;
+        a.energy = h->d_energy.as<float>();
         a.attw = h->d_attw.as<float>(); a.cum = h->d_cum.as<float>();
         a.ctx1 = in1 + Pn; a.ld1 = K1;
         a.ctx2 = in2 + Ha; a.ld2 = K2;
         a.ctx3 = in3 + Hd; a.ld3 = K3;
         a.align = h->d_align.as<float>(); a.align_off = h->d_alignoff.as<long>(); a.step = i;
-        PK_LAUNCH(ctx, "taco_lsa", k_taco_lsa, dim3(B), dim3(256), lsa_smem, a);
+        PK_LAUNCH(ctx, "taco_lsa_energy", k_taco_lsa_energy, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, a);
+        PK_LAUNCH(ctx, "taco_lsa_ctx", k_taco_lsa_ctx, dim3(B, pk_div_up(E, 256)), dim3(256), lsa_smem, a);
         // decoder_rnn (:399-403) on [attention_hidden | context | decoder_hidden]
-        PK_TRY(pk_fft_run_dense(h, "taco_gemm_dec_rnn", h->dec_rnn, in2, K2, gates, 4 * Hd, B, PK_ACT_NONE, nullptr, 0, nullptr));
+        if (use_rg)
+            PK_TRY(rowgemm("taco_row_dec_rnn", h->rw_dec, in2, K2, gates, 4 * Hd, PK_ACT_NONE, -1, 0));
+        else
+            PK_TRY(pk_fft_run_dense(h, "taco_gemm_dec_rnn", h->dec_rnn, in2, K2, gates, 4 * Hd, B, PK_ACT_NONE, nullptr, 0, nullptr));
         PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Hd, 256)), dim3(256), 0, gates,
                   h->d_cdec.as<float>(), Hd, B, in2 + Ha + E, K2, in3, K3);
         // linear_projection on [decoder_hidden | context] (:409-413) -> this step's mel row; stop rules (:515-528)
-        PK_TRY(pk_fft_run_dense(h, "taco_gemm_proj", h->proj, in3, K3, Y + (long)i * B * M, M, B, PK_ACT_NONE, nullptr, 0, nullptr));
+        if (use_rg)
+            PK_TRY(rowgemm("taco_row_proj", h->rw_proj, in3, K3, Y + (long)i * B * M, M, PK_ACT_NONE, -1, 0));
+        else
+            PK_TRY(pk_fft_run_dense(h, "taco_gemm_proj", h->proj, in3, K3, Y + (long)i * B * M, M, B, PK_ACT_NONE, nullptr, 0, nullptr));
         PK_LAUNCH(ctx, "taco_stop", k_taco_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, in3, K3, K3,
                   c.use_stop_token ? h->W(h->stop_w) : (const float*)nullptr, h->stop_b, c.use_stop_token ? 1 : 0, B, i, cap,
                   h->d_attw.as<float>(), tl.d_seg_start(), tl.d_seg_len(), h->d_logits.as<float>(), d_len, d_first, d_ndone);
@@ -781,7 +858,7 @@ extern "C" void pk_taco_destroy(pk_taco* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
     pk_dbuf* bufs[] = {&h->d_tok, &h->d_tone, &h->d_e1, &h->d_e2, &h->d_xg, &h->d_mem, &h->d_pkey, &h->d_attw, &h->d_cum,
-                       &h->d_in1, &h->d_in2, &h->d_in3, &h->d_p1, &h->d_gates, &h->d_catt, &h->d_cdec, &h->d_zero, &h->d_y,
+                       &h->d_in1, &h->d_in2, &h->d_in3, &h->d_p1, &h->d_gates, &h->d_catt, &h->d_cdec, &h->d_zero, &h->d_y, &h->d_pq, &h->d_energy,
                        &h->d_logits, &h->d_state, &h->d_seeds, &h->d_align, &h->d_alignoff, &h->d_before, &h->d_q1,
                        &h->d_q2, &h->d_rowmap, &h->d_stage, &h->d_stage2};
     for (auto* b : bufs) b->release();

@@ -23,6 +23,9 @@
 //  * with a cache the reference computes the last query row only and its mask row is all ones
 //    (decoder_layer.py:110-120): k_tts_attn_step is one query per (utterance, head) over s keys; the same kernel
 //    serves the encoder-decoder attention over the T_b memory rows, whose K/V projections are computed once per call.
+//  * the per-step products of the new rows (B rows, one per utterance) run on the row GEMM of pk_rowgemm.h (weights
+//    streamed once, exact fp32 FMA, LayerNorm fused as a prologue, residual in the epilogue): 8 launches per decoder
+//    layer and step; PK_AR_ROWGEMM=0 selects the tile GEMM of gemm.hip + separate LayerNorm launches instead.
 //  * an utterance that has stopped keeps being stepped (its rows are ignored) until all have; the stop state lives
 //    on the device and is polled every few steps.
 //
@@ -36,6 +39,7 @@
 
 #include "pk_ar.h"
 #include "pk_fft.h"
+#include "pk_rowgemm.h"
 
 namespace {
 
@@ -103,32 +107,43 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
     const int n = a.klen ? a.klen[b] : a.n;
     const long base = a.kbase ? a.kbase[b] : b;
     float* qs = sm;           // dk (16-byte aligned: dk % 4 == 0)
-    float* red = sm + dk;     // 256 partial sums + 8 reduction slots
-    float* sc = red + 264;    // n scores -> probabilities
+    float* red = sm + dk;     // 1024 partial sums (256 threads x float4) + 8 reduction slots
+    float* sc = red + 1032;   // n scores -> probabilities
     const float* qp = a.q + (long)b * a.ldq + head * dk;
     for (int c = tid; c < dk; c += 256) qs[c] = qp[c] * a.scale;
     __syncthreads();
-    // scores: 16 lanes x float4 per key row, 4 keys per wave, 16 keys per pass
+    // scores: 16 lanes x float4 per key row, 4 keys per wave, 16 keys per pass, 4 passes per iteration with all of
+    // their (clamped, unconditional) loads issued before the first use
     const int sub = lane & 15, kq = lane >> 4, nv = dk >> 2;
-    for (int j0 = 0; j0 < n; j0 += 16) {
-        const int j = j0 + wave * 4 + kq;
-        float s = 0.f;
-        if (j < n) {
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        float s4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + u * 16 + wave * 4 + kq, n - 1);
             const float4* kp = reinterpret_cast<const float4*>(a.K + (base + (long)j * a.kstride) * a.ldkv + head * dk);
-            for (int c4 = sub; c4 < nv; c4 += 16) {
-                const float4 kv = kp[c4];
-                const float4 qv = *reinterpret_cast<const float4*>(qs + 4 * c4);
-                s = fmaf(kv.x, qv.x, s);
-                s = fmaf(kv.y, qv.y, s);
-                s = fmaf(kv.z, qv.z, s);
-                s = fmaf(kv.w, qv.w, s);
+            float s = 0.f;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {   // dk <= 192: at most 3 float4 per lane
+                const int c4 = sub + 16 * it;
+                if (16 * it < nv) {            // block-uniform
+                    const float4 kv = kp[min(c4, nv - 1)];
+                    const float4 qv = *reinterpret_cast<const float4*>(qs + 4 * min(c4, nv - 1));
+                    const float t = fmaf(kv.x, qv.x, fmaf(kv.y, qv.y, fmaf(kv.z, qv.z, kv.w * qv.w)));
+                    s += c4 < nv ? t : 0.f;
+                }
             }
+            s4[u] = s;
         }
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 1);
-        if (j < n && sub == 0) sc[j] = s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float s = s4[u];
+            s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 1);
+            const int j = j0 + u * 16 + wave * 4 + kq;
+            if (j < n && sub == 0) sc[j] = s;
+        }
     }
     __syncthreads();
     // softmax over the n keys
@@ -136,9 +151,9 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
     for (int j = tid; j < n; j += 256) m = fmaxf(m, sc[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) red[256 + wave] = m;
+    if (lane == 0) red[1024 + wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[256], red[257]), fmaxf(red[258], red[259]));
+    m = fmaxf(fmaxf(red[1024], red[1025]), fmaxf(red[1026], red[1027]));
     float sum = 0.f;
     for (int j = tid; j < n; j += 256) {
         const float p = expf(sc[j] - m);
@@ -147,20 +162,29 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) red[260 + wave] = sum;
+    if (lane == 0) red[1028 + wave] = sum;
     __syncthreads();   // also publishes the probabilities in sc[]
-    sum = (red[260] + red[261]) + (red[262] + red[263]);
+    sum = (red[1028] + red[1029]) + (red[1030] + red[1031]);
     const float inv = 1.f / sum;
-    // context: groups of dk threads walk the keys G apart, lanes across the head dimension (coalesced V rows)
-    const int G = 256 / dk;
-    const int g = tid / dk, c = tid - g * dk;
-    float acc = 0.f;
+    // context: a thread owns 4 consecutive head dimensions (one float4 of a value row), groups of dk / 4 threads walk
+    // the keys G apart with 8 loads in flight (the loop is bound by load latency: 30 us with dk threads per row and
+    // 4 loads in flight at 640 keys)
+    const int G = 256 / nv;
+    const int g = tid / nv, c4 = tid - g * nv;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g < G) {
-        const float* vp = a.V + head * dk + c;
-#pragma unroll 4
-        for (int j = g; j < n; j += G) acc = fmaf(sc[j], vp[(base + (long)j * a.kstride) * a.ldkv], acc);
+        const float* vp = a.V + head * dk + 4 * c4;
+#pragma unroll 8
+        for (int j = g; j < n; j += G) {
+            const float4 vv = *reinterpret_cast<const float4*>(vp + (base + (long)j * a.kstride) * a.ldkv);
+            const float p = sc[j];
+            acc.x = fmaf(p, vv.x, acc.x);
+            acc.y = fmaf(p, vv.y, acc.y);
+            acc.z = fmaf(p, vv.z, acc.z);
+            acc.w = fmaf(p, vv.w, acc.w);
+        }
     }
-    red[tid] = acc;
+    if (g < G) *reinterpret_cast<float4*>(red + g * dk + 4 * c4) = acc;
     __syncthreads();
     if (tid < dk) {
         float o = 0.f;
@@ -198,9 +222,15 @@ __global__ __launch_bounds__(256) void k_tts_stop(const float* __restrict__ z, i
     }
 }
 
+struct RowW {   // a layer as pk_rowgemm_pack tiles of its [K][N] matrix (+ bias) for the row GEMM
+    size_t w = 0, b = (size_t)-1;
+    int K = 0, N = 0;
+};
+
 struct DecLayer {
     size_t ln1_g, ln1_b, ln2_g, ln2_b, ln3_g, ln3_b;
     Dense qkv, out, src_q, src_kv, src_out, ffn1, ffn2;
+    RowW r_qkv, r_out, r_src_q, r_src_out, r_ffn1, r_ffn2;
 };
 }  // namespace
 
@@ -219,6 +249,7 @@ struct pk_tts : pk_fft_core {
     size_t enc_after_g = 0, enc_after_b = 0, dec_after_g = 0, dec_after_b = 0;
     std::vector<Dense> dprenet;
     Dense dlin, feat_out;
+    RowW r_feat_out;
     std::vector<DecLayer> dec;
     size_t prob_w = 0;
     float prob_b = 0.f;
@@ -350,7 +381,20 @@ int add_kv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A,
     return pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 2 * A, d);
 }
 
-int add_qkv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A, Dense& d) {
+int add_row_linear(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int K, int N, RowW& r) {
+    std::vector<float> w, b;
+    PK_TRY(pk_get_weight(P, base, {K, N}, w));   // Linear weight [in, out] = [K][N]
+    PK_TRY(pk_get_vector(P, base + ".bias", N, b));
+    std::vector<float> wt;
+    pk_rowgemm_pack(w.data(), K, N, wt);
+    r.w = ar.put(wt);
+    r.b = ar.put(b);
+    r.K = K;
+    r.N = N;
+    return PK_OK;
+}
+
+int add_qkv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A, Dense& d, RowW& r) {
     std::vector<float> wq, wk, wv, bq, bk, bv, kn((size_t)A * 3 * A), bias(3 * A);
     PK_TRY(pk_get_weight(P, p + ".linear_q", {A, A}, wq));
     PK_TRY(pk_get_weight(P, p + ".linear_k", {A, A}, wk));
@@ -369,6 +413,12 @@ int add_qkv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A
         bias[A + o] = bk[o];
         bias[2 * A + o] = bv[o];
     }
+    std::vector<float> wt;
+    pk_rowgemm_pack(kn.data(), A, 3 * A, wt);
+    r.w = ar.put(wt);
+    r.b = ar.put(bias);
+    r.K = A;
+    r.N = 3 * A;
     return pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 3 * A, d);
 }
 }  // namespace
@@ -425,17 +475,23 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
         PK_TRY(pk_fft_add_vec(ar, P, p + ".norm2.bias", A, L.ln2_b));
         PK_TRY(pk_fft_add_vec(ar, P, p + ".norm3.weight", A, L.ln3_g));
         PK_TRY(pk_fft_add_vec(ar, P, p + ".norm3.bias", A, L.ln3_b));
-        PK_TRY(add_qkv(ar, P, p + ".self_attn", A, L.qkv));
+        PK_TRY(add_qkv(ar, P, p + ".self_attn", A, L.qkv, L.r_qkv));
         PK_TRY(pk_fft_add_linear(ar, P, p + ".self_attn.linear_out", A, A, L.out));
         PK_TRY(pk_fft_add_linear(ar, P, p + ".src_attn.linear_q", A, A, L.src_q));
         PK_TRY(add_kv(ar, P, p + ".src_attn", A, L.src_kv));
         PK_TRY(pk_fft_add_linear(ar, P, p + ".src_attn.linear_out", A, A, L.src_out));
         PK_TRY(pk_fft_add_linear(ar, P, p + ".feed_forward.w_1", A, c.dunits, L.ffn1));   // PositionwiseFeedForward
         PK_TRY(pk_fft_add_linear(ar, P, p + ".feed_forward.w_2", c.dunits, A, L.ffn2));
+        PK_TRY(add_row_linear(ar, P, p + ".self_attn.linear_out", A, A, L.r_out));
+        PK_TRY(add_row_linear(ar, P, p + ".src_attn.linear_q", A, A, L.r_src_q));
+        PK_TRY(add_row_linear(ar, P, p + ".src_attn.linear_out", A, A, L.r_src_out));
+        PK_TRY(add_row_linear(ar, P, p + ".feed_forward.w_1", A, c.dunits, L.r_ffn1));
+        PK_TRY(add_row_linear(ar, P, p + ".feed_forward.w_2", c.dunits, A, L.r_ffn2));
     }
     PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.weight", A, h->dec_after_g));
     PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.bias", A, h->dec_after_b));
     PK_TRY(pk_fft_add_linear(ar, P, "feat_out", A, c.odim, h->feat_out));
+    PK_TRY(add_row_linear(ar, P, "feat_out", A, c.odim, h->r_feat_out));
     {
         std::vector<float> w, b;
         PK_TRY(pk_get_weight(P, "prob_out", {A, 1}, w));
@@ -471,7 +527,7 @@ constexpr int SLACK = 2 * PK_GEMM_BM;   // rows a GEMM tile may read beyond the 
 int rows_reserve(pk_dbuf& buf, long rows, int C) { return pk_fft_act_reserve(buf, (int)(rows + SLACK), C); }
 
 int attn_step(pk_tts* h, const char* name, const AttnStep& a, int heads, int B, int nmax) {
-    const size_t smem = (size_t)(a.dk + 264 + nmax + 4) * sizeof(float);
+    const size_t smem = (size_t)(a.dk + 1032 + nmax + 4) * sizeof(float);
     if (smem > 60 * 1024) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: %d attention keys exceed the step kernel's LDS budget", nmax);
     PK_LAUNCH(h->ctx, name, k_tts_attn_step, dim3(heads, B), dim3(256), smem, a);
     return PK_OK;
@@ -650,6 +706,16 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     const float att_scale = (float)(1.0 / std::sqrt((double)dk));
     static const int poll = getenv("PK_TTS_POLL") ? std::max(1, atoi(getenv("PK_TTS_POLL"))) : 4;
     const bool use_ham = h->math == PK_GEMM_MATH_F16X3;
+    static const bool use_rg = getenv("PK_AR_ROWGEMM") ? atoi(getenv("PK_AR_ROWGEMM")) != 0 : true;
+    // y = [LayerNorm(x)] . W + b [ReLU] [+ res] for the B new rows of a step (pk_rowgemm.h)
+    auto rowgemm = [&](const char* name, const RowW& w, const float* x, int ldx, float* y, int ldy, int act, const float* res,
+                       int ldr, size_t ln_g, size_t ln_b, bool ln) -> int {
+        pk_rowgemm_args g;
+        g.x = x; g.ldx = ldx; g.Wt = h->W(w.w); g.bias = h->W(w.b); g.y = y; g.ldy = ldy; g.M = B; g.K = w.K; g.N = w.N;
+        g.act = act; g.res = res; g.ldr = ldr;
+        if (ln) { g.ln_g = h->W(ln_g); g.ln_b = h->W(ln_b); }
+        return pk_rowgemm_launch(ctx, name, g);
+    };
     int s = 0;
     for (s = 1; s <= Lcap; ++s) {
         const int R = s * B;
@@ -675,10 +741,16 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             const DecLayer& L = h->dec[l];
             const float* xin = (l == 0 ? X0 : pk_fft_act_ptr(h->d_xc_l[l - 1], A)) + nr * A;
             float* qkv = pk_fft_act_ptr(h->d_qkv_l[l], 3 * A);
+            float* xc_new = pk_fft_act_ptr(h->d_xc_l[l], A) + nr * A;
             if (l > 0) {
-                PK_TRY(pk_fft_layernorm_rows(h, xin, L.ln1_g, L.ln1_b, valid, B, A, rt, use_ham ? ham : nullptr));
-                PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv", L.qkv, rt, A, qkv + nr * 3 * A, 3 * A, B, PK_ACT_NONE, nullptr, 0,
-                                        nullptr, use_ham ? ham : nullptr));
+                if (use_rg) {
+                    PK_TRY(rowgemm("tts_row_qkv", L.r_qkv, xin, A, qkv + nr * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0, L.ln1_g,
+                                   L.ln1_b, true));
+                } else {
+                    PK_TRY(pk_fft_layernorm_rows(h, xin, L.ln1_g, L.ln1_b, valid, B, A, rt, use_ham ? ham : nullptr));
+                    PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv", L.qkv, rt, A, qkv + nr * 3 * A, 3 * A, B, PK_ACT_NONE, nullptr,
+                                            0, nullptr, use_ham ? ham : nullptr));
+                }
             }
             AttnStep a;
             memset(&a, 0, sizeof(a));
@@ -687,33 +759,44 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             a.kbase = nullptr; a.klen = nullptr; a.kstride = B; a.n = s; a.dk = dk; a.scale = att_scale;
             a.out = rc; a.ldo = A;
             PK_TRY(attn_step(h, "tts_attn_self", a, H, B, s));
-            // x = residual + self_attn(...)   (decoder_layer.py:127-128)
+            const float* mkv = pk_fft_act_ptr(h->d_mkv_l[l], 2 * A);
+            AttnStep a2;
+            memset(&a2, 0, sizeof(a2));
+            a2.q = rq; a2.ldq = A;
+            a2.K = mkv; a2.V = mkv + A; a2.ldkv = 2 * A;
+            a2.kbase = tlk.d_seg_start(); a2.klen = tlk.d_seg_len(); a2.kstride = 1; a2.n = 0; a2.dk = dk; a2.scale = att_scale;
+            a2.out = rc; a2.ldo = A;
+            a2.att = att; a2.att_off = d_attoff; a2.att_cap = d_cap; a2.layer = l; a2.step = s - 1;
+            if (use_rg) {
+                // x = residual + self_attn(...) (decoder_layer.py:127-128); x = residual + src_attn(norm2(x), memory)
+                // (:132-141); x = residual + feed_forward(norm3(x)) (:145-148) -> the layer's cached output row
+                PK_TRY(rowgemm("tts_row_attn_out", L.r_out, rc, A, rx, A, PK_ACT_NONE, xin, A, 0, 0, false));
+                PK_TRY(rowgemm("tts_row_src_q", L.r_src_q, rx, A, rq, A, PK_ACT_NONE, nullptr, 0, L.ln2_g, L.ln2_b, true));
+                PK_TRY(attn_step(h, "tts_attn_src", a2, H, B, maxT));
+                PK_TRY(rowgemm("tts_row_src_out", L.r_src_out, rc, A, rx, A, PK_ACT_NONE, rx, A, 0, 0, false));
+                PK_TRY(rowgemm("tts_row_ffn1", L.r_ffn1, rx, A, rf, c.dunits, PK_ACT_RELU, nullptr, 0, L.ln3_g, L.ln3_b, true));
+                PK_TRY(rowgemm("tts_row_ffn2", L.r_ffn2, rf, c.dunits, xc_new, A, PK_ACT_NONE, rx, A, 0, 0, false));
+                continue;
+            }
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_attn_out", L.out, rc, A, rx, A, B, PK_ACT_NONE, xin, A, nullptr));
-            // x = residual + src_attn(norm2(x), memory, memory)   (:132-141)
             PK_TRY(pk_fft_layernorm_rows(h, rx, L.ln2_g, L.ln2_b, valid, B, A, rt, use_ham ? ham : nullptr));
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_src_q", L.src_q, rt, A, rq, A, B, PK_ACT_NONE, nullptr, 0, nullptr,
                                     use_ham ? ham : nullptr));
-            const float* mkv = pk_fft_act_ptr(h->d_mkv_l[l], 2 * A);
-            memset(&a, 0, sizeof(a));
-            a.q = rq; a.ldq = A;
-            a.K = mkv; a.V = mkv + A; a.ldkv = 2 * A;
-            a.kbase = tlk.d_seg_start(); a.klen = tlk.d_seg_len(); a.kstride = 1; a.n = 0; a.dk = dk; a.scale = att_scale;
-            a.out = rc; a.ldo = A;
-            a.att = att; a.att_off = d_attoff; a.att_cap = d_cap; a.layer = l; a.step = s - 1;
-            PK_TRY(attn_step(h, "tts_attn_src", a, H, B, maxT));
+            PK_TRY(attn_step(h, "tts_attn_src", a2, H, B, maxT));
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_src_out", L.src_out, rc, A, rx, A, B, PK_ACT_NONE, rx, A, nullptr));
-            // x = residual + feed_forward(norm3(x))   (:145-148); the result is the layer's cached output row
             PK_TRY(pk_fft_layernorm_rows(h, rx, L.ln3_g, L.ln3_b, valid, B, A, rt, use_ham ? ham : nullptr));
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_ffn1", L.ffn1, rt, A, rf, c.dunits, B, PK_ACT_RELU, nullptr, 0, nullptr,
                                     use_ham ? ham : nullptr));
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_ffn2", L.ffn2, rf, c.dunits, pk_fft_act_ptr(h->d_xc_l[l], A) + nr * A, A, B,
-                                    PK_ACT_NONE, rx, A, nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_ffn2", L.ffn2, rf, c.dunits, xc_new, A, B, PK_ACT_NONE, rx, A, nullptr));
         }
         // after_norm of the last row, feat_out -> the next prefix row, prob_out -> stop state (:613-616, :638-642)
         PK_TRY(pk_fft_layernorm_rows(h, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, h->dec_after_g, h->dec_after_b,
                                      valid, B, A, rz, use_ham ? ham : nullptr));
-        PK_TRY(pk_fft_run_dense(h, "tts_gemm_feat_out", h->feat_out, rz, A, Y + (long)s * B * O, O, B, PK_ACT_NONE, nullptr, 0,
-                                nullptr, use_ham ? ham : nullptr));
+        if (use_rg)
+            PK_TRY(rowgemm("tts_row_feat_out", h->r_feat_out, rz, A, Y + (long)s * B * O, O, PK_ACT_NONE, nullptr, 0, 0, 0, false));
+        else
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_feat_out", h->feat_out, rz, A, Y + (long)s * B * O, O, B, PK_ACT_NONE, nullptr,
+                                    0, nullptr, use_ham ? ham : nullptr));
         PK_LAUNCH(ctx, "tts_stop", k_tts_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, rz, A, h->W(h->prob_w), h->prob_b, B, s,
                   (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone);
         if (s % poll == 0 || s == Lcap) {
