@@ -64,13 +64,18 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
     float acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-    // The weight loads are issued WG at a time, unconditionally (indices clamped, a select zeroes what lies beyond the
-    // chunk: a branch around a load makes the compiler wait for vmcnt(0) at every use) -- the kernel is bound by the
-    // latency of the weight stream, not by its volume.
-    constexpr int WG = 16;
+    // A lane's k of a chunk: part, part + PARTS, ... -- at most KC / PARTS = 16 of them.  Their weight loads are issued
+    // before the chunk's activations are staged (they do not depend on LDS), unconditionally (indices clamped, a select
+    // zeroes what lies beyond the chunk: a branch around a load makes the compiler wait for vmcnt(0) at every use): the
+    // kernel is bound by the LATENCY of the weight stream and of the staging, which now overlap.
+    constexpr int WG = KC / PARTS;
+    static_assert(WG <= 16, "weight registers");
     const float* slab = a.Wt + (long)blockIdx.x * a.K * CW;   // this workgroup's [K][CW] slab
     for (int k0 = 0; k0 < a.K; k0 += KC) {
         const int kc = min(KC, a.K - k0);
+        float w[WG];
+#pragma unroll
+        for (int g = 0; g < WG; ++g) w[g] = slab[(long)(k0 + min(part + PARTS * g, kc - 1)) * CW + col];
         __syncthreads();   // the previous chunk is consumed (first pass: the LayerNorm statistics are published)
         // stage x[m0 + m][k0 + 4 * k4 ..] -> xs[(4 * k4 + i) * 32 + m]; lanes = 32 rows x 2 groups of 4 columns
         for (int e = tid; e < (kc >> 2) * ROWS; e += 512) {
@@ -95,30 +100,19 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
             d[3 * ROWS] = v.w;
         }
         __syncthreads();
-        // k-steps of this lane in the chunk: k = part + PARTS * j < kc  (K % 8 == 0; with KSUB = 4 a chunk that is not
-        // a multiple of 32 leaves the last step to some of the parts only: clamp + select)
-        const int nk = (kc + PARTS - 1) / PARTS;
-        for (int j0 = 0; j0 < nk; j0 += WG) {
-            float w[WG];
 #pragma unroll
-            for (int g = 0; g < WG; ++g) {
-                const int k = min(part + PARTS * (j0 + g), kc - 1);
-                w[g] = slab[(long)(k0 + k) * CW + col];
-            }
+        for (int g = 0; g < WG; ++g) {
+            const int kk = part + PARTS * g;
+            const int k = min(kk, kc - 1);
+            const float wv = kk < kc ? w[g] : 0.f;
+            const float4* xr = reinterpret_cast<const float4*>(xs + k * ROWS);
 #pragma unroll
-            for (int g = 0; g < WG; ++g) {
-                const int kk = part + PARTS * (j0 + g);
-                const int k = min(kk, kc - 1);
-                const float wv = kk < kc ? w[g] : 0.f;
-                const float4* xr = reinterpret_cast<const float4*>(xs + k * ROWS);
-#pragma unroll
-                for (int q = 0; q < ROWS / 4; ++q) {
-                    const float4 xv = xr[q];
-                    acc[4 * q + 0] = fmaf(xv.x, wv, acc[4 * q + 0]);
-                    acc[4 * q + 1] = fmaf(xv.y, wv, acc[4 * q + 1]);
-                    acc[4 * q + 2] = fmaf(xv.z, wv, acc[4 * q + 2]);
-                    acc[4 * q + 3] = fmaf(xv.w, wv, acc[4 * q + 3]);
-                }
+            for (int q = 0; q < ROWS / 4; ++q) {
+                const float4 xv = xr[q];
+                acc[4 * q + 0] = fmaf(xv.x, wv, acc[4 * q + 0]);
+                acc[4 * q + 1] = fmaf(xv.y, wv, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(xv.z, wv, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(xv.w, wv, acc[4 * q + 3]);
             }
         }
     }
@@ -155,7 +149,7 @@ int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args&
     if (a.act != PK_ACT_NONE && a.act != PK_ACT_RELU) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: activation %d", a.act);
     const int cw = pk_rowgemm_cw(a.N);
     dim3 grid((a.N + cw - 1) / cw, (a.M + ROWS - 1) / ROWS);
-    if (cw == 64) PK_LAUNCH(ctx, prof_name, k_rowgemm<64>, grid, dim3(512), 0, a);
-    else PK_LAUNCH(ctx, prof_name, k_rowgemm<16>, grid, dim3(512), 0, a);
+    if (cw != 16) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: only the 16-column tiling is built");
+    PK_LAUNCH(ctx, prof_name, k_rowgemm<16>, grid, dim3(512), 0, a);
     return PK_OK;
 }
