@@ -252,3 +252,46 @@ def load_waveflow(config, checkpoint_path):
     model.set_state_dict(load_params(path if path.endswith(".pdparams") else path + ".pdparams"))
     model.eval()
     return model
+
+
+def load_transformer_tts(config, checkpoint, stats, phones_dict=None, idim=None):
+    """The acoustic-model half of examples/transformer_tts/synthesize.py:45-75: returns
+    ``(TransformerTTSInference, phone_id_map)``.  ``config``: the recipe's yaml (path or dict with ``n_mels`` and
+    ``model``, examples/transformer_tts/ljspeech/conf/default.yaml)."""
+    from .normalizer import ZScore
+    from .transformer_tts import TransformerTTS, TransformerTTSInference
+    cfg = _config(config)
+    phone_id_map = None
+    if phones_dict is not None:
+        phone_id_map, vocab = load_phone_id_map(phones_dict)
+        idim = vocab if idim is None else idim
+    if idim is None:
+        raise ValueError("load_transformer_tts: give phones_dict or idim")
+    model = TransformerTTS(idim=idim, odim=cfg["n_mels"], **cfg["model"])
+    model.set_state_dict(load_params(checkpoint, "main_params"))
+    model.eval()
+    mu, sigma = load_stats(stats)
+    return TransformerTTSInference(ZScore(mu, sigma), model), phone_id_map
+
+
+def load_tacotron2(config, checkpoint_path):
+    """``Tacotron2.from_pretrained`` (models/tacotron2.py:843-883): ``config`` with ``model`` and ``data`` sections
+    (examples/tacotron2/config.py), ``checkpoint_path`` without the ``.pdparams`` suffix."""
+    from .tacotron2 import Tacotron2
+    cfg = _config(config)
+    m = cfg["model"]
+    model = Tacotron2(vocab_size=m["vocab_size"], n_tones=m.get("n_tones"), d_mels=cfg["data"]["n_mels"],
+                      d_encoder=m["d_encoder"], encoder_conv_layers=m["encoder_conv_layers"],
+                      encoder_kernel_size=m["encoder_kernel_size"], d_prenet=m["d_prenet"],
+                      d_attention_rnn=m["d_attention_rnn"], d_decoder_rnn=m["d_decoder_rnn"],
+                      attention_filters=m["attention_filters"], attention_kernel_size=m["attention_kernel_size"],
+                      d_attention=m["d_attention"], d_postnet=m["d_postnet"],
+                      postnet_kernel_size=m["postnet_kernel_size"], postnet_conv_layers=m["postnet_conv_layers"],
+                      reduction_factor=m["reduction_factor"], p_encoder_dropout=m["p_encoder_dropout"],
+                      p_prenet_dropout=m["p_prenet_dropout"], p_attention_dropout=m["p_attention_dropout"],
+                      p_decoder_dropout=m["p_decoder_dropout"], p_postnet_dropout=m["p_postnet_dropout"],
+                      d_global_condition=m.get("d_global_condition"), use_stop_token=m["use_stop_token"])
+    path = str(checkpoint_path)
+    model.set_state_dict(load_params(path if path.endswith(".pdparams") else path + ".pdparams"))
+    model.eval()
+    return model

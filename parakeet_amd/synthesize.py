@@ -53,3 +53,32 @@ class Synthesizer:
 
     def __call__(self, text, alpha=1.0, noise=None):
         return self.synthesize_batch([text], alpha, None if noise is None else [noise])[0]
+
+
+class ARSynthesizer:
+    """An autoregressive acoustic model -> WaveFlow on one GPU, for a ragged batch: the loop body of
+    examples/transformer_tts/synthesize.py:78-88 (``mel = transformer_tts_inference(text); wav = vocoder.infer(mel)``)
+    and of the Tacotron2 + WaveFlow notebook (examples/tacotron2/synthesize.ipynb), with the mel staying in HBM.
+    ``acoustic`` is a ``TransformerTTSInference`` or a ``Tacotron2``; ``vocoder`` a ``ConditionalWaveFlow``."""
+
+    def __init__(self, acoustic, vocoder):
+        self.acoustic, self.vocoder = acoustic, vocoder
+
+    def mels(self, texts, seeds=None, **kw):
+        """List of (L_b, n_mels) log-mel device tensors."""
+        if type(self.acoustic).__name__ == "Tacotron2":
+            outs = self.acoustic.infer_batch(texts, seeds=seeds, **kw)
+            return [o["mel_outputs_postnet"] for o in outs]
+        m = self.acoustic.bind()
+        outs = m.inference_batch(texts, seeds=seeds, return_att=False, denormalize=True, **kw)
+        return [o[0] for o in outs]
+
+    def synthesize_batch(self, texts, seeds=None, zs=None, generator=None, **kw):
+        """Lists of token ids -> list of (T_b,) waveforms (device tensors).  ``seeds``: dropout-stream seed per
+        utterance; ``zs``: WaveFlow latents per utterance (else drawn by the engine / ``generator``)."""
+        mels = self.mels(texts, seeds=seeds, **kw)
+        # waveflow's input is (C_mel, T) per utterance (synthesize.py:81-83)
+        return self.vocoder.infer_batch([m.as_subclass(torch.Tensor).transpose(0, 1) for m in mels], zs, generator)
+
+    def __call__(self, text, seed=0, z=None, **kw):
+        return self.synthesize_batch([text], [seed], None if z is None else [z], **kw)[0]

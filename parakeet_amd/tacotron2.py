@@ -137,6 +137,13 @@ class Tacotron2:
         o = self.infer_batch([x.reshape(-1)], max_decoder_steps, t, [seed])[0]
         return {k: wrap(v.unsqueeze(0)) for k, v in o.items()}
 
+    @classmethod
+    def from_pretrained(cls, config, checkpoint_path):
+        """Tacotron2.from_pretrained (tacotron2.py:843-883): config with ``model`` / ``data`` sections, checkpoint path
+        without the ``.pdparams`` suffix."""
+        from .checkpoint import load_tacotron2
+        return load_tacotron2(config, checkpoint_path)
+
     def debug_tap(self, what, b):
         """0: encoder outputs (T_b, d_encoder)."""
         out = np.empty((self._last_tok[b], self.d_encoder), dtype=np.float32)
