@@ -7,6 +7,7 @@ synthesis hot path named in BASELINE.json:
     FastSpeech2.inference  ->  PWGGenerator.inference      (headline path)
     ConditionalWaveFlow.infer                              (alternative vocoder)
     STFT -> mel -> log10                                   (metric / feature path)
+    SpeedySpeech.inference, TransformerTTS.inference, Tacotron2.infer   (the other acoustic models)
 
 Every function cites the reference file:line it follows (paths relative to
 the reference repository root).
@@ -37,6 +38,11 @@ therefore pinned in two ways, both weaker than a real Paddle run:
      defaults), which are encoded from Paddle's documentation in
      oracle/nn_ref.py and listed in DESIGN.md as "paddle-semantics,
      unverified".
+
+The autoregressive models keep their decoder prenet's dropout on at inference; their oracles and the reference-source
+runs that produced their golden vectors share the engine's counter-based dropout stream (philox_ref.dropout_keep,
+injected into the stand-in's F.dropout by tools/make_golden_ar.py), so masks are identical by construction.
+paddle.nn.LSTM / LSTMCell semantics (gate order i, f, g, o; aliased parameter names) are [paddle-semantics].
 
 Until a real Paddle build has been run against these vectors the status is:
 "parity pinned to the reference's Python source over a Paddle stand-in;
