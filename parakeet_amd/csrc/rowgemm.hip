@@ -64,26 +64,44 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
     float acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-    // A lane's k of a chunk: part, part + PARTS, ... -- at most KC / PARTS = 16 of them.  Their weight loads are issued
-    // before the chunk's activations are staged (they do not depend on LDS), unconditionally (indices clamped, a select
-    // zeroes what lies beyond the chunk: a branch around a load makes the compiler wait for vmcnt(0) at every use): the
-    // kernel is bound by the LATENCY of the weight stream and of the staging, which now overlap.
+    // A lane's k of a chunk: part, part + PARTS, ... -- at most KC / PARTS = 16 of them.  The kernel is bound by the
+    // LATENCY of the weight stream and of the activation staging, not by their volume, so both are software-pipelined
+    // one chunk ahead in registers: while chunk c is multiplied out of LDS, the weight loads (16 per lane) and the
+    // activation loads (8 float4 per thread) of chunk c + 1 are in flight.  Every load is unconditional with clamped
+    // indices -- a branch around a load makes the compiler wait for vmcnt(0) at every use -- and what lies beyond the
+    // problem is zeroed by a select (weights) or simply not stored (activations).
     constexpr int WG = KC / PARTS;
-    static_assert(WG <= 16, "weight registers");
+    constexpr int XR = (KC / 4) * ROWS / 512;   // float4 per thread per chunk
+    static_assert(WG <= 16 && XR == 8, "register budget");
     const float* slab = a.Wt + (long)blockIdx.x * a.K * CW;   // this workgroup's [K][CW] slab
+    float wn[WG];
+    float4 xn[XR];
+    {
+        const int kc = min(KC, a.K);
+#pragma unroll
+        for (int g = 0; g < WG; ++g) wn[g] = slab[(long)min(part + PARTS * g, kc - 1) * CW + col];
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int e = tid + 512 * i;
+            const int m = min(e & (ROWS - 1), rows - 1), k4 = min(e >> 5, (kc >> 2) - 1);
+            xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + m) * a.ldx + 4 * k4);
+        }
+    }
     for (int k0 = 0; k0 < a.K; k0 += KC) {
         const int kc = min(KC, a.K - k0);
         float w[WG];
 #pragma unroll
-        for (int g = 0; g < WG; ++g) w[g] = slab[(long)(k0 + min(part + PARTS * g, kc - 1)) * CW + col];
+        for (int g = 0; g < WG; ++g) w[g] = wn[g];
         __syncthreads();   // the previous chunk is consumed (first pass: the LayerNorm statistics are published)
         // stage x[m0 + m][k0 + 4 * k4 ..] -> xs[(4 * k4 + i) * 32 + m]; lanes = 32 rows x 2 groups of 4 columns
-        for (int e = tid; e < (kc >> 2) * ROWS; e += 512) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int e = tid + 512 * i;
             const int m = e & (ROWS - 1), k4 = e >> 5;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < rows) {
-                v = *reinterpret_cast<const float4*>(a.x + (long)(m0 + m) * a.ldx + k0 + 4 * k4);
-                if (a.ln_g) {
+            if (k4 < (kc >> 2)) {
+                float4 v = xn[i];
+                if (m >= rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (a.ln_g) {
                     const float mean = stat[m], rstd = stat[ROWS + m];
                     const float4 g = *reinterpret_cast<const float4*>(a.ln_g + k0 + 4 * k4);
                     const float4 bb = *reinterpret_cast<const float4*>(a.ln_b + k0 + 4 * k4);
@@ -92,14 +110,29 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
                     v.z = (v.z - mean) * rstd * g.z + bb.z;
                     v.w = (v.w - mean) * rstd * g.w + bb.w;
                 }
+                float* d = xs + (4 * k4) * ROWS + m;
+                d[0] = v.x;
+                d[ROWS] = v.y;
+                d[2 * ROWS] = v.z;
+                d[3 * ROWS] = v.w;
             }
-            float* d = xs + (4 * k4) * ROWS + m;
-            d[0] = v.x;
-            d[ROWS] = v.y;
-            d[2 * ROWS] = v.z;
-            d[3 * ROWS] = v.w;
         }
         __syncthreads();
+        {
+            // the next chunk's operands; when there is none the clamps fold every load onto one cache line
+            const bool has_next = k0 + KC < a.K;
+            const int k0n = has_next ? k0 + KC : 0;
+            const int kcn = has_next ? min(KC, a.K - k0n) : 4;
+            const int mlim = has_next ? rows - 1 : 0;
+#pragma unroll
+            for (int g = 0; g < WG; ++g) wn[g] = slab[(long)(k0n + min(part + PARTS * g, kcn - 1)) * CW + col];
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int e = tid + 512 * i;
+                const int m = min(e & (ROWS - 1), mlim), k4 = min(e >> 5, (kcn >> 2) - 1);
+                xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + m) * a.ldx + k0n + 4 * k4);
+            }
+        }
 #pragma unroll
         for (int g = 0; g < WG; ++g) {
             const int kk = part + PARTS * g;
