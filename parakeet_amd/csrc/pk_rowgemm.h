@@ -28,6 +28,8 @@ static inline int pk_rowgemm_cw(int N) {
 }
 // [K][N] row-major -> tiles [ceil(N / cw)][K][cw], columns beyond N zero
 void pk_rowgemm_pack(const float* Wkn, int K, int N, std::vector<float>& out);
+// LSTM gate columns [i (H) | f (H) | g (H) | o (H)] -> blocks of 16: [i f g o] x 4 units each; perm[new] = old column
+void pk_rowgemm_lstm_perm(int H, std::vector<int>& perm);
 
 struct pk_rowgemm_args {
     const float* x = nullptr;   // [M][ldx], K columns used; ldx % 4 == 0, 16-byte aligned
@@ -43,6 +45,16 @@ struct pk_rowgemm_args {
     const float* ln_g = nullptr;   // LayerNorm(K) weight / bias applied to x first (needs K <= PK_RG_KC), or NULL
     const float* ln_b = nullptr;
     float ln_eps = 1e-5f;
+    // LSTMCell epilogue (lstm_c != NULL): N = 4 * lstm_H gate columns, PERMUTED at pack time (pk_rowgemm_lstm_perm) so
+    // that workgroup bx holds i | f | g | o of units 4 * bx .. 4 * bx + 3; the epilogue then finishes the cell
+    // (c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c')), updates lstm_c [M][lstm_H] in place and writes h'
+    // to two destinations (operand rows of the GEMMs that consume it); y is not written.  No act / dropout / res.
+    float* lstm_c = nullptr;
+    int lstm_H = 0;
+    float* lstm_h1 = nullptr;
+    int lstm_ld1 = 0;
+    float* lstm_h2 = nullptr;
+    int lstm_ld2 = 0;
     // dropout after the activation (before the residual): element index ((drop_base * drop_J + drop_j) * N + n) of the
     // utterance's stream (row m = utterance m), keep <=> word >= drop_thr, kept values * drop_scale
     int dropout = 0;

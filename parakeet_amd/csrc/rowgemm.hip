@@ -13,8 +13,16 @@ void pk_rowgemm_pack(const float* Wkn, int K, int N, std::vector<float>& out) {
                 out[((size_t)b * K + k) * cw + c] = Wkn[(size_t)k * N + b * cw + c];
 }
 
+void pk_rowgemm_lstm_perm(int H, std::vector<int>& perm) {
+    perm.resize((size_t)4 * H);
+    for (int u = 0; u < H; ++u)
+        for (int g = 0; g < 4; ++g) perm[(size_t)(u / 4) * 16 + g * 4 + (u % 4)] = g * H + u;
+}
+
 namespace {
 constexpr int KC = PK_RG_KC, ROWS = PK_RG_ROWS;
+
+__device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // CW columns per workgroup, KSUB = 64 / CW consecutive k per wave-wide load, 8 * KSUB K-parts per workgroup
 template <int CW>
@@ -152,6 +160,35 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) red[(part * ROWS + r) * CW + col] = acc[r];
     __syncthreads();
+    if (a.lstm_c) {
+        // gates of this workgroup's 4 units for every row -> LDS, then one thread per (row, unit) finishes the cell
+        float* gl = xs;   // the activations are consumed: [32][16] gate pre-activations
+        for (int e = tid; e < ROWS * CW; e += 512) {
+            const int m = e / CW, c = e - m * CW;
+            const int nn = blockIdx.x * CW + c;
+            float s = 0.f;
+#pragma unroll 8
+            for (int p = 0; p < PARTS; ++p) s += red[(p * ROWS + m) * CW + c];
+            if (a.bias && nn < a.N) s += a.bias[nn];
+            gl[e] = s;
+        }
+        __syncthreads();
+        if (tid < ROWS * 4) {
+            const int m = tid >> 2, j = tid & 3;
+            const int u = blockIdx.x * 4 + j;
+            if (m < rows && u < a.lstm_H) {
+                const float* g = gl + m * CW;
+                const float gi = rg_sigmoid(g[j]), gf = rg_sigmoid(g[4 + j]), gg = tanhf(g[8 + j]), go = rg_sigmoid(g[12 + j]);
+                float* cp = a.lstm_c + (long)(m0 + m) * a.lstm_H + u;
+                const float cn = gf * *cp + gi * gg;
+                const float h = go * tanhf(cn);
+                *cp = cn;
+                a.lstm_h1[(long)(m0 + m) * a.lstm_ld1 + u] = h;
+                a.lstm_h2[(long)(m0 + m) * a.lstm_ld2 + u] = h;
+            }
+        }
+        return;
+    }
     for (int e = tid; e < ROWS * CW; e += 512) {
         const int m = e / CW, c = e - m * CW;
         const int nn = blockIdx.x * CW + c;
@@ -180,6 +217,9 @@ int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args&
         PK_FAIL(PK_EUNSUPPORTED, "row GEMM: K (%d) must be a multiple of 8 and ldx (%d) of 4", a.K, a.ldx);
     if (a.ln_g && (a.K > KC || !a.ln_b)) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: the LayerNorm prologue needs K <= %d", KC);
     if (a.act != PK_ACT_NONE && a.act != PK_ACT_RELU) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: activation %d", a.act);
+    if (a.lstm_c && (a.N != 4 * a.lstm_H || a.lstm_H % 4 != 0 || a.act != PK_ACT_NONE || a.dropout || a.res || !a.lstm_h1 ||
+                     !a.lstm_h2))
+        PK_FAIL(PK_EINVAL, "row GEMM: LSTM epilogue needs N == 4 * H, H %% 4 == 0, two h destinations and no act / dropout / res");
     const int cw = pk_rowgemm_cw(a.N);
     dim3 grid((a.N + cw - 1) / cw, (a.M + ROWS - 1) / ROWS);
     if (cw != 16) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: only the 16-column tiling is built");

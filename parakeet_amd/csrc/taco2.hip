@@ -332,7 +332,7 @@ struct pk_taco : pk_fft_core {
     int B = 0, cap = 0, steps = 0, maxT = 0;
     std::vector<int> T, len;
     std::vector<long> align_off;
-    pk_dbuf d_tok, d_tone, d_e1, d_e2, d_xg, d_mem, d_pkey, d_attw, d_cum, d_in1, d_in2, d_in3, d_p1, d_gates, d_catt,
+    pk_dbuf d_tok, d_tone, d_e1, d_e2, d_xg, d_mem, d_pkey, d_attw, d_cum, d_in1, d_in1b, d_in2, d_in2b, d_in3, d_p1, d_gates, d_catt,
         d_cdec, d_zero, d_y, d_pq, d_energy, d_logits, d_state, d_seeds, d_align, d_alignoff, d_before, d_q1, d_q2, d_rowmap, d_stage,
         d_stage2;
 };
@@ -367,12 +367,22 @@ int add_cell(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int 
         for (int k = 0; k < H; ++k) kn[(size_t)(in + k) * N + g] = whh[(size_t)g * H + k];
         bias[g] = bih[g] + bhh[g];
     }
-    std::vector<float> wt;
-    pk_rowgemm_pack(kn.data(), K, N, wt);
-    rw.w = ar.put(wt);
-    rw.b = ar.put(bias);
-    rw.K = K;
-    rw.N = N;
+    {
+        // the row GEMM finishes the cell in its epilogue: gate columns regrouped so that a 16-column workgroup holds
+        // i | f | g | o of four units (pk_rowgemm_lstm_perm)
+        std::vector<int> perm;
+        pk_rowgemm_lstm_perm(H, perm);
+        std::vector<float> knp((size_t)K * N), bp(N), wt;
+        for (int c = 0; c < N; ++c) {
+            bp[c] = bias[perm[c]];
+            for (int k = 0; k < K; ++k) knp[(size_t)k * N + c] = kn[(size_t)k * N + perm[c]];
+        }
+        pk_rowgemm_pack(knp.data(), K, N, wt);
+        rw.w = ar.put(wt);
+        rw.b = ar.put(bp);
+        rw.K = K;
+        rw.N = N;
+    }
     return pk_fft_add_dense_kn(ar, kn, &bias, K, 1, N, d);
 }
 }  // namespace
@@ -620,8 +630,12 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     PK_TRY(pk_fft_run_dense(h, "taco_gemm_key", h->key_layer, mem, E, pkey, Da, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));   // :376
     // ---- decoder state (:352-376): zeros
     const int K1 = Pn + E + Ha, K2 = Ha + E + Hd, K3 = Hd + E;
+    // the LSTM operand rows are double buffered: a cell's GEMM reads [x | context | h(t-1)] from one buffer while its
+    // epilogue (and the attention kernel) write h(t) / context(t) for the NEXT step into the other
     PK_TRY(rows_reserve(h->d_in1, B, K1));
+    PK_TRY(rows_reserve(h->d_in1b, B, K1));
     PK_TRY(rows_reserve(h->d_in2, B, K2));
+    PK_TRY(rows_reserve(h->d_in2b, B, K2));
     PK_TRY(rows_reserve(h->d_in3, B, K3));
     PK_TRY(rows_reserve(h->d_p1, B, Pn));
     PK_TRY(rows_reserve(h->d_gates, B, 4 * std::max(Ha, Hd)));
@@ -634,7 +648,7 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     PK_TRY(h->d_logits.reserve((size_t)cap * B * sizeof(float)));
     PK_TRY(rows_reserve(h->d_pq, B, Da));
     PK_TRY(h->d_energy.reserve((size_t)tl.rows_alloc * sizeof(float)));
-    pk_dbuf* zbufs[] = {&h->d_in1, &h->d_in2, &h->d_in3, &h->d_zero, &h->d_catt, &h->d_cdec, &h->d_attw, &h->d_cum};
+    pk_dbuf* zbufs[] = {&h->d_in1, &h->d_in1b, &h->d_in2, &h->d_in2b, &h->d_in3, &h->d_zero, &h->d_catt, &h->d_cdec, &h->d_attw, &h->d_cum};
     for (pk_dbuf* z : zbufs) PK_HIP(hipMemsetAsync(z->p, 0, z->cap, ctx->stream));
     // state block: [len B][first_hit B][ndone 1]
     {
@@ -658,8 +672,8 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     }
     PK_TRY(h->d_align.reserve((size_t)align_total * sizeof(float)));
     PK_TRY(pk_upload(ctx, h->d_alignoff, h->align_off.data(), (size_t)B * sizeof(long)));
-    float* in1 = pk_fft_act_ptr(h->d_in1, K1);
-    float* in2 = pk_fft_act_ptr(h->d_in2, K2);
+    float* in1_[2] = {pk_fft_act_ptr(h->d_in1, K1), pk_fft_act_ptr(h->d_in1b, K1)};
+    float* in2_[2] = {pk_fft_act_ptr(h->d_in2, K2), pk_fft_act_ptr(h->d_in2b, K2)};
     float* in3 = pk_fft_act_ptr(h->d_in3, K3);
     float* p1 = pk_fft_act_ptr(h->d_p1, Pn);
     float* gates = pk_fft_act_ptr(h->d_gates, 4 * std::max(Ha, Hd));
@@ -675,6 +689,14 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     static const bool use_rg = getenv("PK_AR_ROWGEMM") ? atoi(getenv("PK_AR_ROWGEMM")) != 0 : true;
     float* pq = pk_fft_act_ptr(h->d_pq, Da);
     // row GEMM of one of the per-step layers (B rows)
+    // LSTMCell on the row GEMM: gates = [x | context | h] . [W_ih^T ; W_hh^T] + b, cell finished in the epilogue
+    auto rowlstm = [&](const char* name, const pk_taco::RowW& w, const float* x, int ldx, float* cstate, int H, float* h1,
+                       int ld1, float* h2, int ld2) -> int {
+        pk_rowgemm_args g;
+        g.x = x; g.ldx = ldx; g.Wt = h->W(w.w); g.bias = h->W(w.b); g.M = B; g.K = w.K; g.N = w.N;
+        g.lstm_c = cstate; g.lstm_H = H; g.lstm_h1 = h1; g.lstm_ld1 = ld1; g.lstm_h2 = h2; g.lstm_ld2 = ld2;
+        return pk_rowgemm_launch(ctx, name, g);
+    };
     auto rowgemm = [&](const char* name, const pk_taco::RowW& w, const float* x, int ldx, float* y, int ldy, int act,
                        int drop_layer, unsigned long long step) -> int {
         pk_rowgemm_args g;
@@ -690,11 +712,15 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     for (i = 0; i < cap; ++i) {
         // query = prenet(previous mel_output) (:499-500, :538); the first query is zeros (:493-497)
         const float* q = i == 0 ? zero : Y + (long)(i - 1) * B * M;
+        float* in1 = in1_[i & 1];          // this step's attention-LSTM operand rows
+        float* in1n = in1_[(i & 1) ^ 1];   // the next step's: context(t) and attention_hidden(t) go there
+        float* in2 = in2_[i & 1];
+        float* in2n = in2_[(i & 1) ^ 1];
         if (use_rg) {
             PK_TRY(rowgemm("taco_row_prenet", h->rw_pre1, q, M, p1, Pn, PK_ACT_RELU, 0, (unsigned long long)i));
             PK_TRY(rowgemm("taco_row_prenet", h->rw_pre2, p1, Pn, in1, K1, PK_ACT_RELU, 1, (unsigned long long)i));
-            // attention_rnn (:380-385) on [prenet | context | attention_hidden]
-            PK_TRY(rowgemm("taco_row_att_rnn", h->rw_att, in1, K1, gates, 4 * Ha, PK_ACT_NONE, -1, 0));
+            // attention_rnn (:380-385) on [prenet | context | attention_hidden]; h -> the two operand rows that read it
+            PK_TRY(rowlstm("taco_row_att_rnn", h->rw_att, in1, K1, h->d_catt.as<float>(), Ha, in1n + Pn + E, K1, in2, K2));
         } else {
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre1, q, M, p1, Pn, B, PK_ACT_RELU, nullptr, 0, nullptr));
             if (drop)
@@ -705,9 +731,9 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
                 PK_LAUNCH(ctx, "taco_dropout", k_ar_dropout, dim3(pk_div_up((long)B * (Pn / 4), 256)), dim3(256), 0, in1, K1, B,
                           Pn, B, (unsigned long long)i, 2, 1, d_seeds, thr, dscale);
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_att_rnn", h->att_rnn, in1, K1, gates, 4 * Ha, B, PK_ACT_NONE, nullptr, 0, nullptr));
+            PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Ha, 256)), dim3(256), 0, gates,
+                      h->d_catt.as<float>(), Ha, B, in1n + Pn + E, K1, in2, K2);
         }
-        PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Ha, 256)), dim3(256), 0, gates,
-                  h->d_catt.as<float>(), Ha, B, in1 + Pn + E, K1, in2, K2);
         // location sensitive attention (:387-397): processed query, energies of every memory row, softmax + context
         PK_TRY(rowgemm("taco_row_query", h->rw_q, in2, K2, pq, Da, PK_ACT_NONE, -1, 0));
         LsaArgs a;
@@ -719,19 +745,20 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
         a.seg_start = tl.d_seg_start(); a.seg_len = tl.d_seg_len(); a.rows = tl.rows;
         a.energy = h->d_energy.as<float>();
         a.attw = h->d_attw.as<float>(); a.cum = h->d_cum.as<float>();
-        a.ctx1 = in1 + Pn; a.ld1 = K1;
+        a.ctx1 = in1n + Pn; a.ld1 = K1;
         a.ctx2 = in2 + Ha; a.ld2 = K2;
         a.ctx3 = in3 + Hd; a.ld3 = K3;
         a.align = h->d_align.as<float>(); a.align_off = h->d_alignoff.as<long>(); a.step = i;
         PK_LAUNCH(ctx, "taco_lsa_energy", k_taco_lsa_energy, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, a);
         PK_LAUNCH(ctx, "taco_lsa_ctx", k_taco_lsa_ctx, dim3(B, pk_div_up(E, 256)), dim3(256), lsa_smem, a);
         // decoder_rnn (:399-403) on [attention_hidden | context | decoder_hidden]
-        if (use_rg)
-            PK_TRY(rowgemm("taco_row_dec_rnn", h->rw_dec, in2, K2, gates, 4 * Hd, PK_ACT_NONE, -1, 0));
-        else
+        if (use_rg) {
+            PK_TRY(rowlstm("taco_row_dec_rnn", h->rw_dec, in2, K2, h->d_cdec.as<float>(), Hd, in2n + Ha + E, K2, in3, K3));
+        } else {
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_dec_rnn", h->dec_rnn, in2, K2, gates, 4 * Hd, B, PK_ACT_NONE, nullptr, 0, nullptr));
-        PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Hd, 256)), dim3(256), 0, gates,
-                  h->d_cdec.as<float>(), Hd, B, in2 + Ha + E, K2, in3, K3);
+            PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Hd, 256)), dim3(256), 0, gates,
+                      h->d_cdec.as<float>(), Hd, B, in2n + Ha + E, K2, in3, K3);
+        }
         // linear_projection on [decoder_hidden | context] (:409-413) -> this step's mel row; stop rules (:515-528)
         if (use_rg)
             PK_TRY(rowgemm("taco_row_proj", h->rw_proj, in3, K3, Y + (long)i * B * M, M, PK_ACT_NONE, -1, 0));
@@ -858,7 +885,7 @@ extern "C" void pk_taco_destroy(pk_taco* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
     pk_dbuf* bufs[] = {&h->d_tok, &h->d_tone, &h->d_e1, &h->d_e2, &h->d_xg, &h->d_mem, &h->d_pkey, &h->d_attw, &h->d_cum,
-                       &h->d_in1, &h->d_in2, &h->d_in3, &h->d_p1, &h->d_gates, &h->d_catt, &h->d_cdec, &h->d_zero, &h->d_y, &h->d_pq, &h->d_energy,
+                       &h->d_in1, &h->d_in1b, &h->d_in2, &h->d_in2b, &h->d_in3, &h->d_p1, &h->d_gates, &h->d_catt, &h->d_cdec, &h->d_zero, &h->d_y, &h->d_pq, &h->d_energy,
                        &h->d_logits, &h->d_state, &h->d_seeds, &h->d_align, &h->d_alignoff, &h->d_before, &h->d_q1,
                        &h->d_q2, &h->d_rowmap, &h->d_stage, &h->d_stage2};
     for (auto* b : bufs) b->release();
