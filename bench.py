@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--minibatch", type=int, default=UTT_PER_GPU, help="utterances per engine call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-value extra measurements")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1: issue the next batch's acoustic model on a side stream during this batch's vocoder")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU/gloo rehearsal of the multi-process orchestration with a stub in place of the engine "
                          "(test infrastructure; prints value null)")
@@ -285,6 +287,24 @@ def main():
             out = synth(texts_all[a:b], nz) if dry else synth.synthesize_packed(texts_all[a:b], noise=nz)
         return out
 
+    # --pipeline: the acoustic model of the NEXT step's batch is issued on a side stream while this step's vocoder
+    # runs (Synthesizer.issue_acoustic / vocode_issued), so that its launches are queued before the GPU needs them.
+    # Every step still does one acoustic pass and one vocoder pass over one batch; the acoustic pass belongs to the
+    # following step's batch (all batches are the same synthetic utterances).  One mini-batch per step only.
+    pipelined = bool(args.pipeline) and not dry and len(chunks) == 1
+    pending = [None]
+
+    def step_pipelined():
+        if pending[0] is None:
+            pending[0] = synth.issue_acoustic(texts_all)
+        out = synth.vocode_issued(pending[0], noise=noise)
+        pending[0] = synth.issue_acoustic(texts_all)
+        return out
+
+    plain_step = step
+    if pipelined:
+        step = step_pipelined
+
     def barrier():
         if distributed:
             import torch.distributed as dist
@@ -310,6 +330,22 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    pipeline_check = None
+    if pipelined:
+        # back to the plain step for everything after the timed region; the pipelined waveform must be the plain one
+        step = plain_step
+        pending[0] = None
+        w_plain, _ = step()
+        sync()
+        pipeline_check = {"bit_identical_to_unpipelined": bool(torch.equal(w_plain, wav))}
+        # the same K steps without the pipeline, for the record (never `value`)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dtp = (time.perf_counter() - t1) / args.steps
+        pipeline_check["unpipelined_ms_per_step"] = dtp * 1e3
+        pipeline_check["unpipelined_samples_per_s"] = n_samples / dtp
     gather_ms = None
     if distributed:
         import torch.distributed as dist
@@ -566,6 +602,8 @@ def main():
                 "global_batch": global_batch,
                 "minibatch": mb,
                 "parallelism": f"dp{world} (utterance sharding, no data-path collective)",
+                "pipeline": ("acoustic model of the next step's batch issued on a side stream during this step's "
+                             "vocoder (one acoustic + one vocoder pass per step)") if pipelined else "none",
             },
             "roofline": dict(roof, **{
                 "kernel": {"pwg_layer": "k_pwg_layer (exact fp32 MFMA)", "pwg_layer_h3": "k_pwg_layer_b3<HALF> (3-term split-fp16 MFMA)",
@@ -585,6 +623,8 @@ def main():
             "kernel_ms_per_step": {k: ms / prof_steps for k, (_, ms) in sorted(prof.items())},
             "kernel_ms_sum": total_prof_ms,
         }
+        if pipeline_check is not None:
+            out["pipeline_check"] = pipeline_check
         if extras:
             out["extras"] = extras
         if gather_ms is not None:
