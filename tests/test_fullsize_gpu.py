@@ -130,3 +130,27 @@ def test_pwg_batch32_full_size_determinism_and_invariance():
     n2 = torch.cat([noise[:3 * 256], noise[5 * per:6 * per], noise[10 * 256:12 * 256]])
     c = gen.infer_packed(m2, [3, 640, 2], noise=n2)
     assert torch.equal(c[3 * 256:3 * 256 + per], a[5 * per:6 * per])
+
+
+def test_issue_ahead_pipeline_is_bit_identical():
+    """Synthesizer.issue_acoustic / vocode_issued: the next batch's acoustic model on a side stream during the current
+    batch's vocoder must give exactly the waveforms of synthesize_packed, for ragged batches of different shapes."""
+    synth = _models(seed=4)
+    batches = [[syn.phoneme_ids(T, seed=700 + 10 * j + i) for i, T in enumerate(lens)]
+               for j, lens in enumerate(((9, 4, 13), (6, 11), (3,), (8, 8, 2, 5)))]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    want, noises = [], []
+    for texts in batches:
+        frames = synth.am.encode_batch(texts, 1.0)
+        nz = torch.randn(int(frames.sum()) * 256, device="cuda", generator=gen)
+        wav, fr = synth.synthesize_packed(texts, noise=nz)
+        want.append((wav.clone(), [int(f) for f in fr]))
+        noises.append(nz)
+    torch.cuda.synchronize()
+    pending = synth.issue_acoustic(batches[0])
+    for j in range(len(batches)):
+        wav, fr = synth.vocode_issued(pending, noise=noises[j])
+        pending = synth.issue_acoustic(batches[j + 1]) if j + 1 < len(batches) else None
+        torch.cuda.synchronize()
+        assert [int(f) for f in fr] == want[j][1]
+        assert torch.equal(wav, want[j][0])
