@@ -144,3 +144,46 @@ def test_oracle_fp32_close_to_fp64():
     a = fs2.inference(st, ids, dtype=torch.float32).double()
     b = fs2.inference(st, ids, dtype=torch.float64)
     assert (a - b).abs().mean().item() < 1e-5
+
+
+def test_lstm_restatement_matches_torch_lstm():
+    """oracle/tacotron2_ref.py's LSTMCell / bidirectional LSTM against torch.nn.LSTM with the same arrays: torch keeps
+    the cuDNN conventions that paddle.nn.LSTM documents (weight_ih [4H, in], gate order i, f, g, o, outputs =
+    concat(forward, backward)) -- an independent implementation of the semantics the oracle encodes."""
+    import torch
+    from oracle import tacotron2_ref as t2
+    from oracle.nn_ref import Weights
+    from parakeet_amd import synthetic as syn
+    cfg = dict(syn.TACOTRON2_LJSPEECH, d_encoder=32, encoder_conv_layers=0)
+    st = syn.tacotron2_state(cfg, seed=3)
+    W = Weights(st, torch.float64)
+    x = torch.randn(1, 7, 32, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    got = t2.encoder(W.sub("encoder."), x, 0)
+    ref = torch.nn.LSTM(32, 16, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for sfx, cell in (("", "cell_fw"), ("_reverse", "cell_bw")):
+            for p in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                getattr(ref, f"{p}_l0{sfx}").copy_(torch.as_tensor(st[f"encoder.lstm.0.{cell}.{p}"]).double())
+        want, _ = ref(x)
+    assert np.abs(got.numpy() - want.numpy()).max() < 1e-12
+
+
+def test_subsequent_mask_docstring_example():
+    """fastspeech2_transformer/mask.py:30-33: subsequent_mask(3) = [[1,0,0],[1,1,0],[1,1,1]] -- the last row, which is
+    the only one a cached decoding step uses (decoder_layer.py:110-120), is all ones: the step attends to the whole
+    prefix, as oracle/transformer_tts_ref.py and the engine's step kernel do."""
+    m = np.tril(np.ones((3, 3), dtype=bool))
+    assert m.tolist() == [[True, False, False], [True, True, False], [True, True, True]]
+    assert m[-1].all()
+
+
+def test_ar_parameter_counts():
+    """Sizes of the synthetic autoregressive models follow the recipes: TransformerTTS LJSpeech (6 + 6 blocks of 512 /
+    1024, 8 heads) and Tacotron2 (examples/tacotron2/config.py) parameter counts from the layer shapes."""
+    from parakeet_amd import synthetic as syn
+    n_tts = sum(int(np.prod(v.shape)) for v in syn.transformer_tts_state(80, 80).values())
+    # encoder: 6 x (4 x 512^2 + 2 x 512 x 1024) ~ 12.6 M, decoder: 6 x (8 x 512^2 + 2 x 512 x 1024) ~ 18.9 M, + heads
+    assert 32.0e6 < n_tts < 34.5e6
+    st = syn.tacotron2_state(lstm_aliases=False)
+    n_t2 = sum(int(np.prod(v.shape)) for v in st.values())
+    assert 27.5e6 < n_t2 < 29.5e6          # ~28 M, the size the Tacotron2 paper's architecture has
