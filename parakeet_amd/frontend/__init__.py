@@ -11,6 +11,11 @@ offline.  ``LexiconG2p`` stands in for ``g2p_en.G2p`` with the same call contrac
 phones with " " between words and punctuation marks as their own tokens out -- driven by a pronunciation lexicon in
 CMUdict format that the caller provides (``lexicon=`` path; a small demonstration lexicon ships with the package),
 with letter-to-sound rules for words the lexicon lacks.
+
+Mandarin (``zh_frontend.Frontend``, zh_frontend.py:30-254 with tone_sandhi.py and zh_normalization/): the reference's
+own logic -- text normalisation, merge rules, tone sandhi, initial / final splitting, erhua, id mapping -- over ONE
+caller-supplied resource, a pinyin lexicon (``PinyinLexicon``), in place of the jieba / pypinyin / g2pM dictionaries;
+pinned against the reference source run over dictionary stand-ins (tools/make_golden_zh.py).
 """
 from .vocab import Vocab
 from .punctuation import get_punctuations
@@ -18,7 +23,10 @@ from .normalizer import normalize, normalize_numbers, full2half_width, half2full
 from .g2p import LexiconG2p, ARPABET_PHONEMES
 from .phonectic import English, EnglishCharacter, Phonetics
 from .phone_map import phones_to_ids, read_phone_id_map, text_to_ids
+from .zh_frontend import Frontend, PinyinLexicon
+from .zh_normalization import TextNormalizer
+from .tone_sandhi import ToneSandhi
 
 __all__ = ["Vocab", "get_punctuations", "normalize", "normalize_numbers", "full2half_width", "half2full_width",
            "LexiconG2p", "ARPABET_PHONEMES", "English", "EnglishCharacter", "Phonetics", "phones_to_ids",
-           "read_phone_id_map", "text_to_ids"]
+           "read_phone_id_map", "text_to_ids", "Frontend", "PinyinLexicon", "TextNormalizer", "ToneSandhi"]

@@ -1,0 +1,86 @@
+"""Mandarin frontend (parakeet_amd/frontend/zh_*.py, tone_sandhi.py, pinyin_split.py) against golden vectors produced by
+the reference's own source run over dictionary stand-ins (tools/make_golden_zh.py), and against facts stated in the
+reference's comments.  CPU only."""
+import json
+import os
+import sys
+
+import numpy as np
+
+from parakeet_amd.frontend.pinyin_split import split_syllable
+from parakeet_amd.frontend.zh_frontend import Frontend, PinyinLexicon
+from parakeet_amd.frontend.zh_normalization import TextNormalizer, num2str, verbalize_cardinal
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from zh_cases import PHONES, TONES  # noqa: E402
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zh_frontend.json"), encoding="utf-8"))
+
+
+def _frontend(tmp_path):
+    pv, tv = tmp_path / "phones.txt", tmp_path / "tones.txt"
+    pv.write_text("".join(f"{p} {i}\n" for i, p in enumerate(PHONES)))
+    tv.write_text("".join(f"{t} {i}\n" for i, t in enumerate(TONES)))
+    # the reference ran with its own neutral-tone word list; the ones the demonstration lexicon knows:
+    return Frontend(phone_vocab_path=str(pv), tone_vocab_path=str(tv), neutral_words=set(GOLD["neutral_words_used"]))
+
+
+def test_normalizer_matches_reference_source():
+    n = TextNormalizer()
+    for text, want in GOLD["normalize"].items():
+        assert n.normalize(text) == want, text
+    # facts from the reference's comments (num.py:108, 179-193, 203-224; chronology.py; quantifier.py:19)
+    assert verbalize_cardinal("000") == "零" and verbalize_cardinal("12") == "十二" and verbalize_cardinal("10086") == "一万零八十六"
+    assert num2str(".22".lstrip()) == "零点二二" and num2str("3.20") == "三点二"
+    assert n.normalize("-3°C") == ["零下三度"] and n.normalize("00078") == ["零零零七八"]
+    assert n.normalize("ＡＢ１２") == ["AB十二"]          # full-width forms are folded (the reference's tables are no-ops)
+
+
+def test_tone_sandhi_matches_reference_source(tmp_path):
+    fe = _frontend(tmp_path)
+    for word, pos, finals, want in GOLD["sandhi"]:
+        assert fe.tone_modifier.modified_tone(word, pos, list(finals)) == want, (word, pos)
+    got = {w: f for w, _, _, f in GOLD["sandhi"]}
+    # the worked examples in tone_sandhi.py's comments
+    assert got["家里"] == ["ia1", "i5"] and got["看不懂"][1] == "u5" and got["不怕"][0] == "u2"
+    assert got["一段"][0] == "i2" and got["一天"][0] == "i4" and got["第一"][1] == "i1" and got["看一看"][1] == "i5"
+    assert got["展览馆"] == ["an2", "an2", "uan3"] and got["纸老虎"] == ["iii3", "ao2", "u3"]    # 2 + 1 and 1 + 2 third tones
+    assert got["蒙古包"] == ["eng2", "u3", "ao1"] and got["所有人"][0] == "uo2" and got["你好"] == ["i2", "ao3"]
+    assert got["男子"][1] == "i3" and got["桌子"][1] == "i5"                  # must_not_neural_tone_words vs 子
+    for text, want in GOLD["merge"]:
+        seg = fe.lexicon.segment(text)
+        assert [[w, p] for w, p in fe.tone_modifier.pre_merge_for_modify(seg)] == want, text
+    # _merge_yi's docstring example (:228-231)
+    assert fe.tone_modifier._merge_yi([("听", "v"), ("一", "m"), ("听", "v")]) == [["听一听", "v"]]
+
+
+def test_frontend_matches_reference_source(tmp_path):
+    fe = _frontend(tmp_path)
+    for text, want in GOLD["phonemes"].items():
+        assert fe.get_phonemes(text) == want["merged"], text
+        assert fe.get_phonemes(text, merge_sentences=False) == want["split"], text
+        assert fe.get_phonemes(text, with_erhua=False) == want["no_erhua"], text
+    for text, want in GOLD["ids"].items():
+        ids = fe.get_input_ids(text, merge_sentences=True, get_tone_ids=True)
+        assert [a.tolist() for a in ids["phone_ids"]] == want["phone_ids"], text
+        assert [a.tolist() for a in ids["tone_ids"]] == want["tone_ids"], text
+        ids2 = fe.get_input_ids(text, merge_sentences=False)
+        assert [a.tolist() for a in ids2["phone_ids"]] == want["phone_ids_split_no_tones"], text
+        assert all(a.dtype == np.int64 for a in ids["phone_ids"] + ids["tone_ids"])
+    # erhua: 小孩儿 -> the r joins the previous final; 女儿 / 花儿 keep their own syllable (not_erhua)
+    ph = fe.get_phonemes("小孩儿在胡同儿里看花儿，女儿也去")[0]
+    assert "air2" in ph and "ongr5" in ph and ph.count("er2") == 2      # 胡同 is on the neutral-tone list: tong5 + r
+    assert "龘" in fe.missing                                   # characters the lexicon lacks are reported
+
+
+def test_pinyin_split_and_lexicon():
+    for syl, want in (("zhong1", ("zh", "ong1")), ("yuan2", ("", "van2")), ("jiu3", ("j", "iou3")), ("hui4", ("h", "uei4")),
+                      ("dun1", ("d", "uen1")), ("xue2", ("x", "ve2")), ("yi1", ("", "i1")), ("wu3", ("", "u3")),
+                      ("lv4", ("l", "v4")), ("er5", ("", "er5")), ("ma", ("m", "a5")), ("ng2", ("", "ng2")), ("，", ("，", "，"))):
+        assert split_syllable(syl) == want, syl
+    lex = PinyinLexicon(entries={"测试": (("ce4", "shi4"), "vn")})
+    assert lex.segment("测试hello 测") == [("测试", "vn"), ("hello", "eng"), ("测", "x")]
+    assert lex.cut_for_search("测试") == ["测试"] and lex.pinyin("测试") == ["ce4", "shi4"]
+    demo = PinyinLexicon()
+    assert demo.cut_for_search("蒙古包") == ["蒙古", "蒙古包"] and demo.cut_for_search("纸老虎") == ["老虎", "纸老虎"]
+    assert [w for w, _ in demo.segment("我们今天去北京")] == ["我们", "今天", "去", "北京"]

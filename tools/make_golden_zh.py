@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Golden vectors of the Mandarin frontend from the REFERENCE's own source (parakeet/frontend/zh_frontend.py,
+tone_sandhi.py, zh_normalization/) executed with stand-ins for the three dictionary packages it imports:
+``pypinyin`` / ``jieba`` are answered from parakeet_amd's demonstration lexicon (the same resource the engine-side
+frontend uses), ``g2pM`` is a dummy.  This pins the reference's own logic -- normalisation, merge rules, tone sandhi,
+erhua, "sp", id mapping -- not the dictionaries.  Build container only.  Output: tests/golden/zh_frontend.json."""
+import importlib
+import json
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_import  # noqa: E402
+
+ref_import.setup()   # the paddle stand-in (zh_frontend.py wraps its ids in paddle tensors)
+from parakeet_amd.frontend.pinyin_split import split_syllable  # noqa: E402
+from parakeet_amd.frontend.zh_frontend import PinyinLexicon  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from zh_cases import NORMALIZE, SANDHI, SENTENCES, PHONES, TONES  # noqa: E402
+
+LEX = PinyinLexicon()
+
+
+def install_stubs():
+    pp = types.ModuleType("pypinyin")
+    ppc = types.ModuleType("pypinyin.constants")
+    ppc.SUPPORT_UCS4 = True
+
+    class Style:
+        INITIALS, FINALS_TONE3 = "initials", "finals_tone3"
+
+    def lazy_pinyin(word, neutral_tone_with_five=True, style=None):
+        which = 0 if style == Style.INITIALS else 1
+        return [split_syllable(s)[which] for s in LEX.pinyin(word)]
+
+    pp.Style, pp.lazy_pinyin, pp.constants = Style, lazy_pinyin, ppc
+    jb = types.ModuleType("jieba")
+    jb.cut_for_search = LEX.cut_for_search
+    psg = types.ModuleType("jieba.posseg")
+    psg.lcut = LEX.segment
+    jb.posseg = psg
+    g2pm = types.ModuleType("g2pM")
+    g2pm.G2pM = type("G2pM", (), {})
+    for name, mod in (("pypinyin", pp), ("pypinyin.constants", ppc), ("jieba", jb), ("jieba.posseg", psg), ("g2pM", g2pm)):
+        sys.modules[name] = mod
+    for sub in ("frontend", "frontend.zh_normalization"):
+        m = types.ModuleType("parakeet." + sub)
+        m.__path__ = [os.path.join(ref_import.REF, "parakeet", *sub.split("."))]
+        sys.modules["parakeet." + sub] = m
+
+
+def main():
+    install_stubs()
+    zf = importlib.import_module("parakeet.frontend.zh_frontend")
+    ts = importlib.import_module("parakeet.frontend.tone_sandhi")
+    tn = importlib.import_module("parakeet.frontend.zh_normalization.text_normlization")
+    tmp = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(tmp, exist_ok=True)
+    pv, tv = os.path.join(tmp, "zh_phones.txt"), os.path.join(tmp, "zh_tones.txt")
+    open(pv, "wt").write("".join(f"{p} {i}\n" for i, p in enumerate(PHONES)))
+    open(tv, "wt").write("".join(f"{t} {i}\n" for i, t in enumerate(TONES)))
+    fe = zf.Frontend(phone_vocab_path=pv, tone_vocab_path=tv)
+    sandhi = ts.ToneSandhi()
+    sandhi.must_neural_tone_words = set(sandhi.must_neural_tone_words)   # the reference's own list
+    out = {"normalize": {}, "sandhi": [], "merge": [], "phonemes": {}, "ids": {}}
+    norm = tn.TextNormalizer()
+    for text in NORMALIZE:
+        out["normalize"][text] = norm.normalize(text)
+    for word, pos, finals in SANDHI:
+        out["sandhi"].append([word, pos, finals, sandhi.modified_tone(word, pos, list(finals))])
+    for text in SENTENCES:
+        seg = LEX.segment(text)
+        out["merge"].append([text, [[w, p] for w, p in sandhi.pre_merge_for_modify(seg)]])
+        out["phonemes"][text] = {"merged": fe.get_phonemes(text), "split": fe.get_phonemes(text, merge_sentences=False),
+                                 "no_erhua": fe.get_phonemes(text, with_erhua=False)}
+        ids = fe.get_input_ids(text, merge_sentences=True, get_tone_ids=True)
+        ids2 = fe.get_input_ids(text, merge_sentences=False)
+        out["ids"][text] = {"phone_ids": [t.numpy().tolist() for t in ids["phone_ids"]],
+                            "tone_ids": [t.numpy().tolist() for t in ids["tone_ids"]],
+                            "phone_ids_split_no_tones": [t.numpy().tolist() for t in ids2["phone_ids"]]}
+    out["neutral_words_used"] = sorted(w for w in sandhi.must_neural_tone_words if w in LEX.words)
+    path = os.path.join(ROOT, "tests", "golden", "zh_frontend.json")
+    json.dump(out, open(path, "wt", encoding="utf-8"), ensure_ascii=False, indent=0)
+    print("wrote", path, {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
