@@ -6,7 +6,7 @@ from .normalizer import normalize
 from .punctuation import get_punctuations
 from .vocab import Vocab
 
-__all__ = ["Phonetics", "English", "EnglishCharacter"]
+__all__ = ["Phonetics", "English", "EnglishCharacter", "ARPABET", "ARPABETWithStress"]
 
 
 class Phonetics(ABC):
@@ -75,3 +75,57 @@ class EnglishCharacter(Phonetics):
     @property
     def vocab_size(self):
         return len(self.vocab)
+
+
+_ARPABET_VOWELS = ("AA", "AE", "AH", "AO", "AW", "AY", "EH", "ER", "EY", "IH", "IY", "OW", "OY", "UW", "UH")
+
+
+class ARPABET(Phonetics):
+    """Text -> ARPAbet phones WITHOUT stress marks -> ids over a fixed 39-phone inventory + , . ? ! (arpabet.py:26-209:
+    the phonology of the reference's Tacotron2 / TransformerTTS "phone" recipes).  ``lexicon`` / ``backend`` as English."""
+    phonemes = ["AA", "AE", "AH", "AO", "AW", "AY", "B", "CH", "D", "DH", "EH", "ER", "EY", "F", "G", "HH", "IH", "IY", "JH",
+                "K", "L", "M", "N", "NG", "OW", "OY", "P", "R", "S", "SH", "T", "TH", "UW", "UH", "V", "W", "Y", "Z", "ZH"]
+    punctuations = [",", ".", "?", "!"]
+    symbols = phonemes + punctuations
+    keep_stress = False
+
+    def __init__(self, lexicon=None, backend=None):
+        self.backend = backend if backend is not None else LexiconG2p(lexicon)
+        self.vocab = Vocab(self.phonemes + self.punctuations)
+
+    def _remove_vowels(self, phone):
+        """'AH0' -> 'AH' (the reference's name for dropping the stress digit of a vowel, arpabet.py:131-132)."""
+        return phone[:-1] if phone[-1:] in "012" and phone[:-1] in _ARPABET_VOWELS else phone
+
+    def phoneticize(self, sentence, add_start_end=False):
+        phonemes = list(self.backend(sentence))
+        if not self.keep_stress:
+            phonemes = [self._remove_vowels(p) for p in phonemes]
+        if add_start_end:
+            phonemes = [self.vocab.start_symbol] + phonemes + [self.vocab.end_symbol]
+        return [p for p in phonemes if p in self.vocab.stoi]
+
+    def numericalize(self, phonemes):
+        return [self.vocab.lookup(p) for p in phonemes]
+
+    def reverse(self, ids):
+        return [self.vocab.reverse(i) for i in ids]
+
+    def __call__(self, sentence, add_start_end=False):
+        return self.numericalize(self.phoneticize(sentence, add_start_end=add_start_end))
+
+    @property
+    def vocab_size(self):
+        return len(self.vocab)    # 47 = 39 phones + 4 punctuation marks + 4 special tokens
+
+
+class ARPABETWithStress(ARPABET):
+    """The same with stress marks kept: 69 phones (arpabet.py:212-302)."""
+    phonemes = [p for base in ("AA", "AE", "AH", "AO", "AW", "AY") for p in (base + "0", base + "1", base + "2")] + \
+        ["B", "CH", "D", "DH"] + [p for base in ("EH", "ER", "EY") for p in (base + "0", base + "1", base + "2")] + \
+        ["F", "G", "HH"] + [p for base in ("IH", "IY") for p in (base + "0", base + "1", base + "2")] + \
+        ["JH", "K", "L", "M", "N", "NG"] + [p for base in ("OW", "OY") for p in (base + "0", base + "1", base + "2")] + \
+        ["P", "R", "S", "SH", "T", "TH"] + [p for base in ("UH", "UW") for p in (base + "0", base + "1", base + "2")] + \
+        ["V", "W", "Y", "Z", "ZH"]
+    symbols = phonemes + ARPABET.punctuations
+    keep_stress = True

@@ -84,3 +84,17 @@ def test_pinyin_split_and_lexicon():
     demo = PinyinLexicon()
     assert demo.cut_for_search("蒙古包") == ["蒙古", "蒙古包"] and demo.cut_for_search("纸老虎") == ["老虎", "纸老虎"]
     assert [w for w, _ in demo.segment("我们今天去北京")] == ["我们", "今天", "去", "北京"]
+
+
+def test_arpabet_phonologies_match_reference_source():
+    """ARPABET / ARPABETWithStress (arpabet.py:26-302) over the same G2P backend as the reference classes were run with."""
+    from parakeet_amd.frontend import ARPABET, ARPABETWithStress
+    for text, per_cls in GOLD["arpabet"].items():
+        for cls in (ARPABET, ARPABETWithStress):
+            want, fe = per_cls[cls.__name__], cls()
+            assert fe.phoneticize(text) == want["phones"], (text, cls.__name__)
+            assert fe.phoneticize(text, add_start_end=True) == want["phones_se"]
+            assert fe(text, add_start_end=True) == want["ids_se"] and fe.vocab_size == want["vocab_size"]
+            assert fe.reverse(fe(text)) == fe.phoneticize(text)
+    assert ARPABET().vocab_size == 47 and ARPABETWithStress().vocab_size == 77      # arpabet.py:208, :301
+    assert all(p[-1] not in "012" for p in ARPABET().phoneticize("Hello, world!"))   # stress marks dropped

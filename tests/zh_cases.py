@@ -34,3 +34,6 @@ PHONES = ["<pad>", "<unk>", "sp", "b", "p", "m", "f", "d", "t", "n", "l", "g", "
 # phones with tone digits for the no-tone-id path (speedyspeech uses separate tones; fastspeech2 baker uses toned finals)
 PHONES = PHONES[:-1] + [f + t for f in PHONES[24:-2] for t in "12345"] + ["<eos>"]
 TONES = ["<pad>", "<unk>", "0", "1", "2", "3", "4", "5"]
+
+# English ARPABET phonologies (parakeet/frontend/arpabet.py) over the demonstration CMUdict-format lexicon
+ARPABET_TEXTS = ["Hello, world! This is a test.", "The quick brown fox? Yes.", "unknownword zyx, forty two dollars"]

@@ -21,7 +21,7 @@ from parakeet_amd.frontend.pinyin_split import split_syllable  # noqa: E402
 from parakeet_amd.frontend.zh_frontend import PinyinLexicon  # noqa: E402
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from zh_cases import NORMALIZE, SANDHI, SENTENCES, PHONES, TONES  # noqa: E402
+from zh_cases import ARPABET_TEXTS, NORMALIZE, SANDHI, SENTENCES, PHONES, TONES  # noqa: E402
 
 LEX = PinyinLexicon()
 
@@ -46,9 +46,15 @@ def install_stubs():
     jb.posseg = psg
     g2pm = types.ModuleType("g2pM")
     g2pm.G2pM = type("G2pM", (), {})
-    for name, mod in (("pypinyin", pp), ("pypinyin.constants", ppc), ("jieba", jb), ("jieba.posseg", psg), ("g2pM", g2pm)):
+    from parakeet_amd.frontend.g2p import LexiconG2p
+    g2pen = types.ModuleType("g2p_en")          # the English phonologies ask g2p_en for phones: the lexicon stand-in answers
+    g2pen.G2p = LexiconG2p
+    infl = types.ModuleType("inflect")          # imported by the reference's number normaliser, unused on these inputs
+    infl.engine = lambda: None
+    for name, mod in (("pypinyin", pp), ("pypinyin.constants", ppc), ("jieba", jb), ("jieba.posseg", psg), ("g2pM", g2pm),
+                      ("g2p_en", g2pen), ("inflect", infl)):
         sys.modules[name] = mod
-    for sub in ("frontend", "frontend.zh_normalization"):
+    for sub in ("frontend", "frontend.zh_normalization", "frontend.normalizer"):
         m = types.ModuleType("parakeet." + sub)
         m.__path__ = [os.path.join(ref_import.REF, "parakeet", *sub.split("."))]
         sys.modules["parakeet." + sub] = m
@@ -83,6 +89,15 @@ def main():
         out["ids"][text] = {"phone_ids": [t.numpy().tolist() for t in ids["phone_ids"]],
                             "tone_ids": [t.numpy().tolist() for t in ids["tone_ids"]],
                             "phone_ids_split_no_tones": [t.numpy().tolist() for t in ids2["phone_ids"]]}
+    ra = importlib.import_module("parakeet.frontend.arpabet")
+    out["arpabet"] = {}
+    for text in ARPABET_TEXTS:
+        out["arpabet"][text] = {}
+        for cls in (ra.ARPABET, ra.ARPABETWithStress):
+            fe_en = cls()
+            out["arpabet"][text][cls.__name__] = {
+                "phones": fe_en.phoneticize(text), "phones_se": fe_en.phoneticize(text, add_start_end=True),
+                "ids_se": fe_en(text, add_start_end=True), "vocab_size": fe_en.vocab_size}
     out["neutral_words_used"] = sorted(w for w in sandhi.must_neural_tone_words if w in LEX.words)
     path = os.path.join(ROOT, "tests", "golden", "zh_frontend.json")
     json.dump(out, open(path, "wt", encoding="utf-8"), ensure_ascii=False, indent=0)
