@@ -4,7 +4,9 @@ of the reference's examples/transformer_tts/synthesize.py (same arguments, minus
 examples/tacotron2/synthesize.py + WaveFlow.
 
 ``--text`` holds one ``utt_id PH1 PH2 ...`` line per utterance (phones of ``--phones-dict``, as the recipe's
-``test_metadata`` carries them), or with ``--tacotron2-config`` raw sentences that go through
+``test_metadata`` carries them); with ``--raw-text`` the lines are ``utt_id sentence`` and go through
+``parakeet_amd.frontend.English`` (``--lexicon``) and the id mapping of
+examples/transformer_tts/ljspeech/synthesize_e2e.py:84-90; with ``--tacotron2-config`` raw sentences go through
 ``parakeet_amd.frontend.EnglishCharacter`` like examples/tacotron2/synthesize.py:49.
 All utterances are decoded in lockstep as ONE ragged batch and vocoded as one batch (the reference loops one by one).
 The decoder prenets keep dropout on at inference (as in the reference); ``--seed`` selects the engine's dropout stream.
@@ -34,6 +36,8 @@ def main():
     ap.add_argument("--output-dir", required=True)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-decoder-steps", type=int, default=1000)
+    ap.add_argument("--raw-text", action="store_true", help="--text holds 'utt_id sentence' lines (TransformerTTS)")
+    ap.add_argument("--lexicon", default=None, help="CMUdict-format lexicon for the English frontend")
     args = ap.parse_args()
 
     voc = checkpoint.load_waveflow(args.waveflow_config, args.waveflow_checkpoint)
@@ -53,12 +57,19 @@ def main():
         am, phone_id_map = checkpoint.load_transformer_tts(args.transformer_tts_config, args.transformer_tts_checkpoint,
                                                            args.transformer_tts_stat, args.phones_dict)
         fs = checkpoint._config(args.transformer_tts_config)["fs"]
+        frontend = None
+        if args.raw_text:
+            from parakeet_amd.frontend import English, phones_to_ids_transformer_tts
+            frontend = English(lexicon=args.lexicon)
         with open(args.text, "rt") as f:
             for line in f:
                 parts = line.strip().split()
                 if parts:
                     utt_ids.append(parts[0])
-                    batch.append([phone_id_map[p] for p in parts[1:]])
+                    if frontend is None:
+                        batch.append([phone_id_map[p] for p in parts[1:]])
+                    else:
+                        batch.append(phones_to_ids_transformer_tts(frontend.phoneticize(" ".join(parts[1:])), phone_id_map))
     wavs = ARSynthesizer(am, voc).synthesize_batch(batch, seeds=[args.seed + i for i in range(len(batch))], **kw)
     os.makedirs(args.output_dir, exist_ok=True)
     for utt_id, wav in zip(utt_ids, wavs):

@@ -7,7 +7,7 @@ tokens, and maps everything the map does not know -- and every punctuation mark 
 """
 import numpy as np
 
-__all__ = ["RECIPE_PUNC", "read_phone_id_map", "phones_to_ids", "text_to_ids"]
+__all__ = ["RECIPE_PUNC", "read_phone_id_map", "phones_to_ids", "text_to_ids", "phones_to_ids_transformer_tts"]
 
 RECIPE_PUNC = "：，；。？！“”‘’':,;.?!"     # synthesize_e2e.py:67
 
@@ -40,3 +40,14 @@ def phones_to_ids(phones, phone_id_map, punc=RECIPE_PUNC, strip_start_end=True):
 def text_to_ids(frontend, sentence, phone_id_map, punc=RECIPE_PUNC):
     """``frontend.phoneticize`` + the recipe's mapping: raw text -> int64 ids for ``FastSpeech2.inference``."""
     return phones_to_ids(frontend.phoneticize(sentence), phone_id_map, punc)
+
+
+def phones_to_ids_transformer_tts(phones, phone_id_map, strip_start_end=True):
+    """The loop body of examples/transformer_tts/ljspeech/synthesize_e2e.py:84-90: start / end symbols and whitespace
+    tokens dropped, punctuation KEPT (that recipe's vocabulary has it), anything the map lacks -> ","."""
+    if strip_start_end:
+        phones = phones[1:-1]
+    phones = [p for p in phones if not p.isspace()]
+    if "," not in phone_id_map and any(p not in phone_id_map for p in phones):
+        raise KeyError("phone_id_map has no ',' entry to map unknown phones to")
+    return np.asarray([phone_id_map[p if p in phone_id_map else ","] for p in phones], dtype=np.int64)

@@ -143,3 +143,16 @@ def test_recipe_id_mapping(tmp_path):
     assert text_to_ids(English(), "Hello,", table).tolist() == [2, 3, 4, 5, 6]
     with pytest.raises(KeyError):
         phones_to_ids(phones, {"HH": 2})
+
+
+def test_transformer_tts_recipe_id_mapping():
+    """examples/transformer_tts/ljspeech/synthesize_e2e.py:84-90: punctuation kept, unknown phones -> ','."""
+    from parakeet_amd.frontend import English, phones_to_ids_transformer_tts
+    fe = English()
+    phones = fe.phoneticize("Hello, world!")
+    table = {p: i for i, p in enumerate(["<pad>", "<unk>", ",", "!", "HH", "AH0", "L", "OW1", "W", "ER1", "D", "<eos>"])}
+    ids = phones_to_ids_transformer_tts(phones, table)
+    inner = [p for p in phones[1:-1] if not p.isspace()]
+    assert len(ids) == len(inner) and ids.dtype.kind == "i"
+    assert [table.get(p, table[","]) for p in inner] == ids.tolist()
+    assert table["!"] in ids.tolist() and table[","] in ids.tolist()          # punctuation survives
