@@ -389,7 +389,8 @@ void pk_tts_destroy(pk_tts* h);
 
 /* ---------------------------------------------------------------- Tacotron2 */
 /* Tacotron2(vocab_size, n_tones, d_mels, d_encoder, ...) -- parakeet/models/tacotron2.py:626-689.
- * Refused with PK_EUNSUPPORTED: reduction_factor != 1, d_global_condition. */
+ * Refused with PK_EUNSUPPORTED: reduction_factor != 1 (Tacotron2.infer itself cannot run it: the postnet receives the
+ * (B, T, d_mels * r) decoder output, :822-826). */
 typedef struct {
     int32_t vocab_size;
     int32_t n_tones;                 /* 0 = None */
@@ -398,7 +399,7 @@ typedef struct {
     int32_t d_prenet, d_attention_rnn, d_decoder_rnn;
     int32_t d_attention, attention_filters, attention_kernel_size;
     int32_t d_postnet, postnet_kernel_size, postnet_conv_layers;
-    int32_t d_global_condition;      /* 0 = None */
+    int32_t d_global_condition;      /* 0 = None; else a multiple of 16: the decoder's memory is d_encoder + this wide (:668-669) */
     int32_t use_stop_token;
     float p_prenet_dropout;          /* DecoderPreNet applies it with training=True (:76-79) */
 } pk_taco_cfg;
@@ -414,6 +415,10 @@ int pk_taco_set_math(pk_taco* h, int32_t mode);
  * (step * 2 + layer) * d_prenet + unit for decoding step 0, 1, ...; 0 = no dropout (not what the reference computes). */
 int pk_taco_set_dropout(pk_taco* h, int32_t on);
 int pk_taco_finalize(pk_taco* h);
+/* Global condition of the NEXT pk_taco_infer call (:816-821): g HOST float32 (B, d_global_condition), one row per
+ * utterance, concatenated to every encoder output row of that utterance.  Consumed by that call; NULL clears it.
+ * A model with d_global_condition > 0 refuses to infer without it (the reference fails on the shapes). */
+int pk_taco_set_global_condition(pk_taco* h, const float* g, int32_t B);
 /* Tacotron2.infer (:781-840) for a packed batch, up to (not including) the postnet: embedding (+ tones), encoder
  * (conv stack, bidirectional LSTM), then the attention decoder is stepped in lockstep until every utterance has
  * ended: sigmoid(stop_logit) > 0.5 with a stop token (:515-518), else the "content exhausted" rule on the argmax of

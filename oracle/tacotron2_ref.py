@@ -97,12 +97,12 @@ def postnet(W, x, n_layers):
 
 
 def infer(state, ids, cfg=None, tones=None, max_decoder_steps=1000, seed=0, drop="stream", dtype=torch.float32,
-          return_parts=False):
+          return_parts=False, global_condition=None):
     """Tacotron2.infer :781-840 for one utterance.  ids (T,) int64.  Returns a dict with mel_output (L, d_mels),
     mel_outputs_postnet (L, d_mels), alignments (L, T) and, with a stop token, stop_logits (L,)."""
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
-    if cfg.get("reduction_factor", 1) != 1 or cfg.get("d_global_condition"):
-        raise NotImplementedError("reduction_factor != 1 / global condition")
+    if cfg.get("reduction_factor", 1) != 1:
+        raise NotImplementedError("reduction_factor != 1: Tacotron2.infer cannot run it (postnet on (B, T, C * r), :822-826)")
     W = Weights(state, dtype)
     x = torch.as_tensor(np.asarray(ids)).to(torch.int64).reshape(1, -1)
     emb = W["embedding.weight"][x]                                                    # :807-808
@@ -111,6 +111,10 @@ def infer(state, ids, cfg=None, tones=None, max_decoder_steps=1000, seed=0, drop
         te = W["embedding_tones.weight"][tn]
         emb = emb + torch.where((tn == 0).unsqueeze(-1), torch.zeros_like(te), te)    # padding_idx=0 [paddle-semantics]
     key = encoder(W.sub("encoder."), emb, cfg["encoder_conv_layers"])                 # :811
+    enc_out = key
+    if global_condition is not None:                                                  # :816-821
+        g = torch.as_tensor(np.asarray(global_condition)).to(dtype).reshape(1, 1, -1)
+        key = torch.cat([key, g.expand(-1, key.shape[1], -1)], dim=-1)
     D = W.sub("decoder.")
     A = D.sub("attention_layer.")
     T = key.shape[1]
@@ -161,5 +165,5 @@ def infer(state, ids, cfg=None, tones=None, max_decoder_steps=1000, seed=0, drop
     if cfg["use_stop_token"]:
         out["stop_logits"] = torch.cat(stops, dim=1)[0]
     if return_parts:
-        out["encoder_outputs"] = key[0]
+        out["encoder_outputs"] = enc_out[0]
     return out

@@ -165,6 +165,7 @@ def _declare(lib):
         "pk_taco_set_math": (C.c_int, [vp, i32]),
         "pk_taco_set_dropout": (C.c_int, [vp, i32]),
         "pk_taco_finalize": (C.c_int, [vp]),
+        "pk_taco_set_global_condition": (C.c_int, [vp, f32p, i32]),
         "pk_taco_infer": (C.c_int, [vp, i64p, i64p, i32p, i32, i32, C.POINTER(C.c_uint64), i32, i32p]),
         "pk_taco_read": (C.c_int, [vp, f32p, f32p, f32p, f32p, i32]),
         "pk_taco_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),

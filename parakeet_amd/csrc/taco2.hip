@@ -55,6 +55,18 @@ __global__ __launch_bounds__(128) void k_taco_embed(const int* __restrict__ tok,
     }
 }
 
+// memory[r] = [encoder_outputs[r] | global_condition[utterance of r]] (:816-821), gap rows zero
+__global__ __launch_bounds__(128) void k_taco_concat_global(const float* __restrict__ enc, int E, const float* __restrict__ g,
+                                                            int G, const int* __restrict__ row_utt, float* __restrict__ mem) {
+    const long r = blockIdx.x;
+    const int b = row_utt[r];
+    for (int c = threadIdx.x; c < E + G; c += blockDim.x) {
+        float v = 0.f;
+        if (b >= 0) v = c < E ? enc[r * E + c] : g[(long)b * G + (c - E)];
+        mem[r * (E + G) + c] = v;
+    }
+}
+
 // One direction of one utterance of nn.LSTM: grid (B, 2), dir 1 walks the sequence backwards.
 //   xg   [rows][8H]: x_t W_ih^T + b_ih + b_hh for (forward | backward), gate order i, f, g, o
 //   whhT [2][H][4H]: recurrent weights, k-major (coalesced over the gate index)
@@ -332,6 +344,9 @@ struct pk_taco : pk_fft_core {
     int B = 0, cap = 0, steps = 0, maxT = 0;
     std::vector<int> T, len;
     std::vector<long> align_off;
+    std::vector<float> cond_g;   // global condition of the next infer (pk_taco_set_global_condition)
+    int cond_B = 0;
+    pk_dbuf d_gc, d_enc;
     pk_dbuf d_tok, d_tone, d_e1, d_e2, d_xg, d_mem, d_pkey, d_attw, d_cum, d_in1, d_in1b, d_in2, d_in2b, d_in3, d_p1, d_gates, d_catt,
         d_cdec, d_zero, d_y, d_pq, d_energy, d_logits, d_state, d_seeds, d_align, d_alignoff, d_before, d_q1, d_q2, d_rowmap, d_stage,
         d_stage2;
@@ -392,8 +407,11 @@ extern "C" int pk_taco_create(pk_ctx* ctx, const pk_taco_cfg* cfg, pk_taco** out
     *out = nullptr;
     const pk_taco_cfg& c = *cfg;
     if (c.vocab_size <= 0 || c.n_tones < 0 || c.d_mels <= 0) PK_FAIL(PK_EINVAL, "Tacotron2: vocab_size / d_mels must be positive");
+    // Tacotron2.infer hands the (B, T, d_mels * r) decoder output straight to the postnet (:822-826), whose first
+    // convolution has d_mels input channels: with r > 1 the reference's own inference path cannot run
     if (c.reduction_factor != 1) PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: reduction_factor != 1 not implemented");
-    if (c.d_global_condition > 0) PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: d_global_condition not implemented");
+    if (c.d_global_condition < 0 || c.d_global_condition % PK_GEMM_BK != 0)
+        PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: d_global_condition must be a multiple of 16 (or 0 = None)");
     if (c.d_encoder <= 0 || c.d_encoder % 32 != 0) PK_FAIL(PK_EUNSUPPORTED, "Tacotron2: d_encoder must be a positive multiple of 32");
     const int sizes[] = {c.d_mels, c.d_prenet, c.d_attention_rnn, c.d_decoder_rnn, c.d_postnet, c.d_attention};
     for (int s : sizes)
@@ -442,6 +460,18 @@ extern "C" int pk_taco_set_dropout(pk_taco* h, int32_t on) {
     return PK_OK;
 }
 
+extern "C" int pk_taco_set_global_condition(pk_taco* h, const float* g, int32_t B) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_taco_set_global_condition: handle is NULL");
+    h->cond_g.clear();
+    h->cond_B = 0;
+    if (!g) return PK_OK;
+    if (h->cfg.d_global_condition <= 0) PK_FAIL(PK_ESTATE, "pk_taco_set_global_condition: the model has no global condition");
+    if (B <= 0) PK_FAIL(PK_EINVAL, "pk_taco_set_global_condition: batch size must be positive");
+    h->cond_g.assign(g, g + (size_t)B * h->cfg.d_global_condition);
+    h->cond_B = B;
+    return PK_OK;
+}
+
 extern "C" int pk_taco_finalize(pk_taco* h) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_taco_finalize: handle is NULL");
     pk_ctx* ctx = h->ctx;
@@ -450,6 +480,7 @@ extern "C" int pk_taco_finalize(pk_taco* h) {
     const pk_param_map& P = h->params;
     const int E = c.d_encoder, Hh = E / 2, M = c.d_mels, Pn = c.d_prenet, Ha = c.d_attention_rnn, Hd = c.d_decoder_rnn,
               Da = c.d_attention, F = c.attention_filters, K = c.attention_kernel_size;
+    const int Eg = E + c.d_global_condition;   // width of the decoder's memory rows (:668-669)
     h->arena_h.clear();
     h->arena16_h.clear();
     pk_fft_arena ar{h->arena_h, &h->arena16_h};
@@ -491,8 +522,8 @@ extern "C" int pk_taco_finalize(pk_taco* h) {
     }
     {
         std::vector<float> w;
-        PK_TRY(pk_get_weight(P, "decoder.attention_layer.key_layer", {E, Da}, w));
-        PK_TRY(pk_fft_add_dense_kn(ar, w, nullptr, E, 1, Da, h->key_layer));
+        PK_TRY(pk_get_weight(P, "decoder.attention_layer.key_layer", {Eg, Da}, w));
+        PK_TRY(pk_fft_add_dense_kn(ar, w, nullptr, Eg, 1, Da, h->key_layer));
         PK_TRY(pk_get_weight(P, "decoder.prenet.linear1", {M, Pn}, w));
         PK_TRY(pk_fft_add_dense_kn(ar, w, nullptr, M, 1, Pn, h->pre1));
         std::vector<float> wt;
@@ -512,20 +543,20 @@ extern "C" int pk_taco_finalize(pk_taco* h) {
         PK_TRY(pk_get_weight(P, "decoder.attention_layer.location_layer", {F, Da}, w));
         h->Wloc = ar.put(w);
     }
-    PK_TRY(add_cell(ar, P, "decoder.attention_rnn", Pn + E, Ha, h->att_rnn, h->rw_att));   // input [prenet | context] (:380)
-    PK_TRY(add_cell(ar, P, "decoder.decoder_rnn", Ha + E, Hd, h->dec_rnn, h->rw_dec));     // input [attention_hidden | context] (:400-401)
-    PK_TRY(pk_fft_add_linear(ar, P, "decoder.linear_projection", Hd + E, M, h->proj));   // [decoder_hidden | context] (:409-412)
+    PK_TRY(add_cell(ar, P, "decoder.attention_rnn", Pn + Eg, Ha, h->att_rnn, h->rw_att));   // input [prenet | context] (:380)
+    PK_TRY(add_cell(ar, P, "decoder.decoder_rnn", Ha + Eg, Hd, h->dec_rnn, h->rw_dec));     // input [attention_hidden | context] (:400-401)
+    PK_TRY(pk_fft_add_linear(ar, P, "decoder.linear_projection", Hd + Eg, M, h->proj));   // [decoder_hidden | context] (:409-412)
     {
         std::vector<float> w, b;
-        PK_TRY(pk_get_weight(P, "decoder.linear_projection", {Hd + E, M}, w));
+        PK_TRY(pk_get_weight(P, "decoder.linear_projection", {Hd + Eg, M}, w));
         PK_TRY(pk_get_vector(P, "decoder.linear_projection.bias", M, b));
         std::vector<float> wt;
-        pk_rowgemm_pack(w.data(), Hd + E, M, wt);
-        h->rw_proj.w = ar.put(wt); h->rw_proj.b = ar.put(b); h->rw_proj.K = Hd + E; h->rw_proj.N = M;
+        pk_rowgemm_pack(w.data(), Hd + Eg, M, wt);
+        h->rw_proj.w = ar.put(wt); h->rw_proj.b = ar.put(b); h->rw_proj.K = Hd + Eg; h->rw_proj.N = M;
     }
     if (c.use_stop_token) {
         std::vector<float> w, b;
-        PK_TRY(pk_get_weight(P, "decoder.stop_layer", {Hd + E, 1}, w));
+        PK_TRY(pk_get_weight(P, "decoder.stop_layer", {Hd + Eg, 1}, w));
         PK_TRY(pk_get_vector(P, "decoder.stop_layer.bias", 1, b));
         h->stop_w = ar.put(w);
         h->stop_b = b[0];
@@ -557,7 +588,13 @@ int rows_reserve(pk_dbuf& buf, long rows, int C) { return pk_fft_act_reserve(buf
 extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tones, const int32_t* tok_lens, int32_t B,
                              int32_t max_decoder_steps, const uint64_t* seeds, int32_t flags, int32_t* out_frames) {
     (void)flags;
-    if (!h || !ids || !tok_lens || !out_frames) PK_FAIL(PK_EINVAL, "pk_taco_infer: NULL argument");
+    if (!h) PK_FAIL(PK_EINVAL, "pk_taco_infer: NULL argument");
+    // the per-call conditioning is consumed by this call, whatever happens next
+    std::vector<float> cond_g;
+    cond_g.swap(h->cond_g);
+    const int condB = h->cond_B;
+    h->cond_B = 0;
+    if (!ids || !tok_lens || !out_frames) PK_FAIL(PK_EINVAL, "pk_taco_infer: NULL argument");
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_taco_infer: call pk_taco_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_taco_infer: batch size must be positive");
     if (max_decoder_steps <= 0) PK_FAIL(PK_EINVAL, "pk_taco_infer: max_decoder_steps must be positive");
@@ -567,7 +604,10 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     if (c.n_tones > 0 && !tones) PK_FAIL(PK_EINVAL, "pk_taco_infer: the model has a tone embedding, tones are required (:809-810)");
     if (c.n_tones <= 0 && tones) PK_FAIL(PK_ESTATE, "pk_taco_infer: the model has no tone embedding");
     const int E = c.d_encoder, Hh = E / 2, M = c.d_mels, Pn = c.d_prenet, Ha = c.d_attention_rnn, Hd = c.d_decoder_rnn,
-              Da = c.d_attention;
+              Da = c.d_attention, G = c.d_global_condition, Eg = E + G;
+    if (G > 0 && condB != B)
+        PK_FAIL(PK_EINVAL, "pk_taco_infer: the model concatenates a global condition to the encoder outputs (:816-821): "
+                           "pk_taco_set_global_condition needs %d rows, got %d", B, condB);
     h->inferred = false;
     h->B = B;
     h->T.assign(tok_lens, tok_lens + B);
@@ -602,13 +642,15 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     PK_TRY(pk_fft_act_reserve(h->d_e1, tl.rows, E));
     PK_TRY(pk_fft_act_reserve(h->d_e2, tl.rows, E));
     PK_TRY(pk_fft_act_reserve(h->d_xg, tl.rows, 8 * Hh));
-    PK_TRY(pk_fft_act_reserve(h->d_mem, tl.rows, E));
+    PK_TRY(pk_fft_act_reserve(h->d_mem, tl.rows, Eg));
+    if (G > 0) PK_TRY(pk_fft_act_reserve(h->d_enc, tl.rows, E));
     PK_TRY(pk_fft_act_reserve(h->d_pkey, tl.rows, Da));
     PK_HIP(hipMemsetAsync(h->d_e1.p, 0, h->d_e1.cap, ctx->stream));   // margins read by the k > 1 taps
     PK_HIP(hipMemsetAsync(h->d_e2.p, 0, h->d_e2.cap, ctx->stream));
     PK_HIP(hipMemsetAsync(h->d_mem.p, 0, h->d_mem.cap, ctx->stream));
     float* cur = pk_fft_act_ptr(h->d_e1, E);
-    float* mem = pk_fft_act_ptr(h->d_mem, E);
+    float* mem = pk_fft_act_ptr(h->d_mem, Eg);
+    float* enc_out = G > 0 ? pk_fft_act_ptr(h->d_enc, E) : mem;
     PK_LAUNCH(ctx, "taco_embed", k_taco_embed, dim3(tl.rows), dim3(128), 0, h->d_tok.as<int>(),
               tones ? h->d_tone.as<int>() : (const int*)nullptr, tl.d_row_utt(), h->W(h->emb),
               c.n_tones > 0 ? h->W(h->temb) : (const float*)nullptr, E, cur);
@@ -624,12 +666,17 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     {
         const int nthreads = std::min(1024, ((4 * Hh + 63) / 64) * 64);
         PK_LAUNCH(ctx, "taco_lstm_seq", k_taco_lstm_seq, dim3(B, 2), dim3(nthreads), (size_t)6 * Hh * sizeof(float), xg,
-                  h->W(h->whhT), tl.d_seg_start(), tl.d_seg_len(), Hh, mem);
+                  h->W(h->whhT), tl.d_seg_start(), tl.d_seg_len(), Hh, enc_out);
+    }
+    if (G > 0) {
+        PK_TRY(pk_upload(ctx, h->d_gc, cond_g.data(), cond_g.size() * sizeof(float)));
+        PK_LAUNCH(ctx, "taco_concat_global", k_taco_concat_global, dim3(tl.rows), dim3(128), 0, enc_out, E, h->d_gc.as<float>(), G,
+                  tl.d_row_utt(), mem);
     }
     float* pkey = pk_fft_act_ptr(h->d_pkey, Da);
-    PK_TRY(pk_fft_run_dense(h, "taco_gemm_key", h->key_layer, mem, E, pkey, Da, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));   // :376
+    PK_TRY(pk_fft_run_dense(h, "taco_gemm_key", h->key_layer, mem, Eg, pkey, Da, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));   // :376
     // ---- decoder state (:352-376): zeros
-    const int K1 = Pn + E + Ha, K2 = Ha + E + Hd, K3 = Hd + E;
+    const int K1 = Pn + Eg + Ha, K2 = Ha + Eg + Hd, K3 = Hd + Eg;
     // the LSTM operand rows are double buffered: a cell's GEMM reads [x | context | h(t-1)] from one buffer while its
     // epilogue (and the attention kernel) write h(t) / context(t) for the NEXT step into the other
     PK_TRY(rows_reserve(h->d_in1, B, K1));
@@ -720,7 +767,7 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
             PK_TRY(rowgemm("taco_row_prenet", h->rw_pre1, q, M, p1, Pn, PK_ACT_RELU, 0, (unsigned long long)i));
             PK_TRY(rowgemm("taco_row_prenet", h->rw_pre2, p1, Pn, in1, K1, PK_ACT_RELU, 1, (unsigned long long)i));
             // attention_rnn (:380-385) on [prenet | context | attention_hidden]; h -> the two operand rows that read it
-            PK_TRY(rowlstm("taco_row_att_rnn", h->rw_att, in1, K1, h->d_catt.as<float>(), Ha, in1n + Pn + E, K1, in2, K2));
+            PK_TRY(rowlstm("taco_row_att_rnn", h->rw_att, in1, K1, h->d_catt.as<float>(), Ha, in1n + Pn + Eg, K1, in2, K2));
         } else {
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre1, q, M, p1, Pn, B, PK_ACT_RELU, nullptr, 0, nullptr));
             if (drop)
@@ -732,13 +779,13 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
                           Pn, B, (unsigned long long)i, 2, 1, d_seeds, thr, dscale);
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_att_rnn", h->att_rnn, in1, K1, gates, 4 * Ha, B, PK_ACT_NONE, nullptr, 0, nullptr));
             PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Ha, 256)), dim3(256), 0, gates,
-                      h->d_catt.as<float>(), Ha, B, in1n + Pn + E, K1, in2, K2);
+                      h->d_catt.as<float>(), Ha, B, in1n + Pn + Eg, K1, in2, K2);
         }
         // location sensitive attention (:387-397): processed query, energies of every memory row, softmax + context
         PK_TRY(rowgemm("taco_row_query", h->rw_q, in2, K2, pq, Da, PK_ACT_NONE, -1, 0));
         LsaArgs a;
         memset(&a, 0, sizeof(a));
-        a.Da = Da; a.E = E; a.F = c.attention_filters; a.K = c.attention_kernel_size;
+        a.Da = Da; a.E = Eg; a.F = c.attention_filters; a.K = c.attention_kernel_size;
         a.pq = pq; a.Wconv = h->W(h->Wconv); a.Wloc = h->W(h->Wloc); a.v = h->W(h->vvec);
         a.pkey = pkey; a.mem = mem;
         a.row_utt = tl.d_row_utt(); a.row_pos = tl.d_row_pos();
@@ -750,14 +797,14 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
         a.ctx3 = in3 + Hd; a.ld3 = K3;
         a.align = h->d_align.as<float>(); a.align_off = h->d_alignoff.as<long>(); a.step = i;
         PK_LAUNCH(ctx, "taco_lsa_energy", k_taco_lsa_energy, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, a);
-        PK_LAUNCH(ctx, "taco_lsa_ctx", k_taco_lsa_ctx, dim3(B, pk_div_up(E, 256)), dim3(256), lsa_smem, a);
+        PK_LAUNCH(ctx, "taco_lsa_ctx", k_taco_lsa_ctx, dim3(B, pk_div_up(Eg, 256)), dim3(256), lsa_smem, a);
         // decoder_rnn (:399-403) on [attention_hidden | context | decoder_hidden]
         if (use_rg) {
-            PK_TRY(rowlstm("taco_row_dec_rnn", h->rw_dec, in2, K2, h->d_cdec.as<float>(), Hd, in2n + Ha + E, K2, in3, K3));
+            PK_TRY(rowlstm("taco_row_dec_rnn", h->rw_dec, in2, K2, h->d_cdec.as<float>(), Hd, in2n + Ha + Eg, K2, in3, K3));
         } else {
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_dec_rnn", h->dec_rnn, in2, K2, gates, 4 * Hd, B, PK_ACT_NONE, nullptr, 0, nullptr));
             PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Hd, 256)), dim3(256), 0, gates,
-                      h->d_cdec.as<float>(), Hd, B, in2n + Ha + E, K2, in3, K3);
+                      h->d_cdec.as<float>(), Hd, B, in2n + Ha + Eg, K2, in3, K3);
         }
         // linear_projection on [decoder_hidden | context] (:409-413) -> this step's mel row; stop rules (:515-528)
         if (use_rg)
@@ -874,8 +921,8 @@ extern "C" int pk_taco_debug_read(pk_taco* h, int32_t what, int32_t b, float* ho
     const long n = (long)h->T[b] * E;
     if (n_floats != n) PK_FAIL(PK_ESHAPE, "pk_taco_debug_read: expected %ld floats, got %lld", n, (long long)n_floats);
     PK_HIP(hipStreamSynchronize(ctx->stream));
-    PK_HIP(hipMemcpy(host_out, pk_fft_act_ptr(h->d_mem, E) + (long)h->tl_tok.seg_start[b] * E, n * sizeof(float),
-                     hipMemcpyDeviceToHost));
+    const float* enc = h->cfg.d_global_condition > 0 ? pk_fft_act_ptr(h->d_enc, E) : pk_fft_act_ptr(h->d_mem, E);
+    PK_HIP(hipMemcpy(host_out, enc + (long)h->tl_tok.seg_start[b] * E, n * sizeof(float), hipMemcpyDeviceToHost));
     return PK_OK;
 }
 
@@ -884,7 +931,7 @@ extern "C" void pk_taco_destroy(pk_taco* h) {
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
-    pk_dbuf* bufs[] = {&h->d_tok, &h->d_tone, &h->d_e1, &h->d_e2, &h->d_xg, &h->d_mem, &h->d_pkey, &h->d_attw, &h->d_cum,
+    pk_dbuf* bufs[] = {&h->d_gc, &h->d_enc, &h->d_tok, &h->d_tone, &h->d_e1, &h->d_e2, &h->d_xg, &h->d_mem, &h->d_pkey, &h->d_attw, &h->d_cum,
                        &h->d_in1, &h->d_in1b, &h->d_in2, &h->d_in2b, &h->d_in3, &h->d_p1, &h->d_gates, &h->d_catt, &h->d_cdec, &h->d_zero, &h->d_y, &h->d_pq, &h->d_energy,
                        &h->d_logits, &h->d_state, &h->d_seeds, &h->d_align, &h->d_alignoff, &h->d_before, &h->d_q1,
                        &h->d_q2, &h->d_rowmap, &h->d_stage, &h->d_stage2};

@@ -2,8 +2,8 @@
 
 Mirrors parakeet/models/tacotron2.py: ``Tacotron2`` (constructor kwargs :626-649, ``set_state_dict``, ``eval``,
 ``infer`` :781-840 -> dict of mel_output / mel_outputs_postnet / alignments [/ stop_logits]).  All arithmetic runs in
-libpk_synth.so (csrc/taco2.hip).  Training (``forward`` / loss), the global condition and reduction_factor > 1 are out
-of scope.
+libpk_synth.so (csrc/taco2.hip).  Training (``forward`` / loss) is out of scope; reduction_factor > 1 is refused (the
+reference's ``infer`` cannot run it either: the postnet gets the (B, T, d_mels * r) decoder output, :822-826).
 
 The decoder prenet keeps dropout on at inference (:76-79, training=True); the mask comes from the engine's
 counter-based dropout stream (include/pk_synth.h), selected by ``seed=``.
@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .runtime import Context, dptr, set_params, wrap
+from .runtime import Context, dptr, set_params, to_numpy_f32, wrap
 
 
 def _ids(v):
@@ -33,6 +33,7 @@ class Tacotron2:
                  p_postnet_dropout=0.5, d_global_condition=None, use_stop_token=False, device=None):
         self.toned = n_tones is not None
         self.d_mels, self.d_encoder = d_mels, d_encoder
+        self.d_global_condition = int(d_global_condition or 0)
         self.use_stop_token = bool(use_stop_token)
         self.training = True
         self._ctx = Context.get(device)
@@ -82,10 +83,17 @@ class Tacotron2:
             _capi.check(self._ctx.lib.pk_taco_finalize(self._h))
             self._finalized = True
 
-    def infer_batch(self, texts, max_decoder_steps=1000, tones=None, seeds=None):
-        """Lists of (T_b,) ids (and tone ids) -> list of dicts like ``infer`` returns, without the batch axis."""
+    def infer_batch(self, texts, max_decoder_steps=1000, tones=None, seeds=None, global_condition=None):
+        """Lists of (T_b,) ids (and tone ids) -> list of dicts like ``infer`` returns, without the batch axis.
+        ``global_condition``: (B, d_global_condition), one row per utterance (:816-821)."""
         ctx = Context.get(self._ctx.device)
         self._finalize()
+        if global_condition is not None:
+            g = to_numpy_f32(global_condition).reshape(len(texts), -1)
+            if g.shape[1] != self.d_global_condition:
+                raise ValueError(f"global_condition has {g.shape[1]} columns, the model was built with "
+                                 f"d_global_condition={self.d_global_condition or None}")
+            _capi.check(ctx.lib.pk_taco_set_global_condition(self._h, _capi.fptr(g), g.shape[0]))
         ids = [_ids(t).reshape(-1) for t in texts]
         B = len(ids)
         lens = np.array([len(i) for i in ids], dtype=np.int32)
@@ -127,14 +135,12 @@ class Tacotron2:
     def infer(self, text_inputs, max_decoder_steps=1000, tones=None, global_condition=None, seed=0):
         """text_inputs (1, T) [or (T,)] int64 -> {"mel_output": (1, L, C), "mel_outputs_postnet": (1, L, C),
         "alignments": (1, L, T), "stop_logits": (1, L) with a stop token}; tacotron2.py:781-840."""
-        if global_condition is not None:
-            raise NotImplementedError("global_condition is not implemented")
         x = _ids(text_inputs)
         if x.ndim == 2 and x.shape[0] != 1:
             raise ValueError("infer() takes one utterance (the reference's stop test needs batch size 1, "
                              "tacotron2.py:515-521); use infer_batch for several")
         t = None if tones is None else [_ids(tones).reshape(-1)]
-        o = self.infer_batch([x.reshape(-1)], max_decoder_steps, t, [seed])[0]
+        o = self.infer_batch([x.reshape(-1)], max_decoder_steps, t, [seed], global_condition)[0]
         return {k: wrap(v.unsqueeze(0)) for k, v in o.items()}
 
     @classmethod

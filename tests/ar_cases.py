@@ -34,4 +34,6 @@ T2_CASES = [
     ("tones", dict(_T2_SMALL, n_tones=5), 8, 24, dict(stop_bias=-8.0), 10),
     # the LJSpeech recipe's sizes (examples/tacotron2/config.py:31-54)
     ("lj", dict(), 12, 25, dict(stop_bias=-8.0), 14),
+    # global condition (B, 32) concatenated to the encoder outputs (:816-821); the vector is rng(800 + seed)'s next draw
+    ("global", dict(_T2_SMALL, d_global_condition=32), 9, 26, dict(stop_bias=-8.0), 10),
 ]

@@ -173,7 +173,8 @@ def test_tacotron2_oracle_matches_reference_source():
         cfg = dict(syn.TACOTRON2_LJSPEECH, **over)
         state = syn.tacotron2_state(cfg, seed=seed, **skw)
         o = t2.infer(state, g[f"{name}_ids"], cfg, tones=g[f"{name}_tones"] if cfg["n_tones"] else None,
-                     max_decoder_steps=max_steps, seed=seed)
+                     max_decoder_steps=max_steps, seed=seed,
+                     global_condition=g[f"{name}_global_condition"] if cfg.get("d_global_condition") else None)
         for k, v in o.items():
             assert v.shape == g[f"{name}_{k}"].shape, (name, k)          # same stop decision
             tol = 2e-3 if (k == "stop_logits" and name == "stop") else 2e-5   # that head has a gain of 500

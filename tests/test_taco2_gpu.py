@@ -52,7 +52,8 @@ def test_engine_matches_reference_source(case, math):
     cfg = dict(syn.TACOTRON2_LJSPEECH, **over)
     m = _model(cfg, syn.tacotron2_state(cfg, seed=seed, **skw), math)
     o = m.infer(g[f"{name}_ids"][None, :], max_decoder_steps=max_steps,
-                tones=g[f"{name}_tones"][None, :] if cfg["n_tones"] else None, seed=seed)
+                tones=g[f"{name}_tones"][None, :] if cfg["n_tones"] else None, seed=seed,
+                global_condition=g[f"{name}_global_condition"][None, :] if cfg.get("d_global_condition") else None)
     got = {k: v.numpy()[0] for k, v in o.items()}
     ref = {k: g[f"{name}_{k}"] for k in KEYS if f"{name}_{k}" in g.files}
     _check(got, ref, name, stop_tol=0.05 if name == "stop" else 1e-3)       # that stop head has a gain of 500
@@ -102,8 +103,35 @@ def test_dropout_switch_and_errors():
     with pytest.raises(NotImplementedError):
         Tacotron2(**dict(cfg, reduction_factor=2))
     with pytest.raises(NotImplementedError):
-        Tacotron2(**dict(cfg, d_global_condition=16))
+        Tacotron2(**dict(cfg, d_global_condition=24))                        # multiples of 16 only
     with pytest.raises(ValueError):
         m.infer(np.array([1, 2, 37]))                                        # id out of range
     with pytest.raises(ValueError):
         m.infer(np.ones((2, 5), dtype=np.int64))                             # one utterance per infer() call
+
+
+def test_global_condition_ragged_batch():
+    """d_global_condition: every utterance of a ragged batch gets its own vector (:816-821); the conditioning is per
+    call -- a model built with it refuses to run without, and a second call does not reuse the first call's rows."""
+    over = dict(T2_CASES[-1][1])
+    assert over["d_global_condition"] == 32
+    cfg = dict(syn.TACOTRON2_LJSPEECH, **over)
+    state = syn.tacotron2_state(cfg, seed=31, stop_bias=-8.0)
+    m = _model(cfg, state)
+    rng = np.random.default_rng(32)
+    texts = [rng.integers(1, 37, size=n) for n in (5, 11, 3)]
+    gc = rng.standard_normal((3, 32)).astype(np.float32)
+    outs = m.infer_batch(texts, max_decoder_steps=7, seeds=[1, 2, 3], global_condition=gc)
+    for b, (t, o) in enumerate(zip(texts, outs)):
+        ref = t2.infer(state, t, cfg, max_decoder_steps=7, seed=b + 1, dtype=torch.float64, global_condition=gc[b],
+                       return_parts=True)
+        enc = ref.pop("encoder_outputs").numpy()
+        assert np.abs(m.debug_tap(0, b) - enc).max() < 1e-4                  # the tap stays d_encoder wide
+        _check({k: v.numpy() for k, v in o.items()}, {k: v.numpy() for k, v in ref.items()}, f"utt{b}")
+    with pytest.raises(ValueError):
+        m.infer_batch(texts, max_decoder_steps=7)                            # no condition for a model that needs one
+    with pytest.raises(ValueError):
+        m.infer_batch(texts, max_decoder_steps=7, global_condition=gc[:, :16])
+    plain = _model(dict(syn.TACOTRON2_LJSPEECH, **T2_CASES[2][1]), syn.tacotron2_state(dict(syn.TACOTRON2_LJSPEECH, **T2_CASES[2][1]), seed=5))
+    with pytest.raises(ValueError):
+        plain.infer(np.arange(1, 6), max_decoder_steps=3, global_condition=gc[:1])

@@ -104,16 +104,20 @@ def golden_tacotron2():
         rng = np.random.default_rng(800 + seed)
         ids = rng.integers(1, cfg["vocab_size"], size=(1, T)).astype(np.int64)
         tones = rng.integers(0, cfg["n_tones"], size=(1, T)).astype(np.int64) if cfg["n_tones"] else None
+        gc = rng.standard_normal((1, cfg["d_global_condition"])).astype(np.float32) if cfg.get("d_global_condition") else None
         PF.DROPOUT_HOOK = Tacotron2Dropout(seed, cfg["d_prenet"], cfg["p_prenet_dropout"])
         try:
             with paddle.no_grad():
                 o = model.infer(paddle.to_tensor(ids), max_decoder_steps=max_steps,
-                                tones=None if tones is None else paddle.to_tensor(tones))
+                                tones=None if tones is None else paddle.to_tensor(tones),
+                                global_condition=None if gc is None else paddle.to_tensor(gc))
         finally:
             PF.DROPOUT_HOOK = None
         out[f"{name}_ids"] = ids[0]
         if tones is not None:
             out[f"{name}_tones"] = tones[0]
+        if gc is not None:
+            out[f"{name}_global_condition"] = gc[0]
         for k in ("mel_output", "mel_outputs_postnet", "alignments", "stop_logits"):
             if k in o:
                 out[f"{name}_{k}"] = o[k].numpy()[0].astype(np.float32)
