@@ -331,8 +331,8 @@ void pk_ss_destroy(pk_ss* h);
 /* ----------------------------------------------------------- TransformerTTS */
 /* TransformerTTS(idim, odim, **model_cfg) -- parakeet/models/transformer_tts/transformer_tts.py:172-358.
  * Built: the embedding or conv-prenet encoder input layer, pre-norm blocks, the decoder prenet, the stop token,
- * the postnet.  Refused with PK_EUNSUPPORTED: post-norm / concat_after blocks, reduction_factor != 1,
- * spk_embed_dim, use_gst, dprenet_layers == 0. */
+ * the postnet, speaker embeddings ("add" / "concat").  Refused with PK_EUNSUPPORTED: post-norm / concat_after blocks,
+ * reduction_factor != 1, use_gst, dprenet_layers == 0. */
 typedef struct {
     int32_t idim, odim;
     int32_t embed_dim, eprenet_conv_layers, eprenet_conv_chans, eprenet_conv_filts;   /* layers 0: nn.Embedding(idim, adim) (:272-277) */
@@ -348,6 +348,7 @@ typedef struct {
     int32_t reduction_factor;
     int32_t spk_embed_dim;                 /* 0 = None */
     int32_t use_gst;
+    int32_t spk_embed_integration_type;    /* 0 = "add", 1 = "concat" (:313-317) */
 } pk_tts_cfg;
 typedef struct pk_tts pk_tts;
 
@@ -365,6 +366,10 @@ int pk_tts_set_math(pk_tts* h, int32_t mode);
  * 0 = no dropout (deterministic variant; not what the reference computes). */
 int pk_tts_set_dropout(pk_tts* h, int32_t on);
 int pk_tts_finalize(pk_tts* h);
+/* Speaker embeddings of the NEXT pk_tts_infer call (_integrate_with_spk_embed :725-755, applied to the encoder output
+ * :591-593): spembs HOST float32 (B, spk_embed_dim), one row per utterance.  Consumed by that call; NULL clears it.
+ * A model with spk_embed_dim > 0 refuses to infer without them (the reference fails on spemb = None). */
+int pk_tts_set_speakers(pk_tts* h, const float* spembs, int32_t B);
 /* TransformerTTS.inference (:511-647) for a packed batch, up to (not including) the postnet: <eos> = idim - 1 is
  * appended to every utterance (:563-565), the encoder runs once, then the decoder is stepped until every utterance
  * has stopped: utterance b ends at the first step s >= int(T_b * minlenratio) with sigmoid(prob_out) >= threshold

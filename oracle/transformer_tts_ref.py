@@ -1,7 +1,8 @@
 """Oracle: TransformerTTS single-utterance inference (test infrastructure).
 
 Restates, op for op, parakeet/models/transformer_tts/transformer_tts.py
-  TransformerTTS.inference                   :511-647  (no teacher forcing, no GST, no speaker embedding)
+  TransformerTTS.inference                   :511-647  (no teacher forcing, no GST)
+  TransformerTTS._integrate_with_spk_embed   :725-755
 and the modules it calls:
   Encoder.forward                            fastspeech2_transformer/encoder.py:171-192
   EncoderPrenet (tacotron2 Encoder, elayers=0) modules/tacotron2/encoder.py:150-176
@@ -40,7 +41,8 @@ from .nn_ref import Weights, batch_norm_eval, conv1d, layer_norm, linear, sinuso
 DEFAULT_CFG = dict(
     embed_dim=0, eprenet_conv_layers=0, eprenet_conv_filts=0, eprenet_conv_chans=0,
     dprenet_layers=2, dprenet_units=256, adim=512, aheads=8, elayers=6, eunits=1024, dlayers=6, dunits=1024,
-    postnet_layers=5, postnet_filts=5, postnet_chans=256, reduction_factor=1, use_scaled_pos_enc=True)
+    postnet_layers=5, postnet_filts=5, postnet_chans=256, reduction_factor=1, use_scaled_pos_enc=True,
+    spk_embed_dim=None, spk_embed_integration_type="add")
 
 PRENET_DROPOUT_P = 0.5   # F.dropout's default; Prenet.forward passes no rate (modules/tacotron2/decoder.py:80)
 
@@ -70,6 +72,15 @@ def mha(W, q_in, kv_in, n_head):
     return linear(ctx, W["linear_out.weight"], W["linear_out.bias"]), attn
 
 
+def posenc(W, x, cfg):
+    """ScaledPositionalEncoding.forward embedding.py:111-126 (x + alpha * pe) or, with use_scaled_pos_enc=False,
+    PositionalEncoding.forward :64-80 (x * sqrt(d_model) + pe)."""
+    if cfg.get("use_scaled_pos_enc", True):
+        return scaled_posenc(W, x)
+    pe = sinusoid_table(x.shape[1], x.shape[2], x.dtype)
+    return x * math.sqrt(x.shape[2]) + pe.unsqueeze(0)
+
+
 def encoder_input(W, ids, cfg):
     """The encoder's ``embed`` Sequential (transformer_tts.py:258-277, encoder.py:112-121): Embedding(padding_idx=0)
     [+ conv prenet + Linear] followed by ScaledPositionalEncoding."""
@@ -88,7 +99,7 @@ def encoder_input(W, ids, cfg):
         table = W["embed.0.weight"].clone()
         table[0] = 0.0
         x = table[ids]
-    return scaled_posenc(W.sub("embed.1."), x)
+    return posenc(W.sub("embed.1."), x, cfg)
 
 
 def encode(W, ids, cfg):
@@ -103,13 +114,29 @@ def decoder_embed(W, ys, step, cfg, drop):
     """decoder.embed = Sequential(Sequential(DecoderPrenet, Linear), ScaledPositionalEncoding) on the whole prefix
     ys (1, step, odim)."""
     x = ys
+    if cfg["dprenet_layers"] == 0:
+        # input_layer "linear" (decoder.py:112-118): Linear -> LayerNorm -> Dropout(eval: off) -> ReLU -> pos_enc
+        x = linear(x, W["embed.0.weight"], W["embed.0.bias"])
+        x = torch.relu(layer_norm(x, W["embed.1.weight"], W["embed.1.bias"]))
+        return posenc(W.sub("embed.4."), x, cfg)
     for j in range(cfg["dprenet_layers"]):
         x = torch.relu(linear(x, W[f"embed.0.0.prenet.{j}.0.weight"], W[f"embed.0.0.prenet.{j}.0.bias"]))
         if drop is not None:
             keep = torch.as_tensor(drop(step, j, x.shape[1], x.shape[2]))
             x = torch.where(keep.unsqueeze(0), x / (1.0 - PRENET_DROPOUT_P), torch.zeros_like(x))
     x = linear(x, W["embed.0.1.weight"], W["embed.0.1.bias"])
-    return scaled_posenc(W.sub("embed.1."), x)
+    return posenc(W.sub("embed.1."), x, cfg)
+
+
+def integrate_with_spk_embed(W, hs, spembs, kind):
+    """TransformerTTS._integrate_with_spk_embed :725-755.  hs (1, T, adim), spembs (1, D)."""
+    e = spembs / torch.clamp(torch.linalg.vector_norm(spembs, dim=1, keepdim=True), min=1e-12)   # F.normalize
+    if kind == "add":
+        return hs + linear(e, W["projection.weight"], W["projection.bias"]).unsqueeze(1)
+    if kind == "concat":
+        e = e.unsqueeze(1).expand(-1, hs.shape[1], -1)
+        return linear(torch.cat([hs, e], dim=-1), W["projection.weight"], W["projection.bias"])
+    raise NotImplementedError("support only add or concat.")
 
 
 def decoder_layer_step(W, tgt, memory, cache, n_head):
@@ -136,21 +163,24 @@ def decoder_layer_step(W, tgt, memory, cache, n_head):
 
 
 def inference(state, ids, cfg=None, threshold=0.5, minlenratio=0.0, maxlenratio=10.0, seed=0, drop="stream",
-              dtype=torch.float32, return_parts=False):
+              dtype=torch.float32, return_parts=False, spembs=None):
     """TransformerTTS.inference transformer_tts.py:511-647.  ids (T,) int64 without <eos>.
     Returns (outs (L, odim), probs (L,), att_ws (dlayers, aheads, L, T+1))."""
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
-    if cfg.get("reduction_factor", 1) != 1:
-        raise NotImplementedError("reduction_factor != 1")
+    r = cfg.get("reduction_factor", 1)
     W = Weights(state, dtype)
     idim = (state["encoder.embed.0.weight"] if "encoder.embed.0.weight" in state
             else state["encoder.embed.0.0.embed.weight"]).shape[0]
-    odim = state["feat_out.weight"].shape[1]
+    odim = state["feat_out.weight"].shape[1] // r
     x = np.pad(np.asarray(ids), (0, 1), "constant", constant_values=idim - 1)      # :563-565 add <eos>
     xs = torch.as_tensor(x).to(torch.int64).unsqueeze(0)
     hs = encode(W.sub("encoder."), xs, cfg)                                        # :584-585
-    maxlen = int(hs.shape[1] * maxlenratio / 1)                                    # :597-598
-    minlen = int(hs.shape[1] * minlenratio / 1)
+    enc_out = hs
+    if cfg.get("spk_embed_dim"):                                                   # :591-593
+        e = torch.as_tensor(np.asarray(spembs)).to(dtype).reshape(1, -1)
+        hs = integrate_with_spk_embed(W, hs, e, cfg["spk_embed_integration_type"])
+    maxlen = int(hs.shape[1] * maxlenratio / r)                                    # :597-598
+    minlen = int(hs.shape[1] * minlenratio / r)
     if drop == "stream":
         drop = stream_dropout(seed, cfg["dprenet_layers"], cfg["dprenet_units"])
     D = W.sub("decoder.")
@@ -171,10 +201,10 @@ def inference(state, ids, cfg=None, threshold=0.5, minlenratio=0.0, maxlenratio=
             att_step.append(a)
         cache = new_cache
         z = layer_norm(xdec[:, -1], D["after_norm.weight"], D["after_norm.bias"])  # decoder.py:220-221
-        out = linear(z, W["feat_out.weight"], W["feat_out.bias"]).reshape(1, odim)  # :613-615
+        out = linear(z, W["feat_out.weight"], W["feat_out.bias"]).reshape(r, odim)  # :613-615
         outs.append(out)
-        probs.append(torch.sigmoid(linear(z, W["prob_out.weight"], W["prob_out.bias"]))[0])   # :616
-        ys = torch.cat([ys, out.reshape(1, 1, odim)], dim=1)                       # :619-621
+        probs.append(torch.sigmoid(linear(z, W["prob_out.weight"], W["prob_out.bias"]))[0])   # :616  (r,)
+        ys = torch.cat([ys, out[-1].reshape(1, 1, odim)], dim=1)                   # :619-621: the LAST of the r frames
         att_ws.append(torch.stack(att_step, dim=0))                                # (dlayers, H, T)
         if int((probs[-1] >= threshold).sum()) > 0 or idx >= maxlen:               # :638-639
             if idx < minlen:                                                       # :641-642
@@ -188,6 +218,6 @@ def inference(state, ids, cfg=None, threshold=0.5, minlenratio=0.0, maxlenratio=
             break
     att = torch.stack(att_ws, dim=2)                                               # (dlayers, H, L, T)
     if return_parts:
-        parts.update(hs=hs[0], before=before[0].transpose(0, 1), zs=cache[-1][0])
+        parts.update(hs=hs[0], enc=enc_out[0], before=before[0].transpose(0, 1), zs=cache[-1][0])
         return mel, probs_t, att, parts
     return mel, probs_t, att

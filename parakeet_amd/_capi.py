@@ -76,7 +76,7 @@ class TtsCfg(C.Structure):
         "postnet_layers", "postnet_chans", "postnet_filts", "positionwise_layer_type",
         "positionwise_conv_kernel_size", "use_scaled_pos_enc", "use_batch_norm", "encoder_normalize_before",
         "decoder_normalize_before", "encoder_concat_after", "decoder_concat_after", "reduction_factor",
-        "spk_embed_dim", "use_gst")]
+        "spk_embed_dim", "use_gst", "spk_embed_integration_type")]
 
 
 class TacoCfg(C.Structure):
@@ -154,6 +154,7 @@ def _declare(lib):
         "pk_tts_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
         "pk_tts_set_math": (C.c_int, [vp, i32]),
         "pk_tts_set_dropout": (C.c_int, [vp, i32]),
+        "pk_tts_set_speakers": (C.c_int, [vp, f32p, i32]),
         "pk_tts_finalize": (C.c_int, [vp]),
         "pk_tts_infer": (C.c_int, [vp, i64p, i32p, i32, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_uint64), i32,
                                    i32p]),

@@ -788,6 +788,29 @@ struct Predictor {
     int chans;
 };
 
+// _integrate_with_spk_embed (fastspeech2.py:560-586, transformer_tts.py:725-755) on the rows of a timeline:
+//   "add":    hs += normalize(e_b) . W + bias
+//   "concat": hs  = hs . W[:A] + (normalize(e_b) . W[A:] + bias)      (hs_proj = the [A][A] part; tmp: A-wide rows)
+// e_b = d_spembs[b] (B x D) or table[d_spk_id[b]].
+int pk_fft_run_speaker(pk_fft_core* h, const pk_fft_timeline& tl, const long long* d_spk_id, const float* d_spembs,
+                       size_t table, size_t w, size_t bias, const pk_fft_dense* hs_proj, int D, pk_dbuf& d_vec, float* hs,
+                       float* tmp) {
+    pk_ctx* ctx = h->ctx;
+    const int A = h->adim, B = tl.B;
+    PK_TRY(d_vec.reserve((size_t)B * A * sizeof(float)));
+    PK_LAUNCH(ctx, "fft_spk_vec", k_spk_vec, dim3(B), dim3(256), (size_t)D * sizeof(float), d_spk_id, d_spembs, h->W(table),
+              h->W(w), h->W(bias), D, A, d_vec.as<float>());
+    const float* src = hs;
+    if (hs_proj) {
+        PK_TRY(pk_fft_run_dense(h, "fft_gemm_spk_proj", *hs_proj, hs, A, tmp, A, tl.rows, PK_ACT_NONE, nullptr, 0,
+                                tl.d_row_utt()));
+        src = tmp;
+    }
+    PK_LAUNCH(ctx, "fft_add_rowvec", k_add_rowvec, dim3(tl.rows), dim3(256), 0, src, d_vec.as<float>(), tl.d_row_utt(), tl.rows,
+              A, hs);
+    return PK_OK;
+}
+
 struct pk_fs2 : pk_fft_core {
     pk_fs2_cfg cfg;
     pk_param_map params;
@@ -1512,17 +1535,8 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
             PK_TRY(pk_upload(ctx, h->d_spk_id, cond_spk.data(), cond_spk.size() * sizeof(long long)));
             d_id = h->d_spk_id.as<long long>();
         }
-        PK_TRY(h->d_spk_vec.reserve((size_t)B * A * sizeof(float)));
-        PK_LAUNCH(ctx, "fs2_spk_vec", k_spk_vec, dim3(B), dim3(256), (size_t)D * sizeof(float), d_id, d_emb,
-                  h->W(h->spk_table), h->W(h->spk_w), h->W(h->spk_b), D, A, h->d_spk_vec.as<float>());
-        const float* src = hs;
-        if (c.spk_embed_integration_type == 1) {
-            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_spk_proj", h->spk_hs, hs, A, x, A, tl.rows, PK_ACT_NONE, nullptr, 0,
-                             tl.d_row_utt()));
-            src = x;
-        }
-        PK_LAUNCH(ctx, "fs2_add_rowvec", k_add_rowvec, dim3(tl.rows), dim3(256), 0, src, h->d_spk_vec.as<float>(),
-                  tl.d_row_utt(), tl.rows, A, hs);
+        PK_TRY(pk_fft_run_speaker(h, tl, d_id, d_emb, h->spk_table, h->spk_w, h->spk_b,
+                                  c.spk_embed_integration_type == 1 ? &h->spk_hs : nullptr, D, h->d_spk_vec, hs, x));
     }
     // tone embedding (:404-408)
     if (c.tone_embed_dim > 0 && !cond_tone.empty()) {

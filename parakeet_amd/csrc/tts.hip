@@ -77,6 +77,16 @@ __global__ __launch_bounds__(128) void k_tts_lookup(const int* __restrict__ tok,
     for (int c = threadIdx.x; c < E; c += blockDim.x) x[r * E + c] = valid ? e[c] : 0.f;
 }
 
+// x = relu(t) + peb: the tail of the "linear" decoder input layer (Linear -> LayerNorm -> Dropout(eval) -> ReLU ->
+// positional encoding, decoder.py:112-118); n4 float4 elements
+__global__ __launch_bounds__(256) void k_tts_relu_add(const float4* __restrict__ t, const float4* __restrict__ peb, long n4,
+                                                      float4* __restrict__ x) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = t[i], p = peb[i];
+    x[i] = make_float4(fmaxf(a.x, 0.f) + p.x, fmaxf(a.y, 0.f) + p.y, fmaxf(a.z, 0.f) + p.z, fmaxf(a.w, 0.f) + p.w);
+}
+
 // One decoding step of MultiHeadedAttention (attention.py:133-156) for ONE query row per utterance:
 //   grid (heads, B), 256 threads.  Key / value row j of utterance b is row kbase[b] + j * kstride (ld = ldkv).
 //   self-attention: K/V = the layer's projected prefix rows (position-major: kbase = b, kstride = B, n = step);
@@ -243,6 +253,8 @@ struct pk_tts : pk_fft_core {
     // weights
     size_t emb_table = 0;
     float alpha_enc = 1.f, alpha_dec = 1.f;
+    float xscale = 1.f;                // PositionalEncoding (use_scaled_pos_enc=False): x * sqrt(adim) + pe (embedding.py:78)
+    size_t dlin_ln_g = 0, dlin_ln_b = 0;   // LayerNorm of the "linear" decoder input layer (dprenet_layers == 0)
     std::vector<Dense> eprenet;
     Dense eprenet_lin;
     std::vector<pk_fft_layer> enc;
@@ -254,6 +266,11 @@ struct pk_tts : pk_fft_core {
     size_t prob_w = 0;
     float prob_b = 0.f;
     std::vector<Dense> postnet;
+    size_t spk_w = 0, spk_b = 0;      // speaker part of `projection` ([D][A]) and its bias (:313-317)
+    Dense spk_hs;                      // "concat": the [A][A] hidden-state part
+    std::vector<float> cond_emb;       // speaker embeddings of the next infer (pk_tts_set_speakers)
+    int cond_B = 0;
+    pk_dbuf d_spk_emb, d_spk_vec;
     size_t out_scale = 0, out_shift = 0;
     bool has_out_affine = false;
     std::vector<float> h_out_scale, h_out_shift;
@@ -287,12 +304,12 @@ extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: post-norm blocks not implemented");
     if (c.encoder_concat_after || c.decoder_concat_after)
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: concat_after not implemented");
-    if (!c.use_scaled_pos_enc) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: use_scaled_pos_enc=False not implemented");
-    if (c.spk_embed_dim > 0) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: speaker embeddings not implemented");
+    if (c.spk_embed_dim < 0 || c.spk_embed_dim > 8192) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: spk_embed_dim must be in [0, 8192]");
+    if (c.spk_embed_dim > 0 && c.spk_embed_integration_type != 0 && c.spk_embed_integration_type != 1)
+        PK_FAIL(PK_EUNSUPPORTED, "support only add or concat. (transformer_tts.py:753)");
     if (c.use_gst) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: global style tokens not implemented");
-    if (c.dprenet_layers <= 0)
-        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: dprenet_layers == 0 (the 'linear' decoder input layer) not implemented");
-    if (c.dprenet_units % 16 != 0 || c.dprenet_units <= 0)
+    if (c.dprenet_layers < 0) PK_FAIL(PK_EINVAL, "TransformerTTS: dprenet_layers must be >= 0");
+    if (c.dprenet_layers > 0 && (c.dprenet_units % 16 != 0 || c.dprenet_units <= 0))
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: dprenet_units must be a positive multiple of 16");
     if (c.elayers < 0 || c.dlayers <= 0) PK_FAIL(PK_EINVAL, "TransformerTTS: elayers >= 0, dlayers > 0");
     if (c.positionwise_layer_type < 0 || c.positionwise_layer_type > 2)
@@ -355,6 +372,18 @@ extern "C" int pk_tts_set_math(pk_tts* h, int32_t mode) {
     return PK_OK;
 }
 
+extern "C" int pk_tts_set_speakers(pk_tts* h, const float* spembs, int32_t B) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_set_speakers: handle is NULL");
+    h->cond_emb.clear();
+    h->cond_B = 0;
+    if (!spembs) return PK_OK;
+    if (h->cfg.spk_embed_dim <= 0) PK_FAIL(PK_ESTATE, "pk_tts_set_speakers: the model has no speaker embedding (spk_embed_dim=None)");
+    if (B <= 0) PK_FAIL(PK_EINVAL, "pk_tts_set_speakers: batch size must be positive");
+    h->cond_emb.assign(spembs, spembs + (size_t)B * h->cfg.spk_embed_dim);
+    h->cond_B = B;
+    return PK_OK;
+}
+
 extern "C" int pk_tts_set_dropout(pk_tts* h, int32_t on) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_tts_set_dropout: handle is NULL");
     h->dropout = on != 0;
@@ -362,6 +391,17 @@ extern "C" int pk_tts_set_dropout(pk_tts* h, int32_t on) {
 }
 
 namespace {
+// Linear (weight [in, out] + bias) with both multiplied by `scale`: (x . W + b) * scale as one dense layer
+int add_linear_scaled(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int K, int N, float scale, Dense& d) {
+    if (scale == 1.f) return pk_fft_add_linear(ar, P, base, K, N, d);
+    std::vector<float> w, b;
+    PK_TRY(pk_get_weight(P, base, {K, N}, w));
+    PK_TRY(pk_get_vector(P, base + ".bias", N, b));
+    for (float& v : w) v *= scale;
+    for (float& v : b) v *= scale;
+    return pk_fft_add_dense_kn(ar, w, &b, K, 1, N, d);
+}
+
 // k | v projections of one attention module fused into one [A][2A] dense layer
 int add_kv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A, Dense& d) {
     std::vector<float> wk, wv, bk, bv, kn((size_t)A * 2 * A), bias(2 * A);
@@ -434,6 +474,9 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
     h->arena16_h.clear();
     pk_fft_arena ar{h->arena_h, &h->arena16_h};
     std::vector<float> al;
+    // ScaledPositionalEncoding: x + alpha * pe; PositionalEncoding: x * sqrt(adim) + pe (embedding.py:78,125).  The
+    // scale is folded into the Linear that produces x (or applied by the embedding lookup)
+    h->xscale = c.use_scaled_pos_enc ? 1.f : std::sqrt((float)A);
     // encoder input layer (:258-277)
     if (c.eprenet_conv_layers > 0) {
         std::vector<float> t;
@@ -446,25 +489,64 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
             PK_TRY(pk_fft_add_conv_bn(ar, P, p + ".0", p + ".1", c.eprenet_conv_chans,
                                       i == 0 ? c.embed_dim : c.eprenet_conv_chans, c.eprenet_conv_filts, h->eprenet[i]));
         }
-        PK_TRY(pk_fft_add_linear(ar, P, "encoder.embed.0.1", c.eprenet_conv_chans, A, h->eprenet_lin));
+        PK_TRY(add_linear_scaled(ar, P, "encoder.embed.0.1", c.eprenet_conv_chans, A, h->xscale, h->eprenet_lin));
     } else {
         std::vector<float> t;
         PK_TRY(pk_get_weight(P, "encoder.embed.0", {c.idim, A}, t));
         for (int i = 0; i < A; ++i) t[i] = 0.f;
         h->emb_table = ar.put(t);
     }
-    PK_TRY(pk_get_vector(P, "encoder.embed.1.alpha", 1, al));
-    h->alpha_enc = al[0];
+    h->alpha_enc = 1.f;
+    if (c.use_scaled_pos_enc) {
+        PK_TRY(pk_get_vector(P, "encoder.embed.1.alpha", 1, al));
+        h->alpha_enc = al[0];
+    }
     PK_TRY(pk_fft_add_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size,
                             c.positionwise_layer_type, c.aheads, h->enc, h->enc_after_g, h->enc_after_b));
+    if (c.spk_embed_dim > 0) {
+        // `projection` (:313-317): Linear(D, adim) for "add", Linear(adim + D, adim) on concat([hs, e]) for "concat"
+        const int D = c.spk_embed_dim;
+        std::vector<float> w, b;
+        PK_TRY(pk_get_vector(P, "projection.bias", A, b));
+        h->spk_b = ar.put(b);
+        if (c.spk_embed_integration_type == 0) {
+            PK_TRY(pk_get_weight(P, "projection", {D, A}, w));
+            h->spk_w = ar.put(w);
+        } else {
+            PK_TRY(pk_get_weight(P, "projection", {A + D, A}, w));
+            std::vector<float> whs(w.begin(), w.begin() + (size_t)A * A), wsp(w.begin() + (size_t)A * A, w.end());
+            PK_TRY(pk_fft_add_dense_kn(ar, whs, nullptr, A, 1, A, h->spk_hs));
+            h->spk_w = ar.put(wsp);
+        }
+    }
     // decoder input layer: Sequential(Sequential(Prenet, Linear), ScaledPositionalEncoding) (:311-321, decoder.py:124-127)
     h->dprenet.resize(c.dprenet_layers);
     for (int j = 0; j < c.dprenet_layers; ++j)
         PK_TRY(pk_fft_add_linear(ar, P, "decoder.embed.0.0.prenet." + std::to_string(j) + ".0",
                                  j == 0 ? c.odim : c.dprenet_units, c.dprenet_units, h->dprenet[j]));
-    PK_TRY(pk_fft_add_linear(ar, P, "decoder.embed.0.1", c.dprenet_units, A, h->dlin));
-    PK_TRY(pk_get_vector(P, "decoder.embed.1.alpha", 1, al));
-    h->alpha_dec = al[0];
+    h->alpha_dec = 1.f;
+    if (c.dprenet_layers > 0) {
+        PK_TRY(add_linear_scaled(ar, P, "decoder.embed.0.1", c.dprenet_units, A, h->xscale, h->dlin));
+        if (c.use_scaled_pos_enc) {
+            PK_TRY(pk_get_vector(P, "decoder.embed.1.alpha", 1, al));
+            h->alpha_dec = al[0];
+        }
+    } else {
+        // input_layer "linear" (decoder.py:112-118): Sequential(Linear(odim, adim), LayerNorm, Dropout, ReLU, pos_enc);
+        // relu(s y) = s relu(y) for s > 0: the sqrt(adim) of PositionalEncoding goes into the LayerNorm's affine
+        PK_TRY(pk_fft_add_linear(ar, P, "decoder.embed.0", c.odim, A, h->dlin));
+        std::vector<float> g, b;
+        PK_TRY(pk_get_vector(P, "decoder.embed.1.weight", A, g));
+        PK_TRY(pk_get_vector(P, "decoder.embed.1.bias", A, b));
+        for (float& v : g) v *= h->xscale;
+        for (float& v : b) v *= h->xscale;
+        h->dlin_ln_g = ar.put(g);
+        h->dlin_ln_b = ar.put(b);
+        if (c.use_scaled_pos_enc) {
+            PK_TRY(pk_get_vector(P, "decoder.embed.4.alpha", 1, al));
+            h->alpha_dec = al[0];
+        }
+    }
     h->dec.resize(c.dlayers);
     for (int l = 0; l < c.dlayers; ++l) {
         const std::string p = "decoder.decoders." + std::to_string(l);
@@ -533,7 +615,7 @@ int attn_step(pk_tts* h, const char* name, const AttnStep& a, int heads, int B, 
     return PK_OK;
 }
 
-int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B) {
+int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B, const std::vector<float>& spembs) {
     pk_ctx* ctx = h->ctx;
     const pk_tts_cfg& c = h->cfg;
     const int A = c.adim;
@@ -583,9 +665,15 @@ int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B) {
         PK_TRY(pk_fft_run_dense(h, "tts_gemm_eprenet_lin", h->eprenet_lin, cur, ldin, x, A, tl.rows, PK_ACT_NONE, tpe, A,
                                 tl.d_row_utt()));
     } else {
-        PK_TRY(pk_fft_embed(h, "tts_embed", h->d_tok.as<int>(), tl, h->emb_table, h->alpha_enc, 1.f, x));
+        PK_TRY(pk_fft_embed(h, "tts_embed", h->d_tok.as<int>(), tl, h->emb_table, h->alpha_enc, h->xscale, x));
     }
     PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    if (c.spk_embed_dim > 0) {
+        // hs = _integrate_with_spk_embed(hs, spembs) (:591-593, :725-755); the residual stream x is free by now
+        PK_TRY(pk_upload(ctx, h->d_spk_emb, spembs.data(), spembs.size() * sizeof(float)));
+        PK_TRY(pk_fft_run_speaker(h, tl, nullptr, h->d_spk_emb.as<float>(), 0, h->spk_w, h->spk_b,
+                                  c.spk_embed_integration_type == 1 ? &h->spk_hs : nullptr, c.spk_embed_dim, h->d_spk_vec, hs, x));
+    }
     // encoder-decoder attention: K | V of the memory, once per decoder layer
     for (int l = 0; l < c.dlayers; ++l) {
         PK_TRY(pk_fft_act_reserve(h->d_mkv_l[l], tl.rows, 2 * A));
@@ -599,14 +687,23 @@ int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B) {
 extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int32_t B, double threshold,
                             double minlenratio, double maxlenratio, const uint64_t* seeds, int32_t flags,
                             int32_t* out_frames) {
-    if (!h || !ids || !tok_lens || !out_frames) PK_FAIL(PK_EINVAL, "pk_tts_infer: NULL argument");
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_infer: NULL argument");
+    // the per-call conditioning is consumed by this call, whatever happens next
+    std::vector<float> spembs;
+    spembs.swap(h->cond_emb);
+    const int condB = h->cond_B;
+    h->cond_B = 0;
+    if (!ids || !tok_lens || !out_frames) PK_FAIL(PK_EINVAL, "pk_tts_infer: NULL argument");
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_tts_infer: call pk_tts_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_tts_infer: batch size must be positive");
+    if (h->cfg.spk_embed_dim > 0 && condB != B)
+        PK_FAIL(PK_EINVAL, "pk_tts_infer: the model integrates a speaker embedding into the encoder output (:591-593): "
+                           "pk_tts_set_speakers needs %d rows, got %d", B, condB);
     if (!(minlenratio >= 0.0) || !(maxlenratio >= 0.0)) PK_FAIL(PK_EINVAL, "pk_tts_infer: length ratios must be >= 0");
     pk_ctx* ctx = h->ctx;
     PK_DEVICE(ctx->device);
     const pk_tts_cfg& c = h->cfg;
-    const int A = c.adim, H = c.aheads, dk = A / H, O = c.odim, U = c.dprenet_units, J = c.dprenet_layers;
+    const int A = c.adim, H = c.aheads, dk = A / H, O = c.odim, J = c.dprenet_layers, U = J > 0 ? c.dprenet_units : 16;
     h->inferred = false;
     h->B = B;
     h->keep_att = (flags & PK_TTS_KEEP_ATT) != 0;
@@ -627,7 +724,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     const long rowsCap = (long)Lcap * B;
     if (rowsCap + B + SLACK > 0x3fffffff) PK_FAIL(PK_EUNSUPPORTED, "pk_tts_infer: %ld decoder rows", rowsCap);
     PK_TRY(pk_fft_ensure_pe(h, std::max(maxT, Lcap)));
-    PK_TRY(encode(h, ids, tok_lens, B));
+    PK_TRY(encode(h, ids, tok_lens, B, spembs));
     const Timeline& tlk = h->tl_tok;
     // ---- decoder state
     PK_TRY(rows_reserve(h->d_y, rowsCap + B, O));
@@ -732,7 +829,15 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             in = o;
             ldin = U;
         }
-        PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, PEB, A, nullptr));
+        if (J > 0) {
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, PEB, A, nullptr));
+        } else {
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, nullptr, 0, nullptr));
+            PK_TRY(pk_fft_layernorm_rows(h, X0, h->dlin_ln_g, h->dlin_ln_b, valid, R, A, Tn, nullptr));
+            const long n4 = (long)R * (A / 4);
+            PK_LAUNCH(ctx, "tts_relu_pe", k_tts_relu_add, dim3(pk_div_up(n4, 256)), dim3(256), 0,
+                      reinterpret_cast<const float4*>(Tn), reinterpret_cast<const float4*>(PEB), n4, reinterpret_cast<float4*>(X0));
+        }
         // layer 0: norm1 and q | k | v of every prefix row
         PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
         PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, Tn, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
@@ -922,7 +1027,7 @@ extern "C" void pk_tts_destroy(pk_tts* h) {
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
-    pk_dbuf* bufs[] = {&h->d_tok, &h->d_e1, &h->d_e2, &h->d_tpe, &h->d_hs, &h->d_valid, &h->d_y, &h->d_p0, &h->d_p1,
+    pk_dbuf* bufs[] = {&h->d_spk_emb, &h->d_spk_vec, &h->d_tok, &h->d_e1, &h->d_e2, &h->d_tpe, &h->d_hs, &h->d_valid, &h->d_y, &h->d_p0, &h->d_p1,
                        &h->d_x0, &h->d_t, &h->d_ham, &h->d_peb, &h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rf, &h->d_rz,
                        &h->d_probs, &h->d_state, &h->d_seeds, &h->d_att, &h->d_attoff, &h->d_before, &h->d_q1, &h->d_q2,
                        &h->d_rowmap, &h->d_stage, &h->d_stage2};

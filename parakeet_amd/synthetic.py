@@ -380,7 +380,9 @@ def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, 
         emb = _xavier(rng, (idim, A))
         emb[0] = 0.0
         st["encoder.embed.0.weight"] = emb
-    st["encoder.embed.1.alpha"] = np.array(cfg["init_enc_alpha"], dtype=np.float32)
+    scaled = cfg.get("use_scaled_pos_enc", True)   # PositionalEncoding has no alpha parameter (embedding.py:44-62)
+    if scaled:
+        st["encoder.embed.1.alpha"] = np.array(cfg["init_enc_alpha"], dtype=np.float32)
     k = cfg["positionwise_conv_kernel_size"]
     kind = cfg.get("positionwise_layer_type", "conv1d")
     for i in range(cfg["elayers"]):
@@ -397,8 +399,15 @@ def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, 
     P = cfg["dprenet_units"]
     for j in range(cfg["dprenet_layers"]):
         lin(f"decoder.embed.0.0.prenet.{j}.0", odim if j == 0 else P, P)
-    lin("decoder.embed.0.1", P, A)
-    st["decoder.embed.1.alpha"] = np.array(cfg["init_dec_alpha"], dtype=np.float32)
+    if cfg["dprenet_layers"] > 0:
+        lin("decoder.embed.0.1", P, A)
+        pos = "decoder.embed.1"
+    else:   # input_layer "linear": Sequential(Linear, LayerNorm, Dropout, ReLU, pos_enc) (decoder.py:112-118)
+        lin("decoder.embed.0", odim, A)
+        ln("decoder.embed.1", A)
+        pos = "decoder.embed.4"
+    if scaled:
+        st[pos + ".alpha"] = np.array(cfg["init_dec_alpha"], dtype=np.float32)
     for i in range(cfg["dlayers"]):
         p = f"decoder.decoders.{i}"
         mha(p + ".self_attn")
@@ -419,6 +428,9 @@ def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, 
         cout = odim if j == n - 1 else ch
         st[f"postnet.postnet.{j}.0.weight"] = _xavier(rng, (cout, cin, kf))
         bn(f"postnet.postnet.{j}.1", cout)
+    D = cfg.get("spk_embed_dim")
+    if D:   # :313-317
+        lin("projection", D if cfg.get("spk_embed_integration_type", "add") == "add" else A + D, A)
     return st
 
 

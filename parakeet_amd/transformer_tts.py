@@ -3,7 +3,7 @@
 Mirrors parakeet/models/transformer_tts/transformer_tts.py: ``TransformerTTS`` (constructor kwargs :172-250,
 ``set_state_dict``, ``eval``, ``inference`` :511-647 -> (outs, probs, att_ws)) and ``TransformerTTSInference``
 (:757-767).  All arithmetic runs in libpk_synth.so (csrc/tts.hip on the shared transformer machinery of csrc/fs2.hip).
-Training (``forward`` / loss), teacher forcing, GST and speaker embeddings are out of scope.
+Training (``forward`` / loss), teacher forcing and GST are out of scope.
 
 The reference's decoder prenet keeps dropout on at inference (modules/tacotron2/decoder.py:78-81), so its output
 depends on Paddle's random generator.  Here the mask comes from the engine's counter-based dropout stream
@@ -50,6 +50,9 @@ class TransformerTTS:
         self.padding_idx = 0
         self.training = True
         self._adim, self._aheads, self._dlayers = adim, aheads, dlayers
+        self.spk_embed_dim = spk_embed_dim
+        if spk_embed_dim is not None and spk_embed_integration_type not in ("add", "concat"):
+            raise NotImplementedError("support only add or concat.")   # transformer_tts.py:753
         self._ctx = Context.get(device)
         cfg = _capi.TtsCfg()
         cfg.idim, cfg.odim = idim, odim
@@ -70,6 +73,7 @@ class TransformerTTS:
         cfg.reduction_factor = reduction_factor
         cfg.spk_embed_dim = 0 if spk_embed_dim is None else int(spk_embed_dim)
         cfg.use_gst = 1 if use_gst else 0
+        cfg.spk_embed_integration_type = 1 if spk_embed_integration_type == "concat" else 0
         h = C.c_void_p()
         _capi.check(self._ctx.lib.pk_tts_create(self._ctx.handle, C.byref(cfg), C.byref(h)))
         self._h = h
@@ -116,11 +120,17 @@ class TransformerTTS:
             self._finalized = True
 
     def inference_batch(self, texts, threshold=0.5, minlenratio=0.0, maxlenratio=10.0, seeds=None,
-                        return_att=True, denormalize=False):
+                        return_att=True, denormalize=False, spembs=None):
         """Lists of (T_b,) token ids (without <eos>) -> list of (outs (L_b, odim), probs (L_b,),
-        att_ws (dlayers, aheads, L_b, T_b + 1) or None) device tensors."""
+        att_ws (dlayers, aheads, L_b, T_b + 1) or None) device tensors.  ``spembs``: (B, spk_embed_dim), one speaker
+        embedding per utterance, for a model built with ``spk_embed_dim``."""
         ctx = Context.get(self._ctx.device)
         self._finalize()
+        if spembs is not None:
+            e = to_numpy_f32(spembs).reshape(len(texts), -1)
+            if e.shape[1] != (self.spk_embed_dim or 0):
+                raise ValueError(f"spembs has {e.shape[1]} columns, the model was built with spk_embed_dim={self.spk_embed_dim}")
+            _capi.check(ctx.lib.pk_tts_set_speakers(self._h, _capi.fptr(e), e.shape[0]))
         ids = [_ids(t) for t in texts]
         B = len(ids)
         lens = np.array([len(i) for i in ids], dtype=np.int32)
@@ -162,9 +172,9 @@ class TransformerTTS:
         """(T,) int64 -> (outs (L, odim), probs (L,), att_ws (#layers, #heads, L, T + 1)); transformer_tts.py:511-647."""
         if use_teacher_forcing:
             raise NotImplementedError("teacher forcing needs the training graph (transformer_tts.py:568-582)")
-        if spembs is not None:
-            raise NotImplementedError("speaker embeddings are not implemented")
-        return self.inference_batch([text], threshold, minlenratio, maxlenratio, [seed], True, denormalize)[0]
+        # ``speech`` feeds teacher forcing and the style encoder only (:552-582); both are refused above / at construction
+        return self.inference_batch([text], threshold, minlenratio, maxlenratio, [seed], True, denormalize,
+                                    None if spembs is None else to_numpy_f32(spembs).reshape(1, -1))[0]
 
     def debug_tap(self, what, b):
         """0: encoder output (T_b + 1, adim); 1: outs before the postnet (L_b, odim); 2: last decoder layer (L_b, adim)."""

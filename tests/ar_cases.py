@@ -16,6 +16,21 @@ TTS_CASES = [
     ("eprenet", dict(elayers=1, dlayers=2, postnet_layers=2, embed_dim=128, eprenet_conv_layers=2, eprenet_conv_filts=5,
                      eprenet_conv_chans=64, adim=256, aheads=4, eunits=512, dunits=512, dprenet_units=128,
                      positionwise_conv_kernel_size=3), 30, 8, 14, dict(stop_bias=-6.0), dict(maxlenratio=1.0)),
+    # speaker embedding added to / concatenated with the encoder output (_integrate_with_spk_embed :725-755); the
+    # embedding is standard_normal(spk_embed_dim) of rng(900 + seed)
+    ("spk_add", dict(elayers=1, dlayers=2, postnet_layers=2, spk_embed_dim=48, spk_embed_integration_type="add"), 40, 7, 15,
+     dict(stop_bias=-6.0), dict(maxlenratio=1.0)),
+    ("spk_concat", dict(elayers=1, dlayers=1, postnet_layers=0, spk_embed_dim=64, spk_embed_integration_type="concat"), 40, 5,
+     16, dict(stop_bias=-6.0), dict(maxlenratio=1.5)),
+    # PositionalEncoding instead of ScaledPositionalEncoding (x * sqrt(adim) + pe), embedding and conv-prenet encoders
+    ("unscaled", dict(elayers=1, dlayers=2, postnet_layers=2, use_scaled_pos_enc=False), 40, 6, 17, dict(stop_bias=-6.0),
+     dict(maxlenratio=1.0)),
+    ("unscaled_eprenet", dict(elayers=1, dlayers=1, postnet_layers=0, embed_dim=64, eprenet_conv_layers=1, eprenet_conv_filts=3,
+                              eprenet_conv_chans=64, adim=256, aheads=4, eunits=256, dunits=256, dprenet_units=64,
+                              use_scaled_pos_enc=False), 30, 5, 18, dict(stop_bias=-6.0), dict(maxlenratio=1.0)),
+    # dprenet_layers = 0: the "linear" decoder input layer (Linear -> LayerNorm -> ReLU -> pos_enc, no dropout at all)
+    ("linear_in", dict(elayers=1, dlayers=2, postnet_layers=2, dprenet_layers=0), 40, 6, 19, dict(stop_bias=-6.0),
+     dict(maxlenratio=1.5)),
 ]
 
 # Tacotron2: name, config overrides on synthetic.TACOTRON2_LJSPEECH, tokens, seed (weights, ids = 800 + seed, dropout

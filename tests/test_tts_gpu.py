@@ -39,7 +39,8 @@ def test_engine_matches_reference_source(case, math):
     g = np.load(os.path.join(GOLD, "transformer_tts.npz"))
     cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, **over)
     m = _model(cfg, idim, syn.transformer_tts_state(idim, 80, cfg, seed=seed, **skw), math)
-    mel, probs, att = m.inference(g[f"{name}_ids"], seed=seed, **kw)
+    mel, probs, att = m.inference(g[f"{name}_ids"], seed=seed,
+                                  spembs=g[f"{name}_spemb"] if cfg.get("spk_embed_dim") else None, **kw)
     assert mel.shape == g[f"{name}_mel"].shape                      # same stop decision
     assert _close(mel.numpy(), g[f"{name}_mel"])                    # mel L1 bar of the north star
     assert np.abs(probs.numpy() - g[f"{name}_probs"]).max() < 1e-4
@@ -110,6 +111,33 @@ def test_dropout_switch_normalizer_and_errors():
     with pytest.raises(NotImplementedError):
         TransformerTTS(idim=40, odim=80, **dict(cfg, reduction_factor=2))
     with pytest.raises(NotImplementedError):
-        TransformerTTS(idim=40, odim=80, **dict(cfg, spk_embed_dim=64))
+        TransformerTTS(idim=40, odim=80, **dict(cfg, use_gst=True))
+    with pytest.raises(NotImplementedError):
+        TransformerTTS(idim=40, odim=80, **dict(cfg, spk_embed_dim=64, spk_embed_integration_type="mul"))
     with pytest.raises(ValueError):
         m.inference(np.array([1, 2, 40]))                                        # id out of range
+
+
+def test_speaker_embeddings_ragged_batch():
+    """One speaker embedding per utterance of a ragged batch ("concat": a dense layer on the encoder rows plus a
+    per-utterance vector); the conditioning is per call -- a model built with spk_embed_dim refuses to run without."""
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=1, postnet_layers=2, spk_embed_dim=32,
+               spk_embed_integration_type="concat")
+    state = syn.transformer_tts_state(40, 80, cfg, seed=41, stop_bias=-6.0)
+    m = _model(cfg, 40, state)
+    rng = np.random.default_rng(42)
+    texts = [syn.phoneme_ids(T, idim=40, seed=400 + T) for T in (5, 2, 7)]
+    emb = rng.standard_normal((3, 32)).astype(np.float32)
+    outs = m.inference_batch(texts, maxlenratio=1.0, seeds=[1, 2, 3], spembs=emb)
+    for b, (t, (mel, probs, att)) in enumerate(zip(texts, outs)):
+        ref, rprobs, ratt, parts = tt.inference(state, t, cfg, maxlenratio=1.0, seed=b + 1, dtype=torch.float64,
+                                                spembs=emb[b], return_parts=True)
+        assert np.abs(m.debug_tap(0, b) - parts["hs"].numpy()).max() < 1e-4      # encoder output after the integration
+        assert _close(mel.numpy(), ref.numpy())
+        assert np.abs(att.numpy() - ratt.numpy()).max() < 1e-4
+    with pytest.raises(ValueError):
+        m.inference_batch(texts, maxlenratio=1.0)
+    with pytest.raises(ValueError):
+        m.inference_batch(texts, maxlenratio=1.0, spembs=emb[:, :16])
+    one = m.inference(texts[1], spembs=emb[1], maxlenratio=1.0, seed=2)
+    assert np.abs(one[0].numpy() - outs[1][0].numpy()).max() < 1e-5

@@ -60,10 +60,15 @@ def golden_transformer_tts():
         model.set_state_dict(state)
         model.eval()
         ids = syn.phoneme_ids(T, idim=idim, seed=700 + seed)
-        PF.DROPOUT_HOOK = TransformerTTSDropout(seed=seed, n_layers=cfg["dprenet_layers"], units=cfg["dprenet_units"])
+        spemb = None
+        if cfg.get("spk_embed_dim"):
+            spemb = np.random.default_rng(900 + seed).standard_normal(cfg["spk_embed_dim"]).astype(np.float32)
+            out[f"{name}_spemb"] = spemb
+        PF.DROPOUT_HOOK = TransformerTTSDropout(seed=seed, n_layers=max(cfg["dprenet_layers"], 1), units=cfg["dprenet_units"])
         try:
             with paddle.no_grad():
-                mel, probs, att = model.inference(paddle.to_tensor(ids), **kw)
+                mel, probs, att = model.inference(paddle.to_tensor(ids), spembs=None if spemb is None else paddle.to_tensor(spemb),
+                                                  **kw)
         finally:
             PF.DROPOUT_HOOK = None
         out[f"{name}_ids"] = ids
