@@ -331,8 +331,8 @@ void pk_ss_destroy(pk_ss* h);
 /* ----------------------------------------------------------- TransformerTTS */
 /* TransformerTTS(idim, odim, **model_cfg) -- parakeet/models/transformer_tts/transformer_tts.py:172-358.
  * Built: the embedding or conv-prenet encoder input layer, pre-norm blocks, the decoder prenet, the stop token,
- * the postnet, speaker embeddings ("add" / "concat").  Refused with PK_EUNSUPPORTED: post-norm / concat_after blocks,
- * reduction_factor != 1, use_gst, dprenet_layers == 0. */
+ * the postnet, speaker embeddings ("add" / "concat"), both positional encodings, the "linear" decoder input layer
+ * (dprenet_layers == 0), reduction_factor >= 1.  Refused with PK_EUNSUPPORTED: post-norm / concat_after blocks, use_gst. */
 typedef struct {
     int32_t idim, odim;
     int32_t embed_dim, eprenet_conv_layers, eprenet_conv_chans, eprenet_conv_filts;   /* layers 0: nn.Embedding(idim, adim) (:272-277) */
@@ -376,19 +376,19 @@ int pk_tts_set_speakers(pk_tts* h, const float* spembs, int32_t B);
  * or s >= int(T_b * maxlenratio), T_b counting <eos> (:597-598, :638-642).
  *   ids      HOST int64, packed by utterance, WITHOUT <eos>;  tok_lens HOST (B)
  *   seeds    HOST (B) dropout-stream seed per utterance, or NULL = seed 0 for every utterance
- *   out_frames (B) host: L_b (the per-step sync the reference has at :638)
+ *   out_frames (B) host: L_b = decoder steps * reduction_factor (the per-step sync the reference has at :638)
  * flags: PK_TTS_KEEP_ATT keeps the encoder-decoder attention weights for pk_tts_read. */
 int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int32_t B, double threshold,
                  double minlenratio, double maxlenratio, const uint64_t* seeds, int32_t flags, int32_t* out_frames);
 /* Postnet + outputs of the last pk_tts_infer (:644-651).
  *   mel_out   packed (sum(L_b), odim): outs + postnet(outs), de-normalised under PK_APPLY_NORMALIZER
  *   probs_out packed (sum(L_b)) stop probabilities, or NULL
- *   att_out   per utterance (dlayers, aheads, L_b, T_b) encoder-decoder attention weights, utterances one after
- *             another, or NULL; needs PK_TTS_KEEP_ATT at infer
+ *   att_out   per utterance (dlayers, aheads, L_b / reduction_factor, T_b) encoder-decoder attention weights (one row
+ *             per decoder step, :623-636), utterances one after another, or NULL; needs PK_TTS_KEEP_ATT at infer
  * flags: PK_HOST_IO if the three are host pointers. */
 int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* att_out, int32_t flags);
 /* Test taps of the last infer: 0 = encoder output hs (T_b, adim), 1 = outs before the postnet (L_b, odim),
- * 2 = last decoder layer's output rows (L_b, adim). */
+ * 2 = last decoder layer's output rows (L_b / reduction_factor, adim). */
 int pk_tts_debug_read(pk_tts* h, int32_t what, int32_t b, float* host_out, int64_t n_floats);
 void pk_tts_destroy(pk_tts* h);
 

@@ -232,6 +232,54 @@ __global__ __launch_bounds__(256) void k_tts_stop(const float* __restrict__ z, i
     }
 }
 
+// reduction_factor r > 1: prob_out has r outputs per step (w [A][r]); the utterance ends at a step where ANY of them
+// reaches the threshold (:638-642).  probs[((step - 1) * B + b) * r + k].
+__global__ __launch_bounds__(256) void k_tts_stop_r(const float* __restrict__ z, int A, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int r, int B, int step, float thr,
+                                                    const int* __restrict__ minlen, const int* __restrict__ maxlen,
+                                                    float* __restrict__ probs, int* __restrict__ len,
+                                                    int* __restrict__ ndone) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    bool any = false;
+    for (int k = 0; k < r; ++k) {
+        float s = 0.f;
+        for (int c = lane; c < A; c += 64) s = fmaf(z[(long)b * A + c], w[(long)c * r + k], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float p = 1.f / (1.f + expf(-(s + bias[k])));
+        if (lane == 0) probs[((long)(step - 1) * B + b) * r + k] = p;
+        any = any || p >= thr;
+    }
+    if (lane == 0 && len[b] == 0 && (any || step >= maxlen[b]) && step >= minlen[b]) {
+        len[b] = step;
+        atomicAdd(ndone, 1);
+    }
+}
+
+// k_ar_gather for r frames per step: frame p of utterance u is the C-wide slice p % r of step row (p / r + off) * B + u
+__global__ __launch_bounds__(128) void k_tts_gather_r(const float* __restrict__ src, int C, int B, int r, int off,
+                                                      const int* __restrict__ row_utt, const int* __restrict__ row_pos,
+                                                      const int* __restrict__ rowmap, const float* __restrict__ cscale,
+                                                      const float* __restrict__ cshift, float* __restrict__ dst) {
+    const long q = blockIdx.x;
+    const int u = row_utt[q];
+    const long o = rowmap ? rowmap[q] : q;
+    if (o < 0) return;
+    if (u < 0) {
+        if (!rowmap)
+            for (int c = threadIdx.x; c < C; c += blockDim.x) dst[o * C + c] = 0.f;
+        return;
+    }
+    const int p = row_pos[q];
+    const float* s = src + (((long)(p / r + off) * B + u) * r + p % r) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v = s[c];
+        if (cscale) v = v * cscale[c] + cshift[c];
+        dst[o * C + c] = v;
+    }
+}
+
 struct RowW {   // a layer as pk_rowgemm_pack tiles of its [K][N] matrix (+ bias) for the row GEMM
     size_t w = 0, b = (size_t)-1;
     int K = 0, N = 0;
@@ -263,7 +311,7 @@ struct pk_tts : pk_fft_core {
     Dense dlin, feat_out;
     RowW r_feat_out;
     std::vector<DecLayer> dec;
-    size_t prob_w = 0;
+    size_t prob_w = 0, prob_bv = 0;   // prob_out weight [A][r] and bias [r]
     float prob_b = 0.f;
     std::vector<Dense> postnet;
     size_t spk_w = 0, spk_b = 0;      // speaker part of `projection` ([D][A]) and its bias (:313-317)
@@ -278,7 +326,7 @@ struct pk_tts : pk_fft_core {
     Timeline tl_tok, tl_frm;
     int B = 0, Lcap = 0, steps = 0;
     bool keep_att = false;
-    std::vector<int> T, len, cap;
+    std::vector<int> T, len, cap, frames;   // per utterance: tokens (+ eos), decoder steps, step capacity, frames = steps * r
     std::vector<long> att_off;
     long att_total = 0;
     pk_dbuf d_tok, d_e1, d_e2, d_tpe, d_hs, d_valid, d_y, d_p0, d_p1, d_x0, d_t, d_ham, d_peb, d_rt, d_rc, d_rx, d_rq,
@@ -299,7 +347,7 @@ extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: head size %d not built (64/96/128/192)", dk);
     if (c.adim % 64 != 0 || c.adim > 64 * PK_FFT_LN_MAXPER)
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: adim must be a multiple of 64, <= %d", 64 * PK_FFT_LN_MAXPER);
-    if (c.reduction_factor != 1) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: reduction_factor != 1 not implemented");
+    if (c.reduction_factor < 1 || c.reduction_factor > 16) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: reduction_factor must be in [1, 16]");
     if (!c.encoder_normalize_before || !c.decoder_normalize_before)
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: post-norm blocks not implemented");
     if (c.encoder_concat_after || c.decoder_concat_after)
@@ -572,13 +620,15 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
     }
     PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.weight", A, h->dec_after_g));
     PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.bias", A, h->dec_after_b));
-    PK_TRY(pk_fft_add_linear(ar, P, "feat_out", A, c.odim, h->feat_out));
-    PK_TRY(add_row_linear(ar, P, "feat_out", A, c.odim, h->r_feat_out));
+    // feat_out: adim -> odim * reduction_factor, prob_out: adim -> reduction_factor (:348-349)
+    PK_TRY(pk_fft_add_linear(ar, P, "feat_out", A, c.odim * c.reduction_factor, h->feat_out));
+    PK_TRY(add_row_linear(ar, P, "feat_out", A, c.odim * c.reduction_factor, h->r_feat_out));
     {
         std::vector<float> w, b;
-        PK_TRY(pk_get_weight(P, "prob_out", {A, 1}, w));
-        PK_TRY(pk_get_vector(P, "prob_out.bias", 1, b));
+        PK_TRY(pk_get_weight(P, "prob_out", {A, c.reduction_factor}, w));
+        PK_TRY(pk_get_vector(P, "prob_out.bias", c.reduction_factor, b));
         h->prob_w = ar.put(w);
+        h->prob_bv = ar.put(b);
         h->prob_b = b[0];
     }
     PK_TRY(pk_fft_add_postnet(ar, P, "postnet", c.postnet_layers, c.odim, c.postnet_chans, c.postnet_filts, h->postnet));
@@ -704,6 +754,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     PK_DEVICE(ctx->device);
     const pk_tts_cfg& c = h->cfg;
     const int A = c.adim, H = c.aheads, dk = A / H, O = c.odim, J = c.dprenet_layers, U = J > 0 ? c.dprenet_units : 16;
+    const int RF = c.reduction_factor, OR = O * RF;   // a decoder step emits RF frames: its Y row is [frame 0 | ... | frame RF-1]
     h->inferred = false;
     h->B = B;
     h->keep_att = (flags & PK_TTS_KEEP_ATT) != 0;
@@ -714,8 +765,8 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     for (int b = 0; b < B; ++b) {
         if (tok_lens[b] < 0) PK_FAIL(PK_EINVAL, "pk_tts_infer: utterance %d has %d tokens", b, tok_lens[b]);
         h->T[b] = tok_lens[b] + 1;                                   // with <eos>
-        maxlen[b] = (int)((double)h->T[b] * maxlenratio / 1.0);      // :597-598 (reduction_factor 1)
-        minlen[b] = (int)((double)h->T[b] * minlenratio / 1.0);
+        maxlen[b] = (int)((double)h->T[b] * maxlenratio / (double)RF);      // :597-598, counted in decoder steps
+        minlen[b] = (int)((double)h->T[b] * minlenratio / (double)RF);
         h->cap[b] = std::max(1, std::max(maxlen[b], minlen[b]));
         maxT = std::max(maxT, h->T[b]);
         Lcap = std::max(Lcap, h->cap[b]);
@@ -727,7 +778,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     PK_TRY(encode(h, ids, tok_lens, B, spembs));
     const Timeline& tlk = h->tl_tok;
     // ---- decoder state
-    PK_TRY(rows_reserve(h->d_y, rowsCap + B, O));
+    PK_TRY(rows_reserve(h->d_y, rowsCap + B, OR));
     PK_TRY(rows_reserve(h->d_p0, rowsCap, U));
     PK_TRY(rows_reserve(h->d_p1, rowsCap, U));
     PK_TRY(rows_reserve(h->d_x0, rowsCap, A));
@@ -741,7 +792,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     pk_dbuf* rowbufs[] = {&h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rz};
     for (pk_dbuf* rb : rowbufs) PK_TRY(rows_reserve(*rb, B, A));
     PK_TRY(rows_reserve(h->d_rf, B, c.dunits));
-    PK_TRY(h->d_probs.reserve((size_t)(rowsCap + B) * sizeof(float)));
+    PK_TRY(h->d_probs.reserve((size_t)(rowsCap + B) * RF * sizeof(float)));
     // rows of a "timeline" whose every row is valid, for the LayerNorm launcher
     {
         const size_t nvalid = (size_t)(rowsCap + B + SLACK);
@@ -782,7 +833,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         att = h->d_att.as<float>();
         d_attoff = h->d_attoff.as<long>();
     }
-    float* Y = pk_fft_act_ptr(h->d_y, O);
+    float* Y = pk_fft_act_ptr(h->d_y, OR);
     float* P[2] = {pk_fft_act_ptr(h->d_p0, U), pk_fft_act_ptr(h->d_p1, U)};
     float* X0 = pk_fft_act_ptr(h->d_x0, A);
     float* Tn = pk_fft_act_ptr(h->d_t, A);
@@ -795,7 +846,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     float* rz = pk_fft_act_ptr(h->d_rz, A);
     float* rf = pk_fft_act_ptr(h->d_rf, c.dunits);
     const int* valid = h->d_valid.as<int>();
-    PK_HIP(hipMemsetAsync(Y, 0, (size_t)B * O * sizeof(float), ctx->stream));   // ys = zeros(1, 1, odim) (:601-602)
+    PK_HIP(hipMemsetAsync(Y, 0, (size_t)B * OR * sizeof(float), ctx->stream));   // ys = zeros(1, 1, odim) (:601-602)
     PK_LAUNCH(ctx, "tts_pe", k_tts_pe_pos_major, dim3((unsigned)rowsCap), dim3(128), 0, h->d_pe.as<float>(),
               h->alpha_dec, B, A, PEB);
     const unsigned thr = h->dropout ? pk_dropout_threshold(0.5) : 0u;   // F.dropout's default p (decoder.py:80)
@@ -818,8 +869,8 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         const int R = s * B;
         const long nr = (long)(s - 1) * B;   // first new row
         // decoder.embed on the whole prefix (decoder.py:210)
-        const float* in = Y;
-        int ldin = O;
+        const float* in = Y + (RF - 1) * O;   // the LAST frame of every step's output is the next input (:619-621)
+        int ldin = OR;
         for (int j = 0; j < J; ++j) {
             float* o = P[j & 1];
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_prenet", h->dprenet[j], in, ldin, o, U, R, PK_ACT_RELU, nullptr, 0, nullptr));
@@ -898,12 +949,16 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         PK_TRY(pk_fft_layernorm_rows(h, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, h->dec_after_g, h->dec_after_b,
                                      valid, B, A, rz, use_ham ? ham : nullptr));
         if (use_rg)
-            PK_TRY(rowgemm("tts_row_feat_out", h->r_feat_out, rz, A, Y + (long)s * B * O, O, PK_ACT_NONE, nullptr, 0, 0, 0, false));
+            PK_TRY(rowgemm("tts_row_feat_out", h->r_feat_out, rz, A, Y + (long)s * B * OR, OR, PK_ACT_NONE, nullptr, 0, 0, 0, false));
         else
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_feat_out", h->feat_out, rz, A, Y + (long)s * B * O, O, B, PK_ACT_NONE, nullptr,
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_feat_out", h->feat_out, rz, A, Y + (long)s * B * OR, OR, B, PK_ACT_NONE, nullptr,
                                     0, nullptr, use_ham ? ham : nullptr));
-        PK_LAUNCH(ctx, "tts_stop", k_tts_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, rz, A, h->W(h->prob_w), h->prob_b, B, s,
-                  (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone);
+        if (RF == 1)
+            PK_LAUNCH(ctx, "tts_stop", k_tts_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, rz, A, h->W(h->prob_w), h->prob_b, B, s,
+                      (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone);
+        else
+            PK_LAUNCH(ctx, "tts_stop", k_tts_stop_r, dim3(pk_div_up(B, 4)), dim3(256), 0, rz, A, h->W(h->prob_w),
+                      h->W(h->prob_bv), RF, B, s, (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone);
         if (s % poll == 0 || s == Lcap) {
             int ndone = 0;
             PK_HIP(hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -918,8 +973,9 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     for (int b = 0; b < B; ++b) {
         if (h->len[b] <= 0 || h->len[b] > h->steps)
             PK_FAIL(PK_EHIP, "pk_tts_infer: utterance %d did not stop within %d steps (internal error)", b, h->steps);
-        out_frames[b] = h->len[b];
     }
+    h->frames.resize(B);
+    for (int b = 0; b < B; ++b) out_frames[b] = h->frames[b] = h->len[b] * RF;
     h->inferred = true;
     return PK_OK;
 }
@@ -931,16 +987,16 @@ extern "C" int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* a
     pk_ctx* ctx = h->ctx;
     PK_DEVICE(ctx->device);
     const pk_tts_cfg& c = h->cfg;
-    const int B = h->B, O = c.odim, H = c.aheads;
+    const int B = h->B, O = c.odim, H = c.aheads, rf = c.reduction_factor;
     long total = 0;
-    for (int b = 0; b < B; ++b) total += h->len[b];
-    PK_TRY(pk_fft_build_timeline(ctx, h->tl_frm, h->len.data(), B, h->gapr));
+    for (int b = 0; b < B; ++b) total += h->frames[b];
+    PK_TRY(pk_fft_build_timeline(ctx, h->tl_frm, h->frames.data(), B, h->gapr));
     Timeline& tl = h->tl_frm;
     {
         std::vector<int> rowmap(tl.rows_alloc, -1);
         int o = 0;
         for (int b = 0; b < B; ++b)
-            for (int l = 0; l < h->len[b]; ++l) rowmap[tl.seg_start[b] + l] = o++;
+            for (int l = 0; l < h->frames[b]; ++l) rowmap[tl.seg_start[b] + l] = o++;
         PK_TRY(pk_upload(ctx, h->d_rowmap, rowmap.data(), rowmap.size() * sizeof(int)));
     }
     const bool host = (flags & PK_HOST_IO) != 0;
@@ -952,17 +1008,25 @@ extern "C" int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* a
     const bool denorm = h->has_out_affine && (flags & PK_APPLY_NORMALIZER);   // TransformerTTSInference (:757-767)
     const float* cs = denorm ? h->W(h->out_scale) : nullptr;
     const float* ch = denorm ? h->W(h->out_shift) : nullptr;
-    const float* Y = pk_fft_act_ptr(h->d_y, O);
+    const float* Y = pk_fft_act_ptr(h->d_y, O * rf);
+    // frames of the steps' output rows: position-major step rows [frame 0 | ... | frame rf-1], step s at row s * B + b
+    auto gather = [&](const float* src, int C, int off, const int* rowmap, const float* scale, const float* shift, float* dst) -> int {
+        if (rf == 1)
+            PK_LAUNCH(ctx, "tts_gather", k_ar_gather, dim3(tl.rows), dim3(128), 0, src, C, B, off, tl.d_row_utt(), tl.d_row_pos(),
+                      rowmap, scale, shift, dst);
+        else
+            PK_LAUNCH(ctx, "tts_gather", k_tts_gather_r, dim3(tl.rows), dim3(128), 0, src, C, B, rf, off, tl.d_row_utt(),
+                      tl.d_row_pos(), rowmap, scale, shift, dst);
+        return PK_OK;
+    };
     if (c.postnet_layers == 0) {
-        PK_LAUNCH(ctx, "tts_gather", k_ar_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
-                  h->d_rowmap.as<int>(), cs, ch, d_mel);
+        PK_TRY(gather(Y, O, 1, h->d_rowmap.as<int>(), cs, ch, d_mel));
     } else {
         // outs on a frame timeline with zero gap rows, then outs + postnet(outs) (:644-648)
         PK_TRY(pk_fft_act_reserve(h->d_before, tl.rows, O));
         PK_HIP(hipMemsetAsync(h->d_before.p, 0, h->d_before.cap, ctx->stream));
         float* before = pk_fft_act_ptr(h->d_before, O);
-        PK_LAUNCH(ctx, "tts_gather", k_ar_gather, dim3(tl.rows), dim3(128), 0, Y, O, B, 1, tl.d_row_utt(), tl.d_row_pos(),
-                  (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, before);
+        PK_TRY(gather(Y, O, 1, nullptr, nullptr, nullptr, before));
         PK_TRY(pk_fft_run_postnet(h, "tts_conv_postnet", h->postnet, before, O, c.postnet_chans, tl, h->d_q1, h->d_q2, d_mel,
                                   h->d_rowmap.as<int>(), cs, ch));
     }
@@ -973,8 +1037,7 @@ extern "C" int pk_tts_read(pk_tts* h, float* mel_out, float* probs_out, float* a
             PK_TRY(h->d_stage2.reserve((size_t)total * sizeof(float)));
             d_p = h->d_stage2.as<float>();
         }
-        PK_LAUNCH(ctx, "tts_gather", k_ar_gather, dim3(tl.rows), dim3(128), 0, h->d_probs.as<float>(), 1, B, 0,
-                  tl.d_row_utt(), tl.d_row_pos(), h->d_rowmap.as<int>(), (const float*)nullptr, (const float*)nullptr, d_p);
+        PK_TRY(gather(h->d_probs.as<float>(), 1, 0, h->d_rowmap.as<int>(), nullptr, nullptr, d_p));
         if (host) PK_HIP(hipMemcpyAsync(probs_out, d_p, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     if (att_out) {
@@ -1011,8 +1074,8 @@ extern "C" int pk_tts_debug_read(pk_tts* h, int32_t what, int32_t b, float* host
         return PK_OK;
     }
     if (what != 1 && what != 2) PK_FAIL(PK_EINVAL, "pk_tts_debug_read: unknown tap %d", what);
-    const int C = what == 1 ? O : A;
-    const float* src = what == 1 ? pk_fft_act_ptr(h->d_y, O) + (long)B * O
+    const int C = what == 1 ? O * h->cfg.reduction_factor : A;   // a step's row holds its reduction_factor frames
+    const float* src = what == 1 ? pk_fft_act_ptr(h->d_y, C) + (long)B * C
                                  : pk_fft_act_ptr(h->d_xc_l[h->cfg.dlayers - 1], A);
     const long n = (long)h->len[b] * C;
     if (n_floats != n) PK_FAIL(PK_ESHAPE, "pk_tts_debug_read: expected %ld floats, got %lld", n, (long long)n_floats);

@@ -122,7 +122,7 @@ class TransformerTTS:
     def inference_batch(self, texts, threshold=0.5, minlenratio=0.0, maxlenratio=10.0, seeds=None,
                         return_att=True, denormalize=False, spembs=None):
         """Lists of (T_b,) token ids (without <eos>) -> list of (outs (L_b, odim), probs (L_b,),
-        att_ws (dlayers, aheads, L_b, T_b + 1) or None) device tensors.  ``spembs``: (B, spk_embed_dim), one speaker
+        att_ws (dlayers, aheads, L_b / reduction_factor, T_b + 1) or None) device tensors.  ``spembs``: (B, spk_embed_dim), one speaker
         embedding per utterance, for a model built with ``spk_embed_dim``."""
         ctx = Context.get(self._ctx.device)
         self._finalize()
@@ -147,21 +147,22 @@ class TransformerTTS:
                                          None if sd is None else sd.ctypes.data_as(C.POINTER(C.c_uint64)), flags,
                                          frames.ctypes.data_as(C.POINTER(C.c_int32))))
         self._last_tok, self._last_frames = [int(v) + 1 for v in lens], [int(v) for v in frames]
+        steps = [L // self.reduction_factor for L in self._last_frames]     # one attention row per decoder step
         total = int(frames.sum())
         mel = ctx.empty((total, self.odim))
         probs = ctx.empty((total,))
         att = None
         if return_att:
-            n_att = sum(self._dlayers * self._aheads * L * T for L, T in zip(self._last_frames, self._last_tok))
+            n_att = sum(self._dlayers * self._aheads * S * T for S, T in zip(steps, self._last_tok))
             att = ctx.empty((n_att,))
         _capi.check(ctx.lib.pk_tts_read(self._h, dptr(mel), dptr(probs), None if att is None else dptr(att),
                                         _capi.PK_APPLY_NORMALIZER if denormalize else 0))
         outs, o, oa = [], 0, 0
-        for L, T in zip(self._last_frames, self._last_tok):
+        for L, S, T in zip(self._last_frames, steps, self._last_tok):
             a = None
             if att is not None:
-                n = self._dlayers * self._aheads * L * T
-                a = wrap(att[oa:oa + n].view(self._dlayers, self._aheads, L, T))
+                n = self._dlayers * self._aheads * S * T
+                a = wrap(att[oa:oa + n].view(self._dlayers, self._aheads, S, T))
                 oa += n
             outs.append((wrap(mel[o:o + L]), wrap(probs[o:o + L]), a))
             o += L
@@ -178,7 +179,8 @@ class TransformerTTS:
 
     def debug_tap(self, what, b):
         """0: encoder output (T_b + 1, adim); 1: outs before the postnet (L_b, odim); 2: last decoder layer (L_b, adim)."""
-        rows = self._last_tok[b] if what == 0 else self._last_frames[b]
+        rows = (self._last_tok[b] if what == 0 else self._last_frames[b] if what == 1
+                else self._last_frames[b] // self.reduction_factor)
         out = np.empty((rows, self.odim if what == 1 else self._adim), dtype=np.float32)
         _capi.check(self._ctx.lib.pk_tts_debug_read(self._h, what, b, _capi.fptr(out), out.size))
         return out

@@ -31,6 +31,12 @@ TTS_CASES = [
     # dprenet_layers = 0: the "linear" decoder input layer (Linear -> LayerNorm -> ReLU -> pos_enc, no dropout at all)
     ("linear_in", dict(elayers=1, dlayers=2, postnet_layers=2, dprenet_layers=0), 40, 6, 19, dict(stop_bias=-6.0),
      dict(maxlenratio=1.5)),
+    # reduction_factor 2 and 3: r frames per decoder step, the last one fed back (:613-621); "r3stop": the stop token
+    # fires at step 7 of at most 14 through ONE of the 3 probabilities of that step (:638), 0.03 away from the threshold
+    ("r2", dict(elayers=1, dlayers=2, postnet_layers=2, reduction_factor=2), 40, 7, 20, dict(stop_bias=-6.0),
+     dict(maxlenratio=1.5)),
+    ("r3stop", dict(elayers=1, dlayers=1, postnet_layers=0, reduction_factor=3), 40, 6, 21, dict(stop_bias=-3.1, stop_gain=2.0),
+     dict(maxlenratio=6.0, threshold=0.5)),
 ]
 
 # Tacotron2: name, config overrides on synthetic.TACOTRON2_LJSPEECH, tokens, seed (weights, ids = 800 + seed, dropout

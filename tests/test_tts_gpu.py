@@ -109,7 +109,7 @@ def test_dropout_switch_normalizer_and_errors():
     raw = m.inference(ids, seed=1)[0].numpy()
     assert np.abs(lm - (raw * sigma + mu)).max() < 1e-5
     with pytest.raises(NotImplementedError):
-        TransformerTTS(idim=40, odim=80, **dict(cfg, reduction_factor=2))
+        TransformerTTS(idim=40, odim=80, **dict(cfg, reduction_factor=32))
     with pytest.raises(NotImplementedError):
         TransformerTTS(idim=40, odim=80, **dict(cfg, use_gst=True))
     with pytest.raises(NotImplementedError):
@@ -141,3 +141,27 @@ def test_speaker_embeddings_ragged_batch():
         m.inference_batch(texts, maxlenratio=1.0, spembs=emb[:, :16])
     one = m.inference(texts[1], spembs=emb[1], maxlenratio=1.0, seed=2)
     assert np.abs(one[0].numpy() - outs[1][0].numpy()).max() < 1e-5
+
+
+def test_reduction_factor_ragged_batch():
+    """reduction_factor 2: two frames per decoder step, lengths counted in steps, one attention row per step; utterances
+    of a ragged batch stop at different steps (stop token through either of the step's two probabilities, maxlen)."""
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=2, postnet_layers=2, reduction_factor=2)
+    state = syn.transformer_tts_state(40, 80, cfg, seed=51, stop_bias=-3.5, stop_gain=2.0)
+    m = _model(cfg, 40, state)
+    texts = [syn.phoneme_ids(T, idim=40, seed=500 + T) for T in (6, 3, 8)]
+    seeds = [5, 6, 7]
+    outs = m.inference_batch(texts, maxlenratio=3.0, seeds=seeds)
+    lens = []
+    for b, (t, sd, (mel, probs, att)) in enumerate(zip(texts, seeds, outs)):
+        ref, rprobs, ratt, parts = tt.inference(state, t, cfg, maxlenratio=3.0, seed=sd, dtype=torch.float64, return_parts=True)
+        assert mel.shape == ref.shape and mel.shape[0] % 2 == 0
+        assert att.shape == ratt.shape and att.shape[2] == mel.shape[0] // 2
+        assert np.abs(rprobs.numpy() - 0.5).min() > 2e-3                         # the stop decisions are not marginal
+        assert np.abs(m.debug_tap(1, b) - parts["before"].numpy()).max() < 2e-4  # frames before the postnet
+        assert np.abs(m.debug_tap(2, b) - parts["zs"].numpy()).max() < 2e-4      # one decoder row per step
+        assert _close(mel.numpy(), ref.numpy())
+        assert np.abs(probs.numpy() - rprobs.numpy()).max() < 1e-4
+        assert np.abs(att.numpy() - ratt.numpy()).max() < 1e-4
+        lens.append(int(mel.shape[0]))
+    assert lens == [20, 12, 2]                                                   # maxlen, maxlen, stop token at step 1
