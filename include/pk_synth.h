@@ -332,7 +332,8 @@ void pk_ss_destroy(pk_ss* h);
 /* TransformerTTS(idim, odim, **model_cfg) -- parakeet/models/transformer_tts/transformer_tts.py:172-358.
  * Built: the embedding or conv-prenet encoder input layer, pre-norm blocks, the decoder prenet, the stop token,
  * the postnet, speaker embeddings ("add" / "concat"), both positional encodings, the "linear" decoder input layer
- * (dprenet_layers == 0), reduction_factor >= 1.  Refused with PK_EUNSUPPORTED: post-norm / concat_after blocks, use_gst. */
+ * (dprenet_layers == 0), reduction_factor >= 1, global style tokens (use_gst: modules/style_encoder.py).  Refused with
+ * PK_EUNSUPPORTED: post-norm / concat_after blocks. */
 typedef struct {
     int32_t idim, odim;
     int32_t embed_dim, eprenet_conv_layers, eprenet_conv_chans, eprenet_conv_filts;   /* layers 0: nn.Embedding(idim, adim) (:272-277) */
@@ -349,6 +350,11 @@ typedef struct {
     int32_t spk_embed_dim;                 /* 0 = None */
     int32_t use_gst;
     int32_t spk_embed_integration_type;    /* 0 = "add", 1 = "concat" (:313-317) */
+    /* StyleEncoder(idim=odim, gst_token_dim=adim, ...) (:299-310), read when use_gst != 0 */
+    int32_t gst_tokens, gst_heads;
+    int32_t gst_conv_layers, gst_conv_kernel_size, gst_conv_stride;
+    int32_t gst_gru_layers, gst_gru_units;
+    int32_t gst_conv_chans[8];             /* gst_conv_chans_list, gst_conv_layers entries used */
 } pk_tts_cfg;
 typedef struct pk_tts pk_tts;
 
@@ -370,6 +376,9 @@ int pk_tts_finalize(pk_tts* h);
  * :591-593): spembs HOST float32 (B, spk_embed_dim), one row per utterance.  Consumed by that call; NULL clears it.
  * A model with spk_embed_dim > 0 refuses to infer without them (the reference fails on spemb = None). */
 int pk_tts_set_speakers(pk_tts* h, const float* spembs, int32_t B);
+/* Reference spectrograms of the NEXT pk_tts_infer call for a use_gst model (`speech` of inference(), :586-588): speech
+ * HOST float32 packed (sum(lens), odim), lens HOST (B) frames per utterance.  Consumed by that call; NULL clears it. */
+int pk_tts_set_style_reference(pk_tts* h, const float* speech, const int32_t* lens, int32_t B);
 /* TransformerTTS.inference (:511-647) for a packed batch, up to (not including) the postnet: <eos> = idim - 1 is
  * appended to every utterance (:563-565), the encoder runs once, then the decoder is stepped until every utterance
  * has stopped: utterance b ends at the first step s >= int(T_b * minlenratio) with sigmoid(prob_out) >= threshold

@@ -156,6 +156,10 @@ class BatchNorm1D(Layer):
         return _wrap(TF.batch_norm(x, self._mean, self._variance, self.weight, self.bias, False, 0.0, self._eps))
 
 
+class BatchNorm2D(BatchNorm1D):
+    """NCHW eval-mode batch norm (same arithmetic as BatchNorm1D on the channel axis)."""
+
+
 class Embedding(Layer):
     def __init__(self, num_embeddings, embedding_dim, padding_idx=None, sparse=False, weight_attr=None, name=None):
         super().__init__()
@@ -194,6 +198,65 @@ class LSTMCell(Layer):
         c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
         h2 = torch.sigmoid(o) * torch.tanh(c2)
         return _wrap(h2), (_wrap(h2), _wrap(c2))
+
+
+class GRUCell(Layer):
+    """paddle.nn.GRUCell: weight_ih [3H, in], weight_hh [3H, H], bias_ih / bias_hh [3H]; gates in the order r, z, c along
+    the 3H axis; r = sigmoid(W_ir x + b_ir + W_hr h + b_hr), z likewise, c = tanh(W_ic x + b_ic + r * (W_hc h + b_hc)),
+    h' = z * h + (1 - z) * c [paddle-semantics, from Paddle's API documentation of GRUCell].  forward -> (h', h')."""
+
+    def __init__(self, input_size, hidden_size, weight_ih_attr=None, weight_hh_attr=None, bias_ih_attr=None,
+                 bias_hh_attr=None, name=None):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        k = 1.0 / math.sqrt(hidden_size)
+        for nm, shape in (("weight_ih", (3 * hidden_size, input_size)), ("weight_hh", (3 * hidden_size, hidden_size)),
+                          ("bias_ih", (3 * hidden_size,)), ("bias_hh", (3 * hidden_size,))):
+            self.register_parameter(nm, torch.nn.Parameter(torch.empty(*shape).uniform_(-k, k), requires_grad=False))
+
+    def forward(self, inputs, states=None):
+        h = torch.zeros(inputs.shape[0], self.hidden_size, dtype=inputs.dtype) if states is None else states
+        gx = torch.matmul(inputs, self.weight_ih.t()) + self.bias_ih
+        gh = torch.matmul(h, self.weight_hh.t()) + self.bias_hh
+        xr, xz, xc = torch.chunk(gx, 3, dim=-1)
+        hr, hz, hc = torch.chunk(gh, 3, dim=-1)
+        r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+        c = torch.tanh(xc + r * hc)
+        h2 = z * h + (1.0 - z) * c
+        return _wrap(h2), _wrap(h2)
+
+
+class GRU(torch.nn.ModuleList, Layer):
+    """paddle.nn.GRU, forward direction: sublayer "{layer}" is RNN(cell); every cell parameter is also registered under
+    the cuDNN-style names weight_ih_l{k}, ... (as LSTM below).  Returns (outputs, final_states (num_layers, B, H))."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, direction="forward", time_major=False, dropout=0.0,
+                 weight_ih_attr=None, weight_hh_attr=None, bias_ih_attr=None, bias_hh_attr=None, name=None):
+        torch.nn.ModuleList.__init__(self)
+        assert direction == "forward", direction
+        self.time_major, self.hidden_size, self.num_layers = time_major, hidden_size, num_layers
+        for layer in range(num_layers):
+            self.append(_RNN(GRUCell(input_size if layer == 0 else hidden_size, hidden_size)))
+            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                self.register_parameter(f"{nm}_l{layer}", getattr(self[layer].cell, nm))
+
+    def flatten_parameters(self):
+        return None
+
+    def forward(self, inputs, initial_states=None, sequence_length=None):
+        assert initial_states is None and sequence_length is None, "only the inference call pattern is restated"
+        x = inputs if self.time_major else inputs.transpose(0, 1)             # (T, B, C)
+        x = x.as_subclass(torch.Tensor)
+        finals = []
+        for layer in range(self.num_layers):
+            cell, state, seq = self[layer].cell, None, []
+            for t in range(x.shape[0]):
+                h, state = cell(x[t], state)
+                seq.append(h)
+            x = torch.stack(seq, dim=0)
+            finals.append(state)
+        y = x if self.time_major else x.transpose(0, 1)
+        return _wrap(y), _wrap(torch.stack(finals, 0))
 
 
 class _BiRNN(Layer):

@@ -3,6 +3,7 @@
 Restates, op for op, parakeet/models/transformer_tts/transformer_tts.py
   TransformerTTS.inference                   :511-647  (no teacher forcing, no GST)
   TransformerTTS._integrate_with_spk_embed   :725-755
+  StyleEncoder / ReferenceEncoder / StyleTokenLayer  parakeet/modules/style_encoder.py:24-308 (use_gst)
 and the modules it calls:
   Encoder.forward                            fastspeech2_transformer/encoder.py:171-192
   EncoderPrenet (tacotron2 Encoder, elayers=0) modules/tacotron2/encoder.py:150-176
@@ -42,7 +43,9 @@ DEFAULT_CFG = dict(
     embed_dim=0, eprenet_conv_layers=0, eprenet_conv_filts=0, eprenet_conv_chans=0,
     dprenet_layers=2, dprenet_units=256, adim=512, aheads=8, elayers=6, eunits=1024, dlayers=6, dunits=1024,
     postnet_layers=5, postnet_filts=5, postnet_chans=256, reduction_factor=1, use_scaled_pos_enc=True,
-    spk_embed_dim=None, spk_embed_integration_type="add")
+    spk_embed_dim=None, spk_embed_integration_type="add", use_gst=False, gst_tokens=10, gst_heads=4, gst_conv_layers=6,
+    gst_conv_chans_list=(32, 32, 64, 64, 128, 128), gst_conv_kernel_size=3, gst_conv_stride=2, gst_gru_layers=1,
+    gst_gru_units=128)
 
 PRENET_DROPOUT_P = 0.5   # F.dropout's default; Prenet.forward passes no rate (modules/tacotron2/decoder.py:80)
 
@@ -139,6 +142,58 @@ def integrate_with_spk_embed(W, hs, spembs, kind):
     raise NotImplementedError("support only add or concat.")
 
 
+def gru_cell(W, x, h):
+    """paddle.nn.GRUCell.forward [paddle-semantics, from Paddle's API documentation]: gate order r, z, c."""
+    gx = linear(x, W["weight_ih"].t(), W["bias_ih"])
+    gh = linear(h, W["weight_hh"].t(), W["bias_hh"])
+    xr, xz, xc = torch.chunk(gx, 3, dim=-1)
+    hr, hz, hc = torch.chunk(gh, 3, dim=-1)
+    r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+    c = torch.tanh(xc + r * hc)
+    return z * h + (1.0 - z) * c
+
+
+def style_encoder(W, speech, cfg):
+    """StyleEncoder.forward style_encoder.py:93-106 for one reference spectrogram speech (L, odim) -> (1, adim).
+    ReferenceEncoder.forward :187-215: Conv2D(no bias) -> BatchNorm2D(eval) -> ReLU stack, transpose / reshape, GRU, last
+    hidden state; StyleTokenLayer.forward :266-288: multi-head attention of that one query over tanh(gst_embs), with
+    the q / k / v input widths of style_encoder.MultiHeadedAttention :291-308."""
+    R = W.sub("ref_enc.")
+    k, stride = cfg["gst_conv_kernel_size"], cfg["gst_conv_stride"]
+    x = speech.reshape(1, 1, speech.shape[0], speech.shape[1])
+    for i in range(cfg["gst_conv_layers"]):
+        x = torch.nn.functional.conv2d(x, R[f"convs.{3 * i}.weight"], None, stride=stride, padding=(k - 1) // 2)
+        shp = (1, -1, 1, 1)
+        bn = R.sub(f"convs.{3 * i + 1}.")
+        x = (x - bn["_mean"].view(shp)) / torch.sqrt(bn["_variance"].view(shp) + 1e-5) * bn["weight"].view(shp) + bn["bias"].view(shp)
+        x = torch.relu(x)
+    hs = x.transpose(1, 2).reshape(1, x.shape[2], -1)                     # (1, L', C * F')
+    for l in range(cfg["gst_gru_layers"]):
+        C = R.sub(f"gru.{l}.cell.")
+        h = torch.zeros(1, C["weight_hh"].shape[1], dtype=hs.dtype)
+        seq = []
+        for t in range(hs.shape[1]):
+            h = gru_cell(C, hs[:, t], h)
+            seq.append(h)
+        hs = torch.stack(seq, dim=1)
+    ref = h                                                                # (1, gru_units): ref_embs[-1]
+    S = W.sub("stl.")
+    M = S.sub("mha.")
+    n_head = cfg["gst_heads"]
+    gst = torch.tanh(S["gst_embs"]).unsqueeze(0)                           # (1, tokens, adim / heads)
+    q = linear(ref.unsqueeze(1), M["linear_q.weight"], M["linear_q.bias"])
+    kk = linear(gst, M["linear_k.weight"], M["linear_k.bias"])
+    vv = linear(gst, M["linear_v.weight"], M["linear_v.bias"])
+    A = q.shape[-1]
+    dk = A // n_head
+    qh = q.reshape(1, 1, n_head, dk).transpose(1, 2)
+    kh = kk.reshape(1, -1, n_head, dk).transpose(1, 2)
+    vh = vv.reshape(1, -1, n_head, dk).transpose(1, 2)
+    attn = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(dk), dim=-1)
+    ctx = torch.matmul(attn, vh).transpose(1, 2).reshape(1, 1, A)
+    return linear(ctx, M["linear_out.weight"], M["linear_out.bias"]).squeeze(1)
+
+
 def decoder_layer_step(W, tgt, memory, cache, n_head):
     """DecoderLayer.forward decoder_layer.py:74-158, normalize_before=True, concat_after=False.
     tgt (1, s, D); cache (1, s-1, D) or None.  Returns (x (1, s, D), src attention weights (H, T) of the last row)."""
@@ -163,7 +218,7 @@ def decoder_layer_step(W, tgt, memory, cache, n_head):
 
 
 def inference(state, ids, cfg=None, threshold=0.5, minlenratio=0.0, maxlenratio=10.0, seed=0, drop="stream",
-              dtype=torch.float32, return_parts=False, spembs=None):
+              dtype=torch.float32, return_parts=False, spembs=None, speech=None):
     """TransformerTTS.inference transformer_tts.py:511-647.  ids (T,) int64 without <eos>.
     Returns (outs (L, odim), probs (L,), att_ws (dlayers, aheads, L, T+1))."""
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
@@ -176,6 +231,9 @@ def inference(state, ids, cfg=None, threshold=0.5, minlenratio=0.0, maxlenratio=
     xs = torch.as_tensor(x).to(torch.int64).unsqueeze(0)
     hs = encode(W.sub("encoder."), xs, cfg)                                        # :584-585
     enc_out = hs
+    if cfg.get("use_gst"):                                                         # :586-588
+        style = style_encoder(W.sub("gst."), torch.as_tensor(np.asarray(speech)).to(dtype), cfg)
+        hs = hs + style.unsqueeze(1)
     if cfg.get("spk_embed_dim"):                                                   # :591-593
         e = torch.as_tensor(np.asarray(spembs)).to(dtype).reshape(1, -1)
         hs = integrate_with_spk_embed(W, hs, e, cfg["spk_embed_integration_type"])

@@ -76,7 +76,8 @@ class TtsCfg(C.Structure):
         "postnet_layers", "postnet_chans", "postnet_filts", "positionwise_layer_type",
         "positionwise_conv_kernel_size", "use_scaled_pos_enc", "use_batch_norm", "encoder_normalize_before",
         "decoder_normalize_before", "encoder_concat_after", "decoder_concat_after", "reduction_factor",
-        "spk_embed_dim", "use_gst", "spk_embed_integration_type")]
+        "spk_embed_dim", "use_gst", "spk_embed_integration_type", "gst_tokens", "gst_heads", "gst_conv_layers",
+        "gst_conv_kernel_size", "gst_conv_stride", "gst_gru_layers", "gst_gru_units")] + [("gst_conv_chans", C.c_int32 * 8)]
 
 
 class TacoCfg(C.Structure):
@@ -155,6 +156,7 @@ def _declare(lib):
         "pk_tts_set_math": (C.c_int, [vp, i32]),
         "pk_tts_set_dropout": (C.c_int, [vp, i32]),
         "pk_tts_set_speakers": (C.c_int, [vp, f32p, i32]),
+        "pk_tts_set_style_reference": (C.c_int, [vp, f32p, i32p, i32]),
         "pk_tts_finalize": (C.c_int, [vp]),
         "pk_tts_infer": (C.c_int, [vp, i64p, i32p, i32, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_uint64), i32,
                                    i32p]),

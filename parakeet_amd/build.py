@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libpk_synth.so")
-SOURCES = ["pk_ctx.cpp", "pwg.hip", "gemm.hip", "fs2.hip", "waveflow.hip", "wf_layer.hip", "speedyspeech.hip", "tts.hip", "taco2.hip", "rowgemm.hip", "mel.hip", "ops.hip"]
+SOURCES = ["pk_ctx.cpp", "pwg.hip", "gemm.hip", "fs2.hip", "waveflow.hip", "wf_layer.hip", "speedyspeech.hip", "tts.hip", "gst.hip", "taco2.hip", "rowgemm.hip", "mel.hip", "ops.hip"]
 
 
 def hipcc():

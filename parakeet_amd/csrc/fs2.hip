@@ -788,6 +788,12 @@ struct Predictor {
     int chans;
 };
 
+// hs[r] += v[utterance of r] on the rows of a timeline (v: [B][adim])
+int pk_fft_add_rowvec(pk_fft_core* h, const pk_fft_timeline& tl, const float* d_vec, float* hs) {
+    PK_LAUNCH(h->ctx, "fft_add_rowvec", k_add_rowvec, dim3(tl.rows), dim3(256), 0, hs, d_vec, tl.d_row_utt(), tl.rows, h->adim, hs);
+    return PK_OK;
+}
+
 // _integrate_with_spk_embed (fastspeech2.py:560-586, transformer_tts.py:725-755) on the rows of a timeline:
 //   "add":    hs += normalize(e_b) . W + bias
 //   "concat": hs  = hs . W[:A] + (normalize(e_b) . W[A:] + bias)      (hs_proj = the [A][A] part; tmp: A-wide rows)

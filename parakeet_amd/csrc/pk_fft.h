@@ -130,6 +130,8 @@ int pk_fft_run_attention(pk_fft_core* h, const pk_fft_timeline& tl, const float*
 // N FFT blocks + after_norm on the timeline tl; the residual stream core->d_x is updated in place, result in hs_out
 int pk_fft_run_stack(pk_fft_core* h, const std::vector<pk_fft_layer>& layers, size_t after_g, size_t after_b,
                      const pk_fft_timeline& tl, int units, float* hs_out);
+// hs[r] += v[utterance of r] for the rows of a timeline that belong to an utterance; v: [B][adim]
+int pk_fft_add_rowvec(pk_fft_core* h, const pk_fft_timeline& tl, const float* d_vec, float* hs);
 // Speaker-embedding integration on the rows of a timeline ("add" / "concat"; hs_proj NULL = "add"); fs2.hip
 int pk_fft_run_speaker(pk_fft_core* h, const pk_fft_timeline& tl, const long long* d_spk_id, const float* d_spembs,
                        size_t table, size_t w, size_t bias, const pk_fft_dense* hs_proj, int D, pk_dbuf& d_vec, float* hs,

@@ -39,6 +39,7 @@
 
 #include "pk_ar.h"
 #include "pk_fft.h"
+#include "pk_gst.h"
 #include "pk_rowgemm.h"
 
 namespace {
@@ -319,6 +320,10 @@ struct pk_tts : pk_fft_core {
     std::vector<float> cond_emb;       // speaker embeddings of the next infer (pk_tts_set_speakers)
     int cond_B = 0;
     pk_dbuf d_spk_emb, d_spk_vec;
+    pk_gst gst;                        // global style tokens (use_gst)
+    std::vector<float> cond_speech;    // reference spectrograms of the next infer (pk_tts_set_style_reference)
+    std::vector<int> cond_speech_lens;
+    pk_dbuf d_style;
     size_t out_scale = 0, out_shift = 0;
     bool has_out_affine = false;
     std::vector<float> h_out_scale, h_out_shift;
@@ -355,7 +360,15 @@ extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
     if (c.spk_embed_dim < 0 || c.spk_embed_dim > 8192) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: spk_embed_dim must be in [0, 8192]");
     if (c.spk_embed_dim > 0 && c.spk_embed_integration_type != 0 && c.spk_embed_integration_type != 1)
         PK_FAIL(PK_EUNSUPPORTED, "support only add or concat. (transformer_tts.py:753)");
-    if (c.use_gst) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: global style tokens not implemented");
+    pk_gst_cfg gc;
+    if (c.use_gst) {
+        gc.idim = c.odim;   // the style encoder reads a mel spectrogram (:300)
+        gc.tokens = c.gst_tokens; gc.token_dim = c.adim; gc.heads = c.gst_heads;
+        gc.conv_layers = c.gst_conv_layers; gc.conv_kernel_size = c.gst_conv_kernel_size; gc.conv_stride = c.gst_conv_stride;
+        gc.gru_layers = c.gst_gru_layers; gc.gru_units = c.gst_gru_units;
+        for (int i = 0; i < PK_GST_MAX_CONV; ++i) gc.conv_chans[i] = c.gst_conv_chans[i];
+        PK_TRY(pk_gst_check(gc));
+    }
     if (c.dprenet_layers < 0) PK_FAIL(PK_EINVAL, "TransformerTTS: dprenet_layers must be >= 0");
     if (c.dprenet_layers > 0 && (c.dprenet_units % 16 != 0 || c.dprenet_units <= 0))
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: dprenet_units must be a positive multiple of 16");
@@ -388,6 +401,7 @@ extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
     h->adim = c.adim;
     h->aheads = c.aheads;
     h->gapr = gapr;
+    h->gst.cfg = gc;
     if (const char* e = getenv("PK_TTS_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     *out = h;
     return PK_OK;
@@ -429,6 +443,23 @@ extern "C" int pk_tts_set_speakers(pk_tts* h, const float* spembs, int32_t B) {
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_tts_set_speakers: batch size must be positive");
     h->cond_emb.assign(spembs, spembs + (size_t)B * h->cfg.spk_embed_dim);
     h->cond_B = B;
+    return PK_OK;
+}
+
+extern "C" int pk_tts_set_style_reference(pk_tts* h, const float* speech, const int32_t* lens, int32_t B) {
+    if (!h) PK_FAIL(PK_EINVAL, "pk_tts_set_style_reference: handle is NULL");
+    h->cond_speech.clear();
+    h->cond_speech_lens.clear();
+    if (!speech) return PK_OK;
+    if (!h->cfg.use_gst) PK_FAIL(PK_ESTATE, "pk_tts_set_style_reference: the model has no style encoder (use_gst=False)");
+    if (!lens || B <= 0) PK_FAIL(PK_EINVAL, "pk_tts_set_style_reference: lens / batch size");
+    size_t total = 0;
+    for (int b = 0; b < B; ++b) {
+        if (lens[b] <= 0) PK_FAIL(PK_EINVAL, "pk_tts_set_style_reference: reference %d has %d frames", b, lens[b]);
+        total += (size_t)lens[b];
+    }
+    h->cond_speech.assign(speech, speech + total * h->cfg.odim);
+    h->cond_speech_lens.assign(lens, lens + B);
     return PK_OK;
 }
 
@@ -551,6 +582,7 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
     }
     PK_TRY(pk_fft_add_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size,
                             c.positionwise_layer_type, c.aheads, h->enc, h->enc_after_g, h->enc_after_b));
+    if (c.use_gst) PK_TRY(pk_gst_finalize(ar, P, "gst", h->gst));
     if (c.spk_embed_dim > 0) {
         // `projection` (:313-317): Linear(D, adim) for "add", Linear(adim + D, adim) on concat([hs, e]) for "concat"
         const int D = c.spk_embed_dim;
@@ -665,7 +697,8 @@ int attn_step(pk_tts* h, const char* name, const AttnStep& a, int heads, int B, 
     return PK_OK;
 }
 
-int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B, const std::vector<float>& spembs) {
+int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B, const std::vector<float>& spembs,
+           const std::vector<float>& speech, const std::vector<int>& speech_lens) {
     pk_ctx* ctx = h->ctx;
     const pk_tts_cfg& c = h->cfg;
     const int A = c.adim;
@@ -718,6 +751,12 @@ int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B, const 
         PK_TRY(pk_fft_embed(h, "tts_embed", h->d_tok.as<int>(), tl, h->emb_table, h->alpha_enc, h->xscale, x));
     }
     PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    if (c.use_gst) {
+        // hs = hs + gst(speech).unsqueeze(1) (:586-588)
+        PK_TRY(h->d_style.reserve((size_t)B * A * sizeof(float)));
+        PK_TRY(pk_gst_run(h, h->gst, speech.data(), speech_lens.data(), B, h->d_style.as<float>()));
+        PK_TRY(pk_fft_add_rowvec(h, tl, h->d_style.as<float>(), hs));
+    }
     if (c.spk_embed_dim > 0) {
         // hs = _integrate_with_spk_embed(hs, spembs) (:591-593, :725-755); the residual stream x is free by now
         PK_TRY(pk_upload(ctx, h->d_spk_emb, spembs.data(), spembs.size() * sizeof(float)));
@@ -743,12 +782,19 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     spembs.swap(h->cond_emb);
     const int condB = h->cond_B;
     h->cond_B = 0;
+    std::vector<float> speech;
+    std::vector<int> speech_lens;
+    speech.swap(h->cond_speech);
+    speech_lens.swap(h->cond_speech_lens);
     if (!ids || !tok_lens || !out_frames) PK_FAIL(PK_EINVAL, "pk_tts_infer: NULL argument");
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_tts_infer: call pk_tts_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_tts_infer: batch size must be positive");
     if (h->cfg.spk_embed_dim > 0 && condB != B)
         PK_FAIL(PK_EINVAL, "pk_tts_infer: the model integrates a speaker embedding into the encoder output (:591-593): "
                            "pk_tts_set_speakers needs %d rows, got %d", B, condB);
+    if (h->cfg.use_gst && (int)speech_lens.size() != B)
+        PK_FAIL(PK_EINVAL, "pk_tts_infer: the model adds a style embedding of a reference spectrogram to the encoder output "
+                           "(:586-588): pk_tts_set_style_reference needs %d spectrograms, got %d", B, (int)speech_lens.size());
     if (!(minlenratio >= 0.0) || !(maxlenratio >= 0.0)) PK_FAIL(PK_EINVAL, "pk_tts_infer: length ratios must be >= 0");
     pk_ctx* ctx = h->ctx;
     PK_DEVICE(ctx->device);
@@ -775,7 +821,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     const long rowsCap = (long)Lcap * B;
     if (rowsCap + B + SLACK > 0x3fffffff) PK_FAIL(PK_EUNSUPPORTED, "pk_tts_infer: %ld decoder rows", rowsCap);
     PK_TRY(pk_fft_ensure_pe(h, std::max(maxT, Lcap)));
-    PK_TRY(encode(h, ids, tok_lens, B, spembs));
+    PK_TRY(encode(h, ids, tok_lens, B, spembs, speech, speech_lens));
     const Timeline& tlk = h->tl_tok;
     // ---- decoder state
     PK_TRY(rows_reserve(h->d_y, rowsCap + B, OR));
@@ -1090,7 +1136,8 @@ extern "C" void pk_tts_destroy(pk_tts* h) {
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
-    pk_dbuf* bufs[] = {&h->d_spk_emb, &h->d_spk_vec, &h->d_tok, &h->d_e1, &h->d_e2, &h->d_tpe, &h->d_hs, &h->d_valid, &h->d_y, &h->d_p0, &h->d_p1,
+    pk_gst_release(h->gst);
+    pk_dbuf* bufs[] = {&h->d_style, &h->d_spk_emb, &h->d_spk_vec, &h->d_tok, &h->d_e1, &h->d_e2, &h->d_tpe, &h->d_hs, &h->d_valid, &h->d_y, &h->d_p0, &h->d_p1,
                        &h->d_x0, &h->d_t, &h->d_ham, &h->d_peb, &h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rf, &h->d_rz,
                        &h->d_probs, &h->d_state, &h->d_seeds, &h->d_att, &h->d_attoff, &h->d_before, &h->d_q1, &h->d_q2,
                        &h->d_rowmap, &h->d_stage, &h->d_stage2};

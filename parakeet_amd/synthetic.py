@@ -428,6 +428,29 @@ def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, 
         cout = odim if j == n - 1 else ch
         st[f"postnet.postnet.{j}.0.weight"] = _xavier(rng, (cout, cin, kf))
         bn(f"postnet.postnet.{j}.1", cout)
+    if cfg.get("use_gst"):   # StyleEncoder (modules/style_encoder.py), idim = odim, gst_token_dim = adim (:299-310)
+        chans = list(cfg.get("gst_conv_chans_list", (32, 32, 64, 64, 128, 128)))
+        kk, stride = cfg.get("gst_conv_kernel_size", 3), cfg.get("gst_conv_stride", 2)
+        F = odim
+        for i, co in enumerate(chans):
+            st[f"gst.ref_enc.convs.{3 * i}.weight"] = _xavier(rng, (co, 1 if i == 0 else chans[i - 1], kk, kk))
+            bn(f"gst.ref_enc.convs.{3 * i + 1}", co)
+            F = (F - kk + 2 * ((kk - 1) // 2)) // stride + 1
+        Hg = cfg.get("gst_gru_units", 128)
+        for l in range(cfg.get("gst_gru_layers", 1)):
+            isz = F * chans[-1] if l == 0 else Hg
+            kq = 1.0 / math.sqrt(Hg)
+            for nm, shape in (("weight_ih", (3 * Hg, isz)), ("weight_hh", (3 * Hg, Hg)), ("bias_ih", (3 * Hg,)),
+                              ("bias_hh", (3 * Hg,))):
+                w = rng.uniform(-kq, kq, size=shape).astype(np.float32)
+                st[f"gst.ref_enc.gru.{l}.cell.{nm}"] = w
+                st[f"gst.ref_enc.gru.{nm}_l{l}"] = w      # paddle registers every cell parameter twice (as nn.LSTM)
+        heads, tokens = cfg.get("gst_heads", 4), cfg.get("gst_tokens", 10)
+        st["gst.stl.gst_embs"] = rng.standard_normal((tokens, A // heads)).astype(np.float32)
+        lin("gst.stl.mha.linear_q", Hg, A)
+        lin("gst.stl.mha.linear_k", A // heads, A)
+        lin("gst.stl.mha.linear_v", A // heads, A)
+        lin("gst.stl.mha.linear_out", A, A)
     D = cfg.get("spk_embed_dim")
     if D:   # :313-317
         lin("projection", D if cfg.get("spk_embed_integration_type", "add") == "add" else A + D, A)

@@ -3,7 +3,7 @@
 Mirrors parakeet/models/transformer_tts/transformer_tts.py: ``TransformerTTS`` (constructor kwargs :172-250,
 ``set_state_dict``, ``eval``, ``inference`` :511-647 -> (outs, probs, att_ws)) and ``TransformerTTSInference``
 (:757-767).  All arithmetic runs in libpk_synth.so (csrc/tts.hip on the shared transformer machinery of csrc/fs2.hip).
-Training (``forward`` / loss), teacher forcing and GST are out of scope.
+Training (``forward`` / loss) and teacher forcing are out of scope.
 
 The reference's decoder prenet keeps dropout on at inference (modules/tacotron2/decoder.py:78-81), so its output
 depends on Paddle's random generator.  Here the mask comes from the engine's counter-based dropout stream
@@ -73,6 +73,18 @@ class TransformerTTS:
         cfg.reduction_factor = reduction_factor
         cfg.spk_embed_dim = 0 if spk_embed_dim is None else int(spk_embed_dim)
         cfg.use_gst = 1 if use_gst else 0
+        self.use_gst = bool(use_gst)
+        if use_gst:
+            chans = [int(v) for v in gst_conv_chans_list]
+            if len(chans) != gst_conv_layers:   # style_encoder.py:153-155
+                raise ValueError("the number of conv layers and length of channels list must be the same.")
+            if len(chans) > 8:
+                raise NotImplementedError("at most 8 reference-encoder conv layers")
+            cfg.gst_tokens, cfg.gst_heads = gst_tokens, gst_heads
+            cfg.gst_conv_layers, cfg.gst_conv_kernel_size, cfg.gst_conv_stride = gst_conv_layers, gst_conv_kernel_size, gst_conv_stride
+            cfg.gst_gru_layers, cfg.gst_gru_units = gst_gru_layers, gst_gru_units
+            for i, v in enumerate(chans):
+                cfg.gst_conv_chans[i] = v
         cfg.spk_embed_integration_type = 1 if spk_embed_integration_type == "concat" else 0
         h = C.c_void_p()
         _capi.check(self._ctx.lib.pk_tts_create(self._ctx.handle, C.byref(cfg), C.byref(h)))
@@ -120,12 +132,21 @@ class TransformerTTS:
             self._finalized = True
 
     def inference_batch(self, texts, threshold=0.5, minlenratio=0.0, maxlenratio=10.0, seeds=None,
-                        return_att=True, denormalize=False, spembs=None):
+                        return_att=True, denormalize=False, spembs=None, speech=None):
         """Lists of (T_b,) token ids (without <eos>) -> list of (outs (L_b, odim), probs (L_b,),
         att_ws (dlayers, aheads, L_b / reduction_factor, T_b + 1) or None) device tensors.  ``spembs``: (B, spk_embed_dim), one speaker
-        embedding per utterance, for a model built with ``spk_embed_dim``."""
+        embedding per utterance, for a model built with ``spk_embed_dim``.  ``speech``: list of (L_b, odim) reference
+        spectrograms, one per utterance, for a ``use_gst`` model."""
         ctx = Context.get(self._ctx.device)
         self._finalize()
+        if speech is not None and self.use_gst:
+            refs = [to_numpy_f32(y).reshape(-1, self.odim) for y in speech]
+            if len(refs) != len(texts):
+                raise ValueError("one reference spectrogram per utterance")
+            rl = np.array([r.shape[0] for r in refs], dtype=np.int32)
+            flat_ref = np.ascontiguousarray(np.concatenate(refs, axis=0))
+            _capi.check(ctx.lib.pk_tts_set_style_reference(self._h, _capi.fptr(flat_ref), rl.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                           len(refs)))
         if spembs is not None:
             e = to_numpy_f32(spembs).reshape(len(texts), -1)
             if e.shape[1] != (self.spk_embed_dim or 0):
@@ -173,9 +194,10 @@ class TransformerTTS:
         """(T,) int64 -> (outs (L, odim), probs (L,), att_ws (#layers, #heads, L, T + 1)); transformer_tts.py:511-647."""
         if use_teacher_forcing:
             raise NotImplementedError("teacher forcing needs the training graph (transformer_tts.py:568-582)")
-        # ``speech`` feeds teacher forcing and the style encoder only (:552-582); both are refused above / at construction
+        # ``speech`` feeds teacher forcing (refused above) and the style encoder (:552-588); ignored otherwise
         return self.inference_batch([text], threshold, minlenratio, maxlenratio, [seed], True, denormalize,
-                                    None if spembs is None else to_numpy_f32(spembs).reshape(1, -1))[0]
+                                    None if spembs is None else to_numpy_f32(spembs).reshape(1, -1),
+                                    None if (speech is None or not self.use_gst) else [speech])[0]
 
     def debug_tap(self, what, b):
         """0: encoder output (T_b + 1, adim); 1: outs before the postnet (L_b, odim); 2: last decoder layer (L_b, adim)."""

@@ -37,6 +37,13 @@ TTS_CASES = [
      dict(maxlenratio=1.5)),
     ("r3stop", dict(elayers=1, dlayers=1, postnet_layers=0, reduction_factor=3), 40, 6, 21, dict(stop_bias=-3.1, stop_gain=2.0),
      dict(maxlenratio=6.0, threshold=0.5)),
+    # global style tokens: the style embedding of a reference spectrogram (standard_normal((L, 80)) of rng(950 + seed),
+    # L = 70 -> 2 GRU steps after six stride-2 convs) is added to the encoder output (:586-588); with a speaker embedding
+    ("gst", dict(elayers=1, dlayers=1, postnet_layers=0, use_gst=True), 40, 5, 22, dict(stop_bias=-6.0), dict(maxlenratio=1.0)),
+    ("gst_small", dict(elayers=1, dlayers=1, postnet_layers=0, use_gst=True, gst_tokens=6, gst_heads=2, gst_conv_layers=3,
+                       gst_conv_chans_list=(8, 16, 16), gst_conv_kernel_size=5, gst_conv_stride=3, gst_gru_layers=2,
+                       gst_gru_units=48, spk_embed_dim=32, spk_embed_integration_type="add"), 40, 4, 23, dict(stop_bias=-6.0),
+     dict(maxlenratio=1.0)),
 ]
 
 # Tacotron2: name, config overrides on synthetic.TACOTRON2_LJSPEECH, tokens, seed (weights, ids = 800 + seed, dropout

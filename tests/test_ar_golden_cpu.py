@@ -38,7 +38,8 @@ def test_transformer_tts_oracle_matches_reference_source():
         cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, **over)
         state = syn.transformer_tts_state(idim, 80, cfg, seed=seed, **skw)
         mel, probs, att = tt.inference(state, g[f"{name}_ids"], cfg, seed=seed,
-                                       spembs=g[f"{name}_spemb"] if cfg.get("spk_embed_dim") else None, **kw)
+                                       spembs=g[f"{name}_spemb"] if cfg.get("spk_embed_dim") else None,
+                                       speech=g[f"{name}_speech"] if cfg.get("use_gst") else None, **kw)
         assert mel.shape == g[f"{name}_mel"].shape, name          # same stop decision
         assert np.abs(mel.numpy() - g[f"{name}_mel"]).max() < 2e-5, name
         assert np.abs(probs.numpy() - g[f"{name}_probs"]).max() < 1e-5, name

@@ -40,7 +40,8 @@ def test_engine_matches_reference_source(case, math):
     cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, **over)
     m = _model(cfg, idim, syn.transformer_tts_state(idim, 80, cfg, seed=seed, **skw), math)
     mel, probs, att = m.inference(g[f"{name}_ids"], seed=seed,
-                                  spembs=g[f"{name}_spemb"] if cfg.get("spk_embed_dim") else None, **kw)
+                                  spembs=g[f"{name}_spemb"] if cfg.get("spk_embed_dim") else None,
+                                  speech=g[f"{name}_speech"] if cfg.get("use_gst") else None, **kw)
     assert mel.shape == g[f"{name}_mel"].shape                      # same stop decision
     assert _close(mel.numpy(), g[f"{name}_mel"])                    # mel L1 bar of the north star
     assert np.abs(probs.numpy() - g[f"{name}_probs"]).max() < 1e-4
@@ -110,8 +111,8 @@ def test_dropout_switch_normalizer_and_errors():
     assert np.abs(lm - (raw * sigma + mu)).max() < 1e-5
     with pytest.raises(NotImplementedError):
         TransformerTTS(idim=40, odim=80, **dict(cfg, reduction_factor=32))
-    with pytest.raises(NotImplementedError):
-        TransformerTTS(idim=40, odim=80, **dict(cfg, use_gst=True))
+    with pytest.raises(ValueError):
+        TransformerTTS(idim=40, odim=80, **dict(cfg, use_gst=True, gst_conv_layers=2))   # 2 layers, 6 channel entries
     with pytest.raises(NotImplementedError):
         TransformerTTS(idim=40, odim=80, **dict(cfg, spk_embed_dim=64, spk_embed_integration_type="mul"))
     with pytest.raises(ValueError):
@@ -165,3 +166,25 @@ def test_reduction_factor_ragged_batch():
         assert np.abs(att.numpy() - ratt.numpy()).max() < 1e-4
         lens.append(int(mel.shape[0]))
     assert lens == [20, 12, 2]                                                   # maxlen, maxlen, stop token at step 1
+
+
+def test_style_tokens_ragged_batch():
+    """use_gst: reference spectrograms of different lengths (1 .. 3 GRU steps after the stride-2 conv stack, one of them a
+    single frame), one per utterance; a two-layer GRU; the conditioning is per call."""
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=1, postnet_layers=0, use_gst=True, gst_tokens=7, gst_heads=4,
+               gst_conv_layers=4, gst_conv_chans_list=(8, 8, 16, 16), gst_gru_layers=2, gst_gru_units=32)
+    state = syn.transformer_tts_state(40, 80, cfg, seed=61, stop_bias=-6.0)
+    m = _model(cfg, 40, state)
+    rng = np.random.default_rng(62)
+    texts = [syn.phoneme_ids(T, idim=40, seed=600 + T) for T in (4, 6, 3)]
+    refs = [rng.standard_normal((L, 80)).astype(np.float32) for L in (33, 1, 17)]
+    outs = m.inference_batch(texts, maxlenratio=1.0, seeds=[1, 2, 3], speech=refs)
+    for b, (t, (mel, probs, att)) in enumerate(zip(texts, outs)):
+        ref, rprobs, ratt, parts = tt.inference(state, t, cfg, maxlenratio=1.0, seed=b + 1, dtype=torch.float64,
+                                                speech=refs[b], return_parts=True)
+        assert np.abs(m.debug_tap(0, b) - parts["hs"].numpy()).max() < 1e-4      # encoder output + style embedding
+        assert _close(mel.numpy(), ref.numpy())
+    with pytest.raises(ValueError):
+        m.inference_batch(texts, maxlenratio=1.0)                                # a use_gst model needs its references
+    one = m.inference(texts[2], speech=refs[2], maxlenratio=1.0, seed=3)
+    assert np.abs(one[0].numpy() - outs[2][0].numpy()).max() < 1e-5

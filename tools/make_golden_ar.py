@@ -64,11 +64,15 @@ def golden_transformer_tts():
         if cfg.get("spk_embed_dim"):
             spemb = np.random.default_rng(900 + seed).standard_normal(cfg["spk_embed_dim"]).astype(np.float32)
             out[f"{name}_spemb"] = spemb
+        speech = None
+        if cfg.get("use_gst"):
+            speech = np.random.default_rng(950 + seed).standard_normal((70, 80)).astype(np.float32)
+            out[f"{name}_speech"] = speech
         PF.DROPOUT_HOOK = TransformerTTSDropout(seed=seed, n_layers=max(cfg["dprenet_layers"], 1), units=cfg["dprenet_units"])
         try:
             with paddle.no_grad():
                 mel, probs, att = model.inference(paddle.to_tensor(ids), spembs=None if spemb is None else paddle.to_tensor(spemb),
-                                                  **kw)
+                                                  speech=None if speech is None else paddle.to_tensor(speech), **kw)
         finally:
             PF.DROPOUT_HOOK = None
         out[f"{name}_ids"] = ids
