@@ -184,7 +184,7 @@ typedef struct {
     int32_t postnet_layers, postnet_chans, postnet_filts;
     int32_t use_batch_norm;
     int32_t use_scaled_pos_enc;
-    int32_t encoder_normalize_before, decoder_normalize_before;  /* 1 only */
+    int32_t encoder_normalize_before, decoder_normalize_before;  /* 0: post-norm blocks, no after_norm (encoder.py:142-143) */
     int32_t reduction_factor;                                    /* 1 only */
     /* multi-speaker recipes (aishell3 / vctk: spk_embed_dim 256, "concat"): spk_embedding_table
      * [num_speakers, spk_embed_dim] (padding_idx 0) + spk_projection (fastspeech2.py:147-151,190-194). */
@@ -197,6 +197,7 @@ typedef struct {
     int32_t num_tones;
     int32_t tone_embed_dim;              /* 0 = no tone embedding */
     int32_t tone_embed_integration_type; /* 0 = "add" only */
+    int32_t encoder_concat_after, decoder_concat_after;   /* concat_linear after the self-attention (encoder_layer.py:103-106) */
 } pk_fs2_cfg;
 
 int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out);
@@ -332,8 +333,8 @@ void pk_ss_destroy(pk_ss* h);
 /* TransformerTTS(idim, odim, **model_cfg) -- parakeet/models/transformer_tts/transformer_tts.py:172-358.
  * Built: the embedding or conv-prenet encoder input layer, pre-norm blocks, the decoder prenet, the stop token,
  * the postnet, speaker embeddings ("add" / "concat"), both positional encodings, the "linear" decoder input layer
- * (dprenet_layers == 0), reduction_factor >= 1, global style tokens (use_gst: modules/style_encoder.py).  Refused with
- * PK_EUNSUPPORTED: post-norm / concat_after blocks. */
+ * (dprenet_layers == 0), reduction_factor >= 1, global style tokens (use_gst: modules/style_encoder.py), post-norm and
+ * concat_after blocks in the encoder and the decoder (encoder_layer.py:64-115, decoder_layer.py:104-151). */
 typedef struct {
     int32_t idim, odim;
     int32_t embed_dim, eprenet_conv_layers, eprenet_conv_chans, eprenet_conv_filts;   /* layers 0: nn.Embedding(idim, adim) (:272-277) */

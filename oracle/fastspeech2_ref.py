@@ -86,18 +86,28 @@ def conv_ffn(W, x):
     return linear(h, W["w_2.weight"], W["w_2.bias"])
 
 
-def encoder_layer(W, x, mask, n_head):
-    """EncoderLayer.forward encoder_layer.py:64-115 (normalize_before=True,
-    concat_after=False, no cache, dropout off)."""
+def encoder_layer(W, x, mask, n_head, normalize_before=True, concat_after=False):
+    """EncoderLayer.forward encoder_layer.py:64-115 (no cache, dropout off)."""
     residual = x
-    h = layer_norm(x, W["norm1.weight"], W["norm1.bias"])
-    x = residual + attention(W.sub("self_attn."), h, mask, n_head)
+    if normalize_before:
+        x = layer_norm(x, W["norm1.weight"], W["norm1.bias"])
+    att = attention(W.sub("self_attn."), x, mask, n_head)
+    if concat_after:                                                          # :103-106
+        x = residual + linear(torch.cat([x, att], dim=-1), W["concat_linear.weight"], W["concat_linear.bias"])
+    else:
+        x = residual + att
+    if not normalize_before:
+        x = layer_norm(x, W["norm1.weight"], W["norm1.bias"])
     residual = x
-    h = layer_norm(x, W["norm2.weight"], W["norm2.bias"])
-    return residual + conv_ffn(W.sub("feed_forward."), h)
+    if normalize_before:
+        x = layer_norm(x, W["norm2.weight"], W["norm2.bias"])
+    x = residual + conv_ffn(W.sub("feed_forward."), x)
+    if not normalize_before:
+        x = layer_norm(x, W["norm2.weight"], W["norm2.bias"])
+    return x
 
 
-def encoder(W, xs, mask, n_layers, n_head, embed_ids):
+def encoder(W, xs, mask, n_layers, n_head, embed_ids, normalize_before=True, concat_after=False):
     """Encoder.forward encoder.py:171-192.  embed_ids=True: input_layer is
     nn.Embedding(padding_idx=0) followed by ScaledPositionalEncoding (embed.0 /
     embed.1); False: positional encoding only (embed.0) -- fastspeech2.py:250-266."""
@@ -109,7 +119,9 @@ def encoder(W, xs, mask, n_layers, n_head, embed_ids):
     else:
         x = scaled_posenc(W.sub("embed.0."), xs)
     for i in range(n_layers):
-        x = encoder_layer(W.sub(f"encoders.{i}."), x, mask, n_head)
+        x = encoder_layer(W.sub(f"encoders.{i}."), x, mask, n_head, normalize_before, concat_after)
+    if not normalize_before:                                                  # encoder.py:190-191
+        return x
     return layer_norm(x, W["after_norm.weight"], W["after_norm.bias"])
 
 
@@ -201,7 +213,8 @@ def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts
     ilens = [int(x.shape[0])]                       # :519-521
     xs = x.unsqueeze(0)                             # :522
     x_masks = make_non_pad_mask(ilens).unsqueeze(-2)  # _source_mask :618-641
-    hs = encoder(W.sub("encoder."), xs, x_masks, cfg["elayers"], cfg["aheads"], True)  # :393
+    hs = encoder(W.sub("encoder."), xs, x_masks, cfg["elayers"], cfg["aheads"], True,
+                 cfg.get("encoder_normalize_before", True), cfg.get("encoder_concat_after", False))  # :393
     if cfg.get("spk_embed_dim") is not None:        # :396-402
         emb = None
         if spembs is not None:
@@ -233,7 +246,8 @@ def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts
                     padding=(ke - 1) // 2).transpose(1, 2)               # :428-429
     hs2 = hs + e_embs + p_embs                      # :430
     hs_up = length_regulate(hs2, d_outs, alpha)     # :432
-    zs = encoder(W.sub("decoder."), hs_up, None, cfg["dlayers"], cfg["aheads"], False)  # :455 (h_masks=None)
+    zs = encoder(W.sub("decoder."), hs_up, None, cfg["dlayers"], cfg["aheads"], False,
+                 cfg.get("decoder_normalize_before", True), cfg.get("decoder_concat_after", False))  # :455 (h_masks=None)
     before = linear(zs, W["feat_out.weight"], W["feat_out.bias"])        # :457
     after = before + postnet(W.sub("postnet."), before.transpose(1, 2),
                              cfg["postnet_layers"]).transpose(1, 2)      # :463-464

@@ -109,7 +109,10 @@ def encode(W, ids, cfg):
     """Encoder.forward encoder.py:171-192 with masks=None (transformer_tts.py:585)."""
     x = encoder_input(W, ids, cfg)
     for i in range(cfg["elayers"]):
-        x = encoder_layer(W.sub(f"encoders.{i}."), x, None, cfg["aheads"])
+        x = encoder_layer(W.sub(f"encoders.{i}."), x, None, cfg["aheads"], cfg.get("encoder_normalize_before", True),
+                          cfg.get("encoder_concat_after", False))
+    if not cfg.get("encoder_normalize_before", True):                            # encoder.py:190-191
+        return x
     return layer_norm(x, W["after_norm.weight"], W["after_norm.bias"])
 
 
@@ -194,24 +197,37 @@ def style_encoder(W, speech, cfg):
     return linear(ctx, M["linear_out.weight"], M["linear_out.bias"]).squeeze(1)
 
 
-def decoder_layer_step(W, tgt, memory, cache, n_head):
-    """DecoderLayer.forward decoder_layer.py:74-158, normalize_before=True, concat_after=False.
+def decoder_layer_step(W, tgt, memory, cache, n_head, normalize_before=True, concat_after=False):
+    """DecoderLayer.forward decoder_layer.py:74-158.
     tgt (1, s, D); cache (1, s-1, D) or None.  Returns (x (1, s, D), src attention weights (H, T) of the last row)."""
     residual = tgt
-    t = layer_norm(tgt, W["norm1.weight"], W["norm1.bias"])
+    t = layer_norm(tgt, W["norm1.weight"], W["norm1.bias"]) if normalize_before else tgt
     if cache is None:
         tq = t
     else:
         tq = t[:, -1:, :]
         residual = residual[:, -1:, :]
-    x = residual + mha(W.sub("self_attn."), tq, t, n_head)[0]
+    a = mha(W.sub("self_attn."), tq, t, n_head)[0]
+    if concat_after:                                                               # :126-129
+        x = residual + linear(torch.cat([tq, a], dim=-1), W["concat_linear1.weight"], W["concat_linear1.bias"])
+    else:
+        x = residual + a
+    if not normalize_before:
+        x = layer_norm(x, W["norm1.weight"], W["norm1.bias"])
     residual = x
-    h = layer_norm(x, W["norm2.weight"], W["norm2.bias"])
+    h = layer_norm(x, W["norm2.weight"], W["norm2.bias"]) if normalize_before else x
     a, attn = mha(W.sub("src_attn."), h, memory, n_head)
-    x = residual + a
+    if concat_after:                                                               # :139-142
+        x = residual + linear(torch.cat([h, a], dim=-1), W["concat_linear2.weight"], W["concat_linear2.bias"])
+    else:
+        x = residual + a
+    if not normalize_before:
+        x = layer_norm(x, W["norm2.weight"], W["norm2.bias"])
     residual = x
-    h = layer_norm(x, W["norm3.weight"], W["norm3.bias"])
+    h = layer_norm(x, W["norm3.weight"], W["norm3.bias"]) if normalize_before else x
     x = residual + conv_ffn(W.sub("feed_forward."), h)
+    if not normalize_before:
+        x = layer_norm(x, W["norm3.weight"], W["norm3.bias"])
     if cache is not None:
         x = torch.cat([cache, x], dim=1)
     return x, attn[0, :, -1]
@@ -254,11 +270,14 @@ def inference(state, ids, cfg=None, threshold=0.5, minlenratio=0.0, maxlenratio=
             cache = [None] * cfg["dlayers"]
         new_cache, att_step = [], []
         for l in range(cfg["dlayers"]):                                            # decoder.py:214-218
-            xdec, a = decoder_layer_step(D.sub(f"decoders.{l}."), xdec, hs, cache[l], cfg["aheads"])
+            xdec, a = decoder_layer_step(D.sub(f"decoders.{l}."), xdec, hs, cache[l], cfg["aheads"],
+                                         cfg.get("decoder_normalize_before", True), cfg.get("decoder_concat_after", False))
             new_cache.append(xdec)
             att_step.append(a)
         cache = new_cache
-        z = layer_norm(xdec[:, -1], D["after_norm.weight"], D["after_norm.bias"])  # decoder.py:220-221
+        z = xdec[:, -1]
+        if cfg.get("decoder_normalize_before", True):
+            z = layer_norm(z, D["after_norm.weight"], D["after_norm.bias"])        # decoder.py:220-221
         out = linear(z, W["feat_out.weight"], W["feat_out.bias"]).reshape(r, odim)  # :613-615
         outs.append(out)
         probs.append(torch.sigmoid(linear(z, W["prob_out.weight"], W["prob_out.bias"]))[0])   # :616  (r,)

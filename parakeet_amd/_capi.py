@@ -51,7 +51,7 @@ class Fs2Cfg(C.Structure):
         "postnet_layers", "postnet_chans", "postnet_filts",
         "use_batch_norm", "use_scaled_pos_enc", "encoder_normalize_before", "decoder_normalize_before",
         "reduction_factor", "num_speakers", "spk_embed_dim", "spk_embed_integration_type", "num_tones", "tone_embed_dim",
-        "tone_embed_integration_type")]
+        "tone_embed_integration_type", "encoder_concat_after", "decoder_concat_after")]
 
 
 class WfCfg(C.Structure):

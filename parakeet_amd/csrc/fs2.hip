@@ -899,8 +899,6 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
     if (c.reduction_factor != 1) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: reduction_factor != 1 not implemented");
     if (c.pitch_embed_kernel_size != 1 || c.energy_embed_kernel_size != 1)
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: pitch/energy_embed_kernel_size must be 1 (all reference recipes)");
-    if (!c.encoder_normalize_before || !c.decoder_normalize_before)
-        PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: post-norm blocks not implemented");
     if (c.tone_embed_dim < 0 || c.num_tones < 0) PK_FAIL(PK_EINVAL, "FastSpeech2: negative tone sizes");
     if (c.tone_embed_dim > 0 && c.num_tones <= 0) PK_FAIL(PK_EINVAL, "FastSpeech2: tone_embed_dim needs num_tones");
     if (c.tone_embed_dim > 0 && c.tone_embed_integration_type != 0)
@@ -1056,7 +1054,8 @@ int pk_fft_add_postnet(Arena& ar, const pk_param_map& P, const std::string& pref
 }
 
 int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A, int units,
-                  int k, int ff_type, int heads, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b) {
+                  int k, int ff_type, int heads, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b,
+                  bool normalize_before, bool concat_after) {
     out.resize(n_layers);
     for (int l = 0; l < n_layers; ++l) {
         const std::string p = prefix + ".encoders." + std::to_string(l);
@@ -1093,6 +1092,16 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
         PK_TRY(pk_get_weight(P, p + ".self_attn.linear_out", {A, A}, wo));
         PK_TRY(pk_get_vector(P, p + ".self_attn.linear_out.bias", A, bo));
         PK_TRY(pk_fft_add_dense_kn(ar, wo, &bo, A, 1, A, L.out));
+        L.concat = concat_after;
+        if (concat_after) {
+            // concat_linear: Linear(2A -> A) on cat(x, attention output) = x . W[:A] + att . W[A:] + b (encoder_layer.py:103-106)
+            std::vector<float> w, b;
+            PK_TRY(pk_get_weight(P, p + ".concat_linear", {2 * A, A}, w));
+            PK_TRY(pk_get_vector(P, p + ".concat_linear.bias", A, b));
+            std::vector<float> wx(w.begin(), w.begin() + (size_t)A * A), wa(w.begin() + (size_t)A * A, w.end());
+            PK_TRY(pk_fft_add_dense_kn(ar, wx, &b, A, 1, A, L.cat_x));
+            PK_TRY(pk_fft_add_dense_kn(ar, wa, nullptr, A, 1, A, L.cat_a));
+        }
         // position-wise layer (encoder.py:145-170): conv1d = (k, k), conv1d-linear = (k, Linear), linear = 2 x Linear
         if (ff_type == 1) {
             std::vector<float> w, b;
@@ -1111,8 +1120,10 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
             PK_TRY(pk_fft_add_dense_kn(ar, w, &b, units, 1, A, L.ffn2));
         }
     }
-    PK_TRY(pk_fft_add_vec(ar, P, prefix + ".after_norm.weight", A, after_g));
-    PK_TRY(pk_fft_add_vec(ar, P, prefix + ".after_norm.bias", A, after_b));
+    if (normalize_before) {   // after_norm exists only then (encoder.py:142-143)
+        PK_TRY(pk_fft_add_vec(ar, P, prefix + ".after_norm.weight", A, after_g));
+        PK_TRY(pk_fft_add_vec(ar, P, prefix + ".after_norm.bias", A, after_b));
+    }
     return PK_OK;
 }
 
@@ -1184,9 +1195,9 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
         h->xscale = std::sqrt((float)A);  // PositionalEncoding.forward embedding.py:78
     }
     PK_TRY(pk_fft_add_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->enc,
-                         h->enc_after_g, h->enc_after_b));
+                         h->enc_after_g, h->enc_after_b, c.encoder_normalize_before != 0, c.encoder_concat_after != 0));
     PK_TRY(pk_fft_add_stack(ar, P, "decoder", c.dlayers, A, c.dunits, c.positionwise_conv_kernel_size, c.positionwise_layer_type, c.aheads, h->dec,
-                         h->dec_after_g, h->dec_after_b));
+                         h->dec_after_g, h->dec_after_b, c.decoder_normalize_before != 0, c.decoder_concat_after != 0));
     PK_TRY(add_predictor(ar, P, "duration_predictor", c.duration_predictor_layers, A, c.duration_predictor_chans,
                          c.duration_predictor_kernel_size, h->dur));
     PK_TRY(add_predictor(ar, P, "pitch_predictor", c.pitch_predictor_layers, A, c.pitch_predictor_chans,
@@ -1350,8 +1361,55 @@ int pk_fft_run_attention(pk_fft_core* h, const Timeline& tl, const float* qkv, f
 }
 
 // N FFT blocks + after_norm on the timeline tl; x is updated in place, result in hs.
+// Post-norm blocks (normalize_before = False, encoder_layer.py:64-115): x = norm1(x + att(x)); x = norm2(x + ffn(x)); no
+// after_norm.  The LayerNorms ping-pong between the two A-wide row buffers (their output is the next residual stream);
+// operand scales of the split-fp16 GEMMs come from passes over the data (the LayerNorm-based magnitude bounds of the
+// pre-norm path do not apply to layer 0's input).
+static int run_stack_postnorm(pk_fft_core* h, const std::vector<FftLayer>& layers, const Timeline& tl, int units, float* hs_out) {
+    const int A = h->adim;
+    PK_TRY(pk_fft_act_reserve(h->d_h, tl.rows, A));
+    PK_TRY(pk_fft_act_reserve(h->d_qkv, tl.rows, 3 * A));
+    PK_TRY(pk_fft_act_reserve(h->d_ctx, tl.rows, A));
+    PK_TRY(pk_fft_act_reserve(h->d_f, tl.rows, units));
+    PK_TRY(pk_fft_act_reserve(h->d_cat, tl.rows, A));
+    float* cur = pk_fft_act_ptr(h->d_x, A);
+    float* alt = pk_fft_act_ptr(h->d_h, A);
+    float* qkv = pk_fft_act_ptr(h->d_qkv, 3 * A);
+    float* ctxb = pk_fft_act_ptr(h->d_ctx, A);
+    float* f = pk_fft_act_ptr(h->d_f, units);
+    float* t = pk_fft_act_ptr(h->d_cat, A);
+    const int* rv = tl.d_row_utt();
+    if (layers.empty()) {
+        PK_HIP(hipMemcpyAsync(hs_out, cur, (size_t)tl.rows * A * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
+        return PK_OK;
+    }
+    for (size_t li = 0; li < layers.size(); ++li) {
+        const FftLayer& L = layers[li];
+        PK_TRY(pk_fft_run_dense(h, "fs2_gemm_qkv", L.qkv, cur, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));
+        PK_TRY(pk_fft_run_attention(h, tl, qkv, ctxb, nullptr));
+        if (L.concat) {
+            // alt = cur + concat_linear(cat(cur, att)); a GEMM must not write the rows it reads, hence the second buffer
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, t, A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_concat_x", L.cat_x, cur, A, alt, A, tl.rows, PK_ACT_NONE, cur, A, nullptr));
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_concat_a", L.cat_a, t, A, alt, A, tl.rows, PK_ACT_NONE, alt, A, nullptr));
+            PK_TRY(pk_fft_run_layernorm(h, alt, L.ln1_g, L.ln1_b, tl, A, cur));
+        } else {
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, cur, A, tl.rows, PK_ACT_NONE, cur, A, nullptr));
+            PK_TRY(pk_fft_run_layernorm(h, cur, L.ln1_g, L.ln1_b, tl, A, alt));
+            std::swap(cur, alt);
+        }
+        PK_TRY(pk_fft_run_dense(h, "fs2_conv_ffn1", L.ffn1, cur, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv));
+        PK_TRY(pk_fft_run_dense(h, "fs2_conv_ffn2", L.ffn2, f, units, cur, A, tl.rows, PK_ACT_NONE, cur, A, nullptr));
+        float* dst = li + 1 == layers.size() ? hs_out : alt;
+        PK_TRY(pk_fft_run_layernorm(h, cur, L.ln2_g, L.ln2_b, tl, A, dst));
+        std::swap(cur, alt);   // (after the last layer the pointers are dead)
+    }
+    return PK_OK;
+}
+
 int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t after_g, size_t after_b,
-                         const Timeline& tl, int units, float* hs_out) {
+                         const Timeline& tl, int units, float* hs_out, bool normalize_before) {
+    if (!normalize_before) return run_stack_postnorm(h, layers, tl, units, hs_out);
     const int A = h->adim;
     PK_TRY(pk_fft_act_reserve(h->d_h, tl.rows, A));
     PK_TRY(pk_fft_act_reserve(h->d_qkv, tl.rows, 3 * A));
@@ -1397,6 +1455,14 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
                       tl.d_seg_len(), heads, qc, segb, cbnd);
         }
         PK_TRY(pk_fft_run_attention(h, tl, qkv, ctxb, segb));
+        if (L.concat) {
+            // x = x + concat_linear(cat(norm1(x), att)) (encoder_layer.py:103-106)
+            PK_TRY(pk_fft_act_reserve(h->d_cat, tl.rows, A));
+            float* t = pk_fft_act_ptr(h->d_cat, A);
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, t, A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, cbnd));
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_concat_x", L.cat_x, hh, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, ham));
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_concat_a", L.cat_a, t, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
+        } else
         PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, cbnd));
         PK_TRY(pk_fft_run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh, ham));
         PK_TRY(pk_fft_run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv, ham));
@@ -1527,7 +1593,7 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
     float* x = pk_fft_act_ptr(h->d_x, A);
     float* hs = pk_fft_act_ptr(h->d_hs, A);
     PK_TRY(pk_fft_embed(h, "fs2_embed", h->d_tok.as<int>(), tl, h->emb_table, h->alpha_enc, h->xscale, x));
-    PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs, c.encoder_normalize_before != 0));
     // speaker embedding (:396-402)
     if (c.spk_embed_dim > 0 && condB > 0) {
         const int D = c.spk_embed_dim;
@@ -1617,7 +1683,7 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
               h->d_pe.as<float>(), h->alpha_dec, h->xscale, A, x, up_dbg);
     PK_TRY(pk_fft_act_reserve(h->d_zs, tl.rows, A));
     float* zs = pk_fft_act_ptr(h->d_zs, A);
-    PK_TRY(pk_fft_run_stack(h, h->dec, h->dec_after_g, h->dec_after_b, tl, c.dunits, zs));
+    PK_TRY(pk_fft_run_stack(h, h->dec, h->dec_after_g, h->dec_after_b, tl, c.dunits, zs, c.decoder_normalize_before != 0));
     // feat_out (+ row mask: the postnet convolves over it)
     PK_TRY(pk_fft_act_reserve(h->d_before, tl.rows, c.odim));
     float* before = pk_fft_act_ptr(h->d_before, c.odim);

@@ -30,6 +30,10 @@ struct pk_fft_dense {
 struct pk_fft_layer {
     size_t ln1_g, ln1_b, ln2_g, ln2_b;
     pk_fft_dense qkv, out, ffn1, ffn2;
+    // concat_after (encoder_layer.py:103-106): x = residual + concat_linear(cat(x, self_attn(x))) as two dense layers,
+    // the x half (with the bias) and the attention half of the [2A][A] weight
+    bool concat = false;
+    pk_fft_dense cat_x, cat_a;
     float qkv_c1[3 * PK_FFT_MAX_HEADS] = {0}, qkv_c0[3 * PK_FFT_MAX_HEADS] = {0};   // the same bound per (q|k|v, head)
 };
 
@@ -76,12 +80,12 @@ struct pk_fft_core {
     bool no_bounds = false;          // measurement switch (PK_FS2_NO_BOUNDS): block maxima by passes over the data
     int max_len = 0;                 // rows of the positional table
     pk_dbuf d_pe, d_div;
-    pk_dbuf d_x, d_h, d_qkv, d_ctx, d_f, d_lnamax, d_cbnd, d_fbnd, d_segb;
+    pk_dbuf d_x, d_h, d_qkv, d_ctx, d_f, d_lnamax, d_cbnd, d_fbnd, d_segb, d_cat;
 
     const float* W(size_t off) const { return arena.as<float>() + off; }
     void release_core() {
         pk_dbuf* bufs[] = {&arena, &arena16, &d_pe, &d_div, &d_x, &d_h, &d_qkv, &d_ctx, &d_f, &d_lnamax, &d_cbnd,
-                           &d_fbnd, &d_segb};
+                           &d_fbnd, &d_segb, &d_cat};
         for (pk_dbuf* b : bufs) b->release();
     }
 };
@@ -104,10 +108,11 @@ int pk_fft_add_conv_bn(pk_fft_arena& ar, const pk_param_map& P, const std::strin
                        const std::string& bn_base, int Cout, int Cin, int k, pk_fft_dense& d, bool conv_bias = false);
 int pk_fft_add_vec(pk_fft_arena& ar, const pk_param_map& P, const std::string& name, int n, size_t& off);
 // `n_layers` EncoderLayers under prefix + ".encoders.{l}" and prefix + ".after_norm"; ff_type 0 conv1d, 1 linear,
-// 2 conv1d-linear (encoder.py:145-170)
+// 2 conv1d-linear (encoder.py:145-170).  normalize_before = false: post-norm blocks, no after_norm (encoder.py:142-143);
+// concat_after: every layer has a concat_linear (encoder_layer.py:61-62)
 int pk_fft_add_stack(pk_fft_arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int A,
                      int units, int k, int ff_type, int heads, std::vector<pk_fft_layer>& out, size_t& after_g,
-                     size_t& after_b);
+                     size_t& after_b, bool normalize_before = true, bool concat_after = false);
 // Postnet (modules/tacotron2/decoder.py:127-198) under prefix + ".postnet.{j}": Conv1D(no bias) + BatchNorm folded
 int pk_fft_add_postnet(pk_fft_arena& ar, const pk_param_map& P, const std::string& prefix, int n_layers, int odim,
                        int chans, int filts, std::vector<pk_fft_dense>& out);
@@ -129,7 +134,7 @@ int pk_fft_run_attention(pk_fft_core* h, const pk_fft_timeline& tl, const float*
                          const unsigned* seg_bounds = nullptr);
 // N FFT blocks + after_norm on the timeline tl; the residual stream core->d_x is updated in place, result in hs_out
 int pk_fft_run_stack(pk_fft_core* h, const std::vector<pk_fft_layer>& layers, size_t after_g, size_t after_b,
-                     const pk_fft_timeline& tl, int units, float* hs_out);
+                     const pk_fft_timeline& tl, int units, float* hs_out, bool normalize_before = true);
 // hs[r] += v[utterance of r] for the rows of a timeline that belong to an utterance; v: [B][adim]
 int pk_fft_add_rowvec(pk_fft_core* h, const pk_fft_timeline& tl, const float* d_vec, float* hs);
 // Speaker-embedding integration on the rows of a timeline ("add" / "concat"; hs_proj NULL = "add"); fs2.hip

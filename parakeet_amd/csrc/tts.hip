@@ -290,6 +290,7 @@ struct DecLayer {
     size_t ln1_g, ln1_b, ln2_g, ln2_b, ln3_g, ln3_b;
     Dense qkv, out, src_q, src_kv, src_out, ffn1, ffn2;
     RowW r_qkv, r_out, r_src_q, r_src_out, r_ffn1, r_ffn2;
+    RowW r_cat1_x, r_cat1_a, r_cat2_x, r_cat2_a;   // concat_linear1 / 2 (decoder_layer.py:66-68): input half (+ bias), attention half
 };
 }  // namespace
 
@@ -335,7 +336,7 @@ struct pk_tts : pk_fft_core {
     std::vector<long> att_off;
     long att_total = 0;
     pk_dbuf d_tok, d_e1, d_e2, d_tpe, d_hs, d_valid, d_y, d_p0, d_p1, d_x0, d_t, d_ham, d_peb, d_rt, d_rc, d_rx, d_rq,
-        d_rf, d_rz, d_probs, d_state, d_seeds, d_att, d_attoff, d_before, d_q1, d_q2, d_rowmap, d_stage, d_stage2;
+        d_rf, d_rz, d_ra, d_rn, d_probs, d_state, d_seeds, d_att, d_attoff, d_before, d_q1, d_q2, d_rowmap, d_stage, d_stage2;
     std::vector<pk_dbuf> d_qkv_l, d_xc_l, d_mkv_l;
 };
 
@@ -353,10 +354,8 @@ extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
     if (c.adim % 64 != 0 || c.adim > 64 * PK_FFT_LN_MAXPER)
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: adim must be a multiple of 64, <= %d", 64 * PK_FFT_LN_MAXPER);
     if (c.reduction_factor < 1 || c.reduction_factor > 16) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: reduction_factor must be in [1, 16]");
-    if (!c.encoder_normalize_before || !c.decoder_normalize_before)
-        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: post-norm blocks not implemented");
-    if (c.encoder_concat_after || c.decoder_concat_after)
-        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: concat_after not implemented");
+    if ((!c.decoder_normalize_before || c.decoder_concat_after) && getenv("PK_AR_ROWGEMM") && atoi(getenv("PK_AR_ROWGEMM")) == 0)
+        PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: post-norm / concat_after decoder blocks run on the row-GEMM path only");
     if (c.spk_embed_dim < 0 || c.spk_embed_dim > 8192) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: spk_embed_dim must be in [0, 8192]");
     if (c.spk_embed_dim > 0 && c.spk_embed_integration_type != 0 && c.spk_embed_integration_type != 1)
         PK_FAIL(PK_EUNSUPPORTED, "support only add or concat. (transformer_tts.py:753)");
@@ -513,6 +512,24 @@ int add_row_linear(pk_fft_arena& ar, const pk_param_map& P, const std::string& b
     return PK_OK;
 }
 
+// concat_linear{1,2}: Linear(2A -> A) on cat(x, attention output) as two row-GEMM layers, x . W[:A] + b and att . W[A:]
+int add_row_concat(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int A, RowW& rx, RowW& ra) {
+    std::vector<float> w, b, wt;
+    PK_TRY(pk_get_weight(P, base, {2 * A, A}, w));
+    PK_TRY(pk_get_vector(P, base + ".bias", A, b));
+    pk_rowgemm_pack(w.data(), A, A, wt);
+    rx.w = ar.put(wt);
+    rx.b = ar.put(b);
+    rx.K = A;
+    rx.N = A;
+    pk_rowgemm_pack(w.data() + (size_t)A * A, A, A, wt);
+    ra.w = ar.put(wt);
+    ra.b = (size_t)-1;
+    ra.K = A;
+    ra.N = A;
+    return PK_OK;
+}
+
 int add_qkv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A, Dense& d, RowW& r) {
     std::vector<float> wq, wk, wv, bq, bk, bv, kn((size_t)A * 3 * A), bias(3 * A);
     PK_TRY(pk_get_weight(P, p + ".linear_q", {A, A}, wq));
@@ -581,7 +598,8 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
         h->alpha_enc = al[0];
     }
     PK_TRY(pk_fft_add_stack(ar, P, "encoder", c.elayers, A, c.eunits, c.positionwise_conv_kernel_size,
-                            c.positionwise_layer_type, c.aheads, h->enc, h->enc_after_g, h->enc_after_b));
+                            c.positionwise_layer_type, c.aheads, h->enc, h->enc_after_g, h->enc_after_b,
+                            c.encoder_normalize_before != 0, c.encoder_concat_after != 0));
     if (c.use_gst) PK_TRY(pk_gst_finalize(ar, P, "gst", h->gst));
     if (c.spk_embed_dim > 0) {
         // `projection` (:313-317): Linear(D, adim) for "add", Linear(adim + D, adim) on concat([hs, e]) for "concat"
@@ -649,9 +667,15 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
         PK_TRY(add_row_linear(ar, P, p + ".src_attn.linear_out", A, A, L.r_src_out));
         PK_TRY(add_row_linear(ar, P, p + ".feed_forward.w_1", A, c.dunits, L.r_ffn1));
         PK_TRY(add_row_linear(ar, P, p + ".feed_forward.w_2", c.dunits, A, L.r_ffn2));
+        if (c.decoder_concat_after) {
+            PK_TRY(add_row_concat(ar, P, p + ".concat_linear1", A, L.r_cat1_x, L.r_cat1_a));
+            PK_TRY(add_row_concat(ar, P, p + ".concat_linear2", A, L.r_cat2_x, L.r_cat2_a));
+        }
     }
-    PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.weight", A, h->dec_after_g));
-    PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.bias", A, h->dec_after_b));
+    if (c.decoder_normalize_before) {   // after_norm exists only then (decoder.py:168-169)
+        PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.weight", A, h->dec_after_g));
+        PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.bias", A, h->dec_after_b));
+    }
     // feat_out: adim -> odim * reduction_factor, prob_out: adim -> reduction_factor (:348-349)
     PK_TRY(pk_fft_add_linear(ar, P, "feat_out", A, c.odim * c.reduction_factor, h->feat_out));
     PK_TRY(add_row_linear(ar, P, "feat_out", A, c.odim * c.reduction_factor, h->r_feat_out));
@@ -750,7 +774,7 @@ int encode(pk_tts* h, const int64_t* ids, const int32_t* tok_lens, int B, const 
     } else {
         PK_TRY(pk_fft_embed(h, "tts_embed", h->d_tok.as<int>(), tl, h->emb_table, h->alpha_enc, h->xscale, x));
     }
-    PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs));
+    PK_TRY(pk_fft_run_stack(h, h->enc, h->enc_after_g, h->enc_after_b, tl, c.eunits, hs, c.encoder_normalize_before != 0));
     if (c.use_gst) {
         // hs = hs + gst(speech).unsqueeze(1) (:586-588)
         PK_TRY(h->d_style.reserve((size_t)B * A * sizeof(float)));
@@ -835,7 +859,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         PK_TRY(rows_reserve(h->d_qkv_l[l], rowsCap, 3 * A));
         PK_TRY(rows_reserve(h->d_xc_l[l], rowsCap, A));
     }
-    pk_dbuf* rowbufs[] = {&h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rz};
+    pk_dbuf* rowbufs[] = {&h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rz, &h->d_ra, &h->d_rn};
     for (pk_dbuf* rb : rowbufs) PK_TRY(rows_reserve(*rb, B, A));
     PK_TRY(rows_reserve(h->d_rf, B, c.dunits));
     PK_TRY(h->d_probs.reserve((size_t)(rowsCap + B) * RF * sizeof(float)));
@@ -890,6 +914,9 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     float* rx = pk_fft_act_ptr(h->d_rx, A);
     float* rq = pk_fft_act_ptr(h->d_rq, A);
     float* rz = pk_fft_act_ptr(h->d_rz, A);
+    float* ra = pk_fft_act_ptr(h->d_ra, A);
+    float* rn = pk_fft_act_ptr(h->d_rn, A);
+    const bool post = !c.decoder_normalize_before, cat = c.decoder_concat_after != 0;
     float* rf = pk_fft_act_ptr(h->d_rf, c.dunits);
     const int* valid = h->d_valid.as<int>();
     PK_HIP(hipMemsetAsync(Y, 0, (size_t)B * OR * sizeof(float), ctx->stream));   // ys = zeros(1, 1, odim) (:601-602)
@@ -936,14 +963,91 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
                       reinterpret_cast<const float4*>(Tn), reinterpret_cast<const float4*>(PEB), n4, reinterpret_cast<float4*>(X0));
         }
         // layer 0: norm1 and q | k | v of every prefix row
-        PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
-        PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, Tn, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
-                                PK_ACT_NONE, nullptr, 0, nullptr, use_ham ? ham : nullptr));
+        if (!post) {
+            PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, Tn, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
+                                    PK_ACT_NONE, nullptr, 0, nullptr, use_ham ? ham : nullptr));
+        } else {   // post-norm: the self-attention reads the un-normalised rows (decoder_layer.py:104-106)
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, X0, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
+                                    PK_ACT_NONE, nullptr, 0, nullptr));
+        }
         for (int l = 0; l < c.dlayers; ++l) {
             const DecLayer& L = h->dec[l];
             const float* xin = (l == 0 ? X0 : pk_fft_act_ptr(h->d_xc_l[l - 1], A)) + nr * A;
             float* qkv = pk_fft_act_ptr(h->d_qkv_l[l], 3 * A);
             float* xc_new = pk_fft_act_ptr(h->d_xc_l[l], A) + nr * A;
+            if (post || cat) {
+                // post-norm and / or concat_after blocks: the same kernels in the order of decoder_layer.py:104-151.
+                // tq = the new rows of tgt (normed with pre-norm blocks), needed on its own only by concat_linear1
+                const float* tq = xin;
+                if (!post && cat) {
+                    if (l == 0) tq = Tn + nr * A;
+                    else {
+                        PK_TRY(pk_fft_layernorm_rows(h, xin, L.ln1_g, L.ln1_b, valid, B, A, rt, nullptr));
+                        tq = rt;
+                    }
+                }
+                if (l > 0)
+                    PK_TRY(rowgemm("tts_row_qkv", L.r_qkv, xin, A, qkv + nr * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0, L.ln1_g, L.ln1_b, !post));
+                AttnStep a;
+                memset(&a, 0, sizeof(a));
+                a.q = qkv + nr * 3 * A; a.ldq = 3 * A;
+                a.K = qkv + A; a.V = qkv + 2 * A; a.ldkv = 3 * A;
+                a.kbase = nullptr; a.klen = nullptr; a.kstride = B; a.n = s; a.dk = dk; a.scale = att_scale;
+                a.out = rc; a.ldo = A;
+                PK_TRY(attn_step(h, "tts_attn_self", a, H, B, s));
+                float* x1 = post ? rn : rx;   // x after the self-attention sub-block, before its post-norm
+                if (cat) {
+                    PK_TRY(rowgemm("tts_row_attn_out", L.r_out, rc, A, ra, A, PK_ACT_NONE, nullptr, 0, 0, 0, false));
+                    PK_TRY(rowgemm("tts_row_concat1", L.r_cat1_x, tq, A, x1, A, PK_ACT_NONE, xin, A, 0, 0, false));
+                    PK_TRY(rowgemm("tts_row_concat1", L.r_cat1_a, ra, A, x1, A, PK_ACT_NONE, x1, A, 0, 0, false));
+                } else {
+                    PK_TRY(rowgemm("tts_row_attn_out", L.r_out, rc, A, x1, A, PK_ACT_NONE, xin, A, 0, 0, false));
+                }
+                if (post) PK_TRY(pk_fft_layernorm_rows(h, rn, L.ln1_g, L.ln1_b, valid, B, A, rx, nullptr));
+                // rx = x; encoder-decoder attention on x2 = norm2(x) (pre-norm) or x (post-norm)
+                const float* x2 = rx;
+                if (!post && cat) {
+                    PK_TRY(pk_fft_layernorm_rows(h, rx, L.ln2_g, L.ln2_b, valid, B, A, rt, nullptr));
+                    x2 = rt;
+                    PK_TRY(rowgemm("tts_row_src_q", L.r_src_q, rt, A, rq, A, PK_ACT_NONE, nullptr, 0, 0, 0, false));
+                } else {
+                    PK_TRY(rowgemm("tts_row_src_q", L.r_src_q, rx, A, rq, A, PK_ACT_NONE, nullptr, 0, L.ln2_g, L.ln2_b, !post));
+                }
+                const float* mkv = pk_fft_act_ptr(h->d_mkv_l[l], 2 * A);
+                AttnStep a2;
+                memset(&a2, 0, sizeof(a2));
+                a2.q = rq; a2.ldq = A;
+                a2.K = mkv; a2.V = mkv + A; a2.ldkv = 2 * A;
+                a2.kbase = tlk.d_seg_start(); a2.klen = tlk.d_seg_len(); a2.kstride = 1; a2.n = 0; a2.dk = dk; a2.scale = att_scale;
+                a2.out = rc; a2.ldo = A;
+                a2.att = att; a2.att_off = d_attoff; a2.att_cap = d_cap; a2.layer = l; a2.step = s - 1;
+                PK_TRY(attn_step(h, "tts_attn_src", a2, H, B, maxT));
+                float* x3 = post ? rn : rx;
+                if (cat) {
+                    PK_TRY(rowgemm("tts_row_src_out", L.r_src_out, rc, A, ra, A, PK_ACT_NONE, nullptr, 0, 0, 0, false));
+                    PK_TRY(rowgemm("tts_row_concat2", L.r_cat2_x, x2, A, post ? rn : rz, A, PK_ACT_NONE, rx, A, 0, 0, false));
+                    // (pre-norm: x2 may be rt and the sum goes through rz, because a row GEMM must not write the rows it reads)
+                    float* acc = post ? rn : rz;
+                    PK_TRY(rowgemm("tts_row_concat2", L.r_cat2_a, ra, A, acc, A, PK_ACT_NONE, acc, A, 0, 0, false));
+                    x3 = acc;
+                } else {
+                    PK_TRY(rowgemm("tts_row_src_out", L.r_src_out, rc, A, x3, A, PK_ACT_NONE, rx, A, 0, 0, false));
+                }
+                const float* x4 = x3;   // x after the second sub-block
+                if (post) {
+                    PK_TRY(pk_fft_layernorm_rows(h, x3, L.ln2_g, L.ln2_b, valid, B, A, rx, nullptr));
+                    x4 = rx;
+                }
+                PK_TRY(rowgemm("tts_row_ffn1", L.r_ffn1, x4, A, rf, c.dunits, PK_ACT_RELU, nullptr, 0, L.ln3_g, L.ln3_b, !post));
+                if (post) {
+                    PK_TRY(rowgemm("tts_row_ffn2", L.r_ffn2, rf, c.dunits, rn, A, PK_ACT_NONE, x4, A, 0, 0, false));
+                    PK_TRY(pk_fft_layernorm_rows(h, rn, L.ln3_g, L.ln3_b, valid, B, A, xc_new, nullptr));
+                } else {
+                    PK_TRY(rowgemm("tts_row_ffn2", L.r_ffn2, rf, c.dunits, xc_new, A, PK_ACT_NONE, x4, A, 0, 0, false));
+                }
+                continue;
+            }
             if (l > 0) {
                 if (use_rg) {
                     PK_TRY(rowgemm("tts_row_qkv", L.r_qkv, xin, A, qkv + nr * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0, L.ln1_g,
@@ -992,8 +1096,12 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_ffn2", L.ffn2, rf, c.dunits, xc_new, A, B, PK_ACT_NONE, rx, A, nullptr));
         }
         // after_norm of the last row, feat_out -> the next prefix row, prob_out -> stop state (:613-616, :638-642)
-        PK_TRY(pk_fft_layernorm_rows(h, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, h->dec_after_g, h->dec_after_b,
-                                     valid, B, A, rz, use_ham ? ham : nullptr));
+        if (!post)
+            PK_TRY(pk_fft_layernorm_rows(h, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, h->dec_after_g, h->dec_after_b,
+                                         valid, B, A, rz, use_ham ? ham : nullptr));
+        else   // no after_norm with post-norm blocks (decoder.py:220-221): the last layer's row as it is
+            PK_HIP(hipMemcpyAsync(rz, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, (size_t)B * A * sizeof(float),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
         if (use_rg)
             PK_TRY(rowgemm("tts_row_feat_out", h->r_feat_out, rz, A, Y + (long)s * B * OR, OR, PK_ACT_NONE, nullptr, 0, 0, 0, false));
         else
@@ -1139,7 +1247,7 @@ extern "C" void pk_tts_destroy(pk_tts* h) {
     pk_gst_release(h->gst);
     pk_dbuf* bufs[] = {&h->d_style, &h->d_spk_emb, &h->d_spk_vec, &h->d_tok, &h->d_e1, &h->d_e2, &h->d_tpe, &h->d_hs, &h->d_valid, &h->d_y, &h->d_p0, &h->d_p1,
                        &h->d_x0, &h->d_t, &h->d_ham, &h->d_peb, &h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rf, &h->d_rz,
-                       &h->d_probs, &h->d_state, &h->d_seeds, &h->d_att, &h->d_attoff, &h->d_before, &h->d_q1, &h->d_q2,
+                       &h->d_ra, &h->d_rn, &h->d_probs, &h->d_state, &h->d_seeds, &h->d_att, &h->d_attoff, &h->d_before, &h->d_q1, &h->d_q2,
                        &h->d_rowmap, &h->d_stage, &h->d_stage2};
     for (auto* b : bufs) b->release();
     for (auto& b : h->d_qkv_l) b.release();

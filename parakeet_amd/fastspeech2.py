@@ -43,8 +43,6 @@ class FastSpeech2:
             raise ValueError(f"{decoder_type} is not supported.")   # fastspeech2.py:268
         if positionwise_layer_type not in ("conv1d", "linear", "conv1d-linear"):
             raise NotImplementedError("Support only linear or conv1d.")   # encoder.py:169
-        if encoder_concat_after or decoder_concat_after:
-            raise NotImplementedError("concat_after=True is not implemented")
         self.idim, self.odim = idim, odim
         self._adim = adim
         self.eos = idim - 1
@@ -73,6 +71,8 @@ class FastSpeech2:
         cfg.use_scaled_pos_enc = 1 if use_scaled_pos_enc else 0
         cfg.encoder_normalize_before = 1 if encoder_normalize_before else 0
         cfg.decoder_normalize_before = 1 if decoder_normalize_before else 0
+        cfg.encoder_concat_after = 1 if encoder_concat_after else 0
+        cfg.decoder_concat_after = 1 if decoder_concat_after else 0
         cfg.reduction_factor = reduction_factor
         if spk_embed_dim is not None and spk_embed_integration_type not in ("add", "concat"):
             raise NotImplementedError("support only add or concat.")   # fastspeech2.py:584

@@ -98,7 +98,11 @@ def fastspeech2_state(idim=80, odim=80, cfg=None, seed=10086, fixed_duration=Non
             st[f"{p}.feed_forward.w_2.bias"] = small(A)
             ln(f"{p}.norm1", A)
             ln(f"{p}.norm2", A)
-        ln(f"{prefix}.after_norm", A)
+            if cfg.get(f"{prefix}_concat_after"):       # encoder_layer.py:61-62
+                st[f"{p}.concat_linear.weight"] = _xavier(rng, (2 * A, A))
+                st[f"{p}.concat_linear.bias"] = small(A)
+        if cfg.get(f"{prefix}_normalize_before", True):  # encoder.py:142-143
+            ln(f"{prefix}.after_norm", A)
 
     emb = _xavier(rng, (idim, A))
     emb[0] = 0.0  # padding_idx row
@@ -395,7 +399,10 @@ def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, 
         st[f"{p}.feed_forward.w_2.bias"] = small(A)
         ln(p + ".norm1", A)
         ln(p + ".norm2", A)
-    ln("encoder.after_norm", A)
+        if cfg.get("encoder_concat_after"):
+            lin(p + ".concat_linear", 2 * A, A)
+    if cfg.get("encoder_normalize_before", True):
+        ln("encoder.after_norm", A)
     P = cfg["dprenet_units"]
     for j in range(cfg["dprenet_layers"]):
         lin(f"decoder.embed.0.0.prenet.{j}.0", odim if j == 0 else P, P)
@@ -416,7 +423,11 @@ def transformer_tts_state(idim=80, odim=80, cfg=None, seed=4242, stop_bias=0.0, 
         lin(p + ".feed_forward.w_2", cfg["dunits"], A)
         for n in (1, 2, 3):
             ln(f"{p}.norm{n}", A)
-    ln("decoder.after_norm", A)
+        if cfg.get("decoder_concat_after"):   # decoder_layer.py:66-68
+            lin(p + ".concat_linear1", 2 * A, A)
+            lin(p + ".concat_linear2", 2 * A, A)
+    if cfg.get("decoder_normalize_before", True):
+        ln("decoder.after_norm", A)
     r = cfg["reduction_factor"]
     lin("feat_out", A, odim * r)
     lin("prob_out", A, r)

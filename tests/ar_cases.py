@@ -44,6 +44,19 @@ TTS_CASES = [
                        gst_conv_chans_list=(8, 16, 16), gst_conv_kernel_size=5, gst_conv_stride=3, gst_gru_layers=2,
                        gst_gru_units=48, spk_embed_dim=32, spk_embed_integration_type="add"), 40, 4, 23, dict(stop_bias=-6.0),
      dict(maxlenratio=1.0)),
+    # post-norm encoder blocks (no after_norm) / concat_after in the ENCODER stack (encoder_layer.py:64-115)
+    ("enc_postnorm", dict(elayers=2, dlayers=1, postnet_layers=0, encoder_normalize_before=False), 40, 6, 24,
+     dict(stop_bias=-6.0), dict(maxlenratio=1.0)),
+    ("enc_concat", dict(elayers=2, dlayers=1, postnet_layers=0, encoder_concat_after=True), 40, 6, 25, dict(stop_bias=-6.0),
+     dict(maxlenratio=1.0)),
+    # the same in the DECODER blocks (decoder_layer.py:104-151; no decoder after_norm with post-norm blocks)
+    ("dec_postnorm", dict(elayers=1, dlayers=2, postnet_layers=0, decoder_normalize_before=False), 40, 5, 26,
+     dict(stop_bias=-6.0), dict(maxlenratio=1.5)),
+    ("dec_concat", dict(elayers=1, dlayers=2, postnet_layers=0, decoder_concat_after=True), 40, 5, 27, dict(stop_bias=-6.0),
+     dict(maxlenratio=1.5)),
+    ("all_post_concat", dict(elayers=1, dlayers=2, postnet_layers=2, encoder_normalize_before=False, encoder_concat_after=True,
+                             decoder_normalize_before=False, decoder_concat_after=True), 40, 4, 28, dict(stop_bias=-6.0),
+     dict(maxlenratio=1.5)),
 ]
 
 # Tacotron2: name, config overrides on synthetic.TACOTRON2_LJSPEECH, tokens, seed (weights, ids = 800 + seed, dropout

@@ -50,7 +50,7 @@ def test_no_gpu_fails_loudly():
 def test_struct_sizes_match_header():
     from parakeet_amd import _capi
     assert C.sizeof(_capi.PwgCfg) == 4 * (11 + 8 + 1)
-    assert C.sizeof(_capi.Fs2Cfg) == 4 * 35
+    assert C.sizeof(_capi.Fs2Cfg) == 4 * 37
     assert C.sizeof(_capi.WfCfg) == 4 * (1 + 4 + 7)
     assert C.sizeof(_capi.TtsCfg) == 4 * (29 + 7 + 8)   # pk_tts_cfg: 29 int32 fields + 7 + 8 for the style encoder
     assert C.sizeof(_capi.TacoCfg) == 4 * 18 + 4     # pk_taco_cfg: 18 int32 fields + float p_prenet_dropout

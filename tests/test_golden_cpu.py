@@ -53,6 +53,25 @@ def test_fastspeech2_ffn_variants_oracle_matches_reference_source():
             assert np.abs(mel - g[f"{tag}_mel{i}"]).max() < 2e-5
 
 
+FS2_BLOCK_VARIANTS = {   # tools/make_golden.py
+    "postnorm": dict(encoder_normalize_before=False, decoder_normalize_before=False),
+    "concat": dict(encoder_concat_after=True, decoder_concat_after=True),
+    "mixed": dict(encoder_normalize_before=False, encoder_concat_after=True, positionwise_conv_kernel_size=3),
+}
+
+
+def test_fastspeech2_block_variants_oracle_matches_reference_source():
+    g = np.load(os.path.join(GOLD, "fastspeech2_block_variants.npz"))
+    for tag, over in FS2_BLOCK_VARIANTS.items():
+        cfg = dict(syn.FS2_LJSPEECH, elayers=2, dlayers=2, **over)
+        state = syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), fixed_duration=2)
+        assert ("encoder.after_norm.weight" in state) == cfg.get("encoder_normalize_before", True)
+        for i in range(2):
+            mel = fs2.inference(state, g[f"{tag}_ids{i}"], cfg).numpy()
+            assert mel.shape == g[f"{tag}_mel{i}"].shape
+            assert np.abs(mel - g[f"{tag}_mel{i}"]).max() < 2e-5, tag
+
+
 def test_fastspeech2_tone_embedding_oracle_matches_reference_source():
     g = np.load(os.path.join(GOLD, "fastspeech2_tones.npz"))
     cfg = dict(syn.FS2_LJSPEECH, tone_embed_dim=64, tone_embed_integration_type="add")

@@ -1,6 +1,7 @@
 """The HIP engine against the golden vectors produced by the reference's own Python source
 (tools/make_golden.py).  /root/reference is not needed at run time."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -75,6 +76,27 @@ def test_fastspeech2_ffn_variants_engine_matches_reference_source(kind):
         assert np.abs(o.numpy() - g[f"{tag}_mel{i}"]).mean() < 1e-4
     with pytest.raises(NotImplementedError):
         FastSpeech2(80, 80, **dict(cfg, positionwise_layer_type="conv2d"))
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("tag", ["postnorm", "concat", "mixed"])
+def test_fastspeech2_block_variants_engine_matches_reference_source(tag, math):
+    """Post-norm blocks (normalize_before=False: no after_norm) and concat_after in the shared FFT stack."""
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_golden_cpu import FS2_BLOCK_VARIANTS
+    g = np.load(os.path.join(GOLD, "fastspeech2_block_variants.npz"))
+    cfg = dict(syn.FS2_LJSPEECH, elayers=2, dlayers=2, **FS2_BLOCK_VARIANTS[tag])
+    model = FastSpeech2(80, 80, **cfg)
+    model.set_state_dict(syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), fixed_duration=2))
+    model.eval()
+    model.set_math(math)
+    outs = model.inference_batch([g[f"{tag}_ids0"], g[f"{tag}_ids1"]])
+    for i, o in enumerate(outs):
+        assert o.shape == g[f"{tag}_mel{i}"].shape
+        assert np.abs(o.numpy() - g[f"{tag}_mel{i}"]).mean() < 1e-4 and np.abs(o.numpy() - g[f"{tag}_mel{i}"]).max() < 2e-3
+    one = model.inference(g[f"{tag}_ids1"])
+    assert np.abs(one.numpy() - outs[1].numpy()).max() < 1e-5
 
 
 def test_fastspeech2_tone_embedding_engine_matches_reference_source():

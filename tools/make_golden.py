@@ -95,6 +95,34 @@ def golden_fastspeech2_ffn_variants():
     print("fastspeech2 ffn variants:", {k: v.shape for k, v in out.items() if "mel" in k})
 
 
+FS2_BLOCK_VARIANTS = {
+    # name -> overrides: post-norm blocks (no after_norm), concat_after, in the encoder / decoder stacks
+    "postnorm": dict(encoder_normalize_before=False, decoder_normalize_before=False),
+    "concat": dict(encoder_concat_after=True, decoder_concat_after=True),
+    "mixed": dict(encoder_normalize_before=False, encoder_concat_after=True, positionwise_conv_kernel_size=3),
+}
+
+
+def golden_fastspeech2_block_variants():
+    """normalize_before=False and concat_after=True (encoder_layer.py:64-115, encoder.py:142-143, 190-191); no recipe of the
+    reference sets them, the constructor accepts them."""
+    fsm = ref_import.load("parakeet.models.fastspeech2.fastspeech2")
+    out = {"seed": np.array(2028)}
+    for tag, over in FS2_BLOCK_VARIANTS.items():
+        cfg = dict(syn.FS2_LJSPEECH, elayers=2, dlayers=2, **over)
+        state = syn.fastspeech2_state(80, 80, cfg, seed=2028, fixed_duration=2)
+        model = fsm.FastSpeech2(idim=80, odim=80, **cfg)
+        model.set_state_dict(state)
+        model.eval()
+        for i in range(2):
+            ids = syn.phoneme_ids(6 + 5 * i, seed=900 + i)
+            with paddle.no_grad():
+                mel = model.inference(paddle.to_tensor(ids)).numpy()
+            out[f"{tag}_ids{i}"], out[f"{tag}_mel{i}"] = ids, mel.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fastspeech2_block_variants.npz"), **out)
+    print("fastspeech2 block variants:", {k: v.shape for k, v in out.items() if "mel" in k})
+
+
 def golden_fastspeech2_tones():
     """tone_embed_dim 64, "add"; tone ids forwarded as FastSpeech2.inference does (1-D)."""
     fsm = ref_import.load("parakeet.models.fastspeech2.fastspeech2")
@@ -156,6 +184,7 @@ if __name__ == "__main__":
     golden_fastspeech2_multispeaker()
     golden_fastspeech2_ffn_variants()
     golden_fastspeech2_tones()
+    golden_fastspeech2_block_variants()
     golden_pwg()
     if "--with-waveflow" in sys.argv or True:
         try:
