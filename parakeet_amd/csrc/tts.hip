@@ -312,6 +312,8 @@ struct pk_tts : pk_fft_core {
     std::vector<Dense> dprenet;
     Dense dlin, feat_out;
     RowW r_feat_out;
+    Dense kv0;    // layer 0's self-attention k | v only ([A][2A]) and its q as a row-GEMM layer: PK_TTS_KV_PREFIX (see pk_tts_infer)
+    RowW r_q0;
     std::vector<DecLayer> dec;
     size_t prob_w = 0, prob_bv = 0;   // prob_out weight [A][r] and bias [r]
     float prob_b = 0.f;
@@ -672,6 +674,8 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
             PK_TRY(add_row_concat(ar, P, p + ".concat_linear2", A, L.r_cat2_x, L.r_cat2_a));
         }
     }
+    PK_TRY(add_kv(ar, P, "decoder.decoders.0.self_attn", A, h->kv0));
+    PK_TRY(add_row_linear(ar, P, "decoder.decoders.0.self_attn.linear_q", A, A, h->r_q0));
     if (c.decoder_normalize_before) {   // after_norm exists only then (decoder.py:168-169)
         PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.weight", A, h->dec_after_g));
         PK_TRY(pk_fft_add_vec(ar, P, "decoder.after_norm.bias", A, h->dec_after_b));
@@ -928,6 +932,9 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     static const int poll = getenv("PK_TTS_POLL") ? std::max(1, atoi(getenv("PK_TTS_POLL"))) : 4;
     const bool use_ham = h->math == PK_GEMM_MATH_F16X3;
     static const bool use_rg = getenv("PK_AR_ROWGEMM") ? atoi(getenv("PK_AR_ROWGEMM")) != 0 : true;
+    // Experiment, off by default (not yet measured on a GPU): layer 0's query is needed for the NEW rows only, so the
+    // prefix GEMM can project k | v alone (2/3 of its work) and the B new queries come from a row GEMM.
+    const bool kv_prefix = getenv("PK_TTS_KV_PREFIX") ? atoi(getenv("PK_TTS_KV_PREFIX")) != 0 : false;   // read per call
     // y = [LayerNorm(x)] . W + b [ReLU] [+ res] for the B new rows of a step (pk_rowgemm.h)
     auto rowgemm = [&](const char* name, const RowW& w, const float* x, int ldx, float* y, int ldy, int act, const float* res,
                        int ldr, size_t ln_g, size_t ln_b, bool ln) -> int {
@@ -963,7 +970,14 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
                       reinterpret_cast<const float4*>(Tn), reinterpret_cast<const float4*>(PEB), n4, reinterpret_cast<float4*>(X0));
         }
         // layer 0: norm1 and q | k | v of every prefix row
-        if (!post) {
+        if (!post && kv_prefix && use_rg) {
+            float* qkv0 = pk_fft_act_ptr(h->d_qkv_l[0], 3 * A);
+            PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_kv0", h->kv0, Tn, A, qkv0 + A, 3 * A, R, PK_ACT_NONE, nullptr, 0, nullptr,
+                                    use_ham ? ham : nullptr));
+            PK_TRY(rowgemm("tts_row_q0", h->r_q0, X0 + nr * A, A, qkv0 + nr * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0,
+                           h->dec[0].ln1_g, h->dec[0].ln1_b, true));
+        } else if (!post) {
             PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, Tn, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
                                     PK_ACT_NONE, nullptr, 0, nullptr, use_ham ? ham : nullptr));

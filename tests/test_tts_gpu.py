@@ -188,3 +188,20 @@ def test_style_tokens_ragged_batch():
         m.inference_batch(texts, maxlenratio=1.0)                                # a use_gst model needs its references
     one = m.inference(texts[2], speech=refs[2], maxlenratio=1.0, seed=3)
     assert np.abs(one[0].numpy() - outs[2][0].numpy()).max() < 1e-5
+
+
+def test_kv_only_prefix_projection_experiment(monkeypatch):
+    """PK_TTS_KV_PREFIX=1 (off by default): layer 0 projects k | v only for the prefix rows and q for the new rows with a
+    row GEMM; same result as the fused q | k | v projection up to the two GEMM kernels' rounding."""
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=2, postnet_layers=2)
+    state = syn.transformer_tts_state(40, 80, cfg, seed=71, stop_bias=-6.0)
+    m = _model(cfg, 40, state)
+    texts = [syn.phoneme_ids(T, idim=40, seed=700 + T) for T in (5, 3)]
+    base = m.inference_batch(texts, maxlenratio=2.0, seeds=[1, 2])
+    monkeypatch.setenv("PK_TTS_KV_PREFIX", "1")
+    alt = m.inference_batch(texts, maxlenratio=2.0, seeds=[1, 2])
+    for (a, pa, wa), (b, pb, wb) in zip(base, alt):
+        assert a.shape == b.shape and np.abs(a.numpy() - b.numpy()).max() < 2e-4
+        assert np.abs(wa.numpy() - wb.numpy()).max() < 1e-5
+    ref = tt.inference(state, texts[0], cfg, maxlenratio=2.0, seed=1, dtype=torch.float64)[0].numpy()
+    assert _close(alt[0][0].numpy(), ref)
