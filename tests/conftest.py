@@ -30,7 +30,20 @@ def _has_gpu():
         return False
 
 
+# GPU tests of the variants added after the round's GPU minutes were spent: they have run under
+# the host emulation only.  They are moved behind the tests that have run on an MI355X, so that under `-x` a failure among
+# them cannot hide the results of the validated ones.  Remove an entry once its tests have passed on hardware.
+FIRST_GPU_RUN_PENDING = (
+    "spk_add", "spk_concat", "unscaled", "linear_in", "-r2-", "r2-f", "r3stop", "gst", "enc_postnorm", "enc_concat", "dec_postnorm",
+    "dec_concat", "all_post_concat", "[global-", "test_global_condition", "test_speaker_embeddings", "test_reduction_factor",
+    "test_style_tokens", "block_variants", "test_kv_only")
+
+
 def pytest_collection_modifyitems(config, items):
+    pending = [it for it in items if "gpu" in it.keywords and any(k in it.nodeid for k in FIRST_GPU_RUN_PENDING)]
+    if pending:
+        ids = {id(it) for it in pending}
+        items[:] = [it for it in items if id(it) not in ids] + pending
     if _has_gpu() or _emulated():
         return
     skip = pytest.mark.skip(reason="no HIP device in this container")
