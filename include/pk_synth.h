@@ -185,7 +185,7 @@ typedef struct {
     int32_t use_batch_norm;
     int32_t use_scaled_pos_enc;
     int32_t encoder_normalize_before, decoder_normalize_before;  /* 0: post-norm blocks, no after_norm (encoder.py:142-143) */
-    int32_t reduction_factor;                                    /* 1 only */
+    int32_t reduction_factor;                                    /* r mel frames per decoder row (feat_out: adim -> odim * r) */
     /* multi-speaker recipes (aishell3 / vctk: spk_embed_dim 256, "concat"): spk_embedding_table
      * [num_speakers, spk_embed_dim] (padding_idx 0) + spk_projection (fastspeech2.py:147-151,190-194). */
     int32_t num_speakers;                /* 0 with spk_embed_dim: only external embeddings (spembs) */

@@ -21,7 +21,7 @@ and the modules it calls:
 
 Configuration = examples/fastspeech2/ljspeech/conf/default.yaml:33-75
 (transformer encoder/decoder, conv1d position-wise layers, pre-norm, scaled
-positional encoding, no speaker / tone embedding, reduction_factor 1).
+positional encoding, no speaker / tone embedding).
 """
 import math
 
@@ -249,8 +249,12 @@ def inference(state, ids, cfg=None, alpha=1.0, dtype=torch.float32, return_parts
     zs = encoder(W.sub("decoder."), hs_up, None, cfg["dlayers"], cfg["aheads"], False,
                  cfg.get("decoder_normalize_before", True), cfg.get("decoder_concat_after", False))  # :455 (h_masks=None)
     before = linear(zs, W["feat_out.weight"], W["feat_out.bias"])        # :457
-    after = before + postnet(W.sub("postnet."), before.transpose(1, 2),
-                             cfg["postnet_layers"]).transpose(1, 2)      # :463-464
+    odim = before.shape[-1] // cfg.get("reduction_factor", 1)
+    before = before.reshape(before.shape[0], -1, odim)                   # (B, L * r, odim)
+    after = before                                                       # :460-461 (postnet is None)
+    if cfg["postnet_layers"] > 0:
+        after = before + postnet(W.sub("postnet."), before.transpose(1, 2),
+                                 cfg["postnet_layers"]).transpose(1, 2)  # :463-464
     if return_parts:
         return after[0], dict(hs=hs[0], p=p_outs[0, :, 0], e=e_outs[0, :, 0], d=d_outs[0],
                               hs_up=hs_up[0], zs=zs[0], before=before[0])

@@ -766,6 +766,32 @@ __global__ __launch_bounds__(256) void k_add_rowvec(const float* __restrict__ x,
     for (int c = threadIdx.x; c < A; c += blockDim.x) y[(long)r * A + c] = x[(long)r * A + c] + v[(long)b * A + c];
 }
 
+// reduction_factor r > 1: feat_out gives r frames per decoder row ([frame 0 | ... | frame r-1], fastspeech2.py:457:
+// .reshape((B, -1, odim))).  Frame row q of the frame timeline (utterance u, position p) takes columns (p % r) * O .. of
+// decoder row dec_seg_start[u] + p / r; gap rows are zeroed when rowmap == NULL (the postnet convolves over them).
+__global__ __launch_bounds__(128) void k_fs2_unfold_r(const float* __restrict__ wide, int O, int r,
+                                                      const int* __restrict__ dec_seg_start, const int* __restrict__ row_utt,
+                                                      const int* __restrict__ row_pos, const int* __restrict__ rowmap,
+                                                      const float* __restrict__ cscale, const float* __restrict__ cshift,
+                                                      float* __restrict__ dst) {
+    const long q = blockIdx.x;
+    const int u = row_utt[q];
+    const long o = rowmap ? rowmap[q] : q;
+    if (o < 0) return;
+    if (u < 0) {
+        if (!rowmap)
+            for (int c = threadIdx.x; c < O; c += blockDim.x) dst[o * O + c] = 0.f;
+        return;
+    }
+    const int p = row_pos[q];
+    const float* s = wide + ((long)(dec_seg_start[u] + p / r) * r + p % r) * O;
+    for (int c = threadIdx.x; c < O; c += blockDim.x) {
+        float v = s[c];
+        if (cscale) v = v * cscale[c] + cshift[c];
+        dst[o * O + c] = v;
+    }
+}
+
 // hs[r] += ptone[tone[r]] on the rows of the timeline that belong to an utterance
 __global__ __launch_bounds__(256) void k_add_tone(float* __restrict__ hs, const float* __restrict__ ptone,
                                                   const int* __restrict__ tone, const int* __restrict__ row_utt,
@@ -843,7 +869,8 @@ struct pk_fs2 : pk_fft_core {
     bool has_out_affine = false;
     std::vector<float> h_out_scale, h_out_shift;
     // per-call state
-    Timeline tl_tok, tl_frm;
+    Timeline tl_tok, tl_frm, tl_frm2;   // tokens, decoder rows, mel frames (= decoder rows unless reduction_factor > 1)
+    pk_dbuf d_wide, d_rowmap2;
     pk_dbuf d_tok, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
         d_before, d_q1, d_q2, d_rowmap, d_dbg_up, d_zs, d_mel_stage;
     std::vector<int> frames;   // per utterance, result of encode
@@ -896,7 +923,7 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: head size %d not built (64/96/128/192)", dk);
     if (c.adim % 64 != 0 || c.adim > 64 * LN_MAXPER)
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: adim must be a multiple of 64, <= %d", 64 * LN_MAXPER);
-    if (c.reduction_factor != 1) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: reduction_factor != 1 not implemented");
+    if (c.reduction_factor < 1 || c.reduction_factor > 16) PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: reduction_factor must be in [1, 16]");
     if (c.pitch_embed_kernel_size != 1 || c.energy_embed_kernel_size != 1)
         PK_FAIL(PK_EUNSUPPORTED, "FastSpeech2: pitch/energy_embed_kernel_size must be 1 (all reference recipes)");
     if (c.tone_embed_dim < 0 || c.num_tones < 0) PK_FAIL(PK_EINVAL, "FastSpeech2: negative tone sizes");
@@ -1210,9 +1237,10 @@ extern "C" int pk_fs2_finalize(pk_fs2* h) {
     PK_TRY(pk_fft_add_vec(ar, P, "energy_embed.0.bias", A, h->energy_b));
     {
         std::vector<float> w, b;
-        PK_TRY(pk_get_weight(P, "feat_out", {A, c.odim}, w));
-        PK_TRY(pk_get_vector(P, "feat_out.bias", c.odim, b));
-        PK_TRY(pk_fft_add_dense_kn(ar, w, &b, A, 1, c.odim, h->feat_out));
+        const int OR = c.odim * c.reduction_factor;   // feat_out: adim -> odim * reduction_factor (fastspeech2.py:271)
+        PK_TRY(pk_get_weight(P, "feat_out", {A, OR}, w));
+        PK_TRY(pk_get_vector(P, "feat_out.bias", OR, b));
+        PK_TRY(pk_fft_add_dense_kn(ar, w, &b, A, 1, OR, h->feat_out));
     }
     PK_TRY(pk_fft_add_postnet(ar, P, "postnet", c.postnet_layers, c.odim, c.postnet_chans, c.postnet_filts, h->postnet));
     if (c.tone_embed_dim > 0) {
@@ -1635,7 +1663,7 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
     h->frames.resize(B);
     PK_HIP(hipMemcpyAsync(h->frames.data(), h->d_frames.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
     PK_HIP(hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < B; ++b) out_frames[b] = h->frames[b];
+    for (int b = 0; b < B; ++b) out_frames[b] = h->frames[b] * c.reduction_factor;   // mel frames; h->frames: decoder rows
     h->encoded = true;
     return PK_OK;
 }
@@ -1695,6 +1723,48 @@ extern "C" int pk_fs2_decode(pk_fs2* h, float* mel_out, int32_t flags) {
     const bool denorm = h->has_out_affine && (flags & PK_APPLY_NORMALIZER);   // FastSpeech2Inference (:668-671)
     const float* cs = denorm ? h->W(h->out_scale) : nullptr;
     const float* ch = denorm ? h->W(h->out_shift) : nullptr;
+    if (c.reduction_factor > 1) {
+        // feat_out -> (rows, odim * r), unfolded onto a timeline of rows * r frames for the postnet (:457-464)
+        const int RF = c.reduction_factor, O = c.odim;
+        PK_TRY(pk_fft_act_reserve(h->d_wide, tl.rows, O * RF));
+        float* wide = pk_fft_act_ptr(h->d_wide, O * RF);
+        PK_TRY(pk_fft_run_dense(h, "fs2_gemm_feat_out", h->feat_out, zs, A, wide, O * RF, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr));
+        std::vector<int> flens(B);
+        long sumF = 0;
+        for (int b = 0; b < B; ++b) {
+            flens[b] = lens[b] * RF;
+            sumF += flens[b];
+        }
+        PK_TRY(pk_fft_build_timeline(ctx, h->tl_frm2, flens.data(), B, h->gapr));
+        Timeline& tf = h->tl_frm2;
+        {
+            std::vector<int> rowmap(tf.rows_alloc, -1);
+            int o = 0;
+            for (int b = 0; b < B; ++b)
+                for (int l = 0; l < flens[b]; ++l) rowmap[tf.seg_start[b] + l] = o++;
+            PK_TRY(pk_upload(ctx, h->d_rowmap2, rowmap.data(), rowmap.size() * sizeof(int)));
+        }
+        if (flags & PK_HOST_IO) {
+            PK_TRY(h->d_mel_stage.reserve((size_t)sumF * O * 4));
+            d_out = h->d_mel_stage.as<float>();
+        }
+        if (c.postnet_layers == 0) {
+            PK_LAUNCH(ctx, "fs2_unfold", k_fs2_unfold_r, dim3(tf.rows), dim3(128), 0, wide, O, RF, tl.d_seg_start(), tf.d_row_utt(),
+                      tf.d_row_pos(), h->d_rowmap2.as<int>(), cs, ch, d_out);
+        } else {
+            PK_TRY(pk_fft_act_reserve(h->d_before, tf.rows, O));
+            float* before2 = pk_fft_act_ptr(h->d_before, O);
+            PK_LAUNCH(ctx, "fs2_unfold", k_fs2_unfold_r, dim3(tf.rows), dim3(128), 0, wide, O, RF, tl.d_seg_start(), tf.d_row_utt(),
+                      tf.d_row_pos(), (const int*)nullptr, (const float*)nullptr, (const float*)nullptr, before2);
+            PK_TRY(pk_fft_run_postnet(h, "fs2_conv_postnet", h->postnet, before2, O, c.postnet_chans, tf, h->d_q1, h->d_q2, d_out,
+                                      h->d_rowmap2.as<int>(), cs, ch));
+        }
+        if (flags & PK_HOST_IO) {
+            PK_HIP(hipMemcpyAsync(mel_out, d_out, (size_t)sumF * O * 4, hipMemcpyDeviceToHost, ctx->stream));
+            PK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return PK_OK;
+    }
     if (c.postnet_layers == 0) {
         pk_gemm_args g;
         g.A = zs; g.lda = A; g.Wp = h->W(h->feat_out.w); g.bias = h->W(h->feat_out.b);
@@ -1779,7 +1849,7 @@ extern "C" int pk_fs2_debug_read(pk_fs2* h, int32_t what, int32_t b, float* host
         case 3: src = h->d_dout.as<float>(); C = 1; break;                  // durations (T,)
         case 4: tl = &h->tl_frm; src = pk_fft_act_ptr(h->d_dbg_up, A); break;      // length-regulated hs (L, adim)
         case 5: tl = &h->tl_frm; src = pk_fft_act_ptr(h->d_zs, A); break;      // decoder output zs (L, adim)
-        case 6: tl = &h->tl_frm; src = pk_fft_act_ptr(h->d_before, h->cfg.odim); C = h->cfg.odim; break;  // before_outs
+        case 6: tl = h->cfg.reduction_factor > 1 ? &h->tl_frm2 : &h->tl_frm; src = pk_fft_act_ptr(h->d_before, h->cfg.odim); C = h->cfg.odim; break;  // before_outs
         default: PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: unknown tap %d", what);
     }
     if (b < 0 || b >= tl->B) PK_FAIL(PK_EINVAL, "pk_fs2_debug_read: utterance out of range");
@@ -1798,9 +1868,11 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
     pk_dbuf* bufs[] = {&h->d_tok, &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
-                       &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage};
+                       &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage,
+                       &h->d_wide, &h->d_rowmap2};
     for (auto* b : bufs) b->release();
     h->tl_tok.release();
     h->tl_frm.release();
+    h->tl_frm2.release();
     delete h;
 }

@@ -79,9 +79,10 @@ def test_fastspeech2_ffn_variants_engine_matches_reference_source(kind):
 
 
 @pytest.mark.parametrize("math", ["f32", "f16x3"])
-@pytest.mark.parametrize("tag", ["postnorm", "concat", "mixed"])
+@pytest.mark.parametrize("tag", ["postnorm", "concat", "mixed", "r2", "r3_nopostnet"])
 def test_fastspeech2_block_variants_engine_matches_reference_source(tag, math):
-    """Post-norm blocks (normalize_before=False: no after_norm) and concat_after in the shared FFT stack."""
+    """Post-norm blocks (normalize_before=False: no after_norm) and concat_after in the shared FFT stack;
+    reduction_factor > 1 (r mel frames per decoder row)."""
     from parakeet_amd.fastspeech2 import FastSpeech2
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_golden_cpu import FS2_BLOCK_VARIANTS

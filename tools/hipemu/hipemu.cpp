@@ -263,7 +263,30 @@ v2fp16 cvt_pkrtz(float a, float b) {   // fp32 -> fp16, round toward zero, satur
 using hipemu::g_last_error;
 
 extern "C" {
+// HIPEMU_GUARD=1: every allocation ends (up to 255 bytes early, for the 256-byte alignment hipMalloc guarantees) at an
+// inaccessible page, so that a kernel reading or writing past its buffer faults instead of passing by luck.
+struct GuardRec {
+    void* base;
+    size_t len;
+};
+static std::vector<std::pair<void*, GuardRec>> g_guarded;
+static bool guard_mode() {
+    static const bool on = getenv("HIPEMU_GUARD") && atoi(getenv("HIPEMU_GUARD")) != 0;
+    return on;
+}
 hipError_t hipMalloc(void** p, size_t bytes) {
+    if (guard_mode()) {
+        const size_t page = 4096, need = (bytes + 255) & ~(size_t)255;
+        const size_t len = ((need + page - 1) / page + 1) * page;
+        char* base = (char*)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base == MAP_FAILED) return hipErrorOutOfMemory;
+        mprotect(base + len - page, page, PROT_NONE);
+        char* q = base + len - page - need;
+        std::memset(q, 0xCD, need);
+        g_guarded.push_back({q, GuardRec{base, len}});
+        *p = q;
+        return hipSuccess;
+    }
     // a guard band behind every allocation keeps the clamped / speculative loads of the kernels inside mapped memory
     void* q = nullptr;
     if (posix_memalign(&q, 256, bytes + 4096) != 0) return hipErrorOutOfMemory;
@@ -272,6 +295,15 @@ hipError_t hipMalloc(void** p, size_t bytes) {
     return hipSuccess;
 }
 hipError_t hipFree(void* p) {
+    if (guard_mode()) {
+        for (size_t i = 0; i < g_guarded.size(); ++i)
+            if (g_guarded[i].first == p) {
+                munmap(g_guarded[i].second.base, g_guarded[i].second.len);
+                g_guarded.erase(g_guarded.begin() + i);
+                return hipSuccess;
+            }
+        return p ? hipErrorInvalidValue : hipSuccess;
+    }
     std::free(p);
     return hipSuccess;
 }

@@ -100,6 +100,9 @@ FS2_BLOCK_VARIANTS = {
     "postnorm": dict(encoder_normalize_before=False, decoder_normalize_before=False),
     "concat": dict(encoder_concat_after=True, decoder_concat_after=True),
     "mixed": dict(encoder_normalize_before=False, encoder_concat_after=True, positionwise_conv_kernel_size=3),
+    # reduction_factor: r mel frames per decoder row (feat_out adim -> odim * r, reshaped; fastspeech2.py:271, :457)
+    "r2": dict(reduction_factor=2),
+    "r3_nopostnet": dict(reduction_factor=3, postnet_layers=0),
 }
 
 
