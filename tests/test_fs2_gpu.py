@@ -175,7 +175,7 @@ def test_fs2_error_mapping():
     with pytest.raises(ValueError):
         FastSpeech2(80, 80, encoder_type="conformer")
     with pytest.raises(NotImplementedError):
-        FastSpeech2(80, 80, **_cfg(reduction_factor=2))
+        FastSpeech2(80, 80, **_cfg(reduction_factor=32))            # 1 .. 16
     m = FastSpeech2(80, 80, **_cfg())
     with pytest.raises(RuntimeError):
         m.inference(np.array([1, 2, 3]))            # parameters never set
