@@ -512,6 +512,13 @@ int pk_op_conv1d_batchnorm_nlc(pk_ctx* ctx, const float* x, int32_t B, int32_t T
                                const float* bias, const float* bn_weight, const float* bn_bias,
                                const float* bn_mean, const float* bn_var, float eps, float* y);
 
+/* Conv1dCell.add_input (modules/conv.py:166-183): one step of a causal dilated Conv1D used as a cell.  buffer DEVICE
+ * (B, Cin, r), r = 1 + (k - 1) * dilation, zeros before the first step (initialize_buffer :129-139), shifted by one
+ * step and fed x_t DEVICE (B, Cin) here; weight DEVICE [Cout][Cin][k], bias DEVICE [Cout] or NULL; y DEVICE (B, Cout).
+ * With r == 1 the buffer may be NULL.  Asynchronous on the context's stream. */
+int pk_op_conv1d_cell_step(pk_ctx* ctx, float* buffer, const float* x_t, const float* weight, const float* bias,
+                           int32_t B, int32_t Cin, int32_t Cout, int32_t k, int32_t dilation, float* y);
+
 /* Plain row-major product y[M][N] = x[M][K] . w[K][N] (+ bias[N]) on the exact-fp32 MFMA GEMM: the
  * `paddle.matmul(self.weight, spectrogram)` of MelScale.forward (modules/audio.py:226-229) with rows =
  * (batch, frame).  x, y device; w, bias (or NULL) HOST.  Synchronous (the weight is packed per call). */

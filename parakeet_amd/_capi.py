@@ -182,6 +182,7 @@ def _declare(lib):
         "pk_op_scaled_dot_product_attention": (C.c_int, [vp, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, i32,
                                                          f32p, f32p]),
         "pk_op_matmul": (C.c_int, [vp, f32p, i32, i32, i32, f32p, f32p, f32p]),
+        "pk_op_conv1d_cell_step": (C.c_int, [vp, f32p, f32p, f32p, f32p, i32, i32, i32, i32, i32, f32p]),
         "pk_op_conv1d_batchnorm_nlc": (C.c_int, [vp, f32p, i32, i32, i32, i32, i32, i32, f32p, f32p, f32p, f32p,
                                                  f32p, f32p, C.c_float, f32p]),
     }

@@ -107,6 +107,35 @@ __global__ __launch_bounds__(256) void k_sdpa(const float* __restrict__ q, const
     }
 }
 
+// Conv1dCell.add_input (modules/conv.py:166-183), two launches:
+//   k_cell_shift: buffer[b][ci][:] <- concat(buffer[b][ci][1:], x_t[b][ci])   (update_buffer :141-151); one thread per (b, ci)
+//   k_cell_out:   y[b][co] = bias[co] + sum_ci sum_j W[co][ci][j] * buffer[b][ci][j * dilation]   (:176-182); one wave per (b, co)
+__global__ __launch_bounds__(256) void k_cell_shift(float* __restrict__ buf, const float* __restrict__ x, int rows, int r) {
+    const int q = blockIdx.x * 256 + threadIdx.x;   // (b, ci)
+    if (q >= rows) return;
+    float* p = buf + (long)q * r;
+    for (int j = 0; j + 1 < r; ++j) p[j] = p[j + 1];
+    p[r - 1] = x[q];
+}
+__global__ __launch_bounds__(256) void k_cell_out(const float* __restrict__ buf, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, int B, int Cin, int Cout, int k, int dil,
+                                                  int r, float* __restrict__ y) {
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, co)
+    const int lane = threadIdx.x & 63;
+    if (o >= (long)B * Cout) return;
+    const int b = (int)(o / Cout), co = (int)(o - (long)b * Cout);
+    const float* w = W + (long)co * Cin * k;
+    const float* x = buf + (long)b * Cin * r;
+    float s = 0.f;
+    for (int e = lane; e < Cin * k; e += 64) {
+        const int ci = e / k, j = e - ci * k;
+        s = fmaf(w[e], x[(long)ci * r + j * dil], s);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) y[o] = s + (bias ? bias[co] : 0.f);
+}
+
 // rows of a (B, T, C) NLC tensor -> row timeline with `gap` zero rows around every sequence
 __global__ void k_nlc_to_timeline(const float* __restrict__ x, int T, int C, int gap, float* __restrict__ tl) {
     const int r = blockIdx.x;                       // timeline row
@@ -324,4 +353,21 @@ extern "C" int pk_op_matmul(pk_ctx* ctx, const float* x, int32_t M, int32_t K, i
     }
     cleanup();
     return st;
+}
+
+extern "C" int pk_op_conv1d_cell_step(pk_ctx* ctx, float* buffer, const float* x_t, const float* weight, const float* bias,
+                                      int32_t B, int32_t Cin, int32_t Cout, int32_t k, int32_t dilation, float* y) {
+    if (!ctx || !x_t || !weight || !y) PK_FAIL(PK_EINVAL, "pk_op_conv1d_cell_step: NULL argument");
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || dilation <= 0) PK_FAIL(PK_EINVAL, "pk_op_conv1d_cell_step: bad shape");
+    const int r = 1 + (k - 1) * dilation;   // receptive field (:84)
+    if (r > 1 && !buffer) PK_FAIL(PK_EINVAL, "pk_op_conv1d_cell_step: a receptive field of %d needs the buffer", r);
+    PK_DEVICE(ctx->device);
+    const float* in = x_t;   // receptive field 1: the step input itself (:178-179)
+    if (r > 1) {
+        PK_LAUNCH(ctx, "cell_shift", k_cell_shift, dim3(pk_div_up((long)B * Cin, 256)), dim3(256), 0, buffer, x_t, B * Cin, r);
+        in = buffer;
+    }
+    PK_LAUNCH(ctx, "cell_out", k_cell_out, dim3(pk_div_up((long)B * Cout, 4)), dim3(256), 0, in, weight, bias, B, Cin, Cout, k,
+              dilation, r, y);
+    return PK_OK;
 }

@@ -111,6 +111,58 @@ class Conv1dBatchNorm:
     __call__ = forward
 
 
+class Conv1dCell:
+    """Conv1dCell (modules/conv.py:22-183): a causal dilated Conv1D used like an RNN cell -- ``start_sequence()`` then one
+    ``add_input(x_t (B, Cin)) -> y_t (B, Cout)`` per step, the last ``receptive_field`` inputs kept in a device buffer.
+    State-dict keys ``weight`` [Cout, Cin, k] and ``bias``.  (No model of the reference uses it since WaveNet was removed.)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dilation=1, weight_attr=None, bias_attr=None):
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        d = dilation[0] if isinstance(dilation, (tuple, list)) else dilation
+        self.cin, self.cout, self.k, self.dilation = in_channels, out_channels, int(k), int(d)
+        self._r = 1 + (self.k - 1) * self.dilation
+        self._has_bias = bias_attr is not False
+        self._w = self._b = self._buffer = None
+        self._started = False
+        self.training = True
+
+    @property
+    def receptive_field(self):
+        return self._r
+
+    def set_state_dict(self, state):
+        ctx = Context.get()
+        self._w = ctx.to_device(to_numpy_f32(state["weight"]).reshape(self.cout, self.cin, self.k))
+        self._b = ctx.to_device(to_numpy_f32(state["bias"]).reshape(self.cout)) if "bias" in state else None
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def start_sequence(self):
+        if self.training:
+            raise Exception("only use start_sequence in evaluation")   # conv.py:108-109
+        self._buffer, self._started = None, True
+
+    def add_input(self, x_t):
+        if self._w is None:
+            raise RuntimeError("Conv1dCell: parameters were never set")
+        if not self._started:
+            raise RuntimeError("Conv1dCell: call start_sequence() first")
+        ctx = Context.get()
+        x = ctx.to_device(x_t)
+        B = x.shape[0]
+        if x.dim() != 2 or x.shape[1] != self.cin:
+            raise ValueError(f"Conv1dCell.add_input: expected (B, {self.cin}), got {tuple(x.shape)}")
+        if self._r > 1 and self._buffer is None:                           # initialize_buffer (:129-139)
+            self._buffer = torch.zeros((B, self.cin, self._r), dtype=torch.float32, device=ctx.device)
+        y = ctx.empty((B, self.cout))
+        _capi.check(ctx.lib.pk_op_conv1d_cell_step(ctx.handle, None if self._buffer is None else dptr(self._buffer), dptr(x),
+                                                   dptr(self._w), None if self._b is None else dptr(self._b), B, self.cin,
+                                                   self.cout, self.k, self.dilation, dptr(y)))
+        return wrap(y)
+
+
 class Linear:
     """nn.Linear with Paddle's [in, out] weight, on the engine's GEMM (Conv1D k = 1 without batch norm)."""
 

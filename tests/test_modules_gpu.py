@@ -126,3 +126,28 @@ def test_expand_matches_reference_construction():
     assert np.array_equal(y[0, 6:], np.zeros((2, 3), np.float32))          # padding of the shorter sequence
     with pytest.raises(ValueError):
         expand(x, -d)
+
+
+def test_conv1d_cell_add_input_equals_causal_conv():
+    """Conv1dCell (modules/conv.py:62-72 docstring example and shapes): stepping the cell over a sequence equals the causal
+    dilated convolution of the whole sequence (padding (receptive_field - 1, 0)), for k = 1 too."""
+    from parakeet_amd.modules import Conv1dCell
+    rng = np.random.default_rng(5)
+    for cin, cout, k, dil, B, T in ((3, 4, 5, 1, 4, 16), (6, 5, 3, 4, 2, 20), (7, 2, 1, 1, 3, 4)):
+        w = rng.normal(size=(cout, cin, k)).astype(np.float32)
+        b = rng.normal(size=(cout,)).astype(np.float32)
+        x = rng.normal(size=(B, cin, T)).astype(np.float32)
+        cell = Conv1dCell(cin, cout, k, dilation=dil)
+        cell.set_state_dict({"weight": w, "bias": b})
+        with pytest.raises(Exception):
+            cell.start_sequence()                                      # training mode (:108-109)
+        cell.eval()
+        assert cell.receptive_field == 1 + (k - 1) * dil
+        cell.start_sequence()
+        ys = [cell.add_input(x[:, :, t]).numpy() for t in range(T)]
+        assert ys[0].shape == (B, cout) and len(ys) == T
+        xp = torch.nn.functional.pad(torch.tensor(x).double(), (cell.receptive_field - 1, 0))
+        ref = torch.nn.functional.conv1d(xp, torch.tensor(w).double(), torch.tensor(b).double(), dilation=dil).numpy()
+        assert np.abs(np.stack(ys, axis=-1) - ref).max() < 1e-5
+        cell.start_sequence()                                          # the buffer starts from zeros again
+        assert np.abs(cell.add_input(x[:, :, 0]).numpy() - ys[0]).max() == 0.0
