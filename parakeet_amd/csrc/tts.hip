@@ -1039,12 +1039,12 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
                 PK_TRY(attn_step(h, "tts_attn_src", a2, H, B, maxT));
                 float* x3 = post ? rn : rx;
                 if (cat) {
+                    // x + concat_linear2(cat(x2, att)) accumulates in a buffer that is neither of the GEMMs' inputs (a row
+                    // GEMM must not write the rows it reads): rn with post-norm blocks, rz (free until after_norm) otherwise
+                    x3 = post ? rn : rz;
                     PK_TRY(rowgemm("tts_row_src_out", L.r_src_out, rc, A, ra, A, PK_ACT_NONE, nullptr, 0, 0, 0, false));
-                    PK_TRY(rowgemm("tts_row_concat2", L.r_cat2_x, x2, A, post ? rn : rz, A, PK_ACT_NONE, rx, A, 0, 0, false));
-                    // (pre-norm: x2 may be rt and the sum goes through rz, because a row GEMM must not write the rows it reads)
-                    float* acc = post ? rn : rz;
-                    PK_TRY(rowgemm("tts_row_concat2", L.r_cat2_a, ra, A, acc, A, PK_ACT_NONE, acc, A, 0, 0, false));
-                    x3 = acc;
+                    PK_TRY(rowgemm("tts_row_concat2", L.r_cat2_x, x2, A, x3, A, PK_ACT_NONE, rx, A, 0, 0, false));
+                    PK_TRY(rowgemm("tts_row_concat2", L.r_cat2_a, ra, A, x3, A, PK_ACT_NONE, x3, A, 0, 0, false));
                 } else {
                     PK_TRY(rowgemm("tts_row_src_out", L.r_src_out, rc, A, x3, A, PK_ACT_NONE, rx, A, 0, 0, false));
                 }
