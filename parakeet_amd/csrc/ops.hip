@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void k_sdpa(const float* __restrict__ q, const
     float* sc = qs + d;
     const float* qp = q + row * d;
     for (int c = lane; c < d; c += 64) qs[c] = qp[c];
+    // [wave-lds-exchange] qs[] is read below by every lane of the wave (wave-private LDS: no workgroup barrier needed)
     const float scale = 1.0f / sqrtf((float)d);
     float mx = -INFINITY;
     for (int j = lane; j < Tk; j += 64) {
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void k_sdpa(const float* __restrict__ q, const
         sc[j] *= inv;
         if (weights) weights[row * Tk + j] = sc[j];
     }
+    // [wave-lds-exchange] sc[] (one key per lane) is read below by every lane of the wave
     for (int c = lane; c < dv; c += 64) {
         float acc = 0.f;
         for (int j = 0; j < Tk; ++j) acc = fmaf(sc[j], v[((long)b * Tk + j) * dv + c], acc);

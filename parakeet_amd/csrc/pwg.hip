@@ -406,11 +406,14 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const unsigned vo4 = (unsigned)(xoff(t) + 4 * hi * XBLK);      // result rows mfma_row(r, hi)
 
         // aux projection rows f-2..f+2 (UPW x G floats) -> wave-private LDS (no barrier: same wave)
+        // [wave-lds-exchange] every lane of the wave has finished reading the previous tile's rows out of lds_p
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = lane + 64 * it;
             if (idx < (UPW + (GEN ? 1 : 0)) * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
         }
+        // [wave-lds-exchange] the rows are read below by OTHER lanes of the same wave (a wave's LDS instructions execute in
+        // order for all its lanes, so the hardware needs no barrier here; tools/hipemu turns these markers into a rendezvous)
         const bool lane_valid = valid_n;                 // of THIS tile (prefetch_head(next) overwrites valid_n)
         const float* lds_pl = lds_p + (GEN ? df_n * G : 0);   // GEN: lanes in the tile's second frame read one row on
         // accumulators start from conv bias + upsampled aux projection
@@ -771,11 +774,14 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         int cls_next = 0;
         const unsigned vo4 = vo8[1];   // centre tap: operand rows and result rows share the lane offset
         float x_old[32];
+        // [wave-lds-exchange] every lane of the wave has finished reading the previous tile's rows out of lds_p
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             const int idx = lane + 64 * it;
             if (idx < (UPW + (GEN ? 1 : 0)) * (G / 4)) reinterpret_cast<f32x4*>(lds_p)[idx] = preg[it];
         }
+        // [wave-lds-exchange] the rows are read below by OTHER lanes of the same wave (a wave's LDS instructions execute in
+        // order for all its lanes, so the hardware needs no barrier here; tools/hipemu turns these markers into a rendezvous)
         const bool lane_valid = valid_n;                 // of THIS tile (prefetch_head(next) overwrites valid_n)
         const float* lds_pl = lds_p + (GEN ? df_n * G : 0);   // GEN: lanes in the tile's second frame read one row on
         // HALF: the stage-1 accumulators hold S1 * (pre-activation), S1 = 2^(kx + k1) = x scale * W1 scale

@@ -3,7 +3,10 @@ stand-in <hip/hip_runtime.h> of this directory (DEVELOPMENT ONLY -- see that hea
 
 Two source rewrites happen on the way (copies under _build/src, the originals are untouched):
   * ``extern __shared__ float x[];``  ->  a pointer to the emulator's dynamic-LDS block;
-  * the one inline-assembly idiom of the code base (v_fma_mix_f32 d, h[sel], -1.0, x) -> hipemu::fma_mix_sub.
+  * the one inline-assembly idiom of the code base (v_fma_mix_f32 d, h[sel], -1.0, x) -> hipemu::fma_mix_sub;
+  * a comment line starting with ``// [wave-lds-exchange]`` -> hipemu::wave_sync(): the places where lanes of one wave
+    exchange data through LDS without a barrier (legal on the hardware, which runs a wave's LDS instructions in order for
+    all lanes; the fibers of the emulation need the rendezvous).
 """
 import os
 import re
@@ -19,6 +22,7 @@ LIB = os.path.join(OUT, "libpk_synth_emu.so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 _DYN_LDS = re.compile(r"extern\s+__shared__\s+(\w+)\s+(\w+)\[\];")
+_WAVE_LDS = re.compile(r"^(\s*)// \[wave-lds-exchange\]", re.M)
 _FMA_MIX = re.compile(r'asm\("v_fma_mix_f32 %0, %1, -1\.0, %2 op_sel:\[(\d),0,0\] op_sel_hi:\[1,0,0\]"\s*:\s*"=v"\((\w+)\)\s*:\s*'
                       r'"v"\((\w+)\),\s*"v"\(([^;]+)\)\);')
 
@@ -26,6 +30,7 @@ _FMA_MIX = re.compile(r'asm\("v_fma_mix_f32 %0, %1, -1\.0, %2 op_sel:\[(\d),0,0\
 def rewrite(text):
     text = _DYN_LDS.sub(r"\1* \2 = (\1*)hipemu::dynamic_lds();", text)
     text = _FMA_MIX.sub(r"\2 = hipemu::fma_mix_sub(\3, \1, \4);", text)
+    text = _WAVE_LDS.sub(r"\1hipemu::wave_sync(); //", text)
     if "asm(" in text or "asm volatile" in text:
         raise RuntimeError("inline assembly the emulator has no rewrite for")
     return text

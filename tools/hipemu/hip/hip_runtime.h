@@ -193,6 +193,8 @@ inline T shfl_up(T v, int d, int width = WAVE) {
     const int l = cur->lane & (width - 1);
     return l - d >= 0 ? peek<T>(p, cur->lane - d) : v;
 }
+// rendezvous of the live lanes of the wave (build.py puts it where a "// [wave-lds-exchange]" marker stands)
+inline void wave_sync() { arrive(&cur->wave->rv); }
 inline int readlane(int v, int lane) {
     const int p = exchange(v);
     return peek<int>(p, lane);
