@@ -15,7 +15,8 @@ with letter-to-sound rules for words the lexicon lacks.
 Mandarin (``zh_frontend.Frontend``, zh_frontend.py:30-254 with tone_sandhi.py and zh_normalization/): the reference's
 own logic -- text normalisation, merge rules, tone sandhi, initial / final splitting, erhua, id mapping -- over ONE
 caller-supplied resource, a pinyin lexicon (``PinyinLexicon``), in place of the jieba / pypinyin / g2pM dictionaries;
-pinned against the reference source run over dictionary stand-ins (tools/make_golden_zh.py).
+pinned against the reference source run over dictionary stand-ins (tools/make_golden_zh.py).  ``ParakeetPinyin`` /
+``ParakeetPinyinWithTone`` (pinyin.py:55-215): the pinyin phonologies of the Mandarin Tacotron2 recipes, same lexicon.
 """
 from .vocab import Vocab
 from .punctuation import get_punctuations
@@ -26,7 +27,9 @@ from .phone_map import phones_to_ids, phones_to_ids_transformer_tts, read_phone_
 from .zh_frontend import Frontend, PinyinLexicon
 from .zh_normalization import TextNormalizer
 from .tone_sandhi import ToneSandhi
+from .pinyin import ParakeetPinyin, ParakeetPinyinWithTone
 
 __all__ = ["Vocab", "get_punctuations", "normalize", "normalize_numbers", "full2half_width", "half2full_width",
            "LexiconG2p", "ARPABET_PHONEMES", "ARPABET", "ARPABETWithStress", "English", "EnglishCharacter", "Phonetics", "phones_to_ids",
-           "read_phone_id_map", "text_to_ids", "phones_to_ids_transformer_tts", "Frontend", "PinyinLexicon", "TextNormalizer", "ToneSandhi"]
+           "read_phone_id_map", "text_to_ids", "phones_to_ids_transformer_tts", "Frontend", "PinyinLexicon", "TextNormalizer", "ToneSandhi",
+           "ParakeetPinyin", "ParakeetPinyinWithTone"]

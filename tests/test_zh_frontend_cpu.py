@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 from parakeet_amd.frontend.pinyin_split import split_syllable
 from parakeet_amd.frontend.zh_frontend import Frontend, PinyinLexicon
@@ -98,3 +99,30 @@ def test_arpabet_phonologies_match_reference_source():
             assert fe.reverse(fe(text)) == fe.phoneticize(text)
     assert ARPABET().vocab_size == 47 and ARPABETWithStress().vocab_size == 77      # arpabet.py:208, :301
     assert all(p[-1] not in "012" for p in ARPABET().phoneticize("Hello, world!"))   # stress marks dropped
+
+
+def test_pinyin_phonologies_match_reference_source():
+    """ParakeetPinyin / ParakeetPinyinWithTone (frontend/pinyin.py) over the lexicon vs the reference's own source run with a
+    pypinyin stand-in that answers from the same lexicon (tools/make_golden_zh.py)."""
+    from parakeet_amd.frontend import ParakeetPinyin, ParakeetPinyinWithTone
+    from parakeet_amd.frontend.pinyin import split_syllable, to_parakeet_convention
+    g = GOLD
+    plain, toned = ParakeetPinyin(), ParakeetPinyinWithTone()
+    assert (plain.vocab_size, plain.tone_vocab_size, toned.vocab_size) == (70, 10, 230)          # pinyin.py:131-140, :213
+    assert g["pinyin_vocab"] == {"phones": 70, "tones": 10, "toned": 230}
+    for text, ref in g["pinyin"].items():
+        ph, tn = plain.phoneticize(text)
+        assert (ph, tn) == (ref["phonemes"], ref["tones"]), text
+        ids = plain(text)
+        assert (ids[0], ids[1]) == (ref["phone_ids"], ref["tone_ids"]), text
+        assert [list(v) for v in plain.phoneticize(text, add_start_end=True)] == ref["start_end"], text   # the kept slip
+        assert toned.phoneticize(text) == ref["toned"] and toned(text) == ref["toned_ids"], text
+    # the rewriting rules one by one (pinyin.py:224-257)
+    for src, want in (("bo1", "buo1"), ("zhong1", "zhueng1"), ("xiong2", "xveng2"), ("jin1", "jien1"), ("ying2", "ieng2"),
+                      ("lun2", "luen2"), ("gui4", "guei4"), ("liu2", "liou2"), ("zi3", "zii3"), ("shi4", "shiii4"), ("ri4", "riii4"),
+                      ("yu3", "v3"), ("ye3", "ie3"), ("wu3", "u3"), ("wo3", "uo3"), ("ju2", "jv2"), ("xue2", "xve2")):
+        assert to_parakeet_convention(src) == want, src
+    assert split_syllable("zhong1") == (["zh", "ueng"], ["0", "1"]) and split_syllable("，") == (["，"], ["0"])
+    assert split_syllable("a1") == (["a"], ["1"])
+    with pytest.raises(AttributeError):
+        toned.phoneticize("你好", add_start_end=True)

@@ -37,3 +37,9 @@ TONES = ["<pad>", "<unk>", "0", "1", "2", "3", "4", "5"]
 
 # English ARPABET phonologies (parakeet/frontend/arpabet.py) over the demonstration CMUdict-format lexicon
 ARPABET_TEXTS = ["Hello, world! This is a test.", "The quick brown fox? Yes.", "unknownword zyx, forty two dollars"]
+
+# frontend/pinyin.py (ParakeetPinyin / ParakeetPinyinWithTone): sentences of the lexicon, the four marks of its inventory,
+# a run of letters (kept together, as pypinyin leaves it) and syllables that exercise every rewriting rule the demonstration
+# lexicon can reach (bo -> buo, ong / iong, in / ing, un / ui / iu, zi / zhi, y / w glides, ju / qu / xu)
+PINYIN_SENTENCES = ["你好，我们今天去北京。", "他不怕，也不好说！", "看一看这个东西吧？", "所有人都买手表", "我有一个朋友，他很喜欢纸老虎。",
+                    "他说hello我不懂", "第一天一样一起走", "展览馆很好，水果也很好", "听一听，想想", "蒙古包里有奶奶的桌子"]

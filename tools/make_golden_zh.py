@@ -21,7 +21,7 @@ from parakeet_amd.frontend.pinyin_split import split_syllable  # noqa: E402
 from parakeet_amd.frontend.zh_frontend import PinyinLexicon  # noqa: E402
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from zh_cases import ARPABET_TEXTS, NORMALIZE, SANDHI, SENTENCES, PHONES, TONES  # noqa: E402
+from zh_cases import ARPABET_TEXTS, NORMALIZE, PINYIN_SENTENCES, SANDHI, SENTENCES, PHONES, TONES  # noqa: E402
 
 LEX = PinyinLexicon()
 
@@ -39,6 +39,38 @@ def install_stubs():
         return [split_syllable(s)[which] for s in LEX.pinyin(word)]
 
     pp.Style, pp.lazy_pinyin, pp.constants = Style, lazy_pinyin, ppc
+    # pypinyin.core.Pinyin(converter).lazy_pinyin(sentence, style=Style.TONE3, strict=True) of frontend/pinyin.py: one
+    # tone-number syllable per character the lexicon reads, runs of other characters kept together (as pypinyin does)
+    core = types.ModuleType("pypinyin.core")
+
+    class CoreStyle:
+        TONE3 = "tone3"
+
+    class Pinyin:
+        def __init__(self, converter=None):
+            pass
+
+        def lazy_pinyin(self, sentence, style=None, strict=True):
+            assert style == CoreStyle.TONE3
+            out, run = [], ""
+            for piece, _ in LEX.segment(sentence):
+                if piece in LEX.words:
+                    if run:
+                        out.append(run)
+                        run = ""
+                    out += list(LEX.words[piece][0])
+                else:
+                    run += piece
+            return out + ([run] if run else [])
+
+    core.DefaultConverter, core.Pinyin, core.Style = type("DefaultConverter", (), {}), Pinyin, CoreStyle
+    contrib = types.ModuleType("pypinyin.contrib")
+    neutral = types.ModuleType("pypinyin.contrib.neutral_tone")
+    neutral.NeutralToneWith5Mixin = type("NeutralToneWith5Mixin", (), {})
+    contrib.neutral_tone = neutral
+    pp.core, pp.contrib = core, contrib
+    for name, mod in (("pypinyin.core", core), ("pypinyin.contrib", contrib), ("pypinyin.contrib.neutral_tone", neutral)):
+        sys.modules[name] = mod
     jb = types.ModuleType("jieba")
     jb.cut_for_search = LEX.cut_for_search
     psg = types.ModuleType("jieba.posseg")
@@ -98,6 +130,16 @@ def main():
             out["arpabet"][text][cls.__name__] = {
                 "phones": fe_en.phoneticize(text), "phones_se": fe_en.phoneticize(text, add_start_end=True),
                 "ids_se": fe_en(text, add_start_end=True), "vocab_size": fe_en.vocab_size}
+    rp = importlib.import_module("parakeet.frontend.pinyin")
+    out["pinyin"] = {}
+    plain, toned = rp.ParakeetPinyin(), rp.ParakeetPinyinWithTone()
+    for text in PINYIN_SENTENCES:
+        ph, tn_ = plain.phoneticize(text)
+        ids = plain(text)
+        out["pinyin"][text] = {"phonemes": ph, "tones": tn_, "phone_ids": ids[0], "tone_ids": ids[1],
+                               "start_end": [list(v) for v in plain.phoneticize(text, add_start_end=True)],
+                               "toned": toned.phoneticize(text), "toned_ids": toned(text)}
+    out["pinyin_vocab"] = {"phones": plain.vocab_size, "tones": plain.tone_vocab_size, "toned": toned.vocab_size}
     out["neutral_words_used"] = sorted(w for w in sandhi.must_neural_tone_words if w in LEX.words)
     path = os.path.join(ROOT, "tests", "golden", "zh_frontend.json")
     json.dump(out, open(path, "wt", encoding="utf-8"), ensure_ascii=False, indent=0)
