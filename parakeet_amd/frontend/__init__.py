@@ -28,8 +28,9 @@ from .zh_frontend import Frontend, PinyinLexicon
 from .zh_normalization import TextNormalizer
 from .tone_sandhi import ToneSandhi
 from .pinyin import ParakeetPinyin, ParakeetPinyinWithTone
+from .generate_lexicon import generate_lexicon
 
 __all__ = ["Vocab", "get_punctuations", "normalize", "normalize_numbers", "full2half_width", "half2full_width",
            "LexiconG2p", "ARPABET_PHONEMES", "ARPABET", "ARPABETWithStress", "English", "EnglishCharacter", "Phonetics", "phones_to_ids",
            "read_phone_id_map", "text_to_ids", "phones_to_ids_transformer_tts", "Frontend", "PinyinLexicon", "TextNormalizer", "ToneSandhi",
-           "ParakeetPinyin", "ParakeetPinyinWithTone"]
+           "ParakeetPinyin", "ParakeetPinyinWithTone", "generate_lexicon"]

@@ -2,6 +2,9 @@
 (``Frontend`` :30-254: ``get_phonemes``, ``get_input_ids``) -- what the baker / aishell3 recipes call before
 FastSpeech2 and SpeedySpeech (examples/speedyspeech/baker/synthesize_e2e.py:113-121).
 
+Both of the reference's pipelines are here: ``g2p_model="pypinyin"`` (initial / final styles) and ``"g2pM"`` (tone-number
+syllables split with the table of generate_lexicon.py, :78-92).
+
 The reference leans on three packages that cannot be installed here and whose dictionaries are their substance:
 jieba (word segmentation + part-of-speech tags), pypinyin (characters -> pinyin) and g2pM.  This module keeps every
 piece of the reference's OWN logic -- text normalisation (zh_normalization.py), the merge rules and tone sandhi
@@ -104,8 +107,14 @@ class PinyinLexicon:
 class Frontend:
     def __init__(self, g2p_model="pypinyin", phone_vocab_path=None, tone_vocab_path=None, lexicon=None,
                  neutral_words=None):
-        if g2p_model != "pypinyin":
-            raise NotImplementedError("only the pypinyin-style pipeline is restated (g2pM is a neural model)")
+        if g2p_model not in ("pypinyin", "g2pM"):
+            raise ValueError(f"g2p_model {g2p_model!r}: pypinyin or g2pM")
+        # "g2pM": the reference asks the g2pM network for tone-number syllables and splits them with the table of
+        # generate_lexicon (:40-44, :78-92); here the lexicon answers in the network's place, the table path is the same
+        self.g2p_model = g2p_model
+        if g2p_model == "g2pM":
+            from .generate_lexicon import generate_lexicon
+            self.pinyin2phone = generate_lexicon(with_tone=True, with_erhua=False)
         self.lexicon = lexicon if isinstance(lexicon, PinyinLexicon) else PinyinLexicon(lexicon)
         self.missing = []
         kw = {} if neutral_words is None else {"neutral_words": neutral_words}
@@ -131,6 +140,16 @@ class Frontend:
     def _get_initials_finals(self, word):
         """(:63-92) with the i -> ii / iii distinction after z c s / zh ch sh r."""
         initials, finals = [], []
+        if self.g2p_model == "g2pM":
+            for syl in self.lexicon.pinyin(word, self.missing):
+                syl = syl.replace("u:", "v")
+                if syl in self.pinyin2phone:
+                    c, v = self.pinyin2phone[syl].split(" ")
+                else:                      # not pinyin (punctuation, an unread character): passed through (:89-92)
+                    c = v = syl
+                initials.append(c)
+                finals.append(v)
+            return initials, finals
         for syl in self.lexicon.pinyin(word, self.missing):
             c, v = split_syllable(syl)
             if re.match(r"i\d", v):

@@ -126,3 +126,37 @@ def test_pinyin_phonologies_match_reference_source():
     assert split_syllable("a1") == (["a"], ["1"])
     with pytest.raises(AttributeError):
         toned.phoneticize("你好", add_start_end=True)
+
+
+def test_generate_lexicon_matches_reference_source():
+    """generate_lexicon (frontend/generate_lexicon.py:146-160): every syllable, in order, with its initial / final spelling,
+    in all four modes -- compared through a digest of the whole table plus samples (tools/make_golden_zh.py)."""
+    import hashlib
+    from parakeet_amd.frontend.generate_lexicon import generate_lexicon, rule
+    for key, ref in GOLD["generate_lexicon"].items():
+        wt, we = key[4] == "1", key[-1] == "1"
+        lex = generate_lexicon(with_tone=wt, with_erhua=we)
+        items = list(lex.items())
+        assert len(lex) == ref["n"], key
+        assert [list(i) for i in items[:12]] == ref["head"] and [list(i) for i in items[::97]] == ref["every_97th"], key
+        blob = "\n".join(f"{k}\t{v}" for k, v in items).encode("utf-8")
+        assert hashlib.sha256(blob).hexdigest() == ref["sha256"], key
+    assert GOLD["generate_lexicon"]["tone0_erhua0"]["n"] == 460
+    assert rule("", "ueng", "", "1") == "weng1" and rule("j", "van", "", "") == "juan" and rule("b", "ong", "", "") is None
+    assert rule("", "er", "r", "2") is None and rule("zh", "iii", "r", "4") == "zhir4"
+
+
+def test_g2pm_path_matches_reference_source(tmp_path):
+    """Frontend(g2p_model="g2pM") (zh_frontend.py:40-44, :78-92): syllables split with the generate_lexicon table; the lexicon
+    answers in the place of the g2pM network, as the stand-in did when the golden was made."""
+    pv, tv = tmp_path / "phones.txt", tmp_path / "tones.txt"
+    pv.write_text("".join(f"{p} {i}\n" for i, p in enumerate(PHONES)), encoding="utf-8")
+    tv.write_text("".join(f"{t} {i}\n" for i, t in enumerate(TONES)), encoding="utf-8")
+    fe = Frontend(g2p_model="g2pM", phone_vocab_path=str(pv), tone_vocab_path=str(tv), neutral_words=set(GOLD["neutral_words_used"]))
+    for text, ref in GOLD["g2pM"].items():
+        assert fe.get_phonemes(text) == ref["merged"], text
+        ids = fe.get_input_ids(text, merge_sentences=True, get_tone_ids=True)
+        assert [t.tolist() for t in ids["phone_ids"]] == ref["phone_ids"], text
+        assert [t.tolist() for t in ids["tone_ids"]] == ref["tone_ids"], text
+    with pytest.raises(ValueError):
+        Frontend(g2p_model="espeak")

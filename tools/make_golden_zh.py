@@ -4,6 +4,7 @@ tone_sandhi.py, zh_normalization/) executed with stand-ins for the three diction
 ``pypinyin`` / ``jieba`` are answered from parakeet_amd's demonstration lexicon (the same resource the engine-side
 frontend uses), ``g2pM`` is a dummy.  This pins the reference's own logic -- normalisation, merge rules, tone sandhi,
 erhua, "sp", id mapping -- not the dictionaries.  Build container only.  Output: tests/golden/zh_frontend.json."""
+import hashlib
 import importlib
 import json
 import os
@@ -77,7 +78,13 @@ def install_stubs():
     psg.lcut = LEX.segment
     jb.posseg = psg
     g2pm = types.ModuleType("g2pM")
-    g2pm.G2pM = type("G2pM", (), {})
+
+    class G2pM:   # the network's call contract (zh_frontend.py:79): tone-number syllables, ü written "u:"
+        def __call__(self, word, tone=True, char_split=False):
+            assert tone and not char_split
+            return [p.replace("v", "u:") for p in LEX.pinyin(word)]
+
+    g2pm.G2pM = G2pM
     from parakeet_amd.frontend.g2p import LexiconG2p
     g2pen = types.ModuleType("g2p_en")          # the English phonologies ask g2p_en for phones: the lexicon stand-in answers
     g2pen.G2p = LexiconG2p
@@ -130,6 +137,12 @@ def main():
             out["arpabet"][text][cls.__name__] = {
                 "phones": fe_en.phoneticize(text), "phones_se": fe_en.phoneticize(text, add_start_end=True),
                 "ids_se": fe_en(text, add_start_end=True), "vocab_size": fe_en.vocab_size}
+    fe_m = zf.Frontend(g2p_model="g2pM", phone_vocab_path=pv, tone_vocab_path=tv)
+    out["g2pM"] = {}
+    for text in SENTENCES:
+        ids = fe_m.get_input_ids(text, merge_sentences=True, get_tone_ids=True)
+        out["g2pM"][text] = {"merged": fe_m.get_phonemes(text), "phone_ids": [t.numpy().tolist() for t in ids["phone_ids"]],
+                             "tone_ids": [t.numpy().tolist() for t in ids["tone_ids"]]}
     rp = importlib.import_module("parakeet.frontend.pinyin")
     out["pinyin"] = {}
     plain, toned = rp.ParakeetPinyin(), rp.ParakeetPinyinWithTone()
@@ -140,6 +153,15 @@ def main():
                                "start_end": [list(v) for v in plain.phoneticize(text, add_start_end=True)],
                                "toned": toned.phoneticize(text), "toned_ids": toned(text)}
     out["pinyin_vocab"] = {"phones": plain.vocab_size, "tones": plain.tone_vocab_size, "toned": toned.vocab_size}
+    gl = importlib.import_module("parakeet.frontend.generate_lexicon")
+    out["generate_lexicon"] = {}
+    for wt in (False, True):
+        for we in (False, True):
+            lex = gl.generate_lexicon(with_tone=wt, with_erhua=we)
+            blob = "\n".join(f"{k}\t{v}" for k, v in lex.items()).encode("utf-8")
+            items = list(lex.items())
+            out["generate_lexicon"][f"tone{int(wt)}_erhua{int(we)}"] = {
+                "n": len(lex), "sha256": hashlib.sha256(blob).hexdigest(), "head": items[:12], "every_97th": items[::97]}
     out["neutral_words_used"] = sorted(w for w in sandhi.must_neural_tone_words if w in LEX.words)
     path = os.path.join(ROOT, "tests", "golden", "zh_frontend.json")
     json.dump(out, open(path, "wt", encoding="utf-8"), ensure_ascii=False, indent=0)
