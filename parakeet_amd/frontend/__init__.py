@@ -22,7 +22,7 @@ from .vocab import Vocab
 from .punctuation import get_punctuations
 from .normalizer import normalize, normalize_numbers, full2half_width, half2full_width
 from .g2p import LexiconG2p, ARPABET_PHONEMES
-from .phonectic import ARPABET, ARPABETWithStress, English, EnglishCharacter, Phonetics
+from .phonectic import ARPABET, ARPABETWithStress, Chinese, English, EnglishCharacter, Phonetics
 from .phone_map import phones_to_ids, phones_to_ids_transformer_tts, read_phone_id_map, text_to_ids
 from .zh_frontend import Frontend, PinyinLexicon
 from .zh_normalization import TextNormalizer
@@ -33,4 +33,4 @@ from .generate_lexicon import generate_lexicon
 __all__ = ["Vocab", "get_punctuations", "normalize", "normalize_numbers", "full2half_width", "half2full_width",
            "LexiconG2p", "ARPABET_PHONEMES", "ARPABET", "ARPABETWithStress", "English", "EnglishCharacter", "Phonetics", "phones_to_ids",
            "read_phone_id_map", "text_to_ids", "phones_to_ids_transformer_tts", "Frontend", "PinyinLexicon", "TextNormalizer", "ToneSandhi",
-           "ParakeetPinyin", "ParakeetPinyinWithTone", "generate_lexicon"]
+           "ParakeetPinyin", "ParakeetPinyinWithTone", "generate_lexicon", "Chinese"]

@@ -6,7 +6,7 @@ from .normalizer import normalize
 from .punctuation import get_punctuations
 from .vocab import Vocab
 
-__all__ = ["Phonetics", "English", "EnglishCharacter", "ARPABET", "ARPABETWithStress"]
+__all__ = ["Phonetics", "English", "EnglishCharacter", "ARPABET", "ARPABETWithStress", "Chinese"]
 
 
 class Phonetics(ABC):
@@ -129,3 +129,57 @@ class ARPABETWithStress(ARPABET):
         ["V", "W", "Y", "Z", "ZH"]
     symbols = phonemes + ARPABET.punctuations
     keep_stress = True
+
+
+class Chinese(Phonetics):
+    """Whole-syllable Mandarin phonology (phonectic.py:213-300): a sentence -> tone-number syllables and punctuation marks,
+    ``<s>`` / ``</s>`` around them, ids from a vocabulary of every syllable the backend knows plus the Chinese punctuation.
+
+    The reference's backend is the g2pM network and its vocabulary is ``list(set(...))`` over g2pM's dictionary -- an order
+    that changes with the interpreter's string hashing.  Here the backend is the caller's pinyin lexicon and the syllables
+    are sorted, so ids are reproducible; a model trained with the reference needs the id table it was trained with."""
+
+    def __init__(self, lexicon=None):
+        from .zh_frontend import PinyinLexicon
+        self.lexicon = lexicon if isinstance(lexicon, PinyinLexicon) else PinyinLexicon(lexicon)
+        self.phonemes = sorted({syl for syls, _ in self.lexicon.words.values() for syl in syls})
+        self.punctuations = get_punctuations("cn")
+        self.vocab = Vocab(self.phonemes + self.punctuations)
+
+    def backend(self, sentence):
+        """g2pM's call contract (tone=True, char_split=False): one syllable per character it reads; a run of other
+        characters stays together as one item."""
+        out, run = [], ""
+        for piece, _ in self.lexicon.segment(sentence):
+            if piece in self.lexicon.words:
+                if run:
+                    out.append(run)
+                    run = ""
+                out += list(self.lexicon.words[piece][0])
+            else:
+                run += piece
+        return out + ([run] if run else [])
+
+    def _filter_symbols(self, phonemes):
+        """Items of the vocabulary pass; anything else is looked at character by character (:254-263)."""
+        out = []
+        for item in phonemes:
+            if item in self.vocab.stoi:
+                out.append(item)
+            else:
+                out += [ch for ch in item if ch in self.vocab.stoi]
+        return out
+
+    def phoneticize(self, sentence):
+        start, end = self.vocab.start_symbol, self.vocab.end_symbol
+        return self._filter_symbols(([] if start is None else [start]) + self.backend(sentence) + ([] if end is None else [end]))
+
+    def numericalize(self, phonemes):
+        return [self.vocab.lookup(item) for item in phonemes]
+
+    def __call__(self, sentence):
+        return self.numericalize(self.phoneticize(sentence))
+
+    @property
+    def vocab_size(self):
+        return len(self.vocab)

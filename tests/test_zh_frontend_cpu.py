@@ -160,3 +160,17 @@ def test_g2pm_path_matches_reference_source(tmp_path):
         assert [t.tolist() for t in ids["tone_ids"]] == ref["tone_ids"], text
     with pytest.raises(ValueError):
         Frontend(g2p_model="espeak")
+
+
+def test_chinese_syllable_phonology_matches_reference_source():
+    """phonectic.Chinese (:213-300): whole syllables + punctuation, <s> / </s>, the character-wise filter of what the vocabulary
+    lacks -- the reference's source over a g2pM stand-in that answers from the lexicon.  Ids are compared through the symbols:
+    the reference's vocabulary order is a set's."""
+    from parakeet_amd.frontend import Chinese
+    zh = Chinese()
+    assert zh.vocab_size == GOLD["chinese"]["vocab_size"]
+    for text, ref in GOLD["chinese"]["phoneticize"].items():
+        ph = zh.phoneticize(text)
+        assert ph == ref, text
+        assert [zh.vocab.reverse(i) for i in zh(text)] == ref
+    assert zh.phonemes == sorted(zh.phonemes) and zh.vocab.lookup("<s>") == 2

@@ -80,8 +80,19 @@ def install_stubs():
     g2pm = types.ModuleType("g2pM")
 
     class G2pM:   # the network's call contract (zh_frontend.py:79): tone-number syllables, ü written "u:"
+        cedict = {w: list(syl) for w, (syl, _) in LEX.words.items()}   # phonectic.Chinese reads its syllable inventory here
+
         def __call__(self, word, tone=True, char_split=False):
             assert tone and not char_split
+            if getattr(self, "plain_v", False):          # phonectic.Chinese: syllables as the dictionary spells them,
+                out, run = [], ""                        # runs of other characters kept together
+                for piece, _ in LEX.segment(word):
+                    if piece in LEX.words:
+                        out += ([run] if run else []) + list(LEX.words[piece][0])
+                        run = ""
+                    else:
+                        run += piece
+                return out + ([run] if run else [])
             return [p.replace("v", "u:") for p in LEX.pinyin(word)]
 
     g2pm.G2pM = G2pM
@@ -143,6 +154,10 @@ def main():
         ids = fe_m.get_input_ids(text, merge_sentences=True, get_tone_ids=True)
         out["g2pM"][text] = {"merged": fe_m.get_phonemes(text), "phone_ids": [t.numpy().tolist() for t in ids["phone_ids"]],
                              "tone_ids": [t.numpy().tolist() for t in ids["tone_ids"]]}
+    rph = importlib.import_module("parakeet.frontend.phonectic")
+    zh = rph.Chinese()
+    zh.backend.plain_v = True
+    out["chinese"] = {"vocab_size": zh.vocab_size, "phoneticize": {t: zh.phoneticize(t) for t in PINYIN_SENTENCES + ["未登录的字：龘abc，。"]}}
     rp = importlib.import_module("parakeet.frontend.pinyin")
     out["pinyin"] = {}
     plain, toned = rp.ParakeetPinyin(), rp.ParakeetPinyinWithTone()
