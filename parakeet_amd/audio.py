@@ -234,6 +234,22 @@ class LogMagnitude:
         return np.exp(np.asarray(x))
 
 
+class UnitMagnitude:
+    """parakeet/audio/spec_normalizer.py:56-75: dB scale mapped to [0, 1] (20 log10(max(x, min)) - 20, then (. + 100) / 100,
+    clipped) and back.  Host-side numpy, like the reference."""
+
+    def __init__(self, min=1e-5):   # noqa: A002
+        self.min = min
+
+    def transform(self, x):
+        db = 20.0 * np.log10(np.maximum(self.min, np.asarray(x))) - 20.0
+        return np.clip((db + 100.0) / 100.0, 0, 1)
+
+    def inverse(self, x):
+        db = np.clip(np.asarray(x), 0, 1) * 100.0 - 100.0
+        return np.exp((db + 20.0) / 20.0 * np.log(10))
+
+
 class AudioProcessor:
     """parakeet/audio/audio.py:20-102 with the transforms on the engine: ``spectrogram`` = |STFT|,
     ``mel_spectrogram`` = mel_filter . |STFT| (the Slaney filterbank of ``librosa.filters.mel``), both returned

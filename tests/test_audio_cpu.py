@@ -62,3 +62,29 @@ def test_write_wav_roundtrip(tmp_path):
     raw = (tmp_path / "f.wav").read_bytes()
     assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE" and len(raw) == 44 + 4 * 2205
     assert np.array_equal(np.frombuffer(raw[44:], dtype="<f4"), x)
+
+
+def test_spec_normalizers_match_reference_source():
+    """LogMagnitude / UnitMagnitude (parakeet/audio/spec_normalizer.py:39-75): the reference file itself is numpy-only, so it is
+    executed here when /root/reference is present; its formulas are also checked through their defining properties."""
+    import importlib.util
+    import os
+    from parakeet_amd.audio import LogMagnitude, UnitMagnitude
+    rng = np.random.default_rng(3)
+    x = np.abs(rng.normal(size=(80, 50))) * 10.0 ** rng.uniform(-7, 2, size=(80, 50))
+    lm, um = LogMagnitude(), UnitMagnitude()
+    assert np.array_equal(lm.transform(x), np.log(np.maximum(x, 1e-5)))
+    assert np.allclose(lm.inverse(lm.transform(x)), np.maximum(x, 1e-5))
+    u = um.transform(x)
+    assert u.min() >= 0 and u.max() <= 1
+    assert np.allclose(um.transform(np.array([1e-4, 10.0 ** (-4 + 100 / 20)])), [0.0, 1.0])   # -80 dB - 20 -> 0; +20 dB - 20 -> 1
+    inside = (u > 0) & (u < 1)
+    assert np.allclose(um.inverse(u)[inside], x[inside], rtol=1e-10)
+    path = "/root/reference/parakeet/audio/spec_normalizer.py"
+    if os.path.exists(path):
+        spec = importlib.util.spec_from_file_location("ref_spec_normalizer", path)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        for mine, theirs in ((lm, ref.LogMagnitude()), (um, ref.UnitMagnitude())):
+            assert np.array_equal(mine.transform(x), theirs.transform(x))
+            assert np.array_equal(mine.inverse(mine.transform(x)), theirs.inverse(theirs.transform(x)))
