@@ -82,3 +82,36 @@ def test_example_recipe_script_writes_wavs(tmp_path):
     for utt, n_tok in (("001", 5), ("002", 7)):
         with wave.open(str(tmp_path / "out" / f"{utt}.wav"), "rb") as w:
             assert w.getframerate() == 22050 and w.getnframes() == n_tok * 2 * 256
+
+
+def test_vocoder_recipe_script_from_mel_files(tmp_path):
+    """examples/synthesize_vocoder.py parallel_wavegan (the arguments of the reference's
+    examples/GANVocoder/parallelwave_gan/synthesize.py): jsonlines metadata of normalised mel files -> one wav per utterance,
+    equal to the vocoder called directly with the engine's own noise stream."""
+    import importlib.util
+    import json
+    import types
+    import wave
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    pwg_state = syn.pwg_state(weight_norm=True)
+    with open(tmp_path / "pwg.pdz", "wb") as f:
+        pickle.dump({"generator_params": dict(pwg_state)}, f, protocol=4)
+    rng = np.random.default_rng(3)
+    meta = []
+    for utt, L in (("a01", 5), ("b02", 3)):
+        np.save(tmp_path / f"{utt}.npy", rng.normal(size=(L, 80)).astype(np.float32))
+        meta.append({"utt_id": utt, "feats": f"{utt}.npy"})
+    (tmp_path / "metadata.jsonl").write_text("".join(json.dumps(m) + "\n" for m in meta))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("synthesize_vocoder", os.path.join(root, "examples", "synthesize_vocoder.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.parallel_wavegan(types.SimpleNamespace(config=os.path.join(FIX, "pwg_ljspeech.yaml"), checkpoint=str(tmp_path / "pwg.pdz"),
+                                               test_metadata=str(tmp_path / "metadata.jsonl"), output_dir=str(tmp_path / "out")))
+    gen = PWGGenerator(**syn.PWG_LJSPEECH)
+    gen.set_state_dict(pwg_state)
+    gen.remove_weight_norm()
+    gen.eval()
+    for m, L in zip(meta, (5, 3)):
+        with wave.open(str(tmp_path / "out" / (m["utt_id"] + ".wav")), "rb") as w:
+            assert w.getnframes() == L * 256 and w.getframerate() == 22050
