@@ -189,10 +189,11 @@ def _config(cfg):
     return cfg
 
 
-def load_fastspeech2(config, checkpoint, stats, phones_dict=None, idim=None):
+def load_fastspeech2(config, checkpoint, stats, phones_dict=None, idim=None, speaker_dict=None):
     """The FastSpeech2 half of examples/fastspeech2/ljspeech/synthesize_e2e.py:45-83: returns
     ``(FastSpeech2Inference, phone_id_map)``.  ``config``: the recipe's yaml (path or dict with ``n_mels``
-    and ``model``); ``idim`` overrides the vocabulary size read from ``phones_dict``."""
+    and ``model``); ``idim`` overrides the vocabulary size read from ``phones_dict``; ``speaker_dict``: the speaker id map
+    of the multi-speaker recipes, whose line count is ``num_speakers`` (examples/fastspeech2/aishell3/synthesize_e2e.py:47-57)."""
     from .fastspeech2 import FastSpeech2, FastSpeech2Inference
     from .normalizer import ZScore
     cfg = _config(config)
@@ -202,7 +203,11 @@ def load_fastspeech2(config, checkpoint, stats, phones_dict=None, idim=None):
         idim = vocab if idim is None else idim
     if idim is None:
         raise ValueError("load_fastspeech2: give phones_dict or idim")
-    model = FastSpeech2(idim=idim, odim=cfg["n_mels"], **cfg["model"])
+    kw = {}
+    if speaker_dict is not None:
+        with open(speaker_dict, "rt") as f:
+            kw["num_speakers"] = sum(1 for line in f if line.strip())
+    model = FastSpeech2(idim=idim, odim=cfg["n_mels"], **kw, **cfg["model"])
     model.set_state_dict(load_params(checkpoint, "main_params"))
     model.eval()
     mu, sigma = load_stats(stats)

@@ -22,8 +22,9 @@ class Synthesizer:
         self.voc = pwg_inference.pwg_generator
         self.hop = self.voc.upsample_factor
 
-    def synthesize_packed(self, texts, alpha=1.0, noise=None, generator=None, tones=None):
-        """Returns (packed wav device tensor, frames per utterance)."""
+    def synthesize_packed(self, texts, alpha=1.0, noise=None, generator=None, tones=None, spk_ids=None):
+        """Returns (packed wav device tensor, frames per utterance).  ``spk_ids``: one speaker id per utterance for a
+        multi-speaker FastSpeech2 (examples/fastspeech2/aishell3/synthesize_e2e.py:90-98)."""
         self.am_inference.bind()
         self.voc_inference.bind()
         if type(self.am).__name__ == "SpeedySpeech":
@@ -31,7 +32,7 @@ class Synthesizer:
             frames = self.am.encode_batch(texts, tones)
         else:
             assert tones is None, "tone ids go to FastSpeech2 through encode_batch(tone_ids=...)"
-            frames = self.am.encode_batch(texts, alpha)
+            frames = self.am.encode_batch(texts, alpha) if spk_ids is None else self.am.encode_batch(texts, alpha, spk_ids)
         if int(frames.sum()) == 0:
             return torch.empty(0, device=self.am._ctx.device), frames
         mel = self.am.decode_packed(denormalize=True)       # FastSpeech2Inference: log-mel domain
@@ -76,11 +77,11 @@ class Synthesizer:
         wav = self.voc.infer_packed(mel, frames[keep], noise=noise, generator=generator, normalize=True)
         return wav, frames
 
-    def synthesize_batch(self, texts, alpha=1.0, noises=None, generator=None, tones=None):
+    def synthesize_batch(self, texts, alpha=1.0, noises=None, generator=None, tones=None, spk_ids=None):
         noise = None
         if noises is not None:
             noise = torch.cat([torch.as_tensor(np.asarray(n)).reshape(-1) for n in noises])
-        wav, frames = self.synthesize_packed(texts, alpha, noise, generator, tones)
+        wav, frames = self.synthesize_packed(texts, alpha, noise, generator, tones, spk_ids)
         outs, o = [], 0
         for f in frames:
             n = int(f) * self.hop

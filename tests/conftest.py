@@ -36,7 +36,7 @@ def _has_gpu():
 FIRST_GPU_RUN_PENDING = (
     "spk_add", "spk_concat", "unscaled", "linear_in", "-r2-", "r2-f", "r3stop", "gst", "enc_postnorm", "enc_concat", "dec_postnorm",
     "dec_concat", "all_post_concat", "[global-", "test_global_condition", "test_speaker_embeddings", "test_reduction_factor",
-    "test_style_tokens", "block_variants", "test_kv_only", "test_conv1d_cell", "test_vocoder_recipe_script")   # block_variants: FastSpeech2 post-norm / concat / r > 1
+    "test_style_tokens", "block_variants", "test_kv_only", "test_conv1d_cell", "test_vocoder_recipe_script", "test_mandarin_multispeaker_recipe")   # block_variants: FastSpeech2 post-norm / concat / r > 1
 
 
 def pytest_collection_modifyitems(config, items):

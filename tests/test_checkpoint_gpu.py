@@ -2,6 +2,7 @@
 parakeet_amd.checkpoint exactly as examples/fastspeech2/ljspeech/synthesize_e2e.py:45-83 loads the
 released one, must synthesise bit-identically to set_state_dict with the same arrays."""
 import os
+import sys
 import pickle
 
 import numpy as np
@@ -115,3 +116,52 @@ def test_vocoder_recipe_script_from_mel_files(tmp_path):
     for m, L in zip(meta, (5, 3)):
         with wave.open(str(tmp_path / "out" / (m["utt_id"] + ".wav")), "rb") as w:
             assert w.getnframes() == L * 256 and w.getframerate() == 22050
+
+
+def test_mandarin_multispeaker_recipe_script(tmp_path):
+    """examples/synthesize_e2e_zh.py with --speaker-dict (the arguments of examples/fastspeech2/aishell3/synthesize_e2e.py):
+    Mandarin text -> frontend ids -> multi-speaker FastSpeech2 (speaker 3) -> Parallel WaveGAN; the waveform lengths equal the
+    frame counts of the same model called directly with the same speaker."""
+    import importlib.util
+    import types
+    import wave
+    import yaml
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    from parakeet_amd.frontend import Frontend
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from zh_cases import PHONES
+    cfg = yaml.safe_load(open(os.path.join(FIX, "fastspeech2_ljspeech.yaml")))
+    cfg["model"].update(elayers=1, dlayers=1, spk_embed_dim=64, spk_embed_integration_type="concat")
+    (tmp_path / "fs2.yaml").write_text(yaml.safe_dump(cfg))
+    model_cfg = dict(syn.FS2_LJSPEECH, elayers=1, dlayers=1, spk_embed_dim=64, spk_embed_integration_type="concat")
+    fs2_state = syn.fastspeech2_state(len(PHONES), 80, model_cfg, seed=8, fixed_duration=2, num_speakers=5)
+    pwg_state = syn.pwg_state(weight_norm=True)
+    with open(tmp_path / "fs2.pdz", "wb") as f:
+        pickle.dump({"main_params": dict(fs2_state)}, f, protocol=4)
+    with open(tmp_path / "pwg.pdz", "wb") as f:
+        pickle.dump({"generator_params": dict(pwg_state)}, f, protocol=4)
+    np.save(tmp_path / "speech_stats.npy", np.stack(syn.mel_stats(seed=5)))
+    np.save(tmp_path / "pwg_stats.npy", np.stack(syn.mel_stats(seed=6)))
+    (tmp_path / "phone_id_map.txt").write_text("".join(f"{p} {i}\n" for i, p in enumerate(PHONES)), encoding="utf-8")
+    (tmp_path / "speaker_id_map.txt").write_text("".join(f"SSB{i:04d} {i}\n" for i in range(5)))
+    (tmp_path / "sentences.txt").write_text("001 你好，我们今天去北京。\n002 看一看这个东西吧？\n", encoding="utf-8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("synthesize_e2e_zh", os.path.join(root, "examples", "synthesize_e2e_zh.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(types.SimpleNamespace(
+        fastspeech2_config=str(tmp_path / "fs2.yaml"), fastspeech2_checkpoint=str(tmp_path / "fs2.pdz"),
+        fastspeech2_stat=str(tmp_path / "speech_stats.npy"), pwg_config=os.path.join(FIX, "pwg_ljspeech.yaml"),
+        pwg_checkpoint=str(tmp_path / "pwg.pdz"), pwg_stat=str(tmp_path / "pwg_stats.npy"),
+        phones_dict=str(tmp_path / "phone_id_map.txt"), speaker_dict=str(tmp_path / "speaker_id_map.txt"), spk_id=3, lexicon=None,
+        text=str(tmp_path / "sentences.txt"), output_dir=str(tmp_path / "out"), seed=0))
+    fe = Frontend(phone_vocab_path=str(tmp_path / "phone_id_map.txt"))
+    m = FastSpeech2(len(PHONES), 80, num_speakers=5, **model_cfg)
+    m.set_state_dict(fs2_state)
+    m.eval()
+    for utt, text in (("001", "你好，我们今天去北京。"), ("002", "看一看这个东西吧？")):
+        ids = fe.get_input_ids(text, merge_sentences=True)["phone_ids"][0]
+        frames = int(m.inference(ids, spk_id=np.array([3])).shape[0])
+        assert frames == 2 * len(ids)
+        with wave.open(str(tmp_path / "out" / f"3_{utt}.wav"), "rb") as w:
+            assert w.getnframes() == frames * 256 and w.getframerate() == 22050
