@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """FastSpeech2 + Parallel WaveGAN synthesis from released checkpoints on the MI355X engine -- the counterpart
-of the reference's examples/fastspeech2/ljspeech/synthesize_e2e.py with the same arguments, minus Paddle.
+of the reference's examples/fastspeech2/ljspeech/synthesize_e2e.py with the same arguments, minus Paddle; with
+``--speaker-dict`` of examples/fastspeech2/vctk/synthesize_e2e.py (multi-speaker, speaker ``--spk-id``).
 
 ``--text`` holds one ``utt_id sentence`` per line as in the reference (:45-50).  Sentences go through
 ``parakeet_amd.frontend.English`` -- the reference's ``parakeet.frontend.English`` with its g2p_en backend replaced
@@ -37,12 +38,15 @@ def main():
     ap.add_argument("--lexicon", default=None, help="CMUdict-format pronunciation lexicon for the English frontend "
                                                     "(default: the small demonstration lexicon of the package)")
     ap.add_argument("--phones-input", action="store_true", help="--text holds 'utt_id PH1 PH2 ...' lines")
+    ap.add_argument("--speaker-dict", default=None, help="speaker id map of the multi-speaker recipe "
+                                                         "(examples/fastspeech2/vctk/synthesize_e2e.py); files become {spk_id}_{utt_id}.wav")
+    ap.add_argument("--spk-id", type=int, default=0, help="the vctk recipe synthesises speaker 0 only (:93-94)")
     ap.add_argument("--output-dir", required=True)
     ap.add_argument("--seed", type=int, default=0, help="seed of the engine's noise stream")
     args = ap.parse_args()
 
     am, phone_id_map = checkpoint.load_fastspeech2(args.fastspeech2_config, args.fastspeech2_checkpoint,
-                                                   args.fastspeech2_stat, args.phones_dict)
+                                                   args.fastspeech2_stat, args.phones_dict, speaker_dict=args.speaker_dict)
     voc = checkpoint.load_pwg(args.pwg_config, args.pwg_checkpoint, args.pwg_stat)
     voc.pwg_generator.set_seed(args.seed)
     fs = checkpoint._config(args.fastspeech2_config)["fs"]
@@ -64,7 +68,10 @@ def main():
             batch.append([int(i) for i in ids])
     os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.perf_counter()
-    wavs = Synthesizer(am, voc).synthesize_batch(batch)
+    multi = args.speaker_dict is not None
+    wavs = Synthesizer(am, voc).synthesize_batch(batch, spk_ids=[args.spk_id] * len(batch) if multi else None)
+    if multi:
+        utt_ids = [f"{args.spk_id}_{u}" for u in utt_ids]
     n = 0
     for utt_id, wav in zip(utt_ids, wavs):
         w = wav.numpy()
