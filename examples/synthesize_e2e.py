@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """FastSpeech2 + Parallel WaveGAN synthesis from released checkpoints on the MI355X engine -- the counterpart
 of the reference's examples/fastspeech2/ljspeech/synthesize_e2e.py with the same arguments, minus Paddle; with
-``--speaker-dict`` of examples/fastspeech2/vctk/synthesize_e2e.py (multi-speaker, speaker ``--spk-id``).
+``--speaker-dict`` of examples/fastspeech2/vctk/synthesize_e2e.py (multi-speaker, speaker ``--spk-id``); with
+``--test-metadata`` of examples/fastspeech2/synthesize.py (preprocessed phone ids, a speaker per utterance).
 
 ``--text`` holds one ``utt_id sentence`` per line as in the reference (:45-50).  Sentences go through
 ``parakeet_amd.frontend.English`` -- the reference's ``parakeet.frontend.English`` with its g2p_en backend replaced
@@ -34,7 +35,9 @@ def main():
     ap.add_argument("--pwg-checkpoint", required=True)
     ap.add_argument("--pwg-stat", required=True)
     ap.add_argument("--phones-dict", default="phone_id_map.txt")
-    ap.add_argument("--text", required=True, help="'utt_id sentence' per line")
+    ap.add_argument("--text", help="'utt_id sentence' per line")
+    ap.add_argument("--test-metadata", help="instead of --text: the jsonlines file of examples/fastspeech2/synthesize.py "
+                                            "(records with utt_id, text = phone ids and, with --speaker-dict, spk_id)")
     ap.add_argument("--lexicon", default=None, help="CMUdict-format pronunciation lexicon for the English frontend "
                                                     "(default: the small demonstration lexicon of the package)")
     ap.add_argument("--phones-input", action="store_true", help="--text holds 'utt_id PH1 PH2 ...' lines")
@@ -51,9 +54,20 @@ def main():
     voc.pwg_generator.set_seed(args.seed)
     fs = checkpoint._config(args.fastspeech2_config)["fs"]
 
-    frontend = None if args.phones_input else English(lexicon=args.lexicon)
-    utt_ids, batch = [], []
-    with open(args.text, "rt") as f:
+    if (args.text is None) == (args.test_metadata is None):
+        ap.error("give --text or --test-metadata")
+    frontend = None if (args.phones_input or args.test_metadata) else English(lexicon=args.lexicon)
+    utt_ids, batch, spk = [], [], []
+    if args.test_metadata:            # examples/fastspeech2/synthesize.py:37-53, :98-106: ids (and speakers) as preprocessed
+        import json
+        with open(args.test_metadata, "rt") as f:
+            for line in f:
+                if line.strip():
+                    rec = json.loads(line)
+                    utt_ids.append(rec["utt_id"])
+                    batch.append([int(i) for i in rec["text"]])
+                    spk.append(int(rec.get("spk_id", args.spk_id)))
+    with open(args.text if args.text else os.devnull, "rt") as f:
         for line in f:
             parts = line.strip().split()
             if not parts:
@@ -69,9 +83,11 @@ def main():
     os.makedirs(args.output_dir, exist_ok=True)
     t0 = time.perf_counter()
     multi = args.speaker_dict is not None
-    wavs = Synthesizer(am, voc).synthesize_batch(batch, spk_ids=[args.spk_id] * len(batch) if multi else None)
-    if multi:
-        utt_ids = [f"{args.spk_id}_{u}" for u in utt_ids]
+    if not spk:
+        spk = [args.spk_id] * len(batch)
+    wavs = Synthesizer(am, voc).synthesize_batch(batch, spk_ids=spk if multi else None)
+    if multi and not args.test_metadata:          # the e2e recipe's file names (vctk/synthesize_e2e.py:106-110)
+        utt_ids = [f"{s}_{u}" for s, u in zip(spk, utt_ids)]
     n = 0
     for utt_id, wav in zip(utt_ids, wavs):
         w = wav.numpy()
