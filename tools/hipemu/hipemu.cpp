@@ -132,9 +132,14 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, Thunk fn, void* closure) 
     g_grid_dim = grid;
     g_block_dim = block;
     g_abort = false;
-    for (unsigned bz = 0; bz < grid.z && !g_abort; ++bz)
-        for (unsigned by = 0; by < grid.y && !g_abort; ++by)
-            for (unsigned bx = 0; bx < grid.x && !g_abort; ++bx) {
+    // HIPEMU_ORDER=reverse runs the workgroups of every launch from the last to the first: a result that changes with it
+    // means one workgroup reads what another writes in the same launch (on the GPU: a race)
+    static const bool reverse = getenv("HIPEMU_ORDER") && std::strcmp(getenv("HIPEMU_ORDER"), "reverse") == 0;
+    for (unsigned iz = 0; iz < grid.z && !g_abort; ++iz)
+        for (unsigned iy = 0; iy < grid.y && !g_abort; ++iy)
+            for (unsigned ix = 0; ix < grid.x && !g_abort; ++ix) {
+                const unsigned bx = reverse ? grid.x - 1 - ix : ix, by = reverse ? grid.y - 1 - iy : iy,
+                               bz = reverse ? grid.z - 1 - iz : iz;
                 g_block_idx = uint3{bx, by, bz};
                 g_wg = Rendezvous{};
                 g_wg.live = n;
