@@ -23,6 +23,7 @@ CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 _DYN_LDS = re.compile(r"extern\s+__shared__\s+(\w+)\s+(\w+)\[\];")
 _WAVE_LDS = re.compile(r"^(\s*)// \[wave-lds-exchange\]", re.M)
+_STATIC_LDS = re.compile(r"^(\s*)(__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?[\w:<>]+\s+(\w+)(?:\[[^\];]+\])+;)", re.M)
 _FMA_MIX = re.compile(r'asm\("v_fma_mix_f32 %0, %1, -1\.0, %2 op_sel:\[(\d),0,0\] op_sel_hi:\[1,0,0\]"\s*:\s*"=v"\((\w+)\)\s*:\s*'
                       r'"v"\((\w+)\),\s*"v"\(([^;]+)\)\);')
 
@@ -31,6 +32,9 @@ def rewrite(text):
     text = _DYN_LDS.sub(r"\1* \2 = (\1*)hipemu::dynamic_lds();", text)
     text = _FMA_MIX.sub(r"\2 = hipemu::fma_mix_sub(\3, \1, \4);", text)
     text = _WAVE_LDS.sub(r"\1hipemu::wave_sync(); //", text)
+    # HIPEMU_POISON: LDS is not initialised on the hardware; the first work-item of a workgroup fills every __shared__ array
+    # with NaN bytes before anything runs, so that a read-before-write cannot pass on what the previous workgroup left behind
+    text = _STATIC_LDS.sub(r"\1\2 hipemu::poison_lds(\3, sizeof(\3));", text)
     if "asm(" in text or "asm volatile" in text:
         raise RuntimeError("inline assembly the emulator has no rewrite for")
     return text

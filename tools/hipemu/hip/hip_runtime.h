@@ -193,6 +193,11 @@ inline T shfl_up(T v, int d, int width = WAVE) {
     const int l = cur->lane & (width - 1);
     return l - d >= 0 ? peek<T>(p, cur->lane - d) : v;
 }
+extern bool g_poison;
+// build.py appends this to every __shared__ array declaration (HIPEMU_POISON=1: NaN bytes at the start of each workgroup)
+inline void poison_lds(void* p, size_t bytes) {
+    if (g_poison && cur->linear == 0) std::memset(p, 0xFF, bytes);
+}
 // rendezvous of the live lanes of the wave (build.py puts it where a "// [wave-lds-exchange]" marker stands)
 inline void wave_sync() { arrive(&cur->wave->rv); }
 inline int readlane(int v, int lane) {

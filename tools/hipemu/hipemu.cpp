@@ -11,6 +11,7 @@
 namespace hipemu {
 
 Lane* cur = nullptr;
+bool g_poison = getenv("HIPEMU_POISON") && atoi(getenv("HIPEMU_POISON")) != 0;
 uint3 g_block_idx;
 dim3 g_block_dim, g_grid_dim;
 Rendezvous g_wg;
@@ -141,6 +142,7 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, Thunk fn, void* closure) 
                 const unsigned bx = reverse ? grid.x - 1 - ix : ix, by = reverse ? grid.y - 1 - iy : iy,
                                bz = reverse ? grid.z - 1 - iz : iz;
                 g_block_idx = uint3{bx, by, bz};
+                if (g_poison && lds_bytes) std::memset(g_dyn_lds.data(), 0xFF, lds_bytes);
                 g_wg = Rendezvous{};
                 g_wg.live = n;
                 for (int w = 0; w < nw; ++w) {
