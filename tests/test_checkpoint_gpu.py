@@ -55,11 +55,7 @@ def test_end_to_end_from_checkpoint_files(tmp_path):
     assert np.array_equal(wav, wav2) and wav.shape == (33 * 256, 1)
 
 
-def test_example_recipe_script_writes_wavs(tmp_path):
-    """examples/synthesize_e2e.py (the reference recipe's arguments) on a synthetic checkpoint directory."""
-    import subprocess
-    import sys
-    import wave
+def _recipe_dir(tmp_path):
     fs2_state, pwg_state = syn.fastspeech2_state(fixed_duration=2), syn.pwg_state(weight_norm=True)
     with open(tmp_path / "fs2.pdz", "wb") as f:
         pickle.dump({"main_params": {k: ("t", v) for k, v in fs2_state.items()}}, f, protocol=2)
@@ -71,18 +67,51 @@ def test_example_recipe_script_writes_wavs(tmp_path):
     (tmp_path / "phone_id_map.txt").write_text("".join(f"{p} {i}\n" for i, p in enumerate(phones)))
     (tmp_path / "sentences.txt").write_text("001 P1 P2 , P3 P40\n002 P7 XX P9 P10 P11 P12 .\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "examples", "synthesize_e2e.py"),
-                        "--fastspeech2-config", os.path.join(FIX, "fastspeech2_ljspeech.yaml"),
-                        "--fastspeech2-checkpoint", str(tmp_path / "fs2.pdz"),
-                        "--fastspeech2-stat", str(tmp_path / "speech_stats.npy"),
-                        "--pwg-config", os.path.join(FIX, "pwg_ljspeech.yaml"),
-                        "--pwg-checkpoint", str(tmp_path / "pwg.pdz"), "--pwg-stat", str(tmp_path / "pwg_stats.npy"),
-                        "--phones-dict", str(tmp_path / "phone_id_map.txt"), "--text", str(tmp_path / "sentences.txt"),
-                        "--output-dir", str(tmp_path / "out")], capture_output=True, text=True, timeout=300)
+    return [sys.executable, os.path.join(root, "examples", "synthesize_e2e.py"),
+            "--fastspeech2-config", os.path.join(FIX, "fastspeech2_ljspeech.yaml"),
+            "--fastspeech2-checkpoint", str(tmp_path / "fs2.pdz"),
+            "--fastspeech2-stat", str(tmp_path / "speech_stats.npy"),
+            "--pwg-config", os.path.join(FIX, "pwg_ljspeech.yaml"),
+            "--pwg-checkpoint", str(tmp_path / "pwg.pdz"), "--pwg-stat", str(tmp_path / "pwg_stats.npy"),
+            "--phones-dict", str(tmp_path / "phone_id_map.txt"), "--text", str(tmp_path / "sentences.txt"),
+            "--output-dir", str(tmp_path / "out")]
+
+
+def _wav_frames(path):
+    import wave
+    with wave.open(str(path), "rb") as w:
+        assert w.getframerate() == 22050
+        return w.getnframes()
+
+
+def test_example_recipe_script_writes_wavs(tmp_path):
+    """examples/synthesize_e2e.py (the reference recipe's arguments) on a synthetic checkpoint directory, --phones-input
+    mode: the lines hold phone sequences, one id per token (unknown phones and punctuation -> "sp")."""
+    import subprocess
+    r = subprocess.run(_recipe_dir(tmp_path) + ["--phones-input"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     for utt, n_tok in (("001", 5), ("002", 7)):
-        with wave.open(str(tmp_path / "out" / f"{utt}.wav"), "rb") as w:
-            assert w.getframerate() == 22050 and w.getnframes() == n_tok * 2 * 256
+        assert _wav_frames(tmp_path / "out" / f"{utt}.wav") == n_tok * 2 * 256
+
+
+def test_example_recipe_script_raw_text(tmp_path):
+    """The same script in the reference's own mode (examples/fastspeech2/ljspeech/synthesize_e2e.py:88-97): --text sentences go
+    through the English frontend (lexicon G2P, words it lacks spelled by rule) and the recipe's id mapping; the number of ids
+    is the frontend's own count on the same sentence (18 and 30 with the package's demonstration lexicon)."""
+    import subprocess
+    from parakeet_amd.frontend import English, phones_to_ids
+    from parakeet_amd.frontend.phone_map import RECIPE_PUNC
+    cmd = _recipe_dir(tmp_path)
+    table = {ln.split()[0]: int(ln.split()[1]) for ln in (tmp_path / "phone_id_map.txt").read_text().splitlines()}
+    fe = English()
+    want = {u: len(phones_to_ids(fe.phoneticize(s), table, RECIPE_PUNC))
+            for u, s in (("001", "P1 P2 , P3 P40"), ("002", "P7 XX P9 P10 P11 P12 ."))}
+    assert want == {"001": 18, "002": 30}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "pronounced by rule" in r.stderr
+    for utt, n_tok in want.items():
+        assert _wav_frames(tmp_path / "out" / f"{utt}.wav") == n_tok * 2 * 256
 
 
 def test_vocoder_recipe_script_from_mel_files(tmp_path):

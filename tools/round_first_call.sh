@@ -10,8 +10,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-timeout 900 python -m pytest tests -m gpu -q --timeout=300 > $OUT/tests.log 2>&1
-tail -15 $OUT/tests.log
+timeout 1500 python -m pytest tests -m gpu -q -rA --durations=60 --timeout=300 > $OUT/tests.log 2>&1
+grep -E "^(FAILED|ERROR)|passed|failed" $OUT/tests.log | tail -40
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 cd /tmp
 timeout 300 python $R/bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench.json
