@@ -229,6 +229,8 @@ def main():
     elif distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))   # PK_BENCH_FORCE_DIST without a launcher
         # stdout is for the one JSON line: RCCL prints its NCCL_DEBUG=VERSION banner (set on the GPU boxes) with
         # printf when the communicator is created, so fd 1 points at stderr until the first collective has run
         sys.stdout.flush()
