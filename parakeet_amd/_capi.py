@@ -201,12 +201,19 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP engine is not built "
                 "(run `python -m parakeet_amd.build`); there is no CPU fallback")
-        from . import build as _build
-        want, have = _build.source_hash(), _build.library_hash(LIB_PATH)
-        if have != want and not os.environ.get("PK_ALLOW_STALE_LIB"):
-            raise RuntimeError(
-                f"{LIB_PATH} was built from other sources (library {str(have)[:12]}, tree {want[:12]}): "
-                "run `python -m parakeet_amd.build` (or __graft_entry__.build()); a stale engine is never used")
+        # The library must have been built from the sources next to it.  PK_ALLOW_STALE_LIB skips the check; so does an
+        # install that ships the library without csrc/ or include/ (nothing to compare with).
+        if not os.environ.get("PK_ALLOW_STALE_LIB"):
+            from . import build as _build
+            try:
+                want = _build.source_hash()
+            except FileNotFoundError:
+                want = None
+            have = _build.library_hash(LIB_PATH) if want is not None else None
+            if have != want:
+                raise RuntimeError(
+                    f"{LIB_PATH} was built from other sources (library {str(have)[:12]}, tree {want[:12]}): "
+                    "run `python -m parakeet_amd.build` (or __graft_entry__.build()); a stale engine is never used")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

@@ -74,7 +74,10 @@ struct pk_ctx {
     std::map<std::string, int> prof_ids;
     std::vector<pk_prof_rec> prof_recs;
     std::vector<hipEvent_t> event_pool;
-    pk_ctx_scratch* scratch = nullptr;   // small grow-only device buffers shared by the launchers (stream-ordered)
+    // small grow-only device buffers shared by the launchers.  Stream-ordered, so one set PER STREAM the context has been
+    // bound to: two engine handles issued concurrently on two streams of one context (Synthesizer.issue_acoustic) never
+    // share a scratch buffer.
+    std::map<hipStream_t, pk_ctx_scratch*> scratch;
 
     int prof_begin(const char* name);   // returns record index or -1
     void prof_end(int rec);
@@ -119,7 +122,7 @@ struct pk_dbuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// per-context scratch (allocated on first use, freed by pk_ctx_destroy)
+// per-(context, stream) scratch (allocated on first use, freed by pk_ctx_destroy)
 struct pk_ctx_scratch {
     pk_dbuf row_amax;    // pk_gemm_launch: max|A[r, :]| per row when the caller does not supply it
     pk_dbuf row_amax2;

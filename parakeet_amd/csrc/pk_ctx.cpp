@@ -74,19 +74,20 @@ extern "C" void pk_ctx_destroy(pk_ctx* ctx) {
         (void)hipEventDestroy(r.stop);
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
-    if (ctx->scratch) {
-        ctx->scratch->row_amax.release();
-        ctx->scratch->row_amax2.release();
-        ctx->scratch->attn_amax.release();
-        delete ctx->scratch;
+    for (auto& kv : ctx->scratch) {
+        kv.second->row_amax.release();
+        kv.second->row_amax2.release();
+        kv.second->attn_amax.release();
+        delete kv.second;
     }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 pk_ctx_scratch* pk_ctx_get_scratch(pk_ctx* ctx) {
-    if (!ctx->scratch) ctx->scratch = new pk_ctx_scratch();
-    return ctx->scratch;
+    pk_ctx_scratch*& sc = ctx->scratch[ctx->stream];   // the stream the caller's launches go to
+    if (!sc) sc = new pk_ctx_scratch();
+    return sc;
 }
 
 // ------------------------------------------------------------------ profiler

@@ -49,16 +49,19 @@ class Synthesizer:
     #         wav, frames = s.vocode_issued(pending, noise); pending = s.issue_acoustic(nxt) if nxt else None
     # Results are bit-identical to synthesize_packed (same kernels, same order per handle).
 
-    def issue_acoustic(self, texts, alpha=1.0, tones=None):
-        """Acoustic model of one batch on the side stream; returns (mel, frames, event) for vocode_issued."""
+    def issue_acoustic(self, texts, alpha=1.0, tones=None, spk_ids=None):
+        """Acoustic model of one batch on the side stream; returns (mel, frames, event) for vocode_issued.  Arguments as
+        ``synthesize_packed`` (``spk_ids`` for a multi-speaker FastSpeech2)."""
         if not hasattr(self, "_am_stream"):
             self._am_stream = torch.cuda.Stream(device=self.am._ctx.device)
-        self.am_inference.bind()
         with torch.cuda.stream(self._am_stream):
+            self.am_inference.bind()
             if type(self.am).__name__ == "SpeedySpeech":
+                assert alpha == 1.0, "SpeedySpeech has no speed control (speedyspeech.py:178-218)"
                 frames = self.am.encode_batch(texts, tones)
             else:
-                frames = self.am.encode_batch(texts, alpha)
+                assert tones is None, "tone ids go to FastSpeech2 through encode_batch(tone_ids=...)"
+                frames = self.am.encode_batch(texts, alpha) if spk_ids is None else self.am.encode_batch(texts, alpha, spk_ids)
             mel = self.am.decode_packed(denormalize=True) if int(frames.sum()) else None
             ev = torch.cuda.Event()
             ev.record(self._am_stream)

@@ -87,3 +87,22 @@ def test_build_rebuilds_on_source_hash_mismatch_not_on_mtime(tmp_path, monkeypat
     import pytest
     with pytest.raises(RuntimeError, match="built from other sources"):
         _capi.lib()
+
+
+def test_library_only_install_and_stale_override(tmp_path, monkeypatch):
+    """an install that ships libpk_synth.so without csrc/ (nothing to hash) loads the library instead of
+    raising FileNotFoundError, and PK_ALLOW_STALE_LIB is honoured before any hashing."""
+    import shutil
+    from parakeet_amd import _capi
+    from parakeet_amd import build as b
+    monkeypatch.setattr(b, "CSRC", str(tmp_path / "no_such_csrc"))
+    monkeypatch.setattr(_capi, "_lib", None)
+    assert _capi.lib().pk_version()                          # no source tree: loads
+    csrc = tmp_path / "csrc"
+    shutil.copytree(os.path.join(os.path.dirname(b.LIB), "csrc"), csrc, ignore=shutil.ignore_patterns("*.o"))
+    with open(csrc / "ops.hip", "a") as f:
+        f.write("\n// edited\n")
+    monkeypatch.setattr(b, "CSRC", str(csrc))
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setenv("PK_ALLOW_STALE_LIB", "1")
+    assert _capi.lib().pk_version()                          # mismatch, but explicitly allowed
