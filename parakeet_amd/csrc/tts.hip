@@ -939,7 +939,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     auto rowgemm = [&](const char* name, const RowW& w, const float* x, int ldx, float* y, int ldy, int act, const float* res,
                        int ldr, size_t ln_g, size_t ln_b, bool ln) -> int {
         pk_rowgemm_args g;
-        g.x = x; g.ldx = ldx; g.Wt = h->W(w.w); g.bias = h->W(w.b); g.y = y; g.ldy = ldy; g.M = B; g.K = w.K; g.N = w.N;
+        g.x = x; g.ldx = ldx; g.Wt = h->W(w.w); g.bias = w.b == (size_t)-1 ? nullptr : h->W(w.b); g.y = y; g.ldy = ldy; g.M = B; g.K = w.K; g.N = w.N;
         g.act = act; g.res = res; g.ldr = ldr;
         if (ln) { g.ln_g = h->W(ln_g); g.ln_b = h->W(ln_b); }
         return pk_rowgemm_launch(ctx, name, g);

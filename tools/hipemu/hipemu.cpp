@@ -287,8 +287,12 @@ hipError_t hipMalloc(void** p, size_t bytes) {
         const size_t len = ((need + page - 1) / page + 1) * page;
         char* base = (char*)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (base == MAP_FAILED) return hipErrorOutOfMemory;
-        mprotect(base + len - page, page, PROT_NONE);
-        char* q = base + len - page - need;
+        // HIPEMU_GUARD=2: the inaccessible page stands IN FRONT of the allocation instead (a read before the start of a
+        // buffer -- e.g. a pointer formed from a "no such tensor" offset of -1 -- faults as it does on the GPU, where
+        // hipMalloc returns the start of a mapping)
+        static const bool front = atoi(getenv("HIPEMU_GUARD")) == 2;
+        mprotect(front ? base : base + len - page, page, PROT_NONE);
+        char* q = front ? base + page : base + len - page - need;
         std::memset(q, 0xCD, need);
         g_guarded.push_back({q, GuardRec{base, len}});
         *p = q;
