@@ -138,6 +138,77 @@ def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5, bud
     return rec, logmel.numpy(), wav[:, 0].numpy()
 
 
+def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5):
+    """ConditionalWaveFlow.infer on BASELINE config 5's shape (batch 8 x 640 mel frames): median of `runs` batches, the
+    layer kernel's average launch time from the engine's HIP-event profile and its roofline.
+    Algorithmic work of one layer launch (per folded position): the (3,3) conv over the rows that exist +
+    condition_proj + out_proj = 2 * (9 C + 80) * 2C + 2 * C * 2C FLOP at full taps; bytes: one fp32 read of each input row the
+    kernel rows touch (1 - 3 x 4C), the condition row (4 * 80), the residual output (4C, not for the last layer) and the
+    skip sum (read + write 4C each; the first layer only writes)."""
+    from parakeet_amd import synthetic as syn
+    from parakeet_amd.waveflow import ConditionalWaveFlow
+    wcfg = dict(syn.WAVEFLOW_LJSPEECH, channels=channels)
+    wf = ConditionalWaveFlow(**wcfg)
+    wf.set_state_dict(syn.waveflow_state(wcfg))
+    wf.eval()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    mels = [torch.clamp(torch.randn(80, frames, device="cuda", generator=g) * 2 - 4, min=float(np.log(1e-5)))
+            for _ in range(batch)]
+    zs = [torch.randn(wf.lengths(frames)[0], device="cuda", generator=g) for _ in range(batch)]
+    out = wf.infer_batch(mels, zs)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(runs):
+        t1 = time.perf_counter()
+        out = wf.infer_batch(mels, zs)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t1)
+    dtw = float(np.median(times))
+    nsw = sum(o.numel() for o in out)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    wf.infer_batch(mels, zs)
+    prof = ctx.prof_dump()
+    ctx.prof_enable(False)
+    n_l, ms_l = prof.get("wf_layer", (0, 0.0))
+    G, NL, NF, C = wcfg["n_group"], wcfg["n_layers"], wcfg["n_flows"], channels
+    pos = nsw // G                                        # folded positions of the batch
+    flop = byts = 0.0
+    for i in range(1, G):                                 # row i of a flow: min(i, 3) input rows exist
+        rows = min(i, 3)
+        for l in range(NL):
+            flop += pos * (2.0 * (3 * rows * C + 80) * 2 * C + 2.0 * C * 2 * C)
+            byts += pos * 4.0 * (rows * C + 80 + (C if l + 1 < NL else 0) + (C if l == 0 else 2 * C))
+    launches = NF * (G - 1) * NL
+    ent = {
+        "what": f"BASELINE config 5 shape (ConditionalWaveFlow, {channels} channels, batch {batch} x {frames} frames), "
+                "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes",
+        "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,
+        "ms_per_batch_runs": [t * 1e3 for t in times],
+        "reference_published": "about 40x real time on V100 (docs/src/released_models.md:275-276)"}
+    if n_l == launches and ms_l > 0:
+        avg_s = ms_l / n_l * 1e-3
+        b_l, f_l = byts * NF / launches, flop * NF / launches
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"wf_layer_c{channels}_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ent["roofline"] = {
+            "kernel": "k_wf_layer_p -- one WaveFlow residual layer of one row, %d launches per batch" % launches,
+            "bound": "hbm", "achieved": b_l / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": b_l / avg_s / 8e12,
+            "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": b_l,
+            "algorithmic_flop_per_launch": f_l, "algorithmic_tflops": f_l / avg_s / 1e12,
+            "split_fp16_mfma_frac": 3.0 * f_l / avg_s / 2.5e15,
+            "note": "averages over the launches of a batch (rows 1 and 2 of a flow read one and two input rows); the "
+                    "matrix pipe issues three fp16 MFMAs per fp32 product (split_fp16_mfma_frac = 3 x FLOP / 2.5 PFLOP/s)"}
+    del wf
+    return ent
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -440,31 +511,12 @@ def main():
             extras[key] = ent
         synth.voc.set_math("f16x3")
         synth.am.set_math("f16x3")
-        try:
-            from parakeet_amd.waveflow import ConditionalWaveFlow
-            wcfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64)
-            wf = ConditionalWaveFlow(**wcfg)
-            wf.set_state_dict(syn.waveflow_state(wcfg))
-            wf.eval()
-            g = torch.Generator(device="cuda").manual_seed(7)
-            mels = [torch.clamp(torch.randn(80, 640, device="cuda", generator=g) * 2 - 4, min=float(np.log(1e-5)))
-                    for _ in range(8)]
-            zs = [torch.randn(wf.lengths(640)[0], device="cuda", generator=g) for _ in range(8)]
-            out = wf.infer_batch(mels, zs)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            out = wf.infer_batch(mels, zs)
-            torch.cuda.synchronize()
-            dtw = time.perf_counter() - t1
-            nsw = sum(o.numel() for o in out)
-            extras["waveflow_c64_batch8"] = {
-                "what": "BASELINE config 5 shape (ConditionalWaveFlow, 64 channels, batch 8 x 640 frames), fp32 storage, "
-                        "split-fp16 conv GEMMs (default math)",
-                "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,
-                "reference_published": "about 40x real time on V100 (docs/src/released_models.md:275-276)"}
-            del wf
-        except Exception as e:  # never let an extra break the headline line
-            extras["waveflow_c64_batch8"] = {"error": repr(e)}
+        for wf_c in (64, 128):   # BASELINE config 5 (64 channels) and the reference repository's default width (128)
+            key = f"waveflow_c{wf_c}_batch8"
+            try:
+                extras[key] = waveflow_extra(wf_c, ctx)
+            except Exception as e:  # never let an extra break the headline line
+                extras[key] = {"error": repr(e)}
         try:   # the two acoustic models alone (BASELINE config 2 shape at 32 utterances; SpeedySpeech)
             t1 = time.perf_counter()
             for _ in range(args.steps):

@@ -16,6 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libpk_synth.so")
+# per-file flags.  wf_layer.hip: the layer kernel's slab loop must unroll completely (26 slabs at 128 channels; a ring slot is a
+# register only under a compile-time index) -- beyond LLVM's default budget for `#pragma unroll`, where it silently keeps a
+# loop and the operand ring moves to scratch memory
+FILE_FLAGS = {"wf_layer.hip": ["-mllvm", "-pragma-unroll-threshold=2000000"]}
 SOURCES = ["pk_ctx.cpp", "pwg.hip", "gemm.hip", "fs2.hip", "waveflow.hip", "wf_layer.hip", "speedyspeech.hip", "tts.hip", "gst.hip", "taco2.hip", "rowgemm.hip", "mel.hip", "ops.hip"]
 
 
@@ -35,6 +39,7 @@ def source_hash():
         with open(path, "rb") as f:
             h.update(f.read())
         h.update(b"\0")
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())   # a flag change is a different library too
     return h.hexdigest()
 
 
@@ -60,7 +65,7 @@ def build(force=False, verbose=False, extra_flags=()):
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
-               "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + list(extra_flags)
+               "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + list(extra_flags) + FILE_FLAGS.get(src, [])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -1,33 +1,47 @@
-// pk_wf_layer.h -- the fused WaveFlow residual-layer kernel (wf_layer.hip) and the kernels around it that work
-// on its blocked feature layout.  Used by waveflow.hip for the 64-channel model under the split-fp16 math.
+// pk_wf_layer.h -- the fused WaveFlow residual-layer kernel (wf_layer.hip) and the kernels around it that work on its
+// feature storage.  Used by waveflow.hip for the 64- and 128-channel models under the split-fp16 math.
+//
+// Feature storage ("planes"): the layer inputs are MFMA B operands of nine conv taps each, i.e. every stored value is
+// split into its fp16 (hi, lo) parts nine times if it is stored as fp32 (round 2: 12.5 k of a wave tile's 30 k cycles
+// were VALU, two thirds of them operand splits).  They are therefore stored ALREADY SPLIT, by the kernel that produces
+// them: per 32-position block one power-of-two scale 2^k (k = blk_scale_exp of the block's max|.|, pk_split.h, kept as
+// the max's fp32 bits in a side array) and per value the pair hi = fp16_rtz(x 2^k), lo = fp16_rne(x 2^k - hi) -- the
+// same 4 bytes as the fp32 value, the same 22 significant bits the split-fp16 products used before.  A consumer brings
+// the blocks its taps touch to one common scale with a power-of-two multiply of the packed halves (v_pk_mul_f16) and
+// feeds them to the MFMA as they are.  Layout of a block of CH channels (bytes):
+//   [octet = CH / 8][position 32][plane hi | lo][8 halves]      = CH * 128 bytes = CH * 32 "slots" of 4 bytes
+// octet o = 2 * kq + hh holds the 8 channels that lane half hh supplies to k-step kq (16 channels) of a contraction:
+//   channel(kq, hh, e) = 16 kq + 8 (e >> 2) + 4 hh + (e & 3),   e = 0..7
+// which is also the set of channels lane half hh owns as accumulator rows (mfma_row) -- so a lane's B-operand vector
+// of the centre tap is its residual input, and its 8 accumulator registers of a k-step are one stored vector.
+// A lane's operand of one k-step is two 16-byte loads (hi, lo); across the 32 lanes of a half wave they are 1 KB
+// contiguous.  The running skip sum stays fp32: [block][channel / 4][position 32][4] (16-byte accesses).
 #pragma once
 #include <cstdint>
 #include <vector>
 
 #include "pk_common.h"
 
-constexpr int WFL_C = 64;          // residual channels the kernel is built for
 constexpr int WFL_MP = 96;         // condition channels padded to a multiple of 16 (n_mels 80 -> 96)
-constexpr int WFL_BLK = 32;        // positions per block of the blocked layout
-// Blocked feature layout: a [positions][CH] tensor is stored as [pos / 32][CH][32] floats, i.e.
-//   addr(p, ch) = (p >> 5) * (CH * 32) + ch * 32 + (p & 31)
-// so that the 32 positions of a wave tile are contiguous per channel (coalesced MFMA B-operand loads and
-// epilogue stores).  Buffers keep their margins: the base pointer is margin_positions * CH floats into the buffer.
-static inline long wfl_off(long p, int ch, int CH) { return (p >> 5) * ((long)CH * 32) + (long)ch * 32 + (p & 31); }
+constexpr int WFL_BLK = 32;        // positions per block
+constexpr int WFL_KS_COND = WFL_MP / 16;   // 6 k-steps of the condition block
 
-constexpr int WFL_KS_TAP = WFL_C / 16;                 // 4 k-steps of 16 channels per conv tap
-constexpr int WFL_KS_COND = WFL_MP / 16;               // 6
-constexpr int WFL_KS1 = 9 * WFL_KS_TAP + WFL_KS_COND;  // 42 k-steps of the first contraction
-constexpr int WFL_KS2 = WFL_C / 16;                    // 4 k-steps of the out projection
-constexpr size_t WFL_KSTEP_HALVES = 2 * 4 * 64 * 8;    // one k-step of A fragments: [part 2][co-tile 4][lane 64][8]
-constexpr size_t WFL_W1_HALVES = WFL_KS1 * WFL_KSTEP_HALVES;   // 172 032 halves = 336 KB
-constexpr size_t WFL_W2_HALVES = WFL_KS2 * WFL_KSTEP_HALVES;   //  16 384 halves =  32 KB
+static inline bool wfl_supports(int C) { return C == 64 || C == 128; }
+// channel of element e of lane half hh in k-step kq (see above)
+__host__ __device__ static inline int wfl_chan(int kq, int hh, int e) { return 16 * kq + 8 * (e >> 2) + 4 * hh + (e & 3); }
+// byte offset of (position p, channel ch, plane) from the buffer base (position 0) in a planes buffer of CH channels
+static inline long wfl_plane_off(long p, int ch, int plane, int CH) {
+    const int kq = ch >> 4, w = ch & 15, hh = (w >> 2) & 1, e = 4 * (w >> 3) + (w & 3);
+    return (p >> 5) * ((long)CH * 128) + (long)(2 * kq + hh) * 1024 + (p & 31) * 32 + plane * 16 + e * 2;
+}
+// float offset of (p, ch) in the skip buffer
+static inline long wfl_skip_off(long p, int ch, int C) { return (p >> 5) * ((long)C * 32) + (long)(ch >> 2) * 128 + (p & 31) * 4 + (ch & 3); }
 
 struct WflWeights {          // one residual layer, as packed by wfl_pack()
-    const uint16_t* w1;      // [WFL_KS1][part][co-tile][lane][8]: conv taps (kr*3 + kc) x 4 k-steps, then the condition block
-    const uint16_t* w2;      // [WFL_KS2][part][out-tile][lane][8]: res (tiles 0, 1) | skip (tiles 2, 3)
-    const float* b1;         // [128] conv bias + condition_proj bias: content 0..63, gate 64..127
-    const float* b2s;        // [128] out_proj bias * 2^(14 + k2): res 0..63, skip 64..127
+    const uint16_t* w1;      // [KS1][part 2][co-tile 2C/32][lane 64][8]: conv taps (kr*3 + kc) x C/16 k-steps, then the condition
+    const uint16_t* w2;      // [pass res | skip][k2 C/16][part 2][tile C/32][lane 64][8]
+    const float* b1;         // [2C] conv bias + condition_proj bias: content 0..C-1, gate C..2C-1
+    const float* b2s;        // [2C] out_proj bias * 2^(14 + k2): res 0..C-1, skip C..2C-1
     int k1, k2res, k2skip;   // block-scale exponents of the three weight tensors (pk_split.h)
 };
 
@@ -38,36 +52,36 @@ struct WflPacked {
     size_t b1, b2s;          // offsets (floats) into f32
     int k1, k2res, k2skip;
 };
-WflPacked wfl_pack(const float* conv, const float* conv_b, const float* cond, const float* cond_b, int n_mels,
+WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* cond, const float* cond_b, int n_mels,
                    const float* outp, const float* outp_b, std::vector<uint16_t>& w16, std::vector<float>& f32);
 
 struct WflLaunch {
     WflWeights w;
-    const float* in0;        // layer input ring, slot 0 (blocked [pos/32][64][32]); slot s at in0 + s * slot_stride
-    long slot_stride;        // floats
-    const unsigned* in_amax0;   // max|.| per 32-position block of slot 0; slot s at + s * amax_stride
+    int C;                   // 64 or 128
+    const float* in0;        // layer input ring, slot 0 (planes, C channels; one float = one 4-byte slot); slot s at + s * slot_stride
+    long slot_stride;        // slots (= floats)
+    const unsigned* in_amax0;   // max|.| per 32-position block of slot 0 (fp32 bits); slot s at + s * amax_stride
     long amax_stride;
     int cur_slot;            // slot of the current row (residual input = centre tap of the last kernel row)
-    float* out;              // next layer's input, slot of the current row, or NULL (last layer)
+    float* out;              // next layer's input, slot of the current row (planes), or NULL (last layer)
     unsigned* out_amax;
-    float* skip;             // running skip sum (blocked), written (first) or accumulated
+    float* skip;             // running skip sum (fp32, wfl_skip_off layout), written (first) or accumulated
     int first;
-    const float* cond;       // condition row (blocked [pos/32][96][32])
+    const float* cond;       // condition row (planes, 96 channels)
     const unsigned* cond_amax;
     int ntap;                // conv taps whose input row exists (3, 6 or 9)
     int tap_slot[9], tap_shift[9], tap_w[9];   // ring slot, position shift, weight tap index kr*3 + kc
     const int* pos_utt;      // [npos_alloc] utterance of a position, < 0: gap (outputs forced to 0)
     int npos_alloc;          // multiple of 32
     int active, tiles_per_wg;   // set by wfl_layer_launch: most waves that take a tile per round, tiles per workgroup
-    int warm;                   // measurement switches: bit 0 touch the weight lines up front, bit 1 even rounds
 };
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);
 
-// max|cond| per 32-position block of every folded row: cond [rows][pos/32][96][32] -> amax [rows][pos/32]
-int wfl_cond_amax_launch(pk_ctx* ctx, const float* cond, long row_stride, int rows, int nblk, long amax_row_stride,
-                         unsigned* amax);
-// k_wf_step on the blocked layout: params = output_proj(skip sum), x[i] = (z'[i] - b) * exp(-logs), then
-// h0 = input_proj(x[i]) into layer 0's ring (blocked) with its block maxima
-int wfl_step_launch(pk_ctx* ctx, const float* skip, const float* w_out, float b_logs, float b_b, const float* z_row,
+// The folded condition rows, written by the upsampler as fp32 [rows][pos / 32][96][32], become planes IN PLACE (one wave
+// per block: read the block, take its maximum, write it back split) with amax [rows][pos / 32].
+int wfl_cond_planes_launch(pk_ctx* ctx, float* cond, long row_stride, int rows, int nblk, long amax_row_stride, unsigned* amax);
+// Flow._predict_row_parameters + _inverse_transform_row + input_proj of the new row: params = output_proj(skip sum),
+// x[i] = (z'[i] - b) * exp(-logs), then h0 = input_proj(x[i]) into layer 0's ring (planes) with its block maxima
+int wfl_step_launch(pk_ctx* ctx, int C, const float* skip, const float* w_out, float b_logs, float b_b, const float* z_row,
                     float* x_row, const float* w_in, const float* b_in, float* h0_next, unsigned* h0_amax,
                     const int* pos_utt, int npos_alloc, int first);

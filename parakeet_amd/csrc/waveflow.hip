@@ -307,8 +307,8 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
             pk_gemm_pack_h3(kn2.data(), C, 2 * C, ph);
             F.layers[l].w2h = put16(h->arena16_h, ph);
             F.layers[l].b2 = ar.put(bo);
-            if (C == WFL_C && MP == WFL_MP)
-                F.layers[l].fl = wfl_pack(wc.data(), bc.data(), wp.data(), bp.data(), M, wo.data(), bo.data(),
+            if (wfl_supports(C) && MP == WFL_MP)
+                F.layers[l].fl = wfl_pack(C, wc.data(), bc.data(), wp.data(), bp.data(), M, wo.data(), bo.data(),
                                           h->arena16_h, h->arena_h);
         }
     }
@@ -443,7 +443,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     // block scaling of the split-fp16 GEMMs (pk_split.h): max|row| of every hist / cond row, kept next to the data
     // so that a launch only scans the one row set that is new (zero = margins, gaps and rows not yet written)
     // (the fused layer kernel keeps block maxima instead, one per 32 positions, in the same buffers)
-    const bool use_wfl = C == WFL_C && MP == WFL_MP && h->math == PK_GEMM_MATH_F16X3 && !h->no_fuse;
+    const bool use_wfl = wfl_supports(C) && MP == WFL_MP && h->math == PK_GEMM_MATH_F16X3 && !h->no_fuse;
     const long bstride = pstride / WFL_BLK;   // blocks per buffer row incl. margins
     PK_TRY(h->ws_hamax.reserve((size_t)(NL + 1) * 3 * pstride * 4));
     PK_TRY(h->ws_camax.reserve((size_t)G * pstride * 4));
@@ -492,7 +492,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     unsigned* hbmax = h->ws_hamax.as<unsigned>() + WF_LEAD / WFL_BLK;   // block maxima (fused layer kernel)
     unsigned* cbmax = h->ws_camax.as<unsigned>() + WF_LEAD / WFL_BLK;
     auto hbmax_ptr = [&](int layer, int slot) { return hbmax + ((size_t)layer * 3 + slot) * bstride; };
-    if (use_wfl) PK_TRY(wfl_cond_amax_launch(ctx, cond, cond_row, G, npos_alloc / WFL_BLK, bstride, cbmax));
+    if (use_wfl) PK_TRY(wfl_cond_planes_launch(ctx, cond, cond_row, G, npos_alloc / WFL_BLK, bstride, cbmax));   // in place
     else if (split_math) PK_TRY(pk_row_amax_launch(ctx, cond, MP, MP, 0, (long)G * pstride - WF_LEAD, camax));
     // ---- fold z
     PK_LAUNCH(ctx, "wf_fold", k_wf_fold, dim3(pk_div_up(npos, 256)), dim3(256), 0, d_z, d_tab + o_putt, d_tab + o_pw,
@@ -512,7 +512,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         const WfFlowW& F = h->flows[fl];
         // row 0: copy + input_proj into slot 1 of layer 0
         if (use_wfl) {
-            PK_TRY(wfl_step_launch(ctx, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[0] * pstride, nxt,
+            PK_TRY(wfl_step_launch(ctx, C, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[0] * pstride, nxt,
                                    h->W(F.w_in), h->W(F.b_in), hist_ptr(0, 1), hbmax_ptr(0, 1), rowvalid, npos_alloc, 1));
         } else {
         PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out), F.b_logs,
@@ -528,6 +528,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 // the fused layer kernel (wf_layer.hip): conv taps + condition + gate + res|skip projection
                 const WfLayerW& L = F.layers[l];
                 WflLaunch w;
+                w.C = C;
                 w.w.w1 = h->arena16.as<uint16_t>() + L.fl.w1;
                 w.w.w2 = h->arena16.as<uint16_t>() + L.fl.w2;
                 w.w.b1 = h->W(L.fl.b1);
@@ -641,7 +642,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
             }
             float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
             if (use_wfl) {
-                PK_TRY(wfl_step_launch(ctx, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[i] * pstride,
+                PK_TRY(wfl_step_launch(ctx, C, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[i] * pstride,
                                        nxt + (long)i * pstride, h->W(F.w_in), h->W(F.b_in), h0n,
                                        h0n ? hbmax_ptr(0, (i + 1) % 3) : nullptr, rowvalid, npos_alloc, 0));
                 continue;

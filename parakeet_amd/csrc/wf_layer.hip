@@ -1,26 +1,28 @@
-// wf_layer.hip -- one WaveFlow residual layer for one autoregressive row as ONE kernel (64-channel model, split-fp16
-// math): the (3,3) dilated causal conv over the 3-row input ring + condition_proj as one contraction (K = 9*64 + 96),
-// gated tanh, the res|skip out projection, the residual into the next layer's ring and the skip accumulation.
+// wf_layer.hip -- one WaveFlow residual layer for one autoregressive row as ONE kernel (64- or 128-channel model,
+// split-fp16 math): the (3,3) dilated causal conv over the 3-row input ring + condition_proj as one contraction
+// (K = 9 C + 96), gated tanh, the res|skip out projection, the residual into the next layer's ring and the skip
+// accumulation.
 //
 // Reference: parakeet/models/waveflow.py ResidualBlock.add_input :248-283 (conv2d over the row buffer :268-274,
 // condition_proj :275, gate :276-277, out_proj + chunk + residual :279-282), ResidualNet.add_input :368-392.
 //
-// Why not the shared GEMM (k_gemm_h3 with the PK_EPI_GATE_PROJ epilogue, which this replaces for C = 64): with
-// N = 128 output columns a 64-row GEMM tile re-reads the whole 336 KB of split weights for 10.7 MFLOP of work, 1296
-// times per launch -- the launch is bound by weight traffic out of the L2 and by LDS bandwidth (both operands pass
-// through LDS), at 16 % of the matrix pipe.  Here the roles are swapped, as in the Parallel WaveGAN layer kernel:
-//   * positions are the MFMA N dimension: a wave owns 32 positions and ALL 128 gate channels (4 accumulator tiles),
-//     its B operand (the input features of those positions, per tap) comes straight from global memory / L2 into
-//     registers -- the blocked [pos/32][ch][32] layout makes every load a coalesced 128-byte segment -- and is
-//     split in registers;
-//   * weights are the A operand: streamed through LDS in slabs of six k-steps (48 KB), double buffered, each slab
-//     used by the 8 waves = 256 positions of the workgroup -- a slab is 72 MFMAs per wave, long enough to cover the
-//     L2 latency of the next slab's loads (two-k-step slabs measured 1.9 us per slab against 0.64 us of matrix
-//     work); the out-projection weights (32 KB) stay resident;
-//   * the gated activations never leave the accumulator registers: register r of the first contraction IS the B
-//     operand element of k-step r / 8 of the second (K order of W2 permuted at pack time), as in pwg.hip;
-//   * results are stored in the same blocked layout (coalesced), with the block maxima the next layer's operand
-//     scale needs (pk_split.h).
+// Structure (as the Parallel WaveGAN layer kernel): positions are the MFMA N dimension -- a wave owns 32 positions and
+// ALL 2C gate channels (2C/32 accumulator tiles); weights are the A operand, streamed through LDS in 48 KB slabs,
+// double buffered, each slab used by the 8 waves = 256 positions of the workgroup; the gated activations never leave
+// the accumulator registers (register r of the first contraction IS the B operand element of k-step r / 8 of the
+// second: K order of W2 permuted at pack time); the out-projection weights follow the conv weights through the same
+// slab buffers (32 KB resident in round 2; at 128 channels they are 128 KB).
+//
+// Round 3: the layer inputs are stored as pre-split fp16 planes (pk_wf_layer.h).  In round 2 a wave tile spent 12.5 k
+// of its 30 k cycles in the VALU (rocprofv3: SQ_ACTIVE_INST_VALU 8.1 M quad-cycles per launch against 43 M matrix
+// cycles / 4 SIMDs), most of it the hi / lo split of every operand -- nine times per stored value, once per tap that
+// reads it -- and the scalar loads that fed it (8 dword loads per k-step: the vmcnt counter holds 63 loads, i.e. less
+// than 8 k-steps of prefetch).  Now the producer's epilogue splits each value once; a k-step's operand is two 16-byte
+// loads and one v_pk_mul_f16 per register (the power of two that brings the tap's block to the tile's common scale).
+// The operand ring is two weight slabs deep (k-step k's registers are refilled with k-step k + 2 slabs' operand as
+// soon as k has been consumed; the slab loop is unrolled by two so that ring slots are compile-time registers) and
+// the epilogue's old values (residual input, running skip sum) are requested before the gate, a few hundred VALU
+// instructions ahead of their use, not right before the 24 MFMAs of their pass.
 // Rows before the sequence start are skipped as taps (ntap = 3, 6, 9), never stored as zeros.
 #include "pk_wf_layer.h"
 
@@ -28,12 +30,14 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "pk_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
@@ -41,10 +45,28 @@ namespace {
 constexpr int WAVES = 8;
 constexpr int THREADS = WAVES * 64;
 constexpr int WAVE_T = 32;
-constexpr int KCH = 512;   // 16-byte chunks per k-step of A fragments (= threads: one chunk per thread per k-step)
-constexpr int SLAB = 6;    // k-steps per weight slab: 18, 30 and 42 k-steps (3, 6, 9 taps + condition) are multiples
-constexpr int BLK_C = WFL_C * WFL_BLK;      // 2048 floats per feature block
-constexpr int BLK_M = WFL_MP * WFL_BLK;     // 3072 floats per condition block
+constexpr int SLAB_BYTES = 48 * 1024;   // one weight slab in LDS; two of them
+constexpr int SLAB_CH = SLAB_BYTES / 16;   // 16-byte chunks per slab buffer
+constexpr int BLK_M_BYTES = WFL_MP * 128;  // bytes per 32-position block of the condition planes
+
+template <int CT>
+struct Shape {
+    static constexpr int C = 32 * CT;
+    static constexpr int KS_TAP = C / 16;                 // k-steps per conv tap: 4 / 8
+    static constexpr int KS1 = 9 * KS_TAP + WFL_KS_COND;  // 42 / 78
+    static constexpr int NQ = 2 * CT;                     // accumulator tiles of the first contraction: 4 / 8
+    static constexpr int KCH1 = 2 * NQ * 64;              // chunks per k-step of W1: 512 / 1024
+    static constexpr int SLAB = SLAB_CH / KCH1;           // k-steps per main slab: 6 / 3
+    static constexpr int CPT1 = SLAB * KCH1 / THREADS;    // chunks per thread per main slab: 6
+    static constexpr int KS2 = C / 16;                    // k-steps of the out projection: 4 / 8
+    static constexpr int KCH2 = 2 * CT * 64;              // chunks per (pass, k-step) unit of W2: 256 / 512
+    static constexpr int U2 = 2 * KS2;                    // units: 8 / 16
+    static constexpr int SLAB2 = (32 * 1024 / 16) / KCH2; // units per W2 slab (32 KB): 8 / 4
+    static constexpr int NS2 = U2 / SLAB2;                // W2 slabs: 1 / 4
+    static constexpr int CPT2 = SLAB2 * KCH2 / THREADS;   // chunks per thread per W2 slab: 4
+    static constexpr int BLK_BYTES = C * 128;             // bytes per 32-position block of the feature planes
+    static constexpr int RING = 2 * SLAB;                 // operand ring depth in k-steps: 12 / 6
+};
 
 __host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -98,278 +120,469 @@ __device__ __forceinline__ float gated_s(float a, float b, float ca, float cb) {
     const float eb = __builtin_amdgcn_exp2f(b * cb);
     return fmaf(ea, -PK_UNIT_SCALE, PK_UNIT_SCALE) * __builtin_amdgcn_rcpf((1.f + ea) * (1.f + eb));
 }
+// biased exponent of a block maximum, clamped as blk_scale_exp clamps it (pk_split.h)
+__device__ __forceinline__ int amax_exp(unsigned bits) {
+    const int e = (int)(bits >> 23);
+    return e < PK_EXP_MIN ? PK_EXP_MIN : (e > PK_EXP_MAX ? PK_EXP_MAX : e);
+}
+// eight copies of the fp16 value 2^-d (d >= 0; subnormal / zero beyond 2^-14: what the rescaled values would be anyway)
+__device__ __forceinline__ f16x8 pow2_neg_h8(int d) {
+    const float f = __uint_as_float((unsigned)(127 - min(d, 60)) << 23);
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f, f));
+    const u32x4 v = {u, u, u, u};
+    return __builtin_bit_cast(f16x8, v);
+}
+__device__ __forceinline__ f16x8 ld_h8(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+__device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 
-__global__ __launch_bounds__(THREADS, 2) void k_wf_layer(WflLaunch a) {
-    __shared__ __attribute__((aligned(16))) f16x8 wbuf[2][SLAB * KCH];   // two slabs of six k-steps: 96 KB
-    __shared__ __attribute__((aligned(16))) f16x8 w2l[WFL_KS2 * KCH]; // out projection, resident: 32 KB
-    __shared__ float lb[256];                                         // b1 [128] | b2s [128]
-    // per logical k-step (taps whose row exists, then the condition block): where its B operand lives and which
-    // packed weight k-step multiplies it.  Table driven so that the loads below are straight-line code: with
-    // branches around them hipcc's s_waitcnt insertion falls back to vmcnt(0) before every load (seen in the first
-    // version of this kernel: 60 % of the wave cycles in SQ_WAIT_ANY).
-    __shared__ long kt_off[WFL_KS1];     // element offset from in0 of (position 0, channel 0 of this k-step)
-    __shared__ int kt_shift[WFL_KS1];    // position shift of the tap
-    __shared__ int kt_blk[WFL_KS1];      // floats per 32-position block of the source (64 or 96 channels)
-    __shared__ int kt_w[WFL_KS1];        // packed k-step of W1
+// NT = ntap / 3 (1, 2, 3 rows of the ring exist): a template parameter so that the slab loop unrolls completely.  With a
+// run-time loop the operand ring is carried around the back edge, hipcc's register allocator does not keep the refilled
+// slots in place, and the copies it inserts at the loop end wait for every load in flight (vmcnt(0) once per slab pair).
+//
+// Weights: the stream of a (layer, NT) is nslab conv slabs followed by NS2 out-projection slabs, through THREE LDS buffers.
+// Slab g + 2 is requested at the start of slab g, before any of slab g's operand loads, and written to LDS at its end:
+// vmcnt counts loads in order, so waiting for a weight load also waits for every older load -- with the weights
+// requested first, "older" is only the operands the next slab needs anyway, and the operands of slab g + 2 (requested
+// during slab g) stay in flight across the wait.  (With two buffers the weights of slab g + 1 would be requested during
+// slab g - 1's operand prefetch and their wait would drain it: measured in the ISA as vmcnt(6) two k-steps after a load
+// that is needed twelve k-steps later.)
+template <int CT, int NT>
+__global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
+    typedef Shape<CT> S;
+    constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, RING = S::RING;
+    constexpr int ntap = 3 * NT;
+    constexpr int nks_conv = S::KS_TAP * ntap;
+    constexpr int nks = nks_conv + WFL_KS_COND;
+    constexpr int nslab = nks / SLAB;    // C = 64: 3, 5, 7;  C = 128: 10, 18, 26
+    constexpr int G = nslab + S::NS2;    // slabs of the weight stream
+    __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];   // three weight slabs: 144 KB
+    __shared__ float lb[4 * C];                                        // b1 [2C] | b2s [2C]
+    // per logical k-step (taps whose row exists, then the condition block): where its B operand lives and which packed
+    // weight k-step multiplies it (run-time: which ring slot a tap reads depends on the row).  The tail repeats the last
+    // k-step: the prefetch beyond the end stays unconditional.
+    __shared__ long kt_off[nks + RING];    // byte offset from in0 of (position 0, octet 2 kq) of this k-step's source
+    __shared__ long kt_am[nks + RING];     // element offset from in_amax0 of block 0 of the source's block maxima
+    __shared__ int kt_shift[nks + RING];   // position shift of the tap
+    __shared__ int kt_blk[nks + RING];     // bytes per 32-position block of the source (C or 96 channels)
+    __shared__ int kt_w[nks + RING];       // packed k-step of W1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hi = lane >> 5;
-    {
-        const f16x8* src = reinterpret_cast<const f16x8*>(a.w.w2);
-        for (int i = tid; i < WFL_KS2 * KCH; i += THREADS) w2l[i] = src[i];
-        if (tid < 128) lb[tid] = a.w.b1[tid];
-        else if (tid < 256) lb[tid] = a.w.b2s[tid - 128];
-    }
-    __syncthreads();
-    // Measurement switch (PK_WF_WARM bit 0, default off): touch one dword of every 128-byte line of W1 up front.
-    // Every launch uses another layer's weights, so their lines are cold in this XCD's L2; measured: no gain (the
-    // slab loads are issued a slab ahead, which covers the miss).
-    float warm = 0.f;
-    if (a.warm & 1) {
-        const float* wl = reinterpret_cast<const float*>(a.w.w1);
-        constexpr int W1_LINES = (int)(WFL_W1_HALVES * 2 / 128);   // 2688
-        for (int i = tid; i < W1_LINES; i += THREADS) warm += wl[(long)i * 32];
-    }
-    const int ntap = a.ntap;
-    const int nks_conv = WFL_KS_TAP * ntap;
-    const int nks = nks_conv + WFL_KS_COND;
-    const int nslab = nks / SLAB;  // 3, 5 or 7
-    if (tid < nks) {
-        const int ks = tid;
+    const int j = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < 4 * C; i += THREADS) lb[i] = i < 2 * C ? a.w.b1[i] : a.w.b2s[i - 2 * C];
+    if (tid < nks + RING) {
+        const int ks = min(tid, nks - 1);
         if (ks < nks_conv) {
-            const int t = ks >> 2;
-            kt_off[ks] = (long)a.tap_slot[t] * a.slot_stride + (long)(16 * (ks & 3)) * WFL_BLK;
-            kt_shift[ks] = a.tap_shift[t];
-            kt_blk[ks] = BLK_C;
-            kt_w[ks] = a.tap_w[t] * WFL_KS_TAP + (ks & 3);
+            const int t = ks / S::KS_TAP, kq = ks % S::KS_TAP;
+            kt_off[tid] = ((long)a.tap_slot[t] * a.slot_stride) * 4 + (long)(2 * kq) * 1024;
+            kt_am[tid] = (long)a.tap_slot[t] * a.amax_stride;
+            kt_shift[tid] = a.tap_shift[t];
+            kt_blk[tid] = S::BLK_BYTES;
+            kt_w[tid] = a.tap_w[t] * S::KS_TAP + kq;
         } else {
-            kt_off[ks] = (a.cond - a.in0) + (long)(16 * (ks - nks_conv)) * WFL_BLK;
-            kt_shift[ks] = 0;
-            kt_blk[ks] = BLK_M;
-            kt_w[ks] = 9 * WFL_KS_TAP + (ks - nks_conv);
+            kt_off[tid] = (reinterpret_cast<const char*>(a.cond) - reinterpret_cast<const char*>(a.in0)) +
+                          (long)(2 * (ks - nks_conv)) * 1024;
+            kt_am[tid] = a.cond_amax - a.in_amax0;
+            kt_shift[tid] = 0;
+            kt_blk[tid] = BLK_M_BYTES;
+            kt_w[tid] = 9 * S::KS_TAP + (ks - nks_conv);
         }
     }
-    const f16x8* w1 = reinterpret_cast<const f16x8*>(a.w.w1) + tid;
-    auto w_kstep = [&](int ks) -> const f16x8* { return w1 + (long)kt_w[ks] * KCH; };   // packed k-step of logical ks
+    const f16x8* w1 = reinterpret_cast<const f16x8*>(a.w.w1);
+    const f16x8* w2 = reinterpret_cast<const f16x8*>(a.w.w2);
+    const char* in0b = reinterpret_cast<const char*>(a.in0);
     __syncthreads();   // tables visible
     const int ntiles = a.npos_alloc / WAVE_T;
     const float i_res = pow2f(-(PK_UNIT_EXP + a.w.k2res)), i_skip = pow2f(-(PK_UNIT_EXP + a.w.k2skip));
-    // A workgroup owns tiles_per_wg consecutive wave tiles and works through them in rounds of at most `active`
-    // tiles (one pass over the weights per round).  The waves of a round run in lockstep (they share the LDS weight
-    // slabs), so a round takes as long as its busiest SIMD: measured 25 us with one working wave per SIMD, 35 us
-    // with two.  Full rounds first (11 tiles = 8 + 3: 35 + 25 us) therefore beat even rounds (6 + 5: a SIMD with two
-    // waves in both, 35 + 35 us) and rounds of four (3 x 25 us).  The other waves only move weights and keep the
-    // barriers.
+    // A workgroup owns tiles_per_wg consecutive wave tiles and works through them in rounds of at most `active` tiles
+    // (one pass over the weights per round).  The waves of a round run in lockstep (they share the LDS weight slabs);
+    // waves without a tile only move weights and keep the barriers.
     const int t_begin = (int)blockIdx.x * a.tiles_per_wg, t_end = min(t_begin + a.tiles_per_wg, ntiles);
-    const int nrounds = (t_end - t_begin + a.active - 1) / a.active;
 
-    for (int base = t_begin, rnd = 0; base < t_end; ++rnd) {   // uniform over the workgroup
-        const int nact = (a.warm & 2) ? (t_end - base + (nrounds - rnd) - 1) / (nrounds - rnd)   // even rounds (A/B)
-                                      : min(a.active, t_end - base);                           // tiles of this round
+    // chunk c of this thread in slab g of the weight stream (its slot in the LDS slab buffer is c * THREADS + tid)
+    // (tz: an opaque zero, renewed per slab -- the tables are the same in every round and every slab, and with the slab
+    // loop unrolled the compiler would otherwise read all of them up front and hold them in registers)
+    auto w_src = [&](int g, int c, int tz) -> const f16x8* {
+        const int f = c * THREADS + tid;
+        if (g < nslab) return w1 + (long)kt_w[SLAB * g + f / S::KCH1 + tz] * S::KCH1 + (f % S::KCH1);
+        return w2 + (long)(g - nslab) * (S::SLAB2 * S::KCH2) + f;
+    };
+    f16x8 wreg[S::CPT1];   // one slab of weights on its way from global memory to LDS
+    auto w_load = [&](int g, int tz) {
+        if (g >= G) return;
+#pragma unroll
+        for (int c = 0; c < S::CPT1; ++c)
+            if (c < (g < nslab ? S::CPT1 : S::CPT2)) wreg[c] = *w_src(g, c, tz);
+    };
+    auto w_store = [&](int g) {
+        if (g >= G) return;
+#pragma unroll
+        for (int c = 0; c < S::CPT1; ++c)
+            if (c < (g < nslab ? S::CPT1 : S::CPT2)) wbuf[g % 3][c * THREADS + tid] = wreg[c];
+    };
+
+    for (int base = t_begin; base < t_end;) {   // uniform over the workgroup
+        const int nact = min(a.active, t_end - base);
         const int wt = base + wave;
         const bool tile_ok = wave < nact;
         base += nact;
         const int p0 = tile_ok ? wt * WAVE_T : 0;
         const int p = p0 + j;
         const bool lane_ok = tile_ok && a.pos_utt[p] >= 0;
+        // the bias reads below are the same in every round: without this the compiler keeps them in registers across the
+        // round loop
+        int lz = 0;
+        asm volatile("" : "+s"(lz));
+        const float* lbr = lb + lz;
 
-        // ---- operand scale of this wave tile: the largest block maximum among the blocks its taps read
-        int kx;
-        {
-            float m = 0.f;
-            if (lane < 2 * ntap) {
-                const int t = lane >> 1;
-                const int blk = (p0 + a.tap_shift[t] + 31 * (lane & 1)) >> 5;
-                m = __uint_as_float(a.in_amax0[(long)a.tap_slot[t] * a.amax_stride + blk]);
-            } else if (lane == 2 * ntap) {
-                m = __uint_as_float(a.cond_amax[p0 >> 5]);
-            }
-            m = wave_max64(m);
-            kx = blk_scale_exp(__float_as_uint(m));
-        }
-        const int ks1 = kx + a.w.k1;
-        const float sx = pow2f(kx), S1 = pow2f(ks1);
-        const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
-        const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
-
-        f32x16 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = lb[32 * q + mfma_row(r, hi)] * S1;
-
-        // ---- B operand of k-step ks: 8 channels per lane, 128-byte segments across the lanes of a half wave
-        auto load_b = [&](int ks, float (&dst)[8]) {
-            const int q = p + kt_shift[ks];
-            const float* src = a.in0 + kt_off[ks] + (long)(q >> 5) * kt_blk[ks] + (q & 31) + (8 * hi) * WFL_BLK;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dst[e] = src[e * WFL_BLK];
-        };
-        f16x8 wreg[SLAB];      // next slab's weights on their way from global memory to the other LDS buffer
-        // Working and idle waves run separate copies of the slab loop (same number of barriers): the working copy
-        // has no branch inside, loads and LDS stores are unconditional (the slab after the last one is the last one
-        // again, parked in the buffer nobody reads any more).
+        // Working and idle waves run separate copies of the whole round (same number of barriers): the working copy
+        // has no branch inside, and nothing of it is live in the idle copy.
         if (tile_ok) {
-            float ring[SLAB][8];   // B operands, one slab ahead: slot kk is refilled as soon as k-step kk has split it
-#pragma unroll
-            for (int kk = 0; kk < SLAB; ++kk) {
-                wreg[kk] = *w_kstep(kk);
-                load_b(kk, ring[kk]);
+            // ---- common scale of this wave tile: the largest block maximum among the blocks its taps read
+            int ex;   // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex
+            {
+                float m = 0.f;
+                if (lane < 2 * ntap) {
+                    const int t = lane >> 1;
+                    const int blk = (p0 + a.tap_shift[t] + 31 * (lane & 1)) >> 5;
+                    m = __uint_as_float(a.in_amax0[(long)a.tap_slot[t] * a.amax_stride + blk]);
+                } else if (lane == 2 * ntap) {
+                    m = __uint_as_float(a.cond_amax[p0 >> 5]);
+                }
+                m = wave_max64(m);
+                ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(m)));
             }
+            const int kx = PK_BLK_TOP + 127 - ex;
+            const int ks1 = kx + a.w.k1;
+            const float S1 = pow2f(ks1);
+            const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
+            const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
+
+            f32x16 acc[NQ];
 #pragma unroll
-            for (int kk = 0; kk < SLAB; ++kk) wbuf[0][kk * KCH + tid] = wreg[kk];
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = lbr[32 * q + mfma_row(r, hh)] * S1;
+
+            // ---- B operand of k-step ks: the lane's 8 channels (octet 2 kq + hh) of position p + shift, hi and lo vectors;
+            // with the first k-step of a tap also the maximum of the block that position lies in (for the rescale to the
+            // tile's common scale; a tap's k-steps share it: at most 4 taps are in flight)
+            f16x8 rhi[RING], rlo[RING];
+            unsigned ram[4];
+            auto tap_of = [&](int ks) { return ks < nks_conv ? ks / S::KS_TAP : ntap; };
+            auto load_b = [&](int ksu, int tz) {   // ksu may run past the end: the table tail repeats the last k-step
+                const int ks = ksu < nks ? ksu : nks - 1, slot = ksu % RING, ti = ksu + tz;
+                const int q = p + kt_shift[ti];
+                const char* src = in0b + kt_off[ti] + (long)(q >> 5) * kt_blk[ti] + (q & 31) * 32 + hh * 1024;
+                rhi[slot] = ld_h8(src);
+                rlo[slot] = ld_h8(src + 16);
+                if (ksu < nks && (ks == nks_conv || (ks < nks_conv && ks % S::KS_TAP == 0)))
+                    ram[tap_of(ks) % 4] = (a.in_amax0 + kt_am[ti])[q >> 5];
+            };
+            const long pblk = (long)(p >> 5);
+            const int pin = p & 31;
+
+            w_load(0, lz);
+#pragma unroll
+            for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nslab >= 3: the first two slabs always exist
+            w_store(0);
+            w_load(1, lz);
+            w_store(1);
             __syncthreads();
-            for (int s = 0; s < nslab; ++s) {
-                const int sn = min(s + 1, nslab - 1);
 #pragma unroll
-                for (int kk = 0; kk < SLAB; ++kk) wreg[kk] = *w_kstep(SLAB * sn + kk);
+            for (int g = 0; g < nslab; ++g) {
+                int tz = 0;
+                asm volatile("" : "+s"(tz));
+                // 128 channels (128 accumulator registers): the slab's weights travel in two halves of 12 registers, the
+                // second requested when the first has gone to LDS after the first k-step, and a ring slot is rescaled in
+                // place and refilled after its k-step's MFMAs.  (A k-step is 24 MFMAs there: the loads a weight wait drains
+                // early are still three k-steps = 2 300 matrix cycles old.)
+                constexpr bool TIGHT = CT == 4;
+                const int NW = g + 2 >= G ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = TIGHT ? NW / 2 : NW;   // constants once unrolled
+#pragma unroll
+                for (int c = 0; c < S::CPT1; ++c)
+                    if (c < HW) wreg[c] = *w_src(g + 2, c, tz);   // first: every load below is younger
                 __builtin_amdgcn_sched_barrier(0);   // keep the weight loads up here: hipcc would sink them to their stores
-                const f16x8* wl = wbuf[s & 1] + lane;
+                // (the slab's LDS base as ONE opaque register: from a constant base the third buffer's fragments lie beyond the
+                // 64 KB reach of a ds_read offset, and the compiler keeps a separate address register for each of them)
+                unsigned wo = (g % 3) * SLAB_CH + lane;
+                asm volatile("" : "+v"(wo));
+                const f16x8* wl = &wbuf[0][0] + wo;
 #pragma unroll
                 for (int kk = 0; kk < SLAB; ++kk) {
+                    const int ks = SLAB * g + kk, slot = ks % RING;
+                    const f16x8 f = pow2_neg_h8(ex - amax_exp(ram[tap_of(ks) % 4]));
                     f16x8 bh, bl;
-                    split8s(ring[kk], sx, bh, bl);
-                    load_b(SLAB * sn + kk, ring[kk]);
-                    __builtin_amdgcn_sched_barrier(0);   // ... and these ahead of the k-step's MFMAs
+                    if (TIGHT) {
+                        rhi[slot] *= f;
+                        rlo[slot] *= f;
+                    } else {
+                        bh = rhi[slot] * f;
+                        bl = rlo[slot] * f;
+                        __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
+                        load_b(ks + RING, tz);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // ... and the loads ahead of the k-step's MFMAs
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f16x8 ah = wl[kk * KCH + (0 * 4 + q) * 64];
-                        const f16x8 al = wl[kk * KCH + (1 * 4 + q) * 64];
-                        acc[q] = mfma16(ah, bh, acc[q]);
-                        acc[q] = mfma16(al, bh, acc[q]);
-                        acc[q] = mfma16(ah, bl, acc[q]);
+                    for (int q = 0; q < NQ; ++q) {
+                        const f16x8 ah = wl[kk * S::KCH1 + (0 * NQ + q) * 64];
+                        const f16x8 al = wl[kk * S::KCH1 + (1 * NQ + q) * 64];
+                        acc[q] = mfma16(ah, TIGHT ? rhi[slot] : bh, acc[q]);
+                        acc[q] = mfma16(al, TIGHT ? rhi[slot] : bh, acc[q]);
+                        acc[q] = mfma16(ah, TIGHT ? rlo[slot] : bl, acc[q]);
+                    }
+                    // A fragments at most one co-tile ahead of their MFMAs (16 registers, not 8 NQ)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int q = 0; q + 1 < NQ; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    if (TIGHT) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_b(ks + RING, tz);
+                        if (kk == 0 && NW > 0) {
+#pragma unroll
+                            for (int c = 0; c < S::CPT1; ++c)
+                                if (c < HW) wbuf[(g + 2) % 3][c * THREADS + tid] = wreg[c];
+#pragma unroll
+                            for (int c = 0; c < S::CPT1; ++c)
+                                if (c < NW - HW) wreg[c] = *w_src(g + 2, HW + c, tz);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
-                for (int kk = 0; kk < SLAB; ++kk) wbuf[(s + 1) & 1][kk * KCH + tid] = wreg[kk];
-                __syncthreads();   // everyone is done reading this slab's buffer and sees the other one
+                for (int c = 0; c < S::CPT1; ++c)
+                    if (c < (TIGHT ? NW - HW : NW)) wbuf[(g + 2) % 3][((TIGHT ? HW : 0) + c) * THREADS + tid] = wreg[c];
+                __syncthreads();   // everyone is done reading this slab's buffer and sees the next two
+            }
+            // the ring is dead: request the epilogue's old values now, a whole gate ahead of their use
+            f16x8 xin_hi[S::KS2], xin_lo[S::KS2];   // residual input: this lane's centre-tap vectors of the current row
+            f32x4 skip_old[4 * CT];                 // running skip sum: 4 channels per register, (tile t, group g) -> [4 t + g]
+            unsigned cur_am;
+            {
+                const char* cur = in0b + ((long)a.cur_slot * a.slot_stride) * 4 + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
+#pragma unroll
+                for (int kq = 0; kq < S::KS2; ++kq) {
+                    xin_hi[kq] = ld_h8(cur + kq * 2048);
+                    xin_lo[kq] = ld_h8(cur + kq * 2048 + 16);
+                }
+                cur_am = a.in_amax0[(long)a.cur_slot * a.amax_stride + (p0 >> 5)];
+                const f32x4* sk = reinterpret_cast<const f32x4*>(a.skip) + pblk * (C * 8) + pin;
+                if (CT == 2) {   // (128 channels: requested at the start of the skip pass, the registers are not free before)
+#pragma unroll
+                    for (int t = 0; t < CT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            skip_old[4 * t + g] = a.first ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
+                }
+            }
+            // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection
+            __builtin_amdgcn_sched_barrier(0);   // the old-value loads stay ahead of the gate
+            f16x8 zh[S::KS2], zl[S::KS2];
+#pragma unroll
+            for (int k2 = 0; k2 < S::KS2; ++k2) {
+                const int zq = k2 >> 1, r0 = 8 * (k2 & 1);
+                float zv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zv[e] = gated_s(acc[zq][r0 + e], acc[zq + CT][r0 + e], gca, gcb);
+                split8(zv, zh[k2], zl[k2]);
+            }
+            // ---- out projection: pass 0 = res (-> next layer's input planes), pass 1 = skip; its weights follow the conv
+            // weights through the slab buffers (NS2 slabs of 32 KB, pass-major).  C = 64: one slab holds both passes.
+            float am = 0.f;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                f32x16 acc2[CT];
+#pragma unroll
+                for (int t = 0; t < CT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[t][r] = lbr[2 * C + C * pass + 32 * t + mfma_row(r, hh)];
+                if (CT == 4 && pass == 1) {
+                    const f32x4* sk = reinterpret_cast<const f32x4*>(a.skip) + pblk * (C * 8) + pin;
+#pragma unroll
+                    for (int t = 0; t < CT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            skip_old[4 * t + g] = a.first ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
+                }
+                constexpr int SPP = S::NS2 >= 2 ? S::NS2 / 2 : 1;   // slabs per pass
+                constexpr int KPS = S::KS2 / SPP;                   // k-steps of a pass per slab
+#pragma unroll
+                for (int h2 = 0; h2 < SPP; ++h2) {
+                    const int g = nslab + (S::NS2 >= 2 ? pass * SPP + h2 : 0);   // slab of the weight stream
+                    unsigned wo = (g % 3) * SLAB_CH + lane;
+                    asm volatile("" : "+v"(wo));
+                    const f16x8* buf = &wbuf[0][0] + wo;
+                    if (S::NS2 >= 2) w_load(g + 2, 0);
+                    const int u0 = S::NS2 >= 2 ? 0 : pass * S::KS2;   // first unit of this pass inside the slab
+#pragma unroll
+                    for (int kk = 0; kk < KPS; ++kk) {
+                        const int k2 = h2 * KPS + kk;
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) {
+                            const f16x8 ah = buf[(u0 + kk) * S::KCH2 + (0 * CT + t) * 64];
+                            const f16x8 al = buf[(u0 + kk) * S::KCH2 + (1 * CT + t) * 64];
+                            acc2[t] = mfma16(ah, zh[k2], acc2[t]);
+                            acc2[t] = mfma16(al, zh[k2], acc2[t]);
+                            acc2[t] = mfma16(ah, zl[k2], acc2[t]);
+                        }
+                    }
+                    if (S::NS2 >= 2) {
+                        w_store(g + 2);
+                        __syncthreads();   // slab g consumed by every wave, the next two visible
+                    }
+                }
+                if (pass == 0) {
+                    // res = x_in + res (:281) -> the next layer's input of this row, as planes with this block's scale
+                    if (a.out) {
+                        const float xs = pow2f(-(PK_BLK_TOP + 127 - amax_exp(cur_am)));   // the stored input is x * 2^k
+                        float v[CT][16];
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int kq = 2 * t + (r >> 3), e = r & 7;
+                                const float x_in = ((float)xin_hi[kq][e] + (float)xin_lo[kq][e]) * xs;
+                                float o = fmaf(acc2[t][r], i_res, x_in);
+                                if (!lane_ok) o = 0.f;   // gap positions stay zero
+                                am = fmaxf(am, fabsf(o));
+                                v[t][r] = o;
+                            }
+                        am = wave_max64(am);
+                        const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
+                        char* dst = reinterpret_cast<char*>(a.out) + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
+#pragma unroll
+                        for (int kq = 0; kq < S::KS2; ++kq) {
+                            float t8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t8[e] = v[kq >> 1][8 * (kq & 1) + e];
+                            f16x8 oh, ol;
+                            split8s(t8, so, oh, ol);
+                            st_h8(dst + kq * 2048, oh);
+                            st_h8(dst + kq * 2048 + 16, ol);
+                        }
+                        if (lane == 0) a.out_amax[p0 >> 5] = __float_as_uint(am);
+                    }
+                } else {
+                    f32x4* sk = reinterpret_cast<f32x4*>(a.skip) + pblk * (C * 8) + pin;
+#pragma unroll
+                    for (int t = 0; t < CT; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float sv = fmaf(acc2[t][4 * g + e], i_skip, skip_old[4 * t + g][e]);   // skips summed (:390)
+                                o[e] = lane_ok ? sv : 0.f;
+                            }
+                            sk[(8 * t + 2 * g + hh) * 32] = o;
+                        }
+                }
             }
         } else {
-#pragma unroll
-            for (int kk = 0; kk < SLAB; ++kk) wreg[kk] = *w_kstep(kk);
-#pragma unroll
-            for (int kk = 0; kk < SLAB; ++kk) wbuf[0][kk * KCH + tid] = wreg[kk];
+            w_load(0, lz);
+            w_store(0);
+            w_load(1, lz);
+            w_store(1);
             __syncthreads();
-            for (int s = 0; s < nslab; ++s) {
-                const int sn = min(s + 1, nslab - 1);
 #pragma unroll
-                for (int kk = 0; kk < SLAB; ++kk) wreg[kk] = *w_kstep(SLAB * sn + kk);
-#pragma unroll
-                for (int kk = 0; kk < SLAB; ++kk) wbuf[(s + 1) & 1][kk * KCH + tid] = wreg[kk];
+            for (int g = 0; g < (S::NS2 >= 2 ? G : nslab); ++g) {
+                int tz = 0;
+                asm volatile("" : "+s"(tz));
+                w_load(g + 2, tz);
+                w_store(g + 2);
                 __syncthreads();
             }
         }
-        if (!tile_ok) continue;   // (no barrier below this point)
-        // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection
-        f16x8 zh[WFL_KS2], zl[WFL_KS2];
-#pragma unroll
-        for (int k2 = 0; k2 < WFL_KS2; ++k2) {
-            const int zq = k2 >> 1, r0 = 8 * (k2 & 1);
-            float zv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) zv[e] = gated_s(acc[zq][r0 + e], acc[zq + 2][r0 + e], gca, gcb);
-            split8(zv, zh[k2], zl[k2]);
-        }
-        // ---- out projection in two passes (res, skip): 32 old values + 32 accumulators live at a time
-        const long po = (long)(p >> 5) * BLK_C + (p & 31);
-        const float* res_in = a.in0 + (long)a.cur_slot * a.slot_stride + po;
-        float am = 0.f;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            float old[32];
-            const float* osrc = pass == 0 ? res_in : a.skip + po;
-            if (pass == 0 || !a.first) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) old[16 * q + r] = osrc[(32 * q + mfma_row(r, hi)) * WFL_BLK];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 32; ++e) old[e] = 0.f;
-            }
-            f32x16 acc2[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[q][r] = lb[128 + 64 * pass + 32 * q + mfma_row(r, hi)];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k2 = 0; k2 < WFL_KS2; ++k2)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const f16x8 ah = w2l[k2 * KCH + (0 * 4 + 2 * pass + q) * 64 + lane];
-                    const f16x8 al = w2l[k2 * KCH + (1 * 4 + 2 * pass + q) * 64 + lane];
-                    acc2[q] = mfma16(ah, zh[k2], acc2[q]);
-                    acc2[q] = mfma16(al, zh[k2], acc2[q]);
-                    acc2[q] = mfma16(ah, zl[k2], acc2[q]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            float* dst = pass == 0 ? a.out : a.skip;
-            const float inv = pass == 0 ? i_res : i_skip;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = fmaf(acc2[q][r], inv, old[16 * q + r]);   // res = x_in + res (:281); skips summed (:390)
-                    if (!lane_ok) v = 0.f;                              // gap positions stay zero
-                    if (pass == 0) am = fmaxf(am, fabsf(v));
-                    if (dst) (dst + po)[(32 * q + mfma_row(r, hi)) * WFL_BLK] = v;
-                }
-        }
-        am = wave_max64(am);
-        if (lane == 0 && a.out_amax) a.out_amax[p0 >> 5] = __float_as_uint(am);
+        if (S::NS2 < 2) __syncthreads();   // one slab for both passes: consumed before the next round overwrites its buffer
     }
-    if (warm == 1.2345e-30f) a.skip[0] = warm;   // never true: keeps the warm-up loads
 }
 
-// max|cond| per block: one wave per (row, block) of 96 x 32 contiguous floats
-__global__ __launch_bounds__(64) void k_wf_cond_amax(const float* __restrict__ cond, long row_stride, long amax_row_stride,
-                                                     unsigned* __restrict__ amax) {
-    const float* src = cond + (long)blockIdx.y * row_stride + (long)blockIdx.x * BLK_M;
+// The folded condition rows as planes, in place: one wave per (row, block) of 96 x 32 floats stored [channel][32]
+__global__ __launch_bounds__(64) void k_wf_cond_planes(float* __restrict__ cond, long row_stride, long amax_row_stride,
+                                                      unsigned* __restrict__ amax) {
+    float* blk = cond + (long)blockIdx.y * row_stride + (long)blockIdx.x * (WFL_MP * WFL_BLK);
+    const int lane = threadIdx.x, j = lane & 31, hh = lane >> 5;
+    float v[WFL_KS_COND][8];
     float m = 0.f;
-    for (int i = threadIdx.x; i < BLK_M; i += 64) m = fmaxf(m, fabsf(src[i]));
-    m = wave_max64(m);
-    if (threadIdx.x == 0) amax[(long)blockIdx.y * amax_row_stride + blockIdx.x] = __float_as_uint(m);
+#pragma unroll
+    for (int kq = 0; kq < WFL_KS_COND; ++kq)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[kq][e] = blk[wfl_chan(kq, hh, e) * WFL_BLK + j];
+            m = fmaxf(m, fabsf(v[kq][e]));
+        }
+    m = wave_max64(m);   // every lane has read its values: the block can be overwritten
+    const float s = pow2f(blk_scale_exp(__float_as_uint(m)));
+    char* dst = reinterpret_cast<char*>(blk) + j * 32 + hh * 1024;
+#pragma unroll
+    for (int kq = 0; kq < WFL_KS_COND; ++kq) {
+        f16x8 oh, ol;
+        split8s(v[kq], s, oh, ol);
+        st_h8(dst + kq * 2048, oh);
+        st_h8(dst + kq * 2048 + 16, ol);
+    }
+    if (lane == 0) amax[(long)blockIdx.y * amax_row_stride + blockIdx.x] = __float_as_uint(m);
 }
 
-// Flow._predict_row_parameters :496-501 + _inverse_transform_row :503-505 + input_proj of the new row (:497) on the
-// blocked layout: one wave per 32 positions, lane (j, hi) = position j, channels 32*hi .. 32*hi + 31
-__global__ __launch_bounds__(256) void k_wf_step_blk(const float* __restrict__ skip, const float* __restrict__ w_out,
-                                                     float b_logs, float b_b, const float* __restrict__ z_row,
-                                                     float* __restrict__ x_row, const float* __restrict__ w_in,
-                                                     const float* __restrict__ b_in, float* __restrict__ h0_next,
-                                                     unsigned* __restrict__ h0_amax, const int* __restrict__ pos_utt,
-                                                     int npos_alloc, int first) {
+// Flow._predict_row_parameters :496-501 + _inverse_transform_row :503-505 + input_proj of the new row (:497): one wave
+// per 32 positions, lane (j, hh) = position j and the channels of the octets 2 kq + hh (the ones it stores)
+template <int CT>
+__global__ __launch_bounds__(256) void k_wf_step_p(const float* __restrict__ skip, const float* __restrict__ w_out,
+                                                   float b_logs, float b_b, const float* __restrict__ z_row,
+                                                   float* __restrict__ x_row, const float* __restrict__ w_in,
+                                                   const float* __restrict__ b_in, float* __restrict__ h0_next,
+                                                   unsigned* __restrict__ h0_amax, const int* __restrict__ pos_utt,
+                                                   int npos_alloc, int first) {
+    constexpr int C = 32 * CT, KS = C / 16;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile * WAVE_T >= npos_alloc) return;
-    const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
+    const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
     const int p = tile * WAVE_T + j;
     const bool valid = pos_utt[p] >= 0;
-    const long po = (long)tile * BLK_C + j + (long)(32 * hi) * WFL_BLK;
     float xn = 0.f;
     if (first) {
         xn = valid ? z_row[p] : 0.f;
     } else {
+        const f32x4* sk = reinterpret_cast<const f32x4*>(skip) + (long)tile * (C * 8) + j;
         float l = 0.f, bb = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < 32; ++c) {
-            const float v = skip[po + c * WFL_BLK];
-            l = fmaf(w_out[32 * hi + c], v, l);
-            bb = fmaf(w_out[WFL_C + 32 * hi + c], v, bb);
+#pragma unroll
+        for (int i = 0; i < C / 8; ++i) {   // channel quads 2 i + hh
+            const f32x4 v = sk[(2 * i + hh) * 32];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 8 * i + 4 * hh + e;
+                l = fmaf(w_out[c], v[e], l);
+                bb = fmaf(w_out[C + c], v[e], bb);
+            }
         }
         l += __shfl_xor(l, 32);
         bb += __shfl_xor(bb, 32);
         xn = valid ? (z_row[p] - (bb + b_b)) * expf(-(l + b_logs)) : 0.f;
     }
-    if (hi == 0) x_row[p] = xn;
+    if (hh == 0) x_row[p] = xn;
     if (h0_next) {
+        float v[KS][8];
         float am = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < 32; ++c) {
-            const float v = valid ? fmaf(w_in[32 * hi + c], xn, b_in[32 * hi + c]) : 0.f;
-            am = fmaxf(am, fabsf(v));
-            h0_next[po + c * WFL_BLK] = v;
-        }
+#pragma unroll
+        for (int kq = 0; kq < KS; ++kq)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = wfl_chan(kq, hh, e);
+                v[kq][e] = valid ? fmaf(w_in[c], xn, b_in[c]) : 0.f;
+                am = fmaxf(am, fabsf(v[kq][e]));
+            }
         am = wave_max64(am);
+        const float s = pow2f(blk_scale_exp(__float_as_uint(am)));
+        char* dst = reinterpret_cast<char*>(h0_next) + (long)tile * (C * 128) + j * 32 + hh * 1024;
+#pragma unroll
+        for (int kq = 0; kq < KS; ++kq) {
+            f16x8 oh, ol;
+            split8s(v[kq], s, oh, ol);
+            st_h8(dst + kq * 2048, oh);
+            st_h8(dst + kq * 2048 + 16, ol);
+        }
         if (lane == 0) h0_amax[tile] = __float_as_uint(am);
     }
 }
@@ -419,9 +632,9 @@ inline void put_split(uint16_t* dst_hi, uint16_t* dst_lo, float w) {
 }
 }  // namespace
 
-WflPacked wfl_pack(const float* conv, const float* conv_b, const float* cond, const float* cond_b, int n_mels,
+WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* cond, const float* cond_b, int n_mels,
                    const float* outp, const float* outp_b, std::vector<uint16_t>& w16, std::vector<float>& f32) {
-    constexpr int C = WFL_C;
+    const int CT = C / 32, NQ = 2 * CT, KS_TAP = C / 16, KS1 = 9 * KS_TAP + WFL_KS_COND, KS2 = C / 16;
     WflPacked o;
     // one exponent for the first contraction (conv and condition weights share the accumulators), one each for the
     // res and the skip half of the out projection
@@ -436,42 +649,44 @@ WflPacked wfl_pack(const float* conv, const float* conv_b, const float* cond, co
     auto align8 = [&]() { w16.resize((w16.size() + 7) & ~(size_t)7); };
     align8();
     o.w1 = w16.size();
-    w16.resize(o.w1 + WFL_W1_HALVES, 0);
+    w16.resize(o.w1 + (size_t)KS1 * 2 * NQ * 64 * 8, 0);
     uint16_t* a1 = w16.data() + o.w1;
-    for (int ks = 0; ks < WFL_KS1; ++ks)
-        for (int q = 0; q < 4; ++q)
+    for (int ks = 0; ks < KS1; ++ks)
+        for (int q = 0; q < NQ; ++q)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int i = lane & 31, hi = lane >> 5;
-                    const int co = q < 2 ? 32 * q + i : C + 32 * (q - 2) + i;   // content | gate (chunk :276)
+                    const int i = lane & 31, hh = lane >> 5;
+                    const int co = q < CT ? 32 * q + i : C + 32 * (q - CT) + i;   // content | gate (chunk :276)
                     float w;
-                    if (ks < 9 * WFL_KS_TAP) {
-                        const int tap = ks / WFL_KS_TAP, kr = tap / 3, kc = tap % 3;
-                        const int ci = 16 * (ks % WFL_KS_TAP) + 8 * hi + e;
+                    if (ks < 9 * KS_TAP) {
+                        const int tap = ks / KS_TAP, kr = tap / 3, kc = tap % 3;
+                        const int ci = wfl_chan(ks % KS_TAP, hh, e);
                         w = conv[(((size_t)co * C + ci) * 3 + kr) * 3 + kc];
                     } else {
-                        const int m = 16 * (ks - 9 * WFL_KS_TAP) + 8 * hi + e;
+                        const int m = wfl_chan(ks - 9 * KS_TAP, hh, e);
                         w = m < n_mels ? cond[(size_t)co * n_mels + m] : 0.f;
                     }
                     w = std::ldexp(w, o.k1);
-                    put_split(a1 + ((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e,
-                              a1 + ((((size_t)ks * 2 + 1) * 4 + q) * 64 + lane) * 8 + e, w);
+                    put_split(a1 + ((((size_t)ks * 2 + 0) * NQ + q) * 64 + lane) * 8 + e,
+                              a1 + ((((size_t)ks * 2 + 1) * NQ + q) * 64 + lane) * 8 + e, w);
                 }
     align8();
     o.w2 = w16.size();
-    w16.resize(o.w2 + WFL_W2_HALVES, 0);
+    w16.resize(o.w2 + (size_t)2 * KS2 * 2 * CT * 64 * 8, 0);
     uint16_t* a2 = w16.data() + o.w2;
-    for (int ks = 0; ks < WFL_KS2; ++ks)
-        for (int q = 0; q < 4; ++q)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 8; ++e) {
-                    const int i = lane & 31, hi = lane >> 5;
-                    const int zc = 32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, hi);   // gated channel of this k-slot
-                    const int row = q < 2 ? 32 * q + i : C + 32 * (q - 2) + i;        // res | skip (chunk :280)
-                    const float w = std::ldexp(outp[(size_t)row * C + zc], q < 2 ? o.k2res : o.k2skip);
-                    put_split(a2 + ((((size_t)ks * 2 + 0) * 4 + q) * 64 + lane) * 8 + e,
-                              a2 + ((((size_t)ks * 2 + 1) * 4 + q) * 64 + lane) * 8 + e, w);
-                }
+    for (int pass = 0; pass < 2; ++pass)
+        for (int ks = 0; ks < KS2; ++ks)
+            for (int t = 0; t < CT; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = lane & 31, hh = lane >> 5;
+                        const int zc = 32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, hh);   // gated channel of this k-slot
+                        const int row = pass * C + 32 * t + i;                            // res | skip (chunk :280)
+                        const float w = std::ldexp(outp[(size_t)row * C + zc], pass == 0 ? o.k2res : o.k2skip);
+                        const size_t unit = (size_t)pass * KS2 + ks;
+                        put_split(a2 + (((unit * 2 + 0) * CT + t) * 64 + lane) * 8 + e,
+                                  a2 + (((unit * 2 + 1) * CT + t) * 64 + lane) * 8 + e, w);
+                    }
     f32.resize((f32.size() + 3) & ~(size_t)3);
     o.b1 = f32.size();
     for (int c = 0; c < 2 * C; ++c) f32.push_back(conv_b[c] + cond_b[c]);   // :274-275
@@ -481,30 +696,39 @@ WflPacked wfl_pack(const float* conv, const float* conv_b, const float* cond, co
 }
 
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
-    if (a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9)
-        PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (npos %d, taps %d)", a.npos_alloc, a.ntap);
+    if (!wfl_supports(a.C) || a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9)
+        PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (C %d, npos %d, taps %d)", a.C, a.npos_alloc, a.ntap);
     const int ntiles = a.npos_alloc / WAVE_T;
     WflLaunch b = a;
     static const int active_env = getenv("PK_WF_ACTIVE") ? atoi(getenv("PK_WF_ACTIVE")) : WAVES;   // measurement switch
     b.active = active_env >= 1 && active_env <= WAVES ? active_env : WAVES;
-    static const int warm_env = getenv("PK_WF_WARM") ? atoi(getenv("PK_WF_WARM")) : 0;   // measurement switches
-    b.warm = warm_env;
     b.tiles_per_wg = std::max(1, (ntiles + ctx->n_cu - 1) / ctx->n_cu);
     const int grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
-    PK_LAUNCH(ctx, "wf_layer", k_wf_layer, dim3(grid), dim3(THREADS), 0, b);
+    auto go = [&](auto kern) -> int {
+        PK_LAUNCH(ctx, "wf_layer", kern, dim3(grid), dim3(THREADS), 0, b);
+        return PK_OK;
+    };
+    const int nt = a.ntap / 3;
+    if (a.C == 64) return nt == 1 ? go(k_wf_layer_p<2, 1>) : (nt == 2 ? go(k_wf_layer_p<2, 2>) : go(k_wf_layer_p<2, 3>));
+    return nt == 1 ? go(k_wf_layer_p<4, 1>) : (nt == 2 ? go(k_wf_layer_p<4, 2>) : go(k_wf_layer_p<4, 3>));
+}
+
+int wfl_cond_planes_launch(pk_ctx* ctx, float* cond, long row_stride, int rows, int nblk, long amax_row_stride,
+                           unsigned* amax) {
+    PK_LAUNCH(ctx, "wf_cond_planes", k_wf_cond_planes, dim3(nblk, rows), dim3(64), 0, cond, row_stride, amax_row_stride, amax);
     return PK_OK;
 }
 
-int wfl_cond_amax_launch(pk_ctx* ctx, const float* cond, long row_stride, int rows, int nblk, long amax_row_stride,
-                         unsigned* amax) {
-    PK_LAUNCH(ctx, "wf_cond_amax", k_wf_cond_amax, dim3(nblk, rows), dim3(64), 0, cond, row_stride, amax_row_stride, amax);
-    return PK_OK;
-}
-
-int wfl_step_launch(pk_ctx* ctx, const float* skip, const float* w_out, float b_logs, float b_b, const float* z_row,
+int wfl_step_launch(pk_ctx* ctx, int C, const float* skip, const float* w_out, float b_logs, float b_b, const float* z_row,
                     float* x_row, const float* w_in, const float* b_in, float* h0_next, unsigned* h0_amax,
                     const int* pos_utt, int npos_alloc, int first) {
-    PK_LAUNCH(ctx, "wf_step", k_wf_step_blk, dim3(pk_div_up(npos_alloc / WAVE_T, 4)), dim3(256), 0, skip, w_out, b_logs,
-              b_b, z_row, x_row, w_in, b_in, h0_next, h0_amax, pos_utt, npos_alloc, first);
+    if (!wfl_supports(C)) PK_FAIL(PK_EINVAL, "wfl_step_launch: %d channels", C);
+    const dim3 grid(pk_div_up(npos_alloc / WAVE_T, 4));
+    if (C == 64)
+        PK_LAUNCH(ctx, "wf_step", k_wf_step_p<2>, grid, dim3(256), 0, skip, w_out, b_logs, b_b, z_row, x_row, w_in, b_in,
+                  h0_next, h0_amax, pos_utt, npos_alloc, first);
+    else
+        PK_LAUNCH(ctx, "wf_step", k_wf_step_p<4>, grid, dim3(256), 0, skip, w_out, b_logs, b_b, z_row, x_row, w_in, b_in,
+                  h0_next, h0_amax, pos_utt, npos_alloc, first);
     return PK_OK;
 }
