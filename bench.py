@@ -130,6 +130,10 @@ def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5, bud
     rec = {
         "value": n / dt, "unit": "samples/s", "cores": cores, "cores_available": avail, "kind": "port",
         "cpu_model": _cpu_model(),
+        "cores_note": "torch intra-op threads = min(cores this process may run on, 32): the oracle's time is dominated by "
+                      "oneDNN convolutions over ONE utterance (30 layers of 64-channel 1-D convs), which stop scaling near 32 "
+                      "threads; with the pool at the box's few hundred logical CPUs the same run took > 5 min in round 2 "
+                      "(thread-pool contention), so more threads would make the baseline slower, not faster",
         "sample": f"utterance 0 of the benchmark batch ({len(ids)} tokens -> {n // HOP} frames -> {n} samples), "
                   f"FastSpeech2+PWG torch-CPU fp32 oracle (Paddle-equivalent restatement); {warmup} warm-up + "
                   f"{timed} timed runs, median {dt:.2f} s (min {min(times):.2f}, max {max(times):.2f})",
