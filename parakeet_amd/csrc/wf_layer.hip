@@ -146,7 +146,10 @@ __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x
 // during slab g) stay in flight across the wait.  (With two buffers the weights of slab g + 1 would be requested during
 // slab g - 1's operand prefetch and their wait would drain it: measured in the ISA as vmcnt(6) two k-steps after a load
 // that is needed twelve k-steps later.)
-template <int CT, int NT>
+// ABL (profiling only, PK_WF_ABLATE, results are wrong when set): 1 = the operand ring is not refilled after the prologue
+// (no operand traffic), 4 = no epilogue loads / stores, 8 = the weight slabs are not reloaded after the prologue (barriers
+// stay); sums combine
+template <int CT, int NT, int ABL = 0>
 __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     typedef Shape<CT> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, RING = S::RING;
@@ -256,12 +259,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
             const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
 
-            f32x16 acc[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][r] = lbr[32 * q + mfma_row(r, hh)] * S1;
-
             // ---- B operand of k-step ks: the lane's 8 channels (octet 2 kq + hh) of position p + shift, hi and lo vectors;
             // with the first k-step of a tap also the maximum of the block that position lies in (for the rescale to the
             // tile's common scale; a tap's k-steps share it: at most 4 taps are in flight)
@@ -280,12 +277,22 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             const long pblk = (long)(p >> 5);
             const int pin = p & 31;
 
-            w_load(0, lz);
+            {   // slabs 0 and 1 of the weights in ONE round trip (a second register set: nothing else is live yet)
+                f16x8 wreg1[S::CPT1];
+                w_load(0, lz);
 #pragma unroll
-            for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nslab >= 3: the first two slabs always exist
-            w_store(0);
-            w_load(1, lz);
-            w_store(1);
+                for (int c = 0; c < S::CPT1; ++c) wreg1[c] = *w_src(1, c, lz);
+#pragma unroll
+                for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nslab >= 3: the first two slabs always exist
+                w_store(0);
+#pragma unroll
+                for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+            }
+            f32x16 acc[NQ];   // (initialised here, not above the prologue: its loads need the registers first)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = lbr[32 * q + mfma_row(r, hh)] * S1;
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < nslab; ++g) {
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 const int NW = g + 2 >= G ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = TIGHT ? NW / 2 : NW;   // constants once unrolled
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
-                    if (c < HW) wreg[c] = *w_src(g + 2, c, tz);   // first: every load below is younger
+                    if (c < HW && !(ABL & 8)) wreg[c] = *w_src(g + 2, c, tz);   // first: every load below is younger
                 __builtin_amdgcn_sched_barrier(0);   // keep the weight loads up here: hipcc would sink them to their stores
                 // (the slab's LDS base as ONE opaque register: from a constant base the third buffer's fragments lie beyond the
                 // 64 KB reach of a ds_read offset, and the compiler keeps a separate address register for each of them)
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                         bh = rhi[slot] * f;
                         bl = rlo[slot] * f;
                         __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
-                        load_b(ks + RING, tz);
+                        if (!(ABL & 1)) load_b(ks + RING, tz);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // ... and the loads ahead of the k-step's MFMAs
 #pragma unroll
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 }
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
-                    if (c < (TIGHT ? NW - HW : NW)) wbuf[(g + 2) % 3][((TIGHT ? HW : 0) + c) * THREADS + tid] = wreg[c];
+                    if (c < (TIGHT ? NW - HW : NW) && !(ABL & 8)) wbuf[(g + 2) % 3][((TIGHT ? HW : 0) + c) * THREADS + tid] = wreg[c];
                 __syncthreads();   // everyone is done reading this slab's buffer and sees the next two
             }
             // the ring is dead: request the epilogue's old values now, a whole gate ahead of their use
@@ -364,8 +371,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 const char* cur = in0b + ((long)a.cur_slot * a.slot_stride) * 4 + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
 #pragma unroll
                 for (int kq = 0; kq < S::KS2; ++kq) {
-                    xin_hi[kq] = ld_h8(cur + kq * 2048);
-                    xin_lo[kq] = ld_h8(cur + kq * 2048 + 16);
+                    xin_hi[kq] = (ABL & 4) ? rhi[kq] : ld_h8(cur + kq * 2048);
+                    xin_lo[kq] = (ABL & 4) ? rlo[kq] : ld_h8(cur + kq * 2048 + 16);
                 }
                 cur_am = a.in_amax0[(long)a.cur_slot * a.amax_stride + (p0 >> 5)];
                 const f32x4* sk = reinterpret_cast<const f32x4*>(a.skip) + pblk * (C * 8) + pin;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     for (int t = 0; t < CT; ++t)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            skip_old[4 * t + g] = a.first ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
+                            skip_old[4 * t + g] = (a.first || (ABL & 4)) ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
                 }
             }
             // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     for (int t = 0; t < CT; ++t)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            skip_old[4 * t + g] = a.first ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
+                            skip_old[4 * t + g] = (a.first || (ABL & 4)) ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
                 }
                 constexpr int SPP = S::NS2 >= 2 ? S::NS2 / 2 : 1;   // slabs per pass
                 constexpr int KPS = S::KS2 / SPP;                   // k-steps of a pass per slab
@@ -459,6 +466,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                             for (int e = 0; e < 8; ++e) t8[e] = v[kq >> 1][8 * (kq & 1) + e];
                             f16x8 oh, ol;
                             split8s(t8, so, oh, ol);
+                            if ((ABL & 4) && oh[0] != (_Float16)12345.f) continue;   // (never equal: keeps the arithmetic)
                             st_h8(dst + kq * 2048, oh);
                             st_h8(dst + kq * 2048 + 16, ol);
                         }
@@ -476,15 +484,21 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                                 const float sv = fmaf(acc2[t][4 * g + e], i_skip, skip_old[4 * t + g][e]);   // skips summed (:390)
                                 o[e] = lane_ok ? sv : 0.f;
                             }
+                            if ((ABL & 4) && o[0] != 12345.f) continue;
                             sk[(8 * t + 2 * g + hh) * 32] = o;
                         }
                 }
             }
         } else {
-            w_load(0, lz);
-            w_store(0);
-            w_load(1, lz);
-            w_store(1);
+            {
+                f16x8 wreg1[S::CPT1];
+                w_load(0, lz);
+#pragma unroll
+                for (int c = 0; c < S::CPT1; ++c) wreg1[c] = *w_src(1, c, lz);
+                w_store(0);
+#pragma unroll
+                for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+            }
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < (S::NS2 >= 2 ? G : nslab); ++g) {
@@ -709,6 +723,17 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         return PK_OK;
     };
     const int nt = a.ntap / 3;
+    static const int abl = getenv("PK_WF_ABLATE") ? atoi(getenv("PK_WF_ABLATE")) : 0;   // profiling only: results are wrong
+    if (abl && a.C == 64 && nt == 3) {
+        switch (abl) {
+            case 1: return go(k_wf_layer_p<2, 3, 1>);
+            case 4: return go(k_wf_layer_p<2, 3, 4>);
+            case 8: return go(k_wf_layer_p<2, 3, 8>);
+            case 9: return go(k_wf_layer_p<2, 3, 9>);
+            case 13: return go(k_wf_layer_p<2, 3, 13>);
+            default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9 or 13");
+        }
+    }
     if (a.C == 64) return nt == 1 ? go(k_wf_layer_p<2, 1>) : (nt == 2 ? go(k_wf_layer_p<2, 2>) : go(k_wf_layer_p<2, 3>));
     return nt == 1 ? go(k_wf_layer_p<4, 1>) : (nt == 2 ? go(k_wf_layer_p<4, 2>) : go(k_wf_layer_p<4, 3>));
 }

@@ -16,6 +16,14 @@ def _emulated():
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The fp64 oracles are many small torch CPU ops.  On the GPU boxes (a few hundred logical CPUs) torch's default intra-op
+    # pool makes them 10 - 20x slower than on 8 threads (thread wake-ups dominate): the two bench-size autoregressive tests
+    # took 122 s + 105 s there against 17 s here.  Oracle results do not depend on the thread count.
+    try:
+        import torch
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+    except Exception:
+        pass
     if _emulated():
         sys.path.insert(0, os.path.join(ROOT, "tools", "hipemu"))
         import harness
