@@ -142,7 +142,7 @@ def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5, bud
     return rec, logmel.numpy(), wav[:, 0].numpy()
 
 
-def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5):
+def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
     """ConditionalWaveFlow.infer on BASELINE config 5's shape (batch 8 x 640 mel frames): median of `runs` batches, the
     layer kernel's average launch time from the engine's HIP-event profile and its roofline.
     Algorithmic work of one layer launch (per folded position): the (3,3) conv over the rows that exist +
@@ -155,6 +155,8 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5):
     wf = ConditionalWaveFlow(**wcfg)
     wf.set_state_dict(syn.waveflow_state(wcfg))
     wf.eval()
+    if math:
+        wf.set_math(math)
     g = torch.Generator(device="cuda").manual_seed(7)
     mels = [torch.clamp(torch.randn(80, frames, device="cuda", generator=g) * 2 - 4, min=float(np.log(1e-5)))
             for _ in range(batch)]
@@ -185,8 +187,11 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5):
             byts += pos * 4.0 * (rows * C + 80 + (C if l + 1 < NL else 0) + (C if l == 0 else 2 * C))
     launches = NF * (G - 1) * NL
     ent = {
-        "what": f"BASELINE config 5 shape (ConditionalWaveFlow, {channels} channels, batch {batch} x {frames} frames), "
-                "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes",
+        "what": f"BASELINE config 5 shape (ConditionalWaveFlow, {channels} channels, batch {batch} x {frames} frames), " +
+                ("fp16 operands / fp32 accumulation: the reference's own AMP inference precision "
+                 "(examples/waveflow/synthesize.py:40), set_math('f16'); NOT fp32-equivalent (about 1e-4 of the peak)"
+                 if math == "f16" else
+                 "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes"),
         "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,
         "ms_per_batch_runs": [t * 1e3 for t in times],
         "reference_published": "about 40x real time on V100 (docs/src/released_models.md:275-276)"}
@@ -206,9 +211,9 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5):
             "bound": "hbm", "achieved": b_l / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": b_l / avg_s / 8e12,
             "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": b_l,
             "algorithmic_flop_per_launch": f_l, "algorithmic_tflops": f_l / avg_s / 1e12,
-            "split_fp16_mfma_frac": 3.0 * f_l / avg_s / 2.5e15,
-            "note": "averages over the launches of a batch (rows 1 and 2 of a flow read one and two input rows); the "
-                    "matrix pipe issues three fp16 MFMAs per fp32 product (split_fp16_mfma_frac = 3 x FLOP / 2.5 PFLOP/s)"}
+            "fp16_mfma_frac": (1.0 if math == "f16" else 3.0) * f_l / avg_s / 2.5e15,
+            "note": "averages over the launches of a batch (rows 1 and 2 of a flow read one and two input rows); "
+                    "fp16_mfma_frac = issued fp16 MFMA FLOP (3 per product in the split mode, 1 in the fp16 mode) / 2.5 PFLOP/s"}
     del wf
     return ent
 
@@ -516,11 +521,12 @@ def main():
         synth.voc.set_math("f16x3")
         synth.am.set_math("f16x3")
         for wf_c in (64, 128):   # BASELINE config 5 (64 channels) and the reference repository's default width (128)
-            key = f"waveflow_c{wf_c}_batch8"
-            try:
-                extras[key] = waveflow_extra(wf_c, ctx)
-            except Exception as e:  # never let an extra break the headline line
-                extras[key] = {"error": repr(e)}
+            for wmath in (None, "f16"):
+                key = f"waveflow_c{wf_c}_batch8" + ("_fp16" if wmath else "")
+                try:
+                    extras[key] = waveflow_extra(wf_c, ctx, math=wmath)
+                except Exception as e:  # never let an extra break the headline line
+                    extras[key] = {"error": repr(e)}
         try:   # the two acoustic models alone (BASELINE config 2 shape at 32 utterances; SpeedySpeech)
             t1 = time.perf_counter()
             for _ in range(args.steps):

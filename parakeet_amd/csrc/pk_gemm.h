@@ -12,7 +12,7 @@ constexpr int PK_GEMM_BK = 16;
 
 constexpr int PK_GEMM_HBK = 32;   // K slab of the split-fp16 variant
 constexpr int PK_GEMM_MAX_TAPS = 12;
-enum { PK_GEMM_MATH_F32 = 0, PK_GEMM_MATH_F16X3 = 1 };
+enum { PK_GEMM_MATH_F32 = 0, PK_GEMM_MATH_F16X3 = 1, PK_GEMM_MATH_F16 = 2 };   // F16: WaveFlow only (pk_wf_set_math)
 
 enum { PK_ACT_NONE = 0, PK_ACT_RELU = 1, PK_ACT_TANH = 2 };
 enum { PK_EPI_STD = 0, PK_EPI_GATE = 1, PK_EPI_GATE_PROJ = 2 };

@@ -58,6 +58,7 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
 struct WflLaunch {
     WflWeights w;
     int C;                   // 64 or 128
+    int f16;                 // 1: fp16 operands, one MFMA per product (the reference's AMP precision); 0: three-term split
     const float* in0;        // layer input ring, slot 0 (planes, C channels; one float = one 4-byte slot); slot s at + s * slot_stride
     long slot_stride;        // slots (= floats)
     const unsigned* in_amax0;   // max|.| per 32-position block of slot 0 (fp32 bits); slot s at + s * amax_stride
@@ -73,6 +74,8 @@ struct WflLaunch {
     int tap_slot[9], tap_shift[9], tap_w[9];   // ring slot, position shift, weight tap index kr*3 + kc
     const int* pos_utt;      // [npos_alloc] utterance of a position, < 0: gap (outputs forced to 0)
     int npos_alloc;          // multiple of 32
+    const uint16_t* next_w1;    // the NEXT launch's packed weights (or NULL): touched at the end of this one so that they
+    const uint16_t* next_w2;    // are in every XCD's L2 when that launch starts (each launch uses another layer's 376 KB)
     int active, tiles_per_wg;   // set by wfl_layer_launch: most waves that take a tile per round, tiles per workgroup
 };
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);

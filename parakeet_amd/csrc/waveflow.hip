@@ -229,7 +229,10 @@ extern "C" int pk_wf_set_seed(pk_wf* h, uint64_t seed) {
 
 extern "C" int pk_wf_set_math(pk_wf* h, int32_t mode) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_wf_set_math: handle is NULL");
-    if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3) PK_FAIL(PK_EINVAL, "pk_wf_set_math: unknown mode %d", mode);
+    if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3 && mode != PK_GEMM_MATH_F16)
+        PK_FAIL(PK_EINVAL, "pk_wf_set_math: unknown mode %d", mode);
+    if (mode == PK_GEMM_MATH_F16 && !(wfl_supports(h->cfg.channels) && !h->no_fuse))
+        PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_math: the fp16-operand mode runs on the fused layer kernel (64 or 128 channels)");
     h->math = mode;
     return PK_OK;
 }
@@ -443,7 +446,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     // block scaling of the split-fp16 GEMMs (pk_split.h): max|row| of every hist / cond row, kept next to the data
     // so that a launch only scans the one row set that is new (zero = margins, gaps and rows not yet written)
     // (the fused layer kernel keeps block maxima instead, one per 32 positions, in the same buffers)
-    const bool use_wfl = wfl_supports(C) && MP == WFL_MP && h->math == PK_GEMM_MATH_F16X3 && !h->no_fuse;
+    const bool use_wfl = wfl_supports(C) && MP == WFL_MP && (h->math == PK_GEMM_MATH_F16X3 || h->math == PK_GEMM_MATH_F16) && !h->no_fuse;
     const long bstride = pstride / WFL_BLK;   // blocks per buffer row incl. margins
     PK_TRY(h->ws_hamax.reserve((size_t)(NL + 1) * 3 * pstride * 4));
     PK_TRY(h->ws_camax.reserve((size_t)G * pstride * 4));
@@ -529,6 +532,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 const WfLayerW& L = F.layers[l];
                 WflLaunch w;
                 w.C = C;
+                w.f16 = h->math == PK_GEMM_MATH_F16;
                 w.w.w1 = h->arena16.as<uint16_t>() + L.fl.w1;
                 w.w.w2 = h->arena16.as<uint16_t>() + L.fl.w2;
                 w.w.b1 = h->W(L.fl.b1);
@@ -561,6 +565,12 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 for (int t = w.ntap; t < 9; ++t) w.tap_slot[t] = w.tap_shift[t] = w.tap_w[t] = 0;
                 w.pos_utt = rowvalid;
                 w.npos_alloc = npos_alloc;
+                {   // the layer kernel that runs next: l + 1, else layer 0 of the next row, else of the next flow
+                    static const bool prefetch = getenv("PK_WF_PREFETCH") ? atoi(getenv("PK_WF_PREFETCH")) != 0 : true;
+                    const WfLayerW* nx = l + 1 < NL ? &F.layers[l + 1] : (i + 1 < G ? &F.layers[0] : (fl > 0 ? &h->flows[fl - 1].layers[0] : nullptr));
+                    w.next_w1 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w1 : nullptr;
+                    w.next_w2 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w2 : nullptr;
+                }
                 PK_TRY(wfl_layer_launch(ctx, w));
             }
             for (int l = 0; l < NL && !use_wfl; ++l) {

@@ -149,7 +149,14 @@ __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x
 // ABL (profiling only, PK_WF_ABLATE, results are wrong when set): 1 = the operand ring is not refilled after the prologue
 // (no operand traffic), 4 = no epilogue loads / stores, 8 = the weight slabs are not reloaded after the prologue (barriers
 // stay); sums combine
-template <int CT, int NT, int ABL = 0>
+//
+// F16 = the reference's own inference precision for this model (examples/waveflow/synthesize.py:40 runs under
+// paddle.amp.auto_cast: fp16 conv operands, fp32 accumulation): every product is ONE fp16 MFMA of the operands rounded to
+// nearest -- weights: their stored hi part (rounded to nearest at pack time); activations: hi + lo of the stored pair in
+// one v_pk_add_f16 (the correctly rounded fp16 of the 22-bit value); gate outputs: one conversion.  The layer inputs
+// stay the same 22-bit planes, so only the products lose precision, not the residual stream.  A third of the matrix
+// work; not the default.
+template <int CT, int NT, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     typedef Shape<CT> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, RING = S::RING;
@@ -160,34 +167,30 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     constexpr int G = nslab + S::NS2;    // slabs of the weight stream
     __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];   // three weight slabs: 144 KB
     __shared__ float lb[4 * C];                                        // b1 [2C] | b2s [2C]
-    // per logical k-step (taps whose row exists, then the condition block): where its B operand lives and which packed
-    // weight k-step multiplies it (run-time: which ring slot a tap reads depends on the row).  The tail repeats the last
-    // k-step: the prefetch beyond the end stays unconditional.
-    __shared__ long kt_off[nks + RING];    // byte offset from in0 of (position 0, octet 2 kq) of this k-step's source
-    __shared__ long kt_am[nks + RING];     // element offset from in_amax0 of block 0 of the source's block maxima
-    __shared__ int kt_shift[nks + RING];   // position shift of the tap
-    __shared__ int kt_blk[nks + RING];     // bytes per 32-position block of the source (C or 96 channels)
-    __shared__ int kt_w[nks + RING];       // packed k-step of W1
+    // per source (the taps whose row exists, then the condition block): where its B operand lives (run-time: which ring slot
+    // a tap reads depends on the row); per logical k-step: the packed weight k-step that multiplies it
+    __shared__ long tp_off[ntap + 1];     // byte offset from in0 of (position 0, octet 0) of the source
+    __shared__ long tp_am[ntap + 1];      // element offset from in_amax0 of block 0 of the source's block maxima
+    __shared__ int tp_shift[ntap + 1];    // position shift of the tap
+    __shared__ int tp_blk[ntap + 1];      // bytes per 32-position block of the source (C or 96 channels)
+    __shared__ int kt_w[nks];             // packed k-step of W1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
     for (int i = tid; i < 4 * C; i += THREADS) lb[i] = i < 2 * C ? a.w.b1[i] : a.w.b2s[i - 2 * C];
-    if (tid < nks + RING) {
-        const int ks = min(tid, nks - 1);
-        if (ks < nks_conv) {
-            const int t = ks / S::KS_TAP, kq = ks % S::KS_TAP;
-            kt_off[tid] = ((long)a.tap_slot[t] * a.slot_stride) * 4 + (long)(2 * kq) * 1024;
-            kt_am[tid] = (long)a.tap_slot[t] * a.amax_stride;
-            kt_shift[tid] = a.tap_shift[t];
-            kt_blk[tid] = S::BLK_BYTES;
-            kt_w[tid] = a.tap_w[t] * S::KS_TAP + kq;
-        } else {
-            kt_off[tid] = (reinterpret_cast<const char*>(a.cond) - reinterpret_cast<const char*>(a.in0)) +
-                          (long)(2 * (ks - nks_conv)) * 1024;
-            kt_am[tid] = a.cond_amax - a.in_amax0;
-            kt_shift[tid] = 0;
-            kt_blk[tid] = BLK_M_BYTES;
-            kt_w[tid] = 9 * S::KS_TAP + (ks - nks_conv);
-        }
+    if (tid < nks) {
+        const int ks = tid;
+        kt_w[tid] = ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv);
+    }
+    if (tid < ntap) {
+        tp_off[tid] = ((long)a.tap_slot[tid] * a.slot_stride) * 4;
+        tp_am[tid] = (long)a.tap_slot[tid] * a.amax_stride;
+        tp_shift[tid] = a.tap_shift[tid];
+        tp_blk[tid] = S::BLK_BYTES;
+    } else if (tid == ntap) {
+        tp_off[tid] = reinterpret_cast<const char*>(a.cond) - reinterpret_cast<const char*>(a.in0);
+        tp_am[tid] = a.cond_amax - a.in_amax0;
+        tp_shift[tid] = 0;
+        tp_blk[tid] = BLK_M_BYTES;
     }
     const f16x8* w1 = reinterpret_cast<const f16x8*>(a.w.w1);
     const f16x8* w2 = reinterpret_cast<const f16x8*>(a.w.w2);
@@ -265,14 +268,24 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             f16x8 rhi[RING], rlo[RING];
             unsigned ram[4];
             auto tap_of = [&](int ks) { return ks < nks_conv ? ks / S::KS_TAP : ntap; };
-            auto load_b = [&](int ksu, int tz) {   // ksu may run past the end: the table tail repeats the last k-step
-                const int ks = ksu < nks ? ksu : nks - 1, slot = ksu % RING, ti = ksu + tz;
-                const int q = p + kt_shift[ti];
-                const char* src = in0b + kt_off[ti] + (long)(q >> 5) * kt_blk[ti] + (q & 31) * 32 + hh * 1024;
+            // the source of the k-steps being requested: its base as a scalar pair, this lane's byte offset in it (a tap's
+            // k-steps differ by a constant: one address add per k-step instead of a 64-bit multiply-add chain)
+            const char* cur_base = in0b;
+            unsigned cur_off = 0;
+            auto load_b = [&](int ksu, int tz) {   // ksu may run past the end: the last k-step again
+                const int ks = ksu < nks ? ksu : nks - 1, slot = ksu % RING;
+                const int tap = tap_of(ks), kq = ks - (tap < ntap ? tap * S::KS_TAP : nks_conv);
+                if (ksu < nks && kq == 0) {
+                    const int q = p + tp_shift[tap + tz];
+                    cur_off = (unsigned)((q >> 5) * tp_blk[tap + tz] + (q & 31) * 32 + hh * 1024);
+                    const long bo = tp_off[tap + tz];
+                    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bo), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bo >> 32));
+                    cur_base = in0b + (long)(((unsigned long)bhi << 32) | blo);
+                    ram[tap % 4] = (a.in_amax0 + tp_am[tap + tz])[q >> 5];
+                }
+                const char* src = cur_base + (cur_off + (unsigned)(kq * 2048));
                 rhi[slot] = ld_h8(src);
                 rlo[slot] = ld_h8(src + 16);
-                if (ksu < nks && (ks == nks_conv || (ks < nks_conv && ks % S::KS_TAP == 0)))
-                    ram[tap_of(ks) % 4] = (a.in_amax0 + kt_am[ti])[q >> 5];
             };
             const long pblk = (long)(p >> 5);
             const int pin = p & 31;
@@ -288,6 +301,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
             }
+            f16x8 f;          // rescale factor of the tap being consumed
             f32x16 acc[NQ];   // (initialised here, not above the prologue: its loads need the registers first)
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -316,13 +330,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                 for (int kk = 0; kk < SLAB; ++kk) {
                     const int ks = SLAB * g + kk, slot = ks % RING;
-                    const f16x8 f = pow2_neg_h8(ex - amax_exp(ram[tap_of(ks) % 4]));
+                    if (ks == nks_conv || (ks < nks_conv && ks % S::KS_TAP == 0)) f = pow2_neg_h8(ex - amax_exp(ram[tap_of(ks) % 4]));
                     f16x8 bh, bl;
                     if (TIGHT) {
-                        rhi[slot] *= f;
-                        rlo[slot] *= f;
+                        if (F16) rhi[slot] = (rhi[slot] + rlo[slot]) * f;
+                        else {
+                            rhi[slot] *= f;
+                            rlo[slot] *= f;
+                        }
                     } else {
-                        bh = rhi[slot] * f;
+                        bh = F16 ? (rhi[slot] + rlo[slot]) * f : rhi[slot] * f;
                         bl = rlo[slot] * f;
                         __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
                         if (!(ABL & 1)) load_b(ks + RING, tz);
@@ -331,19 +348,21 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const f16x8 ah = wl[kk * S::KCH1 + (0 * NQ + q) * 64];
-                        const f16x8 al = wl[kk * S::KCH1 + (1 * NQ + q) * 64];
                         acc[q] = mfma16(ah, TIGHT ? rhi[slot] : bh, acc[q]);
-                        acc[q] = mfma16(al, TIGHT ? rhi[slot] : bh, acc[q]);
-                        acc[q] = mfma16(ah, TIGHT ? rlo[slot] : bl, acc[q]);
+                        if (!F16) {
+                            const f16x8 al = wl[kk * S::KCH1 + (1 * NQ + q) * 64];
+                            acc[q] = mfma16(al, TIGHT ? rhi[slot] : bh, acc[q]);
+                            acc[q] = mfma16(ah, TIGHT ? rlo[slot] : bl, acc[q]);
+                        }
                     }
                     // A fragments at most one co-tile ahead of their MFMAs (16 registers, not 8 NQ)
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 4, 0);
 #pragma unroll
                     for (int q = 0; q + 1 < NQ; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 1 : 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 1 : 2, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 1 : 3, 0);
                     if (TIGHT) {
                         __builtin_amdgcn_sched_barrier(0);
                         load_b(ks + RING, tz);
@@ -393,7 +412,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 float zv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) zv[e] = gated_s(acc[zq][r0 + e], acc[zq + CT][r0 + e], gca, gcb);
-                split8(zv, zh[k2], zl[k2]);
+                if (F16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zh[k2][e] = (_Float16)zv[e];
+                } else {
+                    split8(zv, zh[k2], zl[k2]);
+                }
             }
             // ---- out projection: pass 0 = res (-> next layer's input planes), pass 1 = skip; its weights follow the conv
             // weights through the slab buffers (NS2 slabs of 32 KB, pass-major).  C = 64: one slab holds both passes.
@@ -429,10 +453,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                         for (int t = 0; t < CT; ++t) {
                             const f16x8 ah = buf[(u0 + kk) * S::KCH2 + (0 * CT + t) * 64];
-                            const f16x8 al = buf[(u0 + kk) * S::KCH2 + (1 * CT + t) * 64];
                             acc2[t] = mfma16(ah, zh[k2], acc2[t]);
-                            acc2[t] = mfma16(al, zh[k2], acc2[t]);
-                            acc2[t] = mfma16(ah, zl[k2], acc2[t]);
+                            if (!F16) {
+                                const f16x8 al = buf[(u0 + kk) * S::KCH2 + (1 * CT + t) * 64];
+                                acc2[t] = mfma16(al, zh[k2], acc2[t]);
+                                acc2[t] = mfma16(ah, zl[k2], acc2[t]);
+                            }
                         }
                     }
                     if (S::NS2 >= 2) {
@@ -510,6 +536,20 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             }
         }
         if (S::NS2 < 2) __syncthreads();   // one slab for both passes: consumed before the next round overwrites its buffer
+    }
+    // ---- warm the L2 of this XCD with the next launch's weights: the workgroups of an XCD (block b runs on XCD b % 8 --
+    // observed, used for speed only) each touch a slice of the 128-byte lines
+    if (a.next_w1) {
+        constexpr int L1 = (int)((size_t)S::KS1 * S::KCH1 * 16 / 128), L2 = (int)((size_t)S::U2 * S::KCH2 * 16 / 128);
+        const int nwg = ((int)gridDim.x + 7) >> 3, me = (int)blockIdx.x >> 3;
+        const int per = (L1 + L2 + nwg - 1) / nwg;
+        float warm = 0.f;
+        for (int i = me * per + tid; i < min((me + 1) * per, L1 + L2); i += THREADS) {
+            const float* src = i < L1 ? reinterpret_cast<const float*>(a.next_w1) + (long)i * 32
+                                      : reinterpret_cast<const float*>(a.next_w2) + (long)(i - L1) * 32;
+            warm += *src;
+        }
+        if (warm == 1.2345e-30f) a.skip[0] = warm;   // never true: keeps the loads
     }
 }
 
@@ -724,7 +764,7 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     };
     const int nt = a.ntap / 3;
     static const int abl = getenv("PK_WF_ABLATE") ? atoi(getenv("PK_WF_ABLATE")) : 0;   // profiling only: results are wrong
-    if (abl && a.C == 64 && nt == 3) {
+    if (abl && a.C == 64 && nt == 3 && !a.f16) {
         switch (abl) {
             case 1: return go(k_wf_layer_p<2, 3, 1>);
             case 4: return go(k_wf_layer_p<2, 3, 4>);
@@ -733,6 +773,11 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
             case 13: return go(k_wf_layer_p<2, 3, 13>);
             default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9 or 13");
         }
+    }
+    if (a.f16) {
+        if (a.C == 64)
+            return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true>) : go(k_wf_layer_p<2, 3, 0, true>));
+        return nt == 1 ? go(k_wf_layer_p<4, 1, 0, true>) : (nt == 2 ? go(k_wf_layer_p<4, 2, 0, true>) : go(k_wf_layer_p<4, 3, 0, true>));
     }
     if (a.C == 64) return nt == 1 ? go(k_wf_layer_p<2, 1>) : (nt == 2 ? go(k_wf_layer_p<2, 2>) : go(k_wf_layer_p<2, 3>));
     return nt == 1 ? go(k_wf_layer_p<4, 1>) : (nt == 2 ? go(k_wf_layer_p<4, 2>) : go(k_wf_layer_p<4, 3>));

@@ -51,7 +51,7 @@ class ConditionalWaveFlow:
 
     def set_math(self, mode):
         """'f16x3' (default: split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
-        _capi.check(self._ctx.lib.pk_wf_set_math(self._h, {"f32": 0, "f16x3": 1}[mode]))
+        _capi.check(self._ctx.lib.pk_wf_set_math(self._h, {"f32": 0, "f16x3": 1, "f16": 2}[mode]))
 
     def set_seed(self, seed):
         """Seed of the engine's own latent stream (``pk_randn``), used when neither ``z`` nor a torch

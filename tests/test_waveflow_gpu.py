@@ -8,7 +8,7 @@ from parakeet_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg_over, frames, seed, tol=2e-4):
+def _run(cfg_over, frames, seed, tol=2e-4, math=None):
     from oracle import waveflow_ref as ref
     from parakeet_amd.waveflow import ConditionalWaveFlow
     cfg = dict(syn.WAVEFLOW_LJSPEECH, **cfg_over)
@@ -16,6 +16,8 @@ def _run(cfg_over, frames, seed, tol=2e-4):
     model = ConditionalWaveFlow(**cfg)
     model.set_state_dict(state)
     model.eval()
+    if math:
+        model.set_math(math)
     rng = np.random.default_rng(seed + 1)
     mels = [np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32) for T in frames]
     zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
@@ -40,6 +42,16 @@ def test_waveflow_c64_all_flows():
 
 def test_waveflow_c128_repo_default_width():
     _run(dict(channels=128, n_flows=2), [4], seed=3)
+
+
+def test_waveflow_fp16_operand_mode():
+    """set_math("f16"): the reference's own inference precision for this model (examples/waveflow/synthesize.py:40 runs under
+    paddle.amp.auto_cast) -- fp16 conv operands, fp32 accumulation, the residual stream kept at 22 bits.  Not the default and
+    not fp32-equivalent: the bar is 2e-3 of the waveform's peak against the fp64 oracle (measured: 5e-5 .. 8e-5 with two
+    flows), ten times the split-fp16 default's bar."""
+    _run(dict(channels=64, n_flows=2), [4, 7, 3], seed=1, tol=2e-3, math="f16")
+    _run(dict(channels=64), [5, 3], seed=2, tol=2e-3, math="f16")
+    _run(dict(channels=128, n_flows=2), [4], seed=3, tol=2e-3, math="f16")
 
 
 def test_waveflow_infer_api_and_errors():
