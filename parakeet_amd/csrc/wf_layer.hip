@@ -276,9 +276,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 const int ks = ksu < nks ? ksu : nks - 1, slot = ksu % RING;
                 const int tap = tap_of(ks), kq = ks - (tap < ntap ? tap * S::KS_TAP : nks_conv);
                 if (ksu < nks && kq == 0) {
+                    // q can be negative (a tap of the first tiles reaches into the buffer's leading margin): the offset is
+                    // taken from 8 blocks before the source's position 0, so that it is a non-negative 32-bit number
                     const int q = p + tp_shift[tap + tz];
-                    cur_off = (unsigned)((q >> 5) * tp_blk[tap + tz] + (q & 31) * 32 + hh * 1024);
-                    const long bo = tp_off[tap + tz];
+                    const int blkb = tp_blk[tap + tz];
+                    cur_off = (unsigned)(((q >> 5) + 8) * blkb + (q & 31) * 32 + hh * 1024);
+                    const long bo = tp_off[tap + tz] - 8L * blkb;
                     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bo), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bo >> 32));
                     cur_base = in0b + (long)(((unsigned long)bhi << 32) | blo);
                     ram[tap % 4] = (a.in_amax0 + tp_am[tap + tz])[q >> 5];
