@@ -76,6 +76,7 @@ struct WflLaunch {
     int npos_alloc;          // multiple of 32
     const uint16_t* next_w1;    // the NEXT launch's packed weights (or NULL): touched at the end of this one so that they
     const uint16_t* next_w2;    // are in every XCD's L2 when that launch starts (each launch uses another layer's 376 KB)
+    unsigned long long* trace;  // profiling only (PK_WF_ABLATE=16): s_memtime stamps of workgroup 5, [wave 8][round 2][24]
     int active, tiles_per_wg;   // set by wfl_layer_launch: most waves that take a tile per round, tiles per workgroup
 };
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);

@@ -165,7 +165,7 @@ struct pk_wf {
     std::vector<size_t> up_w;
     std::vector<float> up_b;
     // workspace
-    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip, ws_hamax, ws_camax;
+    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip, ws_hamax, ws_camax, ws_trace;
     const float* W(size_t off) const { return arena.as<float>() + off; }
 };
 
@@ -501,6 +501,14 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     PK_LAUNCH(ctx, "wf_fold", k_wf_fold, dim3(pk_div_up(npos, 256)), dim3(256), 0, d_z, d_tab + o_putt, d_tab + o_pw,
               d_tab + o_zoff, G, npos, pstride, cur);
 
+    // profiling only (PK_WF_ABLATE=16): the layer kernel's s_memtime stamps, printed after the last launch
+    unsigned long long* d_trace = nullptr;
+    static const bool want_trace = getenv("PK_WF_ABLATE") && atoi(getenv("PK_WF_ABLATE")) == 16;
+    if (want_trace) {
+        PK_TRY(h->ws_trace.reserve(8 * 2 * 24 * sizeof(unsigned long long)));
+        PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, 8 * 2 * 24 * sizeof(unsigned long long), ctx->stream));
+        d_trace = h->ws_trace.as<unsigned long long>();
+    }
     // ---- flows, reversed (:703-706)
     std::vector<int> cidx(G);
     for (int i = 0; i < G; ++i) cidx[i] = i;
@@ -571,6 +579,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                     w.next_w1 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w1 : nullptr;
                     w.next_w2 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w2 : nullptr;
                 }
+                w.trace = d_trace;
                 PK_TRY(wfl_layer_launch(ctx, w));
             }
             for (int l = 0; l < NL && !use_wfl; ++l) {
@@ -664,6 +673,19 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         }
         std::swap(cur, nxt);
     }
+    if (d_trace) {
+        unsigned long long tr[8 * 2 * 24];
+        PK_HIP(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+        unsigned long long t0 = ~0ull;
+        for (unsigned long long v : tr) if (v && v < t0) t0 = v;
+        for (int wv = 0; wv < 8; ++wv)
+            for (int r = 0; r < 2; ++r) {
+                fprintf(stderr, "wf_trace wave %d round %d:", wv, r);
+                for (int i = 0; i < 24; ++i) fprintf(stderr, " %lld", tr[(wv * 2 + r) * 24 + i] ? (long long)(tr[(wv * 2 + r) * 24 + i] - t0) : -1LL);
+                fprintf(stderr, "\n");
+            }
+    }
     PK_LAUNCH(ctx, "wf_unfold", k_wf_unfold, dim3(pk_div_up(npos, 256)), dim3(256), 0, cur, d_tab + o_putt,
               d_tab + o_pw, d_tab + o_ooff, G, npos, pstride, d_wav);
     if (flags & PK_HOST_IO) {
@@ -679,7 +701,7 @@ extern "C" void pk_wf_destroy(pk_wf* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
                        &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip,
-                       &h->ws_hamax, &h->ws_camax};
+                       &h->ws_hamax, &h->ws_camax, &h->ws_trace};
     for (auto* b : bufs) b->release();
     delete h;
 }

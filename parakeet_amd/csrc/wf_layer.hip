@@ -203,6 +203,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     // waves without a tile only move weights and keep the barriers.
     const int t_begin = (int)blockIdx.x * a.tiles_per_wg, t_end = min(t_begin + a.tiles_per_wg, ntiles);
 
+    int rnd = 0;
+    auto stamp = [&](int i) {   // ABL & 16: where does a round's time go (s_memtime of lane 0 of every wave of workgroup 5)
+        if ((ABL & 16) && blockIdx.x == 5 && lane == 0 && rnd < 2) a.trace[(wave * 2 + rnd) * 24 + i] = __builtin_amdgcn_s_memtime();
+    };
     // chunk c of this thread in slab g of the weight stream (its slot in the LDS slab buffer is c * THREADS + tid)
     // (tz: an opaque zero, renewed per slab -- the tables are the same in every round and every slab, and with the slab
     // loop unrolled the compiler would otherwise read all of them up front and hold them in registers)
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
         const int p0 = tile_ok ? wt * WAVE_T : 0;
         const int p = p0 + j;
         const bool lane_ok = tile_ok && a.pos_utt[p] >= 0;
+        stamp(0);
         // the bias reads below are the same in every round: without this the compiler keeps them in registers across the
         // round loop
         int lz = 0;
@@ -310,7 +315,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][r] = lbr[32 * q + mfma_row(r, hh)] * S1;
+            stamp(1);
             __syncthreads();
+            stamp(2);
 #pragma unroll
             for (int g = 0; g < nslab; ++g) {
                 int tz = 0;
@@ -383,7 +390,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
                     if (c < (TIGHT ? NW - HW : NW) && !(ABL & 8)) wbuf[(g + 2) % 3][((TIGHT ? HW : 0) + c) * THREADS + tid] = wreg[c];
+                if (g < 8) stamp(3 + 2 * g);
                 __syncthreads();   // everyone is done reading this slab's buffer and sees the next two
+                if (g < 8) stamp(4 + 2 * g);
             }
             // the ring is dead: request the epilogue's old values now, a whole gate ahead of their use
             f16x8 xin_hi[S::KS2], xin_lo[S::KS2];   // residual input: this lane's centre-tap vectors of the current row
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             }
             // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection
             __builtin_amdgcn_sched_barrier(0);   // the old-value loads stay ahead of the gate
+            stamp(19);
             f16x8 zh[S::KS2], zl[S::KS2];
 #pragma unroll
             for (int k2 = 0; k2 < S::KS2; ++k2) {
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             // ---- out projection: pass 0 = res (-> next layer's input planes), pass 1 = skip; its weights follow the conv
             // weights through the slab buffers (NS2 slabs of 32 KB, pass-major).  C = 64: one slab holds both passes.
             float am = 0.f;
+            stamp(20);
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 f32x16 acc2[CT];
@@ -469,6 +480,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                         __syncthreads();   // slab g consumed by every wave, the next two visible
                     }
                 }
+                stamp(21 + pass);
                 if (pass == 0) {
                     // res = x_in + res (:281) -> the next layer's input of this row, as planes with this block's scale
                     if (a.out) {
@@ -538,7 +550,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 __syncthreads();
             }
         }
+        stamp(23);
         if (S::NS2 < 2) __syncthreads();   // one slab for both passes: consumed before the next round overwrites its buffer
+        ++rnd;
     }
     // ---- warm the L2 of this XCD with the next launch's weights: the workgroups of an XCD (block b runs on XCD b % 8 --
     // observed, used for speed only) each touch a slice of the 128-byte lines
@@ -774,7 +788,8 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
             case 8: return go(k_wf_layer_p<2, 3, 8>);
             case 9: return go(k_wf_layer_p<2, 3, 9>);
             case 13: return go(k_wf_layer_p<2, 3, 13>);
-            default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9 or 13");
+            case 16: if (b.trace) return go(k_wf_layer_p<2, 3, 16>); break;
+            default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13 or 16");
         }
     }
     if (a.f16) {
