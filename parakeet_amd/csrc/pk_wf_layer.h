@@ -15,7 +15,12 @@
 // which is also the set of channels lane half hh owns as accumulator rows (mfma_row) -- so a lane's B-operand vector
 // of the centre tap is its residual input, and its 8 accumulator registers of a k-step are one stored vector.
 // A lane's operand of one k-step is two 16-byte loads (hi, lo); across the 32 lanes of a half wave they are 1 KB
-// contiguous.  The running skip sum stays fp32: [block][channel / 4][position 32][4] (16-byte accesses).
+// contiguous.
+// The skip path is folded: a flow's parameters are output_proj(sum_l skip_l) with skip_l = W2skip_l z_l + b_l, both linear,
+// so each layer accumulates (W_out W2skip_l) z_l -- TWO numbers per position -- into prm[pos][2] instead of its C skip
+// channels into a [pos][C] buffer (C = 64: 16 instead of 512 bytes of read-modify-write per position and layer, and the
+// skip half of the out projection, 24 of a tile's 552 MFMAs, becomes 2 C FMAs per lane); the biases W_out b_l are
+// constants and go into the flow's output_proj bias.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -34,26 +39,28 @@ static inline long wfl_plane_off(long p, int ch, int plane, int CH) {
     const int kq = ch >> 4, w = ch & 15, hh = (w >> 2) & 1, e = 4 * (w >> 3) + (w & 3);
     return (p >> 5) * ((long)CH * 128) + (long)(2 * kq + hh) * 1024 + (p & 31) * 32 + plane * 16 + e * 2;
 }
-// float offset of (p, ch) in the skip buffer
-static inline long wfl_skip_off(long p, int ch, int C) { return (p >> 5) * ((long)C * 32) + (long)(ch >> 2) * 128 + (p & 31) * 4 + (ch & 3); }
 
 struct WflWeights {          // one residual layer, as packed by wfl_pack()
     const uint16_t* w1;      // [KS1][part 2][co-tile 2C/32][lane 64][8]: conv taps (kr*3 + kc) x C/16 k-steps, then the condition
-    const uint16_t* w2;      // [pass res | skip][k2 C/16][part 2][tile C/32][lane 64][8]
+    const uint16_t* w2;      // [k2 C/16][part 2][tile C/32][lane 64][8]: the res half of out_proj
     const float* b1;         // [2C] conv bias + condition_proj bias: content 0..C-1, gate C..2C-1
-    const float* b2s;        // [2C] out_proj bias * 2^(14 + k2): res 0..C-1, skip C..2C-1
-    int k1, k2res, k2skip;   // block-scale exponents of the three weight tensors (pk_split.h)
+    const float* b2r;        // [C] res half of the out_proj bias * 2^(14 + k2res)
+    const float* wso;        // [2C] (W_out W2skip) * 2^-14 in the order a lane reads it: [hh 2][k2 C/16][e 8][logs | b]
+    int k1, k2res;           // block-scale exponents of the two weight tensors (pk_split.h)
 };
 
 // Pack one layer.  conv [2C][C][3][3], conv bias [2C], condition_proj [2C][n_mels], its bias [2C], out_proj [2C][C],
 // its bias [2C] (paddle layouts, weight norm folded).  Appends to w16 / f32 and returns the offsets.
 struct WflPacked {
     size_t w1, w2;           // offsets (halves) into w16
-    size_t b1, b2s;          // offsets (floats) into f32
-    int k1, k2res, k2skip;
+    size_t b1, b2r, wso;     // offsets (floats) into f32
+    int k1, k2res;
+    double cso[2];           // W_out . (skip half of the out_proj bias): this layer's constant share of (logs, b)
 };
+// w_out: the flow's output_proj weight [2][C] (logs row, b row)
 WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* cond, const float* cond_b, int n_mels,
-                   const float* outp, const float* outp_b, std::vector<uint16_t>& w16, std::vector<float>& f32);
+                   const float* outp, const float* outp_b, const float* w_out, std::vector<uint16_t>& w16,
+                   std::vector<float>& f32);
 
 struct WflLaunch {
     WflWeights w;
@@ -66,7 +73,7 @@ struct WflLaunch {
     int cur_slot;            // slot of the current row (residual input = centre tap of the last kernel row)
     float* out;              // next layer's input, slot of the current row (planes), or NULL (last layer)
     unsigned* out_amax;
-    float* skip;             // running skip sum (fp32, wfl_skip_off layout), written (first) or accumulated
+    float* prm;              // [pos][2] running (logs, b) of this row without the constant terms, written (first) or accumulated
     int first;
     const float* cond;       // condition row (planes, 96 channels)
     const unsigned* cond_amax;
@@ -84,8 +91,8 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);
 // The folded condition rows, written by the upsampler as fp32 [rows][pos / 32][96][32], become planes IN PLACE (one wave
 // per block: read the block, take its maximum, write it back split) with amax [rows][pos / 32].
 int wfl_cond_planes_launch(pk_ctx* ctx, float* cond, long row_stride, int rows, int nblk, long amax_row_stride, unsigned* amax);
-// Flow._predict_row_parameters + _inverse_transform_row + input_proj of the new row: params = output_proj(skip sum),
-// x[i] = (z'[i] - b) * exp(-logs), then h0 = input_proj(x[i]) into layer 0's ring (planes) with its block maxima
-int wfl_step_launch(pk_ctx* ctx, int C, const float* skip, const float* w_out, float b_logs, float b_b, const float* z_row,
+// Flow._predict_row_parameters + _inverse_transform_row + input_proj of the new row: (logs, b) = prm[pos] + the folded
+// biases, x[i] = (z'[i] - b) * exp(-logs), then h0 = input_proj(x[i]) into layer 0's ring (planes) with its block maxima
+int wfl_step_launch(pk_ctx* ctx, int C, const float* prm, float b_logs, float b_b, const float* z_row,
                     float* x_row, const float* w_in, const float* b_in, float* h0_next, unsigned* h0_amax,
                     const int* pos_utt, int npos_alloc, int first);

@@ -144,6 +144,7 @@ struct WfLayerW {
 struct WfFlowW {
     size_t w_in, b_in, w_out;
     float b_logs, b_b;
+    float b_logs_f, b_b_f;   // with the layers' folded skip biases (fused layer kernel, pk_wf_layer.h)
     std::vector<WfLayerW> layers;
 };
 
@@ -272,6 +273,8 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
         F.w_out = ar.put(w);   // [logs row (C)] [b row (C)]  (chunk(params, 2, axis=1) :500)
         F.b_logs = b[0];
         F.b_b = b[1];
+        const std::vector<float> w_out_flow = w;
+        double fold_l = b[0], fold_b = b[1];
         F.layers.resize(c.n_layers);
         for (int l = 0; l < c.n_layers; ++l) {
             const std::string q = p + ".resnet." + std::to_string(l);
@@ -311,9 +314,15 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
             F.layers[l].w2h = put16(h->arena16_h, ph);
             F.layers[l].b2 = ar.put(bo);
             if (wfl_supports(C) && MP == WFL_MP)
+            {
                 F.layers[l].fl = wfl_pack(C, wc.data(), bc.data(), wp.data(), bp.data(), M, wo.data(), bo.data(),
-                                          h->arena16_h, h->arena_h);
+                                          w_out_flow.data(), h->arena16_h, h->arena_h);
+                fold_l += F.layers[l].fl.cso[0];
+                fold_b += F.layers[l].fl.cso[1];
+            }
         }
+        F.b_logs_f = (float)fold_l;
+        F.b_b_f = (float)fold_b;
     }
     PK_TRY(pk_upload(ctx, h->arena, h->arena_h.data(), h->arena_h.size() * sizeof(float)));
     h->arena_h.clear();
@@ -463,6 +472,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     float* hist = h->ws_hist.as<float>() + (size_t)WF_LEAD * C;
     float* zbuf = h->ws_zbuf.as<float>() + (size_t)WF_LEAD * C;
     float* skip = h->ws_skip.as<float>() + (size_t)WF_LEAD * C;
+    float* prm = skip;   // the fused path keeps two floats per position here instead of C
     auto hist_ptr = [&](int layer, int slot) { return hist + ((size_t)layer * 3 + slot) * feat_row; };
     float* hamax = h->ws_hamax.as<float>() + WF_LEAD;
     float* camax = h->ws_camax.as<float>() + WF_LEAD;
@@ -523,7 +533,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         const WfFlowW& F = h->flows[fl];
         // row 0: copy + input_proj into slot 1 of layer 0
         if (use_wfl) {
-            PK_TRY(wfl_step_launch(ctx, C, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[0] * pstride, nxt,
+            PK_TRY(wfl_step_launch(ctx, C, prm, F.b_logs_f, F.b_b_f, cur + (long)perm[0] * pstride, nxt,
                                    h->W(F.w_in), h->W(F.b_in), hist_ptr(0, 1), hbmax_ptr(0, 1), rowvalid, npos_alloc, 1));
         } else {
         PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out), F.b_logs,
@@ -544,10 +554,10 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 w.w.w1 = h->arena16.as<uint16_t>() + L.fl.w1;
                 w.w.w2 = h->arena16.as<uint16_t>() + L.fl.w2;
                 w.w.b1 = h->W(L.fl.b1);
-                w.w.b2s = h->W(L.fl.b2s);
+                w.w.b2r = h->W(L.fl.b2r);
+                w.w.wso = h->W(L.fl.wso);
                 w.w.k1 = L.fl.k1;
                 w.w.k2res = L.fl.k2res;
-                w.w.k2skip = L.fl.k2skip;
                 w.in0 = hist_ptr(l, 0);
                 w.slot_stride = feat_row;
                 w.in_amax0 = hbmax_ptr(l, 0);
@@ -555,7 +565,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 w.cur_slot = slot;
                 w.out = l + 1 < NL ? hist_ptr(l + 1, slot) : nullptr;   // the last layer's residual output is unused (:390)
                 w.out_amax = l + 1 < NL ? hbmax_ptr(l + 1, slot) : nullptr;
-                w.skip = skip;
+                w.prm = prm;
                 w.first = l == 0;
                 w.cond = cond + (long)cidx[i] * cond_row;
                 w.cond_amax = cbmax + (long)cidx[i] * bstride;
@@ -661,7 +671,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
             }
             float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
             if (use_wfl) {
-                PK_TRY(wfl_step_launch(ctx, C, skip, h->W(F.w_out), F.b_logs, F.b_b, cur + (long)perm[i] * pstride,
+                PK_TRY(wfl_step_launch(ctx, C, prm, F.b_logs_f, F.b_b_f, cur + (long)perm[i] * pstride,
                                        nxt + (long)i * pstride, h->W(F.w_in), h->W(F.b_in), h0n,
                                        h0n ? hbmax_ptr(0, (i + 1) % 3) : nullptr, rowvalid, npos_alloc, 0));
                 continue;

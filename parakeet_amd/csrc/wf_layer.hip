@@ -1,7 +1,7 @@
 // wf_layer.hip -- one WaveFlow residual layer for one autoregressive row as ONE kernel (64- or 128-channel model,
 // split-fp16 math): the (3,3) dilated causal conv over the 3-row input ring + condition_proj as one contraction
-// (K = 9 C + 96), gated tanh, the res|skip out projection, the residual into the next layer's ring and the skip
-// accumulation.
+// (K = 9 C + 96), gated tanh, the res half of the out projection with the residual into the next layer's ring, and this
+// layer's share of the flow's (logs, b) -- the skip half of the out projection folded with output_proj (pk_wf_layer.h).
 //
 // Reference: parakeet/models/waveflow.py ResidualBlock.add_input :248-283 (conv2d over the row buffer :268-274,
 // condition_proj :275, gate :276-277, out_proj + chunk + residual :279-282), ResidualNet.add_input :368-392.
@@ -58,12 +58,11 @@ struct Shape {
     static constexpr int KCH1 = 2 * NQ * 64;              // chunks per k-step of W1: 512 / 1024
     static constexpr int SLAB = SLAB_CH / KCH1;           // k-steps per main slab: 6 / 3
     static constexpr int CPT1 = SLAB * KCH1 / THREADS;    // chunks per thread per main slab: 6
-    static constexpr int KS2 = C / 16;                    // k-steps of the out projection: 4 / 8
-    static constexpr int KCH2 = 2 * CT * 64;              // chunks per (pass, k-step) unit of W2: 256 / 512
-    static constexpr int U2 = 2 * KS2;                    // units: 8 / 16
-    static constexpr int SLAB2 = (32 * 1024 / 16) / KCH2; // units per W2 slab (32 KB): 8 / 4
-    static constexpr int NS2 = U2 / SLAB2;                // W2 slabs: 1 / 4
-    static constexpr int CPT2 = SLAB2 * KCH2 / THREADS;   // chunks per thread per W2 slab: 4
+    static constexpr int KS2 = C / 16;                    // k-steps of the out projection (res half): 4 / 8
+    static constexpr int KCH2 = 2 * CT * 64;              // chunks per k-step of W2: 256 / 512
+    static constexpr int SLAB2 = 4;                       // k-steps per W2 slab: 16 / 32 KB
+    static constexpr int NS2 = KS2 / SLAB2;               // W2 slabs: 1 / 2
+    static constexpr int CPT2 = SLAB2 * KCH2 / THREADS;   // chunks per thread per W2 slab: 2 / 4
     static constexpr int BLK_BYTES = C * 128;             // bytes per 32-position block of the feature planes
     static constexpr int RING = 2 * SLAB;                 // operand ring depth in k-steps: 12 / 6
 };
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     constexpr int nslab = nks / SLAB;    // C = 64: 3, 5, 7;  C = 128: 10, 18, 26
     constexpr int G = nslab + S::NS2;    // slabs of the weight stream
     __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];   // three weight slabs: 144 KB
-    __shared__ float lb[4 * C];                                        // b1 [2C] | b2s [2C]
+    __shared__ __attribute__((aligned(16))) float lb[5 * C];           // b1 [2C] | b2r [C] | wso [2C]
     // per source (the taps whose row exists, then the condition block): where its B operand lives (run-time: which ring slot
     // a tap reads depends on the row); per logical k-step: the packed weight k-step that multiplies it
     __shared__ long tp_off[ntap + 1];     // byte offset from in0 of (position 0, octet 0) of the source
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     __shared__ int kt_w[nks];             // packed k-step of W1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    for (int i = tid; i < 4 * C; i += THREADS) lb[i] = i < 2 * C ? a.w.b1[i] : a.w.b2s[i - 2 * C];
+    for (int i = tid; i < 5 * C; i += THREADS) lb[i] = i < 2 * C ? a.w.b1[i] : (i < 3 * C ? a.w.b2r[i - 2 * C] : a.w.wso[i - 3 * C]);
     if (tid < nks) {
         const int ks = tid;
         kt_w[tid] = ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv);
@@ -197,7 +196,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     const char* in0b = reinterpret_cast<const char*>(a.in0);
     __syncthreads();   // tables visible
     const int ntiles = a.npos_alloc / WAVE_T;
-    const float i_res = pow2f(-(PK_UNIT_EXP + a.w.k2res)), i_skip = pow2f(-(PK_UNIT_EXP + a.w.k2skip));
+    const float i_res = pow2f(-(PK_UNIT_EXP + a.w.k2res));
     // A workgroup owns tiles_per_wg consecutive wave tiles and works through them in rounds of at most `active` tiles
     // (one pass over the weights per round).  The waves of a round run in lockstep (they share the LDS weight slabs);
     // waves without a tile only move weights and keep the barriers.
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
         base += nact;
         const int p0 = tile_ok ? wt * WAVE_T : 0;
         const int p = p0 + j;
-        const bool lane_ok = tile_ok && a.pos_utt[p] >= 0;
+        const int p_utt = a.pos_utt[p];   // (compared in the epilogue: a comparison here would wait for the load before anything else is requested)
         stamp(0);
         // the bias reads below are the same in every round: without this the compiler keeps them in registers across the
         // round loop
@@ -247,25 +246,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
         // Working and idle waves run separate copies of the whole round (same number of barriers): the working copy
         // has no branch inside, and nothing of it is live in the idle copy.
         if (tile_ok) {
-            // ---- common scale of this wave tile: the largest block maximum among the blocks its taps read
-            int ex;   // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex
+            // ---- common scale of this wave tile: the largest block maximum among the blocks its taps read.  Only the loads
+            // here: the reduction (which waits for them) comes after the prologue has requested the weights and the operands
+            // -- one memory round trip for the whole prologue instead of three in a row (s_memtime trace, round 3: 14 k of a
+            // round's 77 k cycles were the prologue)
+            // (one unconditional load per lane -- lanes beyond the 2 ntap + 1 sources repeat lane 0's: loads inside divergent
+            // branches are waited for where the branches join)
+            unsigned m_raw;
             {
-                float m = 0.f;
-                if (lane < 2 * ntap) {
-                    const int t = lane >> 1;
-                    const int blk = (p0 + a.tap_shift[t] + 31 * (lane & 1)) >> 5;
-                    m = __uint_as_float(a.in_amax0[(long)a.tap_slot[t] * a.amax_stride + blk]);
-                } else if (lane == 2 * ntap) {
-                    m = __uint_as_float(a.cond_amax[p0 >> 5]);
-                }
-                m = wave_max64(m);
-                ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(m)));
+                const int li = lane <= 2 * ntap ? lane : 0, t = li >> 1;   // t = ntap: the condition block (shift 0)
+                const int blk = (p0 + tp_shift[t + lz] + 31 * (li & 1)) >> 5;   // (the LDS tables, not the kernel arguments: those
+                m_raw = (a.in_amax0 + tp_am[t + lz])[blk];                       //  indexed per lane would be loads from memory)
             }
-            const int kx = PK_BLK_TOP + 127 - ex;
-            const int ks1 = kx + a.w.k1;
-            const float S1 = pow2f(ks1);
-            const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
-            const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
 
             // ---- B operand of k-step ks: the lane's 8 channels (octet 2 kq + hh) of position p + shift, hi and lo vectors;
             // with the first k-step of a tap also the maximum of the block that position lies in (for the rescale to the
@@ -305,10 +297,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 for (int c = 0; c < S::CPT1; ++c) wreg1[c] = *w_src(1, c, lz);
 #pragma unroll
                 for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nslab >= 3: the first two slabs always exist
+                __builtin_amdgcn_sched_barrier(0);   // everything above is requested before anything below waits
                 w_store(0);
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
             }
+            // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex
+            const int ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(wave_max64(__uint_as_float(m_raw)))));   // (all sources are maxima: the repeats change nothing)
+            const int kx = PK_BLK_TOP + 127 - ex;
+            const int ks1 = kx + a.w.k1;
+            const float S1 = pow2f(ks1);
+            const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
+            const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
             f16x8 f;          // rescale factor of the tap being consumed
             f32x16 acc[NQ];   // (initialised here, not above the prologue: its loads need the registers first)
 #pragma unroll
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                         bh = F16 ? (rhi[slot] + rlo[slot]) * f : rhi[slot] * f;
                         bl = rlo[slot] * f;
                         __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
-                        if (!(ABL & 1)) load_b(ks + RING, tz);
+                        if (!(ABL & 1) && ks + RING < nks) load_b(ks + RING, tz);   // (a compile-time condition once unrolled)
                     }
                     __builtin_amdgcn_sched_barrier(0);   // ... and the loads ahead of the k-step's MFMAs
 #pragma unroll
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 1 : 3, 0);
                     if (TIGHT) {
                         __builtin_amdgcn_sched_barrier(0);
-                        load_b(ks + RING, tz);
+                        if (ks + RING < nks) load_b(ks + RING, tz);
                         if (kk == 0 && NW > 0) {
 #pragma unroll
                             for (int c = 0; c < S::CPT1; ++c)
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             }
             // the ring is dead: request the epilogue's old values now, a whole gate ahead of their use
             f16x8 xin_hi[S::KS2], xin_lo[S::KS2];   // residual input: this lane's centre-tap vectors of the current row
-            f32x4 skip_old[4 * CT];                 // running skip sum: 4 channels per register, (tile t, group g) -> [4 t + g]
             unsigned cur_am;
+            float2 prm_old = {0.f, 0.f};
             {
                 const char* cur = in0b + ((long)a.cur_slot * a.slot_stride) * 4 + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
 #pragma unroll
@@ -406,25 +406,29 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     xin_lo[kq] = (ABL & 4) ? rlo[kq] : ld_h8(cur + kq * 2048 + 16);
                 }
                 cur_am = a.in_amax0[(long)a.cur_slot * a.amax_stride + (p0 >> 5)];
-                const f32x4* sk = reinterpret_cast<const f32x4*>(a.skip) + pblk * (C * 8) + pin;
-                if (CT == 2) {   // (128 channels: requested at the start of the skip pass, the registers are not free before)
-#pragma unroll
-                    for (int t = 0; t < CT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            skip_old[4 * t + g] = (a.first || (ABL & 4)) ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
-                }
+                if (!a.first && !(ABL & 4)) prm_old = reinterpret_cast<const float2*>(a.prm)[p];
             }
-            // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection
+            // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection; on the way this
+            // lane's part of the folded skip path: (logs, b) += sum over its C/2 channels of wso[.][channel] * z
             __builtin_amdgcn_sched_barrier(0);   // the old-value loads stay ahead of the gate
             stamp(19);
             f16x8 zh[S::KS2], zl[S::KS2];
+            float pl = 0.f, pb = 0.f;
+            const f32x4* wso = reinterpret_cast<const f32x4*>(lbr + 3 * C) + hh * (S::KS2 * 4);
 #pragma unroll
             for (int k2 = 0; k2 < S::KS2; ++k2) {
                 const int zq = k2 >> 1, r0 = 8 * (k2 & 1);
                 float zv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) zv[e] = gated_s(acc[zq][r0 + e], acc[zq + CT][r0 + e], gca, gcb);
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {   // [k2][e][logs | b]: two channels per 16-byte read
+                    const f32x4 w = wso[k2 * 4 + e2];
+                    pl = fmaf(w[0], zv[2 * e2], pl);
+                    pb = fmaf(w[1], zv[2 * e2], pb);
+                    pl = fmaf(w[2], zv[2 * e2 + 1], pl);
+                    pb = fmaf(w[3], zv[2 * e2 + 1], pb);
+                }
                 if (F16) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) zh[k2][e] = (_Float16)zv[e];
@@ -432,104 +436,84 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     split8(zv, zh[k2], zl[k2]);
                 }
             }
-            // ---- out projection: pass 0 = res (-> next layer's input planes), pass 1 = skip; its weights follow the conv
-            // weights through the slab buffers (NS2 slabs of 32 KB, pass-major).  C = 64: one slab holds both passes.
-            float am = 0.f;
+            const bool lane_ok = p_utt >= 0;
+            pl += __shfl_xor(pl, 32);   // the other half wave holds the other C/2 channels of the same position
+            pb += __shfl_xor(pb, 32);
+            if (hh == 0) {
+                float2 o = {prm_old.x + pl, prm_old.y + pb};   // skips summed (:390), then output_proj (:499-500)
+                if (!lane_ok) o = float2{0.f, 0.f};
+                if (!(ABL & 4)) reinterpret_cast<float2*>(a.prm)[p] = o;
+            }
             stamp(20);
+            // ---- out projection, res half (-> next layer's input planes; the last layer has none): its weights follow the
+            // conv weights through the slab buffers (NS2 slabs of SLAB2 k-steps)
+            f32x16 acc2[CT];
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                f32x16 acc2[CT];
+            for (int t = 0; t < CT; ++t)
 #pragma unroll
-                for (int t = 0; t < CT; ++t)
+                for (int r = 0; r < 16; ++r) acc2[t][r] = lbr[2 * C + 32 * t + mfma_row(r, hh)];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[t][r] = lbr[2 * C + C * pass + 32 * t + mfma_row(r, hh)];
-                if (CT == 4 && pass == 1) {
-                    const f32x4* sk = reinterpret_cast<const f32x4*>(a.skip) + pblk * (C * 8) + pin;
+            for (int h2 = 0; h2 < S::NS2; ++h2) {
+                const int g = nslab + h2;   // slab of the weight stream
+                unsigned wo = (g % 3) * SLAB_CH + lane;
+                asm volatile("" : "+v"(wo));
+                const f16x8* buf = &wbuf[0][0] + wo;
+                if (S::NS2 >= 2) w_load(g + 2, 0);
+                if (a.out) {
 #pragma unroll
-                    for (int t = 0; t < CT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            skip_old[4 * t + g] = (a.first || (ABL & 4)) ? f32x4{0.f, 0.f, 0.f, 0.f} : sk[(8 * t + 2 * g + hh) * 32];
-                }
-                constexpr int SPP = S::NS2 >= 2 ? S::NS2 / 2 : 1;   // slabs per pass
-                constexpr int KPS = S::KS2 / SPP;                   // k-steps of a pass per slab
-#pragma unroll
-                for (int h2 = 0; h2 < SPP; ++h2) {
-                    const int g = nslab + (S::NS2 >= 2 ? pass * SPP + h2 : 0);   // slab of the weight stream
-                    unsigned wo = (g % 3) * SLAB_CH + lane;
-                    asm volatile("" : "+v"(wo));
-                    const f16x8* buf = &wbuf[0][0] + wo;
-                    if (S::NS2 >= 2) w_load(g + 2, 0);
-                    const int u0 = S::NS2 >= 2 ? 0 : pass * S::KS2;   // first unit of this pass inside the slab
-#pragma unroll
-                    for (int kk = 0; kk < KPS; ++kk) {
-                        const int k2 = h2 * KPS + kk;
+                    for (int kk = 0; kk < S::SLAB2; ++kk) {
+                        const int k2 = h2 * S::SLAB2 + kk;
 #pragma unroll
                         for (int t = 0; t < CT; ++t) {
-                            const f16x8 ah = buf[(u0 + kk) * S::KCH2 + (0 * CT + t) * 64];
+                            const f16x8 ah = buf[kk * S::KCH2 + (0 * CT + t) * 64];
                             acc2[t] = mfma16(ah, zh[k2], acc2[t]);
                             if (!F16) {
-                                const f16x8 al = buf[(u0 + kk) * S::KCH2 + (1 * CT + t) * 64];
+                                const f16x8 al = buf[kk * S::KCH2 + (1 * CT + t) * 64];
                                 acc2[t] = mfma16(al, zh[k2], acc2[t]);
                                 acc2[t] = mfma16(ah, zl[k2], acc2[t]);
                             }
                         }
                     }
-                    if (S::NS2 >= 2) {
-                        w_store(g + 2);
-                        __syncthreads();   // slab g consumed by every wave, the next two visible
-                    }
                 }
-                stamp(21 + pass);
-                if (pass == 0) {
-                    // res = x_in + res (:281) -> the next layer's input of this row, as planes with this block's scale
-                    if (a.out) {
-                        const float xs = pow2f(-(PK_BLK_TOP + 127 - amax_exp(cur_am)));   // the stored input is x * 2^k
-                        float v[CT][16];
-#pragma unroll
-                        for (int t = 0; t < CT; ++t)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int kq = 2 * t + (r >> 3), e = r & 7;
-                                const float x_in = ((float)xin_hi[kq][e] + (float)xin_lo[kq][e]) * xs;
-                                float o = fmaf(acc2[t][r], i_res, x_in);
-                                if (!lane_ok) o = 0.f;   // gap positions stay zero
-                                am = fmaxf(am, fabsf(o));
-                                v[t][r] = o;
-                            }
-                        am = wave_max64(am);
-                        const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
-                        char* dst = reinterpret_cast<char*>(a.out) + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
-#pragma unroll
-                        for (int kq = 0; kq < S::KS2; ++kq) {
-                            float t8[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) t8[e] = v[kq >> 1][8 * (kq & 1) + e];
-                            f16x8 oh, ol;
-                            split8s(t8, so, oh, ol);
-                            if ((ABL & 4) && oh[0] != (_Float16)12345.f) continue;   // (never equal: keeps the arithmetic)
-                            st_h8(dst + kq * 2048, oh);
-                            st_h8(dst + kq * 2048 + 16, ol);
-                        }
-                        if (lane == 0) a.out_amax[p0 >> 5] = __float_as_uint(am);
-                    }
-                } else {
-                    f32x4* sk = reinterpret_cast<f32x4*>(a.skip) + pblk * (C * 8) + pin;
-#pragma unroll
-                    for (int t = 0; t < CT; ++t)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float sv = fmaf(acc2[t][4 * g + e], i_skip, skip_old[4 * t + g][e]);   // skips summed (:390)
-                                o[e] = lane_ok ? sv : 0.f;
-                            }
-                            if ((ABL & 4) && o[0] != 12345.f) continue;
-                            sk[(8 * t + 2 * g + hh) * 32] = o;
-                        }
+                if (S::NS2 >= 2) {
+                    w_store(g + 2);
+                    __syncthreads();   // slab g consumed by every wave, the next visible
                 }
             }
+            stamp(21);
+            // res = x_in + res (:281) -> the next layer's input of this row, as planes with this block's scale
+            if (a.out) {
+                const float xs = pow2f(-(PK_BLK_TOP + 127 - amax_exp(cur_am)));   // the stored input is x * 2^k
+                float v[CT][16];
+                float am = 0.f;
+#pragma unroll
+                for (int t = 0; t < CT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kq = 2 * t + (r >> 3), e = r & 7;
+                        const float x_in = ((float)xin_hi[kq][e] + (float)xin_lo[kq][e]) * xs;
+                        float o = fmaf(acc2[t][r], i_res, x_in);
+                        if (!lane_ok) o = 0.f;   // gap positions stay zero
+                        am = fmaxf(am, fabsf(o));
+                        v[t][r] = o;
+                    }
+                am = wave_max64(am);
+                const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
+                char* dst = reinterpret_cast<char*>(a.out) + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
+#pragma unroll
+                for (int kq = 0; kq < S::KS2; ++kq) {
+                    float t8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t8[e] = v[kq >> 1][8 * (kq & 1) + e];
+                    f16x8 oh, ol;
+                    split8s(t8, so, oh, ol);
+                    if ((ABL & 4) && oh[0] != (_Float16)12345.f) continue;   // (never equal: keeps the arithmetic)
+                    st_h8(dst + kq * 2048, oh);
+                    st_h8(dst + kq * 2048 + 16, ol);
+                }
+                if (lane == 0) a.out_amax[p0 >> 5] = __float_as_uint(am);
+            }
+            stamp(22);
         } else {
             {
                 f16x8 wreg1[S::CPT1];
@@ -557,7 +541,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     // ---- warm the L2 of this XCD with the next launch's weights: the workgroups of an XCD (block b runs on XCD b % 8 --
     // observed, used for speed only) each touch a slice of the 128-byte lines
     if (a.next_w1) {
-        constexpr int L1 = (int)((size_t)S::KS1 * S::KCH1 * 16 / 128), L2 = (int)((size_t)S::U2 * S::KCH2 * 16 / 128);
+        constexpr int L1 = (int)((size_t)S::KS1 * S::KCH1 * 16 / 128), L2 = (int)((size_t)S::KS2 * S::KCH2 * 16 / 128);
         const int nwg = ((int)gridDim.x + 7) >> 3, me = (int)blockIdx.x >> 3;
         const int per = (L1 + L2 + nwg - 1) / nwg;
         float warm = 0.f;
@@ -566,7 +550,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                                       : reinterpret_cast<const float*>(a.next_w2) + (long)(i - L1) * 32;
             warm += *src;
         }
-        if (warm == 1.2345e-30f) a.skip[0] = warm;   // never true: keeps the loads
+        if (warm == 1.2345e-30f) a.prm[0] = warm;   // never true: keeps the loads
     }
 }
 
@@ -598,14 +582,14 @@ __global__ __launch_bounds__(64) void k_wf_cond_planes(float* __restrict__ cond,
 }
 
 // Flow._predict_row_parameters :496-501 + _inverse_transform_row :503-505 + input_proj of the new row (:497): one wave
-// per 32 positions, lane (j, hh) = position j and the channels of the octets 2 kq + hh (the ones it stores)
+// per 32 positions, lane (j, hh) = position j and the channels of the octets 2 kq + hh (the ones it stores).  (logs, b) of a
+// position = what the layer kernels accumulated in prm + the folded biases.
 template <int CT>
-__global__ __launch_bounds__(256) void k_wf_step_p(const float* __restrict__ skip, const float* __restrict__ w_out,
-                                                   float b_logs, float b_b, const float* __restrict__ z_row,
-                                                   float* __restrict__ x_row, const float* __restrict__ w_in,
-                                                   const float* __restrict__ b_in, float* __restrict__ h0_next,
-                                                   unsigned* __restrict__ h0_amax, const int* __restrict__ pos_utt,
-                                                   int npos_alloc, int first) {
+__global__ __launch_bounds__(256) void k_wf_step_p(const float* __restrict__ prm, float b_logs, float b_b,
+                                                   const float* __restrict__ z_row, float* __restrict__ x_row,
+                                                   const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                   float* __restrict__ h0_next, unsigned* __restrict__ h0_amax,
+                                                   const int* __restrict__ pos_utt, int npos_alloc, int first) {
     constexpr int C = 32 * CT, KS = C / 16;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile * WAVE_T >= npos_alloc) return;
@@ -616,21 +600,8 @@ __global__ __launch_bounds__(256) void k_wf_step_p(const float* __restrict__ ski
     if (first) {
         xn = valid ? z_row[p] : 0.f;
     } else {
-        const f32x4* sk = reinterpret_cast<const f32x4*>(skip) + (long)tile * (C * 8) + j;
-        float l = 0.f, bb = 0.f;
-#pragma unroll
-        for (int i = 0; i < C / 8; ++i) {   // channel quads 2 i + hh
-            const f32x4 v = sk[(2 * i + hh) * 32];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 8 * i + 4 * hh + e;
-                l = fmaf(w_out[c], v[e], l);
-                bb = fmaf(w_out[C + c], v[e], bb);
-            }
-        }
-        l += __shfl_xor(l, 32);
-        bb += __shfl_xor(bb, 32);
-        xn = valid ? (z_row[p] - (bb + b_b)) * expf(-(l + b_logs)) : 0.f;
+        const float2 lb2 = reinterpret_cast<const float2*>(prm)[p];
+        xn = valid ? (z_row[p] - (lb2.y + b_b)) * expf(-(lb2.x + b_logs)) : 0.f;
     }
     if (hh == 0) x_row[p] = xn;
     if (h0_next) {
@@ -704,18 +675,18 @@ inline void put_split(uint16_t* dst_hi, uint16_t* dst_lo, float w) {
 }  // namespace
 
 WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* cond, const float* cond_b, int n_mels,
-                   const float* outp, const float* outp_b, std::vector<uint16_t>& w16, std::vector<float>& f32) {
+                   const float* outp, const float* outp_b, const float* w_out, std::vector<uint16_t>& w16,
+                   std::vector<float>& f32) {
     const int CT = C / 32, NQ = 2 * CT, KS_TAP = C / 16, KS1 = 9 * KS_TAP + WFL_KS_COND, KS2 = C / 16;
     WflPacked o;
-    // one exponent for the first contraction (conv and condition weights share the accumulators), one each for the
-    // res and the skip half of the out projection
+    // one exponent for the first contraction (conv and condition weights share the accumulators), one for the res half
+    // of the out projection
     {
         float m = 0.f;
         for (size_t i = 0; i < (size_t)2 * C * C * 9; ++i) m = std::fmax(m, std::fabs(conv[i]));
         for (size_t i = 0; i < (size_t)2 * C * n_mels; ++i) m = std::fmax(m, std::fabs(cond[i]));
         o.k1 = pk_weight_scale_exp(&m, 1);
         o.k2res = pk_weight_scale_exp(outp, (size_t)C * C);
-        o.k2skip = pk_weight_scale_exp(outp + (size_t)C * C, (size_t)C * C);
     }
     auto align8 = [&]() { w16.resize((w16.size() + 7) & ~(size_t)7); };
     align8();
@@ -743,26 +714,42 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
                 }
     align8();
     o.w2 = w16.size();
-    w16.resize(o.w2 + (size_t)2 * KS2 * 2 * CT * 64 * 8, 0);
+    w16.resize(o.w2 + (size_t)KS2 * 2 * CT * 64 * 8, 0);
     uint16_t* a2 = w16.data() + o.w2;
-    for (int pass = 0; pass < 2; ++pass)
-        for (int ks = 0; ks < KS2; ++ks)
-            for (int t = 0; t < CT; ++t)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 8; ++e) {
-                        const int i = lane & 31, hh = lane >> 5;
-                        const int zc = 32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, hh);   // gated channel of this k-slot
-                        const int row = pass * C + 32 * t + i;                            // res | skip (chunk :280)
-                        const float w = std::ldexp(outp[(size_t)row * C + zc], pass == 0 ? o.k2res : o.k2skip);
-                        const size_t unit = (size_t)pass * KS2 + ks;
-                        put_split(a2 + (((unit * 2 + 0) * CT + t) * 64 + lane) * 8 + e,
-                                  a2 + (((unit * 2 + 1) * CT + t) * 64 + lane) * 8 + e, w);
-                    }
+    for (int ks = 0; ks < KS2; ++ks)
+        for (int t = 0; t < CT; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int i = lane & 31, hh = lane >> 5;
+                    const int zc = 32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, hh);   // gated channel of this k-slot
+                    const int row = 32 * t + i;                                       // res half (chunk :280)
+                    const float w = std::ldexp(outp[(size_t)row * C + zc], o.k2res);
+                    put_split(a2 + ((((size_t)ks * 2 + 0) * CT + t) * 64 + lane) * 8 + e,
+                              a2 + ((((size_t)ks * 2 + 1) * CT + t) * 64 + lane) * 8 + e, w);
+                }
     f32.resize((f32.size() + 3) & ~(size_t)3);
     o.b1 = f32.size();
     for (int c = 0; c < 2 * C; ++c) f32.push_back(conv_b[c] + cond_b[c]);   // :274-275
-    o.b2s = f32.size();
-    for (int c = 0; c < 2 * C; ++c) f32.push_back(std::ldexp(outp_b[c], PK_UNIT_EXP + (c < C ? o.k2res : o.k2skip)));
+    o.b2r = f32.size();
+    for (int c = 0; c < C; ++c) f32.push_back(std::ldexp(outp_b[c], PK_UNIT_EXP + o.k2res));
+    // the skip half folded with the flow's output_proj: wso[which][zc] = sum_s w_out[which][s] * outp[C + s][zc], scaled
+    // by 2^-14 (the gate leaves z * 2^14), in the order lane half hh reads it: [hh][k2][e][logs | b]
+    o.wso = f32.size();
+    for (int hh = 0; hh < 2; ++hh)
+        for (int ks = 0; ks < KS2; ++ks)
+            for (int e = 0; e < 8; ++e) {
+                const int zc = 32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, hh);
+                for (int which = 0; which < 2; ++which) {
+                    double acc = 0.0;
+                    for (int sc = 0; sc < C; ++sc) acc += (double)w_out[(size_t)which * C + sc] * (double)outp[(size_t)(C + sc) * C + zc];
+                    f32.push_back((float)std::ldexp(acc, -PK_UNIT_EXP));
+                }
+            }
+    for (int which = 0; which < 2; ++which) {
+        double acc = 0.0;
+        for (int sc = 0; sc < C; ++sc) acc += (double)w_out[(size_t)which * C + sc] * (double)outp_b[C + sc];
+        o.cso[which] = acc;
+    }
     return o;
 }
 
@@ -807,16 +794,16 @@ int wfl_cond_planes_launch(pk_ctx* ctx, float* cond, long row_stride, int rows, 
     return PK_OK;
 }
 
-int wfl_step_launch(pk_ctx* ctx, int C, const float* skip, const float* w_out, float b_logs, float b_b, const float* z_row,
+int wfl_step_launch(pk_ctx* ctx, int C, const float* prm, float b_logs, float b_b, const float* z_row,
                     float* x_row, const float* w_in, const float* b_in, float* h0_next, unsigned* h0_amax,
                     const int* pos_utt, int npos_alloc, int first) {
     if (!wfl_supports(C)) PK_FAIL(PK_EINVAL, "wfl_step_launch: %d channels", C);
     const dim3 grid(pk_div_up(npos_alloc / WAVE_T, 4));
     if (C == 64)
-        PK_LAUNCH(ctx, "wf_step", k_wf_step_p<2>, grid, dim3(256), 0, skip, w_out, b_logs, b_b, z_row, x_row, w_in, b_in,
-                  h0_next, h0_amax, pos_utt, npos_alloc, first);
+        PK_LAUNCH(ctx, "wf_step", k_wf_step_p<2>, grid, dim3(256), 0, prm, b_logs, b_b, z_row, x_row, w_in, b_in, h0_next,
+                  h0_amax, pos_utt, npos_alloc, first);
     else
-        PK_LAUNCH(ctx, "wf_step", k_wf_step_p<4>, grid, dim3(256), 0, skip, w_out, b_logs, b_b, z_row, x_row, w_in, b_in,
-                  h0_next, h0_amax, pos_utt, npos_alloc, first);
+        PK_LAUNCH(ctx, "wf_step", k_wf_step_p<4>, grid, dim3(256), 0, prm, b_logs, b_b, z_row, x_row, w_in, b_in, h0_next,
+                  h0_amax, pos_utt, npos_alloc, first);
     return PK_OK;
 }

@@ -268,6 +268,7 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 #define __builtin_amdgcn_s_sleep(x) hipemu::yield_to_scheduler()
 #define __builtin_amdgcn_exp2f(x) std::exp2((float)(x))

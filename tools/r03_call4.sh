@@ -18,3 +18,6 @@ for abl in 13 9; do
   PK_WF_ABLATE=$abl timeout 200 python tools/quick_wf_noassert.py 64 > $OUT/quick_abl$abl.log 2>&1; echo "ABL $abl: $(grep wf_layer $OUT/quick_abl$abl.log)"
 done
 ls $OUT
+PK_WF_ABLATE=16 timeout 200 python tools/quick_wf_noassert.py 64 > $OUT/trace.log 2>&1
+grep wf_trace $OUT/trace.log | grep "wave [0245] " | tail -8 | cut -c1-230
+timeout 300 python -m pytest tests/test_ar_e2e_gpu.py -m gpu -q --timeout=300 2>&1 | tail -n 2
