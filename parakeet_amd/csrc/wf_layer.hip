@@ -64,7 +64,8 @@ struct Shape {
     static constexpr int NS2 = KS2 / SLAB2;               // W2 slabs: 1 / 2
     static constexpr int CPT2 = SLAB2 * KCH2 / THREADS;   // chunks per thread per W2 slab: 2 / 4
     static constexpr int BLK_BYTES = C * 128;             // bytes per 32-position block of the feature planes
-    static constexpr int RING = 2 * SLAB;                 // operand ring depth in k-steps: 12 / 6
+    static constexpr int RING = CT == 2 ? 9 : 2 * SLAB;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12 would leave the
+                                                          // A fragments two register quads -- every LDS read latency exposed)
 };
 
 __host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wreg1[c] = *w_src(1, c, lz);
 #pragma unroll
-                for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nslab >= 3: the first two slabs always exist
+                for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nks >= 18 > RING
                 __builtin_amdgcn_sched_barrier(0);   // everything above is requested before anything below waits
                 w_store(0);
 #pragma unroll
@@ -365,14 +366,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                             acc[q] = mfma16(ah, TIGHT ? rlo[slot] : bl, acc[q]);
                         }
                     }
-                    // A fragments at most one co-tile ahead of their MFMAs (16 registers, not 8 NQ)
-                    __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 2 : 4, 0);
+                    // A fragments AHEAD co-tiles ahead of their MFMAs (not all NQ of them: registers).  Two at 64 channels:
+                    // with one, every co-tile's three MFMAs (96 cycles) had to cover a whole LDS read latency, and the trace
+                    // showed about 200 cycles per k-step and wave that nothing covered
+                    constexpr int AHEAD = (CT == 2 && !(ABL & 32)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;
+                    __builtin_amdgcn_sched_group_barrier(0x100, PER * (AHEAD + 0), 0);
 #pragma unroll
-                    for (int q = 0; q + 1 < NQ; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 1 : 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 1 : 2, 0);
+                    for (int q = 0; q < NQ; ++q) {
+                        if (q + AHEAD < NQ) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 1 : 3, 0);
                     if (TIGHT) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (ks + RING < nks) load_b(ks + RING, tz);
@@ -776,7 +779,8 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
             case 9: return go(k_wf_layer_p<2, 3, 9>);
             case 13: return go(k_wf_layer_p<2, 3, 13>);
             case 16: if (b.trace) return go(k_wf_layer_p<2, 3, 16>); break;
-            default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13 or 16");
+            case 32: return go(k_wf_layer_p<2, 3, 32>);   // A fragments one co-tile ahead (A/B of the LDS prefetch depth)
+            default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16 or 32");
         }
     }
     if (a.f16) {

@@ -14,7 +14,7 @@ C=64; M=f16x3; run c64 X=1; run c64_noprefetch PK_WF_PREFETCH=0
 C=64; M=f16;   run c64_f16 X=1
 C=128; M=f16x3; run c128 X=1
 C=128; M=f16;   run c128_f16 X=1
-for abl in 13 9; do
+for abl in 13 32; do
   PK_WF_ABLATE=$abl timeout 200 python tools/quick_wf_noassert.py 64 > $OUT/quick_abl$abl.log 2>&1; echo "ABL $abl: $(grep wf_layer $OUT/quick_abl$abl.log)"
 done
 ls $OUT
