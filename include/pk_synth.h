@@ -260,7 +260,10 @@ int pk_wf_create(pk_ctx* ctx, const pk_wf_cfg* cfg, pk_wf** out);
  * decoder.{f}.resnet.{l}.{conv,condition_proj,out_proj}.*, decoder.{f}.output_proj.*;
  * weight_g / weight_v pairs are folded (recursively_remove_weight_norm). */
 int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
-/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs with fp32 accumulation (default, as pk_fs2_set_math). */
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA products with fp32 accumulation (default: fp32-equivalent error, as
+ * pk_fs2_set_math), 2 = fp16 operands rounded to nearest, ONE MFMA per product, fp32 accumulation -- the precision the
+ * reference itself synthesises at (examples/waveflow/synthesize.py:40 runs under paddle.amp.auto_cast), about 1e-4 of the
+ * waveform's peak away from the fp64 oracle; 64- and 128-channel models only (PK_EUNSUPPORTED otherwise). */
 int pk_wf_set_math(pk_wf* h, int32_t mode);
 int pk_wf_finalize(pk_wf* h);
 /* For t_mel frames: length of the trimmed upsampled condition (= length of the z the reference
