@@ -17,8 +17,11 @@ kind, src, dst = sys.argv[1:4]
 d = json.load(open(src))
 if kind == "pwg":
     LK = [k for k in d if k.startswith("k_pwg_layer") and "false" in k][0]
-    L, F = d[LK], d["k_pwg_first"]
-    Z = d.get("k_pwg_last_h3") or d["k_pwg_last"]
+    def pick(prefix):   # kernel names carry their template arguments ("k_pwg_first<false>")
+        ks = [k for k in d if k == prefix or k.startswith(prefix + "<")]
+        return d[sorted(ks)[0]] if ks else None
+    L, F = d[LK], pick("k_pwg_first")
+    Z = pick("k_pwg_last_h3") or pick("k_pwg_last")
     n = 32 * 163840
     wcal = F["WRITE_SIZE"] * 1024 / (64 * 4 * n)
     rcal = Z["FETCH_SIZE"] * 1024 / (64 * 4 * n)
