@@ -200,7 +200,7 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
         b_l, f_l = byts * NF / launches, flop * NF / launches
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"wf_layer_c{channels}_traffic.json")
-        if os.path.exists(tpath):
+        if math is None and os.path.exists(tpath):   # the counters were collected on the default-math kernel
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
