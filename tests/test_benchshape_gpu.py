@@ -124,29 +124,45 @@ def test_fs2_batch16_ragged_vs_oracle():
     assert worst < 1e-4, worst
 
 
-def test_waveflow_bench_shape_vs_oracle():
-    """BASELINE config 5's utterance shape (640 mel frames, C = 64, all 8 flows): 2 x 640 frames -- the grid
-    shape that selects the tile variant bench.py's WaveFlow extra runs with -- vs the fp64 oracle."""
+def _waveflow_bench_shape(channels, frames, maths, seed=31, check=(0,)):
+    """maths: {math mode or None: bar}; the fp64 oracle runs once per checked utterance, every mode is compared with it."""
     from oracle import waveflow_ref as ref
     from parakeet_amd.waveflow import ConditionalWaveFlow
-    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64)
-    state = syn.waveflow_state(cfg, seed=31, weight_norm=True)
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=channels)
+    state = syn.waveflow_state(cfg, seed=seed, weight_norm=True)
     model = ConditionalWaveFlow(**cfg)
     model.set_state_dict(state)
     model.eval()
-    rng = np.random.default_rng(32)
-    frames = [640, 640]
+    rng = np.random.default_rng(seed + 1)
     mels = [np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32) for T in frames]
     zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
-    outs = model.infer_batch(mels, zs)
-    for b in (0, 1):
+    want = {}
+    for b in check:
         with torch.no_grad():
-            want = ref.infer(state, torch.from_numpy(mels[b])[None], torch.from_numpy(zs[b])[None], cfg,
-                             torch.float64)[0].numpy()
-        got = outs[b].numpy()
-        assert got.shape == want.shape
-        err = _rel_err(got, want)
-        assert err < 1e-3, f"utt {b}: rel err {err}"
+            want[b] = ref.infer(state, torch.from_numpy(mels[b])[None], torch.from_numpy(zs[b])[None], cfg,
+                                torch.float64)[0].numpy()
+    for math, tol in maths.items():
+        model.set_math(math or "f16x3")
+        outs = model.infer_batch(mels, zs)
+        for b in check:
+            got = outs[b].numpy()
+            assert got.shape == want[b].shape
+            err = _rel_err(got, want[b])
+            assert err < tol, f"{channels} channels, math {math}, utt {b}: rel err {err}"
+
+
+def test_waveflow_bench_shape_vs_oracle():
+    """BASELINE config 5's utterance shape (640 mel frames, C = 64, all 8 flows): 2 x 640 frames -- full rounds of the layer
+    kernel's wave tiles, utterance boundaries inside a workgroup -- vs the fp64 oracle, both utterances; the default math at
+    its bar, the fp16-operand mode (the reference's AMP precision) at its own: 5e-3 of the peak over 8 flows x 15 rows of
+    feedback."""
+    _waveflow_bench_shape(64, [640, 640], {None: 1e-3, "f16": 5e-3}, check=(0, 1))
+
+
+def test_waveflow_c128_bench_shape_vs_oracle():
+    """The 128-channel model (the reference repository's default width, examples/waveflow/config.py:32-41) at a 640-frame
+    utterance, default math and fp16 operands -- the other two WaveFlow configurations bench.py times."""
+    _waveflow_bench_shape(128, [640], {None: 1e-3, "f16": 5e-3}, seed=41)
 
 
 def test_speedyspeech_batch32_vs_oracle():
