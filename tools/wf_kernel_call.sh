@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3, fourth GPU call: per-tap addressing, next-layer weight prefetch (A/B), the fp16-operand mode; ablations again.
+# WaveFlow layer kernel on the GPU box: tests, per-launch times of the four timed configurations, prefetch A/B, memory ablations, s_memtime trace.
 set -u
 TAG=${1:-r03d}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
