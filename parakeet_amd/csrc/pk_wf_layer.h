@@ -5,7 +5,7 @@
 // split into its fp16 (hi, lo) parts nine times if it is stored as fp32 (round 2: 12.5 k of a wave tile's 30 k cycles
 // were VALU, two thirds of them operand splits).  They are therefore stored ALREADY SPLIT, by the kernel that produces
 // them: per 32-position block one power-of-two scale 2^k (k = blk_scale_exp of the block's max|.|, pk_split.h, kept as
-// the max's fp32 bits in a side array) and per value the pair hi = fp16_rtz(x 2^k), lo = fp16_rne(x 2^k - hi) -- the
+// the max's fp32 bits in a side array) and per value the pair hi = fp16_rne(x 2^k), lo = fp16_rne(x 2^k - hi) -- the
 // same 4 bytes as the fp32 value, the same 22 significant bits the split-fp16 products used before.  A consumer brings
 // the blocks its taps touch to one common scale with a power-of-two multiply of the packed halves (v_pk_mul_f16) and
 // feeds them to the MFMA as they are.  Layout of a block of CH channels (bytes):

@@ -88,16 +88,18 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
         lo[2 * p + 1] = (_Float16)l1;
     }
 }
-__device__ __forceinline__ void split8s(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
-    float t[8];
+// The stored pair of a layer input (producer side, once per value): hi = fp16_rne(s x), lo = fp16_rne(s x - hi).  Round to
+// nearest, not toward zero as in the in-register splits above: |lo| is at most half an ulp of hi (one more bit for the pair),
+// and hi alone IS the correctly rounded fp16 of the value -- the fp16-operand mode reads only the hi plane.  (The block scale
+// keeps |s x| below 2^14, so the conversion cannot overflow.)
+__device__ __forceinline__ void store_pair8(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        f32x2 u = {v[2 * p], v[2 * p + 1]};
-        u *= s;
-        t[2 * p] = u[0];
-        t[2 * p + 1] = u[1];
+    for (int e = 0; e < 8; ++e) {
+        const float t = v[e] * s;
+        const _Float16 h = (_Float16)t;
+        hi[e] = h;
+        lo[e] = (_Float16)(t - (float)h);
     }
-    split8(t, hi, lo);
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_max_step(float v) {
@@ -152,9 +154,9 @@ __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x
 //
 // F16 = the reference's own inference precision for this model (examples/waveflow/synthesize.py:40 runs under
 // paddle.amp.auto_cast: fp16 conv operands, fp32 accumulation): every product is ONE fp16 MFMA of the operands rounded to
-// nearest -- weights: their stored hi part (rounded to nearest at pack time); activations: hi + lo of the stored pair in
-// one v_pk_add_f16 (the correctly rounded fp16 of the 22-bit value); gate outputs: one conversion.  The layer inputs
-// stay the same 22-bit planes, so only the products lose precision, not the residual stream.  A third of the matrix
+// nearest -- weights: their stored hi part (rounded to nearest at pack time); activations: the hi plane alone (store_pair8
+// rounds it to nearest: half the operand bytes, no arithmetic on the way to the MFMA); gate outputs: one conversion.  The
+// layer inputs stay the same 22-bit pairs, so only the products lose precision, not the residual stream.  A third of the matrix
 // work; not the default.
 template <int CT, int NT, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 }
                 const char* src = cur_base + (cur_off + (unsigned)(kq * 2048));
                 rhi[slot] = ld_h8(src);
-                rlo[slot] = ld_h8(src + 16);
+                if (!F16) rlo[slot] = ld_h8(src + 16);   // fp16-operand mode: the hi plane is the rounded value
             };
             const long pblk = (long)(p >> 5);
             const int pin = p & 31;
@@ -344,14 +346,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     if (ks == nks_conv || (ks < nks_conv && ks % S::KS_TAP == 0)) f = pow2_neg_h8(ex - amax_exp(ram[tap_of(ks) % 4]));
                     f16x8 bh, bl;
                     if (TIGHT) {
-                        if (F16) rhi[slot] = (rhi[slot] + rlo[slot]) * f;
+                        if (F16) rhi[slot] *= f;
                         else {
                             rhi[slot] *= f;
                             rlo[slot] *= f;
                         }
                     } else {
-                        bh = F16 ? (rhi[slot] + rlo[slot]) * f : rhi[slot] * f;
-                        bl = rlo[slot] * f;
+                        bh = rhi[slot] * f;
+                        if (!F16) bl = rlo[slot] * f;
                         __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
                         if (!(ABL & 1) && ks + RING < nks) load_b(ks + RING, tz);   // (a compile-time condition once unrolled)
                     }
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) t8[e] = v[kq >> 1][8 * (kq & 1) + e];
                     f16x8 oh, ol;
-                    split8s(t8, so, oh, ol);
+                    store_pair8(t8, so, oh, ol);
                     if ((ABL & 4) && oh[0] != (_Float16)12345.f) continue;   // (never equal: keeps the arithmetic)
                     st_h8(dst + kq * 2048, oh);
                     st_h8(dst + kq * 2048 + 16, ol);
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(64) void k_wf_cond_planes(float* __restrict__ cond,
 #pragma unroll
     for (int kq = 0; kq < WFL_KS_COND; ++kq) {
         f16x8 oh, ol;
-        split8s(v[kq], s, oh, ol);
+        store_pair8(v[kq], s, oh, ol);
         st_h8(dst + kq * 2048, oh);
         st_h8(dst + kq * 2048 + 16, ol);
     }
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(256) void k_wf_step_p(const float* __restrict__ prm
 #pragma unroll
         for (int kq = 0; kq < KS; ++kq) {
             f16x8 oh, ol;
-            split8s(v[kq], s, oh, ol);
+            store_pair8(v[kq], s, oh, ol);
             st_h8(dst + kq * 2048, oh);
             st_h8(dst + kq * 2048 + 16, ol);
         }

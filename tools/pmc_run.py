@@ -14,10 +14,11 @@ if mode == "pwg":
     noises = [torch.randn(L * 256, device="cuda") for _ in range(B)]
     gen.inference_batch(mels, noises)
     torch.cuda.synchronize()
-elif mode == "wf":
+elif mode in ("wf", "wf128", "wf16", "wf128_16"):                  # 64 / 128 channels, default math / fp16 operands
     from parakeet_amd.waveflow import ConditionalWaveFlow
-    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64, n_flows=2)      # two flows = 240 layer launches are plenty for counters
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=128 if "128" in mode else 64, n_flows=2)   # two flows = 240 layer launches are plenty for counters
     m = ConditionalWaveFlow(**cfg); m.set_state_dict(syn.waveflow_state(cfg)); m.eval()
+    if mode.endswith("16"): m.set_math("f16")
     rng = np.random.default_rng(0)
     Bw = min(B, 8)
     mels = [torch.tensor(np.maximum(rng.normal(-4, 2, size=(80, L)), np.log(1e-5)).astype(np.float32)).cuda() for _ in range(Bw)]
