@@ -41,9 +41,9 @@ static inline long wfl_plane_off(long p, int ch, int plane, int CH) {
 }
 
 struct WflWeights {          // one residual layer, as packed by wfl_pack()
-    const uint16_t* w1;      // [KS1][part 2][co-tile 2C/32][lane 64][8]: conv taps (kr*3 + kc) x C/16 k-steps, then the condition
+    const uint16_t* w1;      // [KS1][part 2][co-tile 2C/32][lane 64][8]: conv taps (kr*3 + kc) x C/16 k-steps, then the condition block,
+                             // whose channel n_mels (a constant 1 in the planes) carries conv bias + condition_proj bias
     const uint16_t* w2;      // [k2 C/16][part 2][tile C/32][lane 64][8]: the res half of out_proj
-    const float* b1;         // [2C] conv bias + condition_proj bias: content 0..C-1, gate C..2C-1
     const float* b2r;        // [C] res half of the out_proj bias * 2^(14 + k2res)
     const float* wso;        // [2C] (W_out W2skip) * 2^-14 in the order a lane reads it: [hh 2][k2 C/16][e 8][logs | b]
     int k1, k2res;           // block-scale exponents of the two weight tensors (pk_split.h)
@@ -53,7 +53,7 @@ struct WflWeights {          // one residual layer, as packed by wfl_pack()
 // its bias [2C] (paddle layouts, weight norm folded).  Appends to w16 / f32 and returns the offsets.
 struct WflPacked {
     size_t w1, w2;           // offsets (halves) into w16
-    size_t b1, b2r, wso;     // offsets (floats) into f32
+    size_t b2r, wso;         // offsets (floats) into f32
     int k1, k2res;
     double cso[2];           // W_out . (skip half of the out_proj bias): this layer's constant share of (logs, b)
 };
@@ -90,7 +90,9 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);
 
 // The folded condition rows, written by the upsampler as fp32 [rows][pos / 32][96][32], become planes IN PLACE (one wave
 // per block: read the block, take its maximum, write it back split) with amax [rows][pos / 32].
-int wfl_cond_planes_launch(pk_ctx* ctx, float* cond, long row_stride, int rows, int nblk, long amax_row_stride, unsigned* amax);
+// Channel n_mels of the planes is set to the constant 1: its weight column carries the layers' biases (wfl_pack).
+int wfl_cond_planes_launch(pk_ctx* ctx, float* cond, long row_stride, int rows, int nblk, long amax_row_stride, unsigned* amax,
+                           int n_mels);
 // Flow._predict_row_parameters + _inverse_transform_row + input_proj of the new row: (logs, b) = prm[pos] + the folded
 // biases, x[i] = (z'[i] - b) * exp(-logs), then h0 = input_proj(x[i]) into layer 0's ring (planes) with its block maxima
 int wfl_step_launch(pk_ctx* ctx, int C, const float* prm, float b_logs, float b_b, const float* z_row,

@@ -505,7 +505,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     unsigned* hbmax = h->ws_hamax.as<unsigned>() + WF_LEAD / WFL_BLK;   // block maxima (fused layer kernel)
     unsigned* cbmax = h->ws_camax.as<unsigned>() + WF_LEAD / WFL_BLK;
     auto hbmax_ptr = [&](int layer, int slot) { return hbmax + ((size_t)layer * 3 + slot) * bstride; };
-    if (use_wfl) PK_TRY(wfl_cond_planes_launch(ctx, cond, cond_row, G, npos_alloc / WFL_BLK, bstride, cbmax));   // in place
+    if (use_wfl) PK_TRY(wfl_cond_planes_launch(ctx, cond, cond_row, G, npos_alloc / WFL_BLK, bstride, cbmax, M));   // in place
     else if (split_math) PK_TRY(pk_row_amax_launch(ctx, cond, MP, MP, 0, (long)G * pstride - WF_LEAD, camax));
     // ---- fold z
     PK_LAUNCH(ctx, "wf_fold", k_wf_fold, dim3(pk_div_up(npos, 256)), dim3(256), 0, d_z, d_tab + o_putt, d_tab + o_pw,
@@ -553,7 +553,6 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 w.f16 = h->math == PK_GEMM_MATH_F16;
                 w.w.w1 = h->arena16.as<uint16_t>() + L.fl.w1;
                 w.w.w2 = h->arena16.as<uint16_t>() + L.fl.w2;
-                w.w.b1 = h->W(L.fl.b1);
                 w.w.b2r = h->W(L.fl.b2r);
                 w.w.wso = h->W(L.fl.wso);
                 w.w.k1 = L.fl.k1;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     constexpr int nslab = nks / SLAB;    // C = 64: 3, 5, 7;  C = 128: 10, 18, 26
     constexpr int G = nslab + S::NS2;    // slabs of the weight stream
     __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];   // three weight slabs: 144 KB
-    __shared__ __attribute__((aligned(16))) float lb[5 * C];           // b1 [2C] | b2r [C] | wso [2C]
+    __shared__ __attribute__((aligned(16))) float lb[3 * C];           // b2r [C] | wso [2C]
     // per source (the taps whose row exists, then the condition block): where its B operand lives (run-time: which ring slot
     // a tap reads depends on the row); per logical k-step: the packed weight k-step that multiplies it
     __shared__ long tp_off[ntap + 1];     // byte offset from in0 of (position 0, octet 0) of the source
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     __shared__ int kt_w[nks];             // packed k-step of W1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    for (int i = tid; i < 5 * C; i += THREADS) lb[i] = i < 2 * C ? a.w.b1[i] : (i < 3 * C ? a.w.b2r[i - 2 * C] : a.w.wso[i - 3 * C]);
+    for (int i = tid; i < 3 * C; i += THREADS) lb[i] = i < C ? a.w.b2r[i] : a.w.wso[i - C];
     if (tid < nks) {
         const int ks = tid;
         kt_w[tid] = ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv);
@@ -309,15 +309,17 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             const int ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(wave_max64(__uint_as_float(m_raw)))));   // (all sources are maxima: the repeats change nothing)
             const int kx = PK_BLK_TOP + 127 - ex;
             const int ks1 = kx + a.w.k1;
-            const float S1 = pow2f(ks1);
             const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
             const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
             f16x8 f;          // rescale factor of the tap being consumed
-            f32x16 acc[NQ];   // (initialised here, not above the prologue: its loads need the registers first)
+            // the accumulators start at zero: the bias of the first contraction is the weight column of condition channel
+            // n_mels, which k_wf_cond_planes sets to 1 (the 80 mel channels are padded to 96 anyway) -- 2C LDS reads and
+            // multiplies per tile less
+            f32x16 acc[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][r] = lbr[32 * q + mfma_row(r, hh)] * S1;
+                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
             stamp(1);
             __syncthreads();
             stamp(2);
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             stamp(19);
             f16x8 zh[S::KS2], zl[S::KS2];
             float pl = 0.f, pb = 0.f;
-            const f32x4* wso = reinterpret_cast<const f32x4*>(lbr + 3 * C) + hh * (S::KS2 * 4);
+            const f32x4* wso = reinterpret_cast<const f32x4*>(lbr + C) + hh * (S::KS2 * 4);
 #pragma unroll
             for (int k2 = 0; k2 < S::KS2; ++k2) {
                 const int zq = k2 >> 1, r0 = 8 * (k2 & 1);
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
             for (int t = 0; t < CT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[t][r] = lbr[2 * C + 32 * t + mfma_row(r, hh)];
+                for (int r = 0; r < 16; ++r) acc2[t][r] = lbr[32 * t + mfma_row(r, hh)];
 #pragma unroll
             for (int h2 = 0; h2 < S::NS2; ++h2) {
                 const int g = nslab + h2;   // slab of the weight stream
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 
 // The folded condition rows as planes, in place: one wave per (row, block) of 96 x 32 floats stored [channel][32]
 __global__ __launch_bounds__(64) void k_wf_cond_planes(float* __restrict__ cond, long row_stride, long amax_row_stride,
-                                                      unsigned* __restrict__ amax) {
+                                                      unsigned* __restrict__ amax, int one_ch) {
     float* blk = cond + (long)blockIdx.y * row_stride + (long)blockIdx.x * (WFL_MP * WFL_BLK);
     const int lane = threadIdx.x, j = lane & 31, hh = lane >> 5;
     float v[WFL_KS_COND][8];
@@ -570,7 +572,8 @@ __global__ __launch_bounds__(64) void k_wf_cond_planes(float* __restrict__ cond,
     for (int kq = 0; kq < WFL_KS_COND; ++kq)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            v[kq][e] = blk[wfl_chan(kq, hh, e) * WFL_BLK + j];
+            const int ch = wfl_chan(kq, hh, e);
+            v[kq][e] = ch == one_ch ? 1.f : blk[ch * WFL_BLK + j];   // the constant channel that carries the layers' biases
             m = fmaxf(m, fabsf(v[kq][e]));
         }
     m = wave_max64(m);   // every lane has read its values: the block can be overwritten
@@ -690,6 +693,7 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
         float m = 0.f;
         for (size_t i = 0; i < (size_t)2 * C * C * 9; ++i) m = std::fmax(m, std::fabs(conv[i]));
         for (size_t i = 0; i < (size_t)2 * C * n_mels; ++i) m = std::fmax(m, std::fabs(cond[i]));
+        for (int i = 0; i < 2 * C; ++i) m = std::fmax(m, std::fabs(conv_b[i] + cond_b[i]));   // the bias column (below)
         o.k1 = pk_weight_scale_exp(&m, 1);
         o.k2res = pk_weight_scale_exp(outp, (size_t)C * C);
     }
@@ -711,7 +715,8 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
                         w = conv[(((size_t)co * C + ci) * 3 + kr) * 3 + kc];
                     } else {
                         const int m = wfl_chan(ks - 9 * KS_TAP, hh, e);
-                        w = m < n_mels ? cond[(size_t)co * n_mels + m] : 0.f;
+                        // channel n_mels is the constant 1 of k_wf_cond_planes: its weight is the bias (:274-275)
+                        w = m < n_mels ? cond[(size_t)co * n_mels + m] : (m == n_mels ? conv_b[co] + cond_b[co] : 0.f);
                     }
                     w = std::ldexp(w, o.k1);
                     put_split(a1 + ((((size_t)ks * 2 + 0) * NQ + q) * 64 + lane) * 8 + e,
@@ -733,8 +738,6 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
                               a2 + ((((size_t)ks * 2 + 1) * CT + t) * 64 + lane) * 8 + e, w);
                 }
     f32.resize((f32.size() + 3) & ~(size_t)3);
-    o.b1 = f32.size();
-    for (int c = 0; c < 2 * C; ++c) f32.push_back(conv_b[c] + cond_b[c]);   // :274-275
     o.b2r = f32.size();
     for (int c = 0; c < C; ++c) f32.push_back(std::ldexp(outp_b[c], PK_UNIT_EXP + o.k2res));
     // the skip half folded with the flow's output_proj: wso[which][zc] = sum_s w_out[which][s] * outp[C + s][zc], scaled
@@ -795,8 +798,10 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
 }
 
 int wfl_cond_planes_launch(pk_ctx* ctx, float* cond, long row_stride, int rows, int nblk, long amax_row_stride,
-                           unsigned* amax) {
-    PK_LAUNCH(ctx, "wf_cond_planes", k_wf_cond_planes, dim3(nblk, rows), dim3(64), 0, cond, row_stride, amax_row_stride, amax);
+                           unsigned* amax, int n_mels) {
+    if (n_mels >= WFL_MP) PK_FAIL(PK_EUNSUPPORTED, "the fused WaveFlow layer kernel needs a free condition channel (n_mels < %d)", WFL_MP);
+    PK_LAUNCH(ctx, "wf_cond_planes", k_wf_cond_planes, dim3(nblk, rows), dim3(64), 0, cond, row_stride, amax_row_stride, amax,
+              n_mels);
     return PK_OK;
 }
 
