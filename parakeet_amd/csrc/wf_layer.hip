@@ -122,6 +122,23 @@ __device__ __forceinline__ float gated_s(float a, float b, float ca, float cb) {
     const float eb = __builtin_amdgcn_exp2f(b * cb);
     return fmaf(ea, -PK_UNIT_SCALE, PK_UNIT_SCALE) * __builtin_amdgcn_rcpf((1.f + ea) * (1.f + eb));
 }
+// two gates at once on packed fp32 math (v_pk_mul / v_pk_add / v_pk_fma take a register pair per issue slot; the clamp and
+// the transcendentals stay per element), as in pwg.hip
+__device__ __forceinline__ f32x2 gated_s2(f32x2 a, f32x2 b, float ca, float cb) {
+    f32x2 ta = a * ca, tb = b * cb;
+    ta[0] = __builtin_amdgcn_fmed3f(ta[0], -28.853900817779268f, 28.853900817779268f);
+    ta[1] = __builtin_amdgcn_fmed3f(ta[1], -28.853900817779268f, 28.853900817779268f);
+    f32x2 ea, eb, rc;
+    ea[0] = __builtin_amdgcn_exp2f(ta[0]);
+    ea[1] = __builtin_amdgcn_exp2f(ta[1]);
+    eb[0] = __builtin_amdgcn_exp2f(tb[0]);
+    eb[1] = __builtin_amdgcn_exp2f(tb[1]);
+    const f32x2 num = ea * (-PK_UNIT_SCALE) + PK_UNIT_SCALE;
+    const f32x2 den = (ea + 1.f) * (eb + 1.f);
+    rc[0] = __builtin_amdgcn_rcpf(den[0]);
+    rc[1] = __builtin_amdgcn_rcpf(den[1]);
+    return num * rc;
+}
 // biased exponent of a block maximum, clamped as blk_scale_exp clamps it (pk_split.h)
 __device__ __forceinline__ int amax_exp(unsigned bits) {
     const int e = (int)(bits >> 23);
@@ -175,13 +192,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     __shared__ long tp_am[ntap + 1];      // element offset from in_amax0 of block 0 of the source's block maxima
     __shared__ int tp_shift[ntap + 1];    // position shift of the tap
     __shared__ int tp_blk[ntap + 1];      // bytes per 32-position block of the source (C or 96 channels)
-    __shared__ int kt_w[nks];             // packed k-step of W1
+    __shared__ unsigned kt_w[nks];        // byte offset of the packed k-step of W1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
     for (int i = tid; i < 3 * C; i += THREADS) lb[i] = i < C ? a.w.b2r[i] : a.w.wso[i - C];
     if (tid < nks) {
         const int ks = tid;
-        kt_w[tid] = ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv);
+        kt_w[tid] = (unsigned)(ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv)) *
+                    (unsigned)(S::KCH1 * 16);
     }
     if (tid < ntap) {
         tp_off[tid] = ((long)a.tap_slot[tid] * a.slot_stride) * 4;
@@ -212,10 +230,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     // chunk c of this thread in slab g of the weight stream (its slot in the LDS slab buffer is c * THREADS + tid)
     // (tz: an opaque zero, renewed per slab -- the tables are the same in every round and every slab, and with the slab
     // loop unrolled the compiler would otherwise read all of them up front and hold them in registers)
+    // (addresses = a scalar base + a 32-bit byte offset: one add per chunk instead of a 64-bit multiply-add chain -- 54 chunks
+    // per tile)
     auto w_src = [&](int g, int c, int tz) -> const f16x8* {
         const int f = c * THREADS + tid;
-        if (g < nslab) return w1 + (long)kt_w[SLAB * g + f / S::KCH1 + tz] * S::KCH1 + (f % S::KCH1);
-        return w2 + (long)(g - nslab) * (S::SLAB2 * S::KCH2) + f;
+        if (g < nslab)
+            return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
+                                                  (kt_w[SLAB * g + f / S::KCH1 + tz] + (unsigned)((f % S::KCH1) * 16)));
+        return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w2) +
+                                              (unsigned)(((g - nslab) * (S::SLAB2 * S::KCH2) + f) * 16));
     };
     f16x8 wreg[S::CPT1];   // one slab of weights on its way from global memory to LDS
     auto w_load = [&](int g, int tz) {
@@ -427,7 +450,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 const int zq = k2 >> 1, r0 = 8 * (k2 & 1);
                 float zv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) zv[e] = gated_s(acc[zq][r0 + e], acc[zq + CT][r0 + e], gca, gcb);
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const f32x2 av = {acc[zq][r0 + 2 * e2], acc[zq][r0 + 2 * e2 + 1]};
+                    const f32x2 bv = {acc[zq + CT][r0 + 2 * e2], acc[zq + CT][r0 + 2 * e2 + 1]};
+                    const f32x2 z2 = gated_s2(av, bv, gca, gcb);
+                    zv[2 * e2] = z2[0];
+                    zv[2 * e2 + 1] = z2[1];
+                }
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {   // [k2][e][logs | b]: two channels per 16-byte read
                     const f32x4 w = wso[k2 * 4 + e2];
@@ -498,8 +527,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kq = 2 * t + (r >> 3), e = r & 7;
-                        const float x_in = ((float)xin_hi[kq][e] + (float)xin_lo[kq][e]) * xs;
-                        float o = fmaf(acc2[t][r], i_res, x_in);
+                        // res + x_in with x_in = (hi + lo) * 2^-k: one multiply and two v_fma_mix (the halves are sources)
+                        float o = fmaf((float)xin_hi[kq][e], xs, fmaf((float)xin_lo[kq][e], xs, acc2[t][r] * i_res));
                         if (!lane_ok) o = 0.f;   // gap positions stay zero
                         am = fmaxf(am, fabsf(o));
                         v[t][r] = o;
