@@ -793,6 +793,9 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     if (!wfl_supports(a.C) || a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9)
         PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (C %d, npos %d, taps %d)", a.C, a.npos_alloc, a.ntap);
+    // operand offsets inside a source are 32-bit (k_wf_layer_p: scalar base + unsigned offset): 16 blocks of margin included
+    if (((long)a.npos_alloc / WAVE_T + 16) * (long)std::max(a.C * 128, BLK_M_BYTES) >= (1L << 32))
+        PK_FAIL(PK_EUNSUPPORTED, "wfl_layer_launch: %d positions per row exceed the 32-bit operand offsets; split the batch", a.npos_alloc);
     const int ntiles = a.npos_alloc / WAVE_T;
     WflLaunch b = a;
     static const int active_env = getenv("PK_WF_ACTIVE") ? atoi(getenv("PK_WF_ACTIVE")) : WAVES;   // measurement switch
