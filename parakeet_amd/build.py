@@ -19,8 +19,9 @@ LIB = os.path.join(HERE, "libpk_synth.so")
 # per-file flags.  wf_layer.hip: the layer kernel's slab loop must unroll completely (26 slabs at 128 channels; a ring slot is a
 # register only under a compile-time index) -- beyond LLVM's default budget for `#pragma unroll`, where it silently keeps a
 # loop and the operand ring moves to scratch memory
-FILE_FLAGS = {"wf_layer.hip": ["-mllvm", "-pragma-unroll-threshold=2000000"]}
-SOURCES = ["pk_ctx.cpp", "pwg.hip", "gemm.hip", "fs2.hip", "waveflow.hip", "wf_layer.hip", "speedyspeech.hip", "tts.hip", "gst.hip", "taco2.hip", "rowgemm.hip", "mel.hip", "ops.hip"]
+_UNROLL_ALL = ["-mllvm", "-pragma-unroll-threshold=2000000"]
+FILE_FLAGS = {"wf_layer.hip": _UNROLL_ALL, "ffn_planes.hip": _UNROLL_ALL}
+SOURCES = ["pk_ctx.cpp", "pwg.hip", "gemm.hip", "fs2.hip", "ffn_planes.hip", "waveflow.hip", "wf_layer.hip", "speedyspeech.hip", "tts.hip", "gst.hip", "taco2.hip", "rowgemm.hip", "mel.hip", "ops.hip"]
 
 
 def hipcc():

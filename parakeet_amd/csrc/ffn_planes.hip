@@ -1,0 +1,512 @@
+// ffn_planes.hip -- the two Conv1D(k = 3) layers of an FFT block's position-wise feed-forward (MultiLayeredConv1d,
+// parakeet/modules/fastspeech2_transformer/multi_layer_conv.py:19-62: w_2(dropout(relu(w_1(x)))), both convs over time with
+// zero padding at the utterance edges) and the LayerNorm in front of them (encoder_layer.py:108-112: residual = x; x =
+// norm2(x); x = residual + feed_forward(x)) on pre-split fp16 planes (pk_ffn_planes.h).
+//
+// Why: the tile GEMM (gemm.hip k_gemm_h3) runs these two layers -- 72 % of FastSpeech2's flops -- at 26-32 % matrix-pipe
+// utilisation: every activation element is split into its fp16 (hi, lo) parts once per column tile that reads it by the
+// threads that stage it, both operands travel through LDS, and a 64 x 64 wave tile reads 2 LDS bytes per MFMA byte.  The
+// WaveFlow layer kernel (wf_layer.hip) has the structure that avoids all three, and these layers fit it: rows of the
+// timeline are the MFMA N dimension, a wave owns 32 rows x (256 | 128) output channels, its B operand (the activations of
+// its own rows, shifted by the tap) comes straight from global memory as two 16-byte loads per k-step -- already split by
+// the kernel that produced it --, only the weights go through LDS (three 48 KB slabs, requested two slabs ahead), and the
+// k loop is unrolled completely so that the operand ring is registers.
+//
+//   k_ffn_ln_planes          LayerNorm of 32 rows -> planes + the block's maximum                                      (norm2)
+//   k_ffn_planes<NQ, 24, 0>  relu(conv(planes) + b) -> planes of the hidden activations, scaled by a magnitude BOUND  (w_1)
+//   k_ffn_planes<4, 96, 1>   x += conv(hidden planes) + b on the fp32 residual stream                                 (w_2)
+// The hidden activations' scale cannot be their maximum (a block's 1536 channels are produced by several workgroups): it is
+// the bound c1 max|norm2 output| + c0 of pk_fft_dense (pk_fft.h), as on the tile-GEMM path.
+//
+// k order: k-step = kq * 3 + tap (the three taps of 16 input channels are consecutive: their loads hit the same lines one
+// row apart).  Per-tap rescale: a wave tile is one block; tap -1 leaves it in lane 0, tap +1 in lane 31 -- those lanes take
+// the neighbouring block's scale.
+//
+// Measured (MI355X, 32 utterances: encoder 4 224 rows, decoder 20 544 rows; per launch, rocprofv3): decoder
+// w_1 313 -> 188 us, w_2 234 -> 195 us; encoder w_1 103 -> 50 us, w_2 48 -> 80 us; norm2 + bounds 24 -> 21 us.  The matrix
+// pipe is 49 % busy in the decoder launches (tile GEMM: 29-35 %); a third of the wave cycles wait for global loads.
+// Tried and measured without effect on that (PK_FFNP_ABLATE / variants since removed): 4-wave workgroups two per CU for
+// w_2, 96 / 192 columns per wave with each XCD working on its own column tiles (weights L2-resident: 10-25 % slower, every
+// XCD then reads all activations), the weight slabs' LDS writes spread over the k-steps instead of bunched at the slab
+// end, A fragments three column tiles ahead, non-temporal operand loads (10 % slower).  With the weight slabs neither
+// loaded nor written (PK_FFNP_ABLATE=8) w_2 takes 139 us, loaded but not written 163, written but not loaded 171, with
+// no operand traffic either 139: what is left of the gap to the matrix-pipe time (100 us at the 2.2 GHz the counters show)
+// is LDS reads, barriers and issue.
+#include "pk_ffn_planes.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "pk_split.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+// an octet's 1 KB of a block: [plane hi | lo][row 32][8 halves] -- a half wave's operand load of one k-step is 512 contiguous
+// bytes per plane (pk_wf_layer.h interleaves the planes per row: [row][hi | lo][8], 16 of every 32 bytes per load)
+constexpr int ROW_B = 16, LO_OFF = 512;
+constexpr int CPT = 6;   // 16-byte chunks of a weight slab per thread: a slab is 6 KB per wave of the workgroup (48 KB for 8 waves)
+
+struct Args {
+    FfnpConv c;
+    int active;        // waves of a workgroup that take a tile (the rest only move weights)
+    int nrg;           // row groups = ceil(nblk / active)
+    int nct;           // column tiles
+    long in_blk, out_blk;   // bytes per block of the input / output planes
+};
+
+__host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// the stored pair of an activation: hi = fp16_rne(s x), lo = fp16_rne(s x - hi) (wf_layer.hip)
+__device__ __forceinline__ void store_pair8(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = v[e] * s;
+        const _Float16 h = (_Float16)t;
+        hi[e] = h;
+        lo[e] = (_Float16)(t - (float)h);
+    }
+}
+__device__ __forceinline__ int amax_exp(unsigned bits) {
+    const int e = (int)(bits >> 23);
+    return e < PK_EXP_MIN ? PK_EXP_MIN : (e > PK_EXP_MAX ? PK_EXP_MAX : e);
+}
+// the fp16 value 2^-d twice in a register (d >= 0)
+__device__ __forceinline__ unsigned pow2_neg_h2(int d) {
+    const float f = __uint_as_float((unsigned)(127 - min(d, 60)) << 23);
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f, f));
+}
+__device__ __forceinline__ f16x8 h8_of(unsigned u) {
+    const u32x4 v = {u, u, u, u};
+    return __builtin_bit_cast(f16x8, v);
+}
+__device__ __forceinline__ f16x8 ld_h8(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+__device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
+
+// NQ accumulator tiles (32 output channels each) per wave, KQ = Cin / 16, EPI 0: bias + ReLU -> planes, 1: += into fp32 rows.
+// Grid: one workgroup per (row group of `active` blocks, column tile); blockIdx -> (row group, column tile) keeps the column
+// tiles of a row group on one XCD (block b runs on XCD b % 8: observed, used for speed only), where its activations are read
+// from memory once.
+// W waves per workgroup: 8 (one workgroup per CU) or 4 (24 KB slabs, two workgroups per CU: half the rows per workgroup --
+// finer scheduling granularity, barriers among four waves, and the two workgroups of a CU cover each other's barriers,
+// prologues and epilogues; the weights travel to LDS twice per CU).
+// ABL (profiling only, PK_FFNP_ABLATE, results are wrong when set): 1 = the operand ring is not refilled after the prologue,
+// 4 = no epilogue loads / stores, 8 = the weight slabs are not reloaded after the prologue (barriers stay), 128 = weight
+// slabs loaded but not written to LDS, 256 = written (stale registers) but not loaded; sums combine
+template <int NQ, int KQ, int EPI, int W, int ABL = 0>
+__global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
+    constexpr int THREADS = 64 * W;
+    constexpr int SLAB_CH = CPT * THREADS;    // 16-byte chunks per slab buffer
+    constexpr int KCH = 2 * NQ * 64;          // chunks per k-step of the packed weights
+    constexpr int SLAB = SLAB_CH / KCH;       // k-steps per slab: 3 / 6
+    constexpr int nks = FFNP_TAPS * KQ;
+    constexpr int G = nks / SLAB;             // slabs
+    constexpr int RING = NQ == 8 ? 6 : 9;     // operand ring depth in k-steps (wf_layer.hip Shape::RING)
+    constexpr bool TIGHT = NQ == 8;
+    static_assert(SLAB_CH % KCH == 0 && nks % SLAB == 0 && nks > RING && G >= 3, "shape");
+    __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];
+    __shared__ __attribute__((aligned(16))) float lb[32 * NQ];   // this column tile's bias in lane order [hh][q][r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    // blockIdx -> (row group, column tile): the column tiles of a row group on one XCD
+    const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+    const int rg = (k / a.nct) * 8 + xcd, ct = k % a.nct;
+    if (rg >= a.nrg) return;   // (the whole workgroup)
+    for (int i = tid; i < 32 * NQ; i += THREADS) {
+        const int h2 = i / (16 * NQ), q = (i / 16) % NQ, r = i % 16;
+        lb[i] = a.c.bias ? a.c.bias[ct * (32 * NQ) + 32 * q + mfma_row(r, h2)] : 0.f;
+    }
+    const f16x8* wt = reinterpret_cast<const f16x8*>(a.c.w) + (long)ct * ((long)G * SLAB_CH) + tid;
+    const int blk = rg * a.active + wave;
+    const bool tile_ok = wave < a.active && blk < a.c.nblk;
+    f16x8 wreg[CPT];   // one slab of weights on its way from global memory to LDS
+
+    if (tile_ok) {
+        const int p = blk * FFNP_BLK + j;
+        const int rv = a.c.row_utt[p];
+        // the maxima of the three blocks the taps read (lanes 0..2; the others repeat lane 0's)
+        const unsigned m_raw = a.c.in_amax[blk - 1 + (lane < 3 ? lane : 0)];
+        // this lane's operand of tap t = its 8 channels (octet 2 kq + hh) of row p + t - 1: byte offset from block blk - 1
+        const char* inb = reinterpret_cast<const char*>(a.c.in) + ((long)blk - 1) * a.in_blk;
+        unsigned off[FFNP_TAPS];
+#pragma unroll
+        for (int t = 0; t < FFNP_TAPS; ++t) {
+            const int q = j + t - 1;   // -1 .. 32
+            off[t] = (unsigned)((q + 32) >> 5) * (unsigned)a.in_blk + (unsigned)((q & 31) * ROW_B + hh * 1024);
+        }
+        f16x8 rhi[RING], rlo[RING];
+        auto load_b = [&](int ks) {
+            const int kq = ks / FFNP_TAPS, tap = ks % FFNP_TAPS, slot = ks % RING;
+            const char* src = inb + (off[tap] + (unsigned)(kq * 2048));
+            rhi[slot] = ld_h8(src);
+            rlo[slot] = ld_h8(src + LO_OFF);
+        };
+        {   // slabs 0 and 1 of the weights and the first ring in ONE round trip
+            f16x8 wreg1[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) wreg[c] = wt[c * THREADS];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) wreg1[c] = wt[SLAB_CH + c * THREADS];
+#pragma unroll
+            for (int kk = 0; kk < RING; ++kk) load_b(kk);
+            __builtin_amdgcn_sched_barrier(0);   // everything above is requested before anything below waits
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) wbuf[0][c * THREADS + tid] = wreg[c];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+        }
+        // common scale of the tile: the largest of the three block maxima; per tap and lane the power of two that brings the
+        // block the lane reads to it
+        const unsigned am0 = __builtin_amdgcn_readlane(m_raw, 0), am1 = __builtin_amdgcn_readlane(m_raw, 1),
+                       am2 = __builtin_amdgcn_readlane(m_raw, 2);
+        const int e0 = amax_exp(am0), e1 = amax_exp(am1), e2 = amax_exp(am2);
+        const int ex = max(e0, max(e1, e2));
+        const int kx = PK_BLK_TOP + 127 - ex;
+        unsigned fu[FFNP_TAPS];
+        fu[0] = pow2_neg_h2(ex - (j == 0 ? e0 : e1));
+        fu[1] = pow2_neg_h2(ex - e1);
+        fu[2] = pow2_neg_h2(ex - (j == 31 ? e2 : e1));
+        f32x16 acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            // (wf_layer.hip: the weights of slab g + 2 are requested first -- every load below is younger --, in two halves
+            // where the accumulators take 128 registers)
+            const int NW = g + 2 >= G ? 0 : CPT, HW = TIGHT ? NW / 2 : NW;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (c < HW && !(ABL & (8 | 256))) wreg[c] = wt[(long)(g + 2) * SLAB_CH + c * THREADS];
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned wo = (g % 3) * SLAB_CH + lane;   // the slab's LDS base as one opaque register (wf_layer.hip)
+            asm volatile("" : "+v"(wo));
+            const f16x8* wl = &wbuf[0][0] + wo;
+#pragma unroll
+            for (int kk = 0; kk < SLAB; ++kk) {
+                const int ks = SLAB * g + kk, slot = ks % RING;
+                const f16x8 f = h8_of(fu[ks % FFNP_TAPS]);
+                f16x8 bh, bl;
+                if (TIGHT) {
+                    rhi[slot] *= f;
+                    rlo[slot] *= f;
+                } else {
+                    bh = rhi[slot] * f;
+                    bl = rlo[slot] * f;
+                    __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
+                    if (!(ABL & 1) && ks + RING < nks) load_b(ks + RING);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f16x8 ah = wl[kk * KCH + (0 * NQ + q) * 64];
+                    acc[q] = mfma16(ah, TIGHT ? rhi[slot] : bh, acc[q]);
+                    const f16x8 al = wl[kk * KCH + (1 * NQ + q) * 64];
+                    acc[q] = mfma16(al, TIGHT ? rhi[slot] : bh, acc[q]);
+                    acc[q] = mfma16(ah, TIGHT ? rlo[slot] : bl, acc[q]);
+                }
+                constexpr int AHEAD = NQ == 8 ? 1 : 2;   // A fragments this many column tiles ahead of their MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * AHEAD, 0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + AHEAD < NQ) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                }
+                if (TIGHT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ABL & 1) && ks + RING < nks) load_b(ks + RING);
+                    if (kk == 0 && NW > 0 && !(ABL & 8)) {
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c)
+                            if (c < HW) wbuf[(g + 2) % 3][c * THREADS + tid] = wreg[c];
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c)
+                            if (c < NW - HW) wreg[c] = wt[(long)(g + 2) * SLAB_CH + (HW + c) * THREADS];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (c < (TIGHT ? NW - HW : NW) && !(ABL & 8)) {
+                    if (ABL & 128) {   // the loads stay (their results are "used"), the LDS writes go
+                        unsigned keep = __builtin_bit_cast(u32x4, wreg[c])[0];
+                        asm volatile("" : "+v"(keep));
+                    } else {
+                        wbuf[(g + 2) % 3][((TIGHT ? HW : 0) + c) * THREADS + tid] = wreg[c];
+                    }
+                }
+            __syncthreads();   // everyone is done reading this slab's buffer and sees the next two
+        }
+        const float inv = pow2f(-(kx + a.c.kw));
+        const f32x4* lb4 = reinterpret_cast<const f32x4*>(lb) + hh * (NQ * 4);
+        if (EPI == 0) {
+            // relu(. + b) -> the hidden planes, scaled by the bound of this block's rows (gap rows: 0)
+            const float m3 = fmaxf(__uint_as_float(am0), fmaxf(__uint_as_float(am1), __uint_as_float(am2)));
+            const float hb = fmaf(m3, a.c.c1, a.c.c0);
+            const float so = pow2f(blk_scale_exp(__float_as_uint(hb)));
+            char* dst = reinterpret_cast<char*>(a.c.out) + (long)blk * a.out_blk + (long)(ct * NQ * 2) * 2048 + j * ROW_B + hh * 1024;
+            const bool row_ok = rv >= 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f32x4 b4 = lb4[q * 4 + 2 * m + i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = fmaxf(fmaf(acc[q][8 * m + 4 * i + e], inv, b4[e]), 0.f);
+                            v[4 * i + e] = row_ok ? t : 0.f;
+                        }
+                    }
+                    f16x8 oh, ol;
+                    store_pair8(v, so, oh, ol);
+                    if ((ABL & 4) && oh[0] != (_Float16)12345.f) continue;   // (never equal: keeps the arithmetic)
+                    st_h8(dst + (2 * q + m) * 2048, oh);
+                    st_h8(dst + (2 * q + m) * 2048 + LO_OFF, ol);
+                }
+            if (ct == 0 && lane == 0) a.c.out_amax[blk] = __float_as_uint(hb);
+        } else {
+            // x += . + b: lane (j, hh) holds row p, channels 32 q + 8 i + 4 hh + (0..3) of the column tile
+            float* xr = a.c.x + (long)p * a.c.ldx + ct * (32 * NQ) + 4 * hh;
+            f32x4 old[NQ][4];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) old[q][i] = (ABL & 4) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(xr + 32 * q + 8 * i);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 b4 = lb4[q * 4 + i];
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = old[q][i][e] + fmaf(acc[q][4 * i + e], inv, b4[e]);
+                    if ((ABL & 4) && o[0] != 12345.f) continue;
+                    *reinterpret_cast<f32x4*>(xr + 32 * q + 8 * i) = o;
+                }
+        }
+    } else {
+        // a wave without a tile only moves weights and keeps the barriers
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) wbuf[0][c * THREADS + tid] = wt[c * THREADS];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) wbuf[1][c * THREADS + tid] = wt[SLAB_CH + c * THREADS];
+        __syncthreads();
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+            if (g + 2 < G) {
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) wreg[c] = wt[(long)(g + 2) * SLAB_CH + c * THREADS];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) wbuf[(g + 2) % 3][c * THREADS + tid] = wreg[c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// LayerNorm -> planes: one workgroup of four waves per block, a wave per row (eight rows each), lane o < C / 8 holds the 8
+// channels of octet o.  The block's maximum decides the scale of all 32 rows, so the rows stay in registers until it is known.
+__global__ __launch_bounds__(256) void k_ffn_ln_planes(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ b, const int* __restrict__ row_utt, int C,
+                                                      float eps, char* __restrict__ out, unsigned* __restrict__ out_amax) {
+    __shared__ float red[4];
+    const int blk = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int noct = C >> 3;
+    const bool on = lane < noct;
+    const int kq = lane >> 1, hh = lane & 1;
+    const int c0 = 16 * kq + 4 * hh;   // channels c0..c0+3 and c0+8..c0+11 (wfl_chan)
+    f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = ga, ba = ga, bb = ga;
+    if (on) {
+        ga = *reinterpret_cast<const f32x4*>(g + c0);
+        gb = *reinterpret_cast<const f32x4*>(g + c0 + 8);
+        ba = *reinterpret_cast<const f32x4*>(b + c0);
+        bb = *reinterpret_cast<const f32x4*>(b + c0 + 8);
+    }
+    float v[8][8];
+    float am = 0.f;
+    const float rc = 1.f / (float)C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = blk * FFNP_BLK + wave * 8 + i;
+        const bool ok = row_utt[r] >= 0;   // wave-uniform
+        f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
+        if (ok && on) {
+            xa = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0);
+            xb = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0 + 8);
+        }
+        float s = (xa[0] + xa[1]) + (xa[2] + xa[3]) + ((xb[0] + xb[1]) + (xb[2] + xb[3]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * rc;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xa[e] -= mean;
+            xb[e] -= mean;
+            q += xa[e] * xa[e] + xb[e] * xb[e];
+        }
+        if (!on) q = 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float inv = 1.0f / sqrtf(q * rc + eps);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ya = ok && on ? xa[e] * inv * ga[e] + ba[e] : 0.f;
+            const float yb = ok && on ? xb[e] * inv * gb[e] + bb[e] : 0.f;
+            v[i][e] = ya;
+            v[i][4 + e] = yb;
+            am = fmaxf(am, fmaxf(fabsf(ya), fabsf(yb)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if (lane == 0) red[wave] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = pow2f(blk_scale_exp(__float_as_uint(am)));
+    if (on) {
+        char* dst = out + (long)blk * ((long)C * 128) + lane * 1024 + (wave * 8) * ROW_B;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f16x8 oh, ol;
+            store_pair8(v[i], s, oh, ol);
+            st_h8(dst + i * ROW_B, oh);
+            st_h8(dst + i * ROW_B + LO_OFF, ol);
+        }
+    }
+    if (threadIdx.x == 0) out_amax[blk] = __float_as_uint(am);
+}
+
+inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 113 - (int)(x >> 23);
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t half = 1u << (shift + 12), mask = (half << 1) - 1;
+        uint32_t r = m >> (shift + 13);
+        const uint32_t rem = m & mask;
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = x - 0x38000000u;
+    const uint32_t rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            e = 113;
+            while (!(m & 0x400u)) { m <<= 1; --e; }
+            x = sign | (e << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+}  // namespace
+
+size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>& w16, int& kw) {
+    const int KQ = Cin / 16, nks = FFNP_TAPS * KQ, nct = N / (32 * nq);
+    kw = pk_weight_scale_exp(kn, (size_t)FFNP_TAPS * Cin * N);
+    w16.resize((w16.size() + 7) & ~(size_t)7);
+    const size_t off = w16.size();
+    w16.resize(off + (size_t)nct * nks * 2 * nq * 64 * 8, 0);
+    uint16_t* dst = w16.data() + off;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ks = 0; ks < nks; ++ks) {
+            const int kq = ks / FFNP_TAPS, tap = ks % FFNP_TAPS;
+            uint16_t* base = dst + ((size_t)ct * nks + ks) * (2 * nq * 64 * 8);
+            for (int q = 0; q < nq; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = lane & 31, hh = lane >> 5;
+                        const int co = ct * 32 * nq + 32 * q + i;
+                        const int ci = 16 * kq + 8 * (e >> 2) + 4 * hh + (e & 3);   // wfl_chan(kq, hh, e)
+                        const float w = std::ldexp(kn[((size_t)tap * Cin + ci) * N + co], kw);
+                        const uint16_t h = f32_to_f16_rne(w);
+                        base[((size_t)(0 * nq + q) * 64 + lane) * 8 + e] = h;
+                        base[((size_t)(1 * nq + q) * 64 + lane) * 8 + e] = f32_to_f16_rne(w - f16_to_f32(h));
+                    }
+        }
+    return off;
+}
+
+int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
+    const bool first = c.out != nullptr;
+    if (!(first ? (c.Cin == 384 && c.N % (32 * FFNP_NQ1) == 0) : (c.Cin == 1536 && c.N % (32 * FFNP_NQ2) == 0)) || c.nblk <= 0 || !c.w)
+        PK_FAIL(PK_EINVAL, "ffnp_conv_launch: shape (Cin %d, N %d) not built", c.Cin, c.N);
+    // First conv: 256 columns per wave in 8-wave workgroups (decoder-sized timelines: half the operand traffic per MFMA), or
+    // 128 columns per wave in 4-wave workgroups, two per CU (short timelines: four times the workgroups).  Second conv: 128
+    // columns per wave, 8-wave workgroups.  PK_FFNP_VARIANT (measurement switch): 88 / 44 force the first conv's kernel, the
+    // second digit 4 runs the second conv in 4-wave workgroups.
+    const char* venv = getenv("PK_FFNP_VARIANT");   // (read per launch: tests switch it)
+    const int variant = venv ? atoi(venv) : 0;
+    const bool small = first && c.w4 && (variant / 10 == 4 || (variant / 10 != 8 && c.nblk < FFNP_NQ1_MIN_BLOCKS));
+    const int nq = first && !small ? FFNP_NQ1 : FFNP_NQ2;
+    const int W = first ? (small ? 4 : 8) : (variant % 10 == 4 ? 4 : 8);
+    Args a;
+    a.c = c;
+    if (small) a.c.w = c.w4;
+    a.nct = c.N / (32 * nq);
+    a.in_blk = (long)c.Cin * 128;
+    a.out_blk = (long)c.N * 128;
+    // 8-wave workgroups: a short timeline does not fill the chip with 8-block row groups -- fewer working waves per
+    // workgroup, more workgroups
+    int active = W;
+    if (W == 8)
+        while (active > 2 && (long)pk_div_up(c.nblk, active) * a.nct < ctx->n_cu) active >>= 1;
+    a.active = active;
+    a.nrg = pk_div_up(c.nblk, active);
+    const int grid = pk_div_up(a.nrg, 8) * 8 * a.nct;
+    auto go = [&](auto kern) -> int {
+        PK_LAUNCH(ctx, prof_name, kern, dim3(grid), dim3(64 * W), 0, a);
+        return PK_OK;
+    };
+    static const int abl = getenv("PK_FFNP_ABLATE") ? atoi(getenv("PK_FFNP_ABLATE")) : 0;   // profiling only: results are wrong
+    if (abl && !first && W == 4) {
+        switch (abl) {
+            case 1: return go(k_ffn_planes<4, 96, 1, 4, 1>);
+            case 4: return go(k_ffn_planes<4, 96, 1, 4, 4>);
+            case 8: return go(k_ffn_planes<4, 96, 1, 4, 8>);
+            case 13: return go(k_ffn_planes<4, 96, 1, 4, 13>);
+            case 128: return go(k_ffn_planes<4, 96, 1, 4, 128>);
+            case 256: return go(k_ffn_planes<4, 96, 1, 4, 256>);
+            default: PK_FAIL(PK_EINVAL, "PK_FFNP_ABLATE: 1, 4, 8, 13, 128 or 256 (with PK_FFNP_VARIANT=84)");
+        }
+    }
+    if (first) return small ? go(k_ffn_planes<FFNP_NQ2, 24, 0, 4>) : go(k_ffn_planes<FFNP_NQ1, 24, 0, 8>);
+    return W == 8 ? go(k_ffn_planes<FFNP_NQ2, 96, 1, 8>) : go(k_ffn_planes<FFNP_NQ2, 96, 1, 4>);
+}
+
+int ffnp_layernorm_launch(pk_ctx* ctx, const float* x, const float* g, const float* b, const int* row_utt, int nblk, int C,
+                          float eps, void* out, unsigned* out_amax) {
+    if (C % 16 != 0 || C / 8 > 64) PK_FAIL(PK_EINVAL, "ffnp_layernorm_launch: %d channels", C);
+    PK_LAUNCH(ctx, "fs2_layernorm_planes", k_ffn_ln_planes, dim3(nblk), dim3(256), 0, x, g, b, row_utt, C, eps,
+              reinterpret_cast<char*>(out), out_amax);
+    return PK_OK;
+}

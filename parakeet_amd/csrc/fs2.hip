@@ -24,6 +24,7 @@
 #include <cstring>
 
 #include "pk_fft.h"
+#include "pk_ffn_planes.h"
 #include "pk_gemm.h"
 #include "pk_split.h"
 
@@ -1006,6 +1007,19 @@ static void dense_bound(const std::vector<float>& kn, const std::vector<float>* 
     c0 = (float)(m0 * (1.0 + 1e-6));
 }
 
+// PK_FS2_FFN_PLANES=0: the feed-forward convs stay on the tile GEMM (A/B measurements; nothing is packed for the planes kernel)
+static bool ffn_planes_enabled() {
+    const char* e = getenv("PK_FS2_FFN_PLANES");
+    return !(e && e[0] == '0');
+}
+
+// ... and PK_FS2_FFN_PLANES_MIN_BLOCKS moves the timeline length (in 32-row blocks) from which they leave it (tests run
+// the planes kernels on short timelines with 0)
+static int ffn_planes_min_blocks() {
+    const char* e = getenv("PK_FS2_FFN_PLANES_MIN_BLOCKS");
+    return e ? atoi(e) : FFNP_MIN_BLOCKS;
+}
+
 int pk_fft_add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<float>* bias, int Cin, int taps,
                  int N, Dense& d) {
     std::vector<float> packed;
@@ -1026,12 +1040,17 @@ int pk_fft_add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vect
 }
 
 int pk_fft_add_conv(Arena& ar, const pk_param_map& P, const std::string& base, int Cout, int Cin, int k, bool bias,
-             Dense& d) {
+             Dense& d, int planes) {
     std::vector<float> w, kn, b;
     PK_TRY(pk_get_weight(P, base, {Cout, Cin, k}, w));
     pk_conv_to_kn(w.data(), Cout, Cin, k, kn);
     if (bias) PK_TRY(pk_get_vector(P, base + ".bias", Cout, b));
-    return pk_fft_add_dense_kn(ar, kn, bias ? &b : nullptr, Cin, k, Cout, d);
+    PK_TRY(pk_fft_add_dense_kn(ar, kn, bias ? &b : nullptr, Cin, k, Cout, d));
+    if (planes && ar.v16 && k == FFNP_TAPS) {
+        d.wp = ffnp_pack(kn.data(), Cin, Cout, planes == 1 ? FFNP_NQ1 : FFNP_NQ2, *ar.v16, d.kwp);
+        if (planes == 1) d.wp4 = ffnp_pack(kn.data(), Cin, Cout, FFNP_NQ2, *ar.v16, d.kwp);
+    }
+    return PK_OK;
 }
 
 int pk_fft_add_vec(Arena& ar, const pk_param_map& P, const std::string& name, int n, size_t& off) {
@@ -1084,6 +1103,8 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
                   int k, int ff_type, int heads, std::vector<FftLayer>& out, size_t& after_g, size_t& after_b,
                   bool normalize_before, bool concat_after) {
     out.resize(n_layers);
+    // pre-norm stacks with conv feed-forward layers of the built shape also get the planes-kernel fragments (pk_ffn_planes.h)
+    const bool planes = normalize_before && ffnp_supports(A, units, k, k) && ffn_planes_enabled();
     for (int l = 0; l < n_layers; ++l) {
         const std::string p = prefix + ".encoders." + std::to_string(l);
         FftLayer& L = out[l];
@@ -1136,10 +1157,10 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
             PK_TRY(pk_get_vector(P, p + ".feed_forward.w_1.bias", units, b));
             PK_TRY(pk_fft_add_dense_kn(ar, w, &b, A, 1, units, L.ffn1));
         } else {
-            PK_TRY(pk_fft_add_conv(ar, P, p + ".feed_forward.w_1", units, A, k, true, L.ffn1));
+            PK_TRY(pk_fft_add_conv(ar, P, p + ".feed_forward.w_1", units, A, k, true, L.ffn1, planes && ff_type == 0 ? 1 : 0));
         }
         if (ff_type == 0) {
-            PK_TRY(pk_fft_add_conv(ar, P, p + ".feed_forward.w_2", A, units, k, true, L.ffn2));
+            PK_TRY(pk_fft_add_conv(ar, P, p + ".feed_forward.w_2", A, units, k, true, L.ffn2, planes ? 2 : 0));
         } else {
             std::vector<float> w, b;
             PK_TRY(pk_get_weight(P, p + ".feed_forward.w_2", {units, A}, w));
@@ -1472,6 +1493,30 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
         fbnd = pk_fft_act_ptr(h->d_fbnd, 1);
         segb = h->d_segb.as<unsigned>();
     }
+    // norm2 and the two feed-forward convs on pre-split planes (pk_ffn_planes.h) where pk_fft_add_stack packed for them
+    const bool planes = h->math == PK_GEMM_MATH_F16X3 && !layers.empty() && layers[0].ffn1.wp != (size_t)-1 &&
+                        layers[0].ffn2.wp != (size_t)-1 && tl.rows_alloc % FFNP_BLK == 0 &&
+                        tl.rows_alloc / FFNP_BLK >= ffn_planes_min_blocks();
+    const int nblk = tl.rows_alloc / FFNP_BLK;
+    char *hp = nullptr, *fp = nullptr;
+    unsigned *hpam = nullptr, *fpam = nullptr;
+    if (planes) {
+        // one block / one element of margin on either side (the +-1 taps of the edge tiles); the leading block is zero from the
+        // allocation on, the maxima are cleared per run (what lies behind the last block only reaches gap rows)
+        pk_dbuf* pb[2] = {&h->d_hp, &h->d_fp};
+        const int pc[2] = {A, units};
+        for (int i = 0; i < 2; ++i) {
+            const void* p0 = pb[i]->p;
+            PK_TRY(pb[i]->reserve(ffnp_plane_bytes(nblk, pc[i])));
+            if (pb[i]->p != p0) PK_HIP(hipMemsetAsync(pb[i]->p, 0, pb[i]->cap, h->ctx->stream));
+        }
+        PK_TRY(h->d_pam.reserve((size_t)2 * (nblk + 2) * sizeof(unsigned)));
+        PK_HIP(hipMemsetAsync(h->d_pam.p, 0, (size_t)2 * (nblk + 2) * sizeof(unsigned), h->ctx->stream));
+        hp = h->d_hp.as<char>() + (size_t)A * 128;
+        fp = h->d_fp.as<char>() + (size_t)units * 128;
+        hpam = h->d_pam.as<unsigned>() + 1;
+        fpam = hpam + nblk + 2;
+    }
     for (const FftLayer& L : layers) {
         PK_TRY(pk_fft_run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh, ham));
         PK_TRY(pk_fft_run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, ham));
@@ -1492,6 +1537,29 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             PK_TRY(pk_fft_run_dense(h, "fs2_gemm_concat_a", L.cat_a, t, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
         } else
         PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, cbnd));
+        if (planes) {
+            PK_TRY(ffnp_layernorm_launch(h->ctx, x, h->W(L.ln2_g), h->W(L.ln2_b), rv, nblk, A, 1e-5f, hp, hpam));
+            FfnpConv c;
+            memset(&c, 0, sizeof(c));
+            c.nblk = nblk;
+            c.row_utt = rv;
+            c.w = h->arena16.as<uint16_t>() + L.ffn1.wp;
+            c.w4 = L.ffn1.wp4 == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + L.ffn1.wp4;
+            c.bias = L.ffn1.b == (size_t)-1 ? nullptr : h->W(L.ffn1.b);
+            c.kw = L.ffn1.kwp; c.Cin = A; c.N = units;
+            c.in = hp; c.in_amax = hpam;
+            c.out = fp; c.out_amax = fpam; c.c1 = L.ffn1.c1; c.c0 = L.ffn1.c0;
+            PK_TRY(ffnp_conv_launch(h->ctx, "fs2_conv_ffn1_planes", c));
+            c.w = h->arena16.as<uint16_t>() + L.ffn2.wp;
+            c.w4 = nullptr;
+            c.bias = L.ffn2.b == (size_t)-1 ? nullptr : h->W(L.ffn2.b);
+            c.kw = L.ffn2.kwp; c.Cin = units; c.N = A;
+            c.in = fp; c.in_amax = fpam;
+            c.out = nullptr; c.out_amax = nullptr;
+            c.x = x; c.ldx = A;
+            PK_TRY(ffnp_conv_launch(h->ctx, "fs2_conv_ffn2_planes", c));
+            continue;
+        }
         PK_TRY(pk_fft_run_layernorm(h, x, L.ln2_g, L.ln2_b, tl, A, hh, ham));
         PK_TRY(pk_fft_run_dense(h, "fs2_conv_ffn1", L.ffn1, hh, A, f, units, tl.rows, PK_ACT_RELU, nullptr, 0, rv, ham));
         if (bounds)

@@ -19,6 +19,9 @@ constexpr int PK_FFT_LEAD = 8;         // rows of margin in front of every activ
 struct pk_fft_dense {
     size_t w = 0, b = 0;   // offsets (floats) into the weight arena; b == SIZE_MAX: no bias
     size_t wh = (size_t)-1;   // offset (halves) of the split-fp16 fragments, SIZE_MAX if Cin % 32 != 0
+    size_t wp = (size_t)-1;   // offset (halves) of the planes-kernel fragments (pk_ffn_planes.h), SIZE_MAX if not packed
+    size_t wp4 = (size_t)-1;  // first feed-forward conv: the same for the kernel with 4 tiles per wave (short timelines)
+    int kwp = 0;              // their block-scale exponent
     int Cin = 0, N = 0, taps = 1, pad = 0;
     // |y[r, n]| <= c1 * max|x[r + tap, :]| + c0 with c1 = max_n sum_k |W[k, n]|, c0 = max_n |bias[n]|: an upper
     // bound on the magnitude of this layer's output rows, used as the block maximum of the NEXT split-fp16 GEMM's
@@ -81,11 +84,12 @@ struct pk_fft_core {
     int max_len = 0;                 // rows of the positional table
     pk_dbuf d_pe, d_div;
     pk_dbuf d_x, d_h, d_qkv, d_ctx, d_f, d_lnamax, d_cbnd, d_fbnd, d_segb, d_cat;
+    pk_dbuf d_hp, d_fp, d_pam;       // planes of the norm2 output and of the hidden activations, their block maxima
 
     const float* W(size_t off) const { return arena.as<float>() + off; }
     void release_core() {
         pk_dbuf* bufs[] = {&arena, &arena16, &d_pe, &d_div, &d_x, &d_h, &d_qkv, &d_ctx, &d_f, &d_lnamax, &d_cbnd,
-                           &d_fbnd, &d_segb, &d_cat};
+                           &d_fbnd, &d_segb, &d_cat, &d_hp, &d_fp, &d_pam};
         for (pk_dbuf* b : bufs) b->release();
     }
 };
@@ -99,8 +103,9 @@ int pk_fft_add_dense_kn(pk_fft_arena& ar, const std::vector<float>& kn, const st
                         int taps, int N, pk_fft_dense& d);
 int pk_fft_add_linear(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int Cin, int N,
                       pk_fft_dense& d);   // Linear weight [in, out] + bias
+// planes: 1 / 2 = also pack the weights as the first / second feed-forward conv of the planes kernels (pk_ffn_planes.h)
 int pk_fft_add_conv(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int Cout, int Cin, int k,
-                    bool bias, pk_fft_dense& d);
+                    bool bias, pk_fft_dense& d, int planes = 0);
 // Conv1D -> BatchNorm1D(eval, eps 1e-5) folded into one dense layer (tacotron2/decoder.py:133-147,
 // tacotron2/encoder.py:98-110; with conv_bias: Conv1dBatchNorm, modules/conv.py:186-260): conv at `conv_base`,
 // batch norm at `bn_base`

@@ -143,6 +143,68 @@ def test_fs2_split_math_is_scale_invariant(kf, kv, kq):
     assert l1["f16x3"] < 2.0 * l1["f32"] + 5e-7, l1
 
 
+def _planes_env(monkeypatch, variant):
+    """Run norm2 + the feed-forward convs on the planes kernels (csrc/ffn_planes.hip) whatever the timeline length; variant:
+    PK_FFNP_VARIANT (first digit 8 / 4: 256 / 128 columns per wave in the first conv, second digit: waves per workgroup of
+    the second), '' = the launcher's own choice."""
+    monkeypatch.setenv("PK_FS2_FFN_PLANES", "1")
+    monkeypatch.setenv("PK_FS2_FFN_PLANES_MIN_BLOCKS", "0")
+    if variant:
+        monkeypatch.setenv("PK_FFNP_VARIANT", variant)
+    else:
+        monkeypatch.delenv("PK_FFNP_VARIANT", raising=False)
+
+
+@pytest.mark.parametrize("variant", ["", "88", "44"])
+def test_fs2_ffn_planes_kernels(monkeypatch, variant):
+    """By default only timelines of >= 4096 rows take the planes kernels (the bench-shape tests); here the ragged batch of
+    test_fs2_ljspeech_ragged_batch runs them (gaps, 1-token utterances, tiles that straddle utterances, idle waves) and
+    must meet the same bars, internal taps included."""
+    from parakeet_amd.runtime import Context
+    _planes_env(monkeypatch, variant)
+    ctx = Context.get()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    try:
+        _check(_cfg(), [37, 5, 64, 1, 23], seed=100)
+        names = set(ctx.prof_dump().keys())
+    finally:
+        ctx.prof_enable(False)
+    assert {"fs2_layernorm_planes", "fs2_conv_ffn1_planes", "fs2_conv_ffn2_planes"} <= names, names
+    assert not any(n.startswith("fs2_conv_ffn") and "planes" not in n for n in names), names
+
+
+def test_fs2_ffn_planes_long_utterance(monkeypatch):
+    _planes_env(monkeypatch, "")
+    _check(_cfg(), [150, 33], seed=104, taps=False)
+
+
+@pytest.mark.parametrize("kf", [-20, 8])
+def test_fs2_ffn_planes_scale_invariant(monkeypatch, kf):
+    """The hidden activations are stored with the scale of a magnitude BOUND: a model whose hidden stream is rescaled by 2^kf
+    (exactly compensated) must give the original's output at the exact-fp32 path's error."""
+    from oracle import fastspeech2_ref as ref
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    _planes_env(monkeypatch, "")
+    cfg = _cfg()
+    state = syn.fastspeech2_state(80, 80, cfg, seed=140)
+    ids = syn.phoneme_ids(45, 80, seed=141)
+    want, parts = ref.inference(state, ids, _oracle_cfg(cfg), dtype=torch.float64, return_parts=True)
+    want = want.numpy()
+    model = FastSpeech2(80, 80, **cfg)
+    model.set_state_dict(_rescaled_fs2_state(state, cfg, kf, 0, 0))
+    model.eval()
+    model.set_debug(True)
+    l1 = {}
+    for mode in ("f32", "f16x3"):
+        model.set_math(mode)
+        got = model.inference(ids).numpy()
+        np.testing.assert_array_equal(model.debug_tap(3, 0), parts["d"].numpy())
+        l1[mode] = float(np.abs(got - want).mean())
+    assert l1["f32"] < 2e-5, l1
+    assert l1["f16x3"] < 2.0 * l1["f32"] + 5e-7, l1
+
+
 def test_fs2_inference_wrapper_denormalizes():
     from oracle import fastspeech2_ref as ref
     from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
