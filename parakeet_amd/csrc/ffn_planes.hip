@@ -100,15 +100,15 @@ __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x
 // ABL (profiling only, PK_FFNP_ABLATE, results are wrong when set): 1 = the operand ring is not refilled after the prologue,
 // 4 = no epilogue loads / stores, 8 = the weight slabs are not reloaded after the prologue (barriers stay), 128 = weight
 // slabs loaded but not written to LDS, 256 = written (stale registers) but not loaded; sums combine
-template <int NQ, int KQ, int EPI, int W, int ABL = 0>
+template <int NQ, int KQ, int EPI, int W, int TAPS = FFNP_TAPS, int ABL = 0>
 __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
     constexpr int THREADS = 64 * W;
     constexpr int SLAB_CH = CPT * THREADS;    // 16-byte chunks per slab buffer
     constexpr int KCH = 2 * NQ * 64;          // chunks per k-step of the packed weights
     constexpr int SLAB = SLAB_CH / KCH;       // k-steps per slab: 3 / 6
-    constexpr int nks = FFNP_TAPS * KQ;
+    constexpr int nks = TAPS * KQ;            // TAPS = 3: conv over rows r - 1, r, r + 1; 1: a Linear layer
     constexpr int G = nks / SLAB;             // slabs
-    constexpr int RING = NQ == 8 ? 6 : 9;     // operand ring depth in k-steps (wf_layer.hip Shape::RING)
+    constexpr int RING = NQ >= 6 ? 6 : 9;     // operand ring depth in k-steps (wf_layer.hip Shape::RING)
     constexpr bool TIGHT = NQ == 8;
     static_assert(SLAB_CH % KCH == 0 && nks % SLAB == 0 && nks > RING && G >= 3, "shape");
     __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];
@@ -138,12 +138,12 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         unsigned off[FFNP_TAPS];
 #pragma unroll
         for (int t = 0; t < FFNP_TAPS; ++t) {
-            const int q = j + t - 1;   // -1 .. 32
+            const int q = j + t - 1;   // -1 .. 32 (one tap: only t = 1 is used)
             off[t] = (unsigned)((q + 32) >> 5) * (unsigned)a.in_blk + (unsigned)((q & 31) * ROW_B + hh * 1024);
         }
         f16x8 rhi[RING], rlo[RING];
         auto load_b = [&](int ks) {
-            const int kq = ks / FFNP_TAPS, tap = ks % FFNP_TAPS, slot = ks % RING;
+            const int kq = ks / TAPS, tap = TAPS == 1 ? 1 : ks % TAPS, slot = ks % RING;
             const char* src = inb + (off[tap] + (unsigned)(kq * 2048));
             rhi[slot] = ld_h8(src);
             rlo[slot] = ld_h8(src + LO_OFF);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         const unsigned am0 = __builtin_amdgcn_readlane(m_raw, 0), am1 = __builtin_amdgcn_readlane(m_raw, 1),
                        am2 = __builtin_amdgcn_readlane(m_raw, 2);
         const int e0 = amax_exp(am0), e1 = amax_exp(am1), e2 = amax_exp(am2);
-        const int ex = max(e0, max(e1, e2));
+        const int ex = TAPS == 1 ? e1 : max(e0, max(e1, e2));
         const int kx = PK_BLK_TOP + 127 - ex;
         unsigned fu[FFNP_TAPS];
         fu[0] = pow2_neg_h2(ex - (j == 0 ? e0 : e1));
@@ -194,14 +194,14 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
 #pragma unroll
             for (int kk = 0; kk < SLAB; ++kk) {
                 const int ks = SLAB * g + kk, slot = ks % RING;
-                const f16x8 f = h8_of(fu[ks % FFNP_TAPS]);
+                const f16x8 f = h8_of(fu[TAPS == 1 ? 1 : ks % TAPS]);   // (one tap: 2^0, the block's own scale)
                 f16x8 bh, bl;
                 if (TIGHT) {
                     rhi[slot] *= f;
                     rlo[slot] *= f;
                 } else {
-                    bh = rhi[slot] * f;
-                    bl = rlo[slot] * f;
+                    bh = TAPS == 1 ? rhi[slot] : rhi[slot] * f;
+                    bl = TAPS == 1 ? rlo[slot] : rlo[slot] * f;
                     __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
                     if (!(ABL & 1) && ks + RING < nks) load_b(ks + RING);
                 }
@@ -277,6 +277,19 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                     st_h8(dst + (2 * q + m) * 2048 + LO_OFF, ol);
                 }
             if (ct == 0 && lane == 0) a.c.out_amax[blk] = __float_as_uint(hb);
+        } else if (EPI == 2) {
+            // y = . + b (fp32 row-major): lane (j, hh) holds row p, channels 32 q + 8 i + 4 hh + (0..3) of the column tile
+            float* yr = a.c.x + (long)p * a.c.ldx + ct * (32 * NQ) + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 b4 = lb4[q * 4 + i];
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[q][4 * i + e], inv, b4[e]);
+                    *reinterpret_cast<f32x4*>(yr + 32 * q + 8 * i) = o;
+                }
         } else {
             // x += . + b: lane (j, hh) holds row p, channels 32 q + 8 i + 4 hh + (0..3) of the column tile
             float* xr = a.c.x + (long)p * a.c.ldx + ct * (32 * NQ) + 4 * hh;
@@ -430,16 +443,16 @@ inline float f16_to_f32(uint16_t h) {
 }
 }  // namespace
 
-size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>& w16, int& kw) {
-    const int KQ = Cin / 16, nks = FFNP_TAPS * KQ, nct = N / (32 * nq);
-    kw = pk_weight_scale_exp(kn, (size_t)FFNP_TAPS * Cin * N);
+size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>& w16, int& kw, int taps) {
+    const int KQ = Cin / 16, nks = taps * KQ, nct = N / (32 * nq);
+    kw = pk_weight_scale_exp(kn, (size_t)taps * Cin * N);
     w16.resize((w16.size() + 7) & ~(size_t)7);
     const size_t off = w16.size();
     w16.resize(off + (size_t)nct * nks * 2 * nq * 64 * 8, 0);
     uint16_t* dst = w16.data() + off;
     for (int ct = 0; ct < nct; ++ct)
         for (int ks = 0; ks < nks; ++ks) {
-            const int kq = ks / FFNP_TAPS, tap = ks % FFNP_TAPS;
+            const int kq = ks / taps, tap = ks % taps;
             uint16_t* base = dst + ((size_t)ct * nks + ks) * (2 * nq * 64 * 8);
             for (int q = 0; q < nq; ++q)
                 for (int lane = 0; lane < 64; ++lane)
@@ -490,17 +503,37 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     static const int abl = getenv("PK_FFNP_ABLATE") ? atoi(getenv("PK_FFNP_ABLATE")) : 0;   // profiling only: results are wrong
     if (abl && !first && W == 4) {
         switch (abl) {
-            case 1: return go(k_ffn_planes<4, 96, 1, 4, 1>);
-            case 4: return go(k_ffn_planes<4, 96, 1, 4, 4>);
-            case 8: return go(k_ffn_planes<4, 96, 1, 4, 8>);
-            case 13: return go(k_ffn_planes<4, 96, 1, 4, 13>);
-            case 128: return go(k_ffn_planes<4, 96, 1, 4, 128>);
-            case 256: return go(k_ffn_planes<4, 96, 1, 4, 256>);
+            case 1: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 1>);
+            case 4: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 4>);
+            case 8: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 8>);
+            case 13: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 13>);
+            case 128: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 128>);
+            case 256: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 256>);
             default: PK_FAIL(PK_EINVAL, "PK_FFNP_ABLATE: 1, 4, 8, 13, 128 or 256 (with PK_FFNP_VARIANT=84)");
         }
     }
     if (first) return small ? go(k_ffn_planes<FFNP_NQ2, 24, 0, 4>) : go(k_ffn_planes<FFNP_NQ1, 24, 0, 8>);
     return W == 8 ? go(k_ffn_planes<FFNP_NQ2, 96, 1, 8>) : go(k_ffn_planes<FFNP_NQ2, 96, 1, 4>);
+}
+
+int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
+    if (c.Cin != 384 || c.N % (32 * FFNP_NQL) != 0 || c.nblk <= 0 || !c.w || !c.x)
+        PK_FAIL(PK_EINVAL, "ffnp_linear_launch: shape (Cin %d, N %d) not built", c.Cin, c.N);
+    Args a;
+    a.c = c;
+    a.nct = c.N / (32 * FFNP_NQL);
+    a.in_blk = (long)c.Cin * 128;
+    a.out_blk = 0;
+    int active = 8;
+    while (active > 2 && (long)pk_div_up(c.nblk, active) * a.nct < ctx->n_cu) active >>= 1;
+    a.active = active;
+    a.nrg = pk_div_up(c.nblk, active);
+    const int grid = pk_div_up(a.nrg, 8) * 8 * a.nct;
+    auto go = [&](auto kern) -> int {
+        PK_LAUNCH(ctx, prof_name, kern, dim3(grid), dim3(512), 0, a);
+        return PK_OK;
+    };
+    return go(k_ffn_planes<FFNP_NQL, 24, 2, 8, 1>);
 }
 
 int ffnp_layernorm_launch(pk_ctx* ctx, const float* x, const float* g, const float* b, const int* row_utt, int nblk, int C,

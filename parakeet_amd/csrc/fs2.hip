@@ -323,12 +323,19 @@ struct QkvBoundC {
 };
 __global__ __launch_bounds__(256) void k_fs2_seg_bounds(const float* __restrict__ ham, const int* __restrict__ seg_start,
                                                         const int* __restrict__ seg_len, int heads, QkvBoundC c,
-                                                        unsigned* __restrict__ segb, float* __restrict__ ctx_bound) {
+                                                        unsigned* __restrict__ segb, float* __restrict__ ctx_bound,
+                                                        int per_block) {
+    // per_block: ham holds one maximum per 32-row block (the planes LayerNorm, pk_ffn_planes.h) -- the blocks an utterance
+    // touches may hold a neighbour's rows too: a bound all the same
     __shared__ float red[4];
     const int b = blockIdx.x;
     const int start = seg_start[b], len = seg_len[b];
     float m = 0.f;
-    for (int r = threadIdx.x; r < len; r += 256) m = fmaxf(m, ham[start + r]);
+    if (per_block) {
+        for (int r = (start >> 5) + threadIdx.x; r <= ((start + len - 1) >> 5) && len > 0; r += 256) m = fmaxf(m, ham[r]);
+    } else {
+        for (int r = threadIdx.x; r < len; r += 256) m = fmaxf(m, ham[start + r]);
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -1132,6 +1139,8 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
             bias[2 * A + o] = bv[o];
         }
         PK_TRY(pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 3 * A, L.qkv));
+        if (planes && !concat_after && ar.v16 && (3 * A) % (32 * FFNP_NQL) == 0)
+            L.qkv.wp = ffnp_pack(kn.data(), A, 3 * A, FFNP_NQL, *ar.v16, L.qkv.kwp, 1);
         for (int part = 0; part < 3; ++part)
             for (int hd = 0; hd < heads && hd < FS2_MAX_HEADS; ++hd)
                 dense_bound(kn, &bias, A, 3 * A, part * A + hd * (A / heads), part * A + (hd + 1) * (A / heads),
@@ -1518,14 +1527,31 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
         fpam = hpam + nblk + 2;
     }
     for (const FftLayer& L : layers) {
-        PK_TRY(pk_fft_run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh, ham));
-        PK_TRY(pk_fft_run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, ham));
+        const bool qkv_planes = planes && bounds && !L.concat && L.qkv.wp != (size_t)-1;
+        if (qkv_planes) {
+            // norm1 -> planes, the fused q | k | v projection on them; the segment bounds from the block maxima
+            PK_TRY(ffnp_layernorm_launch(h->ctx, x, h->W(L.ln1_g), h->W(L.ln1_b), rv, nblk, A, 1e-5f, hp, hpam));
+            FfnpConv c;
+            memset(&c, 0, sizeof(c));
+            c.nblk = nblk;
+            c.row_utt = rv;
+            c.w = h->arena16.as<uint16_t>() + L.qkv.wp;
+            c.bias = L.qkv.b == (size_t)-1 ? nullptr : h->W(L.qkv.b);
+            c.kw = L.qkv.kwp; c.Cin = A; c.N = 3 * A;
+            c.in = hp; c.in_amax = hpam;
+            c.x = qkv; c.ldx = 3 * A;
+            PK_TRY(ffnp_linear_launch(h->ctx, "fs2_gemm_qkv_planes", c));
+        } else {
+            PK_TRY(pk_fft_run_layernorm(h, x, L.ln1_g, L.ln1_b, tl, A, hh, ham));
+            PK_TRY(pk_fft_run_dense(h, "fs2_gemm_qkv", L.qkv, hh, A, qkv, 3 * A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, ham));
+        }
         if (bounds) {
             QkvBoundC qc;
             memcpy(qc.c1, L.qkv_c1, sizeof(qc.c1));
             memcpy(qc.c0, L.qkv_c0, sizeof(qc.c0));
-            PK_LAUNCH(h->ctx, "fs2_bounds", k_fs2_seg_bounds, dim3(tl.B), dim3(256), 0, ham, tl.d_seg_start(),
-                      tl.d_seg_len(), heads, qc, segb, cbnd);
+            PK_LAUNCH(h->ctx, "fs2_bounds", k_fs2_seg_bounds, dim3(tl.B), dim3(256), 0,
+                      qkv_planes ? reinterpret_cast<const float*>(hpam) : ham, tl.d_seg_start(), tl.d_seg_len(), heads, qc, segb,
+                      cbnd, qkv_planes ? 1 : 0);
         }
         PK_TRY(pk_fft_run_attention(h, tl, qkv, ctxb, segb));
         if (L.concat) {

@@ -18,6 +18,7 @@ constexpr int FFNP_BLK = 32;    // rows per block
 constexpr int FFNP_TAPS = 3;    // the only kernel size built
 constexpr int FFNP_NQ1 = 8;     // first conv: a wave owns 8 x 32 output channels (long timelines) ...
 constexpr int FFNP_NQ2 = 4;     // ... or 4 x 32 (short ones); second conv: 4 x 32
+constexpr int FFNP_NQL = 6;     // Linear layer on planes (the fused q | k | v projection, N = 3 adim = 6 x 192): 6 x 32
 constexpr int FFNP_NQ1_MIN_BLOCKS = 256;   // timelines from this many blocks on run the first conv with FFNP_NQ1 tiles per wave
 constexpr int FFNP_MIN_BLOCKS = 128;       // shorter timelines stay on the tile GEMM (a wave tile runs the whole k loop: 288 k-steps
                                            // of the second conv take 80 us however few rows there are)
@@ -29,10 +30,10 @@ static inline bool ffnp_supports(int A, int units, int taps1, int taps2) {
 }
 static inline size_t ffnp_plane_bytes(int nblk, int CH) { return (size_t)(nblk + 2) * CH * 128; }
 
-// Pack kn [3 * Cin][N] (tap-major rows, gemm.hip pk_conv_to_kn) for column tiles of 32 nq channels:
-//   [column tile][k-step = kq * 3 + tap][part hi | lo][q nq][lane 64][8]   scaled by 2^kw (returned)
+// Pack kn [taps * Cin][N] (tap-major rows, gemm.hip pk_conv_to_kn) for column tiles of 32 nq channels:
+//   [column tile][k-step = kq * taps + tap][part hi | lo][q nq][lane 64][8]   scaled by 2^kw (returned)
 // appended to w16 at a 16-byte boundary; returns the offset in halves.
-size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>& w16, int& kw);
+size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>& w16, int& kw, int taps = FFNP_TAPS);
 struct FfnpConv {
     const uint16_t* w;     // packed weights: first conv for FFNP_NQ1 tiles per wave, second conv for FFNP_NQ2
     const uint16_t* w4;    // first conv: the same weights packed for FFNP_NQ2 tiles per wave (short timelines), or NULL
@@ -52,6 +53,8 @@ struct FfnpConv {
     int ldx;
 };
 int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a);
+// Linear layer (one tap; weights packed with taps = 1 for FFNP_NQL tiles per wave): x[row][:] = in . W + bias, every row
+int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a);
 
 // LayerNorm (eps) of rows of C channels -> planes + block maxima; gap rows -> 0
 int ffnp_layernorm_launch(pk_ctx* ctx, const float* x, const float* g, const float* b, const int* row_utt, int nblk, int C,

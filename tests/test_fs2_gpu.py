@@ -144,7 +144,7 @@ def test_fs2_split_math_is_scale_invariant(kf, kv, kq):
 
 
 def _planes_env(monkeypatch, variant):
-    """Run norm2 + the feed-forward convs on the planes kernels (csrc/ffn_planes.hip) whatever the timeline length; variant:
+    """Run norm1 + q|k|v and norm2 + the feed-forward convs on the planes kernels (csrc/ffn_planes.hip) whatever the timeline length; variant:
     PK_FFNP_VARIANT (first digit 8 / 4: 256 / 128 columns per wave in the first conv, second digit: waves per workgroup of
     the second), '' = the launcher's own choice."""
     monkeypatch.setenv("PK_FS2_FFN_PLANES", "1")
@@ -170,8 +170,8 @@ def test_fs2_ffn_planes_kernels(monkeypatch, variant):
         names = set(ctx.prof_dump().keys())
     finally:
         ctx.prof_enable(False)
-    assert {"fs2_layernorm_planes", "fs2_conv_ffn1_planes", "fs2_conv_ffn2_planes"} <= names, names
-    assert not any(n.startswith("fs2_conv_ffn") and "planes" not in n for n in names), names
+    assert {"fs2_layernorm_planes", "fs2_gemm_qkv_planes", "fs2_conv_ffn1_planes", "fs2_conv_ffn2_planes"} <= names, names
+    assert not any(n.startswith(("fs2_conv_ffn", "fs2_gemm_qkv")) and "planes" not in n for n in names), names
 
 
 def test_fs2_ffn_planes_long_utterance(monkeypatch):
