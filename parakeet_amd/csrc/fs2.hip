@@ -485,8 +485,10 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
 //   Kf[ks][part][lane]   A fragments of S^T = K . Q^T : 8 halves = K[key = lane&31][16*ks + 8*(lane>>5) + e]
 //   Vf[s2][dt][part][lane] B fragments of O = P . V   : 8 halves = V[key(8*s2 + e, lane>>5)][32*dt + (lane&31)]
 // The next tile's global loads are issued before the current tile's MFMAs (registers), stored after them.
+// PIPE: two sets of fragment buffers -- tile t + 1 is split and stored while tile t is being multiplied (its VALU work fills
+// the MFMA shadow instead of standing between two barriers), one barrier per tile instead of two.
 constexpr int ATT_THREADS = 256;
-template <int DK>
+template <int DK, bool PIPE = false>
 __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a) {
     constexpr int KS = DK / 16;
     constexpr int DT = DK / 32;
@@ -496,8 +498,9 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
     // 65 slots per 64-lane fragment block: neighbouring loader threads write different k-steps of the same key, i.e.
     // blocks 2 KB apart -- the same banks without the pad (PMC r01: 48 % of this kernel's LDS cycles were conflicts)
     constexpr int KP = 65;
-    __shared__ __attribute__((aligned(16))) at_f16x8 Kf[KS * 2 * KP];
-    __shared__ __attribute__((aligned(16))) at_f16x8 Vf[2 * DT * 2 * 64];
+    constexpr int KSZ = KS * 2 * KP, VSZ = 2 * DT * 2 * 64, NB = PIPE ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) at_f16x8 Kf[NB * KSZ];
+    __shared__ __attribute__((aligned(16))) at_f16x8 Vf[NB * VSZ];
     const int b = blockIdx.z, h = blockIdx.y;
     const int len = a.seg_len[b], start = a.seg_start[b];
     if ((int)blockIdx.x * (NT / 2) >= len) return;    // uniform over the workgroup
@@ -549,7 +552,9 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
                 vreg[g][e] = vp[(long)min(k0 + mfma_row(8 * s2 + e, fl >> 5), len - 1) * ld];
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        at_f16x8* kf = Kf + buf * KSZ;
+        at_f16x8* vf = Vf + buf * VSZ;
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             const int idx = tid + NT * g;
@@ -558,8 +563,8 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
             at_f16x8 fh, fl_;
             at_split8s(kreg[g], sc.sk, fh, fl_);
             const int ks = grp >> 1, fl = key + 32 * (grp & 1);
-            Kf[(ks * 2 + 0) * KP + fl] = fh;
-            Kf[(ks * 2 + 1) * KP + fl] = fl_;
+            kf[(ks * 2 + 0) * KP + fl] = fh;
+            kf[(ks * 2 + 1) * KP + fl] = fl_;
         }
 #pragma unroll
         for (int g = 0; g < VG; ++g) {
@@ -568,23 +573,35 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
             const int fl = idx & 63, dt = (idx >> 6) % DT, s2 = idx / (64 * DT);
             at_f16x8 fh, fl_;
             at_split8s(vreg[g], sc.sv, fh, fl_);
-            Vf[((s2 * DT + dt) * 2 + 0) * 64 + fl] = fh;
-            Vf[((s2 * DT + dt) * 2 + 1) * 64 + fl] = fl_;
+            vf[((s2 * DT + dt) * 2 + 0) * 64 + fl] = fh;
+            vf[((s2 * DT + dt) * 2 + 1) * 64 + fl] = fl_;
         }
     };
 
     load_tile(0);
-    for (int k0 = 0; k0 < len; k0 += 32) {
-        __syncthreads();          // every wave is done with the previous tile's fragments
-        store_tile();
-        __syncthreads();
-        if (k0 + 32 < len) load_tile(k0 + 32);
+    if (PIPE) {
+        store_tile(0);
+        load_tile(32);   // (rows are clamped to the utterance: a tile beyond its end is loaded and stored, never multiplied)
+    }
+    for (int k0 = 0, it = 0; k0 < len; k0 += 32, ++it) {
+        const int cur = PIPE ? (it & 1) : 0;
+        __syncthreads();          // every wave is done with the previous tile's fragments (PIPE: and sees this tile's)
+        if (PIPE) {
+            store_tile(cur ^ 1);
+            load_tile(k0 + 64);
+        } else {
+            store_tile(0);
+            __syncthreads();
+            if (k0 + 32 < len) load_tile(k0 + 32);
+        }
+        const at_f16x8* kf = Kf + cur * KSZ;
+        const at_f16x8* vf = Vf + cur * VSZ;
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            S = at_mfma3(Kf[(ks * 2 + 0) * KP + lane], Kf[(ks * 2 + 1) * KP + lane], qh[ks], ql[ks], S);
+            S = at_mfma3(kf[(ks * 2 + 0) * KP + lane], kf[(ks * 2 + 1) * KP + lane], qh[ks], ql[ks], S);
         float mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -619,8 +636,8 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a)
             at_split8(pv, ph, pl);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                O[dt] = at_mfma3(ph, pl, Vf[((s2 * DT + dt) * 2 + 0) * 64 + lane],
-                                 Vf[((s2 * DT + dt) * 2 + 1) * 64 + lane], O[dt]);
+                O[dt] = at_mfma3(ph, pl, vf[((s2 * DT + dt) * 2 + 0) * 64 + lane],
+                                 vf[((s2 * DT + dt) * 2 + 1) * 64 + lane], O[dt]);
         }
     }
     if (q0 >= len) return;
@@ -1389,6 +1406,12 @@ int pk_fft_run_attention(pk_fft_core* h, const Timeline& tl, const float* qkv, f
     dim3 grid(pk_div_up(maxlen, 128), heads, tl.B);
     if (h->math == PK_GEMM_MATH_F16X3 && h->attn_lds) {
         dim3 g2(pk_div_up(maxlen, ATT_THREADS / 2), heads, tl.B);
+        // (measured, 32 x 640 frames: 180 -> 170 us per decoder launch; PK_FS2_ATTN_PIPE=0: the two-barrier loop)
+        static const bool pipe = !(getenv("PK_FS2_ATTN_PIPE") && getenv("PK_FS2_ATTN_PIPE")[0] == '0');
+        if (pipe && dk == 192) {
+            PK_LAUNCH(h->ctx, "fs2_attention_h3", (k_attention_h3_lds<192, true>), g2, dim3(ATT_THREADS), 0, a);
+            return PK_OK;
+        }
         switch (dk) {
             case 64: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3_lds<64>, g2, dim3(ATT_THREADS), 0, a); break;
             case 96: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3_lds<96>, g2, dim3(ATT_THREADS), 0, a); break;
