@@ -18,6 +18,7 @@ head -c 600 $OUT/bench.json; echo
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_stats.csv" | while read f; do cp $f $OUT/bench_kernel_stats.csv; done
 rm -rf $OUT/stats
+[ "${2:-}" = nopmc ] && { ls -la $OUT; exit 0; }   # (kernels of the PMC passes unchanged since the last full call)
 # ---- PMC: Parallel WaveGAN layer kernel (three passes) -> pwg_layer_traffic.json
 pmc() { timeout 240 rocprofv3 --pmc $3 --kernel-trace --output-format csv -d $OUT/pmc_$1 -o p -- python $R/tools/pmc_run.py $2 > $OUT/pmc_$1.log 2>&1; }
 pmc pA "pwg 32" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
