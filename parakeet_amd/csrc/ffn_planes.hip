@@ -12,15 +12,17 @@
 // the kernel that produced it --, only the weights go through LDS (three 48 KB slabs, requested two slabs ahead), and the
 // k loop is unrolled completely so that the operand ring is registers.
 //
-//   k_ffn_ln_planes          LayerNorm of 32 rows -> planes + the block's maximum                                      (norm2)
+//   k_ffn_ln_planes          LayerNorm of 32 rows -> planes + every row's maximum                                      (norm2)
 //   k_ffn_planes<NQ, 24, 0>  relu(conv(planes) + b) -> planes of the hidden activations, scaled by a magnitude BOUND  (w_1)
 //   k_ffn_planes<4, 96, 1>   x += conv(hidden planes) + b on the fp32 residual stream                                 (w_2)
-// The hidden activations' scale cannot be their maximum (a block's 1536 channels are produced by several workgroups): it is
+// The hidden activations' scale cannot be their maximum (a row's 1536 channels are produced by several workgroups): it is
 // the bound c1 max|norm2 output| + c0 of pk_fft_dense (pk_fft.h), as on the tile-GEMM path.
 //
 // k order: k-step = kq * 3 + tap (the three taps of 16 input channels are consecutive: their loads hit the same lines one
-// row apart).  Per-tap rescale: a wave tile is one block; tap -1 leaves it in lane 0, tap +1 in lane 31 -- those lanes take
-// the neighbouring block's scale.
+// row apart).  Scales are per ROW (its maximum as fp32 bits in a side array): a lane's three taps are three rows, brought
+// to the largest of their three scales by a per-lane power-of-two multiply; the lane's accumulators -- all of them belong to
+// its own row -- carry that scale to the epilogue.  Nothing a row's result depends on lies outside its utterance, so results
+// do not depend on the batch an utterance is in.
 //
 // Measured (MI355X, 32 utterances: encoder 4 224 rows, decoder 20 544 rows; per launch, rocprofv3): decoder
 // w_1 313 -> 188 us, w_2 234 -> 195 us; encoder w_1 103 -> 50 us, w_2 48 -> 80 us; norm2 + bounds 24 -> 21 us.  The matrix
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
     static_assert(SLAB_CH % KCH == 0 && nks % SLAB == 0 && nks > RING && G >= 3, "shape");
     __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];
     __shared__ __attribute__((aligned(16))) float lb[32 * NQ];   // this column tile's bias in lane order [hh][q][r]
+    __shared__ float lbs[NQ];                                    // 2^-kw of its NQ 32-column groups (ffnp_pack)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
     // blockIdx -> (row group, column tile): the column tiles of a row group on one XCD
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         const int h2 = i / (16 * NQ), q = (i / 16) % NQ, r = i % 16;
         lb[i] = a.c.bias ? a.c.bias[ct * (32 * NQ) + 32 * q + mfma_row(r, h2)] : 0.f;
     }
+    if (tid < NQ) lbs[tid] = a.c.wscale[ct * NQ + tid];
     const f16x8* wt = reinterpret_cast<const f16x8*>(a.c.w) + (long)ct * ((long)G * SLAB_CH) + tid;
     const int blk = rg * a.active + wave;
     const bool tile_ok = wave < a.active && blk < a.c.nblk;
@@ -132,7 +136,9 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         const int p = blk * FFNP_BLK + j;
         const int rv = a.c.row_utt[p];
         // the maxima of the three blocks the taps read (lanes 0..2; the others repeat lane 0's)
-        const unsigned m_raw = a.c.in_amax[blk - 1 + (lane < 3 ? lane : 0)];
+        // the maxima of the rows this lane's taps read (its own row's output depends on nothing else: every row keeps its own
+        // scale through the whole kernel, so a result does not depend on which utterances share the batch)
+        const unsigned am0 = a.c.in_amax[p - 1], am1 = a.c.in_amax[p], am2 = a.c.in_amax[p + 1];
         // this lane's operand of tap t = its 8 channels (octet 2 kq + hh) of row p + t - 1: byte offset from block blk - 1
         const char* inb = reinterpret_cast<const char*>(a.c.in) + ((long)blk - 1) * a.in_blk;
         unsigned off[FFNP_TAPS];
@@ -164,15 +170,13 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         }
         // common scale of the tile: the largest of the three block maxima; per tap and lane the power of two that brings the
         // block the lane reads to it
-        const unsigned am0 = __builtin_amdgcn_readlane(m_raw, 0), am1 = __builtin_amdgcn_readlane(m_raw, 1),
-                       am2 = __builtin_amdgcn_readlane(m_raw, 2);
         const int e0 = amax_exp(am0), e1 = amax_exp(am1), e2 = amax_exp(am2);
         const int ex = TAPS == 1 ? e1 : max(e0, max(e1, e2));
         const int kx = PK_BLK_TOP + 127 - ex;
         unsigned fu[FFNP_TAPS];
-        fu[0] = pow2_neg_h2(ex - (j == 0 ? e0 : e1));
+        fu[0] = pow2_neg_h2(ex - e0);
         fu[1] = pow2_neg_h2(ex - e1);
-        fu[2] = pow2_neg_h2(ex - (j == 31 ? e2 : e1));
+        fu[2] = pow2_neg_h2(ex - e2);
         f32x16 acc[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
 #pragma unroll
             for (int kk = 0; kk < SLAB; ++kk) {
                 const int ks = SLAB * g + kk, slot = ks % RING;
-                const f16x8 f = h8_of(fu[TAPS == 1 ? 1 : ks % TAPS]);   // (one tap: 2^0, the block's own scale)
+                const f16x8 f = h8_of(fu[TAPS == 1 ? 1 : ks % TAPS]);   // (one tap: 2^0, the row's own scale)
                 f16x8 bh, bl;
                 if (TIGHT) {
                     rhi[slot] *= f;
@@ -247,10 +251,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                 }
             __syncthreads();   // everyone is done reading this slab's buffer and sees the next two
         }
-        const float inv = pow2f(-(kx + a.c.kw));
+        const float pinv = pow2f(-kx);   // x the weights' 2^-kw of the accumulator tile (lbs[q])
         const f32x4* lb4 = reinterpret_cast<const f32x4*>(lb) + hh * (NQ * 4);
         if (EPI == 0) {
-            // relu(. + b) -> the hidden planes, scaled by the bound of this block's rows (gap rows: 0)
+            // relu(. + b) -> the hidden planes, scaled by the bound of this lane's row (gap rows: 0, their bound too)
             const float m3 = fmaxf(__uint_as_float(am0), fmaxf(__uint_as_float(am1), __uint_as_float(am2)));
             const float hb = fmaf(m3, a.c.c1, a.c.c0);
             const float so = pow2f(blk_scale_exp(__float_as_uint(hb)));
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                         const f32x4 b4 = lb4[q * 4 + 2 * m + i];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float t = fmaxf(fmaf(acc[q][8 * m + 4 * i + e], inv, b4[e]), 0.f);
+                            const float t = fmaxf(fmaf(acc[q][8 * m + 4 * i + e], pinv * lbs[q], b4[e]), 0.f);
                             v[4 * i + e] = row_ok ? t : 0.f;
                         }
                     }
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                     st_h8(dst + (2 * q + m) * 2048, oh);
                     st_h8(dst + (2 * q + m) * 2048 + LO_OFF, ol);
                 }
-            if (ct == 0 && lane == 0) a.c.out_amax[blk] = __float_as_uint(hb);
+            if (ct == 0 && hh == 0) a.c.out_amax[p] = row_ok ? __float_as_uint(hb) : 0u;
         } else if (EPI == 2) {
             // y = . + b (fp32 row-major): lane (j, hh) holds row p, channels 32 q + 8 i + 4 hh + (0..3) of the column tile
             float* yr = a.c.x + (long)p * a.c.ldx + ct * (32 * NQ) + 4 * hh;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                     const f32x4 b4 = lb4[q * 4 + i];
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[q][4 * i + e], inv, b4[e]);
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[q][4 * i + e], pinv * lbs[q], b4[e]);
                     *reinterpret_cast<f32x4*>(yr + 32 * q + 8 * i) = o;
                 }
         } else {
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                     const f32x4 b4 = lb4[q * 4 + i];
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = old[q][i][e] + fmaf(acc[q][4 * i + e], inv, b4[e]);
+                    for (int e = 0; e < 4; ++e) o[e] = old[q][i][e] + fmaf(acc[q][4 * i + e], pinv * lbs[q], b4[e]);
                     if ((ABL & 4) && o[0] != 12345.f) continue;
                     *reinterpret_cast<f32x4*>(xr + 32 * q + 8 * i) = o;
                 }
@@ -331,11 +335,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
 }
 
 // LayerNorm -> planes: one workgroup of four waves per block, a wave per row (eight rows each), lane o < C / 8 holds the 8
-// channels of octet o.  The block's maximum decides the scale of all 32 rows, so the rows stay in registers until it is known.
+// channels of octet o.  Every row is stored with the scale of its own maximum.
 __global__ __launch_bounds__(256) void k_ffn_ln_planes(const float* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, const int* __restrict__ row_utt, int C,
                                                       float eps, char* __restrict__ out, unsigned* __restrict__ out_amax) {
-    __shared__ float red[4];
     const int blk = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int noct = C >> 3;
     const bool on = lane < noct;
@@ -348,59 +351,68 @@ __global__ __launch_bounds__(256) void k_ffn_ln_planes(const float* __restrict__
         ba = *reinterpret_cast<const f32x4*>(b + c0);
         bb = *reinterpret_cast<const f32x4*>(b + c0 + 8);
     }
-    float v[8][8];
-    float am = 0.f;
     const float rc = 1.f / (float)C;
+    char* dst = out + (long)blk * ((long)C * 128) + lane * 1024 + (wave * 8) * ROW_B;
+    // all eight rows' loads first (one round trip), then row by row
+    f32x4 xa[8], xb[8];
+    float rmax[8];
+    bool ok[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = blk * FFNP_BLK + wave * 8 + i;
-        const bool ok = row_utt[r] >= 0;   // wave-uniform
-        f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
-        if (ok && on) {
-            xa = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0);
-            xb = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0 + 8);
+        ok[i] = row_utt[r] >= 0;   // wave-uniform
+        xa[i] = xb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[i] && on) {
+            xa[i] = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0);
+            xb[i] = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0 + 8);
         }
-        float s = (xa[0] + xa[1]) + (xa[2] + xa[3]) + ((xb[0] + xb[1]) + (xb[2] + xb[3]));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = blk * FFNP_BLK + wave * 8 + i;
+        float s = (xa[i][0] + xa[i][1]) + (xa[i][2] + xa[i][3]) + ((xb[i][0] + xb[i][1]) + (xb[i][2] + xb[i][3]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float mean = s * rc;
         float q = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            xa[e] -= mean;
-            xb[e] -= mean;
-            q += xa[e] * xa[e] + xb[e] * xb[e];
+            xa[i][e] -= mean;
+            xb[i][e] -= mean;
+            q += xa[i][e] * xa[i][e] + xb[i][e] * xb[i][e];
         }
         if (!on) q = 0.f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
         const float inv = 1.0f / sqrtf(q * rc + eps);
+        float am = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float ya = ok && on ? xa[e] * inv * ga[e] + ba[e] : 0.f;
-            const float yb = ok && on ? xb[e] * inv * gb[e] + bb[e] : 0.f;
-            v[i][e] = ya;
-            v[i][4 + e] = yb;
-            am = fmaxf(am, fmaxf(fabsf(ya), fabsf(yb)));
+            xa[i][e] = ok[i] && on ? xa[i][e] * inv * ga[e] + ba[e] : 0.f;
+            xb[i][e] = ok[i] && on ? xb[i][e] * inv * gb[e] + bb[e] : 0.f;
+            am = fmaxf(am, fmaxf(fabsf(xa[i][e]), fabsf(xb[i][e])));
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+        rmax[i] = am;
     }
+    // the stores of a lane's eight rows together: 8 x 16 bytes of one plane are one 128-byte line
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
-    if (lane == 0) red[wave] = am;
-    __syncthreads();
-    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float s = pow2f(blk_scale_exp(__float_as_uint(am)));
-    if (on) {
-        char* dst = out + (long)blk * ((long)C * 128) + lane * 1024 + (wave * 8) * ROW_B;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i) {
+        if (on) {
+            const float v[8] = {xa[i][0], xa[i][1], xa[i][2], xa[i][3], xb[i][0], xb[i][1], xb[i][2], xb[i][3]};
             f16x8 oh, ol;
-            store_pair8(v[i], s, oh, ol);
+            store_pair8(v, pow2f(blk_scale_exp(__float_as_uint(rmax[i]))), oh, ol);
             st_h8(dst + i * ROW_B, oh);
             st_h8(dst + i * ROW_B + LO_OFF, ol);
         }
     }
-    if (threadIdx.x == 0) out_amax[blk] = __float_as_uint(am);
+    if (lane < 8) {
+        float m = rmax[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) m = lane == i ? rmax[i] : m;
+        out_amax[blk * FFNP_BLK + wave * 8 + lane] = __float_as_uint(m);
+    }
 }
 
 inline uint16_t f32_to_f16_rne(float f) {
@@ -443,9 +455,21 @@ inline float f16_to_f32(uint16_t h) {
 }
 }  // namespace
 
-size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>& w16, int& kw, int taps) {
+size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>& w16, std::vector<float>& wscale, int taps) {
     const int KQ = Cin / 16, nks = taps * KQ, nct = N / (32 * nq);
-    kw = pk_weight_scale_exp(kn, (size_t)taps * Cin * N);
+    // one exponent per 32 output channels -- whatever the tile width, so that every packing of a layer holds the same numbers
+    std::vector<int> kw(N / 32);
+    wscale.resize(N / 32);
+    for (int g = 0; g < N / 32; ++g) {
+        float m = 0.f;
+        for (size_t k = 0; k < (size_t)taps * Cin; ++k)
+            for (int c = 0; c < 32; ++c) {
+                const float v = std::fabs(kn[k * N + 32 * g + c]);
+                if (std::isfinite(v) && v > m) m = v;
+            }
+        kw[g] = pk_weight_scale_exp(&m, 1);
+        wscale[g] = std::ldexp(1.0f, -kw[g]);
+    }
     w16.resize((w16.size() + 7) & ~(size_t)7);
     const size_t off = w16.size();
     w16.resize(off + (size_t)nct * nks * 2 * nq * 64 * 8, 0);
@@ -460,7 +484,7 @@ size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>&
                         const int i = lane & 31, hh = lane >> 5;
                         const int co = ct * 32 * nq + 32 * q + i;
                         const int ci = 16 * kq + 8 * (e >> 2) + 4 * hh + (e & 3);   // wfl_chan(kq, hh, e)
-                        const float w = std::ldexp(kn[((size_t)tap * Cin + ci) * N + co], kw);
+                        const float w = std::ldexp(kn[((size_t)tap * Cin + ci) * N + co], kw[co / 32]);
                         const uint16_t h = f32_to_f16_rne(w);
                         base[((size_t)(0 * nq + q) * 64 + lane) * 8 + e] = h;
                         base[((size_t)(1 * nq + q) * 64 + lane) * 8 + e] = f32_to_f16_rne(w - f16_to_f32(h));
@@ -471,7 +495,7 @@ size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>&
 
 int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     const bool first = c.out != nullptr;
-    if (!(first ? (c.Cin == 384 && c.N % (32 * FFNP_NQ1) == 0) : (c.Cin == 1536 && c.N % (32 * FFNP_NQ2) == 0)) || c.nblk <= 0 || !c.w)
+    if (!(first ? (c.Cin == 384 && c.N % (32 * FFNP_NQ1) == 0) : (c.Cin == 1536 && c.N % (32 * FFNP_NQ2) == 0)) || c.nblk <= 0 || !c.w || !c.wscale)
         PK_FAIL(PK_EINVAL, "ffnp_conv_launch: shape (Cin %d, N %d) not built", c.Cin, c.N);
     // First conv: 256 columns per wave in 8-wave workgroups (decoder-sized timelines: half the operand traffic per MFMA), or
     // 128 columns per wave in 4-wave workgroups, two per CU (short timelines: four times the workgroups).  Second conv: 128
@@ -517,7 +541,7 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
 }
 
 int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
-    if (c.Cin != 384 || c.N % (32 * FFNP_NQL) != 0 || c.nblk <= 0 || !c.w || !c.x)
+    if (c.Cin != 384 || c.N % (32 * FFNP_NQL) != 0 || c.nblk <= 0 || !c.w || !c.wscale || !c.x)
         PK_FAIL(PK_EINVAL, "ffnp_linear_launch: shape (Cin %d, N %d) not built", c.Cin, c.N);
     Args a;
     a.c = c;

@@ -323,19 +323,12 @@ struct QkvBoundC {
 };
 __global__ __launch_bounds__(256) void k_fs2_seg_bounds(const float* __restrict__ ham, const int* __restrict__ seg_start,
                                                         const int* __restrict__ seg_len, int heads, QkvBoundC c,
-                                                        unsigned* __restrict__ segb, float* __restrict__ ctx_bound,
-                                                        int per_block) {
-    // per_block: ham holds one maximum per 32-row block (the planes LayerNorm, pk_ffn_planes.h) -- the blocks an utterance
-    // touches may hold a neighbour's rows too: a bound all the same
+                                                        unsigned* __restrict__ segb, float* __restrict__ ctx_bound) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const int start = seg_start[b], len = seg_len[b];
     float m = 0.f;
-    if (per_block) {
-        for (int r = (start >> 5) + threadIdx.x; r <= ((start + len - 1) >> 5) && len > 0; r += 256) m = fmaxf(m, ham[r]);
-    } else {
-        for (int r = threadIdx.x; r < len; r += 256) m = fmaxf(m, ham[start + r]);
-    }
+    for (int r = threadIdx.x; r < len; r += 256) m = fmaxf(m, ham[start + r]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -1071,8 +1064,10 @@ int pk_fft_add_conv(Arena& ar, const pk_param_map& P, const std::string& base, i
     if (bias) PK_TRY(pk_get_vector(P, base + ".bias", Cout, b));
     PK_TRY(pk_fft_add_dense_kn(ar, kn, bias ? &b : nullptr, Cin, k, Cout, d));
     if (planes && ar.v16 && k == FFNP_TAPS) {
-        d.wp = ffnp_pack(kn.data(), Cin, Cout, planes == 1 ? FFNP_NQ1 : FFNP_NQ2, *ar.v16, d.kwp);
-        if (planes == 1) d.wp4 = ffnp_pack(kn.data(), Cin, Cout, FFNP_NQ2, *ar.v16, d.kwp);
+        std::vector<float> ws;
+        d.wp = ffnp_pack(kn.data(), Cin, Cout, planes == 1 ? FFNP_NQ1 : FFNP_NQ2, *ar.v16, ws);
+        if (planes == 1) d.wp4 = ffnp_pack(kn.data(), Cin, Cout, FFNP_NQ2, *ar.v16, ws);   // (the same scales: per 32 channels)
+        d.wps = ar.put(ws);
     }
     return PK_OK;
 }
@@ -1157,7 +1152,11 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
         }
         PK_TRY(pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 3 * A, L.qkv));
         if (planes && !concat_after && ar.v16 && (3 * A) % (32 * FFNP_NQL) == 0)
-            L.qkv.wp = ffnp_pack(kn.data(), A, 3 * A, FFNP_NQL, *ar.v16, L.qkv.kwp, 1);
+        {
+            std::vector<float> ws;
+            L.qkv.wp = ffnp_pack(kn.data(), A, 3 * A, FFNP_NQL, *ar.v16, ws, 1);
+            L.qkv.wps = ar.put(ws);
+        }
         for (int part = 0; part < 3; ++part)
             for (int hd = 0; hd < heads && hd < FS2_MAX_HEADS; ++hd)
                 dense_bound(kn, &bias, A, 3 * A, part * A + hd * (A / heads), part * A + (hd + 1) * (A / heads),
@@ -1542,17 +1541,17 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             PK_TRY(pb[i]->reserve(ffnp_plane_bytes(nblk, pc[i])));
             if (pb[i]->p != p0) PK_HIP(hipMemsetAsync(pb[i]->p, 0, pb[i]->cap, h->ctx->stream));
         }
-        PK_TRY(h->d_pam.reserve((size_t)2 * (nblk + 2) * sizeof(unsigned)));
-        PK_HIP(hipMemsetAsync(h->d_pam.p, 0, (size_t)2 * (nblk + 2) * sizeof(unsigned), h->ctx->stream));
+        PK_TRY(h->d_pam.reserve((size_t)2 * (tl.rows_alloc + 2) * sizeof(unsigned)));
+        PK_HIP(hipMemsetAsync(h->d_pam.p, 0, (size_t)2 * (tl.rows_alloc + 2) * sizeof(unsigned), h->ctx->stream));
         hp = h->d_hp.as<char>() + (size_t)A * 128;
         fp = h->d_fp.as<char>() + (size_t)units * 128;
-        hpam = h->d_pam.as<unsigned>() + 1;
-        fpam = hpam + nblk + 2;
+        hpam = h->d_pam.as<unsigned>() + 1;   // row maxima (fp32 bits), one element of margin on either side
+        fpam = hpam + tl.rows_alloc + 2;
     }
     for (const FftLayer& L : layers) {
         const bool qkv_planes = planes && bounds && !L.concat && L.qkv.wp != (size_t)-1;
         if (qkv_planes) {
-            // norm1 -> planes, the fused q | k | v projection on them; the segment bounds from the block maxima
+            // norm1 -> planes, the fused q | k | v projection on them; the segment bounds from the row maxima it leaves
             PK_TRY(ffnp_layernorm_launch(h->ctx, x, h->W(L.ln1_g), h->W(L.ln1_b), rv, nblk, A, 1e-5f, hp, hpam));
             FfnpConv c;
             memset(&c, 0, sizeof(c));
@@ -1560,7 +1559,7 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             c.row_utt = rv;
             c.w = h->arena16.as<uint16_t>() + L.qkv.wp;
             c.bias = L.qkv.b == (size_t)-1 ? nullptr : h->W(L.qkv.b);
-            c.kw = L.qkv.kwp; c.Cin = A; c.N = 3 * A;
+            c.wscale = h->W(L.qkv.wps); c.Cin = A; c.N = 3 * A;
             c.in = hp; c.in_amax = hpam;
             c.x = qkv; c.ldx = 3 * A;
             PK_TRY(ffnp_linear_launch(h->ctx, "fs2_gemm_qkv_planes", c));
@@ -1574,7 +1573,7 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             memcpy(qc.c0, L.qkv_c0, sizeof(qc.c0));
             PK_LAUNCH(h->ctx, "fs2_bounds", k_fs2_seg_bounds, dim3(tl.B), dim3(256), 0,
                       qkv_planes ? reinterpret_cast<const float*>(hpam) : ham, tl.d_seg_start(), tl.d_seg_len(), heads, qc, segb,
-                      cbnd, qkv_planes ? 1 : 0);
+                      cbnd);
         }
         PK_TRY(pk_fft_run_attention(h, tl, qkv, ctxb, segb));
         if (L.concat) {
@@ -1595,14 +1594,14 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             c.w = h->arena16.as<uint16_t>() + L.ffn1.wp;
             c.w4 = L.ffn1.wp4 == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + L.ffn1.wp4;
             c.bias = L.ffn1.b == (size_t)-1 ? nullptr : h->W(L.ffn1.b);
-            c.kw = L.ffn1.kwp; c.Cin = A; c.N = units;
+            c.wscale = h->W(L.ffn1.wps); c.Cin = A; c.N = units;
             c.in = hp; c.in_amax = hpam;
             c.out = fp; c.out_amax = fpam; c.c1 = L.ffn1.c1; c.c0 = L.ffn1.c0;
             PK_TRY(ffnp_conv_launch(h->ctx, "fs2_conv_ffn1_planes", c));
             c.w = h->arena16.as<uint16_t>() + L.ffn2.wp;
             c.w4 = nullptr;
             c.bias = L.ffn2.b == (size_t)-1 ? nullptr : h->W(L.ffn2.b);
-            c.kw = L.ffn2.kwp; c.Cin = units; c.N = A;
+            c.wscale = h->W(L.ffn2.wps); c.Cin = units; c.N = A;
             c.in = fp; c.in_amax = fpam;
             c.out = nullptr; c.out_amax = nullptr;
             c.x = x; c.ldx = A;

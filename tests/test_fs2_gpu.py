@@ -157,9 +157,9 @@ def _planes_env(monkeypatch, variant):
 
 @pytest.mark.parametrize("variant", ["", "88", "44"])
 def test_fs2_ffn_planes_kernels(monkeypatch, variant):
-    """By default only timelines of >= 4096 rows take the planes kernels (the bench-shape tests); here the ragged batch of
-    test_fs2_ljspeech_ragged_batch runs them (gaps, 1-token utterances, tiles that straddle utterances, idle waves) and
-    must meet the same bars, internal taps included."""
+    """The ragged batch of test_fs2_ljspeech_ragged_batch (gaps, 1-token utterances, tiles that straddle utterances, idle
+    waves) under each first-conv / second-conv kernel variant: the same bars, internal taps included, and the profile shows
+    that the planes kernels are what ran."""
     from parakeet_amd.runtime import Context
     _planes_env(monkeypatch, variant)
     ctx = Context.get()
@@ -172,6 +172,31 @@ def test_fs2_ffn_planes_kernels(monkeypatch, variant):
         ctx.prof_enable(False)
     assert {"fs2_layernorm_planes", "fs2_gemm_qkv_planes", "fs2_conv_ffn1_planes", "fs2_conv_ffn2_planes"} <= names, names
     assert not any(n.startswith(("fs2_conv_ffn", "fs2_gemm_qkv")) and "planes" not in n for n in names), names
+
+
+def test_fs2_batch_composition_invariance(monkeypatch):
+    """An utterance's mel does not depend on the batch it is in, bit for bit -- alone, in a ragged batch, in the reversed
+    batch -- nor on which of the first-conv kernels runs (PK_FFNP_VARIANT: they differ in tiling only).  The planes
+    kernels keep one scale per ROW for this (a per-block scale would couple neighbouring utterances)."""
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    monkeypatch.delenv("PK_FFNP_VARIANT", raising=False)
+    monkeypatch.delenv("PK_FS2_FFN_PLANES_MIN_BLOCKS", raising=False)
+    cfg = _cfg()
+    model = FastSpeech2(80, 80, **cfg)
+    model.set_state_dict(syn.fastspeech2_state(80, 80, cfg, seed=150))
+    model.eval()
+    texts = [syn.phoneme_ids(T, 80, seed=151 + i) for i, T in enumerate([37, 5, 64, 1, 23])]
+    ref = [o.as_subclass(torch.Tensor).clone() for o in model.inference_batch(texts)]
+    rev = model.inference_batch(texts[::-1])
+    for b in range(len(texts)):
+        assert torch.equal(ref[b], rev[len(texts) - 1 - b].as_subclass(torch.Tensor)), b
+    solo = model.inference_batch([texts[2]])[0].as_subclass(torch.Tensor)
+    assert torch.equal(ref[2], solo)
+    for variant in ("88", "44"):
+        monkeypatch.setenv("PK_FFNP_VARIANT", variant)
+        out = model.inference_batch(texts)
+        for b in range(len(texts)):
+            assert torch.equal(ref[b], out[b].as_subclass(torch.Tensor)), (variant, b)
 
 
 def test_fs2_ffn_planes_long_utterance(monkeypatch):

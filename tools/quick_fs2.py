@@ -3,7 +3,7 @@ import time, numpy as np, torch
 from parakeet_amd import synthetic as syn
 from parakeet_amd.fastspeech2 import FastSpeech2
 from parakeet_amd.runtime import Context
-B, T = 32, 128
+B, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 32), 128
 m = FastSpeech2(80, 80, **syn.FS2_LJSPEECH); m.set_state_dict(syn.fastspeech2_state(fixed_duration=5)); m.eval()
 texts = [syn.phoneme_ids(T, seed=i) for i in range(B)]
 ctx = Context.get()
