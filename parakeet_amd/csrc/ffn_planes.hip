@@ -357,15 +357,21 @@ __global__ __launch_bounds__(256) void k_ffn_ln_planes(const float* __restrict__
     f32x4 xa[8], xb[8];
     float rmax[8];
     bool ok[8];
+    // (unconditional: a branch on a loaded value serialises the round trips; lanes beyond the row and gap rows read memory that
+    // exists -- the activation buffers end in PK_FFT_LEAD rows of margin -- and are masked afterwards)
+    int ru[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ru[i] = row_utt[blk * FFNP_BLK + wave * 8 + i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = blk * FFNP_BLK + wave * 8 + i;
-        ok[i] = row_utt[r] >= 0;   // wave-uniform
-        xa[i] = xb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok[i] && on) {
-            xa[i] = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0);
-            xb[i] = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0 + 8);
-        }
+        xa[i] = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0);
+        xb[i] = *reinterpret_cast<const f32x4*>(x + (long)r * C + c0 + 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ok[i] = ru[i] >= 0;   // wave-uniform
+        if (!(ok[i] && on)) xa[i] = xb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
