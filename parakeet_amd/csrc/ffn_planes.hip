@@ -47,6 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
 namespace {
 // an octet's 1 KB of a block: [plane hi | lo][row 32][8 halves] -- a half wave's operand load of one k-step is 512 contiguous
@@ -65,6 +66,21 @@ struct Args {
 __host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// in-register split of 8 values (wf_layer.hip): hi = v_cvt_pkrtz (round toward zero), x - hi exactly by v_fma_mix_f32, lo = fp16_rne(x - hi)
+__device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const pkh2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        float l0, l1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hu), "v"(v[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hu), "v"(v[2 * p + 1]));
+        hi[2 * p] = (_Float16)h[0];
+        hi[2 * p + 1] = (_Float16)h[1];
+        lo[2 * p] = (_Float16)l0;
+        lo[2 * p + 1] = (_Float16)l1;
+    }
 }
 // the stored pair of an activation: hi = fp16_rne(s x), lo = fp16_rne(s x - hi) (wf_layer.hip)
 __device__ __forceinline__ void store_pair8(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
@@ -102,7 +118,10 @@ __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x
 // ABL (profiling only, PK_FFNP_ABLATE, results are wrong when set): 1 = the operand ring is not refilled after the prologue,
 // 4 = no epilogue loads / stores, 8 = the weight slabs are not reloaded after the prologue (barriers stay), 128 = weight
 // slabs loaded but not written to LDS, 256 = written (stale registers) but not loaded; sums combine
-template <int NQ, int KQ, int EPI, int W, int TAPS = FFNP_TAPS, int ABL = 0>
+// BF32 (one tap only): the B operand is a row-major fp32 matrix (in, ldin floats per row) with a magnitude bound per row in
+// in_amax; it is scaled and split in registers, once per column tile that reads it (the attention output, whose producer
+// holds a channel x 16 queries per lane -- the transpose of a planes vector)
+template <int NQ, int KQ, int EPI, int W, int TAPS = FFNP_TAPS, int ABL = 0, bool BF32 = false>
 __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
     constexpr int THREADS = 64 * W;
     constexpr int SLAB_CH = CPT * THREADS;    // 16-byte chunks per slab buffer
@@ -113,6 +132,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
     constexpr int RING = NQ >= 6 ? 6 : 9;     // operand ring depth in k-steps (wf_layer.hip Shape::RING)
     constexpr bool TIGHT = NQ == 8;
     static_assert(SLAB_CH % KCH == 0 && nks % SLAB == 0 && nks > RING && G >= 3, "shape");
+    static_assert(!BF32 || (TAPS == 1 && !TIGHT), "fp32 operand: one tap, the untight loop");
     __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];
     __shared__ __attribute__((aligned(16))) float lb[32 * NQ];   // this column tile's bias in lane order [hh][q][r]
     __shared__ float lbs[NQ];                                    // 2^-kw of its NQ 32-column groups (ffnp_pack)
@@ -150,6 +170,12 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         f16x8 rhi[RING], rlo[RING];
         auto load_b = [&](int ks) {
             const int kq = ks / TAPS, tap = TAPS == 1 ? 1 : ks % TAPS, slot = ks % RING;
+            if (BF32) {   // channels 16 kq + 4 hh + (0..3) and + 8: wfl_chan(kq, hh, 0..7)
+                const float* src = reinterpret_cast<const float*>(a.c.in) + (long)p * a.c.ldin + 16 * kq + 4 * hh;
+                rhi[slot] = ld_h8(reinterpret_cast<const char*>(src));
+                rlo[slot] = ld_h8(reinterpret_cast<const char*>(src + 8));
+                return;
+            }
             const char* src = inb + (off[tap] + (unsigned)(kq * 2048));
             rhi[slot] = ld_h8(src);
             rlo[slot] = ld_h8(src + LO_OFF);
@@ -173,6 +199,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         const int e0 = amax_exp(am0), e1 = amax_exp(am1), e2 = amax_exp(am2);
         const int ex = TAPS == 1 ? e1 : max(e0, max(e1, e2));
         const int kx = PK_BLK_TOP + 127 - ex;
+        const float sx = pow2f(kx);   // (fp32 operand: applied before the split)
         unsigned fu[FFNP_TAPS];
         fu[0] = pow2_neg_h2(ex - e0);
         fu[1] = pow2_neg_h2(ex - e1);
@@ -204,8 +231,19 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                     rhi[slot] *= f;
                     rlo[slot] *= f;
                 } else {
-                    bh = TAPS == 1 ? rhi[slot] : rhi[slot] * f;
-                    bl = TAPS == 1 ? rlo[slot] : rlo[slot] * f;
+                    if (BF32) {
+                        const f32x4 v0 = __builtin_bit_cast(f32x4, rhi[slot]), v1 = __builtin_bit_cast(f32x4, rlo[slot]);
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = rv >= 0 ? v0[e] * sx : 0.f;        // (gap rows of that buffer are never written)
+                            v[4 + e] = rv >= 0 ? v1[e] * sx : 0.f;
+                        }
+                        split8(v, bh, bl);
+                    } else {
+                        bh = TAPS == 1 ? rhi[slot] : rhi[slot] * f;
+                        bl = TAPS == 1 ? rlo[slot] : rlo[slot] * f;
+                    }
                     __builtin_amdgcn_sched_barrier(0);   // the slot's old value is dead before its refill is requested
                     if (!(ABL & 1) && ks + RING < nks) load_b(ks + RING);
                 }
@@ -547,11 +585,12 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
 }
 
 int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
-    if (c.Cin != 384 || c.N % (32 * FFNP_NQL) != 0 || c.nblk <= 0 || !c.w || !c.wscale || !c.x)
+    const int nq = c.ldin ? FFNP_NQ2 : FFNP_NQL;
+    if (c.Cin != 384 || c.N % (32 * nq) != 0 || c.nblk <= 0 || !c.w || !c.wscale || !c.x)
         PK_FAIL(PK_EINVAL, "ffnp_linear_launch: shape (Cin %d, N %d) not built", c.Cin, c.N);
     Args a;
     a.c = c;
-    a.nct = c.N / (32 * FFNP_NQL);
+    a.nct = c.N / (32 * nq);
     a.in_blk = (long)c.Cin * 128;
     a.out_blk = 0;
     int active = 8;
@@ -563,6 +602,7 @@ int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
         PK_LAUNCH(ctx, prof_name, kern, dim3(grid), dim3(512), 0, a);
         return PK_OK;
     };
+    if (c.ldin) return go(k_ffn_planes<FFNP_NQ2, 24, 1, 8, 1, 0, true>);   // fp32 operand, x += . + b
     return go(k_ffn_planes<FFNP_NQL, 24, 2, 8, 1>);
 }
 

@@ -1165,6 +1165,11 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
         PK_TRY(pk_get_weight(P, p + ".self_attn.linear_out", {A, A}, wo));
         PK_TRY(pk_get_vector(P, p + ".self_attn.linear_out.bias", A, bo));
         PK_TRY(pk_fft_add_dense_kn(ar, wo, &bo, A, 1, A, L.out));
+        if (planes && !concat_after && ar.v16 && A % (32 * FFNP_NQ2) == 0) {
+            std::vector<float> ws;
+            L.out.wp = ffnp_pack(wo.data(), A, A, FFNP_NQ2, *ar.v16, ws, 1);
+            L.out.wps = ar.put(ws);
+        }
         L.concat = concat_after;
         if (concat_after) {
             // concat_linear: Linear(2A -> A) on cat(x, attention output) = x . W[:A] + att . W[A:] + b (encoder_layer.py:103-106)
@@ -1583,6 +1588,20 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, t, A, tl.rows, PK_ACT_NONE, nullptr, 0, nullptr, cbnd));
             PK_TRY(pk_fft_run_dense(h, "fs2_gemm_concat_x", L.cat_x, hh, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, ham));
             PK_TRY(pk_fft_run_dense(h, "fs2_gemm_concat_a", L.cat_a, t, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr));
+        } else if (qkv_planes && L.out.wp != (size_t)-1) {
+            // x += attention output . W_out + b on the planes kernel, its operand the fp32 rows the attention kernel wrote
+            // (split in registers with the row bound |ctx| <= max|v| as scale)
+            FfnpConv c;
+            memset(&c, 0, sizeof(c));
+            c.nblk = nblk;
+            c.row_utt = rv;
+            c.w = h->arena16.as<uint16_t>() + L.out.wp;
+            c.wscale = h->W(L.out.wps);
+            c.bias = L.out.b == (size_t)-1 ? nullptr : h->W(L.out.b);
+            c.Cin = A; c.N = A;
+            c.in = ctxb; c.ldin = A; c.in_amax = reinterpret_cast<const unsigned*>(cbnd);
+            c.x = x; c.ldx = A;
+            PK_TRY(ffnp_linear_launch(h->ctx, "fs2_gemm_attn_out_planes", c));
         } else
         PK_TRY(pk_fft_run_dense(h, "fs2_gemm_attn_out", L.out, ctxb, A, x, A, tl.rows, PK_ACT_NONE, x, A, nullptr, cbnd));
         if (planes) {

@@ -45,7 +45,8 @@ struct FfnpConv {
     const float* bias;     // [N] or NULL
     const float* wscale;   // [N / 32] 2^-kw of the packed weights' 32-channel groups
     int Cin, N;
-    const void* in;        // input planes, block 0
+    const void* in;        // input planes, block 0 (ffnp_linear_launch with ldin != 0: a row-major fp32 matrix)
+    int ldin;              // 0, or floats per row of the fp32 input
     const unsigned* in_amax;   // row maxima of the input (fp32 bits), element 0 = row 0
     int nblk;              // blocks of the timeline (rows_alloc / 32)
     const int* row_utt;    // [32 nblk], < 0: gap row
@@ -59,7 +60,9 @@ struct FfnpConv {
     int ldx;
 };
 int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a);
-// Linear layer (one tap; weights packed with taps = 1 for FFNP_NQL tiles per wave): x[row][:] = in . W + bias, every row
+// Linear layer (one tap).  ldin == 0: planes in, weights packed for FFNP_NQL tiles per wave, x[row][:] = in . W + bias.
+// ldin != 0: fp32 rows in (in_amax = a magnitude bound per row, gap rows of `in` are not read), weights packed for FFNP_NQ2
+// tiles per wave, x[row][:] += in . W + bias.
 int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a);
 
 // LayerNorm (eps) of rows of C channels -> planes + row maxima; gap rows -> 0

@@ -170,8 +170,9 @@ def test_fs2_ffn_planes_kernels(monkeypatch, variant):
         names = set(ctx.prof_dump().keys())
     finally:
         ctx.prof_enable(False)
-    assert {"fs2_layernorm_planes", "fs2_gemm_qkv_planes", "fs2_conv_ffn1_planes", "fs2_conv_ffn2_planes"} <= names, names
-    assert not any(n.startswith(("fs2_conv_ffn", "fs2_gemm_qkv")) and "planes" not in n for n in names), names
+    assert {"fs2_layernorm_planes", "fs2_gemm_qkv_planes", "fs2_gemm_attn_out_planes", "fs2_conv_ffn1_planes",
+            "fs2_conv_ffn2_planes"} <= names, names
+    assert not any(n.startswith(("fs2_conv_ffn", "fs2_gemm_qkv", "fs2_gemm_attn_out")) and "planes" not in n for n in names), names
 
 
 def test_fs2_batch_composition_invariance(monkeypatch):
