@@ -481,11 +481,14 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
 // PIPE: two sets of fragment buffers -- tile t + 1 is split and stored while tile t is being multiplied (its VALU work fills
 // the MFMA shadow instead of standing between two barriers), one barrier per tile instead of two.
 constexpr int ATT_THREADS = 256;
-template <int DK, bool PIPE = false>
-__global__ __launch_bounds__(ATT_THREADS, 1) void k_attention_h3_lds(AttnArgs a) {
+// NTHR: 64 x (query tiles per workgroup).  With the two buffer sets one workgroup fits a CU, so the launch runs in rounds of
+// n_cu workgroups: the launcher picks 4 or 8 query tiles per workgroup (640-frame utterances, 32 x 2 (utterance, head)
+// pairs: 4 tiles -> 320 workgroups = two rounds on 256 CUs, 8 tiles -> 192 = one).
+template <int DK, bool PIPE = false, int NTHR = ATT_THREADS>
+__global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
     constexpr int KS = DK / 16;
     constexpr int DT = DK / 32;
-    constexpr int NT = ATT_THREADS;
+    constexpr int NT = NTHR;
     constexpr int KG = (32 * (DK / 8) + NT - 1) / NT;      // 8-float groups of the K tile per thread (3 for DK = 192)
     constexpr int VG = (2 * DT * 64 + NT - 1) / NT;        // V fragment lanes per thread (3 for DK = 192)
     // 65 slots per 64-lane fragment block: neighbouring loader threads write different k-steps of the same key, i.e.
@@ -1413,8 +1416,21 @@ int pk_fft_run_attention(pk_fft_core* h, const Timeline& tl, const float* qkv, f
         // (measured, 32 x 640 frames: 180 -> 170 us per decoder launch; PK_FS2_ATTN_PIPE=0: the two-barrier loop)
         static const bool pipe = !(getenv("PK_FS2_ATTN_PIPE") && getenv("PK_FS2_ATTN_PIPE")[0] == '0');
         if (pipe && dk == 192) {
-            PK_LAUNCH(h->ctx, "fs2_attention_h3", (k_attention_h3_lds<192, true>), g2, dim3(ATT_THREADS), 0, a);
-            return PK_OK;
+            // query tiles per workgroup: 4, or 8 where that saves rounds of n_cu workgroups.  Measured per decoder launch (32 x 2
+            // pairs of 20 query tiles): 4 tiles 171 us (320 workgroups, two rounds), 5: 148, 6: 138, 8: 132 (192 workgroups);
+            // from 5 waves on the kernel has 256 registers instead of 512 and spills 17-34 of them, a workgroup alone takes
+            // 1.55 x as long -- the encoder's 4-tile utterances stay with 4 (24 vs 30 us).
+            static const int wenv = getenv("PK_FS2_ATTN_WAVES") ? atoi(getenv("PK_FS2_ATTN_WAVES")) : 0;   // measurement switch
+            const long r4 = pk_div_up((long)pk_div_up(maxlen, 128) * heads * tl.B, h->ctx->n_cu);
+            const long r8 = pk_div_up((long)pk_div_up(maxlen, 256) * heads * tl.B, h->ctx->n_cu);
+            int best = 100 * r4 <= 155 * r8 ? 4 : 8;
+            if (wenv == 4 || wenv == 8) best = wenv;
+            const dim3 gw(pk_div_up(maxlen, 32 * best), heads, tl.B);
+            auto go = [&](auto kern) -> int {
+                PK_LAUNCH(h->ctx, "fs2_attention_h3", kern, gw, dim3(64 * best), 0, a);
+                return PK_OK;
+            };
+            return best == 8 ? go(k_attention_h3_lds<192, true, 512>) : go(k_attention_h3_lds<192, true, 256>);
         }
         switch (dk) {
             case 64: PK_LAUNCH(h->ctx, "fs2_attention_h3", k_attention_h3_lds<64>, g2, dim3(ATT_THREADS), 0, a); break;
