@@ -24,16 +24,17 @@
 // its own row -- carry that scale to the epilogue.  Nothing a row's result depends on lies outside its utterance, so results
 // do not depend on the batch an utterance is in.
 //
-// Measured (MI355X, 32 utterances: encoder 4 224 rows, decoder 20 544 rows; per launch, rocprofv3): decoder
-// w_1 313 -> 188 us, w_2 234 -> 195 us; encoder w_1 103 -> 50 us, w_2 48 -> 80 us; norm2 + bounds 24 -> 21 us.  The matrix
-// pipe is 49 % busy in the decoder launches (tile GEMM: 29-35 %); a third of the wave cycles wait for global loads.
-// Tried and measured without effect on that (PK_FFNP_ABLATE / variants since removed): 4-wave workgroups two per CU for
-// w_2, 96 / 192 columns per wave with each XCD working on its own column tiles (weights L2-resident: 10-25 % slower, every
-// XCD then reads all activations), the weight slabs' LDS writes spread over the k-steps instead of bunched at the slab
-// end, A fragments three column tiles ahead, non-temporal operand loads (10 % slower).  With the weight slabs neither
-// loaded nor written (PK_FFNP_ABLATE=8) w_2 takes 139 us, loaded but not written 163, written but not loaded 171, with
-// no operand traffic either 139: what is left of the gap to the matrix-pipe time (100 us at the 2.2 GHz the counters show)
-// is LDS reads, barriers and issue.
+// Measured (MI355X, 32 utterances: encoder 4 224 rows, decoder 20 544 rows; per launch, rocprofv3; DESIGN.md 4.3,
+// profiles/r03_fs2_planes_timings.txt): decoder w_1 320 -> 190 us, w_2 244 -> 195 us, q|k|v 108 -> 64 us, attention-out 76 ->
+// 35 us; encoder w_1 103 -> 52 us, w_2 48 -> 81 us; norm + bounds 24 -> 19 us.  The matrix pipe is 49-56 % busy in the
+// decoder launches (tile GEMM: 29-35 %); a third of the wave cycles wait for global loads.
+// Tried and measured without effect on that (variants since removed): 4-wave workgroups two per CU for w_2, 96 / 192
+// columns per wave with each XCD working on its own column tiles (weights L2-resident: 10-25 % slower, every XCD then
+// reads all activations), the weight slabs' LDS writes spread over the k-steps instead of bunched at the slab end, A
+// fragments three column tiles ahead, non-temporal operand loads (10 % slower).  With the weight slabs neither loaded nor
+// written (PK_FFNP_ABLATE=8 with PK_FFNP_VARIANT=84) w_2 takes 139 us of 205, loaded but not written 163, written but not
+// loaded 171, with no operand traffic either 139: what is left of the gap to the matrix-pipe time (95 us at the 2.2 GHz
+// the counters show) is LDS reads, barriers and issue.
 #include "pk_ffn_planes.h"
 
 #include <algorithm>
