@@ -635,7 +635,8 @@ __device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& h
 // HALF = false: bf16 parts (8 significant bits each, fp32 range); HALF = true: fp16 parts (11 bits each,
 // 22 bits per operand ~ fp32's 24) of block-scaled operands (see "block scaling" above: no subnormal parts, no
 // dependence on the magnitude of weights or activations; |x| beyond 2^113 aside).
-// ABL (profiling only, PK_PWG_ABLATE=1): 1 = no global loads / stores of x and skip (compute-only time)
+// ABL (profiling only, PK_PWG_ABLATE, results are wrong): 1 = no global loads / stores of x and skip (compute-only time);
+// 2 = the x taps go to the MFMA as loaded, without the hi / lo split (what storing x pre-split would save)
 template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
     typedef typename Split16<HALF>::vec bf16x8;     // shadows the bf16 typedef inside this kernel
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     // round 1 paid that twice per tile: tile_t0 at the top of the tile, tile_cls in prefetch_head)
     auto load_amax = [&](int t0, int wt) -> unsigned {
         const long tt0 = (long)(t0 & ~255) + (wt & 7) * WAVE_T;
-        return ABL ? 0x3f800000u : a.xe_in[(tt0 >> 5) + eoff];
+        return (ABL & 1) ? 0x3f800000u : a.xe_in[(tt0 >> 5) + eoff];
     };
     auto tile_scale_exp = [&](unsigned ev) -> int {   // wave-uniform (SGPR) exponent k of the tile's x scale 2^k
         unsigned m = (unsigned)__builtin_amdgcn_readlane((int)ev, 0);
@@ -751,10 +752,14 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         for (int g = 0; g < B3_RING; ++g) {
             const unsigned vo = vo8n[g % 3];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ring[g][e] = ABL ? (float)(lane + e) * 1e-3f : (a.xin + group_row(g, e) * XBLK)[vo];
+            for (int e = 0; e < 8; ++e) ring[g][e] = (ABL & 1) ? (float)(lane + e) * 1e-3f : (a.xin + group_row(g, e) * XBLK)[vo];
         }
         if constexpr (HALF) {
             kx = tile_scale_exp(load_amax(t0c, my_slot));
+            if constexpr ((ABL & 2) != 0) {   // what pre-split storage of x would leave: no arithmetic between the load and the MFMA
+                ph = __builtin_bit_cast(bf16x8, f32x4{ring[0][0], ring[0][1], ring[0][2], ring[0][3]});
+                pl = __builtin_bit_cast(bf16x8, f32x4{ring[0][4], ring[0][5], ring[0][6], ring[0][7]});
+            } else
             split_x8s(ring[0], pow2f(kx), ph, pl);
         } else {
             split_x8<bf16x8, elem16, HALF>(ring[0], ph, pl);
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 const unsigned vo = gn < B3_KS1 ? vo8[gt % 3] : vo8n[gt % 3];
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    ring[g % B3_RING][e] = ABL ? (float)(lane + e + g) * 1e-3f : (a.xin + group_row(gt, e) * XBLK)[vo];
+                    ring[g % B3_RING][e] = (ABL & 1) ? (float)(lane + e + g) * 1e-3f : (a.xin + group_row(gt, e) * XBLK)[vo];
             }
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 nh, nl;
@@ -847,6 +852,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 if constexpr (HALF) {
                     if (g == B3_KS1 - 2) kx_next = tile_scale_exp(ev_next);
                     // group 0 of the NEXT tile is split under the last k-step of this one: its own scale
+                    if constexpr ((ABL & 2) != 0) {
+                        const float(&rr)[8] = ring[(g + 1) % B3_RING];
+                        nh = __builtin_bit_cast(bf16x8, f32x4{rr[0], rr[1], rr[2], rr[3]});
+                        nl = __builtin_bit_cast(bf16x8, f32x4{rr[4], rr[5], rr[6], rr[7]});
+                    } else
                     split_x8s(ring[(g + 1) % B3_RING], g + 1 < B3_KS1 ? sx : pow2f(kx_next), nh, nl);
                 } else {
                     split_x8<bf16x8, elem16, HALF>(ring[(g + 1) % B3_RING], nh, nl);
@@ -939,7 +949,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            sk_old[16 * qq + r] = ABL ? 0.5f : (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4];
+                            sk_old[16 * qq + r] = (ABL & 1) ? 0.5f : (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4];
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // W2 fragments of the next (pass, ks, q) in issue order
@@ -990,12 +1000,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                         else v = FIRST ? acc2[q][r] : (sk_old[16 * q + r] + acc2[q][r]);
                         if (GEN && pass == 0 && !lane_valid) v = 0.f;
                     }
-                    if (!ABL || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
+                    if (!(ABL & 1) || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                 }
             if constexpr (HALF) {
                 if (pass == 0) {   // max|x_out| of this 64 x 32 block for the next layer's operand scale
                     am = wave_max64(am);
-                    if (lane == 0 && (!ABL || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
+                    if (lane == 0 && (!(ABL & 1) || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
                 }
             }
         }
@@ -1823,6 +1833,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 } else if (half) {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true>), dim3(grid), blk, 0, a);
                     else if (h->dbg == 1) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 1>), dim3(grid), blk, 0, a);
+                    else if (h->dbg == 32) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 2>), dim3(grid), blk, 0, a);
                     else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true>), dim3(grid), blk, 0, a);
                 } else {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<true, false>), dim3(grid), blk, 0, a);
