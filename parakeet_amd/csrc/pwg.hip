@@ -67,6 +67,8 @@ constexpr int P_LEAD = 8;                     // margin rows around the frame-ra
 constexpr int XBLK = 32;                       // samples per block
 constexpr int XBLK_FLOATS = R * XBLK;          // 2048 floats = 8 KB
 __host__ __device__ inline long xoff(long t) { return (t >> 5) * XBLK_FLOATS + (t & 31); }   // + ch * 32
+typedef _Float16 pl_f16x8 __attribute__((ext_vector_type(8)));   // one vector of the planes layout (k_pwg_layer_b3<..., PL>)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // Row of the 32x32 MFMA result held in accumulator register r of a lane whose
 // (lane >> 5) is hi.  (cdna guide: row = (r&3) + 8*(r>>2) + 4*hi, col = lane&31)
@@ -151,7 +153,9 @@ __device__ __forceinline__ PwgGenCoord gen_coord(const PwgGen& g, int tile, int 
 }
 
 // first_conv: Conv1D(1 -> R, k=1, bias) (:401-402,464) from packed noise into the timeline.
-template <bool GEN>
+// PL: x is written as pre-split fp16 planes (see k_pwg_layer_b3<..., PL>): per 32-sample block [octet 8][sample 32][hi 8 | lo 8]
+// halves, scaled by the block's own power of two (pk_split.h) -- the same 8 KB per block, the same 4 bytes per value.
+template <bool GEN, bool PL = false>
 __global__ void k_pwg_first(const float* __restrict__ noise, const float* __restrict__ w,
                             const float* __restrict__ bias, const int* __restrict__ tile_t0, long Ttot,
                             float* __restrict__ x, unsigned* __restrict__ xe, PwgGen g) {
@@ -170,11 +174,16 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
     (void)Ttot;
     const long xo = xoff(t);
     float am = 0.f;
+    if constexpr (PL) {
 #pragma unroll 8
-    for (int c = 0; c < R; ++c) {
-        const float v = valid ? fmaf(w[c], n, bias[c]) : 0.f;
-        am = fmaxf(am, fabsf(v));
-        x[xo + c * XBLK] = v;
+        for (int c = 0; c < R; ++c) am = fmaxf(am, valid ? fabsf(fmaf(w[c], n, bias[c])) : 0.f);
+    } else {
+#pragma unroll 8
+        for (int c = 0; c < R; ++c) {
+            const float v = valid ? fmaf(w[c], n, bias[c]) : 0.f;
+            am = fmaxf(am, fabsf(v));
+            x[xo + c * XBLK] = v;
+        }
     }
     // max|x| per 32-sample block for the first layer's operand scale (see "block scaling")
     am = fmaxf(am, __shfl_xor(am, 16));
@@ -183,6 +192,24 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
     am = fmaxf(am, __shfl_xor(am, 2));
     am = fmaxf(am, __shfl_xor(am, 1));
     if ((threadIdx.x & 31) == 0) xe[t >> 5] = __float_as_uint(am);
+    if constexpr (PL) {
+        const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
+        char* dst = reinterpret_cast<char*>(x) + (t >> 5) * (long)(XBLK_FLOATS * 4) + (t & 31) * 32;
+#pragma unroll
+        for (int o = 0; o < R / 8; ++o) {   // octet o = 2 cg + hh holds channels 16 cg + 8 (e >> 2) + 4 hh + (e & 3)
+            pl_f16x8 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 16 * (o >> 1) + 8 * (e >> 2) + 4 * (o & 1) + (e & 3);
+                const float tv = (valid ? fmaf(w[c], n, bias[c]) : 0.f) * so;
+                const _Float16 hv = (_Float16)tv;
+                oh[e] = hv;
+                ol[e] = (_Float16)(tv - (float)hv);
+            }
+            *reinterpret_cast<pl_f16x8*>(dst + o * 1024) = oh;
+            *reinterpret_cast<pl_f16x8*>(dst + o * 1024 + 16) = ol;
+        }
+    }
 }
 
 // Test tap: the sample-rate aux contribution of one layer, aux[co][s] =
@@ -637,8 +664,14 @@ __device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& h
 // dependence on the magnitude of weights or activations; |x| beyond 2^113 aside).
 // ABL (profiling only, PK_PWG_ABLATE, results are wrong): 1 = no global loads / stores of x and skip (compute-only time);
 // 2 = the x taps go to the MFMA as loaded, without the hi / lo split (what storing x pre-split would save)
-template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false>
+// PL (HALF only): x lives in HBM as pre-split fp16 planes -- per 32-sample block [octet 8][sample 32][hi 8 | lo 8] halves (the
+// same 8 KB), each block scaled by the power of two of its own max|x| (xe[]), written so by the producer's epilogue.  An
+// operand group is then two 16-byte loads and one v_pk_mul_f16 per register (the power of two that brings the tap's block to
+// the tile's common scale) instead of eight dword loads and the scale-and-split arithmetic -- which, 290 of the tile's 1 400
+// vector instructions, stood on the load -> split -> MFMA path of every k-step: 20 % of the kernel (PK_PWG_ABLATE=32).
+template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false, bool PL = false>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
+    static_assert(!PL || (HALF && ABL == 0), "planes: the block-scaled split-fp16 path only");
     typedef typename Split16<HALF>::vec bf16x8;     // shadows the bf16 typedef inside this kernel
     typedef typename Split16<HALF>::elem elem16;
     __shared__ __attribute__((aligned(16))) float lds[GEN ? LDS_TOTAL_GEN : LDS_TOTAL];
@@ -696,7 +729,37 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         m = m > m4 ? m : m4;
         return blk_scale_exp(m);
     };
+    // PL: the fp16 powers of two (twice in a register, wave-uniform: scalar integer arithmetic only, so that they live in SGPRs)
+    // that bring the five blocks a tile's taps can touch from their own scale to the tile's; xs = sqrt(0.5) / (the tile's
+    // own block scale), for the residual input.  Which of two blocks a lane's sample of tap -1 / +1 lies in depends on the
+    // lane and the dilation only (lm0, lm2).
+    auto tap_factors = [&](unsigned ev, unsigned (&fs)[5], float& xs) {
+        int e[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int ee = (int)((unsigned)__builtin_amdgcn_readlane((int)ev, k) >> 23);
+            e[k] = ee < PK_EXP_MIN ? PK_EXP_MIN : (ee > PK_EXP_MAX ? PK_EXP_MAX : ee);
+        }
+        const int emax = max(max(max(e[0], e[1]), max(e[3], e[4])), e[2]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int dd = emax - e[k];   // 2^-dd as fp16 bits: normal down to 2^-14, subnormal to 2^-24, then 0
+            const unsigned hb = dd <= 14 ? (unsigned)(15 - dd) << 10 : (dd <= 24 ? 1u << (24 - dd) : 0u);
+            fs[k] = hb | (hb << 16);
+        }
+        xs = __uint_as_float(0x3f3504f3u - ((unsigned)(PK_BLK_TOP + 127 - e[2]) << 23));   // sqrt(0.5) * 2^-k, k in [-60, 53]
+    };
+    const bool lm0 = ((j - d) >> 5) == -((d + 31) >> 5), lm2 = ((j + d) >> 5) == ((d + 31) >> 5);
+    auto tap_f = [&](const unsigned (&fs)[5], int tap) -> unsigned {
+        return tap == 0 ? (lm0 ? fs[0] : fs[1]) : (tap == 1 ? fs[2] : (lm2 ? fs[4] : fs[3]));
+    };
+    auto h8_of = [](unsigned u) -> pl_f16x8 {
+        const u32x4_t v = {u, u, u, u};
+        return __builtin_bit_cast(pl_f16x8, v);
+    };
     int kx = 0, kx_next = 0;   // x-scale exponents of the current / the next wave tile
+    unsigned fu[5] = {0, 0, 0, 0, 0}, fun[5] = {0, 0, 0, 0, 0};   // PL: block factors of the current / the next wave tile
+    float xs_cur = 0.f, xs_next = 0.f;
 
     // operand group g of a wave-tile = k-step g = (channel group cg = g/3, tap = g%3).  Element e of lane
     // (j, hi) is input channel 32*(cg>>1) + mfma_row(8*(cg&1) + e, hi) -- the SAME channel the lane owns as
@@ -711,7 +774,30 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         const long tt = (long)(t0 & ~255) + (wt & 7) * WAVE_T + j + (long)(tap - 1) * d;
         return (unsigned)(xoff(tt) + 4 * hi * XBLK);
     };
-    float ring[B3_RING][8];
+    // PL: byte offset of the lane's (hi, lo) vectors of k-group 0 in the planes (+ 2048 per k-group)
+    auto lane_off_pl = [&](int t0, int wt, int tap) -> unsigned {
+        const long tt = (long)(t0 & ~255) + (wt & 7) * WAVE_T + j + (long)(tap - 1) * d;
+        return (unsigned)((tt >> 5) * (long)(XBLK_FLOATS * 4) + (tt & 31) * 32 + hi * 1024);
+    };
+    float ring[B3_RING][8];   // PL: the raw (hi | lo) vectors of a group, four registers each
+    auto load_group = [&](float (&dst)[8], int gt, unsigned vo, unsigned pvo) {
+        if constexpr (PL) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.xin) + (pvo + (unsigned)((gt / 3) * 2048)));
+            const f32x4 h4 = src[0], l4 = src[1];
+            dst[0] = h4[0]; dst[1] = h4[1]; dst[2] = h4[2]; dst[3] = h4[3];
+            dst[4] = l4[0]; dst[5] = l4[1]; dst[6] = l4[2]; dst[7] = l4[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = (ABL & 1) ? (float)(lane + e + gt) * 1e-3f : (a.xin + group_row(gt, e) * XBLK)[vo];
+        }
+    };
+    auto planes_operand = [&](const float (&rr)[8], unsigned f2, bf16x8& oh, bf16x8& ol) {   // PL: raw vectors x the tap's factor
+        if constexpr (PL) {
+            const pl_f16x8 fv = h8_of(f2);
+            oh = __builtin_bit_cast(pl_f16x8, f32x4{rr[0], rr[1], rr[2], rr[3]}) * fv;
+            ol = __builtin_bit_cast(pl_f16x8, f32x4{rr[4], rr[5], rr[6], rr[7]}) * fv;
+        }
+    };
     bf16x8 ph, pl;     // split operands of the k-step about to run (produced one step ahead, under the MFMAs)
     f32x4 preg[3];
     float uw[UPW];
@@ -743,18 +829,23 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         uw[4] = wrow[4];
     };
     unsigned vo8n[3] = {0, 0, 0};   // lane offsets of the three taps of the NEXT tile (this tile's at the loop top)
+    unsigned pvo8n[3] = {0, 0, 0};  // PL: the same in the planes
     if (my_slot < n_wtiles) {
         const int t0c = a.tile_t0[my_slot >> 3];
 #pragma unroll
-        for (int tp = 0; tp < 3; ++tp) vo8n[tp] = lane_off(t0c, my_slot, tp);
+        for (int tp = 0; tp < 3; ++tp) {
+            vo8n[tp] = lane_off(t0c, my_slot, tp);
+            if constexpr (PL) pvo8n[tp] = lane_off_pl(t0c, my_slot, tp);
+        }
         prefetch_head(my_slot, __builtin_amdgcn_readfirstlane(t0c & 255));
 #pragma unroll
-        for (int g = 0; g < B3_RING; ++g) {
-            const unsigned vo = vo8n[g % 3];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ring[g][e] = (ABL & 1) ? (float)(lane + e) * 1e-3f : (a.xin + group_row(g, e) * XBLK)[vo];
-        }
-        if constexpr (HALF) {
+        for (int g = 0; g < B3_RING; ++g) load_group(ring[g], g, vo8n[g % 3], pvo8n[g % 3]);
+        if constexpr (PL) {
+            const unsigned ev0 = load_amax(t0c, my_slot);
+            kx = tile_scale_exp(ev0);
+            tap_factors(ev0, fu, xs_cur);
+            planes_operand(ring[0], tap_f(fu, 0), ph, pl);
+        } else if constexpr (HALF) {
             kx = tile_scale_exp(load_amax(t0c, my_slot));
             if constexpr ((ABL & 2) != 0) {   // what pre-split storage of x would leave: no arithmetic between the load and the MFMA
                 ph = __builtin_bit_cast(bf16x8, f32x4{ring[0][0], ring[0][1], ring[0][2], ring[0][3]});
@@ -772,9 +863,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     // hold groups g+1..g+RING-1 (of this tile, continuing into the next one); slot g % RING is free.
     for (int wt = my_slot; wt < n_wtiles; wt += stride_slots) {
         const int next_wt = wt + stride_slots < n_wtiles ? wt + stride_slots : wt;
-        unsigned vo8[3];
+        unsigned vo8[3], pvo8[3];
 #pragma unroll
-        for (int tp = 0; tp < 3; ++tp) vo8[tp] = vo8n[tp];
+        for (int tp = 0; tp < 3; ++tp) {
+            vo8[tp] = vo8n[tp];
+            pvo8[tp] = pvo8n[tp];
+        }
         const int t0n = a.tile_t0[next_wt >> 3];   // requested here, first used at k-step T0_USE of stage 1
         int cls_next = 0;
         const unsigned vo4 = vo8[1];   // centre tap: operand rows and result rows share the lane offset
@@ -833,23 +927,30 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         for (int g = 0; g < B3_KS1; ++g) {
             if (g == T0_USE) {
 #pragma unroll
-                for (int tp = 0; tp < 3; ++tp) vo8n[tp] = lane_off(t0n, next_wt, tp);
+                for (int tp = 0; tp < 3; ++tp) {
+                    vo8n[tp] = lane_off(t0n, next_wt, tp);
+                    if constexpr (PL) pvo8n[tp] = lane_off_pl(t0n, next_wt, tp);
+                }
                 cls_next = __builtin_amdgcn_readfirstlane(t0n & 255);
                 if constexpr (HALF) ev_next = load_amax(t0n, next_wt);
             }
             {
                 const int gn = g + B3_RING;
                 const int gt = gn < B3_KS1 ? gn : gn - B3_KS1;
-                const unsigned vo = gn < B3_KS1 ? vo8[gt % 3] : vo8n[gt % 3];
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    ring[g % B3_RING][e] = (ABL & 1) ? (float)(lane + e + g) * 1e-3f : (a.xin + group_row(gt, e) * XBLK)[vo];
+                load_group(ring[g % B3_RING], gt, gn < B3_KS1 ? vo8[gt % 3] : vo8n[gt % 3], gn < B3_KS1 ? pvo8[gt % 3] : pvo8n[gt % 3]);
             }
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 nh, nl;
             {
                 const int g1 = (g + 1) % B3_KS1;
-                if constexpr (HALF) {
+                if constexpr (PL) {
+                    if (g == B3_KS1 - 2) {
+                        kx_next = tile_scale_exp(ev_next);
+                        tap_factors(ev_next, fun, xs_next);
+                    }
+                    // group 0 of the NEXT tile is prepared under the last k-step of this one: its own factor
+                    planes_operand(ring[(g + 1) % B3_RING], g + 1 < B3_KS1 ? tap_f(fu, (g + 1) % 3) : tap_f(fun, 0), nh, nl);
+                } else if constexpr (HALF) {
                     if (g == B3_KS1 - 2) kx_next = tile_scale_exp(ev_next);
                     // group 0 of the NEXT tile is split under the last k-step of this one: its own scale
                     if constexpr ((ABL & 2) != 0) {
@@ -991,8 +1092,16 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 for (int r = 0; r < 16; ++r) {
                     float v;
                     if constexpr (HALF) {   // acc2 = 2^14 * 2^k2 * (W2 z + b); i0 carries the sqrt(0.5) of :314
-                        if (pass == 0) v = fmaf(acc2[q][r], a.i0, x_old[16 * q + r] * rs);
-                        else v = FIRST ? acc2[q][r] * a.i1 : fmaf(acc2[q][r], a.i1, sk_old[16 * q + r]);
+                        if (pass == 0) {
+                            if constexpr (PL) {   // x_in = (hi + lo) / (its block's scale); x_old holds the raw vectors of the centre taps
+                                const int cg = 2 * q + (r >> 3), e = r & 7;
+                                const pl_f16x8 xh = __builtin_bit_cast(pl_f16x8, f32x4{x_old[8 * cg], x_old[8 * cg + 1], x_old[8 * cg + 2], x_old[8 * cg + 3]});
+                                const pl_f16x8 xl = __builtin_bit_cast(pl_f16x8, f32x4{x_old[8 * cg + 4], x_old[8 * cg + 5], x_old[8 * cg + 6], x_old[8 * cg + 7]});
+                                v = fmaf(acc2[q][r], a.i0, ((float)xh[e] + (float)xl[e]) * xs_cur);
+                            } else {
+                                v = fmaf(acc2[q][r], a.i0, x_old[16 * q + r] * rs);
+                            }
+                        } else v = FIRST ? acc2[q][r] * a.i1 : fmaf(acc2[q][r], a.i1, sk_old[16 * q + r]);
                         if (GEN && pass == 0 && !lane_valid) v = 0.f;   // beyond the utterance: stays zero padding
                         if (pass == 0) am = fmaxf(am, fabsf(v));
                     } else {
@@ -1000,16 +1109,43 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                         else v = FIRST ? acc2[q][r] : (sk_old[16 * q + r] + acc2[q][r]);
                         if (GEN && pass == 0 && !lane_valid) v = 0.f;
                     }
-                    if (!(ABL & 1) || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
+                    if constexpr (PL) {
+                        if (pass == 0) acc2[q][r] = v;   // stored below, once the block's maximum (its scale) is known
+                        else (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
+                    } else {
+                        if (!(ABL & 1) || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
+                    }
                 }
             if constexpr (HALF) {
                 if (pass == 0) {   // max|x_out| of this 64 x 32 block for the next layer's operand scale
                     am = wave_max64(am);
                     if (lane == 0 && (!(ABL & 1) || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
+                    if constexpr (PL) {
+                        const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
+                        char* pd = reinterpret_cast<char*>(a.xout) + pvo8[1];
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) {
+                            pl_f16x8 oh, ol;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float tv = acc2[cg >> 1][8 * (cg & 1) + e] * so;
+                                const _Float16 hv = (_Float16)tv;
+                                oh[e] = hv;
+                                ol[e] = (_Float16)(tv - (float)hv);
+                            }
+                            *reinterpret_cast<pl_f16x8*>(pd + cg * 2048) = oh;
+                            *reinterpret_cast<pl_f16x8*>(pd + cg * 2048 + 16) = ol;
+                        }
+                    }
                 }
             }
         }
         kx = kx_next;
+        if constexpr (PL) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) fu[k] = fun[k];
+            xs_cur = xs_next;
+        }
     }
 }
 
@@ -1183,6 +1319,8 @@ struct pk_pwg {
     int last_ldp = 0;
     size_t last_o_cls = 0;
     int dbg = 0;
+    bool planes_on = false;    // PK_PWG_PLANES: x as pre-split fp16 planes under the split-fp16 math (k_pwg_layer_b3<..., PL>)
+    bool last_planes = false;  // ... and whether the last run used them (debug tap 1 decodes)
     unsigned long long seed = 0, rng_offset = 0;   // internal noise stream (noise == NULL)
     long chunk_samples = 1L << 40;                  // residual-stack chunk (env PK_PWG_CHUNK_SAMPLES); default: one chunk
 };
@@ -1228,6 +1366,7 @@ extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
     h->gap = ((h->max_dilation + TILE - 1) / TILE) * TILE;
     if (h->gap < TILE) h->gap = TILE;
     if (const char* e = getenv("PK_PWG_ABLATE")) h->dbg = atoi(e);   // profiling only: results are wrong when set
+    if (const char* e = getenv("PK_PWG_PLANES")) h->planes_on = e[0] == '1';
     if (const char* e = getenv("PK_PWG_CHUNK_SAMPLES")) h->chunk_samples = std::max(1L, atol(e));
     if (const char* e = getenv("PK_PWG_MATH"))
         h->math = strcmp(e, "bf16x3") == 0 ? PK_PWG_MATH_BF16X3 : (strcmp(e, "f16x3") == 0 ? PK_PWG_MATH_F16X3 : PK_PWG_MATH_F32);
@@ -1755,7 +1894,16 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         PK_TRY(pk_gemm_launch(ctx, "pwg_aux_gemm", g));
     }
     // ---- first conv
-    if (gen)
+    // (planes: lane offsets into x are 32-bit byte offsets)
+    const bool planes = h->planes_on && h->math == PK_PWG_MATH_F16X3 && h->dbg == 0 && (size_t)R * Ttot * 4 < ((size_t)1 << 32);
+    h->last_planes = planes;
+    if (planes && gen)
+        PK_LAUNCH(ctx, "pwg_first", (k_pwg_first<true, true>), dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
+    else if (planes)
+        PK_LAUNCH(ctx, "pwg_first", (k_pwg_first<false, true>), dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
+    else if (gen)
         PK_LAUNCH(ctx, "pwg_first", k_pwg_first<true>, dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
                   h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
     else
@@ -1822,7 +1970,15 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 a.w1 = reinterpret_cast<const float*>((half ? h->d_w1h : h->d_w1b).as<char>() + (size_t)l * B3_W1_BYTES);
                 a.w2 = reinterpret_cast<const float*>((half ? h->d_w2h : h->d_w2b).as<char>() + (size_t)l * B3_W2_BYTES);
                 const dim3 blk(LAYER_WAVES * 64);
-                if (gen) {   // hop != 256: frame / phase per sample (GEN kernels)
+                if (planes) {   // (half) x as pre-split planes
+                    if (gen) {
+                        if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true, true>), dim3(grid), blk, 0, a);
+                        else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true, true>), dim3(grid), blk, 0, a);
+                    } else {
+                        if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, false, true>), dim3(grid), blk, 0, a);
+                        else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, false, true>), dim3(grid), blk, 0, a);
+                    }
+                } else if (gen) {   // hop != 256: frame / phase per sample (GEN kernels)
                     if (half) {
                         if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true>), dim3(grid), blk, 0, a);
                         else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true>), dim3(grid), blk, 0, a);
@@ -1919,6 +2075,25 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
     if (n_floats != (int64_t)rows * S)
         PK_FAIL(PK_ESHAPE, "pk_pwg_debug_read: expected %ld floats, got %lld", rows * S, (long long)n_floats);
     PK_HIP(hipStreamSynchronize(ctx->stream));
+    if (what == 1 && h->last_planes) {
+        // x as planes: whole blocks to the host, decoded there -- (hi + lo) / 2^k of the block's maximum (xe)
+        const long nblk = (S + XBLK - 1) / XBLK, blk0 = h->last_toff[b] / XBLK;
+        std::vector<uint16_t> raw((size_t)nblk * XBLK_FLOATS * 2);
+        std::vector<unsigned> am(nblk);
+        const pk_dbuf& xe = h->last_x_final ? h->ws_xe1 : h->ws_xe0;
+        PK_HIP(hipMemcpy(raw.data(), reinterpret_cast<const char*>(src) + (size_t)blk0 * XBLK_FLOATS * 4, raw.size() * 2, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(am.data(), xe.as<unsigned>() + blk0, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+        for (long bi = 0; bi < nblk; ++bi) {
+            const double inv = std::ldexp(1.0, -blk_scale_exp(am[bi]));
+            for (int ch = 0; ch < R; ++ch)
+                for (int sidx = 0; sidx < XBLK && bi * XBLK + sidx < S; ++sidx) {
+                    const int cg = ch >> 4, w16 = ch & 15, hh = (w16 >> 2) & 1, e = 4 * (w16 >> 3) + (w16 & 3);
+                    const uint16_t* v = raw.data() + (size_t)bi * XBLK_FLOATS * 2 + (size_t)(2 * cg + hh) * 512 + sidx * 16;
+                    host_out[(size_t)ch * S + bi * XBLK + sidx] = (float)(((double)f16_to_f32(v[e]) + (double)f16_to_f32(v[8 + e])) * inv);
+                }
+        }
+        return PK_OK;
+    }
     // blocked layout: channel ch of this utterance = S/32 pieces of 32 floats, one per block (+ a shorter last
     // piece when S is not a multiple of 32, hop != 256)
     for (int ch = 0; ch < rows; ++ch) {

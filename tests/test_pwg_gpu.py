@@ -5,6 +5,7 @@ state-dict keys fed to both implementations, same random inputs) but asserts
 numerically, which the reference's test does not.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -192,7 +193,11 @@ def test_pwg_block_maxima_are_exact():
     for b, L in enumerate(frames):
         x = gen.debug_tap(1, b)                                   # (64, S) final residual stream
         want = np.abs(x).reshape(64, -1, 32).max(axis=(0, 2))
-        np.testing.assert_array_equal(gen.debug_tap(3, b), want)
+        if os.environ.get("PK_PWG_PLANES") == "1":
+            # x is stored as (hi, lo) fp16 pairs at the block's scale: 22 of the maximum's 24 bits come back from the tap
+            np.testing.assert_allclose(gen.debug_tap(3, b), want, rtol=2.0 ** -21, atol=0.0)
+        else:
+            np.testing.assert_array_equal(gen.debug_tap(3, b), want)
 
 
 def test_pwg_split_math_lognormal_weights():
