@@ -154,11 +154,11 @@ __device__ __forceinline__ PwgGenCoord gen_coord(const PwgGen& g, int tile, int 
 
 // first_conv: Conv1D(1 -> R, k=1, bias) (:401-402,464) from packed noise into the timeline.
 // PL: x is written as pre-split fp16 planes (see k_pwg_layer_b3<..., PL>): per 32-sample block [octet 8][sample 32][hi 8 | lo 8]
-// halves, scaled by the block's own power of two (pk_split.h) -- the same 8 KB per block, the same 4 bytes per value.
+// halves at the utterance's a-priori scale 2^tile_kx[tile] -- the same 8 KB per block, the same 4 bytes per value.
 template <bool GEN, bool PL = false>
 __global__ void k_pwg_first(const float* __restrict__ noise, const float* __restrict__ w,
                             const float* __restrict__ bias, const int* __restrict__ tile_t0, long Ttot,
-                            float* __restrict__ x, unsigned* __restrict__ xe, PwgGen g) {
+                            float* __restrict__ x, unsigned* __restrict__ xe, PwgGen g, const int* __restrict__ tile_kx) {
     const int tile = blockIdx.x;
     const long t = (long)(tile_t0[tile] & ~255) + threadIdx.x;   // low bits: the tile's edge class (layer kernels)
     float n;
@@ -174,10 +174,7 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
     (void)Ttot;
     const long xo = xoff(t);
     float am = 0.f;
-    if constexpr (PL) {
-#pragma unroll 8
-        for (int c = 0; c < R; ++c) am = fmaxf(am, valid ? fabsf(fmaf(w[c], n, bias[c])) : 0.f);
-    } else {
+    if constexpr (!PL) {
 #pragma unroll 8
         for (int c = 0; c < R; ++c) {
             const float v = valid ? fmaf(w[c], n, bias[c]) : 0.f;
@@ -191,9 +188,9 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
     am = fmaxf(am, __shfl_xor(am, 4));
     am = fmaxf(am, __shfl_xor(am, 2));
     am = fmaxf(am, __shfl_xor(am, 1));
-    if ((threadIdx.x & 31) == 0) xe[t >> 5] = __float_as_uint(am);
+    if (!PL && (threadIdx.x & 31) == 0) xe[t >> 5] = __float_as_uint(am);
     if constexpr (PL) {
-        const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
+        const float so = pow2f(tile_kx[tile]);
         char* dst = reinterpret_cast<char*>(x) + (t >> 5) * (long)(XBLK_FLOATS * 4) + (t & 31) * 32;
 #pragma unroll
         for (int o = 0; o < R / 8; ++o) {   // octet o = 2 cg + hh holds channels 16 cg + 8 (e >> 2) + 4 hh + (e & 3)
@@ -209,6 +206,34 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
             *reinterpret_cast<pl_f16x8*>(dst + o * 1024) = oh;
             *reinterpret_cast<pl_f16x8*>(dst + o * 1024 + 16) = ol;
         }
+    }
+}
+
+// Planes path: max|noise| per utterance, then per work tile the scale exponents of x for every layer from the magnitude bound
+// B_0 = wmax * max|noise| + bmax, B_(l+1) = (B_l + c_l) * sqrt(0.5) (a hair of slack for the engine's own rounding);
+// tile_kx[l * ntiles + tile] = blk_scale_exp(B_l) (pk_split.h), l = 0 .. layers (the last row: the final x).
+__global__ __launch_bounds__(256) void k_pwg_noise_max(const float* __restrict__ noise, const int* __restrict__ utt_off,
+                                                       const int* __restrict__ utt_S, float* __restrict__ nmax) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* p = noise + utt_off[b];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < utt_S[b]; i += 256) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) nmax[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void k_pwg_tile_scales(const int* __restrict__ tile_utt, int ntiles,
+                                                         const float* __restrict__ nmax, float wmax, float bmax,
+                                                         const float* __restrict__ cl, int layers, int* __restrict__ tile_kx) {
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= ntiles) return;
+    float B = fmaf(wmax, nmax[tile_utt[tile]], bmax) * 1.001f;
+    for (int l = 0; l <= layers; ++l) {
+        tile_kx[(long)l * ntiles + tile] = blk_scale_exp(__float_as_uint(B));
+        if (l < layers) B = (B + cl[l]) * (0.70710678118654752440f * 1.001f);
     }
 }
 
@@ -249,6 +274,8 @@ struct PwgLayerArgs {
     unsigned* xe_out;        // the same for xout, written by this launch
     int k1;                  // W1 fragments hold conv.weight * 2^k1
     float i0, i1;            // sqrt(0.5) / (2^14 * 2^k2out), 1 / (2^14 * 2^k2skip): undo the stage-2 scales
+    const int* tile_kx_in;   // PL: [ntiles] scale exponent of xin / of xout per tile (k_pwg_tile_scales)
+    const int* tile_kx_out;
     PwgGen gen;              // GEN kernels only (hop != 256)
 };
 
@@ -665,10 +692,16 @@ __device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& h
 // ABL (profiling only, PK_PWG_ABLATE, results are wrong): 1 = no global loads / stores of x and skip (compute-only time);
 // 2 = the x taps go to the MFMA as loaded, without the hi / lo split (what storing x pre-split would save)
 // PL (HALF only): x lives in HBM as pre-split fp16 planes -- per 32-sample block [octet 8][sample 32][hi 8 | lo 8] halves (the
-// same 8 KB), each block scaled by the power of two of its own max|x| (xe[]), written so by the producer's epilogue.  An
-// operand group is then two 16-byte loads and one v_pk_mul_f16 per register (the power of two that brings the tap's block to
-// the tile's common scale) instead of eight dword loads and the scale-and-split arithmetic -- which, 290 of the tile's 1 400
-// vector instructions, stood on the load -> split -> MFMA path of every k-step: 20 % of the kernel (PK_PWG_ABLATE=32).
+// same 8 KB) --, written so by the producer's epilogue, and an operand group is two 16-byte loads that go to the MFMAs as they
+// are: no arithmetic between load and MFMA.  (The scale-and-split of the fp32 taps, 290 of the tile's 1 400 vector
+// instructions, stood on the load -> split -> MFMA path of every k-step: 20 % of the kernel, PK_PWG_ABLATE=32.  A first
+// planes version kept the per-block scales and rescaled each tap's vectors to the tile's common scale with v_pk_mul_f16:
+// 1.39 instead of 1.41 ms -- any vector instruction on that path costs about the same.)  That needs ONE scale for everything
+// a tile's taps read, known to the producer BEFORE it has seen its output: the scale of a layer's x is per utterance and
+// a priori, from a magnitude bound B_l -- B_0 = max|w| max|noise| + max|b| (first_conv), B_(l+1) = (B_l + c_l) sqrt(0.5)
+// with c_l = max_co (sum_k |W_out[co][k]| + |b_out[co]|) because |z| < 1 (k_pwg_tile_scales).  The bound overshoots the
+// utterance's maximum by a small factor, i.e. the split's error floor moves from 2^-39 of a 32-sample block's maximum to
+// about 2^-36 of the utterance's: elements more than 2^12 below it lose against fp32, by less than 2^-36 of it.
 template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false, bool PL = false>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
     static_assert(!PL || (HALF && ABL == 0), "planes: the block-scaled split-fp16 path only");
@@ -729,37 +762,9 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         m = m > m4 ? m : m4;
         return blk_scale_exp(m);
     };
-    // PL: the fp16 powers of two (twice in a register, wave-uniform: scalar integer arithmetic only, so that they live in SGPRs)
-    // that bring the five blocks a tile's taps can touch from their own scale to the tile's; xs = sqrt(0.5) / (the tile's
-    // own block scale), for the residual input.  Which of two blocks a lane's sample of tap -1 / +1 lies in depends on the
-    // lane and the dilation only (lm0, lm2).
-    auto tap_factors = [&](unsigned ev, unsigned (&fs)[5], float& xs) {
-        int e[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int ee = (int)((unsigned)__builtin_amdgcn_readlane((int)ev, k) >> 23);
-            e[k] = ee < PK_EXP_MIN ? PK_EXP_MIN : (ee > PK_EXP_MAX ? PK_EXP_MAX : ee);
-        }
-        const int emax = max(max(max(e[0], e[1]), max(e[3], e[4])), e[2]);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int dd = emax - e[k];   // 2^-dd as fp16 bits: normal down to 2^-14, subnormal to 2^-24, then 0
-            const unsigned hb = dd <= 14 ? (unsigned)(15 - dd) << 10 : (dd <= 24 ? 1u << (24 - dd) : 0u);
-            fs[k] = hb | (hb << 16);
-        }
-        xs = __uint_as_float(0x3f3504f3u - ((unsigned)(PK_BLK_TOP + 127 - e[2]) << 23));   // sqrt(0.5) * 2^-k, k in [-60, 53]
-    };
-    const bool lm0 = ((j - d) >> 5) == -((d + 31) >> 5), lm2 = ((j + d) >> 5) == ((d + 31) >> 5);
-    auto tap_f = [&](const unsigned (&fs)[5], int tap) -> unsigned {
-        return tap == 0 ? (lm0 ? fs[0] : fs[1]) : (tap == 1 ? fs[2] : (lm2 ? fs[4] : fs[3]));
-    };
-    auto h8_of = [](unsigned u) -> pl_f16x8 {
-        const u32x4_t v = {u, u, u, u};
-        return __builtin_bit_cast(pl_f16x8, v);
-    };
     int kx = 0, kx_next = 0;   // x-scale exponents of the current / the next wave tile
-    unsigned fu[5] = {0, 0, 0, 0, 0}, fun[5] = {0, 0, 0, 0, 0};   // PL: block factors of the current / the next wave tile
-    float xs_cur = 0.f, xs_next = 0.f;
+    float xs_cur = 0.f;   // PL: sqrt(0.5) / (the scale of this tile's x_in), for the residual input
+    int kxn_v = 0;        // PL: the next tile's x-scale exponent as loaded (one tile ahead, like t0n)
 
     // operand group g of a wave-tile = k-step g = (channel group cg = g/3, tap = g%3).  Element e of lane
     // (j, hi) is input channel 32*(cg>>1) + mfma_row(8*(cg&1) + e, hi) -- the SAME channel the lane owns as
@@ -791,11 +796,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             for (int e = 0; e < 8; ++e) dst[e] = (ABL & 1) ? (float)(lane + e + gt) * 1e-3f : (a.xin + group_row(gt, e) * XBLK)[vo];
         }
     };
-    auto planes_operand = [&](const float (&rr)[8], unsigned f2, bf16x8& oh, bf16x8& ol) {   // PL: raw vectors x the tap's factor
+    auto planes_operand = [&](const float (&rr)[8], bf16x8& oh, bf16x8& ol) {   // PL: the vectors as loaded
         if constexpr (PL) {
-            const pl_f16x8 fv = h8_of(f2);
-            oh = __builtin_bit_cast(pl_f16x8, f32x4{rr[0], rr[1], rr[2], rr[3]}) * fv;
-            ol = __builtin_bit_cast(pl_f16x8, f32x4{rr[4], rr[5], rr[6], rr[7]}) * fv;
+            oh = __builtin_bit_cast(pl_f16x8, f32x4{rr[0], rr[1], rr[2], rr[3]});
+            ol = __builtin_bit_cast(pl_f16x8, f32x4{rr[4], rr[5], rr[6], rr[7]});
         }
     };
     bf16x8 ph, pl;     // split operands of the k-step about to run (produced one step ahead, under the MFMAs)
@@ -841,10 +845,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
         for (int g = 0; g < B3_RING; ++g) load_group(ring[g], g, vo8n[g % 3], pvo8n[g % 3]);
         if constexpr (PL) {
-            const unsigned ev0 = load_amax(t0c, my_slot);
-            kx = tile_scale_exp(ev0);
-            tap_factors(ev0, fu, xs_cur);
-            planes_operand(ring[0], tap_f(fu, 0), ph, pl);
+            kx = __builtin_amdgcn_readfirstlane(a.tile_kx_in[my_slot >> 3]);
+            planes_operand(ring[0], ph, pl);
         } else if constexpr (HALF) {
             kx = tile_scale_exp(load_amax(t0c, my_slot));
             if constexpr ((ABL & 2) != 0) {   // what pre-split storage of x would leave: no arithmetic between the load and the MFMA
@@ -870,6 +872,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             pvo8[tp] = pvo8n[tp];
         }
         const int t0n = a.tile_t0[next_wt >> 3];   // requested here, first used at k-step T0_USE of stage 1
+        int ko_v = 0;   // PL: scale exponent of this tile's x_out
+        if constexpr (PL) {
+            kxn_v = a.tile_kx_in[next_wt >> 3];
+            ko_v = a.tile_kx_out[wt >> 3];
+            xs_cur = __uint_as_float(0x3f3504f3u - ((unsigned)kx << 23));   // sqrt(0.5) * 2^-kx
+        }
         int cls_next = 0;
         const unsigned vo4 = vo8[1];   // centre tap: operand rows and result rows share the lane offset
         float x_old[32];
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     if constexpr (PL) pvo8n[tp] = lane_off_pl(t0n, next_wt, tp);
                 }
                 cls_next = __builtin_amdgcn_readfirstlane(t0n & 255);
-                if constexpr (HALF) ev_next = load_amax(t0n, next_wt);
+                if constexpr (HALF && !PL) ev_next = load_amax(t0n, next_wt);
             }
             {
                 const int gn = g + B3_RING;
@@ -944,12 +952,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             {
                 const int g1 = (g + 1) % B3_KS1;
                 if constexpr (PL) {
-                    if (g == B3_KS1 - 2) {
-                        kx_next = tile_scale_exp(ev_next);
-                        tap_factors(ev_next, fun, xs_next);
-                    }
-                    // group 0 of the NEXT tile is prepared under the last k-step of this one: its own factor
-                    planes_operand(ring[(g + 1) % B3_RING], g + 1 < B3_KS1 ? tap_f(fu, (g + 1) % 3) : tap_f(fun, 0), nh, nl);
+                    if (g == B3_KS1 - 2) kx_next = __builtin_amdgcn_readfirstlane(kxn_v);
+                    planes_operand(ring[(g + 1) % B3_RING], nh, nl);
                 } else if constexpr (HALF) {
                     if (g == B3_KS1 - 2) kx_next = tile_scale_exp(ev_next);
                     // group 0 of the NEXT tile is split under the last k-step of this one: its own scale
@@ -1118,10 +1122,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                 }
             if constexpr (HALF) {
                 if (pass == 0) {   // max|x_out| of this 64 x 32 block for the next layer's operand scale
-                    am = wave_max64(am);
-                    if (lane == 0 && (!(ABL & 1) || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
-                    if constexpr (PL) {
-                        const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
+                    if constexpr (!PL) {
+                        am = wave_max64(am);
+                        if (lane == 0 && (!(ABL & 1) || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
+                    }
+                    if constexpr (PL) {   // x_out as planes at its utterance's a-priori scale
+                        const float so = pow2f(__builtin_amdgcn_readfirstlane(ko_v));
                         char* pd = reinterpret_cast<char*>(a.xout) + pvo8[1];
 #pragma unroll
                         for (int cg = 0; cg < 4; ++cg) {
@@ -1141,11 +1147,6 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             }
         }
         kx = kx_next;
-        if constexpr (PL) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) fu[k] = fun[k];
-            xs_cur = xs_next;
-        }
     }
 }
 
@@ -1313,7 +1314,10 @@ struct pk_pwg {
     pk_dbuf ws_mel, ws_noise, ws_wav, ws_c0, ws_cin, ws_P, ws_x0, ws_x1, ws_skip, ws_dbg;
     pk_dbuf ws_tab;   // int tables
     // last call layout (for debug reads)
-    std::vector<int> last_frames, last_toff, last_cuL;
+    std::vector<int> last_frames, last_toff, last_cuL, last_cuC;
+    float first_wmax = 0.f, first_bmax = 0.f;   // planes path: bound of first_conv
+    pk_dbuf d_cl, ws_nmax, ws_tkx;              // ... growth constants per layer, max|noise| per utterance, [layers + 1][tiles] scale exponents
+    int last_ntiles = 0;
     long last_Ttot = 0;
     int last_x_final = 0;
     int last_ldp = 0;
@@ -1510,6 +1514,11 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
     PK_TRY(pk_get_vector(h->params, "first_conv.bias", R, b));
     PK_TRY(pk_upload(ctx, h->d_first_w, w.data(), R * sizeof(float)));
     PK_TRY(pk_upload(ctx, h->d_first_b, b.data(), R * sizeof(float)));
+    h->first_wmax = h->first_bmax = 0.f;   // |first_conv(n)| <= wmax |n| + bmax (the planes path's scale bound)
+    for (int i = 0; i < R; ++i) {
+        h->first_wmax = std::max(h->first_wmax, std::fabs(w[i]));
+        h->first_bmax = std::max(h->first_bmax, std::fabs(b[i]));
+    }
     // conv_in -> implicit-GEMM weight [K = tap*AUX + ci][N = AUX]
     const int kin = 2 * c.aux_context_window + 1;
     if (kin > PK_GEMM_MAX_TAPS) PK_FAIL(PK_EUNSUPPORTED, "PWG: aux_context_window %d too wide", c.aux_context_window);
@@ -1554,6 +1563,7 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         std::vector<float> W1(n1 * c.layers), W2(n2 * c.layers), B(nb * c.layers);
         std::vector<float> Wa((size_t)AUX * c.layers * G);   // [K = aux ch][N = layer*G + co]
         std::vector<float> wc, wa, wo, ws, bc, bo, bs;
+        std::vector<float> cl_h(c.layers, 0.f);
         for (int l = 0; l < c.layers; ++l) {
             const std::string p = "conv_layers." + std::to_string(l);
             PK_TRY(pk_get_weight(h->params, p + ".conv", {G, R, KTAP}, wc));
@@ -1563,6 +1573,15 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
             PK_TRY(pk_get_vector(h->params, p + ".conv.bias", G, bc));
             PK_TRY(pk_get_vector(h->params, p + ".conv1x1_out.bias", R, bo));
             PK_TRY(pk_get_vector(h->params, p + ".conv1x1_skip.bias", SK, bs));
+            {   // |conv1x1_out(z) + b| <= c_l for |z| < 1: the growth of the planes path's magnitude bound per layer
+                double m = 0.0;
+                for (int i = 0; i < R; ++i) {
+                    double acc = std::fabs((double)bo[i]);
+                    for (int k = 0; k < G / 2; ++k) acc += std::fabs((double)wo[(size_t)i * (G / 2) + k]);
+                    m = std::max(m, acc);
+                }
+                cl_h[l] = (float)(m * (1.0 + 1e-6));
+            }
             float* a1 = W1.data() + n1 * l;
             for (int ks = 0; ks < KS1; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
@@ -1650,6 +1669,7 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         PK_TRY(pk_upload(ctx, h->d_w1, W1.data(), W1.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_w2, W2.data(), W2.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_bias, B.data(), B.size() * sizeof(float)));
+        PK_TRY(pk_upload(ctx, h->d_cl, cl_h.data(), cl_h.size() * sizeof(float)));
         {   // bias image of the scaled path: stage-2 accumulators start from 2^14 * 2^k2 * bias
             std::vector<float> Bh(B);
             for (int l = 0; l < c.layers; ++l) {
@@ -1746,6 +1766,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     h->last_frames.assign(frames, frames + B);
     h->last_toff = toff;
     h->last_cuL = cuL;
+    h->last_cuC = cuC;
+    h->last_ntiles = sumC;
     h->last_Ttot = Ttot;
 
     // int tables: [cuL (B+1)] [gap_start (B+1)] [frame_utt (sumL)] [tile_t0 (sumL)] [tile_cls (sumL)]
@@ -1897,18 +1919,28 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     // (planes: lane offsets into x are 32-bit byte offsets)
     const bool planes = h->planes_on && h->math == PK_PWG_MATH_F16X3 && h->dbg == 0 && (size_t)R * Ttot * 4 < ((size_t)1 << 32);
     h->last_planes = planes;
+    int* tkx = nullptr;
+    if (planes) {
+        PK_TRY(h->ws_nmax.reserve((size_t)B * 4));
+        PK_TRY(h->ws_tkx.reserve((size_t)(c.layers + 1) * sumC * 4));
+        tkx = h->ws_tkx.as<int>();
+        PK_LAUNCH(ctx, "pwg_noise_max", k_pwg_noise_max, dim3(B), dim3(256), 0, d_noise, d_tab + o_uoff, d_tab + o_uS,
+                  h->ws_nmax.as<float>());
+        PK_LAUNCH(ctx, "pwg_tile_scales", k_pwg_tile_scales, dim3(pk_div_up(sumC, 256)), dim3(256), 0, d_tab + o_tutt, sumC,
+                  h->ws_nmax.as<float>(), h->first_wmax, h->first_bmax, h->d_cl.as<float>(), c.layers, tkx);
+    }
     if (planes && gen)
         PK_LAUNCH(ctx, "pwg_first", (k_pwg_first<true, true>), dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
-                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab, tkx);
     else if (planes)
         PK_LAUNCH(ctx, "pwg_first", (k_pwg_first<false, true>), dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
-                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab, tkx);
     else if (gen)
         PK_LAUNCH(ctx, "pwg_first", k_pwg_first<true>, dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
-                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab, tkx);
     else
         PK_LAUNCH(ctx, "pwg_first", k_pwg_first<false>, dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
-                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab);
+                  h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab, tkx);
     // ---- residual stack.  Optionally the batch is cut into chunks of whole utterances whose x ping-pong +
     // skip buffers (3 x 256 B per sample) fit the 256 MB Infinity Cache, all layers running over one chunk
     // before the next.  A pure load/store kernel with this access pattern gains from that (tools/micro/
@@ -1959,6 +1991,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             a.xe_out = (l & 1) ? h->ws_xe0.as<unsigned>() : h->ws_xe1.as<unsigned>();
             a.k1 = 0;
             a.i0 = a.i1 = 1.f;
+            a.tile_kx_in = planes ? tkx + (size_t)l * sumC + tile0 : nullptr;
+            a.tile_kx_out = planes ? tkx + (size_t)(l + 1) * sumC + tile0 : nullptr;
             if (h->math == PK_PWG_MATH_BF16X3 || h->math == PK_PWG_MATH_F16X3) {
                 const bool half = h->math == PK_PWG_MATH_F16X3;
                 if (half) {
@@ -2055,6 +2089,7 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
         PK_HIP(hipMemcpy(host_out, h->ws_dbg.p, (size_t)G * S * 4, hipMemcpyDeviceToHost));
         return PK_OK;
     }
+    if (what == 3 && h->last_planes) PK_FAIL(PK_EUNSUPPORTED, "pk_pwg_debug_read: the planes path keeps no block maxima");
     if (what == 3) {
         // max|x| per 32-sample block of the final residual stream, as the last layer's epilogue left it for a next
         // layer's operand scale (block-scaled split-fp16 path only)
@@ -2079,12 +2114,11 @@ extern "C" int pk_pwg_debug_read(pk_pwg* h, int32_t what, int32_t b, float* host
         // x as planes: whole blocks to the host, decoded there -- (hi + lo) / 2^k of the block's maximum (xe)
         const long nblk = (S + XBLK - 1) / XBLK, blk0 = h->last_toff[b] / XBLK;
         std::vector<uint16_t> raw((size_t)nblk * XBLK_FLOATS * 2);
-        std::vector<unsigned> am(nblk);
-        const pk_dbuf& xe = h->last_x_final ? h->ws_xe1 : h->ws_xe0;
+        int kfin = 0;   // scale exponent of the utterance's final x: the last row of the tile table, any tile of the utterance
         PK_HIP(hipMemcpy(raw.data(), reinterpret_cast<const char*>(src) + (size_t)blk0 * XBLK_FLOATS * 4, raw.size() * 2, hipMemcpyDeviceToHost));
-        PK_HIP(hipMemcpy(am.data(), xe.as<unsigned>() + blk0, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(&kfin, h->ws_tkx.as<int>() + (size_t)h->cfg.layers * h->last_ntiles + h->last_cuC[b], sizeof(int), hipMemcpyDeviceToHost));
         for (long bi = 0; bi < nblk; ++bi) {
-            const double inv = std::ldexp(1.0, -blk_scale_exp(am[bi]));
+            const double inv = std::ldexp(1.0, -kfin);
             for (int ch = 0; ch < R; ++ch)
                 for (int sidx = 0; sidx < XBLK && bi * XBLK + sidx < S; ++sidx) {
                     const int cg = ch >> 4, w16 = ch & 15, hh = (w16 >> 2) & 1, e = 4 * (w16 >> 3) + (w16 & 3);
@@ -2117,7 +2151,7 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
                        &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1h, &h->d_l1b, &h->d_l2,
                        &h->d_bias_h, &h->ws_xe0, &h->ws_xe1,
                        &h->ws_mel, &h->ws_cin, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
-                       &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab};
+                       &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab, &h->d_cl, &h->ws_nmax, &h->ws_tkx};
     for (auto* b : bufs) b->release();
     delete h;
 }

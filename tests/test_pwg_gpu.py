@@ -176,6 +176,7 @@ def test_pwg_split_math_is_scale_invariant(kx, ks):
     assert _rel_err(w1, w0) < 1e-6
 
 
+@pytest.mark.skipif(os.environ.get("PK_PWG_PLANES") == "1", reason="the planes path scales x per utterance from a bound: no block maxima")
 def test_pwg_block_maxima_are_exact():
     """The operand scale of a layer comes from max|x| per 32-sample block, written by the previous layer's epilogue
     (a DPP wave reduction): it has to be the maximum of exactly the values that were stored."""
@@ -193,11 +194,7 @@ def test_pwg_block_maxima_are_exact():
     for b, L in enumerate(frames):
         x = gen.debug_tap(1, b)                                   # (64, S) final residual stream
         want = np.abs(x).reshape(64, -1, 32).max(axis=(0, 2))
-        if os.environ.get("PK_PWG_PLANES") == "1":
-            # x is stored as (hi, lo) fp16 pairs at the block's scale: 22 of the maximum's 24 bits come back from the tap
-            np.testing.assert_allclose(gen.debug_tap(3, b), want, rtol=2.0 ** -21, atol=0.0)
-        else:
-            np.testing.assert_array_equal(gen.debug_tap(3, b), want)
+        np.testing.assert_array_equal(gen.debug_tap(3, b), want)
 
 
 def test_pwg_split_math_lognormal_weights():
