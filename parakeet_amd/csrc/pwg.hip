@@ -690,7 +690,8 @@ __device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& h
 // 22 bits per operand ~ fp32's 24) of block-scaled operands (see "block scaling" above: no subnormal parts, no
 // dependence on the magnitude of weights or activations; |x| beyond 2^113 aside).
 // ABL (profiling only, PK_PWG_ABLATE, results are wrong): 1 = no global loads / stores of x and skip (compute-only time);
-// 2 = the x taps go to the MFMA as loaded, without the hi / lo split (what storing x pre-split would save)
+// 2 = the x taps go to the MFMA as loaded, without the hi / lo split (what storing x pre-split would save); 4 / 8 (with 2):
+// the taps loaded as two 16-byte vectors per group instead of eight dwords, in the two candidate planes layouts
 // PL (HALF only): x lives in HBM as pre-split fp16 planes -- per 32-sample block [octet 8][sample 32][hi 8 | lo 8] halves (the
 // same 8 KB) --, written so by the producer's epilogue, and an operand group is two 16-byte loads that go to the MFMAs as they
 // are: no arithmetic between load and MFMA.  (The scale-and-split of the fp32 taps, 290 of the tile's 1 400 vector
@@ -789,6 +790,14 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         if constexpr (PL) {
             const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.xin) + (pvo + (unsigned)((gt / 3) * 2048)));
             const f32x4 h4 = src[0], l4 = src[1];
+            dst[0] = h4[0]; dst[1] = h4[1]; dst[2] = h4[2]; dst[3] = h4[3];
+            dst[4] = l4[0]; dst[5] = l4[1]; dst[6] = l4[2]; dst[7] = l4[3];
+        } else if constexpr ((ABL & 12) != 0) {
+            // profiling only (with ABL & 2): the group as two 16-byte loads of the planes' shape from the fp32 buffer -- 4: hi and lo
+            // of a sample adjacent (32 bytes per sample), 8: the planes apart (16 bytes per sample, lo 512 bytes on)
+            const unsigned bo = (vo >> 11) * 8192u + (unsigned)(hi * 1024 + (gt / 3) * 2048) + (vo & 31) * ((ABL & 4) ? 32u : 16u);
+            const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.xin) + bo);
+            const f32x4 h4 = src[0], l4 = src[(ABL & 4) ? 1 : 32];
             dst[0] = h4[0]; dst[1] = h4[1]; dst[2] = h4[2]; dst[3] = h4[3];
             dst[4] = l4[0]; dst[5] = l4[1]; dst[6] = l4[2]; dst[7] = l4[3];
         } else {
@@ -1101,7 +1110,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                                 const int cg = 2 * q + (r >> 3), e = r & 7;
                                 const pl_f16x8 xh = __builtin_bit_cast(pl_f16x8, f32x4{x_old[8 * cg], x_old[8 * cg + 1], x_old[8 * cg + 2], x_old[8 * cg + 3]});
                                 const pl_f16x8 xl = __builtin_bit_cast(pl_f16x8, f32x4{x_old[8 * cg + 4], x_old[8 * cg + 5], x_old[8 * cg + 6], x_old[8 * cg + 7]});
-                                v = fmaf(acc2[q][r], a.i0, ((float)xh[e] + (float)xl[e]) * xs_cur);
+                                // (one multiply and two v_fma_mix_f32: the halves are read in place)
+                                v = fmaf((float)xh[e], xs_cur, fmaf((float)xl[e], xs_cur, acc2[q][r] * a.i0));
                             } else {
                                 v = fmaf(acc2[q][r], a.i0, x_old[16 * q + r] * rs);
                             }
@@ -1131,14 +1141,13 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                         char* pd = reinterpret_cast<char*>(a.xout) + pvo8[1];
 #pragma unroll
                         for (int cg = 0; cg < 4; ++cg) {
-                            pl_f16x8 oh, ol;
+                            // the same scale-and-split the consumer used to do per tap (v_pk_mul_f32, v_cvt_pkrtz_f16_f32,
+                            // v_fma_mix_f32 x 2, v_cvt_f16_f32 per pair), once per value
+                            float t8[8];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float tv = acc2[cg >> 1][8 * (cg & 1) + e] * so;
-                                const _Float16 hv = (_Float16)tv;
-                                oh[e] = hv;
-                                ol[e] = (_Float16)(tv - (float)hv);
-                            }
+                            for (int e = 0; e < 8; ++e) t8[e] = acc2[cg >> 1][8 * (cg & 1) + e];
+                            pl_f16x8 oh, ol;
+                            split_x8s(t8, so, oh, ol);
                             *reinterpret_cast<pl_f16x8*>(pd + cg * 2048) = oh;
                             *reinterpret_cast<pl_f16x8*>(pd + cg * 2048 + 16) = ol;
                         }
@@ -2024,6 +2033,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true>), dim3(grid), blk, 0, a);
                     else if (h->dbg == 1) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 1>), dim3(grid), blk, 0, a);
                     else if (h->dbg == 32) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 2>), dim3(grid), blk, 0, a);
+                    else if (h->dbg == 96) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 6>), dim3(grid), blk, 0, a);
+                    else if (h->dbg == 160) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 10>), dim3(grid), blk, 0, a);
                     else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true>), dim3(grid), blk, 0, a);
                 } else {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<true, false>), dim3(grid), blk, 0, a);

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Parallel WaveGAN layer kernel, profiling ablations (results wrong by construction): per-launch time of tools/quick_pwg.py
-#   PK_PWG_ABLATE unset = as built, 1 = no global loads / stores, 32 = the x taps without their hi / lo split
+#   PK_PWG_ABLATE: 1 = no global loads / stores, 32 = the x taps without their hi / lo split, 96 / 160 = 32 + the taps loaded
+#   as two 16-byte vectors per group (hi | lo adjacent / the planes 512 bytes apart)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-r03pwgabl}
+shift
 mkdir -p $OUT
 cd $R
-for a in 0 32 1 0 32; do
+for a in "$@"; do
   if [ $a = 0 ]; then unset PK_PWG_ABLATE; else export PK_PWG_ABLATE=$a; fi
   timeout 200 python tools/quick_pwg.py > $OUT/quick_$a.log 2>&1
   echo "ablate $a: $(grep 'PWG B' $OUT/quick_$a.log) | $(grep pwg_layer_h3 $OUT/quick_$a.log)"
