@@ -1332,7 +1332,7 @@ struct pk_pwg {
     int last_ldp = 0;
     size_t last_o_cls = 0;
     int dbg = 0;
-    bool planes_on = false;    // PK_PWG_PLANES: x as pre-split fp16 planes under the split-fp16 math (k_pwg_layer_b3<..., PL>)
+    bool planes_on = true;     // x as pre-split fp16 planes under the split-fp16 math (k_pwg_layer_b3<..., PL>); PK_PWG_PLANES=0: off
     bool last_planes = false;  // ... and whether the last run used them (debug tap 1 decodes)
     unsigned long long seed = 0, rng_offset = 0;   // internal noise stream (noise == NULL)
     long chunk_samples = 1L << 40;                  // residual-stack chunk (env PK_PWG_CHUNK_SAMPLES); default: one chunk
@@ -1379,7 +1379,7 @@ extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
     h->gap = ((h->max_dilation + TILE - 1) / TILE) * TILE;
     if (h->gap < TILE) h->gap = TILE;
     if (const char* e = getenv("PK_PWG_ABLATE")) h->dbg = atoi(e);   // profiling only: results are wrong when set
-    if (const char* e = getenv("PK_PWG_PLANES")) h->planes_on = e[0] == '1';
+    if (const char* e = getenv("PK_PWG_PLANES")) h->planes_on = e[0] != '0';   // PK_PWG_PLANES=0: x as fp32 with per-block scales (round 2)
     if (const char* e = getenv("PK_PWG_CHUNK_SAMPLES")) h->chunk_samples = std::max(1L, atol(e));
     if (const char* e = getenv("PK_PWG_MATH"))
         h->math = strcmp(e, "bf16x3") == 0 ? PK_PWG_MATH_BF16X3 : (strcmp(e, "f16x3") == 0 ? PK_PWG_MATH_F16X3 : PK_PWG_MATH_F32);

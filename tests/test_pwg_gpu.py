@@ -176,11 +176,12 @@ def test_pwg_split_math_is_scale_invariant(kx, ks):
     assert _rel_err(w1, w0) < 1e-6
 
 
-@pytest.mark.skipif(os.environ.get("PK_PWG_PLANES") == "1", reason="the planes path scales x per utterance from a bound: no block maxima")
-def test_pwg_block_maxima_are_exact():
-    """The operand scale of a layer comes from max|x| per 32-sample block, written by the previous layer's epilogue
-    (a DPP wave reduction): it has to be the maximum of exactly the values that were stored."""
+def test_pwg_block_maxima_are_exact(monkeypatch):
+    """PK_PWG_PLANES=0 (x as fp32, the round-2 path): the operand scale of a layer comes from max|x| per 32-sample block,
+    written by the previous layer's epilogue (a DPP wave reduction): it has to be the maximum of exactly the values that were
+    stored.  (The default path stores x pre-split at one a-priori scale per utterance and keeps no block maxima.)"""
     from parakeet_amd.parallel_wavegan import PWGGenerator
+    monkeypatch.setenv("PK_PWG_PLANES", "0")
     cfg = dict(syn.PWG_LJSPEECH, layers=6, stacks=3)
     gen = PWGGenerator(**cfg)
     gen.set_state_dict(syn.pwg_state(cfg, seed=31))
@@ -195,6 +196,13 @@ def test_pwg_block_maxima_are_exact():
         x = gen.debug_tap(1, b)                                   # (64, S) final residual stream
         want = np.abs(x).reshape(64, -1, 32).max(axis=(0, 2))
         np.testing.assert_array_equal(gen.debug_tap(3, b), want)
+
+
+def test_pwg_fp32_x_path_meets_the_same_bars(monkeypatch):
+    """PK_PWG_PLANES=0: the split-fp16 kernels with x stored as fp32 and per-block operand scales (round 2's default) stay
+    built and correct: the full-stack ragged batch against the oracle, internal taps included."""
+    monkeypatch.setenv("PK_PWG_PLANES", "0")
+    test_pwg_full_stack_ragged()
 
 
 def test_pwg_split_math_lognormal_weights():
