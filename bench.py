@@ -682,7 +682,9 @@ def main():
                 "note": "algorithmic bytes = SURVEY.md 8(d) layer-granular model, 1344 B/sample/layer x samples per "
                         "launch; the engine itself never materialises the upsampled conditioning (1024 B/sample)",
                 "traffic_source": "profiles/pwg_layer_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                  "calibrated; same batch)" if traffic is not None else None,
+                                  "calibrated; same batch; collected on the kernel variant named in that file -- the "
+                                  "variant that stores x as pre-split fp16 planes moves the same bytes by construction)"
+                                  if traffic is not None else None,
             }),
             "kernel_ms_per_step": {k: ms / prof_steps for k, (_, ms) in sorted(prof.items())},
             "kernel_ms_sum": total_prof_ms,
