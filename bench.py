@@ -147,8 +147,9 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
     layer kernel's average launch time from the engine's HIP-event profile and its roofline.
     Algorithmic work of one layer launch (per folded position): the (3,3) conv over the rows that exist +
     condition_proj + out_proj = 2 * (9 C + 80) * 2C + 2 * C * 2C FLOP at full taps; bytes: one fp32 read of each input row the
-    kernel rows touch (1 - 3 x 4C), the condition row (4 * 80), the residual output (4C, not for the last layer) and the
-    skip sum (read + write 4C each; the first layer only writes)."""
+    kernel rows touch (1 - 3 x 4C), the condition row (4 * 80), the residual output (4C, not for the last layer) and the two
+    folded output-projection sums per position (8 B read + 8 B write: the skip path is folded into them).  The
+    reference's own data flow -- a C-wide skip sum read and written by every layer -- is reported next to it."""
     from parakeet_amd import synthetic as syn
     from parakeet_amd.waveflow import ConditionalWaveFlow
     wcfg = dict(syn.WAVEFLOW_LJSPEECH, channels=channels)
@@ -179,12 +180,16 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
     n_l, ms_l = prof.get("wf_layer", (0, 0.0))
     G, NL, NF, C = wcfg["n_group"], wcfg["n_layers"], wcfg["n_flows"], channels
     pos = nsw // G                                        # folded positions of the batch
-    flop = byts = 0.0
+    flop = byts = byts_ref = 0.0
     for i in range(1, G):                                 # row i of a flow: min(i, 3) input rows exist
         rows = min(i, 3)
         for l in range(NL):
             flop += pos * (2.0 * (3 * rows * C + 80) * 2 * C + 2.0 * C * 2 * C)
-            byts += pos * 4.0 * (rows * C + 80 + (C if l + 1 < NL else 0) + (C if l == 0 else 2 * C))
+            # the data flow the engine implements: input rows + condition row + residual out + the two folded
+            # output-projection sums per position (8 B read + 8 B write) -- the C-wide skip buffer does not exist
+            byts += pos * (4.0 * (rows * C + 80 + (C if l + 1 < NL else 0)) + 16.0)
+            # the reference's layer-granular data flow (C-wide skip read + write), the basis of the round-2/3 figures
+            byts_ref += pos * 4.0 * (rows * C + 80 + (C if l + 1 < NL else 0) + (C if l == 0 else 2 * C))
     launches = NF * (G - 1) * NL
     ent = {
         "what": f"BASELINE config 5 shape (ConditionalWaveFlow, {channels} channels, batch {batch} x {frames} frames), " +
@@ -197,7 +202,7 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
         "reference_published": "about 40x real time on V100 (docs/src/released_models.md:275-276)"}
     if n_l == launches and ms_l > 0:
         avg_s = ms_l / n_l * 1e-3
-        b_l, f_l = byts * NF / launches, flop * NF / launches
+        b_l, b_ref, f_l = byts * NF / launches, byts_ref * NF / launches, flop * NF / launches
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"wf_layer_c{channels}_traffic.json")
         if math is None and os.path.exists(tpath):   # the counters were collected on the default-math kernel
@@ -210,12 +215,135 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
             "kernel": "k_wf_layer_p -- one WaveFlow residual layer of one row, %d launches per batch" % launches,
             "bound": "hbm", "achieved": b_l / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": b_l / avg_s / 8e12,
             "traffic": traffic, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": b_l,
+            "reference_dataflow_bytes_per_launch": b_ref, "frac_reference_dataflow": b_ref / avg_s / 8e12,
             "algorithmic_flop_per_launch": f_l, "algorithmic_tflops": f_l / avg_s / 1e12,
             "fp16_mfma_frac": (1.0 if math == "f16" else 3.0) * f_l / avg_s / 2.5e15,
-            "note": "averages over the launches of a batch (rows 1 and 2 of a flow read one and two input rows); "
+            "note": "achieved / frac count the bytes of the IMPLEMENTED data flow (input rows, condition row, residual out, 16 B of "
+                    "folded output-projection sums per position); frac_reference_dataflow counts the reference's C-wide skip "
+                    "read-modify-write as well (the basis of the round-2/3 figures and targets); "
+                    "averages over the launches of a batch (rows 1 and 2 of a flow read one and two input rows); "
                     "fp16_mfma_frac = issued fp16 MFMA FLOP (3 per product in the split mode, 1 in the fp16 mode) / 2.5 PFLOP/s"}
     del wf
     return ent
+
+
+def _median_ms(fn, runs, sync):
+    ts = []
+    for _ in range(runs):
+        t = time.perf_counter()
+        fn()
+        sync()
+        ts.append((time.perf_counter() - t) * 1e3)
+    return float(np.median(ts)), ts
+
+
+def measurement_extras(synth, ctx, steps):
+    """the BASELINE configurations as stated, the reference's own call shape, a batch sweep and the
+    host-materialised step.  None of this feeds `value`."""
+    from parakeet_amd import synthetic as syn
+    ex = {}
+    sync = torch.cuda.synchronize
+    per_utt = TOKENS * FRAMES_PER_TOKEN * HOP
+    frames_utt = TOKENS * FRAMES_PER_TOKEN
+    texts64 = [syn.phoneme_ids(TOKENS, seed=10086 + i) for i in range(64)]
+    g = torch.Generator(device="cuda").manual_seed(4242)
+    noise64 = torch.randn(64 * per_utt, device="cuda", generator=g)
+
+    # ---- BASELINE config 2 as stated: FastSpeech2, batch 16, T = 128 -> 640 frames each
+    for b in (16, 1):
+        synth.am.inference_batch(texts64[:b])
+        sync()
+        ms, runs = _median_ms(lambda: synth.am.inference_batch(texts64[:b]), max(steps, 10), sync)
+        ex[f"fastspeech2_batch{b}"] = {
+            "what": f"FastSpeech2 inference alone, {b} x {TOKENS} tokens -> {frames_utt} frames" +
+                    (" (BASELINE config 2 as stated)" if b == 16 else " (the reference's call shape: one utterance per call)") +
+                    ", default math, result left in HBM; median",
+            "ms_per_batch": ms, "utterances_per_s": b / ms * 1e3, "algorithmic_tflops": 30.26e9 * b / ms / 1e9,
+            "runs": len(runs)}
+
+    # ---- BASELINE config 3 as stated (SURVEY 8d): PWG alone, batch 32, mel ~ N(0,1) from default_rng(42), noise from the
+    # same generator passed explicitly, ZScore (0, 1)
+    rng = np.random.default_rng(42)
+    mel = torch.from_numpy(rng.standard_normal((UTT_PER_GPU * frames_utt, 80), dtype=np.float32)).cuda()
+    nz = torch.from_numpy(rng.standard_normal(UTT_PER_GPU * per_utt, dtype=np.float32)).cuda()
+    fr = np.full(UTT_PER_GPU, frames_utt, np.int32)
+    run_pwg = lambda: synth.voc.infer_packed(mel, fr, noise=nz)
+    run_pwg()
+    sync()
+    ms, runs = _median_ms(run_pwg, max(steps, 10), sync)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    wav = run_pwg()
+    prof = ctx.prof_dump()
+    ctx.prof_enable(False)
+    key = next((k for k in ("pwg_layer_h3", "pwg_layer_b3", "pwg_layer") if k in prof), None)
+    n_l, ms_l = prof.get(key, (0, 0.0)) if key else (0, 0.0)
+    ns = UTT_PER_GPU * per_utt
+    ent = {"what": "Parallel WaveGAN alone (BASELINE config 3 as stated): 32 x 640 frames of N(0,1) mel from default_rng(42), "
+                   "explicit N(0,1) noise from the same generator, ZScore (0, 1); default math; waveform left in HBM; median",
+           "ms_per_batch": ms, "samples_per_s": ns / ms * 1e3, "x_realtime": ns / ms * 1e3 / SAMPLE_RATE, "runs": len(runs),
+           "finite": bool(torch.isfinite(wav).all()),
+           "whole_call_hbm_frac": 40329.0 * ns / (ms * 1e-3) / 8e12,
+           "whole_call_note": "SURVEY 8(d)'s 40 329 B per sample (30 layers x 1 344 B + first / last convs) / call time / 8 TB/s"}
+    if n_l:
+        avg = ms_l / n_l
+        ent["roofline"] = {"kernel": "PWG ResidualBlock layer kernel, %d launches" % n_l, "bound": "hbm",
+                           "achieved": PWG_LAYER_BYTES_PER_SAMPLE * ns / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": PWG_LAYER_BYTES_PER_SAMPLE * ns / (avg * 1e-3) / 8e12, "avg_launch_ms": avg}
+    try:
+        over, fb = synth.voc.scale_overshoot()
+        ent["scale_guard"] = {"what": "log2(a-priori bound of the planes path / measured max|x|) per layer input, maximum over "
+                                      "the utterances of the handle's first (guarded) inference; limit 10",
+                              "max": float(over.max()), "per_layer": [round(float(v), 2) for v in over], "fell_back": fb}
+    except Exception as e:
+        ent["scale_guard"] = {"error": repr(e)}
+    ex["pwg_batch32"] = ent
+    del mel, nz
+
+    # ---- the reference's actual call shape: one 128-token utterance per call, waveform materialised on the host
+    # (examples/fastspeech2/ljspeech/synthesize_e2e.py:88-102 -> .numpy()), median of 20
+    host1 = torch.empty(per_utt, dtype=torch.float32, pin_memory=True)
+
+    def one():
+        w, _ = synth.synthesize_packed(texts64[:1], noise=noise64[:per_utt])
+        host1.copy_(w, non_blocking=True)
+    one()
+    sync()
+    ms, runs = _median_ms(one, 20, sync)
+    m_fs2 = ex["fastspeech2_batch1"]["ms_per_batch"]
+    ex["latency_batch1"] = {
+        "what": "one 128-token utterance end to end (FastSpeech2 -> PWG -> waveform in pinned host memory), the only call shape "
+                "of the reference's recipe; median of 20 calls",
+        "ms": ms, "min_ms": min(runs), "max_ms": max(runs), "x_realtime": per_utt / SAMPLE_RATE / (ms * 1e-3),
+        "fastspeech2_ms": m_fs2, "vocoder_and_copy_ms": ms - m_fs2}
+
+    # ---- batch sweep per GPU, end to end, device-resident result (the headline's step without the issue-ahead pipeline)
+    sweep = {}
+    for b in (1, 4, 16, 32, 64):
+        f = lambda: synth.synthesize_packed(texts64[:b], noise=noise64[:b * per_utt])
+        f()
+        sync()
+        ms, _ = _median_ms(f, 5, sync)
+        sweep[str(b)] = {"ms_per_batch": ms, "samples_per_s": b * per_utt / ms * 1e3,
+                         "x_realtime": b * per_utt / ms * 1e3 / SAMPLE_RATE}
+    ex["batch_sweep"] = {"what": "FastSpeech2+PWG end to end per batch size on one GPU (128-token utterances, 640 frames each), "
+                                 "unpipelined, waveform left in HBM; median of 5", "by_batch": sweep}
+
+    # ---- BASELINE.md section 2's call boundary: model call + the waveform materialised on the host
+    host32 = torch.empty(UTT_PER_GPU * per_utt, dtype=torch.float32, pin_memory=True)
+
+    def step_host():
+        w, _ = synth.synthesize_packed(texts64[:UTT_PER_GPU], noise=noise64[:UTT_PER_GPU * per_utt])
+        host32.copy_(w, non_blocking=True)
+    step_host()
+    sync()
+    ms_h, _ = _median_ms(step_host, max(steps, 10), sync)
+    ms_d = sweep["32"]["ms_per_batch"]
+    ex["host_io"] = {"what": "the 32-utterance step with the packed waveform (21 MB) copied to pinned host memory inside the timed "
+                             "region (examples/GANVocoder/parallelwave_gan/synthesize.py:82-88 materialises it), unpipelined",
+                     "host_io_ms_per_step": ms_h, "device_resident_ms_per_step": ms_d, "copy_ms": ms_h - ms_d,
+                     "samples_per_s": UTT_PER_GPU * per_utt / ms_h * 1e3}
+    return ex
 
 
 def _free_port():
@@ -527,6 +655,11 @@ def main():
                     extras[key] = waveflow_extra(wf_c, ctx, math=wmath)
                 except Exception as e:  # never let an extra break the headline line
                     extras[key] = {"error": repr(e)}
+        try:   # BASELINE configs 2 / 3 as stated, single-utterance latency, batch sweep, host-materialised step
+            _log("extras: measurement holes (configs 2 / 3, latency, sweep, host io)")
+            extras.update(measurement_extras(synth, ctx, args.steps))
+        except Exception as e:
+            extras["measurement_extras"] = {"error": repr(e)}
         try:   # the two acoustic models alone (BASELINE config 2 shape at 32 utterances; SpeedySpeech)
             t1 = time.perf_counter()
             for _ in range(args.steps):
@@ -579,7 +712,8 @@ def main():
             extras["transformer_tts_batch32"] = {
                 "what": "TransformerTTS (LJSpeech recipe sizes) inference alone, 32 x 128 tokens decoded in lockstep for 640 "
                         "steps (the stop token is held off so that every utterance runs to int(129 * maxlenratio) = 640 "
-                        "frames), prenet dropout stream on, default math",
+                        "frames; the oracle comparison at these sizes, tests/test_ar_benchsize_gpu.py, covers the first 224 steps), "
+                        "prenet dropout stream on, default math",
                 "ms_per_batch": dtt * 1e3, "us_per_step": dtt / frames_per_utt * 1e6, "frames": nf,
                 "utterances_per_s": UTT_PER_GPU / dtt, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtt}
             del ttm
@@ -597,7 +731,8 @@ def main():
             nf = int(sum(o["mel_output"].shape[0] for o in outs))
             extras["tacotron2_batch32"] = {
                 "what": "Tacotron2 (examples/tacotron2/config.py sizes) inference alone, 32 x 128 tokens decoded in lockstep "
-                        "for max_decoder_steps = 640 (stop token held off), prenet dropout stream on, default math",
+                        "for max_decoder_steps = 640 (stop token held off; tests/test_ar_benchsize_gpu.py compares 256 steps with the "
+                        "oracle), prenet dropout stream on, default math",
                 "ms_per_batch": dtc * 1e3, "us_per_step": dtc / frames_per_utt * 1e6, "frames": nf,
                 "utterances_per_s": UTT_PER_GPU / dtc, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtc}
             del tcm
@@ -691,6 +826,10 @@ def main():
         }
         if pipeline_check is not None:
             out["pipeline_check"] = pipeline_check
+            out["value_unpipelined"] = pipeline_check["unpipelined_samples_per_s"]
+            out["value_note"] = ("`value` = steady-state throughput with the next batch's acoustic model issued during this "
+                                 "batch's vocoder; `value_unpipelined` = the same step issued strictly in order (the latency-true "
+                                 "figure); extras.host_io = with the waveform copied to host memory inside the step")
         if extras:
             out["extras"] = extras
         if gather_ms is not None:

@@ -128,7 +128,7 @@ int pk_pwg_set_param(pk_pwg* h, const char* name, const float* data,
  * mel_in -> (mel_in - mu) / sigma.  NULL,NULL = identity. */
 int pk_pwg_set_normalizer(pk_pwg* h, const float* mu, const float* sigma, int32_t n);
 /* Arithmetic of the residual-block contractions (activations, weights, accumulators and every stored
- * tensor are fp32 in all modes).  Default PK_PWG_MATH_F16X3; env PK_PWG_MATH=f32|bf16x3|f16x3 overrides.
+ * tensor are fp32 in all modes).  Default PK_PWG_MATH_F16X3.
  *   PK_PWG_MATH_F32     exact fp32 products on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);
  *   PK_PWG_MATH_F16X3   each fp32 product as a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with fp16 parts
  *                       (11 + 11 significant bits per operand, dropped term 2^-22) on
@@ -144,8 +144,23 @@ int pk_pwg_set_math(pk_pwg* h, int32_t mode);
 /* Scheduling of the residual stack (no effect on results): the batch is processed in chunks of whole
  * utterances of at most `samples` samples, all layers over one chunk before the next, so that the chunk's
  * activations (768 B per sample) stay in the 256 MB Infinity Cache between layers (327 680 = two 7.4 s
- * utterances = 252 MB).  Default: one chunk (measured faster, see pwg.hip); env PK_PWG_CHUNK_SAMPLES. */
+ * utterances = 252 MB).  Default: one chunk (measured faster, see pwg.hip). */
 int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples);
+/* Named integer options of a handle.  The library reads NO environment variable (the measurement / ablation switches of
+ * earlier rounds exist only in the profile build, parakeet_amd/build.py build(profile=True)); what a caller may choose
+ * is listed here.  Unknown key or value -> PK_EINVAL.
+ *   "planes"       1 (default) = under PK_PWG_MATH_F16X3 the residual stream x is stored as pre-split fp16 planes at one
+ *                  a-priori scale per utterance and layer (pwg.hip, k_pwg_tile_scales); 0 = x stored as fp32 with one
+ *                  measured scale per 32-sample block (round 2's path: ~4 % slower, no magnitude bound involved).
+ *   "scale_guard"  0 = off; 1 (default) = the FIRST inference after pk_pwg_finalize also measures max|x| per utterance and
+ *                  layer on the planes path, and when the a-priori bound overshoots the measured maximum by more than
+ *                  2^10 anywhere, the call is repeated on the "planes" = 0 path, which the handle then keeps; 2 = every call.
+ *                  pk_pwg_scale_overshoot reports what was measured. */
+int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value);
+/* log2(a-priori bound / measured max|x|) per layer input, l = 0 .. layers (n = layers + 1 floats), the maximum over the
+ * utterances of the last guarded inference ("scale_guard"); *fell_back (nullable) = 1 when the handle has left the planes
+ * path.  PK_ESTATE if no guarded inference has run. */
+int pk_pwg_scale_overshoot(pk_pwg* h, float* log2_overshoot, int32_t n, int32_t* fell_back);
 /* remove_weight_norm + packing into the kernels' layouts + upload. */
 int pk_pwg_finalize(pk_pwg* h);
 /* PWGGenerator.inference for a packed batch.
@@ -211,9 +226,16 @@ int pk_fs2_set_normalizer(pk_fs2* h, const float* mu, const float* sigma, int32_
 /* Arithmetic of the dense layers (Linear / Conv1D GEMMs) and of the two attention contractions: 0 = exact fp32
  * MFMA, 1 = block-scaled 3-term split-fp16 MFMA with fp32 accumulation (default; same construction and error
  * class as PK_PWG_MATH_F16X3; layers whose input channel count is not a multiple of 32 stay on the exact path).
- * LayerNorm, softmax, the duration arithmetic and every stored tensor are fp32 in both modes.
- * Env PK_FS2_MATH=f32 overrides. */
+ * LayerNorm, softmax, the duration arithmetic and every stored tensor are fp32 in both modes. */
 int pk_fs2_set_math(pk_fs2* h, int32_t mode);
+/* Named integer options (as pk_pwg_set_option; scheduling / tiling choices, results stay within the math mode's error class):
+ *   "ffn_planes"             1 (default) = the feed-forward convs, q|k|v and attention-out projections of pre-norm FFT blocks
+ *                            run on the planes kernels (csrc/ffn_planes.hip); 0 = on the tile GEMM
+ *   "ffn_planes_min_blocks"  timelines shorter than this many 32-row blocks stay on the tile GEMM (default 0)
+ *   "ffnp_variant"           0 (default) = tiling by shape; 88 / 84 / 48 / 44: first digit 8 / 4 = 256 / 128 output channels
+ *                            per wave in the first conv, second digit = waves per workgroup of the second conv
+ *   "attn_waves"             0 (default) = by shape; 4 / 8 query tiles per attention workgroup */
+int pk_fs2_set_option(pk_fs2* h, const char* key, int64_t value);
 int pk_fs2_finalize(pk_fs2* h);
 /* Speaker conditioning of the NEXT pk_fs2_encode call (_forward :396-402, _integrate_with_spk_embed
  * :560-586): spk_id HOST int64 (B) looked up in spk_embedding_table, or spembs HOST float32
@@ -307,7 +329,7 @@ int pk_ss_create(pk_ctx* ctx, const pk_ss_cfg* cfg, pk_ss** out);
 int pk_ss_set_param(pk_ss* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 /* SpeedySpeechInference's normalizer (:221-231): mel -> mel * sigma + mu.  NULL,NULL = SpeedySpeech.inference. */
 int pk_ss_set_normalizer(pk_ss* h, const float* mu, const float* sigma, int32_t n);
-/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math); env PK_SS_MATH=f32. */
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math). */
 int pk_ss_set_math(pk_ss* h, int32_t mode);
 int pk_ss_finalize(pk_ss* h);
 /* Phase 1 of SpeedySpeech.inference (:178-196) for a packed batch: encoder, duration predictor,
@@ -368,8 +390,12 @@ int pk_tts_set_param(pk_tts* h, const char* name, const float* data, const int64
 /* TransformerTTSInference's normalizer (:757-767): mel -> mel * sigma + mu, applied by pk_tts_read under
  * PK_APPLY_NORMALIZER.  NULL,NULL removes it. */
 int pk_tts_set_normalizer(pk_tts* h, const float* mu, const float* sigma, int32_t n);
-/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math); env PK_TTS_MATH=f32. */
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math). */
 int pk_tts_set_math(pk_tts* h, int32_t mode);
+/* Named integer options: those of pk_fs2_set_option (the encoder's FFT stack), and
+ *   "kv_prefix"  0 (default); 1 = decoder layer 0 projects k | v only for the prefix rows and q for the new rows with a
+ *                row GEMM (measured neutral on an MI355X, kept as an option) */
+int pk_tts_set_option(pk_tts* h, const char* key, int64_t value);
 /* Decoder-prenet dropout: 1 (default) = the dropout stream above with p = 0.5, element index
  * ((s*(s-1)/2 + pos) * dprenet_layers + layer) * dprenet_units + unit for decoding step s = 1, 2, ... and prefix
  * position pos < s (the reference re-applies the prenet to the whole prefix at every step, decoder.py:210);
@@ -427,7 +453,7 @@ int pk_taco_create(pk_ctx* ctx, const pk_taco_cfg* cfg, pk_taco** out);
 /* set_state_dict entry.  paddle.nn.LSTM registers each cell parameter twice ("encoder.lstm.0.cell_fw.weight_ih" and
  * "encoder.lstm.weight_ih_l0"); either name is accepted, the cuDNN-style one wins when both are given. */
 int pk_taco_set_param(pk_taco* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
-/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math); env PK_TACO_MATH=f32. */
+/* 0 = exact fp32 MFMA, 1 = 3-term split-fp16 MFMA GEMMs (default, as pk_fs2_set_math). */
 int pk_taco_set_math(pk_taco* h, int32_t mode);
 /* Decoder-prenet dropout: 1 (default) = the dropout stream with p = p_prenet_dropout, element index
  * (step * 2 + layer) * d_prenet + unit for decoding step 0, 1, ...; 0 = no dropout (not what the reference computes). */

@@ -12,7 +12,10 @@ import os
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpk_synth.so")
+# PK_PROFILE_LIB=1 (read HERE, in Python -- the product library itself reads no environment variable): load the profile
+# build (parakeet_amd.build.build(profile=True)), the one that carries the measurement / ablation switches tools/ uses.
+PROFILE_LIB = os.environ.get("PK_PROFILE_LIB", "0") not in ("", "0")
+LIB_PATH = os.path.join(_HERE, "libpk_synth_prof.so" if PROFILE_LIB else "libpk_synth.so")
 
 PK_OK = 0
 PK_HOST_IO = 1
@@ -118,6 +121,8 @@ def _declare(lib):
         "pk_wf_set_seed": (C.c_int, [vp, C.c_uint64]),
         "pk_pwg_set_math": (C.c_int, [vp, i32]),
         "pk_pwg_set_chunk_samples": (C.c_int, [vp, i64]),
+        "pk_pwg_set_option": (C.c_int, [vp, cstr, i64]),
+        "pk_pwg_scale_overshoot": (C.c_int, [vp, f32p, i32, i32p]),
         "pk_pwg_finalize": (C.c_int, [vp]),
         "pk_pwg_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),
         "pk_pwg_debug_read": (C.c_int, [vp, i32, i32, f32p, i64]),
@@ -126,6 +131,7 @@ def _declare(lib):
         "pk_fs2_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
         "pk_fs2_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
         "pk_fs2_set_math": (C.c_int, [vp, i32]),
+        "pk_fs2_set_option": (C.c_int, [vp, cstr, i64]),
         "pk_fs2_set_speakers": (C.c_int, [vp, i64p, f32p, i32]),
         "pk_fs2_set_tones": (C.c_int, [vp, i64p, i64]),
         "pk_fs2_finalize": (C.c_int, [vp]),
@@ -154,6 +160,7 @@ def _declare(lib):
         "pk_tts_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
         "pk_tts_set_normalizer": (C.c_int, [vp, f32p, f32p, i32]),
         "pk_tts_set_math": (C.c_int, [vp, i32]),
+        "pk_tts_set_option": (C.c_int, [vp, cstr, i64]),
         "pk_tts_set_dropout": (C.c_int, [vp, i32]),
         "pk_tts_set_speakers": (C.c_int, [vp, f32p, i32]),
         "pk_tts_set_style_reference": (C.c_int, [vp, f32p, i32p, i32]),

@@ -5,6 +5,13 @@ The library carries a hash of the sources it was built from (``pk_version()``: `
 consulted (the .so is git-ignored but travels to the GPU box, where a stale binary may well be newer than
 an edited source).  Without hipcc (never the case in the build image) a mismatching library is an error,
 not something to run.
+
+Two libraries come from the same sources:
+  libpk_synth.so       the product.  Reads no environment variable: ``pk_prof_env`` (csrc/pk_common.h) is a constant
+                       nullptr, the measurement / ablation switches and the kernels instantiated for them are not in it.
+  libpk_synth_prof.so  ``build(profile=True)`` / ``python -m parakeet_amd.build --profile``: -DPK_PROFILE_BUILD=1, the
+                       switches the tools/ scripts use (PK_WF_ABLATE, PK_PWG_ABLATE, PK_FFNP_ABLATE, PK_GEMM_TILE, ...;
+                       several give WRONG results by design).  ``_capi`` loads it only under PK_PROFILE_LIB=1.
 """
 import hashlib
 import os
@@ -16,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libpk_synth.so")
+LIB_PROF = os.path.join(HERE, "libpk_synth_prof.so")
 # per-file flags.  wf_layer.hip: the layer kernel's slab loop must unroll completely (26 slabs at 128 channels; a ring slot is a
 # register only under a compile-time index) -- beyond LLVM's default budget for `#pragma unroll`, where it silently keeps a
 # loop and the operand ring moves to scratch memory
@@ -53,18 +61,19 @@ def library_hash(path=LIB):
     return m.group(1).decode() if m else None
 
 
-def needs_build():
-    return library_hash() != source_hash()
+def needs_build(profile=False):
+    return library_hash(LIB_PROF if profile else LIB) != source_hash()
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
-        return LIB
+def build(force=False, verbose=False, extra_flags=(), profile=False):
+    lib = LIB_PROF if profile else LIB
+    if not force and not needs_build(profile):
+        return lib
     objs = []
     procs = []
-    extra_flags = list(extra_flags) + [f'-DPK_SOURCE_HASH="{source_hash()}"']
+    extra_flags = list(extra_flags) + [f'-DPK_SOURCE_HASH="{source_hash()}"', f"-DPK_PROFILE_BUILD={int(profile)}"]
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + (".prof.o" if profile else ".o"))
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
                "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + list(extra_flags) + FILE_FLAGS.get(src, [])
         if verbose:
@@ -77,15 +86,15 @@ def build(force=False, verbose=False, extra_flags=()):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode(), file=sys.stderr)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
-    if library_hash() != source_hash():
-        raise RuntimeError("libpk_synth.so does not carry the hash of the sources it was just built from")
-    return LIB
+    if library_hash(lib) != source_hash():
+        raise RuntimeError(f"{os.path.basename(lib)} does not carry the hash of the sources it was just built from")
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True,
+    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv,
                 extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ()))

@@ -538,6 +538,26 @@ size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>&
     return off;
 }
 
+// Timing ablations (PK_FFNP_ABLATE; results are WRONG): instantiated in the profile build only.  Returns 1 when none applies.
+template <bool PROF, class Go>
+static int ffnp_ablation(Go& go, bool shape_ok) {
+    if constexpr (PROF) {
+        static const int abl = pk_prof_env("PK_FFNP_ABLATE") ? atoi(pk_prof_env("PK_FFNP_ABLATE")) : 0;
+        if (abl && shape_ok) {
+            switch (abl) {
+                case 1: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 1>);
+                case 4: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 4>);
+                case 8: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 8>);
+                case 13: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 13>);
+                case 128: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 128>);
+                case 256: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 256>);
+                default: PK_FAIL(PK_EINVAL, "PK_FFNP_ABLATE: 1, 4, 8, 13, 128 or 256 (with PK_FFNP_VARIANT=84)");
+            }
+        }
+    }
+    return 1;
+}
+
 int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     const bool first = c.out != nullptr;
     if (!(first ? (c.Cin == 384 && c.N % (32 * FFNP_NQ1) == 0) : (c.Cin == 1536 && c.N % (32 * FFNP_NQ2) == 0)) || c.nblk <= 0 || !c.w || !c.wscale)
@@ -546,8 +566,7 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     // 128 columns per wave in 4-wave workgroups, two per CU (short timelines: four times the workgroups).  Second conv: 128
     // columns per wave, 8-wave workgroups.  PK_FFNP_VARIANT (measurement switch): 88 / 44 force the first conv's kernel, the
     // second digit 4 runs the second conv in 4-wave workgroups.
-    const char* venv = getenv("PK_FFNP_VARIANT");   // (read per launch: tests switch it)
-    const int variant = venv ? atoi(venv) : 0;
+    const int variant = c.variant;   // (the "ffnp_variant" option of the owning handle)
     const bool small = first && c.w4 && (variant / 10 == 4 || (variant / 10 != 8 && c.nblk < FFNP_NQ1_MIN_BLOCKS));
     const int nq = first && !small ? FFNP_NQ1 : FFNP_NQ2;
     const int W = first ? (small ? 4 : 8) : (variant % 10 == 4 ? 4 : 8);
@@ -569,18 +588,7 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
         PK_LAUNCH(ctx, prof_name, kern, dim3(grid), dim3(64 * W), 0, a);
         return PK_OK;
     };
-    static const int abl = getenv("PK_FFNP_ABLATE") ? atoi(getenv("PK_FFNP_ABLATE")) : 0;   // profiling only: results are wrong
-    if (abl && !first && W == 4) {
-        switch (abl) {
-            case 1: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 1>);
-            case 4: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 4>);
-            case 8: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 8>);
-            case 13: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 13>);
-            case 128: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 128>);
-            case 256: return go(k_ffn_planes<4, 96, 1, 4, FFNP_TAPS, 256>);
-            default: PK_FAIL(PK_EINVAL, "PK_FFNP_ABLATE: 1, 4, 8, 13, 128 or 256 (with PK_FFNP_VARIANT=84)");
-        }
-    }
+    if (int st = ffnp_ablation<PK_PROFILE_BUILD != 0>(go, !first && W == 4); st != 1) return st;
     if (first) return small ? go(k_ffn_planes<FFNP_NQ2, 24, 0, 4>) : go(k_ffn_planes<FFNP_NQ1, 24, 0, 8>);
     return W == 8 ? go(k_ffn_planes<FFNP_NQ2, 96, 1, 8>) : go(k_ffn_planes<FFNP_NQ2, 96, 1, 4>);
 }

@@ -981,10 +981,15 @@ extern "C" int pk_fs2_create(pk_ctx* ctx, const pk_fs2_cfg* cfg, pk_fs2** out) {
     h->cfg = c;
     h->adim = c.adim;
     h->aheads = c.aheads;
-    h->attn_lds = getenv("PK_FS2_ATTN_NO_LDS") == nullptr;
-    h->no_bounds = getenv("PK_FS2_NO_BOUNDS") != nullptr;
+    h->attn_lds = pk_prof_env("PK_FS2_ATTN_NO_LDS") == nullptr;
+    h->no_bounds = pk_prof_env("PK_FS2_NO_BOUNDS") != nullptr;
     h->gapr = gapr;
-    if (const char* e = getenv("PK_FS2_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
+    h->ffn_planes_min_blocks = FFNP_MIN_BLOCKS;
+    if (const char* e = pk_prof_env("PK_FS2_FFN_PLANES")) h->ffn_planes = e[0] != '0';
+    if (const char* e = pk_prof_env("PK_FS2_FFN_PLANES_MIN_BLOCKS")) h->ffn_planes_min_blocks = atoi(e);
+    if (const char* e = pk_prof_env("PK_FFNP_VARIANT")) h->ffnp_variant = atoi(e);
+    if (const char* e = pk_prof_env("PK_FS2_ATTN_WAVES")) h->attn_waves = atoi(e);
+    if (const char* e = pk_prof_env("PK_FS2_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     if (gapr > LEAD) { delete h; PK_FAIL(PK_EUNSUPPORTED, "conv kernel too wide"); }
     *out = h;
     return PK_OK;
@@ -1025,19 +1030,6 @@ static void dense_bound(const std::vector<float>& kn, const std::vector<float>* 
     }
     c1 = (float)(m1 * (1.0 + 1e-6));
     c0 = (float)(m0 * (1.0 + 1e-6));
-}
-
-// PK_FS2_FFN_PLANES=0: the feed-forward convs stay on the tile GEMM (A/B measurements; nothing is packed for the planes kernel)
-static bool ffn_planes_enabled() {
-    const char* e = getenv("PK_FS2_FFN_PLANES");
-    return !(e && e[0] == '0');
-}
-
-// ... and PK_FS2_FFN_PLANES_MIN_BLOCKS moves the timeline length (in 32-row blocks) from which they leave it (tests run
-// the planes kernels on short timelines with 0)
-static int ffn_planes_min_blocks() {
-    const char* e = getenv("PK_FS2_FFN_PLANES_MIN_BLOCKS");
-    return e ? atoi(e) : FFNP_MIN_BLOCKS;
 }
 
 int pk_fft_add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vector<float>* bias, int Cin, int taps,
@@ -1126,7 +1118,7 @@ int pk_fft_add_stack(Arena& ar, const pk_param_map& P, const std::string& prefix
                   bool normalize_before, bool concat_after) {
     out.resize(n_layers);
     // pre-norm stacks with conv feed-forward layers of the built shape also get the planes-kernel fragments (pk_ffn_planes.h)
-    const bool planes = normalize_before && ffnp_supports(A, units, k, k) && ffn_planes_enabled();
+    const bool planes = normalize_before && ffnp_supports(A, units, k, k);
     for (int l = 0; l < n_layers; ++l) {
         const std::string p = prefix + ".encoders." + std::to_string(l);
         FftLayer& L = out[l];
@@ -1414,13 +1406,13 @@ int pk_fft_run_attention(pk_fft_core* h, const Timeline& tl, const float* qkv, f
     if (h->math == PK_GEMM_MATH_F16X3 && h->attn_lds) {
         dim3 g2(pk_div_up(maxlen, ATT_THREADS / 2), heads, tl.B);
         // (measured, 32 x 640 frames: 180 -> 170 us per decoder launch; PK_FS2_ATTN_PIPE=0: the two-barrier loop)
-        static const bool pipe = !(getenv("PK_FS2_ATTN_PIPE") && getenv("PK_FS2_ATTN_PIPE")[0] == '0');
+        static const bool pipe = !(pk_prof_env("PK_FS2_ATTN_PIPE") && pk_prof_env("PK_FS2_ATTN_PIPE")[0] == '0');
         if (pipe && dk == 192) {
             // query tiles per workgroup: 4, or 8 where that saves rounds of n_cu workgroups.  Measured per decoder launch (32 x 2
             // pairs of 20 query tiles): 4 tiles 171 us (320 workgroups, two rounds), 5: 148, 6: 138, 8: 132 (192 workgroups);
             // from 5 waves on the kernel has 256 registers instead of 512 and spills 17-34 of them, a workgroup alone takes
             // 1.55 x as long -- the encoder's 4-tile utterances stay with 4 (24 vs 30 us).
-            static const int wenv = getenv("PK_FS2_ATTN_WAVES") ? atoi(getenv("PK_FS2_ATTN_WAVES")) : 0;   // measurement switch
+            const int wenv = h->attn_waves;   // measurement override ("attn_waves" option)
             const long r4 = pk_div_up((long)pk_div_up(maxlen, 128) * heads * tl.B, h->ctx->n_cu);
             const long r8 = pk_div_up((long)pk_div_up(maxlen, 256) * heads * tl.B, h->ctx->n_cu);
             int best = 100 * r4 <= 155 * r8 ? 4 : 8;
@@ -1548,7 +1540,7 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
     // norm2 and the two feed-forward convs on pre-split planes (pk_ffn_planes.h) where pk_fft_add_stack packed for them
     const bool planes = h->math == PK_GEMM_MATH_F16X3 && !layers.empty() && layers[0].ffn1.wp != (size_t)-1 &&
                         layers[0].ffn2.wp != (size_t)-1 && tl.rows_alloc % FFNP_BLK == 0 &&
-                        tl.rows_alloc / FFNP_BLK >= ffn_planes_min_blocks();
+                        h->ffn_planes && tl.rows_alloc / FFNP_BLK >= h->ffn_planes_min_blocks;
     const int nblk = tl.rows_alloc / FFNP_BLK;
     char *hp = nullptr, *fp = nullptr;
     unsigned *hpam = nullptr, *fpam = nullptr;
@@ -1566,6 +1558,10 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
         PK_HIP(hipMemsetAsync(h->d_pam.p, 0, (size_t)2 * (tl.rows_alloc + 2) * sizeof(unsigned), h->ctx->stream));
         hp = h->d_hp.as<char>() + (size_t)A * 128;
         fp = h->d_fp.as<char>() + (size_t)units * 128;
+        // the margin block BEHIND the last block may hold planes of an earlier, longer timeline: cleared per run, so that the
+        // +1 taps of the last tile read zeros whatever ran before (the leading margin block is never written)
+        PK_HIP(hipMemsetAsync(hp + (size_t)nblk * A * 128, 0, (size_t)A * 128, h->ctx->stream));
+        PK_HIP(hipMemsetAsync(fp + (size_t)nblk * units * 128, 0, (size_t)units * 128, h->ctx->stream));
         hpam = h->d_pam.as<unsigned>() + 1;   // row maxima (fp32 bits), one element of margin on either side
         fpam = hpam + tl.rows_alloc + 2;
     }
@@ -1632,6 +1628,7 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             c.wscale = h->W(L.ffn1.wps); c.Cin = A; c.N = units;
             c.in = hp; c.in_amax = hpam;
             c.out = fp; c.out_amax = fpam; c.c1 = L.ffn1.c1; c.c0 = L.ffn1.c0;
+            c.variant = h->ffnp_variant;
             PK_TRY(ffnp_conv_launch(h->ctx, "fs2_conv_ffn1_planes", c));
             c.w = h->arena16.as<uint16_t>() + L.ffn2.wp;
             c.w4 = nullptr;
@@ -1976,6 +1973,25 @@ extern "C" int pk_fs2_set_math(pk_fs2* h, int32_t mode) {
     if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3) PK_FAIL(PK_EINVAL, "pk_fs2_set_math: unknown mode %d", mode);
     h->math = mode;
     return PK_OK;
+}
+
+// shared by pk_fs2_set_option and pk_tts_set_option: the options of an FFT stack
+int pk_fft_set_option(pk_fft_core* h, const char* key, int64_t value, const char* who) {
+    if (!h || !key) PK_FAIL(PK_EINVAL, "%s: NULL argument", who);
+    if (strcmp(key, "ffn_planes") == 0) h->ffn_planes = value != 0;
+    else if (strcmp(key, "ffn_planes_min_blocks") == 0) h->ffn_planes_min_blocks = (int)std::max<int64_t>(0, value);
+    else if (strcmp(key, "ffnp_variant") == 0) {
+        if (value != 0 && value != 44 && value != 48 && value != 84 && value != 88) PK_FAIL(PK_EINVAL, "%s: ffnp_variant %lld (0, 44, 48, 84, 88)", who, (long long)value);
+        h->ffnp_variant = (int)value;
+    } else if (strcmp(key, "attn_waves") == 0) {
+        if (value != 0 && value != 4 && value != 8) PK_FAIL(PK_EINVAL, "%s: attn_waves %lld (0, 4, 8)", who, (long long)value);
+        h->attn_waves = (int)value;
+    } else PK_FAIL(PK_EINVAL, "%s: unknown option '%s'", who, key);
+    return PK_OK;
+}
+
+extern "C" int pk_fs2_set_option(pk_fs2* h, const char* key, int64_t value) {
+    return pk_fft_set_option(h, key, value, "pk_fs2_set_option");
 }
 
 extern "C" int pk_fs2_set_debug(pk_fs2* h, int32_t on) {

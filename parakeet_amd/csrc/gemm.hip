@@ -649,7 +649,7 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
     // (WaveFlow out_proj, K = 64: 64 us vs 92 us); from K = 128 the split kernel with its 64-row tiles is ahead
     // (WaveFlow C = 128 out_proj 140 -> 104 us, SpeedySpeech Linear layers)
     const int k_total = (a.ntaps ? a.ntaps : a.taps) * a.Cin + a.Cin2;
-    static const int h3_min_k = getenv("PK_GEMM_H3_MINK") ? atoi(getenv("PK_GEMM_H3_MINK")) : 128;
+    static const int h3_min_k = pk_prof_env("PK_GEMM_H3_MINK") ? atoi(pk_prof_env("PK_GEMM_H3_MINK")) : 128;
     const bool h3 = a.math == PK_GEMM_MATH_F16X3 && a.Wh && a.Cin % PK_GEMM_HBK == 0 && a.Cin2 % PK_GEMM_HBK == 0 &&
                     k_total >= h3_min_k;
     const int bk = h3 ? PK_GEMM_HBK : BK;
@@ -707,9 +707,9 @@ int pk_gemm_launch(pk_ctx* ctx, const char* prof_name, const pk_gemm_args& in) {
         const long slots2 = 2L * ctx->n_cu, slots3 = 3L * ctx->n_cu;
         const long wg2 = (long)grid.x * grid.y, wg1 = (long)((a.M + 63) / 64) * grid.y;
         const double t2 = (double)((wg2 + slots2 - 1) / slots2);            // rounds of full-size work
-        static const double small_factor = getenv("PK_GEMM_SMALL_FACTOR") ? atof(getenv("PK_GEMM_SMALL_FACTOR")) : 0.7;
+        static const double small_factor = pk_prof_env("PK_GEMM_SMALL_FACTOR") ? atof(pk_prof_env("PK_GEMM_SMALL_FACTOR")) : 0.7;
         const double t1 = small_factor * (double)((wg1 + slots3 - 1) / slots3);   // half-size tiles, 3 per CU share the pipes
-        static const int force = getenv("PK_GEMM_TILE") ? atoi(getenv("PK_GEMM_TILE")) : 0;   // 64 / 128: measurement override
+        static const int force = pk_prof_env("PK_GEMM_TILE") ? atoi(pk_prof_env("PK_GEMM_TILE")) : 0;   // 64 / 128: measurement override
         if (force == 64 || (force != 128 && t1 < t2)) {
             dim3 g1((a.M + 63) / 64, grid.y);
             PK_LAUNCH(ctx, nm.c_str(), k_gemm_h3<1>, g1, dim3(256), 0, a);

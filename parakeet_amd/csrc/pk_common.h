@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -13,6 +14,20 @@
 #include "pk_synth.h"
 
 void pk_set_error(const char* fmt, ...);
+
+// Measurement / ablation switches (environment variables read by the launchers: tile overrides, timing ablations that give
+// WRONG results, traces) exist only in the profile build -- parakeet_amd/build.py build(profile=True) compiles
+// libpk_synth_prof.so with -DPK_PROFILE_BUILD=1, the tools/ scripts load that one.  In the product library this function is
+// a constant nullptr: every `if (pk_prof_env("PK_..."))` folds away at compile time, the names do not reach the binary and
+// no environment variable changes what the library computes.  Behaviour a caller may legitimately choose goes through the
+// documented pk_*_set_math / pk_*_set_option calls of pk_synth.h.
+#ifndef PK_PROFILE_BUILD
+#define PK_PROFILE_BUILD 0
+#endif
+static inline const char* pk_prof_env(const char* name) {
+    if constexpr (PK_PROFILE_BUILD != 0) return std::getenv(name);
+    else return nullptr;
+}
 
 #define PK_FAIL(code, ...)            \
     do {                              \

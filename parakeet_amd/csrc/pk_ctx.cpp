@@ -20,7 +20,11 @@ extern "C" const char* pk_last_error(void) { return g_err; }
 #ifndef PK_SOURCE_HASH
 #define PK_SOURCE_HASH "unknown"
 #endif
-extern "C" const char* pk_version(void) { return "parakeet_amd 0.2 (gfx950) PK_SOURCE_HASH=" PK_SOURCE_HASH ";"; }
+#define PK_STR2(x) #x
+#define PK_STR(x) PK_STR2(x)
+extern "C" const char* pk_version(void) {
+    return "parakeet_amd 0.4 (gfx950) PK_SOURCE_HASH=" PK_SOURCE_HASH "; PK_PROFILE_BUILD=" PK_STR(PK_PROFILE_BUILD) ";";
+}
 
 extern "C" int pk_ctx_create(int device_id, pk_ctx** out) {
     if (!out) PK_FAIL(PK_EINVAL, "pk_ctx_create: out is NULL");

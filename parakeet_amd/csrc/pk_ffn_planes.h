@@ -58,6 +58,8 @@ struct FfnpConv {
     // second conv (out == NULL): x[row][:] += conv + bias (fp32 row-major, ldx floats per row)
     float* x;
     int ldx;
+    int variant = 0;       // tiling override (the owner's "ffnp_variant" option): first digit 8 / 4 = 256 / 128 columns per wave in
+                           // the first conv, second digit = waves per workgroup of the second conv; 0 = by shape
 };
 int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a);
 // Linear layer (one tap).  ldin == 0: planes in, weights packed for FFNP_NQL tiles per wave, x[row][:] = in . W + bias.

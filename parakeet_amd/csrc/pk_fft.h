@@ -81,6 +81,11 @@ struct pk_fft_core {
     int math = PK_GEMM_MATH_F16X3;   // dense layers: 3-term split-fp16 MFMA (fp32-equivalent error) or exact fp32
     bool attn_lds = true;            // measurement switch (PK_FS2_ATTN_NO_LDS): per-wave K/V loads instead
     bool no_bounds = false;          // measurement switch (PK_FS2_NO_BOUNDS): block maxima by passes over the data
+    // options (pk_fs2_set_option / pk_tts_set_option)
+    bool ffn_planes = true;          // "ffn_planes": feed-forward convs on the planes kernels (pk_ffn_planes.h) where packed for them
+    int ffn_planes_min_blocks = 0;   // "ffn_planes_min_blocks": timelines shorter than this many 32-row blocks stay on the tile GEMM
+    int ffnp_variant = 0;            // "ffnp_variant": tiling override of the planes kernels (ffnp_conv_launch), 0 = by shape
+    int attn_waves = 0;              // "attn_waves": 4 / 8 query tiles per attention workgroup, 0 = by shape
     int max_len = 0;                 // rows of the positional table
     pk_dbuf d_pe, d_div;
     pk_dbuf d_x, d_h, d_qkv, d_ctx, d_f, d_lnamax, d_cbnd, d_fbnd, d_segb, d_cat;

@@ -237,6 +237,36 @@ __global__ __launch_bounds__(256) void k_pwg_tile_scales(const int* __restrict__
     }
 }
 
+// "scale_guard" (pk_pwg_set_option): the measured side of the a-priori bound.  max|x| per utterance of one layer's planes --
+// a workgroup per 256-sample work tile decodes its 8 blocks ((hi + lo) / 2^k) and folds the tile's maximum into amax[utterance]
+// (non-negative floats order like their bit patterns).  30 + 1 launches per guarded inference, none otherwise: the layer
+// kernel itself is untouched.
+__global__ __launch_bounds__(256) void k_pwg_planes_amax(const float* __restrict__ x, const int* __restrict__ tile_t0,
+                                                         const int* __restrict__ tile_utt, const int* __restrict__ tile_kx,
+                                                         unsigned* __restrict__ amax) {
+    __shared__ float red[4];
+    const int tile = blockIdx.x;
+    const long blk0 = (long)(tile_t0[tile] & ~255) >> 5;
+    const pl_f16x8* src = reinterpret_cast<const pl_f16x8*>(reinterpret_cast<const char*>(x) + blk0 * (long)(XBLK_FLOATS * 4));
+    float m = 0.f;
+    // a block: [octet 8][sample 32][hi 8 | lo 8] halves = 512 vectors of 8 halves, hi at even, lo at odd vector indices
+#pragma unroll
+    for (int i = 0; i < (TILE / XBLK) * 256 / 256; ++i) {
+        const int pair = i * 256 + threadIdx.x;   // 0 .. 2047: (hi, lo) pairs of the tile
+        const pl_f16x8 vh = src[2 * pair], vl = src[2 * pair + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)vh[e] + (float)vl[e]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * pow2f(-tile_kx[tile]);
+        atomicMax(amax + tile_utt[tile], __float_as_uint(m));
+    }
+}
+
 // Test tap: the sample-rate aux contribution of one layer, aux[co][s] =
 // sum_j T[class][phase][j] * P[frame + j - 2][layer*G + co], written channel-major for one utterance.
 // (frame-indexed: row0 = P row of the utterance's frame 0, n_frames frames, hop threads per block)
@@ -1334,9 +1364,32 @@ struct pk_pwg {
     int dbg = 0;
     bool planes_on = true;     // x as pre-split fp16 planes under the split-fp16 math (k_pwg_layer_b3<..., PL>); PK_PWG_PLANES=0: off
     bool last_planes = false;  // ... and whether the last run used them (debug tap 1 decodes)
+    // "scale_guard": 0 off, 1 the first inference after finalize, 2 every inference.  A guarded inference on the planes path
+    // measures max|x| per utterance and layer (k_pwg_planes_amax) and compares with the a-priori bound of k_pwg_tile_scales
+    int scale_guard = 1;
+    bool guard_done = false;   // mode 1: a guarded inference has run since finalize
+    bool fell_back = false;    // the bound overshot by more than 2^GUARD_MAX_LOG2: the handle left the planes path
+    std::vector<float> overshoot_log2;   // [layers + 1] of the last guarded inference (max over utterances)
+    std::vector<float> cl_host;          // c_l of the bound, as uploaded to d_cl
+    pk_dbuf ws_amax;
     unsigned long long seed = 0, rng_offset = 0;   // internal noise stream (noise == NULL)
     long chunk_samples = 1L << 40;                  // residual-stack chunk (env PK_PWG_CHUNK_SAMPLES); default: one chunk
 };
+
+// Timing ablations of the layer kernel (PK_PWG_ABLATE -> pk_pwg::dbg; results are WRONG): instantiated in the profile build only
+template <bool PROF>
+static int pwg_ablation_launch(pk_ctx* ctx, int dbg, int grid, dim3 blk, const PwgLayerArgs& a) {
+    if constexpr (PROF) {
+        if (dbg == 1) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 1>), dim3(grid), blk, 0, a);
+        else if (dbg == 32) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 2>), dim3(grid), blk, 0, a);
+        else if (dbg == 96) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 6>), dim3(grid), blk, 0, a);
+        else if (dbg == 160) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 10>), dim3(grid), blk, 0, a);
+        else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true>), dim3(grid), blk, 0, a);
+        return PK_OK;
+    } else {
+        PK_FAIL(PK_ESTATE, "ablation switches exist in the profile build only");
+    }
+}
 
 extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
     if (!ctx || !cfg || !out) PK_FAIL(PK_EINVAL, "pk_pwg_create: NULL argument");
@@ -1378,10 +1431,10 @@ extern "C" int pk_pwg_create(pk_ctx* ctx, const pk_pwg_cfg* cfg, pk_pwg** out) {
     h->max_dilation = 1 << (lps - 1);
     h->gap = ((h->max_dilation + TILE - 1) / TILE) * TILE;
     if (h->gap < TILE) h->gap = TILE;
-    if (const char* e = getenv("PK_PWG_ABLATE")) h->dbg = atoi(e);   // profiling only: results are wrong when set
-    if (const char* e = getenv("PK_PWG_PLANES")) h->planes_on = e[0] != '0';   // PK_PWG_PLANES=0: x as fp32 with per-block scales (round 2)
-    if (const char* e = getenv("PK_PWG_CHUNK_SAMPLES")) h->chunk_samples = std::max(1L, atol(e));
-    if (const char* e = getenv("PK_PWG_MATH"))
+    if (const char* e = pk_prof_env("PK_PWG_ABLATE")) h->dbg = atoi(e);   // profile build only: results are wrong when set
+    if (const char* e = pk_prof_env("PK_PWG_PLANES")) h->planes_on = e[0] != '0';   // PK_PWG_PLANES=0: x as fp32 with per-block scales (round 2)
+    if (const char* e = pk_prof_env("PK_PWG_CHUNK_SAMPLES")) h->chunk_samples = std::max(1L, atol(e));
+    if (const char* e = pk_prof_env("PK_PWG_MATH"))
         h->math = strcmp(e, "bf16x3") == 0 ? PK_PWG_MATH_BF16X3 : (strcmp(e, "f16x3") == 0 ? PK_PWG_MATH_F16X3 : PK_PWG_MATH_F32);
     *out = h;
     return PK_OK;
@@ -1422,6 +1475,28 @@ extern "C" int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_pwg_set_chunk_samples: handle is NULL");
     if (samples <= 0) PK_FAIL(PK_EINVAL, "pk_pwg_set_chunk_samples: must be positive");
     h->chunk_samples = samples;
+    return PK_OK;
+}
+
+extern "C" int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value) {
+    if (!h || !key) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: NULL argument");
+    if (strcmp(key, "planes") == 0) {
+        h->planes_on = value != 0;
+        if (h->planes_on) h->fell_back = false;
+    } else if (strcmp(key, "scale_guard") == 0) {
+        if (value < 0 || value > 2) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: scale_guard %lld (0, 1, 2)", (long long)value);
+        h->scale_guard = (int)value;
+    } else PK_FAIL(PK_EINVAL, "pk_pwg_set_option: unknown option '%s'", key);
+    return PK_OK;
+}
+
+extern "C" int pk_pwg_scale_overshoot(pk_pwg* h, float* log2_overshoot, int32_t n, int32_t* fell_back) {
+    if (!h || !log2_overshoot) PK_FAIL(PK_EINVAL, "pk_pwg_scale_overshoot: NULL argument");
+    if (h->overshoot_log2.empty()) PK_FAIL(PK_ESTATE, "pk_pwg_scale_overshoot: no guarded inference has run (option \"scale_guard\")");
+    if (n != (int32_t)h->overshoot_log2.size())
+        PK_FAIL(PK_ESHAPE, "pk_pwg_scale_overshoot: expected %d floats (layers + 1)", (int)h->overshoot_log2.size());
+    memcpy(log2_overshoot, h->overshoot_log2.data(), (size_t)n * sizeof(float));
+    if (fell_back) *fell_back = h->fell_back ? 1 : 0;
     return PK_OK;
 }
 
@@ -1679,6 +1754,8 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         PK_TRY(pk_upload(ctx, h->d_w2, W2.data(), W2.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_bias, B.data(), B.size() * sizeof(float)));
         PK_TRY(pk_upload(ctx, h->d_cl, cl_h.data(), cl_h.size() * sizeof(float)));
+        h->cl_host = cl_h;
+        h->guard_done = false;   // new weights: the next inference is guarded again (scale_guard 1)
         {   // bias image of the scaled path: stage-2 accumulators start from 2^14 * 2^k2 * bias
             std::vector<float> Bh(B);
             for (int l = 0; l < c.layers; ++l) {
@@ -1926,7 +2003,19 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     }
     // ---- first conv
     // (planes: lane offsets into x are 32-bit byte offsets)
-    const bool planes = h->planes_on && h->math == PK_PWG_MATH_F16X3 && h->dbg == 0 && (size_t)R * Ttot * 4 < ((size_t)1 << 32);
+    bool planes = h->planes_on && h->math == PK_PWG_MATH_F16X3 && h->dbg == 0 && (size_t)R * Ttot * 4 < ((size_t)1 << 32);
+    // a guarded inference (option "scale_guard") measures max|x| per utterance and layer next to the a-priori bound; should
+    // the bound overshoot by more than 2^GUARD_MAX_LOG2 the stack is run again on the fp32-x path (second pass of this loop:
+    // the noise, the conditioning P and the zeroed gaps are all still in place), which the handle then keeps
+    constexpr float GUARD_MAX_LOG2 = 10.f;
+    const bool guard = planes && (h->scale_guard == 2 || (h->scale_guard == 1 && !h->guard_done));
+    unsigned* amax = nullptr;
+    if (guard) {
+        PK_TRY(h->ws_amax.reserve((size_t)(c.layers + 1) * B * sizeof(unsigned)));
+        amax = h->ws_amax.as<unsigned>();
+        PK_HIP(hipMemsetAsync(amax, 0, (size_t)(c.layers + 1) * B * sizeof(unsigned), ctx->stream));
+    }
+    for (int attempt = 0;; ++attempt) {
     h->last_planes = planes;
     int* tkx = nullptr;
     if (planes) {
@@ -1950,6 +2039,9 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     else
         PK_LAUNCH(ctx, "pwg_first", k_pwg_first<false>, dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
                   h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab, tkx);
+    if (guard && planes)
+        PK_LAUNCH(ctx, "pwg_planes_amax", k_pwg_planes_amax, dim3(sumC), dim3(256), 0, h->ws_x0.as<float>(), d_tab + o_tile,
+                  d_tab + o_tutt, tkx, amax);
     // ---- residual stack.  Optionally the batch is cut into chunks of whole utterances whose x ping-pong +
     // skip buffers (3 x 256 B per sample) fit the 256 MB Infinity Cache, all layers running over one chunk
     // before the next.  A pure load/store kernel with this access pattern gains from that (tools/micro/
@@ -2031,10 +2123,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                     }
                 } else if (half) {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true>), dim3(grid), blk, 0, a);
-                    else if (h->dbg == 1) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 1>), dim3(grid), blk, 0, a);
-                    else if (h->dbg == 32) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 2>), dim3(grid), blk, 0, a);
-                    else if (h->dbg == 96) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 6>), dim3(grid), blk, 0, a);
-                    else if (h->dbg == 160) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 10>), dim3(grid), blk, 0, a);
+                    else if (h->dbg != 0) PK_TRY(pwg_ablation_launch<PK_PROFILE_BUILD != 0>(ctx, h->dbg, grid, blk, a));
                     else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true>), dim3(grid), blk, 0, a);
                 } else {
                     if (l == 0) PK_LAUNCH(ctx, "pwg_layer_b3", (k_pwg_layer_b3<true, false>), dim3(grid), blk, 0, a);
@@ -2047,9 +2136,39 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<true, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
             else
                 PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<false, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
+            if (guard && planes)
+                PK_LAUNCH(ctx, "pwg_planes_amax", k_pwg_planes_amax, dim3(ntile), dim3(256), 0, a.xout, a.tile_t0, a.gen.tile_utt,
+                          a.tile_kx_out, amax + (size_t)(l + 1) * B);
         }
         }
         h->last_x_final = c.layers & 1;
+    }
+    if (!(guard && attempt == 0)) break;
+    {   // the verdict of the guard: bound (the recursion of k_pwg_tile_scales, on the host) against the measured maxima
+        std::vector<float> am((size_t)(c.layers + 1) * B), nmax(B);
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+        PK_HIP(hipMemcpy(am.data(), amax, am.size() * sizeof(float), hipMemcpyDeviceToHost));
+        PK_HIP(hipMemcpy(nmax.data(), h->ws_nmax.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost));
+        h->overshoot_log2.assign(c.layers + 1, 0.f);
+        float worst = 0.f;
+        for (int b = 0; b < B; ++b) {
+            if (frames[b] <= 0) continue;
+            float bound = std::fma(h->first_wmax, nmax[b], h->first_bmax) * 1.001f;
+            for (int l = 0; l <= c.layers; ++l) {
+                const float m = am[(size_t)l * B + b];
+                // (an all-zero stream has no precision to lose)
+                const float o = m > 0.f ? std::log2(bound / m) : 0.f;
+                h->overshoot_log2[l] = std::max(h->overshoot_log2[l], o);
+                worst = std::max(worst, o);
+                if (l < c.layers) bound = (bound + h->cl_host[l]) * (0.70710678118654752440f * 1.001f);
+            }
+        }
+        h->guard_done = true;
+        if (worst <= GUARD_MAX_LOG2) break;
+        h->planes_on = false;
+        h->fell_back = true;
+        planes = false;
+    }
     }
     // ---- last layers
     {
@@ -2162,7 +2281,7 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
                        &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1h, &h->d_l1b, &h->d_l2,
                        &h->d_bias_h, &h->ws_xe0, &h->ws_xe1,
                        &h->ws_mel, &h->ws_cin, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
-                       &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab, &h->d_cl, &h->ws_nmax, &h->ws_tkx};
+                       &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab, &h->d_cl, &h->ws_nmax, &h->ws_tkx, &h->ws_amax};
     for (auto* b : bufs) b->release();
     delete h;
 }

@@ -367,7 +367,7 @@ extern "C" int pk_ss_create(pk_ctx* ctx, const pk_ss_cfg* cfg, pk_ss** out) {
     upd(c.decoder_kernel_size, 1);
     h->gap = reach;
     h->lead = std::max(8, reach);
-    if (const char* e = getenv("PK_SS_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
+    if (const char* e = pk_prof_env("PK_SS_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     *out = h;
     return PK_OK;
 }

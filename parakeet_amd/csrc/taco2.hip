@@ -436,7 +436,7 @@ extern "C" int pk_taco_create(pk_ctx* ctx, const pk_taco_cfg* cfg, pk_taco** out
     h->adim = c.d_encoder;
     h->aheads = 1;
     h->gapr = gapr;
-    if (const char* e = getenv("PK_TACO_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
+    if (const char* e = pk_prof_env("PK_TACO_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     *out = h;
     return PK_OK;
 }
@@ -732,8 +732,8 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
     const float dscale = 1.0f / (1.0f - p);
     const size_t lsa_smem = (size_t)(8 + maxT + 4) * sizeof(float);
     if (lsa_smem > 60 * 1024) PK_FAIL(PK_EUNSUPPORTED, "pk_taco_infer: %d tokens exceed the attention kernel's LDS budget", maxT);
-    static const int poll = getenv("PK_TACO_POLL") ? std::max(1, atoi(getenv("PK_TACO_POLL"))) : 8;
-    static const bool use_rg = getenv("PK_AR_ROWGEMM") ? atoi(getenv("PK_AR_ROWGEMM")) != 0 : true;
+    static const int poll = pk_prof_env("PK_TACO_POLL") ? std::max(1, atoi(pk_prof_env("PK_TACO_POLL"))) : 8;
+    static const bool use_rg = pk_prof_env("PK_AR_ROWGEMM") ? atoi(pk_prof_env("PK_AR_ROWGEMM")) != 0 : true;
     float* pq = pk_fft_act_ptr(h->d_pq, Da);
     // row GEMM of one of the per-step layers (B rows)
     // LSTMCell on the row GEMM: gates = [x | context | h] . [W_ih^T ; W_hh^T] + b, cell finished in the epilogue

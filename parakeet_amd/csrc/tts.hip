@@ -300,6 +300,7 @@ struct pk_tts : pk_fft_core {
     bool finalized = false, inferred = false;
     int gapr = 1;
     bool dropout = true;
+    bool kv_prefix = false;            // "kv_prefix" option (pk_tts_set_option), see pk_tts_infer
     // weights
     size_t emb_table = 0;
     float alpha_enc = 1.f, alpha_dec = 1.f;
@@ -356,7 +357,7 @@ extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
     if (c.adim % 64 != 0 || c.adim > 64 * PK_FFT_LN_MAXPER)
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: adim must be a multiple of 64, <= %d", 64 * PK_FFT_LN_MAXPER);
     if (c.reduction_factor < 1 || c.reduction_factor > 16) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: reduction_factor must be in [1, 16]");
-    if ((!c.decoder_normalize_before || c.decoder_concat_after) && getenv("PK_AR_ROWGEMM") && atoi(getenv("PK_AR_ROWGEMM")) == 0)
+    if ((!c.decoder_normalize_before || c.decoder_concat_after) && pk_prof_env("PK_AR_ROWGEMM") && atoi(pk_prof_env("PK_AR_ROWGEMM")) == 0)
         PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: post-norm / concat_after decoder blocks run on the row-GEMM path only");
     if (c.spk_embed_dim < 0 || c.spk_embed_dim > 8192) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: spk_embed_dim must be in [0, 8192]");
     if (c.spk_embed_dim > 0 && c.spk_embed_integration_type != 0 && c.spk_embed_integration_type != 1)
@@ -403,7 +404,7 @@ extern "C" int pk_tts_create(pk_ctx* ctx, const pk_tts_cfg* cfg, pk_tts** out) {
     h->aheads = c.aheads;
     h->gapr = gapr;
     h->gst.cfg = gc;
-    if (const char* e = getenv("PK_TTS_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
+    if (const char* e = pk_prof_env("PK_TTS_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     *out = h;
     return PK_OK;
 }
@@ -433,6 +434,16 @@ extern "C" int pk_tts_set_math(pk_tts* h, int32_t mode) {
     if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3) PK_FAIL(PK_EINVAL, "pk_tts_set_math: unknown mode %d", mode);
     h->math = mode;
     return PK_OK;
+}
+
+int pk_fft_set_option(pk_fft_core* h, const char* key, int64_t value, const char* who);   // fs2.hip
+extern "C" int pk_tts_set_option(pk_tts* h, const char* key, int64_t value) {
+    if (!h || !key) PK_FAIL(PK_EINVAL, "pk_tts_set_option: NULL argument");
+    if (strcmp(key, "kv_prefix") == 0) {
+        h->kv_prefix = value != 0;
+        return PK_OK;
+    }
+    return pk_fft_set_option(h, key, value, "pk_tts_set_option");
 }
 
 extern "C" int pk_tts_set_speakers(pk_tts* h, const float* spembs, int32_t B) {
@@ -929,12 +940,12 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     const unsigned thr = h->dropout ? pk_dropout_threshold(0.5) : 0u;   // F.dropout's default p (decoder.py:80)
     const float dscale = 2.0f;
     const float att_scale = (float)(1.0 / std::sqrt((double)dk));
-    static const int poll = getenv("PK_TTS_POLL") ? std::max(1, atoi(getenv("PK_TTS_POLL"))) : 4;
+    static const int poll = pk_prof_env("PK_TTS_POLL") ? std::max(1, atoi(pk_prof_env("PK_TTS_POLL"))) : 4;
     const bool use_ham = h->math == PK_GEMM_MATH_F16X3;
-    static const bool use_rg = getenv("PK_AR_ROWGEMM") ? atoi(getenv("PK_AR_ROWGEMM")) != 0 : true;
+    static const bool use_rg = pk_prof_env("PK_AR_ROWGEMM") ? atoi(pk_prof_env("PK_AR_ROWGEMM")) != 0 : true;
     // Experiment, off by default (not yet measured on a GPU): layer 0's query is needed for the NEW rows only, so the
     // prefix GEMM can project k | v alone (2/3 of its work) and the B new queries come from a row GEMM.
-    const bool kv_prefix = getenv("PK_TTS_KV_PREFIX") ? atoi(getenv("PK_TTS_KV_PREFIX")) != 0 : false;   // read per call
+    const bool kv_prefix = h->kv_prefix;
     // y = [LayerNorm(x)] . W + b [ReLU] [+ res] for the B new rows of a step (pk_rowgemm.h)
     auto rowgemm = [&](const char* name, const RowW& w, const float* x, int ldx, float* y, int ldy, int act, const float* res,
                        int ldr, size_t ln_g, size_t ln_b, bool ln) -> int {

@@ -160,7 +160,7 @@ struct pk_wf {
     pk_dbuf arena16;
     int math = PK_GEMM_MATH_F16X3;
     unsigned long long seed = 0, rng_offset = 0;   // internal latent stream (z == NULL)
-    bool no_fuse = getenv("PK_WF_NO_FUSE") != nullptr;   // measurement switch: separate out_proj launches
+    bool no_fuse = pk_prof_env("PK_WF_NO_FUSE") != nullptr;   // measurement switch: separate out_proj launches
     int mp = 96;              // mel channels padded to a multiple of 32 (GEMM K block of the condition)
     std::vector<WfFlowW> flows;
     std::vector<size_t> up_w;
@@ -192,7 +192,7 @@ extern "C" int pk_wf_create(pk_ctx* ctx, const pk_wf_cfg* cfg, pk_wf** out) {
     h->cfg = c;
     h->gapw = 1 << (c.n_layers - 1);
     h->mp = ((c.n_mels + PK_GEMM_HBK - 1) / PK_GEMM_HBK) * PK_GEMM_HBK;
-    if (const char* e = getenv("PK_WF_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
+    if (const char* e = pk_prof_env("PK_WF_MATH")) h->math = strcmp(e, "f32") == 0 ? PK_GEMM_MATH_F32 : PK_GEMM_MATH_F16X3;
     *out = h;
     return PK_OK;
 }
@@ -228,12 +228,19 @@ extern "C" int pk_wf_set_seed(pk_wf* h, uint64_t seed) {
     return PK_OK;
 }
 
+// ONE predicate for "this model runs on the fused layer kernel (wf_layer.hip)": the kernel is built for 64 / 128 channels and a
+// condition block of WFL_MP = 96 channels of which one must be free -- channel n_mels carries the folded biases
+// (k_wf_cond_planes).  Used by finalize (what gets packed), by pk_wf_infer (which path runs) and by pk_wf_set_math.
+static bool wfl_usable(const pk_wf* h) {
+    return wfl_supports(h->cfg.channels) && h->mp == WFL_MP && h->cfg.n_mels < WFL_MP && !h->no_fuse;
+}
+
 extern "C" int pk_wf_set_math(pk_wf* h, int32_t mode) {
     if (!h) PK_FAIL(PK_EINVAL, "pk_wf_set_math: handle is NULL");
     if (mode != PK_GEMM_MATH_F32 && mode != PK_GEMM_MATH_F16X3 && mode != PK_GEMM_MATH_F16)
         PK_FAIL(PK_EINVAL, "pk_wf_set_math: unknown mode %d", mode);
-    if (mode == PK_GEMM_MATH_F16 && !(wfl_supports(h->cfg.channels) && !h->no_fuse))
-        PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_math: the fp16-operand mode runs on the fused layer kernel (64 or 128 channels)");
+    if (mode == PK_GEMM_MATH_F16 && !wfl_usable(h))
+        PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_math: the fp16-operand mode runs on the fused layer kernel (64 or 128 channels, n_mels in (64, 96))");
     h->math = mode;
     return PK_OK;
 }
@@ -313,7 +320,7 @@ extern "C" int pk_wf_finalize(pk_wf* h) {
             pk_gemm_pack_h3(kn2.data(), C, 2 * C, ph);
             F.layers[l].w2h = put16(h->arena16_h, ph);
             F.layers[l].b2 = ar.put(bo);
-            if (wfl_supports(C) && MP == WFL_MP)
+            if (wfl_usable(h))
             {
                 F.layers[l].fl = wfl_pack(C, wc.data(), bc.data(), wp.data(), bp.data(), M, wo.data(), bo.data(),
                                           w_out_flow.data(), h->arena16_h, h->arena_h);
@@ -455,7 +462,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     // block scaling of the split-fp16 GEMMs (pk_split.h): max|row| of every hist / cond row, kept next to the data
     // so that a launch only scans the one row set that is new (zero = margins, gaps and rows not yet written)
     // (the fused layer kernel keeps block maxima instead, one per 32 positions, in the same buffers)
-    const bool use_wfl = wfl_supports(C) && MP == WFL_MP && (h->math == PK_GEMM_MATH_F16X3 || h->math == PK_GEMM_MATH_F16) && !h->no_fuse;
+    const bool use_wfl = wfl_usable(h) && (h->math == PK_GEMM_MATH_F16X3 || h->math == PK_GEMM_MATH_F16);
     const long bstride = pstride / WFL_BLK;   // blocks per buffer row incl. margins
     PK_TRY(h->ws_hamax.reserve((size_t)(NL + 1) * 3 * pstride * 4));
     PK_TRY(h->ws_camax.reserve((size_t)G * pstride * 4));
@@ -513,7 +520,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
 
     // profiling only (PK_WF_ABLATE=16): the layer kernel's s_memtime stamps, printed after the last launch
     unsigned long long* d_trace = nullptr;
-    static const bool want_trace = getenv("PK_WF_ABLATE") && atoi(getenv("PK_WF_ABLATE")) == 16;
+    static const bool want_trace = pk_prof_env("PK_WF_ABLATE") && atoi(pk_prof_env("PK_WF_ABLATE")) == 16;
     if (want_trace) {
         PK_TRY(h->ws_trace.reserve(8 * 2 * 24 * sizeof(unsigned long long)));
         PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, 8 * 2 * 24 * sizeof(unsigned long long), ctx->stream));
@@ -583,7 +590,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 w.pos_utt = rowvalid;
                 w.npos_alloc = npos_alloc;
                 {   // the layer kernel that runs next: l + 1, else layer 0 of the next row, else of the next flow
-                    static const bool prefetch = getenv("PK_WF_PREFETCH") ? atoi(getenv("PK_WF_PREFETCH")) != 0 : true;
+                    static const bool prefetch = pk_prof_env("PK_WF_PREFETCH") ? atoi(pk_prof_env("PK_WF_PREFETCH")) != 0 : true;
                     const WfLayerW* nx = l + 1 < NL ? &F.layers[l + 1] : (i + 1 < G ? &F.layers[0] : (fl > 0 ? &h->flows[fl - 1].layers[0] : nullptr));
                     w.next_w1 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w1 : nullptr;
                     w.next_w2 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w2 : nullptr;

@@ -790,6 +790,28 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
     return o;
 }
 
+// Timing ablations and the s_memtime trace (PK_WF_ABLATE; results are WRONG): instantiated in the profile build only
+// (parakeet_amd/build.py build(profile=True)).  Returns 1 when no ablation applies.
+template <bool PROF, class Go>
+static int wfl_ablation(Go& go, bool shape_ok, bool trace) {
+    if constexpr (PROF) {
+        static const int abl = pk_prof_env("PK_WF_ABLATE") ? atoi(pk_prof_env("PK_WF_ABLATE")) : 0;
+        if (abl && shape_ok) {
+            switch (abl) {
+                case 1: return go(k_wf_layer_p<2, 3, 1>);
+                case 4: return go(k_wf_layer_p<2, 3, 4>);
+                case 8: return go(k_wf_layer_p<2, 3, 8>);
+                case 9: return go(k_wf_layer_p<2, 3, 9>);
+                case 13: return go(k_wf_layer_p<2, 3, 13>);
+                case 16: if (trace) return go(k_wf_layer_p<2, 3, 16>); break;
+                case 32: return go(k_wf_layer_p<2, 3, 32>);   // A fragments one co-tile ahead (A/B of the LDS prefetch depth)
+                default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16 or 32");
+            }
+        }
+    }
+    return 1;
+}
+
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     if (!wfl_supports(a.C) || a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9)
         PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (C %d, npos %d, taps %d)", a.C, a.npos_alloc, a.ntap);
@@ -798,7 +820,7 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         PK_FAIL(PK_EUNSUPPORTED, "wfl_layer_launch: %d positions per row exceed the 32-bit operand offsets; split the batch", a.npos_alloc);
     const int ntiles = a.npos_alloc / WAVE_T;
     WflLaunch b = a;
-    static const int active_env = getenv("PK_WF_ACTIVE") ? atoi(getenv("PK_WF_ACTIVE")) : WAVES;   // measurement switch
+    static const int active_env = pk_prof_env("PK_WF_ACTIVE") ? atoi(pk_prof_env("PK_WF_ACTIVE")) : WAVES;   // measurement switch
     b.active = active_env >= 1 && active_env <= WAVES ? active_env : WAVES;
     b.tiles_per_wg = std::max(1, (ntiles + ctx->n_cu - 1) / ctx->n_cu);
     const int grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
@@ -807,19 +829,7 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         return PK_OK;
     };
     const int nt = a.ntap / 3;
-    static const int abl = getenv("PK_WF_ABLATE") ? atoi(getenv("PK_WF_ABLATE")) : 0;   // profiling only: results are wrong
-    if (abl && a.C == 64 && nt == 3 && !a.f16) {
-        switch (abl) {
-            case 1: return go(k_wf_layer_p<2, 3, 1>);
-            case 4: return go(k_wf_layer_p<2, 3, 4>);
-            case 8: return go(k_wf_layer_p<2, 3, 8>);
-            case 9: return go(k_wf_layer_p<2, 3, 9>);
-            case 13: return go(k_wf_layer_p<2, 3, 13>);
-            case 16: if (b.trace) return go(k_wf_layer_p<2, 3, 16>); break;
-            case 32: return go(k_wf_layer_p<2, 3, 32>);   // A fragments one co-tile ahead (A/B of the LDS prefetch depth)
-            default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16 or 32");
-        }
-    }
+    if (int st = wfl_ablation<PK_PROFILE_BUILD != 0>(go, a.C == 64 && nt == 3 && !a.f16, b.trace != nullptr); st != 1) return st;
     if (a.f16) {
         if (a.C == 64)
             return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true>) : go(k_wf_layer_p<2, 3, 0, true>));

@@ -130,6 +130,11 @@ class FastSpeech2:
         """'f16x3' (default: 3-term split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
         _capi.check(self._ctx.lib.pk_fs2_set_math(self._h, {"f32": 0, "f16x3": 1}[mode]))
 
+    def set_option(self, key, value):
+        """Named integer options of the engine handle (include/pk_synth.h, pk_fs2_set_option): 'ffn_planes',
+        'ffn_planes_min_blocks', 'ffnp_variant', 'attn_waves'.  The library reads no environment variable."""
+        _capi.check(self._ctx.lib.pk_fs2_set_option(self._h, key.encode(), int(value)))
+
     def set_debug(self, on=True):
         _capi.check(self._ctx.lib.pk_fs2_set_debug(self._h, 1 if on else 0))
 

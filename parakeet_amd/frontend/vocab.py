@@ -1,9 +1,9 @@
 """Symbol table of the text frontends: the interface of the reference's ``Vocab`` (parakeet/frontend/vocab.py:20-130 --
 ``lookup`` / ``reverse`` / ``add_symbol(s)``, ``stoi`` / ``itos``, the four ``*_index`` properties) over one ordered
-symbol list and its inverse index.  Ids are positions in that list: the special symbols that are set come first in the
-order pad, unk, start, end, then the caller's symbols in first-seen order."""
-
-from types import MappingProxyType
+symbol table.  Ids are insertion positions: the special symbols that are set come first in the order pad, unk, start, end,
+then the caller's symbols in first-seen order.  ``stoi`` / ``itos`` / ``special_symbols`` are plain dict attributes kept in step
+by ``add_symbol`` -- callers of the reference read AND write them (``vocab.stoi[s] = i``), so they are neither copies nor
+read-only views."""
 
 __all__ = ["Vocab"]
 
@@ -13,17 +13,22 @@ _ROLES = ("padding", "unk", "start", "end")
 class Vocab:
     def __init__(self, symbols, padding_symbol="<pad>", unk_symbol="<unk>", start_symbol="<s>", end_symbol="</s>"):
         self._role = dict(zip(_ROLES, (padding_symbol, unk_symbol, start_symbol, end_symbol)))
-        self._symbols = []            # id -> symbol
-        self._index = {}              # symbol -> id
+        self.stoi = {}                # symbol -> id (insertion ordered)
+        self.itos = {}                # id -> symbol
         self.add_symbols(s for s in self._role.values() if s)      # None / "" means "this table has no such symbol"
-        self.num_specials = len(self._symbols)
+        self.special_symbols = dict(self.stoi)
         self.add_symbols(symbols)
+
+    @property
+    def num_specials(self):
+        return len(self.special_symbols)
 
     # -- growing the table -------------------------------------------------------------------------------------------
     def add_symbol(self, symbol):
         """Append ``symbol`` with the next free id; a symbol already present keeps its id."""
-        if self._index.setdefault(symbol, len(self._symbols)) == len(self._symbols):
-            self._symbols.append(symbol)
+        n = len(self.stoi)
+        if self.stoi.setdefault(symbol, n) == n:
+            self.itos[n] = symbol
 
     def add_symbols(self, symbols):
         for symbol in symbols:
@@ -32,18 +37,16 @@ class Vocab:
     # -- lookups -----------------------------------------------------------------------------------------------------
     def lookup(self, symbol):
         """Id of ``symbol``; unknown symbols raise KeyError (the callers map them to a fallback themselves)."""
-        return self._index[symbol]
+        return self.stoi[symbol]
 
     def reverse(self, index):
-        if not 0 <= index < len(self._symbols):
-            raise KeyError(index)
-        return self._symbols[index]
+        return self.itos[index]
 
     def __len__(self):
-        return len(self._symbols)
+        return len(self.stoi)
 
     def _special(self, role):
-        return self._index.get(self._role[role], -1)
+        return self.stoi.get(self._role[role], -1)
 
     padding_symbol = property(lambda self: self._role["padding"])
     unk_symbol = property(lambda self: self._role["unk"])
@@ -54,21 +57,8 @@ class Vocab:
     start_index = property(lambda self: self._special("start"))
     end_index = property(lambda self: self._special("end"))
 
-    # -- the reference's public dict views (read-only, in id order) -------------------------------------------
-    @property
-    def stoi(self):
-        return MappingProxyType(self._index)
-
     def __contains__(self, symbol):
-        return symbol in self._index
-
-    @property
-    def itos(self):
-        return dict(enumerate(self._symbols))
-
-    @property
-    def special_symbols(self):
-        return {s: i for i, s in enumerate(self._symbols[:self.num_specials])}
+        return symbol in self.stoi
 
     def __repr__(self):
-        return "Vocab(size: {},\nstoi:\n{})".format(len(self), dict(self._index))
+        return "Vocab(size: {},\nstoi:\n{})".format(len(self), dict(self.stoi))

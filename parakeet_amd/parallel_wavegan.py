@@ -86,6 +86,19 @@ class PWGGenerator:
         m = {"f32": _capi.PK_PWG_MATH_F32, "bf16x3": _capi.PK_PWG_MATH_BF16X3, "f16x3": _capi.PK_PWG_MATH_F16X3}[mode]
         _capi.check(self._ctx.lib.pk_pwg_set_math(self._h, m))
 
+    def set_option(self, key, value):
+        """Named integer options of the engine handle (include/pk_synth.h, pk_pwg_set_option): 'planes', 'scale_guard'."""
+        _capi.check(self._ctx.lib.pk_pwg_set_option(self._h, key.encode(), int(value)))
+
+    def scale_overshoot(self):
+        """(log2(a-priori bound / measured max|x|) per layer input [layers + 1], fell_back) of the last guarded inference
+        (pk_pwg_scale_overshoot)."""
+        import numpy as np
+        out = np.zeros(self.layers + 1, np.float32)
+        fb = C.c_int32(0)
+        _capi.check(self._ctx.lib.pk_pwg_scale_overshoot(self._h, _capi.fptr(out), out.size, C.byref(fb)))
+        return out, bool(fb.value)
+
     def set_chunk_samples(self, samples):
         """Scheduling only (results are unchanged): samples per cache-resident chunk of the residual stack."""
         _capi.check(self._ctx.lib.pk_pwg_set_chunk_samples(self._h, int(samples)))

@@ -122,6 +122,11 @@ class TransformerTTS:
         """'f16x3' (default: split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
         _capi.check(self._ctx.lib.pk_tts_set_math(self._h, {"f32": 0, "f16x3": 1}[mode]))
 
+    def set_option(self, key, value):
+        """Named integer options of the engine handle (include/pk_synth.h, pk_tts_set_option): 'kv_prefix' and the FFT-stack
+        options of FastSpeech2.set_option."""
+        _capi.check(self._ctx.lib.pk_tts_set_option(self._h, key.encode(), int(value)))
+
     def set_dropout(self, on):
         """False switches the decoder prenet's dropout off (deterministic; not what the reference computes)."""
         _capi.check(self._ctx.lib.pk_tts_set_dropout(self._h, 1 if on else 0))

@@ -27,6 +27,23 @@ def test_build_and_exports():
     assert b"gfx950" in lib.pk_version()
 
 
+def test_product_library_carries_no_measurement_switches():
+    """the ablation / measurement switches (several give wrong results by design) exist in the profile build
+    only.  The product library imports no getenv and contains none of the switch names; behaviour a caller may choose goes
+    through pk_*_set_math / pk_*_set_option."""
+    import subprocess
+    from parakeet_amd import build as b
+    b.build()
+    blob = open(b.LIB, "rb").read()
+    for name in (b"ABLATE", b"PK_WF_ACTIVE", b"PK_FS2_ATTN_WAVES", b"PK_GEMM_TILE", b"PK_PWG_PLANES", b"PK_FS2_FFN_PLANES",
+                 b"PK_FFNP_VARIANT", b"PK_TTS_KV_PREFIX", b"_MATH="):
+        assert name not in blob, name
+    assert not re.search(rb"PK_[A-Z0-9]+_MATH\0", blob)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", b.LIB], capture_output=True, text=True).stdout
+    assert "getenv" not in nm
+    assert b"PK_PROFILE_BUILD=0;" in blob
+
+
 def test_binding_covers_header():
     from parakeet_amd import _capi
     bound = set(_capi._declare(_capi.lib()).keys())

@@ -28,6 +28,23 @@ def test_vocab_layout_and_lookup():
     assert list(v2.stoi) == ["<pad>", "<unk>", "x"] and v2.start_index == -1
 
 
+def test_vocab_public_dicts_are_live_attributes():
+    """the reference's ``stoi`` / ``itos`` / ``special_symbols`` are plain dicts its callers read and WRITE
+    (parakeet/frontend/vocab.py:28-45,98-105): same objects on every access, writable, kept in step by add_symbol."""
+    v = Vocab(["a", "b"])
+    assert v.stoi is v.stoi and v.itos is v.itos and v.special_symbols is v.special_symbols
+    assert v.itos == {0: "<pad>", 1: "<unk>", 2: "<s>", 3: "</s>", 4: "a", 5: "b"}
+    assert v.special_symbols == {"<pad>": 0, "<unk>": 1, "<s>": 2, "</s>": 3} and v.num_specials == 4
+    v.add_symbol("c")
+    assert v.itos[6] == "c" and v.stoi["c"] == 6 and len(v) == 7
+    v.stoi["zz"] = 7                      # reference-style mutation by a caller
+    v.itos[7] = "zz"
+    assert v.lookup("zz") == 7 and v.reverse(7) == "zz" and len(v) == 8 and "zz" in v
+    with pytest.raises(KeyError):
+        v.reverse(99)
+    assert str(v) == repr(v) and repr(v).startswith("Vocab(size: 8,")
+
+
 def test_punctuations():
     assert get_punctuations("en") == [" ", "-", "...", ",", ".", "?", "!"]
     assert get_punctuations("cn") == ["、", "，", "；", "：", "。", "？", "！"]

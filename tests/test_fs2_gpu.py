@@ -34,7 +34,7 @@ def _oracle_cfg(cfg):
     return {k: cfg[k] for k in keys}
 
 
-def _check(cfg, tok_lens, seed, alpha=1.0, fixed_duration=None, taps=True, idim=80, odim=80):
+def _check(cfg, tok_lens, seed, alpha=1.0, fixed_duration=None, taps=True, idim=80, odim=80, options=None):
     from oracle import fastspeech2_ref as ref
     from parakeet_amd.fastspeech2 import FastSpeech2
 
@@ -44,6 +44,8 @@ def _check(cfg, tok_lens, seed, alpha=1.0, fixed_duration=None, taps=True, idim=
     model.set_state_dict(state)
     model.eval()
     model.set_debug(True)
+    for k, v in (options or {}).items():
+        model.set_option(k, v)
     outs = model.inference_batch(texts, alpha=alpha)
     for b, ids in enumerate(texts):
         want, parts = ref.inference(state, ids, _oracle_cfg(cfg), alpha=alpha, dtype=torch.float64,
@@ -143,30 +145,24 @@ def test_fs2_split_math_is_scale_invariant(kf, kv, kq):
     assert l1["f16x3"] < 2.0 * l1["f32"] + 5e-7, l1
 
 
-def _planes_env(monkeypatch, variant):
-    """Run norm1 + q|k|v and norm2 + the feed-forward convs on the planes kernels (csrc/ffn_planes.hip) whatever the timeline length; variant:
-    PK_FFNP_VARIANT (first digit 8 / 4: 256 / 128 columns per wave in the first conv, second digit: waves per workgroup of
-    the second), '' = the launcher's own choice."""
-    monkeypatch.setenv("PK_FS2_FFN_PLANES", "1")
-    monkeypatch.setenv("PK_FS2_FFN_PLANES_MIN_BLOCKS", "0")
-    if variant:
-        monkeypatch.setenv("PK_FFNP_VARIANT", variant)
-    else:
-        monkeypatch.delenv("PK_FFNP_VARIANT", raising=False)
+def _planes_options(variant):
+    """Run norm1 + q|k|v and norm2 + the feed-forward convs on the planes kernels (csrc/ffn_planes.hip) whatever the timeline
+    length; variant: the "ffnp_variant" option of pk_fs2_set_option (first digit 8 / 4: 256 / 128 columns per wave in the first
+    conv, second digit: waves per workgroup of the second), 0 = the launcher's own choice."""
+    return {"ffn_planes": 1, "ffn_planes_min_blocks": 0, "ffnp_variant": variant}
 
 
-@pytest.mark.parametrize("variant", ["", "88", "44"])
-def test_fs2_ffn_planes_kernels(monkeypatch, variant):
+@pytest.mark.parametrize("variant", [0, 88, 44])
+def test_fs2_ffn_planes_kernels(variant):
     """The ragged batch of test_fs2_ljspeech_ragged_batch (gaps, 1-token utterances, tiles that straddle utterances, idle
     waves) under each first-conv / second-conv kernel variant: the same bars, internal taps included, and the profile shows
     that the planes kernels are what ran."""
     from parakeet_amd.runtime import Context
-    _planes_env(monkeypatch, variant)
     ctx = Context.get()
     ctx.prof_enable(True)
     ctx.prof_reset()
     try:
-        _check(_cfg(), [37, 5, 64, 1, 23], seed=100)
+        _check(_cfg(), [37, 5, 64, 1, 23], seed=100, options=_planes_options(variant))
         names = set(ctx.prof_dump().keys())
     finally:
         ctx.prof_enable(False)
@@ -175,13 +171,11 @@ def test_fs2_ffn_planes_kernels(monkeypatch, variant):
     assert not any(n.startswith(("fs2_conv_ffn", "fs2_gemm_qkv", "fs2_gemm_attn_out")) and "planes" not in n for n in names), names
 
 
-def test_fs2_batch_composition_invariance(monkeypatch):
+def test_fs2_batch_composition_invariance():
     """An utterance's mel does not depend on the batch it is in, bit for bit -- alone, in a ragged batch, in the reversed
-    batch -- nor on which of the first-conv kernels runs (PK_FFNP_VARIANT: they differ in tiling only).  The planes
+    batch -- nor on which of the first-conv kernels runs (the "ffnp_variant" option: they differ in tiling only).  The planes
     kernels keep one scale per ROW for this (a per-block scale would couple neighbouring utterances)."""
     from parakeet_amd.fastspeech2 import FastSpeech2
-    monkeypatch.delenv("PK_FFNP_VARIANT", raising=False)
-    monkeypatch.delenv("PK_FS2_FFN_PLANES_MIN_BLOCKS", raising=False)
     cfg = _cfg()
     model = FastSpeech2(80, 80, **cfg)
     model.set_state_dict(syn.fastspeech2_state(80, 80, cfg, seed=150))
@@ -193,25 +187,23 @@ def test_fs2_batch_composition_invariance(monkeypatch):
         assert torch.equal(ref[b], rev[len(texts) - 1 - b].as_subclass(torch.Tensor)), b
     solo = model.inference_batch([texts[2]])[0].as_subclass(torch.Tensor)
     assert torch.equal(ref[2], solo)
-    for variant in ("88", "44"):
-        monkeypatch.setenv("PK_FFNP_VARIANT", variant)
+    for variant in (88, 44):
+        model.set_option("ffnp_variant", variant)
         out = model.inference_batch(texts)
         for b in range(len(texts)):
             assert torch.equal(ref[b], out[b].as_subclass(torch.Tensor)), (variant, b)
 
 
-def test_fs2_ffn_planes_long_utterance(monkeypatch):
-    _planes_env(monkeypatch, "")
-    _check(_cfg(), [150, 33], seed=104, taps=False)
+def test_fs2_ffn_planes_long_utterance():
+    _check(_cfg(), [150, 33], seed=104, taps=False, options=_planes_options(0))
 
 
 @pytest.mark.parametrize("kf", [-20, 8])
-def test_fs2_ffn_planes_scale_invariant(monkeypatch, kf):
+def test_fs2_ffn_planes_scale_invariant(kf):
     """The hidden activations are stored with the scale of a magnitude BOUND: a model whose hidden stream is rescaled by 2^kf
     (exactly compensated) must give the original's output at the exact-fp32 path's error."""
     from oracle import fastspeech2_ref as ref
     from parakeet_amd.fastspeech2 import FastSpeech2
-    _planes_env(monkeypatch, "")
     cfg = _cfg()
     state = syn.fastspeech2_state(80, 80, cfg, seed=140)
     ids = syn.phoneme_ids(45, 80, seed=141)
@@ -221,6 +213,8 @@ def test_fs2_ffn_planes_scale_invariant(monkeypatch, kf):
     model.set_state_dict(_rescaled_fs2_state(state, cfg, kf, 0, 0))
     model.eval()
     model.set_debug(True)
+    for k, v in _planes_options(0).items():
+        model.set_option(k, v)
     l1 = {}
     for mode in ("f32", "f16x3"):
         model.set_math(mode)

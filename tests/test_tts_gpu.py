@@ -190,15 +190,15 @@ def test_style_tokens_ragged_batch():
     assert np.abs(one[0].numpy() - outs[2][0].numpy()).max() < 1e-5
 
 
-def test_kv_only_prefix_projection_experiment(monkeypatch):
-    """PK_TTS_KV_PREFIX=1 (off by default): layer 0 projects k | v only for the prefix rows and q for the new rows with a
+def test_kv_only_prefix_projection_experiment():
+    """Option "kv_prefix" = 1 (pk_tts_set_option; off by default): layer 0 projects k | v only for the prefix rows and q for the new rows with a
     row GEMM; same result as the fused q | k | v projection up to the two GEMM kernels' rounding."""
     cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=2, postnet_layers=2)
     state = syn.transformer_tts_state(40, 80, cfg, seed=71, stop_bias=-6.0)
     m = _model(cfg, 40, state)
     texts = [syn.phoneme_ids(T, idim=40, seed=700 + T) for T in (5, 3)]
     base = m.inference_batch(texts, maxlenratio=2.0, seeds=[1, 2])
-    monkeypatch.setenv("PK_TTS_KV_PREFIX", "1")
+    m.set_option("kv_prefix", 1)
     alt = m.inference_batch(texts, maxlenratio=2.0, seeds=[1, 2])
     for (a, pa, wa), (b, pb, wb) in zip(base, alt):
         assert a.shape == b.shape and np.abs(a.numpy() - b.numpy()).max() < 2e-4

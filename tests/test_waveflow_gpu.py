@@ -8,7 +8,7 @@ from parakeet_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg_over, frames, seed, tol=2e-4, math=None):
+def _run(cfg_over, frames, seed, tol=2e-4, math=None, expect_kernel=None):
     from oracle import waveflow_ref as ref
     from parakeet_amd.waveflow import ConditionalWaveFlow
     cfg = dict(syn.WAVEFLOW_LJSPEECH, **cfg_over)
@@ -19,9 +19,19 @@ def _run(cfg_over, frames, seed, tol=2e-4, math=None):
     if math:
         model.set_math(math)
     rng = np.random.default_rng(seed + 1)
-    mels = [np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32) for T in frames]
+    mels = [np.maximum(rng.normal(-4, 2, size=(cfg["n_mels"], T)), np.log(1e-5)).astype(np.float32) for T in frames]
     zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
+    if expect_kernel:
+        from parakeet_amd.runtime import Context
+        ctx = Context.get()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
     outs = model.infer_batch(mels, zs)
+    if expect_kernel:
+        names = set(ctx.prof_dump().keys())
+        ctx.prof_enable(False)
+        present, absent = expect_kernel
+        assert any(n.startswith(present) for n in names) and not any(n.startswith(absent) for n in names), names
     for b, T in enumerate(frames):
         want = ref.infer(state, torch.from_numpy(mels[b])[None], torch.from_numpy(zs[b])[None], cfg,
                          torch.float64)[0].numpy()
@@ -42,6 +52,19 @@ def test_waveflow_c64_all_flows():
 
 def test_waveflow_c128_repo_default_width():
     _run(dict(channels=128, n_flows=2), [4], seed=3)
+
+
+def test_waveflow_96_mel_channels_runs_unfused():
+    """the fused layer kernel needs a free condition channel (channel n_mels of its 96 carries the folded biases).
+    A 96-mel model must take the unfused GEMM path -- same result bars -- and refuse the fp16-operand mode, which exists on the
+    fused kernel only; an 80-mel model runs the fused kernel."""
+    from parakeet_amd.waveflow import ConditionalWaveFlow
+    _run(dict(channels=64, n_flows=2, n_mels=96), [4, 3], seed=6, expect_kernel=("wf_gemm_conv_gate", "wf_layer"))
+    _run(dict(channels=64, n_flows=2), [4, 3], seed=6, expect_kernel=("wf_layer", "wf_gemm_conv_gate"))
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64, n_flows=2, n_mels=96)
+    m = ConditionalWaveFlow(**cfg)
+    with pytest.raises(NotImplementedError):
+        m.set_math("f16")
 
 
 def test_waveflow_fp16_operand_mode():

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PK_PROFILE_LIB=1   # the PK_* measurement switches exist in the profile build only: python -m parakeet_amd.build --profile (libpk_synth_prof.so)
 # Attention kernel variants on the GPU box: FS2 tests under each PK_FS2_ATTN_WAVES, then per-launch durations.
 set -u
 TAG=${1:-r03attn}

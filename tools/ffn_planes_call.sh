@@ -1,4 +1,5 @@
 #!/bin/bash
+export PK_PROFILE_LIB=1   # the PK_* measurement switches exist in the profile build only: python -m parakeet_amd.build --profile (libpk_synth_prof.so)
 # FastSpeech2 on planes (ffn_planes.hip) on the GPU box: tests, error vs the fp64 oracle of both paths, timings per batch size.
 set -u
 TAG=${1:-r03ffn}

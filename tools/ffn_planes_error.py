@@ -18,7 +18,7 @@ lens = [int(x) for x in (sys.argv[1:] or [9, 33, 2])]
 texts = [syn.phoneme_ids(T, seed=i) for i,T in enumerate(lens)]
 want = [ref.inference(state, ids, ocfg, dtype=torch.float64).numpy() for ids in texts]
 for env in ('1', '0'):
-    os.environ['PK_FS2_FFN_PLANES'] = env
+    os.environ['PK_FS2_FFN_PLANES'] = env   # profile build (PK_PROFILE_LIB=1)
     m = FastSpeech2(80, 80, **cfg); m.set_state_dict(state); m.eval()
     o = [x.cpu().numpy() for x in m.inference_batch(texts)]
     print('planes' if env=='1' else 'gemm  ', ' '.join(f"L1 {np.abs(a-b).mean():.2e} max {np.abs(a-b).max():.2e}" for a,b in zip(o,want)))

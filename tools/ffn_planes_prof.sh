@@ -1,4 +1,5 @@
 #!/bin/bash
+export PK_PROFILE_LIB=1   # the PK_* measurement switches exist in the profile build only: python -m parakeet_amd.build --profile (libpk_synth_prof.so)
 # per-launch durations of the feed-forward kernels of tools/quick_fs2.py (encoder and decoder launches apart).
 # usage: ffn_planes_prof.sh <tag> <case>...   case = gemm | <variant>[:<ablate>]   (PK_FFNP_VARIANT / PK_FFNP_ABLATE)
 set -u

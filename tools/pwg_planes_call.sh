@@ -1,4 +1,5 @@
 #!/bin/bash
+export PK_PROFILE_LIB=1   # the PK_* measurement switches exist in the profile build only: python -m parakeet_amd.build --profile (libpk_synth_prof.so)
 # Parallel WaveGAN with x as pre-split planes (PK_PWG_PLANES) on the GPU box: the PWG tests with it on, then the per-launch
 # time of the layer kernel both ways.
 set -u

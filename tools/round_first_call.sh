@@ -1,4 +1,5 @@
 #!/bin/bash
+export PK_PROFILE_LIB=1   # the PK_* measurement switches exist in the profile build only: python -m parakeet_amd.build --profile (libpk_synth_prof.so)
 # First gpurun call of a round: everything that was added without a GPU gets its first hardware run, then the numbers.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/round_first_call.sh r03a'      -> gpurun_out/<tag>/
 # 1. the full GPU suite (tests/conftest.py orders the never-run-on-hardware tests last); 2. smoke; 3. the bench line;

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PK_PROFILE_LIB=1   # the PK_* measurement switches exist in the profile build only: python -m parakeet_amd.build --profile (libpk_synth_prof.so)
 # WaveFlow layer kernel on the GPU box: tests, per-launch times of the four timed configurations, prefetch A/B, memory ablations, s_memtime trace.
 set -u
 TAG=${1:-r03d}
