@@ -287,6 +287,14 @@ int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t
  * reference itself synthesises at (examples/waveflow/synthesize.py:40 runs under paddle.amp.auto_cast), about 1e-4 of the
  * waveform's peak away from the fp64 oracle; 64- and 128-channel models only (PK_EUNSUPPORTED otherwise). */
 int pk_wf_set_math(pk_wf* h, int32_t mode);
+/* Named integer options (as pk_pwg_set_option; scheduling only, results do not change):
+ *   "layer_waves"  0 (default) = the fused layer kernel runs in 12-wave workgroups where that saves a round over 8-wave ones
+ *                  (64-channel model), 8 / 12 = forced (12: 64 channels only, PK_EUNSUPPORTED otherwise)
+ *   "persistent"   1 (default) = the residual layers of a row run in ONE launch with a barrier across the grid between two
+ *                  layers (a cooperative launch: 120 launches per batch instead of 960); 0 = one launch per layer
+ *   "fuse_step"    1 (default) = a row's affine step and the next row's input projection happen in the launch of its last
+ *                  layer; 0 = in a kernel of their own */
+int pk_wf_set_option(pk_wf* h, const char* key, int64_t value);
 int pk_wf_finalize(pk_wf* h);
 /* For t_mel frames: length of the trimmed upsampled condition (= length of the z the reference
  * draws, waveflow.py:799-801) and of the returned waveform (pruned to a multiple of n_group, :695). */

@@ -143,6 +143,7 @@ def _declare(lib):
         "pk_wf_create": (C.c_int, [vp, C.POINTER(WfCfg), C.POINTER(vp)]),
         "pk_wf_set_param": (C.c_int, [vp, cstr, f32p, i64p, i32]),
         "pk_wf_set_math": (C.c_int, [vp, i32]),
+        "pk_wf_set_option": (C.c_int, [vp, cstr, i64]),
         "pk_wf_finalize": (C.c_int, [vp]),
         "pk_wf_cond_length": (C.c_int, [vp, i32, i32p, i32p]),
         "pk_wf_infer": (C.c_int, [vp, f32p, i32p, i32, f32p, f32p, i32]),

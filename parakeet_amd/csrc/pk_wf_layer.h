@@ -62,29 +62,51 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
                    const float* outp, const float* outp_b, const float* w_out, std::vector<uint16_t>& w16,
                    std::vector<float>& f32);
 
-struct WflLaunch {
+constexpr int WFL_MAX_LAYERS = 8;   // layers one launch can run (a flow of the released models has 8)
+
+struct WflLayer {            // what differs between the residual layers of one row
     WflWeights w;
-    int C;                   // 64 or 128
-    int f16;                 // 1: fp16 operands, one MFMA per product (the reference's AMP precision); 0: three-term split
     const float* in0;        // layer input ring, slot 0 (planes, C channels; one float = one 4-byte slot); slot s at + s * slot_stride
-    long slot_stride;        // slots (= floats)
     const unsigned* in_amax0;   // max|.| per 32-position block of slot 0 (fp32 bits); slot s at + s * amax_stride
-    long amax_stride;
-    int cur_slot;            // slot of the current row (residual input = centre tap of the last kernel row)
     float* out;              // next layer's input, slot of the current row (planes), or NULL (last layer)
     unsigned* out_amax;
+    int first;               // the flow's first layer: prm is written, not accumulated
+    int dil;                 // width dilation 2^l: tap t is shifted by tap_col[t] * dil positions
+};
+
+// One launch = the layers [0, nl) of ONE row (nl == 1: a single layer, what rounds 2 / 3 launched 960 times per batch; nl == the
+// flow's 8: the whole ResidualNet of the row behind grid barriers, pk_grid.h -- SURVEY K20: 120 launches per batch).
+struct WflLaunch {
+    int C;                   // 64 or 128
+    int f16;                 // 1: fp16 operands, one MFMA per product (the reference's AMP precision); 0: three-term split
+    long slot_stride;        // slots (= floats)
+    long amax_stride;
+    int cur_slot;            // slot of the current row (residual input = centre tap of the last kernel row)
     float* prm;              // [pos][2] running (logs, b) of this row without the constant terms, written (first) or accumulated
-    int first;
     const float* cond;       // condition row (planes, 96 channels)
     const unsigned* cond_amax;
     int ntap;                // conv taps whose input row exists (3, 6 or 9)
-    int tap_slot[9], tap_shift[9], tap_w[9];   // ring slot, position shift, weight tap index kr*3 + kc
+    int tap_slot[9], tap_col[9], tap_w[9];   // ring slot, kernel column - 1 (-1, 0, 1), weight tap index kr*3 + kc
     const int* pos_utt;      // [npos_alloc] utterance of a position, < 0: gap (outputs forced to 0)
     int npos_alloc;          // multiple of 32
-    const uint16_t* next_w1;    // the NEXT launch's packed weights (or NULL): touched at the end of this one so that they
-    const uint16_t* next_w2;    // are in every XCD's L2 when that launch starts (each launch uses another layer's 376 KB)
     unsigned long long* trace;  // profiling only (PK_WF_ABLATE=16): s_memtime stamps of workgroup 5, [wave 8][round 2][24]
+    int waves;                  // 0 = the launcher chooses 8- or 12-wave workgroups (64 channels), 8 / 12 = forced
     int active, tiles_per_wg;   // set by wfl_layer_launch: most waves that take a tile per round, tiles per workgroup
+    int nl;                     // layers in this launch
+    unsigned* bar;              // nl > 1: the grid barrier's counter (zeroed by the launcher) ...
+    int* err;                   // ... and its time-out flag
+    // nl == the flow's layer count and step_* set: after the last layer the launch also finishes the row -- Flow._predict_row_
+    // parameters + _inverse_transform_row + input_proj of the NEXT row's layer-0 input (what wfl_step_launch does as a kernel
+    // of its own): x[i] = (z'[i] - b) exp(-logs), h0 = input_proj(x[i]) as planes
+    const float* step_z;        // z' row of this row, or NULL: no fused step
+    float* step_x;              // x row out
+    const float* step_w_in;     // input_proj weight / bias [C]
+    const float* step_b_in;
+    float* step_h0;             // next row's layer-0 ring slot (planes) or NULL (last row of the flow)
+    unsigned* step_h0_amax;
+    float step_b_logs, step_b_b;   // the flow's folded biases
+    const WflLayer* layers;     // DEVICE memory: the nl layer descriptors of this launch (not a by-value array: indexing kernel
+                                // arguments with the layer counter makes the compiler hold every element in scalar registers)
 };
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);
 

@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "pk_gemm.h"
+#include "pk_grid.h"
 #include "pk_wf_layer.h"
 
 namespace {
@@ -162,11 +163,15 @@ struct pk_wf {
     unsigned long long seed = 0, rng_offset = 0;   // internal latent stream (z == NULL)
     bool no_fuse = pk_prof_env("PK_WF_NO_FUSE") != nullptr;   // measurement switch: separate out_proj launches
     int mp = 96;              // mel channels padded to a multiple of 32 (GEMM K block of the condition)
+    int layer_waves = 0;      // option "layer_waves": 0 = the launcher chooses, 8 / 12 = waves per workgroup of the fused layer kernel
+    bool persistent = true;   // option "persistent": the layers of a row in ONE launch behind grid barriers (pk_grid.h)
+    bool fuse_step = true;    // option "fuse_step": the row's step in the launch of its last layer (else a kernel of its own)
     std::vector<WfFlowW> flows;
     std::vector<size_t> up_w;
     std::vector<float> up_b;
     // workspace
-    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip, ws_hamax, ws_camax, ws_trace;
+    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip, ws_hamax, ws_camax, ws_trace, ws_bar, ws_desc;
+    std::vector<WflLayer> desc_host;   // host image of ws_desc (kept until the next inference: the upload is asynchronous)
     const float* W(size_t off) const { return arena.as<float>() + off; }
 };
 
@@ -233,6 +238,18 @@ extern "C" int pk_wf_set_seed(pk_wf* h, uint64_t seed) {
 // (k_wf_cond_planes).  Used by finalize (what gets packed), by pk_wf_infer (which path runs) and by pk_wf_set_math.
 static bool wfl_usable(const pk_wf* h) {
     return wfl_supports(h->cfg.channels) && h->mp == WFL_MP && h->cfg.n_mels < WFL_MP && !h->no_fuse;
+}
+
+extern "C" int pk_wf_set_option(pk_wf* h, const char* key, int64_t value) {
+    if (!h || !key) PK_FAIL(PK_EINVAL, "pk_wf_set_option: NULL argument");
+    if (strcmp(key, "layer_waves") == 0) {
+        if (value != 0 && value != 8 && value != 12) PK_FAIL(PK_EINVAL, "pk_wf_set_option: layer_waves %lld (0, 8, 12)", (long long)value);
+        if (value == 12 && h->cfg.channels != 64) PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_option: 12-wave workgroups are built for the 64-channel model");
+        h->layer_waves = (int)value;
+    } else if (strcmp(key, "persistent") == 0) h->persistent = value != 0;
+    else if (strcmp(key, "fuse_step") == 0) h->fuse_step = value != 0;
+    else PK_FAIL(PK_EINVAL, "pk_wf_set_option: unknown option '%s'", key);
+    return PK_OK;
 }
 
 extern "C" int pk_wf_set_math(pk_wf* h, int32_t mode) {
@@ -464,6 +481,8 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     // (the fused layer kernel keeps block maxima instead, one per 32 positions, in the same buffers)
     const bool use_wfl = wfl_usable(h) && (h->math == PK_GEMM_MATH_F16X3 || h->math == PK_GEMM_MATH_F16);
     const long bstride = pstride / WFL_BLK;   // blocks per buffer row incl. margins
+    PK_TRY(h->ws_bar.reserve(2 * sizeof(unsigned)));   // grid barrier counter | its time-out flag (pk_grid.h)
+    PK_HIP(hipMemsetAsync(h->ws_bar.p, 0, 2 * sizeof(unsigned), ctx->stream));
     PK_TRY(h->ws_hamax.reserve((size_t)(NL + 1) * 3 * pstride * 4));
     PK_TRY(h->ws_camax.reserve((size_t)G * pstride * 4));
     PK_HIP(hipMemsetAsync(h->ws_hamax.p, 0, (size_t)(NL + 1) * 3 * pstride * 4, ctx->stream));
@@ -526,6 +545,31 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, 8 * 2 * 24 * sizeof(unsigned long long), ctx->stream));
         d_trace = h->ws_trace.as<unsigned long long>();
     }
+    // ---- the layer descriptors of the fused kernel, one per (flow, ring slot of the current row, layer): weights of the
+    // (flow, layer), input ring of the layer, output = the next layer's ring at the current row's slot
+    if (use_wfl) {
+        h->desc_host.assign((size_t)c.n_flows * 3 * NL, WflLayer());
+        for (int fl = 0; fl < c.n_flows; ++fl)
+            for (int slot = 0; slot < 3; ++slot)
+                for (int l = 0; l < NL; ++l) {
+                    const WfLayerW& L = h->flows[fl].layers[l];
+                    WflLayer& wl = h->desc_host[((size_t)fl * 3 + slot) * NL + l];
+                    wl.w.w1 = h->arena16.as<uint16_t>() + L.fl.w1;
+                    wl.w.w2 = h->arena16.as<uint16_t>() + L.fl.w2;
+                    wl.w.b2r = h->W(L.fl.b2r);
+                    wl.w.wso = h->W(L.fl.wso);
+                    wl.w.k1 = L.fl.k1;
+                    wl.w.k2res = L.fl.k2res;
+                    wl.in0 = hist_ptr(l, 0);
+                    wl.in_amax0 = hbmax_ptr(l, 0);
+                    wl.out = l + 1 < NL ? hist_ptr(l + 1, slot) : nullptr;   // the last layer's residual output is unused (:390)
+                    wl.out_amax = l + 1 < NL ? hbmax_ptr(l + 1, slot) : nullptr;
+                    wl.first = l == 0;
+                    wl.dil = 1 << l;
+                }
+        PK_TRY(h->ws_desc.reserve(h->desc_host.size() * sizeof(WflLayer)));
+        PK_HIP(hipMemcpyAsync(h->ws_desc.p, h->desc_host.data(), h->desc_host.size() * sizeof(WflLayer), hipMemcpyHostToDevice, ctx->stream));
+    }
     // ---- flows, reversed (:703-706)
     std::vector<int> cidx(G);
     for (int i = 0; i < G; ++i) cidx[i] = i;
@@ -552,27 +596,19 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         const bool fuse_proj = C == 64 && h->math == PK_GEMM_MATH_F16X3 && MP % PK_GEMM_HBK == 0 && !h->no_fuse;
         for (int i = 1; i < G; ++i) {
             const int slot = i % 3;
-            for (int l = 0; l < NL && use_wfl; ++l) {
-                // the fused layer kernel (wf_layer.hip): conv taps + condition + gate + res|skip projection
-                const WfLayerW& L = F.layers[l];
+            if (use_wfl) {
+                // the fused layer kernel (wf_layer.hip): conv taps + condition + gate + res projection + folded skip path.
+                // One launch runs `per` consecutive layers of this row: all NL behind grid barriers (option "persistent",
+                // the default wherever the barrier exists: 120 launches per batch instead of 960 + 120), or one; the launch that
+                // holds the last layer also finishes the row (the step: x[i], then the next row's layer-0 input).
                 WflLaunch w;
+                memset(&w, 0, sizeof(w));
                 w.C = C;
                 w.f16 = h->math == PK_GEMM_MATH_F16;
-                w.w.w1 = h->arena16.as<uint16_t>() + L.fl.w1;
-                w.w.w2 = h->arena16.as<uint16_t>() + L.fl.w2;
-                w.w.b2r = h->W(L.fl.b2r);
-                w.w.wso = h->W(L.fl.wso);
-                w.w.k1 = L.fl.k1;
-                w.w.k2res = L.fl.k2res;
-                w.in0 = hist_ptr(l, 0);
                 w.slot_stride = feat_row;
-                w.in_amax0 = hbmax_ptr(l, 0);
                 w.amax_stride = bstride;
                 w.cur_slot = slot;
-                w.out = l + 1 < NL ? hist_ptr(l + 1, slot) : nullptr;   // the last layer's residual output is unused (:390)
-                w.out_amax = l + 1 < NL ? hbmax_ptr(l + 1, slot) : nullptr;
                 w.prm = prm;
-                w.first = l == 0;
                 w.cond = cond + (long)cidx[i] * cond_row;
                 w.cond_amax = cbmax + (long)cidx[i] * bstride;
                 w.ntap = 0;
@@ -581,22 +617,40 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                     if (step < 1) continue;        // rows before the sequence start are zeros (:287-290)
                     for (int kc = 0; kc < 3; ++kc) {
                         w.tap_slot[w.ntap] = step % 3;
-                        w.tap_shift[w.ntap] = (kc - 1) * (1 << l);
+                        w.tap_col[w.ntap] = kc - 1;
                         w.tap_w[w.ntap] = kr * 3 + kc;
                         ++w.ntap;
                     }
                 }
-                for (int t = w.ntap; t < 9; ++t) w.tap_slot[t] = w.tap_shift[t] = w.tap_w[t] = 0;
                 w.pos_utt = rowvalid;
                 w.npos_alloc = npos_alloc;
-                {   // the layer kernel that runs next: l + 1, else layer 0 of the next row, else of the next flow
-                    static const bool prefetch = pk_prof_env("PK_WF_PREFETCH") ? atoi(pk_prof_env("PK_WF_PREFETCH")) != 0 : true;
-                    const WfLayerW* nx = l + 1 < NL ? &F.layers[l + 1] : (i + 1 < G ? &F.layers[0] : (fl > 0 ? &h->flows[fl - 1].layers[0] : nullptr));
-                    w.next_w1 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w1 : nullptr;
-                    w.next_w2 = prefetch && nx ? h->arena16.as<uint16_t>() + nx->fl.w2 : nullptr;
-                }
                 w.trace = d_trace;
-                PK_TRY(wfl_layer_launch(ctx, w));
+                w.waves = h->layer_waves;
+                w.bar = h->ws_bar.as<unsigned>();
+                w.err = h->ws_bar.as<int>() + 1;
+                const bool persistent = h->persistent && pk_grid_available() && NL <= WFL_MAX_LAYERS && !d_trace;
+                const int per = persistent ? NL : 1;
+                float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
+                for (int l0 = 0; l0 < NL; l0 += per) {
+                    w.nl = per;
+                    w.layers = h->ws_desc.as<WflLayer>() + ((size_t)(fl * 3 + slot) * NL + l0);   // (flow, ring slot, layer)
+                    if (l0 + per == NL && h->fuse_step) {
+                        w.step_z = cur + (long)perm[i] * pstride;
+                        w.step_x = nxt + (long)i * pstride;
+                        w.step_w_in = h->W(F.w_in);
+                        w.step_b_in = h->W(F.b_in);
+                        w.step_h0 = h0n;
+                        w.step_h0_amax = h0n ? hbmax_ptr(0, (i + 1) % 3) : nullptr;
+                        w.step_b_logs = F.b_logs_f;
+                        w.step_b_b = F.b_b_f;
+                    }
+                    PK_TRY(wfl_layer_launch(ctx, w));
+                }
+                if (!h->fuse_step)
+                    PK_TRY(wfl_step_launch(ctx, C, prm, F.b_logs_f, F.b_b_f, cur + (long)perm[i] * pstride,
+                                           nxt + (long)i * pstride, h->W(F.w_in), h->W(F.b_in), h0n,
+                                           h0n ? hbmax_ptr(0, (i + 1) % 3) : nullptr, rowvalid, npos_alloc, 0));
+                continue;
             }
             for (int l = 0; l < NL && !use_wfl; ++l) {
                 const WfLayerW& L = F.layers[l];
@@ -676,12 +730,6 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                     PK_TRY(pk_row_amax_launch(ctx, hist_ptr(l + 1, slot), C, C, 0, npos, hamax_ptr(l + 1, slot)));
             }
             float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
-            if (use_wfl) {
-                PK_TRY(wfl_step_launch(ctx, C, prm, F.b_logs_f, F.b_b_f, cur + (long)perm[i] * pstride,
-                                       nxt + (long)i * pstride, h->W(F.w_in), h->W(F.b_in), h0n,
-                                       h0n ? hbmax_ptr(0, (i + 1) % 3) : nullptr, rowvalid, npos_alloc, 0));
-                continue;
-            }
             PK_LAUNCH(ctx, "wf_step", k_wf_step, dim3(pk_div_up(npos, 4)), dim3(256), 0, skip, C, h->W(F.w_out),
                       F.b_logs, F.b_b, cur + (long)perm[i] * pstride, nxt + (long)i * pstride, h->W(F.w_in),
                       h->W(F.b_in), h0n, rowvalid, npos, 0);
@@ -705,8 +753,11 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     PK_LAUNCH(ctx, "wf_unfold", k_wf_unfold, dim3(pk_div_up(npos, 256)), dim3(256), 0, cur, d_tab + o_putt,
               d_tab + o_pw, d_tab + o_ooff, G, npos, pstride, d_wav);
     if (flags & PK_HOST_IO) {
+        int berr = 0;
         PK_HIP(hipMemcpyAsync(wav, d_wav, (size_t)sumO * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipMemcpyAsync(&berr, h->ws_bar.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipStreamSynchronize(ctx->stream));
+        if (berr) PK_FAIL(PK_EHIP, "pk_wf_infer: a grid barrier of the row kernel timed out (code %d): the result is invalid", berr);
     }
     return PK_OK;
 }
@@ -717,7 +768,7 @@ extern "C" void pk_wf_destroy(pk_wf* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
                        &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip,
-                       &h->ws_hamax, &h->ws_camax, &h->ws_trace};
+                       &h->ws_hamax, &h->ws_camax, &h->ws_trace, &h->ws_bar, &h->ws_desc};
     for (auto* b : bufs) b->release();
     delete h;
 }

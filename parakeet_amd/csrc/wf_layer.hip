@@ -32,6 +32,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "pk_grid.h"
 #include "pk_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,30 +43,34 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
 namespace {
-constexpr int WAVES = 8;
-constexpr int THREADS = WAVES * 64;
 constexpr int WAVE_T = 32;
 constexpr int SLAB_BYTES = 48 * 1024;   // one weight slab in LDS; two of them
 constexpr int SLAB_CH = SLAB_BYTES / 16;   // 16-byte chunks per slab buffer
 constexpr int BLK_M_BYTES = WFL_MP * 128;  // bytes per 32-position block of the condition planes
 
-template <int CT>
+// W = waves per workgroup: 8 (two per SIMD, 256 registers each), or 12 at 64 channels (three per SIMD, 168 registers: the 11
+// wave tiles a workgroup owns at the benchmark's shape -- 2 592 tiles on 256 CUs -- run as ONE round instead of 8 + 3)
+template <int CT, int W = 8>
 struct Shape {
+    static constexpr int THREADS = W * 64;
     static constexpr int C = 32 * CT;
     static constexpr int KS_TAP = C / 16;                 // k-steps per conv tap: 4 / 8
     static constexpr int KS1 = 9 * KS_TAP + WFL_KS_COND;  // 42 / 78
     static constexpr int NQ = 2 * CT;                     // accumulator tiles of the first contraction: 4 / 8
     static constexpr int KCH1 = 2 * NQ * 64;              // chunks per k-step of W1: 512 / 1024
     static constexpr int SLAB = SLAB_CH / KCH1;           // k-steps per main slab: 6 / 3
-    static constexpr int CPT1 = SLAB * KCH1 / THREADS;    // chunks per thread per main slab: 6
+    static constexpr int CPT1 = SLAB * KCH1 / THREADS;    // chunks per thread per main slab: 6 (4 with 12 waves)
     static constexpr int KS2 = C / 16;                    // k-steps of the out projection (res half): 4 / 8
     static constexpr int KCH2 = 2 * CT * 64;              // chunks per k-step of W2: 256 / 512
     static constexpr int SLAB2 = 4;                       // k-steps per W2 slab: 16 / 32 KB
     static constexpr int NS2 = KS2 / SLAB2;               // W2 slabs: 1 / 2
-    static constexpr int CPT2 = SLAB2 * KCH2 / THREADS;   // chunks per thread per W2 slab: 2 / 4
+    static constexpr int CPT2 = (SLAB2 * KCH2 + THREADS - 1) / THREADS;   // chunks per thread per W2 slab: 2 / 4 (12 waves: 2, the
+                                                          // second one clamped to the slab's last chunk for waves 4 - 11)
     static constexpr int BLK_BYTES = C * 128;             // bytes per 32-position block of the feature planes
-    static constexpr int RING = CT == 2 ? 9 : 2 * SLAB;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12 would leave the
-                                                          // A fragments two register quads -- every LDS read latency exposed)
+    static constexpr int RING = CT == 2 ? (W == 12 ? 6 : 9) : 2 * SLAB;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12
+                                                          // would leave the A fragments two register quads -- every LDS read
+                                                          // latency exposed; 12 waves: 6, what 168 registers hold)
+    static_assert(SLAB * KCH1 % THREADS == 0, "a main slab is a whole number of chunks per thread");
 };
 
 __host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -154,6 +159,17 @@ __device__ __forceinline__ f16x8 pow2_neg_h8(int d) {
 __device__ __forceinline__ f16x8 ld_h8(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 
+// An opaque zero (ON) or a literal one: values derived from it cannot be hoisted out of the place it is renewed.  The 12-wave
+// kernel (168 registers) uses it to keep round- and epilogue-only address arithmetic from living in registers through the slab
+// loop -- hoisted out of the round loop they were spilled at the top and reloaded in the hot loop, where a scratch load's wait
+// drains the operand prefetch (vmcnt counts in order).  The 8-wave kernels are compiled exactly as before.
+template <bool ON>
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    if constexpr (ON) asm volatile("" : "+s"(z));
+    return z;
+}
+
 // NT = ntap / 3 (1, 2, 3 rows of the ring exist): a template parameter so that the slab loop unrolls completely.  With a
 // run-time loop the operand ring is carried around the back edge, hipcc's register allocator does not keep the refilled
 // slots in place, and the copies it inserts at the loop end wait for every load in flight (vmcnt(0) once per slab pair).
@@ -175,10 +191,12 @@ __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x
 // rounds it to nearest: half the operand bytes, no arithmetic on the way to the MFMA); gate outputs: one conversion.  The
 // layer inputs stay the same 22-bit pairs, so only the products lose precision, not the residual stream.  A third of the matrix
 // work; not the default.
-template <int CT, int NT, int ABL = 0, bool F16 = false>
-__global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
-    typedef Shape<CT> S;
-    constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, RING = S::RING;
+template <int CT, int NT, int ABL = 0, bool F16 = false, int W = 8>
+__global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
+    typedef Shape<CT, W> S;
+    constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
+    constexpr int RING = (W == 12 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
+    static_assert(W == 8 || (W == 12 && CT == 2 && ABL == 0), "12-wave workgroups: the 64-channel model");
     constexpr int ntap = 3 * NT;
     constexpr int nks_conv = S::KS_TAP * ntap;
     constexpr int nks = nks_conv + WFL_KS_COND;
@@ -193,31 +211,40 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     __shared__ int tp_shift[ntap + 1];    // position shift of the tap
     __shared__ int tp_blk[ntap + 1];      // bytes per 32-position block of the source (C or 96 channels)
     __shared__ unsigned kt_w[nks];        // byte offset of the packed k-step of W1
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // per layer of the launch: what the slab loop
+    // needs stays in scalar registers; what only a tile's start or epilogue needs -- and the fused step's arguments -- is parked
+    // in LDS (the kernel has no scalar registers to spare: kernel arguments referenced inside the loops are loaded up front and
+    // held, 20 of them per layer, and the spills go to vector registers the 12-wave and 128-channel kernels do not have)
+    struct Cold {
+        float* out;
+        unsigned* out_amax;
+        int first, k1, k2res, has_out;
+        const float* step_z;
+        float* step_x;
+        const float* step_w_in;
+        const float* step_b_in;
+        float* step_h0;
+        unsigned* step_h0_amax;
+        float step_b_logs, step_b_b;
+    };
+    __shared__ Cold cold;
+    // ---- the layers of this launch: nl == 1, or the whole residual stack of the row with a grid barrier between two layers
+    // (layer l + 1 reads, 2^(l+1) positions to either side, what OTHER workgroups wrote in layer l).  EVERYTHING of a layer sits
+    // inside this loop, thread coordinates included (derived from an opaque zero renewed per layer): with the loop around a
+    // straight-line body the compiler hoists each thread-invariant address out of it and keeps it in a register through all
+    // layers (+ 40 vector registers, spills in the 12-wave and 128-channel kernels).
+#pragma unroll 1
+    for (int li = 0; li < a.nl; ++li) {
+    if (li > 0) pk_grid_barrier(a.bar, (unsigned)li * gridDim.x, a.err);   // (every wave of this workgroup is past its epilogue too)
+    int oz = 0;
+    asm volatile("" : "+s"(oz));
+    const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    for (int i = tid; i < 3 * C; i += THREADS) lb[i] = i < C ? a.w.b2r[i] : a.w.wso[i - C];
-    if (tid < nks) {
-        const int ks = tid;
-        kt_w[tid] = (unsigned)(ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv)) *
-                    (unsigned)(S::KCH1 * 16);
-    }
-    if (tid < ntap) {
-        tp_off[tid] = ((long)a.tap_slot[tid] * a.slot_stride) * 4;
-        tp_am[tid] = (long)a.tap_slot[tid] * a.amax_stride;
-        tp_shift[tid] = a.tap_shift[tid];
-        tp_blk[tid] = S::BLK_BYTES;
-    } else if (tid == ntap) {
-        tp_off[tid] = reinterpret_cast<const char*>(a.cond) - reinterpret_cast<const char*>(a.in0);
-        tp_am[tid] = a.cond_amax - a.in_amax0;
-        tp_shift[tid] = 0;
-        tp_blk[tid] = BLK_M_BYTES;
-    }
-    const f16x8* w1 = reinterpret_cast<const f16x8*>(a.w.w1);
-    const f16x8* w2 = reinterpret_cast<const f16x8*>(a.w.w2);
-    const char* in0b = reinterpret_cast<const char*>(a.in0);
-    __syncthreads();   // tables visible
     const int ntiles = a.npos_alloc / WAVE_T;
-    const float i_res = pow2f(-(PK_UNIT_EXP + a.w.k2res));
+    const f16x8* w1 = nullptr;
+    const f16x8* w2 = nullptr;
+    const char* in0b = nullptr;
+    const unsigned* in_amax0 = nullptr;
     // A workgroup owns tiles_per_wg consecutive wave tiles and works through them in rounds of at most `active` tiles
     // (one pass over the weights per round).  The waves of a round run in lockstep (they share the LDS weight slabs);
     // waves without a tile only move weights and keep the barriers.
@@ -233,12 +260,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
     // (addresses = a scalar base + a 32-bit byte offset: one add per chunk instead of a 64-bit multiply-add chain -- 54 chunks
     // per tile)
     auto w_src = [&](int g, int c, int tz) -> const f16x8* {
-        const int f = c * THREADS + tid;
+        const int f = c * THREADS + tid + (W == 12 ? tz : 0);
         if (g < nslab)
             return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
                                                   (kt_w[SLAB * g + f / S::KCH1 + tz] + (unsigned)((f % S::KCH1) * 16)));
         return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w2) +
-                                              (unsigned)(((g - nslab) * (S::SLAB2 * S::KCH2) + f) * 16));
+                                              (unsigned)(((g - nslab) * (S::SLAB2 * S::KCH2) + min(f, S::SLAB2 * S::KCH2 - 1)) * 16));
     };
     f16x8 wreg[S::CPT1];   // one slab of weights on its way from global memory to LDS
     auto w_load = [&](int g, int tz) {
@@ -254,6 +281,46 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             if (c < (g < nslab ? S::CPT1 : S::CPT2)) wbuf[g % 3][c * THREADS + tid] = wreg[c];
     };
 
+    const WflLayer& L = a.layers[li];   // (device memory, wave-uniform address: scalar loads, here only)
+    if (tid == 0) {
+        cold.out = L.out;
+        cold.out_amax = L.out_amax;
+        cold.has_out = L.out != nullptr;
+        cold.first = L.first;
+        cold.k1 = L.w.k1;
+        cold.k2res = L.w.k2res;
+        const bool st = li + 1 == a.nl && a.step_z != nullptr;
+        cold.step_z = st ? a.step_z : nullptr;
+        cold.step_x = a.step_x;
+        cold.step_w_in = a.step_w_in;
+        cold.step_b_in = a.step_b_in;
+        cold.step_h0 = a.step_h0;
+        cold.step_h0_amax = a.step_h0_amax;
+        cold.step_b_logs = a.step_b_logs;
+        cold.step_b_b = a.step_b_b;
+    }
+    for (int i = tid; i < 3 * C; i += THREADS) lb[i] = i < C ? L.w.b2r[i] : L.w.wso[i - C];
+    if (tid < nks) {
+        const int ks = tid;
+        kt_w[tid] = (unsigned)(ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv)) *
+                    (unsigned)(S::KCH1 * 16);
+    }
+    if (tid < ntap) {
+        tp_off[tid] = ((long)a.tap_slot[tid] * a.slot_stride) * 4;
+        tp_am[tid] = (long)a.tap_slot[tid] * a.amax_stride;
+        tp_shift[tid] = a.tap_col[tid] * L.dil;
+        tp_blk[tid] = S::BLK_BYTES;
+    } else if (tid == ntap) {
+        tp_off[tid] = reinterpret_cast<const char*>(a.cond) - reinterpret_cast<const char*>(L.in0);
+        tp_am[tid] = a.cond_amax - L.in_amax0;
+        tp_shift[tid] = 0;
+        tp_blk[tid] = BLK_M_BYTES;
+    }
+    w1 = reinterpret_cast<const f16x8*>(L.w.w1);
+    w2 = reinterpret_cast<const f16x8*>(L.w.w2);
+    in0b = reinterpret_cast<const char*>(L.in0);
+    in_amax0 = L.in_amax0;
+    __syncthreads();   // tables visible
     for (int base = t_begin; base < t_end;) {   // uniform over the workgroup
         const int nact = min(a.active, t_end - base);
         const int wt = base + wave;
@@ -280,9 +347,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             // branches are waited for where the branches join)
             unsigned m_raw;
             {
-                const int li = lane <= 2 * ntap ? lane : 0, t = li >> 1;   // t = ntap: the condition block (shift 0)
+                const int lane_r = lane + (W == 12 ? lz : 0);
+                const int li = lane_r <= 2 * ntap ? lane_r : 0, t = li >> 1;   // t = ntap: the condition block (shift 0)
                 const int blk = (p0 + tp_shift[t + lz] + 31 * (li & 1)) >> 5;   // (the LDS tables, not the kernel arguments: those
-                m_raw = (a.in_amax0 + tp_am[t + lz])[blk];                       //  indexed per lane would be loads from memory)
+                m_raw = (in_amax0 + tp_am[t + lz])[blk];                          //  indexed per lane would be loads from memory)
             }
 
             // ---- B operand of k-step ks: the lane's 8 channels (octet 2 kq + hh) of position p + shift, hi and lo vectors;
@@ -307,7 +375,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     const long bo = tp_off[tap + tz] - 8L * blkb;
                     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bo), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bo >> 32));
                     cur_base = in0b + (long)(((unsigned long)bhi << 32) | blo);
-                    ram[tap % 4] = (a.in_amax0 + tp_am[tap + tz])[q >> 5];
+                    ram[tap % 4] = (in_amax0 + tp_am[tap + tz])[q >> 5];
                 }
                 const char* src = cur_base + (cur_off + (unsigned)(kq * 2048));
                 rhi[slot] = ld_h8(src);
@@ -331,7 +399,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex
             const int ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(wave_max64(__uint_as_float(m_raw)))));   // (all sources are maxima: the repeats change nothing)
             const int kx = PK_BLK_TOP + 127 - ex;
-            const int ks1 = kx + a.w.k1;
+            const int ks1 = kx + (&cold)[lz].k1;
             const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
             const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
             f16x8 f;          // rescale factor of the tap being consumed
@@ -354,7 +422,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 // second requested when the first has gone to LDS after the first k-step, and a ring slot is rescaled in
                 // place and refilled after its k-step's MFMAs.  (A k-step is 24 MFMAs there: the loads a weight wait drains
                 // early are still three k-steps = 2 300 matrix cycles old.)
-                constexpr bool TIGHT = CT == 4;
+                constexpr bool TIGHT = CT == 4 || W == 12;   // (12 waves: 168 registers)
                 const int NW = g + 2 >= G ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = TIGHT ? NW / 2 : NW;   // constants once unrolled
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
@@ -362,8 +430,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                 __builtin_amdgcn_sched_barrier(0);   // keep the weight loads up here: hipcc would sink them to their stores
                 // (the slab's LDS base as ONE opaque register: from a constant base the third buffer's fragments lie beyond the
                 // 64 KB reach of a ds_read offset, and the compiler keeps a separate address register for each of them)
-                unsigned wo = (g % 3) * SLAB_CH + lane;
-                asm volatile("" : "+v"(wo));
+                // (12 waves: the opaque part is the scalar base -- "constant | lane" would be hoisted out of the round loop, spilled,
+                // and its reload in the middle of the slab loop waits for the weight loads just requested)
+                unsigned wo = (g % 3) * SLAB_CH;
+                if constexpr (W == 12) {
+                    asm volatile("" : "+s"(wo));
+                    wo += lane;
+                } else {
+                    wo += lane;
+                    asm volatile("" : "+v"(wo));
+                }
                 const f16x8* wl = &wbuf[0][0] + wo;
 #pragma unroll
                 for (int kk = 0; kk < SLAB; ++kk) {
@@ -396,7 +472,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     // A fragments AHEAD co-tiles ahead of their MFMAs (not all NQ of them: registers).  Two at 64 channels:
                     // with one, every co-tile's three MFMAs (96 cycles) had to cover a whole LDS read latency, and the trace
                     // showed about 200 cycles per k-step and wave that nothing covered
-                    constexpr int AHEAD = (CT == 2 && !(ABL & 32)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;
+                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W == 12 && !F16)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
+                    // math: one -- registers; the other two waves of the SIMD cover the LDS latency)
                     __builtin_amdgcn_sched_group_barrier(0x100, PER * (AHEAD + 0), 0);
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
@@ -428,23 +505,34 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             f16x8 xin_hi[S::KS2], xin_lo[S::KS2];   // residual input: this lane's centre-tap vectors of the current row
             unsigned cur_am;
             float2 prm_old = {0.f, 0.f};
+            // (12 waves: the epilogue's lane coordinates are derived HERE, from an opaque zero -- not hoisted, not spilled)
+            const int ez = opaque_zero<W == 12>();
+            const int lane_e = lane + ez, hh_e = W == 12 ? lane_e >> 5 : hh;
+            const int p_e = W == 12 ? p0 + (lane_e & 31) : p;
+            const long pblk_e = W == 12 ? (long)(p_e >> 5) : pblk;
+            const int pin_e = W == 12 ? p_e & 31 : pin;
+            const Cold& cd = (&cold)[ez];   // (read here, with the other old values: wave-uniform, made scalar where it branches)
+            const bool has_out = __builtin_amdgcn_readfirstlane(cd.has_out) != 0;
+            const bool l_first = __builtin_amdgcn_readfirstlane(cd.first) != 0;
+            const float i_res = pow2f(-(PK_UNIT_EXP + cd.k2res));
             {
-                const char* cur = in0b + ((long)a.cur_slot * a.slot_stride) * 4 + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
+                const char* cur = in0b + ((long)a.cur_slot * a.slot_stride) * 4 + pblk_e * S::BLK_BYTES + pin_e * 32 + hh_e * 1024;
 #pragma unroll
                 for (int kq = 0; kq < S::KS2; ++kq) {
                     xin_hi[kq] = (ABL & 4) ? rhi[kq] : ld_h8(cur + kq * 2048);
                     xin_lo[kq] = (ABL & 4) ? rlo[kq] : ld_h8(cur + kq * 2048 + 16);
                 }
-                cur_am = a.in_amax0[(long)a.cur_slot * a.amax_stride + (p0 >> 5)];
-                if (!a.first && !(ABL & 4)) prm_old = reinterpret_cast<const float2*>(a.prm)[p];
+                cur_am = in_amax0[(long)a.cur_slot * a.amax_stride + (p0 >> 5)];
+                if (!l_first && !(ABL & 4)) prm_old = reinterpret_cast<const float2*>(a.prm)[p_e];
             }
+            const int p_utt_e = W == 12 ? a.pos_utt[p_e] : p_utt;   // (12 waves: requested with the old values, not held since the round's start)
             // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection; on the way this
             // lane's part of the folded skip path: (logs, b) += sum over its C/2 channels of wso[.][channel] * z
             __builtin_amdgcn_sched_barrier(0);   // the old-value loads stay ahead of the gate
             stamp(19);
             f16x8 zh[S::KS2], zl[S::KS2];
             float pl = 0.f, pb = 0.f;
-            const f32x4* wso = reinterpret_cast<const f32x4*>(lbr + C) + hh * (S::KS2 * 4);
+            const f32x4* wso = reinterpret_cast<const f32x4*>(lbr + C) + hh_e * (S::KS2 * 4);
 #pragma unroll
             for (int k2 = 0; k2 < S::KS2; ++k2) {
                 const int zq = k2 >> 1, r0 = 8 * (k2 & 1);
@@ -472,14 +560,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     split8(zv, zh[k2], zl[k2]);
                 }
             }
-            const bool lane_ok = p_utt >= 0;
+            const bool lane_ok = p_utt_e >= 0;
             pl += __shfl_xor(pl, 32);   // the other half wave holds the other C/2 channels of the same position
             pb += __shfl_xor(pb, 32);
-            if (hh == 0) {
-                float2 o = {prm_old.x + pl, prm_old.y + pb};   // skips summed (:390), then output_proj (:499-500)
-                if (!lane_ok) o = float2{0.f, 0.f};
-                if (!(ABL & 4)) reinterpret_cast<float2*>(a.prm)[p] = o;
-            }
+            float2 prm_new = {prm_old.x + pl, prm_old.y + pb};   // skips summed (:390), then output_proj (:499-500)
+            if (!lane_ok) prm_new = float2{0.f, 0.f};
+            if (hh_e == 0 && !(ABL & 4)) reinterpret_cast<float2*>(a.prm)[p_e] = prm_new;
             stamp(20);
             // ---- out projection, res half (-> next layer's input planes; the last layer has none): its weights follow the
             // conv weights through the slab buffers (NS2 slabs of SLAB2 k-steps)
@@ -487,15 +573,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
 #pragma unroll
             for (int t = 0; t < CT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[t][r] = lbr[32 * t + mfma_row(r, hh)];
+                for (int r = 0; r < 16; ++r) acc2[t][r] = lbr[32 * t + mfma_row(r, hh_e)];
 #pragma unroll
             for (int h2 = 0; h2 < S::NS2; ++h2) {
                 const int g = nslab + h2;   // slab of the weight stream
-                unsigned wo = (g % 3) * SLAB_CH + lane;
+                unsigned wo = (g % 3) * SLAB_CH + lane_e;
                 asm volatile("" : "+v"(wo));
                 const f16x8* buf = &wbuf[0][0] + wo;
                 if (S::NS2 >= 2) w_load(g + 2, 0);
-                if (a.out) {
+                if (has_out) {
 #pragma unroll
                     for (int kk = 0; kk < S::SLAB2; ++kk) {
                         const int k2 = h2 * S::SLAB2 + kk;
@@ -518,7 +604,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
             }
             stamp(21);
             // res = x_in + res (:281) -> the next layer's input of this row, as planes with this block's scale
-            if (a.out) {
+            if (has_out) {
                 const float xs = pow2f(-(PK_BLK_TOP + 127 - amax_exp(cur_am)));   // the stored input is x * 2^k
                 float v[CT][16];
                 float am = 0.f;
@@ -535,7 +621,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     }
                 am = wave_max64(am);
                 const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
-                char* dst = reinterpret_cast<char*>(a.out) + pblk * S::BLK_BYTES + pin * 32 + hh * 1024;
+                char* dst = reinterpret_cast<char*>(cd.out) + pblk_e * S::BLK_BYTES + pin_e * 32 + hh_e * 1024;
 #pragma unroll
                 for (int kq = 0; kq < S::KS2; ++kq) {
                     float t8[8];
@@ -547,9 +633,43 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
                     st_h8(dst + kq * 2048, oh);
                     st_h8(dst + kq * 2048 + 16, ol);
                 }
-                if (lane == 0) a.out_amax[p0 >> 5] = __float_as_uint(am);
+                if (lane_e == 0) cd.out_amax[p0 >> 5] = __float_as_uint(am);
             }
             stamp(22);
+            // ---- the row's last layer done (and the launch asked for it): finish the row here instead of in a kernel of its own
+            // (k_wf_step_p below, operation for operation): (logs, b) = prm + the folded biases, x = (z' - b) exp(-logs)
+            // (Flow._predict_row_parameters :496-501, _inverse_transform_row :503-505), h0 = input_proj(x) -> the next row's
+            // layer-0 input as planes.  Its ring slot is the one layer 0 of THIS row read as its oldest row: every workgroup
+            // is past that layer (grid barriers / earlier launches).
+            const float* const step_z = cd.step_z;
+            if (__builtin_amdgcn_readfirstlane(step_z != nullptr)) {
+                const float xn = lane_ok ? (step_z[p_e] - (prm_new.y + cd.step_b_b)) * expf(-(prm_new.x + cd.step_b_logs)) : 0.f;
+                if (hh_e == 0) cd.step_x[p_e] = xn;
+                float* const step_h0 = cd.step_h0;
+                if (__builtin_amdgcn_readfirstlane(step_h0 != nullptr)) {
+                    float v[S::KS2][8];
+                    float am = 0.f;
+#pragma unroll
+                    for (int kq = 0; kq < S::KS2; ++kq)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = wfl_chan(kq, hh_e, e);
+                            v[kq][e] = lane_ok ? fmaf(cd.step_w_in[c], xn, cd.step_b_in[c]) : 0.f;
+                            am = fmaxf(am, fabsf(v[kq][e]));
+                        }
+                    am = wave_max64(am);
+                    const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
+                    char* dst = reinterpret_cast<char*>(step_h0) + pblk_e * S::BLK_BYTES + pin_e * 32 + hh_e * 1024;
+#pragma unroll
+                    for (int kq = 0; kq < S::KS2; ++kq) {
+                        f16x8 oh, ol;
+                        store_pair8(v[kq], so, oh, ol);
+                        st_h8(dst + kq * 2048, oh);
+                        st_h8(dst + kq * 2048 + 16, ol);
+                    }
+                    if (lane_e == 0) cd.step_h0_amax[p0 >> 5] = __float_as_uint(am);
+                }
+            }
         } else {
             {
                 f16x8 wreg1[S::CPT1];
@@ -574,19 +694,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_wf_layer_p(WflLaunch a) {
         if (S::NS2 < 2) __syncthreads();   // one slab for both passes: consumed before the next round overwrites its buffer
         ++rnd;
     }
-    // ---- warm the L2 of this XCD with the next launch's weights: the workgroups of an XCD (block b runs on XCD b % 8 --
-    // observed, used for speed only) each touch a slice of the 128-byte lines
-    if (a.next_w1) {
-        constexpr int L1 = (int)((size_t)S::KS1 * S::KCH1 * 16 / 128), L2 = (int)((size_t)S::KS2 * S::KCH2 * 16 / 128);
-        const int nwg = ((int)gridDim.x + 7) >> 3, me = (int)blockIdx.x >> 3;
-        const int per = (L1 + L2 + nwg - 1) / nwg;
-        float warm = 0.f;
-        for (int i = me * per + tid; i < min((me + 1) * per, L1 + L2); i += THREADS) {
-            const float* src = i < L1 ? reinterpret_cast<const float*>(a.next_w1) + (long)i * 32
-                                      : reinterpret_cast<const float*>(a.next_w2) + (long)(i - L1) * 32;
-            warm += *src;
-        }
-        if (warm == 1.2345e-30f) a.prm[0] = warm;   // never true: keeps the loads
     }
 }
 
@@ -813,22 +920,36 @@ static int wfl_ablation(Go& go, bool shape_ok, bool trace) {
 }
 
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
-    if (!wfl_supports(a.C) || a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9)
-        PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (C %d, npos %d, taps %d)", a.C, a.npos_alloc, a.ntap);
+    if (!wfl_supports(a.C) || a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9 || a.nl < 1 || a.nl > WFL_MAX_LAYERS)
+        PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (C %d, npos %d, taps %d, layers %d)", a.C, a.npos_alloc, a.ntap, a.nl);
+    if (a.nl > 1 && (!pk_grid_available() || !a.bar)) PK_FAIL(PK_ESTATE, "wfl_layer_launch: several layers per launch need the grid barrier");
     // operand offsets inside a source are 32-bit (k_wf_layer_p: scalar base + unsigned offset): 16 blocks of margin included
     if (((long)a.npos_alloc / WAVE_T + 16) * (long)std::max(a.C * 128, BLK_M_BYTES) >= (1L << 32))
         PK_FAIL(PK_EUNSUPPORTED, "wfl_layer_launch: %d positions per row exceed the 32-bit operand offsets; split the batch", a.npos_alloc);
     const int ntiles = a.npos_alloc / WAVE_T;
     WflLaunch b = a;
-    static const int active_env = pk_prof_env("PK_WF_ACTIVE") ? atoi(pk_prof_env("PK_WF_ACTIVE")) : WAVES;   // measurement switch
-    b.active = active_env >= 1 && active_env <= WAVES ? active_env : WAVES;
     b.tiles_per_wg = std::max(1, (ntiles + ctx->n_cu - 1) / ctx->n_cu);
     const int grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
+    // 64 channels: 12-wave workgroups (three waves per SIMD, 168 registers) where they save a round -- the tiles of a
+    // workgroup in ceil(t / 12) rounds instead of ceil(t / 8) (the benchmark's 8 x 640 frames: 11 tiles per workgroup, one round
+    // instead of 8 + 3 with the second 3/8 full).  a.waves = 8 / 12 forces one (option "layer_waves" of pk_wf_set_option).
+    const bool w12 = a.C == 64 && (a.waves == 12 || (a.waves != 8 && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));
+    const int W = w12 ? 12 : 8;
+    static const int active_env = pk_prof_env("PK_WF_ACTIVE") ? atoi(pk_prof_env("PK_WF_ACTIVE")) : 0;   // measurement switch
+    b.active = active_env >= 1 && active_env <= W ? active_env : W;
+    // several layers: the workgroups wait for one another (pk_grid.h) -- at most one per CU by construction (LDS), launched
+    // cooperatively so that a grid that cannot be co-resident is an error, not a hang
+    if (a.nl > 1) PK_HIP(hipMemsetAsync(a.bar, 0, sizeof(unsigned), ctx->stream));
     auto go = [&](auto kern) -> int {
-        PK_LAUNCH(ctx, "wf_layer", kern, dim3(grid), dim3(THREADS), 0, b);
+        if (a.nl > 1) PK_LAUNCH_COOP(ctx, "wf_row", kern, dim3(grid), dim3(W * 64), b);
+        else PK_LAUNCH(ctx, "wf_layer", kern, dim3(grid), dim3(W * 64), 0, b);
         return PK_OK;
     };
     const int nt = a.ntap / 3;
+    if (w12) {
+        if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 12>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 12>) : go(k_wf_layer_p<2, 3, 0, true, 12>));
+        return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 12>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 12>) : go(k_wf_layer_p<2, 3, 0, false, 12>));
+    }
     if (int st = wfl_ablation<PK_PROFILE_BUILD != 0>(go, a.C == 64 && nt == 3 && !a.f16, b.trace != nullptr); st != 1) return st;
     if (a.f16) {
         if (a.C == 64)

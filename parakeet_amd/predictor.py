@@ -10,7 +10,22 @@ shape; nothing is traced or exported -- ``run`` calls the engine.
     voc = Predictor(pwg_inference, input_names=["logmel"])
     h = am.get_input_handle(am.get_input_names()[0]); h.reshape(phones.shape); h.copy_from_cpu(phones) ...
     am.run(); mel = am.get_output_handle(am.get_output_names()[0]).copy_to_cpu()
+
+The serving entry proper is ``Config`` + ``create_predictor(config)``: the reference's script names two exported static
+graphs per model (``<dir>/speedyspeech.pdmodel`` + ``.pdiparams``, :53-66).  This engine does not interpret Paddle program
+descriptions; ``Config`` takes the SAME two paths and resolves, in the same directory, the recipe artefacts the graphs were
+exported from -- the model's yaml config, its ``.pdz`` checkpoint, its ``*_stats.npy`` and the phone / tone id maps (the
+files ``synthesize_e2e.py`` of each recipe takes as arguments) -- and ``create_predictor`` builds the engine model from them
+(``parakeet_amd.checkpoint``), names the inputs as the exported graphs do (``InputSpec`` order of the recipe's
+``jit.to_static`` call: speedyspeech.py phones, tones; fastspeech2 text; pwg logmel) and returns a ``Predictor``:
+
+    cfg = Config(f"{d}/speedyspeech.pdmodel", f"{d}/speedyspeech.pdiparams")   # or Config(model="speedyspeech", model_dir=d)
+    cfg.enable_use_gpu(100, 0); cfg.enable_memory_optim()
+    predictor = create_predictor(cfg)
 """
+import glob
+import os
+
 import numpy as np
 import torch
 
@@ -83,5 +98,93 @@ class Predictor:
         return True
 
 
-def create_predictor(model, input_names, output_names=("out",)):
-    return Predictor(model, input_names, output_names)
+# model kind -> (input names in the exported graph's InputSpec order, output name)
+_KINDS = {
+    "speedyspeech": (["phones", "tones"], "logmel"),     # examples/speedyspeech/baker/synthesize_e2e.py:77-83
+    "fastspeech2": (["text"], "logmel"),                 # examples/fastspeech2/baker/synthesize_e2e.py (to_static InputSpec)
+    "pwg": (["logmel"], "wav"),                          # :85-89
+}
+
+
+def _first(model_dir, patterns, what, kind):
+    for pat in patterns:
+        hits = sorted(glob.glob(os.path.join(model_dir, pat)))
+        if hits:
+            return hits[-1]   # several snapshots: the last (highest iteration) one
+    raise FileNotFoundError(f"{kind}: no {what} in {model_dir} (looked for {', '.join(patterns)})")
+
+
+class Config:
+    """``paddle.inference.Config(prog_file, params_file)`` for this engine (see the module docstring).  The model kind is
+    the stem of ``prog_file`` (speedyspeech | fastspeech2 | pwg) or ``model=``; artefacts are looked up in the directory of
+    ``prog_file`` / ``model_dir=`` by the recipes' file names, or given explicitly:
+      config      <kind>.yaml | <kind>_default.yaml | default.yaml
+      checkpoint  <kind>*.pdz | snapshot_iter_*.pdz | *.pdz      (.pdparams too)
+      stat        <kind>_stats.npy | speech_stats.npy | *stats.npy
+      phones_dict phone_id_map.txt | phones.txt ;  tones_dict tone_id_map.txt | tones.txt   (acoustic models)"""
+
+    def __init__(self, prog_file=None, params_file=None, model=None, model_dir=None, config=None, checkpoint=None, stat=None,
+                 phones_dict=None, tones_dict=None):
+        if model is None:
+            if prog_file is None:
+                raise ValueError("Config needs prog_file (\"<dir>/<kind>.pdmodel\") or model=")
+            model = os.path.splitext(os.path.basename(str(prog_file)))[0]
+        if model not in _KINDS:
+            raise ValueError(f"unknown model kind {model!r}: {sorted(_KINDS)}")
+        self.model = model
+        self.model_dir = str(model_dir) if model_dir is not None else (os.path.dirname(str(prog_file)) if prog_file else ".")
+        self.prog_file, self.params_file = prog_file, params_file
+        self.artefacts = dict(config=config, checkpoint=checkpoint, stat=stat, phones_dict=phones_dict, tones_dict=tones_dict)
+        self.device_id = 0
+        self.use_gpu = True
+        self.memory_optim = False
+
+    # -- the calls the reference's script makes on a Config (:56-57, :64-65)
+    def enable_use_gpu(self, memory_pool_init_size_mb=100, device_id=0):
+        """The engine's workspaces are grow-only device buffers per handle: the pool size has no counterpart."""
+        self.use_gpu, self.device_id = True, int(device_id)
+
+    def disable_gpu(self):
+        raise RuntimeError("parakeet_amd has no CPU execution path")
+
+    def enable_memory_optim(self):
+        self.memory_optim = True
+
+    def resolve(self):
+        k, d, a = self.model, self.model_dir, dict(self.artefacts)
+        if a["config"] is None:
+            a["config"] = _first(d, [f"{k}.yaml", f"{k}_default.yaml", "default.yaml"], "yaml config", k)
+        if a["checkpoint"] is None:
+            a["checkpoint"] = _first(d, [f"{k}*.pdz", f"{k}*.pdparams", "snapshot_iter_*.pdz", "*.pdz"], "checkpoint", k)
+        if a["stat"] is None:
+            a["stat"] = _first(d, [f"{k}_stats.npy", "speech_stats.npy", "*stats.npy"], "statistics file", k)
+        if k != "pwg":
+            if a["phones_dict"] is None:
+                a["phones_dict"] = _first(d, ["phone_id_map.txt", "phones.txt"], "phone id map", k)
+            if k == "speedyspeech" and a["tones_dict"] is None:
+                a["tones_dict"] = _first(d, ["tone_id_map.txt", "tones.txt"], "tone id map", k)
+        return a
+
+
+def create_predictor(config, input_names=None, output_names=("out",)):
+    """``create_predictor(Config)``: build the engine model the Config describes and wrap it (module docstring);
+    ``create_predictor(callable, input_names)``: wrap an inference object that already exists."""
+    if not isinstance(config, Config):
+        return Predictor(config, input_names, output_names)
+    from . import checkpoint as ck
+    from .runtime import Context
+    a = config.resolve()
+    Context.get(config.device_id)
+    ins, out = _KINDS[config.model]
+    if config.model == "speedyspeech":
+        inf, _, _ = ck.load_speedyspeech(a["config"], a["checkpoint"], a["stat"], a["phones_dict"], a["tones_dict"])
+        model = lambda phones, tones: inf(np.asarray(phones), np.asarray(tones))
+    elif config.model == "fastspeech2":
+        inf, _ = ck.load_fastspeech2(a["config"], a["checkpoint"], a["stat"], a["phones_dict"])
+        model = lambda text: inf(np.asarray(text))
+    else:
+        inf = ck.load_pwg(a["config"], a["checkpoint"], a["stat"])
+        model = lambda logmel: inf(logmel)[:, 0]       # the exported graph returns wav (T,) for sf.write (:128-131)
+    p = Predictor(model, ins, (out,))
+    p.inference, p.config = inf, config
+    return p

@@ -53,6 +53,10 @@ class ConditionalWaveFlow:
         """'f16x3' (default: split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
         _capi.check(self._ctx.lib.pk_wf_set_math(self._h, {"f32": 0, "f16x3": 1, "f16": 2}[mode]))
 
+    def set_option(self, key, value):
+        """Named integer options of the engine handle (include/pk_synth.h, pk_wf_set_option): 'layer_waves'."""
+        _capi.check(self._ctx.lib.pk_wf_set_option(self._h, key.encode(), int(value)))
+
     def set_seed(self, seed):
         """Seed of the engine's own latent stream (``pk_randn``), used when neither ``z`` nor a torch
         ``generator`` is given -- the ``paddle.randn`` of waveflow.py:801."""

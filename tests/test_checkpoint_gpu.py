@@ -194,3 +194,61 @@ def test_mandarin_multispeaker_recipe_script(tmp_path):
         assert frames == 2 * len(ids)
         with wave.open(str(tmp_path / "out" / f"3_{utt}.wav"), "rb") as w:
             assert w.getnframes() == frames * 256 and w.getframerate() == 22050
+
+
+def test_serving_entry_from_an_inference_directory(tmp_path):
+    """SURVEY 8f rank 3 / VERDICT r3 missing #8: the loop of examples/speedyspeech/baker/inference.py:53-130 --
+    inference.Config(<dir>/speedyspeech.pdmodel, .pdiparams) -> create_predictor -> get_input_handle / reshape / copy_from_cpu /
+    run / get_output_handle / copy_to_cpu, acoustic model then vocoder -- on an inference directory that holds the recipe's
+    artefacts (yaml, .pdz, stats, id maps): the predictors are built from those files and give, bit for bit, what the models
+    loaded by parakeet_amd.checkpoint give when called directly."""
+    import yaml
+    from parakeet_amd.predictor import Config, create_predictor
+    d = tmp_path
+    ss_state, pwg_state = syn.speedyspeech_state(), syn.pwg_state(dict(syn.PWG_LJSPEECH, upsample_scales=[4, 5, 3, 5]), weight_norm=True)
+    (d / "speedyspeech.yaml").write_text(yaml.safe_dump({"fs": 24000, "model": dict(syn.SPEEDYSPEECH_BAKER)}))
+    gen = {k: v for k, v in syn.PWG_LJSPEECH.items()}
+    gen["upsample_scales"] = [4, 5, 3, 5]
+    (d / "pwg.yaml").write_text(yaml.safe_dump({"fs": 24000, "generator_params": gen}))
+    with open(d / "snapshot_iter_76000.pdz", "wb") as f:
+        pickle.dump({"main_params": {k: ("t", v) for k, v in ss_state.items()}}, f, protocol=2)
+    with open(d / "pwg_snapshot_iter_400000.pdz", "wb") as f:
+        pickle.dump({"generator_params": dict(pwg_state)}, f, protocol=4)
+    np.save(d / "speech_stats.npy", np.stack(syn.mel_stats(seed=5)))
+    np.save(d / "pwg_stats.npy", np.stack(syn.mel_stats(seed=6)))
+    (d / "phone_id_map.txt").write_text("".join(f"p{i} {i}\n" for i in range(70)))
+    (d / "tone_id_map.txt").write_text("".join(f"{i} {i}\n" for i in range(7)))
+
+    cfg = Config(str(d / "speedyspeech.pdmodel"), str(d / "speedyspeech.pdiparams"))
+    cfg.enable_use_gpu(100, 0)
+    cfg.enable_memory_optim()
+    am = create_predictor(cfg)
+    pcfg = Config(str(d / "pwg.pdmodel"), str(d / "pwg.pdiparams"))
+    pcfg.enable_use_gpu(100, 0)
+    voc = create_predictor(pcfg)
+    assert am.get_input_names() == ["phones", "tones"] and voc.get_input_names() == ["logmel"]
+    voc.inference.pwg_generator.set_seed(11)
+
+    rng = np.random.default_rng(1)
+    phones, tones = rng.integers(1, 70, size=13), rng.integers(1, 7, size=13)
+    names = am.get_input_names()
+    for n, v in zip(names, (phones, tones)):
+        h = am.get_input_handle(n)
+        h.reshape(v.shape)
+        h.copy_from_cpu(v)
+    am.run()
+    mel = am.get_output_handle(am.get_output_names()[0]).copy_to_cpu()
+    h = voc.get_input_handle(voc.get_input_names()[0])
+    h.reshape(mel.shape)
+    h.copy_from_cpu(mel)
+    voc.run()
+    wav = voc.get_output_handle(voc.get_output_names()[0]).copy_to_cpu()
+    assert mel.ndim == 2 and mel.shape[1] == 80 and wav.shape == (mel.shape[0] * 300,) and np.isfinite(wav).all()
+
+    inf, _, _ = ck.load_speedyspeech(d / "speedyspeech.yaml", d / "snapshot_iter_76000.pdz", d / "speech_stats.npy",
+                                     d / "phone_id_map.txt", d / "tone_id_map.txt")
+    pwg = ck.load_pwg(d / "pwg.yaml", d / "pwg_snapshot_iter_400000.pdz", d / "pwg_stats.npy")
+    pwg.pwg_generator.set_seed(11)
+    mel2 = inf(phones, tones).numpy()
+    np.testing.assert_array_equal(mel, mel2)
+    np.testing.assert_array_equal(wav, pwg(mel2).numpy()[:, 0])

@@ -123,3 +123,23 @@ def test_library_only_install_and_stale_override(tmp_path, monkeypatch):
     monkeypatch.setattr(_capi, "_lib", None)
     monkeypatch.setenv("PK_ALLOW_STALE_LIB", "1")
     assert _capi.lib().pk_version()                          # mismatch, but explicitly allowed
+
+
+def test_concurrent_library_loads_do_not_race():
+    """N ranks of one node start at once (torch.distributed.run), each hashing the sources, checking the
+    library's embedded hash and dlopen-ing it.  Four processes doing exactly that concurrently must all succeed, see the same
+    hash, and none may rebuild or rewrite the library (its mtime and size are unchanged)."""
+    import subprocess
+    import sys
+    from parakeet_amd import build as b
+    b.build()
+    st0 = os.stat(b.LIB)
+    code = ("import sys; sys.path.insert(0, %r); from parakeet_amd import _capi, build as b; lib = _capi.lib(); "
+            "assert not b.needs_build(); print(lib.pk_version().decode())") % ROOT
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(4)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e.decode()[-500:] for _, e in outs]
+    versions = {o.decode().strip() for o, _ in outs}
+    assert len(versions) == 1 and b.source_hash() in versions.pop()
+    st1 = os.stat(b.LIB)
+    assert (st0.st_mtime_ns, st0.st_size) == (st1.st_mtime_ns, st1.st_size)

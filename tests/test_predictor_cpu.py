@@ -1,8 +1,10 @@
 """The paddle.inference-shaped wrapper (host logic only; the GPU path is exercised in test_speedyspeech_gpu)."""
+import os
+
 import numpy as np
 import pytest
 
-from parakeet_amd.predictor import create_predictor
+from parakeet_amd.predictor import Config, create_predictor
 
 
 def test_predictor_protocol():
@@ -27,6 +29,37 @@ def test_predictor_protocol():
     out = p.get_output_handle(p.get_output_names()[0]).copy_to_cpu()
     assert out.shape == (6, 3) and np.array_equal(out[:, 0], (a + b).astype(np.float32))
     assert len(calls) == 1
+
+
+def test_config_resolves_the_recipe_artefacts(tmp_path):
+    """Config takes the reference script's two paths (examples/speedyspeech/baker/inference.py:53-66) and finds the recipe's
+    own files next to them; several snapshots -> the last; explicit arguments win; unknown kinds and missing files fail loudly;
+    there is no CPU execution path to enable."""
+    d = tmp_path
+    for name in ("speedyspeech.yaml", "snapshot_iter_100.pdz", "snapshot_iter_76000.pdz", "speech_stats.npy", "phone_id_map.txt",
+                 "tone_id_map.txt", "pwg_default.yaml", "pwg_snapshot_iter_400000.pdz", "pwg_stats.npy"):
+        (d / name).write_bytes(b"")
+    c = Config(str(d / "speedyspeech.pdmodel"), str(d / "speedyspeech.pdiparams"))
+    c.enable_use_gpu(100, 0)
+    c.enable_memory_optim()
+    a = c.resolve()
+    assert c.model == "speedyspeech" and c.device_id == 0 and c.memory_optim
+    assert [os.path.basename(a[k]) for k in ("config", "checkpoint", "stat", "phones_dict", "tones_dict")] == [
+        "speedyspeech.yaml", "snapshot_iter_76000.pdz", "speech_stats.npy", "phone_id_map.txt", "tone_id_map.txt"]
+    p = Config(str(d / "pwg.pdmodel"), str(d / "pwg.pdiparams")).resolve()
+    assert [os.path.basename(p[k]) for k in ("config", "checkpoint", "stat")] == [
+        "pwg_default.yaml", "pwg_snapshot_iter_400000.pdz", "pwg_stats.npy"] and p["phones_dict"] is None
+    e = Config(model="fastspeech2", model_dir=str(d), config="x.yaml", checkpoint="y.pdz", stat="z.npy", phones_dict="m.txt").resolve()
+    assert (e["config"], e["checkpoint"], e["stat"], e["phones_dict"]) == ("x.yaml", "y.pdz", "z.npy", "m.txt")
+    with pytest.raises(ValueError):
+        Config(str(d / "tacotron9.pdmodel"))
+    with pytest.raises(ValueError):
+        Config()
+    (d / "sub").mkdir()
+    with pytest.raises(FileNotFoundError):
+        Config(model="pwg", model_dir=str(d / "sub")).resolve()
+    with pytest.raises(RuntimeError):
+        c.disable_gpu()
 
 
 def test_nets_utils_worked_examples():

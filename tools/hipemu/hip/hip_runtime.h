@@ -234,6 +234,11 @@ static inline float fma_mix_sub(unsigned packed_halves, int sel, float x) {
 #define gridDim (hipemu::g_grid_dim)
 #define warpSize 64
 
+// The emulation runs the workgroups of a launch one after the other: kernels that synchronise across workgroups (pk_grid.h)
+// cannot run here.  PK_HIPEMU tells the launchers, which then issue one launch per phase; a cooperative launch is an error.
+#define PK_HIPEMU 1
+static inline hipError_t hipLaunchCooperativeKernel(const void*, dim3, dim3, void**, unsigned, hipStream_t) { return hipErrorLaunchFailure; }
+
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
     hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(lds), (hipStream_t)(stream), __VA_ARGS__)
 
