@@ -290,8 +290,9 @@ int pk_wf_set_math(pk_wf* h, int32_t mode);
 /* Named integer options (as pk_pwg_set_option; scheduling only, results do not change):
  *   "layer_waves"  0 (default) = the fused layer kernel runs in 12-wave workgroups where that saves a round over 8-wave ones
  *                  (64-channel model), 8 / 12 = forced (12: 64 channels only, PK_EUNSUPPORTED otherwise)
- *   "persistent"   1 (default) = the residual layers of a row run in ONE launch with a barrier across the grid between two
- *                  layers (a cooperative launch: 120 launches per batch instead of 960); 0 = one launch per layer
+ *   "persistent"   0 (default) = one launch per residual layer; 1 = the layers of a row in ONE cooperative launch with a barrier
+ *                  across the grid between two layers (120 launches per batch instead of 960; same results; measured slower on
+ *                  the MI355X -- a grid-wide barrier on 8 XCDs costs more than the gap between two launches)
  *   "fuse_step"    1 (default) = a row's affine step and the next row's input projection happen in the launch of its last
  *                  layer; 0 = in a kernel of their own */
 int pk_wf_set_option(pk_wf* h, const char* key, int64_t value);

@@ -7,13 +7,15 @@
 // Prenet dropout (always on at inference: modules/tacotron2/decoder.py:78-81, models/tacotron2.py:76-79), in place,
 // one thread per 4 units of a row.  Row r belongs to utterance r % B at prefix position r / B; element index of the
 // dropout stream (include/pk_synth.h): ((base + r / B) * J + j) * U + u, seed per utterance.
+// amax (optional, U == 256 only: a row is exactly one wave): max|.| of every row after the dropout -- the operand scale the
+// split-fp16 GEMM that reads these rows would otherwise compute with a pass of its own (k_row_amax).
 static __global__ __launch_bounds__(256) void k_ar_dropout(float* __restrict__ x, int ld, int rows, int U, int B,
                                                            unsigned long long base, int J, int j,
                                                            const unsigned long long* __restrict__ seeds,
-                                                           unsigned thr, float scale) {
+                                                           unsigned thr, float scale, float* __restrict__ amax) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const int per_row = U >> 2;
-    if (q >= (long)rows * per_row) return;
+    if (q >= (long)rows * per_row) return;   // (U == 256: whole waves leave)
     const int r = (int)(q / per_row), u4 = (int)(q - (long)r * per_row) * 4;
     const int pos = r / B, b = r - pos * B;
     const unsigned long long e = ((base + (unsigned long long)pos) * (unsigned long long)J + (unsigned long long)j) *
@@ -27,6 +29,12 @@ static __global__ __launch_bounds__(256) void k_ar_dropout(float* __restrict__ x
     v.z = w[2] >= thr ? v.z * scale : 0.f;
     v.w = w[3] >= thr ? v.w * scale : 0.f;
     *p = v;
+    if (amax) {
+        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) amax[r] = m;
+    }
 }
 
 // Position-major rows -> a row timeline (or packed rows through rowmap): timeline row r of utterance u at position p

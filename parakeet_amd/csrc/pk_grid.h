@@ -5,10 +5,10 @@
 //
 // Protocol: `count` is zeroed by the host before the launch (stream-ordered memset); barrier k (k = 1, 2, ...) is passed when
 // count >= k * gridDim.x.  Memory: the workgroups of a launch sit on 8 XCDs with one L2 each, and hipMalloc memory is not
-// kept coherent between them inside a kernel -- every thread therefore performs an agent-scope RELEASE fence before arriving
-// (its stores are written back from this XCD's L2) and an agent-scope ACQUIRE fence after leaving (this XCD's non-coherent
-// lines are invalidated), the construction the LLVM AMDGPU memory model prescribes for gfx942 / gfx950 agent-scope
-// synchronisation.  A workgroup that waits longer than PK_GRID_TIMEOUT cycles of s_memtime (a lost workgroup: never seen, but a
+// kept coherent between them inside a kernel -- one thread per workgroup therefore performs an agent-scope RELEASE fence before
+// arriving (the XCD's L2 is written back; the other waves' stores have reached it: __syncthreads) and an agent-scope ACQUIRE
+// fence after leaving (the CU's L1 and the L2's non-coherent lines are invalidated), the instructions the LLVM AMDGPU memory
+// model prescribes for gfx942 / gfx950 agent-scope synchronisation.  A workgroup that waits longer than PK_GRID_TIMEOUT cycles of s_memtime (a lost workgroup: never seen, but a
 // hang would cost the GPU) sets *err and goes on: the launch then ends with wrong data and a flag instead of never ending.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -24,25 +24,29 @@ constexpr bool PK_GRID_AVAILABLE = true;
 #endif
 static inline bool pk_grid_available() { return PK_GRID_AVAILABLE; }
 
-constexpr unsigned long long PK_GRID_TIMEOUT = 1ull << 31;   // s_memtime ticks (100 MHz constant clock on gfx9: ~20 s; at core clock ~1 s)
+constexpr unsigned long long PK_GRID_TIMEOUT = 1ull << 28;   // s_memtime ticks: 0.1 - 3 s depending on the counter's clock (a barrier wait is < 100 us)
 
 __device__ __forceinline__ void pk_grid_barrier(unsigned* count, unsigned target, int* err) {
 #ifndef PK_HIPEMU
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // __syncthreads(): every wave has waited for its own stores (they are performed at this XCD's L2) before ONE thread does the
+    // agent-scope part -- write back the L2, arrive, wait, invalidate this CU's L1 and the L2's non-coherent lines.  (First
+    // version: every thread fenced at agent scope -- 12 waves x 236 workgroups each writing back and invalidating a whole L2:
+    // 90 us per barrier in the WaveFlow row kernel, tools/micro/grid_barrier.hip mode 1.)
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memtime() - t0 > PK_GRID_TIMEOUT) {
                 if (err) *err = 1;
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
     (void)count; (void)target;
     if (err) *err = 2;   // never reached: launchers split the phases over launches under the emulation

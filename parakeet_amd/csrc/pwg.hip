@@ -2003,7 +2003,10 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     }
     // ---- first conv
     // (planes: lane offsets into x are 32-bit byte offsets)
-    bool planes = h->planes_on && h->math == PK_PWG_MATH_F16X3 && h->dbg == 0 && (size_t)R * Ttot * 4 < ((size_t)1 << 32);
+    // (profile build: PK_PWG_ABLATE=1024 runs every layer on the FIRST kernel -- skip written, never read: the skip sum and the
+    // waveform are wrong, x and the gates are not -- to measure what 256 of the 1 024 B per sample and layer cost)
+    const bool all_first = PK_PROFILE_BUILD != 0 && h->dbg == 1024;
+    bool planes = h->planes_on && h->math == PK_PWG_MATH_F16X3 && (h->dbg == 0 || all_first) && (size_t)R * Ttot * 4 < ((size_t)1 << 32);
     // a guarded inference (option "scale_guard") measures max|x| per utterance and layer next to the a-priori bound; should
     // the bound overshoot by more than 2^GUARD_MAX_LOG2 the stack is run again on the fp32-x path (second pass of this loop:
     // the noise, the conditioning P and the zeroed gaps are all still in place), which the handle then keeps
@@ -2110,7 +2113,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                         if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true, true>), dim3(grid), blk, 0, a);
                         else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true, true>), dim3(grid), blk, 0, a);
                     } else {
-                        if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, false, true>), dim3(grid), blk, 0, a);
+                        if (l == 0 || all_first) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, false, true>), dim3(grid), blk, 0, a);
                         else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, false, true>), dim3(grid), blk, 0, a);
                     }
                 } else if (gen) {   // hop != 256: frame / phase per sample (GEN kernels)

@@ -24,101 +24,118 @@ constexpr int KC = PK_RG_KC, ROWS = PK_RG_ROWS;
 
 __device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-// CW columns per workgroup, KSUB = 64 / CW consecutive k per wave-wide load, 8 * KSUB K-parts per workgroup
+// CW columns per workgroup, KSUB = 64 / CW consecutive k per wave-wide load, 8 * KSUB K-parts per workgroup.
+//
+// Latency is everything here (32 rows: a launch is 10 - 40 MFLOP), so the kernel makes ONE trip to memory before it
+// computes: the first chunk's weights (16 loads per lane), the activation tile (8 float4 per thread), the epilogue's bias and
+// residual are all requested up front, unconditionally, with clamped indices (round 4; rounds 2 / 3 read the rows a first time
+// for the LayerNorm statistics, four rows per wave one after the other, before anything else was requested: five dependent
+// round trips, 12.5 us per launch in the TransformerTTS decoder against 2 us of work).  A thread's 8 float4 all belong to ONE
+// row (m = tid % 32; 512 % 32 == 0), 32 of its K <= 512 values, so the LayerNorm statistics come from the registers that will
+// be staged anyway: per thread mean and M2 of its 32 values, the row's 16 partials merged through LDS by Chan's formula
+// (equal counts: mean = avg(mean_i), M2 = sum M2_i + n sum (mean_i - mean)^2 -- two-pass accuracy without a second pass).
 template <int CW>
 __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
     constexpr int KSUB = 64 / CW, PARTS = 8 * KSUB;
     __shared__ __attribute__((aligned(16))) float xs[KC * ROWS];   // xs[k * 32 + m], 64 KB
     __shared__ float red[PARTS * ROWS * CW];                       // red[(part * 32 + m) * CW + col], 64 KB
-    __shared__ float stat[2 * ROWS];                               // LayerNorm: mean | rstd per row
+    __shared__ float stat[2 * 16 * ROWS];                          // LayerNorm: (mean, M2) of the 16 partials of every row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int col = lane % CW, ks = lane / CW;
     const int part = wave * KSUB + ks;                            // this lane's K-part: k = part, part + PARTS, ...
     const int m0 = blockIdx.y * ROWS;
     const int rows = min(ROWS, a.M - m0);
-    if (a.ln_g) {
-        // two-pass LayerNorm statistics of rows 4 * wave .. 4 * wave + 3 (K <= 512: up to 8 values per lane)
-        for (int mm = 0; mm < 4; ++mm) {
-            const int m = wave * 4 + mm;
-            if (m >= rows) continue;   // wave-uniform
-            const float* xr = a.x + (long)(m0 + m) * a.ldx;
-            float v[KC / 64];
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < KC / 64; ++e) {
-                const int k = lane + 64 * e;
-                v[e] = k < a.K ? xr[k] : 0.f;
-                s += v[e];
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const float mean = s / (float)a.K;
-            float q = 0.f;
-#pragma unroll
-            for (int e = 0; e < KC / 64; ++e) {
-                const int k = lane + 64 * e;
-                const float d = k < a.K ? v[e] - mean : 0.f;
-                q += d * d;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-            if (lane == 0) {
-                stat[m] = mean;
-                stat[ROWS + m] = 1.0f / sqrtf(q / (float)a.K + a.ln_eps);
-            }
-        }
-    }
-    float acc[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-    // A lane's k of a chunk: part, part + PARTS, ... -- at most KC / PARTS = 16 of them.  The kernel is bound by the
-    // LATENCY of the weight stream and of the activation staging, not by their volume, so both are software-pipelined
-    // one chunk ahead in registers: while chunk c is multiplied out of LDS, the weight loads (16 per lane) and the
-    // activation loads (8 float4 per thread) of chunk c + 1 are in flight.  Every load is unconditional with clamped
-    // indices -- a branch around a load makes the compiler wait for vmcnt(0) at every use -- and what lies beyond the
-    // problem is zeroed by a select (weights) or simply not stored (activations).
+    // A lane's k of a chunk: part, part + PARTS, ... -- at most KC / PARTS = 16 of them.
     constexpr int WG = KC / PARTS;
     constexpr int XR = (KC / 4) * ROWS / 512;   // float4 per thread per chunk
     static_assert(WG <= 16 && XR == 8, "register budget");
     const float* slab = a.Wt + (long)blockIdx.x * a.K * CW;   // this workgroup's [K][CW] slab
+    const int xm = tid & (ROWS - 1), xp = tid >> 5;            // this thread's row of the tile and its K-part of it (16 parts)
     float wn[WG];
     float4 xn[XR];
+    // the epilogue's operands of this thread's output element (e = tid: row e / CW, column e % CW), requested now
+    const int em = min(tid / CW, rows - 1), ec = tid % CW, en = min((int)blockIdx.x * CW + ec, a.N - 1);
+    float e_bias = 0.f, e_res = 0.f;
     {
         const int kc = min(KC, a.K);
 #pragma unroll
         for (int g = 0; g < WG; ++g) wn[g] = slab[(long)min(part + PARTS * g, kc - 1) * CW + col];
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const int e = tid + 512 * i;
-            const int m = min(e & (ROWS - 1), rows - 1), k4 = min(e >> 5, (kc >> 2) - 1);
-            xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + m) * a.ldx + 4 * k4);
+            const int k4 = min(xp + 16 * i, (kc >> 2) - 1);
+            xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + min(xm, rows - 1)) * a.ldx + 4 * k4);
         }
+        if (a.bias) e_bias = a.bias[en];
+        if (a.res) e_res = a.res[(long)(m0 + em) * a.ldr + en];
     }
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if (a.ln_g) {   // (uniform) K <= KC: the whole row is in the 16 threads' registers
+        const int n4 = a.K >> 2;           // float4 per row
+        float s = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < XR; ++i)
+            if (xp + 16 * i < n4) {
+                s += (xn[i].x + xn[i].y) + (xn[i].z + xn[i].w);
+                cnt += 4;
+            }
+        const float mu = cnt ? s / (float)cnt : 0.f;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < XR; ++i)
+            if (xp + 16 * i < n4) {
+                const float d0 = xn[i].x - mu, d1 = xn[i].y - mu, d2 = xn[i].z - mu, d3 = xn[i].w - mu;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        stat[(xp * ROWS + xm) * 2] = mu;
+        stat[(xp * ROWS + xm) * 2 + 1] = q;
+        __syncthreads();
+        // merge the row's 16 partials (counts differ only when K is not a multiple of 64: weight them)
+        float tot = 0.f, msum = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            const int c4 = (n4 - pp + 15) / 16;   // float4 the partial pp holds
+            const float w = (float)(4 * max(c4, 0));
+            msum += w * stat[(pp * ROWS + xm) * 2];
+            tot += w;
+        }
+        ln_mean = msum / tot;
+        float m2 = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            const int c4 = (n4 - pp + 15) / 16;
+            const float w = (float)(4 * max(c4, 0));
+            const float d = stat[(pp * ROWS + xm) * 2] - ln_mean;
+            m2 += stat[(pp * ROWS + xm) * 2 + 1] + w * d * d;
+        }
+        ln_rstd = 1.0f / sqrtf(m2 / tot + a.ln_eps);
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
     for (int k0 = 0; k0 < a.K; k0 += KC) {
         const int kc = min(KC, a.K - k0);
         float w[WG];
 #pragma unroll
         for (int g = 0; g < WG; ++g) w[g] = wn[g];
-        __syncthreads();   // the previous chunk is consumed (first pass: the LayerNorm statistics are published)
-        // stage x[m0 + m][k0 + 4 * k4 ..] -> xs[(4 * k4 + i) * 32 + m]; lanes = 32 rows x 2 groups of 4 columns
+        if (k0 > 0) __syncthreads();   // the previous chunk is consumed
+        // stage x[m0 + m][k0 + 4 * k4 ..] -> xs[(4 * k4 + i) * 32 + m]
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const int e = tid + 512 * i;
-            const int m = e & (ROWS - 1), k4 = e >> 5;
+            const int k4 = xp + 16 * i;
             if (k4 < (kc >> 2)) {
                 float4 v = xn[i];
-                if (m >= rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xm >= rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 else if (a.ln_g) {
-                    const float mean = stat[m], rstd = stat[ROWS + m];
                     const float4 g = *reinterpret_cast<const float4*>(a.ln_g + k0 + 4 * k4);
                     const float4 bb = *reinterpret_cast<const float4*>(a.ln_b + k0 + 4 * k4);
-                    v.x = (v.x - mean) * rstd * g.x + bb.x;
-                    v.y = (v.y - mean) * rstd * g.y + bb.y;
-                    v.z = (v.z - mean) * rstd * g.z + bb.z;
-                    v.w = (v.w - mean) * rstd * g.w + bb.w;
+                    v.x = (v.x - ln_mean) * ln_rstd * g.x + bb.x;
+                    v.y = (v.y - ln_mean) * ln_rstd * g.y + bb.y;
+                    v.z = (v.z - ln_mean) * ln_rstd * g.z + bb.z;
+                    v.w = (v.w - ln_mean) * ln_rstd * g.w + bb.w;
                 }
-                float* d = xs + (4 * k4) * ROWS + m;
+                float* d = xs + (4 * k4) * ROWS + xm;
                 d[0] = v.x;
                 d[ROWS] = v.y;
                 d[2 * ROWS] = v.z;
@@ -136,9 +153,8 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
             for (int g = 0; g < WG; ++g) wn[g] = slab[(long)(k0n + min(part + PARTS * g, kcn - 1)) * CW + col];
 #pragma unroll
             for (int i = 0; i < XR; ++i) {
-                const int e = tid + 512 * i;
-                const int m = min(e & (ROWS - 1), mlim), k4 = min(e >> 5, (kcn >> 2) - 1);
-                xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + m) * a.ldx + k0n + 4 * k4);
+                const int k4 = min(xp + 16 * i, (kcn >> 2) - 1);
+                xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + min(xm, mlim)) * a.ldx + k0n + 4 * k4);
             }
         }
 #pragma unroll
@@ -189,14 +205,16 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
         }
         return;
     }
-    for (int e = tid; e < ROWS * CW; e += 512) {
+    static_assert(ROWS * CW == 512, "one output element per thread");
+    {
+        const int e = tid;
         const int m = e / CW, c = e - m * CW;
         const int nn = blockIdx.x * CW + c;
-        if (m >= rows || nn >= a.N) continue;
+        if (m >= rows || nn >= a.N) return;
         float s = 0.f;
 #pragma unroll 8
         for (int p = 0; p < PARTS; ++p) s += red[(p * ROWS + m) * CW + c];
-        if (a.bias) s += a.bias[nn];
+        if (a.bias) s += e_bias;
         if (a.act == PK_ACT_RELU) s = fmaxf(s, 0.f);
         if (a.dropout) {
             const unsigned long long eidx = (a.drop_base * (unsigned long long)a.drop_J + (unsigned long long)a.drop_j) *
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
             pk_dropout_words(eidx & ~3ull, a.drop_seeds ? a.drop_seeds[m0 + m] : 0ull, w4);
             s = w4[eidx & 3ull] >= a.drop_thr ? s * a.drop_scale : 0.f;
         }
-        if (a.res) s += a.res[(long)(m0 + m) * a.ldr + nn];
+        if (a.res) s += e_res;
         a.y[(long)(m0 + m) * a.ldy + nn] = s;
     }
 }

@@ -772,11 +772,11 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre1, q, M, p1, Pn, B, PK_ACT_RELU, nullptr, 0, nullptr));
             if (drop)
                 PK_LAUNCH(ctx, "taco_dropout", k_ar_dropout, dim3(pk_div_up((long)B * (Pn / 4), 256)), dim3(256), 0, p1, Pn, B,
-                          Pn, B, (unsigned long long)i, 2, 0, d_seeds, thr, dscale);
+                          Pn, B, (unsigned long long)i, 2, 0, d_seeds, thr, dscale, (float*)nullptr);
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_prenet", h->pre2, p1, Pn, in1, K1, B, PK_ACT_RELU, nullptr, 0, nullptr));
             if (drop)
                 PK_LAUNCH(ctx, "taco_dropout", k_ar_dropout, dim3(pk_div_up((long)B * (Pn / 4), 256)), dim3(256), 0, in1, K1, B,
-                          Pn, B, (unsigned long long)i, 2, 1, d_seeds, thr, dscale);
+                          Pn, B, (unsigned long long)i, 2, 1, d_seeds, thr, dscale, (float*)nullptr);
             PK_TRY(pk_fft_run_dense(h, "taco_gemm_att_rnn", h->att_rnn, in1, K1, gates, 4 * Ha, B, PK_ACT_NONE, nullptr, 0, nullptr));
             PK_LAUNCH(ctx, "taco_lstm_point", k_taco_lstm_point, dim3(pk_div_up((long)B * Ha, 256)), dim3(256), 0, gates,
                       h->d_catt.as<float>(), Ha, B, in1n + Pn + Eg, K1, in2, K2);

@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -121,32 +122,45 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
     float* red = sm + dk;     // 1024 partial sums (256 threads x float4) + 8 reduction slots
     float* sc = red + 1032;   // n scores -> probabilities
     const float* qp = a.q + (long)b * a.ldq + head * dk;
-    for (int c = tid; c < dk; c += 256) qs[c] = qp[c] * a.scale;
-    __syncthreads();
-    // scores: 16 lanes x float4 per key row, 4 keys per wave, 16 keys per pass, 4 passes per iteration with all of
-    // their (clamped, unconditional) loads issued before the first use
+    // scores: 16 lanes x float4 per key row, 4 keys per wave, 16 keys per pass; NB passes per iteration with all of their
+    // (clamped, unconditional) loads issued before the first use -- at the LJSpeech head size (64) that is 16 key rows per lane
+    // in flight, 256 keys per iteration (round 4; 4 passes before: a 640-key step was ten dependent round trips).  The query
+    // is staged after the first batch has been requested: its load and the barrier wait under the key loads.
     const int sub = lane & 15, kq = lane >> 4, nv = dk >> 2;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        float s4[4];
+    const float qreg = tid < dk ? qp[tid] * a.scale : 0.f;   // (dk <= 192 < 256 threads)
+    auto score_batch = [&](auto nb_tag, int j0) {
+        constexpr int NB = decltype(nb_tag)::value;
+        float4 kv[NB];
+        const float4* kp[NB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NB; ++u) {
             const int j = min(j0 + u * 16 + wave * 4 + kq, n - 1);
-            const float4* kp = reinterpret_cast<const float4*>(a.K + (base + (long)j * a.kstride) * a.ldkv + head * dk);
-            float s = 0.f;
+            kp[u] = reinterpret_cast<const float4*>(a.K + (base + (long)j * a.kstride) * a.ldkv + head * dk);
+            kv[u] = kp[u][min(sub, nv - 1)];
+        }
+        if (j0 == 0) {   // (uniform)
+            if (tid < dk) qs[tid] = qreg;
+            __syncthreads();
+        }
+        float s4[NB];
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {   // dk <= 192: at most 3 float4 per lane
+        for (int u = 0; u < NB; ++u) {
+            const float4 q0 = *reinterpret_cast<const float4*>(qs + 4 * min(sub, nv - 1));
+            float s = sub < nv ? fmaf(kv[u].x, q0.x, fmaf(kv[u].y, q0.y, fmaf(kv[u].z, q0.z, kv[u].w * q0.w))) : 0.f;
+#pragma unroll
+            for (int it = 1; it < 3; ++it) {   // dk <= 192: at most 3 float4 per lane
                 const int c4 = sub + 16 * it;
                 if (16 * it < nv) {            // block-uniform
-                    const float4 kv = kp[min(c4, nv - 1)];
+                    const float4 k2 = kp[u][min(c4, nv - 1)];
                     const float4 qv = *reinterpret_cast<const float4*>(qs + 4 * min(c4, nv - 1));
-                    const float t = fmaf(kv.x, qv.x, fmaf(kv.y, qv.y, fmaf(kv.z, qv.z, kv.w * qv.w)));
+                    const float t = fmaf(k2.x, qv.x, fmaf(k2.y, qv.y, fmaf(k2.z, qv.z, k2.w * qv.w)));
                     s += c4 < nv ? t : 0.f;
                 }
             }
             s4[u] = s;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NB; ++u) {
             float s = s4[u];
             s += __shfl_xor(s, 8);
             s += __shfl_xor(s, 4);
@@ -155,6 +169,15 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
             const int j = j0 + u * 16 + wave * 4 + kq;
             if (j < n && sub == 0) sc[j] = s;
         }
+    };
+    if (nv <= 16) {
+        for (int j0 = 0; j0 < n; j0 += 256) score_batch(std::integral_constant<int, 16>(), j0);
+    } else {
+        for (int j0 = 0; j0 < n; j0 += 64) score_batch(std::integral_constant<int, 4>(), j0);
+    }
+    if (n <= 0) {   // (never: every utterance has at least one key) keep the barrier count uniform
+        if (tid < dk) qs[tid] = qreg;
+        __syncthreads();
     }
     __syncthreads();
     // softmax over the n keys
@@ -185,7 +208,7 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g < G) {
         const float* vp = a.V + head * dk + 4 * c4;
-#pragma unroll 8
+#pragma unroll 16
         for (int j = g; j < n; j += G) {
             const float4 vv = *reinterpret_cast<const float4*>(vp + (base + (long)j * a.kstride) * a.ldkv);
             const float p = sc[j];
@@ -212,14 +235,44 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
 }
 
 // prob_out + sigmoid + the stop rule of :638-642, one wave per utterance.  len[b] == 0 while utterance b runs.
+// ln_g != NULL: z is the decoder's last row BEFORE after_norm, and the LayerNorm (eps 1e-5, two-pass in the wave) happens here --
+// the feat_out row GEMM normalises the same row in its own prologue, so after_norm needs no launch of its own (A <= 1024).
 __global__ __launch_bounds__(256) void k_tts_stop(const float* __restrict__ z, int A, const float* __restrict__ w,
                                                   float bias, int B, int step, float thr,
                                                   const int* __restrict__ minlen, const int* __restrict__ maxlen,
                                                   float* __restrict__ probs, int* __restrict__ len,
-                                                  int* __restrict__ ndone) {
+                                                  int* __restrict__ ndone, const float* __restrict__ ln_g,
+                                                  const float* __restrict__ ln_b) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     float s = 0.f;
+    if (ln_g) {
+        float v[16];
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = lane + 64 * e;
+            v[e] = c < A ? z[(long)b * A + c] : 0.f;
+            t += v[e];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        const float mean = t / (float)A;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float d = lane + 64 * e < A ? v[e] - mean : 0.f;
+            q += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)A + 1e-5f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = lane + 64 * e;
+            if (c < A) s = fmaf((v[e] - mean) * rstd * ln_g[c] + ln_b[c], w[c], s);
+        }
+    } else
     for (int c = lane; c < A; c += 64) s = fmaf(z[(long)b * A + c], w[c], s);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -338,7 +391,7 @@ struct pk_tts : pk_fft_core {
     std::vector<int> T, len, cap, frames;   // per utterance: tokens (+ eos), decoder steps, step capacity, frames = steps * r
     std::vector<long> att_off;
     long att_total = 0;
-    pk_dbuf d_tok, d_e1, d_e2, d_tpe, d_hs, d_valid, d_y, d_p0, d_p1, d_x0, d_t, d_ham, d_peb, d_rt, d_rc, d_rx, d_rq,
+    pk_dbuf d_tok, d_e1, d_e2, d_tpe, d_hs, d_valid, d_y, d_p0, d_p1, d_x0, d_t, d_ham, d_pam, d_peb, d_rt, d_rc, d_rx, d_rq,
         d_rf, d_rz, d_ra, d_rn, d_probs, d_state, d_seeds, d_att, d_attoff, d_before, d_q1, d_q2, d_rowmap, d_stage, d_stage2;
     std::vector<pk_dbuf> d_qkv_l, d_xc_l, d_mkv_l;
 };
@@ -869,6 +922,8 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     PK_TRY(rows_reserve(h->d_x0, rowsCap, A));
     PK_TRY(rows_reserve(h->d_t, rowsCap, A));
     PK_TRY(rows_reserve(h->d_ham, rowsCap, 1));
+    PK_TRY(rows_reserve(h->d_pam, 2 * (rowsCap + SLACK), 1));
+    PK_HIP(hipMemsetAsync(h->d_pam.p, 0, h->d_pam.cap, ctx->stream));   // (rows beyond the prefix are read as scales of unused tile rows)
     PK_TRY(rows_reserve(h->d_peb, rowsCap, A));
     for (int l = 0; l < c.dlayers; ++l) {
         PK_TRY(rows_reserve(h->d_qkv_l[l], rowsCap, 3 * A));
@@ -923,6 +978,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     float* X0 = pk_fft_act_ptr(h->d_x0, A);
     float* Tn = pk_fft_act_ptr(h->d_t, A);
     float* ham = pk_fft_act_ptr(h->d_ham, 1);
+    float* pam[2] = {pk_fft_act_ptr(h->d_pam, 1), pk_fft_act_ptr(h->d_pam, 1) + rowsCap + SLACK};   // row maxima of the prenet outputs
     float* PEB = pk_fft_act_ptr(h->d_peb, A);
     float* rt = pk_fft_act_ptr(h->d_rt, A);
     float* rc = pk_fft_act_ptr(h->d_rc, A);
@@ -962,17 +1018,21 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         // decoder.embed on the whole prefix (decoder.py:210)
         const float* in = Y + (RF - 1) * O;   // the LAST frame of every step's output is the next input (:619-621)
         int ldin = OR;
+        const float* in_amax = nullptr;
         for (int j = 0; j < J; ++j) {
             float* o = P[j & 1];
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_prenet", h->dprenet[j], in, ldin, o, U, R, PK_ACT_RELU, nullptr, 0, nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_prenet", h->dprenet[j], in, ldin, o, U, R, PK_ACT_RELU, nullptr, 0, nullptr, in_amax));
+            // the row maxima of what the next GEMM reads come out of the dropout kernel (one wave per row at 256 units)
+            float* o_amax = (h->dropout && use_ham && U == 256) ? pam[j & 1] : nullptr;
             if (h->dropout)
                 PK_LAUNCH(ctx, "tts_dropout", k_ar_dropout, dim3(pk_div_up((long)R * (U / 4), 256)), dim3(256), 0, o, U, R, U,
-                          B, (unsigned long long)s * (unsigned long long)(s - 1) / 2ull, J, j, d_seeds, thr, dscale);
+                          B, (unsigned long long)s * (unsigned long long)(s - 1) / 2ull, J, j, d_seeds, thr, dscale, o_amax);
             in = o;
             ldin = U;
+            in_amax = o_amax;
         }
         if (J > 0) {
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, PEB, A, nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, PEB, A, nullptr, in_amax));
         } else {
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, nullptr, 0, nullptr));
             PK_TRY(pk_fft_layernorm_rows(h, X0, h->dlin_ln_g, h->dlin_ln_b, valid, R, A, Tn, nullptr));
@@ -1120,13 +1180,22 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
                                     use_ham ? ham : nullptr));
             PK_TRY(pk_fft_run_dense(h, "tts_gemm_ffn2", L.ffn2, rf, c.dunits, xc_new, A, B, PK_ACT_NONE, rx, A, nullptr));
         }
-        // after_norm of the last row, feat_out -> the next prefix row, prob_out -> stop state (:613-616, :638-642)
+        // after_norm of the last row, feat_out -> the next prefix row, prob_out -> stop state (:613-616, :638-642).
+        // Row-GEMM path with pre-norm blocks and one frame per step: after_norm is the LayerNorm prologue of the feat_out row
+        // GEMM and of the stop kernel (two launches instead of three); otherwise rz = the normalised row first.
+        const float* xlast = pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A;
+        const bool fuse_after = !post && use_rg && RF == 1 && A <= 1024 && A <= PK_RG_KC;
+        if (fuse_after) {
+            PK_TRY(rowgemm("tts_row_feat_out", h->r_feat_out, xlast, A, Y + (long)s * B * OR, OR, PK_ACT_NONE, nullptr, 0, h->dec_after_g,
+                           h->dec_after_b, true));
+            PK_LAUNCH(ctx, "tts_stop", k_tts_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, xlast, A, h->W(h->prob_w), h->prob_b, B, s,
+                      (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone, h->W(h->dec_after_g),
+                      h->W(h->dec_after_b));
+        } else {
         if (!post)
-            PK_TRY(pk_fft_layernorm_rows(h, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, h->dec_after_g, h->dec_after_b,
-                                         valid, B, A, rz, use_ham ? ham : nullptr));
+            PK_TRY(pk_fft_layernorm_rows(h, xlast, h->dec_after_g, h->dec_after_b, valid, B, A, rz, use_ham ? ham : nullptr));
         else   // no after_norm with post-norm blocks (decoder.py:220-221): the last layer's row as it is
-            PK_HIP(hipMemcpyAsync(rz, pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A, (size_t)B * A * sizeof(float),
-                                  hipMemcpyDeviceToDevice, ctx->stream));
+            PK_HIP(hipMemcpyAsync(rz, xlast, (size_t)B * A * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         if (use_rg)
             PK_TRY(rowgemm("tts_row_feat_out", h->r_feat_out, rz, A, Y + (long)s * B * OR, OR, PK_ACT_NONE, nullptr, 0, 0, 0, false));
         else
@@ -1134,10 +1203,12 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
                                     0, nullptr, use_ham ? ham : nullptr));
         if (RF == 1)
             PK_LAUNCH(ctx, "tts_stop", k_tts_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, rz, A, h->W(h->prob_w), h->prob_b, B, s,
-                      (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone);
+                      (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone, (const float*)nullptr,
+                      (const float*)nullptr);
         else
             PK_LAUNCH(ctx, "tts_stop", k_tts_stop_r, dim3(pk_div_up(B, 4)), dim3(256), 0, rz, A, h->W(h->prob_w),
                       h->W(h->prob_bv), RF, B, s, (float)threshold, d_minlen, d_maxlen, h->d_probs.as<float>(), d_len, d_ndone);
+        }
         if (s % poll == 0 || s == Lcap) {
             int ndone = 0;
             PK_HIP(hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1271,7 +1342,7 @@ extern "C" void pk_tts_destroy(pk_tts* h) {
     h->release_core();
     pk_gst_release(h->gst);
     pk_dbuf* bufs[] = {&h->d_style, &h->d_spk_emb, &h->d_spk_vec, &h->d_tok, &h->d_e1, &h->d_e2, &h->d_tpe, &h->d_hs, &h->d_valid, &h->d_y, &h->d_p0, &h->d_p1,
-                       &h->d_x0, &h->d_t, &h->d_ham, &h->d_peb, &h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rf, &h->d_rz,
+                       &h->d_x0, &h->d_t, &h->d_ham, &h->d_pam, &h->d_peb, &h->d_rt, &h->d_rc, &h->d_rx, &h->d_rq, &h->d_rf, &h->d_rz,
                        &h->d_ra, &h->d_rn, &h->d_probs, &h->d_state, &h->d_seeds, &h->d_att, &h->d_attoff, &h->d_before, &h->d_q1, &h->d_q2,
                        &h->d_rowmap, &h->d_stage, &h->d_stage2};
     for (auto* b : bufs) b->release();

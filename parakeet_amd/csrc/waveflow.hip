@@ -164,7 +164,11 @@ struct pk_wf {
     bool no_fuse = pk_prof_env("PK_WF_NO_FUSE") != nullptr;   // measurement switch: separate out_proj launches
     int mp = 96;              // mel channels padded to a multiple of 32 (GEMM K block of the condition)
     int layer_waves = 0;      // option "layer_waves": 0 = the launcher chooses, 8 / 12 = waves per workgroup of the fused layer kernel
-    bool persistent = true;   // option "persistent": the layers of a row in ONE launch behind grid barriers (pk_grid.h)
+    bool persistent = false;  // option "persistent": the layers of a row in ONE launch behind grid barriers (pk_grid.h).  Built, correct
+                              // (bit-identical, tests/test_waveflow_gpu.py) and SLOWER on this part: a barrier across 236 workgroups
+                              // on 8 XCDs costs 11 us of serialised atomics + 16 - 27 us of L2 write-back / invalidate
+                              // (tools/micro/grid_barrier.hip, profiles/r04_grid_barrier_micro.txt) against the 5 - 6 us between two
+                              // dependent launches -- 1 089 us per row instead of 8 x 55.  Off by default.
     bool fuse_step = true;    // option "fuse_step": the row's step in the launch of its last layer (else a kernel of its own)
     std::vector<WfFlowW> flows;
     std::vector<size_t> up_w;

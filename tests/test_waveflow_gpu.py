@@ -59,8 +59,8 @@ def test_waveflow_96_mel_channels_runs_unfused():
     A 96-mel model must take the unfused GEMM path -- same result bars -- and refuse the fp16-operand mode, which exists on the
     fused kernel only; an 80-mel model runs the fused kernel."""
     from parakeet_amd.waveflow import ConditionalWaveFlow
-    _run(dict(channels=64, n_flows=2, n_mels=96), [4, 3], seed=6, expect_kernel=("wf_gemm_conv_gate", "wf_layer"))
-    _run(dict(channels=64, n_flows=2), [4, 3], seed=6, expect_kernel=("wf_layer", "wf_gemm_conv_gate"))
+    _run(dict(channels=64, n_flows=2, n_mels=96), [4, 3], seed=6, expect_kernel=("wf_gemm_conv_gate", ("wf_layer", "wf_row")))
+    _run(dict(channels=64, n_flows=2), [4, 3], seed=6, expect_kernel=(("wf_row", "wf_layer"), "wf_gemm_conv_gate"))
     cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64, n_flows=2, n_mels=96)
     m = ConditionalWaveFlow(**cfg)
     with pytest.raises(NotImplementedError):
@@ -105,8 +105,9 @@ def test_waveflow_12_wave_workgroups_bit_identical(math):
 @pytest.mark.parametrize("channels", [64, 128])
 def test_waveflow_row_kernel_variants_bit_identical(channels):
     """the residual stack of a row as ONE launch -- the eight layers behind barriers across the grid
-    (csrc/pk_grid.h, a cooperative launch), the row's affine step and the next row's input projection in the epilogue of the
-    last layer: 120 launches per batch instead of 960 + 120.  The options "persistent" and "fuse_step" only move launch
+    (csrc/pk_grid.h, a cooperative launch; option "persistent", off by default: measured slower than eight launches on the
+    MI355X), the row's affine step and the next row's input projection in the epilogue of the last layer (option "fuse_step",
+    on): 960 launches per batch instead of 960 + 120, or 120.  The options "persistent" and "fuse_step" only move launch
     boundaries: every combination gives the same waveform bit for bit (and the first one is checked against the oracle by the
     tests above).  Under the host emulation (PK_EMU) there is no grid barrier: "persistent" is then one launch per layer."""
     from parakeet_amd.waveflow import ConditionalWaveFlow

@@ -19,6 +19,7 @@ elif mode in ("wf", "wf128", "wf16", "wf128_16"):                  # 64 / 128 ch
     cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=128 if "128" in mode else 64, n_flows=2)   # two flows = 240 layer launches are plenty for counters
     m = ConditionalWaveFlow(**cfg); m.set_state_dict(syn.waveflow_state(cfg)); m.eval()
     if mode.endswith("16"): m.set_math("f16")
+    if os.environ.get("PK_QWF_PERSISTENT"): m.set_option("persistent", int(os.environ["PK_QWF_PERSISTENT"]))   # counters per LAYER launch
     rng = np.random.default_rng(0)
     Bw = min(B, 8)
     mels = [torch.tensor(np.maximum(rng.normal(-4, 2, size=(80, L)), np.log(1e-5)).astype(np.float32)).cuda() for _ in range(Bw)]

@@ -11,6 +11,7 @@ cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=C)
 m = ConditionalWaveFlow(**cfg); m.set_state_dict(syn.waveflow_state(cfg)); m.eval()
 if MATH: m.set_math(MATH)
 if WAVES: m.set_option("layer_waves", WAVES)
+if os.environ.get("PK_QWF_PERSISTENT"): m.set_option("persistent", int(os.environ["PK_QWF_PERSISTENT"]))   # 0: one launch per layer
 rng = np.random.default_rng(0)
 mels = [torch.tensor(np.maximum(rng.normal(-4, 2, size=(80, L)), np.log(1e-5)).astype(np.float32)).cuda() for _ in range(B)]
 zs = [torch.randn(m.lengths(L)[0], device='cuda') for _ in range(B)]
@@ -21,7 +22,7 @@ t=time.time(); n=2
 for i in range(n): m.infer_batch(mels, zs)
 torch.cuda.synchronize(); dt=(time.time()-t)/n
 ns = sum(o.numel() for o in out)
-print(f"WaveFlow C={C} math={MATH} waves={WAVES} B={B} L={L}: {dt*1e3:.1f} ms/batch, {ns/dt/1e6:.2f} Msamples/s, {ns/dt/22050:.0f}x RT")
+print(f"WaveFlow C={C} math={MATH} waves={WAVES} persistent={os.environ.get('PK_QWF_PERSISTENT', 'default')} B={B} L={L}: {dt*1e3:.1f} ms/batch, {ns/dt/1e6:.2f} Msamples/s, {ns/dt/22050:.0f}x RT")
 ctx.prof_enable(True); ctx.prof_reset()
 m.infer_batch(mels, zs)
 for k,(n_,ms) in ctx.prof_dump().items(): print(f"  {k:20s} n={n_:5d} total={ms:9.3f} ms avg={ms/n_*1e3:8.1f} us")
