@@ -196,7 +196,9 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
                 ("fp16 operands / fp32 accumulation: the reference's own AMP inference precision "
                  "(examples/waveflow/synthesize.py:40), set_math('f16'); NOT fp32-equivalent (about 1e-4 of the peak)"
                  if math == "f16" else
-                 "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes"),
+                 "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes") +
+                ("; 12-wave workgroups (one round of 11 tiles per workgroup), the row's step fused into its last layer's launch"
+                 if channels == 64 else "; 8-wave workgroups"),
         "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,
         "ms_per_batch_runs": [t * 1e3 for t in times],
         "reference_published": "about 40x real time on V100 (docs/src/released_models.md:275-276)"}
@@ -414,8 +416,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
-    # PK_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, weight broadcast, barriers, max-reduce) at N = 1
-    distributed = world > 1 or bool(os.environ.get("PK_BENCH_FORCE_DIST"))
+    # PK_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, weight broadcast, barriers, max-reduce) at N = 1; so does a
+    # launcher (torch.distributed.run sets RANK and MASTER_ADDR even for one rank): the path the driver's N > 1 runs take is
+    # the path a launched N = 1 run takes.  Plain `python bench.py` (the driver's N = 1 run) creates no process group.
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ and not os.environ.get("PK_BENCH_SPAWNED_PLAIN")
+    distributed = world > 1 or launched or bool(os.environ.get("PK_BENCH_FORCE_DIST"))
     dry = args.dry_run
     if not dry:
         if not torch.cuda.is_available():

@@ -892,6 +892,7 @@ struct pk_fs2 : pk_fft_core {
     // per-call state
     Timeline tl_tok, tl_frm, tl_frm2;   // tokens, decoder rows, mel frames (= decoder rows unless reduction_factor > 1)
     pk_dbuf d_wide, d_rowmap2;
+    pk_dbuf d_pamax;   // row maxima of the predictors' LayerNorm outputs
     pk_dbuf d_tok, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
         d_before, d_q1, d_q2, d_rowmap, d_dbg_up, d_zs, d_mel_stage;
     std::vector<int> frames;   // per utterance, result of encode
@@ -1659,6 +1660,16 @@ int pk_fft_run_postnet(pk_fft_core* h, const char* name, const std::vector<Dense
     PK_TRY(pk_fft_act_reserve(q2, tl.rows, chans));
     const float* in = before;
     int ldin = odim;
+    // operand scale of the layers that read tanh outputs: |tanh| <= 1 is its own bound -- a constant array of ones in place of a
+    // k_row_amax pass per layer (refilled only when the buffer grows)
+    const float* ones = nullptr;
+    if (h->math == PK_GEMM_MATH_F16X3 && n > 1) {
+        const void* p0 = h->d_ones.p;
+        PK_TRY(pk_fft_act_reserve(h->d_ones, tl.rows, 1));
+        if (h->d_ones.p != p0)
+            PK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_ones.p), 0x3f800000, h->d_ones.cap / 4, h->ctx->stream));
+        ones = pk_fft_act_ptr(h->d_ones, 1);
+    }
     for (int j = 0; j < n; ++j) {
         const Dense& d = postnet[j];
         const bool last = j == n - 1;
@@ -1668,6 +1679,7 @@ int pk_fft_run_postnet(pk_fft_core* h, const char* name, const std::vector<Dense
         g.Wh = d.wh == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + d.wh; g.math = h->math;
         g.M = tl.rows; g.N = d.N; g.Cin = d.Cin; g.taps = d.taps; g.pad = d.pad;
         g.rowvalid = tl.d_row_utt();
+        if (j > 0) g.a_amax = ones;
         if (!last) {
             g.C = outb; g.ldc = chans; g.act = PK_ACT_TANH;
         } else {
@@ -1705,12 +1717,22 @@ static int run_predictor(pk_fs2* h, const Predictor& pr, const Timeline& tl, con
     float* p2 = pk_fft_act_ptr(h->d_p2, pr.chans);
     const float* in = hs;
     int ldin = A;
+    // operand scales of the split-fp16 convs: the row maxima come out of the LayerNorm that produces the rows (no pass of
+    // their own: 6 of the 9 k_row_amax launches of a batch); the buffer is zero outside the rows it writes (margins, padding)
+    float* pam = nullptr;
+    if (h->math == PK_GEMM_MATH_F16X3) {
+        PK_TRY(pk_fft_act_reserve(h->d_pamax, tl.rows, 1));
+        PK_HIP(hipMemsetAsync(h->d_pamax.p, 0, h->d_pamax.cap, h->ctx->stream));
+        pam = pk_fft_act_ptr(h->d_pamax, 1);
+    }
+    const float* in_amax = nullptr;
     for (size_t j = 0; j < pr.conv.size(); ++j) {
         PK_TRY(pk_fft_run_dense(h, "fs2_conv_predictor", pr.conv[j], in, ldin, p1, pr.chans, tl.rows, PK_ACT_RELU, nullptr, 0,
-                         nullptr));
-        PK_TRY(pk_fft_run_layernorm(h, p1, pr.ln_g[j], pr.ln_b[j], tl, pr.chans, p2));
+                         nullptr, in_amax));
+        PK_TRY(pk_fft_run_layernorm(h, p1, pr.ln_g[j], pr.ln_b[j], tl, pr.chans, p2, pam));
         in = p2;
         ldin = pr.chans;
+        in_amax = pam;
     }
     PK_LAUNCH(h->ctx, "fs2_rowdot", k_rowdot, dim3(pk_div_up(tl.rows, 4)), dim3(256), 0, in, ldin, h->W(pr.lin_w),
               pr.lin_b, tl.d_row_utt(), tl.rows, duration_mode, 1.0f, alpha, out);
@@ -2034,7 +2056,7 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
-    pk_dbuf* bufs[] = {&h->d_tok, &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
+    pk_dbuf* bufs[] = {&h->d_pamax, &h->d_tok, &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
                        &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage,
                        &h->d_wide, &h->d_rowmap2};
     for (auto* b : bufs) b->release();

@@ -107,6 +107,9 @@ struct WflLaunch {
     float step_b_logs, step_b_b;   // the flow's folded biases
     const WflLayer* layers;     // DEVICE memory: the nl layer descriptors of this launch (not a by-value array: indexing kernel
                                 // arguments with the layer counter makes the compiler hold every element in scalar registers)
+    WflLayer l0;                // nl == 1: the layer's descriptor by value as well -- the one-layer kernels read it from the kernel
+                                // argument segment, whose loads the compiler re-issues at will instead of holding (or spilling)
+                                // their results across the slab loop (filled by wfl_layer_launch from layers[0]'s host image)
 };
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a);
 

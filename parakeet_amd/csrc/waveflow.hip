@@ -634,11 +634,13 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 w.err = h->ws_bar.as<int>() + 1;
                 const bool persistent = h->persistent && pk_grid_available() && NL <= WFL_MAX_LAYERS && !d_trace;
                 const int per = persistent ? NL : 1;
+                const bool fuse = h->fuse_step && C == 64;   // (the 128-channel kernel has no registers for the fused step)
                 float* h0n = (i + 1 < G) ? hist_ptr(0, (i + 1) % 3) : nullptr;
                 for (int l0 = 0; l0 < NL; l0 += per) {
                     w.nl = per;
                     w.layers = h->ws_desc.as<WflLayer>() + ((size_t)(fl * 3 + slot) * NL + l0);   // (flow, ring slot, layer)
-                    if (l0 + per == NL && h->fuse_step) {
+                    w.l0 = h->desc_host[(size_t)(fl * 3 + slot) * NL + l0];                        // ... and its host image (per == 1)
+                    if (l0 + per == NL && fuse) {
                         w.step_z = cur + (long)perm[i] * pstride;
                         w.step_x = nxt + (long)i * pstride;
                         w.step_w_in = h->W(F.w_in);
@@ -650,7 +652,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                     }
                     PK_TRY(wfl_layer_launch(ctx, w));
                 }
-                if (!h->fuse_step)
+                if (!fuse)
                     PK_TRY(wfl_step_launch(ctx, C, prm, F.b_logs_f, F.b_b_f, cur + (long)perm[i] * pstride,
                                            nxt + (long)i * pstride, h->W(F.w_in), h->W(F.b_in), h0n,
                                            h0n ? hbmax_ptr(0, (i + 1) % 3) : nullptr, rowvalid, npos_alloc, 0));

@@ -191,12 +191,16 @@ __device__ __forceinline__ int opaque_zero() {
 // rounds it to nearest: half the operand bytes, no arithmetic on the way to the MFMA); gate outputs: one conversion.  The
 // layer inputs stay the same 22-bit pairs, so only the products lose precision, not the residual stream.  A third of the matrix
 // work; not the default.
-template <int CT, int NT, int ABL = 0, bool F16 = false, int W = 8>
+// MULTI: the launch may hold several layers of the row (a.nl > 1: grid barriers between them, pk_grid.h).  A separate
+// instantiation because the loop around the layer body is not free: it lengthens live ranges (the 128-channel kernel went from
+// 28 to 63 spilled registers, 88 -> 128 us per launch with fp16 operands) -- the one-layer kernels are compiled without it.
+template <int CT, int NT, int ABL = 0, bool F16 = false, int W = 8, bool MULTI = false>
 __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
     typedef Shape<CT, W> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
     constexpr int RING = (W == 12 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
     static_assert(W == 8 || (W == 12 && CT == 2 && ABL == 0), "12-wave workgroups: the 64-channel model");
+    static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
     constexpr int nks_conv = S::KS_TAP * ntap;
     constexpr int nks = nks_conv + WFL_KS_COND;
@@ -234,10 +238,9 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
     // straight-line body the compiler hoists each thread-invariant address out of it and keeps it in a register through all
     // layers (+ 40 vector registers, spills in the 12-wave and 128-channel kernels).
 #pragma unroll 1
-    for (int li = 0; li < a.nl; ++li) {
-    if (li > 0) pk_grid_barrier(a.bar, (unsigned)li * gridDim.x, a.err);   // (every wave of this workgroup is past its epilogue too)
-    int oz = 0;
-    asm volatile("" : "+s"(oz));
+    for (int li = 0; li < (MULTI ? a.nl : 1); ++li) {
+    if (MULTI && li > 0) pk_grid_barrier(a.bar, (unsigned)li * gridDim.x, a.err);   // (every wave of this workgroup is past its epilogue too)
+    const int oz = opaque_zero<MULTI>();
     const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int ntiles = a.npos_alloc / WAVE_T;
@@ -281,8 +284,9 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
             if (c < (g < nslab ? S::CPT1 : S::CPT2)) wbuf[g % 3][c * THREADS + tid] = wreg[c];
     };
 
-    const WflLayer& L = a.layers[li];   // (device memory, wave-uniform address: scalar loads, here only)
-    if (tid == 0) {
+    // (MULTI: device memory, wave-uniform address -- scalar loads, here only; one layer: the kernel argument segment)
+    const WflLayer& L = MULTI ? a.layers[li] : a.l0;
+    if (MULTI && tid == 0) {
         cold.out = L.out;
         cold.out_amax = L.out_amax;
         cold.has_out = L.out != nullptr;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
             // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex
             const int ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(wave_max64(__uint_as_float(m_raw)))));   // (all sources are maxima: the repeats change nothing)
             const int kx = PK_BLK_TOP + 127 - ex;
-            const int ks1 = kx + (&cold)[lz].k1;
+            const int ks1 = kx + (MULTI ? (&cold)[lz].k1 : a.l0.w.k1);
             const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
             const float gcb = __int_as_float(cbb), gca = __int_as_float(cbb + (1 << 23));
             f16x8 f;          // rescale factor of the tap being consumed
@@ -511,9 +515,30 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
             const int p_e = W == 12 ? p0 + (lane_e & 31) : p;
             const long pblk_e = W == 12 ? (long)(p_e >> 5) : pblk;
             const int pin_e = W == 12 ? p_e & 31 : pin;
-            const Cold& cd = (&cold)[ez];   // (read here, with the other old values: wave-uniform, made scalar where it branches)
-            const bool has_out = __builtin_amdgcn_readfirstlane(cd.has_out) != 0;
-            const bool l_first = __builtin_amdgcn_readfirstlane(cd.first) != 0;
+            // MULTI: the parked copies (read here, with the other old values: wave-uniform, made scalar where they branch);
+            // one layer: the kernel arguments themselves
+            Cold cd;
+            if constexpr (MULTI) {
+                cd = (&cold)[ez];
+                cd.has_out = __builtin_amdgcn_readfirstlane(cd.has_out);
+                cd.first = __builtin_amdgcn_readfirstlane(cd.first);
+            } else {
+                cd.out = a.l0.out;
+                cd.out_amax = a.l0.out_amax;
+                cd.has_out = a.l0.out != nullptr;
+                cd.first = a.l0.first;
+                cd.k2res = a.l0.w.k2res;
+                cd.step_z = a.step_z;
+                cd.step_x = a.step_x;
+                cd.step_w_in = a.step_w_in;
+                cd.step_b_in = a.step_b_in;
+                cd.step_h0 = a.step_h0;
+                cd.step_h0_amax = a.step_h0_amax;
+                cd.step_b_logs = a.step_b_logs;
+                cd.step_b_b = a.step_b_b;
+            }
+            const bool has_out = cd.has_out != 0;
+            const bool l_first = cd.first != 0;
             const float i_res = pow2f(-(PK_UNIT_EXP + cd.k2res));
             {
                 const char* cur = in0b + ((long)a.cur_slot * a.slot_stride) * 4 + pblk_e * S::BLK_BYTES + pin_e * 32 + hh_e * 1024;
@@ -641,12 +666,13 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
             // (Flow._predict_row_parameters :496-501, _inverse_transform_row :503-505), h0 = input_proj(x) -> the next row's
             // layer-0 input as planes.  Its ring slot is the one layer 0 of THIS row read as its oldest row: every workgroup
             // is past that layer (grid barriers / earlier launches).
-            const float* const step_z = cd.step_z;
-            if (__builtin_amdgcn_readfirstlane(step_z != nullptr)) {
+            // (64 channels only: at 128 the kernel has no registers for it -- 10 more spilled --, and the step is 1 % of the batch)
+            const float* const step_z = CT == 2 ? cd.step_z : nullptr;
+            if (CT == 2 && (MULTI ? __builtin_amdgcn_readfirstlane(step_z != nullptr) : step_z != nullptr)) {
                 const float xn = lane_ok ? (step_z[p_e] - (prm_new.y + cd.step_b_b)) * expf(-(prm_new.x + cd.step_b_logs)) : 0.f;
                 if (hh_e == 0) cd.step_x[p_e] = xn;
                 float* const step_h0 = cd.step_h0;
-                if (__builtin_amdgcn_readfirstlane(step_h0 != nullptr)) {
+                if (MULTI ? __builtin_amdgcn_readfirstlane(step_h0 != nullptr) : step_h0 != nullptr) {
                     float v[S::KS2][8];
                     float am = 0.f;
 #pragma unroll
@@ -946,6 +972,19 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         return PK_OK;
     };
     const int nt = a.ntap / 3;
+    if (a.nl > 1) {   // the multi-layer instantiations (option "persistent")
+        if (w12) {
+            if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 12, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 12, true>) : go(k_wf_layer_p<2, 3, 0, true, 12, true>));
+            return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 12, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 12, true>) : go(k_wf_layer_p<2, 3, 0, false, 12, true>));
+        }
+        if (a.f16) {
+            if (a.C == 64)
+                return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 8, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 8, true>) : go(k_wf_layer_p<2, 3, 0, true, 8, true>));
+            return nt == 1 ? go(k_wf_layer_p<4, 1, 0, true, 8, true>) : (nt == 2 ? go(k_wf_layer_p<4, 2, 0, true, 8, true>) : go(k_wf_layer_p<4, 3, 0, true, 8, true>));
+        }
+        if (a.C == 64) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 8, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 8, true>) : go(k_wf_layer_p<2, 3, 0, false, 8, true>));
+        return nt == 1 ? go(k_wf_layer_p<4, 1, 0, false, 8, true>) : (nt == 2 ? go(k_wf_layer_p<4, 2, 0, false, 8, true>) : go(k_wf_layer_p<4, 3, 0, false, 8, true>));
+    }
     if (w12) {
         if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 12>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 12>) : go(k_wf_layer_p<2, 3, 0, true, 12>));
         return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 12>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 12>) : go(k_wf_layer_p<2, 3, 0, false, 12>));

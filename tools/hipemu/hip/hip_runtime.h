@@ -61,6 +61,12 @@ hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t sp
                             hipMemcpyKind kind, hipStream_t s);
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s);
 hipError_t hipMemset(void* dst, int value, size_t bytes);
+typedef void* hipDeviceptr_t;
+static inline hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int value, size_t count, hipStream_t) {
+    int* p = static_cast<int*>(dst);
+    for (size_t i = 0; i < count; ++i) p[i] = value;
+    return hipSuccess;
+}
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize(void);
 hipError_t hipSetDevice(int dev);
