@@ -403,7 +403,10 @@ int pk_tts_set_normalizer(pk_tts* h, const float* mu, const float* sigma, int32_
 int pk_tts_set_math(pk_tts* h, int32_t mode);
 /* Named integer options: those of pk_fs2_set_option (the encoder's FFT stack), and
  *   "kv_prefix"  0 (default); 1 = decoder layer 0 projects k | v only for the prefix rows and q for the new rows with a
- *                row GEMM (measured neutral on an MI355X, kept as an option) */
+ *                row GEMM (measured neutral on an MI355X, kept as an option)
+ *   "overlap_prefix"  1 (default) = the next decoding step's prefix work (prenet with its fresh dropout, input layer, layer 0's
+ *                q | k | v of the row blocks that exist already) runs on a side stream under the current step's layer chain;
+ *                0 = everything in order on one stream.  Same spectrogram bit for bit */
 int pk_tts_set_option(pk_tts* h, const char* key, int64_t value);
 /* Decoder-prenet dropout: 1 (default) = the dropout stream above with p = 0.5, element index
  * ((s*(s-1)/2 + pos) * dprenet_layers + layer) * dprenet_units + unit for decoding step s = 1, 2, ... and prefix

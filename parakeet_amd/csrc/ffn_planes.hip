@@ -54,7 +54,8 @@ namespace {
 // an octet's 1 KB of a block: [plane hi | lo][row 32][8 halves] -- a half wave's operand load of one k-step is 512 contiguous
 // bytes per plane (pk_wf_layer.h interleaves the planes per row: [row][hi | lo][8], 16 of every 32 bytes per load)
 constexpr int ROW_B = 16, LO_OFF = 512;
-constexpr int CPT = 6;   // 16-byte chunks of a weight slab per thread: a slab is 6 KB per wave of the workgroup (48 KB for 8 waves)
+// (a weight slab is CPT 16-byte chunks per thread -- template parameter of the kernel, 6 by default: 6 KB per wave of the
+// workgroup, 48 KB for 8 waves)
 
 struct Args {
     FfnpConv c;
@@ -122,9 +123,14 @@ __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x
 // BF32 (one tap only): the B operand is a row-major fp32 matrix (in, ldin floats per row) with a magnitude bound per row in
 // in_amax; it is scaled and split in registers, once per column tile that reads it (the attention output, whose producer
 // holds a channel x 16 queries per lane -- the transpose of a planes vector)
-template <int NQ, int KQ, int EPI, int W, int TAPS = FFNP_TAPS, int ABL = 0, bool BF32 = false>
+// TAPS = 1 (Linear), 3 or 5 (round 4: the k = 5 convs of the postnet and of the pitch predictor); CPT = 16-byte chunks of a
+// weight slab per thread -- a slab must be a whole number of k-steps AND divide the k loop: 6 for the shapes of rounds 1 - 3,
+// 5 where TAPS * KQ = 80 (256 channels, k = 5).  ACT: activation of EPI 0 (0 ReLU, 1 tanh) and of EPI 2 (0 none, 1 tanh,
+// 2 ReLU; with an activation EPI 2 also zeroes gap rows: its output is the zero-padded input of another conv).
+template <int NQ, int KQ, int EPI, int W, int TAPS = FFNP_TAPS, int ABL = 0, bool BF32 = false, int CPT = 6, int ACT = 0>
 __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
     constexpr int THREADS = 64 * W;
+    constexpr int HT = TAPS / 2;              // taps reach HT rows to either side
     constexpr int SLAB_CH = CPT * THREADS;    // 16-byte chunks per slab buffer
     constexpr int KCH = 2 * NQ * 64;          // chunks per k-step of the packed weights
     constexpr int SLAB = SLAB_CH / KCH;       // k-steps per slab: 3 / 6
@@ -159,18 +165,20 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         // the maxima of the three blocks the taps read (lanes 0..2; the others repeat lane 0's)
         // the maxima of the rows this lane's taps read (its own row's output depends on nothing else: every row keeps its own
         // scale through the whole kernel, so a result does not depend on which utterances share the batch)
-        const unsigned am0 = a.c.in_amax[p - 1], am1 = a.c.in_amax[p], am2 = a.c.in_amax[p + 1];
+        unsigned am[TAPS];   // (TAPS = 1: the row's own)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) am[t] = a.c.in_amax[p + t - HT];
         // this lane's operand of tap t = its 8 channels (octet 2 kq + hh) of row p + t - 1: byte offset from block blk - 1
         const char* inb = reinterpret_cast<const char*>(a.c.in) + ((long)blk - 1) * a.in_blk;
-        unsigned off[FFNP_TAPS];
+        unsigned off[TAPS];
 #pragma unroll
-        for (int t = 0; t < FFNP_TAPS; ++t) {
-            const int q = j + t - 1;   // -1 .. 32 (one tap: only t = 1 is used)
+        for (int t = 0; t < TAPS; ++t) {
+            const int q = j + t - HT;   // -HT .. 31 + HT
             off[t] = (unsigned)((q + 32) >> 5) * (unsigned)a.in_blk + (unsigned)((q & 31) * ROW_B + hh * 1024);
         }
         f16x8 rhi[RING], rlo[RING];
         auto load_b = [&](int ks) {
-            const int kq = ks / TAPS, tap = TAPS == 1 ? 1 : ks % TAPS, slot = ks % RING;
+            const int kq = ks / TAPS, tap = ks % TAPS, slot = ks % RING;
             if (BF32) {   // channels 16 kq + 4 hh + (0..3) and + 8: wfl_chan(kq, hh, 0..7)
                 const float* src = reinterpret_cast<const float*>(a.c.in) + (long)p * a.c.ldin + 16 * kq + 4 * hh;
                 rhi[slot] = ld_h8(reinterpret_cast<const char*>(src));
@@ -197,14 +205,14 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         }
         // common scale of the tile: the largest of the three block maxima; per tap and lane the power of two that brings the
         // block the lane reads to it
-        const int e0 = amax_exp(am0), e1 = amax_exp(am1), e2 = amax_exp(am2);
-        const int ex = TAPS == 1 ? e1 : max(e0, max(e1, e2));
+        int ex = amax_exp(am[0]);
+#pragma unroll
+        for (int t = 1; t < TAPS; ++t) ex = max(ex, amax_exp(am[t]));
         const int kx = PK_BLK_TOP + 127 - ex;
         const float sx = pow2f(kx);   // (fp32 operand: applied before the split)
-        unsigned fu[FFNP_TAPS];
-        fu[0] = pow2_neg_h2(ex - e0);
-        fu[1] = pow2_neg_h2(ex - e1);
-        fu[2] = pow2_neg_h2(ex - e2);
+        unsigned fu[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) fu[t] = pow2_neg_h2(ex - amax_exp(am[t]));
         f32x16 acc[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
 #pragma unroll
             for (int kk = 0; kk < SLAB; ++kk) {
                 const int ks = SLAB * g + kk, slot = ks % RING;
-                const f16x8 f = h8_of(fu[TAPS == 1 ? 1 : ks % TAPS]);   // (one tap: 2^0, the row's own scale)
+                const f16x8 f = h8_of(fu[ks % TAPS]);   // (one tap: 2^0, the row's own scale)
                 f16x8 bh, bl;
                 if (TIGHT) {
                     rhi[slot] *= f;
@@ -294,8 +302,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
         const f32x4* lb4 = reinterpret_cast<const f32x4*>(lb) + hh * (NQ * 4);
         if (EPI == 0) {
             // relu(. + b) -> the hidden planes, scaled by the bound of this lane's row (gap rows: 0, their bound too)
-            const float m3 = fmaxf(__uint_as_float(am0), fmaxf(__uint_as_float(am1), __uint_as_float(am2)));
-            const float hb = fmaf(m3, a.c.c1, a.c.c0);
+            float m3 = __uint_as_float(am[0]);
+#pragma unroll
+            for (int t = 1; t < TAPS; ++t) m3 = fmaxf(m3, __uint_as_float(am[t]));
+            const float hb = fmaf(m3, a.c.c1, a.c.c0);   // (tanh: c1 = 0, c0 = 1 -- |tanh| <= 1 is its own bound)
             const float so = pow2f(blk_scale_exp(__float_as_uint(hb)));
             char* dst = reinterpret_cast<char*>(a.c.out) + (long)blk * a.out_blk + (long)(ct * NQ * 2) * 2048 + j * ROW_B + hh * 1024;
             const bool row_ok = rv >= 0;
@@ -309,7 +319,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                         const f32x4 b4 = lb4[q * 4 + 2 * m + i];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float t = fmaxf(fmaf(acc[q][8 * m + 4 * i + e], pinv * lbs[q], b4[e]), 0.f);
+                            const float pre = fmaf(acc[q][8 * m + 4 * i + e], pinv * lbs[q], b4[e]);
+                            const float t = ACT == 1 ? tanhf(pre) : fmaxf(pre, 0.f);
                             v[4 * i + e] = row_ok ? t : 0.f;
                         }
                     }
@@ -330,7 +341,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_ffn_planes(Args a) {
                     const f32x4 b4 = lb4[q * 4 + i];
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[q][4 * i + e], pinv * lbs[q], b4[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float pre = fmaf(acc[q][4 * i + e], pinv * lbs[q], b4[e]);
+                        o[e] = ACT == 0 ? pre : (rv >= 0 ? (ACT == 1 ? tanhf(pre) : fmaxf(pre, 0.f)) : 0.f);
+                    }
                     *reinterpret_cast<f32x4*>(yr + 32 * q + 8 * i) = o;
                 }
         } else {
@@ -383,8 +397,11 @@ __global__ __launch_bounds__(256) void k_ffn_ln_planes(const float* __restrict__
     const bool on = lane < noct;
     const int kq = lane >> 1, hh = lane & 1;
     const int c0 = 16 * kq + 4 * hh;   // channels c0..c0+3 and c0+8..c0+11 (wfl_chan)
+    // g == NULL: no normalisation -- the rows as they are become planes with the scale of their own maximum (the input of a
+    // conv chain that starts from fp32 rows: encoder output -> predictors, first postnet layer -> the k = 5 convs)
+    const bool ident = g == nullptr;
     f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = ga, ba = ga, bb = ga;
-    if (on) {
+    if (on && !ident) {
         ga = *reinterpret_cast<const f32x4*>(g + c0);
         gb = *reinterpret_cast<const f32x4*>(g + c0 + 8);
         ba = *reinterpret_cast<const f32x4*>(b + c0);
@@ -422,8 +439,10 @@ __global__ __launch_bounds__(256) void k_ffn_ln_planes(const float* __restrict__
         float q = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            xa[i][e] -= mean;
-            xb[i][e] -= mean;
+            if (!ident) {
+                xa[i][e] -= mean;
+                xb[i][e] -= mean;
+            }
             q += xa[i][e] * xa[i][e] + xb[i][e] * xb[i][e];
         }
         if (!on) q = 0.f;
@@ -433,8 +452,13 @@ __global__ __launch_bounds__(256) void k_ffn_ln_planes(const float* __restrict__
         float am = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            xa[i][e] = ok[i] && on ? xa[i][e] * inv * ga[e] + ba[e] : 0.f;
-            xb[i][e] = ok[i] && on ? xb[i][e] * inv * gb[e] + bb[e] : 0.f;
+            if (ident) {   // (uniform) the row itself, untouched
+                xa[i][e] = ok[i] && on ? xa[i][e] : 0.f;
+                xb[i][e] = ok[i] && on ? xb[i][e] : 0.f;
+            } else {
+                xa[i][e] = ok[i] && on ? xa[i][e] * inv * ga[e] + ba[e] : 0.f;
+                xb[i][e] = ok[i] && on ? xb[i][e] * inv * gb[e] + bb[e] : 0.f;
+            }
             am = fmaxf(am, fmaxf(fabsf(xa[i][e]), fabsf(xb[i][e])));
         }
 #pragma unroll
@@ -615,10 +639,48 @@ int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     return go(k_ffn_planes<FFNP_NQL, 24, 2, 8, 1>);
 }
 
+// The 256-channel conv layers of the variance predictors (k = 3 / 5, ReLU, fp32 rows out for the LayerNorm that follows) and of
+// the postnet (k = 5, tanh; planes out, or fp32 rows out for the layer that leaves the planes path).  c.out != NULL: planes
+// (EPI 0, c.c1 / c.c0 = the output bound: 0 / 1 for tanh); else c.x = fp32 rows [row][ldx] written (not accumulated: EPI 2).
+// in_amax needs taps / 2 elements of zero margin on either side, the planes one block (as everywhere).
+bool ffnp_conv256_supports(int Cin, int N, int taps) {
+    return N == 256 && ((Cin == 384 && (taps == 3 || taps == 5)) || (Cin == 256 && (taps == 3 || taps == 5)));
+}
+int ffnp_conv256_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c, int taps, int act) {
+    if (!ffnp_conv256_supports(c.Cin, c.N, taps) || c.nblk <= 0 || !c.w || !c.wscale || (!c.out && !c.x) || act < 1 || act > 2)
+        PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: shape (Cin %d, N %d, k %d, act %d) not built", c.Cin, c.N, taps, act);
+    if (c.out && act != 1) PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: planes output is built for tanh");
+    Args a;
+    a.c = c;
+    a.nct = c.N / (32 * FFNP_NQ2);   // 2 column tiles of 128
+    a.in_blk = (long)c.Cin * 128;
+    a.out_blk = (long)c.N * 128;
+    int active = 8;
+    while (active > 2 && (long)pk_div_up(c.nblk, active) * a.nct < ctx->n_cu) active >>= 1;
+    a.active = active;
+    a.nrg = pk_div_up(c.nblk, active);
+    const int grid = pk_div_up(a.nrg, 8) * 8 * a.nct;
+    auto go = [&](auto kern) -> int {
+        PK_LAUNCH(ctx, prof_name, kern, dim3(grid), dim3(512), 0, a);
+        return PK_OK;
+    };
+    // <NQ, KQ, EPI, W, TAPS, ABL, BF32, CPT, ACT>: CPT such that a slab is a whole number of k-steps that divides TAPS * KQ
+    if (c.out) {
+        if (c.Cin == 256 && taps == 5) return go(k_ffn_planes<4, 16, 0, 8, 5, 0, false, 5, 1>);
+        PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: planes output: 256 -> 256, k = 5 only");
+    }
+    if (act == 1) {   // tanh -> fp32 rows: the postnet's last 256 -> 256 layer
+        if (c.Cin == 256 && taps == 5) return go(k_ffn_planes<4, 16, 2, 8, 5, 0, false, 5, 1>);
+        PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: tanh rows output: 256 -> 256, k = 5 only");
+    }
+    if (c.Cin == 384) return taps == 3 ? go(k_ffn_planes<4, 24, 2, 8, 3, 0, false, 6, 2>) : go(k_ffn_planes<4, 24, 2, 8, 5, 0, false, 6, 2>);
+    return taps == 3 ? go(k_ffn_planes<4, 16, 2, 8, 3, 0, false, 6, 2>) : go(k_ffn_planes<4, 16, 2, 8, 5, 0, false, 5, 2>);
+}
+
 int ffnp_layernorm_launch(pk_ctx* ctx, const float* x, const float* g, const float* b, const int* row_utt, int nblk, int C,
                           float eps, void* out, unsigned* out_amax) {
     if (C % 16 != 0 || C / 8 > 64) PK_FAIL(PK_EINVAL, "ffnp_layernorm_launch: %d channels", C);
-    PK_LAUNCH(ctx, "fs2_layernorm_planes", k_ffn_ln_planes, dim3(nblk), dim3(256), 0, x, g, b, row_utt, C, eps,
+    PK_LAUNCH(ctx, g ? "fs2_layernorm_planes" : "fs2_rows_to_planes", k_ffn_ln_planes, dim3(nblk), dim3(256), 0, x, g, b, row_utt, C, eps,
               reinterpret_cast<char*>(out), out_amax);
     return PK_OK;
 }

@@ -893,6 +893,10 @@ struct pk_fs2 : pk_fft_core {
     Timeline tl_tok, tl_frm, tl_frm2;   // tokens, decoder rows, mel frames (= decoder rows unless reduction_factor > 1)
     pk_dbuf d_wide, d_rowmap2;
     pk_dbuf d_pamax;   // row maxima of the predictors' LayerNorm outputs
+    pk_dbuf d_hsp, d_hsam, d_pp, d_ppam;   // planes path of the predictors: the encoder output as planes, a layer's work planes
+    char* hsp = nullptr;
+    unsigned* hsam = nullptr;
+    bool hs_planes_valid = false;           // ... converted once per pk_fs2_encode
     pk_dbuf d_tok, d_p1, d_p2, d_hs, d_pout, d_eout, d_dout, d_cum, d_frames,
         d_before, d_q1, d_q2, d_rowmap, d_dbg_up, d_zs, d_mel_stage;
     std::vector<int> frames;   // per utterance, result of encode
@@ -1049,6 +1053,13 @@ int pk_fft_add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vect
     d.taps = taps;
     d.pad = (taps - 1) / 2;
     dense_bound(kn, bias, Cin * taps, N, 0, N, d.c1, d.c0);
+    // the 256-channel convs of the variance predictors and of the postnets (384 | 256 -> 256, k = 3 | 5) also get the planes
+    // kernel's fragments (ffnp_conv256_launch)
+    if (ar.v16 && ffnp_conv256_supports(Cin, N, taps)) {
+        std::vector<float> ws;
+        d.wp = ffnp_pack(kn.data(), Cin, N, FFNP_NQ2, *ar.v16, ws, taps);
+        d.wps = ar.put(ws);
+    }
     return PK_OK;
 }
 
@@ -1652,6 +1663,36 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
     return PK_OK;
 }
 
+// A planes work buffer of C channels for a timeline of nblk blocks with its row maxima: one block / FFNP_AM_MARGIN elements of
+// ZERO margin on either side (what the edge tiles' taps read), the rest written by the producers.
+constexpr int FFNP_AM_MARGIN = 4;
+static int planes_buf(pk_fft_core* h, pk_dbuf& buf, pk_dbuf& am, int nblk, int C, char** planes, unsigned** amax) {
+    const size_t pb = ffnp_plane_bytes(nblk, C), ab = ((size_t)nblk * FFNP_BLK + 2 * FFNP_AM_MARGIN) * sizeof(unsigned);
+    PK_TRY(buf.reserve(pb));
+    PK_TRY(am.reserve(ab));
+    PK_HIP(hipMemsetAsync(buf.p, 0, (size_t)C * 128, h->ctx->stream));                                      // leading margin block
+    PK_HIP(hipMemsetAsync(buf.as<char>() + (size_t)(nblk + 1) * C * 128, 0, (size_t)C * 128, h->ctx->stream));   // trailing
+    PK_HIP(hipMemsetAsync(am.p, 0, ab, h->ctx->stream));
+    *planes = buf.as<char>() + (size_t)C * 128;
+    *amax = am.as<unsigned>() + FFNP_AM_MARGIN;
+    return PK_OK;
+}
+
+static FfnpConv conv256_args(pk_fft_core* h, const Dense& d, int nblk, const int* row_utt, const void* in, const unsigned* in_amax) {
+    FfnpConv c;
+    memset(&c, 0, sizeof(c));
+    c.nblk = nblk;
+    c.row_utt = row_utt;
+    c.w = h->arena16.as<uint16_t>() + d.wp;
+    c.bias = d.b == (size_t)-1 ? nullptr : h->W(d.b);
+    c.wscale = h->W(d.wps);
+    c.Cin = d.Cin;
+    c.N = d.N;
+    c.in = in;
+    c.in_amax = in_amax;
+    return c;
+}
+
 int pk_fft_run_postnet(pk_fft_core* h, const char* name, const std::vector<Dense>& postnet, const float* before, int odim,
                        int chans, const Timeline& tl, pk_dbuf& q1, pk_dbuf& q2, float* d_out, const int* out_rowmap,
                        const float* cscale, const float* cshift) {
@@ -1670,10 +1711,47 @@ int pk_fft_run_postnet(pk_fft_core* h, const char* name, const std::vector<Dense
             PK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_ones.p), 0x3f800000, h->d_ones.cap / 4, h->ctx->stream));
         ones = pk_fft_act_ptr(h->d_ones, 1);
     }
+    // Round 4: the middle layers (256 -> 256 channels, k = 5, BatchNorm folded, tanh) on the planes kernel: the first layer's
+    // fp32 rows -> planes, layers 1 .. n - 3 planes -> planes (|tanh| <= 1: scale 2^13, row maximum 1), layer n - 2 planes ->
+    // fp32 rows for the last layer (whose epilogue -- residual, ZScore, row map -- stays the tile GEMM's)
+    bool planes = h->math == PK_GEMM_MATH_F16X3 && h->ffn_planes && n >= 4 && tl.rows_alloc % FFNP_BLK == 0 && chans == 256;
+    for (int j = 1; j + 1 < n; ++j)
+        planes = planes && postnet[j].wp != (size_t)-1 && postnet[j].wps != (size_t)-1 && postnet[j].Cin == 256 && postnet[j].taps == 5;
     for (int j = 0; j < n; ++j) {
         const Dense& d = postnet[j];
         const bool last = j == n - 1;
         float* outb = pk_fft_act_ptr((j & 1) ? q2 : q1, chans);
+        if (planes && j == 1) {
+            const int nblk = tl.rows_alloc / FFNP_BLK;
+            const int* rv = tl.d_row_utt();
+            char* pl[2];
+            unsigned* am[2];
+            PK_TRY(planes_buf(h, h->d_pnp[0], h->d_pnam[0], nblk, chans, &pl[0], &am[0]));
+            PK_TRY(planes_buf(h, h->d_pnp[1], h->d_pnam[1], nblk, chans, &pl[1], &am[1]));
+            PK_TRY(ffnp_layernorm_launch(h->ctx, in, nullptr, nullptr, rv, nblk, chans, 0.f, pl[0], am[0]));
+            int cur = 0;
+            for (; j + 1 < n; ++j) {
+                FfnpConv c = conv256_args(h, postnet[j], nblk, rv, pl[cur], am[cur]);
+                const std::string nm = std::string(name) + "_planes";
+                if (j + 2 < n) {   // planes -> planes
+                    c.out = pl[cur ^ 1];
+                    c.out_amax = am[cur ^ 1];
+                    c.c1 = 0.f;
+                    c.c0 = 1.f;
+                    PK_TRY(ffnp_conv256_launch(h->ctx, nm.c_str(), c, 5, 1));
+                    cur ^= 1;
+                } else {           // planes -> fp32 rows, the last layer's input
+                    outb = pk_fft_act_ptr((j & 1) ? q2 : q1, chans);
+                    c.x = outb;
+                    c.ldx = chans;
+                    PK_TRY(ffnp_conv256_launch(h->ctx, nm.c_str(), c, 5, 1));
+                    in = outb;
+                    ldin = chans;
+                }
+            }
+            --j;   // j == n - 2 was the last planes layer: the loop header moves on to n - 1
+            continue;
+        }
         pk_gemm_args g;
         g.A = in; g.lda = ldin; g.Wp = h->W(d.w); g.bias = h->W(d.b);
         g.Wh = d.wh == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + d.wh; g.math = h->math;
@@ -1725,8 +1803,43 @@ static int run_predictor(pk_fs2* h, const Predictor& pr, const Timeline& tl, con
         PK_HIP(hipMemsetAsync(h->d_pamax.p, 0, h->d_pamax.cap, h->ctx->stream));
         pam = pk_fft_act_ptr(h->d_pamax, 1);
     }
+    // Round 4: the convs on the planes kernel (csrc/ffn_planes.hip, 384 | 256 -> 256 channels, k = 3 | 5): encoder output ->
+    // planes once per batch (shared by the three predictors), conv -> fp32 rows (ReLU), LayerNorm -> planes for the next conv
+    // (k_ffn_ln_planes) or -> fp32 rows for the head after the last one.  Same arithmetic class as the tile GEMM path
+    // (block-scaled split-fp16, one scale per row), half its time.
+    bool planes = h->math == PK_GEMM_MATH_F16X3 && h->ffn_planes && tl.rows_alloc % FFNP_BLK == 0 && !pr.conv.empty();
+    for (const Dense& d : pr.conv) planes = planes && d.wp != (size_t)-1 && d.wps != (size_t)-1;
+    if (planes) {
+        const int nblk = tl.rows_alloc / FFNP_BLK;
+        const int* rv = tl.d_row_utt();
+        if (!h->hs_planes_valid) {
+            PK_TRY(planes_buf(h, h->d_hsp, h->d_hsam, nblk, A, &h->hsp, &h->hsam));
+            PK_TRY(ffnp_layernorm_launch(h->ctx, hs, nullptr, nullptr, rv, nblk, A, 0.f, h->hsp, h->hsam));
+            h->hs_planes_valid = true;
+        }
+        char* pp = nullptr;
+        unsigned* ppam = nullptr;
+        PK_TRY(planes_buf(h, h->d_pp, h->d_ppam, nblk, pr.chans, &pp, &ppam));
+        const void* cin = h->hsp;
+        const unsigned* cam = h->hsam;
+        for (size_t j = 0; j < pr.conv.size(); ++j) {
+            FfnpConv c = conv256_args(h, pr.conv[j], nblk, rv, cin, cam);
+            c.x = p1;
+            c.ldx = pr.chans;
+            PK_TRY(ffnp_conv256_launch(h->ctx, "fs2_conv_predictor_planes", c, pr.conv[j].taps, 2));
+            if (j + 1 < pr.conv.size()) {
+                PK_TRY(ffnp_layernorm_launch(h->ctx, p1, h->W(pr.ln_g[j]), h->W(pr.ln_b[j]), rv, nblk, pr.chans, 1e-5f, pp, ppam));
+                cin = pp;
+                cam = ppam;
+            } else {
+                PK_TRY(pk_fft_run_layernorm(h, p1, pr.ln_g[j], pr.ln_b[j], tl, pr.chans, p2));
+            }
+        }
+        in = p2;
+        ldin = pr.chans;
+    }
     const float* in_amax = nullptr;
-    for (size_t j = 0; j < pr.conv.size(); ++j) {
+    for (size_t j = 0; j < pr.conv.size() && !planes; ++j) {
         PK_TRY(pk_fft_run_dense(h, "fs2_conv_predictor", pr.conv[j], in, ldin, p1, pr.chans, tl.rows, PK_ACT_RELU, nullptr, 0,
                          nullptr, in_amax));
         PK_TRY(pk_fft_run_layernorm(h, p1, pr.ln_g[j], pr.ln_b[j], tl, pr.chans, p2, pam));
@@ -1825,6 +1938,7 @@ extern "C" int pk_fs2_encode(pk_fs2* h, const int64_t* ids, const int32_t* tok_l
     PK_TRY(h->d_dout.reserve((size_t)tl.rows_alloc * 4));
     PK_TRY(h->d_cum.reserve((size_t)tl.rows_alloc * 4));
     PK_TRY(h->d_frames.reserve((size_t)B * 4));
+    h->hs_planes_valid = false;
     PK_TRY(run_predictor(h, h->pitch, tl, hs, 0, 1.f, h->d_pout.as<float>()));
     PK_TRY(run_predictor(h, h->energy, tl, hs, 0, 1.f, h->d_eout.as<float>()));
     PK_TRY(run_predictor(h, h->dur, tl, hs, 1, alpha, h->d_dout.as<float>()));
@@ -2056,7 +2170,7 @@ extern "C" void pk_fs2_destroy(pk_fs2* h) {
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     h->release_core();
-    pk_dbuf* bufs[] = {&h->d_pamax, &h->d_tok, &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
+    pk_dbuf* bufs[] = {&h->d_hsp, &h->d_hsam, &h->d_pp, &h->d_ppam, &h->d_pamax, &h->d_tok, &h->d_p1, &h->d_p2, &h->d_hs, &h->d_pout, &h->d_eout, &h->d_dout, &h->d_cum, &h->d_frames,
                        &h->d_tone, &h->d_spk_id, &h->d_spk_emb, &h->d_spk_vec, &h->d_before, &h->d_q1, &h->d_q2, &h->d_rowmap, &h->d_dbg_up, &h->d_zs, &h->d_mel_stage,
                        &h->d_wide, &h->d_rowmap2};
     for (auto* b : bufs) b->release();

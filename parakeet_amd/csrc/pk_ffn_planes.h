@@ -67,6 +67,12 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a);
 // tiles per wave, x[row][:] += in . W + bias.
 int ffnp_linear_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a);
 
-// LayerNorm (eps) of rows of C channels -> planes + row maxima; gap rows -> 0
+// The 256-channel convs of the variance predictors and of the postnet (round 4): 384 | 256 -> 256 channels, k = 3 | 5.
+// act 1 = tanh, 2 = ReLU.  c.out != NULL: output as planes (tanh only; c1 = 0, c0 = 1), else fp32 rows c.x[row][ldx] (written;
+// gap rows zero).  in_amax: taps / 2 zero elements of margin on either side.
+bool ffnp_conv256_supports(int Cin, int N, int taps);
+int ffnp_conv256_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& a, int taps, int act);
+
+// LayerNorm (eps) of rows of C channels -> planes + row maxima; gap rows -> 0.  g == NULL: no normalisation (rows -> planes)
 int ffnp_layernorm_launch(pk_ctx* ctx, const float* x, const float* g, const float* b, const int* row_utt, int nblk, int C,
                           float eps, void* out, unsigned* out_amax);

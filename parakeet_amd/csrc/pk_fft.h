@@ -91,11 +91,12 @@ struct pk_fft_core {
     pk_dbuf d_x, d_h, d_qkv, d_ctx, d_f, d_lnamax, d_cbnd, d_fbnd, d_segb, d_cat;
     pk_dbuf d_hp, d_fp, d_pam;       // planes of the norm2 output and of the hidden activations, their block maxima
     pk_dbuf d_ones;                  // a row of 1.0f: the operand bound of layers that read tanh outputs (pk_fft_run_postnet)
+    pk_dbuf d_pnp[2], d_pnam[2];     // the postnet's middle layers on planes: two work buffers and their row maxima
 
     const float* W(size_t off) const { return arena.as<float>() + off; }
     void release_core() {
         pk_dbuf* bufs[] = {&arena, &arena16, &d_pe, &d_div, &d_x, &d_h, &d_qkv, &d_ctx, &d_f, &d_lnamax, &d_cbnd,
-                           &d_fbnd, &d_segb, &d_cat, &d_hp, &d_fp, &d_pam, &d_ones};
+                           &d_fbnd, &d_segb, &d_cat, &d_hp, &d_fp, &d_pam, &d_ones, &d_pnp[0], &d_pnp[1], &d_pnam[0], &d_pnam[1]};
         for (pk_dbuf* b : bufs) b->release();
     }
 };

@@ -354,6 +354,11 @@ struct pk_tts : pk_fft_core {
     int gapr = 1;
     bool dropout = true;
     bool kv_prefix = false;            // "kv_prefix" option (pk_tts_set_option), see pk_tts_infer
+    bool overlap_prefix = true;        // "overlap_prefix": the NEXT step's prefix work (prenet .. layer-0 q|k|v of the rows that
+                                       // exist already) on a side stream under this step's layer chain, see pk_tts_infer
+    hipStream_t side = nullptr;        // ... its stream and the two events that order it against the main one
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    pk_dbuf d2_p0, d2_p1, d2_x0, d2_t, d2_ham, d2_pam, d2_qkv0;   // ... and the second set of the buffers it fills
     // weights
     size_t emb_table = 0;
     float alpha_enc = 1.f, alpha_dec = 1.f;
@@ -366,6 +371,8 @@ struct pk_tts : pk_fft_core {
     std::vector<Dense> dprenet;
     Dense dlin, feat_out;
     RowW r_feat_out;
+    std::vector<RowW> r_dprenet;   // the decoder prenet's layers and the input Linear as row-GEMM layers: the NEW row block of a
+    RowW r_dlin;                   // step goes through them (4 launches of 32 rows instead of 7 tile-GEMM launches)
     Dense kv0;    // layer 0's self-attention k | v only ([A][2A]) and its q as a row-GEMM layer: PK_TTS_KV_PREFIX (see pk_tts_infer)
     RowW r_q0;
     std::vector<DecLayer> dec;
@@ -496,6 +503,10 @@ extern "C" int pk_tts_set_option(pk_tts* h, const char* key, int64_t value) {
         h->kv_prefix = value != 0;
         return PK_OK;
     }
+    if (strcmp(key, "overlap_prefix") == 0) {
+        h->overlap_prefix = value != 0;
+        return PK_OK;
+    }
     return pk_fft_set_option(h, key, value, "pk_tts_set_option");
 }
 
@@ -565,10 +576,14 @@ int add_kv(pk_fft_arena& ar, const pk_param_map& P, const std::string& p, int A,
     return pk_fft_add_dense_kn(ar, kn, &bias, A, 1, 2 * A, d);
 }
 
-int add_row_linear(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int K, int N, RowW& r) {
+int add_row_linear(pk_fft_arena& ar, const pk_param_map& P, const std::string& base, int K, int N, RowW& r, float scale = 1.f) {
     std::vector<float> w, b;
     PK_TRY(pk_get_weight(P, base, {K, N}, w));   // Linear weight [in, out] = [K][N]
     PK_TRY(pk_get_vector(P, base + ".bias", N, b));
+    if (scale != 1.f) {   // (as add_linear_scaled: the sqrt(adim) of PositionalEncoding folded into the layer)
+        for (float& v : w) v *= scale;
+        for (float& v : b) v *= scale;
+    }
     std::vector<float> wt;
     pk_rowgemm_pack(w.data(), K, N, wt);
     r.w = ar.put(wt);
@@ -688,9 +703,14 @@ extern "C" int pk_tts_finalize(pk_tts* h) {
     for (int j = 0; j < c.dprenet_layers; ++j)
         PK_TRY(pk_fft_add_linear(ar, P, "decoder.embed.0.0.prenet." + std::to_string(j) + ".0",
                                  j == 0 ? c.odim : c.dprenet_units, c.dprenet_units, h->dprenet[j]));
+    h->r_dprenet.assign(c.dprenet_layers, RowW());
+    for (int j = 0; j < c.dprenet_layers; ++j)
+        PK_TRY(add_row_linear(ar, P, "decoder.embed.0.0.prenet." + std::to_string(j) + ".0", j == 0 ? c.odim : c.dprenet_units,
+                              c.dprenet_units, h->r_dprenet[j]));
     h->alpha_dec = 1.f;
     if (c.dprenet_layers > 0) {
         PK_TRY(add_linear_scaled(ar, P, "decoder.embed.0.1", c.dprenet_units, A, h->xscale, h->dlin));
+        PK_TRY(add_row_linear(ar, P, "decoder.embed.0.1", c.dprenet_units, A, h->r_dlin, h->xscale));
         if (c.use_scaled_pos_enc) {
             PK_TRY(pk_get_vector(P, "decoder.embed.1.alpha", 1, al));
             h->alpha_dec = al[0];
@@ -925,6 +945,28 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     PK_TRY(rows_reserve(h->d_pam, 2 * (rowsCap + SLACK), 1));
     PK_HIP(hipMemsetAsync(h->d_pam.p, 0, h->d_pam.cap, ctx->stream));   // (rows beyond the prefix are read as scales of unused tile rows)
     PK_TRY(rows_reserve(h->d_peb, rowsCap, A));
+    // Overlap of the per-step prefix work with the layer chain (option "overlap_prefix").  decoder.embed and layer 0's q | k | v are
+    // recomputed for EVERY prefix row at every step (fresh prenet dropout, decoder.py:210), but for step s + 1 only the newest
+    // row block depends on step s: the blocks 0 .. s - 1 are issued on a side stream while step s's 47 small dependent launches
+    // run on the main one (they leave most of the chip idle), into a second set of buffers (step parity); at step s + 1 the main
+    // stream waits for them and adds the new block.  Row results do not depend on how the rows are grouped into launches
+    // (per-row operand scales), so the spectrogram is the sequential path's bit for bit.
+    const bool overlap = h->overlap_prefix && !h->kv_prefix;
+    if (overlap) {
+        PK_TRY(rows_reserve(h->d2_p0, rowsCap, U));
+        PK_TRY(rows_reserve(h->d2_p1, rowsCap, U));
+        PK_TRY(rows_reserve(h->d2_x0, rowsCap, A));
+        PK_TRY(rows_reserve(h->d2_t, rowsCap, A));
+        PK_TRY(rows_reserve(h->d2_ham, rowsCap, 1));
+        PK_TRY(rows_reserve(h->d2_pam, 2 * (rowsCap + SLACK), 1));
+        PK_HIP(hipMemsetAsync(h->d2_pam.p, 0, h->d2_pam.cap, ctx->stream));
+        PK_TRY(rows_reserve(h->d2_qkv0, rowsCap, 3 * A));
+        if (!h->side) {
+            PK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            PK_HIP(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+            PK_HIP(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+        }
+    }
     for (int l = 0; l < c.dlayers; ++l) {
         PK_TRY(rows_reserve(h->d_qkv_l[l], rowsCap, 3 * A));
         PK_TRY(rows_reserve(h->d_xc_l[l], rowsCap, A));
@@ -974,11 +1016,18 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         d_attoff = h->d_attoff.as<long>();
     }
     float* Y = pk_fft_act_ptr(h->d_y, OR);
-    float* P[2] = {pk_fft_act_ptr(h->d_p0, U), pk_fft_act_ptr(h->d_p1, U)};
-    float* X0 = pk_fft_act_ptr(h->d_x0, A);
-    float* Tn = pk_fft_act_ptr(h->d_t, A);
-    float* ham = pk_fft_act_ptr(h->d_ham, 1);
-    float* pam[2] = {pk_fft_act_ptr(h->d_pam, 1), pk_fft_act_ptr(h->d_pam, 1) + rowsCap + SLACK};   // row maxima of the prenet outputs
+    struct PrefixSet {   // what the prefix work of one step writes (two sets under "overlap_prefix": step parity)
+        float *P[2], *X0, *Tn, *ham, *pam[2], *QKV0;
+    };
+    PrefixSet sets[2];
+    sets[0] = {{pk_fft_act_ptr(h->d_p0, U), pk_fft_act_ptr(h->d_p1, U)}, pk_fft_act_ptr(h->d_x0, A), pk_fft_act_ptr(h->d_t, A),
+               pk_fft_act_ptr(h->d_ham, 1), {pk_fft_act_ptr(h->d_pam, 1), pk_fft_act_ptr(h->d_pam, 1) + rowsCap + SLACK},
+               pk_fft_act_ptr(h->d_qkv_l[0], 3 * A)};
+    sets[1] = sets[0];
+    if (overlap)
+        sets[1] = {{pk_fft_act_ptr(h->d2_p0, U), pk_fft_act_ptr(h->d2_p1, U)}, pk_fft_act_ptr(h->d2_x0, A), pk_fft_act_ptr(h->d2_t, A),
+                   pk_fft_act_ptr(h->d2_ham, 1), {pk_fft_act_ptr(h->d2_pam, 1), pk_fft_act_ptr(h->d2_pam, 1) + rowsCap + SLACK},
+                   pk_fft_act_ptr(h->d2_qkv0, 3 * A)};
     float* PEB = pk_fft_act_ptr(h->d_peb, A);
     float* rt = pk_fft_act_ptr(h->d_rt, A);
     float* rc = pk_fft_act_ptr(h->d_rc, A);
@@ -1011,55 +1060,120 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         if (ln) { g.ln_g = h->W(ln_g); g.ln_b = h->W(ln_b); }
         return pk_rowgemm_launch(ctx, name, g);
     };
-    int s = 0;
-    for (s = 1; s <= Lcap; ++s) {
-        const int R = s * B;
-        const long nr = (long)(s - 1) * B;   // first new row
-        // decoder.embed on the whole prefix (decoder.py:210)
-        const float* in = Y + (RF - 1) * O;   // the LAST frame of every step's output is the next input (:619-621)
+    // The prefix work of step `st` for the rows [r0, r0 + n) (whole row blocks: r0, n multiples of B): prenet (+ dropout, stream
+    // position st (st - 1) / 2 + row block), the input layer, the positional encoding, layer 0's norm1 and q | k | v.  Every
+    // kernel here works row by row, so any split of the prefix into calls gives the same rows.  Runs on ctx->stream.
+    auto prefix_rows = [&](int st, long r0, long n, PrefixSet& S) -> int {
+        if (n <= 0) return PK_OK;
+        const float* in = Y + (RF - 1) * O + r0 * OR;   // the LAST frame of every step's output is the next input (:619-621)
         int ldin = OR;
         const float* in_amax = nullptr;
+        const unsigned long long base = (unsigned long long)st * (unsigned long long)(st - 1) / 2ull + (unsigned long long)(r0 / B);
         for (int j = 0; j < J; ++j) {
-            float* o = P[j & 1];
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_prenet", h->dprenet[j], in, ldin, o, U, R, PK_ACT_RELU, nullptr, 0, nullptr, in_amax));
+            float* o = S.P[j & 1] + r0 * U;
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_prenet", h->dprenet[j], in, ldin, o, U, (int)n, PK_ACT_RELU, nullptr, 0, nullptr, in_amax));
             // the row maxima of what the next GEMM reads come out of the dropout kernel (one wave per row at 256 units)
-            float* o_amax = (h->dropout && use_ham && U == 256) ? pam[j & 1] : nullptr;
+            float* o_amax = (h->dropout && use_ham && U == 256) ? S.pam[j & 1] + r0 : nullptr;
             if (h->dropout)
-                PK_LAUNCH(ctx, "tts_dropout", k_ar_dropout, dim3(pk_div_up((long)R * (U / 4), 256)), dim3(256), 0, o, U, R, U,
-                          B, (unsigned long long)s * (unsigned long long)(s - 1) / 2ull, J, j, d_seeds, thr, dscale, o_amax);
+                PK_LAUNCH(ctx, "tts_dropout", k_ar_dropout, dim3(pk_div_up(n * (U / 4), 256)), dim3(256), 0, o, U, (int)n, U,
+                          B, base, J, j, d_seeds, thr, dscale, o_amax);
             in = o;
             ldin = U;
             in_amax = o_amax;
         }
+        float* x0 = S.X0 + r0 * A;
+        float* tn = S.Tn + r0 * A;
+        float* hm = S.ham + r0;
         if (J > 0) {
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, PEB, A, nullptr, in_amax));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, x0, A, (int)n, PK_ACT_NONE, PEB + r0 * A, A, nullptr, in_amax));
         } else {
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, X0, A, R, PK_ACT_NONE, nullptr, 0, nullptr));
-            PK_TRY(pk_fft_layernorm_rows(h, X0, h->dlin_ln_g, h->dlin_ln_b, valid, R, A, Tn, nullptr));
-            const long n4 = (long)R * (A / 4);
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_embed", h->dlin, in, ldin, x0, A, (int)n, PK_ACT_NONE, nullptr, 0, nullptr));
+            PK_TRY(pk_fft_layernorm_rows(h, x0, h->dlin_ln_g, h->dlin_ln_b, valid, (int)n, A, tn, nullptr));
+            const long n4 = n * (A / 4);
             PK_LAUNCH(ctx, "tts_relu_pe", k_tts_relu_add, dim3(pk_div_up(n4, 256)), dim3(256), 0,
-                      reinterpret_cast<const float4*>(Tn), reinterpret_cast<const float4*>(PEB), n4, reinterpret_cast<float4*>(X0));
+                      reinterpret_cast<const float4*>(tn), reinterpret_cast<const float4*>(PEB + r0 * A), n4, reinterpret_cast<float4*>(x0));
         }
-        // layer 0: norm1 and q | k | v of every prefix row
-        if (!post && kv_prefix && use_rg) {
-            float* qkv0 = pk_fft_act_ptr(h->d_qkv_l[0], 3 * A);
-            PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_kv0", h->kv0, Tn, A, qkv0 + A, 3 * A, R, PK_ACT_NONE, nullptr, 0, nullptr,
-                                    use_ham ? ham : nullptr));
-            PK_TRY(rowgemm("tts_row_q0", h->r_q0, X0 + nr * A, A, qkv0 + nr * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0,
-                           h->dec[0].ln1_g, h->dec[0].ln1_b, true));
+        // layer 0: norm1 and q | k | v of the rows
+        float* qkv0 = S.QKV0 + r0 * 3 * A;
+        if (!post && kv_prefix && use_rg) {   // (never overlapped: r0 == 0, n == all rows of step st)
+            PK_TRY(pk_fft_layernorm_rows(h, x0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, (int)n, A, tn, use_ham ? hm : nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_kv0", h->kv0, tn, A, qkv0 + A, 3 * A, (int)n, PK_ACT_NONE, nullptr, 0, nullptr,
+                                    use_ham ? hm : nullptr));
+            const long nr0 = (long)(st - 1) * B;
+            if (r0 <= nr0 && nr0 < r0 + n)   // (the call that holds the new row block)
+                PK_TRY(rowgemm("tts_row_q0", h->r_q0, S.X0 + nr0 * A, A, S.QKV0 + nr0 * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0,
+                               h->dec[0].ln1_g, h->dec[0].ln1_b, true));
         } else if (!post) {
-            PK_TRY(pk_fft_layernorm_rows(h, X0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, R, A, Tn, use_ham ? ham : nullptr));
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, Tn, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
-                                    PK_ACT_NONE, nullptr, 0, nullptr, use_ham ? ham : nullptr));
+            PK_TRY(pk_fft_layernorm_rows(h, x0, h->dec[0].ln1_g, h->dec[0].ln1_b, valid, (int)n, A, tn, use_ham ? hm : nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, tn, A, qkv0, 3 * A, (int)n, PK_ACT_NONE, nullptr, 0, nullptr,
+                                    use_ham ? hm : nullptr));
         } else {   // post-norm: the self-attention reads the un-normalised rows (decoder_layer.py:104-106)
-            PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, X0, A, pk_fft_act_ptr(h->d_qkv_l[0], 3 * A), 3 * A, R,
-                                    PK_ACT_NONE, nullptr, 0, nullptr));
+            PK_TRY(pk_fft_run_dense(h, "tts_gemm_qkv0", h->dec[0].qkv, x0, A, qkv0, 3 * A, (int)n, PK_ACT_NONE, nullptr, 0, nullptr));
+        }
+        return PK_OK;
+    };
+    // The same for the NEW row block of step `st` on the row GEMM (exact fp32 FMA; the layer chain's kernels): prenet layers with
+    // ReLU + dropout in the epilogue, the input Linear + positional encoding, layer 0's norm1 + q | k | v -- J + 2 launches of
+    // B rows (the tile GEMM needs 20 - 60 us for such a problem).  Not with concat_after blocks (they read the normed rows).
+    const bool fast_new = use_rg && J > 0 && !cat && !kv_prefix && (int)h->r_dprenet.size() == J;
+    auto prefix_new = [&](int st, PrefixSet& S) -> int {
+        const long r0 = (long)(st - 1) * B;
+        if (!fast_new) return prefix_rows(st, r0, B, S);
+        const float* in = Y + (RF - 1) * O + r0 * OR;
+        int ldin = OR;
+        for (int j = 0; j < J; ++j) {
+            const RowW& w = h->r_dprenet[j];
+            pk_rowgemm_args g;
+            g.x = in; g.ldx = ldin; g.Wt = h->W(w.w); g.bias = h->W(w.b); g.y = S.P[j & 1] + r0 * U; g.ldy = U; g.M = B; g.K = w.K; g.N = w.N;
+            g.act = PK_ACT_RELU;
+            if (h->dropout) {
+                g.dropout = 1;
+                g.drop_base = (unsigned long long)st * (unsigned long long)(st - 1) / 2ull + (unsigned long long)(st - 1);
+                g.drop_J = J; g.drop_j = j; g.drop_seeds = d_seeds; g.drop_thr = thr; g.drop_scale = dscale;
+            }
+            PK_TRY(pk_rowgemm_launch(ctx, "tts_row_prenet", g));
+            in = g.y;
+            ldin = U;
+        }
+        PK_TRY(rowgemm("tts_row_embed", h->r_dlin, in, ldin, S.X0 + r0 * A, A, PK_ACT_NONE, PEB + r0 * A, A, 0, 0, false));
+        PK_TRY(rowgemm("tts_row_qkv", h->dec[0].r_qkv, S.X0 + r0 * A, A, S.QKV0 + r0 * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0,
+                       h->dec[0].ln1_g, h->dec[0].ln1_b, !post));
+        return PK_OK;
+    };
+    int s = 0;
+    for (s = 1; s <= Lcap; ++s) {
+        const int R = s * B;
+        const long nr = (long)(s - 1) * B;   // first new row
+        // decoder.embed on the whole prefix (decoder.py:210) and layer 0's norm1 + q | k | v of every prefix row: prefix_rows().
+        // Sequential: all R rows here.  Overlapped: the blocks 0 .. s - 2 of THIS step were issued on the side stream during the
+        // previous step; the new block follows here, and the next step's old blocks go to the side stream now.
+        PrefixSet& S = sets[s & 1];
+        float* const X0 = S.X0;
+        float* const Tn = S.Tn;
+        float* const ham = S.ham;   // (rows 0 .. B - 1 double as scratch of the tile-GEMM variant of the layer chain)
+        (void)ham;
+        if (!overlap) {
+            PK_TRY(prefix_rows(s, 0, nr, S));
+            PK_TRY(prefix_new(s, S));
+        } else {
+            if (s > 1) PK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_side, 0));   // this step's old blocks (issued last step)
+            PK_HIP(hipEventRecord(h->ev_main, ctx->stream));                     // step s - 1 is complete on the main stream
+            PK_TRY(prefix_new(s, S));
+            if (s + 1 <= Lcap) {
+                // step s + 1's blocks 0 .. s - 1 (inputs Y[0 .. s - 1]: all known) into the other set: free since step s - 1 ended
+                hipStream_t main_stream = ctx->stream;
+                PK_HIP(hipStreamWaitEvent(h->side, h->ev_main, 0));
+                ctx->stream = h->side;
+                const int st = prefix_rows(s + 1, 0, R, sets[(s + 1) & 1]);
+                ctx->stream = main_stream;
+                PK_TRY(st);
+                PK_HIP(hipEventRecord(h->ev_side, h->side));
+            }
         }
         for (int l = 0; l < c.dlayers; ++l) {
             const DecLayer& L = h->dec[l];
             const float* xin = (l == 0 ? X0 : pk_fft_act_ptr(h->d_xc_l[l - 1], A)) + nr * A;
-            float* qkv = pk_fft_act_ptr(h->d_qkv_l[l], 3 * A);
+            float* qkv = l == 0 ? S.QKV0 : pk_fft_act_ptr(h->d_qkv_l[l], 3 * A);
             float* xc_new = pk_fft_act_ptr(h->d_xc_l[l], A) + nr * A;
             if (post || cat) {
                 // post-norm and / or concat_after blocks: the same kernels in the order of decoder_layer.py:104-151.
@@ -1216,6 +1330,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             if (ndone >= B) break;
         }
     }
+    if (overlap) PK_HIP(hipStreamSynchronize(h->side));   // (the prefix of a step that never ran may still be in flight)
     h->steps = std::min(s, Lcap);
     h->len.resize(B);
     PK_HIP(hipMemcpyAsync(h->len.data(), d_len, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1347,6 +1462,16 @@ extern "C" void pk_tts_destroy(pk_tts* h) {
                        &h->d_rowmap, &h->d_stage, &h->d_stage2};
     for (auto* b : bufs) b->release();
     for (auto& b : h->d_qkv_l) b.release();
+    {
+        pk_dbuf* b2[] = {&h->d2_p0, &h->d2_p1, &h->d2_x0, &h->d2_t, &h->d2_ham, &h->d2_pam, &h->d2_qkv0};
+        for (pk_dbuf* b : b2) b->release();
+        if (h->side) {
+            (void)hipStreamSynchronize(h->side);
+            (void)hipEventDestroy(h->ev_main);
+            (void)hipEventDestroy(h->ev_side);
+            (void)hipStreamDestroy(h->side);
+        }
+    }
     for (auto& b : h->d_xc_l) b.release();
     for (auto& b : h->d_mkv_l) b.release();
     h->tl_tok.release();

@@ -167,8 +167,26 @@ def test_fs2_ffn_planes_kernels(variant):
     finally:
         ctx.prof_enable(False)
     assert {"fs2_layernorm_planes", "fs2_gemm_qkv_planes", "fs2_gemm_attn_out_planes", "fs2_conv_ffn1_planes",
-            "fs2_conv_ffn2_planes"} <= names, names
+            "fs2_conv_ffn2_planes", "fs2_rows_to_planes", "fs2_conv_predictor_planes", "fs2_conv_postnet_planes"} <= names, names
+    # (round 4: the predictors' convs and the postnet's middle layers run the planes kernel too; what stays on the tile GEMM
+    # is the postnet's first and last layer)
+    assert "fs2_conv_predictor_h3" not in names and "fs2_conv_predictor" not in names, names
     assert not any(n.startswith(("fs2_conv_ffn", "fs2_gemm_qkv", "fs2_gemm_attn_out")) and "planes" not in n for n in names), names
+
+
+def test_fs2_tile_gemm_path_still_meets_the_bars():
+    """Option "ffn_planes" = 0: every dense layer on the tile GEMM (rounds 1 - 2's path, and the path of shapes the planes kernels
+    are not instantiated for): same bars, internal taps included, and none of the planes kernels runs."""
+    from parakeet_amd.runtime import Context
+    ctx = Context.get()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    try:
+        _check(_cfg(), [37, 5, 64, 1, 23], seed=100, options={"ffn_planes": 0})
+        names = {k for k, (n, _) in ctx.prof_dump().items() if n > 0}
+    finally:
+        ctx.prof_enable(False)
+    assert not any("planes" in n for n in names), names
 
 
 def test_fs2_batch_composition_invariance():

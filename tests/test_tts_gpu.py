@@ -190,6 +190,32 @@ def test_style_tokens_ragged_batch():
     assert np.abs(one[0].numpy() - outs[2][0].numpy()).max() < 1e-5
 
 
+@pytest.mark.parametrize("variant", ["prenorm", "postnorm_concat", "linear_input"])
+def test_prefix_overlap_is_bit_identical(variant):
+    """Option "overlap_prefix" (default on): the next step's prefix work -- prenet with fresh dropout, input layer, layer 0's
+    q | k | v of the row blocks that already exist -- runs on a side stream, into a second set of buffers, under the current step's
+    layer chain.  Every kernel involved works row by row with per-row operand scales, so splitting the prefix into "old blocks
+    early, new block now" must give the sequential path's spectrogram, stop probabilities and attention weights bit for bit --
+    for pre-norm, post-norm / concat_after blocks and the "linear" decoder input layer, on a ragged batch."""
+    over = {"prenorm": {}, "postnorm_concat": dict(decoder_normalize_before=False, decoder_concat_after=True),
+            "linear_input": dict(dprenet_layers=0)}[variant]
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=2, postnet_layers=2, **over)
+    state = syn.transformer_tts_state(40, 80, cfg, seed=81, stop_bias=-0.7, stop_gain=2.0)
+    m = _model(cfg, 40, state)
+    texts = [syn.phoneme_ids(T, idim=40, seed=800 + T) for T in (6, 2, 5)]
+    seeds = [3, 4, 5]
+    m.set_option("overlap_prefix", 1)
+    a = m.inference_batch(texts, maxlenratio=3.0, seeds=seeds)
+    again = m.inference_batch(texts, maxlenratio=3.0, seeds=seeds)     # (buffers of the second set are reused across calls)
+    m.set_option("overlap_prefix", 0)
+    b = m.inference_batch(texts, maxlenratio=3.0, seeds=seeds)
+    for (ma, pa, wa), (mb, pb, wb), (mc, pc, wc) in zip(a, b, again):
+        np.testing.assert_array_equal(ma.numpy(), mb.numpy())
+        np.testing.assert_array_equal(pa.numpy(), pb.numpy())
+        np.testing.assert_array_equal(wa.numpy(), wb.numpy())
+        np.testing.assert_array_equal(ma.numpy(), mc.numpy())
+
+
 def test_kv_only_prefix_projection_experiment():
     """Option "kv_prefix" = 1 (pk_tts_set_option; off by default): layer 0 projects k | v only for the prefix rows and q for the new rows with a
     row GEMM; same result as the fused q | k | v projection up to the two GEMM kernels' rounding."""
