@@ -406,7 +406,9 @@ int pk_tts_set_math(pk_tts* h, int32_t mode);
  *                row GEMM (measured neutral on an MI355X, kept as an option)
  *   "overlap_prefix"  1 (default) = the next decoding step's prefix work (prenet with its fresh dropout, input layer, layer 0's
  *                q | k | v of the row blocks that exist already) runs on a side stream under the current step's layer chain;
- *                0 = everything in order on one stream.  Same spectrogram bit for bit */
+ *                0 = everything in order on one stream.  Same spectrogram bit for bit
+ *   "overlap_cu_mask"  1 (default) = that side stream is confined to every other CU (so that the current step's small dependent
+ *                launches always find free CUs); 0 = an unmasked low-priority stream.  Read when the stream is created */
 int pk_tts_set_option(pk_tts* h, const char* key, int64_t value);
 /* Decoder-prenet dropout: 1 (default) = the dropout stream above with p = 0.5, element index
  * ((s*(s-1)/2 + pos) * dprenet_layers + layer) * dprenet_units + unit for decoding step s = 1, 2, ... and prefix

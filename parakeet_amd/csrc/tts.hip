@@ -356,7 +356,10 @@ struct pk_tts : pk_fft_core {
     bool kv_prefix = false;            // "kv_prefix" option (pk_tts_set_option), see pk_tts_infer
     bool overlap_prefix = true;        // "overlap_prefix": the NEXT step's prefix work (prenet .. layer-0 q|k|v of the rows that
                                        // exist already) on a side stream under this step's layer chain, see pk_tts_infer
-    hipStream_t side = nullptr;        // ... its stream and the two events that order it against the main one
+    int side_cu_mask = 1;              // "overlap_cu_mask": 1 = the side stream runs on every other CU, 0 = an unmasked low-priority stream
+    hipStream_t own_main = nullptr;    // the decoding loop's own stream (see pk_tts_infer), ordered against the caller's by ev_io
+    hipEvent_t ev_io = nullptr;
+    hipStream_t side = nullptr;        // ... the side stream and the two events that order it against the loop's stream
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     pk_dbuf d2_p0, d2_p1, d2_x0, d2_t, d2_ham, d2_pam, d2_qkv0;   // ... and the second set of the buffers it fills
     // weights
@@ -505,6 +508,10 @@ extern "C" int pk_tts_set_option(pk_tts* h, const char* key, int64_t value) {
     }
     if (strcmp(key, "overlap_prefix") == 0) {
         h->overlap_prefix = value != 0;
+        return PK_OK;
+    }
+    if (strcmp(key, "overlap_cu_mask") == 0) {   // (takes effect when the side stream is created: before the first inference)
+        h->side_cu_mask = value != 0;
         return PK_OK;
     }
     return pk_fft_set_option(h, key, value, "pk_tts_set_option");
@@ -962,7 +969,25 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         PK_HIP(hipMemsetAsync(h->d2_pam.p, 0, h->d2_pam.cap, ctx->stream));
         PK_TRY(rows_reserve(h->d2_qkv0, rowsCap, 3 * A));
         if (!h->side) {
-            PK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            // The side stream gets HALF of the CUs (hipExtStreamCreateWithCUMask): the prefix GEMMs are grids of a thousand
+            // workgroups that fill the chip for 30 - 90 us at a time, and with the whole chip theirs every one of the main
+            // stream's small dependent launches waited for workgroups to retire (first version: the layer chain's kernels
+            // went from 11 - 14 to 16 - 18 us each and the overlap gained 1 %).  On half the chip the prefix work of a step
+            // still ends well inside the step.  Fallback: an ordinary low-priority stream.
+            uint32_t mask[16];
+            const int words = std::min(16, (ctx->n_cu + 31) / 32);
+            for (int i = 0; i < words; ++i) mask[i] = 0x55555555u;   // every other CU, all XCDs / shader engines alike
+            // (a CU-masked stream is a BLOCKING stream -- it synchronises implicitly with the NULL stream, which is what torch's
+            // default stream is -- so the loop itself moves to a stream of the engine's own; the caller's stream only waits
+            // for it at the end)
+            PK_HIP(hipStreamCreateWithFlags(&h->own_main, hipStreamNonBlocking));
+            PK_HIP(hipEventCreateWithFlags(&h->ev_io, hipEventDisableTiming));
+            if (h->side_cu_mask == 0 || hipExtStreamCreateWithCUMask(&h->side, (uint32_t)words, mask) != hipSuccess) {
+                (void)hipGetLastError();
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // (lo = the numerically largest = least urgent)
+                PK_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+            }
             PK_HIP(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
             PK_HIP(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
         }
@@ -1039,6 +1064,17 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
     const bool post = !c.decoder_normalize_before, cat = c.decoder_concat_after != 0;
     float* rf = pk_fft_act_ptr(h->d_rf, c.dunits);
     const int* valid = h->d_valid.as<int>();
+    // the decoding loop on the engine's own stream (overlap only): everything issued so far on the caller's stream first
+    struct StreamGuard {   // (restores the context's stream on every return path)
+        pk_ctx* c;
+        hipStream_t user;
+        ~StreamGuard() { c->stream = user; }
+    } sguard{ctx, ctx->stream};
+    if (overlap) {
+        PK_HIP(hipEventRecord(h->ev_io, sguard.user));
+        PK_HIP(hipStreamWaitEvent(h->own_main, h->ev_io, 0));
+        ctx->stream = h->own_main;
+    }
     PK_HIP(hipMemsetAsync(Y, 0, (size_t)B * OR * sizeof(float), ctx->stream));   // ys = zeros(1, 1, odim) (:601-602)
     PK_LAUNCH(ctx, "tts_pe", k_tts_pe_pos_major, dim3((unsigned)rowsCap), dim3(128), 0, h->d_pe.as<float>(),
               h->alpha_dec, B, A, PEB);
@@ -1330,7 +1366,11 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             if (ndone >= B) break;
         }
     }
-    if (overlap) PK_HIP(hipStreamSynchronize(h->side));   // (the prefix of a step that never ran may still be in flight)
+    if (overlap) {
+        PK_HIP(hipStreamSynchronize(h->side));   // (the prefix of a step that never ran may still be in flight)
+        PK_HIP(hipEventRecord(h->ev_io, h->own_main));
+        PK_HIP(hipStreamWaitEvent(sguard.user, h->ev_io, 0));   // what the caller issues next sees the finished decode
+    }
     h->steps = std::min(s, Lcap);
     h->len.resize(B);
     PK_HIP(hipMemcpyAsync(h->len.data(), d_len, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1470,6 +1510,9 @@ extern "C" void pk_tts_destroy(pk_tts* h) {
             (void)hipEventDestroy(h->ev_main);
             (void)hipEventDestroy(h->ev_side);
             (void)hipStreamDestroy(h->side);
+            (void)hipStreamSynchronize(h->own_main);
+            (void)hipEventDestroy(h->ev_io);
+            (void)hipStreamDestroy(h->own_main);
         }
     }
     for (auto& b : h->d_xc_l) b.release();

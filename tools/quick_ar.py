@@ -16,6 +16,8 @@ if which == "tts":
     cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH)
     m = TransformerTTS(idim=80, odim=80, **cfg); m.set_state_dict(syn.transformer_tts_state(80, 80, cfg, stop_bias=-8.0)); m.eval()
     m.set_math(math)
+    for kv in os.environ.get("PK_QAR_OPTS", "").split(","):     # e.g. PK_QAR_OPTS=overlap_prefix=0,overlap_cu_mask=0
+        if "=" in kv: m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     texts = [rng.integers(1, 79, size=T) for _ in range(B)]
     ratio = (L + 0.5) / (T + 1)
     run = lambda: m.inference_batch(texts, maxlenratio=ratio, return_att=False)
@@ -33,7 +35,7 @@ torch.cuda.synchronize(); t = time.time(); n = 2
 for _ in range(n): outs = run()
 torch.cuda.synchronize(); dt = (time.time() - t) / n
 f = frames(outs)
-print(f"{which} B={B} T={T} math={math}: {f} frames, {dt*1e3:.1f} ms/batch, {dt/L*1e6:.0f} us/step, {B/dt:.1f} utt/s, {f*256/22050/dt:.0f}x RT (mel only)")
+print(f"{which} B={B} T={T} math={math} opts={os.environ.get('PK_QAR_OPTS', '')}: {f} frames, {dt*1e3:.1f} ms/batch, {dt/L*1e6:.0f} us/step, {B/dt:.1f} utt/s, {f*256/22050/dt:.0f}x RT (mel only)")
 ctx = Context.get(); ctx.prof_enable(True); ctx.prof_reset(); run()
 tot = 0.0
 for k, (n_, ms) in sorted(ctx.prof_dump().items(), key=lambda kv: -kv[1][1]):
