@@ -718,7 +718,8 @@ def main():
                 "what": "TransformerTTS (LJSpeech recipe sizes) inference alone, 32 x 128 tokens decoded in lockstep for 640 "
                         "steps (the stop token is held off so that every utterance runs to int(129 * maxlenratio) = 640 "
                         "frames; the oracle comparison at these sizes, tests/test_ar_benchsize_gpu.py, covers the first 224 steps), "
-                        "prenet dropout stream on, default math",
+                        "prenet dropout stream on, default math; the next step's prefix work runs on a side stream under the current step's "
+                        "layer chain (option overlap_prefix)",
                 "ms_per_batch": dtt * 1e3, "us_per_step": dtt / frames_per_utt * 1e6, "frames": nf,
                 "utterances_per_s": UTT_PER_GPU / dtt, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtt}
             del ttm

@@ -289,7 +289,8 @@ int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t
 int pk_wf_set_math(pk_wf* h, int32_t mode);
 /* Named integer options (as pk_pwg_set_option; scheduling only, results do not change):
  *   "layer_waves"  0 (default) = the fused layer kernel runs in 12-wave workgroups where that saves a round over 8-wave ones
- *                  (64-channel model), 8 / 12 = forced (12: 64 channels only, PK_EUNSUPPORTED otherwise)
+ *                  (64-channel model), 8 / 12 = forced (12: 64 channels only, PK_EUNSUPPORTED otherwise); 6 = two independent
+ *                  6-wave workgroups per CU with 24 KB weight slabs (64 channels only)
  *   "persistent"   0 (default) = one launch per residual layer; 1 = the layers of a row in ONE cooperative launch with a barrier
  *                  across the grid between two layers (120 launches per batch instead of 960; same results; measured slower on
  *                  the MI355X -- a grid-wide barrier on 8 XCDs costs more than the gap between two launches)

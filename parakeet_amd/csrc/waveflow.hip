@@ -247,8 +247,8 @@ static bool wfl_usable(const pk_wf* h) {
 extern "C" int pk_wf_set_option(pk_wf* h, const char* key, int64_t value) {
     if (!h || !key) PK_FAIL(PK_EINVAL, "pk_wf_set_option: NULL argument");
     if (strcmp(key, "layer_waves") == 0) {
-        if (value != 0 && value != 8 && value != 12) PK_FAIL(PK_EINVAL, "pk_wf_set_option: layer_waves %lld (0, 8, 12)", (long long)value);
-        if (value == 12 && h->cfg.channels != 64) PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_option: 12-wave workgroups are built for the 64-channel model");
+        if (value != 0 && value != 6 && value != 8 && value != 12) PK_FAIL(PK_EINVAL, "pk_wf_set_option: layer_waves %lld (0, 6, 8, 12)", (long long)value);
+        if ((value == 12 || value == 6) && h->cfg.channels != 64) PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_option: 12- / 6-wave workgroups are built for the 64-channel model");
         h->layer_waves = (int)value;
     } else if (strcmp(key, "persistent") == 0) h->persistent = value != 0;
     else if (strcmp(key, "fuse_step") == 0) h->fuse_step = value != 0;

@@ -44,14 +44,18 @@ typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int WAVE_T = 32;
-constexpr int SLAB_BYTES = 48 * 1024;   // one weight slab in LDS; two of them
-constexpr int SLAB_CH = SLAB_BYTES / 16;   // 16-byte chunks per slab buffer
 constexpr int BLK_M_BYTES = WFL_MP * 128;  // bytes per 32-position block of the condition planes
 
 // W = waves per workgroup: 8 (two per SIMD, 256 registers each), or 12 at 64 channels (three per SIMD, 168 registers: the 11
 // wave tiles a workgroup owns at the benchmark's shape -- 2 592 tiles on 256 CUs -- run as ONE round instead of 8 + 3)
+// W = 6 (round 4, 64 channels): TWO workgroups per CU, six waves and three 24 KB slabs each (3 k-steps per slab) -- the same three
+// waves per SIMD and 168 registers as W = 12, but the two workgroups are independent: one's slab barriers, prologue and epilogue
+// lie under the other's MFMAs (the twelve waves of ONE workgroup move in lockstep; the counters of the 12-wave kernel show the
+// matrix pipe 30 % busy with half the wave cycles waiting).  Price: the weights travel from L2 to LDS twice per CU.
 template <int CT, int W = 8>
 struct Shape {
+    static constexpr int SLAB_BYTES = W == 6 ? 24 * 1024 : 48 * 1024;   // one weight slab in LDS; three of them
+    static constexpr int SLAB_CH = SLAB_BYTES / 16;                     // 16-byte chunks per slab buffer
     static constexpr int THREADS = W * 64;
     static constexpr int C = 32 * CT;
     static constexpr int KS_TAP = C / 16;                 // k-steps per conv tap: 4 / 8
@@ -67,7 +71,7 @@ struct Shape {
     static constexpr int CPT2 = (SLAB2 * KCH2 + THREADS - 1) / THREADS;   // chunks per thread per W2 slab: 2 / 4 (12 waves: 2, the
                                                           // second one clamped to the slab's last chunk for waves 4 - 11)
     static constexpr int BLK_BYTES = C * 128;             // bytes per 32-position block of the feature planes
-    static constexpr int RING = CT == 2 ? (W == 12 ? 6 : 9) : 2 * SLAB;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12
+    static constexpr int RING = CT == 2 ? (W != 8 ? 6 : 9) : 2 * SLAB;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12
                                                           // would leave the A fragments two register quads -- every LDS read
                                                           // latency exposed; 12 waves: 6, what 168 registers hold)
     static_assert(SLAB * KCH1 % THREADS == 0, "a main slab is a whole number of chunks per thread");
@@ -195,11 +199,12 @@ __device__ __forceinline__ int opaque_zero() {
 // instantiation because the loop around the layer body is not free: it lengthens live ranges (the 128-channel kernel went from
 // 28 to 63 spilled registers, 88 -> 128 us per launch with fp16 operands) -- the one-layer kernels are compiled without it.
 template <int CT, int NT, int ABL = 0, bool F16 = false, int W = 8, bool MULTI = false>
-__global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
+__global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch a) {
     typedef Shape<CT, W> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
-    constexpr int RING = (W == 12 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
-    static_assert(W == 8 || (W == 12 && CT == 2 && ABL == 0), "12-wave workgroups: the 64-channel model");
+    constexpr int RING = (W != 8 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
+    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && ABL == 0), "12- / 6-wave workgroups: the 64-channel model");
+    constexpr int SLAB_CH = S::SLAB_CH;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
     constexpr int nks_conv = S::KS_TAP * ntap;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
     // (addresses = a scalar base + a 32-bit byte offset: one add per chunk instead of a 64-bit multiply-add chain -- 54 chunks
     // per tile)
     auto w_src = [&](int g, int c, int tz) -> const f16x8* {
-        const int f = c * THREADS + tid + (W == 12 ? tz : 0);
+        const int f = c * THREADS + tid + (W != 8 ? tz : 0);
         if (g < nslab)
             return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
                                                   (kt_w[SLAB * g + f / S::KCH1 + tz] + (unsigned)((f % S::KCH1) * 16)));
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
             // branches are waited for where the branches join)
             unsigned m_raw;
             {
-                const int lane_r = lane + (W == 12 ? lz : 0);
+                const int lane_r = lane + (W != 8 ? lz : 0);
                 const int li = lane_r <= 2 * ntap ? lane_r : 0, t = li >> 1;   // t = ntap: the condition block (shift 0)
                 const int blk = (p0 + tp_shift[t + lz] + 31 * (li & 1)) >> 5;   // (the LDS tables, not the kernel arguments: those
                 m_raw = (in_amax0 + tp_am[t + lz])[blk];                          //  indexed per lane would be loads from memory)
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
                 // second requested when the first has gone to LDS after the first k-step, and a ring slot is rescaled in
                 // place and refilled after its k-step's MFMAs.  (A k-step is 24 MFMAs there: the loads a weight wait drains
                 // early are still three k-steps = 2 300 matrix cycles old.)
-                constexpr bool TIGHT = CT == 4 || W == 12;   // (12 waves: 168 registers)
+                constexpr bool TIGHT = CT == 4 || W != 8;   // (12 waves: 168 registers)
                 const int NW = g + 2 >= G ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = TIGHT ? NW / 2 : NW;   // constants once unrolled
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
                 // (12 waves: the opaque part is the scalar base -- "constant | lane" would be hoisted out of the round loop, spilled,
                 // and its reload in the middle of the slab loop waits for the weight loads just requested)
                 unsigned wo = (g % 3) * SLAB_CH;
-                if constexpr (W == 12) {
+                if constexpr (W != 8) {
                     asm volatile("" : "+s"(wo));
                     wo += lane;
                 } else {
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
                     // A fragments AHEAD co-tiles ahead of their MFMAs (not all NQ of them: registers).  Two at 64 channels:
                     // with one, every co-tile's three MFMAs (96 cycles) had to cover a whole LDS read latency, and the trace
                     // showed about 200 cycles per k-step and wave that nothing covered
-                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W == 12 && !F16)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
+                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W != 8 && !F16)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
                     // math: one -- registers; the other two waves of the SIMD cover the LDS latency)
                     __builtin_amdgcn_sched_group_barrier(0x100, PER * (AHEAD + 0), 0);
 #pragma unroll
@@ -510,11 +515,11 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
             unsigned cur_am;
             float2 prm_old = {0.f, 0.f};
             // (12 waves: the epilogue's lane coordinates are derived HERE, from an opaque zero -- not hoisted, not spilled)
-            const int ez = opaque_zero<W == 12>();
-            const int lane_e = lane + ez, hh_e = W == 12 ? lane_e >> 5 : hh;
-            const int p_e = W == 12 ? p0 + (lane_e & 31) : p;
-            const long pblk_e = W == 12 ? (long)(p_e >> 5) : pblk;
-            const int pin_e = W == 12 ? p_e & 31 : pin;
+            const int ez = opaque_zero<W != 8>();
+            const int lane_e = lane + ez, hh_e = W != 8 ? lane_e >> 5 : hh;
+            const int p_e = W != 8 ? p0 + (lane_e & 31) : p;
+            const long pblk_e = W != 8 ? (long)(p_e >> 5) : pblk;
+            const int pin_e = W != 8 ? p_e & 31 : pin;
             // MULTI: the parked copies (read here, with the other old values: wave-uniform, made scalar where they branch);
             // one layer: the kernel arguments themselves
             Cold cd;
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_wf_layer_p(WflLaunch a) {
                 cur_am = in_amax0[(long)a.cur_slot * a.amax_stride + (p0 >> 5)];
                 if (!l_first && !(ABL & 4)) prm_old = reinterpret_cast<const float2*>(a.prm)[p_e];
             }
-            const int p_utt_e = W == 12 ? a.pos_utt[p_e] : p_utt;   // (12 waves: requested with the old values, not held since the round's start)
+            const int p_utt_e = W != 8 ? a.pos_utt[p_e] : p_utt;   // (12 waves: requested with the old values, not held since the round's start)
             // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection; on the way this
             // lane's part of the folded skip path: (logs, b) += sum over its C/2 channels of wso[.][channel] * z
             __builtin_amdgcn_sched_barrier(0);   // the old-value loads stay ahead of the gate
@@ -955,12 +960,17 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     const int ntiles = a.npos_alloc / WAVE_T;
     WflLaunch b = a;
     b.tiles_per_wg = std::max(1, (ntiles + ctx->n_cu - 1) / ctx->n_cu);
-    const int grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
+    int grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
     // 64 channels: 12-wave workgroups (three waves per SIMD, 168 registers) where they save a round -- the tiles of a
     // workgroup in ceil(t / 12) rounds instead of ceil(t / 8) (the benchmark's 8 x 640 frames: 11 tiles per workgroup, one round
     // instead of 8 + 3 with the second 3/8 full).  a.waves = 8 / 12 forces one (option "layer_waves" of pk_wf_set_option).
-    const bool w12 = a.C == 64 && (a.waves == 12 || (a.waves != 8 && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));
-    const int W = w12 ? 12 : 8;
+    const bool w6 = a.C == 64 && a.waves == 6 && a.nl == 1;   // two 6-wave workgroups per CU (see Shape)
+    const bool w12 = !w6 && a.C == 64 && (a.waves == 12 || a.waves == 6 || (a.waves != 8 && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));
+    const int W = w6 ? 6 : (w12 ? 12 : 8);
+    if (w6) {
+        b.tiles_per_wg = std::max(1, (ntiles + 2 * ctx->n_cu - 1) / (2 * ctx->n_cu));
+        grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
+    }
     static const int active_env = pk_prof_env("PK_WF_ACTIVE") ? atoi(pk_prof_env("PK_WF_ACTIVE")) : 0;   // measurement switch
     b.active = active_env >= 1 && active_env <= W ? active_env : W;
     // several layers: the workgroups wait for one another (pk_grid.h) -- at most one per CU by construction (LDS), launched
@@ -984,6 +994,10 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         }
         if (a.C == 64) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 8, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 8, true>) : go(k_wf_layer_p<2, 3, 0, false, 8, true>));
         return nt == 1 ? go(k_wf_layer_p<4, 1, 0, false, 8, true>) : (nt == 2 ? go(k_wf_layer_p<4, 2, 0, false, 8, true>) : go(k_wf_layer_p<4, 3, 0, false, 8, true>));
+    }
+    if (w6) {
+        if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 6>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 6>) : go(k_wf_layer_p<2, 3, 0, true, 6>));
+        return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 6>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 6>) : go(k_wf_layer_p<2, 3, 0, false, 6>));
     }
     if (w12) {
         if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 12>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 12>) : go(k_wf_layer_p<2, 3, 0, true, 12>));

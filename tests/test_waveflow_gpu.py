@@ -87,11 +87,12 @@ def test_waveflow_12_wave_workgroups_bit_identical(math):
     mels = [np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32) for T in frames]
     zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
     outs = {}
-    for w in (8, 12):
+    for w in (8, 12, 6):   # 6: two independent 6-wave workgroups per CU with 24 KB weight slabs
         model.set_option("layer_waves", w)
         outs[w] = [o.numpy().copy() for o in model.infer_batch(mels, zs)]
-    for a, b in zip(outs[8], outs[12]):
-        np.testing.assert_array_equal(a, b)
+    for w in (12, 6):
+        for a, b in zip(outs[8], outs[w]):
+            np.testing.assert_array_equal(a, b)
     want = ref.infer(state, torch.from_numpy(mels[0])[None], torch.from_numpy(zs[0])[None], cfg, torch.float64)[0].numpy()
     err = np.abs(outs[12][0] - want).max() / np.abs(want).max()
     assert err < (2e-3 if math else 2e-4), err
