@@ -49,12 +49,13 @@ else:
 hbm = L["FETCH_SIZE"] * 1024 / rcal + L["WRITE_SIZE"] * 1024 / wcal
 out = {"kernel": LK, "hbm_bytes_per_launch": hbm, "fetch_size_kb": L["FETCH_SIZE"], "write_size_kb": L["WRITE_SIZE"],
        "fetch_calibration": rcal, "write_calibration": wcal,
-       "mfma_busy_frac": L["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * L["GRBM_GUI_ACTIVE"] / 8),
-       "effective_clock_ghz": L["GRBM_GUI_ACTIVE"] / 8 / (L["_avg_ns_under_pmc"] * 1e-9) / 1e9,
-       "wait_any_frac": L["SQ_WAIT_ANY"] / L["SQ_WAVE_CYCLES"],
-       "wait_inst_any_frac": L["SQ_WAIT_INST_ANY"] / L["SQ_WAVE_CYCLES"],
-       "valu_quadcycles_per_mfma": L["SQ_ACTIVE_INST_VALU"] / L["SQ_INSTS_MFMA"],
        "l2_hit_rate": L["TCC_HIT"] / (L["TCC_HIT"] + L["TCC_MISS"]), "avg_ns_under_pmc": L["_avg_ns_under_pmc"]}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in L:   # (the SQ pass is optional: the traffic passes alone give the bytes)
+    out.update({"mfma_busy_frac": L["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * L["GRBM_GUI_ACTIVE"] / 8),
+                "effective_clock_ghz": L["GRBM_GUI_ACTIVE"] / 8 / (L["_avg_ns_under_pmc"] * 1e-9) / 1e9,
+                "wait_any_frac": L["SQ_WAIT_ANY"] / L["SQ_WAVE_CYCLES"],
+                "wait_inst_any_frac": L["SQ_WAIT_INST_ANY"] / L["SQ_WAVE_CYCLES"],
+                "valu_quadcycles_per_mfma": L["SQ_ACTIVE_INST_VALU"] / L["SQ_INSTS_MFMA"]})
 out.update(extra)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
