@@ -545,8 +545,8 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     unsigned long long* d_trace = nullptr;
     static const bool want_trace = pk_prof_env("PK_WF_ABLATE") && atoi(pk_prof_env("PK_WF_ABLATE")) == 16;
     if (want_trace) {
-        PK_TRY(h->ws_trace.reserve(8 * 2 * 24 * sizeof(unsigned long long)));
-        PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, 8 * 2 * 24 * sizeof(unsigned long long), ctx->stream));
+        PK_TRY(h->ws_trace.reserve(12 * 2 * 24 * sizeof(unsigned long long)));
+        PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, 12 * 2 * 24 * sizeof(unsigned long long), ctx->stream));
         d_trace = h->ws_trace.as<unsigned long long>();
     }
     // ---- the layer descriptors of the fused kernel, one per (flow, ring slot of the current row, layer): weights of the
@@ -744,13 +744,14 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         std::swap(cur, nxt);
     }
     if (d_trace) {
-        unsigned long long tr[8 * 2 * 24];
+        unsigned long long tr[12 * 2 * 24];
         PK_HIP(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipStreamSynchronize(ctx->stream));
         unsigned long long t0 = ~0ull;
         for (unsigned long long v : tr) if (v && v < t0) t0 = v;
-        for (int wv = 0; wv < 8; ++wv)
+        for (int wv = 0; wv < 12; ++wv)
             for (int r = 0; r < 2; ++r) {
+                if (!tr[(wv * 2 + r) * 24]) continue;
                 fprintf(stderr, "wf_trace wave %d round %d:", wv, r);
                 for (int i = 0; i < 24; ++i) fprintf(stderr, " %lld", tr[(wv * 2 + r) * 24 + i] ? (long long)(tr[(wv * 2 + r) * 24 + i] - t0) : -1LL);
                 fprintf(stderr, "\n");

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     typedef Shape<CT, W> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
     constexpr int RING = (W != 8 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
-    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && ABL == 0), "12- / 6-wave workgroups: the 64-channel model");
+    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace only)");
     constexpr int SLAB_CH = S::SLAB_CH;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
@@ -931,7 +931,7 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
 // Timing ablations and the s_memtime trace (PK_WF_ABLATE; results are WRONG): instantiated in the profile build only
 // (parakeet_amd/build.py build(profile=True)).  Returns 1 when no ablation applies.
 template <bool PROF, class Go>
-static int wfl_ablation(Go& go, bool shape_ok, bool trace) {
+static int wfl_ablation(Go& go, bool shape_ok, bool trace, bool w12) {
     if constexpr (PROF) {
         static const int abl = pk_prof_env("PK_WF_ABLATE") ? atoi(pk_prof_env("PK_WF_ABLATE")) : 0;
         if (abl && shape_ok) {
@@ -941,7 +941,7 @@ static int wfl_ablation(Go& go, bool shape_ok, bool trace) {
                 case 8: return go(k_wf_layer_p<2, 3, 8>);
                 case 9: return go(k_wf_layer_p<2, 3, 9>);
                 case 13: return go(k_wf_layer_p<2, 3, 13>);
-                case 16: if (trace) return go(k_wf_layer_p<2, 3, 16>); break;
+                case 16: if (trace) return w12 ? go(k_wf_layer_p<2, 3, 16, false, 12>) : go(k_wf_layer_p<2, 3, 16>); break;
                 case 32: return go(k_wf_layer_p<2, 3, 32>);   // A fragments one co-tile ahead (A/B of the LDS prefetch depth)
                 default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16 or 32");
             }
@@ -995,6 +995,8 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         if (a.C == 64) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 8, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 8, true>) : go(k_wf_layer_p<2, 3, 0, false, 8, true>));
         return nt == 1 ? go(k_wf_layer_p<4, 1, 0, false, 8, true>) : (nt == 2 ? go(k_wf_layer_p<4, 2, 0, false, 8, true>) : go(k_wf_layer_p<4, 3, 0, false, 8, true>));
     }
+    // (profile build: the s_memtime trace exists for the 8- and the 12-wave kernel, the timing ablations for the 8-wave one)
+    if (int st = wfl_ablation<PK_PROFILE_BUILD != 0>(go, a.C == 64 && nt == 3 && !a.f16 && !w6 && (!w12 || b.trace != nullptr), b.trace != nullptr, w12); st != 1) return st;
     if (w6) {
         if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 6>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 6>) : go(k_wf_layer_p<2, 3, 0, true, 6>));
         return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 6>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 6>) : go(k_wf_layer_p<2, 3, 0, false, 6>));
@@ -1003,7 +1005,6 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 12>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 12>) : go(k_wf_layer_p<2, 3, 0, true, 12>));
         return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 12>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 12>) : go(k_wf_layer_p<2, 3, 0, false, 12>));
     }
-    if (int st = wfl_ablation<PK_PROFILE_BUILD != 0>(go, a.C == 64 && nt == 3 && !a.f16, b.trace != nullptr); st != 1) return st;
     if (a.f16) {
         if (a.C == 64)
             return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true>) : go(k_wf_layer_p<2, 3, 0, true>));
