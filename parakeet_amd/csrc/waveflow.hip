@@ -543,7 +543,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
 
     // profiling only (PK_WF_ABLATE=16): the layer kernel's s_memtime stamps, printed after the last launch
     unsigned long long* d_trace = nullptr;
-    static const bool want_trace = pk_prof_env("PK_WF_ABLATE") && atoi(pk_prof_env("PK_WF_ABLATE")) == 16;
+    static const bool want_trace = pk_prof_env("PK_WF_ABLATE") && (atoi(pk_prof_env("PK_WF_ABLATE")) & ~64) == 16;
     if (want_trace) {
         PK_TRY(h->ws_trace.reserve(12 * 2 * 24 * sizeof(unsigned long long)));
         PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, 12 * 2 * 24 * sizeof(unsigned long long), ctx->stream));

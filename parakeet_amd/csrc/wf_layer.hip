@@ -187,7 +187,8 @@ __device__ __forceinline__ int opaque_zero() {
 // that is needed twelve k-steps later.)
 // ABL (profiling only, PK_WF_ABLATE, results are wrong when set): 1 = the operand ring is not refilled after the prologue
 // (no operand traffic), 4 = no epilogue loads / stores, 8 = the weight slabs are not reloaded after the prologue (barriers
-// stay); sums combine
+// stay); sums combine.  16 = s_memtime stamps of workgroup 5 (results stay right), 64 = no raised priority for the prologue's
+// weight requests (results stay right; 80 = both)
 //
 // F16 = the reference's own inference precision for this model (examples/waveflow/synthesize.py:40 runs under
 // paddle.amp.auto_cast: fp16 conv operands, fp32 accumulation): every product is ONE fp16 MFMA of the operands rounded to
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     typedef Shape<CT, W> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
     constexpr int RING = (W != 8 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
-    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace only)");
+    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16 || ABL == 64 || ABL == 80)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace, the prologue priority)");
     constexpr int SLAB_CH = S::SLAB_CH;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
@@ -394,10 +395,24 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             const int pin = p & 31;
 
             {   // slabs 0 and 1 of the weights in ONE round trip (a second register set: nothing else is live yet)
+                // Round 4 (s_memtime trace of the 12-wave kernel, profiles/r04_wf_layer_trace_12_waves.txt): the prologue barrier
+                // passed at 12.2 k of a launch's 80 k cycles, the first wave of every SIMD ready at 5 k, the third at 11.3 k -- the
+                // arbiter serves the oldest wave first, so the youngest wave's weight chunks queue behind the operand loads of
+                // the two older ones (264 KB through a 64 B / clock L1 before the barrier; the barrier itself needs the 96 KB
+                // of weights only).  A wave therefore requests its weights at raised priority and drops back for the operands:
+                // the weight loads of all waves go first.  (ABL & 64: without, for the A/B.)
                 f16x8 wreg1[S::CPT1];
+                if (!(ABL & 64)) {
+                    __builtin_amdgcn_s_setprio(3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 w_load(0, lz);
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wreg1[c] = *w_src(1, c, lz);
+                if (!(ABL & 64)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
 #pragma unroll
                 for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nks >= 18 > RING
                 __builtin_amdgcn_sched_barrier(0);   // everything above is requested before anything below waits
@@ -931,19 +946,24 @@ WflPacked wfl_pack(int C, const float* conv, const float* conv_b, const float* c
 // Timing ablations and the s_memtime trace (PK_WF_ABLATE; results are WRONG): instantiated in the profile build only
 // (parakeet_amd/build.py build(profile=True)).  Returns 1 when no ablation applies.
 template <bool PROF, class Go>
-static int wfl_ablation(Go& go, bool shape_ok, bool trace, bool w12) {
+static int wfl_ablation(Go& go, bool shape_ok, bool trace, bool w12, bool f16, bool c128) {
     if constexpr (PROF) {
         static const int abl = pk_prof_env("PK_WF_ABLATE") ? atoi(pk_prof_env("PK_WF_ABLATE")) : 0;
         if (abl && shape_ok) {
+            const bool plain8 = !w12 && !f16 && !c128;   // (the timing ablations exist for the 8-wave kernel in the default math)
             switch (abl) {
-                case 1: return go(k_wf_layer_p<2, 3, 1>);
-                case 4: return go(k_wf_layer_p<2, 3, 4>);
-                case 8: return go(k_wf_layer_p<2, 3, 8>);
-                case 9: return go(k_wf_layer_p<2, 3, 9>);
-                case 13: return go(k_wf_layer_p<2, 3, 13>);
-                case 16: if (trace) return w12 ? go(k_wf_layer_p<2, 3, 16, false, 12>) : go(k_wf_layer_p<2, 3, 16>); break;
-                case 32: return go(k_wf_layer_p<2, 3, 32>);   // A fragments one co-tile ahead (A/B of the LDS prefetch depth)
-                default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16 or 32");
+                case 1: if (plain8) return go(k_wf_layer_p<2, 3, 1>); break;
+                case 4: if (plain8) return go(k_wf_layer_p<2, 3, 4>); break;
+                case 8: if (plain8) return go(k_wf_layer_p<2, 3, 8>); break;
+                case 9: if (plain8) return go(k_wf_layer_p<2, 3, 9>); break;
+                case 13: if (plain8) return go(k_wf_layer_p<2, 3, 13>); break;
+                case 16: if (trace && !c128) return w12 ? go(k_wf_layer_p<2, 3, 16, false, 12>) : go(k_wf_layer_p<2, 3, 16>); break;
+                case 80: if (trace && !c128) return w12 ? go(k_wf_layer_p<2, 3, 80, false, 12>) : go(k_wf_layer_p<2, 3, 80>); break;
+                case 64: if (c128) return f16 ? go(k_wf_layer_p<4, 3, 64, true>) : go(k_wf_layer_p<4, 3, 64>);
+                         return w12 ? (f16 ? go(k_wf_layer_p<2, 3, 64, true, 12>) : go(k_wf_layer_p<2, 3, 64, false, 12>))
+                                    : (f16 ? go(k_wf_layer_p<2, 3, 64, true>) : go(k_wf_layer_p<2, 3, 64>));
+                case 32: if (plain8) return go(k_wf_layer_p<2, 3, 32>); break;   // A fragments one co-tile ahead (A/B of the LDS prefetch depth)
+                default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16, 32, 64 or 80");
             }
         }
     }
@@ -996,7 +1016,7 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
         return nt == 1 ? go(k_wf_layer_p<4, 1, 0, false, 8, true>) : (nt == 2 ? go(k_wf_layer_p<4, 2, 0, false, 8, true>) : go(k_wf_layer_p<4, 3, 0, false, 8, true>));
     }
     // (profile build: the s_memtime trace exists for the 8- and the 12-wave kernel, the timing ablations for the 8-wave one)
-    if (int st = wfl_ablation<PK_PROFILE_BUILD != 0>(go, a.C == 64 && nt == 3 && !a.f16 && !w6 && (!w12 || b.trace != nullptr), b.trace != nullptr, w12); st != 1) return st;
+    if (int st = wfl_ablation<PK_PROFILE_BUILD != 0>(go, nt == 3 && !w6, b.trace != nullptr, w12, a.f16 != 0, a.C == 128); st != 1) return st;
     if (w6) {
         if (a.f16) return nt == 1 ? go(k_wf_layer_p<2, 1, 0, true, 6>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, true, 6>) : go(k_wf_layer_p<2, 3, 0, true, 6>));
         return nt == 1 ? go(k_wf_layer_p<2, 1, 0, false, 6>) : (nt == 2 ? go(k_wf_layer_p<2, 2, 0, false, 6>) : go(k_wf_layer_p<2, 3, 0, false, 6>));
