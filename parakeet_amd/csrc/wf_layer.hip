@@ -187,8 +187,8 @@ __device__ __forceinline__ int opaque_zero() {
 // that is needed twelve k-steps later.)
 // ABL (profiling only, PK_WF_ABLATE, results are wrong when set): 1 = the operand ring is not refilled after the prologue
 // (no operand traffic), 4 = no epilogue loads / stores, 8 = the weight slabs are not reloaded after the prologue (barriers
-// stay); sums combine.  16 = s_memtime stamps of workgroup 5 (results stay right), 64 = no raised priority for the prologue's
-// weight requests (results stay right; 80 = both)
+// stay); sums combine.  16 = s_memtime stamps of workgroup 5 (results stay right), 64 = the prologue in which every
+// thread brings its share of slabs 0 and 1 before the barrier (results stay right; 80 = both)
 //
 // F16 = the reference's own inference precision for this model (examples/waveflow/synthesize.py:40 runs under
 // paddle.amp.auto_cast: fp16 conv operands, fp32 accumulation): every product is ONE fp16 MFMA of the operands rounded to
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     typedef Shape<CT, W> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
     constexpr int RING = (W != 8 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
-    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16 || ABL == 64 || ABL == 80)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace, the prologue priority)");
+    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16 || ABL == 64 || ABL == 80)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace, the old prologue)");
     constexpr int SLAB_CH = S::SLAB_CH;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
@@ -268,13 +268,44 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // loop unrolled the compiler would otherwise read all of them up front and hold them in registers)
     // (addresses = a scalar base + a 32-bit byte offset: one add per chunk instead of a 64-bit multiply-add chain -- 54 chunks
     // per tile)
-    auto w_src = [&](int g, int c, int tz) -> const f16x8* {
-        const int f = c * THREADS + tid + (W != 8 ? tz : 0);
+    auto w_srcf = [&](int g, int f, int tz) -> const f16x8* {   // chunk f of slab g
         if (g < nslab)
             return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
                                                   (kt_w[SLAB * g + f / S::KCH1 + tz] + (unsigned)((f % S::KCH1) * 16)));
         return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w2) +
                                               (unsigned)(((g - nslab) * (S::SLAB2 * S::KCH2) + min(f, S::SLAB2 * S::KCH2 - 1)) * 16));
+    };
+    auto w_src = [&](int g, int c, int tz) -> const f16x8* { return w_srcf(g, c * THREADS + tid + (W != 8 ? tz : 0), tz); };
+    // The prologue of a round brings the first weight slabs.  Round 4 (s_memtime trace of the 12-wave kernel,
+    // profiles/r04_wf_layer_trace_12_waves.txt): with every thread bringing its share of slabs 0 and 1, the prologue barrier
+    // passed at 12.2 k of a launch's 80 k cycles -- the first wave of a SIMD had its data at 5 k, the second at 8 k, the third at
+    // 10.4 k (the whole chip starts at once: 264 KB per CU behind an idle memory system, served oldest wave first), and nobody
+    // could start before the youngest wave's weight chunks had arrived.  Raising the priority of the weight requests
+    // (tools/r04_wf_prio_call.sh) moved the barrier to 10.6 k: -1 % / 0 / +0.4 % -- the requests were not the problem, the
+    // barrier's wait for the last arrival was.  Now the first NA waves (role A: the oldest wave of every SIMD) bring ALL of
+    // slab 0 and store it before the barrier; the others (role B) bring slab 1 -- and slab 2 where they are twice as many --
+    // pass the barrier without waiting for anything and store behind it (slab 1 is needed behind the barrier that ends
+    // slab 0; buffer 2 is free): the old waves start their matrix work when THEIR data is there.  Every thread runs the
+    // same CL loads into the same registers, the role only selects addresses (no control flow around the loads: with the
+    // roles as branches the register allocator spilled the chunks behind their loads or merged the operand ring through
+    // memory).  ABL & 64: the old prologue, for the A/B.
+    constexpr int NA = W == 6 ? 2 : 4;
+    constexpr int NCH = S::CPT1 * THREADS;       // chunks of a main slab
+    constexpr int CL = NCH / (NA * 64);          // prologue chunks per thread (12)
+    constexpr bool PRO2 = (W - NA) == 2 * NA;    // role B brings slabs 1 and 2 (half of CL each)
+    static_assert(CL % 2 == 0 && CL * NA * 64 == NCH && (PRO2 ? CL / 2 : CL) * (W - NA) * 64 == NCH, "the prologue's split of the slabs over the waves");
+    static_assert(nslab >= 3, "slabs 0 - 2 are conv slabs");
+    constexpr bool NEWPRO = (ABL & 64) == 0 && CT == 2;   // (128 channels: the 12 chunks in flight cost 25 more spilled registers)
+    const bool role_a = __builtin_amdgcn_readfirstlane(wave) < NA;
+    // prologue chunk c of this thread: (slab, chunk in the slab)
+    auto pro_g = [&](int c) { return role_a ? 0 : (PRO2 && c >= CL / 2 ? 2 : 1); };
+    auto pro_f = [&](int c) {
+        return role_a ? c * (NA * 64) + tid : ((PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64));
+    };
+    auto pro_src = [&](int c, int tz) -> const f16x8* {
+        const unsigned f = (unsigned)(pro_f(c) + (W != 8 ? tz : 0));
+        return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
+                                              (kt_w[SLAB * pro_g(c) + (int)(f / S::KCH1) + tz] + (f % S::KCH1) * 16u));
     };
     f16x8 wreg[S::CPT1];   // one slab of weights on its way from global memory to LDS
     auto w_load = [&](int g, int tz) {
@@ -394,31 +425,33 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             const long pblk = (long)(p >> 5);
             const int pin = p & 31;
 
-            {   // slabs 0 and 1 of the weights in ONE round trip (a second register set: nothing else is live yet)
-                // Round 4 (s_memtime trace of the 12-wave kernel, profiles/r04_wf_layer_trace_12_waves.txt): the prologue barrier
-                // passed at 12.2 k of a launch's 80 k cycles, the first wave of every SIMD ready at 5 k, the third at 11.3 k -- the
-                // arbiter serves the oldest wave first, so the youngest wave's weight chunks queue behind the operand loads of
-                // the two older ones (264 KB through a 64 B / clock L1 before the barrier; the barrier itself needs the 96 KB
-                // of weights only).  A wave therefore requests its weights at raised priority and drops back for the operands:
-                // the weight loads of all waves go first.  (ABL & 64: without, for the A/B.)
+            // the first weight slabs and the first RING k-steps of the operands in ONE round trip
+            f16x8 wpro[NEWPRO ? CL : 1];
+            if constexpr (!NEWPRO) {
                 f16x8 wreg1[S::CPT1];
-                if (!(ABL & 64)) {
-                    __builtin_amdgcn_s_setprio(3);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 w_load(0, lz);
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wreg1[c] = *w_src(1, c, lz);
-                if (!(ABL & 64)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(0);
-                }
 #pragma unroll
                 for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nks >= 18 > RING
                 __builtin_amdgcn_sched_barrier(0);   // everything above is requested before anything below waits
                 w_store(0);
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+            } else {
+                // (half of the chunks, the operands, the other half: role B's second half is slab 2, which can wait; role A
+                // needs its operands before it can start anyway)
+#pragma unroll
+                for (int c = 0; c < CL / 2; ++c) wpro[c] = *pro_src(c, lz);
+#pragma unroll
+                for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nks >= 18 > RING
+#pragma unroll
+                for (int c = CL / 2; c < CL; ++c) wpro[c] = *pro_src(c, lz);
+                __builtin_amdgcn_sched_barrier(0);   // everything above is requested before anything below waits
+                if (role_a) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) wbuf[0][c * (NA * 64) + tid] = wpro[c];
+                }
             }
             // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex
             const int ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(wave_max64(__uint_as_float(m_raw)))));   // (all sources are maxima: the repeats change nothing)
@@ -438,6 +471,12 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             stamp(1);
             __syncthreads();
             stamp(2);
+            if constexpr (NEWPRO) {
+                if (!role_a) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
+                }
+            }
 #pragma unroll
             for (int g = 0; g < nslab; ++g) {
                 int tz = 0;
@@ -447,7 +486,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 // place and refilled after its k-step's MFMAs.  (A k-step is 24 MFMAs there: the loads a weight wait drains
                 // early are still three k-steps = 2 300 matrix cycles old.)
                 constexpr bool TIGHT = CT == 4 || W != 8;   // (12 waves: 168 registers)
-                const int NW = g + 2 >= G ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = TIGHT ? NW / 2 : NW;   // constants once unrolled
+                const int NW = (g + 2 >= G || (NEWPRO && PRO2 && g == 0)) ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = TIGHT ? NW / 2 : NW;   // constants once unrolled (slab 2: with the prologue where role B brings it)
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
                     if (c < HW && !(ABL & 8)) wreg[c] = *w_src(g + 2, c, tz);   // first: every load below is younger
@@ -717,7 +756,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 }
             }
         } else {
-            {
+            if constexpr (!NEWPRO) {
                 f16x8 wreg1[S::CPT1];
                 w_load(0, lz);
 #pragma unroll
@@ -725,14 +764,29 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 w_store(0);
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+                __syncthreads();
+            } else {
+                f16x8 wpro[CL];
+#pragma unroll
+                for (int c = 0; c < CL; ++c) wpro[c] = *pro_src(c, lz);
+                if (role_a) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) wbuf[0][c * (NA * 64) + tid] = wpro[c];
+                }
+                __syncthreads();
+                if (!role_a) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
+                }
             }
-            __syncthreads();
 #pragma unroll
             for (int g = 0; g < (S::NS2 >= 2 ? G : nslab); ++g) {
                 int tz = 0;
                 asm volatile("" : "+s"(tz));
-                w_load(g + 2, tz);
-                w_store(g + 2);
+                if (!(NEWPRO && PRO2 && g == 0)) {
+                    w_load(g + 2, tz);
+                    w_store(g + 2);
+                }
                 __syncthreads();
             }
         }
