@@ -5,12 +5,14 @@
 #include "pk_philox.h"
 
 void pk_rowgemm_pack(const float* Wkn, int K, int N, std::vector<float>& out) {
-    const int cw = pk_rowgemm_cw(N), nb = (N + cw - 1) / cw;
-    out.assign((size_t)nb * K * cw, 0.f);
+    // [N / 16][KP / 4][16 columns][4 consecutive k], KP = K rounded up to 16, zeros beyond K and N: the float4 a lane of
+    // k_rowgemm reads holds W[4 q .. 4 q + 3][column] -- the B operands of four matrix instructions
+    const int cw = pk_rowgemm_cw(N), nb = (N + cw - 1) / cw, KP = (K + 15) / 16 * 16;
+    out.assign((size_t)nb * KP * cw, 0.f);
     for (int b = 0; b < nb; ++b)
         for (int k = 0; k < K; ++k)
             for (int c = 0; c < cw && b * cw + c < N; ++c)
-                out[((size_t)b * K + k) * cw + c] = Wkn[(size_t)k * N + b * cw + c];
+                out[(((size_t)b * (KP / 4) + k / 4) * cw + c) * 4 + (k & 3)] = Wkn[(size_t)k * N + b * cw + c];
 }
 
 void pk_rowgemm_lstm_perm(int H, std::vector<int>& perm) {
@@ -21,180 +23,185 @@ void pk_rowgemm_lstm_perm(int H, std::vector<int>& perm) {
 
 namespace {
 constexpr int KC = PK_RG_KC, ROWS = PK_RG_ROWS;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-// CW columns per workgroup, KSUB = 64 / CW consecutive k per wave-wide load, 8 * KSUB K-parts per workgroup.
-//
-// Latency is everything here (32 rows: a launch is 10 - 40 MFLOP), so the kernel makes ONE trip to memory before it
-// computes: the first chunk's weights (16 loads per lane), the activation tile (8 float4 per thread), the epilogue's bias and
-// residual are all requested up front, unconditionally, with clamped indices (round 4; rounds 2 / 3 read the rows a first time
-// for the LayerNorm statistics, four rows per wave one after the other, before anything else was requested: five dependent
-// round trips, 12.5 us per launch in the TransformerTTS decoder against 2 us of work).  A thread's 8 float4 all belong to ONE
-// row (m = tid % 32; 512 % 32 == 0), 32 of its K <= 512 values, so the LayerNorm statistics come from the registers that will
-// be staged anyway: per thread mean and M2 of its 32 values, the row's 16 partials merged through LDS by Chan's formula
-// (equal counts: mean = avg(mean_i), M2 = sum M2_i + n sum (mean_i - mean)^2 -- two-pass accuracy without a second pass).
-template <int CW>
+// Chan's merge of two (count, mean, M2) partials
+__device__ __forceinline__ void rg_merge(float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    const float nt = n + nb;
+    if (nt > 0.f) {
+        const float d = mub - mu, f = nb / nt;
+        mu += d * f;
+        m2 += m2b + d * d * n * f;
+    }
+    n = nt;
+}
+
+// One workgroup = 16 output columns x up to 32 rows, 8 waves; the K range is dealt out in steps of 16 k, wave w takes the steps
+// w, w + 8, ...  Latency is everything here (32 rows: a launch is 10 - 40 MFLOP), and round 4's rocprof / HIP-event figures put
+// the previous kernel (activations transposed into LDS, one fp32 FMA per LDS-broadcast operand) at 10 - 20 us per launch with
+// 3 us of that between two launches: its inner loop was bound by the LDS (a ds_read_b128 per four FMAs, 8 waves on one LDS:
+// 8 k cycles per 512 k), twice with K = 1024, ..., and the tile went through LDS before anything could start.  Now the rows
+// never touch LDS: v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulation: no splitting, no block scales) takes A = 16 rows x
+// 4 k and B = 4 k x 16 columns one value per lane -- lane (r = lane % 16, j = lane / 16) reads the float4 x[row r][16 t + 4 j ..]
+// of both row halves and the float4 W[16 t + 4 j ..][column r] of the packed slab, and component c of the three is one
+// instruction's operands (the k of lane group j in instruction c is 16 t + 4 j + c for A and B alike).  Everything a wave
+// needs for 4 steps (12 float4 per lane, + LayerNorm weight and bias) is requested at once, the next 4 steps before the
+// arithmetic of these; the 8 waves' partial tiles are summed through 16 KB of LDS in wave order (deterministic).
+//   Optional prologue: LayerNorm over K <= 512 (each lane's 16 values of its two rows -> (count, mean, M2), merged over the
+//   wave's four lane groups by shuffles and over the waves through LDS with Chan's formula), applied in registers.
+//   Epilogues: bias, ReLU, dropout, residual; or the LSTM cell (see pk_rowgemm.h).
+template <bool LN>
 __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
-    constexpr int KSUB = 64 / CW, PARTS = 8 * KSUB;
-    __shared__ __attribute__((aligned(16))) float xs[KC * ROWS];   // xs[k * 32 + m], 64 KB
-    __shared__ float red[PARTS * ROWS * CW];                       // red[(part * 32 + m) * CW + col], 64 KB
-    __shared__ float stat[2 * 16 * ROWS];                          // LayerNorm: (mean, M2) of the 16 partials of every row
+    constexpr int NWV = 8, CH = 4, CW = 16;
+    __shared__ float red[NWV * ROWS * CW];     // red[(wave * 32 + m) * 16 + col], 16 KB
+    __shared__ float stat[NWV * ROWS * 3];     // LayerNorm: (count, mean, M2) of every wave's share of every row
+    __shared__ float gl[ROWS * CW];            // LSTM epilogue: the gate pre-activations
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
-    const int col = lane % CW, ks = lane / CW;
-    const int part = wave * KSUB + ks;                            // this lane's K-part: k = part, part + PARTS, ...
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, j = lane >> 4;
     const int m0 = blockIdx.y * ROWS;
     const int rows = min(ROWS, a.M - m0);
-    // A lane's k of a chunk: part, part + PARTS, ... -- at most KC / PARTS = 16 of them.
-    constexpr int WG = KC / PARTS;
-    constexpr int XR = (KC / 4) * ROWS / 512;   // float4 per thread per chunk
-    static_assert(WG <= 16 && XR == 8, "register budget");
-    const float* slab = a.Wt + (long)blockIdx.x * a.K * CW;   // this workgroup's [K][CW] slab
-    const int xm = tid & (ROWS - 1), xp = tid >> 5;            // this thread's row of the tile and its K-part of it (16 parts)
-    float wn[WG];
-    float4 xn[XR];
-    // the epilogue's operands of this thread's output element (e = tid: row e / CW, column e % CW), requested now
+    const int T = (a.K + 15) >> 4;                         // steps of 16 k
+    const int S = T > wave ? (T - wave + NWV - 1) / NWV : 0;   // this wave's steps t = wave + 8 s
+    const f32x4* wt = reinterpret_cast<const f32x4*>(a.Wt) + (long)blockIdx.x * (4 * T) * CW;   // [4 T][16] float4
+    const float* x0 = a.x + (long)(m0 + min(r, rows - 1)) * a.ldx;
+    const float* x1 = a.x + (long)(m0 + min(16 + r, rows - 1)) * a.ldx;
+    // the epilogue's operands of this thread's output element (e = tid: row e / 16, column e % 16), requested now
     const int em = min(tid / CW, rows - 1), ec = tid % CW, en = min((int)blockIdx.x * CW + ec, a.N - 1);
     float e_bias = 0.f, e_res = 0.f;
-    {
-        const int kc = min(KC, a.K);
+
+    f32x4 xa[CH], xb[CH], wv[CH], lg[CH], lb[CH];
+    auto request = [&](int s0, f32x4 (&pa)[CH], f32x4 (&pb)[CH], f32x4 (&pw)[CH]) {
 #pragma unroll
-        for (int g = 0; g < WG; ++g) wn[g] = slab[(long)min(part + PARTS * g, kc - 1) * CW + col];
-#pragma unroll
-        for (int i = 0; i < XR; ++i) {
-            const int k4 = min(xp + 16 * i, (kc >> 2) - 1);
-            xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + min(xm, rows - 1)) * a.ldx + 4 * k4);
-        }
-        if (a.bias) e_bias = a.bias[en];
-        if (a.res) e_res = a.res[(long)(m0 + em) * a.ldr + en];
-    }
-    float ln_mean = 0.f, ln_rstd = 1.f;
-    if (a.ln_g) {   // (uniform) K <= KC: the whole row is in the 16 threads' registers
-        const int n4 = a.K >> 2;           // float4 per row
-        float s = 0.f;
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < XR; ++i)
-            if (xp + 16 * i < n4) {
-                s += (xn[i].x + xn[i].y) + (xn[i].z + xn[i].w);
-                cnt += 4;
+        for (int i = 0; i < CH; ++i) {
+            const bool ok = s0 + i < S;
+            const int t = ok ? wave + NWV * (s0 + i) : 0;
+            const int k0 = 16 * t + 4 * j;
+            const int kx = k0 < a.K ? k0 : 0;              // beyond K: any valid address (the packed weights are zero there)
+            pa[i] = *reinterpret_cast<const f32x4*>(x0 + kx);
+            pb[i] = *reinterpret_cast<const f32x4*>(x1 + kx);
+            pw[i] = wt[(4 * t + j) * CW + r];
+            if (LN && s0 == 0) {
+                lg[i] = *reinterpret_cast<const f32x4*>(a.ln_g + kx);
+                lb[i] = *reinterpret_cast<const f32x4*>(a.ln_b + kx);
             }
-        const float mu = cnt ? s / (float)cnt : 0.f;
-        float q = 0.f;
+        }
+    };
+    request(0, xa, xb, wv);
+    if (a.bias) e_bias = a.bias[en];
+    if (a.res) e_res = a.res[(long)(m0 + em) * a.ldr + en];
+
+    if (LN) {   // K <= 512: S <= 4, the whole of this wave's share is in xa / xb
+        float n = 0.f, s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < XR; ++i)
-            if (xp + 16 * i < n4) {
-                const float d0 = xn[i].x - mu, d1 = xn[i].y - mu, d2 = xn[i].z - mu, d3 = xn[i].w - mu;
-                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        for (int i = 0; i < CH; ++i)
+            if (i < S && 16 * (wave + NWV * i) + 4 * j < a.K) {
+                n += 4.f;
+                s0 += (xa[i][0] + xa[i][1]) + (xa[i][2] + xa[i][3]);
+                s1 += (xb[i][0] + xb[i][1]) + (xb[i][2] + xb[i][3]);
             }
-        stat[(xp * ROWS + xm) * 2] = mu;
-        stat[(xp * ROWS + xm) * 2 + 1] = q;
-        __syncthreads();
-        // merge the row's 16 partials (counts differ only when K is not a multiple of 64: weight them)
-        float tot = 0.f, msum = 0.f;
+        float mu0 = n > 0.f ? s0 / n : 0.f, mu1 = n > 0.f ? s1 / n : 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-            const int c4 = (n4 - pp + 15) / 16;   // float4 the partial pp holds
-            const float w = (float)(4 * max(c4, 0));
-            msum += w * stat[(pp * ROWS + xm) * 2];
-            tot += w;
-        }
-        ln_mean = msum / tot;
-        float m2 = 0.f;
+        for (int i = 0; i < CH; ++i)
+            if (i < S && 16 * (wave + NWV * i) + 4 * j < a.K) {
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-            const int c4 = (n4 - pp + 15) / 16;
-            const float w = (float)(4 * max(c4, 0));
-            const float d = stat[(pp * ROWS + xm) * 2] - ln_mean;
-            m2 += stat[(pp * ROWS + xm) * 2 + 1] + w * d * d;
-        }
-        ln_rstd = 1.0f / sqrtf(m2 / tot + a.ln_eps);
-    }
-    float acc[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < a.K; k0 += KC) {
-        const int kc = min(KC, a.K - k0);
-        float w[WG];
-#pragma unroll
-        for (int g = 0; g < WG; ++g) w[g] = wn[g];
-        if (k0 > 0) __syncthreads();   // the previous chunk is consumed
-        // stage x[m0 + m][k0 + 4 * k4 ..] -> xs[(4 * k4 + i) * 32 + m]
-#pragma unroll
-        for (int i = 0; i < XR; ++i) {
-            const int k4 = xp + 16 * i;
-            if (k4 < (kc >> 2)) {
-                float4 v = xn[i];
-                if (xm >= rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                else if (a.ln_g) {
-                    const float4 g = *reinterpret_cast<const float4*>(a.ln_g + k0 + 4 * k4);
-                    const float4 bb = *reinterpret_cast<const float4*>(a.ln_b + k0 + 4 * k4);
-                    v.x = (v.x - ln_mean) * ln_rstd * g.x + bb.x;
-                    v.y = (v.y - ln_mean) * ln_rstd * g.y + bb.y;
-                    v.z = (v.z - ln_mean) * ln_rstd * g.z + bb.z;
-                    v.w = (v.w - ln_mean) * ln_rstd * g.w + bb.w;
+                for (int c = 0; c < 4; ++c) {
+                    const float d0 = xa[i][c] - mu0, d1 = xb[i][c] - mu1;
+                    q0 = fmaf(d0, d0, q0);
+                    q1 = fmaf(d1, d1, q1);
                 }
-                float* d = xs + (4 * k4) * ROWS + xm;
-                d[0] = v.x;
-                d[ROWS] = v.y;
-                d[2 * ROWS] = v.z;
-                d[3 * ROWS] = v.w;
             }
+        // the wave's four lane groups (same row, different k): two shuffle steps
+        float n0 = n, n1 = n;
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float on = __shfl_xor(n0, off), om0 = __shfl_xor(mu0, off), oq0 = __shfl_xor(q0, off);
+            const float om1 = __shfl_xor(mu1, off), oq1 = __shfl_xor(q1, off);
+            // (both partners must merge in the same order to hold the same result: the lower lane group first)
+            const bool low = (lane & off) == 0;
+            float an = low ? n0 : on, am = low ? mu0 : om0, aq = low ? q0 : oq0;
+            rg_merge(an, am, aq, low ? on : n0, low ? om0 : mu0, low ? oq0 : q0);
+            float bn = low ? n1 : on, bm = low ? mu1 : om1, bq = low ? q1 : oq1;
+            rg_merge(bn, bm, bq, low ? on : n1, low ? om1 : mu1, low ? oq1 : q1);
+            n0 = an; mu0 = am; q0 = aq;
+            n1 = bn; mu1 = bm; q1 = bq;
+        }
+        if (j == 0) {
+            float* st0 = stat + (wave * ROWS + r) * 3;
+            float* st1 = stat + (wave * ROWS + 16 + r) * 3;
+            st0[0] = n0; st0[1] = mu0; st0[2] = q0;
+            st1[0] = n1; st1[1] = mu1; st1[2] = q1;
         }
         __syncthreads();
-        {
-            // the next chunk's operands; when there is none the clamps fold every load onto one cache line
-            const bool has_next = k0 + KC < a.K;
-            const int k0n = has_next ? k0 + KC : 0;
-            const int kcn = has_next ? min(KC, a.K - k0n) : 4;
-            const int mlim = has_next ? rows - 1 : 0;
+        float tn0 = 0.f, tm0 = 0.f, tq0 = 0.f, tn1 = 0.f, tm1 = 0.f, tq1 = 0.f;
 #pragma unroll
-            for (int g = 0; g < WG; ++g) wn[g] = slab[(long)(k0n + min(part + PARTS * g, kcn - 1)) * CW + col];
+        for (int w = 0; w < NWV; ++w) {
+            const float* st0 = stat + (w * ROWS + r) * 3;
+            const float* st1 = stat + (w * ROWS + 16 + r) * 3;
+            rg_merge(tn0, tm0, tq0, st0[0], st0[1], st0[2]);
+            rg_merge(tn1, tm1, tq1, st1[0], st1[1], st1[2]);
+        }
+        const float rs0 = 1.0f / sqrtf(tq0 / tn0 + a.ln_eps), rs1 = 1.0f / sqrtf(tq1 / tn1 + a.ln_eps);
 #pragma unroll
-            for (int i = 0; i < XR; ++i) {
-                const int k4 = min(xp + 16 * i, (kcn >> 2) - 1);
-                xn[i] = *reinterpret_cast<const float4*>(a.x + (long)(m0 + min(xm, mlim)) * a.ldx + k0n + 4 * k4);
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xa[i][c] = (xa[i][c] - tm0) * rs0 * lg[i][c] + lb[i][c];
+                xb[i][c] = (xb[i][c] - tm1) * rs1 * lg[i][c] + lb[i][c];
+            }
+    }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += CH) {
+        f32x4 na[CH], nb[CH], nw[CH];
+        const bool more = s0 + CH < S;   // (wave-uniform)
+        if (more) request(s0 + CH, na, nb, nw);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const bool ok = s0 + i < S;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float w = ok ? wv[i][c] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][c], w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i][c], w, acc1, 0, 0, 0);
             }
         }
+        if (more) {
 #pragma unroll
-        for (int g = 0; g < WG; ++g) {
-            const int kk = part + PARTS * g;
-            const int k = min(kk, kc - 1);
-            const float wv = kk < kc ? w[g] : 0.f;
-            const float4* xr = reinterpret_cast<const float4*>(xs + k * ROWS);
-#pragma unroll
-            for (int q = 0; q < ROWS / 4; ++q) {
-                const float4 xv = xr[q];
-                acc[4 * q + 0] = fmaf(xv.x, wv, acc[4 * q + 0]);
-                acc[4 * q + 1] = fmaf(xv.y, wv, acc[4 * q + 1]);
-                acc[4 * q + 2] = fmaf(xv.z, wv, acc[4 * q + 2]);
-                acc[4 * q + 3] = fmaf(xv.w, wv, acc[4 * q + 3]);
+            for (int i = 0; i < CH; ++i) {
+                xa[i] = na[i];
+                xb[i] = nb[i];
+                wv[i] = nw[i];
             }
         }
     }
+    // lane (r, j) holds rows 4 j + q (acc0) and 16 + 4 j + q (acc1) of column r
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) red[(part * ROWS + r) * CW + col] = acc[r];
+    for (int q = 0; q < 4; ++q) {
+        red[(wave * ROWS + 4 * j + q) * CW + r] = acc0[q];
+        red[(wave * ROWS + 16 + 4 * j + q) * CW + r] = acc1[q];
+    }
     __syncthreads();
     if (a.lstm_c) {
         // gates of this workgroup's 4 units for every row -> LDS, then one thread per (row, unit) finishes the cell
-        float* gl = xs;   // the activations are consumed: [32][16] gate pre-activations
-        for (int e = tid; e < ROWS * CW; e += 512) {
-            const int m = e / CW, c = e - m * CW;
+        {
+            const int m = tid / CW, c = tid - m * CW;
             const int nn = blockIdx.x * CW + c;
             float s = 0.f;
-#pragma unroll 8
-            for (int p = 0; p < PARTS; ++p) s += red[(p * ROWS + m) * CW + c];
+#pragma unroll
+            for (int p = 0; p < NWV; ++p) s += red[(p * ROWS + m) * CW + c];
             if (a.bias && nn < a.N) s += a.bias[nn];
-            gl[e] = s;
+            gl[tid] = s;
         }
         __syncthreads();
         if (tid < ROWS * 4) {
-            const int m = tid >> 2, j = tid & 3;
-            const int u = blockIdx.x * 4 + j;
+            const int m = tid >> 2, jj = tid & 3;
+            const int u = blockIdx.x * 4 + jj;
             if (m < rows && u < a.lstm_H) {
                 const float* g = gl + m * CW;
-                const float gi = rg_sigmoid(g[j]), gf = rg_sigmoid(g[4 + j]), gg = tanhf(g[8 + j]), go = rg_sigmoid(g[12 + j]);
+                const float gi = rg_sigmoid(g[jj]), gf = rg_sigmoid(g[4 + jj]), gg = tanhf(g[8 + jj]), go = rg_sigmoid(g[12 + jj]);
                 float* cp = a.lstm_c + (long)(m0 + m) * a.lstm_H + u;
                 const float cn = gf * *cp + gi * gg;
                 const float h = go * tanhf(cn);
@@ -207,13 +214,12 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
     }
     static_assert(ROWS * CW == 512, "one output element per thread");
     {
-        const int e = tid;
-        const int m = e / CW, c = e - m * CW;
+        const int m = tid / CW, c = tid - m * CW;
         const int nn = blockIdx.x * CW + c;
         if (m >= rows || nn >= a.N) return;
         float s = 0.f;
-#pragma unroll 8
-        for (int p = 0; p < PARTS; ++p) s += red[(p * ROWS + m) * CW + c];
+#pragma unroll
+        for (int p = 0; p < NWV; ++p) s += red[(p * ROWS + m) * CW + c];
         if (a.bias) s += e_bias;
         if (a.act == PK_ACT_RELU) s = fmaxf(s, 0.f);
         if (a.dropout) {
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
 
 int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) PK_FAIL(PK_EINVAL, "row GEMM: empty problem");
-    if (a.K % 8 != 0 || a.ldx % 4 != 0)
-        PK_FAIL(PK_EUNSUPPORTED, "row GEMM: K (%d) must be a multiple of 8 and ldx (%d) of 4", a.K, a.ldx);
+    if (a.K % 4 != 0 || a.ldx % 4 != 0)
+        PK_FAIL(PK_EUNSUPPORTED, "row GEMM: K (%d) and ldx (%d) must be multiples of 4", a.K, a.ldx);
     if (a.ln_g && (a.K > KC || !a.ln_b)) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: the LayerNorm prologue needs K <= %d", KC);
     if (a.act != PK_ACT_NONE && a.act != PK_ACT_RELU) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: activation %d", a.act);
     if (a.lstm_c && (a.N != 4 * a.lstm_H || a.lstm_H % 4 != 0 || a.act != PK_ACT_NONE || a.dropout || a.res || !a.lstm_h1 ||
@@ -240,7 +246,7 @@ int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args&
         PK_FAIL(PK_EINVAL, "row GEMM: LSTM epilogue needs N == 4 * H, H %% 4 == 0, two h destinations and no act / dropout / res");
     const int cw = pk_rowgemm_cw(a.N);
     dim3 grid((a.N + cw - 1) / cw, (a.M + ROWS - 1) / ROWS);
-    if (cw != 16) PK_FAIL(PK_EUNSUPPORTED, "row GEMM: only the 16-column tiling is built");
-    PK_LAUNCH(ctx, prof_name, k_rowgemm<16>, grid, dim3(512), 0, a);
+    if (a.ln_g) PK_LAUNCH(ctx, prof_name, k_rowgemm<true>, grid, dim3(512), 0, a);
+    else PK_LAUNCH(ctx, prof_name, k_rowgemm<false>, grid, dim3(512), 0, a);
     return PK_OK;
 }

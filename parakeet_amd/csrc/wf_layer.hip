@@ -453,8 +453,23 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     for (int c = 0; c < CL; ++c) wbuf[0][c * (NA * 64) + tid] = wpro[c];
                 }
             }
-            // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex
-            const int ex = __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(wave_max64(__uint_as_float(m_raw)))));   // (all sources are maxima: the repeats change nothing)
+            // its (clamped) biased exponent; the tile's operands are scaled by 2^kx, kx = 13 + 127 - ex.  (New prologue: behind the
+            // barrier -- it waits for the block maxima, and a role-B wave must reach the barrier without waiting for any load:
+            // its first answer arrives when the older waves' requests have been served, 10 k cycles into the launch.)
+            auto tile_exp = [&]() { return __builtin_amdgcn_readfirstlane(amax_exp(__float_as_uint(wave_max64(__uint_as_float(m_raw))))); };   // (all sources are maxima: the repeats change nothing)
+            int ex_ = 0;
+            if constexpr (!NEWPRO) ex_ = tile_exp();
+            stamp(1);
+            __syncthreads();
+            stamp(2);
+            if constexpr (NEWPRO) {
+                if (!role_a) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
+                }
+                ex_ = tile_exp();
+            }
+            const int ex = ex_;
             const int kx = PK_BLK_TOP + 127 - ex;
             const int ks1 = kx + (MULTI ? (&cold)[lz].k1 : a.l0.w.k1);
             const int cbb = __builtin_amdgcn_readfirstlane(__float_as_int(-1.4426950408889634f * pow2f(-ks1)));
@@ -468,15 +483,6 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-            stamp(1);
-            __syncthreads();
-            stamp(2);
-            if constexpr (NEWPRO) {
-                if (!role_a) {
-#pragma unroll
-                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
-                }
-            }
 #pragma unroll
             for (int g = 0; g < nslab; ++g) {
                 int tz = 0;

@@ -225,6 +225,8 @@ int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bou
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+v4f mfma_16x16x4_f32(float a, float b, v4f c);
 v16f mfma_32x32x2_f32(float a, float b, v16f c);
 v16f mfma_32x32x16_f16(v8h a, v8h b, v16f c);
 v16f mfma_32x32x16_bf16(v8bf a, v8bf b, v16f c);
@@ -299,5 +301,6 @@ static inline float hipemu_fmed3f(float a, float b, float c) { return std::max(s
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp(old, src, ctrl, rm, bm, bc)
 #define __builtin_amdgcn_cvt_pkrtz(a, b) hipemu::cvt_pkrtz(a, b)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2_f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu::mfma_32x32x16_f16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_32x32x16_bf16(a, b, c)

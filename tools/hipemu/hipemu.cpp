@@ -242,6 +242,22 @@ v16f mfma_32x32x2_f32(float a, float b, v16f c) {
     return mfma32<v1, 1>(va, vb, c);
 }
 
+// v_mfma_f32_16x16x4_f32: lane l holds A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16]; D[i = 4 (l / 16) + r][j = l % 16] in c[r]
+v4f mfma_16x16x4_f32(float a, float b, v4f c) {
+    struct AB {
+        float a, b;
+    } mine{a, b};
+    const int p = exchange(mine);
+    const int l = cur->lane, col = l & 15, blk = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * blk + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc += peek<AB>(p, row + 16 * k).a * peek<AB>(p, col + 16 * k).b;
+        c[r] = acc;
+    }
+    return c;
+}
+
 v2fp16 cvt_pkrtz(float a, float b) {   // fp32 -> fp16, round toward zero, saturating at the largest finite value
     auto one = [](float x) -> unsigned short {
         unsigned u;
