@@ -27,17 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-// Chan's merge of two (count, mean, M2) partials
-__device__ __forceinline__ void rg_merge(float& n, float& mu, float& m2, float nb, float mub, float m2b) {
-    const float nt = n + nb;
-    if (nt > 0.f) {
-        const float d = mub - mu, f = nb / nt;
-        mu += d * f;
-        m2 += m2b + d * d * n * f;
-    }
-    n = nt;
-}
-
 // One workgroup = 16 output columns x up to 32 rows, 8 waves; the K range is dealt out in steps of 16 k, wave w takes the steps
 // w, w + 8, ...  Latency is everything here (32 rows: a launch is 10 - 40 MFLOP), and round 4's rocprof / HIP-event figures put
 // the previous kernel (activations transposed into LDS, one fp32 FMA per LDS-broadcast operand) at 10 - 20 us per launch with
@@ -49,14 +38,14 @@ __device__ __forceinline__ void rg_merge(float& n, float& mu, float& m2, float n
 // instruction's operands (the k of lane group j in instruction c is 16 t + 4 j + c for A and B alike).  Everything a wave
 // needs for 4 steps (12 float4 per lane, + LayerNorm weight and bias) is requested at once, the next 4 steps before the
 // arithmetic of these; the 8 waves' partial tiles are summed through 16 KB of LDS in wave order (deterministic).
-//   Optional prologue: LayerNorm over K <= 512 (each lane's 16 values of its two rows -> (count, mean, M2), merged over the
-//   wave's four lane groups by shuffles and over the waves through LDS with Chan's formula), applied in registers.
+//   Optional prologue: LayerNorm over K <= 512: mean and squared deviations of each lane's 16 values of its two rows, summed
+//   over the wave's four lane groups by shuffles and over the waves through LDS (two passes over the registers), applied there.
 //   Epilogues: bias, ReLU, dropout, residual; or the LSTM cell (see pk_rowgemm.h).
 template <bool LN>
 __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
     constexpr int NWV = 8, CH = 4, CW = 16;
     __shared__ float red[NWV * ROWS * CW];     // red[(wave * 32 + m) * 16 + col], 16 KB
-    __shared__ float stat[NWV * ROWS * 3];     // LayerNorm: (count, mean, M2) of every wave's share of every row
+    __shared__ float stat[2 * NWV * ROWS];     // LayerNorm: every wave's partial sums of every row (sums | squared deviations)
     __shared__ float gl[ROWS * CW];            // LSTM epilogue: the gate pre-activations
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,56 +83,53 @@ __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
     if (a.res) e_res = a.res[(long)(m0 + em) * a.ldr + en];
 
     if (LN) {   // K <= 512: S <= 4, the whole of this wave's share is in xa / xb
-        float n = 0.f, s0 = 0.f, s1 = 0.f;
+        // two passes over the registers (mean, then the squared deviations), each reduced over the wave's four lane groups by
+        // shuffles and over the eight waves through LDS in wave order.  (First version: one pass with Chan's merge of (count,
+        // mean, M2) partials -- 29 divisions and 35 branches in a dependent chain, 3 us of a 9 us launch.)
+        const float inv_k = 1.0f / (float)a.K;
+        auto reduce_rows = [&](float v0, float v1, float* buf, float& t0, float& t1) {
+            v0 += __shfl_xor(v0, 16);
+            v1 += __shfl_xor(v1, 16);
+            v0 += __shfl_xor(v0, 32);
+            v1 += __shfl_xor(v1, 32);
+            if (j == 0) {
+                buf[wave * ROWS + r] = v0;
+                buf[wave * ROWS + 16 + r] = v1;
+            }
+            __syncthreads();
+            t0 = 0.f;
+            t1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) {
+                t0 += buf[w * ROWS + r];
+                t1 += buf[w * ROWS + 16 + r];
+            }
+        };
+        bool okk[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) okk[i] = i < S && 16 * (wave + NWV * i) + 4 * j < a.K;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            s0 += okk[i] ? (xa[i][0] + xa[i][1]) + (xa[i][2] + xa[i][3]) : 0.f;
+            s1 += okk[i] ? (xb[i][0] + xb[i][1]) + (xb[i][2] + xb[i][3]) : 0.f;
+        }
+        float tm0, tm1;
+        reduce_rows(s0, s1, stat, tm0, tm1);
+        tm0 *= inv_k;
+        tm1 *= inv_k;
+        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
         for (int i = 0; i < CH; ++i)
-            if (i < S && 16 * (wave + NWV * i) + 4 * j < a.K) {
-                n += 4.f;
-                s0 += (xa[i][0] + xa[i][1]) + (xa[i][2] + xa[i][3]);
-                s1 += (xb[i][0] + xb[i][1]) + (xb[i][2] + xb[i][3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = xa[i][c] - tm0, d1 = xb[i][c] - tm1;
+                q0 += okk[i] ? d0 * d0 : 0.f;
+                q1 += okk[i] ? d1 * d1 : 0.f;
             }
-        float mu0 = n > 0.f ? s0 / n : 0.f, mu1 = n > 0.f ? s1 / n : 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (i < S && 16 * (wave + NWV * i) + 4 * j < a.K) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float d0 = xa[i][c] - mu0, d1 = xb[i][c] - mu1;
-                    q0 = fmaf(d0, d0, q0);
-                    q1 = fmaf(d1, d1, q1);
-                }
-            }
-        // the wave's four lane groups (same row, different k): two shuffle steps
-        float n0 = n, n1 = n;
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float on = __shfl_xor(n0, off), om0 = __shfl_xor(mu0, off), oq0 = __shfl_xor(q0, off);
-            const float om1 = __shfl_xor(mu1, off), oq1 = __shfl_xor(q1, off);
-            // (both partners must merge in the same order to hold the same result: the lower lane group first)
-            const bool low = (lane & off) == 0;
-            float an = low ? n0 : on, am = low ? mu0 : om0, aq = low ? q0 : oq0;
-            rg_merge(an, am, aq, low ? on : n0, low ? om0 : mu0, low ? oq0 : q0);
-            float bn = low ? n1 : on, bm = low ? mu1 : om1, bq = low ? q1 : oq1;
-            rg_merge(bn, bm, bq, low ? on : n1, low ? om1 : mu1, low ? oq1 : q1);
-            n0 = an; mu0 = am; q0 = aq;
-            n1 = bn; mu1 = bm; q1 = bq;
-        }
-        if (j == 0) {
-            float* st0 = stat + (wave * ROWS + r) * 3;
-            float* st1 = stat + (wave * ROWS + 16 + r) * 3;
-            st0[0] = n0; st0[1] = mu0; st0[2] = q0;
-            st1[0] = n1; st1[1] = mu1; st1[2] = q1;
-        }
-        __syncthreads();
-        float tn0 = 0.f, tm0 = 0.f, tq0 = 0.f, tn1 = 0.f, tm1 = 0.f, tq1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) {
-            const float* st0 = stat + (w * ROWS + r) * 3;
-            const float* st1 = stat + (w * ROWS + 16 + r) * 3;
-            rg_merge(tn0, tm0, tq0, st0[0], st0[1], st0[2]);
-            rg_merge(tn1, tm1, tq1, st1[0], st1[1], st1[2]);
-        }
-        const float rs0 = 1.0f / sqrtf(tq0 / tn0 + a.ln_eps), rs1 = 1.0f / sqrtf(tq1 / tn1 + a.ln_eps);
+        float tq0, tq1;
+        reduce_rows(q0, q1, stat + NWV * ROWS, tq0, tq1);
+        const float rs0 = 1.0f / sqrtf(tq0 * inv_k + a.ln_eps), rs1 = 1.0f / sqrtf(tq1 * inv_k + a.ln_eps);
 #pragma unroll
         for (int i = 0; i < CH; ++i)
 #pragma unroll

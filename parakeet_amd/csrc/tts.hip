@@ -234,6 +234,89 @@ __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
     }
 }
 
+// The same step for 64-wide heads (the LJSpeech recipe: adim 512, 8 heads) and at most 16 NB keys, ONE trip to memory for the
+// keys and one for the values (round 4: the general kernel above walks the keys in passes of 256 and the values 16 deep --
+// seven dependent round trips at 640 keys, 21 us per launch of which 3 are the gap between two launches).  Thread (g = tid / 16,
+// sub = tid % 16) owns float4 column sub of the key AND value rows g, g + 16, ...: all NB key loads are requested at once, the
+// dot products are summed over the row's 16 lanes by DPP rotations (every lane of the group ends up with the score), the value
+// loads are requested before the maximum is exchanged, the probabilities never leave the registers, and the partial contexts
+// of the 16 groups and the wave sums of the normaliser cross one barrier together (two barriers in all).
+template <int CTRL>
+__device__ __forceinline__ float tts_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int NB>
+__global__ __launch_bounds__(256) void k_tts_attn_step64(AttnStep a) {
+    __shared__ __attribute__((aligned(16))) float red[16 * 64];
+    __shared__ float wmax[4], wsum[4];
+    const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, g = tid >> 4;
+    const int n = a.klen ? a.klen[b] : a.n;
+    const long base = a.kbase ? a.kbase[b] : b;
+    float4 q4 = reinterpret_cast<const float4*>(a.q + (long)b * a.ldq + head * 64)[sub];
+    const long rs = (long)a.kstride * a.ldkv;
+    const float* kp = a.K + base * a.ldkv + head * 64 + 4 * sub;
+    const float* vp = a.V + base * a.ldkv + head * 64 + 4 * sub;
+    float4 kv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) kv[u] = *reinterpret_cast<const float4*>(kp + (long)min(16 * u + g, n - 1) * rs);
+    q4.x *= a.scale; q4.y *= a.scale; q4.z *= a.scale; q4.w *= a.scale;
+    float sc[NB];
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        float t = fmaf(kv[u].x, q4.x, fmaf(kv[u].y, q4.y, fmaf(kv[u].z, q4.z, kv[u].w * q4.w)));
+        t = tts_dpp_add<0x128>(t);   // row_ror:8, 4, 2, 1: the sum of the row's 16 lanes in every one of them
+        t = tts_dpp_add<0x124>(t);
+        t = tts_dpp_add<0x122>(t);
+        t = tts_dpp_add<0x121>(t);
+        sc[u] = 16 * u + g < n ? t : -INFINITY;
+        m = fmaxf(m, sc[u]);
+    }
+    float4 vv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) vv[u] = *reinterpret_cast<const float4*>(vp + (long)min(16 * u + g, n - 1) * rs);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    float sum = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const float p = expf(sc[u] - m);   // (keys beyond n: exp(-inf) = 0)
+        sc[u] = p;
+        sum += p;
+        acc.x = fmaf(p, vv[u].x, acc.x);
+        acc.y = fmaf(p, vv[u].y, acc.y);
+        acc.z = fmaf(p, vv[u].z, acc.z);
+        acc.w = fmaf(p, vv[u].w, acc.w);
+    }
+    sum += __shfl_xor(sum, 16);   // (the 16 lanes of a row hold the same values: lane 0 sums its wave's four rows)
+    sum += __shfl_xor(sum, 32);
+    if (lane == 0) wsum[wave] = sum;
+    *reinterpret_cast<float4*>(red + g * 64 + 4 * sub) = acc;
+    __syncthreads();
+    const float inv = 1.f / ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    if (tid < 64) {
+        float o = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) o += red[gg * 64 + tid];
+        a.out[(long)b * a.ldo + head * 64 + tid] = o * inv;
+    }
+    if (a.att) {
+        const int cap = a.att_cap[b];
+        if (a.step < cap && sub == 0) {
+            float* ap = a.att + a.att_off[b] + (((long)a.layer * gridDim.x + head) * cap + a.step) * n;
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                if (16 * u + g < n) ap[16 * u + g] = sc[u] * inv;
+        }
+    }
+}
+
+
 // prob_out + sigmoid + the stop rule of :638-642, one wave per utterance.  len[b] == 0 while utterance b runs.
 // ln_g != NULL: z is the decoder's last row BEFORE after_norm, and the LayerNorm (eps 1e-5, two-pass in the wave) happens here --
 // the feat_out row GEMM normalises the same row in its own prologue, so after_norm needs no launch of its own (A <= 1024).
@@ -810,6 +893,15 @@ constexpr int SLACK = 2 * PK_GEMM_BM;   // rows a GEMM tile may read beyond the 
 int rows_reserve(pk_dbuf& buf, long rows, int C) { return pk_fft_act_reserve(buf, (int)(rows + SLACK), C); }
 
 int attn_step(pk_tts* h, const char* name, const AttnStep& a, int heads, int B, int nmax) {
+    if (a.dk == 64 && nmax <= 640 && a.ldkv % 4 == 0 && a.ldq % 4 == 0) {   // (keys beyond 640: the general kernel)
+        const int nb = (nmax + 15) / 16;
+        if (nb <= 8) PK_LAUNCH(h->ctx, name, k_tts_attn_step64<8>, dim3(heads, B), dim3(256), 0, a);
+        else if (nb <= 16) PK_LAUNCH(h->ctx, name, k_tts_attn_step64<16>, dim3(heads, B), dim3(256), 0, a);
+        else if (nb <= 24) PK_LAUNCH(h->ctx, name, k_tts_attn_step64<24>, dim3(heads, B), dim3(256), 0, a);
+        else if (nb <= 32) PK_LAUNCH(h->ctx, name, k_tts_attn_step64<32>, dim3(heads, B), dim3(256), 0, a);
+        else PK_LAUNCH(h->ctx, name, k_tts_attn_step64<40>, dim3(heads, B), dim3(256), 0, a);
+        return PK_OK;
+    }
     const size_t smem = (size_t)(a.dk + 1032 + nmax + 4) * sizeof(float);
     if (smem > 60 * 1024) PK_FAIL(PK_EUNSUPPORTED, "TransformerTTS: %d attention keys exceed the step kernel's LDS budget", nmax);
     PK_LAUNCH(h->ctx, name, k_tts_attn_step, dim3(heads, B), dim3(256), smem, a);
