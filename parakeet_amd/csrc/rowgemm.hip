@@ -41,8 +41,61 @@ __device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + expf(
 //   Optional prologue: LayerNorm over K <= 512: mean and squared deviations of each lane's 16 values of its two rows, summed
 //   over the wave's four lane groups by shuffles and over the waves through LDS (two passes over the registers), applied there.
 //   Epilogues: bias, ReLU, dropout, residual; or the LSTM cell (see pk_rowgemm.h).
+// The stop-token head (pk_rowgemm.h): one wave per row, 16 values per lane (K <= 1024); the arithmetic of the kernel the
+// decoders used to launch for it.
+__device__ __forceinline__ void rg_stop_block(const pk_rowgemm_args& a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < a.M; b += 8) {
+        const float* z = a.x + (long)b * a.ldx;
+        float s = 0.f;
+        if (a.ln_g) {
+            float v[16];
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = lane + 64 * e;
+                v[e] = c < a.K ? z[c] : 0.f;
+                t += v[e];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            const float mean = t / (float)a.K;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = lane + 64 * e < a.K ? v[e] - mean : 0.f;
+                q += d * d;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = 1.0f / sqrtf(q / (float)a.K + a.ln_eps);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = lane + 64 * e;
+                if (c < a.K) s = fmaf((v[e] - mean) * rstd * a.ln_g[c] + a.ln_b[c], a.stop_w[c], s);
+            }
+        } else {
+            for (int c = lane; c < a.K; c += 64) s = fmaf(z[c], a.stop_w[c], s);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const float p = 1.f / (1.f + expf(-(s + a.stop_bias)));
+            a.stop_probs[(long)(a.stop_step - 1) * a.M + b] = p;
+            if (a.stop_len[b] == 0 && (p >= a.stop_thr || a.stop_step >= a.stop_maxlen[b]) && a.stop_step >= a.stop_minlen[b]) {
+                a.stop_len[b] = a.stop_step;
+                atomicAdd(a.stop_ndone, 1);
+            }
+        }
+    }
+}
+
 template <bool LN>
 __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
+    if (a.stop_w && blockIdx.x == gridDim.x - 1) {   // (block-uniform: the extra workgroup of the launch)
+        rg_stop_block(a);
+        return;
+    }
     constexpr int NWV = 8, CH = 4, CW = 16;
     __shared__ float red[NWV * ROWS * CW];     // red[(wave * 32 + m) * 16 + col], 16 KB
     __shared__ float stat[2 * NWV * ROWS];     // LayerNorm: every wave's partial sums of every row (sums | squared deviations)
@@ -231,7 +284,9 @@ int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args&
                      !a.lstm_h2))
         PK_FAIL(PK_EINVAL, "row GEMM: LSTM epilogue needs N == 4 * H, H %% 4 == 0, two h destinations and no act / dropout / res");
     const int cw = pk_rowgemm_cw(a.N);
-    dim3 grid((a.N + cw - 1) / cw, (a.M + ROWS - 1) / ROWS);
+    if (a.stop_w && (a.M > ROWS || a.K > 1024 || !a.stop_probs || !a.stop_len || !a.stop_ndone || !a.stop_minlen || !a.stop_maxlen))
+        PK_FAIL(PK_EINVAL, "row GEMM: the stop-token head needs M <= %d, K <= 1024 and its five arrays", ROWS);
+    dim3 grid((a.N + cw - 1) / cw + (a.stop_w ? 1 : 0), (a.M + ROWS - 1) / ROWS);
     if (a.ln_g) PK_LAUNCH(ctx, prof_name, k_rowgemm<true>, grid, dim3(512), 0, a);
     else PK_LAUNCH(ctx, prof_name, k_rowgemm<false>, grid, dim3(512), 0, a);
     return PK_OK;

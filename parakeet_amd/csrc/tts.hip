@@ -110,6 +110,15 @@ struct AttnStep {
     const long* att_off;  // per utterance offset (floats) of its (layers, heads, cap_b, T_b) block
     const int* att_cap;   // per utterance cap_b
     int layer, step;      // step counted from 0
+    // k_tts_attn_step64<NB, true>: the query is not read but PROJECTED here -- q[b] = LN?(qx[b]) . W[:, head's 64 columns] + bias
+    // (W as pk_rowgemm_pack tiles, K = qK <= 512): the encoder-decoder attention's linear_q without a launch of its own
+    const float* qx = nullptr;
+    int ldqx = 0, qK = 0;
+    const float* qW = nullptr;
+    const float* qb = nullptr;
+    const float* q_ln_g = nullptr;
+    const float* q_ln_b = nullptr;
+    float q_eps = 1e-5f;
 };
 
 __global__ __launch_bounds__(256) void k_tts_attn_step(AttnStep a) {
@@ -245,22 +254,85 @@ template <int CTRL>
 __device__ __forceinline__ float tts_dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
-template <int NB>
+// QP: the query is projected in the kernel (AttnStep::qx ...): thread (c = tid % 64, part = tid / 64) owns output column c and a
+// quarter of K -- its 32 float4 of the packed weights are requested with the key loads, the row is normalised by wave 0 (8 values
+// per lane, two-pass statistics by shuffles) into LDS, and the four partial dot products meet in LDS: three barriers and
+// 128 KB of L2-resident weights per workgroup instead of a row-GEMM launch (9 us of the decoder's per-layer chain).
+template <int NB, bool QP = false>
 __global__ __launch_bounds__(256) void k_tts_attn_step64(AttnStep a) {
     __shared__ __attribute__((aligned(16))) float red[16 * 64];
     __shared__ float wmax[4], wsum[4];
+    __shared__ __attribute__((aligned(16))) float xs[QP ? 512 : 4];
+    __shared__ __attribute__((aligned(16))) float qs[64];
     const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, g = tid >> 4;
     const int n = a.klen ? a.klen[b] : a.n;
     const long base = a.kbase ? a.kbase[b] : b;
-    float4 q4 = reinterpret_cast<const float4*>(a.q + (long)b * a.ldq + head * 64)[sub];
+    float4 q4;
+    if (!QP) q4 = reinterpret_cast<const float4*>(a.q + (long)b * a.ldq + head * 64)[sub];
     const long rs = (long)a.kstride * a.ldkv;
     const float* kp = a.K + base * a.ldkv + head * 64 + 4 * sub;
     const float* vp = a.V + base * a.ldkv + head * 64 + 4 * sub;
     float4 kv[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) kv[u] = *reinterpret_cast<const float4*>(kp + (long)min(16 * u + g, n - 1) * rs);
-    q4.x *= a.scale; q4.y *= a.scale; q4.z *= a.scale; q4.w *= a.scale;
+    if (QP) {
+        const int K = a.qK, K4 = ((K + 15) / 16) * 4;   // float4 rows of a packed 16-column tile (K padded to 16)
+        const int c = tid & 63, part = tid >> 6;
+        // weights of column c: tile (head * 64 + c) / 16, column c % 16; this thread's k-quads part * 32 .. + 31 (clamped: zeros
+        // beyond K in the pack, and the row is zero there too)
+        const float4* wq = reinterpret_cast<const float4*>(a.qW) + ((long)(head * 4 + (c >> 4)) * K4) * 16 + (c & 15);
+        float4 w4[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) w4[i] = wq[(long)min(part * 32 + i, K4 - 1) * 16];
+        const float qbias = a.qb ? a.qb[head * 64 + c] : 0.f;
+        if (wave == 0) {   // the row, normalised: lane l holds x[8 l .. 8 l + 7]
+            const float* xr = a.qx + (long)b * a.ldqx;
+            float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+            if (8 * lane < K) x0 = *reinterpret_cast<const float4*>(xr + 8 * lane);
+            if (8 * lane + 4 < K) x1 = *reinterpret_cast<const float4*>(xr + 8 * lane + 4);
+            if (a.q_ln_g) {
+                float t = ((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                const float mean = t / (float)K;
+                const bool in0 = 8 * lane < K, in1 = 8 * lane + 4 < K;
+                float d, qq = 0.f;
+                d = x0.x - mean; qq += in0 ? d * d : 0.f;  d = x0.y - mean; qq += in0 ? d * d : 0.f;
+                d = x0.z - mean; qq += in0 ? d * d : 0.f;  d = x0.w - mean; qq += in0 ? d * d : 0.f;
+                d = x1.x - mean; qq += in1 ? d * d : 0.f;  d = x1.y - mean; qq += in1 ? d * d : 0.f;
+                d = x1.z - mean; qq += in1 ? d * d : 0.f;  d = x1.w - mean; qq += in1 ? d * d : 0.f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o);
+                const float rstd = 1.0f / sqrtf(qq / (float)K + a.q_eps);
+                float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, b0 = g0, b1 = g0;
+                if (in0) { g0 = *reinterpret_cast<const float4*>(a.q_ln_g + 8 * lane); b0 = *reinterpret_cast<const float4*>(a.q_ln_b + 8 * lane); }
+                if (in1) { g1 = *reinterpret_cast<const float4*>(a.q_ln_g + 8 * lane + 4); b1 = *reinterpret_cast<const float4*>(a.q_ln_b + 8 * lane + 4); }
+                x0.x = in0 ? (x0.x - mean) * rstd * g0.x + b0.x : 0.f;  x0.y = in0 ? (x0.y - mean) * rstd * g0.y + b0.y : 0.f;
+                x0.z = in0 ? (x0.z - mean) * rstd * g0.z + b0.z : 0.f;  x0.w = in0 ? (x0.w - mean) * rstd * g0.w + b0.w : 0.f;
+                x1.x = in1 ? (x1.x - mean) * rstd * g1.x + b1.x : 0.f;  x1.y = in1 ? (x1.y - mean) * rstd * g1.y + b1.y : 0.f;
+                x1.z = in1 ? (x1.z - mean) * rstd * g1.z + b1.z : 0.f;  x1.w = in1 ? (x1.w - mean) * rstd * g1.w + b1.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(xs + 8 * lane) = x0;
+            *reinterpret_cast<float4*>(xs + 8 * lane + 4) = x1;
+        }
+        __syncthreads();
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int kq = part * 32 + i;   // k = 4 kq .. 4 kq + 3 (xs is zero beyond K: 512 slots, K <= 512)
+            const float4 xv = *reinterpret_cast<const float4*>(xs + 4 * min(kq, 127));
+            const float t = fmaf(w4[i].x, xv.x, fmaf(w4[i].y, xv.y, fmaf(w4[i].z, xv.z, w4[i].w * xv.w)));
+            acc += kq < K4 ? t : 0.f;
+        }
+        red[part * 64 + c] = acc;
+        __syncthreads();
+        if (tid < 64) qs[tid] = (((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid] + qbias) * a.scale;
+        __syncthreads();
+        q4 = *reinterpret_cast<const float4*>(qs + 4 * sub);
+    } else {
+        q4.x *= a.scale; q4.y *= a.scale; q4.z *= a.scale; q4.w *= a.scale;
+    }
     float sc[NB];
     float m = -INFINITY;
 #pragma unroll
@@ -439,6 +511,7 @@ struct pk_tts : pk_fft_core {
     bool kv_prefix = false;            // "kv_prefix" option (pk_tts_set_option), see pk_tts_infer
     bool overlap_prefix = true;        // "overlap_prefix": the NEXT step's prefix work (prenet .. layer-0 q|k|v of the rows that
                                        // exist already) on a side stream under this step's layer chain, see pk_tts_infer
+    bool fuse_src_q = true;            // "fuse_src_q": the encoder-decoder attention projects its query itself (k_tts_attn_step64<8, true>)
     int side_cu_mask = 1;              // "overlap_cu_mask": 1 = the side stream runs on every other CU, 0 = an unmasked low-priority stream
     hipStream_t own_main = nullptr;    // the decoding loop's own stream (see pk_tts_infer), ordered against the caller's by ev_io
     hipEvent_t ev_io = nullptr;
@@ -591,6 +664,10 @@ extern "C" int pk_tts_set_option(pk_tts* h, const char* key, int64_t value) {
     }
     if (strcmp(key, "overlap_prefix") == 0) {
         h->overlap_prefix = value != 0;
+        return PK_OK;
+    }
+    if (strcmp(key, "fuse_src_q") == 0) {
+        h->fuse_src_q = value != 0;
         return PK_OK;
     }
     if (strcmp(key, "overlap_cu_mask") == 0) {   // (takes effect when the side stream is created: before the first inference)
@@ -893,6 +970,10 @@ constexpr int SLACK = 2 * PK_GEMM_BM;   // rows a GEMM tile may read beyond the 
 int rows_reserve(pk_dbuf& buf, long rows, int C) { return pk_fft_act_reserve(buf, (int)(rows + SLACK), C); }
 
 int attn_step(pk_tts* h, const char* name, const AttnStep& a, int heads, int B, int nmax) {
+    if (a.qx) {   // the query projected in the kernel: 64-wide heads, at most 128 keys, K <= 512 (the callers check)
+        PK_LAUNCH(h->ctx, name, (k_tts_attn_step64<8, true>), dim3(heads, B), dim3(256), 0, a);
+        return PK_OK;
+    }
     if (a.dk == 64 && nmax <= 640 && a.ldkv % 4 == 0 && a.ldq % 4 == 0) {   // (keys beyond 640: the general kernel)
         const int nb = (nmax + 15) / 16;
         if (nb <= 8) PK_LAUNCH(h->ctx, name, k_tts_attn_step64<8>, dim3(heads, B), dim3(256), 0, a);
@@ -1404,8 +1485,18 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
                 // x = residual + self_attn(...) (decoder_layer.py:127-128); x = residual + src_attn(norm2(x), memory)
                 // (:132-141); x = residual + feed_forward(norm3(x)) (:145-148) -> the layer's cached output row
                 PK_TRY(rowgemm("tts_row_attn_out", L.r_out, rc, A, rx, A, PK_ACT_NONE, xin, A, 0, 0, false));
-                PK_TRY(rowgemm("tts_row_src_q", L.r_src_q, rx, A, rq, A, PK_ACT_NONE, nullptr, 0, L.ln2_g, L.ln2_b, true));
-                PK_TRY(attn_step(h, "tts_attn_src", a2, H, B, maxT));
+                if (h->fuse_src_q && dk == 64 && maxT <= 128 && A <= 512 && A % 8 == 0) {
+                    // linear_q of the encoder-decoder attention (norm2 in its prologue) inside the attention kernel
+                    a2.q = nullptr;
+                    a2.qx = rx; a2.ldqx = A; a2.qK = A;
+                    a2.qW = h->W(L.r_src_q.w);
+                    a2.qb = L.r_src_q.b == (size_t)-1 ? nullptr : h->W(L.r_src_q.b);
+                    a2.q_ln_g = h->W(L.ln2_g); a2.q_ln_b = h->W(L.ln2_b);
+                    PK_TRY(attn_step(h, "tts_attn_src_q", a2, H, B, maxT));
+                } else {
+                    PK_TRY(rowgemm("tts_row_src_q", L.r_src_q, rx, A, rq, A, PK_ACT_NONE, nullptr, 0, L.ln2_g, L.ln2_b, true));
+                    PK_TRY(attn_step(h, "tts_attn_src", a2, H, B, maxT));
+                }
                 PK_TRY(rowgemm("tts_row_src_out", L.r_src_out, rc, A, rx, A, PK_ACT_NONE, rx, A, 0, 0, false));
                 PK_TRY(rowgemm("tts_row_ffn1", L.r_ffn1, rx, A, rf, c.dunits, PK_ACT_RELU, nullptr, 0, L.ln3_g, L.ln3_b, true));
                 PK_TRY(rowgemm("tts_row_ffn2", L.r_ffn2, rf, c.dunits, xc_new, A, PK_ACT_NONE, rx, A, 0, 0, false));
@@ -1427,7 +1518,17 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         // GEMM and of the stop kernel (two launches instead of three); otherwise rz = the normalised row first.
         const float* xlast = pk_fft_act_ptr(h->d_xc_l[c.dlayers - 1], A) + nr * A;
         const bool fuse_after = !post && use_rg && RF == 1 && A <= 1024 && A <= PK_RG_KC;
-        if (fuse_after) {
+        if (fuse_after && B <= PK_RG_ROWS) {
+            // (one launch: the stop-token head rides on the feat_out row GEMM as an extra workgroup, pk_rowgemm.h)
+            const RowW& w = h->r_feat_out;
+            pk_rowgemm_args g;
+            g.x = xlast; g.ldx = A; g.Wt = h->W(w.w); g.bias = w.b == (size_t)-1 ? nullptr : h->W(w.b); g.y = Y + (long)s * B * OR; g.ldy = OR;
+            g.M = B; g.K = w.K; g.N = w.N; g.act = PK_ACT_NONE;
+            g.ln_g = h->W(h->dec_after_g); g.ln_b = h->W(h->dec_after_b);
+            g.stop_w = h->W(h->prob_w); g.stop_bias = h->prob_b; g.stop_thr = (float)threshold; g.stop_step = s;
+            g.stop_minlen = d_minlen; g.stop_maxlen = d_maxlen; g.stop_probs = h->d_probs.as<float>(); g.stop_len = d_len; g.stop_ndone = d_ndone;
+            PK_TRY(pk_rowgemm_launch(ctx, "tts_row_feat_out_stop", g));
+        } else if (fuse_after) {
             PK_TRY(rowgemm("tts_row_feat_out", h->r_feat_out, xlast, A, Y + (long)s * B * OR, OR, PK_ACT_NONE, nullptr, 0, h->dec_after_g,
                            h->dec_after_b, true));
             PK_LAUNCH(ctx, "tts_stop", k_tts_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, xlast, A, h->W(h->prob_w), h->prob_b, B, s,

@@ -231,3 +231,29 @@ def test_kv_only_prefix_projection_experiment():
         assert np.abs(wa.numpy() - wb.numpy()).max() < 1e-5
     ref = tt.inference(state, texts[0], cfg, maxlenratio=2.0, seed=1, dtype=torch.float64)[0].numpy()
     assert _close(alt[0][0].numpy(), ref)
+
+
+def test_query_projection_inside_the_source_attention():
+    """Option "fuse_src_q" (default on; 64-wide heads, <= 128 memory rows): norm2 + linear_q of the encoder-decoder attention are
+    computed inside the step's attention kernel instead of a row GEMM of their own.  Same spectrogram, stop probabilities and
+    attention weights up to summation order, on a ragged batch; the fused path is the one that ran."""
+    from parakeet_amd.runtime import Context
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH, elayers=1, dlayers=2, postnet_layers=2)
+    state = syn.transformer_tts_state(40, 80, cfg, seed=91, stop_bias=-6.0)
+    m = _model(cfg, 40, state)
+    texts = [syn.phoneme_ids(T, idim=40, seed=900 + T) for T in (7, 3, 5)]
+    ctx = Context.get()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    fused = m.inference_batch(texts, maxlenratio=2.0, seeds=[1, 2, 3])
+    names = {k for k, (n, _) in ctx.prof_dump().items() if n > 0}
+    ctx.prof_enable(False)
+    assert "tts_attn_src_q" in names and "tts_row_src_q" not in names and "tts_row_feat_out_stop" in names
+    m.set_option("fuse_src_q", 0)
+    plain = m.inference_batch(texts, maxlenratio=2.0, seeds=[1, 2, 3])
+    for (a, pa, wa), (b, pb, wb) in zip(fused, plain):
+        assert a.shape == b.shape and np.abs(a.numpy() - b.numpy()).max() < 2e-4
+        assert np.abs(pa.numpy() - pb.numpy()).max() < 1e-5
+        assert np.abs(wa.numpy() - wb.numpy()).max() < 1e-5
+    ref = tt.inference(state, texts[0], cfg, maxlenratio=2.0, seed=1, dtype=torch.float64)[0].numpy()
+    assert _close(fused[0][0].numpy(), ref)
