@@ -64,7 +64,7 @@ struct pk_rowgemm_args {
     unsigned drop_thr = 0;
     float drop_scale = 1.f;
     // Stop-token head riding on the launch (stop_w != NULL; the autoregressive decoders' prob_out, transformer_tts.py:638-642):
-    // ONE more workgroup computes, for every row m, p = sigmoid(LN?(x[m]) . stop_w + stop_bias) (the same LayerNorm prologue as
+    // a few more workgroups (a wave per row) compute, for every row m, p = sigmoid(LN?(x[m]) . stop_w + stop_bias) (the same LayerNorm prologue as
     // the GEMM when ln_g is set, K <= 1024), stores it at stop_probs[(stop_step - 1) * M + m] and applies the stop rule:
     // stop_len[m] == 0 (still running) and (p >= stop_thr or stop_step >= stop_maxlen[m]) and stop_step >= stop_minlen[m]
     // -> stop_len[m] = stop_step, ++*stop_ndone.  (The decoders launched a kernel of their own for this: 10 us per step of

@@ -45,7 +45,9 @@ __device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + expf(
 // decoders used to launch for it.
 __device__ __forceinline__ void rg_stop_block(const pk_rowgemm_args& a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = wave; b < a.M; b += 8) {
+    const int nb = (a.N + 15) / 16;   // the GEMM's workgroups come first; stop workgroup i owns rows 8 i .. 8 i + 7, a wave each
+    const int b = ((int)blockIdx.x - nb) * 8 + wave;
+    if (b < a.M) {
         const float* z = a.x + (long)b * a.ldx;
         float s = 0.f;
         if (a.ln_g) {
@@ -92,7 +94,7 @@ __device__ __forceinline__ void rg_stop_block(const pk_rowgemm_args& a) {
 
 template <bool LN>
 __global__ __launch_bounds__(512) void k_rowgemm(pk_rowgemm_args a) {
-    if (a.stop_w && blockIdx.x == gridDim.x - 1) {   // (block-uniform: the extra workgroup of the launch)
+    if (a.stop_w && (int)blockIdx.x >= (a.N + 15) / 16) {   // (block-uniform: the extra workgroups of the launch)
         rg_stop_block(a);
         return;
     }
@@ -286,7 +288,7 @@ int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args&
     const int cw = pk_rowgemm_cw(a.N);
     if (a.stop_w && (a.M > ROWS || a.K > 1024 || !a.stop_probs || !a.stop_len || !a.stop_ndone || !a.stop_minlen || !a.stop_maxlen))
         PK_FAIL(PK_EINVAL, "row GEMM: the stop-token head needs M <= %d, K <= 1024 and its five arrays", ROWS);
-    dim3 grid((a.N + cw - 1) / cw + (a.stop_w ? 1 : 0), (a.M + ROWS - 1) / ROWS);
+    dim3 grid((a.N + cw - 1) / cw + (a.stop_w ? (a.M + 7) / 8 : 0), (a.M + ROWS - 1) / ROWS);
     if (a.ln_g) PK_LAUNCH(ctx, prof_name, k_rowgemm<true>, grid, dim3(512), 0, a);
     else PK_LAUNCH(ctx, prof_name, k_rowgemm<false>, grid, dim3(512), 0, a);
     return PK_OK;

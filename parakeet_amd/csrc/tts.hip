@@ -970,8 +970,9 @@ constexpr int SLACK = 2 * PK_GEMM_BM;   // rows a GEMM tile may read beyond the 
 int rows_reserve(pk_dbuf& buf, long rows, int C) { return pk_fft_act_reserve(buf, (int)(rows + SLACK), C); }
 
 int attn_step(pk_tts* h, const char* name, const AttnStep& a, int heads, int B, int nmax) {
-    if (a.qx) {   // the query projected in the kernel: 64-wide heads, at most 128 keys, K <= 512 (the callers check)
-        PK_LAUNCH(h->ctx, name, (k_tts_attn_step64<8, true>), dim3(heads, B), dim3(256), 0, a);
+    if (a.qx) {   // the query projected in the kernel: 64-wide heads, at most 256 keys, K <= 512 (the callers check)
+        if (nmax <= 128) PK_LAUNCH(h->ctx, name, (k_tts_attn_step64<8, true>), dim3(heads, B), dim3(256), 0, a);
+        else PK_LAUNCH(h->ctx, name, (k_tts_attn_step64<16, true>), dim3(heads, B), dim3(256), 0, a);
         return PK_OK;
     }
     if (a.dk == 64 && nmax <= 640 && a.ldkv % 4 == 0 && a.ldq % 4 == 0) {   // (keys beyond 640: the general kernel)
@@ -1485,7 +1486,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
                 // x = residual + self_attn(...) (decoder_layer.py:127-128); x = residual + src_attn(norm2(x), memory)
                 // (:132-141); x = residual + feed_forward(norm3(x)) (:145-148) -> the layer's cached output row
                 PK_TRY(rowgemm("tts_row_attn_out", L.r_out, rc, A, rx, A, PK_ACT_NONE, xin, A, 0, 0, false));
-                if (h->fuse_src_q && dk == 64 && maxT <= 128 && A <= 512 && A % 8 == 0) {
+                if (h->fuse_src_q && dk == 64 && maxT <= 256 && A <= 512 && A % 8 == 0) {
                     // linear_q of the encoder-decoder attention (norm2 in its prologue) inside the attention kernel
                     a2.q = nullptr;
                     a2.qx = rx; a2.ldqx = A; a2.qK = A;
