@@ -1154,7 +1154,11 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             // (a CU-masked stream is a BLOCKING stream -- it synchronises implicitly with the NULL stream, which is what torch's
             // default stream is -- so the loop itself moves to a stream of the engine's own; the caller's stream only waits
             // for it at the end)
-            PK_HIP(hipStreamCreateWithFlags(&h->own_main, hipStreamNonBlocking));
+            {   // (the loop's stream at the most urgent priority: its workgroups go first wherever both streams have some waiting)
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                PK_HIP(hipStreamCreateWithPriority(&h->own_main, hipStreamNonBlocking, hi));
+            }
             PK_HIP(hipEventCreateWithFlags(&h->ev_io, hipEventDisableTiming));
             if (h->side_cu_mask == 0 || hipExtStreamCreateWithCUMask(&h->side, (uint32_t)words, mask) != hipSuccess) {
                 (void)hipGetLastError();
