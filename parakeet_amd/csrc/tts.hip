@@ -512,7 +512,7 @@ struct pk_tts : pk_fft_core {
     bool overlap_prefix = true;        // "overlap_prefix": the NEXT step's prefix work (prenet .. layer-0 q|k|v of the rows that
                                        // exist already) on a side stream under this step's layer chain, see pk_tts_infer
     bool fuse_src_q = true;            // "fuse_src_q": the encoder-decoder attention projects its query itself (k_tts_attn_step64<8, true>)
-    int side_cu_mask = 1;              // "overlap_cu_mask": 1 = the side stream runs on every other CU, 0 = an unmasked low-priority stream
+    int side_cu_mask = 2;              // "overlap_cu_mask": 2 = the side stream on every other CU and the loop's stream on the rest, 1 = only the side stream masked, 0 = an unmasked low-priority stream
     hipStream_t own_main = nullptr;    // the decoding loop's own stream (see pk_tts_infer), ordered against the caller's by ev_io
     hipEvent_t ev_io = nullptr;
     hipStream_t side = nullptr;        // ... the side stream and the two events that order it against the loop's stream
@@ -671,7 +671,7 @@ extern "C" int pk_tts_set_option(pk_tts* h, const char* key, int64_t value) {
         return PK_OK;
     }
     if (strcmp(key, "overlap_cu_mask") == 0) {   // (takes effect when the side stream is created: before the first inference)
-        h->side_cu_mask = value != 0;
+        h->side_cu_mask = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
         return PK_OK;
     }
     return pk_fft_set_option(h, key, value, "pk_tts_set_option");
@@ -1154,7 +1154,20 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             // (a CU-masked stream is a BLOCKING stream -- it synchronises implicitly with the NULL stream, which is what torch's
             // default stream is -- so the loop itself moves to a stream of the engine's own; the caller's stream only waits
             // for it at the end)
-            {   // (the loop's stream at the most urgent priority: its workgroups go first wherever both streams have some waiting)
+            // The loop's own stream: on the OTHER half of the CUs ("overlap_cu_mask" 2, the default).  Round 4, one box: everything
+            // in order 568 us per step, of which the prefix work is 240 -- the layer chain alone is 330 us -- but overlapped
+            // with the side stream masked and the loop's stream free to use every CU: 525.  The dispatcher spreads the chain's
+            // 32 - 256 workgroups over all CUs, half of them land next to the prefix GEMMs' waves, and a launch ends with its
+            // slowest workgroup.  With complementary masks no workgroup of the chain shares a CU with the prefix work.
+            if (h->side_cu_mask >= 2) {
+                uint32_t other[16];
+                for (int i = 0; i < words; ++i) other[i] = 0xAAAAAAAAu;
+                if (hipExtStreamCreateWithCUMask(&h->own_main, (uint32_t)words, other) != hipSuccess) {
+                    (void)hipGetLastError();
+                    h->own_main = nullptr;
+                }
+            }
+            if (!h->own_main) {   // (else: at the most urgent priority)
                 int lo = 0, hi = 0;
                 (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
                 PK_HIP(hipStreamCreateWithPriority(&h->own_main, hipStreamNonBlocking, hi));

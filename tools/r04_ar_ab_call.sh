@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $R
 {
 for rep in 1 2; do
-for o in "" "overlap_cu_mask=0" "overlap_prefix=0" "fuse_src_q=0"; do
+for o in "" "overlap_cu_mask=1" "overlap_cu_mask=0" "overlap_prefix=0"; do
   PK_QAR_OPTS=$o timeout 200 python tools/quick_ar.py tts 32 640 2>&1 | grep "tts B="
 done
 done
