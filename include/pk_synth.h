@@ -411,9 +411,9 @@ int pk_tts_set_math(pk_tts* h, int32_t mode);
  *   "fuse_src_q"  1 (default) = with 64-wide heads, at most 256 memory rows and adim <= 512 the encoder-decoder attention of a
  *                decoding step projects its own query (norm2 + linear_q inside the attention kernel: one launch less per layer);
  *                0 = a row GEMM of its own.  Same result up to summation order
- *   "overlap_cu_mask"  2 (default) = that side stream is confined to every other CU and the decoding loop's own stream to the
- *                others (no workgroup of the step's small dependent launches shares a CU with the prefix GEMMs); 1 = only the
- *                side stream is masked; 0 = an unmasked low-priority side stream.  Read when the streams are created */
+ *   "overlap_cu_mask"  0 (default) = that side stream is an ordinary stream at the least urgent priority, the decoding loop's own
+ *                stream at the most urgent; 1 = the side stream is confined to every other CU; 2 = and the loop's stream to the
+ *                others.  Measured within 3 % of one another on an MI355X.  Read when the streams are created */
 int pk_tts_set_option(pk_tts* h, const char* key, int64_t value);
 /* Decoder-prenet dropout: 1 (default) = the dropout stream above with p = 0.5, element index
  * ((s*(s-1)/2 + pos) * dprenet_layers + layer) * dprenet_units + unit for decoding step s = 1, 2, ... and prefix

@@ -512,7 +512,7 @@ struct pk_tts : pk_fft_core {
     bool overlap_prefix = true;        // "overlap_prefix": the NEXT step's prefix work (prenet .. layer-0 q|k|v of the rows that
                                        // exist already) on a side stream under this step's layer chain, see pk_tts_infer
     bool fuse_src_q = true;            // "fuse_src_q": the encoder-decoder attention projects its query itself (k_tts_attn_step64<8, true>)
-    int side_cu_mask = 2;              // "overlap_cu_mask": 2 = the side stream on every other CU and the loop's stream on the rest, 1 = only the side stream masked, 0 = an unmasked low-priority stream
+    int side_cu_mask = 0;              // "overlap_cu_mask": 0 = an unmasked low-priority side stream (the loop's stream at the most urgent priority), 1 = the side stream on every other CU, 2 = ... and the loop's stream on the rest
     hipStream_t own_main = nullptr;    // the decoding loop's own stream (see pk_tts_infer), ordered against the caller's by ev_io
     hipEvent_t ev_io = nullptr;
     hipStream_t side = nullptr;        // ... the side stream and the two events that order it against the loop's stream
@@ -1143,22 +1143,21 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         PK_HIP(hipMemsetAsync(h->d2_pam.p, 0, h->d2_pam.cap, ctx->stream));
         PK_TRY(rows_reserve(h->d2_qkv0, rowsCap, 3 * A));
         if (!h->side) {
-            // The side stream gets HALF of the CUs (hipExtStreamCreateWithCUMask): the prefix GEMMs are grids of a thousand
-            // workgroups that fill the chip for 30 - 90 us at a time, and with the whole chip theirs every one of the main
-            // stream's small dependent launches waited for workgroups to retire (first version: the layer chain's kernels
-            // went from 11 - 14 to 16 - 18 us each and the overlap gained 1 %).  On half the chip the prefix work of a step
-            // still ends well inside the step.  Fallback: an ordinary low-priority stream.
+            // "overlap_cu_mask" >= 1: the side stream gets HALF of the CUs (hipExtStreamCreateWithCUMask) -- with the row GEMM and
+            // step-attention kernels of round 3 this was worth 4 % (the prefix GEMMs are grids of a thousand workgroups that fill
+            // the chip for 30 - 90 us at a time); with round 4's kernels and stream priorities it no longer is (see below).
             uint32_t mask[16];
             const int words = std::min(16, (ctx->n_cu + 31) / 32);
             for (int i = 0; i < words; ++i) mask[i] = 0x55555555u;   // every other CU, all XCDs / shader engines alike
             // (a CU-masked stream is a BLOCKING stream -- it synchronises implicitly with the NULL stream, which is what torch's
             // default stream is -- so the loop itself moves to a stream of the engine's own; the caller's stream only waits
             // for it at the end)
-            // The loop's own stream: on the OTHER half of the CUs ("overlap_cu_mask" 2, the default).  Round 4, one box: everything
-            // in order 568 us per step, of which the prefix work is 240 -- the layer chain alone is 330 us -- but overlapped
-            // with the side stream masked and the loop's stream free to use every CU: 525.  The dispatcher spreads the chain's
-            // 32 - 256 workgroups over all CUs, half of them land next to the prefix GEMMs' waves, and a launch ends with its
-            // slowest workgroup.  With complementary masks no workgroup of the chain shares a CU with the prefix work.
+            // The loop's own stream.  "overlap_cu_mask" 2 puts it on the OTHER half of the CUs, so that no workgroup of the chain
+            // shares a CU with the prefix GEMMs.  Round 4, one box, us per step (profiles/r04_tts_options_ab.txt): everything in
+            // order 568; overlapped 518 - 520 with no masks (side stream at the least, this stream at the most urgent priority),
+            // 528 - 530 with the side stream masked, 528 - 534 with complementary masks: where the workgroups run is not what the
+            // overlap loses -- the chain's kernels are latency chains through a memory system the prefix GEMMs keep busy.  No
+            // masks is the default.
             if (h->side_cu_mask >= 2) {
                 uint32_t other[16];
                 for (int i = 0; i < words; ++i) other[i] = 0xAAAAAAAAu;
