@@ -591,12 +591,17 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     // columns per wave, 8-wave workgroups.  PK_FFNP_VARIANT (measurement switch): 88 / 44 force the first conv's kernel, the
     // second digit 4 runs the second conv in 4-wave workgroups.
     const int variant = c.variant;   // (the "ffnp_variant" option of the owning handle)
-    const bool small = first && c.w4 && (variant / 10 == 4 || (variant / 10 != 8 && c.nblk < FFNP_NQ1_MIN_BLOCKS));
-    const int nq = first && !small ? FFNP_NQ1 : FFNP_NQ2;
-    const int W = first ? (small ? 4 : 8) : (variant % 10 == 4 ? 4 : 8);
+    // An utterance or two (round 4): ONE 32-column tile per wave -- the k loop of a wave is a serial chain (TAPS * Cin / 16 steps x
+    // 3 NQ matrix instructions: 110 k cycles for the second conv at NQ = 4, whatever the number of rows), and with few row blocks
+    // the chip is empty anyway.  Same numbers as every other tiling (the weight scales are per 32 channels, a tile's k order is fixed).
+    const bool one = c.w1 && variant == 0 && (long)c.nblk * (c.N / 32) <= FFNP_NQ_ONE_MAX_TILES;
+    const bool small = !one && first && c.w4 && (variant / 10 == 4 || (variant / 10 != 8 && c.nblk < FFNP_NQ1_MIN_BLOCKS));
+    const int nq = one ? 1 : (first && !small ? FFNP_NQ1 : FFNP_NQ2);
+    const int W = one ? 8 : (first ? (small ? 4 : 8) : (variant % 10 == 4 ? 4 : 8));
     Args a;
     a.c = c;
     if (small) a.c.w = c.w4;
+    if (one) a.c.w = c.w1;
     a.nct = c.N / (32 * nq);
     a.in_blk = (long)c.Cin * 128;
     a.out_blk = (long)c.N * 128;
@@ -613,6 +618,7 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
         return PK_OK;
     };
     if (int st = ffnp_ablation<PK_PROFILE_BUILD != 0>(go, !first && W == 4); st != 1) return st;
+    if (one) return first ? go(k_ffn_planes<1, 24, 0, 8>) : go(k_ffn_planes<1, 96, 1, 8>);
     if (first) return small ? go(k_ffn_planes<FFNP_NQ2, 24, 0, 4>) : go(k_ffn_planes<FFNP_NQ1, 24, 0, 8>);
     return W == 8 ? go(k_ffn_planes<FFNP_NQ2, 96, 1, 8>) : go(k_ffn_planes<FFNP_NQ2, 96, 1, 4>);
 }

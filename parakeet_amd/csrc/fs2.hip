@@ -1074,6 +1074,7 @@ int pk_fft_add_conv(Arena& ar, const pk_param_map& P, const std::string& base, i
         std::vector<float> ws;
         d.wp = ffnp_pack(kn.data(), Cin, Cout, planes == 1 ? FFNP_NQ1 : FFNP_NQ2, *ar.v16, ws);
         if (planes == 1) d.wp4 = ffnp_pack(kn.data(), Cin, Cout, FFNP_NQ2, *ar.v16, ws);   // (the same scales: per 32 channels)
+        d.wp1 = ffnp_pack(kn.data(), Cin, Cout, 1, *ar.v16, ws);
         d.wps = ar.put(ws);
     }
     return PK_OK;
@@ -1636,6 +1637,7 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             c.row_utt = rv;
             c.w = h->arena16.as<uint16_t>() + L.ffn1.wp;
             c.w4 = L.ffn1.wp4 == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + L.ffn1.wp4;
+            c.w1 = L.ffn1.wp1 == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + L.ffn1.wp1;
             c.bias = L.ffn1.b == (size_t)-1 ? nullptr : h->W(L.ffn1.b);
             c.wscale = h->W(L.ffn1.wps); c.Cin = A; c.N = units;
             c.in = hp; c.in_amax = hpam;
@@ -1644,6 +1646,7 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             PK_TRY(ffnp_conv_launch(h->ctx, "fs2_conv_ffn1_planes", c));
             c.w = h->arena16.as<uint16_t>() + L.ffn2.wp;
             c.w4 = nullptr;
+            c.w1 = L.ffn2.wp1 == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + L.ffn2.wp1;
             c.bias = L.ffn2.b == (size_t)-1 ? nullptr : h->W(L.ffn2.b);
             c.wscale = h->W(L.ffn2.wps); c.Cin = units; c.N = A;
             c.in = fp; c.in_amax = fpam;

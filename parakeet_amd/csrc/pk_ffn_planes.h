@@ -21,6 +21,7 @@ constexpr int FFNP_NQ1 = 8;     // first conv: a wave owns 8 x 32 output channel
 constexpr int FFNP_NQ2 = 4;     // ... or 4 x 32 (short ones); second conv: 4 x 32
 constexpr int FFNP_NQL = 6;     // Linear layer on planes (the fused q | k | v projection, N = 3 adim = 6 x 192): 6 x 32
 constexpr int FFNP_NQ1_MIN_BLOCKS = 256;   // timelines from this many blocks on run the first conv with FFNP_NQ1 tiles per wave
+constexpr int FFNP_NQ_ONE_MAX_TILES = 512;     // ... and with ONE tile per wave while blocks x (N / 32) stays at or below this (2 per CU)
 constexpr int FFNP_MIN_BLOCKS = 0;         // timelines shorter than this stay on the tile GEMM.  0: the path does not depend on the
                                            // timeline's length, i.e. an utterance's result does not depend on its batch (bit for
                                            // bit: tests/test_fullsize_gpu.py); the price is the latency of short timelines (a wave
@@ -42,6 +43,9 @@ size_t ffnp_pack(const float* kn, int Cin, int N, int nq, std::vector<uint16_t>&
 struct FfnpConv {
     const uint16_t* w;     // packed weights: first conv for FFNP_NQ1 tiles per wave, second conv for FFNP_NQ2
     const uint16_t* w4;    // first conv: the same weights packed for FFNP_NQ2 tiles per wave (short timelines), or NULL
+    const uint16_t* w1;    // either conv: the same weights packed for ONE tile per wave (timelines of an utterance or two: a wave's k
+                           // loop is a serial chain of TAPS * Cin / 16 steps x 3 NQ matrix instructions -- 78 us for the second conv at
+                           // 4 tiles per wave however few rows there are -- and with 32 columns per wave four times as many CUs share it), or NULL
     const float* bias;     // [N] or NULL
     const float* wscale;   // [N / 32] 2^-kw of the packed weights' 32-channel groups
     int Cin, N;

@@ -21,6 +21,7 @@ struct pk_fft_dense {
     size_t wh = (size_t)-1;   // offset (halves) of the split-fp16 fragments, SIZE_MAX if Cin % 32 != 0
     size_t wp = (size_t)-1;   // offset (halves) of the planes-kernel fragments (pk_ffn_planes.h), SIZE_MAX if not packed
     size_t wp4 = (size_t)-1;  // first feed-forward conv: the same for the kernel with 4 tiles per wave (short timelines)
+    size_t wp1 = (size_t)-1;  // both feed-forward convs: the same for the kernel with ONE tile per wave (an utterance or two)
     size_t wps = (size_t)-1;  // offset (floats) of their [N / 32] scale factors
     int Cin = 0, N = 0, taps = 1, pad = 0;
     // |y[r, n]| <= c1 * max|x[r + tap, :]| + c0 with c1 = max_n sum_k |W[k, n]|, c0 = max_n |bias[n]|: an upper
