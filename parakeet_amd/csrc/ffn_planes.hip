@@ -594,7 +594,7 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     // An utterance or two (round 4): ONE 32-column tile per wave -- the k loop of a wave is a serial chain (TAPS * Cin / 16 steps x
     // 3 NQ matrix instructions: 110 k cycles for the second conv at NQ = 4, whatever the number of rows), and with few row blocks
     // the chip is empty anyway.  Same numbers as every other tiling (the weight scales are per 32 channels, a tile's k order is fixed).
-    const bool one = c.w1 && variant == 0 && (long)c.nblk * (c.N / 32) <= FFNP_NQ_ONE_MAX_TILES;
+    const bool one = c.w1 && variant == 0 && (long)c.nblk * (c.N / 32) <= c.one_max;
     const bool small = !one && first && c.w4 && (variant / 10 == 4 || (variant / 10 != 8 && c.nblk < FFNP_NQ1_MIN_BLOCKS));
     const int nq = one ? 1 : (first && !small ? FFNP_NQ1 : FFNP_NQ2);
     const int W = one ? 8 : (first ? (small ? 4 : 8) : (variant % 10 == 4 ? 4 : 8));

@@ -1643,6 +1643,7 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             c.in = hp; c.in_amax = hpam;
             c.out = fp; c.out_amax = fpam; c.c1 = L.ffn1.c1; c.c0 = L.ffn1.c0;
             c.variant = h->ffnp_variant;
+            c.one_max = h->ffn_one_tile_max;
             PK_TRY(ffnp_conv_launch(h->ctx, "fs2_conv_ffn1_planes", c));
             c.w = h->arena16.as<uint16_t>() + L.ffn2.wp;
             c.w4 = nullptr;
@@ -2119,6 +2120,7 @@ int pk_fft_set_option(pk_fft_core* h, const char* key, int64_t value, const char
     if (!h || !key) PK_FAIL(PK_EINVAL, "%s: NULL argument", who);
     if (strcmp(key, "ffn_planes") == 0) h->ffn_planes = value != 0;
     else if (strcmp(key, "ffn_planes_min_blocks") == 0) h->ffn_planes_min_blocks = (int)std::max<int64_t>(0, value);
+    else if (strcmp(key, "ffn_one_tile_max") == 0) h->ffn_one_tile_max = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
     else if (strcmp(key, "ffnp_variant") == 0) {
         if (value != 0 && value != 44 && value != 48 && value != 84 && value != 88) PK_FAIL(PK_EINVAL, "%s: ffnp_variant %lld (0, 44, 48, 84, 88)", who, (long long)value);
         h->ffnp_variant = (int)value;

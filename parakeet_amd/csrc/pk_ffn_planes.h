@@ -21,7 +21,6 @@ constexpr int FFNP_NQ1 = 8;     // first conv: a wave owns 8 x 32 output channel
 constexpr int FFNP_NQ2 = 4;     // ... or 4 x 32 (short ones); second conv: 4 x 32
 constexpr int FFNP_NQL = 6;     // Linear layer on planes (the fused q | k | v projection, N = 3 adim = 6 x 192): 6 x 32
 constexpr int FFNP_NQ1_MIN_BLOCKS = 256;   // timelines from this many blocks on run the first conv with FFNP_NQ1 tiles per wave
-constexpr int FFNP_NQ_ONE_MAX_TILES = 512;     // ... and with ONE tile per wave while blocks x (N / 32) stays at or below this (2 per CU)
 constexpr int FFNP_MIN_BLOCKS = 0;         // timelines shorter than this stay on the tile GEMM.  0: the path does not depend on the
                                            // timeline's length, i.e. an utterance's result does not depend on its batch (bit for
                                            // bit: tests/test_fullsize_gpu.py); the price is the latency of short timelines (a wave
@@ -62,6 +61,7 @@ struct FfnpConv {
     // second conv (out == NULL): x[row][:] += conv + bias (fp32 row-major, ldx floats per row)
     float* x;
     int ldx;
+    int one_max = 512;     // one 32-column tile per wave while blocks x N / 32 <= this (the owner's "ffn_one_tile_max" option; needs w1)
     int variant = 0;       // tiling override (the owner's "ffnp_variant" option): first digit 8 / 4 = 256 / 128 columns per wave in
                            // the first conv, second digit = waves per workgroup of the second conv; 0 = by shape
 };

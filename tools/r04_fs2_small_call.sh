@@ -7,11 +7,11 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 {
-for B in 1 2 4 8; do
-for o in "" "ffn_planes=0" "ffnp_variant=44" "ffnp_variant=48" "ffnp_variant=84" "attn_waves=4" "attn_waves=8"; do
+for B in 1 2 4 8 16; do
+for o in "ffn_one_tile_max=0" "" "ffn_one_tile_max=1024" "ffn_one_tile_max=2048" "ffn_one_tile_max=4096" "ffn_one_tile_max=1024,attn_waves=4"; do
   PK_QFS2_OPTS=$o timeout 100 python tools/quick_fs2.py $B 2>&1 | grep "FS2 B="
 done
 done
 } > $OUT/fs2_small_batch_options.txt 2>&1
-PK_QFS2_OPTS=ffn_planes=0 timeout 100 python tools/quick_fs2.py 1 2>&1 | grep -v amdgpu > $OUT/fs2_b1_tile_path.txt
-cat $OUT/fs2_small_batch_options.txt; cat $OUT/fs2_b1_tile_path.txt
+PK_QFS2_OPTS=ffn_one_tile_max=1024 timeout 100 python tools/quick_fs2.py 1 2>&1 | grep -v amdgpu > $OUT/fs2_b1_one_tile_1024.txt
+cat $OUT/fs2_small_batch_options.txt; cat $OUT/fs2_b1_one_tile_1024.txt
