@@ -233,8 +233,9 @@ int pk_fs2_set_math(pk_fs2* h, int32_t mode);
  *                            run on the planes kernels (csrc/ffn_planes.hip); 0 = on the tile GEMM
  *   "ffn_planes_min_blocks"  timelines shorter than this many 32-row blocks stay on the tile GEMM (default 0)
  *   "ffn_one_tile_max"       timelines with at most this many (32-row block, 32-column) tiles in a feed-forward conv run one tile
- *                            per wave (default 2048: up to about eight utterances of 640 frames in the second conv -- the latency path of
- *                            small calls: one utterance 2.42 -> 2.0 ms, eight 3.1 -> 2.9 ms on an MI355X); 0 = never
+ *                            per wave (default 4096: the second conv up to sixteen utterances of 640 frames, the encoder's at thirty-two.  One
+ *                            utterance 2.42 -> 2.0 ms, eight 3.1 -> 2.9, sixteen 3.73 -> 3.62, thirty-two 4.72 -> 4.64 on an MI355X;
+ *                            8192 and more lose at thirty-two: four times the operand traffic per product); 0 = never
  *   "ffnp_variant"           0 (default) = tiling by shape; 88 / 84 / 48 / 44: first digit 8 / 4 = 256 / 128 output channels
  *                            per wave in the first conv, second digit = waves per workgroup of the second conv
  *   "attn_waves"             0 (default) = by shape; 4 / 8 query tiles per attention workgroup */

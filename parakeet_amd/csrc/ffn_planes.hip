@@ -591,7 +591,7 @@ int ffnp_conv_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c) {
     // columns per wave, 8-wave workgroups.  PK_FFNP_VARIANT (measurement switch): 88 / 44 force the first conv's kernel, the
     // second digit 4 runs the second conv in 4-wave workgroups.
     const int variant = c.variant;   // (the "ffnp_variant" option of the owning handle)
-    // Short timelines (round 4; c.one_max, default 2 048 tiles): ONE 32-column tile per wave -- the k loop of a wave is a serial chain (TAPS * Cin / 16 steps x
+    // Short timelines (round 4; c.one_max, default 4 096 tiles): ONE 32-column tile per wave -- the k loop of a wave is a serial chain (TAPS * Cin / 16 steps x
     // 3 NQ matrix instructions: 110 k cycles for the second conv at NQ = 4, whatever the number of rows), and with few row blocks
     // the chip is empty anyway.  Same numbers as every other tiling (the weight scales are per 32 channels, a tile's k order is fixed).
     const bool one = c.w1 && variant == 0 && (long)c.nblk * (c.N / 32) <= c.one_max;

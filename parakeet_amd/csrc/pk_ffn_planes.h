@@ -61,7 +61,7 @@ struct FfnpConv {
     // second conv (out == NULL): x[row][:] += conv + bias (fp32 row-major, ldx floats per row)
     float* x;
     int ldx;
-    int one_max = 2048;    // one 32-column tile per wave while blocks x N / 32 <= this (the owner's "ffn_one_tile_max" option; needs w1)
+    int one_max = 4096;    // one 32-column tile per wave while blocks x N / 32 <= this (the owner's "ffn_one_tile_max" option; needs w1)
     int variant = 0;       // tiling override (the owner's "ffnp_variant" option): first digit 8 / 4 = 256 / 128 columns per wave in
                            // the first conv, second digit = waves per workgroup of the second conv; 0 = by shape
 };

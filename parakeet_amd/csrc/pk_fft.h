@@ -85,7 +85,7 @@ struct pk_fft_core {
     // options (pk_fs2_set_option / pk_tts_set_option)
     bool ffn_planes = true;          // "ffn_planes": feed-forward convs on the planes kernels (pk_ffn_planes.h) where packed for them
     int ffn_planes_min_blocks = 0;   // "ffn_planes_min_blocks": timelines shorter than this many 32-row blocks stay on the tile GEMM
-    int ffn_one_tile_max = 2048;     // "ffn_one_tile_max": the feed-forward convs run one 32-column tile per wave while blocks x N / 32 <= this
+    int ffn_one_tile_max = 4096;     // "ffn_one_tile_max": the feed-forward convs run one 32-column tile per wave while blocks x N / 32 <= this
     int ffnp_variant = 0;            // "ffnp_variant": tiling override of the planes kernels (ffnp_conv_launch), 0 = by shape
     int attn_waves = 0;              // "attn_waves": 4 / 8 query tiles per attention workgroup, 0 = by shape
     int max_len = 0;                 // rows of the positional table
