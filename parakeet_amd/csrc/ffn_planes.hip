@@ -658,7 +658,10 @@ int ffnp_conv256_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c, i
     if (c.out && act != 1) PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: planes output is built for tanh");
     Args a;
     a.c = c;
-    a.nct = c.N / (32 * FFNP_NQ2);   // 2 column tiles of 128
+    // (short timelines: one 32-column tile per wave, as ffnp_conv_launch)
+    const bool one = c.w1 && c.variant == 0 && (long)c.nblk * (c.N / 32) <= c.one_max;
+    if (one) a.c.w = c.w1;
+    a.nct = one ? c.N / 32 : c.N / (32 * FFNP_NQ2);   // 2 column tiles of 128, or 8 of 32
     a.in_blk = (long)c.Cin * 128;
     a.out_blk = (long)c.N * 128;
     int active = 8;
@@ -671,6 +674,18 @@ int ffnp_conv256_launch(pk_ctx* ctx, const char* prof_name, const FfnpConv& c, i
         return PK_OK;
     };
     // <NQ, KQ, EPI, W, TAPS, ABL, BF32, CPT, ACT>: CPT such that a slab is a whole number of k-steps that divides TAPS * KQ
+    if (one) {   // (a slab = 4 CPT k-steps; at least three slabs)
+        if (c.out) {
+            if (c.Cin == 256 && taps == 5) return go(k_ffn_planes<1, 16, 0, 8, 5, 0, false, 5, 1>);
+            PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: planes output: 256 -> 256, k = 5 only");
+        }
+        if (act == 1) {
+            if (c.Cin == 256 && taps == 5) return go(k_ffn_planes<1, 16, 2, 8, 5, 0, false, 5, 1>);
+            PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: tanh rows output: 256 -> 256, k = 5 only");
+        }
+        if (c.Cin == 384) return taps == 3 ? go(k_ffn_planes<1, 24, 2, 8, 3, 0, false, 6, 2>) : go(k_ffn_planes<1, 24, 2, 8, 5, 0, false, 6, 2>);
+        return taps == 3 ? go(k_ffn_planes<1, 16, 2, 8, 3, 0, false, 4, 2>) : go(k_ffn_planes<1, 16, 2, 8, 5, 0, false, 5, 2>);
+    }
     if (c.out) {
         if (c.Cin == 256 && taps == 5) return go(k_ffn_planes<4, 16, 0, 8, 5, 0, false, 5, 1>);
         PK_FAIL(PK_EINVAL, "ffnp_conv256_launch: planes output: 256 -> 256, k = 5 only");

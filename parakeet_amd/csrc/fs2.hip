@@ -1058,6 +1058,7 @@ int pk_fft_add_dense_kn(Arena& ar, const std::vector<float>& kn, const std::vect
     if (ar.v16 && ffnp_conv256_supports(Cin, N, taps)) {
         std::vector<float> ws;
         d.wp = ffnp_pack(kn.data(), Cin, N, FFNP_NQ2, *ar.v16, ws, taps);
+        d.wp1 = ffnp_pack(kn.data(), Cin, N, 1, *ar.v16, ws, taps);   // (one tile per wave: short timelines)
         d.wps = ar.put(ws);
     }
     return PK_OK;
@@ -1688,6 +1689,9 @@ static FfnpConv conv256_args(pk_fft_core* h, const Dense& d, int nblk, const int
     c.nblk = nblk;
     c.row_utt = row_utt;
     c.w = h->arena16.as<uint16_t>() + d.wp;
+    c.w1 = d.wp1 == (size_t)-1 ? nullptr : h->arena16.as<uint16_t>() + d.wp1;
+    c.one_max = h->ffn_one_tile_max;
+    c.variant = h->ffnp_variant;
     c.bias = d.b == (size_t)-1 ? nullptr : h->W(d.b);
     c.wscale = h->W(d.wps);
     c.Cin = d.Cin;
