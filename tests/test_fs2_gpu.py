@@ -192,7 +192,8 @@ def test_fs2_tile_gemm_path_still_meets_the_bars():
 def test_fs2_batch_composition_invariance():
     """An utterance's mel does not depend on the batch it is in, bit for bit -- alone, in a ragged batch, in the reversed
     batch -- nor on which of the first-conv kernels runs (the "ffnp_variant" option: they differ in tiling only).  The planes
-    kernels keep one scale per ROW for this (a per-block scale would couple neighbouring utterances)."""
+    kernels keep one scale per ROW for this (a per-block scale would couple neighbouring utterances), and one weight scale per 32
+    output channels whatever the tile width."""
     from parakeet_amd.fastspeech2 import FastSpeech2
     cfg = _cfg()
     model = FastSpeech2(80, 80, **cfg)
@@ -210,6 +211,14 @@ def test_fs2_batch_composition_invariance():
         out = model.inference_batch(texts)
         for b in range(len(texts)):
             assert torch.equal(ref[b], out[b].as_subclass(torch.Tensor)), (variant, b)
+    # ... nor on the one-tile-per-wave kernels of short timelines ("ffn_one_tile_max": the default runs them here, 0 never does,
+    # the forced variants above never do either)
+    model.set_option("ffnp_variant", 0)
+    for one_max in (0, 1 << 20):
+        model.set_option("ffn_one_tile_max", one_max)
+        out = model.inference_batch(texts)
+        for b in range(len(texts)):
+            assert torch.equal(ref[b], out[b].as_subclass(torch.Tensor)), (one_max, b)
 
 
 def test_fs2_ffn_planes_long_utterance():
