@@ -412,6 +412,8 @@ int pk_tts_set_math(pk_tts* h, int32_t mode);
  *   "overlap_prefix"  1 (default) = the next decoding step's prefix work (prenet with its fresh dropout, input layer, layer 0's
  *                q | k | v of the row blocks that exist already) runs on a side stream under the current step's layer chain;
  *                0 = everything in order on one stream.  Same spectrogram bit for bit
+ *   "fuse_prenet"  1 (default) = the decoder prenet (two layers) and the input layer of a step's new rows run as one launch;
+ *                0 = three row GEMMs.  Same result up to summation order
  *   "fuse_src_q"  1 (default) = with 64-wide heads, at most 256 memory rows and adim <= 512 the encoder-decoder attention of a
  *                decoding step projects its own query (norm2 + linear_q inside the attention kernel: one launch less per layer);
  *                0 = a row GEMM of its own.  Same result up to summation order

@@ -249,7 +249,9 @@ def test_query_projection_inside_the_source_attention():
     names = {k for k, (n, _) in ctx.prof_dump().items() if n > 0}
     ctx.prof_enable(False)
     assert "tts_attn_src_q" in names and "tts_row_src_q" not in names and "tts_row_feat_out_stop" in names
+    assert "tts_prenet_embed" in names and "tts_row_prenet" not in names     # (option "fuse_prenet": one launch for the new rows' prenet + input layer)
     m.set_option("fuse_src_q", 0)
+    m.set_option("fuse_prenet", 0)
     plain = m.inference_batch(texts, maxlenratio=2.0, seeds=[1, 2, 3])
     for (a, pa, wa), (b, pb, wb) in zip(fused, plain):
         assert a.shape == b.shape and np.abs(a.numpy() - b.numpy()).max() < 2e-4
