@@ -493,7 +493,7 @@ __global__ __launch_bounds__(128) void k_tts_gather_r(const float* __restrict__ 
 // the input layer (Linear + positional encoding) in ONE launch, a workgroup per utterance: three dependent row GEMMs of 6 us
 // each (+ 3 us between two launches) become three phases behind __syncthreads.  A phase: thread (n4 = tid % (N / 4), part =
 // tid / (N / 4)) owns 4 consecutive outputs and a slice of K, all of its float4 weight loads ([K][N] row-major, L2-resident: every
-// workgroup reads the same 850 KB) in flight in batches of 16, the input row broadcast from LDS; the parts are summed through
+// workgroup reads the same 850 KB) in flight in batches of 32, the input row broadcast from LDS; the parts are summed through
 // LDS in order (deterministic).  LJSpeech recipe shapes: odim 80 -> 256 -> 256 -> adim 512.
 struct PrenetEmbed {
     const float* y; int ldy;                 // [B][ldy]: the previous step's last frame (K0 = O values)
@@ -508,12 +508,12 @@ __device__ __forceinline__ void tts_dense_phase(const float* in, int K, const fl
     const int kper = (K + nparts - 1) / nparts, kbeg = part * kper, kend = min(K, kbeg + kper);
     const float4* W4 = reinterpret_cast<const float4*>(W);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        float4 w[16];
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        float4 w[32];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = W4[(long)min(k0 + i, kend - 1) * ng + n4];
+        for (int i = 0; i < 32; ++i) w[i] = W4[(long)min(k0 + i, kend - 1) * ng + n4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 32; ++i) {
             const float x = k0 + i < kend ? in[k0 + i] : 0.f;
             acc.x = fmaf(x, w[i].x, acc.x);
             acc.y = fmaf(x, w[i].y, acc.y);
