@@ -69,8 +69,12 @@ struct pk_rowgemm_args {
     // stop_len[m] == 0 (still running) and (p >= stop_thr or stop_step >= stop_maxlen[m]) and stop_step >= stop_minlen[m]
     // -> stop_len[m] = stop_step, ++*stop_ndone.  (The decoders launched a kernel of their own for this: 10 us per step of
     // a chain in which nothing else depends on it.)  M <= 32.
+    // stop_kind 1 = Tacotron2's rule (models/tacotron2.py:515-528 with use_stop_token): the raw logit s is stored at
+    // stop_probs[stop_step * M + m] (stop_step counted from 0), the utterance ends when sigmoid(s) > 0.5 or
+    // stop_step + 1 >= stop_max_steps: stop_len[m] = stop_step + 1.  No LayerNorm, any K.
     const float* stop_w = nullptr;
     float stop_bias = 0.f, stop_thr = 0.5f;
+    int stop_kind = 0, stop_max_steps = 0;
     int stop_step = 0;
     const int* stop_minlen = nullptr;
     const int* stop_maxlen = nullptr;

@@ -81,7 +81,15 @@ __device__ __forceinline__ void rg_stop_block(const pk_rowgemm_args& a) {
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) {
+        if (lane == 0 && a.stop_kind == 1) {
+            s += a.stop_bias;
+            a.stop_probs[(long)a.stop_step * a.M + b] = s;
+            const bool end = 1.f / (1.f + expf(-s)) > 0.5f || a.stop_step + 1 >= a.stop_max_steps;
+            if (end && a.stop_len[b] == 0) {
+                a.stop_len[b] = a.stop_step + 1;
+                atomicAdd(a.stop_ndone, 1);
+            }
+        } else if (lane == 0) {
             const float p = 1.f / (1.f + expf(-(s + a.stop_bias)));
             a.stop_probs[(long)(a.stop_step - 1) * a.M + b] = p;
             if (a.stop_len[b] == 0 && (p >= a.stop_thr || a.stop_step >= a.stop_maxlen[b]) && a.stop_step >= a.stop_minlen[b]) {
@@ -286,8 +294,9 @@ int pk_rowgemm_launch(pk_ctx* ctx, const char* prof_name, const pk_rowgemm_args&
                      !a.lstm_h2))
         PK_FAIL(PK_EINVAL, "row GEMM: LSTM epilogue needs N == 4 * H, H %% 4 == 0, two h destinations and no act / dropout / res");
     const int cw = pk_rowgemm_cw(a.N);
-    if (a.stop_w && (a.M > ROWS || a.K > 1024 || !a.stop_probs || !a.stop_len || !a.stop_ndone || !a.stop_minlen || !a.stop_maxlen))
-        PK_FAIL(PK_EINVAL, "row GEMM: the stop-token head needs M <= %d, K <= 1024 and its five arrays", ROWS);
+    if (a.stop_w && (a.M > ROWS || (a.ln_g && a.K > 1024) || !a.stop_probs || !a.stop_len || !a.stop_ndone ||
+                     (a.stop_kind == 0 && (!a.stop_minlen || !a.stop_maxlen)) || (a.stop_kind == 1 && a.ln_g) || a.stop_kind < 0 || a.stop_kind > 1))
+        PK_FAIL(PK_EINVAL, "row GEMM: the stop-token head needs M <= %d, K <= 1024 under LayerNorm, and its arrays", ROWS);
     dim3 grid((a.N + cw - 1) / cw + (a.stop_w ? (a.M + 7) / 8 : 0), (a.M + ROWS - 1) / ROWS);
     if (a.ln_g) PK_LAUNCH(ctx, prof_name, k_rowgemm<true>, grid, dim3(512), 0, a);
     else PK_LAUNCH(ctx, prof_name, k_rowgemm<false>, grid, dim3(512), 0, a);

@@ -807,6 +807,15 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
                       h->d_cdec.as<float>(), Hd, B, in2n + Ha + Eg, K2, in3, K3);
         }
         // linear_projection on [decoder_hidden | context] (:409-413) -> this step's mel row; stop rules (:515-528)
+        if (use_rg && c.use_stop_token && B <= PK_RG_ROWS) {
+            // (one launch: the stop token rides on the projection's row GEMM as extra workgroups, pk_rowgemm.h stop_kind 1)
+            pk_rowgemm_args g;
+            g.x = in3; g.ldx = K3; g.Wt = h->W(h->rw_proj.w); g.bias = h->rw_proj.b == (size_t)-1 ? nullptr : h->W(h->rw_proj.b);
+            g.y = Y + (long)i * B * M; g.ldy = M; g.M = B; g.K = h->rw_proj.K; g.N = h->rw_proj.N; g.act = PK_ACT_NONE;
+            g.stop_w = h->W(h->stop_w); g.stop_bias = h->stop_b; g.stop_kind = 1; g.stop_step = i; g.stop_max_steps = cap;
+            g.stop_probs = h->d_logits.as<float>(); g.stop_len = d_len; g.stop_ndone = d_ndone;
+            PK_TRY(pk_rowgemm_launch(ctx, "taco_row_proj_stop", g));
+        } else {
         if (use_rg)
             PK_TRY(rowgemm("taco_row_proj", h->rw_proj, in3, K3, Y + (long)i * B * M, M, PK_ACT_NONE, -1, 0));
         else
@@ -814,6 +823,7 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
         PK_LAUNCH(ctx, "taco_stop", k_taco_stop, dim3(pk_div_up(B, 4)), dim3(256), 0, in3, K3, K3,
                   c.use_stop_token ? h->W(h->stop_w) : (const float*)nullptr, h->stop_b, c.use_stop_token ? 1 : 0, B, i, cap,
                   h->d_attw.as<float>(), tl.d_seg_start(), tl.d_seg_len(), h->d_logits.as<float>(), d_len, d_first, d_ndone);
+        }
         if ((i + 1) % poll == 0 || i + 1 == cap) {
             int ndone = 0;
             PK_HIP(hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
