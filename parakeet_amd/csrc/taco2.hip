@@ -339,6 +339,7 @@ struct pk_taco : pk_fft_core {
         size_t w = 0, b = (size_t)-1;
         int K = 0, N = 0;
     } rw_pre1, rw_pre2, rw_att, rw_dec, rw_proj, rw_q;   // the same layers as pk_rowgemm_pack tiles for the row GEMM
+    size_t pre1_kn = (size_t)-1, pre2_kn = (size_t)-1;   // the prenet's matrices row-major [K][N] (k_ar_prenet_embed)
     // per call
     Timeline tl_tok, tl_frm;
     int B = 0, cap = 0, steps = 0, maxT = 0;
@@ -529,10 +530,12 @@ extern "C" int pk_taco_finalize(pk_taco* h) {
         std::vector<float> wt;
         pk_rowgemm_pack(w.data(), M, Pn, wt);
         h->rw_pre1.w = ar.put(wt); h->rw_pre1.K = M; h->rw_pre1.N = Pn;
+        h->pre1_kn = ar.put(w);
         PK_TRY(pk_get_weight(P, "decoder.prenet.linear2", {Pn, Pn}, w));
         PK_TRY(pk_fft_add_dense_kn(ar, w, nullptr, Pn, 1, Pn, h->pre2));
         pk_rowgemm_pack(w.data(), Pn, Pn, wt);
         h->rw_pre2.w = ar.put(wt); h->rw_pre2.K = Pn; h->rw_pre2.N = Pn;
+        h->pre2_kn = ar.put(w);
         PK_TRY(pk_get_weight(P, "decoder.attention_layer.query_layer", {Ha, Da}, w));
         pk_rowgemm_pack(w.data(), Ha, Da, wt);
         h->rw_q.w = ar.put(wt); h->rw_q.K = Ha; h->rw_q.N = Da;
@@ -763,7 +766,17 @@ extern "C" int pk_taco_infer(pk_taco* h, const int64_t* ids, const int64_t* tone
         float* in1n = in1_[(i & 1) ^ 1];   // the next step's: context(t) and attention_hidden(t) go there
         float* in2 = in2_[i & 1];
         float* in2n = in2_[(i & 1) ^ 1];
-        if (use_rg) {
+        if (use_rg && Pn % 4 == 0 && Pn / 4 <= 512 && 512 % (Pn / 4) == 0 && Pn <= 512 && M <= 512 && K1 % 4 == 0) {
+            // both prenet layers in one launch (pk_ar.h k_ar_prenet_embed without the input layer)
+            pk_prenet_embed pe;
+            memset(&pe, 0, sizeof(pe));
+            pe.y = q; pe.ldy = M; pe.O = M; pe.U = Pn; pe.A = Pn; pe.B = B;
+            pe.w1 = h->W(h->pre1_kn); pe.w2 = h->W(h->pre2_kn);
+            pe.x0 = in1; pe.ldx0 = K1;
+            pe.dropout = drop ? 1 : 0; pe.base = (unsigned long long)i; pe.J = 2; pe.seeds = d_seeds; pe.thr = thr; pe.scale = dscale;
+            PK_LAUNCH(ctx, "taco_prenet", k_ar_prenet_embed, dim3(B), dim3(512), 0, pe);
+            PK_TRY(rowlstm("taco_row_att_rnn", h->rw_att, in1, K1, h->d_catt.as<float>(), Ha, in1n + Pn + Eg, K1, in2, K2));
+        } else if (use_rg) {
             PK_TRY(rowgemm("taco_row_prenet", h->rw_pre1, q, M, p1, Pn, PK_ACT_RELU, 0, (unsigned long long)i));
             PK_TRY(rowgemm("taco_row_prenet", h->rw_pre2, p1, Pn, in1, K1, PK_ACT_RELU, 1, (unsigned long long)i));
             // attention_rnn (:380-385) on [prenet | context | attention_hidden]; h -> the two operand rows that read it

@@ -489,91 +489,9 @@ __global__ __launch_bounds__(128) void k_tts_gather_r(const float* __restrict__ 
     }
 }
 
-// The NEW row block of a decoding step through the decoder prenet (two Linear + ReLU + dropout layers, always-on dropout) and
-// the input layer (Linear + positional encoding) in ONE launch, a workgroup per utterance: three dependent row GEMMs of 6 us
-// each (+ 3 us between two launches) become three phases behind __syncthreads.  A phase: thread (n4 = tid % (N / 4), part =
-// tid / (N / 4)) owns 4 consecutive outputs and a slice of K, all of its float4 weight loads ([K][N] row-major, L2-resident: every
-// workgroup reads the same 850 KB) in flight in batches of 32, the input row broadcast from LDS; the parts are summed through
-// LDS in order (deterministic).  LJSpeech recipe shapes: odim 80 -> 256 -> 256 -> adim 512.
-struct PrenetEmbed {
-    const float* y; int ldy;                 // [B][ldy]: the previous step's last frame (K0 = O values)
-    int O, U, A, B;
-    const float *w1, *b1, *w2, *b2, *we, *be;   // [O][U], [U][U], [U][A] row-major (+ biases, NULL = none)
-    const float* peb; int ldpe;              // positional encoding (scaled) of the new rows [B][ldpe]
-    float* x0; int ldx0;                     // out: [B][ldx0]
-    int dropout; unsigned long long base; int J; const unsigned long long* seeds; unsigned thr; float scale;
-};
-__device__ __forceinline__ void tts_dense_phase(const float* in, int K, const float* __restrict__ W, int N, float* red, int tid) {
-    const int ng = N >> 2, n4 = tid % ng, part = tid / ng, nparts = 512 / ng;
-    const int kper = (K + nparts - 1) / nparts, kbeg = part * kper, kend = min(K, kbeg + kper);
-    const float4* W4 = reinterpret_cast<const float4*>(W);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        float4 w[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) w[i] = W4[(long)min(k0 + i, kend - 1) * ng + n4];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const float x = k0 + i < kend ? in[k0 + i] : 0.f;
-            acc.x = fmaf(x, w[i].x, acc.x);
-            acc.y = fmaf(x, w[i].y, acc.y);
-            acc.z = fmaf(x, w[i].z, acc.z);
-            acc.w = fmaf(x, w[i].w, acc.w);
-        }
-    }
-    if (part < nparts) *reinterpret_cast<float4*>(red + part * N + 4 * n4) = acc;
-}
-__global__ __launch_bounds__(512) void k_tts_prenet_embed(PrenetEmbed a) {
-    __shared__ __attribute__((aligned(16))) float hin[512];
-    __shared__ __attribute__((aligned(16))) float red[8 * 256];   // (N / 4 column groups x 512 / (N / 4) parts = 2048 floats for every N)
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid < a.O) hin[tid] = a.y[(long)b * a.ldy + tid];
-    __syncthreads();
-    for (int j = 0; j < 2; ++j) {
-        const float* W = j == 0 ? a.w1 : a.w2;
-        const float* bias = j == 0 ? a.b1 : a.b2;
-        const int K = j == 0 ? a.O : a.U, N = a.U;
-        tts_dense_phase(hin, K, W, N, red, tid);
-        __syncthreads();
-        const int ng = N >> 2, nparts = 512 / ng;
-        if (tid < ng) {
-            float4 s = bias ? *reinterpret_cast<const float4*>(bias + 4 * tid) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = 0; p < nparts; ++p) {
-                const float4 r = *reinterpret_cast<const float4*>(red + p * N + 4 * tid);
-                s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
-            }
-            s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
-            if (a.dropout) {
-                const unsigned long long e = (a.base * (unsigned long long)a.J + (unsigned long long)j) * (unsigned long long)N + 4ull * tid;
-                unsigned w4[4];
-                pk_dropout_words(e, a.seeds ? a.seeds[b] : 0ull, w4);
-                s.x = w4[0] >= a.thr ? s.x * a.scale : 0.f;
-                s.y = w4[1] >= a.thr ? s.y * a.scale : 0.f;
-                s.z = w4[2] >= a.thr ? s.z * a.scale : 0.f;
-                s.w = w4[3] >= a.thr ? s.w * a.scale : 0.f;
-            }
-            *reinterpret_cast<float4*>(hin + 4 * tid) = s;
-        }
-        __syncthreads();
-    }
-    tts_dense_phase(hin, a.U, a.we, a.A, red, tid);
-    __syncthreads();
-    const int ng = a.A >> 2, nparts = 512 / ng;
-    if (tid < ng) {
-        float4 s = a.be ? *reinterpret_cast<const float4*>(a.be + 4 * tid) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = 0; p < nparts; ++p) {
-            const float4 r = *reinterpret_cast<const float4*>(red + p * a.A + 4 * tid);
-            s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
-        }
-        const float4 pe = *reinterpret_cast<const float4*>(a.peb + (long)b * a.ldpe + 4 * tid);
-        s.x += pe.x; s.y += pe.y; s.z += pe.z; s.w += pe.w;
-        *reinterpret_cast<float4*>(a.x0 + (long)b * a.ldx0 + 4 * tid) = s;
-    }
-}
-
 struct RowW {   // a layer as pk_rowgemm_pack tiles of its [K][N] matrix (+ bias) for the row GEMM
     size_t w = 0, b = (size_t)-1;
-    size_t kn = (size_t)-1;   // the same matrix row-major [K][N] (k_tts_prenet_embed), when asked for
+    size_t kn = (size_t)-1;   // the same matrix row-major [K][N] (k_ar_prenet_embed, pk_ar.h), when asked for
     int K = 0, N = 0;
 };
 
@@ -594,7 +512,7 @@ struct pk_tts : pk_fft_core {
     bool kv_prefix = false;            // "kv_prefix" option (pk_tts_set_option), see pk_tts_infer
     bool overlap_prefix = true;        // "overlap_prefix": the NEXT step's prefix work (prenet .. layer-0 q|k|v of the rows that
                                        // exist already) on a side stream under this step's layer chain, see pk_tts_infer
-    bool fuse_prenet = true;           // "fuse_prenet": prenet x 2 + input layer of a step's new rows in one launch (k_tts_prenet_embed)
+    bool fuse_prenet = true;           // "fuse_prenet": prenet x 2 + input layer of a step's new rows in one launch (k_ar_prenet_embed, pk_ar.h)
     bool fuse_src_q = true;            // "fuse_src_q": the encoder-decoder attention projects its query itself (k_tts_attn_step64<8, true>)
     int side_cu_mask = 0;              // "overlap_cu_mask": 0 = an unmasked low-priority side stream (the loop's stream at the most urgent priority), 1 = the side stream on every other CU, 2 = ... and the loop's stream on the rest
     hipStream_t own_main = nullptr;    // the decoding loop's own stream (see pk_tts_infer), ordered against the caller's by ev_io
@@ -1440,8 +1358,8 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
         auto phase_ok = [](int N) { return N % 4 == 0 && N / 4 <= 512 && 512 % (N / 4) == 0; };   // (column groups x K parts = 512 threads)
         if (h->fuse_prenet && J == 2 && phase_ok(U) && phase_ok(A) && U <= 512 && O <= 512 && h->r_dprenet[0].kn != (size_t)-1 &&
             h->r_dlin.kn != (size_t)-1) {
-            // prenet x 2 + input layer + positional encoding of the new row block in one launch (k_tts_prenet_embed)
-            PrenetEmbed pe;
+            // prenet x 2 + input layer + positional encoding of the new row block in one launch (k_ar_prenet_embed, pk_ar.h)
+            pk_prenet_embed pe;
             pe.y = in; pe.ldy = ldin; pe.O = O; pe.U = U; pe.A = A; pe.B = B;
             pe.w1 = h->W(h->r_dprenet[0].kn); pe.b1 = h->W(h->r_dprenet[0].b);
             pe.w2 = h->W(h->r_dprenet[1].kn); pe.b2 = h->W(h->r_dprenet[1].b);
@@ -1451,7 +1369,7 @@ extern "C" int pk_tts_infer(pk_tts* h, const int64_t* ids, const int32_t* tok_le
             pe.dropout = h->dropout ? 1 : 0;
             pe.base = (unsigned long long)st * (unsigned long long)(st - 1) / 2ull + (unsigned long long)(st - 1);
             pe.J = J; pe.seeds = d_seeds; pe.thr = thr; pe.scale = dscale;
-            PK_LAUNCH(ctx, "tts_prenet_embed", k_tts_prenet_embed, dim3(B), dim3(512), 0, pe);
+            PK_LAUNCH(ctx, "tts_prenet_embed", k_ar_prenet_embed, dim3(B), dim3(512), 0, pe);
             PK_TRY(rowgemm("tts_row_qkv", h->dec[0].r_qkv, S.X0 + r0 * A, A, S.QKV0 + r0 * 3 * A, 3 * A, PK_ACT_NONE, nullptr, 0,
                            h->dec[0].ln1_g, h->dec[0].ln1_b, !post));
             return PK_OK;
