@@ -164,7 +164,13 @@ struct LsaArgs {
 __global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
     __shared__ float win[4][2][64];   // per wave: the attw / cum window t - pad .. t + pad
     __shared__ float loc[4][64];      // per wave: location_conv output of its row
+    // location_layer [F][Da] in LDS (round 4: read from memory inside the f loop it was 2 F dependent round trips per lane --
+    // 13 of the launch's 15 us; F <= 64, Da <= 256, F * Da <= 8192 here, else from memory as before)
+    __shared__ __attribute__((aligned(16))) float wl[8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool wl_lds = a.F * a.Da <= 8192 && (a.F * a.Da) % 4 == 0;
+    if (wl_lds)
+        for (int i = tid * 4; i < a.F * a.Da; i += 1024) *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(a.Wloc + i);
     const int r = blockIdx.x * 4 + wave;
     const int b = r < a.rows ? a.row_utt[r] : -1;
     const bool valid = b >= 0;   // wave-uniform
@@ -197,9 +203,14 @@ __global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
     if (valid) {
         const float* pq = a.pq + (long)b * Da;
         for (int d = lane; d < Da; d += 64) {
+            const float vd = a.v[d], kd = a.pkey[(long)r * Da + d], qd = pq[d];   // (requested before the f loop)
             float pl = 0.f;
-            for (int f = 0; f < F; ++f) pl = fmaf(loc[wave][f], a.Wloc[(long)f * Da + d], pl);
-            e = fmaf(a.v[d], tanhf(pl + a.pkey[(long)r * Da + d] + pq[d]), e);
+            if (wl_lds) {
+                for (int f = 0; f < F; ++f) pl = fmaf(loc[wave][f], wl[f * Da + d], pl);
+            } else {
+                for (int f = 0; f < F; ++f) pl = fmaf(loc[wave][f], a.Wloc[(long)f * Da + d], pl);
+            }
+            e = fmaf(vd, tanhf(pl + kd + qd), e);
         }
     }
 #pragma unroll
@@ -253,15 +264,20 @@ __global__ __launch_bounds__(256) void k_taco_lsa_ctx(LsaArgs a) {
     const int c = blockIdx.y * 256 + tid;
     if (c < a.E) {
         const float* mp = a.mem + s0 * a.E + c;
+        // (sixteen memory rows in flight: with four the 129-token walk was 32 dependent round trips)
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int t = 0;
-        for (; t + 3 < T; t += 4) {
-            a0 = fmaf(sc[t], mp[(long)t * a.E], a0);
-            a1 = fmaf(sc[t + 1], mp[(long)(t + 1) * a.E], a1);
-            a2 = fmaf(sc[t + 2], mp[(long)(t + 2) * a.E], a2);
-            a3 = fmaf(sc[t + 3], mp[(long)(t + 3) * a.E], a3);
+        for (int t0 = 0; t0 < T; t0 += 16) {
+            float mv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mv[i] = mp[(long)min(t0 + i, T - 1) * a.E];
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                a0 = fmaf(t0 + i < T ? sc[t0 + i] : 0.f, mv[i], a0);
+                a1 = fmaf(t0 + i + 1 < T ? sc[t0 + i + 1] : 0.f, mv[i + 1], a1);
+                a2 = fmaf(t0 + i + 2 < T ? sc[t0 + i + 2] : 0.f, mv[i + 2], a2);
+                a3 = fmaf(t0 + i + 3 < T ? sc[t0 + i + 3] : 0.f, mv[i + 3], a3);
+            }
         }
-        for (; t < T; ++t) a0 = fmaf(sc[t], mp[(long)t * a.E], a0);
         const float acc = ((a0 + a1) + (a2 + a3)) * inv;
         a.ctx1[(long)b * a.ld1 + c] = acc;
         a.ctx2[(long)b * a.ld2 + c] = acc;
