@@ -168,9 +168,13 @@ __global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
     // 13 of the launch's 15 us; F <= 64, Da <= 256, F * Da <= 8192 here, else from memory as before)
     __shared__ __attribute__((aligned(16))) float wl[8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float wcs[64 * 2 * 33];   // location_conv [F][2][K] likewise (K <= 33: the launcher checks)
     const bool wl_lds = a.F * a.Da <= 8192 && (a.F * a.Da) % 4 == 0;
     if (wl_lds)
         for (int i = tid * 4; i < a.F * a.Da; i += 1024) *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(a.Wloc + i);
+    const bool wc_lds = a.F * 2 * a.K <= 64 * 2 * 33;
+    if (wc_lds)
+        for (int i = tid; i < a.F * 2 * a.K; i += 256) wcs[i] = a.Wconv[i];
     const int r = blockIdx.x * 4 + wave;
     const int b = r < a.rows ? a.row_utt[r] : -1;
     const bool valid = b >= 0;   // wave-uniform
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
     }
     __syncthreads();
     if (valid && lane < F) {
-        const float* wc = a.Wconv + (long)lane * 2 * K;
+        const float* wc = wc_lds ? wcs + lane * 2 * K : a.Wconv + (long)lane * 2 * K;
         float acc = 0.f;
         for (int k = 0; k < K; ++k) {
             acc = fmaf(wc[k], win[wave][0][k], acc);
