@@ -164,17 +164,10 @@ struct LsaArgs {
 __global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
     __shared__ float win[4][2][64];   // per wave: the attw / cum window t - pad .. t + pad
     __shared__ float loc[4][64];      // per wave: location_conv output of its row
-    // location_layer [F][Da] in LDS (round 4: read from memory inside the f loop it was 2 F dependent round trips per lane --
-    // 13 of the launch's 15 us; F <= 64, Da <= 256, F * Da <= 8192 here, else from memory as before)
-    __shared__ __attribute__((aligned(16))) float wl[8192];
+    // (Round 4: location_layer and location_conv weights staged in LDS per workgroup instead of read through L1 inside the
+    // loops: 15.2 -> 15.6 us with the first, 18.5 with both -- a workgroup is four memory rows, the staging costs what it saves
+    // and the 52 KB halve the resident workgroups.  Left as it was.)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ float wcs[64 * 2 * 33];   // location_conv [F][2][K] likewise (K <= 33: the launcher checks)
-    const bool wl_lds = a.F * a.Da <= 8192 && (a.F * a.Da) % 4 == 0;
-    if (wl_lds)
-        for (int i = tid * 4; i < a.F * a.Da; i += 1024) *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(a.Wloc + i);
-    const bool wc_lds = a.F * 2 * a.K <= 64 * 2 * 33;
-    if (wc_lds)
-        for (int i = tid; i < a.F * 2 * a.K; i += 256) wcs[i] = a.Wconv[i];
     const int r = blockIdx.x * 4 + wave;
     const int b = r < a.rows ? a.row_utt[r] : -1;
     const bool valid = b >= 0;   // wave-uniform
@@ -194,9 +187,10 @@ __global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
     }
     __syncthreads();
     if (valid && lane < F) {
-        const float* wc = wc_lds ? wcs + lane * 2 * K : a.Wconv + (long)lane * 2 * K;
+        const float* wc = a.Wconv + (long)lane * 2 * K;
         float acc = 0.f;
-        for (int k = 0; k < K; ++k) {
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {   // (unrolled: eight pairs of weight loads in flight instead of one)
             acc = fmaf(wc[k], win[wave][0][k], acc);
             acc = fmaf(wc[K + k], win[wave][1][k], acc);
         }
@@ -209,11 +203,8 @@ __global__ __launch_bounds__(256) void k_taco_lsa_energy(LsaArgs a) {
         for (int d = lane; d < Da; d += 64) {
             const float vd = a.v[d], kd = a.pkey[(long)r * Da + d], qd = pq[d];   // (requested before the f loop)
             float pl = 0.f;
-            if (wl_lds) {
-                for (int f = 0; f < F; ++f) pl = fmaf(loc[wave][f], wl[f * Da + d], pl);
-            } else {
-                for (int f = 0; f < F; ++f) pl = fmaf(loc[wave][f], a.Wloc[(long)f * Da + d], pl);
-            }
+#pragma unroll 8
+            for (int f = 0; f < F; ++f) pl = fmaf(loc[wave][f], a.Wloc[(long)f * Da + d], pl);
             e = fmaf(vd, tanhf(pl + kd + qd), e);
         }
     }
