@@ -293,3 +293,50 @@ def test_fs2_error_mapping():
         m.inference(np.array([1, 2, 999]))          # id out of range
     with pytest.raises(AssertionError):
         m.inference(np.array([1, 2, 3]), alpha=0.0)  # assert alpha > 0 (length_regulator.py:86)
+
+
+def _cancelling_values_state(cfg, seed, gain):
+    """A model whose attention contexts are far below the bound the engine scales them by (|ctx| <= max|v|): two tokens with
+    embeddings +gain u and -gain u alternate, every linear_k is zero (uniform attention), so the values of an utterance alternate
+    in sign at full magnitude and their mean -- the context -- is what the positional encoding leaves: a factor ~gain smaller."""
+    st = {k: np.array(v, dtype=np.float32, copy=True)
+          for k, v in syn.fastspeech2_state(80, 80, cfg, seed=seed, fixed_duration=5).items()}
+    rng = np.random.default_rng(seed + 1)
+    u = rng.standard_normal(cfg["adim"]).astype(np.float32)
+    u /= np.linalg.norm(u) / np.sqrt(cfg["adim"])
+    st["encoder.embed.0.weight"][1] = gain * u
+    st["encoder.embed.0.weight"][2] = -gain * u
+    for stack, n in (("encoder", cfg["elayers"]), ("decoder", cfg["dlayers"])):
+        for i in range(n):
+            st[f"{stack}.encoders.{i}.self_attn.linear_k.weight"][:] = 0
+            st[f"{stack}.encoders.{i}.self_attn.linear_k.bias"][:] = 0
+    return st
+
+
+@pytest.mark.parametrize("gain", [16.0, 1024.0])
+def test_fs2_cancelling_values_under_uniform_attention(gain):
+    """VERDICT r3 #2, second half: the row scales of the split-fp16 path come from magnitude BOUNDS (|ctx| <= max|v| for the
+    attention context, c1 max|x| + c0 for a layer's output), and a value far below its bound loses bits.  Hostile case for the
+    context bound: values that cancel under uniform attention (overshoot ~ gain).  The bounds are per row and per layer -- not
+    cumulative -- and the exact-fp32 evaluation of a cancelling sum has an absolute error relative to the SAME magnitude, so the
+    split path must stay at the exact path's error: 2 x + 5e-7 against the fp64 oracle, durations bit-equal."""
+    from oracle import fastspeech2_ref as ref
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    cfg = _cfg()
+    state = _cancelling_values_state(cfg, 170, gain)
+    ids = np.array([1, 2] * 32, dtype=np.int64)
+    want, parts = ref.inference(state, ids, _oracle_cfg(cfg), dtype=torch.float64, return_parts=True)
+    want = want.numpy()
+    model = FastSpeech2(80, 80, **cfg)
+    model.set_state_dict(state)
+    model.eval()
+    model.set_debug(True)
+    l1 = {}
+    for mode in ("f32", "f16x3"):
+        model.set_math(mode)
+        got = model.inference(ids).numpy()
+        np.testing.assert_array_equal(model.debug_tap(3, 0), parts["d"].numpy())
+        assert got.shape == want.shape
+        l1[mode] = float(np.abs(got - want).mean())
+    assert l1["f32"] < 2e-5, l1
+    assert l1["f16x3"] < 2.0 * l1["f32"] + 5e-7, l1
