@@ -310,7 +310,27 @@ def _cancelling_values_state(cfg, seed, gain):
         for i in range(n):
             st[f"{stack}.encoders.{i}.self_attn.linear_k.weight"][:] = 0
             st[f"{stack}.encoders.{i}.self_attn.linear_k.bias"][:] = 0
+            st[f"{stack}.encoders.{i}.self_attn.linear_v.bias"][:] = 0     # (constant terms of v would not cancel)
+            st[f"{stack}.encoders.{i}.norm1.bias"][:] = 0
     return st
+
+
+def _context_overshoot(state, cfg, ids):
+    """max|v| / max|context| of encoder layer 0 under uniform attention, in fp64 (what the engine's bound is loose by)."""
+    A = cfg["adim"]
+    emb = torch.tensor(state["encoder.embed.0.weight"], dtype=torch.float64)[torch.as_tensor(ids)]
+    pos = torch.arange(len(ids), dtype=torch.float64)[:, None]
+    div = torch.exp(torch.arange(0, A, 2, dtype=torch.float64) * -(np.log(10000.0) / A))
+    pe = torch.zeros(len(ids), A, dtype=torch.float64)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    x = emb + float(state["encoder.embed.1.alpha"][0]) * pe
+    p = "encoder.encoders.0."
+    xn = torch.nn.functional.layer_norm(x, (A,), torch.tensor(state[p + "norm1.weight"], dtype=torch.float64),
+                                        torch.tensor(state[p + "norm1.bias"], dtype=torch.float64), 1e-12)
+    v = xn @ torch.tensor(state[p + "self_attn.linear_v.weight"], dtype=torch.float64) + torch.tensor(state[p + "self_attn.linear_v.bias"], dtype=torch.float64)
+    ctx = v.mean(0)
+    return float(v.abs().max() / ctx.abs().max())
 
 
 @pytest.mark.parametrize("gain", [16.0, 1024.0])
@@ -325,6 +345,7 @@ def test_fs2_cancelling_values_under_uniform_attention(gain):
     cfg = _cfg()
     state = _cancelling_values_state(cfg, 170, gain)
     ids = np.array([1, 2] * 32, dtype=np.int64)
+    assert _context_overshoot(state, cfg, ids) > 0.25 * gain      # (the construction does what it says: the bound is loose by ~gain)
     want, parts = ref.inference(state, ids, _oracle_cfg(cfg), dtype=torch.float64, return_parts=True)
     want = want.numpy()
     model = FastSpeech2(80, 80, **cfg)
