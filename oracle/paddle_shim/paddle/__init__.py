@@ -283,6 +283,44 @@ def seed(s):
     torch.manual_seed(s)
 
 
+def load(path, **configs):
+    """``paddle.load`` of Paddle 2.1.x for pickled archives (python/paddle/framework/io.py: ``load`` ->
+    ``_pickle_loads_mac`` / ``pickle.load(f, encoding='latin1')`` -> ``_pack_loaded_dict`` -> ``_parse_load_result`` /
+    drop of the ``StructuredToParameterName@@`` table): nested containers come back with a Tensor at every leaf that was
+    saved as one -- bare ndarrays of a ``_legacy_save`` state dict, the ``(tensor_name, ndarray)`` pairs of
+    ``_pickle_save``, and LoDTensor leaves (pickled as ``eval('data', {'data': ndarray})``, which unpickling evaluates).
+    [paddle-format, documentation-derived like the rest of this package; tools/verify_with_paddle.py swaps in the real one.]
+    The stand-in only ever reads archives this repository wrote (tools/make_paddle_fixture.py), so plain pickle is fine."""
+    import pickle
+    with open(path, "rb") as f:
+        obj = pickle.load(f, encoding="latin1")
+
+    def pack(d):
+        info = d.get("UnpackBigParamInfor@@")
+        if isinstance(info, dict):
+            d = dict(d)
+            for key, desc in info.items():
+                parts = [np.asarray(d.pop(n)).reshape(-1) for n in desc["slices"]]
+                d[key] = np.concatenate(parts).reshape(tuple(desc["OriginShape"]))
+            d.pop("UnpackBigParamInfor@@")
+        return d
+
+    def parse(o):
+        if isinstance(o, np.ndarray):
+            return to_tensor(o)
+        if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], str) and isinstance(o[1], np.ndarray):
+            t = to_tensor(o[1])
+            t._pk_name = o[0]
+            return t
+        if isinstance(o, dict):
+            o = pack(o)
+            return type(o)((k, parse(v)) for k, v in o.items() if k != "StructuredToParameterName@@")
+        if isinstance(o, (list, tuple)):
+            return type(o)(parse(v) for v in o)
+        return o
+    return parse(obj)
+
+
 from . import nn  # noqa: E402,F401
 
 

@@ -30,6 +30,29 @@ def pytest_configure(config):
         harness.install()
 
 
+# ---- goldens produced by PaddlePaddle itself (tools/verify_with_paddle.py with PARAKEET_REAL_PADDLE=1) ---------------------
+# tests/golden/ = the reference's source over oracle/paddle_shim (the only thing that runs in the build image);
+# tests/golden_paddle/ = the same generators over real Paddle, same file names and keys.  When that directory exists every
+# test of the modules below runs twice: [standin] and [paddle] (the module's GOLD points at the other directory).
+GOLDEN_PADDLE = os.path.join(ROOT, "tests", "golden_paddle")
+GOLDEN_MODULES = ("test_golden_cpu", "test_golden_gpu", "test_ar_golden_cpu", "test_tts_gpu", "test_taco2_gpu",
+                  "test_speedyspeech_gpu")
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split(".")[-1] in GOLDEN_MODULES and os.path.isdir(GOLDEN_PADDLE) \
+            and "golden_source" in metafunc.fixturenames:
+        metafunc.parametrize("golden_source", ["standin", "paddle"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def golden_source(request, monkeypatch):
+    which = getattr(request, "param", "standin")
+    if which == "paddle":
+        monkeypatch.setattr(request.module, "GOLD", GOLDEN_PADDLE)
+    return which
+
+
 def _has_gpu():
     try:
         import torch

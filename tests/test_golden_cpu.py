@@ -90,7 +90,9 @@ def test_speedyspeech_oracle_matches_reference_source():
     from oracle import speedyspeech_ref as ssr
     g = np.load(os.path.join(GOLD, "speedyspeech_baker.npz"))
     state = syn.speedyspeech_state(seed=int(g["seed"]))
-    for tag, quirk in (("rd", True), ("dil", False)):
+    tags = [(t, q) for t, q in (("rd", True), ("dil", False)) if f"{t}_mel0" in g.files]
+    assert tags, "real Paddle agreed with neither reading of padding='same' (tools/make_golden_speedyspeech.py)"
+    for tag, quirk in tags:       # the stand-in file holds both readings, a file made by real Paddle the one it implements
         for i in range(3):
             mel = ssr.inference(state, g[f"{tag}_text{i}"], g[f"{tag}_tones{i}"],
                                 same_padding_resets_dilation=quirk).numpy()
@@ -101,7 +103,7 @@ def test_speedyspeech_oracle_matches_reference_source():
         assert np.abs(logmel - g[f"{tag}_logmel0"]).max() < 2e-5
         nt = ssr.inference(state, g[f"{tag}_text1"], None, same_padding_resets_dilation=quirk).numpy()
         assert nt.shape == g[f"{tag}_notone_mel"].shape and np.abs(nt - g[f"{tag}_notone_mel"]).max() < 2e-5
-    assert g["rd_mel2"].shape != g["dil_mel2"].shape or np.abs(g["rd_mel2"] - g["dil_mel2"]).max() > 1e-2
+    assert len(tags) < 2 or g["rd_mel2"].shape != g["dil_mel2"].shape or np.abs(g["rd_mel2"] - g["dil_mel2"]).max() > 1e-2
 
 
 def test_pwg_oracle_matches_reference_source():

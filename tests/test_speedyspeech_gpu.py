@@ -25,6 +25,8 @@ def test_engine_matches_reference_source(tag, quirk):
     from parakeet_amd.normalizer import ZScore
     from parakeet_amd.speedyspeech import SpeedySpeechInference
     g = np.load(os.path.join(GOLD, "speedyspeech_baker.npz"))
+    if f"{tag}_mel0" not in g.files:
+        pytest.skip("a file made by real Paddle holds only the reading Paddle implements")
     m = _model(quirk, int(g["seed"]))
     for i in range(3):
         mel = m.inference(g[f"{tag}_text{i}"], g[f"{tag}_tones{i}"]).numpy()

@@ -17,11 +17,11 @@ sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
 
 ref_import.setup()
-import paddle  # noqa: E402  (the shim)
+import paddle  # noqa: E402  (oracle/paddle_shim, or PaddlePaddle itself under PARAKEET_REAL_PADDLE=1)
 
 from parakeet_amd import synthetic as syn  # noqa: E402
 
-OUT = os.path.join(ref_import.ROOT, "tests", "golden")
+OUT = ref_import.golden_dir()   # tests/golden (stand-in) or tests/golden_paddle (PARAKEET_REAL_PADDLE=1)
 
 
 def golden_fastspeech2():
@@ -166,16 +166,11 @@ def golden_pwg():
     # inference(c) with the in-call randn replaced by a recorded draw
     mel = rng.normal(size=(3, 80)).astype(np.float32)
     noise = rng.normal(size=(1, 1, 3 * 256)).astype(np.float32)
-    orig = paddle.randn
-    paddle.randn = lambda shape, dtype=None: paddle.to_tensor(noise.reshape([int(s) for s in shape]))
     mu, sigma = syn.mel_stats(seed=8)
-    try:
-        with paddle.no_grad():
-            out["inf_wav"] = gen.inference(paddle.to_tensor(mel)).numpy().astype(np.float32)
-            pinf = pw.PWGInference(norm.ZScore(paddle.to_tensor(mu), paddle.to_tensor(sigma)), gen)
-            out["pinf_wav"] = pinf(paddle.to_tensor(mel * sigma + mu)).numpy().astype(np.float32)
-    finally:
-        paddle.randn = orig
+    with ref_import.fixed_randn(noise), paddle.no_grad():
+        out["inf_wav"] = gen.inference(paddle.to_tensor(mel)).numpy().astype(np.float32)
+        pinf = pw.PWGInference(norm.ZScore(paddle.to_tensor(mu), paddle.to_tensor(sigma)), gen)
+        out["pinf_wav"] = pinf(paddle.to_tensor(mel * sigma + mu)).numpy().astype(np.float32)
     out["inf_mel"], out["inf_noise"], out["mu"], out["sigma"] = mel, noise.reshape(-1), mu, sigma
     np.savez_compressed(os.path.join(OUT, "pwg_ljspeech.npz"), **out)
     print("pwg:", out["fwd_y"].shape, out["inf_wav"].shape)
@@ -189,9 +184,5 @@ if __name__ == "__main__":
     golden_fastspeech2_tones()
     golden_fastspeech2_block_variants()
     golden_pwg()
-    if "--with-waveflow" in sys.argv or True:
-        try:
-            from make_golden_waveflow import golden_waveflow
-            golden_waveflow(OUT)
-        except ImportError:
-            pass
+    from make_golden_waveflow import golden_waveflow
+    golden_waveflow(OUT)

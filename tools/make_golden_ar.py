@@ -12,22 +12,20 @@ import os
 import sys
 
 import numpy as np
-import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
 
 ref_import.setup()
-import paddle  # noqa: E402  (the shim)
-import paddle.nn.functional as PF  # noqa: E402
+import paddle  # noqa: E402  (stand-in or real, see ref_import)
 
 from oracle import philox_ref  # noqa: E402
 from oracle import tacotron2_ref as t2_ref  # noqa: E402
 from oracle import transformer_tts_ref as tt_ref  # noqa: E402
 from parakeet_amd import synthetic as syn  # noqa: E402
 
-OUT = os.path.join(ref_import.ROOT, "tests", "golden")
+OUT = ref_import.golden_dir()
 
 
 class TransformerTTSDropout:
@@ -38,12 +36,11 @@ class TransformerTTSDropout:
         self.drop = tt_ref.stream_dropout(seed, n_layers, units)
         self.n_layers, self.calls = n_layers, 0
 
-    def __call__(self, x, p):
-        assert p == 0.5 and x.dim() == 3 and x.shape[0] == 1
+    def __call__(self, shape, p):
+        assert p == 0.5 and len(shape) == 3 and shape[0] == 1
         layer = self.calls % self.n_layers
         self.calls += 1
-        keep = torch.as_tensor(self.drop(int(x.shape[1]), layer, int(x.shape[1]), int(x.shape[2])))
-        return torch.where(keep.unsqueeze(0), x / (1.0 - p), torch.zeros_like(x))
+        return np.asarray(self.drop(shape[1], layer, shape[1], shape[2]))[None]
 
 
 sys.path.insert(0, os.path.join(ref_import.ROOT, "tests"))
@@ -68,13 +65,10 @@ def golden_transformer_tts():
         if cfg.get("use_gst"):
             speech = np.random.default_rng(950 + seed).standard_normal((70, 80)).astype(np.float32)
             out[f"{name}_speech"] = speech
-        PF.DROPOUT_HOOK = TransformerTTSDropout(seed=seed, n_layers=max(cfg["dprenet_layers"], 1), units=cfg["dprenet_units"])
-        try:
-            with paddle.no_grad():
-                mel, probs, att = model.inference(paddle.to_tensor(ids), spembs=None if spemb is None else paddle.to_tensor(spemb),
-                                                  speech=None if speech is None else paddle.to_tensor(speech), **kw)
-        finally:
-            PF.DROPOUT_HOOK = None
+        hook = TransformerTTSDropout(seed=seed, n_layers=max(cfg["dprenet_layers"], 1), units=cfg["dprenet_units"])
+        with ref_import.dropout_hook(hook), paddle.no_grad():
+            mel, probs, att = model.inference(paddle.to_tensor(ids), spembs=None if spemb is None else paddle.to_tensor(spemb),
+                                              speech=None if speech is None else paddle.to_tensor(speech), **kw)
         out[f"{name}_ids"] = ids
         out[f"{name}_seed"] = np.array(seed)
         out[f"{name}_mel"] = mel.numpy().astype(np.float32)
@@ -93,12 +87,11 @@ class Tacotron2Dropout:
         self.drop = t2_ref.stream_dropout(seed, units, p)
         self.p, self.calls = p, 0
 
-    def __call__(self, x, p):
-        assert p == self.p and x.dim() == 2 and x.shape[0] == 1
+    def __call__(self, shape, p):
+        assert p == self.p and len(shape) == 2 and shape[0] == 1
         step, layer = divmod(self.calls, 2)
         self.calls += 1
-        keep = torch.as_tensor(self.drop(step, layer, int(x.shape[1])))
-        return torch.where(keep.unsqueeze(0), x / (1.0 - p), torch.zeros_like(x))
+        return np.asarray(self.drop(step, layer, shape[1]))[None]
 
 
 def golden_tacotron2():
@@ -114,14 +107,10 @@ def golden_tacotron2():
         ids = rng.integers(1, cfg["vocab_size"], size=(1, T)).astype(np.int64)
         tones = rng.integers(0, cfg["n_tones"], size=(1, T)).astype(np.int64) if cfg["n_tones"] else None
         gc = rng.standard_normal((1, cfg["d_global_condition"])).astype(np.float32) if cfg.get("d_global_condition") else None
-        PF.DROPOUT_HOOK = Tacotron2Dropout(seed, cfg["d_prenet"], cfg["p_prenet_dropout"])
-        try:
-            with paddle.no_grad():
-                o = model.infer(paddle.to_tensor(ids), max_decoder_steps=max_steps,
-                                tones=None if tones is None else paddle.to_tensor(tones),
-                                global_condition=None if gc is None else paddle.to_tensor(gc))
-        finally:
-            PF.DROPOUT_HOOK = None
+        with ref_import.dropout_hook(Tacotron2Dropout(seed, cfg["d_prenet"], cfg["p_prenet_dropout"])), paddle.no_grad():
+            o = model.infer(paddle.to_tensor(ids), max_decoder_steps=max_steps,
+                            tones=None if tones is None else paddle.to_tensor(tones),
+                            global_condition=None if gc is None else paddle.to_tensor(gc))
         out[f"{name}_ids"] = ids[0]
         if tones is not None:
             out[f"{name}_tones"] = tones[0]

@@ -6,7 +6,7 @@ import numpy as np
 import ref_import
 
 ref_import.setup()
-import paddle  # noqa: E402  (the shim)
+import paddle  # noqa: E402  (stand-in or real, see ref_import)
 
 from parakeet_amd import synthetic as syn  # noqa: E402
 
@@ -29,12 +29,7 @@ def golden_waveflow(out_dir):
     for f in cfg["upsample_factors"]:
         t = f * t - f
     z = rng.normal(size=(2, t)).astype(np.float32)
-    orig = paddle.randn
-    paddle.randn = lambda shape, dtype=None: paddle.to_tensor(z.reshape([int(s) for s in shape]))
-    try:
-        with paddle.no_grad():
-            wav = model.infer(paddle.to_tensor(mel)).numpy().astype(np.float32)
-    finally:
-        paddle.randn = orig
+    with ref_import.fixed_randn(z), paddle.no_grad():
+        wav = model.infer(paddle.to_tensor(mel)).numpy().astype(np.float32)
     np.savez_compressed(os.path.join(out_dir, "waveflow_c64.npz"), seed=np.array(314), mel=mel, z=z, wav=wav)
     print("waveflow:", wav.shape)
