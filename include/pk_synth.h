@@ -155,11 +155,19 @@ int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples);
  *   "scale_guard"  0 = off; 1 (default) = the FIRST inference after pk_pwg_finalize also measures max|x| per utterance and
  *                  layer on the planes path, and when the a-priori bound overshoots the measured maximum by more than
  *                  2^10 anywhere, the call is repeated on the "planes" = 0 path, which the handle then keeps; 2 = every call.
+ *                  A guarded call synchronises the stream once and does two small blocking copies INSIDE pk_pwg_infer: the
+ *                  first call after finalize stalls a pipelined caller and must not be stream-captured.
+ *                  Under 1 every "scale_guard_every"-th later inference is SAMPLED as well (same 31 small launches), its
+ *                  verdict deferred: the maxima are copied to pinned host memory behind an event and judged at the start of
+ *                  a later call -- no stall; a verdict above 2^10 moves the handle to the "planes" = 0 path from then on
+ *                  (the sampled call keeps its result: at 2^10 the planes still carry 26 bits of the actual maximum).
+ *   "scale_guard_every"  the sampling period under "scale_guard" 1 (default 16; 0 = never re-sample).
  *                  pk_pwg_scale_overshoot reports what was measured. */
 int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value);
 /* log2(a-priori bound / measured max|x|) per layer input, l = 0 .. layers (n = layers + 1 floats), the maximum over the
- * utterances of the last guarded inference ("scale_guard"); *fell_back (nullable) = 1 when the handle has left the planes
- * path.  PK_ESTATE if no guarded inference has run. */
+ * utterances of the last guarded or sampled inference ("scale_guard"; a sample still in flight is waited for); *fell_back
+ * (nullable) = 1 when the handle has left the planes path inside a guarded call, 2 when a deferred sample moved it there.
+ * PK_ESTATE if no guarded inference has run. */
 int pk_pwg_scale_overshoot(pk_pwg* h, float* log2_overshoot, int32_t n, int32_t* fell_back);
 /* remove_weight_norm + packing into the kernels' layouts + upload. */
 int pk_pwg_finalize(pk_pwg* h);

@@ -1368,6 +1368,20 @@ struct pk_pwg {
     // measures max|x| per utterance and layer (k_pwg_planes_amax) and compares with the a-priori bound of k_pwg_tile_scales
     int scale_guard = 1;
     bool guard_done = false;   // mode 1: a guarded inference has run since finalize
+    // mode 1 also RE-SAMPLES: every guard_every-th inference on the planes path runs the same 31 measuring launches, but its
+    // verdict is DEFERRED -- maxima copied to pinned host memory behind an event, judged at the start of a later call -- so a
+    // pipelined caller never stalls after the first call.  A deferred verdict above the limit moves the handle to the
+    // fp32-x path from the next call on (the sampled call itself stays as computed: at the limit of 2^10 the planes still
+    // carry 26 bits of the actual maximum, see GUARD_MAX_LOG2).
+    int guard_every = 16;
+    int calls_since_sample = 0;
+    bool sample_pending = false;
+    hipEvent_t ev_sample = nullptr;
+    float* host_sample = nullptr;      // pinned: [layers + 1][B] maxima, then B noise maxima
+    size_t host_sample_cap = 0;
+    int sample_B = 0;
+    std::vector<int> sample_frames;
+    int deferred_fallbacks = 0;        // verdicts that arrived after their call (reported by pk_pwg_scale_overshoot's fell_back = 2)
     bool fell_back = false;    // the bound overshot by more than 2^GUARD_MAX_LOG2: the handle left the planes path
     std::vector<float> overshoot_log2;   // [layers + 1] of the last guarded inference (max over utterances)
     std::vector<float> cl_host;          // c_l of the bound, as uploaded to d_cl
@@ -1478,6 +1492,47 @@ extern "C" int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples) {
     return PK_OK;
 }
 
+// The verdict of a guarded / sampled inference: the bound (the recursion of k_pwg_tile_scales, on the host) against the measured
+// maxima am[l][b]; fills overshoot_log2 and returns the worst log2(bound / max|x|).
+static float pwg_guard_verdict(pk_pwg* h, const float* am, const float* nmax, int B, const int* frames) {
+    const int layers = (int)h->cl_host.size();
+    h->overshoot_log2.assign(layers + 1, 0.f);
+    float worst = 0.f;
+    for (int b = 0; b < B; ++b) {
+        if (frames[b] <= 0) continue;
+        float bound = std::fma(h->first_wmax, nmax[b], h->first_bmax) * 1.001f;
+        for (int l = 0; l <= layers; ++l) {
+            const float m = am[(size_t)l * B + b];
+            // (an all-zero stream has no precision to lose)
+            const float o = m > 0.f ? std::log2(bound / m) : 0.f;
+            h->overshoot_log2[l] = std::max(h->overshoot_log2[l], o);
+            worst = std::max(worst, o);
+            if (l < layers) bound = (bound + h->cl_host[l]) * (0.70710678118654752440f * 1.001f);
+        }
+    }
+    return worst;
+}
+
+constexpr float PWG_GUARD_MAX_LOG2 = 10.f;
+
+// A deferred sample whose copies have landed is judged here (start of every inference, and pk_pwg_scale_overshoot).
+static void pwg_poll_sample(pk_pwg* h, bool wait) {
+    if (!h->sample_pending) return;
+    if (wait) (void)hipEventSynchronize(h->ev_sample);
+    else if (hipEventQuery(h->ev_sample) != hipSuccess) {
+        (void)hipGetLastError();   // hipErrorNotReady is not an error
+        return;
+    }
+    h->sample_pending = false;
+    const int layers = (int)h->cl_host.size(), B = h->sample_B;
+    const float worst = pwg_guard_verdict(h, h->host_sample, h->host_sample + (size_t)(layers + 1) * B, B, h->sample_frames.data());
+    if (worst > PWG_GUARD_MAX_LOG2 && h->planes_on) {
+        h->planes_on = false;
+        h->fell_back = true;
+        ++h->deferred_fallbacks;
+    }
+}
+
 extern "C" int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value) {
     if (!h || !key) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: NULL argument");
     if (strcmp(key, "planes") == 0) {
@@ -1486,17 +1541,24 @@ extern "C" int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value) {
     } else if (strcmp(key, "scale_guard") == 0) {
         if (value < 0 || value > 2) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: scale_guard %lld (0, 1, 2)", (long long)value);
         h->scale_guard = (int)value;
+    } else if (strcmp(key, "scale_guard_every") == 0) {
+        if (value < 0 || value > (1 << 30)) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: scale_guard_every %lld", (long long)value);
+        h->guard_every = (int)value;
     } else PK_FAIL(PK_EINVAL, "pk_pwg_set_option: unknown option '%s'", key);
     return PK_OK;
 }
 
 extern "C" int pk_pwg_scale_overshoot(pk_pwg* h, float* log2_overshoot, int32_t n, int32_t* fell_back) {
     if (!h || !log2_overshoot) PK_FAIL(PK_EINVAL, "pk_pwg_scale_overshoot: NULL argument");
+    {
+        pk_device_guard _dg(h->ctx->device);
+        pwg_poll_sample(h, true);    // a sample still in flight is waited for: the report is of the LAST guarded or sampled call
+    }
     if (h->overshoot_log2.empty()) PK_FAIL(PK_ESTATE, "pk_pwg_scale_overshoot: no guarded inference has run (option \"scale_guard\")");
     if (n != (int32_t)h->overshoot_log2.size())
         PK_FAIL(PK_ESHAPE, "pk_pwg_scale_overshoot: expected %d floats (layers + 1)", (int)h->overshoot_log2.size());
     memcpy(log2_overshoot, h->overshoot_log2.data(), (size_t)n * sizeof(float));
-    if (fell_back) *fell_back = h->fell_back ? 1 : 0;
+    if (fell_back) *fell_back = h->fell_back ? (h->deferred_fallbacks > 0 ? 2 : 1) : 0;
     return PK_OK;
 }
 
@@ -1756,6 +1818,9 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         PK_TRY(pk_upload(ctx, h->d_cl, cl_h.data(), cl_h.size() * sizeof(float)));
         h->cl_host = cl_h;
         h->guard_done = false;   // new weights: the next inference is guarded again (scale_guard 1)
+        h->sample_pending = false;
+        h->calls_since_sample = 0;
+        h->deferred_fallbacks = 0;
         {   // bias image of the scaled path: stage-2 accumulators start from 2^14 * 2^k2 * bias
             std::vector<float> Bh(B);
             for (int l = 0; l < c.layers; ++l) {
@@ -1816,6 +1881,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_pwg_infer: batch size must be positive");
     pk_ctx* ctx = h->ctx;
     PK_DEVICE(ctx->device);
+    pwg_poll_sample(h, false);   // the verdict of an earlier sampled call, if its copies have landed (never waits)
     const pk_pwg_cfg& c = h->cfg;
     const int hop = h->hop, gap = h->gap;
     // ---- layout.  Utterances start on 256-sample boundaries (work tiles are 256-sample chunks of an utterance;
@@ -2010,10 +2076,17 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     // a guarded inference (option "scale_guard") measures max|x| per utterance and layer next to the a-priori bound; should
     // the bound overshoot by more than 2^GUARD_MAX_LOG2 the stack is run again on the fp32-x path (second pass of this loop:
     // the noise, the conditioning P and the zeroed gaps are all still in place), which the handle then keeps
-    constexpr float GUARD_MAX_LOG2 = 10.f;
+    constexpr float GUARD_MAX_LOG2 = PWG_GUARD_MAX_LOG2;
     const bool guard = planes && (h->scale_guard == 2 || (h->scale_guard == 1 && !h->guard_done));
+    // mode 1 after the first call: every guard_every-th inference measures too, verdict deferred (see the handle's comment)
+    bool sample = false;
+    if (planes && !guard && h->scale_guard == 1 && h->guard_every > 0 && !h->sample_pending &&
+        ++h->calls_since_sample >= h->guard_every) {
+        sample = true;
+        h->calls_since_sample = 0;
+    }
     unsigned* amax = nullptr;
-    if (guard) {
+    if (guard || sample) {
         PK_TRY(h->ws_amax.reserve((size_t)(c.layers + 1) * B * sizeof(unsigned)));
         amax = h->ws_amax.as<unsigned>();
         PK_HIP(hipMemsetAsync(amax, 0, (size_t)(c.layers + 1) * B * sizeof(unsigned), ctx->stream));
@@ -2139,33 +2212,38 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<true, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
             else
                 PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<false, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
-            if (guard && planes)
+            if ((guard || sample) && planes)
                 PK_LAUNCH(ctx, "pwg_planes_amax", k_pwg_planes_amax, dim3(ntile), dim3(256), 0, a.xout, a.tile_t0, a.gen.tile_utt,
                           a.tile_kx_out, amax + (size_t)(l + 1) * B);
         }
         }
         h->last_x_final = c.layers & 1;
     }
+    if (sample) {   // deferred verdict: the maxima travel to pinned memory behind an event; pwg_poll_sample judges them later
+        const size_t n_am = (size_t)(c.layers + 1) * B, need = (n_am + B) * sizeof(float);
+        if (h->host_sample_cap < need) {
+            if (h->host_sample) (void)hipHostFree(h->host_sample);
+            h->host_sample = nullptr;
+            h->host_sample_cap = 0;
+            PK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_sample), need, hipHostMallocDefault));
+            h->host_sample_cap = need;
+        }
+        if (!h->ev_sample) PK_HIP(hipEventCreateWithFlags(&h->ev_sample, hipEventDisableTiming));
+        PK_HIP(hipMemcpyAsync(h->host_sample, amax, n_am * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipMemcpyAsync(h->host_sample + n_am, h->ws_nmax.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipEventRecord(h->ev_sample, ctx->stream));
+        h->sample_B = B;
+        h->sample_frames.assign(frames, frames + B);
+        h->sample_pending = true;
+    }
     if (!(guard && attempt == 0)) break;
-    {   // the verdict of the guard: bound (the recursion of k_pwg_tile_scales, on the host) against the measured maxima
+    {   // the verdict of the guard, inside the call: one stream synchronisation and two small blocking copies -- this is the
+        // stall of the FIRST inference after finalize (and of every inference under scale_guard 2); not legal under stream capture
         std::vector<float> am((size_t)(c.layers + 1) * B), nmax(B);
         PK_HIP(hipStreamSynchronize(ctx->stream));
         PK_HIP(hipMemcpy(am.data(), amax, am.size() * sizeof(float), hipMemcpyDeviceToHost));
         PK_HIP(hipMemcpy(nmax.data(), h->ws_nmax.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost));
-        h->overshoot_log2.assign(c.layers + 1, 0.f);
-        float worst = 0.f;
-        for (int b = 0; b < B; ++b) {
-            if (frames[b] <= 0) continue;
-            float bound = std::fma(h->first_wmax, nmax[b], h->first_bmax) * 1.001f;
-            for (int l = 0; l <= c.layers; ++l) {
-                const float m = am[(size_t)l * B + b];
-                // (an all-zero stream has no precision to lose)
-                const float o = m > 0.f ? std::log2(bound / m) : 0.f;
-                h->overshoot_log2[l] = std::max(h->overshoot_log2[l], o);
-                worst = std::max(worst, o);
-                if (l < c.layers) bound = (bound + h->cl_host[l]) * (0.70710678118654752440f * 1.001f);
-            }
-        }
+        const float worst = pwg_guard_verdict(h, am.data(), nmax.data(), B, frames);
         h->guard_done = true;
         if (worst <= GUARD_MAX_LOG2) break;
         h->planes_on = false;
@@ -2286,5 +2364,7 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
                        &h->ws_mel, &h->ws_cin, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
                        &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab, &h->d_cl, &h->ws_nmax, &h->ws_tkx, &h->ws_amax};
     for (auto* b : bufs) b->release();
+    if (h->host_sample) (void)hipHostFree(h->host_sample);
+    if (h->ev_sample) (void)hipEventDestroy(h->ev_sample);
     delete h;
 }

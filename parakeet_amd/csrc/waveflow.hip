@@ -603,7 +603,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
             if (use_wfl) {
                 // the fused layer kernel (wf_layer.hip): conv taps + condition + gate + res projection + folded skip path.
                 // One launch runs `per` consecutive layers of this row: all NL behind grid barriers (option "persistent",
-                // the default wherever the barrier exists: 120 launches per batch instead of 960 + 120), or one; the launch that
+                // OFF by default -- 632 us per row against 8 x 57 us, DESIGN 4.3 -- 120 launches per batch instead of 960 + 120), or one; the launch that
                 // holds the last layer also finishes the row (the step: x[i], then the next row's layer-0 input).
                 WflLaunch w;
                 memset(&w, 0, sizeof(w));
@@ -759,12 +759,19 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     }
     PK_LAUNCH(ctx, "wf_unfold", k_wf_unfold, dim3(pk_div_up(npos, 256)), dim3(256), 0, cur, d_tab + o_putt,
               d_tab + o_pw, d_tab + o_ooff, G, npos, pstride, d_wav);
-    if (flags & PK_HOST_IO) {
+    // The row kernel's grid barrier gives up after a bounded spin and raises ws_bar[1]: a waveform computed past a timed-out
+    // barrier is garbage, so the flag is checked on EVERY path that ran the row kernel -- with device-resident output too,
+    // at the price of one 4-byte copy and a stream synchronisation (the option is off by default and slower than the
+    // per-layer launches; a caller who pipelines does not want it anyway).
+    const bool ran_row_kernel = h->persistent && use_wfl && pk_grid_available() && NL <= WFL_MAX_LAYERS && !d_trace;
+    if (flags & PK_HOST_IO) PK_HIP(hipMemcpyAsync(wav, d_wav, (size_t)sumO * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ran_row_kernel) {
         int berr = 0;
-        PK_HIP(hipMemcpyAsync(wav, d_wav, (size_t)sumO * 4, hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipMemcpyAsync(&berr, h->ws_bar.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipStreamSynchronize(ctx->stream));
         if (berr) PK_FAIL(PK_EHIP, "pk_wf_infer: a grid barrier of the row kernel timed out (code %d): the result is invalid", berr);
+    } else if (flags & PK_HOST_IO) {
+        PK_HIP(hipStreamSynchronize(ctx->stream));
     }
     return PK_OK;
 }

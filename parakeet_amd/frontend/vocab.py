@@ -3,19 +3,20 @@
 symbol table.  Ids are insertion positions: the special symbols that are set come first in the order pad, unk, start, end,
 then the caller's symbols in first-seen order.  ``stoi`` / ``itos`` / ``special_symbols`` are plain dict attributes kept in step
 by ``add_symbol`` -- callers of the reference read AND write them (``vocab.stoi[s] = i``), so they are neither copies nor
-read-only views."""
+read-only views (writing ``stoi`` directly leaves ``itos`` and ``len()`` behind, exactly as it does in the reference: use
+``add_symbol``).  The four ``*_symbol`` names are plain instance attributes as in the reference (:57-60), assignable; the
+``*_index`` properties look the CURRENT value up, -1 when the table does not hold it."""
 
 __all__ = ["Vocab"]
-
-_ROLES = ("padding", "unk", "start", "end")
 
 
 class Vocab:
     def __init__(self, symbols, padding_symbol="<pad>", unk_symbol="<unk>", start_symbol="<s>", end_symbol="</s>"):
-        self._role = dict(zip(_ROLES, (padding_symbol, unk_symbol, start_symbol, end_symbol)))
+        self.padding_symbol, self.unk_symbol = padding_symbol, unk_symbol
+        self.start_symbol, self.end_symbol = start_symbol, end_symbol
         self.stoi = {}                # symbol -> id (insertion ordered)
         self.itos = {}                # id -> symbol
-        self.add_symbols(s for s in self._role.values() if s)      # None / "" means "this table has no such symbol"
+        self.add_symbols(s for s in (padding_symbol, unk_symbol, start_symbol, end_symbol) if s)   # None / "": no such symbol
         self.special_symbols = dict(self.stoi)
         self.add_symbols(symbols)
 
@@ -45,17 +46,10 @@ class Vocab:
     def __len__(self):
         return len(self.stoi)
 
-    def _special(self, role):
-        return self.stoi.get(self._role[role], -1)
-
-    padding_symbol = property(lambda self: self._role["padding"])
-    unk_symbol = property(lambda self: self._role["unk"])
-    start_symbol = property(lambda self: self._role["start"])
-    end_symbol = property(lambda self: self._role["end"])
-    padding_index = property(lambda self: self._special("padding"))
-    unk_index = property(lambda self: self._special("unk"))
-    start_index = property(lambda self: self._special("start"))
-    end_index = property(lambda self: self._special("end"))
+    padding_index = property(lambda self: self.stoi.get(self.padding_symbol, -1))
+    unk_index = property(lambda self: self.stoi.get(self.unk_symbol, -1))
+    start_index = property(lambda self: self.stoi.get(self.start_symbol, -1))
+    end_index = property(lambda self: self.stoi.get(self.end_symbol, -1))
 
     def __contains__(self, symbol):
         return symbol in self.stoi

@@ -97,6 +97,7 @@ class PWGGenerator:
         out = np.zeros(self.layers + 1, np.float32)
         fb = C.c_int32(0)
         _capi.check(self._ctx.lib.pk_pwg_scale_overshoot(self._h, _capi.fptr(out), out.size, C.byref(fb)))
+        self.fell_back_code = int(fb.value)      # 1: inside a guarded call; 2: by the deferred verdict of a sampled later call
         return out, bool(fb.value)
 
     def set_chunk_samples(self, samples):

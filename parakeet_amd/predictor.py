@@ -24,6 +24,7 @@ files ``synthesize_e2e.py`` of each recipe takes as arguments) -- and ``create_p
     predictor = create_predictor(cfg)
 """
 import glob
+import re
 import os
 
 import numpy as np
@@ -106,12 +107,33 @@ _KINDS = {
 }
 
 
-def _first(model_dir, patterns, what, kind):
+def _iteration(path):
+    """Sort key of a snapshot: its LAST integer run (``snapshot_iter_10000.pdz`` > ``snapshot_iter_9999.pdz``; a plain
+    string sort puts them the other way round), then the name."""
+    runs = re.findall(r"\d+", os.path.basename(path))
+    return (int(runs[-1]) if runs else -1, os.path.basename(path))
+
+
+def _first(model_dir, patterns, what, kind, arg=None):
+    """``patterns``: most specific first.  In a directory that holds several model kinds (the reference's inference directories
+    do: speedyspeech.pdmodel next to pwg.pdmodel) a careless fall-back would silently load the OTHER model's weights or
+    statistics, so there: files that carry another kind's name never match, the catch-all patterns (``*.pdz``, ``*stats.npy``)
+    are not used, and the vocoder -- whose recipe prefixes every file with its name -- takes nothing but patterns that name it
+    (``snapshot_iter_*.pdz`` / ``speech_stats.npy`` / ``default.yaml`` are the ACOUSTIC recipes' names).  ``arg``: the Config
+    argument that names the file explicitly (None: the lookup is not kind-sensitive, e.g. the phone id map)."""
+    present = [k for k in _KINDS if glob.glob(os.path.join(model_dir, k + "*"))]
+    shared = arg is not None and len(set(present) | {kind}) > 1
+    others = tuple(k for k in _KINDS if k != kind)
     for pat in patterns:
-        hits = sorted(glob.glob(os.path.join(model_dir, pat)))
+        if shared and kind not in pat and (pat.startswith("*") or kind == "pwg"):
+            continue
+        hits = glob.glob(os.path.join(model_dir, pat))
+        if shared:
+            hits = [h for h in hits if not os.path.basename(h).startswith(others)]
         if hits:
-            return hits[-1]   # several snapshots: the last (highest iteration) one
-    raise FileNotFoundError(f"{kind}: no {what} in {model_dir} (looked for {', '.join(patterns)})")
+            return sorted(hits, key=_iteration)[-1]   # several snapshots: the highest iteration
+    hint = f"; {model_dir} holds several model kinds ({', '.join(present)}): pass {arg}=" if shared else ""
+    raise FileNotFoundError(f"{kind}: no {what} in {model_dir} (looked for {', '.join(patterns)}){hint}")
 
 
 class Config:
@@ -153,11 +175,11 @@ class Config:
     def resolve(self):
         k, d, a = self.model, self.model_dir, dict(self.artefacts)
         if a["config"] is None:
-            a["config"] = _first(d, [f"{k}.yaml", f"{k}_default.yaml", "default.yaml"], "yaml config", k)
+            a["config"] = _first(d, [f"{k}.yaml", f"{k}_default.yaml", "default.yaml"], "yaml config", k, "config")
         if a["checkpoint"] is None:
-            a["checkpoint"] = _first(d, [f"{k}*.pdz", f"{k}*.pdparams", "snapshot_iter_*.pdz", "*.pdz"], "checkpoint", k)
+            a["checkpoint"] = _first(d, [f"{k}*.pdz", f"{k}*.pdparams", "snapshot_iter_*.pdz", "*.pdz"], "checkpoint", k, "checkpoint")
         if a["stat"] is None:
-            a["stat"] = _first(d, [f"{k}_stats.npy", "speech_stats.npy", "*stats.npy"], "statistics file", k)
+            a["stat"] = _first(d, [f"{k}_stats.npy", "speech_stats.npy", "*stats.npy"], "statistics file", k, "stat")
         if k != "pwg":
             if a["phones_dict"] is None:
                 a["phones_dict"] = _first(d, ["phone_id_map.txt", "phones.txt"], "phone id map", k)

@@ -173,3 +173,18 @@ def test_transformer_tts_recipe_id_mapping():
     assert len(ids) == len(inner) and ids.dtype.kind == "i"
     assert [table.get(p, table[","]) for p in inner] == ids.tolist()
     assert table["!"] in ids.tolist() and table[","] in ids.tolist()          # punctuation survives
+
+
+def test_vocab_symbol_names_are_plain_attributes_like_the_reference():
+    """parakeet/frontend/vocab.py:57-60 stores the four special symbols as instance attributes: code that re-assigns them
+    (or reads them after changing the table) must work."""
+    from parakeet_amd.frontend.vocab import Vocab
+    v = Vocab(["a", "b"])
+    assert (v.padding_symbol, v.unk_symbol, v.start_symbol, v.end_symbol) == ("<pad>", "<unk>", "<s>", "</s>")
+    assert (v.padding_index, v.unk_index, v.start_index, v.end_index) == (0, 1, 2, 3) and v.num_specials == 4
+    v.unk_symbol = "b"
+    assert v.unk_index == v.lookup("b") == 5
+    v.end_symbol = "missing"
+    assert v.end_index == -1
+    w = Vocab(["x"], start_symbol=None, end_symbol=None)
+    assert w.start_index == -1 and w.end_index == -1 and len(w) == 3

@@ -73,3 +73,40 @@ def test_nets_utils_worked_examples():
     assert nu.source_mask([5, 3]).shape == (2, 1, 5)
     with pytest.raises(ValueError):
         nu.make_pad_mask([3], length_dim=0)
+
+
+def test_snapshot_choice_is_numeric_and_never_crosses_model_kinds(tmp_path):
+    """"snapshot_iter_9999" sorts after "snapshot_iter_10000" as a string; and in a directory that holds two
+    model kinds the catch-all patterns must not hand one model the other's files."""
+    from parakeet_amd.predictor import Config
+    d = tmp_path / "inference"
+    d.mkdir()
+    for name in ("speedyspeech.yaml", "snapshot_iter_9999.pdz", "snapshot_iter_10000.pdz", "speech_stats.npy", "phone_id_map.txt",
+                 "tone_id_map.txt"):
+        (d / name).write_bytes(b"")
+    a = Config(str(d / "speedyspeech.pdmodel")).resolve()
+    assert os.path.basename(a["checkpoint"]) == "snapshot_iter_10000.pdz"
+    # single-kind directory: the fall-backs still work for the vocoder (a bare pwg directory with odd names)
+    v = tmp_path / "voc"
+    v.mkdir()
+    for name in ("default.yaml", "gen.pdz", "feats_stats.npy"):
+        (v / name).write_bytes(b"")
+    p = Config(model="pwg", model_dir=str(v)).resolve()
+    assert [os.path.basename(p[k]) for k in ("config", "checkpoint", "stat")] == ["default.yaml", "gen.pdz", "feats_stats.npy"]
+    # shared directory without the vocoder's own files: refuse instead of taking the acoustic model's
+    (d / "pwg.pdmodel").write_bytes(b"")
+    import pytest
+    with pytest.raises(FileNotFoundError, match="several model kinds"):
+        Config(str(d / "pwg.pdmodel")).resolve()
+    (d / "pwg_default.yaml").write_bytes(b"")
+    (d / "pwg_snapshot_iter_400000.pdz").write_bytes(b"")
+    with pytest.raises(FileNotFoundError, match="stat="):
+        Config(str(d / "pwg.pdmodel")).resolve()
+    (d / "pwg_stats.npy").write_bytes(b"")
+    p = Config(str(d / "pwg.pdmodel")).resolve()
+    assert os.path.basename(p["checkpoint"]) == "pwg_snapshot_iter_400000.pdz" and os.path.basename(p["stat"]) == "pwg_stats.npy"
+    # and the acoustic model of that directory never sees the pwg_* files through a wildcard
+    (d / "snapshot_iter_9999.pdz").unlink()
+    (d / "snapshot_iter_10000.pdz").unlink()
+    with pytest.raises(FileNotFoundError):
+        Config(str(d / "speedyspeech.pdmodel")).resolve()

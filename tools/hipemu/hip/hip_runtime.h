@@ -87,6 +87,10 @@ static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, 
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t e);
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // everything issued has already run
+enum { hipHostMallocDefault = 0 };
+static inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 }
 template <class T>
