@@ -7,9 +7,19 @@ utterances are independent, so the path shards by utterance.
 in CPU tests) is used for exactly two things:
 
   * ``broadcast_state_dict`` -- one-time weight broadcast from rank 0
-    (FS2 148.5 MB + PWG 5.3 MB), as one flat buffer = one collective;
-  * ``gather_ragged`` -- collecting per-rank packed waveforms on every rank:
-    an all_gather of the lengths followed by one padded all_gather.
+    (FS2 148.5 MB + PWG 5.3 MB), as one flat device buffer = one collective.
+    What travels is the flat fp32 state, not the engine's packed image: ``finalize``
+    derives host-side quantities from the weights while it packs (scale bounds per
+    layer, folded ZScore / BatchNorm constants, the a-priori stream bound of the PWG
+    planes path), so every rank packs its own copy -- a second of host work per rank
+    at start-up, concurrent across ranks, never inside a timed step;
+  * ``gather_ragged_to`` -- result collection on ONE rank ("gather to
+    rank 0"): an all_gather of the lengths, then every other rank sends its packed
+    waveform straight to the destination, which posts all receives at once.  xGMI is
+    point to point (7 links per GPU), so 7 senders use 7 different links of rank 0
+    concurrently -- 21 MB per link instead of a ring's 8 x 21 MB through every link;
+  * ``gather_ragged`` -- the same data on EVERY rank (all_gather of the lengths + one
+    padded all_gather), for consumers that need it everywhere.
 
 No collective runs inside the timed synthesis step.
 """
@@ -77,3 +87,28 @@ def gather_ragged(local, lengths_local):
     bufs = [torch.empty(mx, dtype=torch.float32, device=dev) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return [bufs[r][: sizes[r]] for r in range(world)], meta
+
+
+def gather_ragged_to(local, lengths_local, dst=0):
+    """Collect per-rank packed 1-D float tensors of different sizes on rank `dst` only.
+    Returns (list of per-rank tensors, list of per-rank length lists) on `dst` -- element `dst` of the
+    list is `local` itself, not a copy -- and (None, lengths) on the other ranks.  Exact sizes travel
+    (no padding): grouped point-to-point sends, all receives posted together."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _comm_device()
+    meta = [None] * world
+    dist.all_gather_object(meta, [int(v) for v in lengths_local])
+    sizes = [int(sum(m)) for m in meta]
+    flat = local.reshape(-1).to(dev)
+    assert flat.numel() == sizes[rank], (flat.numel(), sizes[rank])
+    if rank != dst:
+        if sizes[rank] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat.contiguous(), dst)]):
+                w.wait()
+        return None, meta
+    bufs = [flat if r == dst else torch.empty(sizes[r], dtype=torch.float32, device=dev) for r in range(world)]
+    ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(world) if r != dst and sizes[r] > 0]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return bufs, meta

@@ -50,7 +50,7 @@ WORKER = textwrap.dedent("""
     costs = [5, 9, 3, 7, 4, 8]
     own = pdist.shard_indices(costs, world, rank)
     lens = [costs[i] * 2 for i in own]
-    local = torch.cat([torch.full((n,), float(i)) for i, n in zip(own, lens)])
+    local = torch.cat([torch.full((n,), float(i)) for i, n in zip(own, lens)]) if own else torch.zeros(0)
     bufs, meta = pdist.gather_ragged(local, lens)
     seen = {{}}
     for r in range(world):
@@ -63,23 +63,43 @@ WORKER = textwrap.dedent("""
             seen[i] = n
             o += n
     assert sorted(seen) == list(range(len(costs)))
+    # 3. the same collection on ONE rank (direct sends, exact sizes), any destination
+    for dst in (0, world - 1):
+        bufs1, meta1 = pdist.gather_ragged_to(local, lens, dst=dst)
+        assert meta1 == meta
+        if rank == dst:
+            assert len(bufs1) == world and bufs1[rank].data_ptr() == local.data_ptr()
+            for r in range(world):
+                assert torch.equal(bufs1[r], bufs[r]), r
+        else:
+            assert bufs1 is None
+    # a rank with nothing to send (more ranks than utterances) must not hang the others
+    empty = torch.zeros(0) if rank == world - 1 else local
+    b2, m2 = pdist.gather_ragged_to(empty, [] if rank == world - 1 else lens, dst=0)
+    if rank == 0:
+        assert b2[world - 1].numel() == 0 and m2[world - 1] == []
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
 """)
 
 
-def test_gloo_world2_broadcast_shard_gather(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_broadcast_shard_gather(tmp_path, world):
+    """world 2, and world 8 = the node the SCALE record will be taken on (6 utterances over 8 ranks: two ranks own nothing)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OMP_NUM_THREADS="1",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
-    for p in procs:
-        out, _ = p.communicate(timeout=240)
-        assert p.returncode == 0, out.decode()
-        assert b"ok" in out
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    bad = [f"--- rank {r} (rc {p.returncode})\n{o[-1500:]}" for r, (p, o) in enumerate(zip(procs, outs)) if p.returncode != 0]
+    assert not bad, "\n".join(bad)      # (the rank that failed FIRST is the one whose message is not "connection closed")
+    assert all("ok" in o for o in outs)
