@@ -348,6 +348,103 @@ def measurement_extras(synth, ctx, steps):
     return ex
 
 
+def text_to_wav_extra(synth, n=UTT_PER_GPU):
+    """VERDICT r4 "next" #5b / SURVEY 8f-3: the reference's whole request -- sentence -> English frontend -> ids -> FastSpeech2
+    -> PWG -> waveform on the host -> WAV bytes (examples/fastspeech2/ljspeech/synthesize_e2e.py:88-107) -- with wall-clock
+    per stage, as ONE batch of n sentences and as n single-sentence requests, frontend uncached and through the
+    CachedTextToIds memo.  The synthetic acoustic model emits 5 frames per phone, so audio length follows the text."""
+    from parakeet_amd.audio import wav_bytes
+    from parakeet_amd.frontend import ARPABET_PHONEMES, CachedTextToIds, English, text_to_ids
+    sync = torch.cuda.synchronize
+    words = ("the speech was read with one hundred and twenty of the world in two thousand nineteen and she paid three "
+             "dollars for this that we have not read to you or they all can be first from about five books").split()
+    rng = np.random.default_rng(2021)
+    sents = []
+    for i in range(n):
+        k = int(rng.integers(14, 26))
+        w = [words[int(j)] for j in rng.integers(0, len(words), size=k)]
+        w[int(rng.integers(0, k))] = str(int(rng.integers(3, 3000)))          # a number for the normaliser in every sentence
+        sents.append((" ".join(w[:k // 2]) + ", " + " ".join(w[k // 2:]) + ".").capitalize())
+    table = ["<pad>", "<unk>"] + sorted(p for p in ARPABET_PHONEMES if not p.startswith("<")) + ["sp", ",", ".", "?", "!", "<eos>"]
+    assert len(table) <= 80                                                   # the bench model's vocabulary (idim 80)
+    pmap = {p: i for i, p in enumerate(table)}
+    en = English()
+    clk = time.perf_counter
+
+    def frontend_ms(fn, reps=5):
+        ts = []
+        for _ in range(reps):
+            t = clk()
+            ids = fn()
+            ts.append((clk() - t) * 1e3)
+        return float(np.median(ts)), ids
+
+    fe_ms, ids = frontend_ms(lambda: [text_to_ids(en, s, pmap) for s in sents])
+    cache = CachedTextToIds(en, pmap)
+    cache.many(sents)
+    fe_cached_ms, ids_c = frontend_ms(lambda: cache.many(sents))
+    assert all(np.array_equal(a, b) for a, b in zip(ids, ids_c))
+    tokens = [int(len(i)) for i in ids]
+    hop_frames = FRAMES_PER_TOKEN * HOP
+
+    def synth_batch(batch_ids, stage):
+        t0 = clk()
+        wav, frames = synth.synthesize_packed(batch_ids)                       # noise drawn by the engine, as in the recipe
+        sync()
+        t1 = clk()
+        host = wav.cpu().numpy()
+        t2 = clk()
+        blobs, o = [], 0
+        for f in frames:
+            blobs.append(wav_bytes(host[o:o + int(f) * HOP], SAMPLE_RATE))
+            o += int(f) * HOP
+        t3 = clk()
+        stage["gpu_ms"] += (t1 - t0) * 1e3
+        stage["d2h_ms"] += (t2 - t1) * 1e3
+        stage["wav_encode_ms"] += (t3 - t2) * 1e3
+        return blobs
+
+    def run(batched, cached):
+        stage = {"frontend_ms": 0.0, "gpu_ms": 0.0, "d2h_ms": 0.0, "wav_encode_ms": 0.0}
+        t0 = clk()
+        if batched:
+            t = clk()
+            b = cache.many(sents) if cached else [text_to_ids(en, s, pmap) for s in sents]
+            stage["frontend_ms"] += (clk() - t) * 1e3
+            blobs = synth_batch(b, stage)
+        else:
+            blobs = []
+            for s in sents:
+                t = clk()
+                b = [cache(s) if cached else text_to_ids(en, s, pmap)]
+                stage["frontend_ms"] += (clk() - t) * 1e3
+                blobs += synth_batch(b, stage)
+        total = (clk() - t0) * 1e3
+        return total, stage, blobs
+
+    out = {"what": f"{n} English sentences ({min(tokens)}-{max(tokens)} phones, {sum(tokens)} in all -> {sum(tokens) * hop_frames} "
+                   "samples; parakeet_amd.frontend.English over the demonstration lexicon, one number per sentence) -> ids -> FastSpeech2 "
+                   "-> PWG (engine-drawn noise) -> waveform on the host -> 16-bit WAV bytes; wall-clock per stage, median of 5 passes "
+                   "after one warm-up pass; 'requests' = one sentence per engine call, the reference's loop",
+           "audio_seconds": sum(tokens) * hop_frames / SAMPLE_RATE, "frontend_ms_per_sentence_uncached": fe_ms / n,
+           "frontend_ms_per_sentence_cached": fe_cached_ms / n}
+    for name, batched, cached in (("one_batch", True, False), ("one_batch_cached_frontend", True, True),
+                                  ("requests", False, False), ("requests_cached_frontend", False, True)):
+        run(batched, cached)
+        passes = [run(batched, cached) for _ in range(5)]
+        passes.sort(key=lambda p: p[0])
+        total, stage, blobs = passes[len(passes) // 2]
+        ent = {"total_ms": total, "per_sentence_ms": total / n, "x_realtime": out["audio_seconds"] / (total * 1e-3)}
+        ent.update({k: v for k, v in stage.items()})
+        ent["frontend_share"] = stage["frontend_ms"] / total
+        ent["wav_bytes"] = int(sum(len(b) for b in blobs))
+        out[name] = ent
+    out["conclusion"] = ("frontend share of a single-sentence request: %.1f %% uncached, %.1f %% through the memo; of the batch: %.1f %%"
+                         % (100 * out["requests"]["frontend_share"], 100 * out["requests_cached_frontend"]["frontend_share"],
+                            100 * out["one_batch"]["frontend_share"]))
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -561,34 +658,54 @@ def main():
         dtp = (time.perf_counter() - t1) / args.steps
         pipeline_check["unpipelined_ms_per_step"] = dtp * 1e3
         pipeline_check["unpipelined_samples_per_s"] = n_samples / dtp
-    gather_ms = None
+    gather_ms = gather_all_ms = None
     if distributed:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # result collection: every rank's packed waveform of its last mini-batch on every rank --
-        # one all_gather of the lengths + one padded all_gather; timed on its own, never part of `value`
+        # result collection: every rank's packed waveform of its last mini-batch gathered on rank 0 --
+        # one all_gather of the lengths + direct sends of the exact sizes (gather_ragged_to); timed on its own, never part
+        # of `value`.  The all-ranks variant (padded all_gather) is timed next to it for consumers that need that.
         lens = [int(f) * HOP for f in frames]
-        pdist.gather_ragged(wav, lens)      # communicator / buffer warm-up
-        barrier()
-        sync()
-        tg = time.perf_counter()
-        bufs, meta = pdist.gather_ragged(wav, lens)
-        sync()
-        tgm = torch.tensor([time.perf_counter() - tg], device=dev, dtype=torch.float64)
-        dist.all_reduce(tgm, op=dist.ReduceOp.MAX)
-        gather_ms = float(tgm.item()) * 1e3
+
+        def timed_gather(fn):
+            fn()                            # communicator / buffer warm-up
+            barrier()
+            sync()
+            tg = time.perf_counter()
+            res = fn()
+            sync()
+            tgm = torch.tensor([time.perf_counter() - tg], device=dev, dtype=torch.float64)
+            dist.all_reduce(tgm, op=dist.ReduceOp.MAX)
+            return float(tgm.item()) * 1e3, res
+        gather_ms, (bufs, meta) = timed_gather(lambda: pdist.gather_ragged_to(wav, lens, dst=0))
+        if rank == 0:
+            assert [int(b.numel()) for b in bufs] == [sum(m) for m in meta] and len(bufs) == world
+        else:
+            assert bufs is None
+        gather_all_ms, (bufs, meta) = timed_gather(lambda: pdist.gather_ragged(wav, lens))
         assert [int(b.numel()) for b in bufs] == [sum(m) for m in meta] and len(bufs) == world
 
+    collectives = {
+        "in_the_timed_step": "none (utterances are independent: each rank synthesises its own shard)",
+        "weights": "once at start-up: the flat fp32 state of each model (FastSpeech2 148.5 MB, PWG 5.3 MB) from rank 0, one "
+                   "broadcast per model (torch.distributed.broadcast = ncclBroadcast over xGMI); every rank then packs its own "
+                   "engine image (finalize derives host-side bounds from the weights)" if distributed else "single process: none",
+        "results": "gather_ms: per-utterance lengths by all_gather_object, then every rank's packed waveform sent straight to "
+                   "rank 0 (grouped isend / irecv = ncclSend / ncclRecv, exact sizes: 7 senders use 7 different xGMI links of "
+                   "rank 0); gather_all_ms: the same data on every rank by one padded all_gather (ncclAllGather)"
+                   if distributed else "single process: none",
+    }
     if dry:
         if rank == 0:
             print(json.dumps({
                 "metric": "audio samples/sec, FastSpeech2+PWGAN 22.05kHz", "value": None, "unit": "samples/s",
                 "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "scaling": args.scaling, "gather_ms": gather_ms,
+                "gather_all_ms": gather_all_ms,
                 "config": {"global_batch": global_batch, "utterances_this_rank": len(own),
-                           "minibatches_per_step": len(chunks)}}))
+                           "minibatches_per_step": len(chunks), "collectives": collectives}}))
         if distributed:
             import torch.distributed as dist
             dist.barrier()
@@ -665,6 +782,11 @@ def main():
             extras.update(measurement_extras(synth, ctx, args.steps))
         except Exception as e:
             extras["measurement_extras"] = {"error": repr(e)}
+        try:   # text -> wav: the reference's whole request with the host side inside the clock
+            _log("extras: text -> wav")
+            extras["text_to_wav"] = text_to_wav_extra(synth)
+        except Exception as e:
+            extras["text_to_wav"] = {"error": repr(e)}
         try:   # the two acoustic models alone (BASELINE config 2 shape at 32 utterances; SpeedySpeech)
             t1 = time.perf_counter()
             for _ in range(args.steps):
@@ -787,7 +909,7 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (3-term split-fp16 MFMA, fp32-equivalent; exact-fp32 in roofline.exact_f32)",
             "dtype_note": "fp32 storage and accumulation everywhere; the dense contractions (PWG residual blocks and "
                           "last convs, FastSpeech2 Linear/Conv1D/attention) evaluate each fp32 product as a 3-term split-fp16 "
                           "MFMA sum (a_hi*b_hi + a_lo*b_hi + a_hi*b_lo) of BLOCK-SCALED operands (every operand block is "
@@ -807,6 +929,7 @@ def main():
                 "global_batch": global_batch,
                 "minibatch": mb,
                 "parallelism": f"dp{world} (utterance sharding, no data-path collective)",
+                "collectives": collectives,
                 "pipeline": ("acoustic model of the next step's batch issued on a side stream during this step's "
                              "vocoder (one acoustic + one vocoder pass per step)") if pipelined else "none",
             },
@@ -830,9 +953,22 @@ def main():
             "kernel_ms_per_step": {k: ms / prof_steps for k, (_, ms) in sorted(prof.items())},
             "kernel_ms_sum": total_prof_ms,
         }
+        ex32 = extras.get("all_exact_f32_mfma")
+        if ex32 and ex32.get("layer_kernel_avg_ms"):
+            # the strict-fp32 configuration of the SAME step (every contraction on v_mfma_f32_32x32x2_f32), where the driver's
+            # parser keeps it: its layer kernel is bound by the fp32 matrix pipe, not by HBM
+            out["roofline"]["exact_f32"] = {
+                "samples_per_s": ex32["samples_per_s"], "ms_per_step": ex32["ms_per_step"],
+                "layer_ms": ex32["layer_kernel_avg_ms"], "bound": "mfma",
+                "achieved_tflops": ex32["roofline"]["achieved"], "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                "frac_of_fp32_mfma": ex32["roofline"]["frac"],
+                "what": "pk_pwg_set_math / pk_fs2_set_math = F32: exact fp32 products, in order (no issue-ahead pipeline)"}
         if pipeline_check is not None:
             out["pipeline_check"] = pipeline_check
             out["value_unpipelined"] = pipeline_check["unpipelined_samples_per_s"]
+            out["values_together"] = {
+                "pipelined (value)": value, "in_order (value_unpipelined)": pipeline_check["unpipelined_samples_per_s"],
+                "in_order_host_materialised": (extras.get("host_io") or {}).get("samples_per_s")}
             out["value_note"] = ("`value` = steady-state throughput with the next batch's acoustic model issued during this "
                                  "batch's vocoder; `value_unpipelined` = the same step issued strictly in order (the latency-true "
                                  "figure); extras.host_io = with the waveform copied to host memory inside the step")
@@ -840,8 +976,10 @@ def main():
             out["extras"] = extras
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
-            out["gather_note"] = ("parakeet_amd.dist.gather_ragged of every rank's packed waveform (last mini-batch) "
-                                  "onto every rank: one all_gather of lengths + one padded RCCL all_gather; not in `value`")
+            out["gather_all_ms"] = gather_all_ms
+            out["gather_note"] = ("gather_ms: parakeet_amd.dist.gather_ragged_to -- every rank's packed waveform (last mini-batch) "
+                                  "collected on rank 0 by direct sends; gather_all_ms: gather_ragged -- the same on every rank (one "
+                                  "padded RCCL all_gather); neither is in `value` (config.collectives)")
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu_baseline (torch-CPU oracle, bounded)")
             rec, ref_mel, ref_wav = cpu_baseline(fs2_state, pwg_state, stats, texts_all[0], noise[:per_utt].cpu())

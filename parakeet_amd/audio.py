@@ -182,6 +182,14 @@ class LogMelFBank:
         return [wrap(o) for o in self._engine(base).run(list(wavs), 2)]
 
 
+def wav_bytes(wav, samplerate, subtype="PCM_16"):
+    """The bytes ``write_wav`` puts into the file (a serving process sends them instead of writing a file)."""
+    import io
+    buf = io.BytesIO()
+    write_wav(buf, wav, samplerate, subtype)
+    return buf.getvalue()
+
+
 def write_wav(path, wav, samplerate, subtype="PCM_16"):
     """Minimal stand-in for the ``soundfile.write(path, wav.numpy(), samplerate=fs)`` at the end of the
     synthesis recipes (examples/fastspeech2/ljspeech/synthesize_e2e.py:104-107): RIFF/WAVE, mono or
@@ -206,6 +214,10 @@ def write_wav(path, wav, samplerate, subtype="PCM_16"):
     header = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
         "<IHHIIHH", 16, fmt, ch, int(samplerate), int(samplerate) * block, block, bits) + b"data" + struct.pack(
         "<I", len(data))
+    if hasattr(path, "write"):       # a binary file object (wav_bytes)
+        path.write(header)
+        path.write(data)
+        return
     with open(path, "wb") as f:
         f.write(header)
         f.write(data)

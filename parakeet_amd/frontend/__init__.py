@@ -23,7 +23,7 @@ from .punctuation import get_punctuations
 from .normalizer import normalize, normalize_numbers, full2half_width, half2full_width
 from .g2p import LexiconG2p, ARPABET_PHONEMES
 from .phonectic import ARPABET, ARPABETWithStress, Chinese, English, EnglishCharacter, Phonetics
-from .phone_map import phones_to_ids, phones_to_ids_transformer_tts, read_phone_id_map, text_to_ids
+from .phone_map import CachedTextToIds, phones_to_ids, phones_to_ids_transformer_tts, read_phone_id_map, text_to_ids
 from .zh_frontend import Frontend, PinyinLexicon
 from .zh_normalization import TextNormalizer
 from .tone_sandhi import ToneSandhi
@@ -33,4 +33,4 @@ from .generate_lexicon import generate_lexicon
 __all__ = ["Vocab", "get_punctuations", "normalize", "normalize_numbers", "full2half_width", "half2full_width",
            "LexiconG2p", "ARPABET_PHONEMES", "ARPABET", "ARPABETWithStress", "English", "EnglishCharacter", "Phonetics", "phones_to_ids",
            "read_phone_id_map", "text_to_ids", "phones_to_ids_transformer_tts", "Frontend", "PinyinLexicon", "TextNormalizer", "ToneSandhi",
-           "ParakeetPinyin", "ParakeetPinyinWithTone", "generate_lexicon", "Chinese"]
+           "ParakeetPinyin", "ParakeetPinyinWithTone", "generate_lexicon", "Chinese", "CachedTextToIds"]

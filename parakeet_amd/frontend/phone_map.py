@@ -7,7 +7,7 @@ tokens, and maps everything the map does not know -- and every punctuation mark 
 """
 import numpy as np
 
-__all__ = ["RECIPE_PUNC", "read_phone_id_map", "phones_to_ids", "text_to_ids", "phones_to_ids_transformer_tts"]
+__all__ = ["RECIPE_PUNC", "read_phone_id_map", "phones_to_ids", "text_to_ids", "phones_to_ids_transformer_tts", "CachedTextToIds"]
 
 RECIPE_PUNC = "：，；。？！“”‘’':,;.?!"     # synthesize_e2e.py:67
 
@@ -51,3 +51,34 @@ def phones_to_ids_transformer_tts(phones, phone_id_map, strip_start_end=True):
     if "," not in phone_id_map and any(p not in phone_id_map for p in phones):
         raise KeyError("phone_id_map has no ',' entry to map unknown phones to")
     return np.asarray([phone_id_map[p if p in phone_id_map else ","] for p in phones], dtype=np.int64)
+
+
+class CachedTextToIds:
+    """``text_to_ids`` behind a bounded least-recently-used memo keyed by the sentence: a serving process sees the same
+    prompts, greetings and sentence fragments again and again, and the frontend (normalisation, tokenisation, lexicon
+    look-ups -- host Python) is the only stage of a request that does not run on the GPU (bench.py ``extras.text_to_wav``
+    gives its share).  ``many(sentences)`` maps a batch, computing each distinct new sentence once.  The arrays are shared
+    between callers: treat them as read-only."""
+
+    def __init__(self, frontend, phone_id_map, punc=RECIPE_PUNC, capacity=4096):
+        from collections import OrderedDict
+        self.frontend, self.phone_id_map, self.punc, self.capacity = frontend, phone_id_map, punc, int(capacity)
+        self._memo = OrderedDict()
+        self.hits = self.misses = 0
+
+    def __call__(self, sentence):
+        memo = self._memo
+        ids = memo.get(sentence)
+        if ids is not None:
+            memo.move_to_end(sentence)
+            self.hits += 1
+            return ids
+        self.misses += 1
+        ids = text_to_ids(self.frontend, sentence, self.phone_id_map, self.punc)
+        memo[sentence] = ids
+        if len(memo) > self.capacity:
+            memo.popitem(last=False)
+        return ids
+
+    def many(self, sentences):
+        return [self(s) for s in sentences]

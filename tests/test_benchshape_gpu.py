@@ -17,6 +17,12 @@ from parakeet_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
+# Two bars everywhere: the north star's (mel L1 < 1e-4 against the reference) and a REGRESSION bar at about ten times the error
+# the engine actually delivers (mel L1 1e-6, waveform 1.3e-6 of the peak, WaveFlow 3e-7: profiles/r03_wf_error.txt, bench.py's
+# parity_check), so that a 100x numerical regression cannot stay green.
+MEL_L1_NORTH_STAR = 1e-4
+MEL_L1_BAR = 1e-5
+
 
 def _rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
@@ -95,9 +101,9 @@ def test_e2e_batch32_bench_shape_vs_oracle():
             want = pwg_ref.pwg_inference(pwg_state, mu_p, sg_p, logmel, nz, dtype=torch.float64)[:, 0].numpy()
         assert logmel.shape == (640, 80)
         l1 = float(np.abs(mel[b] - logmel.numpy()).mean())
-        assert l1 < 1e-4, f"utt {b}: mel L1 {l1}"
+        assert l1 < MEL_L1_NORTH_STAR and l1 < MEL_L1_BAR, f"utt {b}: mel L1 {l1}"
         err = _rel_err(wav[b * per:(b + 1) * per], want)
-        assert err < 1e-4, f"utt {b}: wav rel err {err}"
+        assert err < 1e-4 and err < 1e-5, f"utt {b}: wav rel err {err}"      # (measured 1.3e-6)
 
 
 def test_fs2_batch16_ragged_vs_oracle():
@@ -121,7 +127,7 @@ def test_fs2_batch16_ragged_vs_oracle():
         assert got.shape == want.shape, f"utt {b}: durations differ"
         worst = max(worst, float(np.abs(got - want).mean()))
         assert np.abs(got - want).max() < 2e-3
-    assert worst < 1e-4, worst
+    assert worst < MEL_L1_NORTH_STAR and worst < MEL_L1_BAR, worst
 
 
 def _waveflow_bench_shape(channels, frames, maths, seed=31, check=(0,)):
@@ -154,15 +160,15 @@ def _waveflow_bench_shape(channels, frames, maths, seed=31, check=(0,)):
 def test_waveflow_bench_shape_vs_oracle():
     """BASELINE config 5's utterance shape (640 mel frames, C = 64, all 8 flows): 2 x 640 frames -- full rounds of the layer
     kernel's wave tiles, utterance boundaries inside a workgroup -- vs the fp64 oracle, both utterances; the default math at
-    its bar, the fp16-operand mode (the reference's AMP precision) at its own: 5e-3 of the peak over 8 flows x 15 rows of
-    feedback."""
-    _waveflow_bench_shape(64, [640, 640], {None: 1e-3, "f16": 5e-3}, check=(0, 1))
+    its bar (5e-6: ten times the measured error), the fp16-operand mode (the reference's AMP precision) at its own: 2e-3 of the
+    peak over 8 flows x 15 rows of feedback."""
+    _waveflow_bench_shape(64, [640, 640], {None: 5e-6, "f16": 2e-3}, check=(0, 1))      # measured 3.3e-7 / 1.3e-4
 
 
 def test_waveflow_c128_bench_shape_vs_oracle():
     """The 128-channel model (the reference repository's default width, examples/waveflow/config.py:32-41) at a 640-frame
     utterance, default math and fp16 operands -- the other two WaveFlow configurations bench.py times."""
-    _waveflow_bench_shape(128, [640], {None: 1e-3, "f16": 5e-3}, seed=41)
+    _waveflow_bench_shape(128, [640], {None: 5e-6, "f16": 2e-3}, seed=41)               # measured 2.8e-7 / 9.1e-5
 
 
 def test_speedyspeech_batch32_vs_oracle():
@@ -182,4 +188,4 @@ def test_speedyspeech_batch32_vs_oracle():
             want = ssr.inference(state, ph[b], tn[b], dtype=torch.float64).numpy()
         got = outs[b].numpy()
         assert got.shape == want.shape, f"utt {b}: durations differ"
-        assert np.abs(got - want).mean() < 1e-4
+        assert np.abs(got - want).mean() < MEL_L1_BAR

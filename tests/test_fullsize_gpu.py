@@ -11,6 +11,12 @@ from parakeet_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
+# Two bars everywhere: the north star's (mel L1 < 1e-4 against the reference) and a REGRESSION bar at about ten times the error
+# the engine actually delivers (mel L1 1e-6, waveform 1.3e-6 of the peak, WaveFlow 3e-7: profiles/r03_wf_error.txt, bench.py's
+# parity_check), so that a 100x numerical regression cannot stay green.
+MEL_L1_NORTH_STAR = 1e-4
+MEL_L1_BAR = 1e-5
+
 
 def _models(fixed_duration=None, seed=10086):
     from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
@@ -97,7 +103,7 @@ def test_fs2_edge_cases_zero_frames_single_token_long_sequence():
         want = ref.inference(st2, i).numpy()
         assert o.shape == want.shape
         if want.size:
-            assert np.abs(o.numpy() - want).mean() < 1e-4
+            assert np.abs(o.numpy() - want).mean() < MEL_L1_BAR
     # > 1024 frames: the positional table is regrown on demand (PE max_len 5000, embedding.py:36)
     st3 = syn.fastspeech2_state(80, 80, seed=11, fixed_duration=9)
     am3 = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
@@ -107,7 +113,7 @@ def test_fs2_edge_cases_zero_frames_single_token_long_sequence():
     o = am3.inference(long_ids)
     assert o.shape == (1350, 80)
     want = ref.inference(st3, long_ids).numpy()
-    assert np.abs(o.numpy() - want).mean() < 1e-4
+    assert np.abs(o.numpy() - want).mean() < MEL_L1_BAR
 
 
 def test_pwg_batch32_full_size_determinism_and_invariance():

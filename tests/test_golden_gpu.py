@@ -9,6 +9,12 @@ import pytest
 from parakeet_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
+
+# Two bars everywhere: the north star's (mel L1 < 1e-4 against the reference) and a REGRESSION bar at about ten times the error
+# the engine actually delivers (mel L1 1e-6, waveform 1.3e-6 of the peak, WaveFlow 3e-7: profiles/r03_wf_error.txt, bench.py's
+# parity_check), so that a 100x numerical regression cannot stay green.
+MEL_L1_NORTH_STAR = 1e-4
+MEL_L1_BAR = 1e-5
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -22,14 +28,14 @@ def test_fastspeech2_engine_matches_reference_source():
     for i in range(3):
         mel = model.inference(g[f"ids{i}"], alpha=float(g[f"alpha{i}"])).numpy()
         assert mel.shape == g[f"mel{i}"].shape
-        assert np.abs(mel - g[f"mel{i}"]).mean() < 1e-4     # north_star: mel L1 < 1e-4
+        assert np.abs(mel - g[f"mel{i}"]).mean() < MEL_L1_BAR     # north_star: mel L1 < 1e-4
         assert np.abs(mel - g[f"mel{i}"]).max() < 2e-3
     # ragged batch of all three == the three single-utterance references (alpha 1.0 ones)
     outs = model.inference_batch([g["ids0"], g["ids1"]])
     for i, o in enumerate(outs):
-        assert np.abs(o.numpy() - g[f"mel{i}"]).mean() < 1e-4
+        assert np.abs(o.numpy() - g[f"mel{i}"]).mean() < MEL_L1_BAR
     inf = FastSpeech2Inference(ZScore(g["mu"], g["sigma"]), model)
-    assert np.abs(inf(g["ids0"]).numpy() - g["logmel0"]).mean() < 1e-4
+    assert np.abs(inf(g["ids0"]).numpy() - g["logmel0"]).mean() < MEL_L1_BAR
 
 
 @pytest.mark.parametrize("kind", ["add", "concat"])
@@ -43,16 +49,16 @@ def test_fastspeech2_multispeaker_engine_matches_reference_source(kind):
     for i in range(2):
         mel = model.inference(g[f"{kind}_ids{i}"], spk_id=np.array([int(g[f"{kind}_spk{i}"])])).numpy()
         assert mel.shape == g[f"{kind}_mel{i}"].shape           # same integer durations
-        assert np.abs(mel - g[f"{kind}_mel{i}"]).mean() < 1e-4
+        assert np.abs(mel - g[f"{kind}_mel{i}"]).mean() < MEL_L1_BAR
     mel = model.inference(g[f"{kind}_ids2"], spembs=g[f"{kind}_spemb2"]).numpy()
     assert mel.shape == g[f"{kind}_mel2"].shape
-    assert np.abs(mel - g[f"{kind}_mel2"]).mean() < 1e-4
+    assert np.abs(mel - g[f"{kind}_mel2"]).mean() < MEL_L1_BAR
     # one ragged batch with a different speaker per utterance == the single-utterance references
     outs = model.inference_batch([g[f"{kind}_ids0"], g[f"{kind}_ids1"]],
                                  spk_ids=[int(g[f"{kind}_spk0"]), int(g[f"{kind}_spk1"])])
     for i, o in enumerate(outs):
         assert o.shape == g[f"{kind}_mel{i}"].shape
-        assert np.abs(o.numpy() - g[f"{kind}_mel{i}"]).mean() < 1e-4
+        assert np.abs(o.numpy() - g[f"{kind}_mel{i}"]).mean() < MEL_L1_BAR
     # no speaker given: integration skipped, as in the reference (:396-402); conditioning does not leak
     a = model.inference(g[f"{kind}_ids0"]).numpy()
     b = model.inference(g[f"{kind}_ids0"]).numpy()
@@ -73,7 +79,7 @@ def test_fastspeech2_ffn_variants_engine_matches_reference_source(kind):
     outs = model.inference_batch([g[f"{tag}_ids0"], g[f"{tag}_ids1"]])
     for i, o in enumerate(outs):
         assert o.shape == g[f"{tag}_mel{i}"].shape
-        assert np.abs(o.numpy() - g[f"{tag}_mel{i}"]).mean() < 1e-4
+        assert np.abs(o.numpy() - g[f"{tag}_mel{i}"]).mean() < MEL_L1_BAR
     with pytest.raises(NotImplementedError):
         FastSpeech2(80, 80, **dict(cfg, positionwise_layer_type="conv2d"))
 
@@ -95,7 +101,7 @@ def test_fastspeech2_block_variants_engine_matches_reference_source(tag, math):
     outs = model.inference_batch([g[f"{tag}_ids0"], g[f"{tag}_ids1"]])
     for i, o in enumerate(outs):
         assert o.shape == g[f"{tag}_mel{i}"].shape
-        assert np.abs(o.numpy() - g[f"{tag}_mel{i}"]).mean() < 1e-4 and np.abs(o.numpy() - g[f"{tag}_mel{i}"]).max() < 2e-3
+        assert np.abs(o.numpy() - g[f"{tag}_mel{i}"]).mean() < MEL_L1_BAR and np.abs(o.numpy() - g[f"{tag}_mel{i}"]).max() < 2e-3
     one = model.inference(g[f"{tag}_ids1"])
     assert np.abs(one.numpy() - outs[1].numpy()).max() < 1e-5
 
@@ -108,10 +114,10 @@ def test_fastspeech2_tone_embedding_engine_matches_reference_source():
     model.set_state_dict(syn.fastspeech2_state(80, 80, cfg, seed=int(g["seed"]), num_tones=6, fixed_duration=2))
     model.eval()
     mel = model.inference(g["ids0"], tone_id=g["tones0"]).numpy()
-    assert mel.shape == g["mel0"].shape and np.abs(mel - g["mel0"]).mean() < 1e-4
+    assert mel.shape == g["mel0"].shape and np.abs(mel - g["mel0"]).mean() < MEL_L1_BAR
     outs = model.inference_batch([g["ids0"], g["ids1"]], tone_ids=[g["tones0"], g["tones1"]])
     for i, o in enumerate(outs):
-        assert o.shape == g[f"mel{i}"].shape and np.abs(o.numpy() - g[f"mel{i}"]).mean() < 1e-4
+        assert o.shape == g[f"mel{i}"].shape and np.abs(o.numpy() - g[f"mel{i}"]).mean() < MEL_L1_BAR
     a = model.inference(g["ids0"]).numpy()                 # no tones given: integration skipped (:404-405)
     assert np.abs(a - g["mel0"]).max() > 1e-3
     with pytest.raises(ValueError):
@@ -149,4 +155,4 @@ def test_waveflow_engine_matches_reference_source():
     model.eval()
     wav = model.infer(g["mel"], z=g["z"]).numpy()
     assert wav.shape == g["wav"].shape
-    assert np.abs(wav - g["wav"]).max() < 1e-3 * np.abs(g["wav"]).max()
+    assert np.abs(wav - g["wav"]).max() < 1e-5 * np.abs(g["wav"]).max()      # (measured 3e-7; the bar was 1e-3 until round 5)

@@ -8,7 +8,7 @@ from parakeet_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg_over, frames, seed, tol=2e-4, math=None, expect_kernel=None):
+def _run(cfg_over, frames, seed, tol=1e-5, math=None, expect_kernel=None):   # default math: measured 3e-7 (the bar was 2e-4 until round 5)
     from oracle import waveflow_ref as ref
     from parakeet_amd.waveflow import ConditionalWaveFlow
     cfg = dict(syn.WAVEFLOW_LJSPEECH, **cfg_over)
@@ -47,7 +47,7 @@ def test_waveflow_c64_two_flows_ragged():
 
 def test_waveflow_c64_all_flows():
     # all 8 flows: both permutation kinds and their cumulative effect on the condition
-    _run(dict(channels=64), [5, 3], seed=2, tol=1e-3)
+    _run(dict(channels=64), [5, 3], seed=2)
 
 
 def test_waveflow_c128_repo_default_width():
@@ -95,7 +95,7 @@ def test_waveflow_12_wave_workgroups_bit_identical(math):
             np.testing.assert_array_equal(a, b)
     want = ref.infer(state, torch.from_numpy(mels[0])[None], torch.from_numpy(zs[0])[None], cfg, torch.float64)[0].numpy()
     err = np.abs(outs[12][0] - want).max() / np.abs(want).max()
-    assert err < (2e-3 if math else 2e-4), err
+    assert err < (2e-3 if math else 1e-5), err
     with pytest.raises(ValueError):
         model.set_option("layer_waves", 10)
     m128 = ConditionalWaveFlow(**dict(cfg, channels=128))
