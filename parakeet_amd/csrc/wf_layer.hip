@@ -71,7 +71,10 @@ struct Shape {
     static constexpr int CPT2 = (SLAB2 * KCH2 + THREADS - 1) / THREADS;   // chunks per thread per W2 slab: 2 / 4 (12 waves: 2, the
                                                           // second one clamped to the slab's last chunk for waves 4 - 11)
     static constexpr int BLK_BYTES = C * 128;             // bytes per 32-position block of the feature planes
-    static constexpr int RING = CT == 2 ? (W != 8 ? 6 : 9) : 2 * SLAB;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12
+    static constexpr int RING = CT == 2 ? (W != 8 ? 6 : 9) : 4;   // operand ring depth in k-steps: 9 / 6 / 4 (128 channels, round 5: a
+                                                          // k-step is 24 MFMAs there, four k-steps ahead are 3 k matrix cycles of
+                                                          // ONE wave and the SIMD runs two -- the six of round 3 cost 16 registers the
+                                                          // kernel does not have: 29 spilled, reloaded inside the slab loop; 64 channels: 12
                                                           // would leave the A fragments two register quads -- every LDS read
                                                           // latency exposed; 12 waves: 6, what 168 registers hold)
     static_assert(SLAB * KCH1 % THREADS == 0, "a main slab is a whole number of chunks per thread");
@@ -206,6 +209,11 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     constexpr int RING = (W != 8 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
     static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16 || ABL == 64 || ABL == 80)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace, the old prologue)");
     constexpr int SLAB_CH = S::SLAB_CH;
+    // LEAN: the kernels that live at their register limit (three waves per SIMD: 168; 128 channels: 128 of the 256 are
+    // accumulators) derive round-, slab- and epilogue-only coordinates from opaque zeros so that nothing thread-invariant is
+    // hoisted to the kernel's top, spilled there and reloaded inside the slab loop (round 4 for the 12-wave kernel, round 5 for
+    // the 128-channel one).  The 8-wave 64-channel kernels are compiled exactly as before.
+    constexpr bool LEAN = W != 8 || CT == 4;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
     constexpr int nks_conv = S::KS_TAP * ntap;
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
         return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w2) +
                                               (unsigned)(((g - nslab) * (S::SLAB2 * S::KCH2) + min(f, S::SLAB2 * S::KCH2 - 1)) * 16));
     };
-    auto w_src = [&](int g, int c, int tz) -> const f16x8* { return w_srcf(g, c * THREADS + tid + (W != 8 ? tz : 0), tz); };
+    auto w_src = [&](int g, int c, int tz) -> const f16x8* { return w_srcf(g, c * THREADS + tid + (LEAN ? tz : 0), tz); };
     // The prologue of a round brings the first weight slabs.  Round 4 (s_memtime trace of the 12-wave kernel,
     // profiles/r04_wf_layer_trace_12_waves.txt): with every thread bringing its share of slabs 0 and 1, the prologue barrier
     // passed at 12.2 k of a launch's 80 k cycles -- the first wave of a SIMD had its data at 5 k, the second at 8 k, the third at
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             // branches are waited for where the branches join)
             unsigned m_raw;
             {
-                const int lane_r = lane + (W != 8 ? lz : 0);
+                const int lane_r = lane + (LEAN ? lz : 0);
                 const int li = lane_r <= 2 * ntap ? lane_r : 0, t = li >> 1;   // t = ntap: the condition block (shift 0)
                 const int blk = (p0 + tp_shift[t + lz] + 31 * (li & 1)) >> 5;   // (the LDS tables, not the kernel arguments: those
                 m_raw = (in_amax0 + tp_am[t + lz])[blk];                          //  indexed per lane would be loads from memory)
@@ -492,7 +500,12 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 // place and refilled after its k-step's MFMAs.  (A k-step is 24 MFMAs there: the loads a weight wait drains
                 // early are still three k-steps = 2 300 matrix cycles old.)
                 constexpr bool TIGHT = CT == 4 || W != 8;   // (12 waves: 168 registers)
-                const int NW = (g + 2 >= G || (NEWPRO && PRO2 && g == 0)) ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = TIGHT ? NW / 2 : NW;   // constants once unrolled (slab 2: with the prologue where role B brings it)
+                // PERK (128 channels, round 5): the slab's weights travel in SLAB parts, one per k-step -- part kk + 1 is requested
+                // when part kk has gone to LDS after k-step kk's MFMAs: two chunks (8 registers) on the way instead of three (12),
+                // every part one k-step (24 MFMAs per wave) old when it is stored, as the halves were
+                constexpr bool PERK = CT == 4;
+                const int NW = (g + 2 >= G || (NEWPRO && PRO2 && g == 0)) ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = PERK ? NW / SLAB : (TIGHT ? NW / 2 : NW);   // constants once unrolled (slab 2: with the prologue where role B brings it)
+                auto part_lo = [&](int i) { return i * NW / SLAB; };   // PERK: chunks [part_lo(i), part_lo(i + 1)) are part i
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
                     if (c < HW && !(ABL & 8)) wreg[c] = *w_src(g + 2, c, tz);   // first: every load below is younger
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 // (12 waves: the opaque part is the scalar base -- "constant | lane" would be hoisted out of the round loop, spilled,
                 // and its reload in the middle of the slab loop waits for the weight loads just requested)
                 unsigned wo = (g % 3) * SLAB_CH;
-                if constexpr (W != 8) {
+                if constexpr (LEAN) {
                     asm volatile("" : "+s"(wo));
                     wo += lane;
                 } else {
@@ -552,7 +565,15 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     if (TIGHT) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (ks + RING < nks) load_b(ks + RING, tz);
-                        if (kk == 0 && NW > 0) {
+                        if (PERK && NW > 0) {
+                            const int lo = part_lo(kk), n = part_lo(kk + 1) - lo, n1 = kk + 1 < SLAB ? part_lo(kk + 2) - part_lo(kk + 1) : 0;
+#pragma unroll
+                            for (int c = 0; c < S::CPT1; ++c)
+                                if (c < n) wbuf[(g + 2) % 3][(lo + c) * THREADS + tid] = wreg[c];
+#pragma unroll
+                            for (int c = 0; c < S::CPT1; ++c)
+                                if (c < n1) wreg[c] = *w_src(g + 2, lo + n + c, tz);
+                        } else if (kk == 0 && NW > 0) {
 #pragma unroll
                             for (int c = 0; c < S::CPT1; ++c)
                                 if (c < HW) wbuf[(g + 2) % 3][c * THREADS + tid] = wreg[c];
@@ -565,7 +586,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 }
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c)
-                    if (c < (TIGHT ? NW - HW : NW) && !(ABL & 8)) wbuf[(g + 2) % 3][((TIGHT ? HW : 0) + c) * THREADS + tid] = wreg[c];
+                    if (!PERK && c < (TIGHT ? NW - HW : NW) && !(ABL & 8)) wbuf[(g + 2) % 3][((TIGHT ? HW : 0) + c) * THREADS + tid] = wreg[c];
                 if (g < 8) stamp(3 + 2 * g);
                 __syncthreads();   // everyone is done reading this slab's buffer and sees the next two
                 if (g < 8) stamp(4 + 2 * g);
@@ -575,11 +596,11 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             unsigned cur_am;
             float2 prm_old = {0.f, 0.f};
             // (12 waves: the epilogue's lane coordinates are derived HERE, from an opaque zero -- not hoisted, not spilled)
-            const int ez = opaque_zero<W != 8>();
-            const int lane_e = lane + ez, hh_e = W != 8 ? lane_e >> 5 : hh;
-            const int p_e = W != 8 ? p0 + (lane_e & 31) : p;
-            const long pblk_e = W != 8 ? (long)(p_e >> 5) : pblk;
-            const int pin_e = W != 8 ? p_e & 31 : pin;
+            const int ez = opaque_zero<LEAN>();
+            const int lane_e = lane + ez, hh_e = LEAN ? lane_e >> 5 : hh;
+            const int p_e = LEAN ? p0 + (lane_e & 31) : p;
+            const long pblk_e = LEAN ? (long)(p_e >> 5) : pblk;
+            const int pin_e = LEAN ? p_e & 31 : pin;
             // MULTI: the parked copies (read here, with the other old values: wave-uniform, made scalar where they branch);
             // one layer: the kernel arguments themselves
             Cold cd;
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 cur_am = in_amax0[(long)a.cur_slot * a.amax_stride + (p0 >> 5)];
                 if (!l_first && !(ABL & 4)) prm_old = reinterpret_cast<const float2*>(a.prm)[p_e];
             }
-            const int p_utt_e = W != 8 ? a.pos_utt[p_e] : p_utt;   // (12 waves: requested with the old values, not held since the round's start)
+            const int p_utt_e = LEAN ? a.pos_utt[p_e] : p_utt;   // (12 waves: requested with the old values, not held since the round's start)
             // ---- gate: z * 2^14 in the accumulator registers -> split B operands of the out projection; on the way this
             // lane's part of the folded skip path: (logs, b) += sum over its C/2 channels of wso[.][channel] * z
             __builtin_amdgcn_sched_barrier(0);   // the old-value loads stay ahead of the gate
