@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Register / scratch / LDS use of the kernels of one translation unit (cross-compiles here, no GPU needed).
-usage: python tools/kernel_usage.py <file.hip> [regex on the demangled kernel name] [--profile]"""
+usage: python tools/kernel_usage.py <file.hip> [regex on the demangled kernel name] [--profile] [-DNAME=VALUE ...]"""
 import os
 import re
 import subprocess
@@ -11,10 +11,10 @@ sys.path.insert(0, ROOT)
 from parakeet_amd.build import CSRC, FILE_FLAGS, INCLUDE, hipcc  # noqa: E402
 
 src = sys.argv[1]
-pat = re.compile(sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else ".")
+pat = re.compile(sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ".")
 cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-x", "hip", "-c",
        os.path.join(CSRC, src), "-o", "/tmp/_usage.o", f"-DPK_PROFILE_BUILD={int('--profile' in sys.argv)}",
-       "-Rpass-analysis=kernel-resource-usage"] + FILE_FLAGS.get(src, [])
+       "-Rpass-analysis=kernel-resource-usage"] + FILE_FLAGS.get(src, []) + [a for a in sys.argv[2:] if a.startswith("-D")]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 keys = (("vgpr", r"VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
