@@ -42,6 +42,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
+#ifndef PK_WF_RING128
+#define PK_WF_RING128 6   // operand ring of the 128-channel kernel in k-steps (two slabs).  Round 5: 3 ... 6 compile to the same
+#endif                    // register use once nothing is hoisted into the slab loop (LEAN below): the spills were never the ring
+
 namespace {
 constexpr int WAVE_T = 32;
 constexpr int BLK_M_BYTES = WFL_MP * 128;  // bytes per 32-position block of the condition planes
@@ -71,10 +75,7 @@ struct Shape {
     static constexpr int CPT2 = (SLAB2 * KCH2 + THREADS - 1) / THREADS;   // chunks per thread per W2 slab: 2 / 4 (12 waves: 2, the
                                                           // second one clamped to the slab's last chunk for waves 4 - 11)
     static constexpr int BLK_BYTES = C * 128;             // bytes per 32-position block of the feature planes
-    static constexpr int RING = CT == 2 ? (W != 8 ? 6 : 9) : 4;   // operand ring depth in k-steps: 9 / 6 / 4 (128 channels, round 5: a
-                                                          // k-step is 24 MFMAs there, four k-steps ahead are 3 k matrix cycles of
-                                                          // ONE wave and the SIMD runs two -- the six of round 3 cost 16 registers the
-                                                          // kernel does not have: 29 spilled, reloaded inside the slab loop; 64 channels: 12
+    static constexpr int RING = CT == 2 ? (W != 8 ? 6 : 9) : PK_WF_RING128;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12
                                                           // would leave the A fragments two register quads -- every LDS read
                                                           // latency exposed; 12 waves: 6, what 168 registers hold)
     static_assert(SLAB * KCH1 % THREADS == 0, "a main slab is a whole number of chunks per thread");
@@ -211,8 +212,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     constexpr int SLAB_CH = S::SLAB_CH;
     // LEAN: the kernels that live at their register limit (three waves per SIMD: 168; 128 channels: 128 of the 256 are
     // accumulators) derive round-, slab- and epilogue-only coordinates from opaque zeros so that nothing thread-invariant is
-    // hoisted to the kernel's top, spilled there and reloaded inside the slab loop (round 4 for the 12-wave kernel, round 5 for
-    // the 128-channel one).  The 8-wave 64-channel kernels are compiled exactly as before.
+    // hoisted to the kernel's top, spilled there and reloaded inside the slab loop (round 4 for the 12-wave kernel; round 5 for
+    // the 128-channel one: 29 - 31 spilled registers and 2 665 scratch instructions in the unrolled slab loop -> 5 - 7 and 11,
+    // none of them in the loop; fp16 operands: 8 -> 0).  The 8-wave 64-channel kernels are compiled exactly as before.
     constexpr bool LEAN = W != 8 || CT == 4;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     constexpr int nslab = nks / SLAB;    // C = 64: 3, 5, 7;  C = 128: 10, 18, 26
     constexpr int G = nslab + S::NS2;    // slabs of the weight stream
     __shared__ __attribute__((aligned(16))) f16x8 wbuf[3][SLAB_CH];   // three weight slabs: 144 KB
-    __shared__ __attribute__((aligned(16))) float lb[3 * C];           // b2r [C] | wso [2C]
+    __shared__ __attribute__((aligned(16))) float lb[(CT == 2 ? 5 : 3) * C];   // b2r [C] | wso [2C] | fused step: input_proj w [C] | b [C]
     // per source (the taps whose row exists, then the condition block): where its B operand lives (run-time: which ring slot
     // a tap reads depends on the row); per logical k-step: the packed weight k-step that multiplies it
     __shared__ long tp_off[ntap + 1];     // byte offset from in0 of (position 0, octet 0) of the source
@@ -322,11 +324,28 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
         for (int c = 0; c < S::CPT1; ++c)
             if (c < (g < nslab ? S::CPT1 : S::CPT2)) wreg[c] = *w_src(g, c, tz);
     };
+    // this thread's slot 0 of weight buffer `buf`.  128 channels: from an opaque scalar base -- with constant bases the compiler
+    // keeps one address register per (buffer, chunk) beyond the 64 KB reach of a ds_write offset, sixteen of them, from the
+    // kernel's top to its end
+    // (the 64-channel kernels keep the indexed form they were tuned with: same addresses, another register allocation)
+    constexpr bool WST = CT == 4;
+    auto wst = [&](int buf) -> f16x8* {
+        unsigned o = (unsigned)buf * SLAB_CH;
+        asm volatile("" : "+s"(o));
+        return &wbuf[0][0] + (o + (unsigned)tid);
+    };
     auto w_store = [&](int g) {
         if (g >= G) return;
+        if constexpr (WST) {
+            f16x8* const dst = wst(g % 3);
 #pragma unroll
-        for (int c = 0; c < S::CPT1; ++c)
-            if (c < (g < nslab ? S::CPT1 : S::CPT2)) wbuf[g % 3][c * THREADS + tid] = wreg[c];
+            for (int c = 0; c < S::CPT1; ++c)
+                if (c < (g < nslab ? S::CPT1 : S::CPT2)) dst[c * THREADS] = wreg[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < S::CPT1; ++c)
+                if (c < (g < nslab ? S::CPT1 : S::CPT2)) wbuf[g % 3][c * THREADS + tid] = wreg[c];
+        }
     };
 
     // (MULTI: device memory, wave-uniform address -- scalar loads, here only; one layer: the kernel argument segment)
@@ -349,6 +368,13 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
         cold.step_b_b = a.step_b_b;
     }
     for (int i = tid; i < 3 * C; i += THREADS) lb[i] = i < C ? L.w.b2r[i] : L.w.wso[i - C];
+    // the fused step's input_proj weights: through LDS with the other tables.  (Round 5: read from memory where they are used --
+    // 2 x 32 scalar-indexed loads inside `lane_ok ? ... : 0` -- they compiled to 32 predicated blocks, each a load pair and an
+    // s_waitcnt vmcnt(0): 32 memory round trips in a row at the end of every row's last layer.)
+    if constexpr (CT == 2) {
+        if (a.step_z != nullptr && a.step_h0 != nullptr && (!MULTI || li + 1 == a.nl))
+            for (int i = tid; i < 2 * C; i += THREADS) lb[3 * C + i] = i < C ? a.step_w_in[i] : a.step_b_in[i - C];
+    }
     if (tid < nks) {
         const int ks = tid;
         kt_w[tid] = (unsigned)(ks < nks_conv ? a.tap_w[ks / S::KS_TAP] * S::KS_TAP + ks % S::KS_TAP : 9 * S::KS_TAP + (ks - nks_conv)) *
@@ -444,8 +470,14 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 for (int kk = 0; kk < RING; ++kk) load_b(kk, lz);   // nks >= 18 > RING
                 __builtin_amdgcn_sched_barrier(0);   // everything above is requested before anything below waits
                 w_store(0);
+                if constexpr (WST) {
+                    f16x8* const dst1 = wst(1);
 #pragma unroll
-                for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+                    for (int c = 0; c < S::CPT1; ++c) dst1[c * THREADS] = wreg1[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+                }
             } else {
                 // (half of the chunks, the operands, the other half: role B's second half is slab 2, which can wait; role A
                 // needs its operands before it can start anyway)
@@ -567,9 +599,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                         if (ks + RING < nks) load_b(ks + RING, tz);
                         if (PERK && NW > 0) {
                             const int lo = part_lo(kk), n = part_lo(kk + 1) - lo, n1 = kk + 1 < SLAB ? part_lo(kk + 2) - part_lo(kk + 1) : 0;
+                            f16x8* const dst = wst((g + 2) % 3);
 #pragma unroll
                             for (int c = 0; c < S::CPT1; ++c)
-                                if (c < n) wbuf[(g + 2) % 3][(lo + c) * THREADS + tid] = wreg[c];
+                                if (c < n) dst[(lo + c) * THREADS] = wreg[c];
 #pragma unroll
                             for (int c = 0; c < S::CPT1; ++c)
                                 if (c < n1) wreg[c] = *w_src(g + 2, lo + n + c, tz);
@@ -761,13 +794,20 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 if (MULTI ? __builtin_amdgcn_readfirstlane(step_h0 != nullptr) : step_h0 != nullptr) {
                     float v[S::KS2][8];
                     float am = 0.f;
+                    // wfl_chan(kq, hh, e) = 16 kq + 8 (e >> 2) + 4 hh + (e & 3): two aligned quads per k-step
+                    const float* const lw = lbr + 3 * C + 4 * hh_e;
 #pragma unroll
                     for (int kq = 0; kq < S::KS2; ++kq)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int c = wfl_chan(kq, hh_e, e);
-                            v[kq][e] = lane_ok ? fmaf(cd.step_w_in[c], xn, cd.step_b_in[c]) : 0.f;
-                            am = fmaxf(am, fabsf(v[kq][e]));
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(lw + 16 * kq + 8 * h2);
+                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(lw + C + 16 * kq + 8 * h2);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float t = fmaf(w4[e], xn, b4[e]);
+                                v[kq][4 * h2 + e] = lane_ok ? t : 0.f;
+                                am = fmaxf(am, fabsf(v[kq][4 * h2 + e]));
+                            }
                         }
                     am = wave_max64(am);
                     const float so = pow2f(blk_scale_exp(__float_as_uint(am)));
@@ -789,8 +829,14 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
 #pragma unroll
                 for (int c = 0; c < S::CPT1; ++c) wreg1[c] = *w_src(1, c, lz);
                 w_store(0);
+                if constexpr (WST) {
+                    f16x8* const dst1 = wst(1);
 #pragma unroll
-                for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+                    for (int c = 0; c < S::CPT1; ++c) dst1[c * THREADS] = wreg1[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < S::CPT1; ++c) wbuf[1][c * THREADS + tid] = wreg1[c];
+                }
                 __syncthreads();
             } else {
                 f16x8 wpro[CL];
