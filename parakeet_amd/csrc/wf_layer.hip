@@ -42,6 +42,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
+#ifndef PK_WF_WST64
+#define PK_WF_WST64 0     // experiment switch (A/B through a second build): the opaque LDS store base in the 64-channel kernels too
+#endif
+#ifndef PK_WF_AHEAD12
+#define PK_WF_AHEAD12 1   // experiment switch: A fragments this many co-tiles ahead in the 12-wave split-math kernel
+#endif
 #ifndef PK_WF_RING128
 #define PK_WF_RING128 6   // operand ring of the 128-channel kernel in k-steps (two slabs).  Round 5: 3 ... 6 compile to the same
 #endif                    // register use once nothing is hoisted into the slab loop (LEAN below): the spills were never the ring
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // keeps one address register per (buffer, chunk) beyond the 64 KB reach of a ds_write offset, sixteen of them, from the
     // kernel's top to its end
     // (the 64-channel kernels keep the indexed form they were tuned with: same addresses, another register allocation)
-    constexpr bool WST = CT == 4;
+    constexpr bool WST = CT == 4 || PK_WF_WST64;
     auto wst = [&](int buf) -> f16x8* {
         unsigned o = (unsigned)buf * SLAB_CH;
         asm volatile("" : "+s"(o));
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     // A fragments AHEAD co-tiles ahead of their MFMAs (not all NQ of them: registers).  Two at 64 channels:
                     // with one, every co-tile's three MFMAs (96 cycles) had to cover a whole LDS read latency, and the trace
                     // showed about 200 cycles per k-step and wave that nothing covered
-                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W != 8 && !F16)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
+                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W != 8 && !F16)) ? 2 : ((W != 8 && !F16) ? PK_WF_AHEAD12 : 1), PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
                     // math: one -- registers; the other two waves of the SIMD cover the LDS latency)
                     __builtin_amdgcn_sched_group_barrier(0x100, PER * (AHEAD + 0), 0);
 #pragma unroll
