@@ -42,6 +42,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
+#ifndef PK_WF_BIG16
+#define PK_WF_BIG16 0     // experiment switch: the register diet of the 128-channel kernel with fp16 operands too
+#endif
+#ifndef PK_WF_LINW
+#define PK_WF_LINW 1      // the weight chunks' source addresses as a linear function of the thread index (0: through the kt_w table, as
+#endif                    // rounds 2 - 4 did; kept for the A/B)
+#ifndef PK_WF_WST128F
+#define PK_WF_WST128F 0   // experiment switch: the opaque LDS store base in the 128-channel fp16-operand kernel
+#endif
 #ifndef PK_WF_WST64
 #define PK_WF_WST64 0     // experiment switch (A/B through a second build): the opaque LDS store base in the 64-channel kernels too
 #endif
@@ -221,7 +230,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // hoisted to the kernel's top, spilled there and reloaded inside the slab loop (round 4 for the 12-wave kernel; round 5 for
     // the 128-channel one: 29 - 31 spilled registers and 2 665 scratch instructions in the unrolled slab loop -> 5 - 7 and 11,
     // none of them in the loop; fp16 operands: 8 -> 0).  The 8-wave 64-channel kernels are compiled exactly as before.
-    constexpr bool LEAN = W != 8 || CT == 4;
+    // (Not with fp16 operands at 128 channels: that kernel had 8 spilled registers and is bound by vector issue -- the
+    // recomputed coordinates cost it more than the spills did: 92.7 -> 98.5 us per launch on one box, profiles/r05_wf_ab.txt.)
+    constexpr bool BIG = CT == 4 && (!F16 || PK_WF_BIG16);   // the 128-channel default-math kernel: the round-5 register diet
+    constexpr bool LEAN = W != 8 || BIG;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
     constexpr int ntap = 3 * NT;
     constexpr int nks_conv = S::KS_TAP * ntap;
@@ -284,7 +296,15 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // loop unrolled the compiler would otherwise read all of them up front and hold them in registers)
     // (addresses = a scalar base + a 32-bit byte offset: one add per chunk instead of a 64-bit multiply-add chain -- 54 chunks
     // per tile)
+    // Round 5: the taps a launch skips are the ring's OLDEST rows, i.e. the first 9 - ntap weight taps (wfl_layer_launch checks
+    // tap_w[t] == 9 - ntap + t), so logical k-step ks is packed k-step ks + KOFF and chunk f of slab g sits (SLAB g + KOFF) KCH1 + f
+    // chunks into W1: a constant plus the thread index.  Through the kt_w table every chunk cost an LDS read, a signed division
+    // by KCH1 and a remainder -- ~8 vector instructions x 40 chunks per tile in kernels that are bound by vector issue
+    // (profiles/r05_wf_layer_isa_hist.txt).
+    constexpr int KOFF = (9 - ntap) * S::KS_TAP;
     auto w_srcf = [&](int g, int f, int tz) -> const f16x8* {   // chunk f of slab g
+        if (PK_WF_LINW && g < nslab)
+            return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) + ((unsigned)((SLAB * g + KOFF) * S::KCH1 + f + (LEAN ? 0 : tz)) * 16u));   // (tz: the opaque zero of the slab keeps the request where it is written)
         if (g < nslab)
             return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
                                                   (kt_w[SLAB * g + f / S::KCH1 + tz] + (unsigned)((f % S::KCH1) * 16)));
@@ -320,6 +340,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     };
     auto pro_src = [&](int c, int tz) -> const f16x8* {
         const unsigned f = (unsigned)(pro_f(c) + (W != 8 ? tz : 0));
+        if (PK_WF_LINW)
+            return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) + ((unsigned)((SLAB * pro_g(c) + KOFF) * S::KCH1) + f) * 16u);
         return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
                                               (kt_w[SLAB * pro_g(c) + (int)(f / S::KCH1) + tz] + (f % S::KCH1) * 16u));
     };
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // keeps one address register per (buffer, chunk) beyond the 64 KB reach of a ds_write offset, sixteen of them, from the
     // kernel's top to its end
     // (the 64-channel kernels keep the indexed form they were tuned with: same addresses, another register allocation)
-    constexpr bool WST = CT == 4 || PK_WF_WST64;
+    constexpr bool WST = BIG || PK_WF_WST64 || (CT == 4 && PK_WF_WST128F);
     auto wst = [&](int buf) -> f16x8* {
         unsigned o = (unsigned)buf * SLAB_CH;
         asm volatile("" : "+s"(o));
@@ -451,7 +473,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     // q can be negative (a tap of the first tiles reaches into the buffer's leading margin): the offset is
                     // taken from 8 blocks before the source's position 0, so that it is a non-negative 32-bit number
                     const int q = p + tp_shift[tap + tz];
-                    const int blkb = tp_blk[tap + tz];
+                    const int blkb = PK_WF_LINW ? (tap < ntap ? S::BLK_BYTES : BLK_M_BYTES) : tp_blk[tap + tz];   // (a constant per source kind: a shift, not a 64-bit multiply)
                     cur_off = (unsigned)(((q >> 5) + 8) * blkb + (q & 31) * 32 + hh * 1024);
                     const long bo = tp_off[tap + tz] - 8L * blkb;
                     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bo), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bo >> 32));
@@ -541,7 +563,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 // PERK (128 channels, round 5): the slab's weights travel in SLAB parts, one per k-step -- part kk + 1 is requested
                 // when part kk has gone to LDS after k-step kk's MFMAs: two chunks (8 registers) on the way instead of three (12),
                 // every part one k-step (24 MFMAs per wave) old when it is stored, as the halves were
-                constexpr bool PERK = CT == 4;
+                constexpr bool PERK = BIG;
                 const int NW = (g + 2 >= G || (NEWPRO && PRO2 && g == 0)) ? 0 : (g + 2 < nslab ? S::CPT1 : S::CPT2), HW = PERK ? NW / SLAB : (TIGHT ? NW / 2 : NW);   // constants once unrolled (slab 2: with the prologue where role B brings it)
                 auto part_lo = [&](int i) { return i * NW / SLAB; };   // PERK: chunks [part_lo(i), part_lo(i + 1)) are part i
 #pragma unroll
@@ -1107,6 +1129,8 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     if (!wfl_supports(a.C) || a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9 || a.nl < 1 || a.nl > WFL_MAX_LAYERS)
         PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (C %d, npos %d, taps %d, layers %d)", a.C, a.npos_alloc, a.ntap, a.nl);
     if (a.nl > 1 && (!pk_grid_available() || !a.bar)) PK_FAIL(PK_ESTATE, "wfl_layer_launch: several layers per launch need the grid barrier");
+    for (int t = 0; t < a.ntap; ++t)   // the kernel addresses W1 linearly: the taps present are the LAST ntap of the nine, in order
+        if (a.tap_w[t] != 9 - a.ntap + t) PK_FAIL(PK_EINVAL, "wfl_layer_launch: tap %d carries weight tap %d, expected %d", t, a.tap_w[t], 9 - a.ntap + t);
     // operand offsets inside a source are 32-bit (k_wf_layer_p: scalar base + unsigned offset): 16 blocks of margin included
     if (((long)a.npos_alloc / WAVE_T + 16) * (long)std::max(a.C * 128, BLK_M_BYTES) >= (1L << 32))
         PK_FAIL(PK_EUNSUPPORTED, "wfl_layer_launch: %d positions per row exceed the 32-bit operand offsets; split the batch", a.npos_alloc);

@@ -8,6 +8,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
+(timeout 600 python -m pytest tests/test_waveflow_gpu.py tests/test_benchshape_gpu.py tests/test_golden_gpu.py -m gpu -q --timeout=300 -k "waveflow" 2>&1 | tail -6) > $OUT/tests.txt
+tail -2 $OUT/tests.txt
 cp parakeet_amd/libpk_synth_prof.so /tmp/prof_keep.so
 run() {   # run <label> <C> <math>
   timeout 150 python tools/quick_wf.py $2 $3 0 2>&1 | grep -E "WaveFlow|wf_layer" | tr '\n' ' ' | sed "s/^/$1: /"; echo
@@ -17,8 +19,9 @@ for rep in 1 2; do
   for cfg in "128 -" "128 f16" "64 -" "64 f16"; do
     set -- $cfg
     run product $1 $2
-    for v in r04 ${VARIANTS:-wst64 ahead2 wst64_ahead2}; do
-      [ "$1" = 128 ] && [ $v != r04 ] && continue          # the switches only touch the 64-channel 12-wave kernel
+    for v in ${VARIANTS:-r04 linw0 big16}; do
+      [ "$1" = 64 ] && [ $v = big16 ] && continue          # (a 128-channel switch)
+      [ -f parakeet_amd/variants/$v.so ] || continue
       cp parakeet_amd/variants/$v.so parakeet_amd/libpk_synth_prof.so
       PK_PROFILE_LIB=1 run $v $1 $2
     done
