@@ -43,20 +43,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
 #ifndef PK_WF_BIG16
-#define PK_WF_BIG16 0     // experiment switch: the register diet of the 128-channel kernel with fp16 operands too
-#endif
+#define PK_WF_BIG16 1     // the register diet of the 128-channel kernel with fp16 operands too (0: its round-4 form, 8 spilled registers).
+#endif                    // Before the linear weight addresses the diet cost this vector-bound kernel 6 %; with them it gains 1 %
 #ifndef PK_WF_LINW
 #define PK_WF_LINW 1      // the weight chunks' source addresses as a linear function of the thread index (0: through the kt_w table, as
 #endif                    // rounds 2 - 4 did; kept for the A/B)
-#ifndef PK_WF_WST128F
-#define PK_WF_WST128F 0   // experiment switch: the opaque LDS store base in the 128-channel fp16-operand kernel
-#endif
-#ifndef PK_WF_WST64
-#define PK_WF_WST64 0     // experiment switch (A/B through a second build): the opaque LDS store base in the 64-channel kernels too
-#endif
-#ifndef PK_WF_AHEAD12
-#define PK_WF_AHEAD12 1   // experiment switch: A fragments this many co-tiles ahead in the 12-wave split-math kernel
-#endif
 #ifndef PK_WF_RING128
 #define PK_WF_RING128 6   // operand ring of the 128-channel kernel in k-steps (two slabs).  Round 5: 3 ... 6 compile to the same
 #endif                    // register use once nothing is hoisted into the slab loop (LEAN below): the spills were never the ring
@@ -230,8 +221,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // hoisted to the kernel's top, spilled there and reloaded inside the slab loop (round 4 for the 12-wave kernel; round 5 for
     // the 128-channel one: 29 - 31 spilled registers and 2 665 scratch instructions in the unrolled slab loop -> 5 - 7 and 11,
     // none of them in the loop; fp16 operands: 8 -> 0).  The 8-wave 64-channel kernels are compiled exactly as before.
-    // (Not with fp16 operands at 128 channels: that kernel had 8 spilled registers and is bound by vector issue -- the
-    // recomputed coordinates cost it more than the spills did: 92.7 -> 98.5 us per launch on one box, profiles/r05_wf_ab.txt.)
+    // (fp16 operands at 128 channels -- 8 spilled registers, bound by vector issue: with the weight addresses still read from
+    // the kt_w table the recomputed coordinates cost more than the spills did, 92.7 -> 98.5 us per launch; with the linear
+    // addresses 94.5 -> 93.3: profiles/r05_wf_ab.txt.)
     constexpr bool BIG = CT == 4 && (!F16 || PK_WF_BIG16);   // the 128-channel default-math kernel: the round-5 register diet
     constexpr bool LEAN = W != 8 || BIG;
     static_assert(!MULTI || ABL == 0, "multi-layer launches: no ablations");
@@ -356,7 +348,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // keeps one address register per (buffer, chunk) beyond the 64 KB reach of a ds_write offset, sixteen of them, from the
     // kernel's top to its end
     // (the 64-channel kernels keep the indexed form they were tuned with: same addresses, another register allocation)
-    constexpr bool WST = BIG || PK_WF_WST64 || (CT == 4 && PK_WF_WST128F);
+    constexpr bool WST = BIG;
     auto wst = [&](int buf) -> f16x8* {
         unsigned o = (unsigned)buf * SLAB_CH;
         asm volatile("" : "+s"(o));
@@ -614,7 +606,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     // A fragments AHEAD co-tiles ahead of their MFMAs (not all NQ of them: registers).  Two at 64 channels:
                     // with one, every co-tile's three MFMAs (96 cycles) had to cover a whole LDS read latency, and the trace
                     // showed about 200 cycles per k-step and wave that nothing covered
-                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W != 8 && !F16)) ? 2 : ((W != 8 && !F16) ? PK_WF_AHEAD12 : 1), PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
+                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W != 8 && !F16)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
                     // math: one -- registers; the other two waves of the SIMD cover the LDS latency)
                     __builtin_amdgcn_sched_group_barrier(0x100, PER * (AHEAD + 0), 0);
 #pragma unroll
