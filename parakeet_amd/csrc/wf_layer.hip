@@ -1104,7 +1104,7 @@ static int wfl_ablation(Go& go, bool shape_ok, bool trace, bool w12, bool f16, b
                 case 8: if (plain8) return go(k_wf_layer_p<2, 3, 8>); break;
                 case 9: if (plain8) return go(k_wf_layer_p<2, 3, 9>); break;
                 case 13: if (plain8) return go(k_wf_layer_p<2, 3, 13>); break;
-                case 16: if (trace && !c128) return w12 ? go(k_wf_layer_p<2, 3, 16, false, 12>) : go(k_wf_layer_p<2, 3, 16>); break;
+                case 16: if (trace && !c128) return w12 ? (f16 ? go(k_wf_layer_p<2, 3, 16, true, 12>) : go(k_wf_layer_p<2, 3, 16, false, 12>)) : go(k_wf_layer_p<2, 3, 16>); break;
                 case 80: if (trace && !c128) return w12 ? go(k_wf_layer_p<2, 3, 80, false, 12>) : go(k_wf_layer_p<2, 3, 80>); break;
                 case 64: if (c128) return f16 ? go(k_wf_layer_p<4, 3, 64, true>) : go(k_wf_layer_p<4, 3, 64>);
                          return w12 ? (f16 ? go(k_wf_layer_p<2, 3, 64, true, 12>) : go(k_wf_layer_p<2, 3, 64, false, 12>))
