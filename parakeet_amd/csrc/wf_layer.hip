@@ -62,18 +62,26 @@ constexpr int BLK_M_BYTES = WFL_MP * 128;  // bytes per 32-position block of the
 // waves per SIMD and 168 registers as W = 12, but the two workgroups are independent: one's slab barriers, prologue and epilogue
 // lie under the other's MFMAs (the twelve waves of ONE workgroup move in lockstep; the counters of the 12-wave kernel show the
 // matrix pipe 30 % busy with half the wave cycles waiting).  Price: the weights travel from L2 to LDS twice per CU.
-template <int CT, int W = 8>
+// F16 (round 5): with fp16 operands only the hi parts of the weights are multiplied -- only they travel to LDS (HIW): half the
+// weight bytes per launch from L2 and into LDS.  64 channels: 24 KB slabs of the same six k-steps; 128 channels: the 48 KB slab
+// holds six k-steps instead of three, half as many slabs and barriers.  PK_WF_HIW=0: both parts as in rounds 2 - 4 (the A/B).
+#ifndef PK_WF_HIW
+#define PK_WF_HIW 1
+#endif
+template <int CT, int W = 8, bool F16 = false>
 struct Shape {
-    static constexpr int SLAB_BYTES = W == 6 ? 24 * 1024 : 48 * 1024;   // one weight slab in LDS; three of them
+    static constexpr bool HIW = F16 && PK_WF_HIW;
+    static constexpr int SLAB_BYTES = (W == 6 || (HIW && CT == 2)) ? 24 * 1024 : 48 * 1024;   // one weight slab in LDS; three of them
     static constexpr int SLAB_CH = SLAB_BYTES / 16;                     // 16-byte chunks per slab buffer
     static constexpr int THREADS = W * 64;
     static constexpr int C = 32 * CT;
     static constexpr int KS_TAP = C / 16;                 // k-steps per conv tap: 4 / 8
     static constexpr int KS1 = 9 * KS_TAP + WFL_KS_COND;  // 42 / 78
     static constexpr int NQ = 2 * CT;                     // accumulator tiles of the first contraction: 4 / 8
-    static constexpr int KCH1 = 2 * NQ * 64;              // chunks per k-step of W1: 512 / 1024
-    static constexpr int SLAB = SLAB_CH / KCH1;           // k-steps per main slab: 6 / 3
-    static constexpr int CPT1 = SLAB * KCH1 / THREADS;    // chunks per thread per main slab: 6 (4 with 12 waves)
+    static constexpr int KCH1 = 2 * NQ * 64;              // chunks per k-step of W1 in memory (hi | lo): 512 / 1024
+    static constexpr int KCHL = (HIW ? 1 : 2) * NQ * 64;  // ... of them brought to LDS
+    static constexpr int SLAB = SLAB_CH / KCHL;           // k-steps per main slab: 6 / 3 (HIW: 6 / 6)
+    static constexpr int CPT1 = SLAB * KCHL / THREADS;    // chunks per thread per main slab: 6 (4 with 12 waves; HIW: 3 / 2 / 6)
     static constexpr int KS2 = C / 16;                    // k-steps of the out projection (res half): 4 / 8
     static constexpr int KCH2 = 2 * CT * 64;              // chunks per k-step of W2: 256 / 512
     static constexpr int SLAB2 = 4;                       // k-steps per W2 slab: 16 / 32 KB
@@ -84,7 +92,8 @@ struct Shape {
     static constexpr int RING = CT == 2 ? (W != 8 ? 6 : 9) : PK_WF_RING128;   // operand ring depth in k-steps: 9 / 6 (64 channels: 12
                                                           // would leave the A fragments two register quads -- every LDS read
                                                           // latency exposed; 12 waves: 6, what 168 registers hold)
-    static_assert(SLAB * KCH1 % THREADS == 0, "a main slab is a whole number of chunks per thread");
+    static_assert(SLAB * KCHL % THREADS == 0, "a main slab is a whole number of chunks per thread");
+    static_assert(SLAB2 * KCH2 <= SLAB_CH && CPT2 <= CPT1, "an out-projection slab fits a slab buffer and the staging registers");
 };
 
 __host__ __device__ inline int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -211,7 +220,7 @@ __device__ __forceinline__ int opaque_zero() {
 // 28 to 63 spilled registers, 88 -> 128 us per launch with fp16 operands) -- the one-layer kernels are compiled without it.
 template <int CT, int NT, int ABL = 0, bool F16 = false, int W = 8, bool MULTI = false>
 __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch a) {
-    typedef Shape<CT, W> S;
+    typedef Shape<CT, W, F16> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
     constexpr int RING = (W != 8 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
     static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16 || ABL == 64 || ABL == 80)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace, the old prologue)");
@@ -296,10 +305,15 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     constexpr int KOFF = (9 - ntap) * S::KS_TAP;
     auto w_srcf = [&](int g, int f, int tz) -> const f16x8* {   // chunk f of slab g
         if (PK_WF_LINW && g < nslab)
-            return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) + ((unsigned)((SLAB * g + KOFF) * S::KCH1 + f + (LEAN ? 0 : tz)) * 16u));   // (tz: the opaque zero of the slab keeps the request where it is written)
+        {
+            const unsigned fl = (unsigned)(f + (LEAN ? 0 : tz));   // (tz: the opaque zero of the slab keeps the request where it is written)
+            // chunk fl of the LDS slab = chunk fl % KCHL of k-step fl / KCHL (HIW: the k-step's hi block; else the whole k-step: fl itself)
+            const unsigned src = S::HIW ? (fl / S::KCHL) * S::KCH1 + fl % S::KCHL : fl;
+            return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) + ((unsigned)((SLAB * g + KOFF) * S::KCH1) + src) * 16u);
+        }
         if (g < nslab)
             return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
-                                                  (kt_w[SLAB * g + f / S::KCH1 + tz] + (unsigned)((f % S::KCH1) * 16)));
+                                                  (kt_w[SLAB * g + f / S::KCHL + tz] + (unsigned)((f % S::KCHL) * 16)));
         return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w2) +
                                               (unsigned)(((g - nslab) * (S::SLAB2 * S::KCH2) + min(f, S::SLAB2 * S::KCH2 - 1)) * 16));
     };
@@ -333,9 +347,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     auto pro_src = [&](int c, int tz) -> const f16x8* {
         const unsigned f = (unsigned)(pro_f(c) + (W != 8 ? tz : 0));
         if (PK_WF_LINW)
-            return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) + ((unsigned)((SLAB * pro_g(c) + KOFF) * S::KCH1) + f) * 16u);
+            return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) + ((unsigned)((SLAB * pro_g(c) + KOFF) * S::KCH1) +
+                                                                                        (S::HIW ? (f / S::KCHL) * S::KCH1 + f % S::KCHL : f)) * 16u);
         return reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(w1) +
-                                              (kt_w[SLAB * pro_g(c) + (int)(f / S::KCH1) + tz] + (f % S::KCH1) * 16u));
+                                              (kt_w[SLAB * pro_g(c) + (int)(f / S::KCHL) + tz] + (f % S::KCHL) * 16u));
     };
     f16x8 wreg[S::CPT1];   // one slab of weights on its way from global memory to LDS
     auto w_load = [&](int g, int tz) {
@@ -595,10 +610,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     __builtin_amdgcn_sched_barrier(0);   // ... and the loads ahead of the k-step's MFMAs
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const f16x8 ah = wl[kk * S::KCH1 + (0 * NQ + q) * 64];
+                        const f16x8 ah = wl[kk * S::KCHL + (0 * NQ + q) * 64];
                         acc[q] = mfma16(ah, TIGHT ? rhi[slot] : bh, acc[q]);
                         if (!F16) {
-                            const f16x8 al = wl[kk * S::KCH1 + (1 * NQ + q) * 64];
+                            const f16x8 al = wl[kk * S::KCHL + (1 * NQ + q) * 64];
                             acc[q] = mfma16(al, TIGHT ? rhi[slot] : bh, acc[q]);
                             acc[q] = mfma16(ah, TIGHT ? rlo[slot] : bl, acc[q]);
                         }
