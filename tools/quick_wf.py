@@ -20,9 +20,10 @@ out = m.infer_batch(mels, zs); torch.cuda.synchronize()
 assert all(bool(torch.isfinite(o).all()) for o in out)
 t=time.time(); n=2
 for i in range(n): m.infer_batch(mels, zs)
+t_enq=(time.time()-t)/n     # host time to ENQUEUE a batch (no synchronisation inside infer_batch with device-resident I/O)
 torch.cuda.synchronize(); dt=(time.time()-t)/n
 ns = sum(o.numel() for o in out)
-print(f"WaveFlow C={C} math={MATH} waves={WAVES} persistent={os.environ.get('PK_QWF_PERSISTENT', 'default')} B={B} L={L}: {dt*1e3:.1f} ms/batch, {ns/dt/1e6:.2f} Msamples/s, {ns/dt/22050:.0f}x RT")
+print(f"WaveFlow C={C} math={MATH} waves={WAVES} persistent={os.environ.get('PK_QWF_PERSISTENT', 'default')} B={B} L={L}: {dt*1e3:.1f} ms/batch, {ns/dt/1e6:.2f} Msamples/s, {ns/dt/22050:.0f}x RT; host enqueue {t_enq*1e3:.1f} ms/batch")
 ctx.prof_enable(True); ctx.prof_reset()
 m.infer_batch(mels, zs)
 for k,(n_,ms) in ctx.prof_dump().items(): print(f"  {k:20s} n={n_:5d} total={ms:9.3f} ms avg={ms/n_*1e3:8.1f} us")
