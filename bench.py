@@ -198,7 +198,8 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
                  if math == "f16" else
                  "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes") +
                 ("; 12-wave workgroups (one round of 11 tiles per workgroup), the row's step fused into its last layer's launch"
-                 if channels == 64 else "; 8-wave workgroups"),
+                 if channels == 64 else "; 8-wave workgroups (round 5: no spills in the slab loop)") +
+                ("; only the hi parts of the weights travel to LDS (round 5)" if math == "f16" else ""),
         "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,
         "ms_per_batch_runs": [t * 1e3 for t in times],
         "reference_published": "about 40x real time on V100 (docs/src/released_models.md:275-276)"}
