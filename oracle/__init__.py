@@ -47,4 +47,15 @@ paddle.nn.LSTM / LSTMCell semantics (gate order i, f, g, o; aliased parameter na
 Until a real Paddle build has been run against these vectors the status is:
 "parity pinned to the reference's Python source over a Paddle stand-in;
 Paddle kernel semantics unpinned".
+
+How to change that status (one command, on a machine with paddlepaddle >= 2.1.2 and a checkout of the reference):
+
+    PARAKEET_REAL_PADDLE=1 PARAKEET_REFERENCE=/path/to/Parakeet python tools/verify_with_paddle.py \
+        --fs2-ckpt fastspeech2_nosil_ljspeech_ckpt_0.5 --pwg-ckpt pwg_ljspeech_ckpt_0.5
+
+tools/ref_import.py then leaves the stand-in OFF sys.path and the same generators run over Paddle itself into
+tests/golden_paddle/; the script prints a per-tensor diff against the stand-in vectors, and every golden test, the
+checkpoint-reader tests and tests/test_released_ckpt_*.py then compare this oracle (and, with -m gpu, the engine) with
+what Paddle computed -- including on the released LJSpeech checkpoints.  tests/test_verify_paddle_cpu.py runs the very
+same script over the stand-in.
 """
