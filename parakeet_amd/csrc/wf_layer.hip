@@ -42,9 +42,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 
-#ifndef PK_WF_XPRE
-#define PK_WF_XPRE 1      // 64 channels, fp16 operands: the A fragments of k-step k + 1 are read from LDS under k-step k's MFMAs, across
-#endif                    // slab boundaries too (0: two co-tiles ahead inside a k-step, the first reads of every k-step exposed)
 #ifndef PK_WF_BIG16
 #define PK_WF_BIG16 1     // the register diet of the 128-channel kernel with fp16 operands too (0: its round-4 form, 8 spilled registers).
 #endif                    // Before the linear weight addresses the diet cost this vector-bound kernel 6 %; with them it gains 1 %
@@ -561,29 +558,6 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-            // XPRE (round 5; fp16 operands, 64 channels): with one MFMA (32 cycles) per co-tile a read issued two co-tiles ahead is
-            // 64 cycles old when it is needed and the first reads of every k-step are not covered at all -- the s_memtime trace
-            // showed ~500 cycles per k-step and wave against 128 of matrix work.  The NQ fragments of the NEXT k-step are read while
-            // this one's MFMAs run (slab g + 1's buffer is complete before the barrier that ends slab g: it was written during
-            // slab g - 1), so only the very first k-step of a tile waits for LDS.
-            constexpr bool XPRE = PK_WF_XPRE && F16 && CT == 2;
-            f16x8 apre[XPRE ? NQ : 1];
-            auto slab_base = [&](int gg) -> const f16x8* {   // this lane's fragment 0 of slab gg's buffer (one opaque register)
-                unsigned o = (gg % 3) * SLAB_CH;
-                if constexpr (LEAN) {
-                    asm volatile("" : "+s"(o));
-                    o += lane;
-                } else {
-                    o += lane;
-                    asm volatile("" : "+v"(o));
-                }
-                return &wbuf[0][0] + o;
-            };
-            if constexpr (XPRE) {
-                const f16x8* w0 = slab_base(0);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) apre[q] = w0[q * 64];
-            }
 #pragma unroll
             for (int g = 0; g < nslab; ++g) {
                 int tz = 0;
@@ -634,20 +608,6 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                         if (!(ABL & 1) && ks + RING < nks) load_b(ks + RING, tz);   // (a compile-time condition once unrolled)
                     }
                     __builtin_amdgcn_sched_barrier(0);   // ... and the loads ahead of the k-step's MFMAs
-                    if constexpr (XPRE) {
-                        const bool more = kk + 1 < SLAB || g + 1 < nslab;
-                        const f16x8* wn = kk + 1 < SLAB ? wl + (kk + 1) * S::KCHL : (g + 1 < nslab ? slab_base(g + 1) : wl);
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            acc[q] = mfma16(apre[q], TIGHT ? rhi[slot] : bh, acc[q]);
-                            if (more) apre[q] = wn[q * 64];   // (its register is free once the MFMA has issued)
-                        }
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                    } else {
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const f16x8 ah = wl[kk * S::KCHL + (0 * NQ + q) * 64];
@@ -668,7 +628,6 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     for (int q = 0; q < NQ; ++q) {
                         if (q + AHEAD < NQ) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
-                    }
                     }
                     if (TIGHT) {
                         __builtin_amdgcn_sched_barrier(0);
