@@ -693,9 +693,9 @@ def main():
         "weights": "once at start-up: the flat fp32 state of each model (FastSpeech2 148.5 MB, PWG 5.3 MB) from rank 0, one "
                    "broadcast per model (torch.distributed.broadcast = ncclBroadcast over xGMI); every rank then packs its own "
                    "engine image (finalize derives host-side bounds from the weights)" if distributed else "single process: none",
-        "results": "gather_ms: per-utterance lengths by all_gather_object, then every rank's packed waveform sent straight to "
-                   "rank 0 (grouped isend / irecv = ncclSend / ncclRecv, exact sizes: 7 senders use 7 different xGMI links of "
-                   "rank 0); gather_all_ms: the same data on every rank by one padded all_gather (ncclAllGather)"
+        "results": "gather_ms: per-utterance lengths by all_gather_object, then every rank's packed waveform straight to "
+                   "rank 0 by one gather collective (torch.distributed.gather = a group of ncclSend / ncclRecv: 7 senders use 7 "
+                   "different xGMI links of rank 0); gather_all_ms: the same data on every rank by one padded all_gather (ncclAllGather)"
                    if distributed else "single process: none",
     }
     if dry:

@@ -14,10 +14,11 @@ in CPU tests) is used for exactly two things:
     planes path), so every rank packs its own copy -- a second of host work per rank
     at start-up, concurrent across ranks, never inside a timed step;
   * ``gather_ragged_to`` -- result collection on ONE rank ("gather to
-    rank 0"): an all_gather of the lengths, then every other rank sends its packed
-    waveform straight to the destination, which posts all receives at once.  xGMI is
-    point to point (7 links per GPU), so 7 senders use 7 different links of rank 0
-    concurrently -- 21 MB per link instead of a ring's 8 x 21 MB through every link;
+    rank 0"): an all_gather of the lengths, then one ``gather`` collective -- on RCCL a
+    group of ncclSend / ncclRecv: every rank's packed waveform goes straight to the
+    destination.  xGMI is point to point (7 links per GPU), so 7 senders use 7
+    different links of rank 0 concurrently -- 21 MB per link instead of a ring's
+    8 x 21 MB through every link;
   * ``gather_ragged`` -- the same data on EVERY rank (all_gather of the lengths + one
     padded all_gather), for consumers that need it everywhere.
 
@@ -91,9 +92,11 @@ def gather_ragged(local, lengths_local):
 
 def gather_ragged_to(local, lengths_local, dst=0):
     """Collect per-rank packed 1-D float tensors of different sizes on rank `dst` only.
-    Returns (list of per-rank tensors, list of per-rank length lists) on `dst` -- element `dst` of the
-    list is `local` itself, not a copy -- and (None, lengths) on the other ranks.  Exact sizes travel
-    (no padding): grouped point-to-point sends, all receives posted together."""
+    Returns (list of per-rank tensors, list of per-rank length lists) on `dst` and (None, lengths) on the
+    other ranks.  One ``all_gather_object`` of the lengths, then ONE ``gather`` collective (on RCCL: a group of
+    ncclSend / ncclRecv, every rank's buffer straight to `dst`), padded to the largest rank's size -- the single,
+    library-provided collective rather than hand-rolled point-to-point pairs: this runs for the first time on
+    eight GPUs when the driver takes the SCALE record."""
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = _comm_device()
     meta = [None] * world
@@ -101,14 +104,11 @@ def gather_ragged_to(local, lengths_local, dst=0):
     sizes = [int(sum(m)) for m in meta]
     flat = local.reshape(-1).to(dev)
     assert flat.numel() == sizes[rank], (flat.numel(), sizes[rank])
+    mx = max(max(sizes), 1)
+    pad = torch.zeros(mx, dtype=torch.float32, device=dev)
+    pad[: flat.numel()] = flat
+    bufs = [torch.empty(mx, dtype=torch.float32, device=dev) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, gather_list=bufs, dst=dst)
     if rank != dst:
-        if sizes[rank] > 0:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat.contiguous(), dst)]):
-                w.wait()
         return None, meta
-    bufs = [flat if r == dst else torch.empty(sizes[r], dtype=torch.float32, device=dev) for r in range(world)]
-    ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(world) if r != dst and sizes[r] > 0]
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    return bufs, meta
+    return [bufs[r][: sizes[r]] for r in range(world)], meta

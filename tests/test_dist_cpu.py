@@ -68,7 +68,7 @@ WORKER = textwrap.dedent("""
         bufs1, meta1 = pdist.gather_ragged_to(local, lens, dst=dst)
         assert meta1 == meta
         if rank == dst:
-            assert len(bufs1) == world and bufs1[rank].data_ptr() == local.data_ptr()
+            assert len(bufs1) == world
             for r in range(world):
                 assert torch.equal(bufs1[r], bufs[r]), r
         else:
