@@ -321,6 +321,29 @@ def load(path, **configs):
     return parse(obj)
 
 
+def save(obj, path, protocol=2, **configs):
+    """``paddle.save`` of Paddle 2.1.x: the restatement lives in tools/make_paddle_fixture.py (``paddle_save``: the
+    ``_legacy_save`` path for a bare state dict, ``_pickle_save`` with the VarBase reducer otherwise); here Tensor leaves become
+    its stand-in VarBase objects, named like Paddle names parameters.  Used by tools/verify_with_paddle.py when the "real
+    Paddle" code path is exercised over a disguised stand-in (tests/test_verify_paddle_cpu.py)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(os.path.realpath(__file__))))))
+    spec = importlib.util.spec_from_file_location("_pk_make_paddle_fixture", os.path.join(root, "tools", "make_paddle_fixture.py"))
+    mpf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mpf)
+    n = [0]
+
+    def conv(o):
+        if isinstance(o, torch.Tensor):
+            n[0] += 1
+            return mpf.VarBase("param_%d" % n[0], o.detach().cpu().numpy())
+        if isinstance(o, dict):
+            return type(o)((k, conv(v)) for k, v in o.items())
+        return o
+    mpf.paddle_save(conv(obj), path, protocol=protocol)
+
+
 from . import nn  # noqa: E402,F401
 
 

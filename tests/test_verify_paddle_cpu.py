@@ -61,3 +61,37 @@ def test_committed_stand_in_fixture_is_what_the_script_writes(run):
         assert sorted(a.files) == sorted(b.files)
         for k in a.files:
             assert np.array_equal(a[k], b[k]), (name, k)
+
+
+def test_real_paddle_code_paths_over_a_disguised_stand_in(tmp_path):
+    """The branches only PARAKEET_REAL_PADDLE=1 takes -- the stand-in kept OFF sys.path, ``F.dropout`` replaced for the prenet's
+    always-on dropout, ONE reading of padding="same" named after the oracle reading it equals, archives through ``paddle.save``,
+    the typeguard stub -- cannot meet Paddle here; they run against the stand-in under another path, which ref_import cannot tell
+    from an installed package.  Everything it writes must equal what the stand-in leg writes."""
+    fake = tmp_path / "site"
+    fake.mkdir()
+    os.symlink(os.path.join(ROOT, "oracle", "paddle_shim", "paddle"), fake / "paddle")
+    out = tmp_path / "golden_paddle"
+    env = {k: v for k, v in os.environ.items() if k != "PARAKEET_GOLDEN_DIR"}
+    env.update(PARAKEET_REAL_PADDLE="1", PYTHONPATH=str(fake) + os.pathsep + env.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verify_with_paddle.py"), "--out", str(out), "--quick",
+                        "--only", "make_golden_speedyspeech.py,make_golden_ar.py"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "backend: paddle" in r.stdout
+    rep = json.load(open(out / "report.json"))
+    assert rep["backend"] == "paddle" and not rep["diff"]["infinite"] and rep["diff"]["worst"] == 0.0
+    gold = os.path.join(ROOT, "tests", "golden")
+    # the autoregressive models: the dropout stream injected through the replaced F.dropout gives the stand-in's vectors
+    for name in ("transformer_tts.npz", "tacotron2.npz"):
+        a, b = np.load(out / name), np.load(os.path.join(gold, name))
+        assert sorted(a.files) == sorted(b.files) and all(np.array_equal(a[k], b[k]) for k in a.files), name
+    # SpeedySpeech: one reading, recognised as the dilation-resetting one (the disguised stand-in's default), stored under its tag
+    a, b = np.load(out / "speedyspeech_baker.npz"), np.load(os.path.join(gold, "speedyspeech_baker.npz"))
+    assert str(a["paddle_same_padding_reading"]) == "rd" and not any(k.startswith(("dil_", "real_mel")) for k in a.files)
+    assert all(np.array_equal(a[k], b[k]) for k in a.files if k.startswith("rd_"))
+    # the released-layout leg and the archives: same numbers as the stand-in leg's committed fixtures
+    for name in ("released_standin.npz", "released_waveflow_standin.npz"):
+        a, b = np.load(out / name), np.load(os.path.join(gold, name))
+        assert all(np.array_equal(a[k], b[k]) for k in a.files), name
+    rc.check_paddle_written(str(out))
+    assert rc.check_oracle_released(str(out / "released_standin.npz"), str(out / "released"))["mel"] < 2e-5

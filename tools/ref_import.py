@@ -129,12 +129,19 @@ def dropout_hook(keep_fn):
         finally:
             PF.DROPOUT_HOOK = None
         return
+    import inspect
     orig = PF.dropout
+    sig = inspect.signature(orig)     # (x, p=0.5, axis=None, training=True, mode="upscale_in_train", name=None) in Paddle 2.1
 
-    def dropout(x, p=0.5, axis=None, training=True, mode="upscale_in_train", name=None):
-        if not training or p <= 0:
-            return orig(x, p=p, axis=axis, training=training, mode=mode, name=name)
-        assert mode == "upscale_in_train" and axis is None
+    def dropout(*args, **kwargs):
+        bound = sig.bind(*args, **kwargs)
+        bound.apply_defaults()
+        arg = dict(bound.arguments)
+        arg.update(arg.pop("k", {}) if isinstance(arg.get("k"), dict) else {})   # (a stand-in's **k catch-all)
+        x, p = arg["x"], arg.get("p", 0.5)
+        if not arg.get("training", True) or p <= 0:
+            return orig(*args, **kwargs)
+        assert arg.get("mode", "upscale_in_train") == "upscale_in_train" and arg.get("axis") is None, arg
         keep = paddle.to_tensor(np.asarray(keep_fn(tuple(int(s) for s in x.shape), p), bool))
         return paddle.where(keep, x / (1.0 - p), paddle.zeros_like(x))
     PF.dropout = dropout
