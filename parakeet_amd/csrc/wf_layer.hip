@@ -179,6 +179,13 @@ __device__ __forceinline__ f16x8 pow2_neg_h8(int d) {
     const u32x4 v = {u, u, u, u};
     return __builtin_bit_cast(f16x8, v);
 }
+// v of lane ^ 32
+__device__ __forceinline__ float xor32(float v, int lane, bool own_lane) {
+#ifndef PK_HIPEMU
+    if (own_lane) return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v)));
+#endif
+    return __shfl_xor(v, 32);
+}
 __device__ __forceinline__ f16x8 ld_h8(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
 
@@ -433,7 +440,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     __syncthreads();   // tables visible
     for (int base = t_begin; base < t_end;) {   // uniform over the workgroup
         const int nact = min(a.active, t_end - base);
-        const int wt = base + wave;
+        const int wt = base + (LEAN ? __builtin_amdgcn_readfirstlane(wave) : wave);   // (LEAN: the tile index as a scalar -- what derives from it
+                                                                                       // alone, e.g. the block index of out_amax, needs no vector register)
         const bool tile_ok = wave < nact;
         base += nact;
         const int p0 = tile_ok ? wt * WAVE_T : 0;
@@ -665,7 +673,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             float2 prm_old = {0.f, 0.f};
             // (12 waves: the epilogue's lane coordinates are derived HERE, from an opaque zero -- not hoisted, not spilled)
             const int ez = opaque_zero<LEAN>();
-            const int lane_e = lane + ez, hh_e = LEAN ? lane_e >> 5 : hh;
+            // (LEAN: the lane index itself recomputed -- v_mbcnt of an all-ones mask on top of the opaque zero -- so that not even
+            // it has to live, or be spilled, through the slab loop)
+            const int lane_e = LEAN ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)ez)) : lane + ez;
+            const int hh_e = LEAN ? lane_e >> 5 : hh;
             const int p_e = LEAN ? p0 + (lane_e & 31) : p;
             const long pblk_e = LEAN ? (long)(p_e >> 5) : pblk;
             const int pin_e = LEAN ? p_e & 31 : pin;
@@ -740,8 +751,11 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 }
             }
             const bool lane_ok = p_utt_e >= 0;
-            pl += __shfl_xor(pl, 32);   // the other half wave holds the other C/2 channels of the same position
-            pb += __shfl_xor(pb, 32);
+            // the other half wave holds the other C/2 channels of the same position.  (LEAN: the exchange addressed from the
+            // recomputed lane index -- __shfl_xor derives its own from v_mbcnt, which the compiler merges with the kernel's first
+            // and keeps, or spills, through the slab loop)
+            pl += xor32(pl, lane_e, LEAN);
+            pb += xor32(pb, lane_e, LEAN);
             float2 prm_new = {prm_old.x + pl, prm_old.y + pb};   // skips summed (:390), then output_proj (:499-500)
             if (!lane_ok) prm_new = float2{0.f, 0.f};
             if (hh_e == 0 && !(ABL & 4)) reinterpret_cast<float2*>(a.prm)[p_e] = prm_new;

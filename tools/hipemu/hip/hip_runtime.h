@@ -300,6 +300,9 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 static inline float hipemu_fmed3f(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) hipemu_fmed3f(a, b, c)
 // used in this code base only to pin wave-uniform values into scalar registers
+// v_mbcnt_lo / _hi with an all-ones mask (the only use): base + the lane's index among the lower / upper 32 lanes below it
+#define __builtin_amdgcn_mbcnt_lo(m, b) ((unsigned)(b) + ((threadIdx.x & 63u) < 32u ? (threadIdx.x & 63u) : 32u))
+#define __builtin_amdgcn_mbcnt_hi(m, b) ((unsigned)(b) + ((threadIdx.x & 63u) < 32u ? 0u : (threadIdx.x & 63u) - 32u))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_readlane(v, lane) hipemu::readlane(v, lane)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp(old, src, ctrl, rm, bm, bc)
