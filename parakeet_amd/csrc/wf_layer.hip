@@ -235,8 +235,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     // LEAN: the kernels that live at their register limit (three waves per SIMD: 168; 128 channels: 128 of the 256 are
     // accumulators) derive round-, slab- and epilogue-only coordinates from opaque zeros so that nothing thread-invariant is
     // hoisted to the kernel's top, spilled there and reloaded inside the slab loop (round 4 for the 12-wave kernel; round 5 for
-    // the 128-channel one: 29 - 31 spilled registers and 2 665 scratch instructions in the unrolled slab loop -> 5 - 7 and 11,
-    // none of them in the loop; fp16 operands: 8 -> 0).  The 8-wave 64-channel kernels are compiled exactly as before.
+    // the 128-channel one: 29 - 31 spilled registers and 2 665 scratch instructions in the unrolled slab loop -> 0;
+    // fp16 operands: 8 -> 0).  The 8-wave 64-channel kernels are compiled exactly as before.
     // (fp16 operands at 128 channels -- 8 spilled registers, bound by vector issue: with the weight addresses still read from
     // the kt_w table the recomputed coordinates cost more than the spills did, 92.7 -> 98.5 us per launch; with the linear
     // addresses 94.5 -> 93.3: profiles/r05_wf_ab.txt.)
