@@ -527,10 +527,13 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     float kreg[KG][8], vreg[VG][8];
-    auto load_tile = [&](int k0) {
+    // (tl = the thread index the staging coordinates derive from: the loop passes it on top of an opaque zero renewed per key tile,
+    // so that the dozen thread-invariant offsets are recomputed -- a few integer instructions per 72 MFMAs -- instead of being
+    // hoisted out of the loop, spilled there (17 registers in the 8-tile kernel) and reloaded in every iteration; round 5)
+    auto load_tile = [&](int k0, int tl) {
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
-            const int idx = min(tid + NT * g, 32 * (DK / 8) - 1);   // (key, 8-float group) of the K tile
+            const int idx = min(tl + NT * g, 32 * (DK / 8) - 1);   // (key, 8-float group) of the K tile
             const int key = idx / (DK / 8), grp = idx % (DK / 8);
             const float* kp = base + a.D + (long)min(k0 + key, len - 1) * ld + 8 * grp;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(kp);
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
         }
 #pragma unroll
         for (int g = 0; g < VG; ++g) {
-            const int idx = min(tid + NT * g, 2 * DT * 64 - 1);     // (s2, dt, fragment lane) of the V tile
+            const int idx = min(tl + NT * g, 2 * DT * 64 - 1);     // (s2, dt, fragment lane) of the V tile
             const int fl = idx & 63, dt = (idx >> 6) % DT, s2 = idx / (64 * DT);
             const float* vp = base + 2 * a.D + 32 * dt + (fl & 31);
 #pragma unroll
@@ -548,12 +551,12 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
                 vreg[g][e] = vp[(long)min(k0 + mfma_row(8 * s2 + e, fl >> 5), len - 1) * ld];
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int tl) {
         at_f16x8* kf = Kf + buf * KSZ;
         at_f16x8* vf = Vf + buf * VSZ;
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
-            const int idx = tid + NT * g;
+            const int idx = tl + NT * g;
             if (idx >= 32 * (DK / 8)) break;
             const int key = idx / (DK / 8), grp = idx % (DK / 8);
             at_f16x8 fh, fl_;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
         }
 #pragma unroll
         for (int g = 0; g < VG; ++g) {
-            const int idx = tid + NT * g;
+            const int idx = tl + NT * g;
             if (idx >= 2 * DT * 64) break;
             const int fl = idx & 63, dt = (idx >> 6) % DT, s2 = idx / (64 * DT);
             at_f16x8 fh, fl_;
@@ -574,21 +577,24 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
         }
     };
 
-    load_tile(0);
+    load_tile(0, tid);
     if (PIPE) {
-        store_tile(0);
-        load_tile(32);   // (rows are clamped to the utterance: a tile beyond its end is loaded and stored, never multiplied)
+        store_tile(0, tid);
+        load_tile(32, tid);   // (rows are clamped to the utterance: a tile beyond its end is loaded and stored, never multiplied)
     }
     for (int k0 = 0, it = 0; k0 < len; k0 += 32, ++it) {
         const int cur = PIPE ? (it & 1) : 0;
+        int oz = 0;
+        if (NTHR > ATT_THREADS) asm volatile("" : "+s"(oz));   // (the 8-tile kernel: 256 registers; the 4-tile kernels have 512 and keep their code)
+        const int tl = tid + oz;
         __syncthreads();          // every wave is done with the previous tile's fragments (PIPE: and sees this tile's)
         if (PIPE) {
-            store_tile(cur ^ 1);
-            load_tile(k0 + 64);
+            store_tile(cur ^ 1, tl);
+            load_tile(k0 + 64, tl);
         } else {
-            store_tile(0);
+            store_tile(0, tl);
             __syncthreads();
-            if (k0 + 32 < len) load_tile(k0 + 32);
+            if (k0 + 32 < len) load_tile(k0 + 32, tl);
         }
         const at_f16x8* kf = Kf + cur * KSZ;
         const at_f16x8* vf = Vf + cur * VSZ;
