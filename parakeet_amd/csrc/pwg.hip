@@ -121,12 +121,6 @@ struct PwgGen {
     const float* P0;       // P + this layer's column block, row 0 = frame 0 of utterance 0
     int hop;
     float inv_hop;
-    // round 5: everything gen_coord needs of a tile in ONE 16-byte record {s0, S, F, row0}, which the split-math layer kernel
-    // requests a tile ahead (with tile_t0).  Through the tables above the coordinates were two levels of dependent loads
-    // (tile -> utterance -> its sizes) in front of the P rows' addresses, and a load that feeds an address is waited for with
-    // vmcnt(0): twice per tile the whole operand prefetch was drained (hop 300: 1.96 ms per layer against 1.38 at hop 256
-    // for 17 % more samples)
-    const int4* tile_rec;
 };
 struct PwgGenCoord {
     int fa;       // frame of the wave tile's first (clamped) sample: P rows fa-2 .. fa+3 are staged
@@ -142,14 +136,10 @@ __device__ __forceinline__ int gen_div_hop(int s, int hop, float inv_hop) {   //
     q += r < 0 ? -1 : (r >= hop ? 1 : 0);
     return q;
 }
-__device__ __forceinline__ PwgGenCoord gen_coord_rec(const PwgGen& g, int4 rec, int sub, int j);
 __device__ __forceinline__ PwgGenCoord gen_coord(const PwgGen& g, int tile, int sub, int j) {
     const int b = g.tile_utt[tile];
-    return gen_coord_rec(g, int4{g.tile_s0[tile], g.utt_S[b], g.utt_F[b], g.utt_row0[b]}, sub, j);
-}
-__device__ __forceinline__ PwgGenCoord gen_coord_rec(const PwgGen& g, int4 rec, int sub, int j) {
-    const int S = rec.y, F = rec.z;
-    const int s0 = rec.x + sub * WAVE_T;
+    const int S = g.utt_S[b], F = g.utt_F[b];
+    const int s0 = g.tile_s0[tile] + sub * WAVE_T;
     PwgGenCoord c;
     c.valid = s0 + j < S;
     const int sc = min(s0 + j, S - 1), s0c = min(s0, S - 1);
@@ -158,7 +148,7 @@ __device__ __forceinline__ PwgGenCoord gen_coord_rec(const PwgGen& g, int4 rec, 
     c.df = f - c.fa;
     c.phase = sc - f * g.hop;
     c.cls = min(f, 2) * 3 + min(F - 1 - f, 2);
-    c.row0 = rec.w;
+    c.row0 = g.utt_row0[b];
     return c;
 }
 
@@ -856,12 +846,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     float uw[UPW];
     int df_n = 0;          // GEN: this lane's frame minus the first staged frame (0 / 1) of the tile being prefetched
     bool valid_n = true;   // GEN: the lane's sample lies inside its utterance
-    auto prefetch_head = [&](int wt, int cls, int4 rec) {   // cls: edge class of the tile (hop 256), known a tile ahead; rec: GEN, likewise
+    auto prefetch_head = [&](int wt, int cls) {   // cls: edge class of the tile (hop 256), known a tile ahead
         const int tile = wt >> 3, phase = (wt & 7) * WAVE_T + j;
         const float* prow;
         long wsel;   // row of the upsampler table: edge class * hop + phase
         if constexpr (GEN) {
-            const PwgGenCoord gc = gen_coord_rec(a.gen, rec, wt & 7, j);
+            const PwgGenCoord gc = gen_coord(a.gen, tile, wt & 7, j);
             prow = a.gen.P0 + (long)(gc.row0 + gc.fa - 2) * a.ldp;
             wsel = (long)gc.cls * a.gen.hop + gc.phase;
             df_n = gc.df;
@@ -890,7 +880,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             vo8n[tp] = lane_off(t0c, my_slot, tp);
             if constexpr (PL) pvo8n[tp] = lane_off_pl(t0c, my_slot, tp);
         }
-        prefetch_head(my_slot, __builtin_amdgcn_readfirstlane(t0c & 255), GEN ? a.gen.tile_rec[my_slot >> 3] : int4{0, 0, 0, 0});
+        prefetch_head(my_slot, __builtin_amdgcn_readfirstlane(t0c & 255));
 #pragma unroll
         for (int g = 0; g < B3_RING; ++g) load_group(ring[g], g, vo8n[g % 3], pvo8n[g % 3]);
         if constexpr (PL) {
@@ -921,8 +911,6 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             pvo8[tp] = pvo8n[tp];
         }
         const int t0n = a.tile_t0[next_wt >> 3];   // requested here, first used at k-step T0_USE of stage 1
-        int4 recn = {0, 0, 0, 0};                  // GEN: the next tile's record, used by prefetch_head after stage 1
-        if constexpr (GEN) recn = a.gen.tile_rec[next_wt >> 3];
         int ko_v = 0;   // PL: scale exponent of this tile's x_out
         if constexpr (PL) {
             kxn_v = a.tile_kx_in[next_wt >> 3];
@@ -1051,7 +1039,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             ph = nh;
             pl = nl;
         }
-        prefetch_head(next_wt, cls_next, recn);
+        prefetch_head(next_wt, cls_next);
         float sk_old[32];   // skip accumulator: requested half-way through pass 0, used at the end of pass 1
         __builtin_amdgcn_sched_barrier(0);
 
@@ -1958,19 +1946,6 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             }
         }
     const size_t o_tile = push(tile_t0), o_cls = push(tile_cls), o_ts0 = push(tile_s0), o_tutt = push(tile_utt);
-    size_t o_trec = 0;
-    if (gen) {   // {s0, S, F, row0} per tile, 16-byte aligned (PwgGen::tile_rec)
-        tab.resize((tab.size() + 3) & ~(size_t)3, 0);
-        std::vector<int> rec((size_t)sumC * 4);
-        for (int i = 0; i < sumC; ++i) {
-            const int b = tile_utt[i];
-            rec[4 * (size_t)i + 0] = tile_s0[i];
-            rec[4 * (size_t)i + 1] = utt_S[b];
-            rec[4 * (size_t)i + 2] = frames[b];
-            rec[4 * (size_t)i + 3] = cuL[b];
-        }
-        o_trec = push(rec);
-    }
     const size_t o_uS = push(utt_S), o_uF = push(std::vector<int>(frames, frames + B)), o_uoff = push(utt_off);
     h->last_o_cls = o_cls;
     // conv_in's padded row timeline (k_pwg_convin_prep): source mel row and destination c0 row (-1: padding)
@@ -2042,7 +2017,6 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     gtab.utt_F = d_tab + o_uF;
     gtab.utt_row0 = d_tab + o_cul;
     gtab.utt_off = d_tab + o_uoff;
-    gtab.tile_rec = reinterpret_cast<const int4*>(d_tab + o_trec);
     gtab.P0 = nullptr;
     gtab.hop = hop;
     gtab.inv_hop = 1.0f / (float)hop;
@@ -2181,7 +2155,6 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
             a.gen = gtab;
             a.gen.tile_s0 += tile0;
             a.gen.tile_utt += tile0;
-            a.gen.tile_rec += tile0;
             a.gen.P0 = P + (size_t)l * G;
             a.uptab = h->d_uptab.as<float>();
             a.tile_t0 = d_tab + o_tile + tile0;
