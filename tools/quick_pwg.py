@@ -3,7 +3,7 @@ import time, numpy as np, torch
 from parakeet_amd import synthetic as syn
 from parakeet_amd.parallel_wavegan import PWGGenerator
 from parakeet_amd.runtime import Context
-B, L = 32, 640
+B, L = int(os.environ.get("PK_QPWG_B", 32)), int(os.environ.get("PK_QPWG_L", 640))
 cfg = dict(syn.PWG_LJSPEECH)
 if os.environ.get("PK_QPWG_SCALES"): cfg["upsample_scales"] = [int(v) for v in os.environ["PK_QPWG_SCALES"].split(",")]   # e.g. 4,5,3,5 = hop 300 (baker / vctk)
 HOP = int(np.prod(cfg["upsample_scales"]))
