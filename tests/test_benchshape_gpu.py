@@ -106,6 +106,63 @@ def test_e2e_batch32_bench_shape_vs_oracle():
         assert err < 1e-4 and err < 1e-5, f"utt {b}: wav rel err {err}"      # (measured 1.3e-6)
 
 
+def test_e2e_global_batch_256_in_one_call():
+    """BASELINE config 4's whole global batch on ONE GPU in ONE engine call (the N = 1 point of the strong-scaling curve with
+    --minibatch 256): 256 ragged utterances (64-128 tokens, 5 frames per token: 31 M samples, a 10 GB working set).  Sizes this
+    large are where 32-bit offsets would wrap: utterances from the start, the middle and the very end of the packed buffers
+    against the same utterances synthesised three at a time (an utterance's result does not depend on its batch: mel bit for
+    bit), and the last one against the fp64 oracle."""
+    from oracle import fastspeech2_ref, pwg_ref
+    from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
+    from parakeet_amd.normalizer import ZScore
+    from parakeet_amd.parallel_wavegan import PWGGenerator, PWGInference
+    from parakeet_amd.synthesize import Synthesizer
+    fs2_state = syn.fastspeech2_state(80, 80, fixed_duration=5)
+    pwg_state = syn.pwg_state()
+    am = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am.set_state_dict(fs2_state)
+    am.eval()
+    voc = PWGGenerator(**syn.PWG_LJSPEECH)
+    voc.set_state_dict(pwg_state)
+    voc.remove_weight_norm()
+    voc.eval()
+    mu_f, sg_f = syn.mel_stats(seed=7)
+    mu_p, sg_p = syn.mel_stats(seed=8)
+    synth = Synthesizer(FastSpeech2Inference(ZScore(mu_f, sg_f), am), PWGInference(ZScore(mu_p, sg_p), voc))
+    rng = np.random.default_rng(256)
+    tokens = [int(t) for t in rng.integers(64, 129, size=256)]
+    tokens[-1] = 128
+    texts = [syn.phoneme_ids(t, seed=20000 + i) for i, t in enumerate(tokens)]
+    samples = [t * 5 * 256 for t in tokens]
+    offs = np.concatenate([[0], np.cumsum(samples)])
+    noise = torch.randn(int(offs[-1]), device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    wav, frames = synth.synthesize_packed(texts, noise=noise)
+    assert frames.tolist() == [5 * t for t in tokens]
+    mel = am.decode_packed(denormalize=True).as_subclass(torch.Tensor).cpu().numpy()
+    wav = wav.cpu().numpy()
+    assert wav.shape == (int(offs[-1]),) and np.isfinite(wav).all()
+    foffs = np.concatenate([[0], np.cumsum([5 * t for t in tokens])])
+    pick = [0, 127, 255]
+    small_noise = torch.cat([noise[offs[b]:offs[b + 1]] for b in pick])
+    wav3, frames3 = synth.synthesize_packed([texts[b] for b in pick], noise=small_noise)
+    mel3 = am.decode_packed(denormalize=True).as_subclass(torch.Tensor).cpu().numpy()
+    wav3 = wav3.cpu().numpy()
+    o3 = np.concatenate([[0], np.cumsum([samples[b] for b in pick])])
+    f3 = np.concatenate([[0], np.cumsum([5 * tokens[b] for b in pick])])
+    for i, b in enumerate(pick):
+        assert np.array_equal(mel[foffs[b]:foffs[b + 1]], mel3[f3[i]:f3[i + 1]]), f"utt {b}: mel depends on the batch"
+        err = _rel_err(wav[offs[b]:offs[b + 1]], wav3[o3[i]:o3[i + 1]])
+        assert err < 2e-6, f"utt {b}: waveform differs from the three-utterance call by {err}"
+    b = 255
+    with torch.no_grad():
+        logmel = fastspeech2_ref.fastspeech2_inference(fs2_state, mu_f, sg_f, texts[b], dtype=torch.float64)
+        want = pwg_ref.pwg_inference(pwg_state, mu_p, sg_p, logmel, noise[offs[b]:offs[b + 1]].cpu(), dtype=torch.float64)[:, 0].numpy()
+    l1 = float(np.abs(mel[foffs[b]:foffs[b + 1]] - logmel.numpy()).mean())
+    assert l1 < MEL_L1_BAR, f"utt {b}: mel L1 {l1}"
+    err = _rel_err(wav[offs[b]:offs[b + 1]], want)
+    assert err < 1e-5, f"utt {b}: wav rel err {err}"
+
+
 def test_fs2_batch16_ragged_vs_oracle():
     """BASELINE config 2's parity shape: 16 ragged utterances (T in [37, 128]) with a random duration head;
     every utterance against its own oracle call (the existing bookkeeping test only checks shapes)."""
