@@ -197,7 +197,9 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
                  "(examples/waveflow/synthesize.py:40), set_math('f16'); NOT fp32-equivalent (about 1e-4 of the peak)"
                  if math == "f16" else
                  "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes") +
-                ("; 12-wave workgroups (one round of 11 tiles per workgroup), the row's step fused into its last layer's launch"
+                (("; 12-wave workgroups (one round of 11 tiles per workgroup)" if math == "f16" else
+                  "; 8-wave workgroups (8 + 3 tiles per workgroup: three waves per SIMD are for fp16 operands only since round 5, "
+                  "HISTORY.md 9.9)") + ", the row's step fused into its last layer's launch"
                  if channels == 64 else "; 8-wave workgroups (round 5: no spills in the slab loop)") +
                 ("; only the hi parts of the weights travel to LDS (round 5)" if math == "f16" else ""),
         "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,

@@ -300,12 +300,14 @@ int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t
  * waveform's peak away from the fp64 oracle; 64- and 128-channel models only (PK_EUNSUPPORTED otherwise). */
 int pk_wf_set_math(pk_wf* h, int32_t mode);
 /* Named integer options (as pk_pwg_set_option; scheduling only, results do not change):
- *   "layer_waves"  0 (default) = the fused layer kernel runs in 12-wave workgroups where that saves a round over 8-wave ones
- *                  (64-channel model), 8 / 12 = forced (12: 64 channels only, PK_EUNSUPPORTED otherwise); 6 = two independent
- *                  6-wave workgroups per CU with 24 KB weight slabs (64 channels only)
- *   "persistent"   0 (default) = one launch per residual layer; 1 = the layers of a row in ONE cooperative launch with a barrier
- *                  across the grid between two layers (120 launches per batch instead of 960; same results; measured slower on
- *                  the MI355X -- a grid-wide barrier on 8 XCDs costs more than the gap between two launches)
+ *   "layer_waves"  0 (default) = with fp16 operands (pk_wf_set_math 2) the fused layer kernel of the 64-channel model runs in
+ *                  12-wave workgroups where that saves a round over 8-wave ones; in the default math always 8-wave workgroups.
+ *                  8 / 12 = forced.  12 with the default math, and 6 (two 6-wave workgroups per CU), are refused when the call is
+ *                  made (PK_EUNSUPPORTED): three waves per SIMD running the default math's back-to-back dependent matrix
+ *                  instructions gave non-deterministic results on the MI355X (round 5, HISTORY.md 9.9)
+ *   "persistent"   0 only.  (1 = the layers of a row in ONE cooperative launch with a barrier across the grid between two layers:
+ *                  measured slower than eight launches in round 4, found non-deterministic beyond small sizes in round 5;
+ *                  PK_EUNSUPPORTED in the product, kept in the profile build)
  *   "fuse_step"    1 (default) = a row's affine step and the next row's input projection happen in the launch of its last
  *                  layer; 0 = in a kernel of their own */
 int pk_wf_set_option(pk_wf* h, const char* key, int64_t value);

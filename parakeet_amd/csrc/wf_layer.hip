@@ -48,6 +48,12 @@ typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 #ifndef PK_WF_LINW
 #define PK_WF_LINW 1      // the weight chunks' source addresses as a linear function of the thread index (0: through the kt_w table, as
 #endif                    // rounds 2 - 4 did; kept for the A/B)
+#ifndef PK_WF_LATE_REFILL
+#define PK_WF_LATE_REFILL 0
+#endif
+#ifndef PK_WF_AHEAD128
+#define PK_WF_AHEAD128 1   // A fragments of the 128-channel kernel this many co-tiles ahead (round 5: 2; 1 = rounds 3 - 4)
+#endif
 #ifndef PK_WF_RING128
 #define PK_WF_RING128 6   // operand ring of the 128-channel kernel in k-steps (two slabs).  Round 5: 3 ... 6 compile to the same
 #endif                    // register use once nothing is hoisted into the slab loop (LEAN below): the spills were never the ring
@@ -376,6 +382,16 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
         asm volatile("" : "+s"(o));
         return &wbuf[0][0] + (o + (unsigned)tid);
     };
+    // Round 5 (HISTORY 9.9): behind each of role B's prologue stores in the 12- / 6-wave kernels of the default math, wait for the
+    // store.  These kernels have 168 registers; the addresses beyond the 64 KB reach of a ds_write offset are materialised into
+    // ONE temporary -- which also was the first chunk's data register -- rewritten between the stores
+    // (ds_write_b128 v6, v[18:21]; v_add_u32 v6, 0x11000, v133; ds_write_b128 v6, ...).  With the LDS queue full of the role-A
+    // waves' slab-0 reads, one call in five of the benchmark's shape stored a clobbered chunk (errors of 1e-3 in the tiles of
+    // one workgroup, different on every run); with the stores drained one by one none in 200.  (8 waves: two persistent address
+    // registers; fp16 operands: 24 KB slabs within reach of two bases -- no temporaries there, and no failures.)
+    auto pro_b_fence = [&]() {
+        if constexpr (W != 8 && !F16) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    };
     auto w_store = [&](int g) {
         if (g >= G) return;
         if constexpr (WST) {
@@ -548,7 +564,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             if constexpr (NEWPRO) {
                 if (!role_a) {
 #pragma unroll
-                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
+                    for (int c = 0; c < CL; ++c) {
+                        wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
+                        pro_b_fence();
+                    }
                 }
                 ex_ = tile_exp();
             }
@@ -629,7 +648,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     // A fragments AHEAD co-tiles ahead of their MFMAs (not all NQ of them: registers).  Two at 64 channels:
                     // with one, every co-tile's three MFMAs (96 cycles) had to cover a whole LDS read latency, and the trace
                     // showed about 200 cycles per k-step and wave that nothing covered
-                    constexpr int AHEAD = (CT == 2 && !(ABL & 32) && !(W != 8 && !F16)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
+                    constexpr int AHEAD = ((CT == 2 || PK_WF_AHEAD128 == 2) && !(ABL & 32) && !(W != 8 && !F16)) ? 2 : 1, PER = F16 ? 1 : 2, MM = F16 ? 1 : 3;   // (12 waves, split
                     // math: one -- registers; the other two waves of the SIMD cover the LDS latency)
                     __builtin_amdgcn_sched_group_barrier(0x100, PER * (AHEAD + 0), 0);
 #pragma unroll
@@ -639,7 +658,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     }
                     if (TIGHT) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (ks + RING < nks) load_b(ks + RING, tz);
+                        // (round 5, HISTORY 9.9: the slot consumed ONE k-step ago -- PK_WF_LATE_REFILL=1 -- not the one this k-step's
+                        // matrix instructions may still be reading when the refill's data arrives)
+                        if (ks - PK_WF_LATE_REFILL >= 0 && ks - PK_WF_LATE_REFILL + RING < nks) load_b(ks - PK_WF_LATE_REFILL + RING, tz);
                         if (PERK && NW > 0) {
                             const int lo = part_lo(kk), n = part_lo(kk + 1) - lo, n1 = kk + 1 < SLAB ? part_lo(kk + 2) - part_lo(kk + 1) : 0;
                             f16x8* const dst = wst((g + 2) % 3);
@@ -801,13 +822,35 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 const float xs = pow2f(-(PK_BLK_TOP + 127 - amax_exp(cur_am)));   // the stored input is x * 2^k
                 float v[CT][16];
                 float am = 0.f;
+                // Round 5 (HISTORY 9.9): x_in FIRST, all of it, and only then the accumulators.  The out projection ends in
+                // CT interleaved dependent MFMA chains; the compiler guards the first read of an accumulator with the minimum
+                // the hazard table asks for (s_nop 10: 12 issue slots after that accumulator's last MFMA).  With a second
+                // working wave on the SIMD (its MFMAs in the same pipe) that was one slot short now and then: the 64-channel
+                // kernels returned a few wrong tiles per call (errors of 1e-3, different on every run) whenever a workgroup had
+                // more than four tiles -- found by hand-editing the assembly (same size: only that s_nop widened to 15 cures
+                // it; tools/asm_variant.py, tools/mfma_slack.py).  The 4 CT x 8 conversions and multiply-adds below do not touch
+                // the accumulators: > 100 issue slots between the last MFMA and the first read, at no cost (they were there
+                // anyway, interleaved with the reads).
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < CT; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kq = 2 * t + (r >> 3), e = r & 7;
-                        // res + x_in with x_in = (hi + lo) * 2^-k: one multiply and two v_fma_mix (the halves are sources)
-                        float o = fmaf((float)xin_hi[kq][e], xs, fmaf((float)xin_lo[kq][e], xs, acc2[t][r] * i_res));
+                        // x_in = (hi + lo) * 2^-k: one multiply and one v_fma_mix (the halves are sources)
+                        v[t][r] = fmaf((float)xin_hi[kq][e], xs, (float)xin_lo[kq][e] * xs);
+                        asm volatile("" : "+v"(v[t][r]));   // (computed HERE: pure arithmetic would sink to its use behind the barrier)
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef PK_HIPEMU
+                asm volatile("s_nop 15");   // (belt and braces: sixteen more slots, 64 cycles of a 25 000-cycle tile)
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < CT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float o = fmaf(acc2[t][r], i_res, v[t][r]);   // res + x_in
                         if (!lane_ok) o = 0.f;   // gap positions stay zero
                         am = fmaxf(am, fabsf(o));
                         v[t][r] = o;
@@ -898,7 +941,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 __syncthreads();
                 if (!role_a) {
 #pragma unroll
-                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
+                    for (int c = 0; c < CL; ++c) {
+                        wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
+                        pro_b_fence();
+                    }
                 }
             }
 #pragma unroll
@@ -1162,15 +1208,32 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     // 64 channels: 12-wave workgroups (three waves per SIMD, 168 registers) where they save a round -- the tiles of a
     // workgroup in ceil(t / 12) rounds instead of ceil(t / 8) (the benchmark's 8 x 640 frames: 11 tiles per workgroup, one round
     // instead of 8 + 3 with the second 3/8 full).  a.waves = 8 / 12 forces one (option "layer_waves" of pk_wf_set_option).
+    // Round 5 (HISTORY 9.9): THREE waves per SIMD (12-wave workgroups, or two 6-wave ones per CU) only with fp16 operands.  In the
+    // default math every accumulator receives three dependent matrix instructions back to back; with three waves of a SIMD
+    // issuing such chains side by side, 7 - 25 % of the calls of the benchmark's shape came back with the tiles of one
+    // workgroup off by 1e-3, different on every run (no s_nop of the compiler's widened cures it: tools/asm_variant.py; the
+    // fp16-operand kernels -- one instruction per accumulator and k-step -- and the 8-wave kernels: 0 of 100 runs, bit-identical).
+    // The product therefore runs the default math in 8-wave workgroups only and refuses the option; the profile build keeps
+    // the kernels for whoever wants to find the instruction pair.
+    if (!PK_PROFILE_BUILD && (a.waves == 6 || (a.waves == 12 && !a.f16)))
+        PK_FAIL(PK_EUNSUPPORTED, "wfl_layer_launch: %d-wave workgroups are %s (three waves per SIMD gave non-deterministic results on the MI355X)",
+                a.waves, a.waves == 6 ? "not in the product" : "for fp16 operands only");
     const bool w6 = a.C == 64 && a.waves == 6 && a.nl == 1;   // two 6-wave workgroups per CU (see Shape)
-    const bool w12 = !w6 && a.C == 64 && (a.waves == 12 || a.waves == 6 || (a.waves != 8 && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));
+    const bool w12 = !w6 && a.C == 64 && (a.waves == 12 || a.waves == 6 ||
+                                          (a.waves != 8 && (a.f16 || PK_PROFILE_BUILD) && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));
     const int W = w6 ? 6 : (w12 ? 12 : 8);
     if (w6) {
         b.tiles_per_wg = std::max(1, (ntiles + 2 * ctx->n_cu - 1) / (2 * ctx->n_cu));
         grid = (ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
     }
     static const int active_env = pk_prof_env("PK_WF_ACTIVE") ? atoi(pk_prof_env("PK_WF_ACTIVE")) : 0;   // measurement switch
-    b.active = active_env >= 1 && active_env <= W ? active_env : W;
+    // Round 5 (HISTORY 9.9): 128 channels in the default math -- ONE working wave per SIMD (the other four waves of the workgroup
+    // only move weights, as the idle waves of a partial round do).  With two working waves per SIMD 1 - 5 % of the calls of the
+    // benchmark's shape came back with a few tiles off by 1e-3 (the same signature as the three-waves-per-SIMD kernels of the
+    // 64-channel model); shapes in which no SIMD has two working waves never did.  A workgroup's 11 tiles are 3 per SIMD either
+    // way (8 + 3 or 4 + 4 + 3): the price is the overlap of one wave's vector work with the other's matrix work.
+    const int active_default = (a.C == 128 && !a.f16 && !PK_PROFILE_BUILD) ? 4 : W;
+    b.active = active_env >= 1 && active_env <= W ? active_env : active_default;
     // several layers: the workgroups wait for one another (pk_grid.h) -- at most one per CU by construction (LDS), launched
     // cooperatively so that a grid that cannot be co-resident is an error, not a hang
     if (a.nl > 1) PK_HIP(hipMemsetAsync(a.bar, 0, sizeof(unsigned), ctx->stream));

@@ -116,6 +116,25 @@ def test_fs2_edge_cases_zero_frames_single_token_long_sequence():
     assert np.abs(o.numpy() - want).mean() < MEL_L1_BAR
 
 
+def test_fs2_very_long_utterance_vs_oracle():
+    """Beyond the positional table's initial 5 000 rows (embedding.py:36; extend_pe regrows it, :46-62): 860 tokens x 7 frames =
+    6 020 frames in the decoder -- 189 query tiles walking 6 020 keys -- next to a short utterance in the same call, against the
+    fp64 oracle."""
+    from oracle import fastspeech2_ref as ref
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    st = syn.fastspeech2_state(80, 80, seed=12, fixed_duration=7)
+    am = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am.set_state_dict(st)
+    am.eval()
+    ids = [syn.phoneme_ids(860, seed=3), syn.phoneme_ids(20, seed=4)]
+    outs = am.inference_batch(ids)
+    assert [tuple(o.shape) for o in outs] == [(6020, 80), (140, 80)]
+    for i, o in zip(ids, outs):
+        want = ref.inference(st, i, dtype=torch.float64).numpy()
+        l1 = float(np.abs(o.numpy() - want).mean())
+        assert l1 < MEL_L1_BAR, f"{len(i)} tokens: mel L1 {l1}"
+
+
 def test_pwg_batch32_full_size_determinism_and_invariance():
     from parakeet_amd.parallel_wavegan import PWGGenerator
     gen = PWGGenerator(**syn.PWG_LJSPEECH)

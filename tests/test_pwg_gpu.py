@@ -456,3 +456,31 @@ def test_pwg_chunked_schedule_is_bit_identical():
         outs = [o.numpy() for o in gen.inference_batch(mels, noises)]
         for a, b in zip(ref, outs):
             assert np.array_equal(a, b)
+
+
+def test_pwg_one_utterance_at_the_size_limit():
+    """One utterance just below the engine's limit of 2^24 samples per utterance (12.7 minutes at 22.05 kHz; 65 500 frames,
+    a 17 GB working set) -- where offsets into the timeline are largest.  The generator's receptive field is finite (three
+    stacks of dilations 1 ... 512: 3 069 samples to either side, plus conv_in's two frames), so stretches at the start, in the
+    middle and at the very end must equal the same stretches synthesised from a short window around them.  One frame more is
+    refused with an error, not wrapped."""
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    gen = PWGGenerator(**syn.PWG_LJSPEECH)
+    gen.set_state_dict(syn.pwg_state(seed=31))
+    gen.remove_weight_norm()
+    gen.eval()
+    L, W, M = 65500, 64, 24            # frames, frames compared per stretch, margin of the window in frames (6 144 samples)
+    rng = np.random.default_rng(65500)
+    mel = rng.normal(size=(L, 80)).astype(np.float32)
+    noise = torch.randn(L * 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    wav = gen.inference_batch([mel], [noise])[0].as_subclass(torch.Tensor).reshape(-1)
+    assert wav.shape == (L * 256,) and bool(torch.isfinite(wav).all())
+    for a in (0, 1000, L // 2, L - W):
+        lo, hi = max(0, a - M), min(L, a + W + M)
+        sub = gen.inference_batch([mel[lo:hi]], [noise[lo * 256:hi * 256]])[0].as_subclass(torch.Tensor).reshape(-1)
+        got = wav[a * 256:(a + W) * 256].cpu().numpy()
+        want = sub[(a - lo) * 256:(a - lo + W) * 256].cpu().numpy()
+        err = _rel_err(got, want)
+        assert err < 2e-6, f"frames {a} ... {a + W}: differs from the window's result by {err}"
+    with pytest.raises(Exception, match="2\\^24"):
+        gen.inference_batch([np.zeros((65536, 80), np.float32)])

@@ -67,12 +67,12 @@ def test_waveflow_96_mel_channels_runs_unfused():
         m.set_math("f16")
 
 
-@pytest.mark.parametrize("math", [None, "f16"])
-def test_waveflow_12_wave_workgroups_bit_identical(math):
-    """Option "layer_waves": the 64-channel layer kernel in 12-wave workgroups (three waves per SIMD in 168 registers, one round
-    of 11 tiles at the benchmark's shape instead of 8 + 3) does the arithmetic of the 8-wave kernel tile for tile -- ring depth
-    and register allocation differ, not a single operation: the waveforms are equal bit for bit, in both math modes, on a ragged
-    batch whose tiles straddle utterances and gaps; and the result meets the oracle bar."""
+def test_waveflow_12_wave_workgroups_bit_identical():
+    """Option "layer_waves": with fp16 operands the 64-channel layer kernel also runs in 12-wave workgroups (three waves per SIMD
+    in 168 registers, one round of 11 tiles at the benchmark's shape instead of 8 + 3) -- the arithmetic of the 8-wave kernel tile
+    for tile: the waveforms are equal bit for bit on a ragged batch whose tiles straddle utterances and gaps, and meet the
+    oracle bar.  Round 5: in the DEFAULT math three waves per SIMD gave non-deterministic results on the hardware (HISTORY 9.9):
+    the product runs it in 8-wave workgroups only and refuses the option there, as it refuses the two-6-wave-workgroups variant."""
     from oracle import waveflow_ref as ref
     from parakeet_amd.waveflow import ConditionalWaveFlow
     cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64, n_flows=2)
@@ -80,22 +80,26 @@ def test_waveflow_12_wave_workgroups_bit_identical(math):
     model = ConditionalWaveFlow(**cfg)
     model.set_state_dict(state)
     model.eval()
-    if math:
-        model.set_math(math)
     rng = np.random.default_rng(12)
     frames = [9, 4, 6]
     mels = [np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32) for T in frames]
     zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
+    for w in (12, 6):                     # default math: refused when the call is made
+        model.set_option("layer_waves", w)
+        with pytest.raises(NotImplementedError):
+            model.infer_batch(mels, zs)
+    model.set_math("f16")
+    with pytest.raises(NotImplementedError):
+        model.infer_batch(mels, zs)       # (still 6)
     outs = {}
-    for w in (8, 12, 6):   # 6: two independent 6-wave workgroups per CU with 24 KB weight slabs
+    for w in (8, 12):
         model.set_option("layer_waves", w)
         outs[w] = [o.numpy().copy() for o in model.infer_batch(mels, zs)]
-    for w in (12, 6):
-        for a, b in zip(outs[8], outs[w]):
-            np.testing.assert_array_equal(a, b)
+    for a, b in zip(outs[8], outs[12]):
+        np.testing.assert_array_equal(a, b)
     want = ref.infer(state, torch.from_numpy(mels[0])[None], torch.from_numpy(zs[0])[None], cfg, torch.float64)[0].numpy()
     err = np.abs(outs[12][0] - want).max() / np.abs(want).max()
-    assert err < (2e-3 if math else 1e-5), err
+    assert err < 2e-3, err
     with pytest.raises(ValueError):
         model.set_option("layer_waves", 10)
     m128 = ConditionalWaveFlow(**dict(cfg, channels=128))
@@ -105,12 +109,11 @@ def test_waveflow_12_wave_workgroups_bit_identical(math):
 
 @pytest.mark.parametrize("channels", [64, 128])
 def test_waveflow_row_kernel_variants_bit_identical(channels):
-    """the residual stack of a row as ONE launch -- the eight layers behind barriers across the grid
-    (csrc/pk_grid.h, a cooperative launch; option "persistent", off by default: measured slower than eight launches on the
-    MI355X), the row's affine step and the next row's input projection in the epilogue of the last layer (option "fuse_step",
-    on): 960 launches per batch instead of 960 + 120, or 120.  The options "persistent" and "fuse_step" only move launch
-    boundaries: every combination gives the same waveform bit for bit (and the first one is checked against the oracle by the
-    tests above).  Under the host emulation (PK_EMU) there is no grid barrier: "persistent" is then one launch per layer."""
+    """The row's affine step and the next row's input projection in the epilogue of the last layer (option "fuse_step", on): 960
+    launches per batch instead of 960 + 120.  The option only moves a launch boundary: the same waveform bit for bit.  (SURVEY
+    K20, the residual stack of a row as ONE cooperative launch behind grid barriers -- option "persistent" -- was built in round 4,
+    measured slower than eight launches and left off; round 5 found it non-deterministic at sizes beyond these tests' and took it
+    out of the product: the profile build keeps it.)"""
     from parakeet_amd.waveflow import ConditionalWaveFlow
     cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=channels, n_flows=2)
     model = ConditionalWaveFlow(**cfg)
@@ -121,7 +124,9 @@ def test_waveflow_row_kernel_variants_bit_identical(channels):
     mels = [np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32) for T in frames]
     zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
     ref = None
-    for persistent, fuse in ((1, 1), (0, 1), (1, 0), (0, 0)):
+    with pytest.raises(NotImplementedError):      # round 5: not in the product (not deterministic beyond small sizes, HISTORY 9.9)
+        model.set_option("persistent", 1)
+    for persistent, fuse in ((0, 1), (0, 0)):
         model.set_option("persistent", persistent)
         model.set_option("fuse_step", fuse)
         outs = [o.numpy().copy() for o in model.infer_batch(mels, zs)]
@@ -157,3 +162,64 @@ def test_waveflow_infer_api_and_errors():
     assert np.isfinite(y.numpy()).all()
     w = m.predict(mel[0])
     assert w.shape == (m.lengths(4)[1],)
+
+
+@pytest.mark.parametrize("channels", [64, 128])
+def test_waveflow_large_call_equals_small_calls(channels):
+    """Sizes well beyond the benchmark's (8 x 640 frames): 24 ragged utterances of 500 - 2 000 frames in ONE call (about 7.5 M
+    samples, 470 k positions per row) against the same utterances two at a time.  An utterance's position in the packed row decides
+    where the 32-position scale blocks fall inside it, so the two results differ in the last bits (both fp32-equivalent: 3e-7
+    against fp64) -- a wrapped offset or a tile reading across a gap would show as an error of order one."""
+    from parakeet_amd.waveflow import ConditionalWaveFlow
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=channels)
+    model = ConditionalWaveFlow(**cfg)
+    model.set_state_dict(syn.waveflow_state(cfg, seed=77, weight_norm=True))
+    model.eval()
+    rng = np.random.default_rng(78)
+    frames = [int(t) for t in rng.integers(500, 2001, size=24)]
+    mels = [np.maximum(rng.normal(-4, 2, size=(cfg["n_mels"], T)), np.log(1e-5)).astype(np.float32) for T in frames]
+    zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
+    big = [o.numpy() for o in model.infer_batch(mels, zs)]
+    assert all(np.isfinite(o).all() for o in big)
+    for pair in ((0, 1), (11, 12), (22, 23)):
+        small = model.infer_batch([mels[b] for b in pair], [zs[b] for b in pair])
+        for o, b in zip(small, pair):
+            assert big[b].shape == (model.lengths(frames[b])[1],)
+            err = np.abs(o.numpy() - big[b]).max() / np.abs(big[b]).max()
+            assert err < 2e-6, f"utterance {b}: the large call differs from the small one by {err}"
+
+
+@pytest.mark.parametrize("channels,math,frames", [
+    (64, None, [1200, 1200]),        # 5 tiles per workgroup: the smallest call in which two waves of a SIMD both work
+    (64, None, [1950, 1950]),        # 8: every wave of the 8-wave kernel works
+    (64, None, [2560, 2560]),        # 11 tiles on 12 waves (the benchmark's workgroup shape)
+    (64, "f16", [1950, 1950]),
+    (128, None, [1200, 1200]),
+    (64, None, [640] * 8),           # BASELINE config 5 itself
+    (64, "f16", [640] * 8),
+])
+def test_waveflow_calls_with_two_working_waves_per_simd_are_deterministic_and_right(channels, math, frames):
+    """Round 5 (HISTORY 9.9): with more than four tiles per workgroup two waves of a SIMD run matrix instructions side by side, and
+    the layer kernel's out projection read an accumulator one issue slot too early now and then -- a few tiles per call off by
+    1e-3, different on every run.  None of the earlier tests had such a shape (2 x 640 frames: three tiles per workgroup).  Every
+    shape here runs three times (bit-identical) and against the exact-fp32 unfused path (another kernel family altogether)."""
+    from parakeet_amd.waveflow import ConditionalWaveFlow
+    cfg = dict(syn.WAVEFLOW_LJSPEECH, channels=channels)
+    state = syn.waveflow_state(cfg, seed=77, weight_norm=True)
+
+    def make(m):
+        model = ConditionalWaveFlow(**cfg)
+        model.set_state_dict(state)
+        model.eval()
+        if m:
+            model.set_math(m)
+        return model
+    model, exact = make(math), make("f32")
+    rng = np.random.default_rng(78)
+    mels = [np.maximum(rng.normal(-4, 2, size=(cfg["n_mels"], T)), np.log(1e-5)).astype(np.float32) for T in frames]
+    zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
+    want = np.concatenate([o.numpy() for o in exact.infer_batch(mels, zs)])
+    runs = [np.concatenate([o.numpy() for o in model.infer_batch(mels, zs)]) for _ in range(3)]
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), "two runs of the same call differ"
+    err = np.abs(runs[0] - want).max() / np.abs(want).max()
+    assert err < (2e-3 if math == "f16" else 2e-6), f"differs from the exact-fp32 path by {err}"
