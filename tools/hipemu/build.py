@@ -28,13 +28,15 @@ _FMA_MIX = re.compile(r'asm\("v_fma_mix_f32 %0, %1, -1\.0, %2 op_sel:\[(\d),0,0\
                       r'"v"\((\w+)\),\s*"v"\(([^;]+)\)\);')
 
 
-_OPAQUE = re.compile(r'asm volatile\(""\s*:\s*"\+[sv]"\((\w+)\)\);')   # "the compiler may not reason about this value": nothing to emulate
+_OPAQUE = re.compile(r'asm volatile\(""\s*:\s*"\+[sv]"\(([\w\[\]]+)\)\);')   # "the compiler may not reason about this value": nothing to emulate
+_NOP = re.compile(r'asm volatile\("s_nop \d+"\);')                               # issue-slot padding (wf_layer.hip, round 5): nothing to emulate
 
 
 def rewrite(text):
     text = _DYN_LDS.sub(r"\1* \2 = (\1*)hipemu::dynamic_lds();", text)
     text = _FMA_MIX.sub(r"\2 = hipemu::fma_mix_sub(\3, \1, \4);", text)
     text = _OPAQUE.sub(";", text)
+    text = _NOP.sub(";", text)
     text = _WAVE_LDS.sub(r"\1hipemu::wave_sync(); //", text)
     # HIPEMU_POISON: LDS is not initialised on the hardware; the first work-item of a workgroup fills every __shared__ array
     # with NaN bytes before anything runs, so that a read-before-write cannot pass on what the previous workgroup left behind
