@@ -49,7 +49,7 @@ typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 #define PK_WF_LINW 1      // the weight chunks' source addresses as a linear function of the thread index (0: through the kt_w table, as
 #endif                    // rounds 2 - 4 did; kept for the A/B)
 #ifndef PK_WF_LATE_REFILL
-#define PK_WF_LATE_REFILL 0
+#define PK_WF_LATE_REFILL 0   // experiment of HISTORY 9.9 (1: the operand ring's slot refilled one k-step later -- made the three-waves-per-SIMD kernels fail in EVERY run)
 #endif
 #ifndef PK_WF_AHEAD128
 #define PK_WF_AHEAD128 1   // A fragments of the 128-channel kernel this many co-tiles ahead (round 5: 2; 1 = rounds 3 - 4)
@@ -382,16 +382,6 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
         asm volatile("" : "+s"(o));
         return &wbuf[0][0] + (o + (unsigned)tid);
     };
-    // Round 5 (HISTORY 9.9): behind each of role B's prologue stores in the 12- / 6-wave kernels of the default math, wait for the
-    // store.  These kernels have 168 registers; the addresses beyond the 64 KB reach of a ds_write offset are materialised into
-    // ONE temporary -- which also was the first chunk's data register -- rewritten between the stores
-    // (ds_write_b128 v6, v[18:21]; v_add_u32 v6, 0x11000, v133; ds_write_b128 v6, ...).  With the LDS queue full of the role-A
-    // waves' slab-0 reads, one call in five of the benchmark's shape stored a clobbered chunk (errors of 1e-3 in the tiles of
-    // one workgroup, different on every run); with the stores drained one by one none in 200.  (8 waves: two persistent address
-    // registers; fp16 operands: 24 KB slabs within reach of two bases -- no temporaries there, and no failures.)
-    auto pro_b_fence = [&]() {
-        if constexpr (W != 8 && !F16) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-    };
     auto w_store = [&](int g) {
         if (g >= G) return;
         if constexpr (WST) {
@@ -564,10 +554,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             if constexpr (NEWPRO) {
                 if (!role_a) {
 #pragma unroll
-                    for (int c = 0; c < CL; ++c) {
-                        wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
-                        pro_b_fence();
-                    }
+                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
                 }
                 ex_ = tile_exp();
             }
@@ -941,10 +928,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 __syncthreads();
                 if (!role_a) {
 #pragma unroll
-                    for (int c = 0; c < CL; ++c) {
-                        wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
-                        pro_b_fence();
-                    }
+                    for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
                 }
             }
 #pragma unroll

@@ -135,6 +135,34 @@ def test_fs2_very_long_utterance_vs_oracle():
         assert l1 < MEL_L1_BAR, f"{len(i)} tokens: mel L1 {l1}"
 
 
+def test_headline_path_twelve_runs_bit_identical():
+    """Round 5 (HISTORY 9.9): a hazard that needs two waves of a SIMD at the wrong cycle shows up in one call of twenty, not in a
+    comparison of two runs -- that is how the WaveFlow layer kernel's defect survived two rounds.  The headline path twelve times
+    each (tools/repeat_runs.py: sixty times, none differing): Parallel WaveGAN at the benchmark's size and at a size that ends in
+    a partial sweep of the tile loop, FastSpeech2 at 32 and at 16 ragged utterances."""
+    from parakeet_amd.fastspeech2 import FastSpeech2
+    from parakeet_amd.parallel_wavegan import PWGGenerator
+    gen = PWGGenerator(**syn.PWG_LJSPEECH)
+    gen.set_state_dict(syn.pwg_state())
+    gen.eval()
+    g = torch.Generator(device="cuda").manual_seed(42)
+    mel = torch.randn(32 * 640, 80, device="cuda", generator=g)
+    noise = torch.randn(32 * 640 * 256, device="cuda", generator=g)
+    for B in (32, 7):
+        first = gen.infer_packed(mel[:B * 640], [640] * B, noise=noise[:B * 640 * 256]).as_subclass(torch.Tensor).clone()
+        for _ in range(11):
+            assert torch.equal(gen.infer_packed(mel[:B * 640], [640] * B, noise=noise[:B * 640 * 256]).as_subclass(torch.Tensor), first)
+    am = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am.set_state_dict(syn.fastspeech2_state(fixed_duration=5))
+    am.eval()
+    rng = np.random.default_rng(1)
+    for texts in ([syn.phoneme_ids(128, seed=i) for i in range(32)],
+                  [syn.phoneme_ids(int(t), seed=100 + i) for i, t in enumerate(rng.integers(37, 129, size=16))]):
+        first = torch.cat([o.as_subclass(torch.Tensor).reshape(-1) for o in am.inference_batch(texts)]).clone()
+        for _ in range(11):
+            assert torch.equal(torch.cat([o.as_subclass(torch.Tensor).reshape(-1) for o in am.inference_batch(texts)]), first)
+
+
 def test_pwg_batch32_full_size_determinism_and_invariance():
     from parakeet_amd.parallel_wavegan import PWGGenerator
     gen = PWGGenerator(**syn.PWG_LJSPEECH)
