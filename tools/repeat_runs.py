@@ -32,3 +32,23 @@ outs = []
 for _ in range(N):
     outs.append(torch.cat([o.as_subclass(torch.Tensor).reshape(-1) for o in am.inference_batch(texts)]).clone())
 report("FastSpeech2 16 ragged", outs)
+if "--ar" in sys.argv:
+    rng = np.random.default_rng(0)
+    from parakeet_amd.speedyspeech import SpeedySpeech
+    ss = SpeedySpeech(vocab_size=70, tone_size=7, **syn.SPEEDYSPEECH_BAKER); ss.set_state_dict(syn.speedyspeech_state()); ss.eval()
+    texts = [rng.integers(1, 70, size=128) for _ in range(32)]; tones = [rng.integers(1, 7, size=128) for _ in range(32)]
+    report("SpeedySpeech 32 x 128", [torch.cat([o.as_subclass(torch.Tensor).reshape(-1) for o in ss.inference_batch(texts, tones)]).clone() for _ in range(N)])
+    from parakeet_amd.tacotron2 import Tacotron2
+    cfg = dict(syn.TACOTRON2_LJSPEECH)
+    t2 = Tacotron2(**cfg); t2.set_state_dict(syn.tacotron2_state(cfg, stop_bias=-8.0)); t2.eval()
+    texts = [rng.integers(1, 37, size=128) for _ in range(32)]
+    def taco():
+        return torch.cat([torch.as_tensor(np.asarray(o["mel_output"])).reshape(-1) for o in t2.infer_batch(texts, max_decoder_steps=320, seeds=list(range(32)))])
+    report("Tacotron2 32 x 320 steps", [taco() for _ in range(max(4, N // 4))])
+    from parakeet_amd.transformer_tts import TransformerTTS
+    cfg = dict(syn.TRANSFORMER_TTS_LJSPEECH)
+    tt = TransformerTTS(idim=80, odim=80, **cfg); tt.set_state_dict(syn.transformer_tts_state(80, 80, cfg, stop_bias=-8.0)); tt.eval()
+    texts = [rng.integers(1, 79, size=128) for _ in range(32)]
+    def tts():
+        return torch.cat([torch.as_tensor(np.asarray(o[0])).reshape(-1) for o in tt.inference_batch(texts, maxlenratio=(160 + 0.5) / 129, return_att=False, seeds=list(range(32)))])
+    report("TransformerTTS 32 x 160 steps", [tts() for _ in range(max(4, N // 6))])
