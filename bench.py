@@ -227,7 +227,10 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
                     "folded output-projection sums per position); frac_reference_dataflow counts the reference's C-wide skip "
                     "read-modify-write as well (the basis of the round-2/3 figures and targets); "
                     "averages over the launches of a batch (rows 1 and 2 of a flow read one and two input rows); "
-                    "fp16_mfma_frac = issued fp16 MFMA FLOP (3 per product in the split mode, 1 in the fp16 mode) / 2.5 PFLOP/s"}
+                    "fp16_mfma_frac = issued fp16 MFMA FLOP (3 per product in the split mode, 1 in the fp16 mode) / 2.5 PFLOP/s"
+                    + ("; traffic: counters of round 3, collected on the 12-wave kernel of the default math (since round 5 the "
+                       "default math runs in 8-wave workgroups: the same activations, the weights twice per CU)"
+                       if traffic is not None and channels == 64 else "")}
     del wf
     return ent
 
