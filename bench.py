@@ -245,11 +245,11 @@ def _median_ms(fn, runs, sync):
     return float(np.median(ts)), ts
 
 
-def measurement_extras(synth, ctx, steps):
-    """the BASELINE configurations as stated, the reference's own call shape, a batch sweep and the
-    host-materialised step.  None of this feeds `value`."""
+def measurement_extras(synth, ctx, steps, part, ex):
+    """the BASELINE configurations as stated (part "core": FastSpeech2 at 16 / 1, PWG alone at 32), the
+    reference's own call shape, a batch sweep and the host-materialised step (part "rest").  None of this feeds `value`.
+    Fills `ex`."""
     from parakeet_amd import synthetic as syn
-    ex = {}
     sync = torch.cuda.synchronize
     per_utt = TOKENS * FRAMES_PER_TOKEN * HOP
     frames_utt = TOKENS * FRAMES_PER_TOKEN
@@ -258,17 +258,25 @@ def measurement_extras(synth, ctx, steps):
     noise64 = torch.randn(64 * per_utt, device="cuda", generator=g)
 
     # ---- BASELINE config 2 as stated: FastSpeech2, batch 16, T = 128 -> 640 frames each
-    for b in (16, 1):
+    for b in ((32, 16, 1) if part == "core" else ()):
         synth.am.inference_batch(texts64[:b])
         sync()
         ms, runs = _median_ms(lambda: synth.am.inference_batch(texts64[:b]), max(steps, 10), sync)
         ex[f"fastspeech2_batch{b}"] = {
             "what": f"FastSpeech2 inference alone, {b} x {TOKENS} tokens -> {frames_utt} frames" +
-                    (" (BASELINE config 2 as stated)" if b == 16 else " (the reference's call shape: one utterance per call)") +
+                    (" (BASELINE config 2 as stated)" if b == 16 else
+                     (" (the reference's call shape: one utterance per call)" if b == 1 else " (the headline step's acoustic half)")) +
                     ", default math, result left in HBM; median",
             "ms_per_batch": ms, "utterances_per_s": b / ms * 1e3, "algorithmic_tflops": 30.26e9 * b / ms / 1e9,
             "runs": len(runs)}
 
+    if part == "core":
+        _pwg_alone(synth, ctx, steps, ex, sync, per_utt, frames_utt)
+        return ex
+    return _measurement_rest(synth, steps, ex, sync, per_utt, texts64, noise64)
+
+
+def _pwg_alone(synth, ctx, steps, ex, sync, per_utt, frames_utt):
     # ---- BASELINE config 3 as stated: PWG alone, batch 32, mel ~ N(0,1) from default_rng(42), noise from the
     # same generator passed explicitly, ZScore (0, 1)
     rng = np.random.default_rng(42)
@@ -306,8 +314,9 @@ def measurement_extras(synth, ctx, steps):
     except Exception as e:
         ent["scale_guard"] = {"error": repr(e)}
     ex["pwg_batch32"] = ent
-    del mel, nz
 
+
+def _measurement_rest(synth, steps, ex, sync, per_utt, texts64, noise64):
     # ---- the reference's actual call shape: one 128-token utterance per call, waveform materialised on the host
     # (examples/fastspeech2/ljspeech/synthesize_e2e.py:88-102 -> .numpy()), median of 20
     host1 = torch.empty(per_utt, dtype=torch.float32, pin_memory=True)
@@ -318,7 +327,7 @@ def measurement_extras(synth, ctx, steps):
     one()
     sync()
     ms, runs = _median_ms(one, 20, sync)
-    m_fs2 = ex["fastspeech2_batch1"]["ms_per_batch"]
+    m_fs2 = (ex.get("fastspeech2_batch1") or {}).get("ms_per_batch", float("nan"))
     ex["latency_batch1"] = {
         "what": "one 128-token utterance end to end (FastSpeech2 -> PWG -> waveform in pinned host memory), the only call shape "
                 "of the reference's recipe; median of 20 calls",
@@ -451,6 +460,84 @@ def text_to_wav_extra(synth, n=UTT_PER_GPU):
     return out
 
 
+def other_acoustic_models(synth, texts, steps):
+    """SpeedySpeech and the autoregressive acoustic models (8f-4) at the headline's shape: 32 x 128 tokens ->
+    640 frames each.  Sidecar only."""
+    from parakeet_amd import synthetic as syn
+    ex = {}
+    try:
+        from parakeet_amd.speedyspeech import SpeedySpeech
+        ssm = SpeedySpeech(vocab_size=70, tone_size=7, **syn.SPEEDYSPEECH_BAKER)
+        ssm.set_state_dict(syn.speedyspeech_state())
+        ssm.eval()
+        rng = np.random.default_rng(0)
+        ph = [rng.integers(1, 70, size=TOKENS) for _ in range(UTT_PER_GPU)]
+        tn = [rng.integers(1, 7, size=TOKENS) for _ in range(UTT_PER_GPU)]
+        outs = ssm.inference_batch(ph, tn)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            outs = ssm.inference_batch(ph, tn)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t1) / steps
+        ex["speedyspeech_baker_batch32"] = {
+            "what": "SpeedySpeech (baker configuration) inference alone, 32 x 128 phones with tones",
+            "ms_per_batch": dts * 1e3, "utterances_per_s": UTT_PER_GPU / dts,
+            "frames": int(sum(o.shape[0] for o in outs))}
+        del ssm
+    except Exception as e:
+        ex["speedyspeech_baker_batch32"] = {"error": repr(e)}
+    try:
+        from parakeet_amd.tacotron2 import Tacotron2
+        from parakeet_amd.transformer_tts import TransformerTTS
+        rng = np.random.default_rng(0)
+        frames_per_utt = TOKENS * 5
+        tcfg = dict(syn.TRANSFORMER_TTS_LJSPEECH)
+        ttm = TransformerTTS(idim=80, odim=80, **tcfg)
+        ttm.set_state_dict(syn.transformer_tts_state(80, 80, tcfg, stop_bias=-8.0))
+        ttm.eval()
+        tx = [rng.integers(1, 79, size=TOKENS) for _ in range(UTT_PER_GPU)]
+        ratio = (frames_per_utt + 0.5) / (TOKENS + 1)
+        ttm.inference_batch(tx, maxlenratio=ratio, return_att=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        outs = ttm.inference_batch(tx, maxlenratio=ratio, return_att=False)
+        torch.cuda.synchronize()
+        dtt = time.perf_counter() - t1
+        nf = int(sum(o[0].shape[0] for o in outs))
+        ex["transformer_tts_batch32"] = {
+            "what": "TransformerTTS (LJSpeech recipe sizes) inference alone, 32 x 128 tokens decoded in lockstep for 640 "
+                    "steps (the stop token is held off so that every utterance runs to int(129 * maxlenratio) = 640 "
+                    "frames; the oracle comparison at these sizes, tests/test_ar_benchsize_gpu.py, covers the first 224 steps), "
+                    "prenet dropout stream on, default math; the next step's prefix work runs on a side stream under the current step's "
+                    "layer chain (option overlap_prefix)",
+            "ms_per_batch": dtt * 1e3, "us_per_step": dtt / frames_per_utt * 1e6, "frames": nf,
+            "utterances_per_s": UTT_PER_GPU / dtt, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtt}
+        del ttm
+        ccfg = dict(syn.TACOTRON2_LJSPEECH)
+        tcm = Tacotron2(**ccfg)
+        tcm.set_state_dict(syn.tacotron2_state(ccfg, stop_bias=-8.0))
+        tcm.eval()
+        cx = [rng.integers(1, 37, size=TOKENS) for _ in range(UTT_PER_GPU)]
+        tcm.infer_batch(cx, max_decoder_steps=frames_per_utt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        outs = tcm.infer_batch(cx, max_decoder_steps=frames_per_utt)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - t1
+        nf = int(sum(o["mel_output"].shape[0] for o in outs))
+        ex["tacotron2_batch32"] = {
+            "what": "Tacotron2 (examples/tacotron2/config.py sizes) inference alone, 32 x 128 tokens decoded in lockstep "
+                    "for max_decoder_steps = 640 (stop token held off; tests/test_ar_benchsize_gpu.py compares 256 steps with the "
+                    "oracle), prenet dropout stream on, default math",
+            "ms_per_batch": dtc * 1e3, "us_per_step": dtc / frames_per_utt * 1e6, "frames": nf,
+            "utterances_per_s": UTT_PER_GPU / dtc, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtc}
+        del tcm
+    except Exception as e:
+        ex["autoregressive_models"] = {"error": repr(e)}
+    return ex
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -483,6 +570,129 @@ class _DryStep:
         return torch.zeros(int(frames.sum()) * HOP), frames
 
 
+# ---- the ONE stdout line ------------------------------------------------------------------------------------------------------
+# The driver keeps a bounded tail of stdout and parses the last line: round 5's 20.5 KB line (prose in `what` / `*_note` fields,
+# every extra measurement inline) came back as BENCH_r05.json "parsed": null.  The line is now the contract fields + numbers;
+# everything else -- notes, the per-kernel table, every extra measurement -- is the SIDECAR: profiles/bench_extras_last.json
+# (and gpurun_out/ when that exists), with a pointer in the line.  tests/test_bench_cpu.py holds the line under LINE_LIMIT.
+LINE_LIMIT = 8192
+SIDECAR = os.path.join(ROOT, "profiles", "bench_extras_last.json")
+
+
+def _num(v, nd=6):
+    """Numbers of the line at a readable precision (floats to `nd` significant digits); everything else as it is."""
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}")
+    return v
+
+
+def _pick(d, keys, nd=6):
+    return {k: _num(d[k], nd) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def short_line(full):
+    """The stdout line for a full record: the driver contract's fields, `roofline`, `cpu_baseline`, `parity_check` and a flat
+    `others` of plain numbers (the extra measurements' headline figures); no prose beyond the short labels the contract asks
+    for.  Pure function of `full` (tests call it with a stuffed record)."""
+    out = _pick(full, ("metric", "value", "unit", "dry_run", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                       "scaling", "vs_baseline", "dtype", "data"), nd=9)
+    for k in ("value", "vs_baseline"):            # null is meaningful for these two
+        out.setdefault(k, full.get(k))
+    cfg = full.get("config") or {}
+    out["config"] = _pick(cfg, ("workload", "utterances_per_gpu", "utterances_this_rank", "global_batch", "minibatch",
+                                "minibatches_per_step", "parallelism", "pipeline"))
+    if "collectives" in cfg:                       # which collective carried what, in a few words (the long form: sidecar)
+        out["config"]["collectives"] = {k: str(v)[:160] for k, v in cfg["collectives"].items()}
+    roof = full.get("roofline")
+    if roof:
+        r = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_collected", "avg_launch_ms",
+                         "algorithmic_bytes_per_launch", "algorithmic_flop_per_launch", "algorithmic_tflops",
+                         "engine_min_bytes_per_launch"))
+        r.setdefault("traffic", None)
+        if roof.get("exact_f32"):
+            r["exact_f32"] = _pick(roof["exact_f32"], ("samples_per_s", "ms_per_step", "layer_ms", "bound", "achieved_tflops",
+                                                       "peak_tflops", "frac_of_fp32_mfma"))
+        out["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "cores_available", "kind", "cpu_model", "sample", "x_realtime"))
+        if "sample" in out["cpu_baseline"]:
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:200]
+    pc = full.get("parity_check")
+    if pc:
+        out["parity_check"] = _pick(pc, ("frames_equal", "mel_l1", "wav_relmax", "bars"))
+    out.update(_pick(full, ("x_realtime", "value_unpipelined", "kernel_ms_sum", "rccl_world_size", "gather_ms", "gather_all_ms")))
+    if full.get("rank_ms_per_step"):
+        out["rank_ms_per_step"] = _pick(full["rank_ms_per_step"], ("min", "max"), nd=9)
+    if full.get("pipeline_check"):
+        out["pipeline_check"] = _pick(full["pipeline_check"], ("bit_identical_to_unpipelined", "unpipelined_ms_per_step"))
+    ex = full.get("extras") or {}
+    others = {}
+
+    def put(name, ent, key, nd=5):
+        if isinstance(ent, dict) and isinstance(ent.get(key), (int, float)):
+            others[name] = _num(float(ent[key]), nd)
+    for b in (32, 16, 1):
+        put(f"fastspeech2_batch{b}_ms", ex.get(f"fastspeech2_batch{b}"), "ms_per_batch")
+    put("pwg_batch32_ms", ex.get("pwg_batch32"), "ms_per_batch")
+    put("latency_batch1_ms", ex.get("latency_batch1"), "ms")
+    put("host_io_ms_per_step", ex.get("host_io"), "host_io_ms_per_step")
+    for c in (64, 128):
+        for suf in ("", "_fp16"):
+            ent = ex.get(f"waveflow_c{c}_batch8{suf}")
+            put(f"waveflow_c{c}_batch8{suf}_ms", ent, "ms_per_batch")
+            if isinstance(ent, dict) and isinstance(ent.get("roofline"), dict):
+                put(f"waveflow_c{c}_batch8{suf}_layer_us", {"v": ent["roofline"].get("avg_launch_ms", 0.0) * 1e3}, "v")
+                put(f"waveflow_c{c}_batch8{suf}_hbm_frac", ent["roofline"], "frac", 3)
+            if isinstance(ent, dict) and isinstance(ent.get("oracle_check"), dict):
+                put(f"waveflow_c{c}_batch8{suf}_relmax_vs_oracle", ent["oracle_check"], "relmax", 3)
+    put("speedyspeech_batch32_ms", ex.get("speedyspeech_baker_batch32"), "ms_per_batch")
+    put("transformer_tts_us_per_step", ex.get("transformer_tts_batch32"), "us_per_step")
+    put("tacotron2_us_per_step", ex.get("tacotron2_batch32"), "us_per_step")
+    put("text_to_wav_one_batch_ms", (ex.get("text_to_wav") or {}).get("one_batch"), "total_ms")
+    errs = sorted(k for k, v in ex.items() if isinstance(v, dict) and "error" in v)
+    if errs:
+        others["errors_in"] = errs
+    if others:
+        out["others"] = others
+    if full.get("sidecar"):
+        out["sidecar"] = full["sidecar"]
+    line = json.dumps(out)
+    if len(line) >= LINE_LIMIT:                    # never a line the driver cannot keep: shed the optional parts
+        for k in ("others", "pipeline_check", "parity_check"):
+            out.pop(k, None)
+            line = json.dumps(out)
+            if len(line) < LINE_LIMIT:
+                break
+    assert len(line) < LINE_LIMIT, f"bench line is {len(line)} bytes"
+    return line
+
+
+def write_sidecar(full):
+    """Everything measured, prose included, next to the profiles (the driver's box: read it there; gpurun: comes back under
+    gpurun_out/).  Returns the repository-relative path written, or None.  Never fails the bench."""
+    rel = None
+    for path in (SIDECAR, os.path.join(ROOT, "gpurun_out", "bench_extras_last.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "wt") as f:
+                    json.dump(full, f, indent=1)
+                rel = rel or os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+    return rel
+
+
+def emit(full):
+    """Sidecar first, then the one stdout line (flushed at once: nothing that runs later can lose it)."""
+    full = dict(full)
+    full["sidecar"] = write_sidecar(full)
+    if full["sidecar"]:
+        write_sidecar(full)                        # (with its own name in it)
+    print(short_line(full), flush=True)
+
+
+
 _T0 = time.perf_counter()
 
 
@@ -502,13 +712,20 @@ def main():
     ap.add_argument("--global-batch", type=int, default=256, help="utterances of a strong-scaling step")
     ap.add_argument("--minibatch", type=int, default=UTT_PER_GPU, help="utterances per engine call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-value extra measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-value extra measurements (= --extras none)")
+    ap.add_argument("--extras", choices=("none", "core", "all"), default="all",
+                    help="core: the strict-fp32 configuration, FastSpeech2 / PWG alone, WaveFlow at BASELINE config 5 -- measured "
+                         "before the line is printed (their figures are in it); all (default): also the batch sweep, host io, "
+                         "text -> wav, 128-channel WaveFlow, the other acoustic models -- measured AFTER the line is out, into "
+                         "the sidecar file only")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: issue the next batch's acoustic model on a side stream during this batch's vocoder")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU/gloo rehearsal of the multi-process orchestration with a stub in place of the engine "
                          "(test infrastructure; prints value null)")
     args = ap.parse_args()
+    if args.no_extras:
+        args.extras = "none"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if not args.dry_run and (not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus):
@@ -665,11 +882,17 @@ def main():
         pipeline_check["unpipelined_ms_per_step"] = dtp * 1e3
         pipeline_check["unpipelined_samples_per_s"] = n_samples / dtp
     gather_ms = gather_all_ms = None
+    rank_ms = {"min": elapsed / args.steps * 1e3, "max": elapsed / args.steps * 1e3}
+    comm_world = 1
     if distributed:
         import torch.distributed as dist
+        comm_world = dist.get_world_size()          # the communicator's own count, for the SCALE record
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        elapsed = float(t.item())                   # `value` follows the slowest rank
+        rank_ms = {"min": float(tmin.item()) / args.steps * 1e3, "max": elapsed / args.steps * 1e3}   # load imbalance
         # result collection: every rank's packed waveform of its last mini-batch gathered on rank 0 --
         # one all_gather of the lengths + direct sends of the exact sizes (gather_ragged_to); timed on its own, never part
         # of `value`.  The all-ranks variant (padded all_gather) is timed next to it for consumers that need that.
@@ -693,25 +916,23 @@ def main():
         gather_all_ms, (bufs, meta) = timed_gather(lambda: pdist.gather_ragged(wav, lens))
         assert [int(b.numel()) for b in bufs] == [sum(m) for m in meta] and len(bufs) == world
 
+    # which collective carried what (the long form: DESIGN.md section 7)
     collectives = {
-        "in_the_timed_step": "none (utterances are independent: each rank synthesises its own shard)",
-        "weights": "once at start-up: the flat fp32 state of each model (FastSpeech2 148.5 MB, PWG 5.3 MB) from rank 0, one "
-                   "broadcast per model (torch.distributed.broadcast = ncclBroadcast over xGMI); every rank then packs its own "
-                   "engine image (finalize derives host-side bounds from the weights)" if distributed else "single process: none",
-        "results": "gather_ms: per-utterance lengths by all_gather_object, then every rank's packed waveform straight to "
-                   "rank 0 by one gather collective (torch.distributed.gather = a group of ncclSend / ncclRecv: 7 senders use 7 "
-                   "different xGMI links of rank 0); gather_all_ms: the same data on every rank by one padded all_gather (ncclAllGather)"
+        "in_the_timed_step": "none (utterances are independent; each rank synthesises its own shard)",
+        "weights": "one RCCL broadcast per model from rank 0 at start-up (FastSpeech2 148.5 MB, PWG 5.3 MB)"
                    if distributed else "single process: none",
+        "results": "gather_ms: lengths by all_gather_object + one gather to rank 0 (ncclSend/Recv, one xGMI link per sender); "
+                   "gather_all_ms: one padded all_gather" if distributed else "single process: none",
     }
     if dry:
         if rank == 0:
-            print(json.dumps({
+            print(short_line({
                 "metric": "audio samples/sec, FastSpeech2+PWGAN 22.05kHz", "value": None, "unit": "samples/s",
                 "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "scaling": args.scaling, "gather_ms": gather_ms,
-                "gather_all_ms": gather_all_ms,
+                "gather_all_ms": gather_all_ms, "rccl_world_size": comm_world, "rank_ms_per_step": rank_ms,
                 "config": {"global_batch": global_batch, "utterances_this_rank": len(own),
-                           "minibatches_per_step": len(chunks), "collectives": collectives}}))
+                           "minibatches_per_step": len(chunks), "collectives": collectives}}), flush=True)
         if distributed:
             import torch.distributed as dist
             dist.barrier()
@@ -739,25 +960,34 @@ def main():
         torch.cuda.synchronize()
         parity_src = (m0[:TOKENS * FRAMES_PER_TOKEN].cpu().numpy(), w0[:per_utt].cpu().numpy())
 
-    # ---- extra measurements (do not feed `value`): the split-bf16 PWG matrix path, WaveFlow
+    # ---- extra measurements (none of them feeds `value`).  "core" runs before the line is printed -- its headline figures
+    # are in the line (roofline.exact_f32, others) --, the rest afterwards, into the sidecar only.
     extras = {}
-    _log("per-kernel profile done; extras")
-    if world == 1 and not args.no_extras and args.scaling == "weak":
-        texts = texts_all[:UTT_PER_GPU]
-        for mode, key in (("f32", "all_exact_f32_mfma"), ("bf16x3", "pwg_bf16x3_split")):
-            synth.voc.set_math(mode)
-            synth.am.set_math("f32" if mode == "f32" else "f16x3")
+    do_extras = world == 1 and args.extras != "none" and args.scaling == "weak"
+    texts = texts_all[:UTT_PER_GPU]
+
+    def guarded(key, fn):
+        try:
+            fn()
+        except Exception as e:  # never let an extra break the headline line
+            extras[key] = {"error": repr(e)}
+
+    def other_math(mode, key):
+        """The same end-to-end step under another evaluation of the dense contractions (then back to the default)."""
+        synth.voc.set_math(mode)
+        synth.am.set_math("f32" if mode == "f32" else "f16x3")
+        try:
             for _ in range(2):
-                step()
+                plain_step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                step()
+                plain_step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / args.steps
             ctx.prof_enable(True)
             ctx.prof_reset()
-            step()
+            plain_step()
             p3 = ctx.prof_dump()
             ctx.prof_enable(False)
             pk = "pwg_layer" if mode == "f32" else "pwg_layer_b3"
@@ -774,105 +1004,34 @@ def main():
             else:
                 ent["what"] = "same step with bf16 parts instead of fp16 parts (fp32 range, error 3.7e-6)"
             extras[key] = ent
-        synth.voc.set_math("f16x3")
-        synth.am.set_math("f16x3")
-        for wf_c in (64, 128):   # BASELINE config 5 (64 channels) and the reference repository's default width (128)
-            for wmath in (None, "f16"):
-                key = f"waveflow_c{wf_c}_batch8" + ("_fp16" if wmath else "")
-                try:
-                    extras[key] = waveflow_extra(wf_c, ctx, math=wmath)
-                except Exception as e:  # never let an extra break the headline line
-                    extras[key] = {"error": repr(e)}
-        try:   # BASELINE configs 2 / 3 as stated, single-utterance latency, batch sweep, host-materialised step
-            _log("extras: measurement holes (configs 2 / 3, latency, sweep, host io)")
-            extras.update(measurement_extras(synth, ctx, args.steps))
-        except Exception as e:
-            extras["measurement_extras"] = {"error": repr(e)}
-        try:   # text -> wav: the reference's whole request with the host side inside the clock
-            _log("extras: text -> wav")
-            extras["text_to_wav"] = text_to_wav_extra(synth)
-        except Exception as e:
-            extras["text_to_wav"] = {"error": repr(e)}
-        try:   # the two acoustic models alone (BASELINE config 2 shape at 32 utterances; SpeedySpeech)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                synth.am.inference_batch(texts)
-            torch.cuda.synchronize()
-            dta = (time.perf_counter() - t1) / args.steps
-            extras["fastspeech2_batch32"] = {
-                "what": "FastSpeech2 inference alone, 32 x 128 tokens -> 640 frames, default math",
-                "ms_per_batch": dta * 1e3, "utterances_per_s": UTT_PER_GPU / dta,
-                "algorithmic_tflops": 30.26e9 * UTT_PER_GPU / dta / 1e12}
-            from parakeet_amd.speedyspeech import SpeedySpeech
-            ssm = SpeedySpeech(vocab_size=70, tone_size=7, **syn.SPEEDYSPEECH_BAKER)
-            ssm.set_state_dict(syn.speedyspeech_state())
-            ssm.eval()
-            rng = np.random.default_rng(0)
-            ph = [rng.integers(1, 70, size=TOKENS) for _ in range(UTT_PER_GPU)]
-            tn = [rng.integers(1, 7, size=TOKENS) for _ in range(UTT_PER_GPU)]
-            outs = ssm.inference_batch(ph, tn)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                outs = ssm.inference_batch(ph, tn)
-            torch.cuda.synchronize()
-            dts = (time.perf_counter() - t1) / args.steps
-            extras["speedyspeech_baker_batch32"] = {
-                "what": "SpeedySpeech (baker configuration) inference alone, 32 x 128 phones with tones",
-                "ms_per_batch": dts * 1e3, "utterances_per_s": UTT_PER_GPU / dts,
-                "frames": int(sum(o.shape[0] for o in outs))}
-            del ssm
-        except Exception as e:
-            extras["acoustic_models"] = {"error": repr(e)}
-        try:   # the autoregressive acoustic models at the same shape: 32 x 128 tokens -> 640 frames each
-            from parakeet_amd.tacotron2 import Tacotron2
-            from parakeet_amd.transformer_tts import TransformerTTS
-            rng = np.random.default_rng(0)
-            frames_per_utt = TOKENS * 5
-            tcfg = dict(syn.TRANSFORMER_TTS_LJSPEECH)
-            ttm = TransformerTTS(idim=80, odim=80, **tcfg)
-            ttm.set_state_dict(syn.transformer_tts_state(80, 80, tcfg, stop_bias=-8.0))
-            ttm.eval()
-            tx = [rng.integers(1, 79, size=TOKENS) for _ in range(UTT_PER_GPU)]
-            ratio = (frames_per_utt + 0.5) / (TOKENS + 1)
-            ttm.inference_batch(tx, maxlenratio=ratio, return_att=False)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            outs = ttm.inference_batch(tx, maxlenratio=ratio, return_att=False)
-            torch.cuda.synchronize()
-            dtt = time.perf_counter() - t1
-            nf = int(sum(o[0].shape[0] for o in outs))
-            extras["transformer_tts_batch32"] = {
-                "what": "TransformerTTS (LJSpeech recipe sizes) inference alone, 32 x 128 tokens decoded in lockstep for 640 "
-                        "steps (the stop token is held off so that every utterance runs to int(129 * maxlenratio) = 640 "
-                        "frames; the oracle comparison at these sizes, tests/test_ar_benchsize_gpu.py, covers the first 224 steps), "
-                        "prenet dropout stream on, default math; the next step's prefix work runs on a side stream under the current step's "
-                        "layer chain (option overlap_prefix)",
-                "ms_per_batch": dtt * 1e3, "us_per_step": dtt / frames_per_utt * 1e6, "frames": nf,
-                "utterances_per_s": UTT_PER_GPU / dtt, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtt}
-            del ttm
-            ccfg = dict(syn.TACOTRON2_LJSPEECH)
-            tcm = Tacotron2(**ccfg)
-            tcm.set_state_dict(syn.tacotron2_state(ccfg, stop_bias=-8.0))
-            tcm.eval()
-            cx = [rng.integers(1, 37, size=TOKENS) for _ in range(UTT_PER_GPU)]
-            tcm.infer_batch(cx, max_decoder_steps=frames_per_utt)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            outs = tcm.infer_batch(cx, max_decoder_steps=frames_per_utt)
-            torch.cuda.synchronize()
-            dtc = time.perf_counter() - t1
-            nf = int(sum(o["mel_output"].shape[0] for o in outs))
-            extras["tacotron2_batch32"] = {
-                "what": "Tacotron2 (examples/tacotron2/config.py sizes) inference alone, 32 x 128 tokens decoded in lockstep "
-                        "for max_decoder_steps = 640 (stop token held off; tests/test_ar_benchsize_gpu.py compares 256 steps with the "
-                        "oracle), prenet dropout stream on, default math",
-                "ms_per_batch": dtc * 1e3, "us_per_step": dtc / frames_per_utt * 1e6, "frames": nf,
-                "utterances_per_s": UTT_PER_GPU / dtc, "x_realtime_mel_only": nf * 256 / SAMPLE_RATE / dtc}
-            del tcm
-        except Exception as e:
-            extras["autoregressive_models"] = {"error": repr(e)}
+        finally:
+            synth.voc.set_math("f16x3")
+            synth.am.set_math("f16x3")
 
+    def waveflow(wf_c, wmath):
+        key = f"waveflow_c{wf_c}_batch8" + ("_fp16" if wmath else "")
+        guarded(key, lambda: extras.__setitem__(key, waveflow_extra(wf_c, ctx, math=wmath)))
+
+    def extras_core():
+        _log("extras (core): strict fp32, FastSpeech2 / PWG alone, WaveFlow config 5")
+        guarded("all_exact_f32_mfma", lambda: other_math("f32", "all_exact_f32_mfma"))
+        guarded("measurement_extras", lambda: measurement_extras(synth, ctx, args.steps, "core", extras))
+        for wmath in (None, "f16"):      # BASELINE config 5 (64 channels, batch 8 x 640 frames)
+            waveflow(64, wmath)
+
+    def extras_rest():
+        _log("extras (rest, sidecar only): bf16 parts, 128-channel WaveFlow, sweep / host io, text -> wav, other models")
+        guarded("pwg_bf16x3_split", lambda: other_math("bf16x3", "pwg_bf16x3_split"))
+        for wmath in (None, "f16"):      # the reference repository's default width
+            waveflow(128, wmath)
+        guarded("measurement_extras_rest", lambda: measurement_extras(synth, ctx, args.steps, "rest", extras))
+        guarded("text_to_wav", lambda: extras.__setitem__("text_to_wav", text_to_wav_extra(synth)))
+        guarded("acoustic_models", lambda: extras.update(other_acoustic_models(synth, texts, args.steps)))
+
+    if do_extras:
+        extras_core()
+
+    full = None
     if rank == 0:
         total_samples = global_batch * per_utt             # whole job, all ranks, per step
         ms_per_step = elapsed / args.steps * 1e3
@@ -882,7 +1041,10 @@ def main():
         avg_ms = ms_layer / max(n_layer, 1)
         flop_per_launch = PWG_LAYER_FLOP_PER_SAMPLE * layer_samples
         bytes_per_launch = PWG_LAYER_BYTES_PER_SAMPLE * layer_samples
-        traffic = None
+        # HBM bytes per launch from the PMC counters: collected by tools/pmc_traffic.py on THIS kernel in its own rocprofv3 passes
+        # (counters cannot be read from inside the process); the file names the source hash of the library it was collected
+        # on, and `traffic_collected` says whether that is the library timed here
+        traffic = traffic_of = None
         tpath = os.path.join(ROOT, "profiles", "pwg_layer_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -890,8 +1052,12 @@ def main():
                     tj = json.load(f)
                 if tj.get("prof_key", "pwg_layer") == layer_key and tj.get("samples_per_launch", 32 * per_utt) == layer_samples:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    from parakeet_amd import build as _pb
+                    same = tj.get("kernel_source_sha256") == _pb.file_hash("pwg.hip")
+                    traffic_of = (tj.get("collected", "earlier round") +
+                                  (": this kernel source" if same else ": an earlier build of the kernel"))
             except Exception:
-                traffic = None
+                traffic = traffic_of = None
         if layer_key == "pwg_layer":
             # exact-fp32 matrix pipe: compute bound (intensity 64 FLOP/B > ridge 19.7)
             achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -902,13 +1068,15 @@ def main():
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0}
         total_prof_ms = sum(ms for _, ms in prof.values()) / prof_steps
-        out = {
+        full = {
             "metric": "audio samples/sec, FastSpeech2+PWGAN 22.05kHz",
             "value": value,
             "unit": "samples/s",
             "x_realtime": value / SAMPLE_RATE,
             "rtf_reference_convention": SAMPLE_RATE / value,
             "n_gpus": world,
+            "rccl_world_size": comm_world,
+            "rank_ms_per_step": rank_ms,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -918,14 +1086,10 @@ def main():
             "dtype": "f32 (3-term split-fp16 MFMA, fp32-equivalent; exact-fp32 in roofline.exact_f32)",
             "dtype_note": "fp32 storage and accumulation everywhere; the dense contractions (PWG residual blocks and "
                           "last convs, FastSpeech2 Linear/Conv1D/attention) evaluate each fp32 product as a 3-term split-fp16 "
-                          "MFMA sum (a_hi*b_hi + a_lo*b_hi + a_hi*b_lo) of BLOCK-SCALED operands (every operand block is "
-                          "multiplied by the power of two that brings its maximum to [2^13, 2^14) before the split, exactly "
-                          "undone in the epilogue: DESIGN.md 4.7), so the error is the exact-fp32 MFMA path's independent of "
-                          "the magnitude of weights or activations (tests rescale a model's internal streams by 2^-30..2^12; "
-                          "PWG wav 7.1e-7 vs 5.3e-7 rel. max, FS2 mel L1 1.7e-6 vs 1.1e-6 against the fp64 oracle, whose own "
-                          "fp32 run is at 6.0e-7 / 5.4e-7; same test tolerances; parity_check below compares this very "
-                          "batch with the fp32 CPU oracle); softmax/LayerNorm/durations are plain fp32; the "
-                          "all-exact-fp32 configuration is timed under extras",
+                          "MFMA sum (a_hi*b_hi + a_lo*b_hi + a_hi*b_lo) of BLOCK-SCALED operands (DESIGN.md 3 / HISTORY 4.7): the "
+                          "error is the exact-fp32 MFMA path's independent of the magnitude of weights or activations; "
+                          "parity_check compares this very batch with the fp32 CPU oracle; softmax / LayerNorm / durations are "
+                          "plain fp32; the all-exact-fp32 configuration is timed as roofline.exact_f32",
             "data": "synthetic",
             "config": {
                 "workload": "FastSpeech2+PWG end-to-end (BASELINE config 4 per-GPU share): "
@@ -936,63 +1100,57 @@ def main():
                 "minibatch": mb,
                 "parallelism": f"dp{world} (utterance sharding, no data-path collective)",
                 "collectives": collectives,
-                "pipeline": ("acoustic model of the next step's batch issued on a side stream during this step's "
-                             "vocoder (one acoustic + one vocoder pass per step)") if pipelined else "none",
+                "pipeline": "next batch's acoustic model issued on a side stream under this batch's vocoder" if pipelined else "none",
             },
             "roofline": dict(roof, **{
                 "kernel": {"pwg_layer": "k_pwg_layer (exact fp32 MFMA)", "pwg_layer_h3": "k_pwg_layer_b3<HALF> (3-term split-fp16 MFMA)",
                            "pwg_layer_b3": "k_pwg_layer_b3 (3-term split-bf16 MFMA)"}[layer_key] +
                           " -- PWG ResidualBlock, 30 launches/step",
                 "traffic": traffic,
+                "traffic_collected": traffic_of,
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_tflops": flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                 "engine_min_bytes_per_launch": PWG_LAYER_MIN_BYTES_PER_SAMPLE * layer_samples,
                 "note": "algorithmic bytes = SURVEY.md 8(d) layer-granular model, 1344 B/sample/layer x samples per "
-                        "launch; the engine itself never materialises the upsampled conditioning (1024 B/sample)",
-                "traffic_source": "profiles/pwg_layer_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                  "calibrated; same batch; collected on the kernel variant named in that file -- the "
-                                  "variant that stores x as pre-split fp16 planes moves the same bytes by construction)"
-                                  if traffic is not None else None,
+                        "launch; the engine itself never materialises the upsampled conditioning (1024 B/sample); traffic = "
+                        "profiles/pwg_layer_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py)",
             }),
             "kernel_ms_per_step": {k: ms / prof_steps for k, (_, ms) in sorted(prof.items())},
             "kernel_ms_sum": total_prof_ms,
         }
         ex32 = extras.get("all_exact_f32_mfma")
         if ex32 and ex32.get("layer_kernel_avg_ms"):
-            # the strict-fp32 configuration of the SAME step (every contraction on v_mfma_f32_32x32x2_f32), where the driver's
-            # parser keeps it: its layer kernel is bound by the fp32 matrix pipe, not by HBM
-            out["roofline"]["exact_f32"] = {
+            # the strict-fp32 configuration of the SAME step (every contraction on v_mfma_f32_32x32x2_f32): its layer kernel is
+            # bound by the fp32 matrix pipe, not by HBM
+            full["roofline"]["exact_f32"] = {
                 "samples_per_s": ex32["samples_per_s"], "ms_per_step": ex32["ms_per_step"],
                 "layer_ms": ex32["layer_kernel_avg_ms"], "bound": "mfma",
                 "achieved_tflops": ex32["roofline"]["achieved"], "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                 "frac_of_fp32_mfma": ex32["roofline"]["frac"],
                 "what": "pk_pwg_set_math / pk_fs2_set_math = F32: exact fp32 products, in order (no issue-ahead pipeline)"}
         if pipeline_check is not None:
-            out["pipeline_check"] = pipeline_check
-            out["value_unpipelined"] = pipeline_check["unpipelined_samples_per_s"]
-            out["values_together"] = {
-                "pipelined (value)": value, "in_order (value_unpipelined)": pipeline_check["unpipelined_samples_per_s"],
-                "in_order_host_materialised": (extras.get("host_io") or {}).get("samples_per_s")}
-            out["value_note"] = ("`value` = steady-state throughput with the next batch's acoustic model issued during this "
-                                 "batch's vocoder; `value_unpipelined` = the same step issued strictly in order (the latency-true "
-                                 "figure); extras.host_io = with the waveform copied to host memory inside the step")
+            full["pipeline_check"] = pipeline_check
+            full["value_unpipelined"] = pipeline_check["unpipelined_samples_per_s"]
+            full["value_note"] = ("`value` = steady-state throughput with the next batch's acoustic model issued during this "
+                                  "batch's vocoder; `value_unpipelined` = the same step issued strictly in order (the latency-true "
+                                  "figure); extras.host_io = with the waveform copied to host memory inside the step")
         if extras:
-            out["extras"] = extras
+            full["extras"] = extras
         if gather_ms is not None:
-            out["gather_ms"] = gather_ms
-            out["gather_all_ms"] = gather_all_ms
-            out["gather_note"] = ("gather_ms: parakeet_amd.dist.gather_ragged_to -- every rank's packed waveform (last mini-batch) "
-                                  "collected on rank 0 by direct sends; gather_all_ms: gather_ragged -- the same on every rank (one "
-                                  "padded RCCL all_gather); neither is in `value` (config.collectives)")
+            full["gather_ms"] = gather_ms
+            full["gather_all_ms"] = gather_all_ms
+            full["gather_note"] = ("gather_ms: parakeet_amd.dist.gather_ragged_to -- every rank's packed waveform (last mini-batch) "
+                                   "collected on rank 0 by direct sends; gather_all_ms: gather_ragged -- the same on every rank (one "
+                                   "padded RCCL all_gather); neither is in `value` (config.collectives)")
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu_baseline (torch-CPU oracle, bounded)")
             rec, ref_mel, ref_wav = cpu_baseline(fs2_state, pwg_state, stats, texts_all[0], noise[:per_utt].cpu())
-            out["cpu_baseline"] = rec
+            full["cpu_baseline"] = rec
             if parity_src is not None:
                 got_mel, got_wav = parity_src
-                out["parity_check"] = {
+                full["parity_check"] = {
                     "what": "engine (default math, inside the 32-utterance batch) vs the fp32 CPU oracle run timed above: "
                             "same token ids, same vocoder noise, utterance 0",
                     "frames_equal": bool(got_mel.shape == ref_mel.shape),
@@ -1001,8 +1159,18 @@ def main():
                     if got_wav.shape == ref_wav.shape else None,
                     "bars": {"mel_l1": 1e-4, "wav_relmax": 1e-4},
                 }
-        _log("done")
-        print(json.dumps(out))
+        _log("the line")
+        emit(full)
+    if do_extras and args.extras == "all":
+        extras_rest()
+        if full is not None:
+            full["extras"] = extras
+            full["values_together"] = {
+                "pipelined (value)": full["value"], "in_order (value_unpipelined)": full.get("value_unpipelined"),
+                "in_order_host_materialised": (extras.get("host_io") or {}).get("samples_per_s")}
+            full["sidecar"] = write_sidecar(full)
+            _log(f"sidecar complete: {full['sidecar']}")
+    _log("done")
     if distributed:
         import torch.distributed as dist
         dist.barrier()

@@ -52,6 +52,12 @@ def source_hash():
     return h.hexdigest()
 
 
+def file_hash(name):
+    """sha256 of ONE source file under csrc/ (profiles/*_traffic.json name the kernel source their counters were collected on)."""
+    with open(os.path.join(CSRC, name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def library_hash(path=LIB):
     """The PK_SOURCE_HASH string embedded in a built library (read from the file, nothing is loaded)."""
     if not os.path.exists(path):
