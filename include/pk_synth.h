@@ -159,8 +159,12 @@ int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples);
  *                  first call after finalize stalls a pipelined caller and must not be stream-captured.
  *                  Under 1 every "scale_guard_every"-th later inference is SAMPLED as well (same 31 small launches), its
  *                  verdict deferred: the maxima are copied to pinned host memory behind an event and judged at the start of
- *                  a later call -- no stall; a verdict above 2^10 moves the handle to the "planes" = 0 path from then on
- *                  (the sampled call keeps its result: at 2^10 the planes still carry 26 bits of the actual maximum).
+ *                  a later call -- no stall, no allocation (the pinned buffer, 0.5 MB for up to 4096 utterances, and the
+ *                  event are created by pk_pwg_finalize; a call with more utterances is not sampled; a sample whose event
+ *                  reports an error is dropped, not judged); a verdict above 2^10 moves the handle to the "planes" = 0
+ *                  path from then on (the sampled call keeps its result: at 2^10 the planes still carry 26 bits of the
+ *                  actual maximum).  A sampled call adds two device-to-host copies and an event record to the stream: like
+ *                  a guarded call it must not be stream-captured (capture with "scale_guard" 0).
  *   "scale_guard_every"  the sampling period under "scale_guard" 1 (default 16; 0 = never re-sample).
  *                  pk_pwg_scale_overshoot reports what was measured. */
 int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value);

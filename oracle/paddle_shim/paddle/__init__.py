@@ -290,10 +290,12 @@ def load(path, **configs):
     saved as one -- bare ndarrays of a ``_legacy_save`` state dict, the ``(tensor_name, ndarray)`` pairs of
     ``_pickle_save``, and LoDTensor leaves (pickled as ``eval('data', {'data': ndarray})``, which unpickling evaluates).
     [paddle-format, documentation-derived like the rest of this package; tools/verify_with_paddle.py swaps in the real one.]
-    The stand-in only ever reads archives this repository wrote (tools/make_paddle_fixture.py), so plain pickle is fine."""
-    import pickle
+    Round 6: read through the engine's RESTRICTED unpickler (parakeet_amd/checkpoint.py: containers, numpy
+    reconstruction and the LoDTensor reducer's ``eval('data', ...)`` only) -- tools/verify_with_paddle.py hands downloaded
+    checkpoints to this function in stand-in mode, and a bare ``pickle.load`` would run whatever such a file asks for."""
+    from parakeet_amd.checkpoint import _RestrictedUnpickler
     with open(path, "rb") as f:
-        obj = pickle.load(f, encoding="latin1")
+        obj = _RestrictedUnpickler(f, encoding="latin1").load()
 
     def pack(d):
         info = d.get("UnpackBigParamInfor@@")

@@ -243,19 +243,22 @@ def load_speedyspeech(config, checkpoint, stats, phones_dict, tones_dict, same_p
     return SpeedySpeechInference(ZScore(mu, sigma), model), phone_map, tone_map
 
 
-def load_waveflow(config, checkpoint_path):
+def load_waveflow(config, checkpoint_path, cls=None, eval_mode=True):
     """``ConditionalWaveFlow.from_pretrained`` (waveflow.py:827-852): ``checkpoint_path`` without the
-    ``.pdparams`` suffix, ``config`` with a ``model`` section (examples/waveflow/config.py:32-41)."""
-    from .waveflow import ConditionalWaveFlow
+    ``.pdparams`` suffix, ``config`` with a ``model`` section (examples/waveflow/config.py:32-41).  The classmethod of the
+    same name on ``ConditionalWaveFlow`` calls this with ``eval_mode=False`` (the reference returns a model in training mode)."""
+    if cls is None:
+        from .waveflow import ConditionalWaveFlow as cls
     cfg = _config(config)
     m = cfg["model"]
-    model = ConditionalWaveFlow(upsample_factors=m["upsample_factors"], n_flows=m["n_flows"],
-                                n_layers=m["n_layers"], n_group=m["n_group"], channels=m["channels"],
-                                n_mels=cfg["data"]["n_mels"] if "data" in cfg else m.get("n_mels", 80),
-                                kernel_size=m["kernel_size"])
+    model = cls(upsample_factors=list(m["upsample_factors"]), n_flows=m["n_flows"],
+                n_layers=m["n_layers"], n_group=m["n_group"], channels=m["channels"],
+                n_mels=cfg["data"]["n_mels"] if "data" in cfg else m.get("n_mels", 80),
+                kernel_size=m["kernel_size"])
     path = str(checkpoint_path)
     model.set_state_dict(load_params(path if path.endswith(".pdparams") else path + ".pdparams"))
-    model.eval()
+    if eval_mode:
+        model.eval()
     return model
 
 

@@ -1375,6 +1375,7 @@ struct pk_pwg {
     // carry 26 bits of the actual maximum, see GUARD_MAX_LOG2).
     int guard_every = 16;
     int calls_since_sample = 0;
+    int samples_dropped = 0;           // samples not taken (more utterances than the pinned buffer holds) or not judged (event error)
     bool sample_pending = false;
     hipEvent_t ev_sample = nullptr;
     float* host_sample = nullptr;      // pinned: [layers + 1][B] maxima, then B noise maxima
@@ -1514,16 +1515,22 @@ static float pwg_guard_verdict(pk_pwg* h, const float* am, const float* nmax, in
 }
 
 constexpr float PWG_GUARD_MAX_LOG2 = 10.f;
+constexpr int PWG_SAMPLE_MAX_B = 4096;   // utterances a deferred sample can hold (pinned buffer of pk_pwg_finalize)
 
 // A deferred sample whose copies have landed is judged here (start of every inference, and pk_pwg_scale_overshoot).
 static void pwg_poll_sample(pk_pwg* h, bool wait) {
     if (!h->sample_pending) return;
-    if (wait) (void)hipEventSynchronize(h->ev_sample);
-    else if (hipEventQuery(h->ev_sample) != hipSuccess) {
-        (void)hipGetLastError();   // hipErrorNotReady is not an error
+    const hipError_t st = wait ? hipEventSynchronize(h->ev_sample) : hipEventQuery(h->ev_sample);
+    if (st == hipErrorNotReady) {
+        (void)hipGetLastError();   // not an error: the copies have not landed yet
         return;
     }
     h->sample_pending = false;
+    if (st != hipSuccess) {        // the event failed (device error, reset): whatever is in host_sample is not a measurement
+        (void)hipGetLastError();
+        ++h->samples_dropped;
+        return;
+    }
     const int layers = (int)h->cl_host.size(), B = h->sample_B;
     const float worst = pwg_guard_verdict(h, h->host_sample, h->host_sample + (size_t)(layers + 1) * B, B, h->sample_frames.data());
     if (worst > PWG_GUARD_MAX_LOG2 && h->planes_on) {
@@ -1870,6 +1877,16 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
         PK_TRY(pk_upload(ctx, h->d_l2, w2.data(), SK * sizeof(float)));
         h->l2_bias = b2[0];
     }
+    // The deferred scale-guard sample's landing place and its event are created HERE (hipHostMalloc and
+    // hipEventCreate synchronise the device and are illegal under stream capture -- they used to run inside the 16th
+    // pk_pwg_infer).  Sized for PWG_SAMPLE_MAX_B utterances (0.5 MB pinned); a sampled call with more utterances than that is
+    // not sampled (samples_skipped counts them; "scale_guard" 2 guards every call regardless of size).
+    if (!h->host_sample) {
+        const size_t need = (size_t)(c.layers + 2) * PWG_SAMPLE_MAX_B * sizeof(float);
+        PK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_sample), need, hipHostMallocDefault));
+        h->host_sample_cap = need;
+    }
+    if (!h->ev_sample) PK_HIP(hipEventCreateWithFlags(&h->ev_sample, hipEventDisableTiming));
     h->finalized = true;
     return PK_OK;
 }
@@ -2082,7 +2099,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     bool sample = false;
     if (planes && !guard && h->scale_guard == 1 && h->guard_every > 0 && !h->sample_pending &&
         ++h->calls_since_sample >= h->guard_every) {
-        sample = true;
+        if (B <= PWG_SAMPLE_MAX_B && h->host_sample && h->ev_sample) sample = true;
+        else ++h->samples_dropped;     // larger than the pinned buffer of pk_pwg_finalize: nothing is allocated inside a call
         h->calls_since_sample = 0;
     }
     unsigned* amax = nullptr;
@@ -2220,15 +2238,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         h->last_x_final = c.layers & 1;
     }
     if (sample) {   // deferred verdict: the maxima travel to pinned memory behind an event; pwg_poll_sample judges them later
-        const size_t n_am = (size_t)(c.layers + 1) * B, need = (n_am + B) * sizeof(float);
-        if (h->host_sample_cap < need) {
-            if (h->host_sample) (void)hipHostFree(h->host_sample);
-            h->host_sample = nullptr;
-            h->host_sample_cap = 0;
-            PK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_sample), need, hipHostMallocDefault));
-            h->host_sample_cap = need;
-        }
-        if (!h->ev_sample) PK_HIP(hipEventCreateWithFlags(&h->ev_sample, hipEventDisableTiming));
+        const size_t n_am = (size_t)(c.layers + 1) * B;   // (fits: `sample` is only set for B <= PWG_SAMPLE_MAX_B; buffer and event: pk_pwg_finalize)
         PK_HIP(hipMemcpyAsync(h->host_sample, amax, n_am * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipMemcpyAsync(h->host_sample + n_am, h->ws_nmax.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipEventRecord(h->ev_sample, ctx->stream));

@@ -1176,6 +1176,11 @@ static int wfl_ablation(Go& go, bool shape_ok, bool trace, bool w12, bool f16, b
     return 1;
 }
 
+bool wfl_three_waves_allowed() {
+    static const bool on = PK_PROFILE_BUILD && pk_prof_env("PK_WF_ALLOW_3WAVE") && atoi(pk_prof_env("PK_WF_ALLOW_3WAVE")) != 0;
+    return on;
+}
+
 int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     if (!wfl_supports(a.C) || a.npos_alloc % WAVE_T != 0 || a.ntap % 3 != 0 || a.ntap < 3 || a.ntap > 9 || a.nl < 1 || a.nl > WFL_MAX_LAYERS)
         PK_FAIL(PK_EINVAL, "wfl_layer_launch: bad shape (C %d, npos %d, taps %d, layers %d)", a.C, a.npos_alloc, a.ntap, a.nl);
@@ -1199,12 +1204,13 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     // fp16-operand kernels -- one instruction per accumulator and k-step -- and the 8-wave kernels: 0 of 100 runs, bit-identical).
     // The product therefore runs the default math in 8-wave workgroups only and refuses the option; the profile build keeps
     // the kernels for whoever wants to find the instruction pair.
-    if (!PK_PROFILE_BUILD && (a.waves == 6 || (a.waves == 12 && !a.f16)))
+    const bool allow3 = wfl_three_waves_allowed();
+    if (!allow3 && (a.waves == 6 || (a.waves == 12 && !a.f16)))
         PK_FAIL(PK_EUNSUPPORTED, "wfl_layer_launch: %d-wave workgroups are %s (three waves per SIMD gave non-deterministic results on the MI355X)",
                 a.waves, a.waves == 6 ? "not in the product" : "for fp16 operands only");
     const bool w6 = a.C == 64 && a.waves == 6 && a.nl == 1;   // two 6-wave workgroups per CU (see Shape)
     const bool w12 = !w6 && a.C == 64 && (a.waves == 12 || a.waves == 6 ||
-                                          (a.waves != 8 && (a.f16 || PK_PROFILE_BUILD) && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));
+                                          (a.waves != 8 && (a.f16 || allow3) && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));
     const int W = w6 ? 6 : (w12 ? 12 : 8);
     if (w6) {
         b.tiles_per_wg = std::max(1, (ntiles + 2 * ctx->n_cu - 1) / (2 * ctx->n_cu));
@@ -1216,7 +1222,7 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     // benchmark's shape came back with a few tiles off by 1e-3 (the same signature as the three-waves-per-SIMD kernels of the
     // 64-channel model); shapes in which no SIMD has two working waves never did.  A workgroup's 11 tiles are 3 per SIMD either
     // way (8 + 3 or 4 + 4 + 3): the price is the overlap of one wave's vector work with the other's matrix work.
-    const int active_default = (a.C == 128 && !a.f16 && !PK_PROFILE_BUILD) ? 4 : W;
+    const int active_default = (a.C == 128 && !a.f16 && !allow3) ? 4 : W;
     b.active = active_env >= 1 && active_env <= W ? active_env : active_default;
     // several layers: the workgroups wait for one another (pk_grid.h) -- at most one per CU by construction (LDS), launched
     // cooperatively so that a grid that cannot be co-resident is an error, not a hang

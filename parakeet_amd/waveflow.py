@@ -10,8 +10,10 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _capi
+from . import _capi, amp
 from .runtime import Context, dptr, set_params, wrap
+
+_MATH = {"f32": 0, "f16x3": 1, "f16": 2}
 
 
 class ConditionalWaveFlow:
@@ -32,6 +34,16 @@ class ConditionalWaveFlow:
         _capi.check(self._ctx.lib.pk_wf_create(self._ctx.handle, C.byref(cfg), C.byref(h)))
         self._h = h
         self._finalized = False
+        self._math = "f16x3"
+
+    @classmethod
+    def from_pretrained(cls, config, checkpoint_path):
+        """waveflow.py:827-852: ``config`` with ``model`` / ``data`` sections (examples/waveflow/config.py; a yacs node, a
+        mapping or a yaml path), ``checkpoint_path`` without the ``.pdparams`` suffix.  Like the reference it returns the
+        model in training mode with the checkpoint's weight-norm pairs loaded (folded when the engine packs them): the
+        recipe goes on with ``layer_tools.recursively_remove_weight_norm(model)`` and ``model.eval()``."""
+        from . import checkpoint
+        return checkpoint.load_waveflow(config, checkpoint_path, cls=cls, eval_mode=False)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -51,7 +63,8 @@ class ConditionalWaveFlow:
 
     def set_math(self, mode):
         """'f16x3' (default: split-fp16 MFMA GEMMs, fp32-equivalent error) or 'f32' (exact fp32 MFMA)."""
-        _capi.check(self._ctx.lib.pk_wf_set_math(self._h, {"f32": 0, "f16x3": 1, "f16": 2}[mode]))
+        _capi.check(self._ctx.lib.pk_wf_set_math(self._h, _MATH[mode]))
+        self._math = mode
 
     def set_option(self, key, value):
         """Named integer options of the engine handle (include/pk_synth.h, pk_wf_set_option): 'layer_waves'."""
@@ -83,8 +96,16 @@ class ConditionalWaveFlow:
             z = torch.cat([ctx.to_device(v).reshape(-1) for v in zs])
         assert z is None or z.numel() == total_z, "z must have cond_len samples per utterance"
         wav = ctx.empty((sum(b for _, b in lens),))
-        _capi.check(ctx.lib.pk_wf_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)), len(mels),
-                                        None if z is None else dptr(z), dptr(wav), 0))
+        # inside `with parakeet_amd.amp.auto_cast():` (examples/waveflow/synthesize.py:40) the call runs with fp16 operands
+        cast = amp.enabled() and self._math != "f16"
+        if cast:
+            _capi.check(ctx.lib.pk_wf_set_math(self._h, _MATH["f16"]))
+        try:
+            _capi.check(ctx.lib.pk_wf_infer(self._h, dptr(mel), frames.ctypes.data_as(C.POINTER(C.c_int32)), len(mels),
+                                            None if z is None else dptr(z), dptr(wav), 0))
+        finally:
+            if cast:
+                _capi.check(ctx.lib.pk_wf_set_math(self._h, _MATH[self._math]))
         outs, o = [], 0
         for _, n in lens:
             outs.append(wrap(wav[o:o + n]))

@@ -191,3 +191,32 @@ def test_real_paddle_checkpoint_opt_in():
             assert not missing, f"{path}: parameters the engine needs are absent: {missing[:8]}"
             for n, w in want.items():
                 assert tuple(state[n].shape) == tuple(np.asarray(w).shape), (n, state[n].shape, np.asarray(w).shape)
+
+
+def test_standin_paddle_load_refuses_code_in_an_archive(tmp_path):
+    """the stand-in ``paddle.load`` (oracle/paddle_shim) reads through the engine's restricted unpickler -- an
+    archive that asks for anything but containers and numpy reconstruction is refused, not executed."""
+    import pickle
+    import sys
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "paddle_shim")
+    sys.path.insert(0, shim)
+    try:
+        import paddle
+        assert os.path.abspath(paddle.__file__).startswith(shim)
+
+        class Evil:
+            def __reduce__(self):
+                return (os.system, ("echo pwned > " + str(tmp_path / "pwned"),))
+        with open(tmp_path / "evil.pdparams", "wb") as f:
+            pickle.dump({"w": Evil()}, f, protocol=2)
+        with pytest.raises(pickle.UnpicklingError):
+            paddle.load(str(tmp_path / "evil.pdparams"))
+        assert not (tmp_path / "pwned").exists()
+        with open(tmp_path / "ok.pdparams", "wb") as f:
+            pickle.dump({"w": np.arange(6, dtype=np.float32).reshape(2, 3), "StructuredToParameterName@@": {"w": "linear_0.w_0"}}, f, protocol=2)
+        got = paddle.load(str(tmp_path / "ok.pdparams"))
+        assert list(got) == ["w"] and tuple(got["w"].shape) == (2, 3)
+    finally:
+        sys.path.remove(shim)
+        for k in [k for k in sys.modules if k == "paddle" or k.startswith("paddle.")]:
+            del sys.modules[k]

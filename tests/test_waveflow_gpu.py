@@ -84,13 +84,15 @@ def test_waveflow_12_wave_workgroups_bit_identical():
     frames = [9, 4, 6]
     mels = [np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32) for T in frames]
     zs = [rng.normal(size=(model.lengths(T)[0],)).astype(np.float32) for T in frames]
-    for w in (12, 6):                     # default math: refused when the call is made
-        model.set_option("layer_waves", w)
-        with pytest.raises(NotImplementedError):
-            model.infer_batch(mels, zs)
-    model.set_math("f16")
     with pytest.raises(NotImplementedError):
-        model.infer_batch(mels, zs)       # (still 6)
+        model.set_option("layer_waves", 6)        # not in the product: refused where it is set, nothing changes
+    model.set_option("layer_waves", 12)
+    with pytest.raises(NotImplementedError):      # 12 x default math: refused at the top of the call, before any launch
+        model.infer_batch(mels, zs)
+    model.set_option("layer_waves", 0)
+    first = [o.numpy().copy() for o in model.infer_batch(mels, zs)]      # ... and the handle is as usable as before
+    assert all(np.isfinite(o).all() for o in first)
+    model.set_math("f16")
     outs = {}
     for w in (8, 12):
         model.set_option("layer_waves", w)
@@ -223,3 +225,69 @@ def test_waveflow_calls_with_two_working_waves_per_simd_are_deterministic_and_ri
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), "two runs of the same call differ"
     err = np.abs(runs[0] - want).max() / np.abs(want).max()
     assert err < (2e-3 if math == "f16" else 2e-6), f"differs from the exact-fp32 path by {err}"
+    if frames == [640] * 8:
+        # VERDICT r5 "weak" #2: BASELINE config 5 against the ORACLE itself (fp64 restatement of waveflow.py:785-805), not only
+        # against the engine's other kernel family: the first and the last utterance of the 8 x 640 call
+        from oracle import waveflow_ref as ref
+        o = 0
+        for b, T in enumerate(frames):
+            n = model.lengths(T)[1]
+            if b in (0, 7):
+                with torch.no_grad():
+                    w64 = ref.infer(state, torch.from_numpy(mels[b])[None], torch.from_numpy(zs[b])[None], cfg, torch.float64)[0].numpy()
+                e = np.abs(runs[0][o:o + n] - w64).max() / np.abs(w64).max()
+                assert e < (2e-3 if math == "f16" else 5e-6), f"utterance {b} of the 8 x 640 call differs from the fp64 oracle by {e}"
+            o += n
+
+
+def test_waveflow_recipe_with_three_imports_swapped(tmp_path):
+    """VERDICT r5 "missing" #2 / "next" #6: the body of examples/waveflow/synthesize.py:29-44 with its three imports swapped --
+    `ConditionalWaveFlow.from_pretrained(config, checkpoint_path)` on the class (waveflow.py:827-852),
+    `layer_tools.recursively_remove_weight_norm(model)` (utils/layer_tools.py:40-46), `model.eval()`, then per mel file
+    `with amp.auto_cast(): audio = model.predict(mel)` -- on a weight-normalised checkpoint in the released layout
+    (`<path>.pdparams`, yacs-style config with attribute access).  Under auto_cast the call runs with fp16 operands (the
+    reference's AMP precision) and returns to the default math afterwards."""
+    import pickle
+    from oracle import waveflow_ref as ref
+    # --- the recipe's three imports, swapped:
+    from parakeet_amd.waveflow import ConditionalWaveFlow          # parakeet.models.waveflow
+    from parakeet_amd.utils import layer_tools                     # parakeet.utils
+    from parakeet_amd import amp                                   # paddle.amp
+
+    class Node(dict):                                              # what yacs' CfgNode offers the recipe: items as attributes
+        __getattr__ = dict.__getitem__
+    wcfg = dict(syn.WAVEFLOW_LJSPEECH, channels=64, n_flows=4)
+    config = Node(data=Node(n_mels=80, sample_rate=22050),
+                  model=Node({k: v for k, v in wcfg.items() if k != "n_mels"}))
+    state = syn.waveflow_state(wcfg, seed=5, weight_norm=True)
+    assert any(k.endswith("weight_g") for k in state)
+    with open(tmp_path / "step-2000000.pdparams", "wb") as f:
+        pickle.dump(dict(state), f, protocol=2)
+    mel_dir, output_dir = tmp_path / "mels", tmp_path / "out"
+    mel_dir.mkdir()
+    rng = np.random.default_rng(11)
+    for i, T in enumerate((9, 14)):
+        np.save(mel_dir / f"LJ00{i}.npy", np.maximum(rng.normal(-4, 2, size=(80, T)), np.log(1e-5)).astype(np.float32))
+
+    # --- synthesize.py:29-44
+    model = ConditionalWaveFlow.from_pretrained(config, str(tmp_path / "step-2000000"))
+    assert model.training
+    layer_tools.recursively_remove_weight_norm(model)
+    model.eval()
+    output_dir.mkdir(parents=True, exist_ok=True)
+    model.set_seed(1234)
+    for file_path in sorted(mel_dir.glob("*.npy")):
+        mel = np.load(str(file_path))
+        with amp.auto_cast():
+            audio = model.predict(mel)
+        assert isinstance(audio, np.ndarray) and audio.shape == (model.lengths(mel.shape[1])[1],) and np.isfinite(audio).all()
+        # the same call with the latent given: fp16 operands inside auto_cast, the default math outside
+        z = rng.normal(size=(model.lengths(mel.shape[1])[0],)).astype(np.float32)
+        with torch.no_grad():
+            want = ref.infer(state, torch.from_numpy(mel)[None], torch.from_numpy(z)[None], wcfg, torch.float64)[0].numpy()
+        with amp.auto_cast():
+            a16 = model.predict(mel, z)
+        a32 = model.predict(mel, z)
+        e16 = np.abs(a16 - want).max() / np.abs(want).max()
+        e32 = np.abs(a32 - want).max() / np.abs(want).max()
+        assert e32 < 1e-5 < e16 < 2e-3, (e32, e16)
