@@ -1,0 +1,254 @@
+// VERDICT r5 "next" #2 / HISTORY 9.9: a standalone reproducer for the WaveFlow layer kernel's "cause (ii)".
+//
+// What the failing kernels do on one SIMD: two or three waves each run, per accumulator tile ("co-tile"), a chain of THREE
+// dependent v_mfma_f32_32x32x16_f16 (a_hi b_hi + a_lo b_hi + a_hi b_lo into the same accumulator), the A fragments coming from LDS
+// by ds_read_b128 into a register set that the NEXT co-tile re-uses (one set in the 12-wave kernel, two at 128 channels, three in
+// the 8-wave kernel that never fails), the B operand from a ring of registers that global loads refill right behind the k-step.
+// The fp16-operand kernels (ONE matrix instruction per accumulator and k-step) never failed.
+//
+// This program strips that down to the instruction pattern and nothing else: LDS is written ONCE (no weight streaming, no
+// barrier protocol, no cross-wave hand-off of any kind after the initial __syncthreads), the B values of a k-step come from a
+// read-only global table, every wave of the grid computes THE SAME numbers (small integers: every product and sum is exact in
+// fp16 / fp32, so the result does not depend on any order), and the instruction sequence is written in inline assembly, so
+// the compiler schedules nothing.  A first launch with ONE working wave (block 0, wave 0) gives the expected accumulators;
+// then the same code runs with 1, 2 and 3 working waves per SIMD on all 256 CUs, `reps` launches each, and every wave
+// compares its accumulators with the expected ones bit for bit.
+//
+//   template parameters
+//     SETS   A register sets in rotation: 1 (12-wave kernel), 2 (128 channels), 3 (8-wave kernel).  The ds_read pair of
+//            co-tile s + SETS is issued right behind the chain of co-tile s, into the registers that chain has just used.
+//     MM     matrix instructions per chain: 3 (default math) or 1 (fp16 operands)
+//     PAD    0: the reads directly behind the chain's last MFMA (as compiled); 1: two `s_nop 15` in front of them
+//            (HISTORY 9.9 experiment (a)); 2: the reads behind the FIRST MFMA of the next chain (experiment (b))
+//     BREF   0: B operand constant in registers; 1: the B registers of a k-step are refilled by two global_load_dwordx4 right
+//            behind the k-step's last MFMA and waited for (vmcnt(0)) in front of the next k-step -- a ring one slot deep, every
+//            wait real; 2: the same through a two-slot ring (the refill of slot k lands while slot k + 1 is multiplied)
+//
+// Build / run:  hipcc --offload-arch=gfx950 -O3 -o mfma_chain_hazard mfma_chain_hazard.hip && ./mfma_chain_hazard [reps]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int NQ = 4;             // co-tiles per k-step (64 channels: four accumulator tiles)
+constexpr int KSTEPS = 48;        // k-steps per launch (the kernel's 42 and a bit)
+constexpr int LDS_KS = 18;        // k-steps of A fragments resident in LDS: 18 x 8 KB = 144 KB, read cyclically
+constexpr int KS_BYTES = NQ * 2 * 64 * 16;   // [q][hi | lo][lane][16 B]
+
+struct Args {
+    const u32x4* a_src;   // LDS image: LDS_KS * KS_BYTES bytes
+    const u32x4* b_tab;   // [KSTEPS + 2][hi | lo][64 lanes] 16-byte vectors
+    const float* expect;  // [NQ][16][64]
+    float* expect_out;    // written by the reference launch
+    unsigned* bad;        // [0] mismatching waves, [1] mismatching values, [2..] samples: (block, wave, q, r | lane << 8)
+    int working;          // waves of a block that work (the others return after the barrier)
+    int reference;        // 1: only block 0 / wave 0 works and writes expect_out
+};
+
+#define MFMA(acc, a, b) "v_mfma_f32_32x32x16_f16 " acc ", " a ", " b ", " acc "\n"
+
+template <int SETS, int MM, int PAD, int BREF>
+__global__ __launch_bounds__(768, 3) void k_chain(Args g) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[LDS_KS * KS_BYTES / 16];
+    for (int i = threadIdx.x; i < LDS_KS * KS_BYTES / 16; i += blockDim.x) lds[i] = g.a_src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (g.reference ? (blockIdx.x != 0 || wave != 0) : wave >= g.working) return;
+    f32x16 acc[NQ];
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    u32x4 ah[SETS], al[SETS];          // A register sets
+    u32x4 bh[2], bl[2];                // B ring (BREF 2: two slots)
+    const unsigned lbase = (unsigned)(size_t)(&lds[0]) + lane * 16;   // LDS byte address of this lane's 16 bytes of (k-step 0, q 0, hi)
+    const u32x4* bt = g.b_tab + lane;
+    bh[0] = bt[0];
+    bl[0] = bt[64];
+    if (BREF == 2) {
+        bh[1] = bt[128];
+        bl[1] = bt[192];
+    }
+    // co-tile s = ks * NQ + q lives at LDS offset (ks % LDS_KS) * KS_BYTES + q * 2048 (+ 1024 for the lo part)
+    auto a_off = [&](int s) { return (unsigned)(((s / NQ) % LDS_KS) * KS_BYTES + (s % NQ) * 2048); };
+    // prologue: the first SETS co-tiles' fragments
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+        const unsigned ad = lbase + a_off(s);
+        asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n" : "=v"(ah[s]), "=v"(al[s]) : "v"(ad));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 4" ::: "memory");
+    constexpr int UNR = 24;            // co-tiles per unrolled block: six k-steps (the B ring's slot parity is a constant) and a multiple of every SETS
+    constexpr int WAITN = PAD == 2 ? 2 * (SETS - 2) : 2 * (SETS - 1);   // reads that may stay in flight when a chain starts
+    static_assert(PAD != 2 || SETS >= 2, "reads behind the next chain's first MFMA need a second register set");
+    static_assert(KSTEPS * NQ % UNR == 0 && UNR % NQ == 0 && UNR % SETS == 0, "");
+#pragma unroll 1
+    for (int s0 = 0; s0 < KSTEPS * NQ; s0 += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int s = s0 + u, q = u % NQ, set = u % SETS;
+            const int ks = s / NQ;
+            const unsigned nxt = lbase + a_off(s + SETS);   // fragments of co-tile s + SETS go into this chain's registers
+            const bool last_q = q == NQ - 1;
+            // ---- wait for this co-tile's fragments: the reads of the SETS - 1 later co-tiles may stay in flight (2 reads each)
+            if (BREF && q == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BREF == 2 ? 2 : 0) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(WAITN) : "memory");
+            const int sl = BREF == 2 ? (u / NQ) & 1 : 0;   // = ks & 1: a block starts at an even k-step
+            if (MM == 3) {
+                if (PAD == 2) {
+                    // the reads of the PREVIOUS chain's registers come behind this chain's first MFMA (experiment (b)): with one set
+                    // that cannot be expressed (the chain needs the data) -> PAD 2 is instantiated for SETS >= 2 only, where the
+                    // registers refilled here are those of co-tile s - 1
+                    const int pset = (u + SETS - 1) % SETS;
+                    const unsigned pn = lbase + a_off(s - 1 + SETS);
+                    asm volatile(MFMA("%0", "%1", "%3")
+                                 "ds_read_b128 %5, %7\n ds_read_b128 %6, %7 offset:1024\n"
+                                 MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
+                                 : "+v"(acc[q]), "+v"(ah[set]), "+v"(al[set]), "+v"(bh[sl]), "+v"(bl[sl]), "+v"(ah[pset]), "+v"(al[pset])
+                                 : "v"(pn)
+                                 : "memory");
+                } else {
+                    asm volatile(MFMA("%0", "%1", "%3") MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
+                                 : "+v"(acc[q]), "+v"(ah[set]), "+v"(al[set]), "+v"(bh[sl]), "+v"(bl[sl])
+                                 :
+                                 : "memory");
+                }
+            } else {
+                asm volatile(MFMA("%0", "%1", "%2") : "+v"(acc[q]), "+v"(ah[set]), "+v"(bh[sl]) : : "memory");
+            }
+            if (PAD == 1) asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+            if (PAD != 2)
+                asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n" : "+v"(ah[set]), "+v"(al[set]) : "v"(nxt) : "memory");
+            if (BREF && last_q) {
+                // the k-step's B registers are dead: refill them for k-step ks + (BREF == 2 ? 2 : 1), right behind its last MFMA
+                const u32x4* src = bt + (size_t)(ks + (BREF == 2 ? 2 : 1)) * 128;
+                asm volatile("global_load_dwordx4 %0, %2, off\n global_load_dwordx4 %1, %2, off offset:1024\n"
+                             : "+v"(bh[sl]), "+v"(bl[sl])
+                             : "v"(src)
+                             : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");   // far beyond any MFMA -> VALU distance
+    if (g.reference) {
+        for (int q = 0; q < NQ; ++q)
+            for (int r = 0; r < 16; ++r) g.expect_out[(q * 16 + r) * 64 + lane] = acc[q][r];
+        return;
+    }
+    int nbad = 0, fq = -1, fr = -1;
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r)
+            if (acc[q][r] != g.expect[(q * 16 + r) * 64 + lane]) {
+                if (!nbad) fq = q, fr = r;
+                ++nbad;
+            }
+    const unsigned long long any = __ballot(nbad != 0);
+    if (nbad) {
+        atomicAdd(&g.bad[1], (unsigned)nbad);
+        if (lane == __ffsll((long long)any) - 1) {
+            const unsigned i = atomicAdd(&g.bad[0], 1u);
+            if (i < 16) {
+                g.bad[2 + 4 * i] = blockIdx.x;
+                g.bad[3 + 4 * i] = wave;
+                g.bad[4 + 4 * i] = fq;
+                g.bad[5 + 4 * i] = fr | (lane << 8) | ((unsigned)__popcll(any) << 16);
+            }
+        }
+    }
+}
+
+template <int SETS, int MM, int PAD, int BREF>
+void variant(const char* what, Args g, int reps) {
+    unsigned* bad_h;
+    CK(hipHostMalloc(&bad_h, 4 * 80, 0));
+    g.reference = 1;
+    g.working = 1;
+    hipLaunchKernelGGL((k_chain<SETS, MM, PAD, BREF>), dim3(1), dim3(768), 0, 0, g);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy((void*)g.expect, g.expect_out, NQ * 16 * 64 * 4, hipMemcpyDeviceToDevice));
+    std::vector<float> e(NQ * 16 * 64);
+    CK(hipMemcpy(e.data(), g.expect, e.size() * 4, hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (float v : e) sum += v;
+    printf("%-78s checksum of the expected accumulators %.0f\n", what, sum);
+    g.reference = 0;
+    for (int working : {4, 8, 12}) {
+        g.working = working;
+        CK(hipMemset(g.bad, 0, 4 * 80));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        int bad_launches = 0;
+        unsigned waves = 0, values = 0;
+        unsigned first[4] = {0, 0, 0, 0};
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) {
+            hipLaunchKernelGGL((k_chain<SETS, MM, PAD, BREF>), dim3(256), dim3(768), 0, 0, g);
+            if ((r & 63) == 63 || r + 1 == reps) {     // look at the counters every 64 launches
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(bad_h, g.bad, 4 * 80, hipMemcpyDeviceToHost));
+                if (bad_h[0]) {
+                    ++bad_launches;
+                    if (!waves) for (int i = 0; i < 4; ++i) first[i] = bad_h[2 + i];
+                    waves += bad_h[0];
+                    values += bad_h[1];
+                    CK(hipMemset(g.bad, 0, 4 * 80));
+                }
+            }
+        }
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("    %d working waves per SIMD: %5d launches, %.1f us each: ", working / 4, reps, ms * 1e3 / reps);
+        if (!waves) printf("all waves right\n");
+        else
+            printf("WRONG: %u waves, %u values (in %d groups of 64 launches); first: block %u wave %u tile %u register %u lane %u (%u lanes of the wave)\n",
+                   waves, values, bad_launches, first[0], first[1], first[2], first[3] & 255, (first[3] >> 8) & 255, first[3] >> 16);
+    }
+    CK(hipHostFree(bad_h));
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 2000;
+    // A fragments: small integers that differ by (k-step, co-tile, part, lane, element); B: by (k-step, part, lane, element)
+    std::vector<_Float16> a((size_t)LDS_KS * KS_BYTES / 2), b((size_t)(KSTEPS + 2) * 2 * 64 * 8);
+    for (size_t i = 0; i < a.size(); ++i) {
+        const unsigned h = (unsigned)(i * 2654435761u) >> 13;
+        a[i] = (_Float16)(float)((int)(h % 7) - 3);
+    }
+    for (size_t i = 0; i < b.size(); ++i) {
+        const unsigned h = (unsigned)(i * 40503u + 17) * 2246822519u >> 11;
+        b[i] = (_Float16)(float)((int)(h % 5) - 2);
+    }
+    Args g{};
+    void *da, *db, *de, *deo, *dbad;
+    CK(hipMalloc(&da, a.size() * 2));
+    CK(hipMalloc(&db, b.size() * 2));
+    CK(hipMalloc(&de, NQ * 16 * 64 * 4));
+    CK(hipMalloc(&deo, NQ * 16 * 64 * 4));
+    CK(hipMalloc(&dbad, 4 * 80));
+    CK(hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+    g.a_src = (const u32x4*)da;
+    g.b_tab = (const u32x4*)db;
+    g.expect = (const float*)de;
+    g.expect_out = (float*)deo;
+    g.bad = (unsigned*)dbad;
+    printf("mfma_chain_hazard: 256 workgroups x 12 waves, %d k-steps x %d co-tiles per launch, %d launches per line\n", KSTEPS, NQ, reps);
+    variant<1, 3, 0, 0>("1 A set,  chains of 3, reads right behind the chain (the 12-wave kernel)", g, reps);
+    variant<1, 3, 1, 0>("1 A set,  chains of 3, two s_nop 15 in front of the reads (experiment a)", g, reps);
+    variant<2, 3, 0, 0>("2 A sets, chains of 3 (128 channels)", g, reps);
+    variant<2, 3, 2, 0>("2 A sets, chains of 3, reads behind the next chain's first MFMA (experiment b)", g, reps);
+    variant<3, 3, 0, 0>("3 A sets, chains of 3 (the 8-wave kernel)", g, reps);
+    variant<1, 1, 0, 0>("1 A set,  one MFMA per co-tile (fp16 operands)", g, reps);
+    variant<1, 3, 0, 1>("1 A set,  chains of 3, B refilled behind the k-step, one slot (every wait real)", g, reps);
+    variant<1, 3, 0, 2>("1 A set,  chains of 3, B refilled behind the k-step, two slots", g, reps);
+    variant<2, 3, 0, 2>("2 A sets, chains of 3, B refilled behind the k-step, two slots", g, reps);
+    variant<1, 1, 0, 2>("1 A set,  one MFMA per co-tile, B refilled behind the k-step, two slots", g, reps);
+    return 0;
+}
