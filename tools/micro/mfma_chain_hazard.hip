@@ -213,6 +213,106 @@ void variant(const char* what, Args g, int reps) {
     CK(hipHostFree(bad_h));
 }
 
+
+// ---- second question (round 6): does a VALU write to a DATA register of a ds_write_b128, issued within a few instructions
+// of the store, ever reach LDS instead of the value the store was issued with?  The 12-wave default-math kernel's weight
+// staging compiles to exactly that (k12.s: `ds_write_b128 v133, v[70:73]` / `v_add_u32 v70, ...` as the NEXT instruction;
+// `ds_write_b128 v133, v[118:121]` / two instructions / `v_add_u32 v118, ...`): hipcc inserts no wait state there -- LLVM has a
+// store-data hazard for > 64-bit VMEM / FLAT stores only --, and a corrupted weight chunk would be read by EVERY wave of the
+// workgroup: the signature of cause (ii) ("the tiles of ONE workgroup per event").  Every wave here runs the chains of three
+// with their LDS reads (the load the real kernel puts on the matrix pipe, the register file and the LDS queue), and between
+// two k-steps stores a 16-byte pattern per lane to its own 1 KB of LDS, overwrites the first data register GAP instructions
+// later by a VALU add, and checks what arrived after the next k-step.
+template <int GAP>
+__global__ __launch_bounds__(768, 3) void k_store_war(Args g, unsigned iters) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[LDS_KS * KS_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) u32x4 wreg[12 * 64];
+    for (int i = threadIdx.x; i < LDS_KS * KS_BYTES / 16; i += blockDim.x) lds[i] = g.a_src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= g.working) return;
+    f32x16 acc[NQ];
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    u32x4 ah, al, bh, bl;
+    const unsigned lbase = (unsigned)(size_t)(&lds[0]) + lane * 16;
+    const unsigned wadr = (unsigned)(size_t)(&wreg[0]) + threadIdx.x * 16;
+    bh = g.b_tab[lane];
+    bl = g.b_tab[64 + lane];
+    unsigned nbad = 0, first_it = 0, first_got = 0;
+    asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n s_waitcnt lgkmcnt(0)" : "=v"(ah), "=v"(al) : "v"(lbase));
+#pragma unroll 1
+    for (unsigned it = 0; it < iters; ++it) {
+        u32x4 back;
+        const unsigned pat = it * 2654435761u + threadIdx.x * 40503u + blockIdx.x;
+        const unsigned junk = 0x2d000u + it;
+        // the pattern in v[100:103], the store, GAP other instructions (the kernel has a global load and an address add there), then the
+        // VALU write to v100, the store's first data register
+#define PAT "v_mov_b32 v100, %1\n v_xor_b32 v101, 0x11111111, %1\n v_xor_b32 v102, 0x22222222, %1\n v_xor_b32 v103, 0x33333333, %1\n s_nop 1\n"
+        if (GAP == 0)
+            asm volatile(PAT "ds_write_b128 %0, v[100:103]\n v_add_u32 v100, %2, %3\n"
+                         : : "v"(wadr), "v"(pat), "v"(junk), "v"(lane) : "memory", "v100", "v101", "v102", "v103");
+        else if (GAP == 1)
+            asm volatile(PAT "ds_write_b128 %0, v[100:103]\n v_add_u32 v104, %2, %3\n v_add_u32 v100, %2, %3\n"
+                         : : "v"(wadr), "v"(pat), "v"(junk), "v"(lane) : "memory", "v100", "v101", "v102", "v103", "v104");
+        else if (GAP == 2)
+            asm volatile(PAT "ds_write_b128 %0, v[100:103]\n global_load_dword v104, %4, off\n v_add_u32 v101, %2, %3\n v_add_u32 v100, %2, %3\n s_waitcnt vmcnt(0)"
+                         : : "v"(wadr), "v"(pat), "v"(junk), "v"(lane), "v"(g.b_tab) : "memory", "v100", "v101", "v102", "v103", "v104");
+        else
+            asm volatile(PAT "ds_write_b128 %0, v[100:103]\n s_nop 7\n v_add_u32 v100, %2, %3\n"
+                         : : "v"(wadr), "v"(pat), "v"(junk), "v"(lane) : "memory", "v100", "v101", "v102", "v103");
+#undef PAT
+        // one k-step of chains (their reads queue behind the store)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const unsigned nxt = lbase + (unsigned)(((it + (q == NQ - 1)) % LDS_KS) * KS_BYTES + ((q + 1) % NQ) * 2048);
+            asm volatile(MFMA("%0", "%1", "%3") MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
+                         "ds_read_b128 %1, %5\n ds_read_b128 %2, %5 offset:1024\n s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(acc[q]), "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl) : "v"(nxt) : "memory");
+        }
+        asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(back) : "v"(wadr) : "memory");
+        if (back[0] != pat || back[1] != (pat ^ 0x11111111u) || back[2] != (pat ^ 0x22222222u) || back[3] != (pat ^ 0x33333333u)) {
+            if (!nbad) first_it = it, first_got = back[0] ^ pat;
+            ++nbad;
+        }
+    }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float sink = 0.f;
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r) sink += acc[q][r];
+    if (sink == 1.2345e30f) nbad += 1u << 30;
+    const unsigned long long any = __ballot(nbad != 0);
+    if (nbad) {
+        atomicAdd(&g.bad[1], nbad);
+        if (lane == __ffsll((long long)any) - 1) {
+            const unsigned i = atomicAdd(&g.bad[0], 1u);
+            if (i < 16) {
+                g.bad[2 + 4 * i] = blockIdx.x;
+                g.bad[3 + 4 * i] = wave;
+                g.bad[4 + 4 * i] = first_it;
+                g.bad[5 + 4 * i] = first_got;
+            }
+        }
+    }
+}
+
+template <int GAP>
+void store_war(const char* what, Args g, int reps, unsigned iters) {
+    printf("%s\n", what);
+    unsigned bad_h[80];
+    for (int working : {4, 8, 12}) {
+        g.working = working;
+        CK(hipMemset(g.bad, 0, 4 * 80));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_store_war<GAP>), dim3(256), dim3(768), 0, 0, g, iters);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(bad_h, g.bad, 4 * 80, hipMemcpyDeviceToHost));
+        printf("    %d working waves per SIMD: %d launches x %u stores per lane: ", working / 4, reps, iters);
+        if (!bad_h[0]) printf("every store arrived as issued\n");
+        else printf("CORRUPTED: %u waves, %u stores; first: block %u wave %u iteration %u, first dword xor expected = 0x%08x\n", bad_h[0], bad_h[1],
+                    bad_h[2], bad_h[3], bad_h[4], bad_h[5]);
+    }
+}
+
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     // A fragments: small integers that differ by (k-step, co-tile, part, lane, element); B: by (k-step, part, lane, element)
@@ -240,6 +340,14 @@ int main(int argc, char** argv) {
     g.expect_out = (float*)deo;
     g.bad = (unsigned*)dbad;
     printf("mfma_chain_hazard: 256 workgroups x 12 waves, %d k-steps x %d co-tiles per launch, %d launches per line\n", KSTEPS, NQ, reps);
+    if (argc > 2) {   // ./mfma_chain_hazard <reps> <iters>: the store-data question only
+        const unsigned iters = (unsigned)atoi(argv[2]);
+        store_war<0>("ds_write_b128 v[d:d+3] ; v_add_u32 v[d] (the next instruction)", g, reps, iters);
+        store_war<1>("ds_write_b128 v[d:d+3] ; one VALU ; v_add_u32 v[d]", g, reps, iters);
+        store_war<2>("ds_write_b128 v[d:d+3] ; global_load ; one VALU ; v_add_u32 v[d] (as compiled in the 12-wave kernel)", g, reps, iters);
+        store_war<3>("ds_write_b128 v[d:d+3] ; s_nop 7 ; v_add_u32 v[d]", g, reps, iters);
+        return 0;
+    }
     variant<1, 3, 0, 0>("1 A set,  chains of 3, reads right behind the chain (the 12-wave kernel)", g, reps);
     variant<1, 3, 1, 0>("1 A set,  chains of 3, two s_nop 15 in front of the reads (experiment a)", g, reps);
     variant<2, 3, 0, 0>("2 A sets, chains of 3 (128 channels)", g, reps);
