@@ -95,6 +95,7 @@ struct WflLaunch {
     const int* pos_utt;      // [npos_alloc] utterance of a position, < 0: gap (outputs forced to 0)
     int npos_alloc;          // multiple of 32
     unsigned long long* trace;  // profiling only (PK_WF_ABLATE=16): s_memtime stamps of workgroup 5, [wave 8][round 2][24]
+    int seq;                    // profiling only (PK_WF_ABLATE=128): the launch's number within the inference, for the verifier's records
     int waves;                  // 0 = the launcher chooses 8- or 12-wave workgroups (64 channels), 8 / 12 = forced
     int active, tiles_per_wg;   // set by wfl_layer_launch: most waves that take a tile per round, tiles per workgroup
     int nl;                     // layers in this launch

@@ -174,7 +174,7 @@ struct pk_wf {
     std::vector<size_t> up_w;
     std::vector<float> up_b;
     // workspace
-    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip, ws_hamax, ws_camax, ws_trace, ws_bar, ws_desc;
+    pk_dbuf ws_tab, ws_mel, ws_z, ws_wav, ws_u[2], ws_cond, ws_cur, ws_nxt, ws_hist, ws_zbuf, ws_skip, ws_hamax, ws_camax, ws_trace, ws_bar, ws_desc, ws_replay;
     std::vector<WflLayer> desc_host;   // host image of ws_desc (kept until the next inference: the upload is asynchronous)
     const float* W(size_t off) const { return arena.as<float>() + off; }
 };
@@ -385,6 +385,34 @@ extern "C" int pk_wf_cond_length(pk_wf* h, int32_t t_mel, int32_t* cond_len, int
     return PK_OK;
 }
 
+
+// ---- profile build only (round 6, HISTORY 10): PK_WF_REPLAY="<launch>:<repeats>" replays ONE layer launch of the inference
+// -- a flow's first layer: it writes prm instead of accumulating, so the launch is a pure function of buffers it does not
+// modify -- `repeats` times with the kernel the options select, and compares every run with the 8-wave kernel's result of
+// the same launch (bit-identical by construction).  Per differing 32-position tile: the wave that owned it, the positions
+// whose (logs, b) sums differ, the positions / channel octets whose stored planes differ.
+__global__ void k_wf_replay_compare(const unsigned* __restrict__ out, const unsigned* __restrict__ ref, const float* __restrict__ prm,
+                                    const float* __restrict__ prm_ref, int ntiles, int C, unsigned* __restrict__ rec) {
+    // rec[tile * 4 + {0: differing plane words, 1: position mask (planes), 2: octet mask (planes), 3: position mask (prm)}]
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const int words = C * 32;   // C * 128 bytes per 32-position block
+    unsigned n = 0, pm = 0, om = 0;
+    for (int w = t; w < words; w += blockDim.x) {
+        if (out[(size_t)tile * words + w] != ref[(size_t)tile * words + w]) {
+            ++n;
+            pm |= 1u << ((w & 127) >> 2);
+            om |= 1u << (w >> 8);
+        }
+    }
+    unsigned qm = 0;
+    if (t < 64 && prm[(size_t)tile * 64 + t] != prm_ref[(size_t)tile * 64 + t]) qm = 1u << (t >> 1);
+    if (n) atomicAdd(&rec[tile * 4], n);
+    if (pm) atomicOr(&rec[tile * 4 + 1], pm);
+    if (om) atomicOr(&rec[tile * 4 + 2], om);
+    if (qm) atomicOr(&rec[tile * 4 + 3], qm);
+    (void)ntiles;
+}
+
 extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, int32_t B, const float* z,
                            float* wav, int32_t flags) {
     if (!h || !mel || !frames || !wav) PK_FAIL(PK_EINVAL, "pk_wf_infer: NULL argument");
@@ -558,11 +586,19 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     // profiling only (PK_WF_ABLATE=16): the layer kernel's s_memtime stamps, printed after the last launch
     unsigned long long* d_trace = nullptr;
     static const bool want_trace = pk_prof_env("PK_WF_ABLATE") && (atoi(pk_prof_env("PK_WF_ABLATE")) & ~64) == 16;
-    if (want_trace) {
-        PK_TRY(h->ws_trace.reserve(12 * 2 * 24 * sizeof(unsigned long long)));
-        PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, 12 * 2 * 24 * sizeof(unsigned long long), ctx->stream));
+    static const bool want_verify = pk_prof_env("PK_WF_ABLATE") && atoi(pk_prof_env("PK_WF_ABLATE")) == 128;   // the idle wave's slab verifier
+    constexpr size_t VERIFY_WORDS = 1 + 6 * 200;
+    static const bool verify_off = pk_prof_env("PK_WF_VERIFY_OFF") != nullptr;   // the verifier's instantiation without its traffic (A/B of the two)
+    if (want_trace || (want_verify && !verify_off)) {
+        const size_t bytes = std::max((size_t)12 * 2 * 24, VERIFY_WORDS) * sizeof(unsigned long long);
+        PK_TRY(h->ws_trace.reserve(bytes));
+        PK_HIP(hipMemsetAsync(h->ws_trace.p, 0, bytes, ctx->stream));
         d_trace = h->ws_trace.as<unsigned long long>();
     }
+    int launch_seq = 0;
+    static const char* replay_env = pk_prof_env("PK_WF_REPLAY");   // "<launch>:<repeats>" (see k_wf_replay_compare)
+    const int replay_seq = replay_env ? atoi(replay_env) : -1;
+    const int replay_reps = replay_env && strchr(replay_env, ':') ? atoi(strchr(replay_env, ':') + 1) : 0;
     // ---- the layer descriptors of the fused kernel, one per (flow, ring slot of the current row, layer): weights of the
     // (flow, layer), input ring of the layer, output = the next layer's ring at the current row's slot
     if (use_wfl) {
@@ -643,6 +679,7 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                 w.pos_utt = rowvalid;
                 w.npos_alloc = npos_alloc;
                 w.trace = d_trace;
+                w.seq = launch_seq;      // (flow, row, layer) = (n_flows - 1 - seq / ((G - 1) NL), 1 + seq / NL % (G - 1), seq % NL)
                 w.waves = h->layer_waves;
                 w.bar = h->ws_bar.as<unsigned>();
                 w.err = h->ws_bar.as<int>() + 1;
@@ -664,7 +701,66 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
                         w.step_b_logs = F.b_logs_f;
                         w.step_b_b = F.b_b_f;
                     }
+                    if (PK_PROFILE_BUILD && replay_reps > 0 && launch_seq == replay_seq && per == 1 && w.l0.first && w.l0.out) {
+                        const int ntl = npos_alloc / 32;
+                        const size_t out_bytes = (size_t)npos_alloc * C * 4, prm_bytes = (size_t)npos_alloc * 8;
+                        PK_TRY(h->ws_replay.reserve(out_bytes + prm_bytes + (size_t)ntl * 16));
+                        char* rb = h->ws_replay.as<char>();
+                        unsigned* rec = reinterpret_cast<unsigned*>(rb + out_bytes + prm_bytes);
+                        WflLaunch r8 = w;
+                        r8.waves = 8;
+                        PK_TRY(wfl_layer_launch(ctx, r8));
+                        PK_HIP(hipMemcpyAsync(rb, w.l0.out, out_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        PK_HIP(hipMemcpyAsync(rb + out_bytes, prm, prm_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                        std::vector<unsigned> rec_h((size_t)ntl * 4);
+                        const int tpw = std::max(1, (ntl + ctx->n_cu - 1) / ctx->n_cu);
+                        long events = 0, runs_bad = 0;
+                        std::vector<long> by_wave(16, 0), by_pos_prm(32, 0), by_oct(16, 0), by_npos(33, 0);
+                        for (int rep = 0; rep < replay_reps; ++rep) {
+                            PK_HIP(hipMemsetAsync(rec, 0, (size_t)ntl * 16, ctx->stream));
+                            PK_TRY(wfl_layer_launch(ctx, w));
+                            hipLaunchKernelGGL(k_wf_replay_compare, dim3(ntl), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned*>(w.l0.out),
+                                               reinterpret_cast<const unsigned*>(rb), prm, reinterpret_cast<const float*>(rb + out_bytes), ntl, C, rec);
+                            PK_HIP(hipMemcpyAsync(rec_h.data(), rec, (size_t)ntl * 16, hipMemcpyDeviceToHost, ctx->stream));
+                            PK_HIP(hipStreamSynchronize(ctx->stream));
+                            bool any = false;
+                            for (int t = 0; t < ntl; ++t) {
+                                const unsigned* e = &rec_h[(size_t)t * 4];
+                                if (!e[0] && !e[3]) continue;
+                                any = true;
+                                ++events;
+                                ++by_wave[(t % tpw) & 15];
+                                ++by_npos[__builtin_popcount(e[3])];
+                                for (int b = 0; b < 32; ++b) by_pos_prm[b] += (e[3] >> b) & 1;
+                                for (int b = 0; b < 16; ++b) by_oct[b] += (e[2] >> b) & 1;
+                                if (events <= 24)
+                                    fprintf(stderr, "wf_replay: run %d tile %d = workgroup %d wave %d: %u plane words differ, positions %08x octets %04x; prm positions %08x\n",
+                                            rep, t, t / tpw, t % tpw, e[0], e[1], e[2], e[3]);
+                                if (events <= 6 && e[3]) {   // the (logs, b) sums of the tile: got | expected, per position
+                                    float got[64], want[64];
+                                    PK_HIP(hipMemcpy(got, prm + (size_t)t * 64, sizeof(got), hipMemcpyDeviceToHost));
+                                    PK_HIP(hipMemcpy(want, rb + out_bytes + (size_t)t * 256, sizeof(want), hipMemcpyDeviceToHost));
+                                    for (int q = 0; q < 32; ++q)
+                                        fprintf(stderr, "wf_replay:   pos %2d logs %.9g (want %.9g, diff %.4g)  b %.9g (want %.9g, diff %.4g)\n", q, got[2 * q], want[2 * q],
+                                                got[2 * q] - want[2 * q], got[2 * q + 1], want[2 * q + 1], got[2 * q + 1] - want[2 * q + 1]);
+                                }
+                            }
+                            runs_bad += any;
+                        }
+                        fprintf(stderr, "wf_replay: launch %d (ntap %d, %d tiles, %d per workgroup): %ld of %d runs differ from the 8-wave kernel, %ld tiles in all\n",
+                                launch_seq, w.ntap, ntl, tpw, runs_bad, replay_reps, events);
+                        fprintf(stderr, "wf_replay: tiles by wave of the workgroup:");
+                        for (int i = 0; i < 12; ++i) fprintf(stderr, " %ld", by_wave[i]);
+                        fprintf(stderr, "\nwf_replay: tiles by number of positions whose (logs, b) differ (0 .. 32):");
+                        for (int i = 0; i <= 32; ++i) fprintf(stderr, " %ld", by_npos[i]);
+                        fprintf(stderr, "\nwf_replay: by position:");
+                        for (int i = 0; i < 32; ++i) fprintf(stderr, " %ld", by_pos_prm[i]);
+                        fprintf(stderr, "\nwf_replay: by channel octet of the stored planes:");
+                        for (int i = 0; i < C / 8; ++i) fprintf(stderr, " %ld", by_oct[i]);
+                        fprintf(stderr, "\n");
+                    }
                     PK_TRY(wfl_layer_launch(ctx, w));
+                    w.seq = ++launch_seq;
                 }
                 if (!fuse)
                     PK_TRY(wfl_step_launch(ctx, C, prm, F.b_logs_f, F.b_b_f, cur + (long)perm[i] * pstride,
@@ -757,7 +853,17 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
         }
         std::swap(cur, nxt);
     }
-    if (d_trace) {
+    if (d_trace && want_verify) {
+        std::vector<unsigned long long> tr(VERIFY_WORDS);
+        PK_HIP(hipMemcpyAsync(tr.data(), d_trace, VERIFY_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "wf_verify: %llu LDS weight chunks differed from memory in %d layer launches\n", tr[0], launch_seq);
+        for (unsigned long long k = 0; k < std::min<unsigned long long>(tr[0], 200); ++k) {
+            const unsigned long long* r = tr.data() + 1 + 6 * k;
+            fprintf(stderr, "wf_verify: launch %llu workgroup %llu slab %llu chunk %llu (idle wave %llu, %llu working waves): got %016llx %016llx want %016llx %016llx\n",
+                    r[0] >> 32, (r[0] >> 16) & 0xffff, (r[0] >> 12) & 15, r[0] & 0xfff, r[1] >> 32, r[1] & 0xffffffffu, r[2], r[3], r[4], r[5]);
+        }
+    } else if (d_trace) {
         unsigned long long tr[12 * 2 * 24];
         PK_HIP(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, ctx->stream));
         PK_HIP(hipStreamSynchronize(ctx->stream));
@@ -796,7 +902,7 @@ extern "C" void pk_wf_destroy(pk_wf* h) {
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->arena, &h->arena16, &h->ws_tab, &h->ws_mel, &h->ws_z, &h->ws_wav, &h->ws_u[0], &h->ws_u[1],
                        &h->ws_cond, &h->ws_cur, &h->ws_nxt, &h->ws_hist, &h->ws_zbuf, &h->ws_skip,
-                       &h->ws_hamax, &h->ws_camax, &h->ws_trace, &h->ws_bar, &h->ws_desc};
+                       &h->ws_hamax, &h->ws_camax, &h->ws_trace, &h->ws_bar, &h->ws_desc, &h->ws_replay};
     for (auto* b : bufs) b->release();
     delete h;
 }

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
     typedef Shape<CT, W, F16> S;
     constexpr int C = S::C, NQ = S::NQ, SLAB = S::SLAB, THREADS = S::THREADS;
     constexpr int RING = (W != 8 && F16) ? 9 : S::RING;   // (fp16 operands: a ring slot is one vector, nine fit the 168 registers)
-    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16 || ABL == 64 || ABL == 80)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace, the old prologue)");
+    static_assert(W == 8 || ((W == 12 || W == 6) && CT == 2 && (ABL == 0 || ABL == 16 || ABL == 64 || ABL == 80 || ABL == 128)), "12- / 6-wave workgroups: the 64-channel model (ablations: the trace, the old prologue, the slab verifier)");
     constexpr int SLAB_CH = S::SLAB_CH;
     // LEAN: the kernels that live at their register limit (three waves per SIMD: 168; 128 channels: 128 of the 256 are
     // accumulators) derive round-, slab- and epilogue-only coordinates from opaque zeros so that nothing thread-invariant is
@@ -931,6 +931,33 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     for (int c = 0; c < CL; ++c) wbuf[PRO2 && c >= CL / 2 ? 2 : 1][(PRO2 ? c % (CL / 2) : c) * ((W - NA) * 64) + (tid - NA * 64)] = wpro[c];
                 }
             }
+            // ABL & 128 (round 6, results stay right): an IDLE wave checks what the working waves are reading.  During slab g every
+            // wave of the workgroup is between the barriers that end slab g - 1 and slab g: buffer g % 3 holds slab g, complete and
+            // stable (stored two slabs ago, or by the prologue) -- the idle wave compares all of it with the weights in memory and
+            // records every 16-byte chunk that differs: (launch, workgroup, slab, chunk) -> which thread stored it, in which half, and
+            // what was there instead.  The working waves' instruction stream is untouched (this is the idle copy of the round).
+            auto verify_slab = [&](int g) {
+                if constexpr ((ABL & 128) != 0) {
+                    if (a.trace == nullptr) return;
+                    const int n = g < nslab ? S::CPT1 * THREADS : S::SLAB2 * S::KCH2;
+                    for (int i = lane; i < n; i += 64) {
+                        const u32x4 got = *reinterpret_cast<const u32x4*>(&wbuf[g % 3][i]);
+                        const u32x4 want = *reinterpret_cast<const u32x4*>(w_srcf(g, i, 0));
+                        if (got[0] != want[0] || got[1] != want[1] || got[2] != want[2] || got[3] != want[3]) {
+                            const unsigned long long k = atomicAdd(a.trace, 1ull);
+                            if (k < 200) {
+                                unsigned long long* r = a.trace + 1 + 6 * k;
+                                r[0] = ((unsigned long long)(unsigned)a.seq << 32) | ((unsigned long long)blockIdx.x << 16) | ((unsigned long long)g << 12) | (unsigned long long)i;
+                                r[1] = ((unsigned long long)wave << 32) | (unsigned)nact;
+                                r[2] = ((unsigned long long)got[1] << 32) | got[0];
+                                r[3] = ((unsigned long long)got[3] << 32) | got[2];
+                                r[4] = ((unsigned long long)want[1] << 32) | want[0];
+                                r[5] = ((unsigned long long)want[3] << 32) | want[2];
+                            }
+                        }
+                    }
+                }
+            };
 #pragma unroll
             for (int g = 0; g < (S::NS2 >= 2 ? G : nslab); ++g) {
                 int tz = 0;
@@ -939,8 +966,10 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     w_load(g + 2, tz);
                     w_store(g + 2);
                 }
+                verify_slab(g);
                 __syncthreads();
             }
+            if (S::NS2 < 2) verify_slab(nslab);   // the out-projection slab: read by the working waves until the round's last barrier
         }
         stamp(23);
         if (S::NS2 < 2) __syncthreads();   // one slab for both passes: consumed before the next round overwrites its buffer
@@ -1169,7 +1198,8 @@ static int wfl_ablation(Go& go, bool shape_ok, bool trace, bool w12, bool f16, b
                          return w12 ? (f16 ? go(k_wf_layer_p<2, 3, 64, true, 12>) : go(k_wf_layer_p<2, 3, 64, false, 12>))
                                     : (f16 ? go(k_wf_layer_p<2, 3, 64, true>) : go(k_wf_layer_p<2, 3, 64>));
                 case 32: if (plain8) return go(k_wf_layer_p<2, 3, 32>); break;   // A fragments one co-tile ahead (A/B of the LDS prefetch depth)
-                default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16, 32, 64 or 80");
+                case 128: if (w12 && !f16 && !c128) return go(k_wf_layer_p<2, 3, 128, false, 12>); break;   // the idle wave verifies the LDS slabs (round 6)
+                default: PK_FAIL(PK_EINVAL, "PK_WF_ABLATE: 1, 4, 8, 9, 13, 16, 32, 64, 80 or 128");
             }
         }
     }

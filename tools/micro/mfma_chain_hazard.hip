@@ -313,6 +313,236 @@ void store_war(const char* what, Args g, int reps, unsigned iters) {
     }
 }
 
+
+// ---- third question (round 6): do LDS operations of DIFFERENT kinds complete in order, as `s_waitcnt lgkmcnt(N > 0)` assumes?
+// The layer kernel mixes them: table reads at a wave-uniform address (ds_read_b64 / ds_read_b32: tp_off, tp_shift, tp_am), the
+// weight stores (ds_write_b128, one address per lane) and the A-fragment reads (ds_read_b128), and hipcc waits with partial
+// counts (k12.s: `ds_read_b64 ; ds_read_b32 ; ds_write_b128 ; s_waitcnt lgkmcnt(2) ; v_readfirstlane` of the b64's result).
+// Every wave runs the chains (LDS and matrix load) and per k-step the kernel's sequence on poisoned destination registers;
+// whatever is consumed right behind each partial wait is compared with the table's contents.
+//   MIX 0: b64(uniform) b32(uniform) write_b128 | lgkmcnt(2) use b64 | lgkmcnt(1) use b32      (the kernel's sequence)
+//   MIX 1: read_b128(per lane) b32(uniform)     | lgkmcnt(1) use b128                           (a heavy read overtaken by a light one?)
+//   MIX 2: read_b128(per lane) bpermute         | lgkmcnt(1) use b128
+//   MIX 3: write_b128 read_b128(same address)   | lgkmcnt(0) use                                (read after write, one wave)
+template <int MIX>
+__global__ __launch_bounds__(768, 3) void k_lds_order(Args g, unsigned iters) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[LDS_KS * KS_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) u32x4 wreg[12 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned table[256];
+    for (int i = threadIdx.x; i < LDS_KS * KS_BYTES / 16; i += blockDim.x) lds[i] = g.a_src[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) table[i] = 0x51f00000u + i * 2654435761u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= g.working) return;
+    f32x16 acc[NQ];
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    u32x4 ah, al, bh, bl;
+    const unsigned lbase = (unsigned)(size_t)(&lds[0]) + lane * 16;
+    const unsigned wadr = (unsigned)(size_t)(&wreg[0]) + threadIdx.x * 16;
+    const unsigned tbase = (unsigned)(size_t)(&table[0]);
+    bh = g.b_tab[lane];
+    bl = g.b_tab[64 + lane];
+    unsigned nbad = 0, first_it = 0, first_got = 0;
+    asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n s_waitcnt lgkmcnt(0)" : "=v"(ah), "=v"(al) : "v"(lbase));
+#pragma unroll 1
+    for (unsigned it = 0; it < iters; ++it) {
+        const unsigned ti = (it * 7u + wave) & 127u;
+        const unsigned ta = tbase + ti * 8u, tb = tbase + 1024u - 4u - ti * 4u;     // uniform addresses: a b64 and a b32 entry
+        const unsigned aoff = lbase + (unsigned)(((it * 5u) % LDS_KS) * KS_BYTES + (it & 3u) * 2048);   // a per-lane A fragment
+        unsigned o0 = 0, o1 = 0, o2 = 0, o3 = 0, bad = 0;
+        const unsigned pat = it * 2654435761u + threadIdx.x * 40503u;
+        if (MIX == 0) {
+            asm volatile("v_mov_b32 v100, 0xdead0001\n v_mov_b32 v101, 0xdead0002\n v_mov_b32 v102, 0xdead0003\n"
+                         "v_mov_b32 v104, %6\n v_mov_b32 v105, %6\n v_mov_b32 v106, %6\n v_mov_b32 v107, %6\n s_nop 1\n"
+                         "ds_read_b64 v[100:101], %3\n ds_read_b32 v102, %4\n ds_write_b128 %5, v[104:107]\n"
+                         "s_waitcnt lgkmcnt(2)\n v_mov_b32 %0, v100\n v_mov_b32 %1, v101\n s_waitcnt lgkmcnt(1)\n v_mov_b32 %2, v102\n s_waitcnt lgkmcnt(0)\n"
+                         : "=v"(o0), "=v"(o1), "=v"(o2) : "v"(ta), "v"(tb), "v"(wadr), "v"(pat)
+                         : "memory", "v100", "v101", "v102", "v104", "v105", "v106", "v107");
+            bad = (o0 != table[2 * ti]) | (o1 != table[2 * ti + 1]) | (o2 != table[255 - ti]);
+            first_got = bad && !nbad ? o0 : first_got;
+        } else if (MIX == 1 || MIX == 2) {
+#define SEQ(second) "v_mov_b32 v100, 0xdead0001\n v_mov_b32 v101, 0xdead0002\n v_mov_b32 v102, 0xdead0003\n v_mov_b32 v103, 0xdead0004\n s_nop 1\n" \
+                    "ds_read_b128 v[100:103], %4\n" second                                                                                                    \
+                    "s_waitcnt lgkmcnt(1)\n v_mov_b32 %0, v100\n v_mov_b32 %1, v101\n v_mov_b32 %2, v102\n v_mov_b32 %3, v103\n s_waitcnt lgkmcnt(0)\n"
+            if (MIX == 1)
+                asm volatile(SEQ("ds_read_b32 v104, %5\n") : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3) : "v"(aoff), "v"(tb)
+                             : "memory", "v100", "v101", "v102", "v103", "v104");
+            else
+                asm volatile(SEQ("ds_bpermute_b32 v104, %5, %5\n") : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3) : "v"(aoff), "v"(tb)
+                             : "memory", "v100", "v101", "v102", "v103", "v104");
+#undef SEQ
+        }
+        if (MIX == 1 || MIX == 2) {
+            const u32x4 want = lds[(aoff - (unsigned)(size_t)(&lds[0])) / 16];
+            bad = (o0 != want[0]) | (o1 != want[1]) | (o2 != want[2]) | (o3 != want[3]);
+            first_got = bad && !nbad ? o0 : first_got;
+        }
+        if (MIX == 3) {
+            asm volatile("v_mov_b32 v104, %5\n v_xor_b32 v105, 0x11111111, %5\n v_xor_b32 v106, 0x22222222, %5\n v_xor_b32 v107, 0x33333333, %5\n"
+                         "v_mov_b32 v100, 0xdead0001\n v_mov_b32 v101, 0xdead0002\n v_mov_b32 v102, 0xdead0003\n v_mov_b32 v103, 0xdead0004\n s_nop 1\n"
+                         "ds_write_b128 %4, v[104:107]\n ds_read_b128 v[100:103], %4\n s_waitcnt lgkmcnt(0)\n"
+                         "v_mov_b32 %0, v100\n v_mov_b32 %1, v101\n v_mov_b32 %2, v102\n v_mov_b32 %3, v103\n"
+                         : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3) : "v"(wadr), "v"(pat)
+                         : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+            bad = (o0 != pat) | (o1 != (pat ^ 0x11111111u)) | (o2 != (pat ^ 0x22222222u)) | (o3 != (pat ^ 0x33333333u));
+            first_got = bad && !nbad ? o0 ^ pat : first_got;
+        }
+        if (bad) {
+            if (!nbad) first_it = it;
+            ++nbad;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const unsigned nxt = lbase + (unsigned)(((it + (q == NQ - 1)) % LDS_KS) * KS_BYTES + ((q + 1) % NQ) * 2048);
+            asm volatile(MFMA("%0", "%1", "%3") MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
+                         "ds_read_b128 %1, %5\n ds_read_b128 %2, %5 offset:1024\n s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(acc[q]), "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl) : "v"(nxt) : "memory");
+        }
+    }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float sink = 0.f;
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r) sink += acc[q][r];
+    if (sink == 1.2345e30f) nbad += 1u << 30;
+    const unsigned long long any = __ballot(nbad != 0);
+    if (nbad) {
+        atomicAdd(&g.bad[1], nbad);
+        if (lane == __ffsll((long long)any) - 1) {
+            const unsigned i = atomicAdd(&g.bad[0], 1u);
+            if (i < 16) {
+                g.bad[2 + 4 * i] = blockIdx.x;
+                g.bad[3 + 4 * i] = wave;
+                g.bad[4 + 4 * i] = first_it;
+                g.bad[5 + 4 * i] = first_got;
+            }
+        }
+    }
+}
+
+template <int MIX>
+void lds_order(const char* what, Args g, int reps, unsigned iters) {
+    printf("%s\n", what);
+    unsigned bad_h[80];
+    for (int working : {4, 8, 12}) {
+        g.working = working;
+        CK(hipMemset(g.bad, 0, 4 * 80));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_lds_order<MIX>), dim3(256), dim3(768), 0, 0, g, iters);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(bad_h, g.bad, 4 * 80, hipMemcpyDeviceToHost));
+        printf("    %d working waves per SIMD: %d launches x %u sequences per wave: ", working / 4, reps, iters);
+        if (!bad_h[0]) printf("every value consumed behind a partial wait was the loaded one\n");
+        else printf("STALE: %u waves, %u sequences; first: block %u wave %u iteration %u, got 0x%08x\n", bad_h[0], bad_h[1], bad_h[2], bad_h[3], bad_h[4], bad_h[5]);
+    }
+}
+
+
+// ---- fourth question (round 6) -- the one the replay of the failing launch asked (HISTORY 10): in EVERY wrong tile the stored planes
+// were bit-identical to the 8-wave kernel's and only the (logs, b) sums of positions 16 - 31 differed: what lanes 16 - 31 receive
+// from lanes 48 - 63 through the half-wave exchange `pl += ds_bpermute(lane ^ 32, pl)`.  The compiled sequence is
+//     v_pk_fma_f32 v[2:3], ...            (the last step of the folded skip sums, a packed fp32 FMA)
+//     ds_bpermute_b32 v4, v28, v2         (the very next instruction reads v2)
+//     ds_bpermute_b32 v5, v28, v3
+// Lanes 48 - 63 are the last quarter of a wave's pass through the vector ALU.  Does the exchange read the packed FMA's result
+// before its last quarter is written -- with other waves' matrix instructions in the SIMD?
+//   PK 1: v_pk_fma_f32 -> ds_bpermute (as compiled)     PK 0: two v_fma_f32 -> ds_bpermute     GAP: s_nop states in between (0 = none)
+template <int PK, int GAP>
+__global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
+    __shared__ __attribute__((aligned(16))) u32x4 lds[LDS_KS * KS_BYTES / 16];
+    for (int i = threadIdx.x; i < LDS_KS * KS_BYTES / 16; i += blockDim.x) lds[i] = g.a_src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= g.working) return;
+    f32x16 acc[NQ];
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    u32x4 ah, al, bh, bl;
+    const unsigned lbase = (unsigned)(size_t)(&lds[0]) + lane * 16;
+    bh = g.b_tab[lane];
+    bl = g.b_tab[64 + lane];
+    const unsigned paddr = (unsigned)((lane ^ 32) << 2);
+    unsigned nbad = 0, first_it = 0, first_got = 0, lanes_bad = 0;
+    asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n s_waitcnt lgkmcnt(0)" : "=v"(ah), "=v"(al) : "v"(lbase));
+#pragma unroll 1
+    for (unsigned it = 0; it < iters; ++it) {
+        // own value x = 3 a + c (exact small integers), the partner's the same formula at lane ^ 32
+        const float a0 = (float)(((lane >> 2) + it) & 31), a1 = (float)(((lane >> 1) + 3 * it) & 31), c0 = (float)(it & 7), c1 = (float)((it >> 3) & 7);
+        const int pl = lane ^ 32;
+        const float w0 = 3.f * (float)(((pl >> 2) + it) & 31) + c0, w1 = 5.f * (float)(((pl >> 1) + 3 * it) & 31) + c1;
+        float o0, o1;
+#define NOPS(n) (n == 0 ? "" : (n == 1 ? "s_nop 0\n" : (n == 2 ? "s_nop 1\n" : "s_nop 3\n")))
+        if (PK) {
+            if (GAP == 0)
+                asm volatile("v_mov_b32 v100, %4\n v_mov_b32 v101, %5\n v_mov_b32 v102, 3.0\n v_mov_b32 v103, 5.0\n v_mov_b32 v106, %2\n v_mov_b32 v107, %3\n s_nop 1\n"
+                             "v_pk_fma_f32 v[100:101], v[106:107], v[102:103], v[100:101]\n"
+                             "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n"
+                             : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr)
+                             : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+            else
+                asm volatile("v_mov_b32 v100, %4\n v_mov_b32 v101, %5\n v_mov_b32 v102, 3.0\n v_mov_b32 v103, 5.0\n v_mov_b32 v106, %2\n v_mov_b32 v107, %3\n s_nop 1\n"
+                             "v_pk_fma_f32 v[100:101], v[106:107], v[102:103], v[100:101]\n s_nop %7\n"
+                             "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n"
+                             : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr), "n"(GAP - 1)
+                             : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+        } else {
+            asm volatile("v_mov_b32 v100, %4\n v_mov_b32 v101, %5\n v_mov_b32 v102, 3.0\n v_mov_b32 v103, 5.0\n s_nop 1\n"
+                         "v_fma_f32 v100, %2, v102, v100\n v_fma_f32 v101, %3, v103, v101\n"
+                         "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n"
+                         : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr)
+                         : "memory", "v100", "v101", "v102", "v103", "v104", "v105");
+        }
+#undef NOPS
+        const bool bad = o0 != w0 || o1 != w1;
+        const unsigned long long bm = __ballot(bad);
+        if (bm) {
+            if (!nbad) first_it = it, first_got = (unsigned)(bm >> 32) ^ 0u, lanes_bad = (unsigned)bm;
+            ++nbad;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const unsigned nxt = lbase + (unsigned)(((it + (q == NQ - 1)) % LDS_KS) * KS_BYTES + ((q + 1) % NQ) * 2048);
+            asm volatile(MFMA("%0", "%1", "%3") MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
+                         "ds_read_b128 %1, %5\n ds_read_b128 %2, %5 offset:1024\n s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(acc[q]), "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl) : "v"(nxt) : "memory");
+        }
+    }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    float sink = 0.f;
+    for (int q = 0; q < NQ; ++q)
+        for (int r = 0; r < 16; ++r) sink += acc[q][r];
+    if (sink == 1.2345e30f) nbad += 1u << 30;
+    if (nbad && lane == 0) {
+        atomicAdd(&g.bad[1], nbad);
+        const unsigned i = atomicAdd(&g.bad[0], 1u);
+        if (i < 16) {
+            g.bad[2 + 4 * i] = blockIdx.x | (wave << 16);
+            g.bad[3 + 4 * i] = first_it;
+            g.bad[4 + 4 * i] = lanes_bad;      // receiving lanes 0 - 31 that got a wrong value
+            g.bad[5 + 4 * i] = first_got;      // ... and 32 - 63
+        }
+    }
+}
+
+template <int PK, int GAP>
+void bperm(const char* what, Args g, int reps, unsigned iters) {
+    printf("%s\n", what);
+    unsigned bad_h[80];
+    for (int working : {4, 8, 12}) {
+        g.working = working;
+        CK(hipMemset(g.bad, 0, 4 * 80));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_bperm<PK, GAP>), dim3(256), dim3(768), 0, 0, g, iters);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(bad_h, g.bad, 4 * 80, hipMemcpyDeviceToHost));
+        printf("    %d working waves per SIMD: %d launches x %u exchanges per wave: ", working / 4, reps, iters);
+        if (!bad_h[0]) printf("every lane received its partner's new value\n");
+        else {
+            printf("WRONG in %u waves, %u exchanges; receiving lanes of the first events:", bad_h[0], bad_h[1]);
+            for (unsigned i = 0; i < bad_h[0] && i < 6; ++i) printf(" [wave %u: %08x:%08x]", bad_h[2 + 4 * i] >> 16, bad_h[5 + 4 * i], bad_h[4 + 4 * i]);
+            printf("\n");
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     // A fragments: small integers that differ by (k-step, co-tile, part, lane, element); B: by (k-step, part, lane, element)
@@ -340,12 +570,26 @@ int main(int argc, char** argv) {
     g.expect_out = (float*)deo;
     g.bad = (unsigned*)dbad;
     printf("mfma_chain_hazard: 256 workgroups x 12 waves, %d k-steps x %d co-tiles per launch, %d launches per line\n", KSTEPS, NQ, reps);
-    if (argc > 2) {   // ./mfma_chain_hazard <reps> <iters>: the store-data question only
+    if (argc > 1 && argv[1][0] == 'b') {   // ./mfma_chain_hazard b <reps> <iters>: the packed-FMA -> ds_bpermute question only
+        const int r = argc > 2 ? atoi(argv[2]) : 200;
+        const unsigned iters = argc > 3 ? (unsigned)atoi(argv[3]) : 4000u;
+        bperm<1, 0>("v_pk_fma_f32 v[d:d+1] ; ds_bpermute_b32 of v[d] (the next instruction: as compiled in every layer kernel)", g, r, iters);
+        bperm<0, 0>("v_fma_f32 v[d] ; v_fma_f32 v[d+1] ; ds_bpermute_b32 of v[d], of v[d+1]", g, r, iters);
+        bperm<1, 1>("v_pk_fma_f32 ; s_nop 0 ; ds_bpermute_b32", g, r, iters);
+        bperm<1, 2>("v_pk_fma_f32 ; s_nop 1 ; ds_bpermute_b32", g, r, iters);
+        bperm<1, 4>("v_pk_fma_f32 ; s_nop 3 ; ds_bpermute_b32", g, r, iters);
+        return 0;
+    }
+    if (argc > 2) {   // ./mfma_chain_hazard <reps> <iters>: the store-data and LDS-order questions only
         const unsigned iters = (unsigned)atoi(argv[2]);
         store_war<0>("ds_write_b128 v[d:d+3] ; v_add_u32 v[d] (the next instruction)", g, reps, iters);
         store_war<1>("ds_write_b128 v[d:d+3] ; one VALU ; v_add_u32 v[d]", g, reps, iters);
         store_war<2>("ds_write_b128 v[d:d+3] ; global_load ; one VALU ; v_add_u32 v[d] (as compiled in the 12-wave kernel)", g, reps, iters);
         store_war<3>("ds_write_b128 v[d:d+3] ; s_nop 7 ; v_add_u32 v[d]", g, reps, iters);
+        lds_order<0>("ds_read_b64 (uniform) ; ds_read_b32 (uniform) ; ds_write_b128 ; lgkmcnt(2) use b64 ; lgkmcnt(1) use b32", g, reps, iters);
+        lds_order<1>("ds_read_b128 (per lane) ; ds_read_b32 (uniform) ; lgkmcnt(1) use b128", g, reps, iters);
+        lds_order<2>("ds_read_b128 (per lane) ; ds_bpermute_b32 ; lgkmcnt(1) use b128", g, reps, iters);
+        lds_order<3>("ds_write_b128 ; ds_read_b128 of the same address ; lgkmcnt(0) use", g, reps, iters);
         return 0;
     }
     variant<1, 3, 0, 0>("1 A set,  chains of 3, reads right behind the chain (the 12-wave kernel)", g, reps);
