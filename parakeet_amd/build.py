@@ -49,7 +49,24 @@ def source_hash():
             h.update(f.read())
         h.update(b"\0")
     h.update(repr(sorted(FILE_FLAGS.items())).encode())   # a flag change is a different library too
-    return h.hexdigest()
+    h.update(compiler_id().encode())                       # ... and so is another compiler (the WaveFlow defect of round 5
+    return h.hexdigest()                                   # came and went with instruction placement; a new hipcc must rebuild and re-run the gate tests)
+
+
+_COMPILER_ID = None
+
+
+def compiler_id():
+    """First line of `hipcc --version` that names the HIP / clang version (cached); "unknown" without a compiler."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        try:
+            out = subprocess.run([hipcc(), "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60).stdout.decode()
+            keep = [ln.strip() for ln in out.splitlines() if ln.startswith(("HIP version", "AMD clang version", "clang version"))]
+            _COMPILER_ID = " | ".join(keep) or "unknown"
+        except Exception:
+            _COMPILER_ID = "unknown"
+    return _COMPILER_ID
 
 
 def file_hash(name):

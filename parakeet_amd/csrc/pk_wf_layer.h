@@ -32,11 +32,10 @@ constexpr int WFL_BLK = 32;        // positions per block
 constexpr int WFL_KS_COND = WFL_MP / 16;   // 6 k-steps of the condition block
 
 static inline bool wfl_supports(int C) { return C == 64 || C == 128; }
-// Three waves per SIMD (12- / 6-wave workgroups) with the DEFAULT math, two working waves per SIMD at 128 channels, and the
-// one-launch-per-row variant are measurement configurations: the product never runs them, and the profile build runs them
-// only when asked with PK_WF_ALLOW_3WAVE=1 -- its DEFAULT kernel choice is the product's (measurements through
-// libpk_synth_prof.so used to time kernels the product never runs).
-bool wfl_three_waves_allowed();
+// The one-launch-per-row variant (option "persistent": slower than eight launches, never validated beyond small sizes) is a
+// measurement configuration: the product refuses it, the profile build runs it only under PK_WF_MEASURE=1 -- the profile
+// build's DEFAULT kernel choice is the product's.
+bool wfl_measurement_configs_allowed();
 // channel of element e of lane half hh in k-step kq (see above)
 __host__ __device__ static inline int wfl_chan(int kq, int hh, int e) { return 16 * kq + 8 * (e >> 2) + 4 * hh + (e & 3); }
 // byte offset of (position p, channel ch, plane) from the buffer base (position 0) in a planes buffer of CH channels

@@ -249,15 +249,12 @@ extern "C" int pk_wf_set_option(pk_wf* h, const char* key, int64_t value) {
     if (strcmp(key, "layer_waves") == 0) {
         if (value != 0 && value != 6 && value != 8 && value != 12) PK_FAIL(PK_EINVAL, "pk_wf_set_option: layer_waves %lld (0, 6, 8, 12)", (long long)value);
         if ((value == 12 || value == 6) && h->cfg.channels != 64) PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_option: 12- / 6-wave workgroups are built for the 64-channel model");
-        // (refused HERE, not by the first launch in the middle of an inference; 12 waves with the default math is a
-        // combination of two settings and is checked at the top of pk_wf_infer, before anything is launched)
-        if (value == 6 && !wfl_three_waves_allowed()) PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_option: 6-wave workgroups are not in the product (HISTORY.md 9.9)");
         h->layer_waves = (int)value;
     } else if (strcmp(key, "persistent") == 0) {
         // Round 5: the residual stack of a row as one cooperative launch was never the default (slower than eight launches); at
         // sizes beyond the tests' it is not deterministic either (tools/wf_race_bisect.py: thousands of samples off by 1e-3 per
         // call).  The product refuses it; the profile build keeps it for the barrier measurements.
-        if (value != 0 && !wfl_three_waves_allowed()) PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_option: 'persistent' is not in the product (not deterministic beyond small sizes)");
+        if (value != 0 && !wfl_measurement_configs_allowed()) PK_FAIL(PK_EUNSUPPORTED, "pk_wf_set_option: 'persistent' is not in the product (not deterministic beyond small sizes)");
         h->persistent = value != 0;
     }
     else if (strcmp(key, "fuse_step") == 0) h->fuse_step = value != 0;
@@ -418,11 +415,6 @@ extern "C" int pk_wf_infer(pk_wf* h, const float* mel, const int32_t* frames, in
     if (!h || !mel || !frames || !wav) PK_FAIL(PK_EINVAL, "pk_wf_infer: NULL argument");
     if (!h->finalized) PK_FAIL(PK_ESTATE, "pk_wf_infer: call pk_wf_finalize first");
     if (B <= 0) PK_FAIL(PK_EINVAL, "pk_wf_infer: batch size must be positive");
-    // the one combination of two settings the layer launcher refuses (12-wave workgroups x a math other than fp16 operands):
-    // found here, before a single kernel has been launched
-    if (h->layer_waves == 12 && h->math != PK_GEMM_MATH_F16 && !wfl_three_waves_allowed())
-        PK_FAIL(PK_EUNSUPPORTED, "pk_wf_infer: option layer_waves = 12 needs the fp16-operand math (pk_wf_set_math PK_GEMM_MATH_F16): "
-                                 "three waves per SIMD are not used with the default math (HISTORY.md 9.9)");
     pk_ctx* ctx = h->ctx;
     PK_DEVICE(ctx->device);
     const pk_wf_cfg& c = h->cfg;

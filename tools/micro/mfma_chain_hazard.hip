@@ -468,7 +468,7 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
         // own value x = 3 a + c (exact small integers), the partner's the same formula at lane ^ 32
         const float a0 = (float)(((lane >> 2) + it) & 31), a1 = (float)(((lane >> 1) + 3 * it) & 31), c0 = (float)(it & 7), c1 = (float)((it >> 3) & 7);
         const int pl = lane ^ 32;
-        const float w0 = 3.f * (float)(((pl >> 2) + it) & 31) + c0, w1 = 5.f * (float)(((pl >> 1) + 3 * it) & 31) + c1;
+        const float w0 = 3.f * (float)(((pl >> 2) + it) & 31) + c0, w1 = 5.f * (float)(((pl >> 1) + 3 * it) & 31) + c1;   // (PK 2 / 3: 4 x 0.75 = 3, 4 x 1.25 = 5)
         float o0, o1;
 #define NOPS(n) (n == 0 ? "" : (n == 1 ? "s_nop 0\n" : (n == 2 ? "s_nop 1\n" : "s_nop 3\n")))
         if (PK) {
@@ -484,6 +484,22 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
                              "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n"
                              : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr), "n"(GAP - 1)
                              : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+        } else if (PK == 2 || PK == 3) {
+            // as compiled: the LAST of a chain of dependent packed FMAs into the same register pair, then the exchange (PK 3: with
+            // one wait state in between); the matrix instructions of this variant come without LDS reads (below): the other waves
+            // of the SIMD keep the matrix pipe busy while this one exchanges
+#define CHAIN "v_mov_b32 v100, %4\n v_mov_b32 v101, %5\n v_mov_b32 v102, 0.75\n v_mov_b32 v103, 1.25\n v_mov_b32 v106, %2\n v_mov_b32 v107, %3\n s_nop 1\n" \
+              "v_pk_fma_f32 v[100:101], v[106:107], v[102:103], v[100:101]\n v_pk_fma_f32 v[100:101], v[106:107], v[102:103], v[100:101]\n"                    \
+              "v_pk_fma_f32 v[100:101], v[106:107], v[102:103], v[100:101]\n v_pk_fma_f32 v[100:101], v[106:107], v[102:103], v[100:101]\n"
+#define XCHG "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n"
+            if (PK == 2)
+                asm volatile(CHAIN XCHG : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr)
+                             : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+            else
+                asm volatile(CHAIN "s_nop 0\n" XCHG : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr)
+                             : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+#undef CHAIN
+#undef XCHG
         } else {
             asm volatile("v_mov_b32 v100, %4\n v_mov_b32 v101, %5\n v_mov_b32 v102, 3.0\n v_mov_b32 v103, 5.0\n s_nop 1\n"
                          "v_fma_f32 v100, %2, v102, v100\n v_fma_f32 v101, %3, v103, v101\n"
@@ -493,17 +509,26 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
         }
 #undef NOPS
         const bool bad = o0 != w0 || o1 != w1;
-        const unsigned long long bm = __ballot(bad);
+        const unsigned long long bm = __ballot(bad), b1 = __ballot(o1 != w1);
         if (bm) {
-            if (!nbad) first_it = it, first_got = (unsigned)(bm >> 32) ^ 0u, lanes_bad = (unsigned)bm;
+            if (!nbad) first_it = it | (b1 ? 0x80000000u : 0u), first_got = (unsigned)(bm >> 32) ^ 0u, lanes_bad = (unsigned)bm;
             ++nbad;
         }
+        // (the waves of a SIMD drift apart: wave w does wave-many extra k-steps of matrix work before its first exchange)
+        const int ksteps = (PK >= 2 && it == 0) ? 1 + wave : 1;
+        for (int kk = 0; kk < ksteps; ++kk) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const unsigned nxt = lbase + (unsigned)(((it + (q == NQ - 1)) % LDS_KS) * KS_BYTES + ((q + 1) % NQ) * 2048);
-            asm volatile(MFMA("%0", "%1", "%3") MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
-                         "ds_read_b128 %1, %5\n ds_read_b128 %2, %5 offset:1024\n s_waitcnt lgkmcnt(0)\n"
-                         : "+v"(acc[q]), "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl) : "v"(nxt) : "memory");
+            for (int q = 0; q < NQ; ++q) {
+                if (PK >= 2) {   // twelve matrix instructions back to back, no LDS read in between
+                    asm volatile(MFMA("%0", "%1", "%3") MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
+                                 : "+v"(acc[q]), "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl) : : "memory");
+                } else {
+                    const unsigned nxt = lbase + (unsigned)(((it + (q == NQ - 1)) % LDS_KS) * KS_BYTES + ((q + 1) % NQ) * 2048);
+                    asm volatile(MFMA("%0", "%1", "%3") MFMA("%0", "%2", "%3") MFMA("%0", "%1", "%4")
+                                 "ds_read_b128 %1, %5\n ds_read_b128 %2, %5 offset:1024\n s_waitcnt lgkmcnt(0)\n"
+                                 : "+v"(acc[q]), "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl) : "v"(nxt) : "memory");
+                }
+            }
         }
     }
     asm volatile("s_nop 15\n s_nop 15" ::: "memory");
@@ -537,7 +562,8 @@ void bperm(const char* what, Args g, int reps, unsigned iters) {
         if (!bad_h[0]) printf("every lane received its partner's new value\n");
         else {
             printf("WRONG in %u waves, %u exchanges; receiving lanes of the first events:", bad_h[0], bad_h[1]);
-            for (unsigned i = 0; i < bad_h[0] && i < 6; ++i) printf(" [wave %u: %08x:%08x]", bad_h[2 + 4 * i] >> 16, bad_h[5 + 4 * i], bad_h[4 + 4 * i]);
+            for (unsigned i = 0; i < bad_h[0] && i < 6; ++i)
+                printf(" [wave %u: lanes 63..32 %08x, 31..0 %08x%s]", bad_h[2 + 4 * i] >> 16, bad_h[5 + 4 * i], bad_h[4 + 4 * i], (bad_h[3 + 4 * i] >> 31) ? ", second value too" : ", first value only");
             printf("\n");
         }
     }
@@ -573,6 +599,8 @@ int main(int argc, char** argv) {
     if (argc > 1 && argv[1][0] == 'b') {   // ./mfma_chain_hazard b <reps> <iters>: the packed-FMA -> ds_bpermute question only
         const int r = argc > 2 ? atoi(argv[2]) : 200;
         const unsigned iters = argc > 3 ? (unsigned)atoi(argv[3]) : 4000u;
+        bperm<2, 0>("four dependent v_pk_fma_f32 into v[d:d+1] ; ds_bpermute_b32 of v[d] ; of v[d+1]  (as compiled; matrix instructions back to back)", g, r, iters);
+        bperm<3, 0>("four dependent v_pk_fma_f32 into v[d:d+1] ; s_nop 0 ; ds_bpermute_b32 of v[d] ; of v[d+1]", g, r, iters);
         bperm<1, 0>("v_pk_fma_f32 v[d:d+1] ; ds_bpermute_b32 of v[d] (the next instruction: as compiled in every layer kernel)", g, r, iters);
         bperm<0, 0>("v_fma_f32 v[d] ; v_fma_f32 v[d+1] ; ds_bpermute_b32 of v[d], of v[d+1]", g, r, iters);
         bperm<1, 1>("v_pk_fma_f32 ; s_nop 0 ; ds_bpermute_b32", g, r, iters);
