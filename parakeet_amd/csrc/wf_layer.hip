@@ -51,20 +51,24 @@ typedef __fp16 pkh2 __attribute__((ext_vector_type(2)));
 #ifndef PK_WF_LATE_REFILL
 #define PK_WF_LATE_REFILL 0   // experiment of HISTORY 9.9 (1: the operand ring's slot refilled one k-step later -- made the three-waves-per-SIMD kernels fail in EVERY run)
 #endif
-// THE EXCHANGE RULE (round 6, HISTORY 10).  The folded skip path ends in a chain of v_pk_fma_f32 into {pl, pb}, and the
-// half-wave exchange `pl += bpermute(lane ^ 32, pl)` follows: hipcc emits `v_pk_fma_f32 v[2:3], ... ; ds_bpermute_b32 v4, v28, v2 ;
-// ds_bpermute_b32 v5, v28, v3` -- the first exchange reads v2 in the issue slot right behind the packed FMA that writes it.  With other
-// waves' matrix instructions in the SIMD that read now and then returned, for source lanes 48 - 63 (the last quarter of the wave's pass
-// through the vector ALU), the value BEFORE the FMA: the logs sum of positions 16 - 31 of a tile lost its last term -- errors of 1e-3,
-// nothing else in the tile touched (the stored planes and every b sum bit-identical: tools/r06_wf_replay_call.sh compares 33 000 replays of
-// one launch with the 8-wave kernel's result; the second exchange, one slot later, was never wrong).  This was round 5's "cause (ii)":
-// 7 - 25 % of the calls of BASELINE config 5's shape wrong in 12-wave workgroups, 1 - 5 % at 128 channels, every call in an instantiation
-// whose epilogue happened to be scheduled tighter.  LLVM has no such hazard and the ISA tables list none; the sequence could not be
-// reproduced in isolation (tools/micro/mfma_chain_hazard.hip `b`), so the rule is empirical: ONE wait state between a packed-fp32 result and
-// an LDS instruction that reads it.  1: the s_nop below (0 wrong of 33 000 replays, 0 of 410 whole calls).  0: as compiled before (the A/B).
-// tools/valu_to_mem_slack.py lists every such adjacency of a .s file.
-#ifndef PK_WF_XCHG_PAD
-#define PK_WF_XCHG_PAD 1
+// THE OP_SEL RULE (round 6, HISTORY 10) -- round 5's "cause (ii)", found.  The folded skip path sums `pl += w0 z, pb += w1 z` per
+// gated channel pair; hipcc's SLP vectoriser packs (pl, pb) into a register pair and emits, per z pair,
+//     v_pk_fma_f32 v[2:3], v[w0:w1], v[z:z+1], v[2:3] op_sel_hi:[1,0,1]      {pl, pb} += {w0, w1} * z.lo   (high half from a LOW register: fine)
+//     v_pk_fma_f32 v[2:3], v[w2:w3], v[z:z+1], v[2:3] op_sel:[0,1,0]         {pl, pb} += {w2, w3} * z.hi   (LOW half from a HIGH register)
+// On the MI355X the second form now and then DROPS ITS PRODUCT in the low half for lanes 48 - 63 (the last quarter of the wave's pass through
+// the vector ALU) -- the result is the addend alone -- when another wave of the SIMD is executing matrix instructions: the logs sum of the
+// 16 positions those lanes hand over in the half-wave exchange lost one term, an error of 1e-3, and nothing else in the tile was touched (the
+// stored planes and every b sum bit-identical to the 8-wave kernel's: 33 000 replays of one launch, tools/r06_wf_replay_call.sh).  7 - 25 % of
+// the calls of BASELINE config 5's shape in 12-wave workgroups, 1 - 5 % at 128 channels, every call in an instantiation that happened to
+// overlap its epilogue with more matrix work.  Reproduced in isolation (tools/micro/mfma_chain_hazard.hip `b`: 1 in 3e7 per instruction with
+// two or three waves per SIMD, never with one; wait states anywhere, other registers, full waits do not help; the same sums by scalar
+// v_fma_f32, or by packed FMAs WITHOUT op_sel, never fail in 4e9).  LLVM knows no such hazard, no table lists one.  The rule: no packed fp32
+// instruction whose LOW half reads a HIGH source register (`op_sel:[..1..]`) in code that runs beside matrix instructions.
+// 1: pl and pb pass through an asm statement as two scalar operands behind the sums -- the vectoriser then keeps them scalar (v_fmac_f32; same
+// values bit for bit; 0 wrong of 33 000 replays, 0 of 410 whole calls).  0: as compiled before (the A/B).  tools/pk_opsel_lint.py checks every
+// kernel of the library for the instruction form (tests/test_isa_rules_cpu.py: none is left).
+#ifndef PK_WF_SCALAR_SUMS
+#define PK_WF_SCALAR_SUMS 1
 #endif
 #ifndef PK_WF_AHEAD128
 #define PK_WF_AHEAD128 1   // A fragments of the 128-channel kernel this many co-tiles ahead (round 5: 2; 1 = rounds 3 - 4)
@@ -777,8 +781,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
             // the other half wave holds the other C/2 channels of the same position.  (LEAN: the exchange addressed from the
             // recomputed lane index -- __shfl_xor derives its own from v_mbcnt, which the compiler merges with the kernel's first
             // and keeps, or spills, through the slab loop)
-#if PK_WF_XCHG_PAD
-            asm volatile("s_nop 1" : "+v"(pl), "+v"(pb));   // THE EXCHANGE RULE (top of the file): two wait states between the packed FMA and the exchange
+#if PK_WF_SCALAR_SUMS
+            asm volatile("" : "+v"(pl), "+v"(pb));   // THE OP_SEL RULE (top of the file): pl and pb as two scalars -- no packed FMA with op_sel in the sums above
 #endif
             pl += xor32(pl, lane_e, LEAN);
             pb += xor32(pb, lane_e, LEAN);
@@ -1247,8 +1251,9 @@ int wfl_layer_launch(pk_ctx* ctx, const WflLaunch& a) {
     // instead of 8 + 3 with the second 3/8 full).  a.waves = 6 / 8 / 12 forces one (option "layer_waves" of pk_wf_set_option).
     // Round 5 had taken three waves per SIMD away from the default math (and two working waves per SIMD from the 128-channel
     // model): wrong tiles in 7 - 25 % of the calls.  Round 6 found the instruction pair -- the half-wave exchange of the folded
-    // skip sums read the packed FMA's result one issue slot behind it (PK_WF_XCHG_PAD at the top of this file) --
-    // and with the wait state in place every configuration is back: 0 wrong calls of 410 (profiles/r06_wf_fix_check.txt).
+    // skip sums came out of packed FMAs with op_sel, which drop a product now and then beside other waves' matrix instructions (the op_sel
+    // rule at the top of this file) --
+    // and with the sums kept scalar every configuration is back: 0 wrong calls of 410 (profiles/r06_wf_fix_check.txt).
     const bool w6 = a.C == 64 && a.waves == 6 && a.nl == 1;   // two 6-wave workgroups per CU (see Shape)
     const bool w12 = !w6 && a.C == 64 && (a.waves == 12 || a.waves == 6 ||
                                           (a.waves != 8 && (b.tiles_per_wg + 11) / 12 < (b.tiles_per_wg + 7) / 8));

@@ -72,7 +72,7 @@ def test_waveflow_12_wave_workgroups_bit_identical():
     round of 11 tiles at the benchmark's shape instead of 8 + 3) and as two 6-wave workgroups per CU -- the arithmetic of the 8-wave
     kernel tile for tile: the waveforms are equal bit for bit on a ragged batch whose tiles straddle utterances and gaps, in both
     maths, and meet the oracle bar.  (Round 5 refused three waves per SIMD in the default math: wrong tiles in 7 - 25 % of the calls
-    at the benchmark's shape.  Round 6 found the instruction pair -- DESIGN 4.3, "the exchange rule" -- and every configuration is
+    at the benchmark's shape.  Round 6 found the instruction -- DESIGN 4.3, "the op_sel rule" -- and every configuration is
     back; the calls that failed are in test_waveflow_calls_with_two_working_waves_per_simd_are_deterministic_and_right.)"""
     from oracle import waveflow_ref as ref
     from parakeet_amd.waveflow import ConditionalWaveFlow

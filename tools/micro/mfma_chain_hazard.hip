@@ -1,4 +1,12 @@
-// VERDICT r5 "next" #2 / HISTORY 9.9: a standalone reproducer for the WaveFlow layer kernel's "cause (ii)".
+// VERDICT r5 "next" #2 / HISTORY 9.9 -> 10: the standalone reproducer of the WaveFlow layer kernel's "cause (ii)".
+//
+// RESULT (round 6; profiles/r06_wf_hazard_micro.txt).  Questions 1 - 3 below (the chains of three, LDS store data, LDS ordering) came back
+// clean at 100x the kernel's event count: the hardware does what the tables say.  Question 4 (`./mfma_chain_hazard b`) reproduces the defect:
+// a packed fp32 FMA whose LOW half reads a HIGH source register -- `v_pk_fma_f32 d, a, b, c op_sel:[0,1,0]`, what hipcc's SLP vectoriser makes
+// of `pl += w2 z.hi; pb += w3 z.hi` -- drops its product in the low half for lanes 48 - 63 about once in 3e7 when two or three waves of the
+// SIMD run matrix instructions (never with one wave; wait states, other registers, full waits change nothing; the copy of the result read
+// 16 wait states later is wrong too: it is the FMA, not its consumer).  The same sums by scalar v_fma_f32, or by packed FMAs without op_sel,
+// never failed in 4e9.  "THE OP_SEL RULE" of DESIGN.md 4.3; tools/pk_opsel_lint.py finds the instruction form in a .s file.
 //
 // What the failing kernels do on one SIMD: two or three waves each run, per accumulator tile ("co-tile"), a chain of THREE
 // dependent v_mfma_f32_32x32x16_f16 (a_hi b_hi + a_lo b_hi + a_hi b_lo into the same accumulator), the A fragments coming from LDS
@@ -449,7 +457,9 @@ void lds_order(const char* what, Args g, int reps, unsigned iters) {
 template <int PK, int GAP>
 __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
     __shared__ __attribute__((aligned(16))) u32x4 lds[LDS_KS * KS_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) float wtab[32];   // PK 4 / 5: the folded weights, [half wave][16]
     for (int i = threadIdx.x; i < LDS_KS * KS_BYTES / 16; i += blockDim.x) lds[i] = g.a_src[i];
+    if (threadIdx.x < 32) wtab[threadIdx.x] = (float)((int)((threadIdx.x * 5 + 3) % 7) - 3);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= g.working) return;
@@ -470,8 +480,20 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
         const int pl = lane ^ 32;
         const float w0 = 3.f * (float)(((pl >> 2) + it) & 31) + c0, w1 = 5.f * (float)(((pl >> 1) + 3 * it) & 31) + c1;   // (PK 2 / 3: 4 x 0.75 = 3, 4 x 1.25 = 5)
         float o0, o1;
+        float x0 = w0, x1 = w1;
+        if (PK >= 4 && PK <= 15) {   // the partner's sums: z pairs (a0,a1) (a1,a0) (a0,a0) (a1,a1) at lane ^ 32, weights of ITS half wave
+            const float pa0 = (float)(((pl >> 2) + it) & 31), pa1 = (float)(((pl >> 1) + 3 * it) & 31);
+            const float zlo[4] = {pa0, pa1, pa0, pa1}, zhi[4] = {pa1, pa0, pa0, pa1};
+            const float* w = wtab + (pl >> 5) * 16;
+            x0 = c0;
+            x1 = c1;
+            for (int i = 0; i < 4; ++i) {
+                x0 += w[4 * i] * zlo[i] + w[4 * i + 2] * zhi[i];
+                x1 += w[4 * i + 1] * zlo[i] + w[4 * i + 3] * zhi[i];
+            }
+        }
 #define NOPS(n) (n == 0 ? "" : (n == 1 ? "s_nop 0\n" : (n == 2 ? "s_nop 1\n" : "s_nop 3\n")))
-        if (PK) {
+        if (PK == 1) {
             if (GAP == 0)
                 asm volatile("v_mov_b32 v100, %4\n v_mov_b32 v101, %5\n v_mov_b32 v102, 3.0\n v_mov_b32 v103, 5.0\n v_mov_b32 v106, %2\n v_mov_b32 v107, %3\n s_nop 1\n"
                              "v_pk_fma_f32 v[100:101], v[106:107], v[102:103], v[100:101]\n"
@@ -484,6 +506,135 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
                              "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n"
                              : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr), "n"(GAP - 1)
                              : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+        } else if (PK >= 4 && PK <= 7) {
+            // the layer kernel's own tail (k12.s): four ds_read_b128 of the folded weights (one address per half wave; the FIRST
+            // quad lands in the registers that then hold the sums), partial waits, eight packed FMAs with the op_sel pattern of
+            // `{pl, pb} += {w0, w1} z.lo ; += {w2, w3} z.hi`, v_cvt_pkrtz in between, the exchange right behind the last one
+            const unsigned wa = (unsigned)(size_t)(&wtab[0]) + (lane >> 5) * 64;
+#define TAIL(XNOP) asm volatile("v_mov_b32 v116, %2\n v_mov_b32 v117, %3\n v_mov_b32 v118, %3\n v_mov_b32 v119, %2\n v_mov_b32 v120, %2\n v_mov_b32 v121, %2\n" \
+                         "v_mov_b32 v122, %3\n v_mov_b32 v123, %3\n v_mov_b32 v124, %4\n v_mov_b32 v125, %5\n" \
+                         "ds_read_b128 v[100:103], %7\n ds_read_b128 v[104:107], %7 offset:16\n ds_read_b128 v[108:111], %7 offset:32\n ds_read_b128 v[112:115], %7 offset:48\n" \
+                         "v_cvt_pkrtz_f16_f32 v126, v116, v117\n s_waitcnt lgkmcnt(3)\n" \
+                         "v_pk_fma_f32 v[100:101], v[100:101], v[116:117], v[124:125] op_sel_hi:[1,0,1]\n v_cvt_pkrtz_f16_f32 v127, v118, v119\n" \
+                         "v_pk_fma_f32 v[100:101], v[102:103], v[116:117], v[100:101] op_sel:[0,1,0]\n v_cvt_pkrtz_f16_f32 v126, v120, v121\n s_waitcnt lgkmcnt(2)\n" \
+                         "v_pk_fma_f32 v[100:101], v[104:105], v[118:119], v[100:101] op_sel_hi:[1,0,1]\n v_cvt_pkrtz_f16_f32 v127, v122, v123\n" \
+                         "v_pk_fma_f32 v[100:101], v[106:107], v[118:119], v[100:101] op_sel:[0,1,0]\n s_waitcnt lgkmcnt(1)\n" \
+                         "v_pk_fma_f32 v[100:101], v[108:109], v[120:121], v[100:101] op_sel_hi:[1,0,1]\n" \
+                         "v_pk_fma_f32 v[100:101], v[110:111], v[120:121], v[100:101] op_sel:[0,1,0]\n s_waitcnt lgkmcnt(0)\n" \
+                         "v_pk_fma_f32 v[100:101], v[112:113], v[122:123], v[100:101] op_sel_hi:[1,0,1]\n" \
+                         "v_fma_f32 v126, v126, v126, v127\n v_fma_f32 v127, v126, v126, v127\n s_nop 0\n" \
+                         "v_pk_fma_f32 v[100:101], v[114:115], v[122:123], v[100:101] op_sel:[0,1,0]\n" \
+                         XNOP \
+                         "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" \
+                         : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr), "v"(wa) \
+                         : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
+                           "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+            if (PK == 4) { TAIL(""); } else if (PK == 5) { TAIL("s_nop 0\n"); } else if (PK == 6) { TAIL("s_nop 1\n"); } else { TAIL("s_nop 3\n"); }
+#undef TAIL
+        } else if (PK >= 8 && PK <= 15) {
+            // what cures it?  8: the same sums by sixteen scalar v_fma_f32 (what hipcc emits once pl and pb are separate asm operands);
+            // 9: packed, two wait states behind every s_waitcnt (between an LDS return and the first packed FMA that reads it);
+            // 10: packed, the sums in a register pair of their own (the first weight quad does not land in the accumulator's registers);
+            // 11: packed, ONE full wait (lgkmcnt(0)) + two wait states in front of the first FMA, no partial waits
+            const unsigned wa = (unsigned)(size_t)(&wtab[0]) + (lane >> 5) * 64;
+#define HEAD "v_mov_b32 v116, %2\n v_mov_b32 v117, %3\n v_mov_b32 v118, %3\n v_mov_b32 v119, %2\n v_mov_b32 v120, %2\n v_mov_b32 v121, %2\n" \
+             "v_mov_b32 v122, %3\n v_mov_b32 v123, %3\n v_mov_b32 v124, %4\n v_mov_b32 v125, %5\n" \
+             "ds_read_b128 v[100:103], %7\n ds_read_b128 v[104:107], %7 offset:16\n ds_read_b128 v[108:111], %7 offset:32\n ds_read_b128 v[112:115], %7 offset:48\n" \
+             "v_cvt_pkrtz_f16_f32 v126, v116, v117\n"
+#define FILL "v_fma_f32 v126, v126, v126, v127\n v_fma_f32 v127, v126, v126, v127\n s_nop 0\n"
+#define OPS  : "=v"(o0), "=v"(o1) : "v"(a0), "v"(a1), "v"(c0), "v"(c1), "v"(paddr), "v"(wa) \
+             : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
+               "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129"
+#define PKF(acc, w, z, c, sel) "v_pk_fma_f32 " acc ", " w ", " z ", " c " " sel "\n"
+#define LO "op_sel_hi:[1,0,1]"
+#define HI "op_sel:[0,1,0]"
+            if (PK == 8)
+                asm volatile(HEAD "s_waitcnt lgkmcnt(3)\n"
+                             "v_fma_f32 v128, v100, v116, v124\n v_fma_f32 v129, v101, v116, v125\n v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
+                             "v_fma_f32 v128, v102, v117, v128\n v_fma_f32 v129, v103, v117, v129\n v_cvt_pkrtz_f16_f32 v126, v120, v121\n s_waitcnt lgkmcnt(2)\n"
+                             "v_fma_f32 v128, v104, v118, v128\n v_fma_f32 v129, v105, v118, v129\n v_cvt_pkrtz_f16_f32 v127, v122, v123\n"
+                             "v_fma_f32 v128, v106, v119, v128\n v_fma_f32 v129, v107, v119, v129\n s_waitcnt lgkmcnt(1)\n"
+                             "v_fma_f32 v128, v108, v120, v128\n v_fma_f32 v129, v109, v120, v129\n"
+                             "v_fma_f32 v128, v110, v121, v128\n v_fma_f32 v129, v111, v121, v129\n s_waitcnt lgkmcnt(0)\n"
+                             "v_fma_f32 v128, v112, v122, v128\n v_fma_f32 v129, v113, v122, v129\n" FILL
+                             "v_fma_f32 v128, v114, v123, v128\n v_fma_f32 v129, v115, v123, v129\n"
+                             "ds_bpermute_b32 v104, %6, v128\n ds_bpermute_b32 v105, %6, v129\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS);
+            else if (PK == 9)
+                asm volatile(HEAD "s_waitcnt lgkmcnt(3)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[100:101]", "v[116:117]", "v[124:125]", LO) "v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
+                             PKF("v[100:101]", "v[102:103]", "v[116:117]", "v[100:101]", HI) "v_cvt_pkrtz_f16_f32 v126, v120, v121\n s_waitcnt lgkmcnt(2)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[104:105]", "v[118:119]", "v[100:101]", LO) "v_cvt_pkrtz_f16_f32 v127, v122, v123\n"
+                             PKF("v[100:101]", "v[106:107]", "v[118:119]", "v[100:101]", HI) "s_waitcnt lgkmcnt(1)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[108:109]", "v[120:121]", "v[100:101]", LO)
+                             PKF("v[100:101]", "v[110:111]", "v[120:121]", "v[100:101]", HI) "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[112:113]", "v[122:123]", "v[100:101]", LO) FILL
+                             PKF("v[100:101]", "v[114:115]", "v[122:123]", "v[100:101]", HI)
+                             "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS);
+            else if (PK == 10)
+                asm volatile(HEAD "s_waitcnt lgkmcnt(3)\n"
+                             PKF("v[128:129]", "v[100:101]", "v[116:117]", "v[124:125]", LO) "v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
+                             PKF("v[128:129]", "v[102:103]", "v[116:117]", "v[128:129]", HI) "v_cvt_pkrtz_f16_f32 v126, v120, v121\n s_waitcnt lgkmcnt(2)\n"
+                             PKF("v[128:129]", "v[104:105]", "v[118:119]", "v[128:129]", LO) "v_cvt_pkrtz_f16_f32 v127, v122, v123\n"
+                             PKF("v[128:129]", "v[106:107]", "v[118:119]", "v[128:129]", HI) "s_waitcnt lgkmcnt(1)\n"
+                             PKF("v[128:129]", "v[108:109]", "v[120:121]", "v[128:129]", LO)
+                             PKF("v[128:129]", "v[110:111]", "v[120:121]", "v[128:129]", HI) "s_waitcnt lgkmcnt(0)\n"
+                             PKF("v[128:129]", "v[112:113]", "v[122:123]", "v[128:129]", LO) FILL
+                             PKF("v[128:129]", "v[114:115]", "v[122:123]", "v[128:129]", HI)
+                             "ds_bpermute_b32 v104, %6, v128\n ds_bpermute_b32 v105, %6, v129\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS);
+            else if (PK == 12)      // 11 without the other vector instructions between the packed FMAs (op_sel kept)
+                asm volatile(HEAD "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[100:101]", "v[116:117]", "v[124:125]", LO)
+                             PKF("v[100:101]", "v[102:103]", "v[116:117]", "v[100:101]", HI)
+                             PKF("v[100:101]", "v[104:105]", "v[118:119]", "v[100:101]", LO)
+                             PKF("v[100:101]", "v[106:107]", "v[118:119]", "v[100:101]", HI)
+                             PKF("v[100:101]", "v[108:109]", "v[120:121]", "v[100:101]", LO)
+                             PKF("v[100:101]", "v[110:111]", "v[120:121]", "v[100:101]", HI)
+                             PKF("v[100:101]", "v[112:113]", "v[122:123]", "v[100:101]", LO)
+                             PKF("v[100:101]", "v[114:115]", "v[122:123]", "v[100:101]", HI)
+                             "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS);
+            else if (PK == 13)      // 11 with the z pairs swizzled by v_mov beforehand, so that no packed FMA carries op_sel: {w0,w1} x {zlo,zlo}, {w2,w3} x {zhi,zhi}
+                asm volatile(HEAD "s_waitcnt lgkmcnt(0)\n"
+                             "v_mov_b32 v130, v116\n v_mov_b32 v131, v116\n v_mov_b32 v132, v117\n v_mov_b32 v133, v117\n v_mov_b32 v134, v118\n v_mov_b32 v135, v118\n v_mov_b32 v136, v119\n v_mov_b32 v137, v119\n"
+                             "v_mov_b32 v138, v120\n v_mov_b32 v139, v120\n v_mov_b32 v140, v121\n v_mov_b32 v141, v121\n v_mov_b32 v142, v122\n v_mov_b32 v143, v122\n v_mov_b32 v144, v123\n v_mov_b32 v145, v123\n s_nop 1\n"
+                             PKF("v[100:101]", "v[100:101]", "v[130:131]", "v[124:125]", "") "v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
+                             PKF("v[100:101]", "v[102:103]", "v[132:133]", "v[100:101]", "") "v_cvt_pkrtz_f16_f32 v126, v120, v121\n"
+                             PKF("v[100:101]", "v[104:105]", "v[134:135]", "v[100:101]", "") "v_cvt_pkrtz_f16_f32 v127, v122, v123\n"
+                             PKF("v[100:101]", "v[106:107]", "v[136:137]", "v[100:101]", "")
+                             PKF("v[100:101]", "v[108:109]", "v[138:139]", "v[100:101]", "")
+                             PKF("v[100:101]", "v[110:111]", "v[140:141]", "v[100:101]", "")
+                             PKF("v[100:101]", "v[112:113]", "v[142:143]", "v[100:101]", "") FILL
+                             PKF("v[100:101]", "v[114:115]", "v[144:145]", "v[100:101]", "")
+                             "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS,
+                             "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145");
+            else if (PK == 14)      // 11, and the sums read back DIRECTLY (v_mov of the accumulator, lane by lane through the exchange of an untouched copy): is it the FMA or the exchange?
+                asm volatile(HEAD "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[100:101]", "v[116:117]", "v[124:125]", LO) "v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
+                             PKF("v[100:101]", "v[102:103]", "v[116:117]", "v[100:101]", HI) "v_cvt_pkrtz_f16_f32 v126, v120, v121\n"
+                             PKF("v[100:101]", "v[104:105]", "v[118:119]", "v[100:101]", LO) "v_cvt_pkrtz_f16_f32 v127, v122, v123\n"
+                             PKF("v[100:101]", "v[106:107]", "v[118:119]", "v[100:101]", HI)
+                             PKF("v[100:101]", "v[108:109]", "v[120:121]", "v[100:101]", LO)
+                             PKF("v[100:101]", "v[110:111]", "v[120:121]", "v[100:101]", HI)
+                             PKF("v[100:101]", "v[112:113]", "v[122:123]", "v[100:101]", LO) FILL
+                             PKF("v[100:101]", "v[114:115]", "v[122:123]", "v[100:101]", HI)
+                             "s_nop 7\n s_nop 7\n v_mov_b32 v128, v100\n v_mov_b32 v129, v101\n s_nop 7\n"
+                             "ds_bpermute_b32 v104, %6, v128\n ds_bpermute_b32 v105, %6, v129\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS);
+            else
+                asm volatile(HEAD "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[100:101]", "v[116:117]", "v[124:125]", LO) "v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
+                             PKF("v[100:101]", "v[102:103]", "v[116:117]", "v[100:101]", HI) "v_cvt_pkrtz_f16_f32 v126, v120, v121\n"
+                             PKF("v[100:101]", "v[104:105]", "v[118:119]", "v[100:101]", LO) "v_cvt_pkrtz_f16_f32 v127, v122, v123\n"
+                             PKF("v[100:101]", "v[106:107]", "v[118:119]", "v[100:101]", HI)
+                             PKF("v[100:101]", "v[108:109]", "v[120:121]", "v[100:101]", LO)
+                             PKF("v[100:101]", "v[110:111]", "v[120:121]", "v[100:101]", HI)
+                             PKF("v[100:101]", "v[112:113]", "v[122:123]", "v[100:101]", LO) FILL
+                             PKF("v[100:101]", "v[114:115]", "v[122:123]", "v[100:101]", HI)
+                             "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS);
+#undef HEAD
+#undef FILL
+#undef OPS
+#undef PKF
+#undef LO
+#undef HI
         } else if (PK == 2 || PK == 3) {
             // as compiled: the LAST of a chain of dependent packed FMAs into the same register pair, then the exchange (PK 3: with
             // one wait state in between); the matrix instructions of this variant come without LDS reads (below): the other waves
@@ -508,14 +659,33 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
                          : "memory", "v100", "v101", "v102", "v103", "v104", "v105");
         }
 #undef NOPS
-        const bool bad = o0 != w0 || o1 != w1;
-        const unsigned long long bm = __ballot(bad), b1 = __ballot(o1 != w1);
+        const bool bad = o0 != x0 || o1 != x1;
+        if (bad && PK >= 4 && PK <= 15 && o0 != x0) {
+            // how old is the value that arrived?  the partner's logs sum after k of its 8 packed FMAs, k = 0 .. 7 (8 = none of them)
+            const float pa0 = (float)(((pl >> 2) + it) & 31), pa1 = (float)(((pl >> 1) + 3 * it) & 31);
+            const float zlo[4] = {pa0, pa1, pa0, pa1}, zhi[4] = {pa1, pa0, pa0, pa1};
+            const float* w = wtab + (pl >> 5) * 16;
+            float part = c0;
+            int k = 8;
+            for (int i = 0; i < 8; ++i) {
+                if (part == o0) k = i;
+                part += (i & 1) ? w[4 * (i >> 1) + 2] * zhi[i >> 1] : w[4 * (i >> 1)] * zlo[i >> 1];
+            }
+            atomicAdd(&g.bad[70 + k], 1u);
+        }
+        const unsigned long long bm = __ballot(bad), b1 = __ballot(o1 != x1);
         if (bm) {
             if (!nbad) first_it = it | (b1 ? 0x80000000u : 0u), first_got = (unsigned)(bm >> 32) ^ 0u, lanes_bad = (unsigned)bm;
+            if (!nbad && g.expect_out && blockIdx.x == 0 && wave == 0) {   // debugging aid: what every lane got and expected at the first event
+                g.expect_out[lane] = o0;
+                g.expect_out[64 + lane] = x0;
+                g.expect_out[128 + lane] = o1;
+                g.expect_out[192 + lane] = x1;
+            }
             ++nbad;
         }
         // (the waves of a SIMD drift apart: wave w does wave-many extra k-steps of matrix work before its first exchange)
-        const int ksteps = (PK >= 2 && it == 0) ? 1 + wave : 1;
+        const int ksteps = (PK >= 2 && it == 0) ? 1 + wave : 1;   // (PK >= 2: dense matrix work)
         for (int kk = 0; kk < ksteps; ++kk) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -561,7 +731,16 @@ void bperm(const char* what, Args g, int reps, unsigned iters) {
         printf("    %d working waves per SIMD: %d launches x %u exchanges per wave: ", working / 4, reps, iters);
         if (!bad_h[0]) printf("every lane received its partner's new value\n");
         else {
+            if (getenv("MICRO_DEBUG")) {
+                float d[256];
+                CK(hipMemcpy(d, g.expect_out, sizeof(d), hipMemcpyDeviceToHost));
+                for (int l = 0; l < 64; l += 5) printf("\n      lane %2d: got %g want %g | got %g want %g", l, d[l], d[64 + l], d[128 + l], d[192 + l]);
+                printf("\n");
+            }
             printf("WRONG in %u waves, %u exchanges; receiving lanes of the first events:", bad_h[0], bad_h[1]);
+            printf("\n        age of the value that arrived (partner's sum after k of its 8 packed FMAs; last column: none of them):");
+            for (int k = 0; k <= 8; ++k) printf(" %u", bad_h[70 + k]);
+            printf("\n       ");
             for (unsigned i = 0; i < bad_h[0] && i < 6; ++i)
                 printf(" [wave %u: lanes 63..32 %08x, 31..0 %08x%s]", bad_h[2 + 4 * i] >> 16, bad_h[5 + 4 * i], bad_h[4 + 4 * i], (bad_h[3 + 4 * i] >> 31) ? ", second value too" : ", first value only");
             printf("\n");
@@ -599,6 +778,18 @@ int main(int argc, char** argv) {
     if (argc > 1 && argv[1][0] == 'b') {   // ./mfma_chain_hazard b <reps> <iters>: the packed-FMA -> ds_bpermute question only
         const int r = argc > 2 ? atoi(argv[2]) : 200;
         const unsigned iters = argc > 3 ? (unsigned)atoi(argv[3]) : 4000u;
+        bperm<4, 0>("the layer kernel's tail: 4 ds_read_b128 of the weights, 8 packed FMAs behind partial waits, the exchange behind the last", g, r, iters);
+        bperm<5, 0>("the same with s_nop 0 in front of the exchange", g, r, iters);
+        bperm<6, 0>("the same with s_nop 1 in front of the exchange (the kernel's fix)", g, r, iters);
+        bperm<7, 0>("the same with s_nop 3 in front of the exchange", g, r, iters);
+        bperm<8, 0>("the same sums by scalar v_fma_f32 (no packed fp32 instruction)", g, r, iters);
+        bperm<9, 0>("packed, two wait states behind every s_waitcnt lgkmcnt", g, r, iters);
+        bperm<10, 0>("packed, the sums in a register pair of their own (not where the first weight quad lands)", g, r, iters);
+        bperm<11, 0>("packed, one full wait + two wait states in front of the first FMA", g, r, iters);
+        bperm<12, 0>("as the last, without the other vector instructions between the packed FMAs", g, r, iters);
+        bperm<13, 0>("as the last but one, no op_sel on any packed FMA (the z pairs duplicated by v_mov beforehand)", g, r, iters);
+        bperm<14, 0>("as that, the sums copied by v_mov 16 wait states later and the COPY exchanged (is it the FMA or the exchange?)", g, r, iters);
+        if (getenv("MICRO_TAIL_ONLY")) return 0;
         bperm<2, 0>("four dependent v_pk_fma_f32 into v[d:d+1] ; ds_bpermute_b32 of v[d] ; of v[d+1]  (as compiled; matrix instructions back to back)", g, r, iters);
         bperm<3, 0>("four dependent v_pk_fma_f32 into v[d:d+1] ; s_nop 0 ; ds_bpermute_b32 of v[d] ; of v[d+1]", g, r, iters);
         bperm<1, 0>("v_pk_fma_f32 v[d:d+1] ; ds_bpermute_b32 of v[d] (the next instruction: as compiled in every layer kernel)", g, r, iters);
