@@ -748,6 +748,65 @@ void bperm(const char* what, Args g, int reps, unsigned iters) {
     }
 }
 
+
+// ---- fifth question (round 6): round 5's "cause (i)" -- is the compiler's MFMA -> VALU distance (12 issue slots for an 8-pass MFMA on gfx950)
+// enough when other waves feed the same matrix pipe?  tools/mfma_slack.py finds that distance in the PWG layer, FFN and attention kernels.
+// The out projection's end as compiled then: two interleaved dependent chains (acc1, acc0, acc1, acc0), `s_nop NOPS`, a VALU read of the
+// OLDER chain's accumulator (acc1: one MFMA + NOPS + 1 slots behind its last MFMA).  NOPS 10 = the compiler's minimum.
+template <int NOPS>
+__global__ __launch_bounds__(768, 3) void k_acc_read(Args g, unsigned iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= g.working) return;
+    u32x4 a = g.a_src[lane], b = g.b_tab[lane], a2 = g.a_src[64 + lane];
+    f32x16 acc0, acc1, ref1;
+    unsigned nbad = 0;
+    // reference: the same four products with a long wait
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, 0\n v_mfma_f32_32x32x16_f16 %1, %4, %3, 0\n"
+                 "v_mfma_f32_32x32x16_f16 %0, %4, %3, %0\n v_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n s_nop 15\n s_nop 15\n"
+                 : "=&v"(ref1), "=&v"(acc0) : "v"(a), "v"(b), "v"(a2));
+    float sink = 0.f;
+#pragma unroll 1
+    for (unsigned it = 0; it < iters; ++it) {
+        float o[4];
+        // (acc1 = v[100:115], acc0 = v[116:131]: fixed registers, so that the read can name acc1's first one)
+        asm volatile("v_mfma_f32_32x32x16_f16 v[100:115], %1, %2, 0\n v_mfma_f32_32x32x16_f16 v[116:131], %3, %2, 0\n"
+                     "v_mfma_f32_32x32x16_f16 v[100:115], %3, %2, v[100:115]\n v_mfma_f32_32x32x16_f16 v[116:131], %1, %2, v[116:131]\n"
+                     "s_nop %4\n"
+                     "v_mov_b32 %0, v100\n"       // first register of the OLDER chain's accumulator: the tightest read
+                     "s_nop 15\n s_nop 15\n"
+                     : "=&v"(o[0]) : "v"(a), "v"(b), "v"(a2), "n"(NOPS)
+                     : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
+                       "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131");
+        if (o[0] != ref1[0]) ++nbad;
+        // twelve more matrix instructions back to back: the pipe stays busy for the other waves' reads
+        asm volatile(MFMA("%0", "%2", "%3") MFMA("%1", "%4", "%3") MFMA("%0", "%2", "%3") MFMA("%1", "%4", "%3") MFMA("%0", "%2", "%3") MFMA("%1", "%4", "%3")
+                     MFMA("%0", "%2", "%3") MFMA("%1", "%4", "%3") MFMA("%0", "%2", "%3") MFMA("%1", "%4", "%3") "s_nop 15\n s_nop 15\n"
+                     : "+v"(acc0), "+v"(acc1) : "v"(a), "v"(b), "v"(a2));
+        sink += acc0[3] + acc1[5];
+    }
+    if (sink == 1.2345e30f) nbad += 1u << 30;
+    if (nbad) {
+        atomicAdd(&g.bad[1], nbad);
+        if (lane == 0) atomicAdd(&g.bad[0], 1u);
+    }
+}
+
+template <int NOPS>
+void acc_read(Args g, int reps, unsigned iters) {
+    printf("two interleaved chains ; s_nop %d ; VALU read of the older chain's accumulator (%d issue slots behind its last MFMA)\n", NOPS, NOPS + 2);
+    unsigned bad_h[80];
+    for (int working : {4, 8, 12}) {
+        g.working = working;
+        CK(hipMemset(g.bad, 0, 4 * 80));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_acc_read<NOPS>), dim3(256), dim3(768), 0, 0, g, iters);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(bad_h, g.bad, 4 * 80, hipMemcpyDeviceToHost));
+        printf("    %d working waves per SIMD: %d launches x %u reads per wave: ", working / 4, reps, iters);
+        if (!bad_h[1]) printf("every read saw the finished accumulator\n");
+        else printf("STALE in %u lane-reads\n", bad_h[1]);
+    }
+}
+
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     // A fragments: small integers that differ by (k-step, co-tile, part, lane, element); B: by (k-step, part, lane, element)
@@ -775,6 +834,16 @@ int main(int argc, char** argv) {
     g.expect_out = (float*)deo;
     g.bad = (unsigned*)dbad;
     printf("mfma_chain_hazard: 256 workgroups x 12 waves, %d k-steps x %d co-tiles per launch, %d launches per line\n", KSTEPS, NQ, reps);
+    if (argc > 1 && argv[1][0] == 'a') {   // ./mfma_chain_hazard a <reps> <iters>: the MFMA -> VALU distance
+        const int r = argc > 2 ? atoi(argv[2]) : 200;
+        const unsigned iters = argc > 3 ? (unsigned)atoi(argv[3]) : 4000u;
+        acc_read<10>(g, r, iters);
+        acc_read<9>(g, r, iters);
+        acc_read<8>(g, r, iters);
+        acc_read<6>(g, r, iters);
+        acc_read<15>(g, r, iters);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'b') {   // ./mfma_chain_hazard b <reps> <iters>: the packed-FMA -> ds_bpermute question only
         const int r = argc > 2 ? atoi(argv[2]) : 200;
         const unsigned iters = argc > 3 ? (unsigned)atoi(argv[3]) : 4000u;
