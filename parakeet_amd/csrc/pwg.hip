@@ -44,6 +44,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef PK_PWG_GATE_SCALAR
+#define PK_PWG_GATE_SCALAR 0   // 1: the layer kernel's gate on scalar fp32 instructions (round 6 A/B: packed fp32 beside matrix instructions, profiles/r06_pwg_packed_ab.txt)
+#endif
 
 namespace {
 
@@ -1052,7 +1055,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             if (ks >= B3_KS2) return;
             const int zq = ks >> 1, r0 = 8 * (ks & 1);
             if (slot < 4) {
-                if constexpr (HALF) {   // z * 2^14 from the scaled accumulators
+                if constexpr (HALF && PK_PWG_GATE_SCALAR) {   // (the A/B of round 6: the gate without packed fp32 instructions)
+                    zv[2 * slot] = gated_s(acc[zq][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot], gca, gcb);
+                    zv[2 * slot + 1] = gated_s(acc[zq][r0 + 2 * slot + 1], acc[zq + 2][r0 + 2 * slot + 1], gca, gcb);
+                } else if constexpr (HALF) {   // z * 2^14 from the scaled accumulators
                     const f32x2 av = {acc[zq][r0 + 2 * slot], acc[zq][r0 + 2 * slot + 1]};
                     const f32x2 bv = {acc[zq + 2][r0 + 2 * slot], acc[zq + 2][r0 + 2 * slot + 1]};
                     const f32x2 z2 = gated_s2(av, bv, gca, gcb);

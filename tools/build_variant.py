@@ -3,7 +3,7 @@
 (extra -D flags, or the file as it was at a git revision), linked to parakeet_amd/variants/<name>.so.  A GPU call copies a
 variant over libpk_synth_prof.so and runs the same tool under PK_PROFILE_LIB=1 (the library carries the tree's hash, so the
 loader accepts it; variants are measurement artefacts, git-ignored, never the product).
-usage: python tools/build_variant.py <name> <file.hip> [--rev REV] [-DNAME=VALUE ...]"""
+usage: python tools/build_variant.py <name> <file.hip> [--rev REV] [-DNAME=VALUE | -f... ...]"""
 import os
 import subprocess
 import sys
@@ -14,7 +14,8 @@ from parakeet_amd import build as B  # noqa: E402
 
 name, src = sys.argv[1], sys.argv[2]
 rev = sys.argv[sys.argv.index("--rev") + 1] if "--rev" in sys.argv else None
-flags = [a for a in sys.argv[3:] if a.startswith("-D")]
+flags = [a for a in sys.argv[3:] if a.startswith("-") and a != "--rev"]     # -DNAME=VALUE, -fno-slp-vectorize, -mllvm <x> ...
+flags += [a for i, a in enumerate(sys.argv[3:]) if i > 0 and sys.argv[3:][i - 1] == "-mllvm"]
 B.build(profile=True)                      # the other objects (*.prof.o) must be current
 out_dir = os.path.join(ROOT, "parakeet_amd", "variants")
 os.makedirs(out_dir, exist_ok=True)

@@ -57,5 +57,11 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in L:   # (the SQ pass is optional: the traffic pa
                 "wait_inst_any_frac": L["SQ_WAIT_INST_ANY"] / L["SQ_WAVE_CYCLES"],
                 "valu_quadcycles_per_mfma": L["SQ_ACTIVE_INST_VALU"] / L["SQ_INSTS_MFMA"]})
 out.update(extra)
+# which kernel source the counters were collected on (bench.py says whether that is the library it timed) and when
+import datetime, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from parakeet_amd import build as _b
+out["kernel_source_sha256"] = _b.file_hash("pwg.hip" if kind == "pwg" else "wf_layer.hip")
+out["collected"] = os.environ.get("PK_ROUND", "round 6") + " (" + datetime.date.today().isoformat() + ", tools/pmc_traffic.py)"
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
