@@ -354,6 +354,49 @@ __global__ __launch_bounds__(256) void k_fs2_row_bounds(const float* __restrict_
     out[r] = row_utt[r] >= 0 ? fmaf(m, c1, c0) : 0.f;
 }
 
+// One 32-key tile of the online softmax of the split-fp16 attention kernels (round 6: the vector diet of VERDICT r5 #5).
+// S holds the raw S^T accumulators of this lane's query (16 keys per half wave); c2 = cs * log2(e) > 0 turns them into
+// logits in units of log2.  On return S = 2^14 p (the block scale of the P operand folded into the exponent), m_run / l_run are
+// updated (l_run in the same 2^14 units) and the factor the running sums shrink by is returned.  Per element one v_fma and
+// one v_exp_f32 (before: a multiply, a subtract and libm's expf, and a multiply by 2^14); the key mask only in an utterance's
+// last tile.  Everything is per QUERY = per lane: with O accumulated transposed (O^T = V^T P^T, below) the rescale needs no
+// cross-lane traffic at all (before: 16 ds_bpermute per tile to bring alpha to the accumulator rows).
+__device__ __forceinline__ float at_softmax_tile(f32x16& S, float c2, int k0, int hi, int len, float& m_run, float& l_run) {
+    if (k0 + 32 > len) {   // (uniform: an utterance's last tile only)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (k0 + mfma_row(r, hi) >= len) S[r] = -INFINITY;
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, S[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32)) * c2;
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: 2^-inf = 0
+    const float off = (float)PK_UNIT_EXP - m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        S[r] = __builtin_amdgcn_exp2f(fmaf(S[r], c2, off));
+        lsum += S[r];
+    }
+    lsum += __shfl_xor(lsum, 32);
+    l_run = fmaf(l_run, alpha, lsum);
+    m_run = m_new;
+    return alpha;
+}
+// O^T tile rows are value channels, columns queries: this lane's query row goes out as 4-float pieces
+template <int DT>
+__device__ __forceinline__ void at_store_out(const f32x16 (&O)[DT], float f, float* o_row, int hi) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 v = {O[dt][4 * rq] * f, O[dt][4 * rq + 1] * f, O[dt][4 * rq + 2] * f, O[dt][4 * rq + 3] * f};
+            *reinterpret_cast<f32x4*>(o_row + 32 * dt + 8 * rq + 4 * hi) = v;   // channels mfma_row(4 rq .. 4 rq + 3, hi)
+        }
+}
+
 __device__ __forceinline__ f32x16 at_mfma3(at_f16x8 ah, at_f16x8 al, at_f16x8 bh, at_f16x8 bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
@@ -373,6 +416,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
     const long ld = a.ld;
     const float* base = a.qkv + (long)start * ld + h * DK;
     const AtScales sc = at_scales(a, b, h, gridDim.y);
+    const float c2 = sc.cs * 1.4426950408889634f;   // accumulator units -> log2 units (at_softmax_tile)
 
     at_f16x8 qh[KS], ql[KS];
     {
@@ -410,31 +454,11 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
                 S = at_mfma3(kh, kl, qh[ks], ql[ks], S);
             }
         }
-        float mloc = -INFINITY;
+        const float alpha = at_softmax_tile(S, c2, k0, hi, len, m_run, l_run);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + mfma_row(r, hi);
-            S[r] = (key < len) ? S[r] * sc.cs : -INFINITY;
-            mloc = fmaxf(mloc, S[r]);
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = expf(m_run - m_new);
-        float lsum = 0.f;
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            S[r] = expf(S[r] - m_new);
-            lsum += S[r];
-        }
-        lsum += __shfl_xor(lsum, 32);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float ar = __shfl(alpha, mfma_row(r, hi));
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) O[dt][r] *= ar;
-        }
+            for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;   // O^T: this lane's query in every register
         const float* vp = base + 2 * a.D + j;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -442,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
             long voff[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                pv[e] = S[8 * s2 + e] * PK_UNIT_SCALE;   // p <= 1: fixed block scale 2^14
+                pv[e] = S[8 * s2 + e];   // 2^14 p
                 voff[e] = (long)min(k0 + mfma_row(8 * s2 + e, hi), len - 1) * ld;
             }
             at_f16x8 ph, pl;
@@ -454,21 +478,12 @@ __global__ __launch_bounds__(256, 1) void k_attention_h3(AttnArgs a) {
                 for (int e = 0; e < 8; ++e) vv[e] = vp[voff[e] + 32 * dt];
                 at_f16x8 vh, vl;
                 at_split8s(vv, sc.sv, vh, vl);
-                O[dt] = at_mfma3(ph, pl, vh, vl, O[dt]);
+                O[dt] = at_mfma3(vh, vl, ph, pl, O[dt]);   // O^T += V^T P^T
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = q0 + mfma_row(r, hi);
-        const float lr = __shfl(l_run, mfma_row(r, hi));
-        if (q < len) {
-            float* o = a.out + (long)(start + q) * a.ldo + h * DK + j;
-            const float f = sc.co * (1.f / PK_UNIT_SCALE) / lr;   // O = 2^14 2^kv sum p v
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] * f;
-        }
-    }
+    if (q0 + j < len)   // O^T = 2^14 2^kv sum p v, l_run = 2^14 sum p: the 2^14 cancels
+        at_store_out<DT>(O, sc.co / l_run, a.out + (long)(start + q0 + j) * a.ldo + h * DK, hi);
 }
 
 // LDS-staged version of k_attention_h3: one workgroup = 4 waves = 4 query tiles (128 queries) of one
@@ -504,8 +519,12 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
     const int q0 = (blockIdx.x * (NT / 64) + wave) * 32;
     const int j = lane & 31, hi = lane >> 5;
     const long ld = a.ld;
+    const unsigned ld4 = (unsigned)a.ld * 4u;   // bytes per row
     const float* base = a.qkv + (long)start * ld + h * DK;
+    const char* const kbase = reinterpret_cast<const char*>(base + a.D);
+    const char* const vbase = reinterpret_cast<const char*>(base + 2 * a.D);
     const AtScales sc = at_scales(a, b, h, gridDim.y);
+    const float c2 = sc.cs * 1.4426950408889634f;   // accumulator units -> log2 units (at_softmax_tile)
 
     at_f16x8 qh[KS], ql[KS];
     {
@@ -535,9 +554,11 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
         for (int g = 0; g < KG; ++g) {
             const int idx = min(tl + NT * g, 32 * (DK / 8) - 1);   // (key, 8-float group) of the K tile
             const int key = idx / (DK / 8), grp = idx % (DK / 8);
-            const float* kp = base + a.D + (long)min(k0 + key, len - 1) * ld + 8 * grp;
+            // (round 6: 32-bit offsets inside the utterance -- a scalar base + an unsigned byte offset instead of a 64-bit
+            // multiply-add per address; pk_fft_run_attention checks that an utterance's rows fit)
+            const char* kp = kbase + ((unsigned)min(k0 + key, len - 1) * ld4 + 32u * grp);
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(kp);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(kp + 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(kp + 16);
             kreg[g][0] = v0[0]; kreg[g][1] = v0[1]; kreg[g][2] = v0[2]; kreg[g][3] = v0[3];
             kreg[g][4] = v1[0]; kreg[g][5] = v1[1]; kreg[g][6] = v1[2]; kreg[g][7] = v1[3];
         }
@@ -545,10 +566,10 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
         for (int g = 0; g < VG; ++g) {
             const int idx = min(tl + NT * g, 2 * DT * 64 - 1);     // (s2, dt, fragment lane) of the V tile
             const int fl = idx & 63, dt = (idx >> 6) % DT, s2 = idx / (64 * DT);
-            const float* vp = base + 2 * a.D + 32 * dt + (fl & 31);
+            const unsigned vo = (unsigned)(32 * dt + (fl & 31)) * 4u;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                vreg[g][e] = vp[(long)min(k0 + mfma_row(8 * s2 + e, fl >> 5), len - 1) * ld];
+                vreg[g][e] = *reinterpret_cast<const float*>(vbase + ((unsigned)min(k0 + mfma_row(8 * s2 + e, fl >> 5), len - 1) * ld4 + vo));
         }
     };
     auto store_tile = [&](int buf, int tl) {
@@ -604,56 +625,26 @@ __global__ __launch_bounds__(NTHR, 1) void k_attention_h3_lds(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             S = at_mfma3(kf[(ks * 2 + 0) * KP + lane], kf[(ks * 2 + 1) * KP + lane], qh[ks], ql[ks], S);
-        float mloc = -INFINITY;
+        const float alpha = at_softmax_tile(S, c2, k0, hi, len, m_run, l_run);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + mfma_row(r, hi);
-            S[r] = (key < len) ? S[r] * sc.cs : -INFINITY;
-            mloc = fmaxf(mloc, S[r]);
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = expf(m_run - m_new);
-        float lsum = 0.f;
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            S[r] = expf(S[r] - m_new);
-            lsum += S[r];
-        }
-        lsum += __shfl_xor(lsum, 32);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float ar = __shfl(alpha, mfma_row(r, hi));
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) O[dt][r] *= ar;
-        }
+            for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;   // O^T: this lane's query in every register
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float pv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pv[e] = S[8 * s2 + e] * PK_UNIT_SCALE;   // p <= 1: fixed block scale 2^14
+            for (int e = 0; e < 8; ++e) pv[e] = S[8 * s2 + e];   // 2^14 p (p <= 1: fixed block scale, folded into the exponent)
             at_f16x8 ph, pl;
             at_split8(pv, ph, pl);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                O[dt] = at_mfma3(ph, pl, vf[((s2 * DT + dt) * 2 + 0) * 64 + lane],
-                                 vf[((s2 * DT + dt) * 2 + 1) * 64 + lane], O[dt]);
+            for (int dt = 0; dt < DT; ++dt)   // O^T += V^T P^T: the V fragment is the A operand, P (this lane's query) the B operand
+                O[dt] = at_mfma3(vf[((s2 * DT + dt) * 2 + 0) * 64 + lane], vf[((s2 * DT + dt) * 2 + 1) * 64 + lane], ph, pl, O[dt]);
         }
     }
     if (q0 >= len) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = q0 + mfma_row(r, hi);
-        const float lr = __shfl(l_run, mfma_row(r, hi));
-        if (q < len) {
-            float* o = a.out + (long)(start + q) * a.ldo + h * DK + j;
-            const float f = sc.co * (1.f / PK_UNIT_SCALE) / lr;   // O = 2^14 2^kv sum p v
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[32 * dt] = O[dt][r] * f;
-        }
-    }
+    if (q0 + j < len)   // O^T = 2^14 2^kv sum p v, l_run = 2^14 sum p: the 2^14 cancels
+        at_store_out<DT>(O, sc.co / l_run, a.out + (long)(start + q0 + j) * a.ldo + h * DK, hi);
 }
 
 // Predictor heads: Linear(C -> 1) per row (+ masked_fill) and, for the duration
@@ -1423,6 +1414,7 @@ int pk_fft_run_attention(pk_fft_core* h, const Timeline& tl, const float* qkv, f
         a.amax = sc->attn_amax.as<unsigned>();
     }
     dim3 grid(pk_div_up(maxlen, 128), heads, tl.B);
+    if ((long)maxlen * 3 * A * 4 >= (1L << 32)) PK_FAIL(PK_EUNSUPPORTED, "attention: an utterance of %d rows exceeds the 32-bit row offsets", maxlen);
     if (h->math == PK_GEMM_MATH_F16X3 && h->attn_lds) {
         dim3 g2(pk_div_up(maxlen, ATT_THREADS / 2), heads, tl.B);
         // (measured, 32 x 640 frames: 180 -> 170 us per decoder launch; PK_FS2_ATTN_PIPE=0: the two-barrier loop)
