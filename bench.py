@@ -142,7 +142,7 @@ def cpu_baseline(fs2_state, pwg_state, stats, ids, noise, warmup=2, timed=5, bud
     return rec, logmel.numpy(), wav[:, 0].numpy()
 
 
-def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
+def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None, oracle_check=False):
     """ConditionalWaveFlow.infer on BASELINE config 5's shape (batch 8 x 640 mel frames): median of `runs` batches, the
     layer kernel's average launch time from the engine's HIP-event profile and its roofline.
     Algorithmic work of one layer launch (per folded position): the (3,3) conv over the rows that exist +
@@ -197,10 +197,9 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
                  "(examples/waveflow/synthesize.py:40), set_math('f16'); NOT fp32-equivalent (about 1e-4 of the peak)"
                  if math == "f16" else
                  "block-scaled split-fp16 products (fp32-equivalent error), layer inputs stored as pre-split fp16 planes") +
-                (("; 12-wave workgroups (one round of 11 tiles per workgroup)" if math == "f16" else
-                  "; 8-wave workgroups (8 + 3 tiles per workgroup: three waves per SIMD are for fp16 operands only since round 5, "
-                  "HISTORY.md 9.9)") + ", the row's step fused into its last layer's launch"
-                 if channels == 64 else "; 8-wave workgroups (round 5: no spills in the slab loop)") +
+                ("; 12-wave workgroups (one round of 11 tiles per workgroup; the default math again since round 6: DESIGN.md 4.3, the op_sel "
+                 "rule), the row's step fused into its last layer's launch" if channels == 64 else
+                 "; 8-wave workgroups, two working waves per SIMD") +
                 ("; only the hi parts of the weights travel to LDS (round 5)" if math == "f16" else ""),
         "samples_per_s": nsw / dtw, "x_realtime": nsw / dtw / SAMPLE_RATE, "ms_per_batch": dtw * 1e3,
         "ms_per_batch_runs": [t * 1e3 for t in times],
@@ -228,9 +227,20 @@ def waveflow_extra(channels, ctx, batch=8, frames=640, runs=5, math=None):
                     "read-modify-write as well (the basis of the round-2/3 figures and targets); "
                     "averages over the launches of a batch (rows 1 and 2 of a flow read one and two input rows); "
                     "fp16_mfma_frac = issued fp16 MFMA FLOP (3 per product in the split mode, 1 in the fp16 mode) / 2.5 PFLOP/s"
-                    + ("; traffic: counters of round 3, collected on the 12-wave kernel of the default math (since round 5 the "
-                       "default math runs in 8-wave workgroups: the same activations, the weights twice per CU)"
+                    + ("; traffic: profiles/wf_layer_c64_traffic.json (tools/pmc_traffic.py)"
                        if traffic is not None and channels == 64 else "")}
+    if oracle_check:
+        # BASELINE config 5 against the CPU oracle itself (the checker's role, like parity_check): utterance 0 of the timed call
+        from oracle import waveflow_ref
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+        st = syn.waveflow_state(wcfg)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            want = waveflow_ref.infer(st, mels[0].cpu()[None], zs[0].cpu()[None], wcfg)[0].numpy()
+        got = out[0].cpu().numpy()
+        ent["oracle_check"] = {"what": "utterance 0 of the 8 x 640 call vs oracle/waveflow_ref.infer (torch-CPU fp32)",
+                               "relmax": float(np.abs(got - want).max() / np.abs(want).max()), "oracle_s": time.perf_counter() - t1,
+                               "bar": 2e-3 if math == "f16" else 1e-5}
     del wf
     return ent
 
@@ -1010,7 +1020,8 @@ def main():
 
     def waveflow(wf_c, wmath):
         key = f"waveflow_c{wf_c}_batch8" + ("_fp16" if wmath else "")
-        guarded(key, lambda: extras.__setitem__(key, waveflow_extra(wf_c, ctx, math=wmath)))
+        check = wf_c == 64 and not args.no_cpu_baseline      # (config 5 itself: both maths against the oracle)
+        guarded(key, lambda: extras.__setitem__(key, waveflow_extra(wf_c, ctx, math=wmath, oracle_check=check)))
 
     def extras_core():
         _log("extras (core): strict fp32, FastSpeech2 / PWG alone, WaveFlow config 5")
