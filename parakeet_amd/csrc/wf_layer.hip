@@ -213,6 +213,17 @@ __device__ __forceinline__ float xor32(float v, int lane, bool own_lane) {
 }
 __device__ __forceinline__ f16x8 ld_h8(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ void st_h8(char* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
+// Round 6: the 64-channel kernels store the next layer's planes with non-temporal stores -- 21 MB per launch that the kernel
+// boundary then does not have to write back from L2 (one-box A/B, profiles/r06_wf_ab.txt: 64 channels -1.5 % in both maths;
+// 128 channels -0.4 % / +0.6 %: left as plain stores).  PK_WF_NT_STORE=0: plain stores everywhere (the A/B).
+#ifndef PK_WF_NT_STORE
+#define PK_WF_NT_STORE 1
+#endif
+template <bool NT>
+__device__ __forceinline__ void st_h8_out(char* p, f16x8 v) {
+    if constexpr (NT && PK_WF_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<f16x8*>(p));
+    else *reinterpret_cast<f16x8*>(p) = v;
+}
 
 // An opaque zero (ON) or a literal one: values derived from it cannot be hoisted out of the place it is renewed.  The 12-wave
 // kernel (168 registers) uses it to keep round- and epilogue-only address arithmetic from living in registers through the slab
@@ -875,8 +886,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     f16x8 oh, ol;
                     store_pair8(t8, so, oh, ol);
                     if ((ABL & 4) && oh[0] != (_Float16)12345.f) continue;   // (never equal: keeps the arithmetic)
-                    st_h8(dst + kq * 2048, oh);
-                    st_h8(dst + kq * 2048 + 16, ol);
+                    st_h8_out<CT == 2>(dst + kq * 2048, oh);
+                    st_h8_out<CT == 2>(dst + kq * 2048 + 16, ol);
                 }
                 if (lane_e == 0) cd.out_amax[p0 >> 5] = __float_as_uint(am);
             }

@@ -18,7 +18,7 @@ zs = [torch.randn(m.lengths(L)[0], device='cuda') for _ in range(B)]
 ctx = Context.get()
 out = m.infer_batch(mels, zs); torch.cuda.synchronize()
 assert all(bool(torch.isfinite(o).all()) for o in out)
-t=time.time(); n=2
+t=time.time(); n=5
 for i in range(n): m.infer_batch(mels, zs)
 t_enq=(time.time()-t)/n     # host time to ENQUEUE a batch (no synchronisation inside infer_batch with device-resident I/O)
 torch.cuda.synchronize(); dt=(time.time()-t)/n
