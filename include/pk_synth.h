@@ -304,14 +304,14 @@ int pk_wf_set_param(pk_wf* h, const char* name, const float* data, const int64_t
  * waveform's peak away from the fp64 oracle; 64- and 128-channel models only (PK_EUNSUPPORTED otherwise). */
 int pk_wf_set_math(pk_wf* h, int32_t mode);
 /* Named integer options (as pk_pwg_set_option; scheduling only, results do not change):
- *   "layer_waves"  0 (default) = with fp16 operands (pk_wf_set_math 2) the fused layer kernel of the 64-channel model runs in
- *                  12-wave workgroups where that saves a round over 8-wave ones; in the default math always 8-wave workgroups.
- *                  8 / 12 = forced.  12 with the default math, and 6 (two 6-wave workgroups per CU), are refused when the call is
- *                  made (PK_EUNSUPPORTED): three waves per SIMD running the default math's back-to-back dependent matrix
- *                  instructions gave non-deterministic results on the MI355X (round 5, HISTORY.md 9.9)
+ *   "layer_waves"  0 (default) = the fused layer kernel of the 64-channel model runs in 12-wave workgroups (three waves per SIMD)
+ *                  where that saves a round over 8-wave ones (BASELINE config 5's 8 x 640 frames: 11 tiles per workgroup), in both
+ *                  maths; 6 / 8 / 12 = forced (6: two 6-wave workgroups per CU).  Same waveform bit for bit whatever the value.
+ *                  (Round 5 refused three waves per SIMD in the default math: sporadic wrong tiles.  Round 6 found the cause -- a
+ *                  packed fp32 FMA with op_sel, DESIGN.md 4.3 "the op_sel rule" -- and every configuration is back.)
  *   "persistent"   0 only.  (1 = the layers of a row in ONE cooperative launch with a barrier across the grid between two layers:
- *                  measured slower than eight launches in round 4, found non-deterministic beyond small sizes in round 5;
- *                  PK_EUNSUPPORTED in the product, kept in the profile build)
+ *                  measured slower than eight launches in round 4; PK_EUNSUPPORTED in the product, a measurement configuration of
+ *                  the profile build)
  *   "fuse_step"    1 (default) = a row's affine step and the next row's input projection happen in the launch of its last
  *                  layer; 0 = in a kernel of their own */
 int pk_wf_set_option(pk_wf* h, const char* key, int64_t value);
