@@ -215,18 +215,34 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
 // Planes path: max|noise| per utterance, then per work tile the scale exponents of x for every layer from the magnitude bound
 // B_0 = wmax * max|noise| + bmax, B_(l+1) = (B_l + c_l) * sqrt(0.5) (a hair of slack for the engine's own rounding);
 // tile_kx[l * ntiles + tile] = blk_scale_exp(B_l) (pk_split.h), l = 0 .. layers (the last row: the final x).
+// (round 6: NMAX_PARTS workgroups per utterance, 16-byte loads, the partial maxima folded with an integer atomic max --
+// non-negative floats order like their bit patterns; one workgroup per utterance with dword loads took 0.15 ms of the step)
+constexpr int NMAX_PARTS = 16;
 __global__ __launch_bounds__(256) void k_pwg_noise_max(const float* __restrict__ noise, const int* __restrict__ utt_off,
                                                        const int* __restrict__ utt_S, float* __restrict__ nmax) {
     __shared__ float red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, S = utt_S[b];
     const float* p = noise + utt_off[b];
+    const int per = ((S + NMAX_PARTS - 1) / NMAX_PARTS + 3) & ~3;          // samples per part, a multiple of 4
+    const int lo = blockIdx.y * per, hi = min(lo + per, S);
     float m = 0.f;
-    for (int i = threadIdx.x; i < utt_S[b]; i += 256) m = fmaxf(m, fabsf(p[i]));
+    // head up to a 16-byte boundary, body in float4, tail
+    int i0 = lo + (int)threadIdx.x;
+    const int head = min(hi, lo + (int)((4 - ((reinterpret_cast<size_t>(p + lo) >> 2) & 3)) & 3));
+    if (i0 < head) m = fabsf(p[i0]);
+    const int nb = (hi - head) >> 2;
+    const f32x4* q = reinterpret_cast<const f32x4*>(p + head);
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const f32x4 v = q[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (int i = head + 4 * nb + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(p[i]));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) nmax[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(nmax) + b, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 __global__ __launch_bounds__(256) void k_pwg_tile_scales(const int* __restrict__ tile_utt, int ntiles,
                                                          const float* __restrict__ nmax, float wmax, float bmax,
@@ -2122,7 +2138,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         PK_TRY(h->ws_nmax.reserve((size_t)B * 4));
         PK_TRY(h->ws_tkx.reserve((size_t)(c.layers + 1) * sumC * 4));
         tkx = h->ws_tkx.as<int>();
-        PK_LAUNCH(ctx, "pwg_noise_max", k_pwg_noise_max, dim3(B), dim3(256), 0, d_noise, d_tab + o_uoff, d_tab + o_uS,
+        PK_HIP(hipMemsetAsync(h->ws_nmax.p, 0, (size_t)B * 4, ctx->stream));
+        PK_LAUNCH(ctx, "pwg_noise_max", k_pwg_noise_max, dim3(B, NMAX_PARTS), dim3(256), 0, d_noise, d_tab + o_uoff, d_tab + o_uS,
                   h->ws_nmax.as<float>());
         PK_LAUNCH(ctx, "pwg_tile_scales", k_pwg_tile_scales, dim3(pk_div_up(sumC, 256)), dim3(256), 0, d_tab + o_tutt, sumC,
                   h->ws_nmax.as<float>(), h->first_wmax, h->first_bmax, h->d_cl.as<float>(), c.layers, tkx);
