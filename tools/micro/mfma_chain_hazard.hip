@@ -481,7 +481,19 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
         const float w0 = 3.f * (float)(((pl >> 2) + it) & 31) + c0, w1 = 5.f * (float)(((pl >> 1) + 3 * it) & 31) + c1;   // (PK 2 / 3: 4 x 0.75 = 3, 4 x 1.25 = 5)
         float o0, o1;
         float x0 = w0, x1 = w1;
-        if (PK >= 4 && PK <= 15) {   // the partner's sums: z pairs (a0,a1) (a1,a0) (a0,a0) (a1,a1) at lane ^ 32, weights of ITS half wave
+        if (PK == 15) {   // {x0, x1} = ({c0, c1} + sum_i z_i.lo {w_2i, w_2i+1}) * c0 + 1 with z pairs (a0,a1) (a1,a0) (a0,a0) (a1,a1), twice
+            const float pa0 = (float)(((pl >> 2) + it) & 31), pa1 = (float)(((pl >> 1) + 3 * it) & 31);
+            const float zlo[4] = {pa0, pa1, pa0, pa1};
+            const float* w = wtab + (pl >> 5) * 16;
+            x0 = c0;
+            x1 = c1;
+            for (int i = 0; i < 8; ++i) {
+                x0 += zlo[i & 3] * w[2 * i];
+                x1 += zlo[i & 3] * w[2 * i + 1];
+            }
+            x0 = x0 * c0 + 1.f;
+            x1 = x1 * c0 + 1.f;
+        } else if (PK >= 4 && PK <= 15) {   // the partner's sums: z pairs (a0,a1) (a1,a0) (a0,a0) (a1,a1) at lane ^ 32, weights of ITS half wave
             const float pa0 = (float)(((pl >> 2) + it) & 31), pa1 = (float)(((pl >> 1) + 3 * it) & 31);
             const float zlo[4] = {pa0, pa1, pa0, pa1}, zhi[4] = {pa1, pa0, pa0, pa1};
             const float* w = wtab + (pl >> 5) * 16;
@@ -606,6 +618,18 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
                              PKF("v[100:101]", "v[114:115]", "v[144:145]", "v[100:101]", "")
                              "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS,
                              "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145");
+            else if (PK == 15)      // the forms of the HEADLINE kernels (PWG layer: 2 560 of them): op_sel_hi only -- the HIGH half from a LOW register (a broadcast)
+                asm volatile(HEAD "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
+                             PKF("v[100:101]", "v[116:117]", "v[100:101]", "v[124:125]", "op_sel_hi:[0,1,1]") "v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
+                             PKF("v[100:101]", "v[118:119]", "v[102:103]", "v[100:101]", "op_sel_hi:[0,1,1]") "v_cvt_pkrtz_f16_f32 v126, v120, v121\n"
+                             PKF("v[100:101]", "v[120:121]", "v[104:105]", "v[100:101]", "op_sel_hi:[0,1,1]") "v_cvt_pkrtz_f16_f32 v127, v122, v123\n"
+                             PKF("v[100:101]", "v[122:123]", "v[106:107]", "v[100:101]", "op_sel_hi:[0,1,1]")
+                             PKF("v[100:101]", "v[116:117]", "v[108:109]", "v[100:101]", "op_sel_hi:[0,1,1]")
+                             PKF("v[100:101]", "v[118:119]", "v[110:111]", "v[100:101]", "op_sel_hi:[0,1,1]")
+                             PKF("v[100:101]", "v[120:121]", "v[112:113]", "v[100:101]", "op_sel_hi:[0,1,1]") FILL
+                             PKF("v[100:101]", "v[122:123]", "v[114:115]", "v[100:101]", "op_sel_hi:[0,1,1]")
+                             "v_pk_mul_f32 v[100:101], v[100:101], v[124:125] op_sel_hi:[1,0]\n v_pk_add_f32 v[100:101], v[100:101], 1.0 op_sel_hi:[1,0]\n"
+                             "ds_bpermute_b32 v104, %6, v100\n ds_bpermute_b32 v105, %6, v101\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n" OPS);
             else if (PK == 14)      // 11, and the sums read back DIRECTLY (v_mov of the accumulator, lane by lane through the exchange of an untouched copy): is it the FMA or the exchange?
                 asm volatile(HEAD "s_waitcnt lgkmcnt(0)\n s_nop 1\n"
                              PKF("v[100:101]", "v[100:101]", "v[116:117]", "v[124:125]", LO) "v_cvt_pkrtz_f16_f32 v127, v118, v119\n"
@@ -660,7 +684,7 @@ __global__ __launch_bounds__(768, 3) void k_bperm(Args g, unsigned iters) {
         }
 #undef NOPS
         const bool bad = o0 != x0 || o1 != x1;
-        if (bad && PK >= 4 && PK <= 15 && o0 != x0) {
+        if (bad && PK >= 4 && PK <= 14 && o0 != x0) {
             // how old is the value that arrived?  the partner's logs sum after k of its 8 packed FMAs, k = 0 .. 7 (8 = none of them)
             const float pa0 = (float)(((pl >> 2) + it) & 31), pa1 = (float)(((pl >> 1) + 3 * it) & 31);
             const float zlo[4] = {pa0, pa1, pa0, pa1}, zhi[4] = {pa1, pa0, pa0, pa1};
@@ -858,6 +882,7 @@ int main(int argc, char** argv) {
         bperm<12, 0>("as the last, without the other vector instructions between the packed FMAs", g, r, iters);
         bperm<13, 0>("as the last but one, no op_sel on any packed FMA (the z pairs duplicated by v_mov beforehand)", g, r, iters);
         bperm<14, 0>("as that, the sums copied by v_mov 16 wait states later and the COPY exchanged (is it the FMA or the exchange?)", g, r, iters);
+        bperm<15, 0>("the headline kernels' packed forms: op_sel_hi only (v_pk_fma op_sel_hi:[0,1,1] x 8, v_pk_mul / v_pk_add op_sel_hi:[1,0])", g, r, iters);
         if (getenv("MICRO_TAIL_ONLY")) return 0;
         bperm<2, 0>("four dependent v_pk_fma_f32 into v[d:d+1] ; ds_bpermute_b32 of v[d] ; of v[d+1]  (as compiled; matrix instructions back to back)", g, r, iters);
         bperm<3, 0>("four dependent v_pk_fma_f32 into v[d:d+1] ; s_nop 0 ; ds_bpermute_b32 of v[d] ; of v[d+1]", g, r, iters);
