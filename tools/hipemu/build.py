@@ -28,7 +28,7 @@ _FMA_MIX = re.compile(r'asm\("v_fma_mix_f32 %0, %1, -1\.0, %2 op_sel:\[(\d),0,0\
                       r'"v"\((\w+)\),\s*"v"\(([^;]+)\)\);')
 
 
-_OPAQUE = re.compile(r'asm volatile\(""\s*:\s*"\+[sv]"\(([\w\[\]]+)\)\);')   # "the compiler may not reason about this value": nothing to emulate
+_OPAQUE = re.compile(r'asm volatile\(""\s*:\s*"\+[sv]"\(([\w\[\]]+)\)(?:\s*,\s*"\+[sv]"\([\w\[\]]+\))*\);')   # "the compiler may not reason about this value" (one or more operands): nothing to emulate
 _NOP = re.compile(r'asm volatile\("s_nop \d+"\);')                               # issue-slot padding (wf_layer.hip, round 5): nothing to emulate
 
 

@@ -44,7 +44,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorLaunchFailure = 719 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorLaunchFailure = 719 };
 typedef struct hipemu_stream* hipStream_t;
 typedef struct hipemu_event* hipEvent_t;
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
@@ -285,6 +285,7 @@ using std::min;
 // single host thread: plain read-modify-write is atomic with respect to the other fibers
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 
