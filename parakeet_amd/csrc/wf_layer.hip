@@ -842,15 +842,11 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 const float xs = pow2f(-(PK_BLK_TOP + 127 - amax_exp(cur_am)));   // the stored input is x * 2^k
                 float v[CT][16];
                 float am = 0.f;
-                // Round 5 (HISTORY 9.9): x_in FIRST, all of it, and only then the accumulators.  The out projection ends in
-                // CT interleaved dependent MFMA chains; the compiler guards the first read of an accumulator with the minimum
-                // the hazard table asks for (s_nop 10: 12 issue slots after that accumulator's last MFMA).  With a second
-                // working wave on the SIMD (its MFMAs in the same pipe) that was one slot short now and then: the 64-channel
-                // kernels returned a few wrong tiles per call (errors of 1e-3, different on every run) whenever a workgroup had
-                // more than four tiles -- found by hand-editing the assembly (same size: only that s_nop widened to 15 cures
-                // it; tools/asm_variant.py, tools/mfma_slack.py).  The 4 CT x 8 conversions and multiply-adds below do not touch
-                // the accumulators: > 100 issue slots between the last MFMA and the first read, at no cost (they were there
-                // anyway, interleaved with the reads).
+                // x_in first, all of it, and only then the accumulators (round 5 put this order and the s_nop below in against what it took for
+                // a short MFMA -> VALU distance; round 6 showed that distance to be safe down to 8 slots and the wrong tiles to be the op_sel
+                // defect of the sums above -- HISTORY 10.3; the order costs nothing and stays).
+                // Gap positions are zero in the planes: their scale factors are zero (bit-identical to a select per element, 64 of them).
+                const float xs_l = lane_ok ? xs : 0.f, i_res_l = lane_ok ? i_res : 0.f;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < CT; ++t)
@@ -858,7 +854,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                     for (int r = 0; r < 16; ++r) {
                         const int kq = 2 * t + (r >> 3), e = r & 7;
                         // x_in = (hi + lo) * 2^-k: one multiply and one v_fma_mix (the halves are sources)
-                        v[t][r] = fmaf((float)xin_hi[kq][e], xs, (float)xin_lo[kq][e] * xs);
+                        v[t][r] = fmaf((float)xin_hi[kq][e], xs_l, (float)xin_lo[kq][e] * xs_l);
                         asm volatile("" : "+v"(v[t][r]));   // (computed HERE: pure arithmetic would sink to its use behind the barrier)
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -870,8 +866,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 3) void k_wf_layer_p(WflLaunch
                 for (int t = 0; t < CT; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float o = fmaf(acc2[t][r], i_res, v[t][r]);   // res + x_in
-                        if (!lane_ok) o = 0.f;   // gap positions stay zero
+                        const float o = fmaf(acc2[t][r], i_res_l, v[t][r]);   // res + x_in (gap positions: 0 * finite + 0)
                         am = fmaxf(am, fabsf(o));
                         v[t][r] = o;
                     }
