@@ -44,6 +44,16 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Round 6 (profiles/r06_pwg_nt_ab.txt): the layer kernel's skip stream (read once, written once per layer: 512 of the 1 024 B per sample) and its
+// x-plane stores are non-temporal accesses -- they no longer displace the x lines the other two taps re-read from the XCD's L2, and the kernel
+// boundary has less to write back.  One-box A/B, three interleaved repetitions, same waveform bit for bit: skip 1 333 -> 1 313 us per launch,
+// both 1 314 (41.14 -> 40.45 ms per 30 layers, -1.7 %).  0 = plain accesses (the A/B).
+#ifndef PK_PWG_NT_SKIP
+#define PK_PWG_NT_SKIP 1
+#endif
+#ifndef PK_PWG_NT_XOUT
+#define PK_PWG_NT_XOUT 1
+#endif
 #ifndef PK_PWG_GATE_SCALAR
 #define PK_PWG_GATE_SCALAR 0   // 1: the layer kernel's gate on scalar fp32 instructions (round 6 A/B: packed fp32 beside matrix instructions, profiles/r06_pwg_packed_ab.txt)
 #endif
@@ -1115,7 +1125,9 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            sk_old[16 * qq + r] = (ABL & 1) ? 0.5f : (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4];
+                            sk_old[16 * qq + r] = (ABL & 1) ? 0.5f
+                                                            : (PK_PWG_NT_SKIP ? __builtin_nontemporal_load((a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK) + vo4)
+                                                                              : (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // W2 fragments of the next (pass, ks, q) in issue order
@@ -1177,6 +1189,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     }
                     if constexpr (PL) {
                         if (pass == 0) acc2[q][r] = v;   // stored below, once the block's maximum (its scale) is known
+                        else if (PK_PWG_NT_SKIP) __builtin_nontemporal_store(v, (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK) + vo4);
                         else (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                     } else {
                         if (!(ABL & 1) || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
@@ -1200,8 +1213,13 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                             for (int e = 0; e < 8; ++e) t8[e] = acc2[cg >> 1][8 * (cg & 1) + e];
                             pl_f16x8 oh, ol;
                             split_x8s(t8, so, oh, ol);
-                            *reinterpret_cast<pl_f16x8*>(pd + cg * 2048) = oh;
-                            *reinterpret_cast<pl_f16x8*>(pd + cg * 2048 + 16) = ol;
+                            if (PK_PWG_NT_XOUT) {
+                                __builtin_nontemporal_store(oh, reinterpret_cast<pl_f16x8*>(pd + cg * 2048));
+                                __builtin_nontemporal_store(ol, reinterpret_cast<pl_f16x8*>(pd + cg * 2048 + 16));
+                            } else {
+                                *reinterpret_cast<pl_f16x8*>(pd + cg * 2048) = oh;
+                                *reinterpret_cast<pl_f16x8*>(pd + cg * 2048 + 16) = ol;
+                            }
                         }
                     }
                 }
