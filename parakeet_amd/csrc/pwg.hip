@@ -48,6 +48,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // x-plane stores are non-temporal accesses -- they no longer displace the x lines the other two taps re-read from the XCD's L2, and the kernel
 // boundary has less to write back.  One-box A/B, three interleaved repetitions, same waveform bit for bit: skip 1 333 -> 1 313 us per launch,
 // both 1 314 (41.14 -> 40.45 ms per 30 layers, -1.7 %).  0 = plain accesses (the A/B).
+// Round 6 (profiles/r06_pwg_tile_map.txt): which wave of an XCD takes which wave tile of the XCD's window of a sweep.  A tile's +-d taps are the centre
+// taps of the tiles d / 32 further on, so a line is fetched from HBM once only if those tiles run while it is still in the XCD's L2 -- and the two
+// waves of a SIMD run half a tile (8 us) apart, the time the L2 holds this stream.  FETCH_SIZE per launch by dilation showed it: with tile = 8 * workgroup
+// + wave, the launches with d = 64 / 128 (partner = wave +-2 / +-4 of the same workgroup) fetched 1.5 x the bytes of d <= 4, those with d = 256 / 512
+// (partner = the SAME wave of the next workgroups) 1.1 x.  1: the first waves of the SIMDs (0..3 of every workgroup) take the first half of the window,
+// the second waves the second half -- fetched bytes -12 %, launch 1 316 -> 1 291 us, same waveform bit for bit.  0 = workgroup-major (the A/B),
+// 2 = wave-major (as good), 3 = SIMD-major (the two waves of a SIMD on adjacent tiles: worse, which confirms the reading).
+#ifndef PK_PWG_TILE_MAP
+#define PK_PWG_TILE_MAP 1
+#endif
 #ifndef PK_PWG_NT_SKIP
 #define PK_PWG_NT_SKIP 1
 #endif
@@ -792,7 +802,17 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
     const int per_xcd = gridDim.x >> 3;
     const int wg_slot = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)
                                              : (int)blockIdx.x;
-    const int my_slot = wg_slot * LAYER_WAVES + wave;
+    int my_slot = wg_slot * LAYER_WAVES + wave;
+#if PK_PWG_TILE_MAP
+    // which wave of the XCD's window of 8 * per_xcd wave tiles takes which tile (PK_PWG_TILE_MAP above)
+    if ((gridDim.x & 7) == 0) {
+        const int wgl = (int)(blockIdx.x >> 3), win = per_xcd * LAYER_WAVES;
+        const int local = PK_PWG_TILE_MAP == 1 ? (wave >> 2) * (win >> 1) + wgl * 4 + (wave & 3)      // first / second wave of the SIMDs: halves
+                        : PK_PWG_TILE_MAP == 2 ? wave * per_xcd + wgl                                  // wave-major
+                                               : (wave & 3) * (win >> 2) + wgl * 2 + (wave >> 2);      // SIMD-major
+        my_slot = (int)(blockIdx.x & 7) * win + local;
+    }
+#endif
     const int stride_slots = (int)gridDim.x * LAYER_WAVES;
     const int n_wtiles = a.ntiles * (TILE / WAVE_T);
 

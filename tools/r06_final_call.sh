@@ -44,3 +44,5 @@ pmc fA "fs2 32" "$SQ"; pmc fB "fs2 32" "$LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_
 python $R/tools/pmc_parse.py $OUT/pmc_fA $OUT/pmc_fB --kernel=k_ > $OUT/pmc_fs2.json
 find $OUT -maxdepth 1 -type d -name "pmc_*" | xargs rm -rf
 ls -la $OUT
+# ---- repeat-run identity of the other hot kernels (the WaveFlow gate is in the suite)
+cd $R && timeout 400 python tools/repeat_runs.py 40 > $OUT/repeat_runs.txt 2>&1; cat $OUT/repeat_runs.txt
