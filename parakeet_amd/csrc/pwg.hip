@@ -61,9 +61,41 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PK_PWG_NT_SKIP
 #define PK_PWG_NT_SKIP 1
 #endif
+// measurement: the skip stream at another cache policy than `nt` -- 1: agent scope (sc1), 2: system scope (sc0 sc1), 3: workgroup scope (sc0)
+#ifndef PK_PWG_SKIP_SCOPE
+#define PK_PWG_SKIP_SCOPE 0
+#endif
 #ifndef PK_PWG_NT_XOUT
 #define PK_PWG_NT_XOUT 1
 #endif
+namespace {
+__device__ __forceinline__ float pwg_skip_ld(const float* p) {
+#if PK_PWG_SKIP_SCOPE == 1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif PK_PWG_SKIP_SCOPE == 2
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif PK_PWG_SKIP_SCOPE == 3
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif PK_PWG_NT_SKIP
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void pwg_skip_st(float v, float* p) {
+#if PK_PWG_SKIP_SCOPE == 1
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif PK_PWG_SKIP_SCOPE == 2
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif PK_PWG_SKIP_SCOPE == 3
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif PK_PWG_NT_SKIP
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+}  // namespace
 #ifndef PK_PWG_GATE_SCALAR
 #define PK_PWG_GATE_SCALAR 0   // 1: the layer kernel's gate on scalar fp32 instructions (round 6 A/B: packed fp32 beside matrix instructions, profiles/r06_pwg_packed_ab.txt)
 #endif
@@ -1146,8 +1178,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             sk_old[16 * qq + r] = (ABL & 1) ? 0.5f
-                                                            : (PK_PWG_NT_SKIP ? __builtin_nontemporal_load((a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK) + vo4)
-                                                                              : (a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK)[vo4]);
+                                                            : pwg_skip_ld((a.skip + (long)(32 * qq + mfma_row(r, 0)) * XBLK) + vo4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // W2 fragments of the next (pass, ks, q) in issue order
@@ -1209,8 +1240,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     }
                     if constexpr (PL) {
                         if (pass == 0) acc2[q][r] = v;   // stored below, once the block's maximum (its scale) is known
-                        else if (PK_PWG_NT_SKIP) __builtin_nontemporal_store(v, (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK) + vo4);
-                        else (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
+                        else pwg_skip_st(v, (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK) + vo4);
                     } else {
                         if (!(ABL & 1) || a.Ttot < 0) (dst + (long)(32 * q + mfma_row(r, 0)) * XBLK)[vo4] = v;
                     }
