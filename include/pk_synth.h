@@ -157,7 +157,8 @@ int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples);
  *                  2^10 anywhere, the call is repeated on the "planes" = 0 path, which the handle then keeps; 2 = every call.
  *                  A guarded call synchronises the stream once and does two small blocking copies INSIDE pk_pwg_infer: the
  *                  first call after finalize stalls a pipelined caller and must not be stream-captured.
- *                  Under 1 every "scale_guard_every"-th later inference is SAMPLED as well (same 31 small launches), its
+ *                  Under 1 every "scale_guard_every"-th later inference is SAMPLED as well (the layer kernel folds each layer's maxima
+ *                  in from its epilogue on such calls: one extra small launch, not a pass over x per layer), its
  *                  verdict deferred: the maxima are copied to pinned host memory behind an event and judged at the start of
  *                  a later call -- no stall, no allocation (the pinned buffer, 0.5 MB for up to 4096 utterances, and the
  *                  event are created by pk_pwg_finalize; a call with more utterances is not sampled; a sample whose event

@@ -65,6 +65,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PK_PWG_SKIP_SCOPE
 #define PK_PWG_SKIP_SCOPE 0
 #endif
+#ifndef PK_PWG_AMAX_PROBE   // measurement: 1 = the AMAX instantiations without their atomics (what the reduction and the register pressure cost)
+#define PK_PWG_AMAX_PROBE 0
+#endif
 #ifndef PK_PWG_NT_XOUT
 #define PK_PWG_NT_XOUT 1
 #endif
@@ -310,8 +313,10 @@ __global__ __launch_bounds__(256) void k_pwg_tile_scales(const int* __restrict__
 
 // "scale_guard" (pk_pwg_set_option): the measured side of the a-priori bound.  max|x| per utterance of one layer's planes --
 // a workgroup per 256-sample work tile decodes its 8 blocks ((hi + lo) / 2^k) and folds the tile's maximum into amax[utterance]
-// (non-negative floats order like their bit patterns).  30 + 1 launches per guarded inference, none otherwise: the layer
-// kernel itself is untouched.
+// (non-negative floats order like their bit patterns).  Round 6: one launch per guarded / sampled inference (the planes of
+// k_pwg_first); the 30 layers' maxima come from the layer kernel's own epilogue on those calls (its AMAX instantiations, which
+// only guarded / sampled calls launch: 30 x 0.28 ms of extra passes over x gone from every 16th call) -- the instantiation every
+// other call runs is untouched.
 __global__ __launch_bounds__(256) void k_pwg_planes_amax(const float* __restrict__ x, const int* __restrict__ tile_t0,
                                                          const int* __restrict__ tile_utt, const int* __restrict__ tile_kx,
                                                          unsigned* __restrict__ amax) {
@@ -336,6 +341,19 @@ __global__ __launch_bounds__(256) void k_pwg_planes_amax(const float* __restrict
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * pow2f(-tile_kx[tile]);
         atomicMax(amax + tile_utt[tile], __float_as_uint(m));
     }
+}
+
+// The layer kernel's AMAX instantiations fold a tile's max|x_out| into parts[(utterance) * PWG_AMAX_PARTS + (workgroup & 31)] -- one address per
+// utterance took +0.3 ms per launch in same-address atomics (163 840 tiles on 32 addresses); the workgroups that share a part sit on one XCD.
+// This folds the parts of all layers into amax[1 + layer][utterance] at the end of the stack.
+constexpr int PWG_AMAX_PARTS = 32;
+__global__ __launch_bounds__(256) void k_pwg_amax_fold(const unsigned* __restrict__ parts, unsigned* __restrict__ amax, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned m = 0;
+#pragma unroll
+    for (int p = 0; p < PWG_AMAX_PARTS; ++p) m = max(m, parts[(size_t)i * PWG_AMAX_PARTS + p]);
+    amax[i] = m;
 }
 
 // Test tap: the sample-rate aux contribution of one layer, aux[co][s] =
@@ -377,6 +395,7 @@ struct PwgLayerArgs {
     float i0, i1;            // sqrt(0.5) / (2^14 * 2^k2out), 1 / (2^14 * 2^k2skip): undo the stage-2 scales
     const int* tile_kx_in;   // PL: [ntiles] scale exponent of xin / of xout per tile (k_pwg_tile_scales)
     const int* tile_kx_out;
+    unsigned* amax_out;      // PL + AMAX (guarded / sampled calls): [B][PWG_AMAX_PARTS] bits of max|xout| per utterance, folded in by the epilogue
     PwgGen gen;              // GEN kernels only (hop != 256)
 };
 
@@ -804,7 +823,7 @@ __device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& h
 // with c_l = max_co (sum_k |W_out[co][k]| + |b_out[co]|) because |z| < 1 (k_pwg_tile_scales).  The bound overshoots the
 // utterance's maximum by a small factor, i.e. the split's error floor moves from 2^-39 of a 32-sample block's maximum to
 // about 2^-36 of the utterance's: elements more than 2^12 below it lose against fp32, by less than 2^-36 of it.
-template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false, bool PL = false>
+template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false, bool PL = false, bool AMAX = false>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
     static_assert(!PL || (HALF && ABL == 0), "planes: the block-scaled split-fp16 path only");
     typedef typename Split16<HALF>::vec bf16x8;     // shadows the bf16 typedef inside this kernel
@@ -1251,6 +1270,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                         am = wave_max64(am);
                         if (lane == 0 && (!(ABL & 1) || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
                     }
+                    if constexpr (PL && AMAX) {   // scale guard: the tile's max|x_out| into its utterance's slot (guarded / sampled calls only)
+                        const float m = wave_max64(am);
+                        if (lane == 0 && (!PK_PWG_AMAX_PROBE || m < 0.f)) atomicMax(a.amax_out + a.gen.tile_utt[wt >> 3] * PWG_AMAX_PARTS + (int)(blockIdx.x & (PWG_AMAX_PARTS - 1)), __float_as_uint(m));
+                    }
                     if constexpr (PL) {   // x_out as planes at its utterance's a-priori scale
                         const float so = pow2f(__builtin_amdgcn_readfirstlane(ko_v));
                         char* pd = reinterpret_cast<char*>(a.xout) + pvo8[1];
@@ -1458,7 +1481,7 @@ struct pk_pwg {
     // measures max|x| per utterance and layer (k_pwg_planes_amax) and compares with the a-priori bound of k_pwg_tile_scales
     int scale_guard = 1;
     bool guard_done = false;   // mode 1: a guarded inference has run since finalize
-    // mode 1 also RE-SAMPLES: every guard_every-th inference on the planes path runs the same 31 measuring launches, but its
+    // mode 1 also RE-SAMPLES: every guard_every-th inference on the planes path measures the same way (AMAX layer kernels + one k_pwg_planes_amax launch), but its
     // verdict is DEFERRED -- maxima copied to pinned host memory behind an event, judged at the start of a later call -- so a
     // pipelined caller never stalls after the first call.  A deferred verdict above the limit moves the handle to the
     // fp32-x path from the next call on (the sampled call itself stays as computed: at the limit of 2^10 the planes still
@@ -2195,11 +2218,14 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     }
     unsigned* amax = nullptr;
     if (guard || sample) {
-        PK_TRY(h->ws_amax.reserve((size_t)(c.layers + 1) * B * sizeof(unsigned)));
+        // [layers + 1][B] maxima, then the layer kernels' parts [layers][B][PWG_AMAX_PARTS] (k_pwg_amax_fold)
+        const size_t n_amax = (size_t)(c.layers + 1) * B + (size_t)c.layers * B * PWG_AMAX_PARTS;
+        PK_TRY(h->ws_amax.reserve(n_amax * sizeof(unsigned)));
         amax = h->ws_amax.as<unsigned>();
-        PK_HIP(hipMemsetAsync(amax, 0, (size_t)(c.layers + 1) * B * sizeof(unsigned), ctx->stream));
+        PK_HIP(hipMemsetAsync(amax, 0, n_amax * sizeof(unsigned), ctx->stream));
     }
     for (int attempt = 0;; ++attempt) {
+    bool amax_parts_used = false;   // AMAX layer kernels ran: their parts are folded into amax[] behind the stack
     h->last_planes = planes;
     int* tkx = nullptr;
     if (planes) {
@@ -2254,6 +2280,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         const int row0 = cuL[chunk_first[ck]];   // first P row of the chunk (== tile0 when hop == 256)
         for (int l = 0; l < c.layers; ++l) {
             PwgLayerArgs a;
+            a.amax_out = nullptr;
             a.xin = (l & 1) ? h->ws_x1.as<float>() : h->ws_x0.as<float>();
             a.xout = (l & 1) ? h->ws_x0.as<float>() : h->ws_x1.as<float>();
             a.skip = h->ws_skip.as<float>();
@@ -2290,7 +2317,17 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 a.w1 = reinterpret_cast<const float*>((half ? h->d_w1h : h->d_w1b).as<char>() + (size_t)l * B3_W1_BYTES);
                 a.w2 = reinterpret_cast<const float*>((half ? h->d_w2h : h->d_w2b).as<char>() + (size_t)l * B3_W2_BYTES);
                 const dim3 blk(LAYER_WAVES * 64);
-                if (planes) {   // (half) x as pre-split planes
+                if (planes && (guard || sample) && !all_first) {   // ... and the scale guard's maxima from the epilogue (AMAX instantiations)
+                    a.amax_out = amax + (size_t)(c.layers + 1) * B + (size_t)l * B * PWG_AMAX_PARTS;
+                    amax_parts_used = true;
+                    if (gen) {
+                        if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true, true, true>), dim3(grid), blk, 0, a);
+                        else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true, true, true>), dim3(grid), blk, 0, a);
+                    } else {
+                        if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, false, true, true>), dim3(grid), blk, 0, a);
+                        else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, false, true, true>), dim3(grid), blk, 0, a);
+                    }
+                } else if (planes) {   // (half) x as pre-split planes
                     if (gen) {
                         if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true, true>), dim3(grid), blk, 0, a);
                         else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true, true>), dim3(grid), blk, 0, a);
@@ -2321,12 +2358,15 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<true, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
             else
                 PK_LAUNCH(ctx, "pwg_layer", (k_pwg_layer<false, false>), dim3(grid), dim3(LAYER_WAVES * 64), 0, a);
-            if ((guard || sample) && planes)
+            if ((guard || sample) && planes && all_first)   // (the all-FIRST measurement configuration keeps the separate pass)
                 PK_LAUNCH(ctx, "pwg_planes_amax", k_pwg_planes_amax, dim3(ntile), dim3(256), 0, a.xout, a.tile_t0, a.gen.tile_utt,
                           a.tile_kx_out, amax + (size_t)(l + 1) * B);
         }
         }
         h->last_x_final = c.layers & 1;
+        if (amax_parts_used)
+            PK_LAUNCH(ctx, "pwg_amax_fold", k_pwg_amax_fold, dim3(pk_div_up(c.layers * B, 256)), dim3(256), 0,
+                      amax + (size_t)(c.layers + 1) * B, amax + B, c.layers * B);
     }
     if (sample) {   // deferred verdict: the maxima travel to pinned memory behind an event; pwg_poll_sample judges them later
         const size_t n_am = (size_t)(c.layers + 1) * B;   // (fits: `sample` is only set for B <= PWG_SAMPLE_MAX_B; buffer and event: pk_pwg_finalize)
