@@ -65,6 +65,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PK_PWG_SKIP_SCOPE
 #define PK_PWG_SKIP_SCOPE 0
 #endif
+#ifndef PK_PWG_NT_EDGE   // k_pwg_first's plane stores and k_pwg_last_h3's skip loads as non-temporal accesses (profiles/r06_pwg_nt_ab.txt)
+#define PK_PWG_NT_EDGE 0
+#endif
 #ifndef PK_PWG_AMAX_PROBE   // measurement: 1 = the AMAX instantiations without their atomics (what the reduction and the register pressure cost)
 #define PK_PWG_AMAX_PROBE 0
 #endif
@@ -261,8 +264,13 @@ __global__ void k_pwg_first(const float* __restrict__ noise, const float* __rest
                 oh[e] = hv;
                 ol[e] = (_Float16)(tv - (float)hv);
             }
-            *reinterpret_cast<pl_f16x8*>(dst + o * 1024) = oh;
-            *reinterpret_cast<pl_f16x8*>(dst + o * 1024 + 16) = ol;
+            if (PK_PWG_NT_EDGE) {
+                __builtin_nontemporal_store(oh, reinterpret_cast<pl_f16x8*>(dst + o * 1024));
+                __builtin_nontemporal_store(ol, reinterpret_cast<pl_f16x8*>(dst + o * 1024 + 16));
+            } else {
+                *reinterpret_cast<pl_f16x8*>(dst + o * 1024) = oh;
+                *reinterpret_cast<pl_f16x8*>(dst + o * 1024 + 16) = ol;
+            }
         }
     }
 }
@@ -1388,7 +1396,8 @@ __global__ __launch_bounds__(512) void k_pwg_last_h3(PwgLastArgs a) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            sv[ks][e] = sb[(long)(32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, 0)) * XBLK];
+            sv[ks][e] = PK_PWG_NT_EDGE ? __builtin_nontemporal_load(sb + (long)(32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, 0)) * XBLK)
+                                       : sb[(long)(32 * (ks >> 1) + mfma_row(8 * (ks & 1) + e, 0)) * XBLK];
     f32x16 acc[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q)

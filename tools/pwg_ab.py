@@ -21,4 +21,5 @@ for i in range(3): gen.inference_batch(mels, noises)
 p = ctx.prof_dump(); ctx.prof_enable(False)
 k = next(k for k in ("pwg_layer_h3", "pwg_layer_b3", "pwg_layer") if k in p)
 h = hashlib.sha256(torch.cat([o.reshape(-1) for o in out]).cpu().numpy().tobytes()).hexdigest()[:12]
-print(f"{sys.argv[1] if len(sys.argv) > 1 else 'run':28s} {dt*1e3:7.2f} ms/batch  layer kernel {p[k][1]/p[k][0]*1e3:8.1f} us x {p[k][0]//3}  wav {h}")
+edge = "  ".join(f"{n} {p[n][1]/p[n][0]*1e3:.1f}" for n in ("pwg_first", "pwg_last", "pwg_last_h3") if n in p)
+print(f"{sys.argv[1] if len(sys.argv) > 1 else 'run':28s} {dt*1e3:7.2f} ms/batch  layer kernel {p[k][1]/p[k][0]*1e3:8.1f} us x {p[k][0]//3}  {edge}  wav {h}")
