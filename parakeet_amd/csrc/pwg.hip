@@ -1020,9 +1020,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         }
         const int t0n = a.tile_t0[next_wt >> 3];   // requested here, first used at k-step T0_USE of stage 1
         int ko_v = 0;   // PL: scale exponent of this tile's x_out
+        int utt_v = 0;  // PL + AMAX: the tile's utterance
         if constexpr (PL) {
             kxn_v = a.tile_kx_in[next_wt >> 3];
             ko_v = a.tile_kx_out[wt >> 3];
+            if constexpr (AMAX) utt_v = a.gen.tile_utt[wt >> 3];   // requested here like ko_v: a load in the epilogue would wait for every prefetched operand
             xs_cur = __uint_as_float(0x3f3504f3u - ((unsigned)kx << 23));   // sqrt(0.5) * 2^-kx
         }
         int cls_next = 0;
@@ -1280,7 +1282,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     }
                     if constexpr (PL && AMAX) {   // scale guard: the tile's max|x_out| into its utterance's slot (guarded / sampled calls only)
                         const float m = wave_max64(am);
-                        if (lane == 0 && (!PK_PWG_AMAX_PROBE || m < 0.f)) atomicMax(a.amax_out + a.gen.tile_utt[wt >> 3] * PWG_AMAX_PARTS + (int)(blockIdx.x & (PWG_AMAX_PARTS - 1)), __float_as_uint(m));
+                        if (lane == 0 && (!PK_PWG_AMAX_PROBE || m < 0.f)) atomicMax(a.amax_out + __builtin_amdgcn_readfirstlane(utt_v) * PWG_AMAX_PARTS + (int)(blockIdx.x & (PWG_AMAX_PARTS - 1)), __float_as_uint(m));
                     }
                     if constexpr (PL) {   // x_out as planes at its utterance's a-priori scale
                         const float so = pow2f(__builtin_amdgcn_readfirstlane(ko_v));
