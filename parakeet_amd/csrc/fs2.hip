@@ -1470,6 +1470,39 @@ int pk_fft_run_attention(pk_fft_core* h, const Timeline& tl, const float* qkv, f
 // after_norm.  The LayerNorms ping-pong between the two A-wide row buffers (their output is the next residual stream);
 // operand scales of the split-fp16 GEMMs come from passes over the data (the LayerNorm-based magnitude bounds of the
 // pre-norm path do not apply to layer 0's input).
+// Several small clears as ONE launch.  A hipMemsetAsync is a kernel launch of its own, and a FastSpeech2 call issued 43 of them (rocprofv3,
+// round 6): the six clears of a stack and the three of a planes work buffer each go out together now.
+namespace {
+constexpr int ZERO_LIST_MAX = 8;
+struct ZeroList {
+    unsigned* p[ZERO_LIST_MAX];
+    unsigned words[ZERO_LIST_MAX];
+};
+__global__ __launch_bounds__(256) void k_zero_list(ZeroList z) {
+    unsigned* p = z.p[blockIdx.y];
+    const unsigned n = z.words[blockIdx.y];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) p[i] = 0u;
+}
+struct ZeroItems {
+    ZeroList z;
+    int n = 0;
+    int add(void* p, size_t bytes) {
+        if (!p || bytes == 0) return PK_OK;
+        // (whole 32-bit words: every user is an array of floats / unsigneds; a pk_dbuf's capacity may end in a few spare bytes)
+        if (n == ZERO_LIST_MAX || bytes > ((size_t)1 << 33)) PK_FAIL(PK_EINVAL, "zero_list: %d entries / %zu bytes", n, bytes);
+        z.p[n] = static_cast<unsigned*>(p);
+        z.words[n++] = (unsigned)(bytes >> 2);
+        return PK_OK;
+    }
+    int launch(pk_ctx* ctx) {
+        if (n == 0) return PK_OK;
+        for (int i = n; i < ZERO_LIST_MAX; ++i) { z.p[i] = nullptr; z.words[i] = 0; }
+        PK_LAUNCH(ctx, "zero_list", k_zero_list, dim3(32, n), dim3(256), 0, z);
+        return PK_OK;
+    }
+};
+}  // namespace
+
 static int run_stack_postnorm(pk_fft_core* h, const std::vector<FftLayer>& layers, const Timeline& tl, int units, float* hs_out) {
     const int A = h->adim;
     PK_TRY(pk_fft_act_reserve(h->d_h, tl.rows, A));
@@ -1532,19 +1565,20 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
     // attention output or the FFN hidden activations is needed for the operand scales
     float *ham = nullptr, *cbnd = nullptr, *fbnd = nullptr;
     unsigned* segb = nullptr;
+    ZeroItems zl;   // the per-run clears below, one launch
     const int heads = h->aheads;
     const bool bounds = h->math == PK_GEMM_MATH_F16X3 && heads <= FS2_MAX_HEADS && !h->no_bounds;
     if (h->math == PK_GEMM_MATH_F16X3) {
         PK_TRY(pk_fft_act_reserve(h->d_lnamax, tl.rows, 1));
-        PK_HIP(hipMemsetAsync(h->d_lnamax.p, 0, h->d_lnamax.cap, h->ctx->stream));
+        PK_TRY(zl.add(h->d_lnamax.p, h->d_lnamax.cap));
         ham = pk_fft_act_ptr(h->d_lnamax, 1);
     }
     if (bounds) {
         PK_TRY(pk_fft_act_reserve(h->d_cbnd, tl.rows, 1));
         PK_TRY(pk_fft_act_reserve(h->d_fbnd, tl.rows, 1));
         PK_TRY(h->d_segb.reserve((size_t)tl.B * heads * 3 * sizeof(unsigned)));
-        PK_HIP(hipMemsetAsync(h->d_cbnd.p, 0, h->d_cbnd.cap, h->ctx->stream));
-        PK_HIP(hipMemsetAsync(h->d_fbnd.p, 0, h->d_fbnd.cap, h->ctx->stream));
+        PK_TRY(zl.add(h->d_cbnd.p, h->d_cbnd.cap));
+        PK_TRY(zl.add(h->d_fbnd.p, h->d_fbnd.cap));
         cbnd = pk_fft_act_ptr(h->d_cbnd, 1);
         fbnd = pk_fft_act_ptr(h->d_fbnd, 1);
         segb = h->d_segb.as<unsigned>();
@@ -1567,16 +1601,17 @@ int pk_fft_run_stack(pk_fft_core* h, const std::vector<FftLayer>& layers, size_t
             if (pb[i]->p != p0) PK_HIP(hipMemsetAsync(pb[i]->p, 0, pb[i]->cap, h->ctx->stream));
         }
         PK_TRY(h->d_pam.reserve((size_t)2 * (tl.rows_alloc + 2) * sizeof(unsigned)));
-        PK_HIP(hipMemsetAsync(h->d_pam.p, 0, (size_t)2 * (tl.rows_alloc + 2) * sizeof(unsigned), h->ctx->stream));
+        PK_TRY(zl.add(h->d_pam.p, (size_t)2 * (tl.rows_alloc + 2) * sizeof(unsigned)));
         hp = h->d_hp.as<char>() + (size_t)A * 128;
         fp = h->d_fp.as<char>() + (size_t)units * 128;
         // the margin block BEHIND the last block may hold planes of an earlier, longer timeline: cleared per run, so that the
         // +1 taps of the last tile read zeros whatever ran before (the leading margin block is never written)
-        PK_HIP(hipMemsetAsync(hp + (size_t)nblk * A * 128, 0, (size_t)A * 128, h->ctx->stream));
-        PK_HIP(hipMemsetAsync(fp + (size_t)nblk * units * 128, 0, (size_t)units * 128, h->ctx->stream));
+        PK_TRY(zl.add(hp + (size_t)nblk * A * 128, (size_t)A * 128));
+        PK_TRY(zl.add(fp + (size_t)nblk * units * 128, (size_t)units * 128));
         hpam = h->d_pam.as<unsigned>() + 1;   // row maxima (fp32 bits), one element of margin on either side
         fpam = hpam + tl.rows_alloc + 2;
     }
+    PK_TRY(zl.launch(h->ctx));
     for (const FftLayer& L : layers) {
         const bool qkv_planes = planes && bounds && !L.concat && L.qkv.wp != (size_t)-1;
         if (qkv_planes) {
@@ -1673,9 +1708,11 @@ static int planes_buf(pk_fft_core* h, pk_dbuf& buf, pk_dbuf& am, int nblk, int C
     const size_t pb = ffnp_plane_bytes(nblk, C), ab = ((size_t)nblk * FFNP_BLK + 2 * FFNP_AM_MARGIN) * sizeof(unsigned);
     PK_TRY(buf.reserve(pb));
     PK_TRY(am.reserve(ab));
-    PK_HIP(hipMemsetAsync(buf.p, 0, (size_t)C * 128, h->ctx->stream));                                      // leading margin block
-    PK_HIP(hipMemsetAsync(buf.as<char>() + (size_t)(nblk + 1) * C * 128, 0, (size_t)C * 128, h->ctx->stream));   // trailing
-    PK_HIP(hipMemsetAsync(am.p, 0, ab, h->ctx->stream));
+    ZeroItems zl;
+    PK_TRY(zl.add(buf.p, (size_t)C * 128));                                            // leading margin block
+    PK_TRY(zl.add(buf.as<char>() + (size_t)(nblk + 1) * C * 128, (size_t)C * 128));   // trailing
+    PK_TRY(zl.add(am.p, ab));
+    PK_TRY(zl.launch(h->ctx));
     *planes = buf.as<char>() + (size_t)C * 128;
     *amax = am.as<unsigned>() + FFNP_AM_MARGIN;
     return PK_OK;
