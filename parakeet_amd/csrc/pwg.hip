@@ -1010,6 +1010,8 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
 
     // Invariant at the top of k-step g: (ph, pl) = split operands of group g; ring slots (g+1..g+RING-1) % RING
     // hold groups g+1..g+RING-1 (of this tile, continuing into the next one); slot g % RING is free.
+    int amax_utt = -1;        // PL + AMAX: the utterance of the running maximum (wave-uniform) ...
+    unsigned amax_run = 0u;   // ... and its bits
     for (int wt = my_slot; wt < n_wtiles; wt += stride_slots) {
         const int next_wt = wt + stride_slots < n_wtiles ? wt + stride_slots : wt;
         unsigned vo8[3], pvo8[3];
@@ -1280,9 +1282,20 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                         am = wave_max64(am);
                         if (lane == 0 && (!(ABL & 1) || a.Ttot < 0)) a.xe_out[(vo4 - 4 * hi * XBLK) >> 11] = __float_as_uint(am);
                     }
-                    if constexpr (PL && AMAX) {   // scale guard: the tile's max|x_out| into its utterance's slot (guarded / sampled calls only)
-                        const float m = wave_max64(am);
-                        if (lane == 0 && (!PK_PWG_AMAX_PROBE || m < 0.f)) atomicMax(a.amax_out + __builtin_amdgcn_readfirstlane(utt_v) * PWG_AMAX_PARTS + (int)(blockIdx.x & (PWG_AMAX_PARTS - 1)), __float_as_uint(m));
+                    if constexpr (PL && AMAX) {   // scale guard: the tile's max|x_out| towards its utterance's slot (guarded / sampled calls only)
+                        // a wave's tiles walk the timeline, ~2.5 in a row within one utterance: the running maximum stays in scalar registers and goes
+                        // out when the utterance changes (an atomic is a vmcnt entry the next tile's operand waits queue up behind: +86 us per launch
+                        // with one per tile)
+                        const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(wave_max64(am)));
+                        const int u = __builtin_amdgcn_readfirstlane(utt_v);
+                        if (u != amax_utt) {
+                            if (amax_utt >= 0 && lane == 0 && !PK_PWG_AMAX_PROBE)
+                                atomicMax(a.amax_out + amax_utt * PWG_AMAX_PARTS + (int)(blockIdx.x & (PWG_AMAX_PARTS - 1)), amax_run);
+                            amax_utt = u;
+                            amax_run = m;
+                        } else {
+                            amax_run = amax_run > m ? amax_run : m;
+                        }
                     }
                     if constexpr (PL) {   // x_out as planes at its utterance's a-priori scale
                         const float so = pow2f(__builtin_amdgcn_readfirstlane(ko_v));
@@ -1309,6 +1322,10 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             }
         }
         kx = kx_next;
+    }
+    if constexpr (PL && AMAX) {
+        if (amax_utt >= 0 && lane == 0 && !PK_PWG_AMAX_PROBE)
+            atomicMax(a.amax_out + amax_utt * PWG_AMAX_PARTS + (int)(blockIdx.x & (PWG_AMAX_PARTS - 1)), amax_run);
     }
 }
 
