@@ -728,8 +728,9 @@ def main():
                          "before the line is printed (their figures are in it); all (default): also the batch sweep, host io, "
                          "text -> wav, 128-channel WaveFlow, the other acoustic models -- measured AFTER the line is out, into "
                          "the sidecar file only")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="1: issue the next batch's acoustic model on a side stream during this batch's vocoder")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="2 (default): the next batch's acoustic model on a second engine handle / side stream, issued before this "
+                         "batch's vocoder; 1: one handle, issued after the vocoder is queued (round 5); 0: in order")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU/gloo rehearsal of the multi-process orchestration with a stub in place of the engine "
                          "(test infrastructure; prints value null)")
@@ -806,6 +807,7 @@ def main():
             pwg_b = pdist.broadcast_state_dict(pwg_state, src=0)
             synth.am.set_state_dict(fs2_b)
             synth.voc.set_state_dict(pwg_b)
+            fs2_state = fs2_b   # (what the second acoustic lane below is built from)
 
     # this rank's utterances.  weak: UTT_PER_GPU per rank (global batch grows with N); strong: the same
     # --global-batch utterances for every N, dealt out by cost (all equal here) with shard_indices
@@ -836,14 +838,35 @@ def main():
     # runs (Synthesizer.issue_acoustic / vocode_issued), so that its launches are queued before the GPU needs them.
     # Every step still does one acoustic pass and one vocoder pass over one batch; the acoustic pass belongs to the
     # following step's batch (all batches are the same synthetic utterances).  One mini-batch per step only.
+    # --pipeline 2 (default): two acoustic lanes -- a second FastSpeech2 engine handle with the same weights on its own side
+    # stream, and the next batch's acoustic model issued BEFORE this batch's vocoder (Synthesizer.issue_acoustic's comment;
+    # profiles/r06_pipeline_lanes.txt: the holes that one handle leaves around the frame-count sync are covered by the
+    # other lane's queued work).  --pipeline 1: round 5's one-lane order.
     pipelined = bool(args.pipeline) and not dry and len(chunks) == 1
+    two_lanes = pipelined and args.pipeline >= 2
     pending = [None]
+    step_no = [0]
+    if two_lanes:
+        from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
+        am2 = FastSpeech2(80, 80, **syn.FS2_LJSPEECH, device=local_rank)
+        am2.set_state_dict(fs2_state)
+        am2.eval()
+        synth.add_acoustic_lane(FastSpeech2Inference(synth.am_inference.normalizer, am2))
 
     def step_pipelined():
-        if pending[0] is None:
+        if not two_lanes:
+            if pending[0] is None:
+                pending[0] = synth.issue_acoustic(texts_all)
+            out = synth.vocode_issued(pending[0], noise=noise)
             pending[0] = synth.issue_acoustic(texts_all)
+            return out
+        k = step_no[0]
+        step_no[0] += 1
+        if pending[0] is None:
+            pending[0] = synth.issue_acoustic(texts_all, lane=k & 1)
+        nxt = synth.issue_acoustic(texts_all, lane=(k + 1) & 1)
         out = synth.vocode_issued(pending[0], noise=noise)
-        pending[0] = synth.issue_acoustic(texts_all)
+        pending[0] = nxt
         return out
 
     plain_step = step
@@ -1111,7 +1134,8 @@ def main():
                 "minibatch": mb,
                 "parallelism": f"dp{world} (utterance sharding, no data-path collective)",
                 "collectives": collectives,
-                "pipeline": "next batch's acoustic model issued on a side stream under this batch's vocoder" if pipelined else "none",
+                "pipeline": ("next batch's acoustic model (second engine handle, own side stream) issued before this batch's vocoder" if two_lanes
+                             else "next batch's acoustic model issued on a side stream under this batch's vocoder") if pipelined else "none",
             },
             "roofline": dict(roof, **{
                 "kernel": {"pwg_layer": "k_pwg_layer (exact fp32 MFMA)", "pwg_layer_h3": "k_pwg_layer_b3<HALF> (3-term split-fp16 MFMA)",

@@ -16,11 +16,21 @@ from .runtime import wrap
 
 
 class Synthesizer:
-    def __init__(self, fastspeech2_inference, pwg_inference):
+    def __init__(self, fastspeech2_inference, pwg_inference, acoustic_lanes=()):
         self.am_inference, self.voc_inference = fastspeech2_inference, pwg_inference
         self.am = fastspeech2_inference.acoustic_model
         self.voc = pwg_inference.pwg_generator
         self.hop = self.voc.upsample_factor
+        # issue-ahead lanes (see issue_acoustic): lane 0 is the acoustic model itself; further lanes are wrappers around OTHER
+        # engine handles holding the same weights, each with its own side stream
+        self._lanes = [fastspeech2_inference] + list(acoustic_lanes)
+        self._lane_streams = {}
+
+    def add_acoustic_lane(self, inference):
+        """Another acoustic-model wrapper (its own engine handle, the same weights) for ``issue_acoustic(..., lane=k)``;
+        returns k."""
+        self._lanes.append(inference)
+        return len(self._lanes) - 1
 
     def synthesize_packed(self, texts, alpha=1.0, noise=None, generator=None, tones=None, spk_ids=None):
         """Returns (packed wav device tensor, frames per utterance).  ``spk_ids``: one speaker id per utterance for a
@@ -48,23 +58,35 @@ class Synthesizer:
     #     for nxt in batches[1:] + [None]:
     #         wav, frames = s.vocode_issued(pending, noise); pending = s.issue_acoustic(nxt) if nxt else None
     # Results are bit-identical to synthesize_packed (same kernels, same order per handle).
+    #
+    # Two lanes (round 6, profiles/r06_pipeline_lanes.txt): with ONE handle the acoustic model of batch k + 1 can only be issued
+    # once the vocoder of batch k is queued -- its encoder then sits behind 40 ms of persistent layer kernels, the frame-count
+    # sync returns after them, and the decoder's launches are issued while the GPU waits (0.4 ms of holes per step in the
+    # kernel trace).  With a second handle (same weights) on its own side stream the order can be
+    #     nxt = s.issue_acoustic(batch[k + 1], lane=(k + 1) & 1); wav, frames = s.vocode_issued(pending, noise); pending = nxt
+    # : batch k + 1's encoder and decoder run next to batch k's decoder and the vocoder's small kernels, and every host
+    # latency is covered by queued work of the other lane.
 
-    def issue_acoustic(self, texts, alpha=1.0, tones=None, spk_ids=None):
-        """Acoustic model of one batch on the side stream; returns (mel, frames, event) for vocode_issued.  Arguments as
-        ``synthesize_packed`` (``spk_ids`` for a multi-speaker FastSpeech2)."""
-        if not hasattr(self, "_am_stream"):
-            self._am_stream = torch.cuda.Stream(device=self.am._ctx.device)
-        with torch.cuda.stream(self._am_stream):
-            self.am_inference.bind()
-            if type(self.am).__name__ == "SpeedySpeech":
+    def issue_acoustic(self, texts, alpha=1.0, tones=None, spk_ids=None, lane=0):
+        """Acoustic model of one batch on a side stream; returns (mel, frames, event) for vocode_issued.  Arguments as
+        ``synthesize_packed`` (``spk_ids`` for a multi-speaker FastSpeech2); ``lane`` selects the engine handle / side
+        stream (0 = the acoustic model itself, others: ``add_acoustic_lane``)."""
+        inf = self._lanes[lane]
+        am = inf.acoustic_model
+        if lane not in self._lane_streams:
+            self._lane_streams[lane] = torch.cuda.Stream(device=am._ctx.device)
+        stream = self._lane_streams[lane]
+        with torch.cuda.stream(stream):
+            inf.bind()
+            if type(am).__name__ == "SpeedySpeech":
                 assert alpha == 1.0, "SpeedySpeech has no speed control (speedyspeech.py:178-218)"
-                frames = self.am.encode_batch(texts, tones)
+                frames = am.encode_batch(texts, tones)
             else:
                 assert tones is None, "tone ids go to FastSpeech2 through encode_batch(tone_ids=...)"
-                frames = self.am.encode_batch(texts, alpha) if spk_ids is None else self.am.encode_batch(texts, alpha, spk_ids)
-            mel = self.am.decode_packed(denormalize=True) if int(frames.sum()) else None
+                frames = am.encode_batch(texts, alpha) if spk_ids is None else am.encode_batch(texts, alpha, spk_ids)
+            mel = am.decode_packed(denormalize=True) if int(frames.sum()) else None
             ev = torch.cuda.Event()
-            ev.record(self._am_stream)
+            ev.record(stream)
         return mel, frames, ev
 
     def vocode_issued(self, issued, noise=None, generator=None):

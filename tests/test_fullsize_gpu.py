@@ -207,3 +207,18 @@ def test_issue_ahead_pipeline_is_bit_identical():
         torch.cuda.synchronize()
         assert [int(f) for f in fr] == want[j][1]
         assert torch.equal(wav, want[j][0])
+    # two lanes (round 6): a second engine handle with the same weights on its own side stream, batch j + 1's acoustic model
+    # issued BEFORE batch j's vocoder -- the same waveforms again
+    from parakeet_amd.fastspeech2 import FastSpeech2, FastSpeech2Inference
+    am2 = FastSpeech2(80, 80, **syn.FS2_LJSPEECH)
+    am2.set_state_dict(syn.fastspeech2_state(80, 80, seed=4))
+    am2.eval()
+    assert synth.add_acoustic_lane(FastSpeech2Inference(synth.am_inference.normalizer, am2)) == 1
+    pending = synth.issue_acoustic(batches[0], lane=0)
+    for j in range(len(batches)):
+        nxt = synth.issue_acoustic(batches[j + 1], lane=(j + 1) & 1) if j + 1 < len(batches) else None
+        wav, fr = synth.vocode_issued(pending, noise=noises[j])
+        pending = nxt
+        assert [int(f) for f in fr] == want[j][1]
+        torch.cuda.synchronize()
+        assert torch.equal(wav, want[j][0])
