@@ -166,6 +166,10 @@ int pk_pwg_set_chunk_samples(pk_pwg* h, int64_t samples);
  *                  path from then on (the sampled call keeps its result: at 2^10 the planes still carry 26 bits of the
  *                  actual maximum).  A sampled call adds two device-to-host copies and an event record to the stream: like
  *                  a guarded call it must not be stream-captured (capture with "scale_guard" 0).
+ *   "noise_fed_first"  1 (default) = on the "planes" path at hop 256 the first residual block is fed from the noise itself: first_conv is
+ *                  Conv1D(1 -> 64, k = 1), so the block's dilated conv over x = w n + b is a 3-tap conv on n with weights folded (in fp64) by
+ *                  pk_pwg_finalize -- no first_conv launch, no x planes for layer 0 (round 6); 0 = first_conv, then the ordinary first block.
+ *                  Both are within the engine's error bars of the reference; they differ from each other in the last bits.
  *   "scale_guard_every"  the sampling period under "scale_guard" 1 (default 16; 0 = never re-sample).
  *                  pk_pwg_scale_overshoot reports what was measured. */
 int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value);

@@ -403,6 +403,10 @@ struct PwgLayerArgs {
     float i0, i1;            // sqrt(0.5) / (2^14 * 2^k2out), 1 / (2^14 * 2^k2skip): undo the stage-2 scales
     const int* tile_kx_in;   // PL: [ntiles] scale exponent of xin / of xout per tile (k_pwg_tile_scales)
     const int* tile_kx_out;
+    const float* noise;      // NZ: the packed noise of the tiles (a wave tile wt covers noise[32 wt .. 32 wt + 31]) ...
+    const float* nz_tab;     // ... and its image for the weight region of the LDS: one k-step of A fragments, then [64][w b] (see k_pwg_layer_b3's NZ)
+    float nz_wmax, nz_bmax;  // NZ: max|w|, max|b| of first_conv (the B operand is built from wmax n and bmax)
+    long noise_n;            // NZ: floats in noise (index clamp)
     unsigned* amax_out;      // PL + AMAX (guarded / sampled calls): [B][PWG_AMAX_PARTS] bits of max|xout| per utterance, folded in by the epilogue
     PwgGen gen;              // GEN kernels only (hop != 256)
 };
@@ -831,17 +835,23 @@ __device__ __forceinline__ void split_x8s(const float (&v)[8], float s, f16x8& h
 // with c_l = max_co (sum_k |W_out[co][k]| + |b_out[co]|) because |z| < 1 (k_pwg_tile_scales).  The bound overshoots the
 // utterance's maximum by a small factor, i.e. the split's error floor moves from 2^-39 of a 32-sample block's maximum to
 // about 2^-36 of the utterance's: elements more than 2^12 below it lose against fp32, by less than 2^-36 of it.
-template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false, bool PL = false, bool AMAX = false>
+// NZ (round 6, "noise-fed first block"): layer 0 without its x planes.  first_conv is Conv1D(1 -> 64, k = 1), so x = w n + b inside an utterance and 0 in
+// the gaps, and layer 0's dilated conv over x is a 3-tap conv on the scalar noise: sum_tap (u[co][tap] n[t + tap - 1] + v[co][tap]) over the taps inside the
+// utterance, u = sum_c W1[co][c][tap] w[c], v = sum_c W1[co][c][tap] b[c] folded in fp64 by pk_pwg_finalize.  Stage 1's 12 k-steps become ONE (the six
+// "channels" n(t-1), n(t), n(t+1) and the three in-utterance flags): 12 MFMAs instead of 144, no plane reads (768 B/sample), no k_pwg_first launch (1.34 GB
+// written); the residual input w n + b is recomputed.  hop 256, planes path only.
+template <bool FIRST, bool HALF, int ABL = 0, bool GEN = false, bool PL = false, bool AMAX = false, bool NZ = false>
 __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer_b3(PwgLayerArgs a) {
+    static_assert(!NZ || (FIRST && PL && !GEN), "noise-fed: the first block of the planes path at hop 256");
     static_assert(!PL || (HALF && ABL == 0), "planes: the block-scaled split-fp16 path only");
     typedef typename Split16<HALF>::vec bf16x8;     // shadows the bf16 typedef inside this kernel
     typedef typename Split16<HALF>::elem elem16;
     __shared__ __attribute__((aligned(16))) float lds[GEN ? LDS_TOTAL_GEN : LDS_TOTAL];
     float* lds_bias = lds + LDS_W1 + LDS_W2;
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.w1);
+        const f32x4* src = reinterpret_cast<const f32x4*>(NZ ? a.nz_tab : a.w1);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = threadIdx.x; i < B3_W1_BYTES / 16; i += LAYER_WAVES * 64) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (NZ ? (2048 + 128) * 4 : B3_W1_BYTES) / 16; i += LAYER_WAVES * 64) dst[i] = src[i];   // NZ: one k-step of fragments, then [64][w b]
         const f32x4* src2 = reinterpret_cast<const f32x4*>(a.w2);
         f32x4* dst2 = reinterpret_cast<f32x4*>(lds + LDS_W1);
         for (int i = threadIdx.x; i < B3_W2_BYTES / 16; i += LAYER_WAVES * 64) dst2[i] = src2[i];
@@ -979,6 +989,18 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         uw[0] = w0[0]; uw[1] = w0[1]; uw[2] = w0[2]; uw[3] = w0[3];
         uw[4] = wrow[4];
     };
+    // NZ: the lane's noise at t - 1, t, t + 1 of the NEXT tile (requested a tile ahead, like t0n), and the edge class of the current tile
+    float nzn[3] = {0.f, 0.f, 0.f};
+    int cls_cur = 0;
+    auto nz_load = [&](int wt_) {
+        const long i0 = (long)wt_ * WAVE_T + j;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            long i = i0 + k - 1;
+            i = i < 0 ? 0 : (i >= a.noise_n ? a.noise_n - 1 : i);   // (the clamped values belong to taps outside the utterance: masked where used)
+            nzn[k] = a.noise[i];
+        }
+    };
     unsigned vo8n[3] = {0, 0, 0};   // lane offsets of the three taps of the NEXT tile (this tile's at the loop top)
     unsigned pvo8n[3] = {0, 0, 0};  // PL: the same in the planes
     if (my_slot < n_wtiles) {
@@ -989,9 +1011,15 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             if constexpr (PL) pvo8n[tp] = lane_off_pl(t0c, my_slot, tp);
         }
         prefetch_head(my_slot, __builtin_amdgcn_readfirstlane(t0c & 255));
+        if constexpr (NZ) {
+            cls_cur = __builtin_amdgcn_readfirstlane(t0c & 255);
+            kx = __builtin_amdgcn_readfirstlane(a.tile_kx_in[my_slot >> 3]);
+            nz_load(my_slot);
+        }
 #pragma unroll
-        for (int g = 0; g < B3_RING; ++g) load_group(ring[g], g, vo8n[g % 3], pvo8n[g % 3]);
-        if constexpr (PL) {
+        for (int g = 0; g < (NZ ? 0 : B3_RING); ++g) load_group(ring[g], g, vo8n[g % 3], pvo8n[g % 3]);
+        if constexpr (NZ) {
+        } else if constexpr (PL) {
             kx = __builtin_amdgcn_readfirstlane(a.tile_kx_in[my_slot >> 3]);
             planes_operand(ring[0], ph, pl);
         } else if constexpr (HALF) {
@@ -1006,7 +1034,11 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         }
     }
     // W1 fragments of the next (k-step, co-tile) in issue order, read one co-tile ahead of their MFMAs
-    bf16x8 c_ah = lds_a[0], c_al = lds_a[4 * 64];
+    bf16x8 c_ah, c_al;
+    if constexpr (!NZ) {
+        c_ah = lds_a[0];
+        c_al = lds_a[4 * 64];
+    }
 
     // Invariant at the top of k-step g: (ph, pl) = split operands of group g; ring slots (g+1..g+RING-1) % RING
     // hold groups g+1..g+RING-1 (of this tile, continuing into the next one); slot g % RING is free.
@@ -1032,6 +1064,12 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         int cls_next = 0;
         const unsigned vo4 = vo8[1];   // centre tap: operand rows and result rows share the lane offset
         float x_old[32];
+        float nz_cur[3] = {0.f, 0.f, 0.f};
+        if constexpr (NZ) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nz_cur[k] = nzn[k];
+            nz_load(next_wt);
+        }
         // [wave-lds-exchange] every lane of the wave has finished reading the previous tile's rows out of lds_p
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
@@ -1082,8 +1120,46 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
         // group g while the VALU splits group g+1 (sched_group_barrier interleaves them: a 32x32x16 MFMA
         // occupies the matrix pipe for 8 issue slots, the split fits in the gaps).
         constexpr int T0_USE = 3;   // the next tile's offsets are formed here: before the ring reaches into it (g = 8)
+        if constexpr (NZ) {
+            // ONE k-step: the B operand's 16 "channels" are wmax n(t-1), wmax n(t), wmax n(t+1), bmax m(t-1), bmax m(t), bmax m(t+1), 0 ... (m = 1 inside the
+            // utterance; |wmax n|, bmax <= the bound the tile's x scale was made for), at the tile's x scale like any plane; the A fragments hold
+            // u / wmax, v / bmax * 2^k1 (a.k1 = their own exponent for this launch): the accumulators come out at S1 = 2^(kx + k1) like the init above
+            const bool first_s = (cls_cur / 3 == 0) && (wt & 7) == 0 && j == 0;               // t - 1 lies before the utterance
+            const bool last_s = (cls_cur % 3 == 0) && (wt & 7) == 7 && j == WAVE_T - 1;       // t + 1 lies behind it
+            float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // lane half 0: channels 0..3 (e 0..3), half 1: channels 4..7
+            bv[0] = hi ? a.nz_bmax : (first_s ? 0.f : a.nz_wmax * nz_cur[0]);
+            bv[1] = hi ? (last_s ? 0.f : a.nz_bmax) : a.nz_wmax * nz_cur[1];
+            bv[2] = hi ? 0.f : (last_s ? 0.f : a.nz_wmax * nz_cur[2]);
+            bv[3] = hi ? 0.f : (first_s ? 0.f : a.nz_bmax);
+            bf16x8 bh, bl;
+            split_x8s(bv, sx, bh, bl);
 #pragma unroll
-        for (int g = 0; g < B3_KS1; ++g) {
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 ah = lds_a[(0 * 4 + q) * 64], al = lds_a[(1 * 4 + q) * 64];
+                acc[q] = mfma16(ah, bh, acc[q]);
+                acc[q] = mfma16(al, bh, acc[q]);
+                acc[q] = mfma16(ah, bl, acc[q]);
+            }
+            // x_in sqrt(1/2) = (w n + b) sqrt(1/2) at this lane's output rows, from the [64][w b] table behind the fragments
+            const f32x2* wb = reinterpret_cast<const f32x2*>(lds + 2048);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 t = wb[32 * q + mfma_row(r, hi)];
+                    x_old[16 * q + r] = fmaf(t[0], nz_cur[1], t[1]) * 0.70710678118654752440f;
+                }
+            // what stage 1 does on the side for the next tile
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp) {
+                vo8n[tp] = lane_off(t0n, next_wt, tp);
+                pvo8n[tp] = lane_off_pl(t0n, next_wt, tp);
+            }
+            cls_next = __builtin_amdgcn_readfirstlane(t0n & 255);
+            kx_next = __builtin_amdgcn_readfirstlane(kxn_v);
+        }
+#pragma unroll
+        for (int g = 0; g < (NZ ? 0 : B3_KS1); ++g) {
             if (g == T0_USE) {
 #pragma unroll
                 for (int tp = 0; tp < 3; ++tp) {
@@ -1252,7 +1328,9 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
                     float v;
                     if constexpr (HALF) {   // acc2 = 2^14 * 2^k2 * (W2 z + b); i0 carries the sqrt(0.5) of :314
                         if (pass == 0) {
-                            if constexpr (PL) {   // x_in = (hi + lo) / (its block's scale); x_old holds the raw vectors of the centre taps
+                            if constexpr (NZ) {   // x_old = (w n + b) sqrt(1/2), recomputed above
+                                v = fmaf(acc2[q][r], a.i0, x_old[16 * q + r]);
+                            } else if constexpr (PL) {   // x_in = (hi + lo) / (its block's scale); x_old holds the raw vectors of the centre taps
                                 const int cg = 2 * q + (r >> 3), e = r & 7;
                                 const pl_f16x8 xh = __builtin_bit_cast(pl_f16x8, f32x4{x_old[8 * cg], x_old[8 * cg + 1], x_old[8 * cg + 2], x_old[8 * cg + 3]});
                                 const pl_f16x8 xl = __builtin_bit_cast(pl_f16x8, f32x4{x_old[8 * cg + 4], x_old[8 * cg + 5], x_old[8 * cg + 6], x_old[8 * cg + 7]});
@@ -1322,6 +1400,7 @@ __global__ __launch_bounds__(LAYER_WAVES * 64, LAYER_WAVES / 4) void k_pwg_layer
             }
         }
         kx = kx_next;
+        if constexpr (NZ) cls_cur = cls_next;
     }
     if constexpr (PL && AMAX) {
         if (amax_utt >= 0 && lane == 0 && !PK_PWG_AMAX_PROBE)
@@ -1496,6 +1575,10 @@ struct pk_pwg {
     // last call layout (for debug reads)
     std::vector<int> last_frames, last_toff, last_cuL, last_cuC;
     float first_wmax = 0.f, first_bmax = 0.f;   // planes path: bound of first_conv
+    std::vector<float> first_w_host, first_b_host;
+    pk_dbuf d_nz;              // k_pwg_layer_b3's NZ image: one k-step of A fragments + [64][w b] (split-fp16 math, hop 256)
+    int nz_k1 = 0;             // ... and the exponent its fragments were scaled with
+    bool noise_fed = true;     // option "noise_fed_first": layer 0 from the noise (NZ); 0 = k_pwg_first + the ordinary first block
     pk_dbuf d_cl, ws_nmax, ws_tkx;              // ... growth constants per layer, max|noise| per utterance, [layers + 1][tiles] scale exponents
     int last_ntiles = 0;
     long last_Ttot = 0;
@@ -1689,6 +1772,9 @@ extern "C" int pk_pwg_set_option(pk_pwg* h, const char* key, int64_t value) {
     } else if (strcmp(key, "scale_guard") == 0) {
         if (value < 0 || value > 2) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: scale_guard %lld (0, 1, 2)", (long long)value);
         h->scale_guard = (int)value;
+    } else if (strcmp(key, "noise_fed_first") == 0) {
+        if (value < 0 || value > 1) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: noise_fed_first %lld (0, 1)", (long long)value);
+        h->noise_fed = value != 0;
     } else if (strcmp(key, "scale_guard_every") == 0) {
         if (value < 0 || value > (1 << 30)) PK_FAIL(PK_EINVAL, "pk_pwg_set_option: scale_guard_every %lld", (long long)value);
         h->guard_every = (int)value;
@@ -1808,6 +1894,8 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
     PK_TRY(pk_get_vector(h->params, "first_conv.bias", R, b));
     PK_TRY(pk_upload(ctx, h->d_first_w, w.data(), R * sizeof(float)));
     PK_TRY(pk_upload(ctx, h->d_first_b, b.data(), R * sizeof(float)));
+    h->first_w_host = w;   // (the noise-fed first block folds them into layer 0's conv: nz_tab below)
+    h->first_b_host = b;
     h->first_wmax = h->first_bmax = 0.f;   // |first_conv(n)| <= wmax |n| + bmax (the planes path's scale bound)
     for (int i = 0; i < R; ++i) {
         h->first_wmax = std::max(h->first_wmax, std::fabs(w[i]));
@@ -1921,6 +2009,39 @@ extern "C" int pk_pwg_finalize(pk_pwg* h) {
                 PK_TRY(pk_get_weight(h->params, p + ".conv", {G, R, KTAP}, wc));
                 PK_TRY(pk_get_weight(h->params, p + ".conv1x1_out", {R, G / 2, 1}, wo));
                 PK_TRY(pk_get_weight(h->params, p + ".conv1x1_skip", {SK, G / 2, 1}, ws));
+                if (half && l == 0 && G == 128 && R == 64 && KTAP == 3) {   // the noise-fed first block's LDS image (k_pwg_layer_b3, NZ): folded in fp64
+                    const double wmax = h->first_wmax, bmax = h->first_bmax;
+                    std::vector<float> wn((size_t)G * 16, 0.f);   // [co][16 "channels"]: u / wmax (3 taps), v / bmax (3 taps), zeros
+                    for (int co = 0; co < G; ++co)
+                        for (int tap = 0; tap < KTAP; ++tap) {
+                            double u = 0.0, v = 0.0;
+                            for (int ci = 0; ci < R; ++ci) {
+                                const double wv = wc[((size_t)co * R + ci) * KTAP + tap];
+                                u += wv * (double)h->first_w_host[ci];
+                                v += wv * (double)h->first_b_host[ci];
+                            }
+                            wn[(size_t)co * 16 + tap] = wmax > 0.0 ? (float)(u / wmax) : 0.f;
+                            wn[(size_t)co * 16 + 3 + tap] = bmax > 0.0 ? (float)(v / bmax) : 0.f;
+                        }
+                    h->nz_k1 = pk_weight_scale_exp(wn.data(), wn.size());
+                    std::vector<float> img(2048 + 128, 0.f);
+                    uint16_t* fr = reinterpret_cast<uint16_t*>(img.data());
+                    for (int q = 0; q < 4; ++q)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int i = lane & 31, hi = lane >> 5;
+                                const int ci = mfma_row(e, hi);   // the kernel's operand order within a k-step
+                                uint16_t bh, bl;
+                                split16_host(std::ldexp(wn[(size_t)(32 * q + i) * 16 + ci], h->nz_k1), true, bh, bl);
+                                fr[(((size_t)0 * 4 + q) * 64 + lane) * 8 + e] = bh;
+                                fr[(((size_t)1 * 4 + q) * 64 + lane) * 8 + e] = bl;
+                            }
+                    for (int co = 0; co < R; ++co) {
+                        img[2048 + 2 * co] = h->first_w_host[co];
+                        img[2048 + 2 * co + 1] = h->first_b_host[co];
+                    }
+                    PK_TRY(pk_upload(ctx, h->d_nz, img.data(), img.size() * sizeof(float)));
+                }
                 if (half) {   // fp16 parts are taken of w * 2^k (exact), k per tensor: no subnormal parts
                     h->k1[l] = pk_weight_scale_exp(wc.data(), wc.size());
                     h->k2o[l] = pk_weight_scale_exp(wo.data(), wo.size());
@@ -2266,7 +2387,10 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         PK_LAUNCH(ctx, "pwg_tile_scales", k_pwg_tile_scales, dim3(pk_div_up(sumC, 256)), dim3(256), 0, d_tab + o_tutt, sumC,
                   h->ws_nmax.as<float>(), h->first_wmax, h->first_bmax, h->d_cl.as<float>(), c.layers, tkx);
     }
-    if (planes && gen)
+    // noise-fed first block (k_pwg_layer_b3's NZ): no first_conv launch, no x planes for layer 0 -- hop 256 on the planes path
+    const bool nz = planes && !gen && !all_first && h->noise_fed && h->d_nz.p != nullptr;
+    if (nz) {
+    } else if (planes && gen)
         PK_LAUNCH(ctx, "pwg_first", (k_pwg_first<true, true>), dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
                   h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab, tkx);
     else if (planes)
@@ -2278,7 +2402,7 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
     else
         PK_LAUNCH(ctx, "pwg_first", k_pwg_first<false>, dim3(sumC), dim3(TILE), 0, d_noise, h->d_first_w.as<float>(),
                   h->d_first_b.as<float>(), d_tab + o_tile, Ttot, h->ws_x0.as<float>(), h->ws_xe0.as<unsigned>(), gtab, tkx);
-    if (guard && planes)
+    if (guard && planes && !nz)   // (noise-fed: x_0 is never stored, amax[0] stays 0 = "nothing to lose")
         PK_LAUNCH(ctx, "pwg_planes_amax", k_pwg_planes_amax, dim3(sumC), dim3(256), 0, h->ws_x0.as<float>(), d_tab + o_tile,
                   d_tab + o_tutt, tkx, amax);
     // ---- residual stack.  Optionally the batch is cut into chunks of whole utterances whose x ping-pong +
@@ -2309,6 +2433,10 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
         for (int l = 0; l < c.layers; ++l) {
             PwgLayerArgs a;
             a.amax_out = nullptr;
+            a.noise = nullptr;
+            a.nz_tab = nullptr;
+            a.noise_n = 0;
+            a.nz_wmax = a.nz_bmax = 0.f;
             a.xin = (l & 1) ? h->ws_x1.as<float>() : h->ws_x0.as<float>();
             a.xout = (l & 1) ? h->ws_x0.as<float>() : h->ws_x1.as<float>();
             a.skip = h->ws_skip.as<float>();
@@ -2345,10 +2473,20 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                 a.w1 = reinterpret_cast<const float*>((half ? h->d_w1h : h->d_w1b).as<char>() + (size_t)l * B3_W1_BYTES);
                 a.w2 = reinterpret_cast<const float*>((half ? h->d_w2h : h->d_w2b).as<char>() + (size_t)l * B3_W2_BYTES);
                 const dim3 blk(LAYER_WAVES * 64);
+                if (nz && l == 0) {
+                    a.noise = d_noise + (size_t)tile0 * TILE;
+                    a.noise_n = (long)sumS - (long)tile0 * TILE;
+                    a.nz_tab = h->d_nz.as<float>();
+                    a.nz_wmax = h->first_wmax;
+                    a.nz_bmax = h->first_bmax;
+                    a.k1 = h->nz_k1;   // the accumulators of this launch: 2^(kx + nz_k1) * (pre-activation)
+                }
                 if (planes && (guard || sample) && !all_first) {   // ... and the scale guard's maxima from the epilogue (AMAX instantiations)
                     a.amax_out = amax + (size_t)(c.layers + 1) * B + (size_t)l * B * PWG_AMAX_PARTS;
                     amax_parts_used = true;
-                    if (gen) {
+                    if (nz && l == 0) {
+                        PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, false, true, true, true>), dim3(grid), blk, 0, a);
+                    } else if (gen) {
                         if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true, true, true>), dim3(grid), blk, 0, a);
                         else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true, true, true>), dim3(grid), blk, 0, a);
                     } else {
@@ -2359,6 +2497,8 @@ extern "C" int pk_pwg_infer(pk_pwg* h, const float* mel, const int32_t* frames, 
                     if (gen) {
                         if (l == 0) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, true, true>), dim3(grid), blk, 0, a);
                         else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, true, true>), dim3(grid), blk, 0, a);
+                    } else if (nz && l == 0) {
+                        PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, false, true, false, true>), dim3(grid), blk, 0, a);
                     } else {
                         if (l == 0 || all_first) PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<true, true, 0, false, true>), dim3(grid), blk, 0, a);
                         else PK_LAUNCH(ctx, "pwg_layer_h3", (k_pwg_layer_b3<false, true, 0, false, true>), dim3(grid), blk, 0, a);

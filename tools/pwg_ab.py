@@ -7,6 +7,7 @@ from parakeet_amd.parallel_wavegan import PWGGenerator
 from parakeet_amd.runtime import Context
 B, L, N = int(os.environ.get("PK_QPWG_B", 32)), 640, int(os.environ.get("PK_QPWG_N", 10))
 gen = PWGGenerator(**syn.PWG_LJSPEECH); gen.set_state_dict(syn.pwg_state()); gen.eval()
+if os.environ.get("PK_QPWG_NZ"): gen.set_option("noise_fed_first", int(os.environ["PK_QPWG_NZ"]))   # round 6: 0 = first_conv + the ordinary first block
 rng = np.random.default_rng(42)
 mels = [torch.tensor(rng.normal(size=(L, 80)).astype(np.float32)).cuda() for _ in range(B)]
 noises = [torch.tensor(rng.normal(size=L * 256).astype(np.float32)).cuda() for _ in range(B)]
