@@ -5,7 +5,7 @@ Counter handling as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE / W
 (Infinity Cache hits included); on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, other patterns are
 uncalibrated -- so every factor is taken from a kernel of the same run whose byte count is known exactly:
   pwg:  reads  k_pwg_last[_h3]   (64 ch x 4 B per sample, dword per lane -- the layer kernel's pattern)
-        writes k_pwg_first       (64 ch x 4 B per sample)
+        writes k_pwg_first       (64 ch x 4 B per sample); without it (noise-fed first block) the first block's own launch (2 x 64 ch x 4 B)
   wf:   reads  the guide's factor 2 (16 B per lane, the layer kernel's only access width), cross-checked on
                k_wf_cond_planes (reads and rewrites 96 x 32 x 4 B per block)
         writes k_wf_cond_planes
@@ -16,20 +16,26 @@ import sys
 kind, src, dst = sys.argv[1:4]
 d = json.load(open(src))
 if kind == "pwg":
-    LK = [k for k in d if k.startswith("k_pwg_layer") and "false" in k][0]
+    LK = ([k for k in d if k.startswith("k_pwg_layer_b3<false") or k.startswith("k_pwg_layer<false")] or
+          [k for k in d if k.startswith("k_pwg_layer") and "false" in k])[0]
     def pick(prefix):   # kernel names carry their template arguments ("k_pwg_first<false>")
         ks = [k for k in d if k == prefix or k.startswith(prefix + "<")]
         return d[sorted(ks)[0]] if ks else None
     L, F = d[LK], pick("k_pwg_first")
     Z = pick("k_pwg_last_h3") or pick("k_pwg_last")
     n = 32 * 163840
-    wcal = F["WRITE_SIZE"] * 1024 / (64 * 4 * n)
+    if F is not None:
+        wcal = F["WRITE_SIZE"] * 1024 / (64 * 4 * n)
+    else:
+        # round 6: the noise-fed first block -- no k_pwg_first; its own launch writes exactly the x_out planes and the skip, 2 x 64 x 4 B per sample
+        L0 = [k for k in d if k.startswith("k_pwg_layer_b3<true")][0]
+        wcal = d[L0]["WRITE_SIZE"] * 1024 / (2 * 64 * 4 * n)
     rcal = Z["FETCH_SIZE"] * 1024 / (64 * 4 * n)
     targs = [t.strip() for t in LK[LK.index("<") + 1:LK.rindex(">")].split(",")]   # <FIRST, HALF[, ABL]>
     prof_key = ("pwg_layer_h3" if targs[1] == "true" else "pwg_layer_b3") if "b3" in LK else "pwg_layer"
     extra = {"prof_key": prof_key, "samples_per_launch": n,
              "calibration_note": "FETCH_SIZE calibrated on k_pwg_last[_h3] (reads exactly 64x4 B/sample with the same dword-per-lane, "
-                                 "128-B-segment pattern), WRITE_SIZE on k_pwg_first (writes exactly 64x4 B/sample); "
+                                 "128-B-segment pattern), WRITE_SIZE on k_pwg_first (writes exactly 64x4 B/sample) or, without it, on the noise-fed first block (2x64x4 B/sample); "
                                  "MI355X_MICROARCH.md HBM section: FETCH_SIZE under-counts wide streams by 2x on gfx950"}
 else:
     LK = [k for k in d if k.startswith("k_wf_layer_p<2, 3, 0")][0]
