@@ -2668,7 +2668,7 @@ extern "C" void pk_pwg_destroy(pk_pwg* h) {
     pk_device_guard _dg(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     pk_dbuf* bufs[] = {&h->d_first_w, &h->d_first_b, &h->d_convin_wT, &h->d_uptab, &h->d_mu, &h->d_sigma,
-                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_l1, &h->d_l1h, &h->d_l1b, &h->d_l2,
+                       &h->d_w1, &h->d_w2, &h->d_bias, &h->d_w1b, &h->d_w2b, &h->d_w1h, &h->d_w2h, &h->d_waux, &h->d_nz, &h->d_l1, &h->d_l1h, &h->d_l1b, &h->d_l2,
                        &h->d_bias_h, &h->ws_xe0, &h->ws_xe1,
                        &h->ws_mel, &h->ws_cin, &h->ws_noise, &h->ws_wav, &h->ws_c0, &h->ws_P,
                        &h->ws_x0, &h->ws_x1, &h->ws_skip, &h->ws_dbg, &h->ws_tab, &h->d_cl, &h->ws_nmax, &h->ws_tkx, &h->ws_amax};
